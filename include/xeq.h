@@ -1,0 +1,172 @@
+/* libxeq_hip.so -- C ABI of the MI355X-native XPaiNN energy+force hot path.
+ *
+ * Drop-in boundary.  The reference (X1X1010/XequiNet) is pure
+ * Python and has no FFI; its hot path bottoms out in third-party extension ops.
+ * Each entry point below names the reference call site it replaces
+ * (paths relative to /root/reference/xequinet/).  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    marked "host".  All buffers are owned by the caller (e.g. the PyTorch
+ *    caching allocator); the library never allocates, frees or retains them.
+ *  - Row-major contiguous tensors.  `dtype` selects f32/f64 for all floating
+ *    tensors of a call.  Index tensors are int64 where the reference's are
+ *    (edge_index, ptr), int32 for the library's own CSR arrays.
+ *  - Every call enqueues on `stream` (a hipStream_t passed as void*) and
+ *    returns without synchronising; re-entrant, no global mutable state
+ *    besides the thread-local error string.
+ *  - Return value: 0 = ok, otherwise an XEQ_ERR_* code; xeq_last_error()
+ *    returns the message for the calling thread (the reference raises Python
+ *    exceptions/asserts, e.g. nn/rbf.py:44-46, nn/o3layer.py:105-107).
+ *  - Irreps are passed as mul[3] = channels of l = 0,1,2 (0 = absent), e3nn
+ *    mul_ir layout; C = sum mul, D = mul0 + 3 mul1 + 5 mul2.
+ */
+#ifndef XEQ_H
+#define XEQ_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { XEQ_F32 = 0, XEQ_F64 = 1 };
+enum { XEQ_RBF_BESSEL = 0, XEQ_RBF_GAUSSIAN = 1 };
+enum { XEQ_CUTOFF_COSINE = 0, XEQ_CUTOFF_POLYNOMIAL = 1 };
+enum {
+  XEQ_OK = 0,
+  XEQ_ERR_INVALID_ARGUMENT = 1,
+  XEQ_ERR_LAUNCH = 2,
+  XEQ_ERR_UNSUPPORTED = 3
+};
+
+int xeq_version(void);
+const char* xeq_last_error(void);
+
+/* ------------------------------------------------------------------ graph */
+
+/* rowptr[i] = first position p with keys[p] >= i, i in [0, n_rows]  (keys sorted
+ * ascending).  Turns a destination-sorted edge_index row into CSR. */
+int xeq_csr_rowptr(const int64_t* keys, int64_t n_keys, int64_t n_rows, int32_t* rowptr, void* stream);
+
+/* Exclusive prefix sum of int32 counts[n] into out[n+1] (out[n] = total). */
+int xeq_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* out, void* stream);
+
+/* Replaces torch_cluster.radius_graph at data/transform.py:58-64 (non-PBC):
+ * same-graph pairs with d^2 < r^2 (strict), no self loops, unlimited neighbours.
+ * Phase 1 writes deg[N]; the caller scans it (xeq_exclusive_scan_i32), reads
+ * E = rowptr[N] back, allocates edge_index[2,E]; phase 2 fills it in canonical
+ * order: sorted by center (row 0), then neighbor (row 1). */
+int xeq_radius_graph_count(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                           double cutoff, int32_t* deg, void* stream);
+int xeq_radius_graph_fill(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                          double cutoff, const int32_t* rowptr, int64_t n_edges, int64_t* edge_index, void* stream);
+
+/* Replaces the cdist/nonzero search of radius_graph_pbc (data/radius_graph.py:118-126,
+ * 162-181).  The caller supplies what the reference computes on the host side:
+ * wrapped positions pos_wrap[N,3] (:111), per-graph image translation vectors
+ * img[G, n_cells, 3] (:104) and the integer image table cells[n_cells,3] (:97),
+ * per-atom wrap shift[N,3] (:113).  Pairs with 0.01 < D < cutoff are emitted
+ * center-major, then by (neighbor * n_cells + cell) ascending, bit-identical to the
+ * reference ordering; cell_offsets = cells[cell] + shift[center] - shift[neighbor]
+ * (:186-190). */
+int xeq_radius_graph_pbc_count(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs,
+                               int64_t n_nodes, const void* img, int64_t n_cells, double cutoff, int32_t* deg,
+                               void* stream);
+int xeq_radius_graph_pbc_fill(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs,
+                              int64_t n_nodes, const void* img, const void* cells, const void* shift,
+                              int64_t n_cells, double cutoff, const int32_t* rowptr, int64_t n_edges,
+                              int64_t* edge_index, void* cell_offsets, void* stream);
+
+/* ------------------------------------------------------------ edge geometry */
+
+/* compute_edge_data (nn/basic.py:110-131): vec = pos[c] - pos[n] - cell_offsets @ cell[batch[n]],
+ * dist = |vec|.  cell/cell_offsets/batch may be NULL (non-PBC).  batch == NULL with a
+ * cell means single graph (cell[0], nn/basic.py:121-123). */
+int xeq_edge_vectors_fwd(int dtype, const void* pos, const int64_t* edge_index, int64_t n_edges,
+                         const void* cell, const void* cell_offsets, const int64_t* batch, void* vec, void* dist,
+                         void* stream);
+
+/* Backward of the above w.r.t. pos, as a deterministic segmented sum (no atomics):
+ * grad_pos[i] = sum_{e: center=i} gvec[e] - sum_{e: neighbor=i} gvec[e].
+ * c_rowptr/c_perm: CSR over centers (perm NULL = edges already center-sorted);
+ * n_rowptr/n_perm: CSR over neighbors. */
+int xeq_edge_vectors_bwd(int dtype, const void* grad_vec, int64_t n_nodes, const int32_t* c_rowptr,
+                         const int32_t* c_perm, const int32_t* n_rowptr, const int32_t* n_perm, void* grad_pos,
+                         void* stream);
+
+/* --------------------------------------------- operator-level (e3nn) drop-ins */
+
+/* e3nn.o3.SphericalHarmonics(irreps, normalize=True, "component") as built at
+ * nn/xpainn.py:49-51.  `vec` is in e3nn axis order (the caller already applied
+ * vec[:, [1,2,0]], nn/xpainn.py:71-74).  out[E, D], every Y_l repeated mul[l] times. */
+int xeq_sph_harm_fwd(int dtype, const void* vec, int64_t n, const int32_t mul[3], int normalize, void* out,
+                     void* stream);
+int xeq_sph_harm_bwd(int dtype, const void* vec, const void* grad_out, int64_t n, const int32_t mul[3],
+                     int normalize, void* grad_vec, void* stream);
+
+/* SphericalBesselj0 / GaussianSmearing (nn/rbf.py:114-152) and the envelopes
+ * (nn/rbf.py:43-73) on dist[E].  rbf_out[E,B], fcut_out[E] (either may be NULL). */
+int xeq_radial_fwd(int dtype, const void* dist, int64_t n, int rbf_kind, int cutoff_kind, int num_basis,
+                   double cutoff, const void* p0, const void* p1, void* rbf_out, void* fcut_out, void* stream);
+
+/* e3nn.o3.ElementwiseTensorProduct(irreps, "Cx0e") (nn/xpainn.py:119-121): out[n,u,m] = x[n,u,m]*g[n,u].
+ * g_rows == 1 broadcasts one gate row (EquivariantLayerNorm affine, nn/o3layer.py:164). */
+int xeq_elementwise_tp_fwd(int dtype, const void* x, const void* g, int64_t n, int64_t g_rows,
+                           const int32_t mul[3], void* out, void* stream);
+
+/* TensorProduct 'uuu' l x l -> 0e with path weight ir.dim (Invariant / EquivariantDot,
+ * nn/o3layer.py:23-29,89-95): out[n,u] = sum_m a[n,u,m] b[n,u,m]. */
+int xeq_channel_dot_fwd(int dtype, const void* a, const void* b, int64_t n, const int32_t mul[3], void* out,
+                        void* stream);
+/* grad_a[n,u,m] = g[n,u] * b[n,u,m] (same kernel as the elementwise TP). */
+
+/* EquivariantLayerNorm.forward (nn/o3layer.py:145-171) and its backward w.r.t. x. */
+int xeq_eqln_fwd(int dtype, const void* x, const void* weight, const void* bias, int64_t n,
+                 const int32_t mul[3], double eps, void* out, void* stream);
+int xeq_eqln_bwd(int dtype, const void* x, const void* weight, const void* grad_out, int64_t n,
+                 const int32_t mul[3], double eps, void* grad_x, void* stream);
+
+/* torch_scatter.scatter_sum over a sorted index given as ptr (nn/output.py:124):
+ * out[g, :] = sum_{i in [ptr[g], ptr[g+1])} src[i, :]. */
+int xeq_segment_sum(int dtype, const void* src, const int64_t* ptr, int64_t n_segments, int64_t width,
+                    void* out, void* stream);
+/* torch_scatter.scatter(src, index, dim=0, reduce="sum") for an arbitrary index
+ * (float atomics; `out` must be zero-initialised by the caller). */
+int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n, int64_t width, void* out,
+                    int64_t n_out, void* stream);
+
+/* ------------------------------------------------------------ fused message */
+
+/* XPainnMessage.forward lines nn/xpainn.py:140-159 in one pass over
+ * destination-sorted edges (K5-K7, K11-K16 of SURVEY 2.2):
+ *   filter = (rbf(d) W^T + b) * fcut(d)                       :140
+ *   g = h[nbr] * filter = [gate_state C | gate_edge C | msg_s F]  :142-148
+ *   msg_x = xhat[nbr] (x) gate_state + Y(vec) (x) gate_edge    :150-154
+ *   s_out = s_in + sum_{e->c} msg_s ; x_out = x_in + sum msg_x  :158-159
+ * rbf / fcut / Y_lm are recomputed from vec per edge and never materialised.
+ * h[N, 2C+F] = scalar_mlp output (:139), xhat[N, D] = o3norm output (:131).
+ * rowptr[N+1]/perm[E]: CSR over centers (perm NULL = already sorted);
+ * nbr = edge_index row 1 (int64[E]); vec[E,3] in ORIGINAL axis order.
+ * Per-node segmented sum in registers: no atomics, bitwise reproducible. */
+int xeq_message_fwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* perm,
+                    const int64_t* nbr, const void* vec, const void* h, const void* xhat, const void* s_in,
+                    const void* x_in, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
+                    int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
+                    const int32_t mul[3], void* s_out, void* x_out, void* stream);
+
+/* Reverse pass of the fused message w.r.t. h, xhat and vec (what the force
+ * evaluation nn/basic.py:143-159 needs; parameter gradients are out of scope).
+ * Iterates the CSR over NEIGHBORS (n_rowptr/n_perm; n_perm NULL = edges sorted by
+ * neighbor) so grad_h / grad_xhat are segmented sums too; grad_vec[E,3] is written
+ * at the edge's own position.  center = edge_index row 0. */
+int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                    const int64_t* center, const void* vec, const void* h, const void* xhat, const void* grad_s,
+                    const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
+                    int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
+                    const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XEQ_H */

@@ -1,0 +1,478 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+committed golden fixtures.  Run on the MI355X box:  pytest tests -m gpu
+
+Tolerances:
+  fp64: energies/forces/features 1e-10 relative-ish (pure rounding differences)
+  fp32: energies |dE| <= 1e-5 |E| + 1e-4, forces max-abs <= 1e-4 (model units)
+  integer outputs (edge_index, cell_offsets): bit-exact
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import xpainn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+def _t(a, dtype=None):
+    t = torch.as_tensor(np.asarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+# ----------------------------------------------------------------------------- graph
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_radius_graph_nonpbc_bit_exact(dtype):
+    from xequinet_amd.cluster import radius_graph
+
+    pos, z, ptr = orc.synth_qm9_batch(64, seed=3)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    pos = pos.astype(npdt)
+    want = orc.radius_graph_canonical(pos, ptr, 5.0)
+    got = radius_graph(_t(pos), 5.0, ptr=_t(ptr)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # batch-vector form (sorted batch), smaller cutoff => ragged degrees
+    batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    want = orc.radius_graph_canonical(pos, ptr, 2.0)
+    got = radius_graph(_t(pos), 2.0, batch=_t(batch)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_radius_graph_edge_cases():
+    from xequinet_amd.cluster import radius_graph
+
+    # single atoms, an empty graph in the middle, two coincident-free atoms out of range
+    pos = np.array([[0, 0, 0], [10, 0, 0], [10.5, 0, 0], [30, 0, 0], [36, 0, 0]], dtype=np.float32)
+    ptr = np.array([0, 1, 1, 3, 5])
+    want = orc.radius_graph_canonical(pos, ptr, 5.0)
+    got = radius_graph(_t(pos), 5.0, ptr=_t(ptr)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert got.shape == (2, 2)
+    # no atoms at all
+    got = radius_graph(torch.zeros((0, 3), device=DEV), 5.0, ptr=_t(np.array([0])))
+    assert got.shape == (2, 0)
+
+
+@pytest.mark.parametrize("name", ["water192", "two_graphs_unwrapped", "triclinic40", "slab30"])
+def test_radius_graph_pbc_golden_bit_exact(name):
+    from xequinet_amd.data import radius_graph_pbc
+
+    f = _load(f"radius_graph_pbc_{name}.npz")
+    npg = f["n_per_graph"]
+    pbc = torch.tensor(np.tile(f["pbc"], (len(npg), 1)))
+    ei, co = radius_graph_pbc(_t(f["pos"]), _t(npg), pbc.to(DEV), _t(f["cell"]), float(f["cutoff"]))
+    np.testing.assert_array_equal(ei.cpu().numpy(), f["edge_index"])
+    np.testing.assert_array_equal(co.cpu().numpy(), f["cell_offsets"])
+
+
+def test_single_radius_graph_golden():
+    from xequinet_amd.data import single_radius_graph
+
+    a = _load("radius_graph_pbc_water192.npz")
+    b = _load("single_radius_graph_water192.npz")
+    ei, co = single_radius_graph(_t(a["pos"]), torch.tensor([True, True, True]), _t(a["cell"][0]), 5.0)
+    np.testing.assert_array_equal(ei.cpu().numpy(), b["edge_index"])
+    np.testing.assert_array_equal(co.cpu().numpy(), b["cell_offsets"])
+
+
+def test_edge_graph_csr_views():
+    from xequinet_amd.ops import EdgeGraph
+
+    rng = np.random.default_rng(0)
+    N, E = 50, 400
+    ei = rng.integers(0, N, size=(2, E))
+    g = EdgeGraph(_t(ei), N)
+    c_rowptr = g.c_rowptr.cpu().numpy()
+    n_rowptr = g.n_rowptr.cpu().numpy()
+    np.testing.assert_array_equal(c_rowptr, np.searchsorted(np.sort(ei[0]), np.arange(N + 1)))
+    np.testing.assert_array_equal(n_rowptr, np.searchsorted(np.sort(ei[1]), np.arange(N + 1)))
+    np.testing.assert_array_equal(g.c_perm.cpu().numpy(), np.argsort(ei[0], kind="stable"))
+    np.testing.assert_array_equal(g.n_perm.cpu().numpy(), np.argsort(ei[1], kind="stable"))
+    # exclusive scan helper
+    from xequinet_amd import lib
+    from xequinet_amd.lib import call, ptr, stream
+    for n in (0, 1, 1023, 1024, 1025, 5000):
+        cnt = torch.randint(0, 7, (n,), dtype=torch.int32, device=DEV)
+        out = torch.empty(n + 1, dtype=torch.int32, device=DEV)
+        call("xeq_exclusive_scan_i32", ptr(cnt), n, ptr(out), stream())
+        want = np.concatenate([[0], np.cumsum(cnt.cpu().numpy())])
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+# --------------------------------------------------------------------- edge geometry
+@pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 1e-6), ("f64", torch.float64, 1e-13)])
+def test_edge_vectors_golden(tag, dtype, tol):
+    from xequinet_amd.nn.basic import compute_edge_data
+
+    f = _load(f"edge_data_aspirin_{tag}.npz")
+    data = {"pos": _t(f["pos"], dtype), "edge_index": _t(f["edge_index"])}
+    out = compute_edge_data(data, compute_forces=False)
+    np.testing.assert_allclose(out["edge_vector"].cpu().numpy(), f["edge_vector"], rtol=0, atol=tol)
+    np.testing.assert_allclose(out["edge_length"].cpu().numpy(), f["edge_length"], rtol=0, atol=tol)
+    g = _load("radius_graph_pbc_two_graphs_unwrapped.npz")
+    e = _load(f"edge_data_pbc2_{tag}.npz")
+    npg = g["n_per_graph"]
+    data = {
+        "pos": _t(g["pos"], dtype), "edge_index": _t(g["edge_index"]), "cell": _t(g["cell"], dtype),
+        "cell_offsets": _t(g["cell_offsets"], dtype), "batch": _t(np.repeat(np.arange(len(npg)), npg)),
+        "ptr": _t(np.concatenate([[0], np.cumsum(npg)])),
+    }
+    out = compute_edge_data(data, compute_forces=False)
+    np.testing.assert_allclose(out["edge_vector"].cpu().numpy(), e["edge_vector"], rtol=0, atol=10 * tol)
+    np.testing.assert_allclose(out["edge_length"].cpu().numpy(), e["edge_length"], rtol=0, atol=10 * tol)
+
+
+def test_edge_vectors_backward_matches_autograd():
+    from xequinet_amd.nn.basic import compute_edge_data
+
+    pos, z, ptr = orc.synth_qm9_batch(5, seed=1)
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 4.0)
+    perm = np.random.default_rng(0).permutation(ei.shape[1])  # unsorted edges: exercises both perms
+    ei = ei[:, perm]
+    w = np.random.default_rng(1).normal(size=(ei.shape[1], 3))
+    wd = np.random.default_rng(2).normal(size=(ei.shape[1],))
+    p_ref = torch.tensor(pos, requires_grad=True)
+    d = orc.compute_edge_data({"pos": p_ref, "edge_index": torch.tensor(ei)}, compute_forces=False)
+    (d["edge_vector"] * torch.tensor(w)).sum().add((d["edge_length"] * torch.tensor(wd)).sum()).backward()
+    p = _t(pos, torch.float64).requires_grad_()
+    out = compute_edge_data({"pos": p, "edge_index": _t(ei)}, compute_forces=False)
+    ((out["edge_vector"] * _t(w)).sum() + (out["edge_length"] * _t(wd)).sum()).backward()
+    np.testing.assert_allclose(p.grad.cpu().numpy(), p_ref.grad.numpy(), rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------ operator level
+IRREPS = ["128x0e + 64x1o + 32x2e", "16x1o", "8x0e+4x1o+2x2e", "5x0e+3x2e"]
+
+
+@pytest.mark.parametrize("irreps", IRREPS)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float64, 1e-13)])
+def test_spherical_harmonics_fwd_bwd(irreps, dtype, tol):
+    from xequinet_amd import o3
+
+    torch.manual_seed(0)
+    v = torch.randn(37, 3, dtype=torch.float64) * 2.0
+    v[0] = torch.tensor([0.0, 0.0, 1.5])  # axis-aligned known answers ride along
+    v[1] = torch.tensor([2.0, 0.0, 0.0])
+    w = torch.randn(37, orc.irreps_dim(irreps), dtype=torch.float64)
+    vr = v.clone().requires_grad_()
+    ref = orc.spherical_harmonics(irreps, vr)
+    (ref * w).sum().backward()
+    sh = o3.SphericalHarmonics(irreps, normalize=True, normalization="component")
+    vg = v.to(dtype).to(DEV).requires_grad_()
+    out = sh(vg)
+    (out * w.to(dtype).to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().double().numpy(), ref.detach().numpy(), rtol=0, atol=tol * 5)
+    np.testing.assert_allclose(vg.grad.cpu().double().numpy(), vr.grad.numpy(), rtol=0, atol=tol * 200)
+
+
+@pytest.mark.parametrize("irreps", IRREPS)
+def test_elementwise_tp_dot_invariant(irreps):
+    from xequinet_amd import o3
+    from xequinet_amd.nn.o3layer import EquivariantDot, Invariant
+
+    torch.manual_seed(1)
+    n, D, C = 23, orc.irreps_dim(irreps), orc.irreps_num(irreps)
+    x, y, g = torch.randn(n, D, dtype=torch.float64), torch.randn(n, D, dtype=torch.float64), torch.randn(n, C, dtype=torch.float64)
+    xr, yr, gr = (t.clone().requires_grad_() for t in (x, y, g))
+    ref = orc.elementwise_tp(irreps, xr, gr).square().sum() + (orc.equivariant_dot(irreps, xr, yr) * gr).sum() \
+        + orc.invariant(irreps, yr).sum()
+    ref.backward()
+    xg, yg, gg = (t.to(DEV).requires_grad_() for t in (x, y, g))
+    etp = o3.ElementwiseTensorProduct(irreps, f"{C}x0e")
+    out = etp(xg, gg).square().sum() + (EquivariantDot(irreps)(xg, yg) * gg).sum() + Invariant(irreps)(yg).sum()
+    out.backward()
+    assert abs(out.item() - ref.item()) < 1e-9 * abs(ref.item())
+    for a, b in ((xg, xr), (yg, yr), (gg, gr)):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("irreps", ["128x0e + 64x1o + 32x2e", "8x0e+4x1o+2x2e", "16x1o"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.float64, 1e-11)])
+def test_equivariant_layer_norm_fwd_bwd(irreps, dtype, tol):
+    from xequinet_amd.nn.o3layer import EquivariantLayerNorm
+
+    torch.manual_seed(2)
+    n, D, C = 19, orc.irreps_dim(irreps), orc.irreps_num(irreps)
+    m0 = orc.parse_irreps(irreps)[0][0] if orc.parse_irreps(irreps)[0][1] == 0 else 0
+    x = torch.randn(n, D, dtype=torch.float64) * 3 + 0.5
+    x[0] = 0.0  # first-layer case: zeros in, zeros (+bias) out, finite gradient
+    w, b = torch.rand(C, dtype=torch.float64) + 0.5, torch.randn(m0, dtype=torch.float64)
+    gout = torch.randn(n, D, dtype=torch.float64)
+    xr = x.clone().requires_grad_()
+    ref = orc.equivariant_layer_norm(irreps, xr, w, b)
+    (ref * gout).sum().backward()
+    ln = EquivariantLayerNorm(irreps).to(dtype).to(DEV).requires_grad_(False)
+    ln.affine_weight.copy_(w.to(dtype))
+    ln.affine_bias.copy_(b.to(dtype))
+    xg = x.to(dtype).to(DEV).requires_grad_()
+    out = ln(xg)
+    (out * gout.to(dtype).to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().double().numpy(), ref.detach().numpy(), rtol=tol, atol=tol)
+    scale = xr.grad.abs().max().item()
+    np.testing.assert_allclose(xg.grad.cpu().double().numpy(), xr.grad.numpy(), rtol=tol, atol=tol * scale)
+
+
+def test_radial_and_scatter_ops():
+    from xequinet_amd.nn import rbf as prbf
+    from xequinet_amd.scatter import scatter, scatter_sum
+
+    for tag, dtype, tol in (("f32", torch.float32, 3e-6), ("f64", torch.float64, 1e-12)):
+        f = _load(f"rbf_{tag}.npz")
+        d = _t(f["dist"], dtype)
+        torch.set_default_dtype(dtype)
+        try:
+            np.testing.assert_allclose(prbf.SphericalBesselj0(20, 5.0).to(DEV)(d).cpu().numpy(), f["bessel20_rc5"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(prbf.SphericalBesselj0(8, 4.0).to(DEV)(d).cpu().numpy(), f["bessel8_rc4"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(prbf.CosineCutoff(5.0)(d).cpu().numpy(), f["cosine_rc5"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(prbf.PolynomialCutoff(5.0)(d).cpu().numpy(), f["poly3_rc5"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(prbf.GaussianSmearing(20, 5.0).to(DEV)(d).cpu().numpy(), f["gauss20_rc5"], rtol=tol, atol=tol)
+        finally:
+            torch.set_default_dtype(torch.float32)
+    # segmented / atomic scatter-sum
+    rng = np.random.default_rng(0)
+    counts = rng.integers(0, 40, size=30)
+    counts[3] = 0
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    batch = np.repeat(np.arange(30), counts)
+    for width in (None, 1, 7, 130):
+        shape = (ptr[-1],) if width is None else (ptr[-1], width)
+        src = rng.normal(size=shape)
+        want = np.zeros((30,) + shape[1:])
+        np.add.at(want, batch, src)
+        s = _t(src).requires_grad_()
+        got = scatter_sum(s, _t(batch), ptr=_t(ptr))
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=1e-12, atol=1e-12)
+        gw = rng.normal(size=want.shape)
+        (got * _t(gw)).sum().backward()
+        np.testing.assert_allclose(s.grad.cpu().numpy(), gw[batch], rtol=0, atol=0)
+        got2 = scatter(_t(src), _t(rng.permutation(batch)), dim_size=30)  # arbitrary index: atomics
+        assert got2.shape == want.shape
+
+
+# ------------------------------------------------------------------- fused message
+def _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, dtype, shuffle, seed=0):
+    from xequinet_amd import ops
+
+    rng = np.random.default_rng(seed)
+    pos, z, ptr = orc.synth_qm9_batch(6, seed=seed + 10)
+    rc = 4.0
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, rc)
+    if shuffle:
+        ei = ei[:, rng.permutation(ei.shape[1])]
+    N, E = len(pos), ei.shape[1]
+    C, D = orc.irreps_num(irreps), orc.irreps_dim(irreps)
+    H = node_dim + 2 * C
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64)
+    h, xhat = t64(rng.normal(size=(N, H))), t64(rng.normal(size=(N, D)))
+    s, x = t64(rng.normal(size=(N, node_dim))), t64(rng.normal(size=(N, D)))
+    W, b = t64(rng.normal(size=(H, B)) / math.sqrt(B)), t64(rng.normal(size=(H,)))
+    vec = t64(pos[ei[0]] - pos[ei[1]])
+    gs, gx = t64(rng.normal(size=(N, node_dim))), t64(rng.normal(size=(N, D)))
+    if rbf_kind == "bessel":
+        p0, p1 = t64(math.pi * np.arange(1, B + 1) / rc * (1 + 0.01 * rng.normal(size=B))).view(1, -1), None
+    else:
+        p0, p1 = t64(np.linspace(0, rc, B)).view(1, -1), t64(0.5 + rng.uniform(size=B)).view(1, -1)
+    # ---- oracle (autograd)
+    hr, xr, vr, sr, xir = (t.clone().requires_grad_() for t in (h, xhat, vec, s, x))
+    dist = torch.linalg.norm(vr, dim=-1, keepdim=True)
+    rbf = orc.bessel_rbf(dist, p0, rc) if rbf_kind == "bessel" else orc.gaussian_rbf(dist, p0, p1)
+    fcut = orc.cosine_cutoff(dist, rc) if cutoff_kind == "cosine" else orc.polynomial_cutoff(dist, rc)
+    rsh = orc.spherical_harmonics(irreps, vr[:, [1, 2, 0]])
+    filt = torch.nn.functional.linear(rbf, W, b) * fcut
+    fo = hr.index_select(0, torch.tensor(ei[1])) * filt
+    g_state, g_edge, m_s = torch.split(fo, [C, C, node_dim], dim=-1)
+    m_x = orc.elementwise_tp(irreps, xr.index_select(0, torch.tensor(ei[1])), g_state) + orc.elementwise_tp(irreps, rsh, g_edge)
+    s_ref = sr.index_add(0, torch.tensor(ei[0]), m_s)
+    x_ref = xir.index_add(0, torch.tensor(ei[0]), m_x)
+    ((s_ref * gs).sum() + (x_ref * gx).sum()).backward()
+    # ---- HIP
+    dev = lambda t: None if t is None else t.to(dtype).to(DEV)
+    hg, xg, vg, sg, xig = (dev(t).requires_grad_() for t in (h, xhat, vec, s, x))
+    graph = ops.EdgeGraph(_t(ei), N)
+    mul = [0, 0, 0]
+    for m_, l_, _ in orc.parse_irreps(irreps):
+        mul[l_] = m_
+    cfg = (rbf_kind, cutoff_kind, B, rc, node_dim, tuple(mul))
+    s_out, x_out = ops.FusedMessage.apply(hg, xg, vg, sg, xig, dev(W), dev(b), dev(p0), dev(p1), graph, cfg)
+    ((s_out * dev(gs)).sum() + (x_out * dev(gx)).sum()).backward()
+    return (s_out, x_out, hg.grad, xg.grad, vg.grad, sg.grad, xig.grad), (s_ref, x_ref, hr.grad, xr.grad, vr.grad, sr.grad, xir.grad)
+
+
+MSG_CASES = [
+    ("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", False),
+    ("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", True),
+    ("16x1o", 16, 8, "bessel", "cosine", False),
+    ("8x0e+4x1o+2x2e", 12, 12, "bessel", "polynomial", True),
+    ("5x0e+3x2e", 7, 32, "gaussian", "cosine", False),
+    ("40x0e + 30x1o + 20x2e", 200, 17, "bessel", "cosine", False),
+]
+
+
+@pytest.mark.parametrize("irreps,node_dim,B,rbf_kind,cutoff_kind,shuffle", MSG_CASES)
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-5)])
+def test_fused_message_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff_kind, shuffle, dtype, tol):
+    got, want = _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, dtype, shuffle)
+    names = ["s_out", "x_out", "grad_h", "grad_xhat", "grad_vec", "grad_s", "grad_x"]
+    for name, a, b in zip(names, got, want):
+        a = a.detach().cpu().double().numpy()
+        b = b.detach().numpy()
+        scale = max(1.0, np.abs(b).max())
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol * scale, err_msg=name)
+
+
+def test_fused_message_is_bitwise_reproducible():
+    a, _ = _message_case("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", torch.float32, False)
+    b, _ = _message_case("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", torch.float32, False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+# -------------------------------------------------------------------- whole model
+def _build(dtype, **kw):
+    from xequinet_amd.nn import resolve_model
+
+    torch.manual_seed(0)
+    model = resolve_model("xpainn", **kw).eval().requires_grad_(False)
+    # make every affine parameter non-trivial so that a wrong index shows up
+    g = torch.Generator().manual_seed(1)
+    for name, p in model.named_parameters():
+        if name.endswith(("norm.weight", "affine_weight")):
+            p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+        elif name.endswith(("bias", "affine_bias")):
+            p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().double().clone() for k, v in model.state_dict().items()}
+    return model.to(dtype).to(DEV), orc.XPaiNNOracle(sd, **kw)
+
+
+def _check_model(model, oracle, pos, z, ptr, ei, dtype, extra=None, etol=None, ftol=None):
+    batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    ref_in = {"pos": torch.tensor(pos, dtype=torch.float64), "atomic_numbers": torch.tensor(z.astype(np.int64)),
+              "edge_index": torch.tensor(ei), "batch": torch.tensor(batch), "ptr": torch.tensor(ptr)}
+    data = {"pos": _t(pos, dtype), "atomic_numbers": _t(z.astype(np.int32)), "edge_index": _t(ei),
+            "batch": _t(batch), "ptr": _t(ptr)}
+    if extra:
+        for k, v in extra.items():
+            ref_in[k] = torch.tensor(v, dtype=torch.float64)
+            data[k] = _t(v, dtype)
+    want = oracle(ref_in, compute_forces=True)
+    with torch.enable_grad():
+        got = model(data, compute_forces=True, compute_virial=False)
+    E, Eref = got["energy"].detach().cpu().double().numpy(), want["energy"].numpy()
+    Fg, Fref = got["forces"].detach().cpu().double().numpy(), want["forces"].numpy()
+    if dtype == torch.float64:
+        np.testing.assert_allclose(E, Eref, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(Fg, Fref, rtol=0, atol=1e-9 * max(1.0, np.abs(Fref).max()))
+        np.testing.assert_allclose(got["atomic_energies"].cpu().numpy(), want["atomic_energies"].numpy(), rtol=1e-10, atol=1e-10)
+    else:
+        assert np.all(np.abs(E - Eref) <= 1e-5 * np.abs(Eref) + 1e-4), (E - Eref)
+        assert np.abs(Fg - Fref).max() <= 1e-4, np.abs(Fg - Fref).max()
+    return got, want
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_model_aspirin_energy_forces(dtype):
+    model, oracle = _build(dtype)
+    pos, z, ptr = orc.synth_aspirin()
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
+    got, _ = _check_model(model, oracle, pos, z, ptr, ei, dtype)
+    assert got["forces"].shape == (21, 3) and got["energy"].shape == (1,)
+    assert got["forces"].sum(0).abs().max().item() < (1e-9 if dtype == torch.float64 else 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_model_qm9_batch_energy_forces(dtype):
+    model, oracle = _build(dtype)
+    pos, z, ptr = orc.synth_qm9_batch(48, seed=21)
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
+    _check_model(model, oracle, pos, z, ptr, ei, dtype)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(node_dim=32, node_irreps="32x0e+16x1o+8x2e", num_basis=8, cutoff=4.0, action_blocks=2, hidden_dim=16),
+    dict(node_dim=16, node_irreps="16x1o", num_basis=8, cutoff=4.0, action_blocks=2, layer_norm=False, embed_basis="one-hot"),
+    dict(node_dim=64, node_irreps="64x0e+32x1o", rbf_kernel="gaussian", cutoff_fn="polynomial", aux_basis="aux28"),
+])
+def test_model_other_configs_fp64(kw):
+    model, oracle = _build(torch.float64, **kw)
+    pos, z, ptr = orc.synth_qm9_batch(7, seed=5)
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, kw.get("cutoff", 5.0))
+    _check_model(model, oracle, pos, z, ptr, ei, torch.float64)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_model_pbc_water_energy_forces(dtype):
+    model, oracle = _build(dtype)
+    f = _load("radius_graph_pbc_water192.npz")
+    pos, z, ptr, cell = orc.synth_water_box(4, seed=5)
+    _check_model(model, oracle, f["pos"].astype(np.float64), z, ptr, f["edge_index"], dtype,
+                 extra={"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)})
+
+
+def test_model_pipeline_with_neighbor_transform_and_unsorted_edges():
+    """NeighborTransform -> model gives the same result as an externally built,
+    randomly permuted edge list (index_add is order independent up to rounding)."""
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+
+    model, oracle = _build(torch.float64)
+    pos, z, ptr = orc.synth_qm9_batch(9, seed=77)
+    batch = XequiBatch(_t(pos, torch.float64), _t(z), _t(ptr))
+    batch = NeighborTransform(5.0)(batch)
+    with torch.enable_grad():
+        a = model(batch.to_dict(), compute_forces=True)
+    ei = batch.edge_index.cpu().numpy()
+    ei = ei[:, np.random.default_rng(0).permutation(ei.shape[1])]
+    _, want = _check_model(model, oracle, pos, z, ptr, ei, torch.float64)
+    np.testing.assert_allclose(a["energy"].detach().cpu().numpy(), want["energy"].numpy(), rtol=1e-10)
+    np.testing.assert_allclose(a["forces"].cpu().numpy(), want["forces"].numpy(), atol=1e-9)
+
+
+def test_full_size_properties_qm9_1024():
+    """BASELINE config 2 at full size through size-independent properties:
+    per-molecule sum of forces = 0, rotation + translation invariance of energies,
+    forces co-rotate, molecule order permutation."""
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+
+    model, _ = _build(torch.float32)
+    pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234)
+    assert len(pos) == 18226
+
+    def run(p, zz, pp):
+        b = NeighborTransform(5.0)(XequiBatch(_t(p, torch.float32), _t(zz), _t(pp)))
+        with torch.enable_grad():
+            out = model(b.to_dict(), compute_forces=True)
+        return out["energy"].detach().cpu().double().numpy(), out["forces"].cpu().double().numpy(), b.edge_index.shape[1]
+
+    E, Fo, n_edges = run(pos, z, ptr)
+    assert n_edges == 300406
+    assert np.isfinite(E).all() and np.isfinite(Fo).all()
+    seg = np.repeat(np.arange(1024), np.diff(ptr))
+    net = np.zeros((1024, 3))
+    np.add.at(net, seg, Fo)
+    assert np.abs(net).max() < 2e-3
+    # rigid motion
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] *= -1
+    E2, F2, _ = run(pos @ Q.T + np.array([1.0, -2.0, 0.5]), z, ptr)
+    assert np.all(np.abs(E2 - E) <= 2e-5 * np.abs(E) + 2e-4)
+    assert np.abs(F2 - Fo @ Q.T).max() < 5e-4
+    # reverse molecule order
+    order = np.arange(1024)[::-1]
+    idx = np.concatenate([np.arange(ptr[g], ptr[g + 1]) for g in order])
+    ptr2 = np.concatenate([[0], np.cumsum(np.diff(ptr)[order])])
+    E3, F3, _ = run(pos[idx], z[idx], ptr2)
+    assert np.all(np.abs(E3 - E[order]) <= 1e-5 * np.abs(E[order]) + 1e-4)
+    assert np.abs(F3 - Fo[idx]).max() < 1e-4

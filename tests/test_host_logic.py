@@ -1,0 +1,146 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol that
+include/xeq.h declares, host-side mirrors keep the reference's interface, and the
+product refuses to run without HIP tensors (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from xequinet_amd import lib
+
+    header = open(os.path.join(ROOT, "include", "xeq.h")).read()
+    declared = set(re.findall(r"\b(xeq_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no prototypes parsed"
+    handle = lib.load()
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"{name} declared in xeq.h but not exported"
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    assert handle.xeq_version() >= 100
+
+
+def test_c_abi_argument_errors_are_reported_without_a_gpu():
+    """Argument validation happens on the host before any launch."""
+    from xequinet_amd import lib
+
+    handle = lib.load()
+    mul = lib.mul3((128, 64, 32))
+    rc = handle.xeq_message_fwd(0, 10, 10, None, None, None, None, None, None, None, None, None, None, None, None,
+                                0, 0, 64, 5.0, 128, mul, None, None, None)
+    assert rc == 1 and b"num_basis" in handle.xeq_last_error()
+    rc = handle.xeq_message_fwd(0, 10, 10, None, None, None, None, None, None, None, None, None, None, None, None,
+                                0, 0, 20, 5.0, 300, mul, None, None, None)
+    assert rc == 1 and b"256-channel" in handle.xeq_last_error()
+    rc = handle.xeq_radial_fwd(0, None, 5, 7, 0, 20, 5.0, None, None, None, None, None)
+    assert rc == 1 and b"not implemented" in handle.xeq_last_error()
+    rc = handle.xeq_segment_sum(5, None, None, 3, 4, None, None)  # bad dtype code
+    assert rc == 1
+
+
+def test_irreps_mirror():
+    from xequinet_amd import o3
+
+    ir = o3.Irreps("128x0e + 64x1o + 32x2e")
+    assert ir.dim == 480 and ir.num_irreps == 224 and ir.mul3() == (128, 64, 32) and ir.lmax == 2
+    assert str(ir) == "128x0e+64x1o+32x2e"
+    assert o3.Irreps("16x1o").mul3() == (0, 16, 0)
+    assert o3.Irreps("4x0e+4x0e+2x1o").simplify() == o3.Irreps("8x0e+2x1o")
+    assert [(m, i.l, i.p) for m, i in o3.Irreps("1o+2x2e")] == [(1, 1, -1), (2, 2, 1)]
+    with pytest.raises(NotImplementedError):
+        o3.Irreps("8x3o").mul3()
+    with pytest.raises(NotImplementedError):
+        o3.Irreps("8x1o+8x0e").mul3()
+    with pytest.raises(ValueError):
+        o3.Irreps("8y0e")
+
+
+def test_model_layout_matches_reference_state_dict():
+    """parameter count and key layout of the default XPaiNN."""
+    from xequinet_amd.nn import resolve_model
+
+    model = resolve_model("xpainn")
+    assert sum(p.numel() for p in model.parameters()) == 865141
+    sd = model.state_dict()
+    expect = {
+        "mods.embedding.embedding.0.embed_ten": (87, 56),
+        "mods.embedding.embedding.1.weight": (128, 56),
+        "mods.embedding.rbf.freq": (1, 20),
+        "mods.message_0.scalar_mlp.2.weight": (576, 128),
+        "mods.message_2.rbf_lin.weight": (576, 20),
+        "mods.message_1.o3norm.affine_weight": (224,),
+        "mods.message_1.o3norm.affine_bias": (128,),
+        "mods.message_1.o3norm.scalar_index": (128,),
+        "mods.update_0.update_U.weight": (21504,),
+        "mods.update_0.update_V.bias": (128,),
+        "mods.update_2.dot_lin.weight": (128, 224),
+        "mods.update_1.update_mlp.0.weight": (128, 352),
+        "mods.update_1.update_mlp.2.weight": (480, 128),
+        "mods.output_energy.out_mlp.0.weight": (64, 128),
+        "mods.output_energy.out_mlp.2.weight": (1, 64),
+    }
+    for k, shape in expect.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert list(model.mods.keys()) == ["embedding", "message_0", "update_0", "message_1", "update_1", "message_2",
+                                       "update_2", "output_energy"]
+    assert torch.all(sd["mods.embedding.embedding.0.embed_ten"][0] == 0)
+    assert torch.all(sd["mods.embedding.embedding.1.bias"] == 0)  # nn/xpainn.py:48
+    freq = sd["mods.embedding.rbf.freq"].double().numpy().ravel()
+    np.testing.assert_allclose(freq, np.pi * np.arange(1, 21) / 5.0, rtol=1e-6)
+    # a reference checkpoint carries e3nn bookkeeping entries: they are dropped, the rest is strict
+    ref_sd = dict(sd)
+    ref_sd["mods.message_0.rsh_conv.weight"] = torch.zeros(0)
+    ref_sd["mods.message_0.rsh_conv.output_mask"] = torch.ones(480)
+    ref_sd["mods.update_0.invariant.tp.weight"] = torch.zeros(0)
+    model.load_reference_state_dict(ref_sd)
+    ref_sd["mods.bogus.weight"] = torch.zeros(1)
+    with pytest.raises(KeyError):
+        model.load_reference_state_dict(ref_sd)
+
+
+def test_factories_and_errors_mirror_reference():
+    from xequinet_amd.nn import resolve_activation, resolve_cutoff, resolve_model, resolve_output, resolve_rbf
+
+    with pytest.raises(NotImplementedError):
+        resolve_model("so3krates")
+    with pytest.raises(NotImplementedError):
+        resolve_rbf("nope", 20, 5.0)
+    with pytest.raises(NotImplementedError):
+        resolve_cutoff("nope", 5.0)
+    with pytest.raises(NotImplementedError):
+        resolve_activation("gelu")
+    with pytest.raises(NotImplementedError):
+        resolve_output("dipole")
+    assert isinstance(resolve_activation("silu", devide_x=True), torch.nn.Sigmoid)
+    assert resolve_model("xpainn", action_blocks=1, node_dim=16, node_irreps="16x0e+8x1o").cutoff_radius == 5.0
+
+
+def test_no_cpu_fallback():
+    """Every op rejects CPU tensors loudly instead of computing on the host."""
+    from xequinet_amd import o3, ops
+    from xequinet_amd.nn import resolve_model
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        o3.SphericalHarmonics("4x0e+2x1o", True, "component")(torch.randn(5, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.EdgeGraph(torch.zeros((2, 4), dtype=torch.int64), 3)
+    model = resolve_model("xpainn", action_blocks=1).eval()
+    data = {"pos": torch.randn(4, 3), "atomic_numbers": torch.tensor([1, 6, 8, 1]),
+            "edge_index": torch.tensor([[0, 1], [1, 0]])}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(data)
+
+
+def test_batch_container():
+    from xequinet_amd.data import XequiBatch
+
+    b = XequiBatch(torch.randn(5, 3), torch.tensor([1, 1, 8, 6, 1]), torch.tensor([0, 3, 5]))
+    assert b.num_graphs == 2 and b.batch.tolist() == [0, 0, 0, 1, 1]
+    assert b.atomic_numbers.dtype == torch.int32
+    assert set(b.to_dict()) == {"pos", "atomic_numbers", "ptr", "batch"}
+    with pytest.raises(ValueError):
+        XequiBatch(torch.randn(2, 3), torch.tensor([1, 1]), pbc=torch.tensor([True, True, True]))

@@ -1,0 +1,241 @@
+// Shared device/host helpers for libxeq_hip.so (gfx950 only).
+//
+// Math restated from the reference (citations relative to /root/reference/xequinet/):
+//   radial basis   nn/rbf.py:134-152 (SphericalBesselj0), :114-131 (GaussianSmearing)
+//   envelopes      nn/rbf.py:43-57 (CosineCutoff), :60-73 (PolynomialCutoff)
+//   spherical harmonics  e3nn 0.5.1 o3.SphericalHarmonics as built at nn/xpainn.py:49-51
+//                        and called on vec[:, [1,2,0]] at nn/xpainn.py:71-74
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/xeq.h"
+
+namespace xeq {
+
+void set_error(const char* fmt, ...);
+
+#define XEQ_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      xeq::set_error(__VA_ARGS__);      \
+      return XEQ_ERR_INVALID_ARGUMENT;  \
+    }                                   \
+  } while (0)
+
+#define XEQ_CHECK_LAUNCH(name)                                                   \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      xeq::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+      return XEQ_ERR_LAUNCH;                                                     \
+    }                                                                            \
+  } while (0)
+
+// dtype dispatch: BODY sees `T`
+#define XEQ_DISPATCH_FLOAT(dtype, ...)                         \
+  do {                                                         \
+    if ((dtype) == XEQ_F32) {                                  \
+      using T = float;                                         \
+      __VA_ARGS__                                              \
+    } else if ((dtype) == XEQ_F64) {                           \
+      using T = double;                                        \
+      __VA_ARGS__                                              \
+    } else {                                                   \
+      xeq::set_error("unsupported dtype %d", (int)(dtype));    \
+      return XEQ_ERR_INVALID_ARGUMENT;                         \
+    }                                                          \
+  } while (0)
+
+// Irreps layout: blocks l = 0,1,2 in ascending order, `mul[l]` channels each
+// (0 = absent), e3nn mul_ir layout (channel-major, m-minor).
+struct Irreps {
+  int mul[3];
+  __host__ __device__ int C() const { return mul[0] + mul[1] + mul[2]; }
+  __host__ __device__ int D() const { return mul[0] + 3 * mul[1] + 5 * mul[2]; }
+  // channel u -> (l, flat offset of its first component)
+  __host__ __device__ void locate(int u, int& l, int& off) const {
+    if (u < mul[0]) {
+      l = 0;
+      off = u;
+    } else if (u < mul[0] + mul[1]) {
+      l = 1;
+      off = mul[0] + 3 * (u - mul[0]);
+    } else {
+      l = 2;
+      off = mul[0] + 3 * mul[1] + 5 * (u - mul[0] - mul[1]);
+    }
+  }
+};
+
+// radial-basis / envelope selection (mirrors resolve_rbf / resolve_cutoff, nn/rbf.py:9-32)
+struct RadialSpec {
+  int rbf_kind;     // XEQ_RBF_BESSEL | XEQ_RBF_GAUSSIAN
+  int cutoff_kind;  // XEQ_CUTOFF_COSINE | XEQ_CUTOFF_POLYNOMIAL
+  int num_basis;
+  double cutoff;
+};
+
+template <typename T> __device__ __forceinline__ void sincos_(T x, T* s, T* c);
+template <> __device__ __forceinline__ void sincos_<float>(float x, float* s, float* c) { sincosf(x, s, c); }
+template <> __device__ __forceinline__ void sincos_<double>(double x, double* s, double* c) { sincos(x, s, c); }
+template <typename T> __device__ __forceinline__ T sqrt_(T x);
+template <> __device__ __forceinline__ float sqrt_<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double sqrt_<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T exp_(T x);
+template <> __device__ __forceinline__ float exp_<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double exp_<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T abs_(T x) { return x < T(0) ? -x : x; }
+
+// envelope f(d) and f'(d)
+template <typename T>
+__device__ __forceinline__ void envelope(int kind, T d, T rc, T& f, T& df) {
+  const T PI = T(3.14159265358979323846);
+  if (!(d < rc)) {  // torch.where(dist < cutoff, ..., 0)  nn/rbf.py:47-48
+    f = T(0);
+    df = T(0);
+    return;
+  }
+  if (kind == XEQ_CUTOFF_COSINE) {
+    T s, c;
+    sincos_<T>(PI * d / rc, &s, &c);
+    f = T(0.5) * (c + T(1));
+    df = -T(0.5) * PI / rc * s;
+  } else {  // polynomial, order p = 3 (nn/rbf.py:60-73)
+    const T p = T(3);
+    T r = d / rc;
+    T r2 = r * r, r3 = r2 * r, r4 = r3 * r, r5 = r4 * r;
+    f = T(1) - T(0.5) * (p + 1) * (p + 2) * r3 + p * (p + 2) * r4 - T(0.5) * p * (p + 1) * r5;
+    df = (-T(0.5) * (p + 1) * (p + 2) * p * r2 + p * (p + 2) * (p + 1) * r3 - T(0.5) * p * (p + 1) * (p + 2) * r4) / rc;
+  }
+}
+
+// radial basis rho_k(d) and rho_k'(d); p0/p1 = freq/- (bessel) or mean/std (gaussian)
+template <typename T>
+__device__ __forceinline__ void radial(int kind, T d, T rc, T p0, T p1, T& rho, T& drho) {
+  if (kind == XEQ_RBF_BESSEL) {
+    const T eps = T(1e-5);
+    T coeff = sqrt_<T>(T(2) / rc);
+    T s, c;
+    sincos_<T>(p0 * d, &s, &c);
+    T inv = T(1) / (d + eps);
+    rho = coeff * s * inv;
+    drho = coeff * (p0 * c * inv - s * inv * inv);
+  } else {  // gaussian smearing
+    const T eps = T(1e-5);
+    T sd = abs_<T>(p1) + eps;
+    T coeff = T(1) / (sd * T(2.5066282746310002));  // sqrt(2 pi)
+    T z = (d - p0) / sd;
+    rho = coeff * exp_<T>(-T(0.5) * z * z);
+    drho = -z / sd * rho;
+  }
+}
+
+// Geometry of one edge.  rhat = r / max(|r|, 1e-12) (F.normalize, e3nn normalize=True).
+template <typename T>
+struct EdgeGeom {
+  T d, inv_d;      // |r|, 1/max(|r|,1e-12)
+  T x, y, z;       // unit vector in ORIGINAL axis order
+};
+
+template <typename T>
+__device__ __forceinline__ EdgeGeom<T> edge_geom(T rx, T ry, T rz) {
+  EdgeGeom<T> g;
+  g.d = sqrt_<T>(rx * rx + ry * ry + rz * rz);
+  T dn = g.d > T(1e-12) ? g.d : T(1e-12);
+  g.inv_d = T(1) / dn;
+  g.x = rx * g.inv_d;
+  g.y = ry * g.inv_d;
+  g.z = rz * g.inv_d;
+  return g;
+}
+
+// Component-normalised SH of the unit vector, as the reference evaluates them:
+// e3nn's (x,y,z) <- original (y,z,x).  Y[0]=1 implicit; y1[3], y2[5].
+template <typename T>
+__device__ __forceinline__ void sph_harm_l12(const EdgeGeom<T>& g, T* y1, T* y2) {
+  const T S3 = T(1.7320508075688772), S5 = T(2.23606797749979), S15 = T(3.872983346207417);
+  y1[0] = S3 * g.y;
+  y1[1] = S3 * g.z;
+  y1[2] = S3 * g.x;
+  y2[0] = S15 * g.x * g.y;
+  y2[1] = S15 * g.y * g.z;
+  y2[2] = S5 * (g.z * g.z - T(0.5) * (g.x * g.x + g.y * g.y));
+  y2[3] = S15 * g.x * g.z;
+  y2[4] = T(0.5) * S15 * (g.x * g.x - g.y * g.y);
+}
+
+// Chain rule from (dL/dd, dL/dY1[3], dL/dY2[5]) to dL/dr (original axis order).
+template <typename T>
+__device__ __forceinline__ void edge_grad(const EdgeGeom<T>& g, T gd, const T* p1, const T* p2, T* out) {
+  const T S3 = T(1.7320508075688772), S5 = T(2.23606797749979), S15 = T(3.872983346207417);
+  // G = dL/d rhat
+  T Gx = S3 * p1[2] + S15 * g.y * p2[0] - S5 * g.x * p2[2] + S15 * g.z * p2[3] + S15 * g.x * p2[4];
+  T Gy = S3 * p1[0] + S15 * g.x * p2[0] + S15 * g.z * p2[1] - S5 * g.y * p2[2] - S15 * g.y * p2[4];
+  T Gz = S3 * p1[1] + S15 * g.y * p2[1] + T(2) * S5 * g.z * p2[2] + S15 * g.x * p2[3];
+  T Gr = Gx * g.x + Gy * g.y + Gz * g.z;
+  bool ok = g.d > T(1e-12);  // F.normalize clamps the norm: no gradient through it below the clamp
+  T s = ok ? g.inv_d : T(0);
+  T gdd = ok ? gd : T(0);    // d|r|/dr = rhat (torch.linalg.norm backward is 0 at r = 0)
+  out[0] = gdd * g.x + s * (Gx - Gr * g.x);
+  out[1] = gdd * g.y + s * (Gy - Gr * g.y);
+  out[2] = gdd * g.z + s * (Gz - Gr * g.z);
+}
+
+// ---- wave64 helpers ---------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware persistent work mapping (speed only; every item is visited exactly
+// once for ANY placement).  Items are cut in chunks of `chunk` consecutive items;
+// chunk q belongs to label q % 8; the blocks with blockIdx % 8 == label walk that
+// label's items.  Blocks b and b+8 share an XCD under round-robin dispatch
+// (MI355X_MICROARCH.md, Workgroup dispatch), so consecutive nodes (one molecule)
+// are served by one XCD's L2.
+struct XcdWalk {
+  int64_t n_items;
+  int chunk;
+  int label, slot, n_slots;
+  int64_t idx;
+  __device__ XcdWalk(int64_t n, int chunk_) : n_items(n), chunk(chunk_) {
+    int nb = gridDim.x;
+    if (nb >= 8) {
+      label = blockIdx.x & 7;
+      slot = blockIdx.x >> 3;
+      n_slots = (nb - label + 7) >> 3;  // blocks with this label
+    } else {  // tiny grid: no labelling
+      label = -1;
+      slot = blockIdx.x;
+      n_slots = nb;
+    }
+    idx = slot;
+  }
+  // returns the next item or -1
+  __device__ int64_t next() {
+    while (true) {
+      int64_t item;
+      if (label < 0) {
+        item = idx;
+        if (item >= n_items) return -1;
+      } else {
+        int64_t q8 = idx / chunk;
+        int r = (int)(idx - q8 * chunk);
+        int64_t q = q8 * 8 + label;
+        item = q * chunk + r;
+        if (q * chunk >= n_items) return -1;
+        if (item >= n_items) {  // ragged last chunk
+          idx += n_slots;
+          continue;
+        }
+      }
+      idx += n_slots;
+      return item;
+    }
+  }
+};
+
+}  // namespace xeq

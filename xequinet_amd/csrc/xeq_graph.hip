@@ -1,0 +1,248 @@
+// Neighbour-list and CSR kernels.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "xeq_common.h"
+
+namespace xeq {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------- CSR helpers
+__global__ void k_csr_rowptr(const int64_t* __restrict__ keys, int64_t n_keys, int64_t n_rows,
+                             int32_t* __restrict__ rowptr) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_rows) return;
+  int64_t lo = 0, hi = n_keys;  // first p with keys[p] >= i
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < i) lo = mid + 1;
+    else hi = mid;
+  }
+  rowptr[i] = (int32_t)lo;
+}
+
+// single-workgroup scan with carry; n is O(nodes) and this runs once per graph build
+__global__ void __launch_bounds__(1024) k_exclusive_scan_i32(const int32_t* __restrict__ in, int64_t n,
+                                                             int32_t* __restrict__ out) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    int64_t i = base + t;
+    int32_t v = i < n ? in[i] : 0;
+    int32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int32_t u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    int32_t carry = carry_s;
+    if (i < n) out[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (t == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (t == 0) out[n] = carry_s;
+}
+
+// ---------------------------------------------------------- non-PBC radius graph
+// One thread per center; all lanes of a wave walk (mostly) the same molecule, so the
+// position loads broadcast.  d^2 is evaluated without fma contraction so that the
+// edge decisions are those of the oracle's  (dx*dx + dy*dy) + dz*dz  in the same dtype.
+template <typename T> __device__ __forceinline__ T mul_rn(T a, T b);
+template <> __device__ __forceinline__ float mul_rn<float>(float a, float b) { return __fmul_rn(a, b); }
+template <> __device__ __forceinline__ double mul_rn<double>(double a, double b) { return __dmul_rn(a, b); }
+template <typename T> __device__ __forceinline__ T add_rn(T a, T b);
+template <> __device__ __forceinline__ float add_rn<float>(float a, float b) { return __fadd_rn(a, b); }
+template <> __device__ __forceinline__ double add_rn<double>(double a, double b) { return __dadd_rn(a, b); }
+template <typename T> __device__ __forceinline__ T sub_rn(T a, T b);
+template <> __device__ __forceinline__ float sub_rn<float>(float a, float b) { return __fsub_rn(a, b); }
+template <> __device__ __forceinline__ double sub_rn<double>(double a, double b) { return __dsub_rn(a, b); }
+
+__device__ __forceinline__ int64_t graph_of(const int64_t* __restrict__ ptr, int64_t n_graphs, int64_t i) {
+  int64_t lo = 0, hi = n_graphs;  // last g with ptr[g] <= i
+  while (hi - lo > 1) {
+    int64_t mid = (lo + hi) >> 1;
+    if (ptr[mid] <= i) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+template <typename T, bool FILL>
+__global__ void k_radius_graph(const T* __restrict__ pos, const int64_t* __restrict__ ptr, int64_t n_graphs,
+                               int64_t n_nodes, T r2, int32_t* __restrict__ deg,
+                               const int32_t* __restrict__ rowptr, int64_t n_edges,
+                               int64_t* __restrict__ edge_index) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  int64_t g = graph_of(ptr, n_graphs, i);
+  int64_t a = ptr[g], b = ptr[g + 1];
+  T xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  int32_t cnt = 0;
+  int64_t w = FILL ? (int64_t)rowptr[i] : 0;
+  for (int64_t j = a; j < b; ++j) {
+    T dx = sub_rn<T>(xi, pos[3 * j]), dy = sub_rn<T>(yi, pos[3 * j + 1]), dz = sub_rn<T>(zi, pos[3 * j + 2]);
+    T d2 = add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz));
+    if (d2 < r2 && j != i) {
+      if (FILL) {
+        edge_index[w] = i;            // center
+        edge_index[n_edges + w] = j;  // neighbor
+        ++w;
+      }
+      ++cnt;
+    }
+  }
+  if (!FILL) deg[i] = cnt;
+}
+
+// -------------------------------------------------------------- PBC radius graph
+// One wave per center.  Candidate keys k = (j - a) * n_cells + c are swept in
+// ascending order 64 at a time; a ballot + prefix popcount keeps the reference's
+// (neighbor * n_cells + cell) ordering without any sort.
+template <typename T, bool FILL>
+__global__ void k_radius_graph_pbc(const T* __restrict__ pw, const int64_t* __restrict__ ptr, int64_t n_graphs,
+                                   int64_t n_nodes, const T* __restrict__ img, const T* __restrict__ cells,
+                                   const T* __restrict__ shift, int64_t n_cells, T rc, int32_t* __restrict__ deg,
+                                   const int32_t* __restrict__ rowptr, int64_t n_edges,
+                                   int64_t* __restrict__ edge_index, T* __restrict__ cell_offsets) {
+  const int lane = threadIdx.x & 63;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n_nodes) return;
+  int64_t g = graph_of(ptr, n_graphs, i);
+  int64_t a = ptr[g], b = ptr[g + 1];
+  const T* gimg = img + g * n_cells * 3;
+  T xi = pw[3 * i], yi = pw[3 * i + 1], zi = pw[3 * i + 2];
+  int64_t n_keys = (b - a) * n_cells;
+  int64_t w = FILL ? (int64_t)rowptr[i] : 0;
+  int32_t cnt = 0;
+  for (int64_t k0 = 0; k0 < n_keys; k0 += 64) {
+    int64_t k = k0 + lane;
+    bool hit = false;
+    int64_t j = 0;
+    int64_t c = 0;
+    if (k < n_keys) {
+      j = a + k / n_cells;
+      c = k % n_cells;
+      // B = pos_wrap[j] + img[c]  (radius_graph.py:117), D = |A - B| (cdist)
+      T bx = add_rn<T>(pw[3 * j], gimg[3 * c]), by = add_rn<T>(pw[3 * j + 1], gimg[3 * c + 1]),
+        bz = add_rn<T>(pw[3 * j + 2], gimg[3 * c + 2]);
+      T dx = sub_rn<T>(xi, bx), dy = sub_rn<T>(yi, by), dz = sub_rn<T>(zi, bz);
+      T D = sqrt_<T>(add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz)));
+      hit = (D < rc) && (D > T(0.01));
+    }
+    unsigned long long m = __ballot(hit);
+    if (FILL && hit) {
+      int64_t p = w + __popcll(m & ((1ull << lane) - 1ull));
+      edge_index[p] = i;
+      edge_index[n_edges + p] = j;
+      for (int ax = 0; ax < 3; ++ax)
+        cell_offsets[3 * p + ax] = cells[3 * c + ax] + (shift[3 * i + ax] - shift[3 * j + ax]);
+    }
+    int pc = __popcll(m);
+    w += pc;
+    cnt += pc;
+  }
+  if (!FILL && lane == 0) deg[i] = cnt;
+}
+
+}  // namespace xeq
+
+using namespace xeq;
+
+extern "C" {
+
+int xeq_version(void) { return 100; }
+const char* xeq_last_error(void) { return xeq::g_err; }
+
+int xeq_csr_rowptr(const int64_t* keys, int64_t n_keys, int64_t n_rows, int32_t* rowptr, void* stream) {
+  XEQ_CHECK_ARG(n_keys >= 0 && n_rows >= 0 && n_keys < (1ll << 31), "xeq_csr_rowptr: bad sizes");
+  int64_t n = n_rows + 1;
+  hipLaunchKernelGGL(k_csr_rowptr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
+                     n_keys, n_rows, rowptr);
+  XEQ_CHECK_LAUNCH("xeq_csr_rowptr");
+  return XEQ_OK;
+}
+
+int xeq_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* out, void* stream) {
+  XEQ_CHECK_ARG(n >= 0, "xeq_exclusive_scan_i32: n < 0");
+  hipLaunchKernelGGL(k_exclusive_scan_i32, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n, out);
+  XEQ_CHECK_LAUNCH("xeq_exclusive_scan_i32");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_count(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                           double cutoff, int32_t* deg, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0, "xeq_radius_graph_count: negative size");
+  if (n_nodes == 0) return XEQ_OK;
+  XEQ_CHECK_ARG(n_graphs > 0, "xeq_radius_graph_count: nodes without graphs");
+  XEQ_DISPATCH_FLOAT(dtype, {
+    T rc = (T)cutoff;
+    hipLaunchKernelGGL((k_radius_graph<T, false>), dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos, ptr, n_graphs, n_nodes, rc * rc, deg,
+                       (const int32_t*)nullptr, (int64_t)0, (int64_t*)nullptr);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_count");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_fill(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                          double cutoff, const int32_t* rowptr, int64_t n_edges, int64_t* edge_index,
+                          void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_edges >= 0, "xeq_radius_graph_fill: negative size");
+  if (n_nodes == 0 || n_edges == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    T rc = (T)cutoff;
+    hipLaunchKernelGGL((k_radius_graph<T, true>), dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos, ptr, n_graphs, n_nodes, rc * rc, (int32_t*)nullptr,
+                       rowptr, n_edges, edge_index);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_fill");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_pbc_count(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs,
+                               int64_t n_nodes, const void* img, int64_t n_cells, double cutoff, int32_t* deg,
+                               void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_cells > 0, "xeq_radius_graph_pbc_count: bad sizes");
+  if (n_nodes == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_radius_graph_pbc<T, false>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos_wrap, ptr, n_graphs, n_nodes, (const T*)img,
+                       (const T*)nullptr, (const T*)nullptr, n_cells, (T)cutoff, deg, (const int32_t*)nullptr,
+                       (int64_t)0, (int64_t*)nullptr, (T*)nullptr);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_count");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_pbc_fill(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs,
+                              int64_t n_nodes, const void* img, const void* cells, const void* shift,
+                              int64_t n_cells, double cutoff, const int32_t* rowptr, int64_t n_edges,
+                              int64_t* edge_index, void* cell_offsets, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_cells > 0 && n_edges >= 0, "xeq_radius_graph_pbc_fill: bad sizes");
+  if (n_nodes == 0 || n_edges == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_radius_graph_pbc<T, true>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos_wrap, ptr, n_graphs, n_nodes, (const T*)img,
+                       (const T*)cells, (const T*)shift, n_cells, (T)cutoff, (int32_t*)nullptr, rowptr, n_edges,
+                       edge_index, (T*)cell_offsets);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_fill");
+  return XEQ_OK;
+}
+
+}  // extern "C"

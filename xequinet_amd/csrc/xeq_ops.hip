@@ -1,0 +1,471 @@
+// Operator-level kernels: edge geometry, e3nn-style elementwise ops, equivariant
+// layer norm, segmented sums.
+#include "xeq_common.h"
+
+namespace xeq {
+
+// ------------------------------------------------------------- edge vectors
+template <typename T>
+__global__ void k_edge_vectors_fwd(const T* __restrict__ pos, const int64_t* __restrict__ edge_index, int64_t E,
+                                   const T* __restrict__ cell, const T* __restrict__ cell_offsets,
+                                   const int64_t* __restrict__ batch, T* __restrict__ vec, T* __restrict__ dist) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t c = edge_index[e], n = edge_index[E + e];
+  T v[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v[a] = pos[3 * c + a] - pos[3 * n + a];
+  if (cell != nullptr) {
+    const T* cm = cell + (batch ? 9 * batch[n] : 0);  // cell of the NEIGHBOR's graph (basic.py:125-126)
+    T o0 = cell_offsets[3 * e], o1 = cell_offsets[3 * e + 1], o2 = cell_offsets[3 * e + 2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v[a] -= o0 * cm[a] + o1 * cm[3 + a] + o2 * cm[6 + a];  // einsum ni,nij->nj
+  }
+  vec[3 * e] = v[0];
+  vec[3 * e + 1] = v[1];
+  vec[3 * e + 2] = v[2];
+  if (dist) dist[e] = sqrt_<T>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+}
+
+// grad_pos[i] = sum_{center=i} g[e] - sum_{neighbor=i} g[e]; one thread per (node, axis)
+template <typename T>
+__global__ void k_edge_vectors_bwd(const T* __restrict__ g, int64_t N, const int32_t* __restrict__ c_rowptr,
+                                   const int32_t* __restrict__ c_perm, const int32_t* __restrict__ n_rowptr,
+                                   const int32_t* __restrict__ n_perm, T* __restrict__ grad_pos) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * N) return;
+  int64_t i = t / 3;
+  int a = (int)(t - 3 * i);
+  T acc = T(0);
+  for (int32_t p = c_rowptr[i]; p < c_rowptr[i + 1]; ++p) {
+    int64_t e = c_perm ? c_perm[p] : p;
+    acc += g[3 * e + a];
+  }
+  for (int32_t p = n_rowptr[i]; p < n_rowptr[i + 1]; ++p) {
+    int64_t e = n_perm ? n_perm[p] : p;
+    acc -= g[3 * e + a];
+  }
+  grad_pos[t] = acc;
+}
+
+// ------------------------------------------------------- spherical harmonics
+// `vec` arrives in e3nn axis order (x_e, y_e, z_e) = original (y, z, x).
+template <typename T>
+__global__ void k_sph_harm_fwd(const T* __restrict__ vec, int64_t n, Irreps ir, int normalize,
+                               T* __restrict__ out) {
+  const int D = ir.D();
+  int64_t e = blockIdx.x;
+  if (e >= n) return;
+  T xe = vec[3 * e], ye = vec[3 * e + 1], ze = vec[3 * e + 2];
+  // back to original order: x = z_e, y = x_e, z = y_e
+  EdgeGeom<T> g;
+  if (normalize) {
+    g = edge_geom<T>(ze, xe, ye);
+  } else {
+    g.x = ze; g.y = xe; g.z = ye; g.d = T(1); g.inv_d = T(1);
+  }
+  T y1[3], y2[5];
+  sph_harm_l12<T>(g, y1, y2);
+  for (int f = threadIdx.x; f < D; f += blockDim.x) {
+    T v;
+    if (f < ir.mul[0]) v = T(1);
+    else if (f < ir.mul[0] + 3 * ir.mul[1]) v = y1[(f - ir.mul[0]) % 3];
+    else v = y2[(f - ir.mul[0] - 3 * ir.mul[1]) % 5];
+    out[e * D + f] = v;
+  }
+}
+
+template <typename T>
+__global__ void k_sph_harm_bwd(const T* __restrict__ vec, const T* __restrict__ grad_out, int64_t n, Irreps ir,
+                               int normalize, T* __restrict__ grad_vec) {
+  // one wave per edge: reduce grad_out over the repeated copies, then chain rule
+  const int D = ir.D();
+  const int lane = threadIdx.x & 63;
+  int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= n) return;
+  T p1[3] = {T(0), T(0), T(0)}, p2[5] = {T(0), T(0), T(0), T(0), T(0)};
+  const int o1 = ir.mul[0], o2 = ir.mul[0] + 3 * ir.mul[1];
+  for (int f = o1 + lane; f < D; f += 64) {
+    T gv = grad_out[e * D + f];
+    if (f < o2) {
+      int m = (f - o1) % 3;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) p1[q] += (m == q) ? gv : T(0);
+    } else {
+      int m = (f - o2) % 5;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) p2[q] += (m == q) ? gv : T(0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) p1[q] = wave_sum<T>(p1[q]);
+#pragma unroll
+  for (int q = 0; q < 5; ++q) p2[q] = wave_sum<T>(p2[q]);
+  if (lane == 0) {
+    T xe = vec[3 * e], ye = vec[3 * e + 1], ze = vec[3 * e + 2];
+    T out[3];
+    if (normalize) {
+      EdgeGeom<T> g = edge_geom<T>(ze, xe, ye);
+      edge_grad<T>(g, T(0), p1, p2, out);
+    } else {
+      // polynomial in the raw vector: reuse edge_grad's dY/drhat with projection disabled
+      EdgeGeom<T> g;
+      g.x = ze; g.y = xe; g.z = ye; g.d = T(1); g.inv_d = T(1);
+      const T S3 = T(1.7320508075688772), S5 = T(2.23606797749979), S15 = T(3.872983346207417);
+      out[0] = S3 * p1[2] + S15 * g.y * p2[0] - S5 * g.x * p2[2] + S15 * g.z * p2[3] + S15 * g.x * p2[4];
+      out[1] = S3 * p1[0] + S15 * g.x * p2[0] + S15 * g.z * p2[1] - S5 * g.y * p2[2] - S15 * g.y * p2[4];
+      out[2] = S3 * p1[1] + S15 * g.y * p2[1] + T(2) * S5 * g.z * p2[2] + S15 * g.x * p2[3];
+    }
+    // out is d/d(x,y,z) original; grad_vec in e3nn order (x_e,y_e,z_e) = (y,z,x)
+    grad_vec[3 * e] = out[1];
+    grad_vec[3 * e + 1] = out[2];
+    grad_vec[3 * e + 2] = out[0];
+  }
+}
+
+// ------------------------------------------------------------------- radial
+template <typename T>
+__global__ void k_radial_fwd(const T* __restrict__ dist, int64_t n, RadialSpec rs, const T* __restrict__ p0,
+                             const T* __restrict__ p1, T* __restrict__ rbf, T* __restrict__ fcut) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int B = rs.num_basis;
+  if (t >= n * (B + 1)) return;
+  int64_t e = t / (B + 1);
+  int k = (int)(t - e * (B + 1));
+  T d = dist[e];
+  T rc = (T)rs.cutoff;
+  if (k == B) {
+    if (fcut) {
+      T f, df;
+      envelope<T>(rs.cutoff_kind, d, rc, f, df);
+      fcut[e] = f;
+    }
+  } else if (rbf) {
+    T rho, drho;
+    radial<T>(rs.rbf_kind, d, rc, p0[k], p1 ? p1[k] : T(0), rho, drho);
+    rbf[e * B + k] = rho;
+  }
+}
+
+// ------------------------------------------------ elementwise TP / channel dot
+template <typename T>
+__global__ void k_elementwise_tp(const T* __restrict__ x, const T* __restrict__ g, int64_t n, int64_t g_rows,
+                                 Irreps ir, T* __restrict__ out) {
+  const int D = ir.D(), C = ir.C();
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * D) return;
+  int64_t row = t / D;
+  int f = (int)(t - row * D);
+  int u;
+  if (f < ir.mul[0]) u = f;
+  else if (f < ir.mul[0] + 3 * ir.mul[1]) u = ir.mul[0] + (f - ir.mul[0]) / 3;
+  else u = ir.mul[0] + ir.mul[1] + (f - ir.mul[0] - 3 * ir.mul[1]) / 5;
+  int64_t grow = g_rows == 1 ? 0 : row;
+  out[t] = x[t] * g[grow * C + u];
+}
+
+template <typename T>
+__global__ void k_channel_dot(const T* __restrict__ a, const T* __restrict__ b, int64_t n, Irreps ir,
+                              T* __restrict__ out) {
+  const int D = ir.D(), C = ir.C();
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  int64_t row = t / C;
+  int u = (int)(t - row * C);
+  int l, off;
+  ir.locate(u, l, off);
+  T acc = T(0);
+  for (int m = 0; m < 2 * l + 1; ++m) acc += a[row * D + off + m] * b[row * D + off + m];
+  out[t] = acc;
+}
+
+// ------------------------------------------------------ equivariant layer norm
+// One wave per node.  y = (x - [l=0] mean_0e(x)) * rsqrt(mean_u sum_m xc^2 + eps) * w_u + [l=0] b_u
+template <typename T>
+__global__ void k_eqln_fwd(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
+                           int64_t n, Irreps ir, T eps, T* __restrict__ out) {
+  const int D = ir.D(), C = ir.C(), m0 = ir.mul[0];
+  const int lane = threadIdx.x & 63;
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= n) return;
+  const T* xr = x + row * D;
+  T s = T(0);
+  for (int f = lane; f < m0; f += 64) s += xr[f];
+  T mean = m0 > 0 ? wave_sum<T>(s) / T(m0) : T(0);
+  T sq = T(0);
+  for (int f = lane; f < D; f += 64) {
+    T v = xr[f] - (f < m0 ? mean : T(0));
+    sq += v * v;
+  }
+  sq = wave_sum<T>(sq);
+  T r = T(1) / sqrt_<T>(sq / T(C) + eps);
+  for (int f = lane; f < D; f += 64) {
+    int u;
+    if (f < m0) u = f;
+    else if (f < m0 + 3 * ir.mul[1]) u = m0 + (f - m0) / 3;
+    else u = m0 + ir.mul[1] + (f - m0 - 3 * ir.mul[1]) / 5;
+    T v = (xr[f] - (f < m0 ? mean : T(0))) * r * w[u];
+    if (f < m0) v += bias[f];
+    out[row * D + f] = v;
+  }
+}
+
+template <typename T>
+__global__ void k_eqln_bwd(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ go, int64_t n,
+                           Irreps ir, T eps, T* __restrict__ gx) {
+  const int D = ir.D(), C = ir.C(), m0 = ir.mul[0];
+  const int lane = threadIdx.x & 63;
+  int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= n) return;
+  const T* xr = x + row * D;
+  const T* gr = go + row * D;
+  T s = T(0);
+  for (int f = lane; f < m0; f += 64) s += xr[f];
+  T mean = m0 > 0 ? wave_sum<T>(s) / T(m0) : T(0);
+  T sq = T(0), dotp = T(0);
+  for (int f = lane; f < D; f += 64) {
+    int u;
+    if (f < m0) u = f;
+    else if (f < m0 + 3 * ir.mul[1]) u = m0 + (f - m0) / 3;
+    else u = m0 + ir.mul[1] + (f - m0 - 3 * ir.mul[1]) / 5;
+    T xc = xr[f] - (f < m0 ? mean : T(0));
+    sq += xc * xc;
+    dotp += gr[f] * w[u] * xc;  // sum dy * xc
+  }
+  sq = wave_sum<T>(sq);
+  dotp = wave_sum<T>(dotp);
+  T r = T(1) / sqrt_<T>(sq / T(C) + eps);
+  T coef = dotp * r * r * r / T(C);
+  // gxc = r * dy - coef * xc ; then remove the mean of gxc over the 0e channels
+  T gs = T(0);
+  for (int f = lane; f < m0; f += 64) {
+    T xc = xr[f] - mean;
+    gs += r * gr[f] * w[f] - coef * xc;
+  }
+  T gmean = m0 > 0 ? wave_sum<T>(gs) / T(m0) : T(0);
+  for (int f = lane; f < D; f += 64) {
+    int u;
+    if (f < m0) u = f;
+    else if (f < m0 + 3 * ir.mul[1]) u = m0 + (f - m0) / 3;
+    else u = m0 + ir.mul[1] + (f - m0 - 3 * ir.mul[1]) / 5;
+    T xc = xr[f] - (f < m0 ? mean : T(0));
+    T v = r * gr[f] * w[u] - coef * xc;
+    if (f < m0) v -= gmean;
+    gx[row * D + f] = v;
+  }
+}
+
+// ------------------------------------------------------------- segmented sums
+// one wave per (segment, 64-column slab); rows summed in order => reproducible
+template <typename T>
+__global__ void k_segment_sum(const T* __restrict__ src, const int64_t* __restrict__ ptr, int64_t n_seg,
+                              int64_t width, T* __restrict__ out) {
+  int64_t slabs = (width + 63) / 64;
+  int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wid >= n_seg * slabs) return;
+  int64_t g = wid / slabs;
+  int64_t col = (wid - g * slabs) * 64 + lane;
+  int64_t a = ptr[g], b = ptr[g + 1];
+  if (width == 1) {  // scalar rows: lanes stride the rows, then a wave reduction
+    T acc = T(0);
+    for (int64_t i = a + lane; i < b; i += 64) acc += src[i];
+    acc = wave_sum<T>(acc);
+    if (lane == 0) out[g] = acc;
+    return;
+  }
+  if (col >= width) return;
+  T acc = T(0);
+  for (int64_t i = a; i < b; ++i) acc += src[i * width + col];
+  out[g * width + col] = acc;
+}
+
+template <typename T>
+__global__ void k_scatter_add(const T* __restrict__ src, const int64_t* __restrict__ index, int64_t n,
+                              int64_t width, T* __restrict__ out, int64_t n_out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * width) return;
+  int64_t row = t / width;
+  int64_t col = t - row * width;
+  int64_t dst = index[row];
+  if (dst < 0 || dst >= n_out) return;
+  atomicAdd(&out[dst * width + col], src[t]);
+}
+
+static inline int check_irreps(const int32_t mul[3], Irreps& ir, const char* who) {
+  for (int l = 0; l < 3; ++l) {
+    if (mul[l] < 0) {
+      set_error("%s: negative multiplicity", who);
+      return XEQ_ERR_INVALID_ARGUMENT;
+    }
+    ir.mul[l] = mul[l];
+  }
+  if (ir.C() == 0) {
+    set_error("%s: empty irreps", who);
+    return XEQ_ERR_INVALID_ARGUMENT;
+  }
+  return XEQ_OK;
+}
+
+}  // namespace xeq
+
+using namespace xeq;
+
+#define XEQ_IRREPS(who)                       \
+  Irreps ir;                                  \
+  {                                           \
+    int rc_ = check_irreps(mul, ir, who);     \
+    if (rc_ != XEQ_OK) return rc_;            \
+  }
+
+extern "C" {
+
+int xeq_edge_vectors_fwd(int dtype, const void* pos, const int64_t* edge_index, int64_t n_edges,
+                         const void* cell, const void* cell_offsets, const int64_t* batch, void* vec, void* dist,
+                         void* stream) {
+  XEQ_CHECK_ARG(n_edges >= 0, "xeq_edge_vectors_fwd: n_edges < 0");
+  XEQ_CHECK_ARG((cell == nullptr) == (cell_offsets == nullptr), "xeq_edge_vectors_fwd: cell and cell_offsets must both be given or both be NULL (data/transform.py:67-68)");
+  if (n_edges == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_edge_vectors_fwd<T>), dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos, edge_index, n_edges, (const T*)cell,
+                       (const T*)cell_offsets, batch, (T*)vec, (T*)dist);
+  });
+  XEQ_CHECK_LAUNCH("xeq_edge_vectors_fwd");
+  return XEQ_OK;
+}
+
+int xeq_edge_vectors_bwd(int dtype, const void* grad_vec, int64_t n_nodes, const int32_t* c_rowptr,
+                         const int32_t* c_perm, const int32_t* n_rowptr, const int32_t* n_perm, void* grad_pos,
+                         void* stream) {
+  XEQ_CHECK_ARG(n_nodes >= 0, "xeq_edge_vectors_bwd: n_nodes < 0");
+  if (n_nodes == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_edge_vectors_bwd<T>), dim3((unsigned)((3 * n_nodes + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)grad_vec, n_nodes, c_rowptr, c_perm, n_rowptr, n_perm,
+                       (T*)grad_pos);
+  });
+  XEQ_CHECK_LAUNCH("xeq_edge_vectors_bwd");
+  return XEQ_OK;
+}
+
+int xeq_sph_harm_fwd(int dtype, const void* vec, int64_t n, const int32_t mul[3], int normalize, void* out,
+                     void* stream) {
+  XEQ_IRREPS("xeq_sph_harm_fwd");
+  if (n <= 0) return XEQ_OK;
+  XEQ_CHECK_ARG(n < (1ll << 31), "xeq_sph_harm_fwd: too many rows");
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_sph_harm_fwd<T>), dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, (const T*)vec, n,
+                       ir, normalize, (T*)out);
+  });
+  XEQ_CHECK_LAUNCH("xeq_sph_harm_fwd");
+  return XEQ_OK;
+}
+
+int xeq_sph_harm_bwd(int dtype, const void* vec, const void* grad_out, int64_t n, const int32_t mul[3],
+                     int normalize, void* grad_vec, void* stream) {
+  XEQ_IRREPS("xeq_sph_harm_bwd");
+  if (n <= 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_sph_harm_bwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)vec, (const T*)grad_out, n, ir, normalize, (T*)grad_vec);
+  });
+  XEQ_CHECK_LAUNCH("xeq_sph_harm_bwd");
+  return XEQ_OK;
+}
+
+int xeq_radial_fwd(int dtype, const void* dist, int64_t n, int rbf_kind, int cutoff_kind, int num_basis,
+                   double cutoff, const void* p0, const void* p1, void* rbf_out, void* fcut_out, void* stream) {
+  XEQ_CHECK_ARG(num_basis > 0 && cutoff > 0, "xeq_radial_fwd: bad num_basis/cutoff");
+  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_radial_fwd: rbf kernel %d is not implemented", rbf_kind);
+  XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_radial_fwd: cutoff function %d is not implemented", cutoff_kind);
+  XEQ_CHECK_ARG(rbf_out == nullptr || p0 != nullptr, "xeq_radial_fwd: rbf parameters missing");
+  if (n <= 0) return XEQ_OK;
+  RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
+  int64_t total = n * (num_basis + 1);
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_radial_fwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)dist, n, rs, (const T*)p0, (const T*)p1, (T*)rbf_out, (T*)fcut_out);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radial_fwd");
+  return XEQ_OK;
+}
+
+int xeq_elementwise_tp_fwd(int dtype, const void* x, const void* g, int64_t n, int64_t g_rows,
+                           const int32_t mul[3], void* out, void* stream) {
+  XEQ_IRREPS("xeq_elementwise_tp_fwd");
+  XEQ_CHECK_ARG(g_rows == 1 || g_rows == n, "xeq_elementwise_tp_fwd: gate rows %lld do not match %lld", (long long)g_rows, (long long)n);
+  if (n <= 0) return XEQ_OK;
+  int64_t total = n * ir.D();
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_elementwise_tp<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)x, (const T*)g, n, g_rows, ir, (T*)out);
+  });
+  XEQ_CHECK_LAUNCH("xeq_elementwise_tp_fwd");
+  return XEQ_OK;
+}
+
+int xeq_channel_dot_fwd(int dtype, const void* a, const void* b, int64_t n, const int32_t mul[3], void* out,
+                        void* stream) {
+  XEQ_IRREPS("xeq_channel_dot_fwd");
+  if (n <= 0) return XEQ_OK;
+  int64_t total = n * ir.C();
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_channel_dot<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)a, (const T*)b, n, ir, (T*)out);
+  });
+  XEQ_CHECK_LAUNCH("xeq_channel_dot_fwd");
+  return XEQ_OK;
+}
+
+int xeq_eqln_fwd(int dtype, const void* x, const void* weight, const void* bias, int64_t n,
+                 const int32_t mul[3], double eps, void* out, void* stream) {
+  XEQ_IRREPS("xeq_eqln_fwd");
+  if (n <= 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_eqln_fwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, (const T*)weight, (const T*)bias, n, ir, (T)eps, (T*)out);
+  });
+  XEQ_CHECK_LAUNCH("xeq_eqln_fwd");
+  return XEQ_OK;
+}
+
+int xeq_eqln_bwd(int dtype, const void* x, const void* weight, const void* grad_out, int64_t n,
+                 const int32_t mul[3], double eps, void* grad_x, void* stream) {
+  XEQ_IRREPS("xeq_eqln_bwd");
+  if (n <= 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_eqln_bwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, (const T*)weight, (const T*)grad_out, n, ir, (T)eps, (T*)grad_x);
+  });
+  XEQ_CHECK_LAUNCH("xeq_eqln_bwd");
+  return XEQ_OK;
+}
+
+int xeq_segment_sum(int dtype, const void* src, const int64_t* ptr, int64_t n_segments, int64_t width,
+                    void* out, void* stream) {
+  XEQ_CHECK_ARG(n_segments >= 0 && width > 0, "xeq_segment_sum: bad sizes");
+  if (n_segments == 0) return XEQ_OK;
+  int64_t waves = n_segments * ((width + 63) / 64);
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_segment_sum<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)src, ptr, n_segments, width, (T*)out);
+  });
+  XEQ_CHECK_LAUNCH("xeq_segment_sum");
+  return XEQ_OK;
+}
+
+int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n, int64_t width, void* out,
+                    int64_t n_out, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && width > 0 && n_out >= 0, "xeq_scatter_add: bad sizes");
+  if (n == 0) return XEQ_OK;
+  int64_t total = n * width;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_scatter_add<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)src, index, n, width, (T*)out, n_out);
+  });
+  XEQ_CHECK_LAUNCH("xeq_scatter_add");
+  return XEQ_OK;
+}
+
+}  // extern "C"

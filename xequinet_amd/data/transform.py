@@ -1,0 +1,46 @@
+"""``NeighborTransform`` -- mirror of ``xequinet/data/transform.py:21-69``."""
+from __future__ import annotations
+
+import torch
+
+from .. import keys, ops
+from ..cluster import radius_graph
+from .radius_graph import radius_graph_pbc
+
+
+class NeighborTransform:
+    def __init__(self, cutoff: float) -> None:
+        self.cutoff = cutoff
+
+    def __call__(self, data):
+        device = data.pos.device
+        num_graphs = data.num_graphs if hasattr(data, keys.NUM_GRAPHS) else 1
+        if num_graphs > 1:
+            assert hasattr(data, keys.BATCH)
+            n_nodes_per_graph = data.ptr[1:] - data.ptr[:-1]
+            ptr = data.ptr
+        else:
+            n_nodes_per_graph = torch.tensor([data.pos.shape[0]], device=device)
+            ptr = torch.tensor([0, data.pos.shape[0]], dtype=torch.int64, device=device)
+
+        has_pbc = hasattr(data, keys.PBC) and bool(data.pbc.any())
+        has_cell = hasattr(data, keys.CELL)
+
+        if has_pbc and has_cell:
+            if getattr(data, "edge_index", None) is not None and getattr(data, "cell_offsets", None) is not None:
+                return data
+            edge_index, cell_offsets = radius_graph_pbc(
+                pos=data.pos, n_nodes_per_graph=n_nodes_per_graph, cell=data.cell, pbc=data.pbc, cutoff=self.cutoff,
+            )
+            data.edge_index = edge_index
+            data.cell_offsets = cell_offsets
+        elif not has_pbc and not has_cell:
+            if getattr(data, "edge_index", None) is not None:
+                return data
+            # unlimited neighbours, like max_num_neighbors = sum n_g^2 (data/transform.py:57)
+            data.edge_index = radius_graph(x=data.pos, r=self.cutoff, ptr=ptr)
+        else:
+            raise ValueError("PBC and cell must be both defined or both undefined.")
+        # both builders emit center-sorted edges: hand the CSR views to the model
+        setattr(data, keys.EDGE_GRAPH, ops.EdgeGraph(data.edge_index, data.pos.shape[0], center_sorted=True))
+        return data

@@ -1,0 +1,40 @@
+"""String / int keys of the data dictionary -- same names and values as the
+reference's ``xequinet/keys.py:4-50`` so that data dicts are interchangeable."""
+from typing import Final, Set
+
+# basic keys in datapoints
+POSITIONS: Final[str] = "pos"
+ATOMIC_NUMBERS: Final[str] = "atomic_numbers"
+EDGE_INDEX: Final[str] = "edge_index"
+CELL_OFFSETS: Final[str] = "cell_offsets"
+CELL: Final[str] = "cell"
+PBC: Final[str] = "pbc"
+# keys for collated batches
+BATCH: Final[str] = "batch"
+BATCH_PTR: Final[str] = "ptr"
+NUM_GRAPHS: Final[str] = "num_graphs"
+
+# intermediate variables
+CENTER_IDX: Final[int] = 0
+NEIGHBOR_IDX: Final[int] = 1
+EDGE_LENGTH: Final[str] = "edge_length"
+EDGE_VECTOR: Final[str] = "edge_vector"
+STRAIN: Final[str] = "strain"
+
+RADIAL_BASIS_FUNCTION: Final[str] = "radial_basis_function"
+ENVELOPE_FUNCTION: Final[str] = "envelope_function"
+SPHERICAL_HARMONICS: Final[str] = "spherical_harmonics"
+NODE_INVARIANT: Final[str] = "node_invariant"
+NODE_EQUIVARIANT: Final[str] = "node_equivariant"
+
+# properties
+ATOMIC_ENERGIES: Final[str] = "atomic_energies"
+TOTAL_ENERGY: Final[str] = "energy"
+FORCES: Final[str] = "forces"
+VIRIAL: Final[str] = "virial"
+
+GRAD_PROPERTIES: Final[Set[str]] = {FORCES, VIRIAL}
+
+# private: destination-sorted CSR views of edge_index built once per batch by
+# xequinet_amd.ops.EdgeGraph and shared by all message blocks
+EDGE_GRAPH: Final[str] = "_xeq_edge_graph"

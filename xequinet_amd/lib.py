@@ -1,0 +1,108 @@
+"""ctypes binding of libxeq_hip.so (the C ABI declared in include/xeq.h).
+
+There is NO CPU fallback: if the HIP library is missing the import of any op
+raises, and every op rejects non-HIP tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxeq_hip.so")
+
+XEQ_F32, XEQ_F64 = 0, 1
+RBF_KINDS = {"bessel": 0, "gaussian": 1}
+CUTOFF_KINDS = {"cosine": 0, "polynomial": 1}
+
+_P = c_void_p
+_I3 = ctypes.POINTER(c_int32)
+
+# name -> argtypes, exactly the prototypes of include/xeq.h
+_PROTOS = {
+    "xeq_csr_rowptr": [_P, c_int64, c_int64, _P, _P],
+    "xeq_exclusive_scan_i32": [_P, c_int64, _P, _P],
+    "xeq_radius_graph_count": [c_int, _P, _P, c_int64, c_int64, c_double, _P, _P],
+    "xeq_radius_graph_fill": [c_int, _P, _P, c_int64, c_int64, c_double, _P, c_int64, _P, _P],
+    "xeq_radius_graph_pbc_count": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, c_double, _P, _P],
+    "xeq_radius_graph_pbc_fill": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_double, _P, c_int64, _P, _P, _P],
+    "xeq_edge_vectors_fwd": [c_int, _P, _P, c_int64, _P, _P, _P, _P, _P, _P],
+    "xeq_edge_vectors_bwd": [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
+    "xeq_sph_harm_fwd": [c_int, _P, c_int64, _I3, c_int, _P, _P],
+    "xeq_sph_harm_bwd": [c_int, _P, _P, c_int64, _I3, c_int, _P, _P],
+    "xeq_radial_fwd": [c_int, _P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
+    "xeq_elementwise_tp_fwd": [c_int, _P, _P, c_int64, c_int64, _I3, _P, _P],
+    "xeq_channel_dot_fwd": [c_int, _P, _P, c_int64, _I3, _P, _P],
+    "xeq_eqln_fwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
+    "xeq_eqln_bwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
+    "xeq_segment_sum": [c_int, _P, _P, c_int64, c_int64, _P, _P],
+    "xeq_scatter_add": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, _P],
+    "xeq_message_fwd": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                        c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, _P],
+    "xeq_message_bwd": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                        c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, _P, _P],
+}
+EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree HIP library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m xequinet_amd.csrc.build` "
+            "(xequinet_amd has no CPU / pure-PyTorch fallback)"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.xeq_version.restype = c_int
+    lib.xeq_last_error.restype = c_char_p
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    status = getattr(lib, name)(*args)
+    if status != 0:
+        raise RuntimeError(f"{name} failed ({status}): {lib.xeq_last_error().decode()}")
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return XEQ_F32
+    if t.dtype == torch.float64:
+        return XEQ_F64
+    raise TypeError(f"xequinet_amd supports float32/float64 tensors, got {t.dtype}")
+
+
+def require_hip(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "xequinet_amd ops run on MI355X (HIP) tensors only and have no CPU fallback; "
+                f"got a tensor on {t.device}"
+            )
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def mul3(mul) -> ctypes.Array:
+    return (c_int32 * 3)(*[int(m) for m in mul])

@@ -1,0 +1,124 @@
+"""Edge geometry, property heads by autograd, embedding table and activation
+factory -- host-side mirror of the reference's ``xequinet/nn/basic.py``."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import keys, ops
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+def get_embedding_tensor(embed_basis: str = "gfn2-xtb", aux_basis: str = "aux28") -> torch.Tensor:
+    """Per-element embedding table [87, n_aux], row 0 = zeros (utils/qc.py:222-237).
+    The table is numeric data shipped as ``data/{embed}_{aux}.npy`` (H..Rn, float64)."""
+    path = os.path.join(_DATA, f"{embed_basis}_{aux_basis}.npy")
+    if not os.path.exists(path):
+        raise NotImplementedError(f"no precomputed embedding for {embed_basis}/{aux_basis} (pyscf generation is out of scope)")
+    t = torch.from_numpy(np.load(path))
+    t = torch.cat([torch.zeros(1, t.shape[-1], dtype=t.dtype), t])
+    return t.to(torch.get_default_dtype())
+
+
+class Int2c1eEmbedding(nn.Module):
+    """nn/basic.py:34-57"""
+
+    def __init__(self, embed_basis: str = "gfn2-xtb", aux_basis: str = "aux28") -> None:
+        super().__init__()
+        embed_ten = get_embedding_tensor(embed_basis, aux_basis)
+        self.register_buffer("embed_ten", embed_ten)
+        self.embed_dim = embed_ten.shape[1]
+
+    def forward(self, at_no: torch.Tensor) -> torch.Tensor:
+        return self.embed_ten[at_no.long()]
+
+
+def edge_graph(data: Dict[str, torch.Tensor]) -> ops.EdgeGraph:
+    """The destination-sorted CSR views of ``edge_index`` (built once per batch)."""
+    g = data.get(keys.EDGE_GRAPH)
+    ei = data[keys.EDGE_INDEX]
+    if g is None or g.edge_index.data_ptr() != ei.contiguous().data_ptr() or g.n_edges != ei.shape[1]:
+        g = ops.EdgeGraph(ei, data[keys.POSITIONS].shape[0])
+        data[keys.EDGE_GRAPH] = g
+    return g
+
+
+def compute_edge_data(
+    data: Dict[str, torch.Tensor],
+    compute_forces: bool = True,
+    compute_virial: bool = False,
+) -> Dict[str, torch.Tensor]:
+    """Preprocess edge data (nn/basic.py:60-140) with the HIP edge-vector kernel."""
+    pos = data[keys.POSITIONS]
+    if keys.BATCH not in data:
+        data[keys.BATCH] = torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device)
+        data[keys.BATCH_PTR] = torch.tensor([0, pos.shape[0]], dtype=torch.long, device=pos.device)
+    if keys.BATCH_PTR in data:
+        single_graph = data[keys.BATCH_PTR].numel() == 2
+    else:
+        single_graph = bool(data[keys.BATCH].max() == 0)
+    n_graphs = data[keys.BATCH_PTR].numel() - 1 if keys.BATCH_PTR in data else int(data[keys.BATCH].max()) + 1
+
+    has_cell = keys.CELL in data
+    if compute_virial:
+        raise NotImplementedError("xequinet_amd: the virial/strain path (nn/basic.py:99-107) is not built yet")
+    if compute_forces:
+        pos.requires_grad_()
+    strain = torch.zeros((n_graphs, 3, 3), dtype=pos.dtype, device=pos.device)
+
+    graph = edge_graph(data)
+    cell = data[keys.CELL] if has_cell else None
+    cell_offsets = data[keys.CELL_OFFSETS].to(pos.dtype) if has_cell else None
+    batch = None if (single_graph or not has_cell) else data[keys.BATCH]
+    vectors, dist = ops.EdgeVectors.apply(pos, graph, cell, cell_offsets, batch)
+
+    data.update({keys.EDGE_LENGTH: dist, keys.EDGE_VECTOR: vectors, keys.STRAIN: strain})
+    return data
+
+
+def compute_forces_only(energy: torch.Tensor, pos: torch.Tensor, training: bool = True) -> torch.Tensor:
+    """nn/basic.py:143-159"""
+    if training:
+        raise NotImplementedError("xequinet_amd: create_graph=True (training double backward) is out of scope; use model.eval()")
+    grad_outputs: Optional[List[Optional[torch.Tensor]]] = [torch.ones_like(energy)]
+    pos_grad = torch.autograd.grad(outputs=[energy], inputs=[pos], grad_outputs=grad_outputs, retain_graph=False,
+                                   create_graph=False, allow_unused=True)[0]
+    if pos_grad is None:
+        pos_grad = torch.zeros_like(pos)
+    return -1.0 * pos_grad
+
+
+def compute_properties(
+    data: Dict[str, torch.Tensor],
+    compute_forces: bool = True,
+    compute_virial: bool = False,
+    training: bool = True,
+    extra_properties: Optional[List[str]] = None,
+) -> Dict[str, torch.Tensor]:
+    """nn/basic.py:202-238 (forces branch)."""
+    results = {}
+    if compute_virial:
+        raise NotImplementedError("xequinet_amd: the virial path is not built yet")
+    if compute_forces:
+        results[keys.FORCES] = compute_forces_only(energy=data[keys.TOTAL_ENERGY], pos=data[keys.POSITIONS], training=training)
+    if extra_properties is not None:
+        results.update({k: data[k] for k in extra_properties})
+    return results
+
+
+def resolve_activation(activation: str, devide_x: bool = False) -> nn.Module:
+    """nn/basic.py:241-262"""
+    activation = activation.lower()
+    activation_div_x = {"silu": "sigmoid", "relu": "identity", "leakyrelu": "identity"}
+    if devide_x and activation in activation_div_x:
+        activation = activation_div_x[activation]
+    table = {"relu": nn.ReLU, "leakyrelu": nn.LeakyReLU, "softplus": nn.Softplus, "sigmoid": nn.Sigmoid,
+             "silu": nn.SiLU, "tanh": nn.Tanh, "identity": nn.Identity}
+    if activation not in table:
+        raise NotImplementedError(f"Unsupported activation function {activation}")
+    return table[activation]()

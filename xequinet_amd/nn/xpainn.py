@@ -1,0 +1,188 @@
+"""XPaiNN embedding / message / update blocks -- host-side mirror of
+``xequinet/nn/xpainn.py`` (same class names, constructor signatures, sub-module
+and parameter names, ``forward(data) -> data`` contract).
+
+The message block is ONE fused HIP kernel per direction (ops.FusedMessage); the
+reference's rbf[E,20], fcut[E,1], rsh[E,480], filter[E,576] and msg[E,480] tensors
+never exist.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable
+
+import torch
+import torch.nn as nn
+
+from .. import keys, o3, ops
+from .basic import Int2c1eEmbedding, edge_graph, resolve_activation
+from .o3layer import EquivariantDot, EquivariantLayerNorm, Invariant
+from .rbf import resolve_cutoff, resolve_rbf
+
+# private data-dict entry: (rbf module, cutoff module) of the embedding, read by the fused message blocks
+RADIAL_SPEC = "_xeq_radial_spec"
+
+
+class XEmbedding(nn.Module):
+    """nn/xpainn.py:14-83.  ``materialize_edge_basis=True`` additionally writes the
+    reference's ``radial_basis_function`` / ``envelope_function`` /
+    ``spherical_harmonics`` entries (detached); the fused path does not need them."""
+
+    def __init__(
+        self,
+        node_dim: int = 128,
+        node_irreps: Iterable = "128x0e + 64x1o + 32x2e",
+        embed_basis: str = "gfn2-xtb",
+        aux_basis: str = "aux56",
+        num_basis: int = 20,
+        rbf_kernel: str = "bessel",
+        cutoff: float = 5.0,
+        cutoff_fn: str = "cosine",
+        materialize_edge_basis: bool = False,
+    ) -> None:
+        super().__init__()
+        self.node_dim = node_dim
+        self.node_irreps = o3.Irreps(node_irreps)
+        self.node_num_irreps = self.node_irreps.num_irreps
+        if embed_basis == "one-hot":
+            self.embedding = nn.Embedding(100, self.node_dim, padding_idx=0)
+        else:
+            int2c1e = Int2c1eEmbedding(embed_basis, aux_basis)
+            self.embedding = nn.Sequential(int2c1e, nn.Linear(int2c1e.embed_dim, self.node_dim))
+            nn.init.zeros_(self.embedding[1].bias)
+        self.sph_harm = o3.SphericalHarmonics(self.node_irreps, normalize=True, normalization="component")
+        self.rbf = resolve_rbf(rbf_kernel, num_basis, cutoff)
+        self.cutoff_fn = resolve_cutoff(cutoff_fn, cutoff)
+        self.materialize_edge_basis = materialize_edge_basis
+
+    def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        atomic_numbers = data[keys.ATOMIC_NUMBERS]
+        vectors = data[keys.EDGE_VECTOR]
+        ops.lib.require_hip(vectors)
+
+        node_invariant = self.embedding(atomic_numbers.long() if isinstance(self.embedding, nn.Embedding) else atomic_numbers)
+        data[keys.NODE_INVARIANT] = node_invariant
+        data[RADIAL_SPEC] = (self.rbf, self.cutoff_fn)
+
+        if self.materialize_edge_basis:
+            distances = data[keys.EDGE_LENGTH].unsqueeze(-1)
+            data[keys.RADIAL_BASIS_FUNCTION] = self.rbf(distances)
+            data[keys.ENVELOPE_FUNCTION] = self.cutoff_fn(distances)
+            with torch.no_grad():  # [x, y, z] -> [y, z, x]  (nn/xpainn.py:71-74)
+                data[keys.SPHERICAL_HARMONICS] = self.sph_harm(vectors.detach()[:, [1, 2, 0]])
+
+        node_equivariant = torch.zeros(
+            (node_invariant.shape[0], self.node_irreps.dim), dtype=node_invariant.dtype, device=node_invariant.device
+        )
+        data[keys.NODE_EQUIVARIANT] = node_equivariant
+        return data
+
+
+class XPainnMessage(nn.Module):
+    """Message function for XPaiNN (nn/xpainn.py:86-161)."""
+
+    def __init__(
+        self,
+        node_dim: int = 128,
+        node_irreps: Iterable = "128x0e + 64x1o + 32x2e",
+        num_basis: int = 20,
+        activation: str = "silu",
+        layer_norm: bool = True,
+    ) -> None:
+        super().__init__()
+        self.node_dim = node_dim
+        self.node_irreps = o3.Irreps(node_irreps)
+        self.node_num_irreps = self.node_irreps.num_irreps
+        self.hidden_dim = self.node_dim + self.node_num_irreps * 2
+        self.num_basis = num_basis
+        # scalar feature
+        self.scalar_mlp = nn.Sequential(
+            nn.Linear(self.node_dim, self.node_dim),
+            resolve_activation(activation),
+            nn.Linear(self.node_dim, self.hidden_dim),
+        )
+        # spherical feature
+        self.rbf_lin = nn.Linear(self.num_basis, self.hidden_dim, bias=True)
+        # elementwise tensor product (kept for API parity; fused into the kernel)
+        self.rsh_conv = o3.ElementwiseTensorProduct(self.node_irreps, f"{self.node_num_irreps}x0e")
+        # normalization
+        self.norm = nn.LayerNorm(self.node_dim) if layer_norm else nn.Identity()
+        self.o3norm = EquivariantLayerNorm(self.node_irreps) if layer_norm else nn.Identity()
+        self._mul = self.node_irreps.mul3()
+
+    def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        ori_scalar = data[keys.NODE_INVARIANT]
+        ori_equi = data[keys.NODE_EQUIVARIANT]
+        node_scalar = self.norm(ori_scalar)
+        node_equi = self.o3norm(ori_equi)
+        scalar_out = self.scalar_mlp(node_scalar)
+
+        if RADIAL_SPEC not in data:
+            raise KeyError("XPainnMessage needs the XEmbedding of xequinet_amd to run first (radial spec missing)")
+        rbf, cutoff_fn = data[RADIAL_SPEC]
+        if rbf.num_basis != self.num_basis:
+            raise ValueError(f"num_basis mismatch: embedding {rbf.num_basis} vs message {self.num_basis}")
+        p0, p1 = rbf.params()
+        cfg = (rbf.kind, cutoff_fn.kind, self.num_basis, float(cutoff_fn.cutoff), self.node_dim, self._mul)
+        new_scalar, new_equi = ops.FusedMessage.apply(
+            scalar_out, node_equi, data[keys.EDGE_VECTOR], ori_scalar, ori_equi,
+            self.rbf_lin.weight, self.rbf_lin.bias, p0, p1, edge_graph(data), cfg,
+        )
+        data[keys.NODE_INVARIANT] = new_scalar
+        data[keys.NODE_EQUIVARIANT] = new_equi
+        return data
+
+
+class XPainnUpdate(nn.Module):
+    """Update function for XPaiNN (nn/xpainn.py:164-231)."""
+
+    def __init__(
+        self,
+        node_dim: int = 128,
+        node_irreps: Iterable = "128x0e + 64x1o + 32x2e",
+        activation: str = "silu",
+        layer_norm: bool = True,
+    ) -> None:
+        super().__init__()
+        self.node_dim = node_dim
+        self.node_irreps = o3.Irreps(node_irreps)
+        self.node_num_irreps = self.node_irreps.num_irreps
+        self.hidden_dim = self.node_dim * 2 + self.node_num_irreps
+        # spherical feature
+        self.update_U = o3.Linear(self.node_irreps, self.node_irreps, biases=True)
+        self.update_V = o3.Linear(self.node_irreps, self.node_irreps, biases=True)
+        self.invariant = Invariant(self.node_irreps)
+        self.equidot = EquivariantDot(self.node_irreps)
+        self.dot_lin = nn.Linear(self.node_num_irreps, self.node_dim, bias=False)
+        self.rsh_conv = o3.ElementwiseTensorProduct(self.node_irreps, f"{self.node_num_irreps}x0e")
+        # scalar feature
+        self.update_mlp = nn.Sequential(
+            nn.Linear(self.node_dim + self.node_num_irreps, self.node_dim),
+            resolve_activation(activation),
+            nn.Linear(self.node_dim, self.hidden_dim),
+        )
+        # normalization
+        self.norm = nn.LayerNorm(self.node_dim) if layer_norm else nn.Identity()
+        self.o3norm = EquivariantLayerNorm(self.node_irreps) if layer_norm else nn.Identity()
+
+    def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        node_scalar = self.norm(data[keys.NODE_INVARIANT])
+        node_equi = self.o3norm(data[keys.NODE_EQUIVARIANT])
+
+        U_equi = self.update_U(node_equi)
+        V_equi = self.update_V(node_equi)
+
+        V_scalar = self.invariant(V_equi)
+        mlp_in = torch.cat([node_scalar, V_scalar], dim=-1)
+        mlp_out = self.update_mlp(mlp_in)
+
+        a_vv, a_sv, a_ss = torch.split(mlp_out, [self.node_num_irreps, self.node_dim, self.node_dim], dim=-1)
+        d_equi = self.rsh_conv(U_equi, a_vv)
+        inner_prod = self.equidot(U_equi, V_equi)
+        inner_prod = self.dot_lin(inner_prod)
+        d_scalar = a_sv * inner_prod + a_ss
+
+        ori_scalar = data[keys.NODE_INVARIANT]
+        ori_equi = data[keys.NODE_EQUIVARIANT]
+        data[keys.NODE_INVARIANT] = ori_scalar + d_scalar
+        data[keys.NODE_EQUIVARIANT] = ori_equi + d_equi
+        return data

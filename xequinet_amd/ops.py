@@ -1,0 +1,341 @@
+"""Autograd-aware Python front of the C ABI (include/xeq.h).
+
+Every op here launches a hand-written HIP kernel from libxeq_hip.so on the
+current HIP stream.  Backward passes are explicit HIP kernels too (first order
+only: the force evaluation ``-dE/dpos`` of nn/basic.py:143-159 in eval mode;
+``create_graph=True`` training is out of scope and raises).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import lib
+from .lib import call, dtype_code, mul3, ptr, require_hip, stream
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.contiguous()
+
+
+# --------------------------------------------------------------------------- graph
+def csr_rowptr(sorted_keys: torch.Tensor, n_rows: int) -> torch.Tensor:
+    require_hip(sorted_keys)
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=sorted_keys.device)
+    call("xeq_csr_rowptr", ptr(sorted_keys), sorted_keys.numel(), n_rows, ptr(rowptr), stream())
+    return rowptr
+
+
+class EdgeGraph:
+    """Destination-sorted views of ``edge_index`` shared by all message blocks.
+
+    ``c_*``: CSR over centers (edge_index[0], keys.py:16) -- forward aggregation.
+    ``n_*``: CSR over neighbors (edge_index[1], keys.py:17) -- reverse pass.
+    ``perm`` is None when the edge list is already sorted by that row.
+    Index plumbing (a stable sort of int64 keys) uses torch; rowptr comes from
+    ``xeq_csr_rowptr``.
+    """
+
+    def __init__(self, edge_index: torch.Tensor, n_nodes: int, center_sorted: Optional[bool] = None) -> None:
+        require_hip(edge_index)
+        assert edge_index.dim() == 2 and edge_index.shape[0] == 2 and edge_index.dtype == torch.int64
+        self.edge_index = edge_index = edge_index.contiguous()
+        self.n_nodes = int(n_nodes)
+        self.n_edges = E = int(edge_index.shape[1])
+        center, nbr = edge_index[0], edge_index[1]
+        if center_sorted is None:
+            center_sorted = bool((center[1:] >= center[:-1]).all()) if E > 1 else True
+        if center_sorted:
+            self.c_perm = None
+            self.c_rowptr = csr_rowptr(center, self.n_nodes)
+        else:
+            keys, perm = torch.sort(center, stable=True)
+            self.c_perm = perm.to(torch.int32)
+            self.c_rowptr = csr_rowptr(keys, self.n_nodes)
+        keys, perm = torch.sort(nbr, stable=True)
+        self.n_perm = perm.to(torch.int32)
+        self.n_rowptr = csr_rowptr(keys, self.n_nodes)
+
+
+def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Non-PBC neighbour list; returns (edge_index[2,E] sorted by (center, neighbor), rowptr[N+1])."""
+    require_hip(pos, ptr_)
+    pos = pos.detach().contiguous()
+    ptr_ = ptr_.to(torch.int64).contiguous()
+    N, G = pos.shape[0], ptr_.numel() - 1
+    dev = pos.device
+    deg = torch.empty(N, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    dt = dtype_code(pos)
+    call("xeq_radius_graph_count", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(deg), stream())
+    call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+    E = int(rowptr[-1].item()) if N > 0 else 0  # one host sync, as in the reference's nonzero()
+    edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+    call("xeq_radius_graph_fill", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(rowptr), E, ptr(edge_index), stream())
+    return edge_index, rowptr
+
+
+def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff):
+    """PBC neighbour search over precomputed images (see xeq_radius_graph_pbc_* in xeq.h)."""
+    require_hip(pos_wrap, ptr_, img, cells, shift)
+    pos_wrap, img, cells, shift = (t.contiguous() for t in (pos_wrap, img, cells, shift))
+    ptr_ = ptr_.to(torch.int64).contiguous()
+    N, G, n_cells = pos_wrap.shape[0], ptr_.numel() - 1, cells.shape[0]
+    dev = pos_wrap.device
+    dt = dtype_code(pos_wrap)
+    deg = torch.empty(N, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    call("xeq_radius_graph_pbc_count", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), n_cells, float(cutoff), ptr(deg), stream())
+    call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+    E = int(rowptr[-1].item()) if N > 0 else 0
+    edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+    cell_offsets = torch.empty((E, 3), dtype=pos_wrap.dtype, device=dev)
+    call("xeq_radius_graph_pbc_fill", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), ptr(cells), ptr(shift), n_cells,
+         float(cutoff), ptr(rowptr), E, ptr(edge_index), ptr(cell_offsets), stream())
+    return edge_index, cell_offsets, rowptr
+
+
+# ------------------------------------------------------------------- edge geometry
+class EdgeVectors(Function):
+    """vec = pos[c] - pos[n] - cell_offsets @ cell[batch[n]], dist = |vec| (nn/basic.py:110-131)."""
+
+    @staticmethod
+    def forward(ctx, pos, graph: EdgeGraph, cell, cell_offsets, batch):
+        require_hip(pos)
+        pos_c = pos.contiguous()
+        E = graph.n_edges
+        vec = torch.empty((E, 3), dtype=pos.dtype, device=pos.device)
+        dist = torch.empty((E,), dtype=pos.dtype, device=pos.device)
+        cell, cell_offsets, batch = _c(cell), _c(cell_offsets), _c(batch)
+        call("xeq_edge_vectors_fwd", dtype_code(pos), ptr(pos_c), ptr(graph.edge_index), E, ptr(cell), ptr(cell_offsets),
+             ptr(batch), ptr(vec), ptr(dist), stream())
+        ctx.graph = graph
+        ctx.save_for_backward(vec, dist)
+        return vec, dist
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_vec, g_dist):
+        vec, dist = ctx.saved_tensors
+        graph = ctx.graph
+        g = g_vec if g_vec is not None else torch.zeros_like(vec)
+        if g_dist is not None:
+            g = g + (g_dist / dist.clamp_min(torch.finfo(dist.dtype).tiny)).unsqueeze(-1) * vec
+        g = g.contiguous()
+        grad_pos = torch.empty((graph.n_nodes, 3), dtype=vec.dtype, device=vec.device)
+        call("xeq_edge_vectors_bwd", dtype_code(vec), ptr(g), graph.n_nodes, ptr(graph.c_rowptr), ptr(graph.c_perm),
+             ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(grad_pos), stream())
+        return grad_pos, None, None, None, None
+
+
+# ------------------------------------------------------------- e3nn-style operators
+class SphHarm(Function):
+    @staticmethod
+    def forward(ctx, vec, mul, normalize):
+        require_hip(vec)
+        vec = vec.contiguous()
+        n = vec.shape[0]
+        D = mul[0] + 3 * mul[1] + 5 * mul[2]
+        out = torch.empty((n, D), dtype=vec.dtype, device=vec.device)
+        call("xeq_sph_harm_fwd", dtype_code(vec), ptr(vec), n, mul3(mul), int(normalize), ptr(out), stream())
+        ctx.save_for_backward(vec)
+        ctx.mul, ctx.normalize = mul, normalize
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (vec,) = ctx.saved_tensors
+        g = g.contiguous()
+        gv = torch.empty_like(vec)
+        call("xeq_sph_harm_bwd", dtype_code(vec), ptr(vec), ptr(g), vec.shape[0], mul3(ctx.mul), int(ctx.normalize), ptr(gv), stream())
+        return gv, None, None
+
+
+def _etp(x, g, mul):
+    n = x.shape[0]
+    out = torch.empty_like(x)
+    call("xeq_elementwise_tp_fwd", dtype_code(x), ptr(x), ptr(g), n, g.shape[0], mul3(mul), ptr(out), stream())
+    return out
+
+
+def _cdot(a, b, mul):
+    n = a.shape[0]
+    out = torch.empty((n, sum(mul)), dtype=a.dtype, device=a.device)
+    call("xeq_channel_dot_fwd", dtype_code(a), ptr(a), ptr(b), n, mul3(mul), ptr(out), stream())
+    return out
+
+
+class ElementwiseTP(Function):
+    """out[n,u,m] = x[n,u,m] * g[n,u]; g may be a single broadcast row."""
+
+    @staticmethod
+    def forward(ctx, x, g, mul):
+        require_hip(x, g)
+        x, g = x.contiguous(), g.contiguous()
+        if g.dim() == 1:
+            g = g.unsqueeze(0)
+        ctx.save_for_backward(x, g)
+        ctx.mul = mul
+        return _etp(x, g, mul)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        x, g = ctx.saved_tensors
+        go = go.contiguous()
+        gx = _etp(go, g, ctx.mul) if ctx.needs_input_grad[0] else None
+        gg = None
+        if ctx.needs_input_grad[1]:
+            gg = _cdot(go, x, ctx.mul)
+            if g.shape[0] == 1:
+                gg = gg.sum(0, keepdim=True)
+        return gx, gg, None
+
+
+class ChannelDot(Function):
+    """out[n,u] = sum_m a[n,u,m] b[n,u,m]."""
+
+    @staticmethod
+    def forward(ctx, a, b, mul):
+        require_hip(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        ctx.mul = mul
+        return _cdot(a, b, mul)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        a, b = ctx.saved_tensors
+        go = go.contiguous()
+        ga = _etp(b, go, ctx.mul) if ctx.needs_input_grad[0] else None
+        gb = _etp(a, go, ctx.mul) if ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
+class EqLayerNorm(Function):
+    """EquivariantLayerNorm.forward (nn/o3layer.py:145-171); gradient w.r.t. x only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mul, eps):
+        require_hip(x, weight, bias)
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        out = torch.empty_like(x)
+        call("xeq_eqln_fwd", dtype_code(x), ptr(x), ptr(weight), ptr(bias), x.shape[0], mul3(mul), float(eps), ptr(out), stream())
+        ctx.save_for_backward(x, weight)
+        ctx.mul, ctx.eps = mul, eps
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError("xequinet_amd: parameter gradients (training) are out of scope; "
+                                      "call model.requires_grad_(False) / model.eval()")
+        x, weight = ctx.saved_tensors
+        go = go.contiguous()
+        gx = torch.empty_like(x)
+        call("xeq_eqln_bwd", dtype_code(x), ptr(x), ptr(weight), ptr(go), x.shape[0], mul3(ctx.mul), float(ctx.eps), ptr(gx), stream())
+        return gx, None, None, None, None
+
+
+class SegmentSum(Function):
+    """out[g] = sum_{i in [ptr[g], ptr[g+1])} src[i]  (scatter_sum over a sorted batch index)."""
+
+    @staticmethod
+    def forward(ctx, src, ptr_):
+        require_hip(src, ptr_)
+        src = src.contiguous()
+        ptr_ = ptr_.to(torch.int64).contiguous()
+        G = ptr_.numel() - 1
+        width = 1
+        for d in src.shape[1:]:
+            width *= int(d)
+        out = torch.empty((G,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        call("xeq_segment_sum", dtype_code(src), ptr(src), ptr(ptr_), G, width, ptr(out), stream())
+        ctx.save_for_backward(ptr_)
+        ctx.n = src.shape[0]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        (ptr_,) = ctx.saved_tensors
+        counts = ptr_[1:] - ptr_[:-1]
+        return torch.repeat_interleave(go, counts, dim=0, output_size=ctx.n), None
+
+
+def scatter_add(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
+    """Unsorted scatter-sum (float atomics; forward only)."""
+    require_hip(src, index)
+    src = src.contiguous()
+    width = 1
+    for d in src.shape[1:]:
+        width *= int(d)
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    call("xeq_scatter_add", dtype_code(src), ptr(src), ptr(index.to(torch.int64).contiguous()), src.shape[0], width,
+         ptr(out), dim_size, stream())
+    return out
+
+
+def radial_basis(dist, rbf_kind: str, cutoff_kind: str, num_basis: int, cutoff: float, p0, p1=None,
+                 want_rbf=True, want_fcut=True):
+    """rbf[E,B] and fcut[E] from dist[E] (forward only; the fused message op owns the gradient)."""
+    require_hip(dist)
+    d = dist.detach().reshape(-1).contiguous()
+    n = d.numel()
+    rbf = torch.empty((n, num_basis), dtype=d.dtype, device=d.device) if want_rbf else None
+    fcut = torch.empty((n,), dtype=d.dtype, device=d.device) if want_fcut else None
+    p0 = None if p0 is None else p0.detach().reshape(-1).to(d.dtype).contiguous()
+    p1 = None if p1 is None else p1.detach().reshape(-1).to(d.dtype).contiguous()
+    call("xeq_radial_fwd", dtype_code(d), ptr(d), n, lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis,
+         float(cutoff), ptr(p0), ptr(p1), ptr(rbf), ptr(fcut), stream())
+    return rbf, fcut
+
+
+# ------------------------------------------------------------------- fused message
+class FusedMessage(Function):
+    """nn/xpainn.py:140-159 in one kernel; see xeq_message_fwd / xeq_message_bwd."""
+
+    @staticmethod
+    def forward(ctx, h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg):
+        rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = cfg
+        require_hip(h, xhat, vec, s, x, w_rbf, b_rbf, p0)
+        h, xhat, vec, s, x = (t.contiguous() for t in (h, xhat, vec, s, x))
+        w_rbf, b_rbf, p0 = w_rbf.contiguous(), b_rbf.contiguous(), p0.reshape(-1).contiguous()
+        p1 = None if p1 is None else p1.reshape(-1).contiguous()
+        N, E = graph.n_nodes, graph.n_edges
+        C, D = sum(mul), mul[0] + 3 * mul[1] + 5 * mul[2]
+        assert h.shape == (N, node_dim + 2 * C) and xhat.shape == (N, D) and vec.shape == (E, 3)
+        assert s.shape == (N, node_dim) and x.shape == (N, D) and w_rbf.shape == (node_dim + 2 * C, num_basis)
+        s_out, x_out = torch.empty_like(s), torch.empty_like(x)
+        call("xeq_message_fwd", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm), ptr(graph.edge_index[1]),
+             ptr(vec), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf), ptr(b_rbf), ptr(p0), ptr(p1),
+             lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff), node_dim, mul3(mul),
+             ptr(s_out), ptr(x_out), stream())
+        ctx.save_for_backward(h, xhat, vec, w_rbf, b_rbf, p0, p1)
+        ctx.graph, ctx.cfg = graph, cfg
+        return s_out, x_out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_s, g_x):
+        if any(ctx.needs_input_grad[5:9]):
+            raise NotImplementedError("xequinet_amd: parameter gradients (training) are out of scope; "
+                                      "call model.requires_grad_(False) / model.eval()")
+        h, xhat, vec, w_rbf, b_rbf, p0, p1 = ctx.saved_tensors
+        rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = ctx.cfg
+        graph = ctx.graph
+        g_s = torch.zeros((graph.n_nodes, node_dim), dtype=h.dtype, device=h.device) if g_s is None else g_s.contiguous()
+        g_x = torch.zeros_like(xhat) if g_x is None else g_x.contiguous()
+        g_h, g_xhat = torch.empty_like(h), torch.empty_like(xhat)
+        g_vec = torch.empty_like(vec)
+        call("xeq_message_bwd", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr), ptr(graph.n_perm),
+             ptr(graph.edge_index[0]), ptr(vec), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w_rbf), ptr(b_rbf), ptr(p0),
+             ptr(p1), lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff), node_dim,
+             mul3(mul), ptr(g_h), ptr(g_xhat), ptr(g_vec), stream())
+        return g_h, g_xhat, g_vec, g_s, g_x, None, None, None, None, None, None
