@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Headline benchmark: directed edges/sec of one XPaiNN energy+force evaluation
+(neighbour list + 3 message/update blocks forward + force backward) on a 1024-molecule
+QM9-shape synthetic batch per GPU (BASELINE.json configs[1]), fp32, random-init weights.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; molecules are independent, so ranks never exchange data
+(weak scaling: every rank evaluates its own 1024-molecule batch).  Rank 0 prints
+ONE JSON line.  See DESIGN.md "Measurement" for the roofline bookkeeping.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+METRIC = "edges/sec + achieved HBM GB/s, energy+force inference, QM9-shape batch"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_workload(name: str, seed: int):
+    from oracle import xpainn_oracle as orc  # synthetic-input generators only (pure numpy)
+
+    if name == "qm9_1024":
+        pos, z, ptr = orc.synth_qm9_batch(1024, seed=seed)
+        return pos, z, ptr, None
+    if name == "qm9_64":
+        pos, z, ptr = orc.synth_qm9_batch(64, seed=seed)
+        return pos, z, ptr, None
+    if name == "md17_4096":
+        p0, z0, _ = orc.synth_aspirin()
+        rng = np.random.default_rng(11 + seed)
+        pos = (p0[None] + rng.normal(0, 0.05, size=(4096, 21, 3))).reshape(-1, 3)
+        return pos, np.tile(z0, 4096), np.arange(0, 4097 * 21, 21, dtype=np.int64)[:4097], None
+    if name == "water_512":
+        pos, z, ptr, cell = orc.synth_water_box(8, seed=5 + seed)
+        return pos, z, ptr, cell
+    raise ValueError(name)
+
+
+def cpu_baseline(pos, z, ptr, sd, budget_s=20.0, n_mol=96):
+    """The oracle (a CPU restatement of the reference's eager op graph: index_select ->
+    Linear -> elementwise -> index_add -> autograd.grad) timed on this host, fp32, on the
+    first `n_mol` molecules of the SAME batch, brute-force neighbour list included."""
+    from oracle import xpainn_oracle as orc
+
+    n_mol = min(n_mol, len(ptr) - 1)
+    a = int(ptr[n_mol])
+    p, zz, pp = pos[:a].astype(np.float32), z[:a], ptr[: n_mol + 1]
+    sd32 = {k: (v.float().cpu() if v.is_floating_point() else v.cpu()) for k, v in sd.items()}
+    oracle = orc.XPaiNNOracle(sd32)
+    threads = torch.get_num_threads()
+
+    def one():
+        ei = orc.radius_graph_canonical(p, pp, 5.0)
+        batch = np.repeat(np.arange(n_mol), np.diff(pp))
+        out = oracle({"pos": torch.tensor(p), "atomic_numbers": torch.tensor(zz.astype(np.int64)), "edge_index": torch.tensor(ei),
+                      "batch": torch.tensor(batch), "ptr": torch.tensor(pp)})
+        return ei.shape[1], out
+
+    n_edges, _ = one()  # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 10 and (time.perf_counter() < t_end or len(times) < 2):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": n_edges / med, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"first {n_mol} molecules of the batch ({a} atoms, {n_edges} edges), fp32, median of {len(times)} runs, "
+                      f"{med * 1e3:.1f} ms/eval, brute-force neighbour list included"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="qm9_1024", choices=["qm9_1024", "qm9_64", "md17_4096", "water_512"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from xequinet_amd import dist as xdist
+    from xequinet_amd import ops
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.nn import resolve_model
+
+    rank, local_rank, world = xdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+
+    torch.manual_seed(0)
+    model = resolve_model("xpainn").eval().requires_grad_(False)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dtype).to(dev)
+
+    # every rank gets its own batch of the same shape (weak scaling), resident in HBM
+    pos, z, ptr, cell = make_workload(args.workload, seed=1234 + rank)
+    pos_d = torch.tensor(pos, dtype=dtype, device=dev)
+    z_d = torch.tensor(z, device=dev)
+    ptr_d = torch.tensor(ptr, device=dev)
+    cell_d = None if cell is None else torch.tensor(cell, dtype=dtype, device=dev)
+    pbc_d = None if cell is None else torch.tensor([[True, True, True]], device=dev)
+    transform = NeighborTransform(model.cutoff_radius)
+
+    def step():
+        batch = XequiBatch(pos_d.detach(), z_d, ptr_d, pbc=pbc_d, cell=cell_d)
+        batch = transform(batch)                       # HIP radius graph
+        with torch.enable_grad():
+            out = model(batch.to_dict(), compute_forces=True, compute_virial=False)
+        return batch.edge_index.shape[1], out
+
+    for _ in range(args.warmup):
+        n_edges, out = step()
+    torch.cuda.synchronize()
+    n_atoms = pos_d.shape[0]
+
+    # ---- timed region: exactly K steps between barrier + synchronize
+    ops.KERNEL_TIMER.reset(enabled=True)
+    xdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges_done = 0
+    for _ in range(args.steps):
+        n_edges, out = step()
+        edges_done += n_edges
+    torch.cuda.synchronize()
+    xdist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ops.KERNEL_TIMER.summary()           # HIP events recorded on the launch stream
+    ops.KERNEL_TIMER.reset(enabled=False)
+
+    t_max, edges_total = xdist.reduce_timing(elapsed, edges_done, device=dev)
+    assert bool(torch.isfinite(out["energy"]).all()) and bool(torch.isfinite(out["forces"]).all())
+
+    if rank == 0:
+        ms_per_step = t_max / args.steps * 1e3
+        value = edges_total / t_max
+        # dominant kernel: fused message reverse pass.  Algorithmic bytes per launch:
+        #   B_bwd = 10 880 N + 40 E   (fp32 features, int64 indices), one launch per layer
+        esz = 4 if dtype == torch.float32 else 8
+        dom = max(kernel_ms, key=lambda k: kernel_ms[k]["total_ms"]) if kernel_ms else None
+        alg = {"xeq_message_bwd": (2720 * esz) * n_atoms + (16 + 6 * esz) * n_edges,
+               "xeq_message_fwd": (2272 * esz) * n_atoms + (16 + 3 * esz) * n_edges}
+        roofline = None
+        if dom is not None:
+            avg_ms = kernel_ms[dom]["total_ms"] / kernel_ms[dom]["launches"]
+            achieved = alg[dom] / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tfile):
+                traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                        "algorithmic_bytes_per_launch": alg[dom],
+                        "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernel_ms.items()}}
+        line = {
+            "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: QM9-shape synthetic molecules per GPU, 5 A cutoff, default XPaiNN (865141 params, random init), "
+                                   "neighbour list + energy + forces", "atoms_per_gpu": int(n_atoms), "edges_per_gpu": int(n_edges),
+                       "parallelism": f"molecule shards x{world}, no collectives"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pos, z, ptr, sd)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

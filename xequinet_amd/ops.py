@@ -17,6 +17,37 @@ from . import lib
 from .lib import call, dtype_code, mul3, ptr, require_hip, stream
 
 
+class _KernelTimer:
+    """Optional HIP-event timing of the fused message kernels (bench.py's roofline leg).
+    Events are recorded on torch's current stream, which is the stream the kernels are
+    launched on (lib.stream()).  Disabled by default: zero overhead."""
+
+    def __init__(self) -> None:
+        self.enabled = False
+        self.events = {}
+
+    def reset(self, enabled: bool) -> None:
+        self.enabled = enabled
+        self.events = {}
+
+    def launch(self, name: str, *args) -> None:
+        if not self.enabled:
+            call(name, *args)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        call(name, *args)
+        b.record()
+        self.events.setdefault(name, []).append((a, b))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: {"launches": len(v), "total_ms": sum(a.elapsed_time(b) for a, b in v)} for k, v in self.events.items()}
+
+
+KERNEL_TIMER = _KernelTimer()
+
+
 def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.contiguous()
 
@@ -313,7 +344,7 @@ class FusedMessage(Function):
         assert h.shape == (N, node_dim + 2 * C) and xhat.shape == (N, D) and vec.shape == (E, 3)
         assert s.shape == (N, node_dim) and x.shape == (N, D) and w_rbf.shape == (node_dim + 2 * C, num_basis)
         s_out, x_out = torch.empty_like(s), torch.empty_like(x)
-        call("xeq_message_fwd", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm), ptr(graph.edge_index[1]),
+        KERNEL_TIMER.launch("xeq_message_fwd", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm), ptr(graph.edge_index[1]),
              ptr(vec), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf), ptr(b_rbf), ptr(p0), ptr(p1),
              lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff), node_dim, mul3(mul),
              ptr(s_out), ptr(x_out), stream())
@@ -334,7 +365,7 @@ class FusedMessage(Function):
         g_x = torch.zeros_like(xhat) if g_x is None else g_x.contiguous()
         g_h, g_xhat = torch.empty_like(h), torch.empty_like(xhat)
         g_vec = torch.empty_like(vec)
-        call("xeq_message_bwd", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr), ptr(graph.n_perm),
+        KERNEL_TIMER.launch("xeq_message_bwd", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr), ptr(graph.n_perm),
              ptr(graph.edge_index[0]), ptr(vec), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w_rbf), ptr(b_rbf), ptr(p0),
              ptr(p1), lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff), node_dim,
              mul3(mul), ptr(g_h), ptr(g_xhat), ptr(g_vec), stream())
