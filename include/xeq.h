@@ -153,7 +153,7 @@ int xeq_message_fwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                     const int64_t* nbr, const void* vec, const void* h, const void* xhat, const void* s_in,
                     const void* x_in, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
                     int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
-                    const int32_t mul[3], void* s_out, void* x_out, void* stream);
+                    const int32_t mul[3], void* s_out, void* x_out, int xhat_layout, void* stream);
 
 /* Reverse pass of the fused message w.r.t. h, xhat and vec (what the force
  * evaluation nn/basic.py:143-159 needs; parameter gradients are out of scope).
@@ -164,7 +164,63 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                     const int64_t* center, const void* vec, const void* h, const void* xhat, const void* grad_s,
                     const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
                     int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
-                    const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, void* stream);
+                    const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, int xhat_layout,
+                    void* stream);
+
+/* LDS-window form of the fused message for graphs made of small CLOSED node segments
+ * (molecule batches; no edge leaves its segment).  Same arithmetic as xeq_message_fwd/bwd,
+ * float32 only.  Both directions walk the CSR over NEIGHBORS (n_rowptr); the caller
+ * passes the per-slot arrays in that order: vec_n[E,3] = vec[n_perm], other_n[E] =
+ * center[n_perm] (int32), eid_n[E] = n_perm (int32); seg_ptr[S+1] are the node
+ * boundaries of the closed segments, seg_eptr[S+1] = n_rowptr[seg_ptr], max_seg the
+ * largest segment.  Every node row is read from HBM exactly once per launch: the
+ * forward pass keeps the destination accumulators of a segment in LDS, the reverse pass
+ * keeps the segment's grad_s/grad_x rows there.  xeq_message_seg_max_nodes() returns the
+ * largest segment the 160 KB LDS can hold for a configuration (0: use the general form). */
+int xeq_message_seg_max_nodes(int dtype, int num_basis, int node_dim, const int32_t mul[3], int bwd);
+int xeq_message_fwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
+                        const int32_t* seg_eptr, int64_t n_seg, int64_t max_seg, const void* vec_n,
+                        const int32_t* other_n, const int32_t* eid_n, const void* h, const void* xhat, const void* s_in,
+                        const void* x_in, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
+                        int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim, const int32_t mul[3],
+                        void* s_out, void* x_out, int xhat_layout, void* stream);
+int xeq_message_bwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
+                        const int32_t* seg_eptr, int64_t n_seg, int64_t max_seg, const void* vec_n,
+                        const int32_t* other_n, const int32_t* eid_n, const void* h, const void* xhat,
+                        const void* grad_s, const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0,
+                        const void* p1, int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
+                        const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, int xhat_layout,
+                        void* stream);
+
+/* ------------------------------------------------- node-side fused elementwise stages
+ * Internal "BT" layout of equivariant intermediates (xhat_layout = 1 above): block-major over
+ * l, then node, then m, then channel: addr(n, u' in block l, m) = N*base_l + (n*(2l+1)+m)*W_l + u'
+ * (W_l = mul_l, or 2 mul_l for the U|V pair buffer).  Each block is a plain row-major
+ * [N(2l+1), W_l] matrix, so o3.Linear (nn/xpainn.py:186-187, 211-212) is three ordinary GEMMs. */
+
+/* nn.LayerNorm(s) (nn/xpainn.py:123,130) + EquivariantLayerNorm(x) (nn/o3layer.py:145-171) in one
+ * pass; shat has row stride ld_s, xhat is written in BT layout, stats[N,4] = (mean, rstd, mean0, r).
+ * do_norm = 0: identity norms (layer_norm=False), still re-laying x out. */
+int xeq_norm_fwd(int dtype, const void* s, const void* x, const void* ln_w, const void* ln_b, const void* eq_w,
+                 const void* eq_b, int64_t n, int node_dim, const int32_t mul[3], int do_norm, void* shat, int64_t ld_s,
+                 void* xhat_bt, void* stats, void* stream);
+/* g_s = res_s + LN^T g_shat ; g_x = res_x + EqLN^T g_xhat_bt  (res_* may be NULL; g_x in e3nn layout). */
+int xeq_norm_bwd(int dtype, const void* s, const void* x, const void* ln_w, const void* eq_w, const void* stats,
+                 int64_t n, int node_dim, const int32_t mul[3], int do_norm, const void* g_shat, int64_t ld_gs,
+                 const void* g_xhat_bt, const void* res_s, const void* res_x, void* g_s, void* g_x, void* stream);
+/* Invariant(V) and EquivariantDot(U,V) (nn/xpainn.py:214,222; nn/o3layer.py:39-44,104-109) from the U|V
+ * pair buffer: cat[n, node_dim + u] = sqrt(sum_m V^2 + eps^2) - eps, p[n,u] = sum_m U V; and the reverse. */
+int xeq_uv_reduce_fwd(int dtype, const void* uv_bt, int64_t n, const int32_t mul[3], double eps, void* cat,
+                      int64_t ld_cat, int node_dim, void* p, void* stream);
+int xeq_uv_reduce_bwd(int dtype, const void* uv_bt, const void* g_p, const void* g_cat, int64_t ld_cat, int node_dim,
+                      int64_t n, const int32_t mul[3], double eps, void* g_uv_bt, void* stream);
+/* Output stage of XPainnUpdate (nn/xpainn.py:218-229) with a = [a_vv C | a_sv F | a_ss F], ip = dot_lin(p):
+ * s_out = s + a_sv*ip + a_ss, x_out = x + U (x) a_vv (x, x_out in e3nn layout); and the reverse. */
+int xeq_update_out_fwd(int dtype, const void* s, const void* x, const void* uv_bt, const void* a, const void* ip,
+                       int64_t n, int node_dim, const int32_t mul[3], void* s_out, void* x_out, void* stream);
+int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, const void* uv_bt, const void* a,
+                       const void* ip, int64_t n, int node_dim, const int32_t mul[3], void* g_a, void* g_ip,
+                       void* g_uv_bt, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,10 +31,10 @@ def test_c_abi_argument_errors_are_reported_without_a_gpu():
     handle = lib.load()
     mul = lib.mul3((128, 64, 32))
     rc = handle.xeq_message_fwd(0, 10, 10, None, None, None, None, None, None, None, None, None, None, None, None,
-                                0, 0, 64, 5.0, 128, mul, None, None, None)
+                                0, 0, 64, 5.0, 128, mul, None, None, 0, None)
     assert rc == 1 and b"num_basis" in handle.xeq_last_error()
     rc = handle.xeq_message_fwd(0, 10, 10, None, None, None, None, None, None, None, None, None, None, None, None,
-                                0, 0, 20, 5.0, 300, mul, None, None, None)
+                                0, 0, 20, 5.0, 300, mul, None, None, 0, None)
     assert rc == 1 and b"256-channel" in handle.xeq_last_error()
     rc = handle.xeq_radial_fwd(0, None, 5, 7, 0, 20, 5.0, None, None, None, None, None)
     assert rc == 1 and b"not implemented" in handle.xeq_last_error()

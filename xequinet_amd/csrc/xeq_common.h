@@ -68,6 +68,32 @@ struct Irreps {
   }
 };
 
+// Addressing of an equivariant row for channel u: elem(n, m) = off + n * node + m * comp.
+//   layout 0 (e3nn mul_ir, what crosses the module boundary):  off = flat offset of u, node = D, comp = 1
+//   layout 1 (BT, internal: block-major over l, then node, m, channel; see xeq_node.hip):
+//            off = N * base_l + u', node = (2l+1) mul_l, comp = mul_l
+struct XAddr {
+  int64_t off, node;
+  int comp;
+};
+__host__ __device__ inline XAddr xaddr(const Irreps& ir, int64_t N, int u, int layout) {
+  int l, off;
+  ir.locate(u, l, off);
+  XAddr a;
+  if (layout == 0) {
+    a.off = off;
+    a.node = ir.D();
+    a.comp = 1;
+  } else {
+    const int up = u - (l == 0 ? 0 : (l == 1 ? ir.mul[0] : ir.mul[0] + ir.mul[1]));
+    const int64_t base = l == 0 ? 0 : (l == 1 ? (int64_t)ir.mul[0] : (int64_t)ir.mul[0] + 3 * ir.mul[1]);
+    a.off = N * base + up;
+    a.node = (int64_t)(2 * l + 1) * ir.mul[l];
+    a.comp = ir.mul[l];
+  }
+  return a;
+}
+
 // radial-basis / envelope selection (mirrors resolve_rbf / resolve_cutoff, nn/rbf.py:9-32)
 struct RadialSpec {
   int rbf_kind;     // XEQ_RBF_BESSEL | XEQ_RBF_GAUSSIAN

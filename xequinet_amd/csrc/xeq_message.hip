@@ -26,12 +26,27 @@ int message_fwd_mfma(int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, co
                      const void* vec, const void* h, const void* xhat, const void* s_in, const void* x_in,
                      const void* w_rbf, const void* b_rbf, const void* p0, const void* p1, int rbf_kind, int cutoff_kind,
                      int num_basis, double cutoff, int node_dim, const int32_t mul[3], void* s_out, void* x_out,
-                     void* stream);
+                     int xl, void* stream);
 int message_bwd_mfma(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
                      const int64_t* center, const void* vec, const void* h, const void* xhat, const void* grad_s,
                      const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
                      int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim, const int32_t mul[3],
-                     void* grad_h, void* grad_xhat, void* grad_vec, void* stream);
+                     void* grad_h, void* grad_xhat, void* grad_vec, int xl, void* stream);
+
+// xeq_message_seg.hip
+int seg_path_max_nodes(int dtype, int num_basis, int node_dim, const int32_t mul[3], int bwd);
+int message_fwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
+                    const int32_t* seg_eptr, int n_seg, int max_seg, const void* vec_n, const int32_t* other_n,
+                    const int32_t* eid_n, const void* h, const void* xhat, const void* s_in, const void* x_in,
+                    const void* w_rbf, const void* b_rbf, const void* p0, const void* p1, int rbf_kind, int cutoff_kind,
+                    int num_basis, double cutoff, int node_dim, const int32_t mul[3], void* s_out, void* x_out,
+                    int xl, void* stream);
+int message_bwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
+                    const int32_t* seg_eptr, int n_seg, int max_seg, const void* vec_n, const int32_t* other_n,
+                    const int32_t* eid_n, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
+                    const void* w_rbf, const void* b_rbf, const void* p0, const void* p1, int rbf_kind, int cutoff_kind,
+                    int num_basis, double cutoff, int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat,
+                    void* grad_vec, int xl, void* stream);
 
 // XEQ_MESSAGE_IMPL=valu forces the generic channel-on-lane kernels (A/B tests); default: MFMA path when supported
 static bool use_mfma(int dtype, int num_basis, int node_dim, const int32_t mul[3]) {
@@ -52,6 +67,7 @@ struct MsgArgs {
   Irreps ir;
   RadialSpec rs;
   int chunk;  // consecutive nodes kept on one XCD label
+  int xl;     // layout of xhat / grad_xhat (see XAddr)
 };
 
 template <typename T, int MAXB>
@@ -123,6 +139,7 @@ __global__ void __launch_bounds__(256) k_message_fwd(MsgArgs a, const T* __restr
   if (has_u) a.ir.locate(t, l, off);
   const int nm = has_u ? 2 * l + 1 : 0;
   const int yoff = l == 0 ? 0 : (l == 1 ? 1 : 4);
+  const XAddr xa = xaddr(a.ir, a.n_nodes, has_u ? t : 0, a.xl);
 
   T ws[MAXB], we[MAXB], wm[MAXB], bs, be, bm;
   load_w_row<T, MAXB>(w_rbf, b_rbf, t, B, has_u, ws, bs);
@@ -156,10 +173,10 @@ __global__ void __launch_bounds__(256) k_message_fwd(MsgArgs a, const T* __restr
         if (has_s) acc_s += hn[2 * C + t] * dm;
         if (has_u) {
           T gs = hn[t] * ds, ge = hn[C + t] * de;
-          const T* xn = xhat + n * D + off;
+          const T* xn = xhat + xa.off + n * xa.node;
 #pragma unroll
           for (int m = 0; m < 5; ++m)
-            if (m < nm) acc_x[m] += xn[m] * gs + sh_y[j][yoff + m] * ge;
+            if (m < nm) acc_x[m] += xn[m * xa.comp] * gs + sh_y[j][yoff + m] * ge;
         }
       }
     }
@@ -195,6 +212,7 @@ __global__ void __launch_bounds__(256) k_message_bwd(MsgArgs a, const T* __restr
   const int yoff = l == 0 ? 0 : (l == 1 ? 1 : 4);
   const bool wave_has1 = __ballot(has_u && l == 1) != 0ull;
   const bool wave_has2 = __ballot(has_u && l == 2) != 0ull;
+  const XAddr xa = xaddr(a.ir, a.n_nodes, has_u ? t : 0, a.xl);
 
   T ws[MAXB], we[MAXB], wm[MAXB], bs, be, bm;
   load_w_row<T, MAXB>(w_rbf, b_rbf, t, B, has_u, ws, bs);
@@ -214,7 +232,7 @@ __global__ void __launch_bounds__(256) k_message_bwd(MsgArgs a, const T* __restr
     const T hm = has_s ? h[n * H + 2 * C + t] : T(0);
     T xh[5];
 #pragma unroll
-    for (int m = 0; m < 5; ++m) xh[m] = (m < nm) ? xhat[n * D + off + m] : T(0);
+    for (int m = 0; m < 5; ++m) xh[m] = (m < nm) ? xhat[xa.off + n * xa.node + m * xa.comp] : T(0);
     T acc_hs = T(0), acc_he = T(0), acc_hm = T(0);
     T acc_xh[5] = {T(0), T(0), T(0), T(0), T(0)};
     for (int32_t base = e0; base < e1; base += EC) {
@@ -303,7 +321,7 @@ __global__ void __launch_bounds__(256) k_message_bwd(MsgArgs a, const T* __restr
       grad_h[n * H + C + t] = acc_he;
 #pragma unroll
       for (int m = 0; m < 5; ++m)
-        if (m < nm) grad_xhat[n * D + off + m] = acc_xh[m];
+        if (m < nm) grad_xhat[xa.off + n * xa.node + m * xa.comp] = acc_xh[m];
     }
     if (has_s) grad_h[n * H + 2 * C + t] = acc_hm;
   }
@@ -358,7 +376,7 @@ int xeq_message_fwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                     const int64_t* nbr, const void* vec, const void* h, const void* xhat, const void* s_in,
                     const void* x_in, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
                     int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
-                    const int32_t mul[3], void* s_out, void* x_out, void* stream) {
+                    const int32_t mul[3], void* s_out, void* x_out, int xhat_layout, void* stream) {
   MsgArgs a{};
   int rcode = check_msg("xeq_message_fwd", n_nodes, n_edges, num_basis, cutoff, rbf_kind, cutoff_kind, node_dim,
                         mul, p1, a);
@@ -366,13 +384,14 @@ int xeq_message_fwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
   if (n_nodes == 0) return XEQ_OK;
   if (use_mfma(dtype, num_basis, node_dim, mul)) {
     message_fwd_mfma(n_nodes, n_edges, rowptr, perm, nbr, vec, h, xhat, s_in, x_in, w_rbf, b_rbf, p0, p1, rbf_kind,
-                     cutoff_kind, num_basis, cutoff, node_dim, mul, s_out, x_out, stream);
+                     cutoff_kind, num_basis, cutoff, node_dim, mul, s_out, x_out, xhat_layout, stream);
     XEQ_CHECK_LAUNCH("xeq_message_fwd (mfma)");
     return XEQ_OK;
   }
   a.rowptr = rowptr;
   a.perm = perm;
   a.other = nbr;
+  a.xl = xhat_layout;
   dim3 grid(msg_grid(n_nodes));
   XEQ_DISPATCH_FLOAT(dtype, {
     XEQ_MSG_DISPATCH_B(k_message_fwd, a, (const T*)vec, (const T*)h, (const T*)xhat, (const T*)s_in,
@@ -387,7 +406,7 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                     const int64_t* center, const void* vec, const void* h, const void* xhat, const void* grad_s,
                     const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
                     int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
-                    const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, void* stream) {
+                    const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, int xhat_layout, void* stream) {
   MsgArgs a{};
   int rcode = check_msg("xeq_message_bwd", n_nodes, n_edges, num_basis, cutoff, rbf_kind, cutoff_kind, node_dim,
                         mul, p1, a);
@@ -395,13 +414,14 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
   if (n_nodes == 0) return XEQ_OK;
   if (use_mfma(dtype, num_basis, node_dim, mul)) {
     message_bwd_mfma(n_nodes, n_edges, n_rowptr, n_perm, center, vec, h, xhat, grad_s, grad_x, w_rbf, b_rbf, p0, p1,
-                     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul, grad_h, grad_xhat, grad_vec, stream);
+                     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul, grad_h, grad_xhat, grad_vec, xhat_layout, stream);
     XEQ_CHECK_LAUNCH("xeq_message_bwd (mfma)");
     return XEQ_OK;
   }
   a.rowptr = n_rowptr;
   a.perm = n_perm;
   a.other = center;
+  a.xl = xhat_layout;
   dim3 grid(msg_grid(n_nodes));
   XEQ_DISPATCH_FLOAT(dtype, {
     XEQ_MSG_DISPATCH_B(k_message_bwd, a, (const T*)vec, (const T*)h, (const T*)xhat, (const T*)grad_s,
@@ -409,6 +429,52 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                        (T*)grad_h, (T*)grad_xhat, (T*)grad_vec);
   });
   XEQ_CHECK_LAUNCH("xeq_message_bwd");
+  return XEQ_OK;
+}
+
+
+int xeq_message_seg_max_nodes(int dtype, int num_basis, int node_dim, const int32_t mul[3], int bwd) {
+  return seg_path_max_nodes(dtype, num_basis, node_dim, mul, bwd);
+}
+
+int xeq_message_fwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
+                        const int32_t* seg_eptr, int64_t n_seg, int64_t max_seg, const void* vec_n,
+                        const int32_t* other_n, const int32_t* eid_n, const void* h, const void* xhat, const void* s_in,
+                        const void* x_in, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
+                        int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim, const int32_t mul[3],
+                        void* s_out, void* x_out, int xhat_layout, void* stream) {
+  MsgArgs a{};
+  int rcode = check_msg("xeq_message_fwd_seg", n_nodes, n_edges, num_basis, cutoff, rbf_kind, cutoff_kind, node_dim, mul,
+                        p1, a);
+  if (rcode != XEQ_OK) return rcode;
+  XEQ_CHECK_ARG(n_seg >= 0 && max_seg >= 0 && max_seg <= seg_path_max_nodes(XEQ_F32, num_basis, node_dim, mul, 0),
+                "xeq_message_fwd_seg: segment of %lld nodes exceeds the LDS window", (long long)max_seg);
+  if (n_nodes == 0 || n_seg == 0) return XEQ_OK;
+  message_fwd_seg(n_nodes, n_edges, n_rowptr, seg_ptr, seg_eptr, (int)n_seg, (int)max_seg, vec_n, other_n, eid_n, h, xhat,
+                  s_in, x_in, w_rbf, b_rbf, p0, p1, rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul, s_out, x_out,
+                  xhat_layout, stream);
+  XEQ_CHECK_LAUNCH("xeq_message_fwd_seg");
+  return XEQ_OK;
+}
+
+int xeq_message_bwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
+                        const int32_t* seg_eptr, int64_t n_seg, int64_t max_seg, const void* vec_n,
+                        const int32_t* other_n, const int32_t* eid_n, const void* h, const void* xhat,
+                        const void* grad_s, const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0,
+                        const void* p1, int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
+                        const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, int xhat_layout,
+                        void* stream) {
+  MsgArgs a{};
+  int rcode = check_msg("xeq_message_bwd_seg", n_nodes, n_edges, num_basis, cutoff, rbf_kind, cutoff_kind, node_dim, mul,
+                        p1, a);
+  if (rcode != XEQ_OK) return rcode;
+  XEQ_CHECK_ARG(n_seg >= 0 && max_seg >= 0 && max_seg <= seg_path_max_nodes(XEQ_F32, num_basis, node_dim, mul, 1),
+                "xeq_message_bwd_seg: segment of %lld nodes exceeds the LDS window", (long long)max_seg);
+  if (n_nodes == 0 || n_seg == 0) return XEQ_OK;
+  message_bwd_seg(n_nodes, n_edges, n_rowptr, seg_ptr, seg_eptr, (int)n_seg, (int)max_seg, vec_n, other_n, eid_n, h, xhat,
+                  grad_s, grad_x, w_rbf, b_rbf, p0, p1, rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul, grad_h,
+                  grad_xhat, grad_vec, xhat_layout, stream);
+  XEQ_CHECK_LAUNCH("xeq_message_bwd_seg");
   return XEQ_OK;
 }
 

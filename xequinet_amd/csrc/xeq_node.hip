@@ -1,0 +1,364 @@
+// Node-side fused elementwise kernels around the dense contractions of
+// XPainnMessage / XPainnUpdate (nn/xpainn.py:128-139, 206-231).
+//
+// Internal "BT" layout of equivariant intermediates (xhat, U|V and their gradients):
+// block-major over l, then node, then m, then channel:
+//   addr(n, u' in block l, m) = N * base_l + (n * d_l + m) * W_l + u',  d_l = 2l+1,
+// with W_l = mul_l (xhat) or 2 mul_l (the U|V pair buffer, U in columns [0,mul), V in
+// [mul, 2 mul)).  Every block is a plain row-major [N d_l, W_l] matrix, so o3.Linear is
+// three ordinary GEMMs without transposes, and channel-on-lane accesses are coalesced.
+// Tensors that cross the module boundary (s, x and their gradients) keep the
+// reference's e3nn mul_ir layout.
+#include "xeq_common.h"
+
+namespace xeq {
+
+struct BT {
+  Irreps ir;
+  int64_t N;
+  // element offset of (n, u, m); `pair` = 1 for the U|V buffer (row width 2 mul), col0 = 0 (U) or mul (V)
+  __device__ __forceinline__ int64_t at(int64_t n, int u, int m, int pair, int vcol) const {
+    int l, up;
+    if (u < ir.mul[0]) { l = 0; up = u; }
+    else if (u < ir.mul[0] + ir.mul[1]) { l = 1; up = u - ir.mul[0]; }
+    else { l = 2; up = u - ir.mul[0] - ir.mul[1]; }
+    const int w = (pair + 1) * ir.mul[l];
+    const int64_t base = (l == 0 ? 0 : (l == 1 ? (int64_t)ir.mul[0] : (int64_t)ir.mul[0] + 3 * ir.mul[1])) * (pair + 1);
+    return N * base + (n * (2 * l + 1) + m) * w + (vcol ? ir.mul[l] : 0) + up;
+  }
+};
+
+__device__ __forceinline__ void chan_of_flat(const Irreps& ir, int f, int& u, int& m) {
+  if (f < ir.mul[0]) { u = f; m = 0; }
+  else if (f < ir.mul[0] + 3 * ir.mul[1]) { int r = f - ir.mul[0]; u = ir.mul[0] + r / 3; m = r % 3; }
+  else { int r = f - ir.mul[0] - 3 * ir.mul[1]; u = ir.mul[0] + ir.mul[1] + r / 5; m = r % 5; }
+}
+
+// ---- LayerNorm(s) + EquivariantLayerNorm(x): one wave per node ------------------------------
+// shat row stride ld_s (so it can land in the [shat | v] buffer of the update MLP); xhat in BT.
+// stats[n] = (ln_mean, ln_rstd, eq_mean0, eq_r).  do_norm = 0: identity (layer_norm=False).
+template <typename T>
+__global__ void k_norm_fwd(const T* __restrict__ s, const T* __restrict__ x, const T* __restrict__ lnw,
+                           const T* __restrict__ lnb, const T* __restrict__ eqw, const T* __restrict__ eqb, int64_t N,
+                           int F, Irreps ir, int do_norm, T* __restrict__ shat, int64_t ld_s, T* __restrict__ xhat_bt,
+                           T* __restrict__ stats) {
+  const int D = ir.D(), C = ir.C(), m0 = ir.mul[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (n >= N) return;
+  BT bt{ir, N};
+  const T* sr = s + n * F;
+  const T* xr = x + n * D;
+  if (!do_norm) {
+    for (int f = lane; f < F; f += 64) shat[n * ld_s + f] = sr[f];
+    for (int f = lane; f < D; f += 64) {
+      int u, m;
+      chan_of_flat(ir, f, u, m);
+      xhat_bt[bt.at(n, u, m, 0, 0)] = xr[f];
+    }
+    return;
+  }
+  // LayerNorm over the F scalars (nn.LayerNorm, eps 1e-5, biased variance)
+  T a = T(0);
+  for (int f = lane; f < F; f += 64) a += sr[f];
+  const T mean = wave_sum<T>(a) / T(F);
+  T v = T(0);
+  for (int f = lane; f < F; f += 64) { T d = sr[f] - mean; v += d * d; }
+  const T rstd = T(1) / sqrt_<T>(wave_sum<T>(v) / T(F) + T(1e-5));
+  for (int f = lane; f < F; f += 64) shat[n * ld_s + f] = (sr[f] - mean) * rstd * lnw[f] + lnb[f];
+  // EquivariantLayerNorm (nn/o3layer.py:145-171)
+  T q = T(0);
+  for (int f = lane; f < m0; f += 64) q += xr[f];
+  const T mean0 = m0 > 0 ? wave_sum<T>(q) / T(m0) : T(0);
+  T sq = T(0);
+  for (int f = lane; f < D; f += 64) { T d = xr[f] - (f < m0 ? mean0 : T(0)); sq += d * d; }
+  const T r = T(1) / sqrt_<T>(wave_sum<T>(sq) / T(C) + T(1e-5));
+  for (int f = lane; f < D; f += 64) {
+    int u, m;
+    chan_of_flat(ir, f, u, m);
+    T val = (xr[f] - (f < m0 ? mean0 : T(0))) * r * eqw[u];
+    if (f < m0) val += eqb[f];
+    xhat_bt[bt.at(n, u, m, 0, 0)] = val;
+  }
+  if (lane == 0) {
+    stats[4 * n] = mean;
+    stats[4 * n + 1] = rstd;
+    stats[4 * n + 2] = mean0;
+    stats[4 * n + 3] = r;
+  }
+}
+
+// g_s = res_s + LN^T(g_shat), g_x = res_x + EqLN^T(g_xhat_bt)   (res_* may be NULL)
+template <typename T>
+__global__ void k_norm_bwd(const T* __restrict__ s, const T* __restrict__ x, const T* __restrict__ lnw,
+                           const T* __restrict__ eqw, const T* __restrict__ stats, int64_t N, int F, Irreps ir,
+                           int do_norm, const T* __restrict__ g_shat, int64_t ld_gs, const T* __restrict__ g_xhat_bt,
+                           const T* __restrict__ res_s, const T* __restrict__ res_x, T* __restrict__ g_s,
+                           T* __restrict__ g_x) {
+  const int D = ir.D(), C = ir.C(), m0 = ir.mul[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (n >= N) return;
+  BT bt{ir, N};
+  if (!do_norm) {
+    for (int f = lane; f < F; f += 64) g_s[n * F + f] = g_shat[n * ld_gs + f] + (res_s ? res_s[n * F + f] : T(0));
+    for (int f = lane; f < D; f += 64) {
+      int u, m;
+      chan_of_flat(ir, f, u, m);
+      g_x[n * D + f] = g_xhat_bt[bt.at(n, u, m, 0, 0)] + (res_x ? res_x[n * D + f] : T(0));
+    }
+    return;
+  }
+  const T mean = stats[4 * n], rstd = stats[4 * n + 1], mean0 = stats[4 * n + 2], r = stats[4 * n + 3];
+  // LayerNorm backward: yhat = (s-mean) rstd, dy = g w: g_s = rstd (dy - mean(dy) - yhat mean(dy yhat))
+  T a1 = T(0), a2 = T(0);
+  for (int f = lane; f < F; f += 64) {
+    T yh = (s[n * F + f] - mean) * rstd, dy = g_shat[n * ld_gs + f] * lnw[f];
+    a1 += dy;
+    a2 += dy * yh;
+  }
+  a1 = wave_sum<T>(a1) / T(F);
+  a2 = wave_sum<T>(a2) / T(F);
+  for (int f = lane; f < F; f += 64) {
+    T yh = (s[n * F + f] - mean) * rstd, dy = g_shat[n * ld_gs + f] * lnw[f];
+    g_s[n * F + f] = rstd * (dy - a1 - yh * a2) + (res_s ? res_s[n * F + f] : T(0));
+  }
+  // EquivariantLayerNorm backward
+  const T* xr = x + n * D;
+  T dotp = T(0);
+  for (int f = lane; f < D; f += 64) {
+    int u, m;
+    chan_of_flat(ir, f, u, m);
+    T xc = xr[f] - (f < m0 ? mean0 : T(0));
+    dotp += g_xhat_bt[bt.at(n, u, m, 0, 0)] * eqw[u] * xc;
+  }
+  const T coef = wave_sum<T>(dotp) * r * r * r / T(C);
+  T gs = T(0);
+  for (int f = lane; f < m0; f += 64) gs += r * g_xhat_bt[bt.at(n, f, 0, 0, 0)] * eqw[f] - coef * (xr[f] - mean0);
+  const T gmean = m0 > 0 ? wave_sum<T>(gs) / T(m0) : T(0);
+  for (int f = lane; f < D; f += 64) {
+    int u, m;
+    chan_of_flat(ir, f, u, m);
+    T xc = xr[f] - (f < m0 ? mean0 : T(0));
+    T val = r * g_xhat_bt[bt.at(n, u, m, 0, 0)] * eqw[u] - coef * xc;
+    if (f < m0) val -= gmean;
+    g_x[n * D + f] = val + (res_x ? res_x[n * D + f] : T(0));
+  }
+}
+
+// ---- v = |V|, p = <U,V> per channel (Invariant nn/o3layer.py:39-44, EquivariantDot :104-109) ----
+// one thread per (node, channel); writes v into cat[n, F + u] (row stride ld_cat) and p[n, u]
+template <typename T>
+__global__ void k_uv_reduce_fwd(const T* __restrict__ uv_bt, int64_t N, Irreps ir, T eps, T* __restrict__ cat,
+                                int64_t ld_cat, int F, T* __restrict__ p) {
+  const int C = ir.C();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * C) return;
+  const int64_t n = t / C;
+  const int u = (int)(t - n * C);
+  BT bt{ir, N};
+  int l, off;
+  ir.locate(u, l, off);
+  T vv = T(0), uv = T(0);
+  for (int m = 0; m < 2 * l + 1; ++m) {
+    T U = uv_bt[bt.at(n, u, m, 1, 0)], V = uv_bt[bt.at(n, u, m, 1, 1)];
+    vv += V * V;
+    uv += U * V;
+  }
+  cat[n * ld_cat + F + u] = sqrt_<T>(vv + eps * eps) - eps;
+  p[t] = uv;
+}
+
+// g_U += g_p V ;  g_V = g_p U + g_v V / (v + eps)      (g_uv_bt U-part holds dL/dU from the output stage)
+template <typename T>
+__global__ void k_uv_reduce_bwd(const T* __restrict__ uv_bt, const T* __restrict__ g_p, const T* __restrict__ g_cat,
+                                int64_t ld_cat, int F, int64_t N, Irreps ir, T eps, T* __restrict__ g_uv_bt) {
+  const int C = ir.C();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * C) return;
+  const int64_t n = t / C;
+  const int u = (int)(t - n * C);
+  BT bt{ir, N};
+  int l, off;
+  ir.locate(u, l, off);
+  T vv = T(0);
+  for (int m = 0; m < 2 * l + 1; ++m) { T V = uv_bt[bt.at(n, u, m, 1, 1)]; vv += V * V; }
+  const T gp = g_p[t];
+  const T gv = g_cat[n * ld_cat + F + u] / sqrt_<T>(vv + eps * eps);
+  for (int m = 0; m < 2 * l + 1; ++m) {
+    const int64_t iu = bt.at(n, u, m, 1, 0), iv = bt.at(n, u, m, 1, 1);
+    T U = uv_bt[iu], V = uv_bt[iv];
+    g_uv_bt[iu] += gp * V;
+    g_uv_bt[iv] = gp * U + gv * V;
+  }
+}
+
+// ---- update output stage (nn/xpainn.py:218-229): a = [a_vv C | a_sv F | a_ss F] --------------
+//   s_out = s + a_sv * ip + a_ss ;  x_out[n,u,m] = x + U[n,u,m] * a_vv[u]      (x in e3nn layout)
+template <typename T>
+__global__ void k_update_out_fwd(const T* __restrict__ s, const T* __restrict__ x, const T* __restrict__ uv_bt,
+                                 const T* __restrict__ a, const T* __restrict__ ip, int64_t N, int F, Irreps ir,
+                                 T* __restrict__ s_out, T* __restrict__ x_out) {
+  const int D = ir.D(), C = ir.C(), W = F + D, A = C + 2 * F;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * W) return;
+  const int64_t n = t / W;
+  const int f = (int)(t - n * W);
+  if (f < F) {
+    s_out[n * F + f] = s[n * F + f] + a[n * A + C + f] * ip[n * F + f] + a[n * A + C + F + f];
+  } else {
+    const int fx = f - F;
+    int u, m;
+    chan_of_flat(ir, fx, u, m);
+    BT bt{ir, N};
+    x_out[n * D + fx] = x[n * D + fx] + uv_bt[bt.at(n, u, m, 1, 0)] * a[n * A + u];
+  }
+}
+
+// g_a = [sum_m U g_x | g_s ip | g_s], g_ip = g_s a_sv, g_U = g_x a_vv (written into the U columns of g_uv_bt)
+template <typename T>
+__global__ void k_update_out_bwd(const T* __restrict__ g_s_out, const T* __restrict__ g_x_out,
+                                 const T* __restrict__ uv_bt, const T* __restrict__ a, const T* __restrict__ ip,
+                                 int64_t N, int F, Irreps ir, T* __restrict__ g_a, T* __restrict__ g_ip,
+                                 T* __restrict__ g_uv_bt) {
+  const int D = ir.D(), C = ir.C(), A = C + 2 * F, W = C + F;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * W) return;
+  const int64_t n = t / W;
+  const int f = (int)(t - n * W);
+  if (f < C) {  // gate channel u = f
+    BT bt{ir, N};
+    int l, off;
+    ir.locate(f, l, off);
+    const T avv = a[n * A + f];
+    T acc = T(0);
+    for (int m = 0; m < 2 * l + 1; ++m) {
+      const T gx = g_x_out[n * D + off + m];
+      const int64_t iu = bt.at(n, f, m, 1, 0);
+      acc += uv_bt[iu] * gx;
+      g_uv_bt[iu] = gx * avv;
+    }
+    g_a[n * A + f] = acc;
+  } else {  // scalar channel
+    const int c = f - C;
+    const T gs = g_s_out[n * F + c];
+    g_a[n * A + C + c] = gs * ip[n * F + c];
+    g_a[n * A + C + F + c] = gs;
+    g_ip[n * F + c] = gs * a[n * A + C + c];
+  }
+}
+
+static inline int irreps_from(const int32_t mul[3], Irreps& ir, const char* who) {
+  for (int l = 0; l < 3; ++l) {
+    if (mul[l] < 0) {
+      set_error("%s: negative multiplicity", who);
+      return XEQ_ERR_INVALID_ARGUMENT;
+    }
+    ir.mul[l] = mul[l];
+  }
+  if (ir.C() == 0) {
+    set_error("%s: empty irreps", who);
+    return XEQ_ERR_INVALID_ARGUMENT;
+  }
+  return XEQ_OK;
+}
+
+}  // namespace xeq
+
+using namespace xeq;
+
+#define XEQ_IR(who)                        \
+  Irreps ir;                               \
+  {                                        \
+    int rc_ = irreps_from(mul, ir, who);   \
+    if (rc_ != XEQ_OK) return rc_;         \
+  }
+
+extern "C" {
+
+int xeq_norm_fwd(int dtype, const void* s, const void* x, const void* ln_w, const void* ln_b, const void* eq_w,
+                 const void* eq_b, int64_t n, int node_dim, const int32_t mul[3], int do_norm, void* shat, int64_t ld_s,
+                 void* xhat_bt, void* stats, void* stream) {
+  XEQ_IR("xeq_norm_fwd");
+  XEQ_CHECK_ARG(node_dim > 0 && ld_s >= node_dim, "xeq_norm_fwd: bad node_dim / row stride");
+  if (n <= 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_norm_fwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+                       (const T*)x, (const T*)ln_w, (const T*)ln_b, (const T*)eq_w, (const T*)eq_b, n, node_dim, ir,
+                       do_norm, (T*)shat, ld_s, (T*)xhat_bt, (T*)stats);
+  });
+  XEQ_CHECK_LAUNCH("xeq_norm_fwd");
+  return XEQ_OK;
+}
+
+int xeq_norm_bwd(int dtype, const void* s, const void* x, const void* ln_w, const void* eq_w, const void* stats,
+                 int64_t n, int node_dim, const int32_t mul[3], int do_norm, const void* g_shat, int64_t ld_gs,
+                 const void* g_xhat_bt, const void* res_s, const void* res_x, void* g_s, void* g_x, void* stream) {
+  XEQ_IR("xeq_norm_bwd");
+  XEQ_CHECK_ARG(node_dim > 0 && ld_gs >= node_dim, "xeq_norm_bwd: bad node_dim / row stride");
+  if (n <= 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_norm_bwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+                       (const T*)x, (const T*)ln_w, (const T*)eq_w, (const T*)stats, n, node_dim, ir, do_norm,
+                       (const T*)g_shat, ld_gs, (const T*)g_xhat_bt, (const T*)res_s, (const T*)res_x, (T*)g_s, (T*)g_x);
+  });
+  XEQ_CHECK_LAUNCH("xeq_norm_bwd");
+  return XEQ_OK;
+}
+
+int xeq_uv_reduce_fwd(int dtype, const void* uv_bt, int64_t n, const int32_t mul[3], double eps, void* cat,
+                      int64_t ld_cat, int node_dim, void* p, void* stream) {
+  XEQ_IR("xeq_uv_reduce_fwd");
+  if (n <= 0) return XEQ_OK;
+  const int64_t total = n * ir.C();
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_uv_reduce_fwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)uv_bt, n, ir, (T)eps, (T*)cat, ld_cat, node_dim, (T*)p);
+  });
+  XEQ_CHECK_LAUNCH("xeq_uv_reduce_fwd");
+  return XEQ_OK;
+}
+
+int xeq_uv_reduce_bwd(int dtype, const void* uv_bt, const void* g_p, const void* g_cat, int64_t ld_cat, int node_dim,
+                      int64_t n, const int32_t mul[3], double eps, void* g_uv_bt, void* stream) {
+  XEQ_IR("xeq_uv_reduce_bwd");
+  if (n <= 0) return XEQ_OK;
+  const int64_t total = n * ir.C();
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_uv_reduce_bwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps, (T*)g_uv_bt);
+  });
+  XEQ_CHECK_LAUNCH("xeq_uv_reduce_bwd");
+  return XEQ_OK;
+}
+
+int xeq_update_out_fwd(int dtype, const void* s, const void* x, const void* uv_bt, const void* a, const void* ip,
+                       int64_t n, int node_dim, const int32_t mul[3], void* s_out, void* x_out, void* stream) {
+  XEQ_IR("xeq_update_out_fwd");
+  if (n <= 0) return XEQ_OK;
+  const int64_t total = n * (node_dim + ir.D());
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_update_out_fwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)s, (const T*)x, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir, (T*)s_out,
+                       (T*)x_out);
+  });
+  XEQ_CHECK_LAUNCH("xeq_update_out_fwd");
+  return XEQ_OK;
+}
+
+int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, const void* uv_bt, const void* a,
+                       const void* ip, int64_t n, int node_dim, const int32_t mul[3], void* g_a, void* g_ip,
+                       void* g_uv_bt, void* stream) {
+  XEQ_IR("xeq_update_out_bwd");
+  if (n <= 0) return XEQ_OK;
+  const int64_t total = n * (node_dim + ir.C());
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_update_out_bwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)g_s_out, (const T*)g_x_out, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir,
+                       (T*)g_a, (T*)g_ip, (T*)g_uv_bt);
+  });
+  XEQ_CHECK_LAUNCH("xeq_update_out_bwd");
+  return XEQ_OK;
+}
+
+}  // extern "C"

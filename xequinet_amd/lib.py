@@ -42,9 +42,20 @@ _PROTOS = {
     "xeq_segment_sum": [c_int, _P, _P, c_int64, c_int64, _P, _P],
     "xeq_scatter_add": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, _P],
     "xeq_message_fwd": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                        c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, _P],
+                        c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, c_int, _P],
     "xeq_message_bwd": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                        c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, _P, _P],
+                        c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, _P, c_int, _P],
+    "xeq_message_seg_max_nodes": [c_int, c_int, c_int, _I3, c_int],
+    "xeq_message_fwd_seg": [c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                            c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, c_int, _P],
+    "xeq_message_bwd_seg": [c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                            c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, _P, c_int, _P],
+    "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
+    "xeq_norm_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
+    "xeq_uv_reduce_fwd": [c_int, _P, c_int64, _I3, c_double, _P, c_int64, c_int, _P, _P],
+    "xeq_uv_reduce_bwd": [c_int, _P, _P, _P, c_int64, c_int, c_int64, _I3, c_double, _P, _P],
+    "xeq_update_out_fwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P],
+    "xeq_update_out_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P, _P],
 }
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 

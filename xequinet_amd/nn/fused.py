@@ -1,0 +1,193 @@
+"""Block-level fused paths of XPainnMessage / XPainnUpdate.
+
+One ``torch.autograd.Function`` per block: every elementwise stage is a hand-written HIP
+kernel (``xeq_node.hip``), the dense contractions are plain library GEMMs on contiguous
+views of the internal BT layout, and the reverse pass is explicit (no autograd graph of
+small ops).  Semantics are those of nn/xpainn.py:128-161 and :206-231 of the reference;
+gradients are provided w.r.t. the node features and the edge vectors only (force
+evaluation, nn/basic.py:143-159) -- parameter gradients raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F_
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import lib, ops
+from ..lib import call, dtype_code, mul3, ptr, stream
+
+_NO_PARAM_GRAD = ("xequinet_amd: parameter gradients (training) are out of scope; "
+                  "call model.requires_grad_(False) / model.eval()")
+
+
+def _bt_blocks(buf: torch.Tensor, n: int, mul, width: int):
+    """Views of the BT buffer as plain row-major matrices [n (2l+1), width * mul_l] per non-empty block."""
+    out = []
+    base = 0
+    for l, m in enumerate(mul):
+        d = 2 * l + 1
+        if m > 0:
+            out.append((l, m, buf[n * base * width : n * (base + d * m) * width].view(n * d, width * m)))
+        base += d * m
+    return out
+
+
+def _norm_fwd(s, x, norm, o3norm, node_dim, mul, shat_out=None, ld=None):
+    n, D = x.shape
+    do_norm = int(not isinstance(norm, torch.nn.Identity))
+    if shat_out is None:
+        shat_out = torch.empty((n, node_dim), dtype=s.dtype, device=s.device)
+        ld = node_dim
+    xhat = torch.empty(n * D, dtype=x.dtype, device=x.device)
+    stats = torch.empty((n, 4), dtype=s.dtype, device=s.device)
+    lw, lb, ew, eb = (norm.weight, norm.bias, o3norm.affine_weight, o3norm.affine_bias) if do_norm else (None,) * 4
+    call("xeq_norm_fwd", dtype_code(s), ptr(s), ptr(x), ptr(lw), ptr(lb), ptr(ew), ptr(eb), n, node_dim, mul3(mul), do_norm,
+         ptr(shat_out), ld, ptr(xhat), ptr(stats), stream())
+    return shat_out, xhat, stats, do_norm
+
+
+def _norm_bwd(s, x, norm, o3norm, stats, do_norm, node_dim, mul, g_shat, ld, g_xhat, res_s, res_x):
+    n, D = x.shape
+    g_s, g_x = torch.empty_like(s), torch.empty_like(x)
+    lw, ew = (norm.weight, o3norm.affine_weight) if do_norm else (None, None)
+    call("xeq_norm_bwd", dtype_code(s), ptr(s), ptr(x), ptr(lw), ptr(ew), ptr(stats), n, node_dim, mul3(mul), do_norm,
+         ptr(g_shat), ld, ptr(g_xhat), ptr(res_s), ptr(res_x), ptr(g_s), ptr(g_x), stream())
+    return g_s, g_x
+
+
+def _silu_bwd(g, pre, act):
+    if isinstance(act, torch.nn.SiLU):
+        return torch.ops.aten.silu_backward(g, pre)
+    with torch.enable_grad():  # other activations of resolve_activation: let autograd differentiate the scalar map
+        p = pre.detach().requires_grad_()
+        (out,) = torch.autograd.grad(act(p), p, g)
+    return out
+
+
+class MessageBlock(Function):
+    """XPainnMessage.forward (nn/xpainn.py:128-161): norms -> scalar_mlp -> fused message kernel."""
+
+    @staticmethod
+    def forward(ctx, s, x, vec, module, graph, rbf, cutoff_fn):
+        lib.require_hip(s, x, vec)
+        s, x, vec = s.contiguous(), x.contiguous(), vec.contiguous()
+        F, mul = module.node_dim, module._mul
+        if any(p.requires_grad for p in module.parameters()) and torch.is_grad_enabled():
+            raise NotImplementedError(_NO_PARAM_GRAD)
+        shat, xhat, stats, do_norm = _norm_fwd(s, x, module.norm, module.o3norm, F, mul)
+        lin1, act, lin2 = module.scalar_mlp[0], module.scalar_mlp[1], module.scalar_mlp[2]
+        pre = torch.addmm(lin1.bias, shat, lin1.weight.t())
+        h = torch.addmm(lin2.bias, act(pre), lin2.weight.t())
+        p0, p1 = rbf.params()
+        cfg = (rbf.kind, cutoff_fn.kind, module.num_basis, float(cutoff_fn.cutoff), F, mul, 1)  # xhat in BT layout
+        s_out, x_out, saved, use_seg = ops.message_forward(h, xhat, vec, s, x, module.rbf_lin.weight, module.rbf_lin.bias,
+                                                           p0, p1, graph, cfg)
+        ctx.has_p1 = saved[6] is not None
+        ctx.save_for_backward(*[t for t in saved if t is not None], s, x, stats, pre)
+        ctx.module, ctx.do_norm, ctx.graph, ctx.cfg, ctx.use_seg = module, do_norm, graph, cfg, use_seg
+        return s_out, x_out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_s_out, g_x_out):
+        module = ctx.module
+        F, mul = module.node_dim, module._mul
+        t = ctx.saved_tensors
+        nmsg = 7 if ctx.has_p1 else 6
+        msg_saved = tuple(t[:nmsg]) + (() if ctx.has_p1 else (None,))
+        s, x, stats, pre = t[nmsg:]
+        g_h, g_xhat, g_vec, g_s_res, g_x_res = ops.message_backward(msg_saved, ctx.graph, ctx.cfg, ctx.use_seg, g_s_out, g_x_out)
+        lin1, act, lin2 = module.scalar_mlp[0], module.scalar_mlp[1], module.scalar_mlp[2]
+        g_pre = _silu_bwd(torch.mm(g_h, lin2.weight), pre, act)
+        g_shat = torch.mm(g_pre, lin1.weight)
+        g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_shat, F, g_xhat, g_s_res, g_x_res)
+        return g_s, g_x, g_vec, None, None, None, None
+
+
+def _packed_uv(module) -> Tuple[list, torch.Tensor]:
+    """[W_U | W_V] / sqrt(mul) per l ([mul, 2 mul]) and the 0e bias pair, cached on the module."""
+    wu, wv = module.update_U.weight, module.update_V.weight
+    key = (wu._version, wv._version, wu.data_ptr(), wv.data_ptr(), module.update_U.bias._version, module.update_V.bias._version, wu.dtype)
+    cache = getattr(module, "_uv_pack", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    with torch.no_grad():
+        packs, off = [], 0
+        for mul, l, _, _ in module.node_irreps.blocks():
+            Wu = wu[off : off + mul * mul].view(mul, mul)
+            Wv = wv[off : off + mul * mul].view(mul, mul)
+            packs.append((torch.cat([Wu, Wv], dim=1) / math.sqrt(mul)).contiguous())
+            off += mul * mul
+        bias = torch.cat([module.update_U.bias, module.update_V.bias]) if module.update_U.bias.numel() else None
+    module._uv_pack = (key, packs, bias)
+    return packs, bias
+
+
+class UpdateBlock(Function):
+    """XPainnUpdate.forward (nn/xpainn.py:206-231)."""
+
+    @staticmethod
+    def forward(ctx, s, x, module):
+        lib.require_hip(s, x)
+        s, x = s.contiguous(), x.contiguous()
+        if any(p.requires_grad for p in module.parameters()) and torch.is_grad_enabled():
+            raise NotImplementedError(_NO_PARAM_GRAD)
+        n, D = x.shape
+        F, mul = module.node_dim, module.node_irreps.mul3()
+        C = sum(mul)
+        dt, dev = s.dtype, s.device
+        cat = torch.empty((n, F + C), dtype=dt, device=dev)                  # [shat | v]  (nn/xpainn.py:215)
+        _, xhat, stats, do_norm = _norm_fwd(s, x, module.norm, module.o3norm, F, mul, shat_out=cat, ld=F + C)
+        packs, bias = _packed_uv(module)
+        uv = torch.empty(2 * n * D, dtype=dt, device=dev)                    # U|V pair buffer, BT layout
+        for (l, m, xb), (_, _, ub), W in zip(_bt_blocks(xhat, n, mul, 1), _bt_blocks(uv, n, mul, 2), packs):
+            if l == 0 and bias is not None:
+                torch.addmm(bias, xb, W, out=ub)
+            else:
+                torch.mm(xb, W, out=ub)
+        p = torch.empty((n, C), dtype=dt, device=dev)
+        eps = module.invariant.eps
+        call("xeq_uv_reduce_fwd", dtype_code(s), ptr(uv), n, mul3(mul), float(eps), ptr(cat), F + C, F, ptr(p), stream())
+        lin3, act, lin4 = module.update_mlp[0], module.update_mlp[1], module.update_mlp[2]
+        pre = torch.addmm(lin3.bias, cat, lin3.weight.t())
+        a = torch.addmm(lin4.bias, act(pre), lin4.weight.t())                # [a_vv C | a_sv F | a_ss F]
+        ip = torch.mm(p, module.dot_lin.weight.t())
+        s_out, x_out = torch.empty_like(s), torch.empty_like(x)
+        call("xeq_update_out_fwd", dtype_code(s), ptr(s), ptr(x), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(s_out),
+             ptr(x_out), stream())
+        ctx.save_for_backward(s, x, stats, uv, pre, a, ip)
+        ctx.module, ctx.do_norm = module, do_norm
+        return s_out, x_out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_s_out, g_x_out):
+        module = ctx.module
+        s, x, stats, uv, pre, a, ip = ctx.saved_tensors
+        n, D = x.shape
+        F, mul = module.node_dim, module.node_irreps.mul3()
+        C = sum(mul)
+        dt, dev = s.dtype, s.device
+        g_s_out = torch.zeros_like(s) if g_s_out is None else g_s_out.contiguous()
+        g_x_out = torch.zeros_like(x) if g_x_out is None else g_x_out.contiguous()
+        g_a = torch.empty_like(a)
+        g_ip = torch.empty_like(ip)
+        g_uv = torch.empty_like(uv)
+        call("xeq_update_out_bwd", dtype_code(s), ptr(g_s_out), ptr(g_x_out), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(g_a),
+             ptr(g_ip), ptr(g_uv), stream())
+        g_p = torch.mm(g_ip, module.dot_lin.weight)
+        lin3, act, lin4 = module.update_mlp[0], module.update_mlp[1], module.update_mlp[2]
+        g_pre = _silu_bwd(torch.mm(g_a, lin4.weight), pre, act)
+        g_cat = torch.mm(g_pre, lin3.weight)                                  # [g_shat | g_v]
+        call("xeq_uv_reduce_bwd", dtype_code(s), ptr(uv), ptr(g_p), ptr(g_cat), F + C, F, n, mul3(mul), float(module.invariant.eps),
+             ptr(g_uv), stream())
+        packs, _ = _packed_uv(module)
+        g_xhat = torch.empty(n * D, dtype=dt, device=dev)
+        for (l, m, gb), (_, _, gub), W in zip(_bt_blocks(g_xhat, n, mul, 1), _bt_blocks(g_uv, n, mul, 2), packs):
+            torch.mm(gub, W.t(), out=gb)
+        g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_cat, F + C, g_xhat, g_s_out, g_x_out)
+        return g_s, g_x, None

@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import keys, o3, ops
 from .basic import Int2c1eEmbedding, edge_graph, resolve_activation
+from .fused import MessageBlock, UpdateBlock
 from .o3layer import EquivariantDot, EquivariantLayerNorm, Invariant
 from .rbf import resolve_cutoff, resolve_rbf
 
@@ -108,25 +109,28 @@ class XPainnMessage(nn.Module):
         self.norm = nn.LayerNorm(self.node_dim) if layer_norm else nn.Identity()
         self.o3norm = EquivariantLayerNorm(self.node_irreps) if layer_norm else nn.Identity()
         self._mul = self.node_irreps.mul3()
+        self.fused = True  # False: run the reference's op sequence on the operator-level drop-ins
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         ori_scalar = data[keys.NODE_INVARIANT]
         ori_equi = data[keys.NODE_EQUIVARIANT]
-        node_scalar = self.norm(ori_scalar)
-        node_equi = self.o3norm(ori_equi)
-        scalar_out = self.scalar_mlp(node_scalar)
-
         if RADIAL_SPEC not in data:
             raise KeyError("XPainnMessage needs the XEmbedding of xequinet_amd to run first (radial spec missing)")
         rbf, cutoff_fn = data[RADIAL_SPEC]
         if rbf.num_basis != self.num_basis:
             raise ValueError(f"num_basis mismatch: embedding {rbf.num_basis} vs message {self.num_basis}")
-        p0, p1 = rbf.params()
-        cfg = (rbf.kind, cutoff_fn.kind, self.num_basis, float(cutoff_fn.cutoff), self.node_dim, self._mul)
-        new_scalar, new_equi = ops.FusedMessage.apply(
-            scalar_out, node_equi, data[keys.EDGE_VECTOR], ori_scalar, ori_equi,
-            self.rbf_lin.weight, self.rbf_lin.bias, p0, p1, edge_graph(data), cfg,
-        )
+        if self.fused:  # block-level path: explicit forward/reverse, see nn/fused.py
+            new_scalar, new_equi = MessageBlock.apply(ori_scalar, ori_equi, data[keys.EDGE_VECTOR], self, edge_graph(data), rbf, cutoff_fn)
+        else:           # operator-level path (the reference's own op sequence on the drop-in ops)
+            node_scalar = self.norm(ori_scalar)
+            node_equi = self.o3norm(ori_equi)
+            scalar_out = self.scalar_mlp(node_scalar)
+            p0, p1 = rbf.params()
+            cfg = (rbf.kind, cutoff_fn.kind, self.num_basis, float(cutoff_fn.cutoff), self.node_dim, self._mul)
+            new_scalar, new_equi = ops.FusedMessage.apply(
+                scalar_out, node_equi, data[keys.EDGE_VECTOR], ori_scalar, ori_equi,
+                self.rbf_lin.weight, self.rbf_lin.bias, p0, p1, edge_graph(data), cfg,
+            )
         data[keys.NODE_INVARIANT] = new_scalar
         data[keys.NODE_EQUIVARIANT] = new_equi
         return data
@@ -163,8 +167,14 @@ class XPainnUpdate(nn.Module):
         # normalization
         self.norm = nn.LayerNorm(self.node_dim) if layer_norm else nn.Identity()
         self.o3norm = EquivariantLayerNorm(self.node_irreps) if layer_norm else nn.Identity()
+        self.fused = True  # False: run the reference's op sequence on the operator-level drop-ins
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if self.fused:
+            s_new, x_new = UpdateBlock.apply(data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT], self)
+            data[keys.NODE_INVARIANT] = s_new
+            data[keys.NODE_EQUIVARIANT] = x_new
+            return data
         node_scalar = self.norm(data[keys.NODE_INVARIANT])
         node_equi = self.o3norm(data[keys.NODE_EQUIVARIANT])
 
