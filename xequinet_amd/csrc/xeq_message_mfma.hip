@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(256) k_message_fwd_mfma(Msg2Args a, const floa
   extern __shared__ __attribute__((aligned(16))) float dyn[];
   __shared__ Smem<KS, false> sm;
   float* sh_phi = dyn;                 // [TE][HP]
+  float* sh_bias = dyn + TE * a.HP;    // [NT*16]
   const int t = threadIdx.x;
   const int C = a.C, F = a.F, D = a.D, H = a.H, HP = a.HP;
   const bool has_u = t < C, has_s = t < F;
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(256) k_message_fwd_mfma(Msg2Args a, const floa
 
   float wa[TPW][KS];
   load_a_frags<KS>(a, w_rbf, wa);
+  for (int c = t; c < a.NT * 16; c += 256) sh_bias[c] = c < a.H ? b_rbf[c] : 0.f;
   // radial constants of this thread's basis index (phase 0): k = t % (4 KS)
   const int kq = t % (4 * KS);
   const float p0k = kq < a.rs.num_basis ? p0[kq] : 0.f;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(256) k_message_fwd_mfma(Msg2Args a, const floa
     __syncthreads();  // previous tile fully consumed
     phase0<KS, false>(a, vec, p0, p1, base, cnt, n0, n1, sm, wk, p0k, p1k);
     __syncthreads();
-    if (!(a.ablate & 2)) phase1<KS, false>(a, wa, b_rbf, sm, sh_phi, nullptr);
+    if (!(a.ablate & 2)) phase1<KS, false>(a, wa, sh_bias, sm, sh_phi, nullptr);
     __syncthreads();
     if (a.ablate & 4) continue;
     // ---- phase 2: batches of GB edges; every gather of a batch is issued before its first use
@@ -134,6 +136,7 @@ __global__ void __launch_bounds__(256) k_message_bwd_mfma(Msg2Args a, const floa
   __shared__ Smem<KS, true> sm;
   float* sh_phi = dyn;                   // [TE][HP]
   float* sh_dphi = dyn + TE * a.HP;      // [TE][HP]
+  float* sh_bias = dyn + 2 * TE * a.HP;  // [NT*16]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int C = a.C, F = a.F, D = a.D, H = a.H, HP = a.HP;
   const bool has_u = t < C, has_s = t < F;
@@ -147,6 +150,7 @@ __global__ void __launch_bounds__(256) k_message_bwd_mfma(Msg2Args a, const floa
 
   float wa[TPW][KS];
   load_a_frags<KS>(a, w_rbf, wa);
+  for (int c = t; c < a.NT * 16; c += 256) sh_bias[c] = c < a.H ? b_rbf[c] : 0.f;
   // radial constants of this thread's basis index (phase 0): k = t % (4 KS)
   const int kq = t % (4 * KS);
   const float p0k = kq < a.rs.num_basis ? p0[kq] : 0.f;
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(256) k_message_bwd_mfma(Msg2Args a, const floa
     __syncthreads();
     phase0<KS, true>(a, vec, p0, p1, base, cnt, n0, n1, sm, wk, p0k, p1k);
     __syncthreads();
-    if (!(a.ablate & 2)) phase1<KS, true>(a, wa, b_rbf, sm, sh_phi, sh_dphi);
+    if (!(a.ablate & 2)) phase1<KS, true>(a, wa, sh_bias, sm, sh_phi, sh_dphi);
     __syncthreads();
     if (a.ablate & 4) continue;
     // ---- phase 2
@@ -318,7 +322,7 @@ template <int KS>
 static void launch_fwd(const Msg2Args& a, unsigned grid, hipStream_t st, const float* vec, const float* h, const float* xhat,
                        const float* s_in, const float* x_in, const float* w, const float* b, const float* p0,
                        const float* p1, float* s_out, float* x_out) {
-  size_t dyn = sizeof(float) * (size_t)(TE * a.HP);
+  size_t dyn = sizeof(float) * (size_t)(TE * a.HP + a.NT * 16);
   hipLaunchKernelGGL((k_message_fwd_mfma<KS>), dim3(grid), dim3(256), dyn, st, a, vec, h, xhat, s_in, x_in, w, b, p0, p1,
                      s_out, x_out);
 }
@@ -327,7 +331,7 @@ template <int KS>
 static void launch_bwd(const Msg2Args& a, unsigned grid, hipStream_t st, const float* vec, const float* h, const float* xhat,
                        const float* gs, const float* gx, const float* w, const float* b, const float* p0, const float* p1,
                        float* gh, float* gxh, float* gv) {
-  size_t dyn = sizeof(float) * (size_t)(2 * TE * a.HP);
+  size_t dyn = sizeof(float) * (size_t)(2 * TE * a.HP + a.NT * 16);
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_message_bwd_mfma<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);

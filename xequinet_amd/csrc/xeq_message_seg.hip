@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(256) k_message_fwd_seg(SegArgs a, const float*
   float* sh_phi = dyn;                          // [TE][HP]
   float* sh_acc = dyn + TE * HP;                // [WN][AW]
   int32_t* sh_rowptr = reinterpret_cast<int32_t*>(sh_acc + a.WN * AW);  // [WN + 1]
+  float* sh_bias = reinterpret_cast<float*>(sh_rowptr + ((a.WN + 1 + 3) & ~3));  // [NT*16], 16-B aligned
   const int t = threadIdx.x;
   const bool has_u = t < C, has_s = t < F;
   int l = 0, off = 0;
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(256) k_message_fwd_seg(SegArgs a, const float*
 
   float wa[TPW][KS];
   load_a_frags<KS>(ma, w_rbf, wa);
+  for (int c = t; c < ma.NT * 16; c += 256) sh_bias[c] = c < ma.H ? b_rbf[c] : 0.f;
   const int kq = t % (4 * KS);
   const float p0k = kq < ma.rs.num_basis ? p0[kq] : 0.f;
   const float p1k = (p1 && kq < ma.rs.num_basis) ? p1[kq] : 0.f;
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(256) k_message_fwd_seg(SegArgs a, const float*
       phase0_regs<KS, false>(a, pf, base, cnt, sh_rowptr, nw, na, sm, wk, p0k, p1k);
       if (base + TE < e_end) prefetch_tile<KS>(a, base + TE, min(TE, e_end - base - TE), pf);
       __syncthreads();
-      phase1<KS, false>(ma, wa, b_rbf, sm, sh_phi, nullptr);
+      phase1<KS, false>(ma, wa, sh_bias, sm, sh_phi, nullptr);
       __syncthreads();
       // ---- phase 2: scatter this tile's messages into the LDS accumulators
       for (int j = 0; j < cnt; ++j) {
@@ -262,6 +264,7 @@ __global__ void __launch_bounds__(256) k_message_bwd_seg(SegArgs a, const float*
   float* sh_dphi = dyn + TE * HP;               // [TE][HP]
   float* sh_g = dyn + 2 * TE * HP;              // [WN][AW]  grad_s | grad_x rows of the segment
   int32_t* sh_rowptr = reinterpret_cast<int32_t*>(sh_g + a.WN * AW);
+  float* sh_bias = reinterpret_cast<float*>(sh_rowptr + ((a.WN + 1 + 3) & ~3));
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool has_u = t < C, has_s = t < F;
   int l = 0, off = 0;
@@ -274,6 +277,7 @@ __global__ void __launch_bounds__(256) k_message_bwd_seg(SegArgs a, const float*
 
   float wa[TPW][KS];
   load_a_frags<KS>(ma, w_rbf, wa);
+  for (int c = t; c < ma.NT * 16; c += 256) sh_bias[c] = c < ma.H ? b_rbf[c] : 0.f;
   const int kq = t % (4 * KS);
   const float p0k = kq < ma.rs.num_basis ? p0[kq] : 0.f;
   const float p1k = (p1 && kq < ma.rs.num_basis) ? p1[kq] : 0.f;
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(256) k_message_bwd_seg(SegArgs a, const float*
       phase0_regs<KS, true>(a, pf, base, cnt, sh_rowptr, nw, na, sm, wk, p0k, p1k);
       if (base + TE < e_end) prefetch_tile<KS>(a, base + TE, min(TE, e_end - base - TE), pf);
       __syncthreads();
-      phase1<KS, true>(ma, wa, b_rbf, sm, sh_phi, sh_dphi);
+      phase1<KS, true>(ma, wa, sh_bias, sm, sh_phi, sh_dphi);
       __syncthreads();
       for (int j = 0; j < cnt; ++j) {
         const int32_t src = sm.self[j];
@@ -433,7 +437,9 @@ static constexpr size_t LDS_BYTES = 160 * 1024;
 
 static size_t seg_lds_bytes(const Msg2Args& m, int WN, bool bwd) {
   const size_t AW = (size_t)m.F + m.D;
-  return sizeof(float) * ((bwd ? 2 : 1) * (size_t)TE * m.HP + (size_t)WN * AW) + sizeof(int32_t) * (size_t)(WN + 1);
+  // [phi (, dphi)] [window rows] [rowptr copy, 16-B padded] [bias]
+  const size_t wn_pad = ((size_t)WN + 1 + 3) / 4 * 4;
+  return sizeof(float) * ((bwd ? 2 : 1) * (size_t)TE * m.HP + (size_t)WN * AW + (size_t)m.NT * 16) + sizeof(int32_t) * wn_pad;
 }
 
 void fill_msg2_args(Msg2Args& a, int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* perm,
@@ -448,7 +454,9 @@ int seg_path_max_nodes(int dtype, int num_basis, int node_dim, const int32_t mul
   const size_t stat = bwd ? 8192 : 4096;  // static Smem + slack
   const size_t tiles = sizeof(float) * (bwd ? 2 : 1) * (size_t)TE * m.HP;
   if (LDS_BYTES < stat + tiles + 64) return 0;
-  return (int)((LDS_BYTES - stat - tiles - 64) / (sizeof(float) * ((size_t)m.F + m.D)));
+  const size_t bias = sizeof(float) * (size_t)m.NT * 16;
+  if (LDS_BYTES < stat + tiles + bias + 256) return 0;
+  return (int)((LDS_BYTES - stat - tiles - bias - 256) / (sizeof(float) * ((size_t)m.F + m.D) + 4));
 }
 
 template <int KS>

@@ -61,14 +61,20 @@ __device__ __forceinline__ int32_t node_of_slot(const int32_t* __restrict__ rowp
 
 template <int KS, bool BWD>
 struct Smem {
-  float rho[TE][4 * KS + 1];
-  float drho[BWD ? TE : 1][4 * KS + 1];
+  // rho/drho are dead once phase 1 has loaded its B fragments; the reverse pass reuses their
+  // storage for the per-edge reduction slots of phase 2 (keeps the block under 80 KB of LDS)
+  union {
+    struct {
+      float rho[TE][4 * KS + 1];
+      float drho[BWD ? TE : 1][4 * KS + 1];
+    };
+    float red[BWD ? TE : 1][4][9];
+  };
   float y[TE][12];     // [1 | Y1(3) | Y2(5) | f | f' | pad]
   float g[TE][5];      // unit vector, |r|, 1/|r|
   int32_t self[TE];
   int32_t other[TE];
   int32_t eid[TE];
-  float red[BWD ? TE : 1][4][9];
   int32_t range[2];
 };
 
@@ -177,7 +183,7 @@ __device__ __forceinline__ void phase0(const Msg2Args& a, const float* __restric
 
 // phase 1: filter tile on the matrix cores -> LDS phi[e][c] (and dphi in the reverse pass)
 template <int KS, bool BWD>
-__device__ __forceinline__ void phase1(const Msg2Args& a, const float (&wa)[TPW][KS], const float* __restrict__ b_rbf,
+__device__ __forceinline__ void phase1(const Msg2Args& a, const float (&wa)[TPW][KS], const float* __restrict__ sh_bias,
                                        Smem<KS, BWD>& sm, float* __restrict__ sh_phi, float* __restrict__ sh_dphi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int el = lane & 15, g = lane >> 4;
@@ -194,9 +200,7 @@ __device__ __forceinline__ void phase1(const Msg2Args& a, const float (&wa)[TPW]
     const int tile = wave + 4 * tt;
     if (tile < a.NT) {
       const int c0 = tile * 16 + 4 * g;
-      f32x4 b4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) b4[r] = (c0 + r < a.H) ? b_rbf[c0 + r] : 0.f;  // L1-resident, 9 x 16 B per wave and tile
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sh_bias + c0);  // zero-padded to NT*16 in LDS
       f32x4 acc = b4 * fe;
 #pragma unroll
       for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tt][s], rb[s], acc, 0, 0, 0);

@@ -89,11 +89,14 @@ class EdgeGraph:
         keys, perm = torch.sort(nbr, stable=True)
         self.n_perm = perm.to(torch.int32)
         self.n_rowptr = csr_rowptr(keys, self.n_nodes)
-        self._build_segments(center, nbr, perm)
+        self.n_seg = None  # closed segments are built on demand (LDS-window kernels only)
 
-    def _build_segments(self, center: torch.Tensor, nbr: torch.Tensor, perm: torch.Tensor) -> None:
+    def build_segments(self) -> None:
         """Closed node segments: maximal cuts of the node range that no edge crosses (the
         molecules of a batch).  Index plumbing for the LDS-window message kernels."""
+        if self.n_seg is not None:
+            return
+        center, nbr, perm = self.edge_index[0], self.edge_index[1], self.n_perm.long()
         N, dev = self.n_nodes, center.device
         self.other_n = center.index_select(0, perm).to(torch.int32)  # destination of each neighbor-CSR slot
         if N == 0:
@@ -362,7 +365,10 @@ def _use_seg_path(h, graph: EdgeGraph, num_basis: int, node_dim: int, mul) -> bo
 
     # measured slower than the general MFMA kernels so far (one workgroup per CU leaves the LDS
     # read-modify-write chains unhidden): opt-in with XEQ_MESSAGE_IMPL=seg until it wins
-    if h.dtype != torch.float32 or os.environ.get("XEQ_MESSAGE_IMPL", "") != "seg" or graph.n_seg == 0:
+    if h.dtype != torch.float32 or os.environ.get("XEQ_MESSAGE_IMPL", "") != "seg":
+        return False
+    graph.build_segments()
+    if graph.n_seg == 0:
         return False
     key = (num_basis, node_dim, tuple(mul))
     if key not in _SEG_LIMIT:
