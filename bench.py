@@ -154,10 +154,11 @@ def main():
         #   B_bwd = 10 880 N + 40 E   (fp32 features, int64 indices), one launch per layer
         esz = 4 if dtype == torch.float32 else 8
         dom = max(kernel_ms, key=lambda k: kernel_ms[k]["total_ms"]) if kernel_ms else None
-        alg = {"xeq_message_bwd": (2720 * esz) * n_atoms + (16 + 6 * esz) * n_edges,
-               "xeq_message_fwd": (2272 * esz) * n_atoms + (16 + 3 * esz) * n_edges}
+        alg_fwd = (2272 * esz) * n_atoms + (16 + 3 * esz) * n_edges   # B_fwd
+        alg_bwd = (2720 * esz) * n_atoms + (16 + 6 * esz) * n_edges   # B_bwd
         roofline = None
         if dom is not None:
+            alg = {dom: alg_bwd if "bwd" in dom else alg_fwd}
             avg_ms = kernel_ms[dom]["total_ms"] / kernel_ms[dom]["launches"]
             achieved = alg[dom] / (avg_ms * 1e-3) / 1e9
             traffic = None

@@ -167,30 +167,25 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                     const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, int xhat_layout,
                     void* stream);
 
-/* LDS-window form of the fused message for graphs made of small CLOSED node segments
- * (molecule batches; no edge leaves its segment).  Same arithmetic as xeq_message_fwd/bwd,
- * float32 only.  Both directions walk the CSR over NEIGHBORS (n_rowptr); the caller
- * passes the per-slot arrays in that order: vec_n[E,3] = vec[n_perm], other_n[E] =
- * center[n_perm] (int32), eid_n[E] = n_perm (int32); seg_ptr[S+1] are the node
- * boundaries of the closed segments, seg_eptr[S+1] = n_rowptr[seg_ptr], max_seg the
- * largest segment.  Every node row is read from HBM exactly once per launch: the
- * forward pass keeps the destination accumulators of a segment in LDS, the reverse pass
- * keeps the segment's grad_s/grad_x rows there.  xeq_message_seg_max_nodes() returns the
- * largest segment the 160 KB LDS can hold for a configuration (0: use the general form). */
-int xeq_message_seg_max_nodes(int dtype, int num_basis, int node_dim, const int32_t mul[3], int bwd);
-int xeq_message_fwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
-                        const int32_t* seg_eptr, int64_t n_seg, int64_t max_seg, const void* vec_n,
-                        const int32_t* other_n, const int32_t* eid_n, const void* h, const void* xhat, const void* s_in,
-                        const void* x_in, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
-                        int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim, const int32_t mul[3],
-                        void* s_out, void* x_out, int xhat_layout, void* stream);
-int xeq_message_bwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
-                        const int32_t* seg_eptr, int64_t n_seg, int64_t max_seg, const void* vec_n,
-                        const int32_t* other_n, const int32_t* eid_n, const void* h, const void* xhat,
-                        const void* grad_s, const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0,
-                        const void* p1, int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
-                        const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, int xhat_layout,
-                        void* stream);
+/* "Scalar broadcast" form of the fused message (default path, f32 and f64).  The per-edge quantities
+ * every channel shares -- f*rho_k(d), f, Y_lm, and their d/dd companions -- are evaluated once per
+ * model evaluation into 4*(roundup(B,4)+12)-byte records (xeq_edge_basis), shared by all message
+ * blocks and both directions; the message kernels fetch them with scalar loads (the edge index is
+ * workgroup-uniform) and need no LDS and no barriers in the forward pass.
+ * basis[E, W] / dbasis[E, W], W = xeq_edge_basis_width(B); dbasis may be NULL when only the forward
+ * pass is needed.  Same semantics as xeq_message_fwd / xeq_message_bwd otherwise. */
+int xeq_edge_basis_width(int num_basis);
+int xeq_edge_basis(int dtype, const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis,
+                   double cutoff, const void* p0, const void* p1, void* basis, void* dbasis, void* stream);
+int xeq_message_fwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* perm,
+                       const int64_t* nbr, const void* basis, const void* h, const void* xhat, const void* s_in,
+                       const void* x_in, const void* w_rbf, const void* b_rbf, int num_basis, int node_dim,
+                       const int32_t mul[3], void* s_out, void* x_out, int xhat_layout, void* stream);
+int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                       const int64_t* center, const void* basis, const void* dbasis, const void* h, const void* xhat,
+                       const void* grad_s, const void* grad_x, const void* w_rbf, const void* b_rbf, int num_basis,
+                       int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec,
+                       int xhat_layout, void* stream);
 
 /* ------------------------------------------------- node-side fused elementwise stages
  * Internal "BT" layout of equivariant intermediates (xhat_layout = 1 above): block-major over

@@ -33,7 +33,7 @@ def run(impl):
     so, xo = ops.FusedMessage.apply(hh, xx, vv, s, x, W, bias, p0, None, g, cfg)
     ((so * gs).sum() + (xo * gx).sum()).backward()
     return so.detach(), xo.detach(), hh.grad, xx.grad, vv.grad
-ref = run("valu"); got = run("seg")
+ref = run("valu"); got = run("sb")
 for n, a, r in zip(["s_out", "x_out", "g_h", "g_xhat", "g_vec"], got, ref):
     print(f"{n:8s} max|diff| {float((a - r).abs().max()):.3e}  scale {float(r.abs().max()):.3e}")
 def timeit(impl, reps=20):
@@ -43,8 +43,7 @@ def timeit(impl, reps=20):
         run(impl)
     r = ops.KERNEL_TIMER.summary(); ops.KERNEL_TIMER.reset(False)
     return {k: v["total_ms"] / v["launches"] * 1e3 for k, v in r.items()}
-run("mfma"); run("valu"); run("seg")
-print('n_seg', g.n_seg, 'max_seg', g.max_seg)
+run("mfma"); run("valu"); run("sb")
 print(f"N={N} E={E}")
-for impl in ("valu", "mfma", "seg", "mfma", "seg"):
+for impl in ("sb", "sb"):
     print(impl, {k: f"{v:.1f} us" for k, v in timeit(impl).items()})

@@ -431,9 +431,9 @@ def test_model_pbc_water_energy_forces(dtype):
                  extra={"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)})
 
 
-@pytest.mark.parametrize("impl", ["valu", "mfma", "seg"])
+@pytest.mark.parametrize("impl", ["valu", "mfma", "sb"])
 def test_model_message_kernel_families_agree(impl, monkeypatch):
-    """The three fused-message kernel families (generic VALU, MFMA gather, LDS-window) and the
+    """The three fused-message kernel families (generic VALU, MFMA tile, scalar-broadcast) and the
     operator-level module path all reproduce the oracle on a molecule batch (fp32)."""
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", impl)
     model, oracle = _build(torch.float32)

@@ -33,22 +33,7 @@ int message_bwd_mfma(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, 
                      int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim, const int32_t mul[3],
                      void* grad_h, void* grad_xhat, void* grad_vec, int xl, void* stream);
 
-// xeq_message_seg.hip
-int seg_path_max_nodes(int dtype, int num_basis, int node_dim, const int32_t mul[3], int bwd);
-int message_fwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
-                    const int32_t* seg_eptr, int n_seg, int max_seg, const void* vec_n, const int32_t* other_n,
-                    const int32_t* eid_n, const void* h, const void* xhat, const void* s_in, const void* x_in,
-                    const void* w_rbf, const void* b_rbf, const void* p0, const void* p1, int rbf_kind, int cutoff_kind,
-                    int num_basis, double cutoff, int node_dim, const int32_t mul[3], void* s_out, void* x_out,
-                    int xl, void* stream);
-int message_bwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
-                    const int32_t* seg_eptr, int n_seg, int max_seg, const void* vec_n, const int32_t* other_n,
-                    const int32_t* eid_n, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
-                    const void* w_rbf, const void* b_rbf, const void* p0, const void* p1, int rbf_kind, int cutoff_kind,
-                    int num_basis, double cutoff, int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat,
-                    void* grad_vec, int xl, void* stream);
-
-// XEQ_MESSAGE_IMPL=valu forces the generic channel-on-lane kernels (A/B tests); default: MFMA path when supported
+// XEQ_MESSAGE_IMPL=valu forces the generic channel-on-lane kernels of this file; default: MFMA kernels when supported
 static bool use_mfma(int dtype, int num_basis, int node_dim, const int32_t mul[3]) {
   const char* env = getenv("XEQ_MESSAGE_IMPL");
   if (env && strcmp(env, "valu") == 0) return false;
@@ -432,50 +417,5 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
   return XEQ_OK;
 }
 
-
-int xeq_message_seg_max_nodes(int dtype, int num_basis, int node_dim, const int32_t mul[3], int bwd) {
-  return seg_path_max_nodes(dtype, num_basis, node_dim, mul, bwd);
-}
-
-int xeq_message_fwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
-                        const int32_t* seg_eptr, int64_t n_seg, int64_t max_seg, const void* vec_n,
-                        const int32_t* other_n, const int32_t* eid_n, const void* h, const void* xhat, const void* s_in,
-                        const void* x_in, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
-                        int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim, const int32_t mul[3],
-                        void* s_out, void* x_out, int xhat_layout, void* stream) {
-  MsgArgs a{};
-  int rcode = check_msg("xeq_message_fwd_seg", n_nodes, n_edges, num_basis, cutoff, rbf_kind, cutoff_kind, node_dim, mul,
-                        p1, a);
-  if (rcode != XEQ_OK) return rcode;
-  XEQ_CHECK_ARG(n_seg >= 0 && max_seg >= 0 && max_seg <= seg_path_max_nodes(XEQ_F32, num_basis, node_dim, mul, 0),
-                "xeq_message_fwd_seg: segment of %lld nodes exceeds the LDS window", (long long)max_seg);
-  if (n_nodes == 0 || n_seg == 0) return XEQ_OK;
-  message_fwd_seg(n_nodes, n_edges, n_rowptr, seg_ptr, seg_eptr, (int)n_seg, (int)max_seg, vec_n, other_n, eid_n, h, xhat,
-                  s_in, x_in, w_rbf, b_rbf, p0, p1, rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul, s_out, x_out,
-                  xhat_layout, stream);
-  XEQ_CHECK_LAUNCH("xeq_message_fwd_seg");
-  return XEQ_OK;
-}
-
-int xeq_message_bwd_seg(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* seg_ptr,
-                        const int32_t* seg_eptr, int64_t n_seg, int64_t max_seg, const void* vec_n,
-                        const int32_t* other_n, const int32_t* eid_n, const void* h, const void* xhat,
-                        const void* grad_s, const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0,
-                        const void* p1, int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim,
-                        const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, int xhat_layout,
-                        void* stream) {
-  MsgArgs a{};
-  int rcode = check_msg("xeq_message_bwd_seg", n_nodes, n_edges, num_basis, cutoff, rbf_kind, cutoff_kind, node_dim, mul,
-                        p1, a);
-  if (rcode != XEQ_OK) return rcode;
-  XEQ_CHECK_ARG(n_seg >= 0 && max_seg >= 0 && max_seg <= seg_path_max_nodes(XEQ_F32, num_basis, node_dim, mul, 1),
-                "xeq_message_bwd_seg: segment of %lld nodes exceeds the LDS window", (long long)max_seg);
-  if (n_nodes == 0 || n_seg == 0) return XEQ_OK;
-  message_bwd_seg(n_nodes, n_edges, n_rowptr, seg_ptr, seg_eptr, (int)n_seg, (int)max_seg, vec_n, other_n, eid_n, h, xhat,
-                  grad_s, grad_x, w_rbf, b_rbf, p0, p1, rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul, grad_h,
-                  grad_xhat, grad_vec, xhat_layout, stream);
-  XEQ_CHECK_LAUNCH("xeq_message_bwd_seg");
-  return XEQ_OK;
-}
 
 }  // extern "C"

@@ -1,0 +1,502 @@
+// Fused XPaiNN message kernels, "scalar broadcast" form (default path, fp32 and fp64).
+// Reference dataflow: nn/xpainn.py:140-159; reverse pass for nn/basic.py:143-159.
+//
+// Measured on MI355X: the row gathers of this op run at 11-18 TB/s out of L2 when a thread
+// keeps several independent loads in flight, so the op is bound by instruction issue and by
+// dependent-latency chains, not by memory.  This form therefore has NO barriers and NO LDS in
+// the forward pass:
+//   * the per-edge quantities every channel needs -- f*rho_k(d), f, Y_lm (and their d/dd
+//     companions for the reverse pass) -- are evaluated ONCE per model evaluation by
+//     k_edge_basis into a 128-byte record per edge (shared by the three message blocks and
+//     both directions) instead of 6 x 20 sin/cos per edge;
+//   * a 256-thread workgroup walks one node segment at a time, thread t owns gate channel t
+//     and scalar channel t with its three rbf_lin rows in registers (channel on the lane);
+//   * the edge index is workgroup-uniform, so the record is fetched with SCALAR loads and
+//     feeds the 60 filter FMAs per edge as SGPR operands: no LDS traffic, no VGPRs;
+//   * edges are processed U at a time: all 8 U row gathers of a batch are issued before the
+//     first use;
+//   * the segment sum is a register accumulation in CSR order: no atomics, reproducible.
+// The reverse pass walks the CSR over neighbors the same way; per-edge dL/dd and dL/dY_lm
+// are reduced over the channels with DPP + one LDS slot per wave, finalised once per segment.
+#include "xeq_common.h"
+
+namespace xeq {
+
+// record layout (floats): [0, B) radial terms | BP + {0: envelope, 1..3: Y1, 4..8: Y2}   (forward)
+//                         [0, B) d/dd radial  | BP + {0: f', 1..3: unit vector, 4: |r|, 5: 1/|r|}  (reverse)
+__host__ __device__ inline int eb_bp(int B) { return (B + 3) & ~3; }
+__host__ __device__ inline int eb_width(int B) { return eb_bp(B) + 12; }
+
+template <typename T>
+__global__ void k_edge_basis(const T* __restrict__ vec, int64_t E, RadialSpec rs, const T* __restrict__ p0,
+                             const T* __restrict__ p1, T* __restrict__ eb, T* __restrict__ ed) {
+  const int B = rs.num_basis, BP = eb_bp(B), EW = BP + 12;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= E * (B + 1)) return;
+  const int64_t e = t / (B + 1);
+  const int k = (int)(t - e * (B + 1));
+  const T rc = (T)rs.cutoff;
+  EdgeGeom<T> g = edge_geom<T>(vec[3 * e], vec[3 * e + 1], vec[3 * e + 2]);
+  T f, df;
+  envelope<T>(rs.cutoff_kind, g.d, rc, f, df);
+  if (k < B) {
+    T rho, drho;
+    radial<T>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : T(0), rho, drho);
+    eb[e * EW + k] = f * rho;
+    if (ed) ed[e * EW + k] = df * rho + f * drho;
+  } else {
+    T y1[3], y2[5];
+    sph_harm_l12<T>(g, y1, y2);
+    T* r = eb + e * EW + BP;
+    r[0] = f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) r[1 + m] = y1[m];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) r[4 + m] = y2[m];
+    r[9] = r[10] = r[11] = T(0);
+    for (int q = B; q < BP; ++q) eb[e * EW + q] = T(0);
+    if (ed) {
+      T* s = ed + e * EW + BP;
+      s[0] = df;
+      s[1] = g.x;
+      s[2] = g.y;
+      s[3] = g.z;
+      s[4] = g.d;
+      s[5] = g.inv_d;
+      for (int q = 6; q < 12; ++q) s[q] = T(0);
+      for (int q = B; q < BP; ++q) ed[e * EW + q] = T(0);
+    }
+  }
+}
+
+struct SbArgs {
+  int64_t n_nodes, n_edges;
+  const int32_t* rowptr;
+  const int32_t* perm;
+  const int64_t* other;  // fwd: neighbor per edge; bwd: center per edge
+  int F, C, D, H, B;
+  Irreps ir;
+  int xl;     // layout of xhat / grad_xhat
+  int chunk;  // consecutive nodes per XCD label
+};
+
+template <typename T, int MAXB>
+__device__ __forceinline__ void load_w(const T* __restrict__ w, const T* __restrict__ b, int row, int B, bool valid,
+                                       T (&wr)[MAXB], T& br) {
+#pragma unroll
+  for (int k = 0; k < MAXB; ++k) wr[k] = (valid && k < B) ? w[(int64_t)row * B + k] : T(0);
+  br = valid ? b[row] : T(0);
+}
+
+// filter value of one channel for one edge: scalar record x register-resident weight row
+template <typename T, int MAXB>
+__device__ __forceinline__ T filt(const T (&w)[MAXB], T bias, const T* __restrict__ rec, T fe) {
+  T acc = bias * fe;
+#pragma unroll
+  for (int k = 0; k < MAXB; ++k) acc += w[k] * rec[k];  // rec[k] is workgroup-uniform: SGPR operand
+  return acc;
+}
+
+// Divergence-free addressing: a thread without a channel (t >= C or t >= F) works on a clamped,
+// valid channel with zero weights, and the number of components a wave loads is wave-uniform
+// (extra components of a lane re-read a valid address and are never stored).  Nothing in the edge
+// loop is executed under a per-lane exec mask, so the compiler emits no saveexec/branch pairs.
+struct ChanMap {
+  int tu, ts;        // clamped gate / scalar channel
+  bool has_u, has_s;
+  int l, off, nm;    // of channel tu
+  int wnm;           // wave-uniform max(nm)
+};
+__device__ __forceinline__ ChanMap chan_map(const SbArgs& a) {
+  ChanMap cm;
+  const int t = threadIdx.x;
+  cm.has_u = t < a.C;
+  cm.has_s = t < a.F;
+  cm.tu = min(t, a.C - 1);
+  cm.ts = min(t, a.F - 1);
+  a.ir.locate(cm.tu, cm.l, cm.off);
+  cm.nm = 2 * cm.l + 1;
+  const bool any2 = __ballot(cm.l == 2) != 0ull, any1 = __ballot(cm.l == 1) != 0ull;
+  cm.wnm = any2 ? 5 : (any1 ? 3 : 1);
+  return cm;
+}
+// Y_lm of this lane's l from the scalar record tail [f, Y1(3), Y2(5)]: y[m], m < 5
+template <typename T>
+__device__ __forceinline__ void lane_y(const T* __restrict__ tail, int l, T (&y)[5]) {
+  const T y10 = tail[1], y11 = tail[2], y12 = tail[3];
+  const T y20 = tail[4], y21 = tail[5], y22 = tail[6], y23 = tail[7], y24 = tail[8];
+  y[0] = l == 0 ? T(1) : (l == 1 ? y10 : y20);
+  y[1] = l == 1 ? y11 : y21;
+  y[2] = l == 1 ? y12 : y22;
+  y[3] = y23;
+  y[4] = y24;
+}
+
+template <typename T, int MAXB, int U>
+__global__ void __launch_bounds__(256) k_message_fwd_sb(SbArgs a, const T* __restrict__ eb, const T* __restrict__ h,
+                                                        const T* __restrict__ xhat, const T* __restrict__ s_in,
+                                                        const T* __restrict__ x_in, const T* __restrict__ w_rbf,
+                                                        const T* __restrict__ b_rbf, T* __restrict__ s_out,
+                                                        T* __restrict__ x_out) {
+  const int B = a.B, C = a.C, F = a.F, D = a.D, H = a.H;
+  const int BP = eb_bp(B), EW = BP + 12;
+  const ChanMap cm = chan_map(a);
+  const XAddr xa = xaddr(a.ir, a.n_nodes, cm.tu, a.xl);
+  int xcomp[5];  // component offsets, clamped to the lane's own components
+#pragma unroll
+  for (int m = 0; m < 5; ++m) xcomp[m] = min(m, cm.nm - 1) * xa.comp;
+  T ws[MAXB], we[MAXB], wm[MAXB], bs, be, bm;
+  load_w<T, MAXB>(w_rbf, b_rbf, cm.tu, B, cm.has_u, ws, bs);
+  load_w<T, MAXB>(w_rbf, b_rbf, C + cm.tu, B, cm.has_u, we, be);
+  load_w<T, MAXB>(w_rbf, b_rbf, 2 * C + cm.ts, B, cm.has_s, wm, bm);
+
+  const int lane = threadIdx.x & 63;
+  XcdWalk walk(a.n_nodes, a.chunk);
+  for (int64_t c = walk.next(); c >= 0; c = walk.next()) {
+    const int32_t e0 = a.rowptr[c], e1 = a.rowptr[c + 1];
+    T acc_s = T(0), acc_x[5] = {T(0), T(0), T(0), T(0), T(0)};
+    for (int32_t pb = e0; pb < e1; pb += 64) {
+      // the segment's edge ids / neighbour rows: ONE coalesced vector load per 64 edges, handed out
+      // with v_readlane (no dependent scalar-memory chain per edge)
+      const int cnt = min(64, e1 - pb);
+      const int32_t slot_v = pb + min(lane, cnt - 1);
+      const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
+      const int32_t nbr_v = (int32_t)a.other[eid_v];
+      for (int j0 = 0; j0 < cnt; j0 += U) {
+        uint32_t noff[U], eoff[U];  // 32-bit element offsets (host checks N*H and E*EW < 2^31)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = min(j0 + u, cnt - 1);  // a padded slot repeats the last edge and is skipped below
+          noff[u] = (uint32_t)__builtin_amdgcn_readlane(nbr_v, j);
+          eoff[u] = (uint32_t)__builtin_amdgcn_readlane(eid_v, j) * (uint32_t)EW;
+        }
+        T hs[U], he[U], hm[U], xv[U][5];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const T* hn = h + noff[u] * (uint32_t)H;
+          hm[u] = hn[2 * C + cm.ts];
+          hs[u] = hn[cm.tu];
+          he[u] = hn[C + cm.tu];
+          const T* xn = xhat + xa.off + (int64_t)noff[u] * xa.node;
+          xv[u][0] = xn[0];
+          if (cm.wnm >= 3) {  // wave-uniform
+            xv[u][1] = xn[xcomp[1]];
+            xv[u][2] = xn[xcomp[2]];
+          } else {
+            xv[u][1] = xv[u][2] = T(0);
+          }
+          if (cm.wnm >= 5) {
+            xv[u][3] = xn[xcomp[3]];
+            xv[u][4] = xn[xcomp[4]];
+          } else {
+            xv[u][3] = xv[u][4] = T(0);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (j0 + u < cnt) {  // uniform
+            const T* rec = eb + eoff[u];  // workgroup-uniform address: scalar loads
+            const T fe = rec[BP];
+            const T ps = filt<T, MAXB>(ws, bs, rec, fe);
+            const T pe = filt<T, MAXB>(we, be, rec, fe);
+            const T pm = filt<T, MAXB>(wm, bm, rec, fe);
+            acc_s += hm[u] * pm;
+            const T gs = hs[u] * ps, ge = he[u] * pe;
+            T y[5];
+            lane_y<T>(rec + BP, cm.l, y);
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc_x[m] += xv[u][m] * gs + y[m] * ge;
+          }
+        }
+      }
+    }
+    if (cm.has_s) s_out[c * F + cm.ts] = s_in[c * F + cm.ts] + acc_s;
+    if (cm.has_u) {
+#pragma unroll
+      for (int m = 0; m < 5; ++m)
+        if (m < cm.nm) x_out[c * D + cm.off + m] = x_in[c * D + cm.off + m] + acc_x[m];
+    }
+  }
+}
+
+// wave reduction helpers: DPP for float, shuffles for double
+__device__ __forceinline__ float wave_total(float v) {
+#define XEQ_SB_DPP(v, ctrl, rmask) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), ctrl, rmask, 0xF, true)))
+  v = XEQ_SB_DPP(v, 0xB1, 0xF);
+  v = XEQ_SB_DPP(v, 0x4E, 0xF);
+  v = XEQ_SB_DPP(v, 0x141, 0xF);
+  v = XEQ_SB_DPP(v, 0x140, 0xF);
+  v = XEQ_SB_DPP(v, 0x142, 0xA);
+  v = XEQ_SB_DPP(v, 0x143, 0xC);
+#undef XEQ_SB_DPP
+  return __shfl(v, 63, 64);
+}
+__device__ __forceinline__ double wave_total(double v) { return wave_sum<double>(v); }
+
+constexpr int SB_RED = 64;  // edges whose reduction slots fit in LDS between two finalisations
+
+template <typename T, int MAXB, int U>
+__global__ void __launch_bounds__(256) k_message_bwd_sb(SbArgs a, const T* __restrict__ eb, const T* __restrict__ ed,
+                                                        const T* __restrict__ h, const T* __restrict__ xhat,
+                                                        const T* __restrict__ grad_s, const T* __restrict__ grad_x,
+                                                        const T* __restrict__ w_rbf, const T* __restrict__ b_rbf,
+                                                        T* __restrict__ grad_h, T* __restrict__ grad_xhat,
+                                                        T* __restrict__ grad_vec) {
+  __shared__ T red[SB_RED][4][9];
+  __shared__ int32_t red_eid[SB_RED];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int B = a.B, C = a.C, F = a.F, D = a.D, H = a.H;
+  const int BP = eb_bp(B), EW = BP + 12;
+  const ChanMap cm = chan_map(a);
+  const bool is1 = cm.has_u && cm.l == 1, is2 = cm.has_u && cm.l == 2;
+  const bool wave_has1 = __ballot(is1) != 0ull, wave_has2 = __ballot(is2) != 0ull;
+  const XAddr xa = xaddr(a.ir, a.n_nodes, cm.tu, a.xl);
+  int gcomp[5];  // offsets inside the e3nn row of grad_x, clamped to the lane's own components
+#pragma unroll
+  for (int m = 0; m < 5; ++m) gcomp[m] = cm.off + min(m, cm.nm - 1);
+  T ws[MAXB], we[MAXB], wm[MAXB], bs, be, bm;
+  load_w<T, MAXB>(w_rbf, b_rbf, cm.tu, B, cm.has_u, ws, bs);
+  load_w<T, MAXB>(w_rbf, b_rbf, C + cm.tu, B, cm.has_u, we, be);
+  load_w<T, MAXB>(w_rbf, b_rbf, 2 * C + cm.ts, B, cm.has_s, wm, bm);
+
+  XcdWalk walk(a.n_nodes, a.chunk);
+  for (int64_t n = walk.next(); n >= 0; n = walk.next()) {
+    const int32_t e0 = a.rowptr[n], e1 = a.rowptr[n + 1];
+    const T hs = cm.has_u ? h[n * H + cm.tu] : T(0), he = cm.has_u ? h[n * H + C + cm.tu] : T(0);
+    const T hm = cm.has_s ? h[n * H + 2 * C + cm.ts] : T(0);
+    T xh[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) xh[m] = (cm.has_u && m < cm.nm) ? xhat[xa.off + n * xa.node + m * xa.comp] : T(0);
+    T acc_hs = T(0), acc_he = T(0), acc_hm = T(0), acc_xh[5] = {T(0), T(0), T(0), T(0), T(0)};
+    for (int32_t pb = e0; pb < e1; pb += SB_RED) {  // groups of <= SB_RED edges share one finalisation
+      const int32_t pe_ = min(pb + SB_RED, e1);
+      const int cnt = pe_ - pb;  // <= SB_RED = 64: one vector load of edge ids / centre rows
+      const int32_t slot_v = pb + min(lane, cnt - 1);
+      const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
+      const int32_t ctr_v = (int32_t)a.other[eid_v];
+      for (int32_t p = pb; p < pe_; p += U) {
+        uint32_t cidx[U];
+        int32_t eid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = min(p + u, pe_ - 1) - pb;
+          eid[u] = __builtin_amdgcn_readlane(eid_v, j);
+          cidx[u] = (uint32_t)__builtin_amdgcn_readlane(ctr_v, j);
+        }
+        T gx[U][5], dgm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          dgm[u] = grad_s[cidx[u] * (uint32_t)F + cm.ts];
+          const T* gr = grad_x + cidx[u] * (uint32_t)D;
+          gx[u][0] = gr[gcomp[0]];
+          if (cm.wnm >= 3) {  // wave-uniform
+            gx[u][1] = gr[gcomp[1]];
+            gx[u][2] = gr[gcomp[2]];
+          } else {
+            gx[u][1] = gx[u][2] = T(0);
+          }
+          if (cm.wnm >= 5) {
+            gx[u][3] = gr[gcomp[3]];
+            gx[u][4] = gr[gcomp[4]];
+          } else {
+            gx[u][3] = gx[u][4] = T(0);
+          }
+#pragma unroll
+          for (int m = 0; m < 5; ++m)
+            if (m >= cm.nm) gx[u][m] = T(0);  // components the lane does not own (v_cndmask, no branch)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (p + u < pe_) {  // uniform
+            const T* rec = eb + (uint32_t)eid[u] * (uint32_t)EW;
+            const T* rd = ed + (uint32_t)eid[u] * (uint32_t)EW;
+            const T fe = rec[BP], dfe = rd[BP];
+            const T ps = filt<T, MAXB>(ws, bs, rec, fe), pe = filt<T, MAXB>(we, be, rec, fe), pm = filt<T, MAXB>(wm, bm, rec, fe);
+            const T qs = filt<T, MAXB>(ws, bs, rd, dfe), qe = filt<T, MAXB>(we, be, rd, dfe), qm = filt<T, MAXB>(wm, bm, rd, dfe);
+            T y[5];
+            lane_y<T>(rec + BP, cm.l, y);
+            T dgs = T(0), dge = T(0);
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+              dgs += xh[m] * gx[u][m];
+              dge += y[m] * gx[u][m];
+            }
+            const T dg_m = cm.has_s ? dgm[u] : T(0);
+            acc_hs += ps * dgs;
+            acc_he += pe * dge;
+            acc_hm += pm * dg_m;
+            const T gate = hs * ps;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc_xh[m] += gate * gx[u][m];
+            const T pd = wave_total(hs * dgs * qs + he * dge * qe + hm * dg_m * qm);
+            const T gy = he * pe;
+            T r1[3] = {T(0), T(0), T(0)}, r2[5] = {T(0), T(0), T(0), T(0), T(0)};
+            if (wave_has1) {
+#pragma unroll
+              for (int m = 0; m < 3; ++m) r1[m] = wave_total(is1 ? gy * gx[u][m] : T(0));
+            }
+            if (wave_has2) {
+#pragma unroll
+              for (int m = 0; m < 5; ++m) r2[m] = wave_total(is2 ? gy * gx[u][m] : T(0));
+            }
+            if (lane == 0) {
+              const int j = p + u - pb;
+              red[j][wave][0] = pd;
+#pragma unroll
+              for (int m = 0; m < 3; ++m) red[j][wave][1 + m] = r1[m];
+#pragma unroll
+              for (int m = 0; m < 5; ++m) red[j][wave][4 + m] = r2[m];
+              if (wave == 0) red_eid[j] = eid[u];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (t < pe_ - pb) {  // one lane per edge: sum the four waves, chain rule to dL/dvec
+        T gd = T(0), q1[3] = {T(0), T(0), T(0)}, q2[5] = {T(0), T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          gd += red[t][w][0];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) q1[m] += red[t][w][1 + m];
+#pragma unroll
+          for (int m = 0; m < 5; ++m) q2[m] += red[t][w][4 + m];
+        }
+        const int64_t e = red_eid[t];
+        const T* rd = ed + e * EW + BP;
+        EdgeGeom<T> g;
+        g.x = rd[1];
+        g.y = rd[2];
+        g.z = rd[3];
+        g.d = rd[4];
+        g.inv_d = rd[5];
+        T out[3];
+        edge_grad<T>(g, gd, q1, q2, out);
+        grad_vec[3 * e] = out[0];
+        grad_vec[3 * e + 1] = out[1];
+        grad_vec[3 * e + 2] = out[2];
+      }
+      __syncthreads();
+    }
+    if (cm.has_u) {
+      grad_h[n * H + cm.tu] = acc_hs;
+      grad_h[n * H + C + cm.tu] = acc_he;
+#pragma unroll
+      for (int m = 0; m < 5; ++m)
+        if (m < cm.nm) grad_xhat[xa.off + n * xa.node + m * xa.comp] = acc_xh[m];
+    }
+    if (cm.has_s) grad_h[n * H + 2 * C + cm.ts] = acc_hm;
+  }
+}
+
+static int sb_check(const char* who, int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3],
+                    SbArgs& a) {
+  XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (1ll << 31) && n_nodes < (1ll << 31), "%s: bad sizes", who);
+  XEQ_CHECK_ARG(num_basis >= 1 && num_basis <= 32, "%s: num_basis %d outside the supported range 1..32", who, num_basis);
+  for (int l = 0; l < 3; ++l) {
+    XEQ_CHECK_ARG(mul[l] >= 0, "%s: negative multiplicity", who);
+    a.ir.mul[l] = mul[l];
+  }
+  a.C = a.ir.C();
+  a.D = a.ir.D();
+  a.F = node_dim;
+  a.H = a.F + 2 * a.C;
+  a.B = num_basis;
+  XEQ_CHECK_ARG(a.C >= 1 && a.C <= 256 && a.F >= 1 && a.F <= 256,
+                "%s: node_dim %d / %d irrep channels exceed the 256-channel workgroup mapping", who, a.F, a.C);
+  XEQ_CHECK_ARG(n_nodes * (int64_t)(a.H > a.D ? a.H : a.D) < (1ll << 31) && n_edges * (int64_t)eb_width(num_basis) < (1ll << 31),
+                "%s: tensors too large for 32-bit row offsets (shard the batch)", who);
+  a.n_nodes = n_nodes;
+  a.n_edges = n_edges;
+  a.chunk = n_nodes >= 32 * 1024 ? 32 : (int)(n_nodes / 1024 > 0 ? n_nodes / 1024 : 1);
+  return XEQ_OK;
+}
+
+}  // namespace xeq
+
+using namespace xeq;
+
+// MAXB must cover the zero-padded record head BP = roundup(B, 4)
+#define XEQ_SB_DISPATCH(KERNEL, UF, UD, ...)                                                                        \
+  do {                                                                                                              \
+    if (dtype == XEQ_F32) {                                                                                         \
+      using T = float;                                                                                              \
+      if (num_basis <= 8) hipLaunchKernelGGL((KERNEL<T, 8, UF>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+      else if (num_basis <= 16) hipLaunchKernelGGL((KERNEL<T, 16, UF>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (num_basis <= 20) hipLaunchKernelGGL((KERNEL<T, 20, UF>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<T, 32, UF>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
+    } else if (dtype == XEQ_F64) {                                                                                  \
+      using T = double;                                                                                             \
+      if (num_basis <= 8) hipLaunchKernelGGL((KERNEL<T, 8, UD>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+      else if (num_basis <= 16) hipLaunchKernelGGL((KERNEL<T, 16, UD>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (num_basis <= 20) hipLaunchKernelGGL((KERNEL<T, 20, UD>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<T, 32, UD>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
+    } else {                                                                                                        \
+      xeq::set_error("unsupported dtype %d", dtype);                                                                \
+      return XEQ_ERR_INVALID_ARGUMENT;                                                                              \
+    }                                                                                                               \
+  } while (0)
+
+extern "C" {
+
+int xeq_edge_basis_width(int num_basis) { return eb_width(num_basis); }
+
+int xeq_edge_basis(int dtype, const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis,
+                   double cutoff, const void* p0, const void* p1, void* basis, void* dbasis, void* stream) {
+  XEQ_CHECK_ARG(n_edges >= 0 && num_basis >= 1 && num_basis <= 32 && cutoff > 0, "xeq_edge_basis: bad sizes");
+  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_edge_basis: rbf kernel %d is not implemented", rbf_kind);
+  XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis: gaussian rbf needs std");
+  XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis: cutoff function %d is not implemented", cutoff_kind);
+  if (n_edges == 0) return XEQ_OK;
+  RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
+  const int64_t total = n_edges * (num_basis + 1);
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_edge_basis<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)vec, n_edges, rs, (const T*)p0, (const T*)p1, (T*)basis, (T*)dbasis);
+  });
+  XEQ_CHECK_LAUNCH("xeq_edge_basis");
+  return XEQ_OK;
+}
+
+int xeq_message_fwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* perm,
+                       const int64_t* nbr, const void* basis, const void* h, const void* xhat, const void* s_in,
+                       const void* x_in, const void* w_rbf, const void* b_rbf, int num_basis, int node_dim,
+                       const int32_t mul[3], void* s_out, void* x_out, int xhat_layout, void* stream) {
+  SbArgs a{};
+  int rcode = sb_check("xeq_message_fwd_sb", n_nodes, n_edges, num_basis, node_dim, mul, a);
+  if (rcode != XEQ_OK) return rcode;
+  if (n_nodes == 0) return XEQ_OK;
+  a.rowptr = rowptr;
+  a.perm = perm;
+  a.other = nbr;
+  a.xl = xhat_layout;
+  dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
+  XEQ_SB_DISPATCH(k_message_fwd_sb, 4, 2, a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)s_in, (const T*)x_in,
+                  (const T*)w_rbf, (const T*)b_rbf, (T*)s_out, (T*)x_out);
+  XEQ_CHECK_LAUNCH("xeq_message_fwd_sb");
+  return XEQ_OK;
+}
+
+int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                       const int64_t* center, const void* basis, const void* dbasis, const void* h, const void* xhat,
+                       const void* grad_s, const void* grad_x, const void* w_rbf, const void* b_rbf, int num_basis,
+                       int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec,
+                       int xhat_layout, void* stream) {
+  SbArgs a{};
+  int rcode = sb_check("xeq_message_bwd_sb", n_nodes, n_edges, num_basis, node_dim, mul, a);
+  if (rcode != XEQ_OK) return rcode;
+  if (n_nodes == 0) return XEQ_OK;
+  a.rowptr = n_rowptr;
+  a.perm = n_perm;
+  a.other = center;
+  a.xl = xhat_layout;
+  dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
+  XEQ_SB_DISPATCH(k_message_bwd_sb, 2, 1, a, (const T*)basis, (const T*)dbasis, (const T*)h, (const T*)xhat,
+                  (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat,
+                  (T*)grad_vec);
+  XEQ_CHECK_LAUNCH("xeq_message_bwd_sb");
+  return XEQ_OK;
+}
+
+}  // extern "C"

@@ -45,11 +45,11 @@ _PROTOS = {
                         c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, c_int, _P],
     "xeq_message_bwd": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                         c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, _P, c_int, _P],
-    "xeq_message_seg_max_nodes": [c_int, c_int, c_int, _I3, c_int],
-    "xeq_message_fwd_seg": [c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                            c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, c_int, _P],
-    "xeq_message_bwd_seg": [c_int64, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                            c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, _P, c_int, _P],
+    "xeq_edge_basis_width": [c_int],
+    "xeq_edge_basis": [c_int, _P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
+    "xeq_message_fwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, c_int, _P],
+    "xeq_message_bwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P,
+                           c_int, _P],
     "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
     "xeq_norm_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
     "xeq_uv_reduce_fwd": [c_int, _P, c_int64, _I3, c_double, _P, c_int64, c_int, _P, _P],

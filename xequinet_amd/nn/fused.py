@@ -84,11 +84,11 @@ class MessageBlock(Function):
         h = torch.addmm(lin2.bias, act(pre), lin2.weight.t())
         p0, p1 = rbf.params()
         cfg = (rbf.kind, cutoff_fn.kind, module.num_basis, float(cutoff_fn.cutoff), F, mul, 1)  # xhat in BT layout
-        s_out, x_out, saved, use_seg = ops.message_forward(h, xhat, vec, s, x, module.rbf_lin.weight, module.rbf_lin.bias,
-                                                           p0, p1, graph, cfg)
-        ctx.has_p1 = saved[6] is not None
+        s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, module.rbf_lin.weight, module.rbf_lin.bias,
+                                                        p0, p1, graph, cfg)
+        ctx.none_mask = [t is None for t in saved]
         ctx.save_for_backward(*[t for t in saved if t is not None], s, x, stats, pre)
-        ctx.module, ctx.do_norm, ctx.graph, ctx.cfg, ctx.use_seg = module, do_norm, graph, cfg, use_seg
+        ctx.module, ctx.do_norm, ctx.graph, ctx.cfg, ctx.impl = module, do_norm, graph, cfg, impl
         return s_out, x_out
 
     @staticmethod
@@ -96,11 +96,11 @@ class MessageBlock(Function):
     def backward(ctx, g_s_out, g_x_out):
         module = ctx.module
         F, mul = module.node_dim, module._mul
-        t = ctx.saved_tensors
-        nmsg = 7 if ctx.has_p1 else 6
-        msg_saved = tuple(t[:nmsg]) + (() if ctx.has_p1 else (None,))
-        s, x, stats, pre = t[nmsg:]
-        g_h, g_xhat, g_vec, g_s_res, g_x_res = ops.message_backward(msg_saved, ctx.graph, ctx.cfg, ctx.use_seg, g_s_out, g_x_out)
+        t = list(ctx.saved_tensors)
+        s, x, stats, pre = t[-4:]
+        it = iter(t[:-4])
+        msg_saved = tuple(None if is_none else next(it) for is_none in ctx.none_mask)
+        g_h, g_xhat, g_vec, g_s_res, g_x_res = ops.message_backward(msg_saved, ctx.graph, ctx.cfg, ctx.impl, g_s_out, g_x_out)
         lin1, act, lin2 = module.scalar_mlp[0], module.scalar_mlp[1], module.scalar_mlp[2]
         g_pre = _silu_bwd(torch.mm(g_h, lin2.weight), pre, act)
         g_shat = torch.mm(g_pre, lin1.weight)

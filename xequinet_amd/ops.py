@@ -89,32 +89,6 @@ class EdgeGraph:
         keys, perm = torch.sort(nbr, stable=True)
         self.n_perm = perm.to(torch.int32)
         self.n_rowptr = csr_rowptr(keys, self.n_nodes)
-        self.n_seg = None  # closed segments are built on demand (LDS-window kernels only)
-
-    def build_segments(self) -> None:
-        """Closed node segments: maximal cuts of the node range that no edge crosses (the
-        molecules of a batch).  Index plumbing for the LDS-window message kernels."""
-        if self.n_seg is not None:
-            return
-        center, nbr, perm = self.edge_index[0], self.edge_index[1], self.n_perm.long()
-        N, dev = self.n_nodes, center.device
-        self.other_n = center.index_select(0, perm).to(torch.int32)  # destination of each neighbor-CSR slot
-        if N == 0:
-            self.seg_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.seg_eptr = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.n_seg, self.max_seg = 0, 0
-            return
-        idx = torch.arange(N, device=dev)
-        reach = idx.clone()
-        if self.n_edges > 0:
-            reach = reach.scatter_reduce(0, center, nbr, "amax").scatter_reduce(0, nbr, center, "amax")
-        closed = torch.cummax(reach, 0).values == idx          # node i ends a closed segment
-        ends = torch.nonzero(closed).flatten() + 1
-        seg_ptr = torch.cat([torch.zeros(1, dtype=ends.dtype, device=dev), ends])
-        self.seg_ptr = seg_ptr.to(torch.int32)
-        self.seg_eptr = self.n_rowptr.index_select(0, seg_ptr).contiguous()
-        self.n_seg = int(seg_ptr.numel() - 1)
-        self.max_seg = int((seg_ptr[1:] - seg_ptr[:-1]).max().item())
 
 
 def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -355,31 +329,35 @@ def radial_basis(dist, rbf_kind: str, cutoff_kind: str, num_basis: int, cutoff: 
 
 
 # ------------------------------------------------------------------- fused message
-_SEG_LIMIT = {}
-
-
-def _use_seg_path(h, graph: EdgeGraph, num_basis: int, node_dim: int, mul) -> bool:
-    """LDS-window kernels when every closed segment (molecule) fits the window of both
-    directions; XEQ_MESSAGE_IMPL=valu|mfma forces the general kernels."""
+def _message_impl() -> str:
     import os
 
-    # measured slower than the general MFMA kernels so far (one workgroup per CU leaves the LDS
-    # read-modify-write chains unhidden): opt-in with XEQ_MESSAGE_IMPL=seg until it wins
-    if h.dtype != torch.float32 or os.environ.get("XEQ_MESSAGE_IMPL", "") != "seg":
-        return False
-    graph.build_segments()
-    if graph.n_seg == 0:
-        return False
-    key = (num_basis, node_dim, tuple(mul))
-    if key not in _SEG_LIMIT:
-        handle = lib.load()
-        _SEG_LIMIT[key] = min(handle.xeq_message_seg_max_nodes(lib.XEQ_F32, num_basis, node_dim, mul3(mul), b) for b in (0, 1))
-    return 0 < graph.max_seg <= _SEG_LIMIT[key]
+    impl = os.environ.get("XEQ_MESSAGE_IMPL", "sb")
+    if impl not in ("sb", "mfma", "valu"):
+        raise ValueError(f"XEQ_MESSAGE_IMPL={impl!r}: expected sb | mfma | valu")
+    return impl
+
+
+def edge_basis(vec, graph: EdgeGraph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1):
+    """Per-edge radial / angular records (xeq_edge_basis), computed once per evaluation and cached
+    on the graph: the three message blocks and both directions share them."""
+    key = (vec.data_ptr(), vec._version, vec.dtype, rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version)
+    cached = getattr(graph, "_basis", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    width = lib.load().xeq_edge_basis_width(num_basis)
+    E = vec.shape[0]
+    basis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
+    dbasis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
+    call("xeq_edge_basis", dtype_code(vec), ptr(vec), E, lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis,
+         float(cutoff), ptr(p0), ptr(p1), ptr(basis), ptr(dbasis), stream())
+    graph._basis = (key, basis, dbasis)
+    return basis, dbasis
 
 
 def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg):
     """Launch the fused message kernel.  cfg = (rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul[, xhat_layout]).
-    Returns (s_out, x_out, saved, use_seg): `saved` is what message_backward needs."""
+    Returns (s_out, x_out, saved, impl): `saved` is what message_backward needs."""
     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = cfg[:6]
     xl = int(cfg[6]) if len(cfg) > 6 else 0  # layout of xhat / grad_xhat: 0 e3nn, 1 BT
     require_hip(h, xhat, vec, s, x, w_rbf, b_rbf, p0)
@@ -391,38 +369,36 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
     assert h.shape == (N, node_dim + 2 * C) and xhat.numel() == N * D and vec.shape == (E, 3)
     assert s.shape == (N, node_dim) and x.shape == (N, D) and w_rbf.shape == (node_dim + 2 * C, num_basis)
     s_out, x_out = torch.empty_like(s), torch.empty_like(x)
-    use_seg = _use_seg_path(h, graph, num_basis, node_dim, mul)
-    if use_seg:
-        vec = vec.index_select(0, graph.n_perm)  # slot order of the neighbor CSR
-        KERNEL_TIMER.launch("xeq_message_fwd_seg", N, E, ptr(graph.n_rowptr), ptr(graph.seg_ptr), ptr(graph.seg_eptr),
-                            graph.n_seg, graph.max_seg, ptr(vec), ptr(graph.other_n), ptr(graph.n_perm), ptr(h), ptr(xhat),
-                            ptr(s), ptr(x), ptr(w_rbf), ptr(b_rbf), ptr(p0), ptr(p1), lib.RBF_KINDS[rbf_kind],
-                            lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff), node_dim, mul3(mul), ptr(s_out),
-                            ptr(x_out), xl, stream())
-    else:
-        KERNEL_TIMER.launch("xeq_message_fwd", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm),
-                            ptr(graph.edge_index[1]), ptr(vec), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf), ptr(b_rbf),
-                            ptr(p0), ptr(p1), lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff),
-                            node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
-    return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1), use_seg
+    impl = _message_impl()
+    if impl == "sb":
+        basis, dbasis = edge_basis(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
+        KERNEL_TIMER.launch("xeq_message_fwd_sb", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm),
+                            ptr(graph.edge_index[1]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf), ptr(b_rbf),
+                            num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
+        return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, basis, dbasis), impl
+    # mfma | valu: the library picks the kernel family from XEQ_MESSAGE_IMPL
+    KERNEL_TIMER.launch("xeq_message_fwd", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm),
+                        ptr(graph.edge_index[1]), ptr(vec), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf), ptr(b_rbf),
+                        ptr(p0), ptr(p1), lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff),
+                        node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
+    return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, None, None), impl
 
 
-def message_backward(saved, graph: EdgeGraph, cfg, use_seg: bool, g_s, g_x):
+def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x):
     """Reverse pass of the fused message: (grad_h, grad_xhat, grad_vec, grad_s, grad_x)."""
-    h, xhat, vec, w_rbf, b_rbf, p0, p1 = saved
+    h, xhat, vec, w_rbf, b_rbf, p0, p1, basis, dbasis = saved
     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = cfg[:6]
     xl = int(cfg[6]) if len(cfg) > 6 else 0
     D = mul[0] + 3 * mul[1] + 5 * mul[2]
     g_s = torch.zeros((graph.n_nodes, node_dim), dtype=h.dtype, device=h.device) if g_s is None else g_s.contiguous()
     g_x = torch.zeros((graph.n_nodes, D), dtype=h.dtype, device=h.device) if g_x is None else g_x.contiguous()
     g_h, g_xhat = torch.empty_like(h), torch.empty_like(xhat)
-    g_vec = torch.empty_like(vec)  # written at the edge's own position by both kernel families
-    if use_seg:
-        KERNEL_TIMER.launch("xeq_message_bwd_seg", graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr), ptr(graph.seg_ptr),
-                            ptr(graph.seg_eptr), graph.n_seg, graph.max_seg, ptr(vec), ptr(graph.other_n), ptr(graph.n_perm),
-                            ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w_rbf), ptr(b_rbf), ptr(p0), ptr(p1),
-                            lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff), node_dim,
-                            mul3(mul), ptr(g_h), ptr(g_xhat), ptr(g_vec), xl, stream())
+    g_vec = torch.empty_like(vec)  # written at the edge's own position by every kernel family
+    if impl == "sb":
+        KERNEL_TIMER.launch("xeq_message_bwd_sb", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),
+                            ptr(graph.n_perm), ptr(graph.edge_index[0]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s),
+                            ptr(g_x), ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat),
+                            ptr(g_vec), xl, stream())
     else:
         KERNEL_TIMER.launch("xeq_message_bwd", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),
                             ptr(graph.n_perm), ptr(graph.edge_index[0]), ptr(vec), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x),
@@ -436,9 +412,9 @@ class FusedMessage(Function):
 
     @staticmethod
     def forward(ctx, h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg):
-        s_out, x_out, saved, use_seg = message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph, cfg)
+        s_out, x_out, saved, impl = message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph, cfg)
         ctx.save_for_backward(*saved)
-        ctx.graph, ctx.cfg, ctx.use_seg = graph, cfg, use_seg
+        ctx.graph, ctx.cfg, ctx.impl = graph, cfg, impl
         return s_out, x_out
 
     @staticmethod
@@ -447,5 +423,5 @@ class FusedMessage(Function):
         if any(ctx.needs_input_grad[5:9]):
             raise NotImplementedError("xequinet_amd: parameter gradients (training) are out of scope; "
                                       "call model.requires_grad_(False) / model.eval()")
-        g_h, g_xhat, g_vec, g_s, g_x = message_backward(ctx.saved_tensors, ctx.graph, ctx.cfg, ctx.use_seg, g_s, g_x)
+        g_h, g_xhat, g_vec, g_s, g_x = message_backward(ctx.saved_tensors, ctx.graph, ctx.cfg, ctx.impl, g_s, g_x)
         return g_h, g_xhat, g_vec, g_s, g_x, None, None, None, None, None, None
