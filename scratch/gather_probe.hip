@@ -36,3 +36,27 @@ extern "C" __global__ void __launch_bounds__(256) probe_wave(const int32_t* __re
     reinterpret_cast<f32x4*>(out + c * 256)[lane] = s;
   }
 }
+
+// C: probe_chan + the 60 filter FMAs fed by a scalar (workgroup-uniform) 32-float record per edge
+extern "C" __global__ void __launch_bounds__(256) probe_fma(const int32_t* __restrict__ rowptr, const int64_t* __restrict__ nbr,
+                                                            const float* __restrict__ rows, int64_t N, int W, float* __restrict__ out,
+                                                            const float* __restrict__ eb, const float* __restrict__ wts) {
+  const int t = threadIdx.x;
+  float w0[20], w1[20], w2[20];
+#pragma unroll
+  for (int k = 0; k < 20; ++k) { w0[k] = wts[t * 20 + k]; w1[k] = wts[(256 + t) * 20 + k]; w2[k] = wts[(512 + t) * 20 + k]; }
+  for (int64_t c = blockIdx.x; c < N; c += gridDim.x) {
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    const int e0 = rowptr[c], e1 = rowptr[c + 1];
+#pragma unroll 4
+    for (int e = e0; e < e1; ++e) {
+      const float* r = rows + nbr[e] * W;
+      const float* rec = eb + (int64_t)e * 32;
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 20; ++k) { p0 += w0[k] * rec[k]; p1 += w1[k] * rec[k]; p2 += w2[k] * rec[k]; }
+      acc0 += r[t] * p0; acc1 += r[256 + t] * p1; acc2 += r[512 + t] * p2; acc3 += r[768 + t] * (p0 + rec[21]);
+    }
+    out[c * 256 + t] = acc0 + acc1 + acc2 + acc3;
+  }
+}

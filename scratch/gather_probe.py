@@ -16,14 +16,16 @@ nbr = b.edge_index[1].contiguous()
 hip.hipLaunchKernel.argtypes = [ctypes.c_void_p, ctypes.c_uint*3, ctypes.c_uint*3, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_void_p]
 class dim3(ctypes.Structure): _fields_=[("x",ctypes.c_uint),("y",ctypes.c_uint),("z",ctypes.c_uint)]
 hip.hipLaunchKernel.argtypes = [ctypes.c_void_p, dim3, dim3, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_void_p]
+ebuf = torch.randn(E, 32, device="cuda"); wts = torch.randn(768, 20, device="cuda")
 def launch(name, grid):
     fn = ctypes.cast(getattr(lib, name), ctypes.c_void_p)
     a = [ctypes.c_void_p(g.c_rowptr.data_ptr()), ctypes.c_void_p(nbr.data_ptr()), ctypes.c_void_p(rows.data_ptr()), ctypes.c_int64(N), ctypes.c_int(W), ctypes.c_void_p(out.data_ptr())]
+    if name == "probe_fma": a += [ctypes.c_void_p(ebuf.data_ptr()), ctypes.c_void_p(wts.data_ptr())]
     arr = (ctypes.c_void_p * len(a))(*[ctypes.cast(ctypes.pointer(x), ctypes.c_void_p) for x in a])
     rc = hip.hipLaunchKernel(fn, dim3(grid,1,1), dim3(256,1,1), arr, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
-for name in ("probe_chan", "probe_wave"):
-    for grid in (512, 1024, 2048, 4096):
+for name in ("probe_chan", "probe_fma"):
+    for grid in (1024, 2048):
         launch(name, grid); torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
