@@ -46,4 +46,4 @@ def timeit(impl, reps=20):
 run("mfma"); run("valu"); run("sb")
 print(f"N={N} E={E}")
 for impl in ("sb", "sb"):
-    print(impl, {k: f"{v:.1f} us" for k, v in timeit(impl).items()})
+    print(impl, os.environ.get("XEQ_SB_FORM"), os.environ.get("XEQ_SB_GROUP"), {k: f"{v:.1f} us" for k, v in timeit(impl).items()})

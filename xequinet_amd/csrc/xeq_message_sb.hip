@@ -88,13 +88,30 @@ __device__ __forceinline__ void load_w(const T* __restrict__ w, const T* __restr
   br = valid ? b[row] : T(0);
 }
 
-// filter value of one channel for one edge: scalar record x register-resident weight row
+// filter value of one channel for one edge: scalar record x register-resident weight row.
+// rec[k] is workgroup-uniform (SGPR operands).  Measured on gfx950 (scratch/valu_rate.hip): v_fmac_f32 with an
+// SGPR source issues at HALF rate (4.3 cycles per wave64 instruction against 2.3 with VGPR sources), and
+// v_pk_fma_f32 costs 4.3 cycles with either -- so fp32 uses packed FMAs (two terms per instruction, even/odd
+// partial sums); the compiler's own choice for the scalar loop was v_pk_mul + 2 v_add per two terms.
 template <typename T, int MAXB>
 __device__ __forceinline__ T filt(const T (&w)[MAXB], T bias, const T* __restrict__ rec, T fe) {
   T acc = bias * fe;
 #pragma unroll
-  for (int k = 0; k < MAXB; ++k) acc += w[k] * rec[k];  // rec[k] is workgroup-uniform: SGPR operand
+  for (int k = 0; k < MAXB; ++k) acc += w[k] * rec[k];
   return acc;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int MAXB>
+__device__ __forceinline__ float filt(const float (&w)[MAXB], float bias, const float* __restrict__ rec, float fe) {
+  static_assert(MAXB % 2 == 0, "packed filter needs an even row length");
+  const f32x2* __restrict__ r2 = reinterpret_cast<const f32x2*>(rec);  // records are 16-byte aligned
+  f32x2 acc = {bias * fe, 0.f};
+#pragma unroll
+  for (int k = 0; k < MAXB / 2; ++k) {
+    const f32x2 wv = {w[2 * k], w[2 * k + 1]};
+    acc = __builtin_elementwise_fma(wv, r2[k], acc);
+  }
+  return acc.x + acc.y;
 }
 
 // Divergence-free addressing: a thread without a channel (t >= C or t >= F) works on a clamped,
@@ -197,9 +214,9 @@ __global__ void __launch_bounds__(256) k_message_fwd_sb(SbArgs a, const T* __res
           if (j0 + u < cnt) {  // uniform
             const T* rec = eb + eoff[u];  // workgroup-uniform address: scalar loads
             const T fe = rec[BP];
-            const T ps = filt<T, MAXB>(ws, bs, rec, fe);
-            const T pe = filt<T, MAXB>(we, be, rec, fe);
-            const T pm = filt<T, MAXB>(wm, bm, rec, fe);
+            const T ps = filt(ws, bs, rec, fe);
+            const T pe = filt(we, be, rec, fe);
+            const T pm = filt(wm, bm, rec, fe);
             acc_s += hm[u] * pm;
             const T gs = hs[u] * ps, ge = he[u] * pe;
             T y[5];
@@ -312,8 +329,8 @@ __global__ void __launch_bounds__(256) k_message_bwd_sb(SbArgs a, const T* __res
             const T* rec = eb + (uint32_t)eid[u] * (uint32_t)EW;
             const T* rd = ed + (uint32_t)eid[u] * (uint32_t)EW;
             const T fe = rec[BP], dfe = rd[BP];
-            const T ps = filt<T, MAXB>(ws, bs, rec, fe), pe = filt<T, MAXB>(we, be, rec, fe), pm = filt<T, MAXB>(wm, bm, rec, fe);
-            const T qs = filt<T, MAXB>(ws, bs, rd, dfe), qe = filt<T, MAXB>(we, be, rd, dfe), qm = filt<T, MAXB>(wm, bm, rd, dfe);
+            const T ps = filt(ws, bs, rec, fe), pe = filt(we, be, rec, fe), pm = filt(wm, bm, rec, fe);
+            const T qs = filt(ws, bs, rd, dfe), qe = filt(we, be, rd, dfe), qm = filt(wm, bm, rd, dfe);
             T y[5];
             lane_y<T>(rec + BP, cm.l, y);
             T dgs = T(0), dge = T(0);
