@@ -149,8 +149,12 @@ __device__ __forceinline__ void lane_y(const T* __restrict__ tail, int l, T (&y)
   y[4] = y24;
 }
 
-template <typename T, int MAXB, int U>
-__global__ void __launch_bounds__(256) k_message_fwd_sb(SbArgs a, const T* __restrict__ eb, const T* __restrict__ h,
+// WPE = resident waves per SIMD the register allocation must allow.  Measured (QM9-1024, fp32, B = 20): these
+// kernels are bound by serial latency chains of one workgroup, so occupancy beats registers: 3 -> 4 waves per SIMD
+// (<= 128 VGPRs, U = 2 forward / 1 reverse) took the forward pass from 0.39 to 0.30 ms and the reverse pass from
+// 0.72 to 0.57 ms; 5 waves (96 VGPRs) spills the weight rows and is 3-5x slower.
+template <typename T, int MAXB, int U, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_message_fwd_sb(SbArgs a, const T* __restrict__ eb, const T* __restrict__ h,
                                                         const T* __restrict__ xhat, const T* __restrict__ s_in,
                                                         const T* __restrict__ x_in, const T* __restrict__ w_rbf,
                                                         const T* __restrict__ b_rbf, T* __restrict__ s_out,
@@ -253,8 +257,8 @@ __device__ __forceinline__ double wave_total(double v) { return wave_sum<double>
 
 constexpr int SB_RED = 64;  // edges whose reduction slots fit in LDS between two finalisations
 
-template <typename T, int MAXB, int U>
-__global__ void __launch_bounds__(256) k_message_bwd_sb(SbArgs a, const T* __restrict__ eb, const T* __restrict__ ed,
+template <typename T, int MAXB, int U, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_message_bwd_sb(SbArgs a, const T* __restrict__ eb, const T* __restrict__ ed,
                                                         const T* __restrict__ h, const T* __restrict__ xhat,
                                                         const T* __restrict__ grad_s, const T* __restrict__ grad_x,
                                                         const T* __restrict__ w_rbf, const T* __restrict__ b_rbf,
@@ -439,16 +443,16 @@ using namespace xeq;
   do {                                                                                                              \
     if (dtype == XEQ_F32) {                                                                                         \
       using T = float;                                                                                              \
-      if (num_basis <= 8) hipLaunchKernelGGL((KERNEL<T, 8, UF>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
-      else if (num_basis <= 16) hipLaunchKernelGGL((KERNEL<T, 16, UF>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else if (num_basis <= 20) hipLaunchKernelGGL((KERNEL<T, 20, UF>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<T, 32, UF>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
+      if (num_basis <= 8) hipLaunchKernelGGL((KERNEL<T, 8, UF, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+      else if (num_basis <= 16) hipLaunchKernelGGL((KERNEL<T, 16, UF, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (num_basis <= 20) hipLaunchKernelGGL((KERNEL<T, 20, UF, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<T, 32, UF, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
     } else if (dtype == XEQ_F64) {                                                                                  \
       using T = double;                                                                                             \
-      if (num_basis <= 8) hipLaunchKernelGGL((KERNEL<T, 8, UD>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
-      else if (num_basis <= 16) hipLaunchKernelGGL((KERNEL<T, 16, UD>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else if (num_basis <= 20) hipLaunchKernelGGL((KERNEL<T, 20, UD>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<T, 32, UD>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
+      if (num_basis <= 8) hipLaunchKernelGGL((KERNEL<T, 8, UD, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+      else if (num_basis <= 16) hipLaunchKernelGGL((KERNEL<T, 16, UD, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (num_basis <= 20) hipLaunchKernelGGL((KERNEL<T, 20, UD, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<T, 32, UD, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);           \
     } else {                                                                                                        \
       xeq::set_error("unsupported dtype %d", dtype);                                                                \
       return XEQ_ERR_INVALID_ARGUMENT;                                                                              \
@@ -489,7 +493,7 @@ int xeq_message_fwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.other = nbr;
   a.xl = xhat_layout;
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
-  XEQ_SB_DISPATCH(k_message_fwd_sb, 4, 2, a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)s_in, (const T*)x_in,
+  XEQ_SB_DISPATCH(k_message_fwd_sb, 2, 2, a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)s_in, (const T*)x_in,
                   (const T*)w_rbf, (const T*)b_rbf, (T*)s_out, (T*)x_out);
   XEQ_CHECK_LAUNCH("xeq_message_fwd_sb");
   return XEQ_OK;
@@ -509,7 +513,7 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.other = center;
   a.xl = xhat_layout;
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
-  XEQ_SB_DISPATCH(k_message_bwd_sb, 2, 1, a, (const T*)basis, (const T*)dbasis, (const T*)h, (const T*)xhat,
+  XEQ_SB_DISPATCH(k_message_bwd_sb, 1, 1, a, (const T*)basis, (const T*)dbasis, (const T*)h, (const T*)xhat,
                   (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat,
                   (T*)grad_vec);
   XEQ_CHECK_LAUNCH("xeq_message_bwd_sb");
