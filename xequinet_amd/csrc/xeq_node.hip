@@ -9,6 +9,8 @@
 // three ordinary GEMMs without transposes, and channel-on-lane accesses are coalesced.
 // Tensors that cross the module boundary (s, x and their gradients) keep the
 // reference's e3nn mul_ir layout.
+#include <stdlib.h>
+
 #include "xeq_common.h"
 
 namespace xeq {
@@ -248,6 +250,341 @@ __global__ void k_update_out_bwd(const T* __restrict__ g_s_out, const T* __restr
   }
 }
 
+// =================================================================================================
+// Fast paths.  The kernels above index one element per thread with 64-bit divisions by run-time row
+// widths; the ones below give a thread a fixed COLUMN (its channel/component decoding, BT offsets
+// and weights are computed once) and walk NPB consecutive nodes with all loads of a node issued
+// together, and the norms keep a node's row in registers (one wave per node, DPP reductions).
+// =================================================================================================
+constexpr int NODE_NPB = 8;  // nodes per workgroup of the column kernels
+
+__device__ __forceinline__ float wave_total_n(float v) {
+#define XEQ_N_DPP(v, ctrl, rmask) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), ctrl, rmask, 0xF, true)))
+  v = XEQ_N_DPP(v, 0xB1, 0xF);
+  v = XEQ_N_DPP(v, 0x4E, 0xF);
+  v = XEQ_N_DPP(v, 0x141, 0xF);
+  v = XEQ_N_DPP(v, 0x140, 0xF);
+  v = XEQ_N_DPP(v, 0x142, 0xA);
+  v = XEQ_N_DPP(v, 0x143, 0xC);
+#undef XEQ_N_DPP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double wave_total_n(double v) { return wave_sum<double>(v); }
+
+// per-thread description of gate channel u in the BT buffers
+struct ChanBT {
+  int l, d, up;
+  int64_t base_x, base_uv;  // element offset of (n = 0, m = 0): xhat-like (width mul) / U|V pair (width 2 mul)
+  int w;                    // mul_l
+  int off;                  // flat e3nn offset of component 0
+};
+__device__ __forceinline__ ChanBT chan_bt(const Irreps& ir, int64_t N, int u) {
+  ChanBT c;
+  ir.locate(u, c.l, c.off);
+  c.d = 2 * c.l + 1;
+  c.w = ir.mul[c.l];
+  c.up = u - (c.l == 0 ? 0 : (c.l == 1 ? ir.mul[0] : ir.mul[0] + ir.mul[1]));
+  const int64_t b = c.l == 0 ? 0 : (c.l == 1 ? (int64_t)ir.mul[0] : (int64_t)ir.mul[0] + 3 * ir.mul[1]);
+  c.base_x = N * b + c.up;
+  c.base_uv = 2 * N * b + c.up;
+  return c;
+}
+
+// v = |V|, p = <U,V>: thread = channel, NPB nodes per workgroup
+template <typename T>
+__global__ void __launch_bounds__(256) k_uv_reduce_fwd_c(const T* __restrict__ uv_bt, int64_t N, Irreps ir, T eps,
+                                                          T* __restrict__ cat, int64_t ld_cat, int F, T* __restrict__ p) {
+  const int C = ir.C(), u = threadIdx.x;
+  if (u >= C) return;
+  const ChanBT c = chan_bt(ir, N, u);
+  const int64_t n0 = (int64_t)blockIdx.x * NODE_NPB;
+  const int w2 = 2 * c.w;
+#pragma unroll 4
+  for (int j = 0; j < NODE_NPB; ++j) {
+    const int64_t n = n0 + j;
+    if (n >= N) break;
+    const T* row = uv_bt + c.base_uv + n * c.d * w2;
+    T vv = T(0), uv = T(0);
+    for (int m = 0; m < c.d; ++m) {
+      const T U = row[m * w2], V = row[m * w2 + c.w];
+      vv += V * V;
+      uv += U * V;
+    }
+    cat[n * ld_cat + F + u] = sqrt_<T>(vv + eps * eps) - eps;
+    p[n * C + u] = uv;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_uv_reduce_bwd_c(const T* __restrict__ uv_bt, const T* __restrict__ g_p,
+                                                          const T* __restrict__ g_cat, int64_t ld_cat, int F, int64_t N,
+                                                          Irreps ir, T eps, T* __restrict__ g_uv_bt) {
+  const int C = ir.C(), u = threadIdx.x;
+  if (u >= C) return;
+  const ChanBT c = chan_bt(ir, N, u);
+  const int64_t n0 = (int64_t)blockIdx.x * NODE_NPB;
+  const int w2 = 2 * c.w;
+#pragma unroll 2
+  for (int j = 0; j < NODE_NPB; ++j) {
+    const int64_t n = n0 + j;
+    if (n >= N) break;
+    const int64_t r0 = c.base_uv + n * c.d * w2;
+    const T gp = g_p[n * C + u], gc = g_cat[n * ld_cat + F + u];
+    T U[5], V[5], GU[5];
+    T vv = T(0);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      if (m < c.d) {
+        U[m] = uv_bt[r0 + m * w2];
+        V[m] = uv_bt[r0 + m * w2 + c.w];
+        GU[m] = g_uv_bt[r0 + m * w2];
+        vv += V[m] * V[m];
+      }
+    }
+    const T gv = gc / sqrt_<T>(vv + eps * eps);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      if (m < c.d) {
+        g_uv_bt[r0 + m * w2] = GU[m] + gp * V[m];
+        g_uv_bt[r0 + m * w2 + c.w] = gp * U[m] + gv * V[m];
+      }
+    }
+  }
+}
+
+// update output stage: thread = flat column of [s (F) | x (D)], column blocks of 256
+template <typename T>
+__global__ void __launch_bounds__(256) k_update_out_fwd_c(const T* __restrict__ s, const T* __restrict__ x,
+                                                           const T* __restrict__ uv_bt, const T* __restrict__ a,
+                                                           const T* __restrict__ ip, int64_t N, int F, Irreps ir,
+                                                           int ncb, T* __restrict__ s_out, T* __restrict__ x_out) {
+  const int D = ir.D(), C = ir.C(), A = C + 2 * F;
+  const int cb = blockIdx.x % ncb;
+  const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NODE_NPB;
+  const int f = cb * 256 + threadIdx.x;
+  if (f >= F + D) return;
+  if (f < F) {
+#pragma unroll 4
+    for (int j = 0; j < NODE_NPB; ++j) {
+      const int64_t n = n0 + j;
+      if (n >= N) break;
+      s_out[n * F + f] = s[n * F + f] + a[n * A + C + f] * ip[n * F + f] + a[n * A + C + F + f];
+    }
+  } else {
+    const int fx = f - F;
+    int u, m;
+    chan_of_flat(ir, fx, u, m);
+    const ChanBT c = chan_bt(ir, N, u);
+    const int w2 = 2 * c.w;
+    const int64_t ub = c.base_uv + (int64_t)m * w2;
+#pragma unroll 4
+    for (int j = 0; j < NODE_NPB; ++j) {
+      const int64_t n = n0 + j;
+      if (n >= N) break;
+      x_out[n * D + fx] = x[n * D + fx] + uv_bt[ub + n * c.d * w2] * a[n * A + u];
+    }
+  }
+}
+
+// thread = column of [gate channels (C) | scalar channels (F)]
+template <typename T>
+__global__ void __launch_bounds__(256) k_update_out_bwd_c(const T* __restrict__ g_s_out, const T* __restrict__ g_x_out,
+                                                           const T* __restrict__ uv_bt, const T* __restrict__ a,
+                                                           const T* __restrict__ ip, int64_t N, int F, Irreps ir, int ncb,
+                                                           T* __restrict__ g_a, T* __restrict__ g_ip,
+                                                           T* __restrict__ g_uv_bt) {
+  const int D = ir.D(), C = ir.C(), A = C + 2 * F;
+  const int cb = blockIdx.x % ncb;
+  const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NODE_NPB;
+  const int f = cb * 256 + threadIdx.x;
+  if (f >= C + F) return;
+  if (f < C) {
+    const ChanBT c = chan_bt(ir, N, f);
+    const int w2 = 2 * c.w;
+#pragma unroll 2
+    for (int j = 0; j < NODE_NPB; ++j) {
+      const int64_t n = n0 + j;
+      if (n >= N) break;
+      const int64_t r0 = c.base_uv + n * c.d * w2;
+      const T avv = a[n * A + f];
+      T gx[5], U[5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        if (m < c.d) {
+          gx[m] = g_x_out[n * D + c.off + m];
+          U[m] = uv_bt[r0 + m * w2];
+        }
+      }
+      T acc = T(0);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        if (m < c.d) {
+          acc += U[m] * gx[m];
+          g_uv_bt[r0 + m * w2] = gx[m] * avv;
+        }
+      }
+      g_a[n * A + f] = acc;
+    }
+  } else {
+    const int cc = f - C;
+#pragma unroll 4
+    for (int j = 0; j < NODE_NPB; ++j) {
+      const int64_t n = n0 + j;
+      if (n >= N) break;
+      const T gs = g_s_out[n * F + cc];
+      g_a[n * A + C + cc] = gs * ip[n * F + cc];
+      g_a[n * A + C + F + cc] = gs;
+      g_ip[n * F + cc] = gs * a[n * A + C + cc];
+    }
+  }
+}
+
+// ---- norms with the node's row in registers: one wave per node, SS scalar slots and XS equivariant slots per lane
+template <typename T, int SS, int XS>
+__global__ void __launch_bounds__(256) k_norm_fwd_r(const T* __restrict__ s, const T* __restrict__ x,
+                                                     const T* __restrict__ lnw, const T* __restrict__ lnb,
+                                                     const T* __restrict__ eqw, const T* __restrict__ eqb, int64_t N, int F,
+                                                     Irreps ir, T* __restrict__ shat, int64_t ld_s,
+                                                     T* __restrict__ xhat_bt, T* __restrict__ stats) {
+  const int D = ir.D(), C = ir.C(), m0 = ir.mul[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // slot decoding, once per wave
+  T w_s[SS], b_s[SS], w_x[XS], b_x[XS];
+  int64_t o_x[XS];  // BT offset of (n = 0)
+  int st_x[XS];     // BT node stride
+#pragma unroll
+  for (int k = 0; k < SS; ++k) {
+    const int f = lane + 64 * k;
+    w_s[k] = f < F ? lnw[f] : T(0);
+    b_s[k] = f < F ? lnb[f] : T(0);
+  }
+#pragma unroll
+  for (int k = 0; k < XS; ++k) {
+    const int f = lane + 64 * k;
+    int u = 0, m = 0;
+    if (f < D) chan_of_flat(ir, f, u, m);
+    const ChanBT c = chan_bt(ir, N, u);
+    w_x[k] = f < D ? eqw[u] : T(0);
+    b_x[k] = f < m0 ? eqb[f] : T(0);
+    o_x[k] = c.base_x + (int64_t)m * c.w;
+    st_x[k] = c.d * c.w;
+  }
+  for (int64_t n = wid; n < N; n += nw) {
+    T sv[SS], xv[XS];
+#pragma unroll
+    for (int k = 0; k < SS; ++k) sv[k] = (lane + 64 * k < F) ? s[n * F + lane + 64 * k] : T(0);
+#pragma unroll
+    for (int k = 0; k < XS; ++k) xv[k] = (lane + 64 * k < D) ? x[n * D + lane + 64 * k] : T(0);
+    T a = T(0), q = T(0);
+#pragma unroll
+    for (int k = 0; k < SS; ++k) a += sv[k];
+#pragma unroll
+    for (int k = 0; k < XS; ++k) q += (lane + 64 * k < m0) ? xv[k] : T(0);
+    const T mean = wave_total_n(a) / T(F);
+    const T mean0 = m0 > 0 ? wave_total_n(q) / T(m0) : T(0);
+    T v = T(0), sq = T(0);
+#pragma unroll
+    for (int k = 0; k < SS; ++k) {
+      const T d = (lane + 64 * k < F) ? sv[k] - mean : T(0);
+      sv[k] = d;
+      v += d * d;
+    }
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+      const int f = lane + 64 * k;
+      const T d = f < D ? xv[k] - (f < m0 ? mean0 : T(0)) : T(0);
+      xv[k] = d;
+      sq += d * d;
+    }
+    const T rstd = T(1) / sqrt_<T>(wave_total_n(v) / T(F) + T(1e-5));
+    const T r = T(1) / sqrt_<T>(wave_total_n(sq) / T(C) + T(1e-5));
+#pragma unroll
+    for (int k = 0; k < SS; ++k)
+      if (lane + 64 * k < F) shat[n * ld_s + lane + 64 * k] = sv[k] * rstd * w_s[k] + b_s[k];
+#pragma unroll
+    for (int k = 0; k < XS; ++k)
+      if (lane + 64 * k < D) xhat_bt[o_x[k] + n * st_x[k]] = xv[k] * r * w_x[k] + b_x[k];
+    if (lane == 0) {
+      stats[4 * n] = mean;
+      stats[4 * n + 1] = rstd;
+      stats[4 * n + 2] = mean0;
+      stats[4 * n + 3] = r;
+    }
+  }
+}
+
+template <typename T, int SS, int XS>
+__global__ void __launch_bounds__(256) k_norm_bwd_r(const T* __restrict__ s, const T* __restrict__ x,
+                                                     const T* __restrict__ lnw, const T* __restrict__ eqw,
+                                                     const T* __restrict__ stats, int64_t N, int F, Irreps ir,
+                                                     const T* __restrict__ g_shat, int64_t ld_gs,
+                                                     const T* __restrict__ g_xhat_bt, const T* __restrict__ res_s,
+                                                     const T* __restrict__ res_x, T* __restrict__ g_s, T* __restrict__ g_x) {
+  const int D = ir.D(), C = ir.C(), m0 = ir.mul[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  T w_s[SS], w_x[XS];
+  int64_t o_x[XS];
+  int st_x[XS];
+#pragma unroll
+  for (int k = 0; k < SS; ++k) w_s[k] = (lane + 64 * k < F) ? lnw[lane + 64 * k] : T(0);
+#pragma unroll
+  for (int k = 0; k < XS; ++k) {
+    const int f = lane + 64 * k;
+    int u = 0, m = 0;
+    if (f < D) chan_of_flat(ir, f, u, m);
+    const ChanBT c = chan_bt(ir, N, u);
+    w_x[k] = f < D ? eqw[u] : T(0);
+    o_x[k] = c.base_x + (int64_t)m * c.w;
+    st_x[k] = c.d * c.w;
+  }
+  for (int64_t n = wid; n < N; n += nw) {
+    const T mean = stats[4 * n], rstd = stats[4 * n + 1], mean0 = stats[4 * n + 2], r = stats[4 * n + 3];
+    T yh[SS], dy[SS], rs[SS], xc[XS], gw[XS], rx[XS];
+#pragma unroll
+    for (int k = 0; k < SS; ++k) {
+      const int f = lane + 64 * k;
+      const bool ok = f < F;
+      yh[k] = ok ? (s[n * F + f] - mean) * rstd : T(0);
+      dy[k] = ok ? g_shat[n * ld_gs + f] * w_s[k] : T(0);
+      rs[k] = (ok && res_s) ? res_s[n * F + f] : T(0);
+    }
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+      const int f = lane + 64 * k;
+      const bool ok = f < D;
+      xc[k] = ok ? x[n * D + f] - (f < m0 ? mean0 : T(0)) : T(0);
+      gw[k] = ok ? g_xhat_bt[o_x[k] + n * st_x[k]] * w_x[k] : T(0);
+      rx[k] = (ok && res_x) ? res_x[n * D + f] : T(0);
+    }
+    T a1 = T(0), a2 = T(0), dotp = T(0);
+#pragma unroll
+    for (int k = 0; k < SS; ++k) {
+      a1 += dy[k];
+      a2 += dy[k] * yh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < XS; ++k) dotp += gw[k] * xc[k];
+    a1 = wave_total_n(a1) / T(F);
+    a2 = wave_total_n(a2) / T(F);
+    const T coef = wave_total_n(dotp) * r * r * r / T(C);
+    T gs = T(0);
+#pragma unroll
+    for (int k = 0; k < XS; ++k) gs += (lane + 64 * k < m0) ? r * gw[k] - coef * xc[k] : T(0);
+    const T gmean = m0 > 0 ? wave_total_n(gs) / T(m0) : T(0);
+#pragma unroll
+    for (int k = 0; k < SS; ++k)
+      if (lane + 64 * k < F) g_s[n * F + lane + 64 * k] = rstd * (dy[k] - a1 - yh[k] * a2) + rs[k];
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+      const int f = lane + 64 * k;
+      if (f < D) g_x[n * D + f] = r * gw[k] - coef * xc[k] - (f < m0 ? gmean : T(0)) + rx[k];
+    }
+  }
+}
+
 static inline int irreps_from(const int32_t mul[3], Irreps& ir, const char* who) {
   for (int l = 0; l < 3; ++l) {
     if (mul[l] < 0) {
@@ -282,10 +619,18 @@ int xeq_norm_fwd(int dtype, const void* s, const void* x, const void* ln_w, cons
   XEQ_IR("xeq_norm_fwd");
   XEQ_CHECK_ARG(node_dim > 0 && ld_s >= node_dim, "xeq_norm_fwd: bad node_dim / row stride");
   if (n <= 0) return XEQ_OK;
+  const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512;  // row in registers: 2 + 8 slots per lane
+  // ~4 nodes per wave: the slot decoding of a wave is amortised, every CU still gets >= 16 waves at 18k nodes
+  const unsigned wgrid = (unsigned)((n + 15) / 16 < 65536 ? (n + 15) / 16 : 65536);
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_norm_fwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)s,
-                       (const T*)x, (const T*)ln_w, (const T*)ln_b, (const T*)eq_w, (const T*)eq_b, n, node_dim, ir,
-                       do_norm, (T*)shat, ld_s, (T*)xhat_bt, (T*)stats);
+    if (fast)
+      hipLaunchKernelGGL((k_norm_fwd_r<T, 2, 8>), dim3(wgrid), dim3(256), 0, (hipStream_t)stream, (const T*)s, (const T*)x,
+                         (const T*)ln_w, (const T*)ln_b, (const T*)eq_w, (const T*)eq_b, n, node_dim, ir, (T*)shat, ld_s,
+                         (T*)xhat_bt, (T*)stats);
+    else
+      hipLaunchKernelGGL((k_norm_fwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+                         (const T*)x, (const T*)ln_w, (const T*)ln_b, (const T*)eq_w, (const T*)eq_b, n, node_dim, ir,
+                         do_norm, (T*)shat, ld_s, (T*)xhat_bt, (T*)stats);
   });
   XEQ_CHECK_LAUNCH("xeq_norm_fwd");
   return XEQ_OK;
@@ -297,10 +642,20 @@ int xeq_norm_bwd(int dtype, const void* s, const void* x, const void* ln_w, cons
   XEQ_IR("xeq_norm_bwd");
   XEQ_CHECK_ARG(node_dim > 0 && ld_gs >= node_dim, "xeq_norm_bwd: bad node_dim / row stride");
   if (n <= 0) return XEQ_OK;
+  // measured (QM9-1024): the element-per-lane kernel already moves its 230 MB at 4.1 TB/s (56 us); the
+  // row-in-register form is latency-bound here (71-91 us) and stays opt-in for experiments
+  const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512 && getenv("XEQ_NORM_BWD_ROWREG") != nullptr;
+  const unsigned wgrid = (unsigned)((n + 3) / 4);
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_norm_bwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)s,
-                       (const T*)x, (const T*)ln_w, (const T*)eq_w, (const T*)stats, n, node_dim, ir, do_norm,
-                       (const T*)g_shat, ld_gs, (const T*)g_xhat_bt, (const T*)res_s, (const T*)res_x, (T*)g_s, (T*)g_x);
+    if (fast)
+      hipLaunchKernelGGL((k_norm_bwd_r<T, 2, 8>), dim3(wgrid), dim3(256), 0, (hipStream_t)stream, (const T*)s, (const T*)x,
+                         (const T*)ln_w, (const T*)eq_w, (const T*)stats, n, node_dim, ir, (const T*)g_shat, ld_gs,
+                         (const T*)g_xhat_bt, (const T*)res_s, (const T*)res_x, (T*)g_s, (T*)g_x);
+    else
+      hipLaunchKernelGGL((k_norm_bwd<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+                         (const T*)x, (const T*)ln_w, (const T*)eq_w, (const T*)stats, n, node_dim, ir, do_norm,
+                         (const T*)g_shat, ld_gs, (const T*)g_xhat_bt, (const T*)res_s, (const T*)res_x, (T*)g_s,
+                         (T*)g_x);
   });
   XEQ_CHECK_LAUNCH("xeq_norm_bwd");
   return XEQ_OK;
@@ -312,8 +667,12 @@ int xeq_uv_reduce_fwd(int dtype, const void* uv_bt, int64_t n, const int32_t mul
   if (n <= 0) return XEQ_OK;
   const int64_t total = n * ir.C();
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_uv_reduce_fwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const T*)uv_bt, n, ir, (T)eps, (T*)cat, ld_cat, node_dim, (T*)p);
+    if (ir.C() <= 256)
+      hipLaunchKernelGGL((k_uv_reduce_fwd_c<T>), dim3((unsigned)((n + NODE_NPB - 1) / NODE_NPB)), dim3(256), 0,
+                         (hipStream_t)stream, (const T*)uv_bt, n, ir, (T)eps, (T*)cat, ld_cat, node_dim, (T*)p);
+    else
+      hipLaunchKernelGGL((k_uv_reduce_fwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)uv_bt, n, ir, (T)eps, (T*)cat, ld_cat, node_dim, (T*)p);
   });
   XEQ_CHECK_LAUNCH("xeq_uv_reduce_fwd");
   return XEQ_OK;
@@ -325,8 +684,13 @@ int xeq_uv_reduce_bwd(int dtype, const void* uv_bt, const void* g_p, const void*
   if (n <= 0) return XEQ_OK;
   const int64_t total = n * ir.C();
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_uv_reduce_bwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps, (T*)g_uv_bt);
+    if (ir.C() <= 256)
+      hipLaunchKernelGGL((k_uv_reduce_bwd_c<T>), dim3((unsigned)((n + NODE_NPB - 1) / NODE_NPB)), dim3(256), 0,
+                         (hipStream_t)stream, (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir,
+                         (T)eps, (T*)g_uv_bt);
+    else
+      hipLaunchKernelGGL((k_uv_reduce_bwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps, (T*)g_uv_bt);
   });
   XEQ_CHECK_LAUNCH("xeq_uv_reduce_bwd");
   return XEQ_OK;
@@ -336,11 +700,12 @@ int xeq_update_out_fwd(int dtype, const void* s, const void* x, const void* uv_b
                        int64_t n, int node_dim, const int32_t mul[3], void* s_out, void* x_out, void* stream) {
   XEQ_IR("xeq_update_out_fwd");
   if (n <= 0) return XEQ_OK;
-  const int64_t total = n * (node_dim + ir.D());
+  const int ncb = (node_dim + ir.D() + 255) / 256;
+  const int64_t nblk = (n + NODE_NPB - 1) / NODE_NPB * ncb;
+  XEQ_CHECK_ARG(nblk < (1ll << 31), "xeq_update_out_fwd: too many nodes for one launch");
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_update_out_fwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const T*)s, (const T*)x, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir, (T*)s_out,
-                       (T*)x_out);
+    hipLaunchKernelGGL((k_update_out_fwd_c<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+                       (const T*)x, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir, ncb, (T*)s_out, (T*)x_out);
   });
   XEQ_CHECK_LAUNCH("xeq_update_out_fwd");
   return XEQ_OK;
@@ -351,11 +716,13 @@ int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, cons
                        void* g_uv_bt, void* stream) {
   XEQ_IR("xeq_update_out_bwd");
   if (n <= 0) return XEQ_OK;
-  const int64_t total = n * (node_dim + ir.C());
+  const int ncb = (node_dim + ir.C() + 255) / 256;
+  const int64_t nblk = (n + NODE_NPB - 1) / NODE_NPB * ncb;
+  XEQ_CHECK_ARG(nblk < (1ll << 31), "xeq_update_out_bwd: too many nodes for one launch");
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_update_out_bwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_update_out_bwd_c<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                        (const T*)g_s_out, (const T*)g_x_out, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir,
-                       (T*)g_a, (T*)g_ip, (T*)g_uv_bt);
+                       ncb, (T*)g_a, (T*)g_ip, (T*)g_uv_bt);
   });
   XEQ_CHECK_LAUNCH("xeq_update_out_bwd");
   return XEQ_OK;
