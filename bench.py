@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--workload", default="qm9_1024", choices=["qm9_1024", "qm9_64", "md17_4096", "water_512"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-autotune", action="store_true",
+                    help="keep the libraries' default GEMM heuristics (xequinet_amd/tuning.py)")
     args = ap.parse_args()
 
     from xequinet_amd import dist as xdist
@@ -116,6 +118,9 @@ def main():
     cell_d = None if cell is None else torch.tensor(cell, dtype=dtype, device=dev)
     pbc_d = None if cell is None else torch.tensor([[True, True, True]], device=dev)
     transform = NeighborTransform(model.cutoff_radius)
+    if not args.no_gemm_autotune:
+        from xequinet_amd.tuning import enable_gemm_autotune
+        enable_gemm_autotune()   # every GEMM shape is timed once, during the warm-up steps
 
     def step():
         batch = XequiBatch(pos_d.detach(), z_d, ptr_d, pbc=pbc_d, cell=cell_d)
@@ -175,7 +180,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: QM9-shape synthetic molecules per GPU, 5 A cutoff, default XPaiNN (865141 params, random init), "
                                    "neighbour list + energy + forces", "atoms_per_gpu": int(n_atoms), "edges_per_gpu": int(n_edges),
-                       "parallelism": f"molecule shards x{world}, no collectives"},
+                       "parallelism": f"molecule shards x{world}, no collectives",
+                       "library_gemm_selection": "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,36 @@
+"""Library-GEMM selection for the dense node-side contractions.
+
+The dense contractions of the path (scalar_mlp, update_mlp, o3.Linear, dot_lin, energy MLP: SURVEY 8a rows a9, a14,
+a15) are plain library GEMMs on hipBLASLt / rocBLAS.  Their default heuristics pick slow kernels for the skinny shapes
+of this model ([N, 32..576] x [32..576]): on QM9-1024 the 54 GEMMs of one evaluation take 1.48 ms by default and
+1.05 ms with each shape timed once against the libraries' candidate kernels.  `enable_gemm_autotune()` switches that
+selection on through PyTorch's TunableOp (a one-off cost of ~50 ms per distinct GEMM shape at its first call, i.e.
+during warm-up); the chosen kernels are fp32 GEMMs of the same libraries, so results stay within fp32 rounding.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+__all__ = ["enable_gemm_autotune", "gemm_autotune_enabled"]
+
+
+def enable_gemm_autotune(max_tuning_ms: int = 100, results_file: str | None = None) -> bool:
+    """Time every new GEMM shape once and keep the fastest library kernel.  Returns False (and does nothing) when no
+    HIP device is present."""
+    if not torch.cuda.is_available():
+        return False
+    t = torch.cuda.tunable
+    t.enable(True)
+    t.tuning_enable(True)
+    t.set_max_tuning_duration(int(max_tuning_ms))
+    if results_file is None:
+        # per-process scratch file: nothing is written into the caller's working directory
+        results_file = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"xeq_tunableop_{os.getpid()}.csv")
+    t.set_filename(results_file, insert_device_ordinal=False)
+    return True
+
+
+def gemm_autotune_enabled() -> bool:
+    return torch.cuda.is_available() and torch.cuda.tunable.is_enabled()
