@@ -187,6 +187,40 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
                        int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec,
                        int xhat_layout, void* stream);
 
+/* "Wave / matrix-core" form of the fused message (f32; the default whenever the channel layout allows it).
+ * The filter (rbf_lin, nn/xpainn.py:117,140: [2C+F, B+1] x [B+1] per edge) runs on the matrix cores as exact-f32
+ * MFMA with the channel on the lane and 16 consecutive edges in the 16 accumulator registers; each half-wave
+ * is a STREAM over a contiguous range of CSR segments, so the aggregation (index_add, nn/xpainn.py:158-159) is a
+ * running sum in registers that is stored once per node: deterministic, no atomics, no read-modify-write.
+ * A wave owns (node range, 32 gate channels of one l).  Requires node_dim == mul[0], mul[l] % 32 == 0,
+ * num_basis <= 31 (xeq_message_wm_supported; otherwise XEQ_ERR_UNSUPPORTED: use the _sb form).
+ *   basis/dbasis[E, W], W = xeq_edge_basis_wm_width(B): per-edge records (value / d-by-dd), once per evaluation.
+ *   stream_ptr[2 n_ranges + 1]: node boundaries of the streams (non-decreasing, first 0, last N); range w is
+ *   processed by one wave per unit, stream 2w by its lanes 0-31 and stream 2w+1 by lanes 32-63.  Balance them
+ *   on edge count (about 128 edges per stream).
+ *   forward walks the edges sorted by center: c_rowptr[N+1]; slot_eid/slot_center/slot_nbr[E] = edge id (NULL:
+ *   identity), center and neighbor node of each slot of that order (int32).  The reverse pass walks them sorted
+ *   by neighbor (n_rowptr; slot arrays in that order) and writes per-unit partials of dL/dd and dL/dY_lm into
+ *   parts[xeq_message_wm_parts_floats(E, mul)]; xeq_message_wm_edge_grad sums them in fixed order into
+ *   grad_vec[E,3]. */
+int xeq_message_wm_supported(int num_basis, int node_dim, const int32_t mul[3]);   /* 1 / 0, not a status */
+int xeq_edge_basis_wm_width(int num_basis);
+int xeq_edge_basis_wm(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis, double cutoff,
+                      const void* p0, const void* p1, void* basis, void* dbasis, void* stream);
+int xeq_message_fwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* stream_ptr, const int32_t* c_rowptr,
+                       const int32_t* slot_eid, const int32_t* slot_center, const int32_t* slot_nbr, const void* basis,
+                       const void* h, const void* xhat, const void* s_in, const void* x_in, const void* w_rbf,
+                       const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out,
+                       int xhat_layout, void* stream);
+int xeq_message_bwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* stream_ptr, const int32_t* n_rowptr,
+                       const int32_t* slot_eid, const int32_t* slot_nbr, const int32_t* slot_center, const void* basis,
+                       const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
+                       const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,
+                       void* grad_xhat, void* parts, int xhat_layout, void* stream);
+int64_t xeq_message_wm_parts_floats(int64_t n_edges, const int32_t mul[3]);   /* a size, not a status */
+int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul[3], const void* parts, void* grad_vec,
+                             void* stream);
+
 /* ------------------------------------------------- node-side fused elementwise stages
  * Internal "BT" layout of equivariant intermediates (xhat_layout = 1 above): block-major over
  * l, then node, then m, then channel: addr(n, u' in block l, m) = N*base_l + (n*(2l+1)+m)*W_l + u'

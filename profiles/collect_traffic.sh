@@ -10,3 +10,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python3 profiles/summarise_traffic.py $tag gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE
+cp profiles/${tag}_traffic_pmc.csv profiles/traffic.json gpurun_out/   # only gpurun_out/ travels back
+rm -rf gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE   # raw counter dumps exceed the 64 MiB copy-back limit

@@ -262,11 +262,11 @@ def test_radial_and_scatter_ops():
 
 
 # ------------------------------------------------------------------- fused message
-def _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, dtype, shuffle, seed=0):
+def _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, dtype, shuffle, seed=0, with_ptr=False, n_mol=6):
     from xequinet_amd import ops
 
     rng = np.random.default_rng(seed)
-    pos, z, ptr = orc.synth_qm9_batch(6, seed=seed + 10)
+    pos, z, ptr = orc.synth_qm9_batch(n_mol, seed=seed + 10)
     rc = 4.0
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, rc)
     if shuffle:
@@ -300,7 +300,7 @@ def _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, dtype, shuffle, se
     # ---- HIP
     dev = lambda t: None if t is None else t.to(dtype).to(DEV)
     hg, xg, vg, sg, xig = (dev(t).requires_grad_() for t in (h, xhat, vec, s, x))
-    graph = ops.EdgeGraph(_t(ei), N)
+    graph = ops.EdgeGraph(_t(ei), N, ptr=_t(ptr) if with_ptr else None)  # graph boundaries enable the wm kernels
     mul = [0, 0, 0]
     for m_, l_, _ in orc.parse_irreps(irreps):
         mul[l_] = m_
@@ -330,6 +330,94 @@ def test_fused_message_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff_kind, shuff
         b = b.detach().numpy()
         scale = max(1.0, np.abs(b).max())
         np.testing.assert_allclose(a, b, rtol=tol, atol=tol * scale, err_msg=name)
+
+
+WM_CASES = [
+    ("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", False),
+    ("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", True),
+    ("64x0e + 32x1o + 32x2e", 64, 8, "gaussian", "polynomial", True),
+    ("32x0e + 64x2e", 32, 17, "bessel", "cosine", False),
+    ("96x0e + 32x1o", 96, 31, "bessel", "polynomial", False),
+]
+
+
+@pytest.mark.parametrize("eps", ["16", "128", "100000"])
+@pytest.mark.parametrize("irreps,node_dim,B,rbf_kind,cutoff_kind,shuffle", WM_CASES)
+def test_fused_message_matrix_core_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff_kind, shuffle, eps, monkeypatch):
+    """The wave / matrix-core kernels (xeq_message_{fwd,bwd}_wm, f32) against the fp64 oracle: every output of the
+    forward pass and every gradient of the reverse pass, ragged molecules (3..29 atoms), shuffled edges, K = B + 1
+    from 9 to 32, and stream lengths from one tile per stream to one wave for the whole batch."""
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    monkeypatch.setenv("XEQ_WM_EDGES_PER_STREAM", eps)
+    got, want = _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, torch.float32, shuffle, n_mol=40)
+    names = ["s_out", "x_out", "grad_h", "grad_xhat", "grad_vec", "grad_s", "grad_x"]
+    for name, a, b in zip(names, got, want):
+        a = a.detach().cpu().double().numpy()
+        b = b.detach().numpy()
+        scale = max(1.0, np.abs(b).max())
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * scale, err_msg=name)
+
+
+def test_fused_message_matrix_core_isolated_nodes_and_empty_graph(monkeypatch):
+    """Nodes without edges keep their residual rows (forward) and get zero gradients (reverse); a batch without any
+    edge at all runs through the same entry points."""
+    from xequinet_amd import ops
+
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    torch.manual_seed(3)
+    mul, F, B, rc = (32, 32, 32), 32, 8, 3.0
+    C, D, H = 96, 32 + 96 + 160, 32 + 192
+    for N, ei in ((7, [[1, 2, 4, 1], [2, 1, 1, 4]]), (5, [[], []])):
+        ei = torch.tensor(ei, dtype=torch.int64, device=DEV).reshape(2, -1)
+        E = ei.shape[1]
+        pos = torch.randn(N, 3, device=DEV)
+        vec = (pos[ei[0]] - pos[ei[1]]).contiguous().requires_grad_()
+        h, xhat = torch.randn(N, H, device=DEV, requires_grad=True), torch.randn(N, D, device=DEV, requires_grad=True)
+        s, x = torch.randn(N, F, device=DEV), torch.randn(N, D, device=DEV)
+        W, b = torch.randn(H, B, device=DEV), torch.randn(H, device=DEV)
+        p0 = (math.pi * torch.arange(1, B + 1, device=DEV) / rc).float()
+        cfg = ("bessel", "cosine", B, rc, F, mul)
+        graph = ops.EdgeGraph(ei, N)
+        so, xo = ops.FusedMessage.apply(h, xhat, vec, s, x, W, b, p0, None, graph, cfg)
+        (so.sum() + xo.sum()).backward()
+        touched = torch.zeros(N, dtype=torch.bool, device=DEV)
+        touched[ei[0]] = True
+        assert torch.equal(so[~touched], s[~touched]) and torch.equal(xo[~touched], x[~touched])
+        if E:
+            assert not torch.equal(so[touched], s[touched])
+        nb = torch.zeros(N, dtype=torch.bool, device=DEV)
+        nb[ei[1]] = True
+        assert torch.all(h.grad[~nb] == 0) and torch.all(xhat.grad[~nb] == 0)
+        assert torch.isfinite(h.grad).all() and torch.isfinite(xhat.grad).all() and vec.grad.shape == (E, 3)
+
+
+def test_fused_message_matrix_core_matches_scalar_broadcast_and_is_reproducible(monkeypatch):
+    """wm against the sb kernels on the same f32 inputs (both are exact-f32 fmaf chains over the same terms; the
+    k-order of the filter sum differs), and bitwise reproducibility of wm (register sums in CSR order)."""
+    args = ("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", torch.float32, False)
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "sb")
+    ref, _ = _message_case(*args, n_mol=24)
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    a, _ = _message_case(*args, n_mol=24)
+    b, _ = _message_case(*args, n_mol=24)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    for u, r in zip(a, ref):
+        scale = max(1.0, r.abs().max().item())
+        assert (u - r).abs().max().item() <= 2e-5 * scale
+
+
+def test_fused_message_matrix_core_falls_back_or_refuses(monkeypatch):
+    """Channel layouts outside the wm form (not in multiples of 32) and f64 run on the sb kernels under the default
+    selection, and raise when wm is demanded."""
+    monkeypatch.delenv("XEQ_MESSAGE_IMPL", raising=False)
+    got, want = _message_case("8x0e+4x1o+2x2e", 12, 12, "bessel", "polynomial", torch.float32, True)
+    np.testing.assert_allclose(got[0].detach().cpu().double().numpy(), want[0].detach().numpy(), rtol=2e-5, atol=2e-5)
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    with pytest.raises(RuntimeError, match="does not fit"):
+        _message_case("8x0e+4x1o+2x2e", 12, 12, "bessel", "polynomial", torch.float32, True)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        _message_case("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", torch.float64, False)
 
 
 def test_fused_message_is_bitwise_reproducible():
@@ -431,9 +519,9 @@ def test_model_pbc_water_energy_forces(dtype):
                  extra={"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)})
 
 
-@pytest.mark.parametrize("impl", ["valu", "mfma", "sb"])
+@pytest.mark.parametrize("impl", ["valu", "mfma", "sb", "wm"])
 def test_model_message_kernel_families_agree(impl, monkeypatch):
-    """The three fused-message kernel families (generic VALU, MFMA tile, scalar-broadcast) and the
+    """The fused-message kernel families (generic VALU, MFMA tile, scalar-broadcast, wave / matrix-core) and the
     operator-level module path all reproduce the oracle on a molecule batch (fp32)."""
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", impl)
     model, oracle = _build(torch.float32)

@@ -42,5 +42,5 @@ class NeighborTransform:
         else:
             raise ValueError("PBC and cell must be both defined or both undefined.")
         # both builders emit center-sorted edges: hand the CSR views to the model
-        setattr(data, keys.EDGE_GRAPH, ops.EdgeGraph(data.edge_index, data.pos.shape[0], center_sorted=True))
+        setattr(data, keys.EDGE_GRAPH, ops.EdgeGraph(data.edge_index, data.pos.shape[0], center_sorted=True, ptr=ptr))
         return data

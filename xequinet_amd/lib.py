@@ -50,6 +50,15 @@ _PROTOS = {
     "xeq_message_fwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, c_int, _P],
     "xeq_message_bwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P,
                            c_int, _P],
+    "xeq_message_wm_supported": [c_int, c_int, _I3],
+    "xeq_edge_basis_wm_width": [c_int],
+    "xeq_edge_basis_wm": [_P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
+    "xeq_message_fwd_wm": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3,
+                           _P, _P, c_int, _P],
+    "xeq_message_bwd_wm": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
+                           _I3, _P, _P, _P, c_int, _P],
+    "xeq_message_wm_parts_floats": [c_int64, _I3],
+    "xeq_message_wm_edge_grad": [_P, c_int64, _I3, _P, _P, _P],
     "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
     "xeq_norm_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
     "xeq_uv_reduce_fwd": [c_int, _P, c_int64, _I3, c_double, _P, c_int64, c_int, _P, _P],
@@ -57,6 +66,8 @@ _PROTOS = {
     "xeq_update_out_fwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P],
     "xeq_update_out_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P, _P],
 }
+# entry points that return a size, not a status
+_RET_I64 = {"xeq_message_wm_parts_floats"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None
@@ -78,7 +89,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_int64 if name in _RET_I64 else c_int
     _lib = lib
     return lib
 

@@ -43,8 +43,10 @@ def edge_graph(data: Dict[str, torch.Tensor]) -> ops.EdgeGraph:
     g = data.get(keys.EDGE_GRAPH)
     ei = data[keys.EDGE_INDEX]
     if g is None or g.edge_index.data_ptr() != ei.contiguous().data_ptr() or g.n_edges != ei.shape[1]:
-        g = ops.EdgeGraph(ei, data[keys.POSITIONS].shape[0])
+        g = ops.EdgeGraph(ei, data[keys.POSITIONS].shape[0], ptr=data.get(keys.BATCH_PTR))
         data[keys.EDGE_GRAPH] = g
+    if g.ptr is None and keys.BATCH_PTR in data:
+        g.ptr = data[keys.BATCH_PTR]
     return g
 
 

@@ -70,8 +70,11 @@ class EdgeGraph:
     ``xeq_csr_rowptr``.
     """
 
-    def __init__(self, edge_index: torch.Tensor, n_nodes: int, center_sorted: Optional[bool] = None) -> None:
+    def __init__(self, edge_index: torch.Tensor, n_nodes: int, center_sorted: Optional[bool] = None,
+                 ptr: Optional[torch.Tensor] = None) -> None:
         require_hip(edge_index)
+        self.ptr = ptr          # graph boundaries [G+1] (keys.BATCH_PTR), when the caller knows them
+        self._wm = None
         assert edge_index.dim() == 2 and edge_index.shape[0] == 2 and edge_index.dtype == torch.int64
         self.edge_index = edge_index = edge_index.contiguous()
         self.n_nodes = int(n_nodes)
@@ -89,6 +92,36 @@ class EdgeGraph:
         keys, perm = torch.sort(nbr, stable=True)
         self.n_perm = perm.to(torch.int32)
         self.n_rowptr = csr_rowptr(keys, self.n_nodes)
+
+    def wm_plan(self, reverse: bool, edges_per_stream: int = 128):
+        """Stream table and walk-order index arrays of the wave / matrix-core message kernels
+        (xeq_message_{fwd,bwd}_wm).  A stream is a contiguous range of CSR segments (forward: over centers,
+        reverse: over neighbors) of about `edges_per_stream` edges; boundaries sit on segment starts."""
+        key = (bool(reverse), int(edges_per_stream))
+        if self._wm is None:
+            self._wm = {}
+        plan = self._wm.get(key)
+        if plan is not None:
+            return plan
+        if "c32" not in self._wm:
+            self._wm["c32"] = self.edge_index[0].to(torch.int32)
+            self._wm["n32"] = self.edge_index[1].to(torch.int32)
+        center32, nbr32 = self._wm["c32"], self._wm["n32"]
+        rowptr, perm = (self.n_rowptr, self.n_perm) if reverse else (self.c_rowptr, self.c_perm)
+        E, N = self.n_edges, self.n_nodes
+        n_ranges = max(1, -(-E // (2 * edges_per_stream)))
+        targets = (torch.arange(2 * n_ranges + 1, device=rowptr.device, dtype=torch.int64) * E) // (2 * n_ranges)
+        sp = torch.searchsorted(rowptr.long(), targets).clamp_(max=N)
+        sp[-1] = N
+        if perm is None:
+            eid, c, n = None, center32, nbr32
+        else:
+            pl = perm.long()
+            eid, c, n = perm, center32[pl].contiguous(), nbr32[pl].contiguous()
+        plan = {"n_ranges": n_ranges, "stream_ptr": sp.to(torch.int32).contiguous(), "rowptr": rowptr, "eid": eid,
+                "center": c, "nbr": n}
+        self._wm[key] = plan
+        return plan
 
 
 def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -332,10 +365,37 @@ def radial_basis(dist, rbf_kind: str, cutoff_kind: str, num_basis: int, cutoff: 
 def _message_impl() -> str:
     import os
 
-    impl = os.environ.get("XEQ_MESSAGE_IMPL", "sb")
-    if impl not in ("sb", "mfma", "valu"):
-        raise ValueError(f"XEQ_MESSAGE_IMPL={impl!r}: expected sb | mfma | valu")
+    impl = os.environ.get("XEQ_MESSAGE_IMPL", "sb")  # wm (matrix-core) is opt-in until it beats sb
+    if impl not in ("auto", "wm", "sb", "mfma", "valu"):
+        raise ValueError(f"XEQ_MESSAGE_IMPL={impl!r}: expected auto | wm | sb | mfma | valu")
     return impl
+
+
+def _wm_edges_per_stream() -> int:
+    """Edges per half-wave stream of the wm kernels (XEQ_WM_EDGES_PER_STREAM, default 128 = 8 tiles)."""
+    import os
+
+    return max(16, int(os.environ.get("XEQ_WM_EDGES_PER_STREAM", "128")))
+
+
+def wm_supported(dtype, num_basis, node_dim, mul) -> bool:
+    return dtype == torch.float32 and bool(lib.load().xeq_message_wm_supported(int(num_basis), int(node_dim), mul3(mul)))
+
+
+def edge_basis_wm(vec, graph: "EdgeGraph", rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1):
+    """Per-edge records of the wm kernels (xeq_edge_basis_wm), once per evaluation, cached on the graph."""
+    key = (vec.data_ptr(), vec._version, rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version)
+    cached = getattr(graph, "_basis_wm", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    width = lib.load().xeq_edge_basis_wm_width(num_basis)
+    E = vec.shape[0]
+    basis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
+    dbasis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
+    call("xeq_edge_basis_wm", ptr(vec), E, lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff),
+         ptr(p0), ptr(p1), ptr(basis), ptr(dbasis), stream())
+    graph._basis_wm = (key, basis, dbasis)
+    return basis, dbasis
 
 
 def edge_basis(vec, graph: EdgeGraph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1):
@@ -370,6 +430,19 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
     assert s.shape == (N, node_dim) and x.shape == (N, D) and w_rbf.shape == (node_dim + 2 * C, num_basis)
     s_out, x_out = torch.empty_like(s), torch.empty_like(x)
     impl = _message_impl()
+    if impl in ("auto", "wm"):
+        ok = wm_supported(h.dtype, num_basis, node_dim, mul)
+        if not ok and impl == "wm":
+            raise RuntimeError("XEQ_MESSAGE_IMPL=wm: this configuration does not fit the matrix-core kernels "
+                               "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 31)")
+        impl = "wm" if ok else "sb"
+    if impl == "wm":
+        basis, dbasis = edge_basis_wm(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
+        plan = graph.wm_plan(False, _wm_edges_per_stream())
+        KERNEL_TIMER.launch("xeq_message_fwd_wm", N, E, plan["n_ranges"], ptr(plan["stream_ptr"]), ptr(plan["rowptr"]),
+                            ptr(plan["eid"]), ptr(plan["center"]), ptr(plan["nbr"]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x),
+                            ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
+        return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, basis, dbasis), impl
     if impl == "sb":
         basis, dbasis = edge_basis(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
         KERNEL_TIMER.launch("xeq_message_fwd_sb", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm),
@@ -394,7 +467,15 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x):
     g_x = torch.zeros((graph.n_nodes, D), dtype=h.dtype, device=h.device) if g_x is None else g_x.contiguous()
     g_h, g_xhat = torch.empty_like(h), torch.empty_like(xhat)
     g_vec = torch.empty_like(vec)  # written at the edge's own position by every kernel family
-    if impl == "sb":
+    if impl == "wm":
+        plan = graph.wm_plan(True, _wm_edges_per_stream())
+        parts = torch.empty(lib.load().xeq_message_wm_parts_floats(graph.n_edges, mul3(mul)), dtype=h.dtype, device=h.device)
+        KERNEL_TIMER.launch("xeq_message_bwd_wm", graph.n_nodes, graph.n_edges, plan["n_ranges"], ptr(plan["stream_ptr"]),
+                            ptr(plan["rowptr"]), ptr(plan["eid"]), ptr(plan["nbr"]), ptr(plan["center"]), ptr(basis), ptr(dbasis),
+                            ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul),
+                            ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream())
+        call("xeq_message_wm_edge_grad", ptr(vec), graph.n_edges, mul3(mul), ptr(parts), ptr(g_vec), stream())
+    elif impl == "sb":
         KERNEL_TIMER.launch("xeq_message_bwd_sb", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),
                             ptr(graph.n_perm), ptr(graph.edge_index[0]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s),
                             ptr(g_x), ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat),
