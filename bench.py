@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-autotune", action="store_true",
                     help="keep the libraries' default GEMM heuristics (xequinet_amd/tuning.py)")
+    ap.add_argument("--gemm-results", default=None,
+                    help="file of library-GEMM selections: written by a run that times them, replayed (no timing launches) "
+                         "when it already exists -- used by profiles/collect_stats.sh so that the trace holds no tuning kernels")
     args = ap.parse_args()
 
     from xequinet_amd import dist as xdist
@@ -120,7 +123,7 @@ def main():
     transform = NeighborTransform(model.cutoff_radius)
     if not args.no_gemm_autotune:
         from xequinet_amd.tuning import enable_gemm_autotune
-        enable_gemm_autotune()   # every GEMM shape is timed once, during the warm-up steps
+        enable_gemm_autotune(results_file=args.gemm_results)   # every GEMM shape is timed once, during the warm-up steps
 
     def step():
         batch = XequiBatch(pos_d.detach(), z_d, ptr_d, pbc=pbc_d, cell=cell_d)

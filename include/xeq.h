@@ -49,6 +49,14 @@ const char* xeq_last_error(void);
  * ascending).  Turns a destination-sorted edge_index row into CSR. */
 int xeq_csr_rowptr(const int64_t* keys, int64_t n_keys, int64_t n_rows, int32_t* rowptr, void* stream);
 
+/* CSR view of an UNSORTED index row (edge_index[1] for the reverse pass, edge_index[0] of a user-built edge list):
+ * perm[E] = stable order of the edges by key (a radix sort: ties keep edge order, deterministic), rowptr[n_rows+1] over
+ * the sorted keys.  Replaces the stable torch.sort + searchsorted plumbing with one call; `workspace` is a device
+ * scratch buffer of at least xeq_csr_by_key_workspace(n_keys, n_rows) bytes (-1: sizes out of range). */
+int64_t xeq_csr_by_key_workspace(int64_t n_keys, int64_t n_rows);
+int xeq_csr_by_key(const int64_t* keys, int64_t n_keys, int64_t n_rows, void* workspace, int64_t workspace_bytes,
+                   int32_t* rowptr, int32_t* perm, void* stream);
+
 /* Exclusive prefix sum of int32 counts[n] into out[n+1] (out[n] = total). */
 int xeq_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* out, void* stream);
 
@@ -195,25 +203,28 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
  * A wave owns (node range, 32 gate channels of one l).  Requires node_dim == mul[0], mul[l] % 32 == 0,
  * num_basis <= 31 (xeq_message_wm_supported; otherwise XEQ_ERR_UNSUPPORTED: use the _sb form).
  *   basis/dbasis[E, W], W = xeq_edge_basis_wm_width(B): per-edge records (value / d-by-dd), once per evaluation.
- *   stream_ptr[2 n_ranges + 1]: node boundaries of the streams (non-decreasing, first 0, last N); range w is
- *   processed by one wave per unit, stream 2w by its lanes 0-31 and stream 2w+1 by lanes 32-63.  Balance them
- *   on edge count (about 128 edges per stream).
- *   forward walks the edges sorted by center: c_rowptr[N+1]; slot_eid/slot_center/slot_nbr[E] = edge id (NULL:
- *   identity), center and neighbor node of each slot of that order (int32).  The reverse pass walks them sorted
- *   by neighbor (n_rowptr; slot arrays in that order) and writes per-unit partials of dL/dd and dL/dY_lm into
- *   parts[xeq_message_wm_parts_floats(E, mul)]; xeq_message_wm_edge_grad sums them in fixed order into
- *   grad_vec[E,3]. */
+ *   stream_ptr[2 n_ranges + 1]: node boundaries of the streams (non-decreasing, first 0, last N; every node in
+ *   exactly one stream); range w is processed by one wave per unit, stream 2w by its lanes 0-31 and stream 2w+1 by
+ *   lanes 32-63.  xeq_message_wm_streams cuts them on equal edge counts from the CSR row pointer of the walk order
+ *   (about 128 edges per stream: n_ranges = ceil(E / 256)).
+ *   forward walks the edges sorted by center (c_rowptr[N+1]; c_perm[E] = edge id per slot of that order, NULL when
+ *   edge_index is already center-sorted); the reverse pass walks them sorted by neighbor (n_rowptr, n_perm) and writes
+ *   per-unit partials of dL/dd and dL/dY_lm into parts[xeq_message_wm_parts_floats(E, mul)];
+ *   xeq_message_wm_edge_grad sums them in fixed order into grad_vec[E,3].  center / nbr = edge_index rows 0 / 1.
+ *   Nodes without edges keep s_in / x_in (forward) and get zero gradients (reverse). */
 int xeq_message_wm_supported(int num_basis, int node_dim, const int32_t mul[3]);   /* 1 / 0, not a status */
 int xeq_edge_basis_wm_width(int num_basis);
 int xeq_edge_basis_wm(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis, double cutoff,
                       const void* p0, const void* p1, void* basis, void* dbasis, void* stream);
+int xeq_message_wm_streams(const int32_t* rowptr, int64_t n_nodes, int64_t n_edges, int n_ranges, int32_t* stream_ptr,
+                           void* stream);
 int xeq_message_fwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* stream_ptr, const int32_t* c_rowptr,
-                       const int32_t* slot_eid, const int32_t* slot_center, const int32_t* slot_nbr, const void* basis,
+                       const int32_t* c_perm, const int64_t* center, const int64_t* nbr, const void* basis,
                        const void* h, const void* xhat, const void* s_in, const void* x_in, const void* w_rbf,
                        const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out,
                        int xhat_layout, void* stream);
 int xeq_message_bwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* stream_ptr, const int32_t* n_rowptr,
-                       const int32_t* slot_eid, const int32_t* slot_nbr, const int32_t* slot_center, const void* basis,
+                       const int32_t* n_perm, const int64_t* center, const int64_t* nbr, const void* basis,
                        const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
                        const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,
                        void* grad_xhat, void* parts, int xhat_layout, void* stream);

@@ -6,7 +6,9 @@ tag=${1:-r01}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/prof_$tag.log 2>&1
+# library-GEMM selections are timed in an un-profiled run and replayed under the profiler (no tuning kernels in the trace)
+python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --gemm-results $R/gpurun_out/gemm_$tag.csv "$@" > $R/gpurun_out/tune_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --gemm-results $R/gpurun_out/gemm_$tag.csv "$@" > $R/gpurun_out/prof_$tag.log 2>&1
 rc=$?
 cd $R
 f=$(find gpurun_out/prof_$tag -name '*kernel_stats.csv' | head -1)

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hipcub/hipcub.hpp>
+
 #include "xeq_common.h"
 
 namespace xeq {
@@ -17,6 +19,25 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------- CSR helpers
 __global__ void k_csr_rowptr(const int64_t* __restrict__ keys, int64_t n_keys, int64_t n_rows,
                              int32_t* __restrict__ rowptr) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_rows) return;
+  int64_t lo = 0, hi = n_keys;  // first p with keys[p] >= i
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < i) lo = mid + 1;
+    else hi = mid;
+  }
+  rowptr[i] = (int32_t)lo;
+}
+
+// keys64 -> int32 keys + identity values (input of the stable radix sort of xeq_csr_by_key)
+__global__ void k_sort_prepare(const int64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ k32, int32_t* __restrict__ iota) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  k32[i] = (int32_t)keys[i];
+  iota[i] = (int32_t)i;
+}
+__global__ void k_csr_rowptr32(const int32_t* __restrict__ keys, int64_t n_keys, int64_t n_rows, int32_t* __restrict__ rowptr) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_rows) return;
   int64_t lo = 0, hi = n_keys;  // first p with keys[p] >= i
@@ -174,6 +195,47 @@ int xeq_csr_rowptr(const int64_t* keys, int64_t n_keys, int64_t n_rows, int32_t*
   hipLaunchKernelGGL(k_csr_rowptr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys,
                      n_keys, n_rows, rowptr);
   XEQ_CHECK_LAUNCH("xeq_csr_rowptr");
+  return XEQ_OK;
+}
+
+static int sort_bits(int64_t n_rows) {
+  int b = 1;
+  while (b < 31 && (1ll << b) < n_rows) ++b;
+  return b;
+}
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int64_t xeq_csr_by_key_workspace(int64_t n_keys, int64_t n_rows) {
+  if (n_keys < 0 || n_rows < 0 || n_keys >= (1ll << 31)) return -1;
+  size_t temp = 0;
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr,
+                                         (int32_t*)nullptr, (int)n_keys, 0, sort_bits(n_rows)) != hipSuccess)
+    return -1;
+  return (int64_t)(3 * align256((size_t)n_keys * 4) + align256(temp));
+}
+
+int xeq_csr_by_key(const int64_t* keys, int64_t n_keys, int64_t n_rows, void* workspace, int64_t workspace_bytes,
+                   int32_t* rowptr, int32_t* perm, void* stream) {
+  XEQ_CHECK_ARG(n_keys >= 0 && n_rows >= 0 && n_keys < (1ll << 31), "xeq_csr_by_key: bad sizes");
+  const int64_t need = xeq_csr_by_key_workspace(n_keys, n_rows);
+  XEQ_CHECK_ARG(workspace_bytes >= need, "xeq_csr_by_key: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
+  hipStream_t st = (hipStream_t)stream;
+  char* w = (char*)workspace;
+  const size_t seg = align256((size_t)n_keys * 4);
+  int32_t* k_in = (int32_t*)w;
+  int32_t* k_out = (int32_t*)(w + seg);
+  int32_t* v_in = (int32_t*)(w + 2 * seg);
+  void* temp = w + 3 * seg;
+  size_t temp_bytes = (size_t)(workspace_bytes - 3 * (int64_t)seg);
+  if (n_keys > 0) {
+    hipLaunchKernelGGL(k_sort_prepare, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, st, keys, n_keys, k_in, v_in);
+    hipError_t e_ = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const int32_t*)k_in, k_out, (const int32_t*)v_in, perm,
+                                                       (int)n_keys, 0, sort_bits(n_rows), st);
+    XEQ_CHECK_ARG(e_ == hipSuccess, "xeq_csr_by_key: radix sort failed: %s", hipGetErrorString(e_));
+  }
+  hipLaunchKernelGGL(k_csr_rowptr32, dim3((unsigned)((n_rows + 256) / 256)), dim3(256), 0, st, (const int32_t*)k_out, n_keys,
+                     n_rows, rowptr);
+  XEQ_CHECK_LAUNCH("xeq_csr_by_key");
   return XEQ_OK;
 }
 

@@ -80,9 +80,9 @@ struct WmArgs {
   int n_ranges;                // node ranges; range w = streams 2w (half-wave 0) and 2w + 1 (half-wave 1)
   const int32_t* stream_ptr;   // [2 n_ranges + 1] node boundaries of the streams
   const int32_t* rowptr;       // [N + 1] slots of the walk order per owner node
-  const int32_t* slot_eid;     // [E] edge id per slot (NULL: identity)
-  const int32_t* slot_owner;   // [E] node whose segment the slot belongs to (forward: center, reverse: neighbor)
-  const int32_t* slot_gather;  // [E] node whose rows are gathered    (forward: neighbor, reverse: center)
+  const int32_t* perm;         // [E] edge id per slot of the walk order (NULL: identity)
+  const int64_t* owner;        // [E] per EDGE: node whose segment it belongs to (forward: center, reverse: neighbor)
+  const int64_t* gather;       // [E] per EDGE: node whose rows are gathered    (forward: neighbor, reverse: center)
   int F, C, D, H, B;
   Irreps ir;
   int xl;                      // layout of xhat / grad_xhat
@@ -114,31 +114,46 @@ __device__ __forceinline__ WmUnit wm_unit(const WmArgs& a, int u) {
   return w;
 }
 
+// rows of a tile whose gathers are in flight together (register budget per role)
+#ifndef XEQ_WM_FWD_GR
+#define XEQ_WM_FWD_GR(NM) ((NM) == 1 ? 16 : ((NM) == 3 ? 8 : 4))
+#endif
+#ifndef XEQ_WM_BWD_GR
+#define XEQ_WM_BWD_GR(NM) ((NM) == 1 ? 16 : ((NM) == 3 ? 8 : 4))
+#endif
+// resident waves per SIMD the register allocation must allow
+#ifndef XEQ_WM_FWD_WPE
+#define XEQ_WM_FWD_WPE 3
+#endif
+#ifndef XEQ_WM_BWD_WPE
+#define XEQ_WM_BWD_WPE 2
+#endif
 constexpr int WM_WAVES = 4;   // waves per workgroup (independent of one another)
 
-// (range, unit) of this wave.  Consecutive work items are the units of one range (they share its edge records and
-// index arrays); consecutive groups of WM_WAVES items are dealt to workgroups so that neighbours in that order run on
-// the same XCD (blocks b and b + 8 share one under round-robin dispatch: speed only).
-__device__ __forceinline__ bool wm_decode(const WmArgs& a, int nunits, int& range, int& unit) {
+// (range, unit) of this wave.  The WM_WAVES waves of a workgroup work on the same unit (they share its rbf_lin rows,
+// staged once in LDS) and on WM_WAVES consecutive ranges.  Consecutive work items are the units of one group of
+// ranges (they share its edge records and index arrays) and are dealt to workgroups so that neighbours in that order
+// run on the same XCD (blocks b and b + 8 share one under round-robin dispatch: speed only).
+__device__ __forceinline__ void wm_decode(const WmArgs& a, int nunits, int& range, int& unit) {
   const int nb = gridDim.x, b = blockIdx.x;
-  const int vb = (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-  const int item = vb * WM_WAVES + (threadIdx.x >> 6);
-  range = item / nunits;
-  unit = item - range * nunits;
-  return range < a.n_ranges;
+  const int item = (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+  const int rgroup = item / nunits;   // padding blocks of the grid land beyond the last group: all their ranges are empty
+  unit = item - rgroup * nunits;
+  range = rgroup * WM_WAVES + (threadIdx.x >> 6);   // may be >= n_ranges: such a wave only helps staging
 }
 
-// rbf_lin rows of the unit as the B operand: lane (j = lane & 31 -> channel row0 + j, kh = lane >> 5) holds
-// W~[row][2 s + kh], s < KS, with W~[., B] = bias and zeros beyond.
+// rbf_lin rows of the unit as the B operand, staged in LDS once per workgroup: wl[kind][s][lane] with lane
+// (j = lane & 31 -> channel row0 + j, kh = lane >> 5) holding W~[row][2 s + kh], s < KS, W~[., B] = bias, zeros beyond.
+// kind 0: gate_state rows, 1: gate_edge rows, 2: scalar-message rows (l = 0 units only).
 template <int KS>
-__device__ __forceinline__ void wm_load_weights(const float* __restrict__ w, const float* __restrict__ b, int row, int B,
-                                                int kh, float (&W)[KS]) {
-  const float bias = b[row];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int k = 2 * s + kh;
-    const float wv = w[(int64_t)row * B + (k < B ? k : B - 1)];
-    W[s] = k < B ? wv : (k == B ? bias : 0.f);
+__device__ __forceinline__ void wm_stage_weights(const WmArgs& a, const WmUnit& un, const float* __restrict__ w,
+                                                 const float* __restrict__ b, float* wl) {
+  const int nkind = un.l == 0 ? 3 : 2, B = a.B;
+  for (int idx = threadIdx.x; idx < nkind * KS * 64; idx += blockDim.x) {
+    const int kind = idx / (KS * 64), rem = idx - kind * (KS * 64), sstep = rem >> 6, ln = rem & 63;
+    const int row = (kind == 0 ? un.u0 : (kind == 1 ? a.C + un.u0 : 2 * a.C + 32 * un.cb)) + (ln & 31);
+    const int k = 2 * sstep + (ln >> 5);
+    wl[idx] = k < B ? w[(int64_t)row * B + k] : (k == B ? b[row] : 0.f);
   }
 }
 
@@ -156,24 +171,32 @@ __device__ __forceinline__ void wm_load_record(const float* __restrict__ rp, int
   }
 }
 
+// W: this lane's column of one kind in the staged weights (wl + kind * KS * 64 + lane)
 template <int KS>
-__device__ __forceinline__ f32x16 wm_filter(const float (&R)[KS], const float (&W)[KS]) {
+__device__ __forceinline__ f32x16 wm_filter(const float (&R)[KS], const float* W) {
   f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(R[s], W[s], d, 0, 0, 0);
+  for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(R[s], W[s * 64], d, 0, 0, 0);
   return d;
 }
 
-// The tile table (LDS, private to the wave): per position p = 16 * half + v (v-th edge of the half-wave's
-// stream in this tile) the quantities every lane of the half needs for that row, written by the lane that owns
-// MFMA row i(p) = 8 (v >> 2) + 4 half + (v & 3), read back with half-uniform addresses (broadcast reads).
-enum { T_GOFF = 0, T_OWN = 1, T_FLAGS = 2, T_EID = 3, T_Y = 4, T_ROWS = 12 };
-enum { WM_FIRST = 1, WM_LAST = 2, WM_VALID = 4 };
+// The tile table (LDS, private to the wave, double-buffered): per position p = 16 * half + v (v-th edge of the
+// half-wave's stream in this tile) what every lane of the half needs for that row, written by the lane that owns
+// MFMA row i(p) = 8 (v >> 2) + 4 half + (v & 3) and read back with half-uniform addresses (broadcast reads).
+// Row offsets are BYTES (32-bit: wm_check bounds the tensors), so a gather is one v_add and a saddr load.
+enum { T_G0 = 0, T_G1 = 1, T_OWN = 2, T_EID = 3, T_Y = 4, T_ROWS = 12 };
 
-// Tile setup runs two tiles ahead of the arithmetic, in three steps whose loads are issued one tile apart:
+__device__ __forceinline__ float wm_ld(const float* __restrict__ base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void wm_st(float* __restrict__ base, uint32_t byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// Tile setup runs ahead of the arithmetic, in steps whose loads are issued one tile apart:
 //   wm_idx    (tile t + 2): slot of the lane's MFMA row, its edge id, owner and gathered node
-//   wm_row    (tile t + 1): segment bounds of the owner -> FIRST/LAST flags; the record (A operand); Y_lm
-//   wm_table  (tile t + 1): publish the row's entries in the (double-buffered) tile table
+//   wm_row    (tile t + 1): segment bounds of the owner -> FIRST/LAST bits; the record (A operand); Y_lm
+//   wm_table  (tile t + 1): publish the row's entries in the tile table; the bits become wave-level masks
 struct WmIdx {
   int slot, p;
   bool valid;
@@ -187,15 +210,19 @@ __device__ __forceinline__ WmIdx wm_idx(const WmArgs& a, int lane, int t, int e0
   x.p = 16 * hr + v;
   x.valid = x.slot < end;
   const int sl = x.valid ? x.slot : e2 - 1;   // e2 > e0 whenever a tile exists
-  x.eid = a.slot_eid ? a.slot_eid[sl] : sl;
-  x.own = a.slot_owner[sl];
-  x.g = a.slot_gather[sl];
+  x.eid = a.perm ? a.perm[sl] : sl;
+  x.own = (int)a.owner[x.eid];
+  x.g = (int)a.gather[x.eid];
   return x;
 }
+// bit i of a mask = MFMA row i = position (half (i >> 2) & 1, v = 4 (i >> 3) + (i & 3))
+struct WmMasks {
+  uint32_t first, last, valid;
+};
 template <int KS, int NREC, bool WITH_Y>
 struct WmRow {
   float R[NREC][KS];
-  int flags;
+  bool first, last;
   f32x4 ya, yb;
 };
 template <int KS, int NREC, bool WITH_Y>
@@ -203,24 +230,27 @@ __device__ __forceinline__ void wm_row(const WmArgs& a, const WmIdx& x, int kh, 
                                        const float* __restrict__ drec, WmRow<KS, NREC, WITH_Y>& w) {
   constexpr int KP = (KS + 3) & ~3, EW = 2 * KP + 8;
   const int r_lo = a.rowptr[x.own], r_hi = a.rowptr[x.own + 1];
-  const float* rp = rec + (int64_t)x.eid * EW;
+  const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(rec) + (uint32_t)x.eid * (uint32_t)(EW * 4));
   wm_load_record<KS>(rp, kh, x.valid, w.R[0]);
-  if constexpr (NREC > 1) wm_load_record<KS>(drec + (int64_t)x.eid * EW, kh, x.valid, w.R[1]);
+  if constexpr (NREC > 1) {
+    const float* dp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(drec) + (uint32_t)x.eid * (uint32_t)(EW * 4));
+    wm_load_record<KS>(dp, kh, x.valid, w.R[1]);
+  }
   if constexpr (WITH_Y) {
     w.ya = *reinterpret_cast<const f32x4*>(rp + 2 * KP);
     w.yb = *reinterpret_cast<const f32x4*>(rp + 2 * KP + 4);
   }
-  int flags = x.valid ? WM_VALID : 0;
-  if (x.valid && x.slot == r_lo) flags |= WM_FIRST;
-  if (x.valid && x.slot + 1 == r_hi) flags |= WM_LAST;
-  w.flags = flags;
+  w.first = x.valid && x.slot == r_lo;
+  w.last = x.valid && x.slot + 1 == r_hi;
 }
 template <int KS, int NREC, bool WITH_Y>
-__device__ __forceinline__ void wm_table(int lane, const WmIdx& x, const WmRow<KS, NREC, WITH_Y>& w, int* tbl) {
+__device__ __forceinline__ WmMasks wm_table(int lane, const WmIdx& x, const WmRow<KS, NREC, WITH_Y>& w, uint32_t stride0,
+                                            uint32_t stride1, int* tbl) {
   if (lane < 32) {
-    tbl[T_GOFF * 32 + x.p] = x.valid ? x.g : 0;
+    const uint32_t g = x.valid ? (uint32_t)x.g : 0u;
+    tbl[T_G0 * 32 + x.p] = (int)(g * stride0);
+    tbl[T_G1 * 32 + x.p] = (int)(g * stride1);
     tbl[T_OWN * 32 + x.p] = x.own;
-    tbl[T_FLAGS * 32 + x.p] = w.flags;
     tbl[T_EID * 32 + x.p] = x.eid;
     if constexpr (WITH_Y) {
       float* tf = reinterpret_cast<float*>(tbl);
@@ -231,16 +261,32 @@ __device__ __forceinline__ void wm_table(int lane, const WmIdx& x, const WmRow<K
       }
     }
   }
+  WmMasks m;
+  m.first = (uint32_t)__ballot(w.first);
+  m.last = (uint32_t)__ballot(w.last);
+  m.valid = (uint32_t)__ballot(x.valid);
+  return m;
 }
+// N consecutive table entries (positions v0 .. v0 + N - 1 of one quantity) with one LDS read
+template <int N, typename T>
+__device__ __forceinline__ void wm_tread(const int* trow, int q, int v0, T (&out)[N]) {
+  static_assert(sizeof(T) == 4, "table entries are dwords");
+  typedef T vecN __attribute__((ext_vector_type(N)));
+  const vecN v = *reinterpret_cast<const vecN*>(reinterpret_cast<const T*>(trow) + q * 32 + v0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = v[i];
+}
+// row v of the D layout: bit of half 0; half 1 is 4 higher
+__device__ __forceinline__ constexpr int wm_bit(int v) { return (v & 3) + 8 * (v >> 2); }
 
 // ------------------------------------------------------------------------------------------------ forward
-// Common prologue of a wave: its two streams and the columns of its unit.
+// Common prologue of a wave: its two streams and the per-lane byte columns of its unit.
 struct WmWave {
   int e0, e1, e2, ntiles;
-  int col_hs, col_he, col_hm, col_s, col_xe;   // per-lane columns (floats) in rows of h | s | e3nn x
-  int64_t col_x;                               // per-lane offset in xhat (+ g * xnode + m * xcomp)
-  int64_t xnode;
-  int xcomp;
+  uint32_t b_hs, b_hm, b_s, b_xe;   // byte offset of the lane's column in a row of h (state | msg), s, e3nn x
+  uint32_t b_x;                     // ... in xhat, after the unit's uniform base: + g * xnode_b + m * xcomp_b
+  uint32_t xnode_b, xcomp_b;
+  int64_t x_base;                   // uniform element offset of the unit in xhat
 };
 template <int NM>
 __device__ __forceinline__ WmWave wm_wave(const WmArgs& a, int range, const WmUnit& un, int j) {
@@ -252,15 +298,31 @@ __device__ __forceinline__ WmWave wm_wave(const WmArgs& a, int range, const WmUn
   const int len0 = w.e1 - w.e0, len1 = w.e2 - w.e1;
   w.ntiles = ((len0 > len1 ? len0 : len1) + 15) >> 4;
   const XAddr xa = xaddr(a.ir, a.n_nodes, un.u0, a.xl);
-  w.col_hs = un.u0 + j;
-  w.col_he = a.C + un.u0 + j;
-  w.col_hm = 2 * a.C + 32 * un.cb + j;
-  w.col_s = 32 * un.cb + j;
-  w.col_xe = un.xbase + j * NM;
-  w.col_x = xa.off + (int64_t)j * (a.xl == 0 ? NM : 1);
-  w.xnode = xa.node;
-  w.xcomp = xa.comp;
+  w.b_hs = 4u * (uint32_t)(un.u0 + j);
+  w.b_hm = 4u * (uint32_t)(2 * a.C + 32 * un.cb + j);
+  w.b_s = 4u * (uint32_t)(32 * un.cb + j);
+  w.b_xe = 4u * (uint32_t)(un.xbase + j * NM);
+  w.b_x = 4u * (uint32_t)(j * (a.xl == 0 ? NM : 1));
+  w.xnode_b = 4u * (uint32_t)xa.node;
+  w.xcomp_b = 4u * (uint32_t)xa.comp;
+  w.x_base = xa.off;
   return w;
+}
+
+// Owner nodes of the wave's two streams that have no edge: no tile ever touches them.  The wave copies (forward)
+// or clears (reverse) its unit's columns of their rows.  fn(node) is called by all 64 lanes.
+template <typename F>
+__device__ __forceinline__ void wm_for_isolated(const WmArgs& a, int range, int lane, F fn) {
+  const int n0 = a.stream_ptr[2 * range], n2 = a.stream_ptr[2 * range + 2];
+  for (int base = n0; base < n2; base += 64) {
+    const int n = base + lane;
+    unsigned long long mask = __ballot(n < n2 && a.rowptr[n] == a.rowptr[n + 1]);
+    while (mask) {
+      const int m = base + (__ffsll((long long)mask) - 1);
+      mask &= mask - 1;
+      fn(m);
+    }
+  }
 }
 
 // One role of the forward pass.  Each tile is walked in passes so that at most two 32x32 accumulators are live:
@@ -269,62 +331,78 @@ __device__ __forceinline__ WmWave wm_wave(const WmArgs& a, int range, const WmUn
 // Every pass keeps its own running sums across rows and tiles and stores them when its segment ends.
 template <int NM, int KS>
 __device__ __forceinline__ void wm_fwd_body(const WmArgs& a, int range, const WmUnit un, const float* __restrict__ rec,
-                                            const float* __restrict__ h, const float* __restrict__ xhat,
+                                            const float* __restrict__ h, const float* __restrict__ xhat_,
                                             const float* __restrict__ s_in, const float* __restrict__ x_in,
-                                            const float* __restrict__ w_rbf, const float* __restrict__ b_rbf,
-                                            float* __restrict__ s_out, float* __restrict__ x_out, int* tbl) {
+                                            const float* wl, float* __restrict__ s_out, float* __restrict__ x_out, int* tbl) {
   constexpr bool HAS_S = NM == 1;
   constexpr int YOFF = NM == 3 ? 0 : 3;   // Y1 at table rows T_Y + 0..2, Y2 at T_Y + 3..7
-  constexpr int CH = NM == 5 ? 2 : 4;     // rows per gather chunk (double-buffered)
+  constexpr int GR = XEQ_WM_FWD_GR(NM);   // rows whose gathers are in flight together
   const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-  const int B = a.B, C = a.C, H = a.H, D = a.D, F = a.F;
+  const int C = a.C;
   const WmWave wv = wm_wave<NM>(a, range, un, j);
+  const uint32_t he_off = 4u * (uint32_t)C, row_s = 4u * (uint32_t)a.F, row_x = 4u * (uint32_t)a.D;
+  wm_for_isolated(a, range, lane, [&](int m) {   // s_out = s_in, x_out = x_in on the unit's columns
+    if (hh == 0) {
+      if constexpr (HAS_S) wm_st(s_out, (uint32_t)m * row_s + wv.b_s, wm_ld(s_in, (uint32_t)m * row_s + wv.b_s));
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm)
+        wm_st(x_out, (uint32_t)m * row_x + wv.b_xe + 4u * mm, wm_ld(x_in, (uint32_t)m * row_x + wv.b_xe + 4u * mm));
+    }
+  });
   if (wv.ntiles == 0) return;
   const int e0 = wv.e0, e1 = wv.e1, e2 = wv.e2;
+  const float* __restrict__ xhat = xhat_ + wv.x_base;
+  const uint32_t stride0 = 4u * (uint32_t)a.H, stride1 = wv.xnode_b;
 
-  float Ws[KS], We[KS], Wm[HAS_S ? KS : 1];
-  wm_load_weights<KS>(w_rbf, b_rbf, un.u0 + j, B, hh, Ws);
-  wm_load_weights<KS>(w_rbf, b_rbf, C + un.u0 + j, B, hh, We);
-  if constexpr (HAS_S) wm_load_weights<KS>(w_rbf, b_rbf, 2 * C + 32 * un.cb + j, B, hh, Wm);
+  const float* Ws = wl + lane;
+  const float* We = wl + KS * 64 + lane;
+  const float* Wm = wl + 2 * KS * 64 + lane;
 
   float acc_s = 0.f, res_s = 0.f, acc_x[NM], res_x[NM];
 #pragma unroll
   for (int m = 0; m < NM; ++m) acc_x[m] = res_x[m] = 0.f;
 
-  struct ChunkX {
-    float hs[CH], he[CH], xv[CH][NM];
-  };
-  auto load_x = [&](const int* trow, int c0, ChunkX& c) {
-#pragma unroll
-    for (int r = 0; r < CH; ++r) {
-      const int g = trow[T_GOFF * 32 + c0 + r];
-      const float* hn = h + (int64_t)g * H;
-      c.hs[r] = hn[wv.col_hs];
-      c.he[r] = hn[wv.col_he];
-      const float* xn = xhat + wv.col_x + (int64_t)g * wv.xnode;
-#pragma unroll
-      for (int m = 0; m < NM; ++m) c.xv[r][m] = xn[m * wv.xcomp];
-    }
-  };
-
   using Row = WmRow<KS, 1, (NM > 1)>;
   WmIdx ix = wm_idx(a, lane, 0, e0, e1, e2);
   Row row;
   wm_row<KS, 1, (NM > 1)>(a, ix, hh, rec, nullptr, row);
-  wm_table<KS, 1, (NM > 1)>(lane, ix, row, tbl);
+  WmMasks mk = wm_table<KS, 1, (NM > 1)>(lane, ix, row, stride0, stride1, tbl);
   ix = wm_idx(a, lane, 1, e0, e1, e2);
   __builtin_amdgcn_wave_barrier();
 
   for (int t = 0; t < wv.ntiles; ++t) {
     const int* trow = tbl + (t & 1) * (T_ROWS * 32) + 16 * hh;   // + quantity * 32 + v
     int* tnext = tbl + ((t + 1) & 1) * (T_ROWS * 32);
-    // ---- loads that fly under the MFMAs: first gather chunk, the msg rows, next tile's record, indices of t + 2
-    ChunkX cx[2];
-    load_x(trow, 0, cx[0]);
-    float hm[HAS_S ? 16 : 1];
+    const uint32_t mfirst = mk.first >> (4 * hh), mlast = mk.last >> (4 * hh);   // this half's bits at wm_bit(v)
+    // ---- the gathers of the first GR rows, the msg rows, the next tile's record and the indices of the tile after
+    //      that are issued here and land under the MFMAs
+    float hs[GR], he[GR], xv[GR][NM], hm[HAS_S ? 16 : 1];
+    auto load_group = [&](int r0) {
+#pragma unroll
+      for (int v0 = 0; v0 < GR; v0 += 4) {
+        int g0[4], g1[4];
+        wm_tread<4>(trow, T_G0, r0 + v0, g0);
+        wm_tread<4>(trow, T_G1, r0 + v0, g1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t oh = (uint32_t)g0[r] + wv.b_hs;
+          const uint32_t ox = (uint32_t)g1[r] + wv.b_x;
+          hs[v0 + r] = wm_ld(h, oh);
+          he[v0 + r] = wm_ld(h, oh + he_off);
+#pragma unroll
+          for (int m = 0; m < NM; ++m) xv[v0 + r][m] = wm_ld(xhat, ox + m * wv.xcomp_b);
+        }
+      }
+    };
+    load_group(0);
     if constexpr (HAS_S) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) hm[v] = h[(int64_t)trow[T_GOFF * 32 + v] * H + wv.col_hm];
+      for (int v0 = 0; v0 < 16; v0 += 4) {
+        int g0[4];
+        wm_tread<4>(trow, T_G0, v0, g0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hm[v0 + r] = wm_ld(h, (uint32_t)g0[r] + wv.b_hm);
+      }
     }
     float R[KS];
 #pragma unroll
@@ -336,106 +414,95 @@ __device__ __forceinline__ void wm_fwd_body(const WmArgs& a, int range, const Wm
     {  // ---- pass X
       const f32x16 ds = wm_filter<KS>(R, Ws), de = wm_filter<KS>(R, We);
 #pragma unroll
-      for (int c0 = 0; c0 < 16; c0 += CH) {
-        if (c0 + CH < 16) load_x(trow, c0 + CH, cx[((c0 / CH) + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        const ChunkX& c = cx[(c0 / CH) & 1];
+      for (int r0 = 0; r0 < 16; r0 += GR) {
+        if (r0 > 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_group(r0);
+        }
 #pragma unroll
-        for (int r = 0; r < CH; ++r) {
-          const int v = c0 + r;
-          const int flags = trow[T_FLAGS * 32 + v];
-          if (flags & WM_FIRST) {   // half-uniform: a new segment starts with this row
-            const int64_t own = trow[T_OWN * 32 + v];
+        for (int c0 = r0; c0 < r0 + GR; c0 += 4) {
+          float Y[NM][4];
+          if constexpr (NM > 1) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-              res_x[m] = x_in[own * D + wv.col_xe + m];
-              acc_x[m] = 0.f;
+            for (int m = 0; m < NM; ++m) wm_tread<4>(trow, T_Y + YOFF + m, c0, Y[m]);
+          }
+          const uint32_t any_first = (mk.first >> wm_bit(c0)) & 0xFFu, any_last = (mk.last >> wm_bit(c0)) & 0xFFu;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int v = c0 + r, gv = v - r0;
+            if (any_first) {   // wave-uniform: some row of this chunk starts a segment in some half
+              if ((mfirst >> wm_bit(v)) & 1u) {
+                const uint32_t ob = (uint32_t)trow[T_OWN * 32 + v] * row_x + wv.b_xe;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                  res_x[m] = wm_ld(x_in, ob + 4u * m);
+                  acc_x[m] = 0.f;
+                }
+              }
+            }
+            const float gs = hs[gv] * ds[v], ge = he[gv] * de[v];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) acc_x[m] += xv[gv][m] * gs + (NM > 1 ? Y[m][r] : 1.f) * ge;
+            if (any_last) {    // some row of this chunk ends a segment: its only store
+              if ((mlast >> wm_bit(v)) & 1u) {
+                const uint32_t ob = (uint32_t)trow[T_OWN * 32 + v] * row_x + wv.b_xe;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) wm_st(x_out, ob + 4u * m, res_x[m] + acc_x[m]);
+              }
             }
           }
-          const float gs = c.hs[r] * ds[v], ge = c.he[r] * de[v];
-#pragma unroll
-          for (int m = 0; m < NM; ++m) {
-            const float y = NM > 1 ? reinterpret_cast<const float*>(trow)[(T_Y + YOFF + m) * 32 + v] : 1.f;
-            acc_x[m] += c.xv[r][m] * gs + y * ge;
-          }
-          if (flags & WM_LAST) {    // the segment ends with this row: its only store
-            const int64_t own = trow[T_OWN * 32 + v];
-#pragma unroll
-            for (int m = 0; m < NM; ++m) x_out[own * D + wv.col_xe + m] = res_x[m] + acc_x[m];
-          }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if constexpr (HAS_S) {  // ---- pass M
       const f32x16 dm = wm_filter<KS>(R, Wm);
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int flags = trow[T_FLAGS * 32 + v];
-        if (flags & WM_FIRST) {
-          const int64_t own = trow[T_OWN * 32 + v];
-          res_s = s_in[own * F + wv.col_s];
-          acc_s = 0.f;
-        }
-        acc_s += hm[v] * dm[v];
-        if (flags & WM_LAST) {
-          const int64_t own = trow[T_OWN * 32 + v];
-          s_out[own * F + wv.col_s] = res_s + acc_s;
+      for (int c0 = 0; c0 < 16; c0 += 4) {
+        const uint32_t any_first = (mk.first >> wm_bit(c0)) & 0xFFu, any_last = (mk.last >> wm_bit(c0)) & 0xFFu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = c0 + r;
+          if (any_first) {
+            if ((mfirst >> wm_bit(v)) & 1u) {
+              res_s = wm_ld(s_in, (uint32_t)trow[T_OWN * 32 + v] * row_s + wv.b_s);
+              acc_s = 0.f;
+            }
+          }
+          acc_s += hm[v] * dm[v];
+          if (any_last) {
+            if ((mlast >> wm_bit(v)) & 1u) wm_st(s_out, (uint32_t)trow[T_OWN * 32 + v] * row_s + wv.b_s, res_s + acc_s);
+          }
         }
       }
     }
-    wm_table<KS, 1, (NM > 1)>(lane, ixn, row, tnext);
+    mk = wm_table<KS, 1, (NM > 1)>(lane, ixn, row, stride0, stride1, tnext);
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-// one kernel per l: each role gets its own register allocation
-template <int NM, int KS>
-__global__ void __launch_bounds__(64 * WM_WAVES) k_message_fwd_wm(WmArgs a, int unit0, int nunits, const float* __restrict__ rec,
+// all roles in one launch: units [0, nu0) are l = 0, then l = 1, then l = 2
+template <int KS>
+__global__ void __launch_bounds__(64 * WM_WAVES) __attribute__((amdgpu_waves_per_eu(XEQ_WM_FWD_WPE))) k_message_fwd_wm(WmArgs a, const float* __restrict__ rec,
                                                                   const float* __restrict__ h, const float* __restrict__ xhat,
                                                                   const float* __restrict__ s_in, const float* __restrict__ x_in,
                                                                   const float* __restrict__ w_rbf, const float* __restrict__ b_rbf,
                                                                   float* __restrict__ s_out, float* __restrict__ x_out) {
   __shared__ int tbl_all[WM_WAVES][2 * T_ROWS * 32];   // double-buffered tile table per wave
+  __shared__ float wl[3 * KS * 64];                     // the unit's rbf_lin rows (B operand of every MFMA)
   int range, unit;
-  if (!wm_decode(a, nunits, range, unit)) return;
-  const WmUnit un = wm_unit(a, unit0 + unit);
-  wm_fwd_body<NM, KS>(a, range, un, rec, h, xhat, s_in, x_in, w_rbf, b_rbf, s_out, x_out, tbl_all[threadIdx.x >> 6]);
-}
-
-// Nodes without edges are never touched by a stream: forward s_out = s_in, x_out = x_in; reverse grad_h = 0,
-// grad_xhat = 0.  One lane per node finds them; the wave then writes each such row together.
-__global__ void k_wm_isolated_fwd(int64_t N, const int32_t* __restrict__ rowptr, int F, int D, const float* __restrict__ s_in,
-                                  const float* __restrict__ x_in, float* __restrict__ s_out, float* __restrict__ x_out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
-  const int64_t n = base + lane;
-  unsigned long long mask = __ballot(n < N && rowptr[n] == rowptr[n + 1]);
-  while (mask) {
-    const int64_t m = base + (__ffsll((long long)mask) - 1);
-    mask &= mask - 1;
-    for (int f = lane; f < F; f += 64) s_out[m * F + f] = s_in[m * F + f];
-    for (int f = lane; f < D; f += 64) x_out[m * D + f] = x_in[m * D + f];
-  }
-}
-__global__ void k_wm_isolated_bwd(int64_t N, const int32_t* __restrict__ rowptr, int H, Irreps ir, int xl,
-                                  float* __restrict__ grad_h, float* __restrict__ grad_xhat) {
-  const int lane = threadIdx.x & 63;
-  const int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
-  const int64_t n = base + lane;
-  unsigned long long mask = __ballot(n < N && rowptr[n] == rowptr[n + 1]);
-  const int C = ir.C();
-  while (mask) {
-    const int64_t m = base + (__ffsll((long long)mask) - 1);
-    mask &= mask - 1;
-    for (int f = lane; f < H; f += 64) grad_h[m * H + f] = 0.f;
-    for (int u = lane; u < C; u += 64) {
-      const XAddr xa = xaddr(ir, N, u, xl);
-      int l, off;
-      ir.locate(u, l, off);
-      for (int c = 0; c < 2 * l + 1; ++c) grad_xhat[xa.off + m * xa.node + (int64_t)c * xa.comp] = 0.f;
-    }
-  }
+  wm_decode(a, a.nu[0] + a.nu[1] + a.nu[2], range, unit);
+  const WmUnit un = wm_unit(a, unit);
+  wm_stage_weights<KS>(a, un, w_rbf, b_rbf, wl);
+  __syncthreads();
+  if (range >= a.n_ranges) return;
+  int* tbl = tbl_all[threadIdx.x >> 6];
+#ifdef XEQ_WM_ONLY_L   // development: register budget of one role
+  if (un.l == XEQ_WM_ONLY_L) wm_fwd_body<2 * XEQ_WM_ONLY_L + 1, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
+#else
+  if (un.l == 0) wm_fwd_body<1, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
+  else if (un.l == 1) wm_fwd_body<3, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
+  else wm_fwd_body<5, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ reverse
@@ -466,24 +533,35 @@ __device__ __forceinline__ float wm_half_total(float v) {
 template <int NM, int KS>
 __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit, const WmUnit un, const float* __restrict__ rec,
                                             const float* __restrict__ drec, const float* __restrict__ h,
-                                            const float* __restrict__ xhat, const float* __restrict__ grad_s,
-                                            const float* __restrict__ grad_x, const float* __restrict__ w_rbf,
-                                            const float* __restrict__ b_rbf, float* __restrict__ grad_h,
-                                            float* __restrict__ grad_xhat, const WmParts parts, int* tbl) {
+                                            const float* __restrict__ xhat_, const float* __restrict__ grad_s,
+                                            const float* __restrict__ grad_x, const float* wl, float* __restrict__ grad_h,
+                                            float* __restrict__ grad_xhat_, const WmParts parts, int* tbl) {
   constexpr bool HAS_S = NM == 1;
   constexpr int YOFF = NM == 3 ? 0 : 3;
-  constexpr int CH = NM == 5 ? 2 : 4;
+  constexpr int GR = XEQ_WM_BWD_GR(NM);   // rows whose gathers are in flight together
   const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-  const int B = a.B, C = a.C, H = a.H, D = a.D, F = a.F;
+  const int C = a.C;
   const int64_t E = a.n_edges;
   const WmWave wv = wm_wave<NM>(a, range, un, j);
+  const float* __restrict__ xhat = xhat_ + wv.x_base;
+  float* __restrict__ grad_xhat = grad_xhat_ + wv.x_base;
+  const uint32_t he_off = 4u * (uint32_t)C, row_h = 4u * (uint32_t)a.H;
+  wm_for_isolated(a, range, lane, [&](int m) {   // nobody's neighbor: zero gradients on the unit's columns
+    if (hh == 0) {
+      wm_st(grad_h, (uint32_t)m * row_h + wv.b_hs, 0.f);
+      wm_st(grad_h, (uint32_t)m * row_h + wv.b_hs + he_off, 0.f);
+      if constexpr (HAS_S) wm_st(grad_h, (uint32_t)m * row_h + wv.b_hm, 0.f);
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm) wm_st(grad_xhat, (uint32_t)m * wv.xnode_b + wv.b_x + mm * wv.xcomp_b, 0.f);
+    }
+  });
   if (wv.ntiles == 0) return;
   const int e0 = wv.e0, e1 = wv.e1, e2 = wv.e2;
+  const uint32_t stride0 = 4u * (uint32_t)a.D, stride1 = 4u * (uint32_t)a.F;   // gathered rows: grad_x, grad_s of the center
 
-  float Ws[KS], We[KS], Wm[HAS_S ? KS : 1];
-  wm_load_weights<KS>(w_rbf, b_rbf, un.u0 + j, B, hh, Ws);
-  wm_load_weights<KS>(w_rbf, b_rbf, C + un.u0 + j, B, hh, We);
-  if constexpr (HAS_S) wm_load_weights<KS>(w_rbf, b_rbf, 2 * C + 32 * un.cb + j, B, hh, Wm);
+  const float* Ws = wl + lane;
+  const float* We = wl + KS * 64 + lane;
+  const float* Wm = wl + 2 * KS * 64 + lane;
 
   // the owner (neighbor) node of the running segment, per pass: its own rows and its gradient sums
   float o_hs = 0.f, o_he = 0.f, o_hm = 0.f, o_x[NM];
@@ -492,31 +570,43 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
   for (int m = 0; m < NM; ++m) o_x[m] = a_x[m] = 0.f;
   const bool writer = j == 31;   // lanes 31 / 63 hold the half's DPP totals
 
-  struct ChunkG {   // gradient rows of the centers of CH edges
-    float gx[CH][NM];
-  };
-  auto load_g = [&](const int* trow, int c0, ChunkG& c) {
-#pragma unroll
-    for (int r = 0; r < CH; ++r) {
-      const float* gr = grad_x + (int64_t)trow[T_GOFF * 32 + c0 + r] * D + wv.col_xe;
-#pragma unroll
-      for (int m = 0; m < NM; ++m) c.gx[r][m] = gr[m];
-    }
-  };
-
   using Row = WmRow<KS, 2, (NM > 1)>;
   WmIdx ix = wm_idx(a, lane, 0, e0, e1, e2);
   Row row;
   wm_row<KS, 2, (NM > 1)>(a, ix, hh, rec, drec, row);
-  wm_table<KS, 2, (NM > 1)>(lane, ix, row, tbl);
+  WmMasks mk = wm_table<KS, 2, (NM > 1)>(lane, ix, row, stride0, stride1, tbl);
   ix = wm_idx(a, lane, 1, e0, e1, e2);
   __builtin_amdgcn_wave_barrier();
 
   for (int t = 0; t < wv.ntiles; ++t) {
     const int* trow = tbl + (t & 1) * (T_ROWS * 32) + 16 * hh;
     int* tnext = tbl + ((t + 1) & 1) * (T_ROWS * 32);
-    ChunkG cg[2];
-    load_g(trow, 0, cg[0]);
+    const uint32_t mfirst = mk.first >> (4 * hh), mlast = mk.last >> (4 * hh), mvalid = mk.valid >> (4 * hh);
+    // ---- the first GR gradient rows (and the scalar gradient rows) are issued here, under the MFMAs
+    float gx[GR][NM], gsv[HAS_S ? 16 : 1];
+    auto load_group = [&](int r0) {
+#pragma unroll
+      for (int v0 = 0; v0 < GR; v0 += 4) {
+        int g0[4];
+        wm_tread<4>(trow, T_G0, r0 + v0, g0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t og = (uint32_t)g0[r] + wv.b_xe;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) gx[v0 + r][m] = wm_ld(grad_x, og + 4u * m);
+        }
+      }
+    };
+    load_group(0);
+    if constexpr (HAS_S) {
+#pragma unroll
+      for (int v0 = 0; v0 < 16; v0 += 4) {
+        int g1[4];
+        wm_tread<4>(trow, T_G1, v0, g1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gsv[v0 + r] = wm_ld(grad_s, (uint32_t)g1[r] + wv.b_s);
+      }
+    }
     float R[KS], Rd[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -530,141 +620,188 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     {  // ---- pass S
       const f32x16 ds = wm_filter<KS>(R, Ws), qs = wm_filter<KS>(Rd, Ws);
 #pragma unroll
-      for (int c0 = 0; c0 < 16; c0 += CH) {
-        if (c0 + CH < 16) load_g(trow, c0 + CH, cg[((c0 / CH) + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        const ChunkG& c = cg[(c0 / CH) & 1];
+      for (int r0 = 0; r0 < 16; r0 += GR) {
+        if (r0 > 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_group(r0);
+        }
 #pragma unroll
-        for (int r = 0; r < CH; ++r) {
-          const int v = c0 + r;
-          const int flags = trow[T_FLAGS * 32 + v];
-          if (flags & WM_FIRST) {   // new owner: load its rows, clear its sums
-            const int64_t own = trow[T_OWN * 32 + v];
-            o_hs = h[own * H + wv.col_hs];
-            const float* xn = xhat + wv.col_x + own * wv.xnode;
+        for (int c0 = r0; c0 < r0 + GR; c0 += 4) {
+          const uint32_t any_first = (mk.first >> wm_bit(c0)) & 0xFFu, any_last = (mk.last >> wm_bit(c0)) & 0xFFu;
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-              o_x[m] = xn[m * wv.xcomp];
-              a_x[m] = 0.f;
+          for (int r = 0; r < 4; ++r) {
+            const int v = c0 + r, gv = v - r0;
+            if (any_first) {   // some half starts a segment in this chunk: load the new owner's rows
+              if ((mfirst >> wm_bit(v)) & 1u) {
+                const uint32_t own = (uint32_t)trow[T_OWN * 32 + v];
+                o_hs = wm_ld(h, own * row_h + wv.b_hs);
+                const uint32_t ox = own * wv.xnode_b + wv.b_x;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                  o_x[m] = wm_ld(xhat, ox + m * wv.xcomp_b);
+                  a_x[m] = 0.f;
+                }
+                a_hs = 0.f;
+              }
             }
-            a_hs = 0.f;
-          }
-          float dgs = 0.f;
+            float dgs = 0.f;
 #pragma unroll
-          for (int m = 0; m < NM; ++m) dgs += o_x[m] * c.gx[r][m];
-          const float ps = ds[v];
-          a_hs += ps * dgs;
-          const float gate = o_hs * ps;
+            for (int m = 0; m < NM; ++m) dgs += o_x[m] * gx[gv][m];
+            const float ps = ds[v];
+            a_hs += ps * dgs;
+            const float gate = o_hs * ps;
 #pragma unroll
-          for (int m = 0; m < NM; ++m) a_x[m] += gate * c.gx[r][m];
-          pd[v] = o_hs * dgs * qs[v];
-          if (flags & WM_LAST) {
-            const int64_t own = trow[T_OWN * 32 + v];
-            grad_h[own * H + wv.col_hs] = a_hs;
-            float* gxh = grad_xhat + wv.col_x + own * wv.xnode;
+            for (int m = 0; m < NM; ++m) a_x[m] += gate * gx[gv][m];
+            pd[v] = o_hs * dgs * qs[v];
+            if (any_last) {
+              if ((mlast >> wm_bit(v)) & 1u) {
+                const uint32_t own = (uint32_t)trow[T_OWN * 32 + v];
+                wm_st(grad_h, own * row_h + wv.b_hs, a_hs);
+                const uint32_t ox = own * wv.xnode_b + wv.b_x;
 #pragma unroll
-            for (int m = 0; m < NM; ++m) gxh[m * wv.xcomp] = a_x[m];
+                for (int m = 0; m < NM; ++m) wm_st(grad_xhat, ox + m * wv.xcomp_b, a_x[m]);
+              }
+            }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // next tile's records fly under the remaining passes
+    // next tile's records and the first rows of pass E fly under its MFMAs
     wm_row<KS, 2, (NM > 1)>(a, ixn, hh, rec, drec, row);
-    load_g(trow, 0, cg[0]);
-    float gsv[HAS_S ? 16 : 1];
-    if constexpr (HAS_S) {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) gsv[v] = grad_s[(int64_t)trow[T_GOFF * 32 + v] * F + wv.col_s];
-    }
+    if (GR < 16) load_group(0);
     __builtin_amdgcn_sched_barrier(0);
     {  // ---- pass E
       const f32x16 de = wm_filter<KS>(R, We), qe = wm_filter<KS>(Rd, We);
 #pragma unroll
-      for (int c0 = 0; c0 < 16; c0 += CH) {
-        if (c0 + CH < 16) load_g(trow, c0 + CH, cg[((c0 / CH) + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        const ChunkG& c = cg[(c0 / CH) & 1];
+      for (int r0 = 0; r0 < 16; r0 += GR) {
+        if (r0 > 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_group(r0);
+        }
 #pragma unroll
-        for (int r = 0; r < CH; ++r) {
-          const int v = c0 + r;
-          const int flags = trow[T_FLAGS * 32 + v];
-          if (flags & WM_FIRST) {
-            const int64_t own = trow[T_OWN * 32 + v];
-            o_he = h[own * H + wv.col_he];
-            a_he = 0.f;
+        for (int c0 = r0; c0 < r0 + GR; c0 += 4) {
+          float Yc[NM][4];
+          int eid[4];
+          if constexpr (NM > 1) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) wm_tread<4>(trow, T_Y + YOFF + m, c0, Yc[m]);
+            wm_tread<4>(trow, T_EID, c0, eid);
           }
-          float dge = 0.f;
+          const uint32_t any_first = (mk.first >> wm_bit(c0)) & 0xFFu, any_last = (mk.last >> wm_bit(c0)) & 0xFFu;
 #pragma unroll
-          for (int m = 0; m < NM; ++m) {
-            const float y = NM > 1 ? reinterpret_cast<const float*>(trow)[(T_Y + YOFF + m) * 32 + v] : 1.f;
-            dge += y * c.gx[r][m];
-          }
-          const float pe = de[v];
-          a_he += pe * dge;
-          pd[v] += o_he * dge * qe[v];
-          if constexpr (NM > 1) {   // dL/dY_lm of the row's edge: sum over the unit's 32 channels
-            const float wy = o_he * pe;
-            float ry[NM];
+          for (int r = 0; r < 4; ++r) {
+            const int v = c0 + r, gv = v - r0;
+            if (any_first) {
+              if ((mfirst >> wm_bit(v)) & 1u) {
+                o_he = wm_ld(h, (uint32_t)trow[T_OWN * 32 + v] * row_h + wv.b_hs + he_off);
+                a_he = 0.f;
+              }
+            }
+            float dge = 0.f;
 #pragma unroll
-            for (int m = 0; m < NM; ++m) ry[m] = wm_half_total(wy * c.gx[r][m]);
-            if (writer && (flags & WM_VALID)) {
-              const int eid = trow[T_EID * 32 + v];
-              float* dst = NM == 3 ? parts.y1 : parts.y2;
+            for (int m = 0; m < NM; ++m) dge += (NM > 1 ? Yc[m][r] : 1.f) * gx[gv][m];
+            const float pe = de[v];
+            a_he += pe * dge;
+            pd[v] += o_he * dge * qe[v];
+            if constexpr (NM > 1) {   // dL/dY_lm of the row's edge: sum over the unit's 32 channels
+              const float wy = o_he * pe;
+              float ry[NM];
 #pragma unroll
-              for (int m = 0; m < NM; ++m) dst[((int64_t)un.cb * NM + m) * E + eid] = ry[m];
+              for (int m = 0; m < NM; ++m) ry[m] = wm_half_total(wy * gx[gv][m]);
+              if (writer && ((mvalid >> wm_bit(v)) & 1u)) {
+                float* dst = NM == 3 ? parts.y1 : parts.y2;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) dst[((int64_t)un.cb * NM + m) * E + eid[r]] = ry[m];
+              }
+            }
+            if (any_last) {
+              if ((mlast >> wm_bit(v)) & 1u) wm_st(grad_h, (uint32_t)trow[T_OWN * 32 + v] * row_h + wv.b_hs + he_off, a_he);
             }
           }
-          if (flags & WM_LAST) {
-            const int64_t own = trow[T_OWN * 32 + v];
-            grad_h[own * H + wv.col_he] = a_he;
-          }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if constexpr (HAS_S) {  // ---- pass M
       const f32x16 dm = wm_filter<KS>(R, Wm), qm = wm_filter<KS>(Rd, Wm);
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int flags = trow[T_FLAGS * 32 + v];
-        if (flags & WM_FIRST) {
-          const int64_t own = trow[T_OWN * 32 + v];
-          o_hm = h[own * H + wv.col_hm];
-          a_hm = 0.f;
-        }
-        a_hm += dm[v] * gsv[v];
-        pd[v] += o_hm * gsv[v] * qm[v];
-        if (flags & WM_LAST) {
-          const int64_t own = trow[T_OWN * 32 + v];
-          grad_h[own * H + wv.col_hm] = a_hm;
+      for (int c0 = 0; c0 < 16; c0 += 4) {
+        const uint32_t any_first = (mk.first >> wm_bit(c0)) & 0xFFu, any_last = (mk.last >> wm_bit(c0)) & 0xFFu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = c0 + r;
+          if (any_first) {
+            if ((mfirst >> wm_bit(v)) & 1u) {
+              o_hm = wm_ld(h, (uint32_t)trow[T_OWN * 32 + v] * row_h + wv.b_hm);
+              a_hm = 0.f;
+            }
+          }
+          a_hm += dm[v] * gsv[v];
+          pd[v] += o_hm * gsv[v] * qm[v];
+          if (any_last) {
+            if ((mlast >> wm_bit(v)) & 1u) wm_st(grad_h, (uint32_t)trow[T_OWN * 32 + v] * row_h + wv.b_hm, a_hm);
+          }
         }
       }
     }
     // ---- dL/dd of every row's edge: sum over the unit's 32 channels
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const float tot = wm_half_total(pd[v]);
-      if (writer && (trow[T_FLAGS * 32 + v] & WM_VALID)) parts.pd[(int64_t)unit * E + trow[T_EID * 32 + v]] = tot;
+    for (int v0 = 0; v0 < 16; v0 += 4) {
+      int eid[4];
+      wm_tread<4>(trow, T_EID, v0, eid);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float tot = wm_half_total(pd[v0 + r]);
+        if (writer && ((mvalid >> wm_bit(v0 + r)) & 1u)) parts.pd[(int64_t)unit * E + eid[r]] = tot;
+      }
     }
-    wm_table<KS, 2, (NM > 1)>(lane, ixn, row, tnext);
+    mk = wm_table<KS, 2, (NM > 1)>(lane, ixn, row, stride0, stride1, tnext);
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-template <int NM, int KS>
-__global__ void __launch_bounds__(64 * WM_WAVES) k_message_bwd_wm(WmArgs a, int unit0, int nunits, const float* __restrict__ rec,
+template <int KS>
+__global__ void __launch_bounds__(64 * WM_WAVES) __attribute__((amdgpu_waves_per_eu(XEQ_WM_BWD_WPE))) k_message_bwd_wm(WmArgs a, const float* __restrict__ rec,
                                                                   const float* __restrict__ drec, const float* __restrict__ h,
                                                                   const float* __restrict__ xhat, const float* __restrict__ grad_s,
                                                                   const float* __restrict__ grad_x, const float* __restrict__ w_rbf,
                                                                   const float* __restrict__ b_rbf, float* __restrict__ grad_h,
                                                                   float* __restrict__ grad_xhat, WmParts parts) {
   __shared__ int tbl_all[WM_WAVES][2 * T_ROWS * 32];
+  __shared__ float wl[3 * KS * 64];
   int range, unit;
-  if (!wm_decode(a, nunits, range, unit)) return;
-  const WmUnit un = wm_unit(a, unit0 + unit);
-  wm_bwd_body<NM, KS>(a, range, unit0 + unit, un, rec, drec, h, xhat, grad_s, grad_x, w_rbf, b_rbf, grad_h, grad_xhat, parts,
-                      tbl_all[threadIdx.x >> 6]);
+  wm_decode(a, a.nu[0] + a.nu[1] + a.nu[2], range, unit);
+  const WmUnit un = wm_unit(a, unit);
+  wm_stage_weights<KS>(a, un, w_rbf, b_rbf, wl);
+  __syncthreads();
+  if (range >= a.n_ranges) return;
+  int* tbl = tbl_all[threadIdx.x >> 6];
+#ifdef XEQ_WM_ONLY_L
+  if (un.l == XEQ_WM_ONLY_L)
+    wm_bwd_body<2 * XEQ_WM_ONLY_L + 1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+#else
+  if (un.l == 0) wm_bwd_body<1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+  else if (un.l == 1) wm_bwd_body<3, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+  else wm_bwd_body<5, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+#endif
+}
+
+// stream_ptr[k] = first node c with rowptr[c] >= k E / (2 R)  (k < 2R), stream_ptr[2R] = N: streams of about equal
+// edge counts whose boundaries sit on segment starts; every node belongs to exactly one stream
+__global__ void k_wm_stream_ptr(const int32_t* __restrict__ rowptr, int64_t N, int64_t E, int n_ranges, int32_t* __restrict__ sp) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > 2 * n_ranges) return;
+  if (k == 2 * n_ranges) {
+    sp[k] = (int32_t)N;
+    return;
+  }
+  const int64_t target = (int64_t)k * E / (2 * n_ranges);
+  int64_t lo = 0, hi = N;   // first c in [0, N] with rowptr[c] >= target (rowptr[N] = E >= target)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] >= target) hi = mid;
+    else lo = mid + 1;
+  }
+  sp[k] = (int32_t)lo;
 }
 
 // dL/dvec from the per-unit partials, summed in unit order (deterministic), chain rule of A1-A3
@@ -707,8 +844,8 @@ static int wm_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ran
   a.F = node_dim;
   a.H = a.F + 2 * a.C;
   a.B = num_basis;
-  XEQ_CHECK_ARG(n_nodes * (int64_t)a.H < (1ll << 31) && n_edges * (int64_t)72 < (1ll << 31),
-                "%s: tensors too large for 32-bit offsets (shard the batch)", who);
+  XEQ_CHECK_ARG(n_nodes * (int64_t)a.H * 4 < (1ll << 32) && n_edges * (int64_t)72 * 4 < (1ll << 32),
+                "%s: tensors too large for 32-bit byte offsets (shard the batch)", who);
   for (int l = 0; l < 3; ++l) a.nu[l] = mul[l] / 32;
   a.n_nodes = n_nodes;
   a.n_edges = n_edges;
@@ -720,27 +857,14 @@ static int wm_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ran
 
 using namespace xeq;
 
-// KS covers K = B + 1 (bias column) in steps of two; records are written for the same bucket.  One launch per l.
-#define XEQ_WM_LAUNCH_L(KERNEL, NM_, ...)                                                                                 \
-  do {                                                                                                                    \
-    const int ks = wm_ks(num_basis);                                                                                      \
-    if (ks <= 5) hipLaunchKernelGGL((KERNEL<NM_, 5>), grid, dim3(64 * WM_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);      \
-    else if (ks <= 9) hipLaunchKernelGGL((KERNEL<NM_, 9>), grid, dim3(64 * WM_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
-    else if (ks <= 11) hipLaunchKernelGGL((KERNEL<NM_, 11>), grid, dim3(64 * WM_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<NM_, 16>), grid, dim3(64 * WM_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);             \
-  } while (0)
-#define XEQ_WM_DISPATCH(KERNEL, ...)                                                            \
-  do {                                                                                          \
-    int unit0 = 0;                                                                              \
-    for (int l = 0; l < 3; ++l) {                                                               \
-      const int nunits = a.nu[l];                                                               \
-      if (nunits == 0) continue;                                                                \
-      dim3 grid(wm_grid(n_ranges, nunits));                                                     \
-      if (l == 0) XEQ_WM_LAUNCH_L(KERNEL, 1, a, unit0, nunits, __VA_ARGS__);                    \
-      else if (l == 1) XEQ_WM_LAUNCH_L(KERNEL, 3, a, unit0, nunits, __VA_ARGS__);               \
-      else XEQ_WM_LAUNCH_L(KERNEL, 5, a, unit0, nunits, __VA_ARGS__);                           \
-      unit0 += nunits;                                                                          \
-    }                                                                                           \
+// KS covers K = B + 1 (bias column) in steps of two; records are written for the same bucket
+#define XEQ_WM_DISPATCH(KERNEL, ...)                                                                                   \
+  do {                                                                                                                 \
+    const int ks = wm_ks(num_basis);                                                                                   \
+    if (ks <= 5) hipLaunchKernelGGL((KERNEL<5>), grid, dim3(64 * WM_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);      \
+    else if (ks <= 9) hipLaunchKernelGGL((KERNEL<9>), grid, dim3(64 * WM_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else if (ks <= 11) hipLaunchKernelGGL((KERNEL<11>), grid, dim3(64 * WM_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<16>), grid, dim3(64 * WM_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);             \
   } while (0)
 
 // the template KS a given num_basis is dispatched to; the records are laid out for it
@@ -750,8 +874,7 @@ static int wm_ks_bucket(int num_basis) {
 }
 static int wm_kp_bucket(int num_basis) { return (wm_ks_bucket(num_basis) + 3) & ~3; }
 static unsigned wm_grid(int n_ranges, int nunits) {
-  const int64_t items = (int64_t)n_ranges * nunits;
-  int64_t blocks = (items + WM_WAVES - 1) / WM_WAVES;
+  int64_t blocks = (int64_t)((n_ranges + WM_WAVES - 1) / WM_WAVES) * nunits;   // one workgroup per (range group, unit)
   if (blocks >= 64) blocks = (blocks + 7) / 8 * 8;   // multiple of 8: XCD-aware item order (wm_decode)
   return (unsigned)blocks;
 }
@@ -779,8 +902,18 @@ int xeq_edge_basis_wm(const void* vec, int64_t n_edges, int rbf_kind, int cutoff
 
 int xeq_message_wm_supported(int num_basis, int node_dim, const int32_t mul[3]) { return wm_supported(num_basis, node_dim, mul) ? 1 : 0; }
 
+int xeq_message_wm_streams(const int32_t* rowptr, int64_t n_nodes, int64_t n_edges, int n_ranges, int32_t* stream_ptr,
+                           void* stream) {
+  XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_ranges >= 1, "xeq_message_wm_streams: bad sizes");
+  const int n = 2 * n_ranges + 1;
+  hipLaunchKernelGGL(k_wm_stream_ptr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowptr, n_nodes,
+                     n_edges, n_ranges, stream_ptr);
+  XEQ_CHECK_LAUNCH("xeq_message_wm_streams");
+  return XEQ_OK;
+}
+
 int xeq_message_fwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* stream_ptr, const int32_t* c_rowptr,
-                       const int32_t* slot_eid, const int32_t* slot_center, const int32_t* slot_nbr, const void* basis,
+                       const int32_t* c_perm, const int64_t* center, const int64_t* nbr, const void* basis,
                        const void* h, const void* xhat, const void* s_in, const void* x_in, const void* w_rbf,
                        const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out,
                        int xhat_layout, void* stream) {
@@ -790,22 +923,21 @@ int xeq_message_fwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   if (n_nodes == 0) return XEQ_OK;
   a.stream_ptr = stream_ptr;
   a.rowptr = c_rowptr;
-  a.slot_eid = slot_eid;
-  a.slot_owner = slot_center;
-  a.slot_gather = slot_nbr;
+  a.perm = c_perm;
+  a.owner = center;
+  a.gather = nbr;
   a.xl = xhat_layout;
-  hipLaunchKernelGGL(k_wm_isolated_fwd, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_nodes,
-                     c_rowptr, a.F, a.D, (const float*)s_in, (const float*)x_in, (float*)s_out, (float*)x_out);
-  XEQ_CHECK_LAUNCH("xeq_message_fwd_wm (isolated nodes)");
-  if (n_ranges == 0 || n_edges == 0) return XEQ_OK;
-  XEQ_WM_DISPATCH(k_message_fwd_wm, (const float*)basis, (const float*)h, (const float*)xhat, (const float*)s_in,
+  XEQ_CHECK_ARG(n_ranges >= 1, "%s: the stream table must cover every node (n_ranges >= 1)", "xeq_message_wm");
+  const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
+  dim3 grid(wm_grid(n_ranges, nunits));
+  XEQ_WM_DISPATCH(k_message_fwd_wm, a, (const float*)basis, (const float*)h, (const float*)xhat, (const float*)s_in,
                   (const float*)x_in, (const float*)w_rbf, (const float*)b_rbf, (float*)s_out, (float*)x_out);
   XEQ_CHECK_LAUNCH("xeq_message_fwd_wm");
   return XEQ_OK;
 }
 
 int xeq_message_bwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* stream_ptr, const int32_t* n_rowptr,
-                       const int32_t* slot_eid, const int32_t* slot_nbr, const int32_t* slot_center, const void* basis,
+                       const int32_t* n_perm, const int64_t* center, const int64_t* nbr, const void* basis,
                        const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
                        const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,
                        void* grad_xhat, void* parts, int xhat_layout, void* stream) {
@@ -815,20 +947,18 @@ int xeq_message_bwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   if (n_nodes == 0) return XEQ_OK;
   a.stream_ptr = stream_ptr;
   a.rowptr = n_rowptr;
-  a.slot_eid = slot_eid;
-  a.slot_owner = slot_nbr;
-  a.slot_gather = slot_center;
+  a.perm = n_perm;
+  a.owner = nbr;
+  a.gather = center;
   a.xl = xhat_layout;
-  hipLaunchKernelGGL(k_wm_isolated_bwd, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_nodes,
-                     n_rowptr, a.H, a.ir, a.xl, (float*)grad_h, (float*)grad_xhat);
-  XEQ_CHECK_LAUNCH("xeq_message_bwd_wm (isolated nodes)");
-  if (n_ranges == 0 || n_edges == 0) return XEQ_OK;
+  XEQ_CHECK_ARG(n_ranges >= 1, "%s: the stream table must cover every node (n_ranges >= 1)", "xeq_message_wm");
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
   WmParts pr;
   pr.pd = (float*)parts;
   pr.y1 = pr.pd + (int64_t)nunits * n_edges;
   pr.y2 = pr.y1 + (int64_t)a.nu[1] * 3 * n_edges;
-  XEQ_WM_DISPATCH(k_message_bwd_wm, (const float*)basis, (const float*)dbasis, (const float*)h, (const float*)xhat,
+  dim3 grid(wm_grid(n_ranges, nunits));
+  XEQ_WM_DISPATCH(k_message_bwd_wm, a, (const float*)basis, (const float*)dbasis, (const float*)h, (const float*)xhat,
                   (const float*)grad_s, (const float*)grad_x, (const float*)w_rbf, (const float*)b_rbf, (float*)grad_h,
                   (float*)grad_xhat, pr);
   XEQ_CHECK_LAUNCH("xeq_message_bwd_wm");

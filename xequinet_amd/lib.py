@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxeq_hip.so")
+LIB_PATH = os.environ.get("XEQ_LIB_PATH") or os.path.join(_HERE, "libxeq_hip.so")   # XEQ_LIB_PATH: development builds
 
 XEQ_F32, XEQ_F64 = 0, 1
 RBF_KINDS = {"bessel": 0, "gaussian": 1}
@@ -25,6 +25,8 @@ _I3 = ctypes.POINTER(c_int32)
 # name -> argtypes, exactly the prototypes of include/xeq.h
 _PROTOS = {
     "xeq_csr_rowptr": [_P, c_int64, c_int64, _P, _P],
+    "xeq_csr_by_key_workspace": [c_int64, c_int64],
+    "xeq_csr_by_key": [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P],
     "xeq_exclusive_scan_i32": [_P, c_int64, _P, _P],
     "xeq_radius_graph_count": [c_int, _P, _P, c_int64, c_int64, c_double, _P, _P],
     "xeq_radius_graph_fill": [c_int, _P, _P, c_int64, c_int64, c_double, _P, c_int64, _P, _P],
@@ -51,6 +53,7 @@ _PROTOS = {
     "xeq_message_bwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P,
                            c_int, _P],
     "xeq_message_wm_supported": [c_int, c_int, _I3],
+    "xeq_message_wm_streams": [_P, c_int64, c_int64, c_int, _P, _P],
     "xeq_edge_basis_wm_width": [c_int],
     "xeq_edge_basis_wm": [_P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
     "xeq_message_fwd_wm": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3,
@@ -67,7 +70,7 @@ _PROTOS = {
     "xeq_update_out_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P, _P],
 }
 # entry points that return a size, not a status
-_RET_I64 = {"xeq_message_wm_parts_floats"}
+_RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None

@@ -53,6 +53,21 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 # --------------------------------------------------------------------------- graph
+def csr_by_key(keys: torch.Tensor, n_rows: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rowptr[n_rows+1], perm[E]) of an unsorted int64 index row: stable radix sort + row pointer in one library call."""
+    require_hip(keys)
+    keys = keys.contiguous()
+    n = keys.numel()
+    nbytes = lib.load().xeq_csr_by_key_workspace(n, n_rows)
+    if nbytes < 0:
+        raise ValueError("csr_by_key: sizes out of range")
+    work = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=keys.device)
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=keys.device)
+    perm = torch.empty(n, dtype=torch.int32, device=keys.device)
+    call("xeq_csr_by_key", ptr(keys), n, n_rows, ptr(work), int(nbytes), ptr(rowptr), ptr(perm), stream())
+    return rowptr, perm
+
+
 def csr_rowptr(sorted_keys: torch.Tensor, n_rows: int) -> torch.Tensor:
     require_hip(sorted_keys)
     rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=sorted_keys.device)
@@ -66,8 +81,8 @@ class EdgeGraph:
     ``c_*``: CSR over centers (edge_index[0], keys.py:16) -- forward aggregation.
     ``n_*``: CSR over neighbors (edge_index[1], keys.py:17) -- reverse pass.
     ``perm`` is None when the edge list is already sorted by that row.
-    Index plumbing (a stable sort of int64 keys) uses torch; rowptr comes from
-    ``xeq_csr_rowptr``.
+    Index plumbing is one library call per unsorted row (``xeq_csr_by_key``: stable radix sort +
+    row pointer); a sorted row only needs ``xeq_csr_rowptr``.
     """
 
     def __init__(self, edge_index: torch.Tensor, n_nodes: int, center_sorted: Optional[bool] = None,
@@ -86,41 +101,22 @@ class EdgeGraph:
             self.c_perm = None
             self.c_rowptr = csr_rowptr(center, self.n_nodes)
         else:
-            keys, perm = torch.sort(center, stable=True)
-            self.c_perm = perm.to(torch.int32)
-            self.c_rowptr = csr_rowptr(keys, self.n_nodes)
-        keys, perm = torch.sort(nbr, stable=True)
-        self.n_perm = perm.to(torch.int32)
-        self.n_rowptr = csr_rowptr(keys, self.n_nodes)
+            self.c_rowptr, self.c_perm = csr_by_key(center, self.n_nodes)
+        self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes)
 
     def wm_plan(self, reverse: bool, edges_per_stream: int = 128):
-        """Stream table and walk-order index arrays of the wave / matrix-core message kernels
-        (xeq_message_{fwd,bwd}_wm).  A stream is a contiguous range of CSR segments (forward: over centers,
-        reverse: over neighbors) of about `edges_per_stream` edges; boundaries sit on segment starts."""
+        """Stream table of the wave / matrix-core message kernels (xeq_message_{fwd,bwd}_wm): contiguous ranges of
+        CSR segments (forward: over centers, reverse: over neighbors) of about `edges_per_stream` edges each."""
         key = (bool(reverse), int(edges_per_stream))
         if self._wm is None:
             self._wm = {}
         plan = self._wm.get(key)
-        if plan is not None:
-            return plan
-        if "c32" not in self._wm:
-            self._wm["c32"] = self.edge_index[0].to(torch.int32)
-            self._wm["n32"] = self.edge_index[1].to(torch.int32)
-        center32, nbr32 = self._wm["c32"], self._wm["n32"]
-        rowptr, perm = (self.n_rowptr, self.n_perm) if reverse else (self.c_rowptr, self.c_perm)
-        E, N = self.n_edges, self.n_nodes
-        n_ranges = max(1, -(-E // (2 * edges_per_stream)))
-        targets = (torch.arange(2 * n_ranges + 1, device=rowptr.device, dtype=torch.int64) * E) // (2 * n_ranges)
-        sp = torch.searchsorted(rowptr.long(), targets).clamp_(max=N)
-        sp[-1] = N
-        if perm is None:
-            eid, c, n = None, center32, nbr32
-        else:
-            pl = perm.long()
-            eid, c, n = perm, center32[pl].contiguous(), nbr32[pl].contiguous()
-        plan = {"n_ranges": n_ranges, "stream_ptr": sp.to(torch.int32).contiguous(), "rowptr": rowptr, "eid": eid,
-                "center": c, "nbr": n}
-        self._wm[key] = plan
+        if plan is None:
+            rowptr, perm = (self.n_rowptr, self.n_perm) if reverse else (self.c_rowptr, self.c_perm)
+            n_ranges = max(1, -(-self.n_edges // (2 * edges_per_stream)))
+            sp = torch.empty(2 * n_ranges + 1, dtype=torch.int32, device=rowptr.device)
+            call("xeq_message_wm_streams", ptr(rowptr), self.n_nodes, self.n_edges, n_ranges, ptr(sp), stream())
+            plan = self._wm[key] = {"n_ranges": n_ranges, "stream_ptr": sp, "rowptr": rowptr, "perm": perm}
         return plan
 
 
@@ -365,7 +361,7 @@ def radial_basis(dist, rbf_kind: str, cutoff_kind: str, num_basis: int, cutoff: 
 def _message_impl() -> str:
     import os
 
-    impl = os.environ.get("XEQ_MESSAGE_IMPL", "sb")  # wm (matrix-core) is opt-in until it beats sb
+    impl = os.environ.get("XEQ_MESSAGE_IMPL", "auto")
     if impl not in ("auto", "wm", "sb", "mfma", "valu"):
         raise ValueError(f"XEQ_MESSAGE_IMPL={impl!r}: expected auto | wm | sb | mfma | valu")
     return impl
@@ -440,7 +436,7 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
         basis, dbasis = edge_basis_wm(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
         plan = graph.wm_plan(False, _wm_edges_per_stream())
         KERNEL_TIMER.launch("xeq_message_fwd_wm", N, E, plan["n_ranges"], ptr(plan["stream_ptr"]), ptr(plan["rowptr"]),
-                            ptr(plan["eid"]), ptr(plan["center"]), ptr(plan["nbr"]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x),
+                            ptr(plan["perm"]), ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x),
                             ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
         return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, basis, dbasis), impl
     if impl == "sb":
@@ -471,7 +467,7 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x):
         plan = graph.wm_plan(True, _wm_edges_per_stream())
         parts = torch.empty(lib.load().xeq_message_wm_parts_floats(graph.n_edges, mul3(mul)), dtype=h.dtype, device=h.device)
         KERNEL_TIMER.launch("xeq_message_bwd_wm", graph.n_nodes, graph.n_edges, plan["n_ranges"], ptr(plan["stream_ptr"]),
-                            ptr(plan["rowptr"]), ptr(plan["eid"]), ptr(plan["nbr"]), ptr(plan["center"]), ptr(basis), ptr(dbasis),
+                            ptr(plan["rowptr"]), ptr(plan["perm"]), ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(basis), ptr(dbasis),
                             ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul),
                             ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream())
         call("xeq_message_wm_edge_grad", ptr(vec), graph.n_edges, mul3(mul), ptr(parts), ptr(g_vec), stream())

@@ -18,17 +18,21 @@ __all__ = ["enable_gemm_autotune", "gemm_autotune_enabled"]
 
 def enable_gemm_autotune(max_tuning_ms: int = 100, results_file: str | None = None) -> bool:
     """Time every new GEMM shape once and keep the fastest library kernel.  Returns False (and does nothing) when no
-    HIP device is present."""
+    HIP device is present.  With `results_file` naming an existing file of an earlier run, its selections are
+    replayed and nothing is timed (what a profiled run wants: no tuning launches in the trace)."""
     if not torch.cuda.is_available():
         return False
     t = torch.cuda.tunable
     t.enable(True)
-    t.tuning_enable(True)
+    replay = results_file is not None and os.path.exists(results_file) and os.path.getsize(results_file) > 0
+    t.tuning_enable(not replay)
     t.set_max_tuning_duration(int(max_tuning_ms))
     if results_file is None:
         # per-process scratch file: nothing is written into the caller's working directory
         results_file = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"xeq_tunableop_{os.getpid()}.csv")
     t.set_filename(results_file, insert_device_ordinal=False)
+    if replay:
+        t.read_file(results_file)
     return True
 
 
