@@ -614,6 +614,9 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
       Rd[s] = row.R[1][s];
     }
     const WmIdx ixn = ix;
+    const bool nfirst = row.first, nlast = row.last;
+    (void)nfirst;
+    (void)nlast;
     ix = wm_idx(a, lane, t + 2, e0, e1, e2);
     __builtin_amdgcn_sched_barrier(0);
     float pd[16];
@@ -666,12 +669,15 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
         }
       }
     }
-    // next tile's records and the first rows of pass E fly under its MFMAs
-    wm_row<KS, 2, (NM > 1)>(a, ixn, hh, rec, drec, row);
+    // the first rows of pass E fly under its MFMAs
     if (GR < 16) load_group(0);
     __builtin_amdgcn_sched_barrier(0);
     {  // ---- pass E
       const f32x16 de = wm_filter<KS>(R, We), qe = wm_filter<KS>(Rd, We);
+      if constexpr (!HAS_S) {   // last MFMAs of the tile are issued: the next tile's records take over their registers
+        __builtin_amdgcn_sched_barrier(0);
+        wm_row<KS, 2, (NM > 1)>(a, ixn, hh, rec, drec, row);
+      }
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += GR) {
         if (r0 > 0) {
@@ -723,6 +729,8 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     }
     if constexpr (HAS_S) {  // ---- pass M
       const f32x16 dm = wm_filter<KS>(R, Wm), qm = wm_filter<KS>(Rd, Wm);
+      __builtin_amdgcn_sched_barrier(0);
+      wm_row<KS, 2, (NM > 1)>(a, ixn, hh, rec, drec, row);
 #pragma unroll
       for (int c0 = 0; c0 < 16; c0 += 4) {
         const uint32_t any_first = (mk.first >> wm_bit(c0)) & 0xFFu, any_last = (mk.last >> wm_bit(c0)) & 0xFFu;
