@@ -86,6 +86,21 @@ int xeq_radius_graph_pbc_fill(int dtype, const void* pos_wrap, const int64_t* pt
                               int64_t n_cells, double cutoff, const int32_t* rowptr, int64_t n_edges,
                               int64_t* edge_index, void* cell_offsets, void* stream);
 
+/* The same search with image pruning (default of the Python front): per (center, neighbor) pair only the image
+ * offsets n with |f_a - n_a| <= thr_a on every periodic axis are evaluated, f = (pos_wrap[c] - pos_wrap[n]) . recip^T --
+ * a necessary condition for the pair to be within the cutoff, so the edge set and its order are bit-identical to the
+ * exhaustive form above (the survivors are evaluated with the same arithmetic).  recip[G,3,3]: rows a_j x a_k / V of
+ * each cell (what data/radius_graph.py:61-82 builds for its image counts); thr[G,3] = cutoff |recip_a| + margin;
+ * reps[3] = images per axis of the enumeration (n_cells = prod (2 reps + 1), cartesian_prod order). */
+int xeq_radius_graph_pbc_count_pruned(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs,
+                                      int64_t n_nodes, const void* img, int64_t n_cells, double cutoff, const void* recip,
+                                      const void* thr, const int32_t reps[3], int32_t* deg, void* stream);
+int xeq_radius_graph_pbc_fill_pruned(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs,
+                                     int64_t n_nodes, const void* img, const void* cells, const void* shift, int64_t n_cells,
+                                     double cutoff, const void* recip, const void* thr, const int32_t reps[3],
+                                     const int32_t* rowptr, int64_t n_edges, int64_t* edge_index, void* cell_offsets,
+                                     void* stream);
+
 /* ------------------------------------------------------------ edge geometry */
 
 /* compute_edge_data (nn/basic.py:110-131): vec = pos[c] - pos[n] - cell_offsets @ cell[batch[n]],

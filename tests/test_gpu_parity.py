@@ -77,6 +77,36 @@ def test_radius_graph_pbc_golden_bit_exact(name):
     np.testing.assert_array_equal(co.cpu().numpy(), f["cell_offsets"])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_radius_graph_pbc_pruned_equals_exhaustive(dtype):
+    """The image-pruned search (default) against the exhaustive sweep over all images on random triclinic cells,
+    including cells smaller than the cutoff (2 images per axis), a slab (one open axis) and un-wrapped positions:
+    identical edge_index, cell_offsets and order."""
+    from xequinet_amd import ops
+    from xequinet_amd.data.radius_graph import _image_counts, wrap_positions
+
+    rng = np.random.default_rng(5)
+    for trial, (n_atoms, L, pbc) in enumerate([((40, 25), 9.0, [True, True, True]), ((30,), 4.2, [True, True, True]),
+                                                ((35, 20, 50), 7.5, [True, True, False]), ((64,), 12.0, [True, False, True])]):
+        G = len(n_atoms)
+        cell = np.stack([np.eye(3) * L * rng.uniform(0.8, 1.3) + rng.normal(0, 0.12 * L, size=(3, 3)) for _ in range(G)])
+        frac = [rng.uniform(-0.4, 1.6, size=(n, 3)) for n in n_atoms]
+        pos = np.concatenate([f @ c for f, c in zip(frac, cell)])
+        pos_t, cell_t = _t(pos, dtype), _t(cell, dtype)
+        nn = _t(np.array(n_atoms))
+        reps, prune = _image_counts(cell_t, pbc, 5.0, with_prune=True)
+        cells_per_dim = [torch.arange(-r, r + 1, device=DEV, dtype=dtype) for r in reps]
+        cell_offsets = torch.cartesian_prod(*cells_per_dim).reshape(-1, 3)
+        img = torch.bmm(cell_offsets.view(1, -1, 3).expand(G, -1, -1).contiguous(), cell_t)
+        pw, shift = wrap_positions(pos_t, cell_t, nn, pbc)
+        ptr = _t(np.concatenate([[0], np.cumsum(n_atoms)]))
+        a = ops.radius_graph_pbc_raw(pw, ptr, img, cell_offsets, shift, 5.0)
+        b = ops.radius_graph_pbc_raw(pw, ptr, img, cell_offsets, shift, 5.0, prune=prune)
+        assert a[0].shape[1] > 0, trial
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), trial
+
+
 def test_single_radius_graph_golden():
     from xequinet_amd.data import single_radius_graph
 

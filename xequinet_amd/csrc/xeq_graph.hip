@@ -180,6 +180,112 @@ __global__ void k_radius_graph_pbc(const T* __restrict__ pw, const int64_t* __re
   if (!FILL && lane == 0) deg[i] = cnt;
 }
 
+// Image-pruned form of the same search (default).  One wave per center, lane = candidate neighbor j (64 at a time, in
+// ascending order).  Instead of testing all n_cells images of every j, the lane derives from the fractional
+// separation f = (A - pos_wrap[j]) . recip which image offsets n can possibly be within the cutoff: along axis a the
+// distance is at least |f_a - n_a| / |recip_a| (distance between lattice planes), so only ceil(f_a - t_a) <= n_a <=
+// floor(f_a + t_a), t_a = rc |recip_a| + margin, survive -- typically one image instead of 27.  The survivors are
+// evaluated with EXACTLY the arithmetic of k_radius_graph_pbc (so the edge set is bit-identical), in ascending cell
+// index; a wave prefix over the lanes' hit counts keeps the reference's (neighbor * n_cells + cell) order.
+struct PbcPrune {
+  int rep[3];   // images per axis: cell index c = ((n0 + rep0) (2 rep1 + 1) + (n1 + rep1)) (2 rep2 + 1) + (n2 + rep2)
+};
+template <typename T>
+__device__ __forceinline__ T floor_(T x);
+template <> __device__ __forceinline__ float floor_<float>(float x) { return floorf(x); }
+template <> __device__ __forceinline__ double floor_<double>(double x) { return floor(x); }
+template <typename T>
+__device__ __forceinline__ T ceil_(T x);
+template <> __device__ __forceinline__ float ceil_<float>(float x) { return ceilf(x); }
+template <> __device__ __forceinline__ double ceil_<double>(double x) { return ceil(x); }
+
+template <typename T, bool FILL>
+__global__ void k_radius_graph_pbc_img(const T* __restrict__ pw, const int64_t* __restrict__ ptr, int64_t n_graphs,
+                                       int64_t n_nodes, const T* __restrict__ img, const T* __restrict__ cells,
+                                       const T* __restrict__ shift, int64_t n_cells, T rc, const T* __restrict__ recip,
+                                       const T* __restrict__ thr, PbcPrune pr, int32_t* __restrict__ deg,
+                                       const int32_t* __restrict__ rowptr, int64_t n_edges,
+                                       int64_t* __restrict__ edge_index, T* __restrict__ cell_offsets) {
+  const int lane = threadIdx.x & 63;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n_nodes) return;
+  int64_t g = graph_of(ptr, n_graphs, i);
+  int64_t a = ptr[g], b = ptr[g + 1];
+  const T* gimg = img + g * n_cells * 3;
+  const T* rg = recip + g * 9;
+  const T t0 = thr[3 * g], t1 = thr[3 * g + 1], t2 = thr[3 * g + 2];
+  const T xi = pw[3 * i], yi = pw[3 * i + 1], zi = pw[3 * i + 2];
+  const int w1 = 2 * pr.rep[1] + 1, w2 = 2 * pr.rep[2] + 1;
+  int64_t w = FILL ? (int64_t)rowptr[i] : 0;
+  int32_t cnt = 0;
+  for (int64_t j0 = a; j0 < b; j0 += 64) {
+    const int64_t j = j0 + lane;
+    const bool have = j < b;
+    int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};   // empty ranges for lanes without a candidate
+    T xj = T(0), yj = T(0), zj = T(0);
+    if (have) {
+      xj = pw[3 * j];
+      yj = pw[3 * j + 1];
+      zj = pw[3 * j + 2];
+      const T vx = xi - xj, vy = yi - yj, vz = zi - zj;
+      const T f[3] = {vx * rg[0] + vy * rg[1] + vz * rg[2], vx * rg[3] + vy * rg[4] + vz * rg[5],
+                      vx * rg[6] + vy * rg[7] + vz * rg[8]};
+      const T t[3] = {t0, t1, t2};
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        if (pr.rep[ax] == 0) {
+          lo[ax] = hi[ax] = 0;
+        } else {
+          const T l = ceil_<T>(f[ax] - t[ax]), h = floor_<T>(f[ax] + t[ax]);
+          lo[ax] = l < T(-pr.rep[ax]) ? -pr.rep[ax] : (int)l;
+          hi[ax] = h > T(pr.rep[ax]) ? pr.rep[ax] : (int)h;
+        }
+      }
+    }
+    // ---- pass 1: this lane's hits (cells in ascending index)
+    int nh = 0;
+    for (int n0 = lo[0]; n0 <= hi[0]; ++n0)
+      for (int n1 = lo[1]; n1 <= hi[1]; ++n1)
+        for (int n2 = lo[2]; n2 <= hi[2]; ++n2) {
+          const int64_t c = ((int64_t)(n0 + pr.rep[0]) * w1 + (n1 + pr.rep[1])) * w2 + (n2 + pr.rep[2]);
+          T bx = add_rn<T>(xj, gimg[3 * c]), by = add_rn<T>(yj, gimg[3 * c + 1]), bz = add_rn<T>(zj, gimg[3 * c + 2]);
+          T dx = sub_rn<T>(xi, bx), dy = sub_rn<T>(yi, by), dz = sub_rn<T>(zi, bz);
+          T D = sqrt_<T>(add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz)));
+          if ((D < rc) && (D > T(0.01))) ++nh;
+        }
+    // exclusive prefix of nh over the lanes, bit by bit (nh is small)
+    int base = 0, total = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int bit = 0; bit < 31; ++bit) {
+      const unsigned long long m = __ballot((nh >> bit) & 1);
+      base += __popcll(m & lt) << bit;
+      total += __popcll(m) << bit;
+      if (__ballot(nh >> (bit + 1)) == 0ull) break;
+    }
+    if (FILL && nh > 0) {   // ---- pass 2: the same walk, writing
+      int64_t p = w + base;
+      for (int n0 = lo[0]; n0 <= hi[0]; ++n0)
+        for (int n1 = lo[1]; n1 <= hi[1]; ++n1)
+          for (int n2 = lo[2]; n2 <= hi[2]; ++n2) {
+            const int64_t c = ((int64_t)(n0 + pr.rep[0]) * w1 + (n1 + pr.rep[1])) * w2 + (n2 + pr.rep[2]);
+            T bx = add_rn<T>(xj, gimg[3 * c]), by = add_rn<T>(yj, gimg[3 * c + 1]), bz = add_rn<T>(zj, gimg[3 * c + 2]);
+            T dx = sub_rn<T>(xi, bx), dy = sub_rn<T>(yi, by), dz = sub_rn<T>(zi, bz);
+            T D = sqrt_<T>(add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz)));
+            if ((D < rc) && (D > T(0.01))) {
+              edge_index[p] = i;
+              edge_index[n_edges + p] = j;
+              for (int ax = 0; ax < 3; ++ax)
+                cell_offsets[3 * p + ax] = cells[3 * c + ax] + (shift[3 * i + ax] - shift[3 * j + ax]);
+              ++p;
+            }
+          }
+    }
+    w += total;
+    cnt += total;
+  }
+  if (!FILL && lane == 0) deg[i] = cnt;
+}
+
 }  // namespace xeq
 
 using namespace xeq;
@@ -304,6 +410,46 @@ int xeq_radius_graph_pbc_fill(int dtype, const void* pos_wrap, const int64_t* pt
                        edge_index, (T*)cell_offsets);
   });
   XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_fill");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_pbc_count_pruned(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs,
+                                      int64_t n_nodes, const void* img, int64_t n_cells, double cutoff, const void* recip,
+                                      const void* thr, const int32_t reps[3], int32_t* deg, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_cells > 0, "xeq_radius_graph_pbc_count_pruned: bad sizes");
+  XEQ_CHECK_ARG(reps[0] >= 0 && reps[1] >= 0 && reps[2] >= 0 &&
+                    (int64_t)(2 * reps[0] + 1) * (2 * reps[1] + 1) * (2 * reps[2] + 1) == n_cells,
+                "xeq_radius_graph_pbc_count_pruned: image counts (%d,%d,%d) do not match n_cells %lld", reps[0], reps[1],
+                reps[2], (long long)n_cells);
+  if (n_nodes == 0) return XEQ_OK;
+  PbcPrune pr{{reps[0], reps[1], reps[2]}};
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_radius_graph_pbc_img<T, false>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos_wrap, ptr, n_graphs, n_nodes, (const T*)img, (const T*)nullptr,
+                       (const T*)nullptr, n_cells, (T)cutoff, (const T*)recip, (const T*)thr, pr, deg,
+                       (const int32_t*)nullptr, (int64_t)0, (int64_t*)nullptr, (T*)nullptr);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_count_pruned");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_pbc_fill_pruned(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs,
+                                     int64_t n_nodes, const void* img, const void* cells, const void* shift, int64_t n_cells,
+                                     double cutoff, const void* recip, const void* thr, const int32_t reps[3],
+                                     const int32_t* rowptr, int64_t n_edges, int64_t* edge_index, void* cell_offsets,
+                                     void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_cells > 0 && n_edges >= 0, "xeq_radius_graph_pbc_fill_pruned: bad sizes");
+  XEQ_CHECK_ARG((int64_t)(2 * reps[0] + 1) * (2 * reps[1] + 1) * (2 * reps[2] + 1) == n_cells,
+                "xeq_radius_graph_pbc_fill_pruned: image counts do not match n_cells");
+  if (n_nodes == 0 || n_edges == 0) return XEQ_OK;
+  PbcPrune pr{{reps[0], reps[1], reps[2]}};
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_radius_graph_pbc_img<T, true>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos_wrap, ptr, n_graphs, n_nodes, (const T*)img, (const T*)cells,
+                       (const T*)shift, n_cells, (T)cutoff, (const T*)recip, (const T*)thr, pr, (int32_t*)nullptr, rowptr,
+                       n_edges, edge_index, (T*)cell_offsets);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_fill_pruned");
   return XEQ_OK;
 }
 

@@ -30,19 +30,30 @@ def wrap_positions(pos: torch.Tensor, cell: torch.Tensor, n_nodes_per_graph: tor
     return pos_wrap, shift
 
 
-def _image_counts(cell: torch.Tensor, pbc: List[bool], cutoff: float) -> List[int]:
-    """Images per axis (data/radius_graph.py:61-89): ceil(rc * |a_j x a_k| / V), max over the batch."""
+_PRUNE_MARGIN = 1e-3  # on |f_a - n_a|: far above the rounding of f, far below any lattice spacing
+
+
+def _image_counts(cell: torch.Tensor, pbc: List[bool], cutoff: float, with_prune: bool = False):
+    """Images per axis (data/radius_graph.py:61-89): ceil(rc * |a_j x a_k| / V), max over the batch.
+    with_prune: also the reciprocal rows recip[G,3,3] = a_j x a_k / V and thr[G,3] = rc |recip_a| + margin of the
+    image-pruned kernels (a pair can only be within rc through images n with |f_a - n_a| <= rc |recip_a|)."""
     cross_a2a3 = torch.cross(cell[:, 1], cell[:, 2], dim=-1)
     cell_vol = torch.sum(cell[:, 0] * cross_a2a3, dim=-1, keepdim=True)
     crosses = [cross_a2a3, torch.cross(cell[:, 2], cell[:, 0], dim=-1), torch.cross(cell[:, 0], cell[:, 1], dim=-1)]
-    reps = []
+    reps, inv = [], []
     for ax in range(3):
+        inv_min_dist = torch.norm(crosses[ax] / cell_vol, p=2, dim=-1)
+        inv.append(inv_min_dist)
         if pbc[ax]:
-            inv_min_dist = torch.norm(crosses[ax] / cell_vol, p=2, dim=-1)
             reps.append(torch.ceil(cutoff * inv_min_dist).max())
         else:
             reps.append(cell.new_zeros(()))
-    return [int(v) for v in torch.stack(reps).tolist()]  # one host sync (the reference does three .item())
+    reps = [int(v) for v in torch.stack(reps).tolist()]  # one host sync (the reference does three .item())
+    if not with_prune:
+        return reps
+    recip = torch.stack([c / cell_vol for c in crosses], dim=1)           # [G, 3(axis), 3]
+    thr = cutoff * torch.stack(inv, dim=1) + _PRUNE_MARGIN                 # [G, 3]
+    return reps, (recip, thr, reps)
 
 
 @torch.no_grad()
@@ -59,9 +70,9 @@ def radius_graph_pbc(pos: torch.Tensor, n_nodes_per_graph: torch.Tensor, pbc: to
     pbc_ = pbc_cpu[0].tolist()
     n_nodes_per_graph = n_nodes_per_graph.to(device)
 
-    max_rep = _image_counts(cell, pbc_, cutoff)
+    max_rep, prune = _image_counts(cell, pbc_, cutoff, with_prune=True)
     cells_per_dim = [torch.arange(-rep, rep + 1, device=device, dtype=dtype) for rep in max_rep]
-    cell_offsets = torch.cartesian_prod(*cells_per_dim)  # [n_cells, 3]
+    cell_offsets = torch.cartesian_prod(*cells_per_dim).reshape(-1, 3)  # [n_cells, 3]
     n_cells = cell_offsets.shape[0]
     unit_cell_batch = cell_offsets.view(1, n_cells, 3).expand(batch_size, -1, -1).contiguous()
     pbc_offsets = torch.bmm(unit_cell_batch, cell)  # [G, n_cells, 3]
@@ -69,7 +80,7 @@ def radius_graph_pbc(pos: torch.Tensor, n_nodes_per_graph: torch.Tensor, pbc: to
     pos_wrap, shift = wrap_positions(pos, cell, n_nodes_per_graph, pbc_)
     ptr = torch.zeros(batch_size + 1, dtype=torch.int64, device=device)
     ptr[1:] = torch.cumsum(n_nodes_per_graph, dim=0)
-    edge_index, offsets, rowptr = ops.radius_graph_pbc_raw(pos_wrap, ptr, pbc_offsets, cell_offsets, shift, cutoff)
+    edge_index, offsets, rowptr = ops.radius_graph_pbc_raw(pos_wrap, ptr, pbc_offsets, cell_offsets, shift, cutoff, prune=prune)
     if return_rowptr:
         return edge_index, offsets, rowptr
     return edge_index, offsets
@@ -80,10 +91,11 @@ def single_radius_graph(pos: torch.Tensor, pbc: torch.Tensor, cell: torch.Tensor
     ops.lib.require_hip(pos, cell)
     device, dtype = pos.device, pos.dtype
     pbc_ = [bool(v) for v in pbc.detach().cpu().tolist()]
-    max_rep = _image_counts(cell.unsqueeze(0), pbc_, cutoff)
+    max_rep, prune = _image_counts(cell.unsqueeze(0), pbc_, cutoff, with_prune=True)
     cells_per_dim = [torch.arange(-rep, rep + 1, device=device, dtype=dtype) for rep in max_rep]
-    cell_offsets = torch.cartesian_prod(*cells_per_dim)
+    cell_offsets = torch.cartesian_prod(*cells_per_dim).reshape(-1, 3)
     pbc_offsets = torch.mm(cell_offsets, cell).unsqueeze(0)
     ptr = torch.tensor([0, pos.shape[0]], dtype=torch.int64, device=device)
-    edge_index, offsets, _ = ops.radius_graph_pbc_raw(pos.detach(), ptr, pbc_offsets, cell_offsets, torch.zeros_like(pos), cutoff)
+    edge_index, offsets, _ = ops.radius_graph_pbc_raw(pos.detach(), ptr, pbc_offsets, cell_offsets, torch.zeros_like(pos), cutoff,
+                                                      prune=prune)
     return edge_index, offsets

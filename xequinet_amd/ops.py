@@ -138,10 +138,28 @@ def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tu
     return edge_index, rowptr
 
 
-def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff):
-    """PBC neighbour search over precomputed images (see xeq_radius_graph_pbc_* in xeq.h)."""
+def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):
+    """PBC neighbour search over precomputed images (see xeq_radius_graph_pbc_* in xeq.h).
+    prune = (recip[G,3,3], thr[G,3], reps) selects the image-pruned kernels (same edges, same order)."""
     require_hip(pos_wrap, ptr_, img, cells, shift)
     pos_wrap, img, cells, shift = (t.contiguous() for t in (pos_wrap, img, cells, shift))
+    if prune is not None:
+        recip, thr, reps = prune
+        recip, thr = recip.to(pos_wrap.dtype).contiguous(), thr.to(pos_wrap.dtype).contiguous()
+        ptr_ = ptr_.to(torch.int64).contiguous()
+        N, G, n_cells = pos_wrap.shape[0], ptr_.numel() - 1, cells.shape[0]
+        dev, dt = pos_wrap.device, dtype_code(pos_wrap)
+        deg = torch.empty(N, dtype=torch.int32, device=dev)
+        rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        call("xeq_radius_graph_pbc_count_pruned", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), n_cells, float(cutoff), ptr(recip),
+             ptr(thr), mul3(reps), ptr(deg), stream())
+        call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+        E = int(rowptr[-1].item()) if N > 0 else 0
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+        cell_offsets = torch.empty((E, 3), dtype=pos_wrap.dtype, device=dev)
+        call("xeq_radius_graph_pbc_fill_pruned", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), ptr(cells), ptr(shift), n_cells,
+             float(cutoff), ptr(recip), ptr(thr), mul3(reps), ptr(rowptr), E, ptr(edge_index), ptr(cell_offsets), stream())
+        return edge_index, cell_offsets, rowptr
     ptr_ = ptr_.to(torch.int64).contiguous()
     N, G, n_cells = pos_wrap.shape[0], ptr_.numel() - 1, cells.shape[0]
     dev = pos_wrap.device
