@@ -226,9 +226,8 @@ def gaussian_rbf(dist: Tensor, mean: Tensor, std: Tensor, eps: float = 1e-5) -> 
     return coeff * torch.exp(-0.5 * ((dist - mean) / std) ** 2)
 
 
-def compute_edge_data(data: Dict[str, Tensor], compute_forces: bool = True) -> Dict[str, Tensor]:
-    """``compute_edge_data`` (nn/basic.py:60-140), virial/strain branch omitted
-    (out of scope)."""
+def compute_edge_data(data: Dict[str, Tensor], compute_forces: bool = True, compute_virial: bool = False) -> Dict[str, Tensor]:
+    """``compute_edge_data`` (nn/basic.py:60-140) incl. the virial/strain branch (:93-107)."""
     pos = data[POSITIONS]
     edge_index = data[EDGE_INDEX]
     single_graph = False
@@ -239,12 +238,21 @@ def compute_edge_data(data: Dict[str, Tensor], compute_forces: bool = True) -> D
     elif data[BATCH].max() == 0:
         single_graph = True
     batch = data[BATCH]
+    n_graphs = data[BATCH_PTR].numel() - 1 if BATCH_PTR in data else int(batch.max()) + 1
     if compute_forces:
         pos.requires_grad_()
+    strain = torch.zeros((n_graphs, 3, 3), dtype=pos.dtype)  # :93-97
+    cell = data[CELL] if CELL in data else None
+    if compute_virial:  # :99-107
+        strain.requires_grad_()
+        symm = 0.5 * (strain + strain.transpose(1, 2))
+        pos = pos + torch.bmm(pos.unsqueeze(1), symm.index_select(0, batch)).squeeze(1)
+        if cell is not None:
+            cell = cell + torch.bmm(cell, symm)
+    data["strain"] = strain
     center, neighbor = edge_index[CENTER_IDX], edge_index[NEIGHBOR_IDX]
     vec = pos.index_select(0, center) - pos.index_select(0, neighbor)  # :114-116
-    if CELL in data:
-        cell = data[CELL]
+    if cell is not None:
         co = data[CELL_OFFSETS]
         if single_graph:
             shifts = torch.einsum("ni,ij->nj", co, cell.squeeze(0))  # :121-123
@@ -383,20 +391,29 @@ class XPaiNNOracle:
         data["energy"] = energy
         return data
 
-    def forward(self, data: Dict[str, Tensor], compute_forces: bool = True) -> Dict[str, Tensor]:
+    def forward(self, data: Dict[str, Tensor], compute_forces: bool = True, compute_virial: bool = False) -> Dict[str, Tensor]:
         data = dict(data)
         data[POSITIONS] = data[POSITIONS].detach().clone()
-        data = compute_edge_data(data, compute_forces)
+        data = compute_edge_data(data, compute_forces, compute_virial)
         data = self.embedding(data)
         for i in range(self.blocks):
             data = self.message(i, data)
             data = self.update(i, data)
         data = self.energy_out(data)
         out = {"energy": data["energy"], "atomic_energies": data["atomic_energies"]}
-        if compute_forces:
+        ones = [torch.ones_like(data["energy"])]
+        if compute_forces and compute_virial:
+            # compute_forces_and_virial (basic.py:181-199)
+            g, gs = torch.autograd.grad([data["energy"]], [data[POSITIONS], data["strain"]], ones)
+            out["forces"], out["virial"] = -g, -gs
+        elif compute_forces:
             # compute_forces_only (basic.py:143-159)
-            (g,) = torch.autograd.grad([data["energy"]], [data[POSITIONS]], [torch.ones_like(data["energy"])])
+            (g,) = torch.autograd.grad([data["energy"]], [data[POSITIONS]], ones)
             out["forces"] = -g
+        elif compute_virial:
+            # compute_virial_only (basic.py:162-178)
+            (gs,) = torch.autograd.grad([data["energy"]], [data["strain"]], ones)
+            out["virial"] = -gs
         return {k: v.detach() for k, v in out.items()}
 
     __call__ = forward

@@ -549,6 +549,43 @@ def test_model_pbc_water_energy_forces(dtype):
                  extra={"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)})
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_model_virial_pbc_and_molecules(dtype):
+    """Virial / strain branch (nn/basic.py:93-107,162-199): forces + virial, and virial alone, on a periodic water box
+    (edge vectors with cell offsets) and on a molecule batch with shuffled (not center-sorted) edges, against the
+    oracle, whose virial is pinned by finite differences on the CPU."""
+    model, oracle = _build(dtype)
+    f = _load("radius_graph_pbc_water192.npz")
+    _, z, ptr, _ = orc.synth_water_box(4, seed=5)
+    pos_m, z_m, ptr_m = orc.synth_qm9_batch(12, seed=21)
+    ei_m = orc.radius_graph_canonical(pos_m.astype(np.float32), ptr_m, 5.0)
+    ei_m = ei_m[:, np.random.default_rng(1).permutation(ei_m.shape[1])]
+    cases = [(f["pos"].astype(np.float64), z, ptr, f["edge_index"],
+              {"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)}),
+             (pos_m, z_m, ptr_m, ei_m, {})]
+    for pos, zz, pp, ei, extra in cases:
+        batch = np.repeat(np.arange(len(pp) - 1), np.diff(pp))
+        ref_in = {"pos": torch.tensor(pos), "atomic_numbers": torch.tensor(zz.astype(np.int64)), "edge_index": torch.tensor(ei),
+                  "batch": torch.tensor(batch), "ptr": torch.tensor(pp)}
+        mk = lambda: {"pos": _t(pos, dtype), "atomic_numbers": _t(zz.astype(np.int32)), "edge_index": _t(ei), "batch": _t(batch),
+                      "ptr": _t(pp), **{k: _t(v, dtype) for k, v in extra.items()}}
+        for k, v in extra.items():
+            ref_in[k] = torch.tensor(v)
+        want = oracle(ref_in, compute_forces=True, compute_virial=True)
+        with torch.enable_grad():
+            got = model(mk(), compute_forces=True, compute_virial=True)
+            only = model(mk(), compute_forces=False, compute_virial=True)
+        V, Vref = got["virial"].detach().cpu().double().numpy(), want["virial"].numpy()
+        Fg, Fref = got["forces"].detach().cpu().double().numpy(), want["forces"].numpy()
+        assert V.shape == Vref.shape == (len(pp) - 1, 3, 3)
+        # fp32: the reference's own fp32 evaluation is ~2e-4 from fp64 on 50-neighbour graphs (see _check_model)
+        tol = 1e-9 if dtype == torch.float64 else 2e-3
+        np.testing.assert_allclose(V, Vref, rtol=0, atol=tol * max(1.0, np.abs(Vref).max()))
+        np.testing.assert_allclose(Fg, Fref, rtol=0, atol=tol * max(1.0, np.abs(Fref).max()))
+        np.testing.assert_allclose(only["virial"].detach().cpu().double().numpy(), V, rtol=0, atol=1e-12 if dtype == torch.float64 else 1e-5)
+        assert "forces" not in only
+
+
 @pytest.mark.parametrize("impl", ["valu", "mfma", "sb", "wm"])
 def test_model_message_kernel_families_agree(impl, monkeypatch):
     """The fused-message kernel families (generic VALU, MFMA tile, scalar-broadcast, wave / matrix-core) and the

@@ -117,6 +117,60 @@ def test_energy_invariance_force_equivariance_and_finite_differences():
         assert abs(-(e1 - e2) / (2 * h) - F_[i, a]) < 1e-6 * max(1.0, abs(F_[i, a]))
 
 
+def test_virial_is_minus_dE_dstrain_by_finite_differences():
+    """Virial branch of the oracle (nn/basic.py:93-107,162-199): virial = -dE/dstrain, symmetric, checked by central
+    differences of the energy under a homogeneous deformation of positions AND cell of a small periodic box; for an
+    isolated molecule it equals sum_i r_i (x) F_i (symmetrised)."""
+    model, _ = _small_model()
+    rng = np.random.default_rng(4)
+    # two-graph periodic batch, 14 atoms each, cell ~ 7 A (images needed at rc = 5)
+    pos, cell, z = [], [], []
+    for _ in range(2):
+        c = np.eye(3) * 7.0 + rng.normal(0, 0.4, size=(3, 3))
+        pos.append(rng.uniform(0, 1, size=(14, 3)) @ c)
+        cell.append(c)
+        z.append(rng.choice([1, 6, 8], size=14))
+    pos, cell, z = np.concatenate(pos), np.stack(cell), np.concatenate(z)
+    ptr = np.array([0, 14, 28])
+    batch = np.repeat(np.arange(2), 14)
+    ei, co = orc.radius_graph_pbc_oracle(pos, np.array([14, 14]), [True, True, True], cell, 5.0)
+
+    def run(p, c, **kw):
+        return model({"pos": torch.tensor(p), "atomic_numbers": torch.tensor(z.astype(np.int64)), "edge_index": torch.tensor(ei),
+                      "batch": torch.tensor(batch), "ptr": torch.tensor(ptr), "cell": torch.tensor(c),
+                      "cell_offsets": torch.tensor(co.astype(np.float64))}, **kw)
+
+    out = run(pos, cell, compute_forces=True, compute_virial=True)
+    V = out["virial"].numpy()
+    assert V.shape == (2, 3, 3)
+    np.testing.assert_allclose(V, V.transpose(0, 2, 1), atol=1e-12)
+    np.testing.assert_allclose(out["forces"].numpy(), run(pos, cell)["forces"].numpy(), atol=1e-13)
+    np.testing.assert_allclose(run(pos, cell, compute_forces=False, compute_virial=True)["virial"].numpy(), V, atol=1e-13)
+    h = 1e-5
+    for g, (a, b) in [(0, (0, 0)), (0, (0, 2)), (1, (1, 2)), (1, (2, 2))]:
+        es = []
+        for sgn in (+1, -1):
+            eps = np.zeros((3, 3))
+            eps[a, b] += 0.5 * sgn * h
+            eps[b, a] += 0.5 * sgn * h          # symmetric strain of graph g only
+            p2, c2 = pos.copy(), cell.copy()
+            sl = slice(ptr[g], ptr[g + 1])
+            p2[sl] = pos[sl] + pos[sl] @ eps
+            c2[g] = cell[g] + cell[g] @ eps
+            es.append(run(p2, c2, compute_forces=False)["energy"][g].item())
+        fd = -(es[0] - es[1]) / (2 * h)
+        want = V[g, a, b]   # d/dh of E under eps = h (e_ab + e_ba) / 2 is sym(dE/dstrain)_ab = -V_ab
+        assert abs(fd - want) < 2e-6 * max(1.0, abs(want)), (g, a, b, fd, want)
+    # isolated molecules: virial = sym(sum_i r_i (x) F_i)
+    pos_m, z_m, ptr_m, ei_m, batch_m = _inputs()
+    om = model({"pos": torch.tensor(pos_m), "atomic_numbers": torch.tensor(z_m.astype(np.int64)), "edge_index": torch.tensor(ei_m),
+                "batch": torch.tensor(batch_m), "ptr": torch.tensor(ptr_m)}, compute_forces=True, compute_virial=True)
+    Fm = om["forces"].numpy()
+    W = np.zeros((len(ptr_m) - 1, 3, 3))
+    np.add.at(W, batch_m, pos_m[:, :, None] * Fm[:, None, :])
+    np.testing.assert_allclose(om["virial"].numpy(), 0.5 * (W + W.transpose(0, 2, 1)), atol=1e-10)
+
+
 def test_first_block_reduces_to_edge_term():
     """x^0 = 0 => after the first message, x = sum_e rsh (x) gate_edge only."""
     model, kw = _small_model()

@@ -67,17 +67,22 @@ def compute_edge_data(
     n_graphs = data[keys.BATCH_PTR].numel() - 1 if keys.BATCH_PTR in data else int(data[keys.BATCH].max()) + 1
 
     has_cell = keys.CELL in data
-    if compute_virial:
-        raise NotImplementedError("xequinet_amd: the virial/strain path (nn/basic.py:99-107) is not built yet")
     if compute_forces:
         pos.requires_grad_()
     strain = torch.zeros((n_graphs, 3, 3), dtype=pos.dtype, device=pos.device)
+    if compute_virial:
+        # nn/basic.py:99-107 scales positions and cell by (1 + sym(strain)); every edge vector then scales the same
+        # way, so the strain enters the edge-vector op (values at strain = 0 unchanged, gradient in its backward)
+        strain.requires_grad_()
 
     graph = edge_graph(data)
     cell = data[keys.CELL] if has_cell else None
     cell_offsets = data[keys.CELL_OFFSETS].to(pos.dtype) if has_cell else None
     batch = None if (single_graph or not has_cell) else data[keys.BATCH]
-    vectors, dist = ops.EdgeVectors.apply(pos, graph, cell, cell_offsets, batch)
+    if compute_virial:
+        vectors, dist = ops.EdgeVectors.apply(pos, graph, cell, cell_offsets, batch, strain, data[keys.BATCH_PTR])
+    else:
+        vectors, dist = ops.EdgeVectors.apply(pos, graph, cell, cell_offsets, batch)
 
     data.update({keys.EDGE_LENGTH: dist, keys.EDGE_VECTOR: vectors, keys.STRAIN: strain})
     return data
@@ -95,6 +100,25 @@ def compute_forces_only(energy: torch.Tensor, pos: torch.Tensor, training: bool 
     return -1.0 * pos_grad
 
 
+def _grad(energy, inputs, training):
+    if training:
+        raise NotImplementedError("xequinet_amd: create_graph=True (training double backward) is out of scope; use model.eval()")
+    grads = torch.autograd.grad(outputs=[energy], inputs=inputs, grad_outputs=[torch.ones_like(energy)], retain_graph=False,
+                                create_graph=False, allow_unused=True)
+    return [torch.zeros_like(x) if g is None else g for g, x in zip(grads, inputs)]
+
+
+def compute_virial_only(energy: torch.Tensor, strain: torch.Tensor, training: bool = True) -> torch.Tensor:
+    """nn/basic.py:162-178"""
+    return -1.0 * _grad(energy, [strain], training)[0]
+
+
+def compute_forces_and_virial(energy: torch.Tensor, pos: torch.Tensor, strain: torch.Tensor, training: bool = True):
+    """nn/basic.py:181-199"""
+    pos_grad, strain_grad = _grad(energy, [pos, strain], training)
+    return -1.0 * pos_grad, -1.0 * strain_grad
+
+
 def compute_properties(
     data: Dict[str, torch.Tensor],
     compute_forces: bool = True,
@@ -102,11 +126,14 @@ def compute_properties(
     training: bool = True,
     extra_properties: Optional[List[str]] = None,
 ) -> Dict[str, torch.Tensor]:
-    """nn/basic.py:202-238 (forces branch)."""
+    """nn/basic.py:202-238"""
     results = {}
-    if compute_virial:
-        raise NotImplementedError("xequinet_amd: the virial path is not built yet")
-    if compute_forces:
+    if compute_forces and compute_virial:
+        results[keys.FORCES], results[keys.VIRIAL] = compute_forces_and_virial(
+            energy=data[keys.TOTAL_ENERGY], pos=data[keys.POSITIONS], strain=data[keys.STRAIN], training=training)
+    elif compute_virial:
+        results[keys.VIRIAL] = compute_virial_only(energy=data[keys.TOTAL_ENERGY], strain=data[keys.STRAIN], training=training)
+    elif compute_forces:
         results[keys.FORCES] = compute_forces_only(energy=data[keys.TOTAL_ENERGY], pos=data[keys.POSITIONS], training=training)
     if extra_properties is not None:
         results.update({k: data[k] for k in extra_properties})

@@ -178,10 +178,15 @@ def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):
 
 # ------------------------------------------------------------------- edge geometry
 class EdgeVectors(Function):
-    """vec = pos[c] - pos[n] - cell_offsets @ cell[batch[n]], dist = |vec| (nn/basic.py:110-131)."""
+    """vec = pos[c] - pos[n] - cell_offsets @ cell[batch[n]], dist = |vec| (nn/basic.py:110-131).
+
+    ``strain`` [G,3,3] is the zero tensor of the virial branch (nn/basic.py:93-107): positions and cell are scaled
+    by (1 + sym(strain)), hence vec -> vec (1 + sym(strain)).  At strain = 0 the forward values do not change;
+    the backward pass returns dE/dstrain = sym(sum_{e in graph} vec_e (x) dE/dvec_e), a deterministic segmented
+    sum over the center-sorted edges (``edge_graph_ptr``: first edge of every graph)."""
 
     @staticmethod
-    def forward(ctx, pos, graph: EdgeGraph, cell, cell_offsets, batch):
+    def forward(ctx, pos, graph: EdgeGraph, cell, cell_offsets, batch, strain=None, graph_ptr=None):
         require_hip(pos)
         pos_c = pos.contiguous()
         E = graph.n_edges
@@ -191,6 +196,8 @@ class EdgeVectors(Function):
         call("xeq_edge_vectors_fwd", dtype_code(pos), ptr(pos_c), ptr(graph.edge_index), E, ptr(cell), ptr(cell_offsets),
              ptr(batch), ptr(vec), ptr(dist), stream())
         ctx.graph = graph
+        ctx.graph_ptr = graph_ptr
+        ctx.n_graphs = None if strain is None else strain.shape[0]
         ctx.save_for_backward(vec, dist)
         return vec, dist
 
@@ -203,10 +210,20 @@ class EdgeVectors(Function):
         if g_dist is not None:
             g = g + (g_dist / dist.clamp_min(torch.finfo(dist.dtype).tiny)).unsqueeze(-1) * vec
         g = g.contiguous()
-        grad_pos = torch.empty((graph.n_nodes, 3), dtype=vec.dtype, device=vec.device)
-        call("xeq_edge_vectors_bwd", dtype_code(vec), ptr(g), graph.n_nodes, ptr(graph.c_rowptr), ptr(graph.c_perm),
-             ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(grad_pos), stream())
-        return grad_pos, None, None, None, None
+        grad_pos = None
+        if ctx.needs_input_grad[0]:
+            grad_pos = torch.empty((graph.n_nodes, 3), dtype=vec.dtype, device=vec.device)
+            call("xeq_edge_vectors_bwd", dtype_code(vec), ptr(g), graph.n_nodes, ptr(graph.c_rowptr), ptr(graph.c_perm),
+                 ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(grad_pos), stream())
+        grad_strain = None
+        if ctx.n_graphs is not None and ctx.needs_input_grad[5]:
+            outer = (vec.unsqueeze(2) * g.unsqueeze(1)).reshape(-1, 9)            # vec_e (x) dE/dvec_e
+            if graph.c_perm is not None:
+                outer = outer.index_select(0, graph.c_perm.long())                 # walk the edges center-sorted
+            eptr = graph.c_rowptr.long().index_select(0, ctx.graph_ptr.long())     # first edge of every graph
+            m = SegmentSum.apply(outer.contiguous(), eptr).view(ctx.n_graphs, 3, 3)
+            grad_strain = 0.5 * (m + m.transpose(1, 2))
+        return grad_pos, None, None, None, None, grad_strain, None
 
 
 # ------------------------------------------------------------- e3nn-style operators
