@@ -171,10 +171,20 @@ __device__ __forceinline__ void wm_load_record(const float* __restrict__ rp, int
   }
 }
 
+// development switches (scratch/build_variant.sh -DXEQ_WM_ABLATE=bits): 1 no MFMA, 2 no gathers, 4 no channel sums
+#ifndef XEQ_WM_ABLATE
+#define XEQ_WM_ABLATE 0
+#endif
+
 // W: this lane's column of one kind in the staged weights (wl + kind * KS * 64 + lane)
 template <int KS>
 __device__ __forceinline__ f32x16 wm_filter(const float (&R)[KS], const float* W) {
   f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (XEQ_WM_ABLATE & 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = R[i % KS] * W[0];
+    return d;
+  }
 #pragma unroll
   for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(R[s], W[s * 64], d, 0, 0, 0);
   return d;
@@ -187,6 +197,7 @@ __device__ __forceinline__ f32x16 wm_filter(const float (&R)[KS], const float* W
 enum { T_G0 = 0, T_G1 = 1, T_OWN = 2, T_EID = 3, T_Y = 4, T_ROWS = 12 };
 
 __device__ __forceinline__ float wm_ld(const float* __restrict__ base, uint32_t byte_off) {
+  if (XEQ_WM_ABLATE & 2) return __uint_as_float(byte_off | 0x3f000000u);
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 __device__ __forceinline__ void wm_st(float* __restrict__ base, uint32_t byte_off, float v) {
@@ -340,7 +351,7 @@ __device__ __forceinline__ void wm_fwd_body(const WmArgs& a, int range, const Wm
   const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
   const int C = a.C;
   const WmWave wv = wm_wave<NM>(a, range, un, j);
-  const uint32_t he_off = 4u * (uint32_t)C, row_s = 4u * (uint32_t)a.F, row_x = 4u * (uint32_t)a.D;
+  const uint32_t row_s = 4u * (uint32_t)a.F, row_x = 4u * (uint32_t)a.D;
   wm_for_isolated(a, range, lane, [&](int m) {   // s_out = s_in, x_out = x_in on the unit's columns
     if (hh == 0) {
       if constexpr (HAS_S) wm_st(s_out, (uint32_t)m * row_s + wv.b_s, wm_ld(s_in, (uint32_t)m * row_s + wv.b_s));
@@ -351,7 +362,12 @@ __device__ __forceinline__ void wm_fwd_body(const WmArgs& a, int range, const Wm
   });
   if (wv.ntiles == 0) return;
   const int e0 = wv.e0, e1 = wv.e1, e2 = wv.e2;
-  const float* __restrict__ xhat = xhat_ + wv.x_base;
+  // one uniform base pointer per gathered quantity: a gather is then base[row offset + lane column], no per-load VALU
+  const float* __restrict__ h_e = h + C;                                              // gate_edge rows, same lane column
+  const float* __restrict__ h_m = h + (2 * C + 32 * un.cb - un.u0);                   // scalar-message rows
+  const float* xhat_m[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) xhat_m[m] = xhat_ + wv.x_base + (int64_t)m * (wv.xcomp_b / 4);
   const uint32_t stride0 = 4u * (uint32_t)a.H, stride1 = wv.xnode_b;
 
   const float* Ws = wl + lane;
@@ -388,9 +404,9 @@ __device__ __forceinline__ void wm_fwd_body(const WmArgs& a, int range, const Wm
           const uint32_t oh = (uint32_t)g0[r] + wv.b_hs;
           const uint32_t ox = (uint32_t)g1[r] + wv.b_x;
           hs[v0 + r] = wm_ld(h, oh);
-          he[v0 + r] = wm_ld(h, oh + he_off);
+          he[v0 + r] = wm_ld(h_e, oh);
 #pragma unroll
-          for (int m = 0; m < NM; ++m) xv[v0 + r][m] = wm_ld(xhat, ox + m * wv.xcomp_b);
+          for (int m = 0; m < NM; ++m) xv[v0 + r][m] = wm_ld(xhat_m[m], ox);
         }
       }
     };
@@ -401,7 +417,7 @@ __device__ __forceinline__ void wm_fwd_body(const WmArgs& a, int range, const Wm
         int g0[4];
         wm_tread<4>(trow, T_G0, v0, g0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hm[v0 + r] = wm_ld(h, (uint32_t)g0[r] + wv.b_hm);
+        for (int r = 0; r < 4; ++r) hm[v0 + r] = wm_ld(h_m, (uint32_t)g0[r] + wv.b_hs);
       }
     }
     float R[KS];
@@ -514,6 +530,7 @@ struct WmParts {
 
 // sum over the 32 lanes of each half-wave; the result is valid in lanes 16..31 (half 0) and 48..63 (half 1)
 __device__ __forceinline__ float wm_half_total(float v) {
+  if (XEQ_WM_ABLATE & 4) return v;
 #define XEQ_WM_DPP(v, ctrl, rmask) \
   ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), ctrl, rmask, 0xF, true)))
   v = XEQ_WM_DPP(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
@@ -582,6 +599,31 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     const int* trow = tbl + (t & 1) * (T_ROWS * 32) + 16 * hh;
     int* tnext = tbl + ((t + 1) & 1) * (T_ROWS * 32);
     const uint32_t mfirst = mk.first >> (4 * hh), mlast = mk.last >> (4 * hh), mvalid = mk.valid >> (4 * hh);
+    // ---- the rows of the owners whose segments START in this tile are needed by the first row of the segment: the
+    //      first two starts of each half are fetched here, under the MFMAs (a third start in one tile -- segments
+    //      shorter than 8 edges -- takes the blocking path below)
+    const uint32_t mf = mfirst & 0x0F0F0F0Fu;              // this half's rows only
+    const uint32_t mf2 = mf & (mf - 1u);
+    const int bA = mf ? __ffs((int)mf) - 1 : 0, bB = mf2 ? __ffs((int)mf2) - 1 : 0;
+    const int vA = (bA & 3) + 4 * (bA >> 3), vB = mf2 ? (bB & 3) + 4 * (bB >> 3) : -1;
+    float pA_hs, pA_he, pA_hm = 0.f, pA_x[NM], pB_hs, pB_he, pB_hm = 0.f, pB_x[NM];
+    {
+      const uint32_t ownA = (uint32_t)trow[T_OWN * 32 + vA], ownB = (uint32_t)trow[T_OWN * 32 + (vB < 0 ? vA : vB)];
+      const uint32_t ohA = ownA * row_h + wv.b_hs, ohB = ownB * row_h + wv.b_hs;
+      pA_hs = wm_ld(h, ohA);
+      pA_he = wm_ld(h, ohA + he_off);
+      pB_hs = wm_ld(h, ohB);
+      pB_he = wm_ld(h, ohB + he_off);
+      if constexpr (HAS_S) {
+        pA_hm = wm_ld(h, ownA * row_h + wv.b_hm);
+        pB_hm = wm_ld(h, ownB * row_h + wv.b_hm);
+      }
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        pA_x[m] = wm_ld(xhat, ownA * wv.xnode_b + wv.b_x + m * wv.xcomp_b);
+        pB_x[m] = wm_ld(xhat, ownB * wv.xnode_b + wv.b_x + m * wv.xcomp_b);
+      }
+    }
     // ---- the first GR gradient rows (and the scalar gradient rows) are issued here, under the MFMAs
     float gx[GR][NM], gsv[HAS_S ? 16 : 1];
     auto load_group = [&](int r0) {
@@ -636,14 +678,23 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
             const int v = c0 + r, gv = v - r0;
             if (any_first) {   // some half starts a segment in this chunk: load the new owner's rows
               if ((mfirst >> wm_bit(v)) & 1u) {
-                const uint32_t own = (uint32_t)trow[T_OWN * 32 + v];
-                o_hs = wm_ld(h, own * row_h + wv.b_hs);
-                const uint32_t ox = own * wv.xnode_b + wv.b_x;
+                if (v == vA) {
+                  o_hs = pA_hs;
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                  o_x[m] = wm_ld(xhat, ox + m * wv.xcomp_b);
-                  a_x[m] = 0.f;
+                  for (int m = 0; m < NM; ++m) o_x[m] = pA_x[m];
+                } else if (v == vB) {
+                  o_hs = pB_hs;
+#pragma unroll
+                  for (int m = 0; m < NM; ++m) o_x[m] = pB_x[m];
+                } else {
+                  const uint32_t own = (uint32_t)trow[T_OWN * 32 + v];
+                  o_hs = wm_ld(h, own * row_h + wv.b_hs);
+                  const uint32_t ox = own * wv.xnode_b + wv.b_x;
+#pragma unroll
+                  for (int m = 0; m < NM; ++m) o_x[m] = wm_ld(xhat, ox + m * wv.xcomp_b);
                 }
+#pragma unroll
+                for (int m = 0; m < NM; ++m) a_x[m] = 0.f;
                 a_hs = 0.f;
               }
             }
@@ -699,7 +750,7 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
             const int v = c0 + r, gv = v - r0;
             if (any_first) {
               if ((mfirst >> wm_bit(v)) & 1u) {
-                o_he = wm_ld(h, (uint32_t)trow[T_OWN * 32 + v] * row_h + wv.b_hs + he_off);
+                o_he = v == vA ? pA_he : (v == vB ? pB_he : wm_ld(h, (uint32_t)trow[T_OWN * 32 + v] * row_h + wv.b_hs + he_off));
                 a_he = 0.f;
               }
             }
@@ -739,7 +790,7 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
           const int v = c0 + r;
           if (any_first) {
             if ((mfirst >> wm_bit(v)) & 1u) {
-              o_hm = wm_ld(h, (uint32_t)trow[T_OWN * 32 + v] * row_h + wv.b_hm);
+              o_hm = v == vA ? pA_hm : (v == vB ? pB_hm : wm_ld(h, (uint32_t)trow[T_OWN * 32 + v] * row_h + wv.b_hm));
               a_hm = 0.f;
             }
           }
