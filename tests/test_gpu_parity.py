@@ -712,3 +712,41 @@ def test_full_size_properties_md17_4096_and_water_512():
     dev = np.abs(Ft - Fw)
     # fp32 on a 51-neighbour graph at |pos| ~ 25 A: re-wrapping changes every rounding; bulk and worst case bounded loosely
     assert np.quantile(dev, 0.99) < 2e-3 * fscale and dev.max() < 1e-2 * fscale, (np.quantile(dev, 0.99), dev.max())
+
+
+def test_graphed_model_replays_bitwise_and_recaptures_on_new_shapes():
+    """runtime.GraphedModel: HIP-graph replay of one evaluation equals the eager path bit for bit, also after the atoms
+    move (same topology: replay; different edge count: a new capture), for a molecule batch and a periodic box."""
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.runtime import GraphedModel
+
+    model, _ = _build(torch.float32)
+    gm = GraphedModel(model)
+    tr = NeighborTransform(5.0)
+    pos, z, ptr = orc.synth_qm9_batch(5, seed=9)
+    rng = np.random.default_rng(0)
+
+    def both(p, zz, pp, **kw):
+        d = tr(XequiBatch(_t(p, torch.float32), _t(zz), _t(pp), **kw)).to_dict()
+        with torch.enable_grad():
+            want = model(dict(d), compute_forces=True)
+        got = gm(d)
+        for k in ("energy", "forces", "atomic_energies"):
+            assert torch.equal(got[k], want[k].detach()), k
+        return d["edge_index"].shape[1]
+
+    e0 = both(pos, z, ptr)
+    assert gm.captures == 1
+    e1 = both(pos + rng.normal(0, 1e-3, size=pos.shape), z, ptr)      # same topology
+    assert e1 == e0 and gm.captures == 1
+    p2 = pos.copy()
+    p2[: ptr[1]] *= 2.5                                                  # first molecule blown up: fewer edges
+    e2 = both(p2, z, ptr)
+    assert e2 < e0 and gm.captures == 2
+    both(pos, z, ptr)
+    assert gm.captures == 2                                              # first signature still cached
+    posw, zw, ptrw, cell = orc.synth_water_box(3, seed=2)
+    kw = dict(pbc=torch.tensor([[True, True, True]], device=DEV), cell=_t(cell, torch.float32))
+    both(posw, zw, ptrw, **kw)
+    both(posw + 0.01, zw, ptrw, **dict(kw))
+    assert gm.captures in (3, 4)

@@ -25,7 +25,8 @@ class XequiBatch:
         self.atomic_numbers = atomic_numbers.to(torch.int32)  # data/datapoint.py:52-55
         self.ptr = ptr
         counts = ptr[1:] - ptr[:-1]
-        self.batch = torch.repeat_interleave(torch.arange(counts.numel(), device=ptr.device), counts)
+        # output_size: no device-to-host read-back for the length
+        self.batch = torch.repeat_interleave(torch.arange(counts.numel(), device=ptr.device), counts, output_size=n)
         self.num_graphs = int(ptr.numel() - 1)
         if (pbc is None) != (cell is None):
             raise ValueError("PBC and cell must be both defined or both undefined.")
