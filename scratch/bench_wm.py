@@ -41,3 +41,16 @@ for ab in sys.argv[1:] or ["0"]:
     print("ablate", ab, "threads", os.environ.get("XEQ_WM_THREADS"), {k: f"{v:.1f} us" for k, v in timeit("wm").items()})
 os.environ["XEQ_WM_ABLATE"] = "0"
 print("sb", {k: f"{v:.1f} us" for k, v in timeit("sb").items()})
+if os.environ.get("XEQ_WM_STAMPS"):
+    import ctypes
+    from xequinet_amd import lib
+    L = lib.load()
+    buf = (ctypes.c_ulonglong * 8)()
+    L.xeq_wm_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+    L.xeq_wm_debug_stamps(buf)            # clear
+    run("wm"); torch.cuda.synchronize()
+    L.xeq_wm_debug_stamps(buf)
+    tot = sum(buf)
+    names = ["tile top (issue loads)", "pass S MFMA issue", "pass S rows", "pass E MFMA issue", "pass E rows", "pass M MFMA issue", "pass M rows", "sums+table"]
+    print("reverse kernel, l = 0 waves, cycles by phase (one backward launch):")
+    for n, v in zip(names, buf): print(f"  {n:26s} {v/tot*100:5.1f} %   {v:.3e}")

@@ -137,8 +137,15 @@ constexpr int WM_WAVES = 4;   // waves per workgroup (independent of one another
 __device__ __forceinline__ void wm_decode(const WmArgs& a, int nunits, int& range, int& unit) {
   const int nb = gridDim.x, b = blockIdx.x;
   const int item = (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+#ifdef XEQ_WM_UNIT_MAJOR   // all workgroups of one unit are adjacent in the grid: one role's code in flight at a time
+  const int ngroups = (a.n_ranges + WM_WAVES - 1) / WM_WAVES;
+  unit = item / ngroups;
+  const int rgroup = unit < nunits ? item - unit * ngroups : ngroups;
+  if (unit >= nunits) unit = 0;
+#else
   const int rgroup = item / nunits;   // padding blocks of the grid land beyond the last group: all their ranges are empty
   unit = item - rgroup * nunits;
+#endif
   range = rgroup * WM_WAVES + (threadIdx.x >> 6);   // may be >= n_ranges: such a wave only helps staging
 }
 
@@ -522,6 +529,21 @@ __global__ void __launch_bounds__(64 * WM_WAVES) __attribute__((amdgpu_waves_per
 }
 
 // ------------------------------------------------------------------------------------------------ reverse
+// development (-DXEQ_WM_STAMPS): cycles of one wave per phase of the reverse tile loop, summed over all l = 0 waves
+__device__ unsigned long long g_wm_stamps[8];
+#ifdef XEQ_WM_STAMPS
+#define WM_STAMP(i)                                                 \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    st_[i] += now_ - last_;                                         \
+    last_ = now_;                                                   \
+  } while (0)
+#else
+#define WM_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
 struct WmParts {
   float* pd;   // [NU][E]      per-unit partial of dL/dd
   float* y1;   // [nu1][3][E]  per-unit partial of dL/dY_1m
@@ -595,6 +617,9 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
   ix = wm_idx(a, lane, 1, e0, e1, e2);
   __builtin_amdgcn_wave_barrier();
 
+#ifdef XEQ_WM_STAMPS
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = 0; t < wv.ntiles; ++t) {
     const int* trow = tbl + (t & 1) * (T_ROWS * 32) + 16 * hh;
     int* tnext = tbl + ((t + 1) & 1) * (T_ROWS * 32);
@@ -662,8 +687,11 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     ix = wm_idx(a, lane, t + 2, e0, e1, e2);
     __builtin_amdgcn_sched_barrier(0);
     float pd[16];
+    WM_STAMP(0);   // tile top: table reads, gathers and prefetches issued
     {  // ---- pass S
       const f32x16 ds = wm_filter<KS>(R, Ws), qs = wm_filter<KS>(Rd, Ws);
+      __builtin_amdgcn_sched_barrier(0);
+      WM_STAMP(1);   // MFMAs of pass S issued
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += GR) {
         if (r0 > 0) {
@@ -720,6 +748,7 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
         }
       }
     }
+    WM_STAMP(2);     // rows of pass S
     // the first rows of pass E fly under its MFMAs
     if (GR < 16) load_group(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -729,6 +758,8 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
         __builtin_amdgcn_sched_barrier(0);
         wm_row<KS, 2, (NM > 1)>(a, ixn, hh, rec, drec, row);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      WM_STAMP(3);   // MFMAs of pass E issued
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += GR) {
         if (r0 > 0) {
@@ -778,10 +809,12 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
         }
       }
     }
+    WM_STAMP(4);     // rows of pass E
     if constexpr (HAS_S) {  // ---- pass M
       const f32x16 dm = wm_filter<KS>(R, Wm), qm = wm_filter<KS>(Rd, Wm);
       __builtin_amdgcn_sched_barrier(0);
       wm_row<KS, 2, (NM > 1)>(a, ixn, hh, rec, drec, row);
+      WM_STAMP(5);   // MFMAs of pass M issued
 #pragma unroll
       for (int c0 = 0; c0 < 16; c0 += 4) {
         const uint32_t any_first = (mk.first >> wm_bit(c0)) & 0xFFu, any_last = (mk.last >> wm_bit(c0)) & 0xFFu;
@@ -802,6 +835,7 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
         }
       }
     }
+    WM_STAMP(6);     // rows of pass M
     // ---- dL/dd of every row's edge: sum over the unit's 32 channels
 #pragma unroll
     for (int v0 = 0; v0 < 16; v0 += 4) {
@@ -815,7 +849,12 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     }
     mk = wm_table<KS, 2, (NM > 1)>(lane, ixn, row, stride0, stride1, tnext);
     __builtin_amdgcn_wave_barrier();
+    WM_STAMP(7);     // channel sums, partial writes, next tile's table
   }
+#ifdef XEQ_WM_STAMPS
+  if (HAS_S && lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_wm_stamps[i], st_[i]);
+#endif
 }
 
 template <int KS>
@@ -1021,6 +1060,14 @@ int xeq_message_bwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
                   (const float*)grad_s, (const float*)grad_x, (const float*)w_rbf, (const float*)b_rbf, (float*)grad_h,
                   (float*)grad_xhat, pr);
   XEQ_CHECK_LAUNCH("xeq_message_bwd_wm");
+  return XEQ_OK;
+}
+
+/* development: read and clear the phase cycle counters of a -DXEQ_WM_STAMPS build */
+int xeq_wm_debug_stamps(unsigned long long out[8]) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wm_stamps), sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wm_stamps), zero, sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
   return XEQ_OK;
 }
 
