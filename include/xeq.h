@@ -101,6 +101,26 @@ int xeq_radius_graph_pbc_fill_pruned(int dtype, const void* pos_wrap, const int6
                                      const int32_t* rowptr, int64_t n_edges, int64_t* edge_index, void* cell_offsets,
                                      void* stream);
 
+/* Cell-list form of the same search for graphs of many atoms (the pair sweep above is O(n_g^2)).  Bins live in
+ * fractional coordinates: nbins[G,3] per axis (1 on open axes; bin width >= the cutoff across lattice planes, i.e.
+ * nbins_a <= 1 / thr_a), bin_base[G+1] = running sum of bins per graph.  xeq_radius_graph_pbc_bin_ids writes each atom's
+ * global bin id; the caller sorts atoms by it (xeq_csr_by_key: bin_start[n_bins+1], bin_atom[N]).  count/fill then
+ * visit the 3x3x3 bin block around each center (same per-pair arithmetic and image pruning as the _pruned form); fill
+ * writes unordered keys into tmp_keys[E] and ranks them per center, so edge_index / cell_offsets come out in the
+ * reference's order, bit-identical to the exhaustive form. */
+int xeq_radius_graph_pbc_bin_ids(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                                 const void* recip, const int32_t* nbins, const int32_t* bin_base, int64_t* keys, void* stream);
+int xeq_radius_graph_pbc_count_cl(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                                  const void* img, int64_t n_cells, double cutoff, const void* recip, const void* thr,
+                                  const int32_t reps[3], const int32_t* nbins, const int32_t* bin_base,
+                                  const int32_t* bin_start, const int32_t* bin_atom, int32_t* deg, void* stream);
+int xeq_radius_graph_pbc_fill_cl(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                                 const void* img, const void* cells, const void* shift, int64_t n_cells, double cutoff,
+                                 const void* recip, const void* thr, const int32_t reps[3], const int32_t* nbins,
+                                 const int32_t* bin_base, const int32_t* bin_start, const int32_t* bin_atom,
+                                 const int32_t* rowptr, int64_t n_edges, int64_t* tmp_keys, int64_t* edge_index,
+                                 void* cell_offsets, void* stream);
+
 /* ------------------------------------------------------------ edge geometry */
 
 /* compute_edge_data (nn/basic.py:110-131): vec = pos[c] - pos[n] - cell_offsets @ cell[batch[n]],

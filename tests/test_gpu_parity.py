@@ -87,7 +87,8 @@ def test_radius_graph_pbc_pruned_equals_exhaustive(dtype):
 
     rng = np.random.default_rng(5)
     for trial, (n_atoms, L, pbc) in enumerate([((40, 25), 9.0, [True, True, True]), ((30,), 4.2, [True, True, True]),
-                                                ((35, 20, 50), 7.5, [True, True, False]), ((64,), 12.0, [True, False, True])]):
+                                                ((35, 20, 50), 7.5, [True, True, False]), ((64,), 12.0, [True, False, True]),
+                                                ((900, 300), 27.0, [True, True, True]), ((700,), 31.0, [True, True, False])]):
         G = len(n_atoms)
         cell = np.stack([np.eye(3) * L * rng.uniform(0.8, 1.3) + rng.normal(0, 0.12 * L, size=(3, 3)) for _ in range(G)])
         frac = [rng.uniform(-0.4, 1.6, size=(n, 3)) for n in n_atoms]
@@ -100,11 +101,15 @@ def test_radius_graph_pbc_pruned_equals_exhaustive(dtype):
         img = torch.bmm(cell_offsets.view(1, -1, 3).expand(G, -1, -1).contiguous(), cell_t)
         pw, shift = wrap_positions(pos_t, cell_t, nn, pbc)
         ptr = _t(np.concatenate([[0], np.cumsum(n_atoms)]))
+        from xequinet_amd.data.radius_graph import _with_bins
+
         a = ops.radius_graph_pbc_raw(pw, ptr, img, cell_offsets, shift, 5.0)
         b = ops.radius_graph_pbc_raw(pw, ptr, img, cell_offsets, shift, 5.0, prune=prune)
+        c = ops.radius_graph_pbc_raw(pw, ptr, img, cell_offsets, shift, 5.0, prune=_with_bins(prune, pbc))   # cell list
         assert a[0].shape[1] > 0, trial
-        for u, v in zip(a, b):
+        for u, v, w in zip(a, b, c):
             assert torch.equal(u, v), trial
+            assert torch.equal(u, w), trial
 
 
 def test_single_radius_graph_golden():

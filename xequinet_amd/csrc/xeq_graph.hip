@@ -286,6 +286,161 @@ __global__ void k_radius_graph_pbc_img(const T* __restrict__ pw, const int64_t* 
   if (!FILL && lane == 0) deg[i] = cnt;
 }
 
+// ------------------------------------------------------------------------------ PBC radius graph, cell list
+// For graphs of many atoms the O(n_g^2) pair sweep above is replaced by a bin grid in fractional coordinates:
+//   bins per periodic axis nb_a = floor(1 / thr_a) (bin width >= the cutoff measured across lattice planes), so every
+//   neighbor of a center lies in the 3 x 3 x 3 block of bins around it (periodic wrap; axes with nb <= 2 visit each
+//   bin once; open axes have one bin);
+//   atoms are sorted by (graph, bin) with xeq_csr_by_key (stable: ascending atom index inside a bin);
+//   one wave per center walks the <= 27 bins, lane = candidate atom, and evaluates the surviving images with exactly
+//   the arithmetic of k_radius_graph_pbc;
+//   hits are written unordered as keys (j - a) n_cells + c into the center's segment and k_pbc_sort_segment ranks them
+//   (keys are unique per center), which restores the reference's (neighbor * n_cells + cell) order bit for bit.
+template <typename T>
+__device__ __forceinline__ void pbc_bin_of(const T* __restrict__ p, const T* __restrict__ rg, const int32_t* __restrict__ nb,
+                                           int (&b)[3]) {
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const T f = p[0] * rg[3 * ax] + p[1] * rg[3 * ax + 1] + p[2] * rg[3 * ax + 2];
+    int v = (int)floor_<T>(f * T(nb[ax]));
+    v = v < 0 ? 0 : (v >= nb[ax] ? nb[ax] - 1 : v);   // wrapped positions sit in [0, 1) up to rounding
+    b[ax] = nb[ax] > 1 ? v : 0;
+  }
+}
+
+template <typename T>
+__global__ void k_pbc_bin_ids(const T* __restrict__ pw, const int64_t* __restrict__ ptr, int64_t n_graphs, int64_t n_nodes,
+                              const T* __restrict__ recip, const int32_t* __restrict__ nb, const int32_t* __restrict__ bin_base,
+                              int64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const int64_t g = graph_of(ptr, n_graphs, i);
+  int b[3];
+  pbc_bin_of<T>(pw + 3 * i, recip + 9 * g, nb + 3 * g, b);
+  keys[i] = (int64_t)bin_base[g] + ((int64_t)b[0] * nb[3 * g + 1] + b[1]) * nb[3 * g + 2] + b[2];
+}
+
+template <typename T, bool FILL>
+__global__ void k_radius_graph_pbc_cl(const T* __restrict__ pw, const int64_t* __restrict__ ptr, int64_t n_graphs,
+                                      int64_t n_nodes, const T* __restrict__ img, int64_t n_cells, T rc,
+                                      const T* __restrict__ recip, const T* __restrict__ thr, PbcPrune pr,
+                                      const int32_t* __restrict__ nb, const int32_t* __restrict__ bin_base,
+                                      const int32_t* __restrict__ bin_start, const int32_t* __restrict__ bin_atom,
+                                      int32_t* __restrict__ deg, const int32_t* __restrict__ rowptr,
+                                      int64_t* __restrict__ tmp_keys) {
+  const int lane = threadIdx.x & 63;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n_nodes) return;
+  const int64_t g = graph_of(ptr, n_graphs, i);
+  const int64_t a = ptr[g];
+  const T* gimg = img + g * n_cells * 3;
+  const T* rg = recip + g * 9;
+  const int32_t* nbg = nb + 3 * g;
+  const T t[3] = {thr[3 * g], thr[3 * g + 1], thr[3 * g + 2]};
+  const T xi = pw[3 * i], yi = pw[3 * i + 1], zi = pw[3 * i + 2];
+  const int w1 = 2 * pr.rep[1] + 1, w2 = 2 * pr.rep[2] + 1;
+  int bi[3];
+  pbc_bin_of<T>(pw + 3 * i, rg, nbg, bi);
+  int cntax[3], first[3];   // bins to visit per axis: all of them when nb <= 2, else b-1, b, b+1 (wrapped)
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    cntax[ax] = nbg[ax] <= 2 ? nbg[ax] : 3;
+    first[ax] = nbg[ax] <= 2 ? 0 : bi[ax] - 1;
+  }
+  int64_t w = FILL ? (int64_t)rowptr[i] : 0;
+  int32_t cnt = 0;
+  for (int q0 = 0; q0 < cntax[0]; ++q0)
+    for (int q1 = 0; q1 < cntax[1]; ++q1)
+      for (int q2 = 0; q2 < cntax[2]; ++q2) {
+        int b0 = first[0] + q0, b1 = first[1] + q1, b2 = first[2] + q2;
+        b0 = b0 < 0 ? b0 + nbg[0] : (b0 >= nbg[0] ? b0 - nbg[0] : b0);
+        b1 = b1 < 0 ? b1 + nbg[1] : (b1 >= nbg[1] ? b1 - nbg[1] : b1);
+        b2 = b2 < 0 ? b2 + nbg[2] : (b2 >= nbg[2] ? b2 - nbg[2] : b2);
+        const int64_t bin = (int64_t)bin_base[g] + ((int64_t)b0 * nbg[1] + b1) * nbg[2] + b2;
+        const int s0 = bin_start[bin], s1 = bin_start[bin + 1];
+        for (int sl0 = s0; sl0 < s1; sl0 += 64) {
+          const int sl = sl0 + lane;
+          const bool have = sl < s1;
+          const int64_t j = have ? (int64_t)bin_atom[sl] : a;
+          int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
+          T xj = T(0), yj = T(0), zj = T(0);
+          if (have) {
+            xj = pw[3 * j];
+            yj = pw[3 * j + 1];
+            zj = pw[3 * j + 2];
+            const T vx = xi - xj, vy = yi - yj, vz = zi - zj;
+            const T f[3] = {vx * rg[0] + vy * rg[1] + vz * rg[2], vx * rg[3] + vy * rg[4] + vz * rg[5],
+                            vx * rg[6] + vy * rg[7] + vz * rg[8]};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+              if (pr.rep[ax] == 0) {
+                lo[ax] = hi[ax] = 0;
+              } else {
+                const T l = ceil_<T>(f[ax] - t[ax]), h = floor_<T>(f[ax] + t[ax]);
+                lo[ax] = l < T(-pr.rep[ax]) ? -pr.rep[ax] : (int)l;
+                hi[ax] = h > T(pr.rep[ax]) ? pr.rep[ax] : (int)h;
+              }
+            }
+          }
+          int nh = 0;
+          for (int n0 = lo[0]; n0 <= hi[0]; ++n0)
+            for (int n1 = lo[1]; n1 <= hi[1]; ++n1)
+              for (int n2 = lo[2]; n2 <= hi[2]; ++n2) {
+                const int64_t c = ((int64_t)(n0 + pr.rep[0]) * w1 + (n1 + pr.rep[1])) * w2 + (n2 + pr.rep[2]);
+                T bx = add_rn<T>(xj, gimg[3 * c]), by = add_rn<T>(yj, gimg[3 * c + 1]), bz = add_rn<T>(zj, gimg[3 * c + 2]);
+                T dx = sub_rn<T>(xi, bx), dy = sub_rn<T>(yi, by), dz = sub_rn<T>(zi, bz);
+                T D = sqrt_<T>(add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz)));
+                if ((D < rc) && (D > T(0.01))) ++nh;
+              }
+          int base = 0, total = 0;
+          const unsigned long long lt = (1ull << lane) - 1ull;
+          for (int bit = 0; bit < 31; ++bit) {
+            const unsigned long long m = __ballot((nh >> bit) & 1);
+            base += __popcll(m & lt) << bit;
+            total += __popcll(m) << bit;
+            if (__ballot(nh >> (bit + 1)) == 0ull) break;
+          }
+          if (FILL && nh > 0) {
+            int64_t p = w + base;
+            for (int n0 = lo[0]; n0 <= hi[0]; ++n0)
+              for (int n1 = lo[1]; n1 <= hi[1]; ++n1)
+                for (int n2 = lo[2]; n2 <= hi[2]; ++n2) {
+                  const int64_t c = ((int64_t)(n0 + pr.rep[0]) * w1 + (n1 + pr.rep[1])) * w2 + (n2 + pr.rep[2]);
+                  T bx = add_rn<T>(xj, gimg[3 * c]), by = add_rn<T>(yj, gimg[3 * c + 1]), bz = add_rn<T>(zj, gimg[3 * c + 2]);
+                  T dx = sub_rn<T>(xi, bx), dy = sub_rn<T>(yi, by), dz = sub_rn<T>(zi, bz);
+                  T D = sqrt_<T>(add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz)));
+                  if ((D < rc) && (D > T(0.01))) tmp_keys[p++] = (j - a) * n_cells + c;
+                }
+          }
+          w += total;
+          cnt += total;
+        }
+      }
+  if (!FILL && lane == 0) deg[i] = cnt;
+}
+
+// rank the unordered keys of every center and emit edge_index / cell_offsets in ascending key order
+template <typename T>
+__global__ void k_pbc_sort_segment(const int64_t* __restrict__ tmp_keys, const int32_t* __restrict__ rowptr,
+                                   const int64_t* __restrict__ ptr, int64_t n_graphs, int64_t n_nodes, int64_t n_cells,
+                                   const T* __restrict__ cells, const T* __restrict__ shift, int64_t n_edges,
+                                   int64_t* __restrict__ edge_index, T* __restrict__ cell_offsets) {
+  const int lane = threadIdx.x & 63;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n_nodes) return;
+  const int64_t a = ptr[graph_of(ptr, n_graphs, i)];
+  const int s0 = rowptr[i], s1 = rowptr[i + 1];
+  for (int q = s0 + lane; q < s1; q += 64) {
+    const int64_t key = tmp_keys[q];
+    int rank = 0;
+    for (int r = s0; r < s1; ++r) rank += tmp_keys[r] < key ? 1 : 0;
+    const int64_t p = (int64_t)s0 + rank, jl = key / n_cells, c = key - jl * n_cells, j = a + jl;
+    edge_index[p] = i;
+    edge_index[n_edges + p] = j;
+    for (int ax = 0; ax < 3; ++ax) cell_offsets[3 * p + ax] = cells[3 * c + ax] + (shift[3 * i + ax] - shift[3 * j + ax]);
+  }
+}
+
 }  // namespace xeq
 
 using namespace xeq;
@@ -450,6 +605,62 @@ int xeq_radius_graph_pbc_fill_pruned(int dtype, const void* pos_wrap, const int6
                        n_edges, edge_index, (T*)cell_offsets);
   });
   XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_fill_pruned");
+  return XEQ_OK;
+}
+
+/* ---- cell-list form (graphs of many atoms): see k_radius_graph_pbc_cl */
+int xeq_radius_graph_pbc_bin_ids(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                                 const void* recip, const int32_t* nbins, const int32_t* bin_base, int64_t* keys, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0, "xeq_radius_graph_pbc_bin_ids: bad sizes");
+  if (n_nodes == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_pbc_bin_ids<T>), dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)pos_wrap, ptr, n_graphs, n_nodes, (const T*)recip, nbins, bin_base, keys);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_bin_ids");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_pbc_count_cl(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                                  const void* img, int64_t n_cells, double cutoff, const void* recip, const void* thr,
+                                  const int32_t reps[3], const int32_t* nbins, const int32_t* bin_base,
+                                  const int32_t* bin_start, const int32_t* bin_atom, int32_t* deg, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_cells > 0, "xeq_radius_graph_pbc_count_cl: bad sizes");
+  XEQ_CHECK_ARG((int64_t)(2 * reps[0] + 1) * (2 * reps[1] + 1) * (2 * reps[2] + 1) == n_cells,
+                "xeq_radius_graph_pbc_count_cl: image counts do not match n_cells");
+  if (n_nodes == 0) return XEQ_OK;
+  PbcPrune pr{{reps[0], reps[1], reps[2]}};
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_radius_graph_pbc_cl<T, false>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos_wrap, ptr, n_graphs, n_nodes, (const T*)img, n_cells, (T)cutoff,
+                       (const T*)recip, (const T*)thr, pr, nbins, bin_base, bin_start, bin_atom, deg,
+                       (const int32_t*)nullptr, (int64_t*)nullptr);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_count_cl");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_pbc_fill_cl(int dtype, const void* pos_wrap, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
+                                 const void* img, const void* cells, const void* shift, int64_t n_cells, double cutoff,
+                                 const void* recip, const void* thr, const int32_t reps[3], const int32_t* nbins,
+                                 const int32_t* bin_base, const int32_t* bin_start, const int32_t* bin_atom,
+                                 const int32_t* rowptr, int64_t n_edges, int64_t* tmp_keys, int64_t* edge_index,
+                                 void* cell_offsets, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_cells > 0 && n_edges >= 0, "xeq_radius_graph_pbc_fill_cl: bad sizes");
+  XEQ_CHECK_ARG((int64_t)(2 * reps[0] + 1) * (2 * reps[1] + 1) * (2 * reps[2] + 1) == n_cells,
+                "xeq_radius_graph_pbc_fill_cl: image counts do not match n_cells");
+  if (n_nodes == 0 || n_edges == 0) return XEQ_OK;
+  PbcPrune pr{{reps[0], reps[1], reps[2]}};
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_radius_graph_pbc_cl<T, true>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)pos_wrap, ptr, n_graphs, n_nodes, (const T*)img, n_cells, (T)cutoff,
+                       (const T*)recip, (const T*)thr, pr, nbins, bin_base, bin_start, bin_atom, (int32_t*)nullptr, rowptr,
+                       tmp_keys);
+    hipLaunchKernelGGL((k_pbc_sort_segment<T>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const int64_t*)tmp_keys, rowptr, ptr, n_graphs, n_nodes, n_cells, (const T*)cells, (const T*)shift,
+                       n_edges, edge_index, (T*)cell_offsets);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_fill_cl");
   return XEQ_OK;
 }
 

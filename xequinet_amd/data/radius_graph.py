@@ -31,6 +31,27 @@ def wrap_positions(pos: torch.Tensor, cell: torch.Tensor, n_nodes_per_graph: tor
 
 
 _PRUNE_MARGIN = 1e-3  # on |f_a - n_a|: far above the rounding of f, far below any lattice spacing
+_CELL_LIST_MIN_ATOMS = 512   # average atoms per graph from which the bin grid replaces the O(n_g^2) pair sweep
+_CELL_LIST_MAX_BINS = 64     # per axis
+
+
+def _use_cell_list(n_atoms: int, n_graphs: int) -> bool:
+    import os
+
+    flag = os.environ.get("XEQ_PBC_CELL_LIST")
+    if flag is not None:
+        return flag not in ("0", "", "false")
+    return n_atoms >= _CELL_LIST_MIN_ATOMS * max(1, n_graphs)
+
+
+def _with_bins(prune, pbc: List[bool]):
+    """prune + bins per axis: floor(1 / thr_a) on periodic axes (bin width >= cutoff across lattice planes), 1 on open ones."""
+    recip, thr, reps = prune
+    nb = torch.floor(1.0 / thr).clamp_(1, _CELL_LIST_MAX_BINS).to(torch.int32)
+    for ax in range(3):
+        if not pbc[ax]:
+            nb[:, ax] = 1
+    return recip, thr, reps, nb
 
 
 def _image_counts(cell: torch.Tensor, pbc: List[bool], cutoff: float, with_prune: bool = False):
@@ -80,6 +101,8 @@ def radius_graph_pbc(pos: torch.Tensor, n_nodes_per_graph: torch.Tensor, pbc: to
     pos_wrap, shift = wrap_positions(pos, cell, n_nodes_per_graph, pbc_)
     ptr = torch.zeros(batch_size + 1, dtype=torch.int64, device=device)
     ptr[1:] = torch.cumsum(n_nodes_per_graph, dim=0)
+    if _use_cell_list(pos.shape[0], batch_size):
+        prune = _with_bins(prune, pbc_)
     edge_index, offsets, rowptr = ops.radius_graph_pbc_raw(pos_wrap, ptr, pbc_offsets, cell_offsets, shift, cutoff, prune=prune)
     if return_rowptr:
         return edge_index, offsets, rowptr
@@ -96,6 +119,7 @@ def single_radius_graph(pos: torch.Tensor, pbc: torch.Tensor, cell: torch.Tensor
     cell_offsets = torch.cartesian_prod(*cells_per_dim).reshape(-1, 3)
     pbc_offsets = torch.mm(cell_offsets, cell).unsqueeze(0)
     ptr = torch.tensor([0, pos.shape[0]], dtype=torch.int64, device=device)
+    # positions are NOT wrapped here (:195-275), so the bin grid (fractional coordinates in [0, 1)) does not apply
     edge_index, offsets, _ = ops.radius_graph_pbc_raw(pos.detach(), ptr, pbc_offsets, cell_offsets, torch.zeros_like(pos), cutoff,
                                                       prune=prune)
     return edge_index, offsets

@@ -35,6 +35,10 @@ _PROTOS = {
     "xeq_radius_graph_pbc_count_pruned": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, c_double, _P, _P, _I3, _P, _P],
     "xeq_radius_graph_pbc_fill_pruned": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_double, _P, _P, _I3, _P, c_int64,
                                          _P, _P, _P],
+    "xeq_radius_graph_pbc_bin_ids": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P],
+    "xeq_radius_graph_pbc_count_cl": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, c_double, _P, _P, _I3, _P, _P, _P, _P, _P, _P],
+    "xeq_radius_graph_pbc_fill_cl": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_double, _P, _P, _I3, _P, _P, _P, _P,
+                                     _P, c_int64, _P, _P, _P, _P],
     "xeq_edge_vectors_fwd": [c_int, _P, _P, c_int64, _P, _P, _P, _P, _P, _P],
     "xeq_edge_vectors_bwd": [c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
     "xeq_sph_harm_fwd": [c_int, _P, c_int64, _I3, c_int, _P, _P],

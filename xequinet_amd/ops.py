@@ -143,6 +143,35 @@ def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):
     prune = (recip[G,3,3], thr[G,3], reps) selects the image-pruned kernels (same edges, same order)."""
     require_hip(pos_wrap, ptr_, img, cells, shift)
     pos_wrap, img, cells, shift = (t.contiguous() for t in (pos_wrap, img, cells, shift))
+    if prune is not None and len(prune) == 4:
+        # cell list (graphs of many atoms): bins in fractional coordinates, see xeq_radius_graph_pbc_*_cl
+        recip, thr, reps, nbins = prune
+        recip, thr = recip.to(pos_wrap.dtype).contiguous(), thr.to(pos_wrap.dtype).contiguous()
+        nbins = nbins.to(torch.int32).contiguous()
+        ptr_ = ptr_.to(torch.int64).contiguous()
+        N, G, n_cells = pos_wrap.shape[0], ptr_.numel() - 1, cells.shape[0]
+        dev, dt = pos_wrap.device, dtype_code(pos_wrap)
+        per_graph = nbins.prod(dim=1)
+        bin_base = torch.zeros(G + 1, dtype=torch.int32, device=dev)
+        bin_base[1:] = torch.cumsum(per_graph, 0)
+        n_bins = int(bin_base[-1].item())
+        keys_ = torch.empty(N, dtype=torch.int64, device=dev)
+        call("xeq_radius_graph_pbc_bin_ids", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(recip), ptr(nbins), ptr(bin_base), ptr(keys_),
+             stream())
+        bin_start, bin_atom = csr_by_key(keys_, n_bins)
+        deg = torch.empty(N, dtype=torch.int32, device=dev)
+        rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        call("xeq_radius_graph_pbc_count_cl", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), n_cells, float(cutoff), ptr(recip),
+             ptr(thr), mul3(reps), ptr(nbins), ptr(bin_base), ptr(bin_start), ptr(bin_atom), ptr(deg), stream())
+        call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+        E = int(rowptr[-1].item()) if N > 0 else 0
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+        cell_offsets = torch.empty((E, 3), dtype=pos_wrap.dtype, device=dev)
+        tmp_keys = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+        call("xeq_radius_graph_pbc_fill_cl", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), ptr(cells), ptr(shift), n_cells,
+             float(cutoff), ptr(recip), ptr(thr), mul3(reps), ptr(nbins), ptr(bin_base), ptr(bin_start), ptr(bin_atom), ptr(rowptr),
+             E, ptr(tmp_keys), ptr(edge_index), ptr(cell_offsets), stream())
+        return edge_index, cell_offsets, rowptr
     if prune is not None:
         recip, thr, reps = prune
         recip, thr = recip.to(pos_wrap.dtype).contiguous(), thr.to(pos_wrap.dtype).contiguous()
