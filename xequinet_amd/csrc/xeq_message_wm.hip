@@ -119,7 +119,7 @@ __device__ __forceinline__ WmUnit wm_unit(const WmArgs& a, int u) {
 #define XEQ_WM_FWD_GR(NM) ((NM) == 1 ? 16 : ((NM) == 3 ? 8 : 4))
 #endif
 #ifndef XEQ_WM_BWD_GR
-#define XEQ_WM_BWD_GR(NM) ((NM) == 1 ? 16 : ((NM) == 3 ? 8 : 4))
+#define XEQ_WM_BWD_GR(NM) ((NM) == 5 ? 8 : 16)
 #endif
 // resident waves per SIMD the register allocation must allow
 #ifndef XEQ_WM_FWD_WPE
