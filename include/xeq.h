@@ -70,6 +70,21 @@ int xeq_radius_graph_count(int dtype, const void* pos, const int64_t* ptr, int64
 int xeq_radius_graph_fill(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
                           double cutoff, const int32_t* rowptr, int64_t n_edges, int64_t* edge_index, void* stream);
 
+/* Cell-list form of the open-boundary search for graphs of many atoms (the sweep above is O(n_g^2) per graph): per
+ * graph an axis-aligned bin grid over its bounding box, lo[G,3] / inv_w[G,3] (inverse bin width, width >= cutoff) /
+ * nbins[G,3], bin_base[G+1] = running bin count.  xeq_radius_graph_bin_ids gives each atom's global bin id, the caller
+ * sorts atoms by it (xeq_csr_by_key: bin_start, bin_atom); count/fill visit the 3x3x3 bin block of each center with the
+ * same d^2 < r^2 arithmetic and rank the hits per center: the same canonical edge_index, bit for bit. */
+int xeq_radius_graph_bin_ids(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, const void* lo,
+                             const void* inv_w, const int32_t* nbins, const int32_t* bin_base, int64_t* keys, void* stream);
+int xeq_radius_graph_count_cl(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, double cutoff,
+                              const void* lo, const void* inv_w, const int32_t* nbins, const int32_t* bin_base,
+                              const int32_t* bin_start, const int32_t* bin_atom, int32_t* deg, void* stream);
+int xeq_radius_graph_fill_cl(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, double cutoff,
+                             const void* lo, const void* inv_w, const int32_t* nbins, const int32_t* bin_base,
+                             const int32_t* bin_start, const int32_t* bin_atom, const int32_t* rowptr, int64_t n_edges,
+                             int64_t* tmp_keys, int64_t* edge_index, void* stream);
+
 /* Replaces the cdist/nonzero search of radius_graph_pbc (data/radius_graph.py:118-126,
  * 162-181).  The caller supplies what the reference computes on the host side:
  * wrapped positions pos_wrap[N,3] (:111), per-graph image translation vectors

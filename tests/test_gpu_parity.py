@@ -50,6 +50,30 @@ def test_radius_graph_nonpbc_bit_exact(dtype):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_radius_graph_cell_list_equals_pair_sweep(dtype, monkeypatch):
+    """Open-boundary cell list (graphs of many atoms) against the O(n_g^2) sweep: a 3000-atom blob, a flat sheet (one
+    bin along z), a batch with small and empty graphs -- identical edge_index."""
+    from xequinet_amd.cluster import radius_graph
+
+    rng = np.random.default_rng(12)
+    blob = rng.normal(0, 9.0, size=(3000, 3))
+    sheet = np.concatenate([rng.uniform(0, 60, size=(1500, 2)), rng.uniform(0, 0.5, size=(1500, 1))], axis=1)
+    small = rng.normal(0, 2.0, size=(9, 3))
+    pos = np.concatenate([blob, small, sheet]).astype(np.float32 if dtype == torch.float32 else np.float64)
+    ptr = np.array([0, 3000, 3009, 3009, 4509])
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("XEQ_CELL_LIST", flag)
+        outs[flag] = radius_graph(_t(pos), 5.0, ptr=_t(ptr))
+    assert outs["0"].shape[1] > 20000
+    assert torch.equal(outs["0"], outs["1"])
+    monkeypatch.delenv("XEQ_CELL_LIST")
+    want = orc.radius_graph_canonical(pos[3000:3009], np.array([0, 9]), 5.0)
+    sub = outs["1"][:, (outs["1"][0] >= 3000) & (outs["1"][0] < 3009)].cpu().numpy() - 3000
+    np.testing.assert_array_equal(sub, want)
+
+
 def test_radius_graph_edge_cases():
     from xequinet_amd.cluster import radius_graph
 

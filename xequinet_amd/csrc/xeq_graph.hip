@@ -441,6 +441,91 @@ __global__ void k_pbc_sort_segment(const int64_t* __restrict__ tmp_keys, const i
   }
 }
 
+// ------------------------------------------------------------------------------ open-boundary radius graph, cell list
+// Same idea without images: per graph an axis-aligned grid over its bounding box (lo[G,3], inverse bin width
+// inv_w[G,3], nbins[G,3]; bin width >= the cutoff, so all neighbors of a center sit in the 3x3x3 block around its bin).
+// The per-pair test is the arithmetic of k_radius_graph (d^2 < r^2, rounding-explicit), hits are ranked per center, so
+// edge_index is the same canonical (center, neighbor) order, bit for bit.
+template <typename T>
+__device__ __forceinline__ void box_bin_of(const T* __restrict__ p, const T* __restrict__ lo, const T* __restrict__ inv_w,
+                                           const int32_t* __restrict__ nb, int (&b)[3]) {
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    int v = (int)floor_<T>((p[ax] - lo[ax]) * inv_w[ax]);
+    b[ax] = v < 0 ? 0 : (v >= nb[ax] ? nb[ax] - 1 : v);
+  }
+}
+
+template <typename T>
+__global__ void k_box_bin_ids(const T* __restrict__ pos, const int64_t* __restrict__ ptr, int64_t n_graphs, int64_t n_nodes,
+                              const T* __restrict__ lo, const T* __restrict__ inv_w, const int32_t* __restrict__ nb,
+                              const int32_t* __restrict__ bin_base, int64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const int64_t g = graph_of(ptr, n_graphs, i);
+  int b[3];
+  box_bin_of<T>(pos + 3 * i, lo + 3 * g, inv_w + 3 * g, nb + 3 * g, b);
+  keys[i] = (int64_t)bin_base[g] + ((int64_t)b[0] * nb[3 * g + 1] + b[1]) * nb[3 * g + 2] + b[2];
+}
+
+template <typename T, bool FILL>
+__global__ void k_radius_graph_cl(const T* __restrict__ pos, const int64_t* __restrict__ ptr, int64_t n_graphs,
+                                  int64_t n_nodes, T r2, const T* __restrict__ lo, const T* __restrict__ inv_w,
+                                  const int32_t* __restrict__ nb, const int32_t* __restrict__ bin_base,
+                                  const int32_t* __restrict__ bin_start, const int32_t* __restrict__ bin_atom,
+                                  int32_t* __restrict__ deg, const int32_t* __restrict__ rowptr,
+                                  int64_t* __restrict__ tmp_keys) {
+  const int lane = threadIdx.x & 63;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n_nodes) return;
+  const int64_t g = graph_of(ptr, n_graphs, i);
+  const int32_t* nbg = nb + 3 * g;
+  const T xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  int bi[3];
+  box_bin_of<T>(pos + 3 * i, lo + 3 * g, inv_w + 3 * g, nbg, bi);
+  int64_t w = FILL ? (int64_t)rowptr[i] : 0;
+  int32_t cnt = 0;
+  for (int b0 = max(bi[0] - 1, 0); b0 <= min(bi[0] + 1, nbg[0] - 1); ++b0)
+    for (int b1 = max(bi[1] - 1, 0); b1 <= min(bi[1] + 1, nbg[1] - 1); ++b1)
+      for (int b2 = max(bi[2] - 1, 0); b2 <= min(bi[2] + 1, nbg[2] - 1); ++b2) {
+        const int64_t bin = (int64_t)bin_base[g] + ((int64_t)b0 * nbg[1] + b1) * nbg[2] + b2;
+        const int s0 = bin_start[bin], s1 = bin_start[bin + 1];
+        for (int sl0 = s0; sl0 < s1; sl0 += 64) {
+          const int sl = sl0 + lane;
+          bool hit = false;
+          int64_t j = 0;
+          if (sl < s1) {
+            j = bin_atom[sl];
+            T dx = sub_rn<T>(xi, pos[3 * j]), dy = sub_rn<T>(yi, pos[3 * j + 1]), dz = sub_rn<T>(zi, pos[3 * j + 2]);
+            T d2 = add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz));
+            hit = d2 < r2 && j != i;
+          }
+          const unsigned long long m = __ballot(hit);
+          if (FILL && hit) tmp_keys[w + __popcll(m & ((1ull << lane) - 1ull))] = j;
+          const int pc = __popcll(m);
+          w += pc;
+          cnt += pc;
+        }
+      }
+  if (!FILL && lane == 0) deg[i] = cnt;
+}
+
+// rank the unordered neighbor ids of every center and emit edge_index in (center, neighbor) order
+__global__ void k_sort_segment_plain(const int64_t* __restrict__ tmp_keys, const int32_t* __restrict__ rowptr, int64_t n_nodes,
+                                     int64_t n_edges, int64_t* __restrict__ edge_index) {
+  const int lane = threadIdx.x & 63;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n_nodes) return;
+  const int s0 = rowptr[i], s1 = rowptr[i + 1];
+  for (int q = s0 + lane; q < s1; q += 64) {
+    const int64_t key = tmp_keys[q];
+    int rank = 0;
+    for (int r = s0; r < s1; ++r) rank += tmp_keys[r] < key ? 1 : 0;
+    edge_index[(int64_t)s0 + rank] = i;
+    edge_index[n_edges + s0 + rank] = key;
+  }
+}
+
 }  // namespace xeq
 
 using namespace xeq;
@@ -661,6 +746,52 @@ int xeq_radius_graph_pbc_fill_cl(int dtype, const void* pos_wrap, const int64_t*
                        n_edges, edge_index, (T*)cell_offsets);
   });
   XEQ_CHECK_LAUNCH("xeq_radius_graph_pbc_fill_cl");
+  return XEQ_OK;
+}
+
+/* ---- open-boundary cell list: see k_radius_graph_cl */
+int xeq_radius_graph_bin_ids(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, const void* lo,
+                             const void* inv_w, const int32_t* nbins, const int32_t* bin_base, int64_t* keys, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0, "xeq_radius_graph_bin_ids: bad sizes");
+  if (n_nodes == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_box_bin_ids<T>), dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)pos, ptr, n_graphs, n_nodes, (const T*)lo, (const T*)inv_w, nbins, bin_base, keys);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_bin_ids");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_count_cl(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, double cutoff,
+                              const void* lo, const void* inv_w, const int32_t* nbins, const int32_t* bin_base,
+                              const int32_t* bin_start, const int32_t* bin_atom, int32_t* deg, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0, "xeq_radius_graph_count_cl: bad sizes");
+  if (n_nodes == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    T rc = (T)cutoff;
+    hipLaunchKernelGGL((k_radius_graph_cl<T, false>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)pos, ptr, n_graphs, n_nodes, rc * rc, (const T*)lo, (const T*)inv_w, nbins, bin_base, bin_start,
+                       bin_atom, deg, (const int32_t*)nullptr, (int64_t*)nullptr);
+  });
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_count_cl");
+  return XEQ_OK;
+}
+
+int xeq_radius_graph_fill_cl(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, double cutoff,
+                             const void* lo, const void* inv_w, const int32_t* nbins, const int32_t* bin_base,
+                             const int32_t* bin_start, const int32_t* bin_atom, const int32_t* rowptr, int64_t n_edges,
+                             int64_t* tmp_keys, int64_t* edge_index, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0 && n_edges >= 0, "xeq_radius_graph_fill_cl: bad sizes");
+  if (n_nodes == 0 || n_edges == 0) return XEQ_OK;
+  XEQ_DISPATCH_FLOAT(dtype, {
+    T rc = (T)cutoff;
+    hipLaunchKernelGGL((k_radius_graph_cl<T, true>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)pos, ptr, n_graphs, n_nodes, rc * rc, (const T*)lo, (const T*)inv_w, nbins, bin_base, bin_start,
+                       bin_atom, (int32_t*)nullptr, rowptr, tmp_keys);
+  });
+  hipLaunchKernelGGL(k_sort_segment_plain, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const int64_t*)tmp_keys, rowptr, n_nodes, n_edges, edge_index);
+  XEQ_CHECK_LAUNCH("xeq_radius_graph_fill_cl");
   return XEQ_OK;
 }
 

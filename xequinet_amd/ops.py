@@ -120,12 +120,59 @@ class EdgeGraph:
         return plan
 
 
+_CELL_LIST_MIN_ATOMS = 512   # average atoms per graph from which the bin grid replaces the O(n_g^2) sweep
+_CELL_LIST_MAX_BINS = 64     # per axis
+
+
+def _use_cell_list(n_atoms: int, n_graphs: int) -> bool:
+    import os
+
+    flag = os.environ.get("XEQ_CELL_LIST")
+    if flag is not None:
+        return flag not in ("0", "", "false")
+    return n_atoms >= _CELL_LIST_MIN_ATOMS * max(1, n_graphs)
+
+
+def _radius_graph_cell_list(pos, ptr_, cutoff):
+    """Open-boundary neighbour list through a per-graph bin grid (xeq_radius_graph_*_cl): O(N) instead of O(n_g^2)."""
+    N, G = pos.shape[0], ptr_.numel() - 1
+    dev, dt = pos.device, dtype_code(pos)
+    counts = ptr_[1:] - ptr_[:-1]
+    gidx = torch.repeat_interleave(torch.arange(G, device=dev), counts, output_size=N).unsqueeze(1).expand(N, 3)
+    lo = torch.full((G, 3), float("inf"), dtype=pos.dtype, device=dev).scatter_reduce_(0, gidx, pos, "amin", include_self=True)
+    hi = torch.full((G, 3), float("-inf"), dtype=pos.dtype, device=dev).scatter_reduce_(0, gidx, pos, "amax", include_self=True)
+    ext = (hi - lo).clamp_(min=0).nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)      # empty graphs: one bin
+    lo = lo.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
+    nb = torch.floor(ext / (cutoff * (1.0 + 1e-4))).clamp_(1, _CELL_LIST_MAX_BINS).to(torch.int32)   # bin width >= cutoff
+    inv_w = (nb.to(pos.dtype) / ext.clamp(min=1e-30)).contiguous()
+    bin_base = torch.zeros(G + 1, dtype=torch.int32, device=dev)
+    bin_base[1:] = torch.cumsum(nb.prod(dim=1), 0)
+    n_bins = int(bin_base[-1].item())
+    keys_ = torch.empty(N, dtype=torch.int64, device=dev)
+    lo, nb = lo.contiguous(), nb.contiguous()
+    call("xeq_radius_graph_bin_ids", dt, ptr(pos), ptr(ptr_), G, N, ptr(lo), ptr(inv_w), ptr(nb), ptr(bin_base), ptr(keys_), stream())
+    bin_start, bin_atom = csr_by_key(keys_, n_bins)
+    deg = torch.empty(N, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    call("xeq_radius_graph_count_cl", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(lo), ptr(inv_w), ptr(nb), ptr(bin_base),
+         ptr(bin_start), ptr(bin_atom), ptr(deg), stream())
+    call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+    E = int(rowptr[-1].item()) if N > 0 else 0
+    edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+    tmp_keys = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+    call("xeq_radius_graph_fill_cl", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(lo), ptr(inv_w), ptr(nb), ptr(bin_base),
+         ptr(bin_start), ptr(bin_atom), ptr(rowptr), E, ptr(tmp_keys), ptr(edge_index), stream())
+    return edge_index, rowptr
+
+
 def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """Non-PBC neighbour list; returns (edge_index[2,E] sorted by (center, neighbor), rowptr[N+1])."""
     require_hip(pos, ptr_)
     pos = pos.detach().contiguous()
     ptr_ = ptr_.to(torch.int64).contiguous()
     N, G = pos.shape[0], ptr_.numel() - 1
+    if N > 0 and G > 0 and _use_cell_list(N, G):
+        return _radius_graph_cell_list(pos, ptr_, cutoff)
     dev = pos.device
     deg = torch.empty(N, dtype=torch.int32, device=dev)
     rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
