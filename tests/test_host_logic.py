@@ -144,3 +144,72 @@ def test_batch_container():
     assert set(b.to_dict()) == {"pos", "atomic_numbers", "ptr", "batch"}
     with pytest.raises(ValueError):
         XequiBatch(torch.randn(2, 3), torch.tensor([1, 1]), pbc=torch.tensor([True, True, True]))
+
+
+# ------------------------------------------------------------------ units / MD front-end host logic
+def test_unit_conversion_matches_reference_table():
+    """utils/qc.py:13-114: every table entry and a set of compound conversions against factors produced by the
+    reference's own functions (tests/golden/make_golden_units.py); malformed unit strings are refused."""
+    import json
+
+    from xequinet_amd.utils import check_unit, eval_unit, unit_conversion
+    from xequinet_amd.utils.units import units
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "units.json")))
+    assert set(units) == set(g["table"])
+    for k, v in g["table"].items():
+        assert abs(units[k] / v - 1) < 1e-14, k
+    for a, b, v in g["pairs"]:
+        assert abs(unit_conversion(a, b) / v - 1) < 1e-14, (a, b)
+    assert unit_conversion(None, "eV") == 1.0 and unit_conversion("eV", None) == 1.0 and unit_conversion("eV", "eV") == 1.0
+    # published CODATA 2018 values, to the accuracy of the reference's constant set (mu0 = 4 pi 1e-7)
+    assert abs(unit_conversion("Hartree", "eV") - 27.211386245988) < 1e-7
+    assert abs(unit_conversion("Bohr", "Angstrom") - 0.529177210903) < 1e-9
+    for bad in g["invalid"] + ["", "eV/", "(eV", "eV eV", "1/0"]:
+        assert not check_unit(bad), bad
+    with pytest.raises(ValueError):
+        eval_unit("eV/parsec")
+    assert eval_unit("2^3^2") == 512.0 and eval_unit("-2^2") == -4.0 and eval_unit("8/2/2") == 2.0   # Python's ** rules
+
+
+def test_default_units_and_md_model_factors():
+    from xequinet_amd import keys
+    from xequinet_amd.utils import units as U
+
+    saved = dict(U.DEFAULT_UNITS_MAP)
+    try:
+        with pytest.raises(ValueError):
+            U.set_default_units({keys.FORCES: "eV/Angstrom"})
+        with pytest.raises(ValueError):
+            U.set_default_units({keys.TOTAL_ENERGY: "furlong"})
+        U.set_default_units({keys.TOTAL_ENERGY: "kcal/mol"})
+        d = U.get_default_units()
+        assert d[keys.FORCES] == "kcal/mol/Angstrom" and d[keys.VIRIAL] == "kcal/mol/Angstrom^3"
+        assert abs(U.unit_conversion(d[keys.FORCES], keys.LAMMPS_UNIT_STYLE["metal"][keys.FORCES]) - 0.0433641042) < 1e-9
+    finally:
+        U.DEFAULT_UNITS_MAP.clear()
+        U.DEFAULT_UNITS_MAP.update(saved)
+    assert set(keys.LAMMPS_UNIT_STYLE) == {"metal", "real", "electron"}
+
+
+def test_ase_helpers_without_ase():
+    from xequinet_amd.interface.ase_calculator import datapoint_from_ase, full_3x3_to_voigt_6_stress
+
+    s = np.arange(9.0).reshape(3, 3)
+    np.testing.assert_allclose(full_3x3_to_voigt_6_stress(s), [0, 4, 8, 6, 4, 2])
+
+    class A:
+        def get_pbc(self): return np.array([True, True, False])
+        def get_cell(self): return np.diag([4.0, 5.0, 6.0])
+        def get_atomic_numbers(self): return np.array([8, 1, 1])
+        def get_positions(self, wrap=False): return np.array([[0.5, 0.5, 0.5], [1.0, 1.0, 7.0], [3.9, 4.9, -1.0]])
+
+    d = datapoint_from_ase(A(), torch.float64)
+    assert d.pos.dtype == torch.float64 and d.atomic_numbers.dtype == torch.int32 and d.cell.shape == (1, 3, 3)
+    assert d.pbc.tolist() == [[True, True, False]] and d.ptr.tolist() == [0, 3] and d.num_graphs == 1
+
+    class M(A):
+        def get_pbc(self): return np.array([False, False, False])
+
+    d = datapoint_from_ase(M(), torch.float32)
+    assert not hasattr(d, "cell") and not hasattr(d, "pbc") and d.pos.dtype == torch.float32

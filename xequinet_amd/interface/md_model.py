@@ -1,0 +1,136 @@
+"""MD front ends of the energy+force path: the models LAMMPS and GROMACS drive (single graph, no batch).
+
+Mirror of ``xequinet/interface/jit_model.py``: ``XPaiNNLMP`` (:12-89, ``forward(data, compute_forces, compute_virial)``
+in LAMMPS units), ``XPaiNNGMX`` (:148-216, ``forward(positions, atomic_numbers, box, pbc) -> energy`` in GROMACS units
+with the neighbour search inside the model) and ``resolve_jit_model`` (:219-236).  Unit factors follow the same rules
+(``unit_conversion`` between the model's default units and the engine's).
+
+The reference exports these through ``torch.jit.script`` because its MD plug-ins are libtorch programs; here the
+evaluation is the HIP path of this package, called from Python or through ``include/xeq.h``, and MD-sized systems
+are latency-bound on kernel launches, so ``replay=True`` runs the evaluation as a captured HIP graph
+(``runtime.GraphedModel``): same kernels, same results, one graph launch per step.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import keys
+from ..data.radius_graph import single_radius_graph
+from ..nn.basic import compute_edge_data, compute_properties
+from ..nn.model import BaseModel, XPaiNN
+from ..utils import get_default_units, unit_conversion
+
+
+def _default_unit(prop: str) -> str:
+    units = get_default_units()
+    if prop not in units:
+        raise KeyError(f"default unit of '{prop}' is not set: call utils.set_default_units(ckpt['config']['default_units']) first")
+    return units[prop]
+
+
+class XPaiNNLMP(XPaiNN):
+    """XPaiNN for LAMMPS (jit_model.py:12-89).  ``data`` carries ``atomic_numbers``, ``pos`` and the neighbour list
+    LAMMPS built (``edge_index`` [+ ``cell_offsets``, ``cell``, ``pbc``]) in LAMMPS units; results come back in
+    LAMMPS units.  ``cutoff_radius`` is converted to LAMMPS units for the caller that builds the list."""
+
+    def __init__(self, unit_style: str = "metal", net_charge: Optional[int] = None, replay: bool = False, **kwargs) -> None:
+        super().__init__(**kwargs)
+        lammps_units = keys.LAMMPS_UNIT_STYLE[unit_style]
+        self.pos_unit_factor = unit_conversion(lammps_units[keys.POSITIONS], _default_unit(keys.POSITIONS))        # LAMMPS -> model
+        self.energy_unit_factor = unit_conversion(_default_unit(keys.TOTAL_ENERGY), lammps_units[keys.TOTAL_ENERGY])  # model -> LAMMPS
+        self.forces_unit_factor = unit_conversion(_default_unit(keys.FORCES), lammps_units[keys.FORCES])
+        self.net_charge = net_charge
+        self.cutoff_radius /= self.pos_unit_factor
+        self._replay = None
+        self._use_replay = replay
+
+    def _evaluate(self, data, compute_forces: bool, compute_virial: bool) -> Dict[str, torch.Tensor]:
+        if self._use_replay:
+            from ..runtime import GraphedModel
+            if (self._replay is None or self._replay.compute_forces != compute_forces
+                    or self._replay.compute_virial != compute_virial):
+                self._replay = GraphedModel(_Core(self), compute_forces=compute_forces, compute_virial=compute_virial)
+            if keys.BATCH_PTR not in data:
+                n = data[keys.POSITIONS].shape[0]
+                data[keys.BATCH_PTR] = torch.tensor([0, n], dtype=torch.long, device=data[keys.POSITIONS].device)
+            return {k: v.clone() for k, v in self._replay(data).items()}
+        return _Core(self)(data, compute_forces, compute_virial)
+
+    def forward(self, data: Dict[str, torch.Tensor], compute_forces: bool = True,
+                compute_virial: bool = False) -> Dict[str, torch.Tensor]:
+        data = dict(data)
+        data[keys.POSITIONS] = data[keys.POSITIONS] * self.pos_unit_factor
+        # like the reference (jit_model.py:62) only the positions are rescaled: a cell, when present, is taken as given
+        if self.net_charge is not None:
+            data[keys.TOTAL_CHARGE] = torch.tensor([self.net_charge], device=data[keys.POSITIONS].device)
+        result = self._evaluate(data, compute_forces, compute_virial)
+        result[keys.TOTAL_ENERGY] = result[keys.TOTAL_ENERGY] * self.energy_unit_factor
+        if compute_forces:
+            result[keys.FORCES] = result[keys.FORCES] * self.forces_unit_factor
+        if compute_virial:
+            result[keys.VIRIAL] = result[keys.VIRIAL] * self.energy_unit_factor
+        return result
+
+
+class _Core:
+    """``BaseModel.forward`` over an MD model's blocks without its unit handling (the callable GraphedModel captures)."""
+
+    def __init__(self, model: BaseModel) -> None:
+        self.model = model
+
+    def __call__(self, data, compute_forces: bool = True, compute_virial: bool = False):
+        m = self.model
+        data = compute_edge_data(data=data, compute_forces=compute_forces, compute_virial=compute_virial)
+        for mod in m.mods.values():
+            data = mod(data)
+        return compute_properties(data=data, compute_forces=compute_forces, compute_virial=compute_virial,
+                                  training=m.training, extra_properties=m.extra_properties)
+
+
+class XPaiNNGMX(XPaiNN):
+    """XPaiNN for GROMACS' NNPot interface (jit_model.py:148-216): positions / box in nm, energy in kJ/mol; the
+    caller differentiates the returned energy with respect to ``positions`` for the forces."""
+
+    def __init__(self, net_charge: Optional[int] = None, **kwargs) -> None:
+        kwargs.pop("unit_style", None)
+        super().__init__(**kwargs)
+        self.pos_unit_factor = unit_conversion("nm", _default_unit(keys.POSITIONS))
+        self.energy_unit_factor = unit_conversion(_default_unit(keys.TOTAL_ENERGY), "kJ/mol")
+        self.forces_unit_factor = unit_conversion(_default_unit(keys.FORCES), "kJ/(mol*nm)")
+        self.net_charge = net_charge
+
+    def forward(self, positions: torch.Tensor, atomic_numbers: torch.Tensor, box: Optional[torch.Tensor] = None,
+                pbc: Optional[torch.Tensor] = None) -> torch.Tensor:
+        positions = positions * self.pos_unit_factor
+        if box is None:
+            cell = torch.eye(3, dtype=positions.dtype, device=positions.device)
+        else:
+            cell = box * self.pos_unit_factor
+        if pbc is None:
+            pbc = torch.zeros(3, dtype=torch.bool, device=positions.device)
+        with torch.no_grad():
+            edge_index, cell_offsets = single_radius_graph(pos=positions, cell=cell, pbc=pbc, cutoff=self.cutoff_radius)
+        data = {
+            keys.POSITIONS: positions,
+            keys.ATOMIC_NUMBERS: atomic_numbers,
+            keys.CELL: cell.unsqueeze(0),
+            keys.PBC: pbc.unsqueeze(0),
+            keys.EDGE_INDEX: edge_index,
+            keys.CELL_OFFSETS: cell_offsets,
+        }
+        if self.net_charge is not None:
+            data[keys.TOTAL_CHARGE] = torch.tensor([self.net_charge], device=positions.device)
+        data = compute_edge_data(data=data, compute_forces=True, compute_virial=False)
+        for mod in self.mods.values():
+            data = mod(data)
+        return data[keys.TOTAL_ENERGY] * self.energy_unit_factor
+
+
+def resolve_jit_model(mode: str = "lmp", unit_style: str = "metal", net_charge: Optional[int] = None, **kwargs) -> BaseModel:
+    """jit_model.py:219-236; the dipole head is outside the energy+force path."""
+    factory = {"lmp": XPaiNNLMP, "gmx": XPaiNNGMX}
+    if mode not in factory:
+        raise NotImplementedError(f"Unsupported mode {mode}")
+    return factory[mode](unit_style=unit_style, net_charge=net_charge, **kwargs)

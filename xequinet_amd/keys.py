@@ -1,6 +1,6 @@
 """String / int keys of the data dictionary -- same names and values as the
 reference's ``xequinet/keys.py:4-50`` so that data dicts are interchangeable."""
-from typing import Final, Set
+from typing import Dict, Final, Set
 
 # basic keys in datapoints
 POSITIONS: Final[str] = "pos"
@@ -33,7 +33,19 @@ TOTAL_ENERGY: Final[str] = "energy"
 FORCES: Final[str] = "forces"
 VIRIAL: Final[str] = "virial"
 
+TOTAL_CHARGE: Final[str] = "charge"
+
 GRAD_PROPERTIES: Final[Set[str]] = {FORCES, VIRIAL}
+
+# MD front ends (keys.py:96-120 of the reference): metadata names and the LAMMPS unit styles
+CUTOFF_RADIUS: Final[str] = "cutoff_radius"
+N_SPECIES: Final[str] = "n_species"
+PERIODIC_TABLE: Final[str] = "periodic_table"
+LAMMPS_UNIT_STYLE: Final[Dict[str, Dict[str, str]]] = {
+    "metal": {TOTAL_ENERGY: "eV", POSITIONS: "Angstrom", FORCES: "eV/Angstrom", TOTAL_CHARGE: "e"},
+    "real": {TOTAL_ENERGY: "kcal/mol", POSITIONS: "Angstrom", FORCES: "kcal/mol/Angstrom", TOTAL_CHARGE: "e"},
+    "electron": {TOTAL_ENERGY: "Hartree", POSITIONS: "Bohr", FORCES: "Hartree/Bohr", TOTAL_CHARGE: "e"},
+}
 
 # private: destination-sorted CSR views of edge_index built once per batch by
 # xequinet_amd.ops.EdgeGraph and shared by all message blocks
