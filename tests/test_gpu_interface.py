@@ -55,7 +55,7 @@ def test_lammps_model_units_and_values(style, e_pair, f_pair, len_pair, replay):
     from xequinet_amd.interface import XPaiNNLMP, resolve_jit_model
 
     dtype = torch.float64
-    model, oracle = _twin(XPaiNNLMP, dtype, unit_style=style, replay=replay)
+    model, oracle = _twin(XPaiNNLMP, dtype, unit_style=style, replay=replay, tune_gemms=False)
     assert type(resolve_jit_model("lmp", unit_style=style)) is XPaiNNLMP
     pos, z, ptr = orc.synth_aspirin()
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
@@ -84,7 +84,7 @@ def test_lammps_model_periodic_virial_and_replay_is_bitwise():
     f = P._load("radius_graph_pbc_water192.npz")
     _, z, ptr, _ = orc.synth_water_box(4, seed=5)
     eager, oracle = _twin(XPaiNNLMP, dtype, unit_style="real")
-    fast, _ = _twin(XPaiNNLMP, dtype, unit_style="real", replay=True)
+    fast, _ = _twin(XPaiNNLMP, dtype, unit_style="real", replay=True, tune_gemms=False)
     extra = {"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)}
     want = oracle(_oracle_in(f["pos"].astype(np.float64), z, ptr, f["edge_index"], extra), compute_forces=True, compute_virial=True)
     mk = lambda: {"pos": P._t(f["pos"], dtype), "atomic_numbers": P._t(z.astype(np.int32)), "edge_index": P._t(f["edge_index"]),
@@ -177,7 +177,7 @@ def test_ase_calculator_molecule_and_periodic_box(replay):
         pytest.skip("duck-typed Atoms stand-in is for images without ASE")
     dtype = torch.float64
     model, oracle = P._build(dtype)
-    calc = XequiCalculator(model=model, dtype="float64", replay=replay)
+    calc = XequiCalculator(model=model, dtype="float64", replay=replay, tune_gemms=False)
     # molecule: energy / energies / forces
     pos, z, ptr = orc.synth_aspirin()
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
@@ -201,3 +201,24 @@ def test_ase_calculator_molecule_and_periodic_box(replay):
     v = wantw["virial"].numpy()[0]
     voigt = np.array([v[0, 0], v[1, 1], v[2, 2], v[1, 2], v[0, 2], v[0, 1]]) / abs(np.linalg.det(cell))
     np.testing.assert_allclose(calc.results["stress"], voigt, rtol=0, atol=1e-9 * max(1.0, np.abs(voigt).max()))
+
+
+def test_replay_with_timed_gemm_selection_meets_the_fp32_parity_bar():
+    """GraphedModel(tune_gemms=True), the MD default: library GEMM kernels are timed per shape in the warm-up runs and
+    the captured graph uses the picks.  Which fp32 kernel wins varies from run to run, so the check is the parity bar
+    of the eager path itself (test_gpu_parity._check_model: fp64 oracle, fp32 tolerance) for the capture and the
+    replay.  The switch (PyTorch TunableOp) is process-wide and is turned off again afterwards."""
+    from xequinet_amd.interface import XPaiNNLMP
+
+    dtype = torch.float32
+    f = P._load("radius_graph_pbc_water192.npz")
+    _, z, ptr, _ = orc.synth_water_box(4, seed=5)
+    fast, oracle = _twin(XPaiNNLMP, dtype, unit_style="metal", replay=True, tune_gemms=True)
+    extra = {"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)}
+    try:
+        b, _ = P._check_model(fast, oracle, f["pos"].astype(np.float64), z, ptr, f["edge_index"], dtype, extra=extra)
+        c, _ = P._check_model(fast, oracle, f["pos"].astype(np.float64), z, ptr, f["edge_index"], dtype, extra=extra)
+    finally:
+        torch.cuda.tunable.enable(False)
+    assert fast._replay.captures == 1
+    assert torch.equal(b["forces"], c["forces"]) and torch.equal(b["energy"], c["energy"])

@@ -36,14 +36,31 @@ __global__ void k_edge_vectors_bwd(const T* __restrict__ g, int64_t N, const int
   if (t >= 3 * N) return;
   int64_t i = t / 3;
   int a = (int)(t - 3 * i);
+  // the sums run in CSR order (deterministic); loads of 8 entries are issued together, the adds stay sequential
   T acc = T(0);
-  for (int32_t p = c_rowptr[i]; p < c_rowptr[i + 1]; ++p) {
-    int64_t e = c_perm ? c_perm[p] : p;
-    acc += g[3 * e + a];
+  {
+    int32_t p = c_rowptr[i];
+    const int32_t p1 = c_rowptr[i + 1];
+    for (; p + 8 <= p1; p += 8) {
+      T v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = g[3 * (int64_t)(c_perm ? c_perm[p + k] : p + k) + a];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; p < p1; ++p) acc += g[3 * (int64_t)(c_perm ? c_perm[p] : p) + a];
   }
-  for (int32_t p = n_rowptr[i]; p < n_rowptr[i + 1]; ++p) {
-    int64_t e = n_perm ? n_perm[p] : p;
-    acc -= g[3 * e + a];
+  {
+    int32_t p = n_rowptr[i];
+    const int32_t p1 = n_rowptr[i + 1];
+    for (; p + 8 <= p1; p += 8) {
+      T v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = g[3 * (int64_t)(n_perm ? n_perm[p + k] : p + k) + a];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc -= v[k];
+    }
+    for (; p < p1; ++p) acc -= g[3 * (int64_t)(n_perm ? n_perm[p] : p) + a];
   }
   grad_pos[t] = acc;
 }

@@ -74,12 +74,13 @@ class XequiCalculator(_AseCalculator):
     implemented_properties = ["energy", "energies", "forces", "stress"]
     default_parameters = {"ckpt_file": "model.pt", "dtype": "float32", "device": None}
 
-    def __init__(self, model: Optional[torch.nn.Module] = None, replay: bool = False, **kwargs) -> None:
+    def __init__(self, model: Optional[torch.nn.Module] = None, replay: bool = False, tune_gemms: bool = True, **kwargs) -> None:
         self.dtype = torch.float32
         self.device = torch.device("cuda")
         self.model = model
         self.transform = None
         self._replay_on = replay
+        self._tune_gemms = tune_gemms
         self._replay = {}
         if model is not None:
             self.device = next(model.parameters()).device
@@ -113,7 +114,8 @@ class XequiCalculator(_AseCalculator):
         from ..runtime import GraphedModel
         key = (compute_forces, compute_virial)
         if key not in self._replay:
-            self._replay[key] = GraphedModel(self.model, compute_forces=compute_forces, compute_virial=compute_virial)
+            self._replay[key] = GraphedModel(self.model, compute_forces=compute_forces, compute_virial=compute_virial,
+                                             tune_gemms=self._tune_gemms)
         return self._replay[key](data)
 
     def calculate(self, atoms=None, properties: Optional[List[str]] = None, system_changes: List[str] = all_changes) -> None:

@@ -35,7 +35,8 @@ class XPaiNNLMP(XPaiNN):
     LAMMPS built (``edge_index`` [+ ``cell_offsets``, ``cell``, ``pbc``]) in LAMMPS units; results come back in
     LAMMPS units.  ``cutoff_radius`` is converted to LAMMPS units for the caller that builds the list."""
 
-    def __init__(self, unit_style: str = "metal", net_charge: Optional[int] = None, replay: bool = False, **kwargs) -> None:
+    def __init__(self, unit_style: str = "metal", net_charge: Optional[int] = None, replay: bool = False,
+                 tune_gemms: bool = True, **kwargs) -> None:
         super().__init__(**kwargs)
         lammps_units = keys.LAMMPS_UNIT_STYLE[unit_style]
         self.pos_unit_factor = unit_conversion(lammps_units[keys.POSITIONS], _default_unit(keys.POSITIONS))        # LAMMPS -> model
@@ -45,13 +46,15 @@ class XPaiNNLMP(XPaiNN):
         self.cutoff_radius /= self.pos_unit_factor
         self._replay = None
         self._use_replay = replay
+        self._tune_gemms = tune_gemms
 
     def _evaluate(self, data, compute_forces: bool, compute_virial: bool) -> Dict[str, torch.Tensor]:
         if self._use_replay:
             from ..runtime import GraphedModel
             if (self._replay is None or self._replay.compute_forces != compute_forces
                     or self._replay.compute_virial != compute_virial):
-                self._replay = GraphedModel(_Core(self), compute_forces=compute_forces, compute_virial=compute_virial)
+                self._replay = GraphedModel(_Core(self), compute_forces=compute_forces, compute_virial=compute_virial,
+                                            tune_gemms=self._tune_gemms)
             if keys.BATCH_PTR not in data:
                 n = data[keys.POSITIONS].shape[0]
                 data[keys.BATCH_PTR] = torch.tensor([0, n], dtype=torch.long, device=data[keys.POSITIONS].device)

@@ -119,6 +119,12 @@ class EdgeGraph:
             plan = self._wm[key] = {"n_ranges": n_ranges, "stream_ptr": sp, "rowptr": rowptr, "perm": perm}
         return plan
 
+    def refresh_wm_plans(self) -> None:
+        """Recompute the cached stream tables in place after the CSR arrays were overwritten (HIP-graph replay)."""
+        for plan in (self._wm or {}).values():
+            call("xeq_message_wm_streams", ptr(plan["rowptr"]), self.n_nodes, self.n_edges, plan["n_ranges"],
+                 ptr(plan["stream_ptr"]), stream())
+
 
 _CELL_LIST_MIN_ATOMS = 512   # average atoms per graph from which the bin grid replaces the O(n_g^2) sweep
 _CELL_LIST_MAX_BINS = 64     # per axis
@@ -478,11 +484,19 @@ def _message_impl() -> str:
     return impl
 
 
-def _wm_edges_per_stream() -> int:
-    """Edges per half-wave stream of the wm kernels (XEQ_WM_EDGES_PER_STREAM, default 128 = 8 tiles)."""
+def _wm_edges_per_stream(n_edges: int, n_nodes: int) -> int:
+    """Edges per half-wave stream of the wm kernels.  XEQ_WM_EDGES_PER_STREAM fixes it; otherwise 128 (8 tiles) for
+    large batches, shorter streams for small systems so that the launch still spreads over the chip (a stream is a
+    serial walk: ~1 us per edge tile), but never below the mean segment length (streams hold whole segments; more
+    streams than nodes would be empty waves).  Measured (scratch/eps_sweep.py): water-64 137 -> 62 us per reverse
+    launch, 76 k edges 219 -> 176 us, 312 k edges unchanged."""
     import os
 
-    return max(16, int(os.environ.get("XEQ_WM_EDGES_PER_STREAM", "128")))
+    env = os.environ.get("XEQ_WM_EDGES_PER_STREAM")
+    if env:
+        return max(16, int(env))
+    per_node = n_edges / max(1, n_nodes)
+    return int(min(128, max(16, per_node, n_edges / 1500)))
 
 
 def wm_supported(dtype, num_basis, node_dim, mul) -> bool:
@@ -545,7 +559,7 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
         impl = "wm" if ok else "sb"
     if impl == "wm":
         basis, dbasis = edge_basis_wm(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
-        plan = graph.wm_plan(False, _wm_edges_per_stream())
+        plan = graph.wm_plan(False, _wm_edges_per_stream(E, N))
         KERNEL_TIMER.launch("xeq_message_fwd_wm", N, E, plan["n_ranges"], ptr(plan["stream_ptr"]), ptr(plan["rowptr"]),
                             ptr(plan["perm"]), ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x),
                             ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
@@ -575,7 +589,7 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x):
     g_h, g_xhat = torch.empty_like(h), torch.empty_like(xhat)
     g_vec = torch.empty_like(vec)  # written at the edge's own position by every kernel family
     if impl == "wm":
-        plan = graph.wm_plan(True, _wm_edges_per_stream())
+        plan = graph.wm_plan(True, _wm_edges_per_stream(graph.n_edges, graph.n_nodes))
         parts = torch.empty(lib.load().xeq_message_wm_parts_floats(graph.n_edges, mul3(mul)), dtype=h.dtype, device=h.device)
         KERNEL_TIMER.launch("xeq_message_bwd_wm", graph.n_nodes, graph.n_edges, plan["n_ranges"], ptr(plan["stream_ptr"]),
                             ptr(plan["rowptr"]), ptr(plan["perm"]), ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(basis), ptr(dbasis),

@@ -40,8 +40,13 @@ class GraphedModel:
     _TENSOR_KEYS = (keys.POSITIONS, keys.ATOMIC_NUMBERS, keys.EDGE_INDEX, keys.BATCH, keys.BATCH_PTR, keys.CELL, keys.CELL_OFFSETS)
 
     def __init__(self, model: torch.nn.Module, compute_forces: bool = True, compute_virial: bool = False,
-                 max_graphs: int = 8, warmup: int = 2) -> None:
+                 max_graphs: int = 8, warmup: int = 2, tune_gemms: bool = True) -> None:
+        """``tune_gemms``: time the library GEMM candidates of every new shape once during the warm-up runs
+        (``tuning.enable_gemm_autotune``; PyTorch TunableOp, a process-wide switch).  The libraries' default picks
+        for few-hundred-row operands are tiles of 128-256 rows on one or two workgroups (35 us per GEMM at 192
+        atoms); the timed picks take ~5 us, which halves the replay time of MD-sized systems."""
         self.model = model
+        self.tune_gemms = tune_gemms
         self.compute_forces = compute_forces
         self.compute_virial = compute_virial
         self.max_graphs = max_graphs
@@ -83,6 +88,10 @@ class GraphedModel:
                                      ptr=c.inputs[keys.BATCH_PTR])
         static = dict(c.inputs)
         static[keys.EDGE_GRAPH] = c.edge_graph
+        if self.tune_gemms:
+            from .tuning import enable_gemm_autotune, gemm_autotune_enabled
+            if not gemm_autotune_enabled():
+                enable_gemm_autotune()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):   # warm-up off the capture: library GEMM selection, lazy initialisation
@@ -106,6 +115,7 @@ class GraphedModel:
         s.n_perm.copy_(eg.n_perm, non_blocking=True)
         if s.c_perm is not None:
             s.c_perm.copy_(eg.c_perm, non_blocking=True)
+        s.refresh_wm_plans()
 
     # --------------------------------------------------------------------- call
     def __call__(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
