@@ -8,6 +8,9 @@ from xequinet_amd.utils import set_default_units
 dev = torch.device("cuda", 0)
 set_default_units({"energy": "eV"})
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+if len(sys.argv) > 2:   # file of library-GEMM picks: written by a first (un-profiled) run, replayed under the profiler
+    from xequinet_amd.tuning import enable_gemm_autotune
+    enable_gemm_autotune(results_file=sys.argv[2])
 torch.manual_seed(0)
 m = XPaiNNLMP(unit_style="metal", replay=True).eval().requires_grad_(False).to(dev)
 pos, z, ptr, cell = orc.synth_water_box(n, seed=5)

@@ -256,7 +256,9 @@ __global__ void k_update_out_bwd(const T* __restrict__ g_s_out, const T* __restr
 // and weights are computed once) and walk NPB consecutive nodes with all loads of a node issued
 // together, and the norms keep a node's row in registers (one wave per node, DPP reductions).
 // =================================================================================================
-constexpr int NODE_NPB = 8;  // nodes per workgroup of the column kernels
+constexpr int NODE_NPB = 8;  // nodes per workgroup of the column kernels ...
+// ... and 1 when that would leave most of the chip idle (MD-sized systems: a 192-atom box is 24 workgroups at 8)
+static inline int node_npb(int64_t n) { return n >= 8 * 1024 ? NODE_NPB : 1; }
 
 __device__ __forceinline__ float wave_total_n(float v) {
 #define XEQ_N_DPP(v, ctrl, rmask) \
@@ -292,16 +294,16 @@ __device__ __forceinline__ ChanBT chan_bt(const Irreps& ir, int64_t N, int u) {
 }
 
 // v = |V|, p = <U,V>: thread = channel, NPB nodes per workgroup
-template <typename T>
+template <typename T, int NPB>
 __global__ void __launch_bounds__(256) k_uv_reduce_fwd_c(const T* __restrict__ uv_bt, int64_t N, Irreps ir, T eps,
                                                           T* __restrict__ cat, int64_t ld_cat, int F, T* __restrict__ p) {
   const int C = ir.C(), u = threadIdx.x;
   if (u >= C) return;
   const ChanBT c = chan_bt(ir, N, u);
-  const int64_t n0 = (int64_t)blockIdx.x * NODE_NPB;
+  const int64_t n0 = (int64_t)blockIdx.x * NPB;
   const int w2 = 2 * c.w;
 #pragma unroll 4
-  for (int j = 0; j < NODE_NPB; ++j) {
+  for (int j = 0; j < NPB; ++j) {
     const int64_t n = n0 + j;
     if (n >= N) break;
     const T* row = uv_bt + c.base_uv + n * c.d * w2;
@@ -316,17 +318,17 @@ __global__ void __launch_bounds__(256) k_uv_reduce_fwd_c(const T* __restrict__ u
   }
 }
 
-template <typename T>
+template <typename T, int NPB>
 __global__ void __launch_bounds__(256) k_uv_reduce_bwd_c(const T* __restrict__ uv_bt, const T* __restrict__ g_p,
                                                           const T* __restrict__ g_cat, int64_t ld_cat, int F, int64_t N,
                                                           Irreps ir, T eps, T* __restrict__ g_uv_bt) {
   const int C = ir.C(), u = threadIdx.x;
   if (u >= C) return;
   const ChanBT c = chan_bt(ir, N, u);
-  const int64_t n0 = (int64_t)blockIdx.x * NODE_NPB;
+  const int64_t n0 = (int64_t)blockIdx.x * NPB;
   const int w2 = 2 * c.w;
 #pragma unroll 2
-  for (int j = 0; j < NODE_NPB; ++j) {
+  for (int j = 0; j < NPB; ++j) {
     const int64_t n = n0 + j;
     if (n >= N) break;
     const int64_t r0 = c.base_uv + n * c.d * w2;
@@ -354,19 +356,19 @@ __global__ void __launch_bounds__(256) k_uv_reduce_bwd_c(const T* __restrict__ u
 }
 
 // update output stage: thread = flat column of [s (F) | x (D)], column blocks of 256
-template <typename T>
+template <typename T, int NPB>
 __global__ void __launch_bounds__(256) k_update_out_fwd_c(const T* __restrict__ s, const T* __restrict__ x,
                                                            const T* __restrict__ uv_bt, const T* __restrict__ a,
                                                            const T* __restrict__ ip, int64_t N, int F, Irreps ir,
                                                            int ncb, T* __restrict__ s_out, T* __restrict__ x_out) {
   const int D = ir.D(), C = ir.C(), A = C + 2 * F;
   const int cb = blockIdx.x % ncb;
-  const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NODE_NPB;
+  const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NPB;
   const int f = cb * 256 + threadIdx.x;
   if (f >= F + D) return;
   if (f < F) {
 #pragma unroll 4
-    for (int j = 0; j < NODE_NPB; ++j) {
+    for (int j = 0; j < NPB; ++j) {
       const int64_t n = n0 + j;
       if (n >= N) break;
       s_out[n * F + f] = s[n * F + f] + a[n * A + C + f] * ip[n * F + f] + a[n * A + C + F + f];
@@ -379,7 +381,7 @@ __global__ void __launch_bounds__(256) k_update_out_fwd_c(const T* __restrict__ 
     const int w2 = 2 * c.w;
     const int64_t ub = c.base_uv + (int64_t)m * w2;
 #pragma unroll 4
-    for (int j = 0; j < NODE_NPB; ++j) {
+    for (int j = 0; j < NPB; ++j) {
       const int64_t n = n0 + j;
       if (n >= N) break;
       x_out[n * D + fx] = x[n * D + fx] + uv_bt[ub + n * c.d * w2] * a[n * A + u];
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(256) k_update_out_fwd_c(const T* __restrict__ 
 }
 
 // thread = column of [gate channels (C) | scalar channels (F)]
-template <typename T>
+template <typename T, int NPB>
 __global__ void __launch_bounds__(256) k_update_out_bwd_c(const T* __restrict__ g_s_out, const T* __restrict__ g_x_out,
                                                            const T* __restrict__ uv_bt, const T* __restrict__ a,
                                                            const T* __restrict__ ip, int64_t N, int F, Irreps ir, int ncb,
@@ -396,14 +398,14 @@ __global__ void __launch_bounds__(256) k_update_out_bwd_c(const T* __restrict__ 
                                                            T* __restrict__ g_uv_bt) {
   const int D = ir.D(), C = ir.C(), A = C + 2 * F;
   const int cb = blockIdx.x % ncb;
-  const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NODE_NPB;
+  const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NPB;
   const int f = cb * 256 + threadIdx.x;
   if (f >= C + F) return;
   if (f < C) {
     const ChanBT c = chan_bt(ir, N, f);
     const int w2 = 2 * c.w;
 #pragma unroll 2
-    for (int j = 0; j < NODE_NPB; ++j) {
+    for (int j = 0; j < NPB; ++j) {
       const int64_t n = n0 + j;
       if (n >= N) break;
       const int64_t r0 = c.base_uv + n * c.d * w2;
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(256) k_update_out_bwd_c(const T* __restrict__ 
   } else {
     const int cc = f - C;
 #pragma unroll 4
-    for (int j = 0; j < NODE_NPB; ++j) {
+    for (int j = 0; j < NPB; ++j) {
       const int64_t n = n0 + j;
       if (n >= N) break;
       const T gs = g_s_out[n * F + cc];
@@ -621,7 +623,9 @@ int xeq_norm_fwd(int dtype, const void* s, const void* x, const void* ln_w, cons
   if (n <= 0) return XEQ_OK;
   const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512;  // row in registers: 2 + 8 slots per lane
   // ~4 nodes per wave: the slot decoding of a wave is amortised, every CU still gets >= 16 waves at 18k nodes
-  const unsigned wgrid = (unsigned)((n + 15) / 16 < 65536 ? (n + 15) / 16 : 65536);
+  // (small systems: one node per wave, so that a 192-atom box still spreads over 48 workgroups)
+  const int64_t per_wg = n >= 8 * 1024 ? 16 : 4;
+  const unsigned wgrid = (unsigned)((n + per_wg - 1) / per_wg < 65536 ? (n + per_wg - 1) / per_wg : 65536);
   XEQ_DISPATCH_FLOAT(dtype, {
     if (fast)
       hipLaunchKernelGGL((k_norm_fwd_r<T, 2, 8>), dim3(wgrid), dim3(256), 0, (hipStream_t)stream, (const T*)s, (const T*)x,
@@ -644,7 +648,8 @@ int xeq_norm_bwd(int dtype, const void* s, const void* x, const void* ln_w, cons
   if (n <= 0) return XEQ_OK;
   // measured (QM9-1024): the element-per-lane kernel already moves its 230 MB at 4.1 TB/s (56 us); the
   // row-in-register form is latency-bound here (71-91 us) and stays opt-in for experiments
-  const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512 && getenv("XEQ_NORM_BWD_ROWREG") != nullptr;
+  // (MD-sized systems are latency-bound either way; there the row-in-register form has the shorter dependent chain)
+  const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512 && (n < 8 * 1024 || getenv("XEQ_NORM_BWD_ROWREG") != nullptr);
   const unsigned wgrid = (unsigned)((n + 3) / 4);
   XEQ_DISPATCH_FLOAT(dtype, {
     if (fast)
@@ -668,8 +673,14 @@ int xeq_uv_reduce_fwd(int dtype, const void* uv_bt, int64_t n, const int32_t mul
   const int64_t total = n * ir.C();
   XEQ_DISPATCH_FLOAT(dtype, {
     if (ir.C() <= 256)
-      hipLaunchKernelGGL((k_uv_reduce_fwd_c<T>), dim3((unsigned)((n + NODE_NPB - 1) / NODE_NPB)), dim3(256), 0,
-                         (hipStream_t)stream, (const T*)uv_bt, n, ir, (T)eps, (T*)cat, ld_cat, node_dim, (T*)p);
+    {
+      if (node_npb(n) == 1)
+        hipLaunchKernelGGL((k_uv_reduce_fwd_c<T, 1>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const T*)uv_bt, n,
+                           ir, (T)eps, (T*)cat, ld_cat, node_dim, (T*)p);
+      else
+        hipLaunchKernelGGL((k_uv_reduce_fwd_c<T, NODE_NPB>), dim3((unsigned)((n + NODE_NPB - 1) / NODE_NPB)), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)uv_bt, n, ir, (T)eps, (T*)cat, ld_cat, node_dim, (T*)p);
+    }
     else
       hipLaunchKernelGGL((k_uv_reduce_fwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                          (const T*)uv_bt, n, ir, (T)eps, (T*)cat, ld_cat, node_dim, (T*)p);
@@ -685,9 +696,15 @@ int xeq_uv_reduce_bwd(int dtype, const void* uv_bt, const void* g_p, const void*
   const int64_t total = n * ir.C();
   XEQ_DISPATCH_FLOAT(dtype, {
     if (ir.C() <= 256)
-      hipLaunchKernelGGL((k_uv_reduce_bwd_c<T>), dim3((unsigned)((n + NODE_NPB - 1) / NODE_NPB)), dim3(256), 0,
-                         (hipStream_t)stream, (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir,
-                         (T)eps, (T*)g_uv_bt);
+    {
+      if (node_npb(n) == 1)
+        hipLaunchKernelGGL((k_uv_reduce_bwd_c<T, 1>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const T*)uv_bt,
+                           (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps, (T*)g_uv_bt);
+      else
+        hipLaunchKernelGGL((k_uv_reduce_bwd_c<T, NODE_NPB>), dim3((unsigned)((n + NODE_NPB - 1) / NODE_NPB)), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir,
+                           (T)eps, (T*)g_uv_bt);
+    }
     else
       hipLaunchKernelGGL((k_uv_reduce_bwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                          (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps, (T*)g_uv_bt);
@@ -701,11 +718,16 @@ int xeq_update_out_fwd(int dtype, const void* s, const void* x, const void* uv_b
   XEQ_IR("xeq_update_out_fwd");
   if (n <= 0) return XEQ_OK;
   const int ncb = (node_dim + ir.D() + 255) / 256;
-  const int64_t nblk = (n + NODE_NPB - 1) / NODE_NPB * ncb;
+  const int npb = node_npb(n);
+  const int64_t nblk = (n + npb - 1) / npb * ncb;
   XEQ_CHECK_ARG(nblk < (1ll << 31), "xeq_update_out_fwd: too many nodes for one launch");
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_update_out_fwd_c<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)s,
-                       (const T*)x, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir, ncb, (T*)s_out, (T*)x_out);
+    if (npb == 1)
+      hipLaunchKernelGGL((k_update_out_fwd_c<T, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+                         (const T*)x, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir, ncb, (T*)s_out, (T*)x_out);
+    else
+      hipLaunchKernelGGL((k_update_out_fwd_c<T, NODE_NPB>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+                         (const T*)x, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir, ncb, (T*)s_out, (T*)x_out);
   });
   XEQ_CHECK_LAUNCH("xeq_update_out_fwd");
   return XEQ_OK;
@@ -717,12 +739,18 @@ int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, cons
   XEQ_IR("xeq_update_out_bwd");
   if (n <= 0) return XEQ_OK;
   const int ncb = (node_dim + ir.C() + 255) / 256;
-  const int64_t nblk = (n + NODE_NPB - 1) / NODE_NPB * ncb;
+  const int npb = node_npb(n);
+  const int64_t nblk = (n + npb - 1) / npb * ncb;
   XEQ_CHECK_ARG(nblk < (1ll << 31), "xeq_update_out_bwd: too many nodes for one launch");
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_update_out_bwd_c<T>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       (const T*)g_s_out, (const T*)g_x_out, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir,
-                       ncb, (T*)g_a, (T*)g_ip, (T*)g_uv_bt);
+    if (npb == 1)
+      hipLaunchKernelGGL((k_update_out_bwd_c<T, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)g_s_out, (const T*)g_x_out, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir,
+                         ncb, (T*)g_a, (T*)g_ip, (T*)g_uv_bt);
+    else
+      hipLaunchKernelGGL((k_update_out_bwd_c<T, NODE_NPB>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)g_s_out, (const T*)g_x_out, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir,
+                         ncb, (T*)g_a, (T*)g_ip, (T*)g_uv_bt);
   });
   XEQ_CHECK_LAUNCH("xeq_update_out_bwd");
   return XEQ_OK;

@@ -27,42 +27,42 @@ __global__ void k_edge_vectors_fwd(const T* __restrict__ pos, const int64_t* __r
   if (dist) dist[e] = sqrt_<T>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
 }
 
-// grad_pos[i] = sum_{center=i} g[e] - sum_{neighbor=i} g[e]; one thread per (node, axis)
+// grad_pos[i] = sum_{center=i} g[e] - sum_{neighbor=i} g[e].  16 lanes per node: lane l takes entries l, l+16, ... of the
+// node's two CSR segments (all three axes), then a fixed xor-butterfly over the 16 lanes: deterministic, and a node
+// with 50-100 edges (periodic boxes) costs 4-7 rounds of independent loads instead of a serial walk
 template <typename T>
-__global__ void k_edge_vectors_bwd(const T* __restrict__ g, int64_t N, const int32_t* __restrict__ c_rowptr,
+__global__ void __launch_bounds__(256) k_edge_vectors_bwd(const T* __restrict__ g, int64_t N, const int32_t* __restrict__ c_rowptr,
                                    const int32_t* __restrict__ c_perm, const int32_t* __restrict__ n_rowptr,
                                    const int32_t* __restrict__ n_perm, T* __restrict__ grad_pos) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 3 * N) return;
-  int64_t i = t / 3;
-  int a = (int)(t - 3 * i);
-  // the sums run in CSR order (deterministic); loads of 8 entries are issued together, the adds stay sequential
-  T acc = T(0);
-  {
-    int32_t p = c_rowptr[i];
-    const int32_t p1 = c_rowptr[i + 1];
-    for (; p + 8 <= p1; p += 8) {
-      T v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = g[3 * (int64_t)(c_perm ? c_perm[p + k] : p + k) + a];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc += v[k];
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t >> 4;
+  const int l = (int)(t & 15);
+  T a0 = T(0), a1 = T(0), a2 = T(0);
+  if (i < N) {
+    for (int32_t p = c_rowptr[i] + l, p1 = c_rowptr[i + 1]; p < p1; p += 16) {
+      const int64_t e = c_perm ? c_perm[p] : p;
+      a0 += g[3 * e];
+      a1 += g[3 * e + 1];
+      a2 += g[3 * e + 2];
     }
-    for (; p < p1; ++p) acc += g[3 * (int64_t)(c_perm ? c_perm[p] : p) + a];
-  }
-  {
-    int32_t p = n_rowptr[i];
-    const int32_t p1 = n_rowptr[i + 1];
-    for (; p + 8 <= p1; p += 8) {
-      T v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = g[3 * (int64_t)(n_perm ? n_perm[p + k] : p + k) + a];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc -= v[k];
+    for (int32_t p = n_rowptr[i] + l, p1 = n_rowptr[i + 1]; p < p1; p += 16) {
+      const int64_t e = n_perm ? n_perm[p] : p;
+      a0 -= g[3 * e];
+      a1 -= g[3 * e + 1];
+      a2 -= g[3 * e + 2];
     }
-    for (; p < p1; ++p) acc -= g[3 * (int64_t)(n_perm ? n_perm[p] : p) + a];
   }
-  grad_pos[t] = acc;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    a0 += __shfl_xor(a0, m, 16);
+    a1 += __shfl_xor(a1, m, 16);
+    a2 += __shfl_xor(a2, m, 16);
+  }
+  if (i < N && l == 0) {
+    grad_pos[3 * i] = a0;
+    grad_pos[3 * i + 1] = a1;
+    grad_pos[3 * i + 2] = a2;
+  }
 }
 
 // ------------------------------------------------------- spherical harmonics
@@ -358,7 +358,7 @@ int xeq_edge_vectors_bwd(int dtype, const void* grad_vec, int64_t n_nodes, const
   XEQ_CHECK_ARG(n_nodes >= 0, "xeq_edge_vectors_bwd: n_nodes < 0");
   if (n_nodes == 0) return XEQ_OK;
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((k_edge_vectors_bwd<T>), dim3((unsigned)((3 * n_nodes + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL((k_edge_vectors_bwd<T>), dim3((unsigned)((16 * n_nodes + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const T*)grad_vec, n_nodes, c_rowptr, c_perm, n_rowptr, n_perm,
                        (T*)grad_pos);
   });
