@@ -26,6 +26,7 @@ import torch
 
 METRIC = "edges/sec + achieved HBM GB/s, energy+force inference, QM9-shape batch"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32 (= the f32 vector rate)
 
 
 def make_workload(name: str, seed: int):
@@ -173,9 +174,15 @@ def main():
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tfile):
                 traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
+            # the same launch against the f32 matrix pipe (~26 kFLOP per edge-layer forward, filter
+            # [576 x 21] + gating; the reverse pass evaluates the filter and its d/dd): what the kernel is nearer to
+            flops = (52.0e3 if "bwd" in dom else 26.0e3) * n_edges
+            tfl = flops / (avg_ms * 1e-3) / 1e12
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
                         "algorithmic_bytes_per_launch": alg[dom],
+                        "matrix_pipe": {"algorithmic_flops_per_launch": flops, "achieved": tfl, "peak": F32_MATRIX_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": tfl / F32_MATRIX_PEAK_TFLOPS, "dtype": "f32 (exact, v_mfma_f32_32x32x2_f32)"},
                         "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernel_ms.items()}}
         line = {
             "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
