@@ -33,12 +33,13 @@ def run(name, pos, z, cell=None):
             with torch.enable_grad():
                 return m({"pos": p, "atomic_numbers": zz, "edge_index": ei, **extra}, True, False)["forces"]
         out[tag] = timeit(step)
-    g = mk(XPaiNNGMX)
-    def gstep():
-        x = (p / 10).requires_grad_(True)
-        e = g(x, zz, None if c is None else c / 10, pbc)
-        return torch.autograd.grad(e.sum(), x)[0]
-    out["gmx (search + energy + autograd)"] = timeit(gstep)
+    for tag, replay in (("gmx eager (search + energy + autograd)", False), ("gmx replay", True)):
+        g = mk(XPaiNNGMX, replay=replay)
+        def gstep():
+            x = (p / 10).requires_grad_(True)
+            e = g(x, zz, None if c is None else c / 10, pbc)
+            return torch.autograd.grad(e.sum(), x)[0]
+        out[tag] = timeit(gstep)
     print(name, "E =", ei.shape[1], "|", ", ".join(f"{k} {v:.3f} ms" for k, v in out.items()), flush=True)
 pos, z, ptr = orc.synth_aspirin(); run("aspirin (21 atoms)", pos, z)
 pos, z, ptr, cell = orc.synth_water_box(4, seed=5); run("water-64 (192 atoms, PBC)", pos, z, cell)

@@ -12,8 +12,7 @@ model = resolve_model("xpainn").eval().requires_grad_(False).to(dev)
 pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234)
 pos_d, z_d, ptr_d = torch.tensor(pos, dtype=torch.float32, device=dev), torch.tensor(z, device=dev), torch.tensor(ptr, device=dev)
 tr = NeighborTransform(5.0)
-if os.path.exists("gpurun_out/gemm_r01_h.csv"):
-    enable_gemm_autotune(results_file="gpurun_out/gemm_r01_h.csv")
+enable_gemm_autotune()
 main = torch.cuda.current_stream()
 side = torch.cuda.Stream()
 def build():

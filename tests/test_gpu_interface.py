@@ -104,12 +104,13 @@ def test_lammps_model_periodic_virial_and_replay_is_bitwise():
         assert torch.equal(a[k].detach(), b[k].detach()) and torch.equal(b[k].detach(), c[k].detach()), k
 
 
+@pytest.mark.parametrize("replay", [False, True])
 @pytest.mark.parametrize("periodic", [False, True])
-def test_gromacs_model_energy_and_autograd_forces(periodic):
+def test_gromacs_model_energy_and_autograd_forces(periodic, replay):
     from xequinet_amd.interface import XPaiNNGMX
 
     dtype = torch.float64
-    model, oracle = _twin(XPaiNNGMX, dtype)
+    model, oracle = _twin(XPaiNNGMX, dtype, replay=replay, tune_gemms=False)
     nm = FACTOR[("nm", "Angstrom")]
     if periodic:
         f = P._load("single_radius_graph_water192.npz")
@@ -124,13 +125,14 @@ def test_gromacs_model_energy_and_autograd_forces(periodic):
         ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
         extra, box, pbc = None, None, None
     want = oracle(_oracle_in(pos, z, ptr, ei, extra), compute_forces=True)
-    x = P._t(pos / nm, dtype).requires_grad_(True)
-    energy = model(x, P._t(z.astype(np.int64)), box, pbc)
-    (g,) = torch.autograd.grad(energy.sum(), x)
     kj = FACTOR[("eV", "kcal/mol")] * 4.184
-    np.testing.assert_allclose(energy.detach().cpu().numpy(), want["energy"].numpy() * kj, rtol=1e-9)
     fref = want["forces"].numpy() * FACTOR[("eV/Angstrom", "kJ/(mol*nm)")]
-    np.testing.assert_allclose(-g.cpu().numpy(), fref, rtol=0, atol=1e-8 * np.abs(fref).max())
+    for _ in range(2):   # with replay: capture, then one graph launch
+        x = P._t(pos / nm, dtype).requires_grad_(True)
+        energy = model(x, P._t(z.astype(np.int64)), box, pbc)
+        (g,) = torch.autograd.grad(energy.sum(), x)
+        np.testing.assert_allclose(energy.detach().cpu().numpy(), want["energy"].numpy() * kj, rtol=1e-9)
+        np.testing.assert_allclose(-g.cpu().numpy(), fref, rtol=0, atol=1e-8 * np.abs(fref).max())
     np.testing.assert_allclose(model.forces_unit_factor, FACTOR[("eV/Angstrom", "kJ/(mol*nm)")], rtol=1e-12)
 
 

@@ -92,17 +92,34 @@ class _Core:
                                   training=m.training, extra_properties=m.extra_properties)
 
 
+class _EnergyOfPositions(torch.autograd.Function):
+    """energy(positions) whose reverse pass hands back the forces the replayed evaluation already produced"""
+
+    @staticmethod
+    def forward(ctx, positions, energy, forces):
+        ctx.save_for_backward(forces)
+        return energy.clone()
+
+    @staticmethod
+    def backward(ctx, grad_energy):
+        (forces,) = ctx.saved_tensors
+        return -forces * grad_energy.reshape(-1)[0], None, None
+
+
 class XPaiNNGMX(XPaiNN):
     """XPaiNN for GROMACS' NNPot interface (jit_model.py:148-216): positions / box in nm, energy in kJ/mol; the
-    caller differentiates the returned energy with respect to ``positions`` for the forces."""
+    caller differentiates the returned energy with respect to ``positions`` for the forces.  With ``replay=True`` the
+    evaluation (energy and forces) runs as one HIP-graph launch after the neighbour search, and the caller's
+    ``backward`` receives those forces."""
 
-    def __init__(self, net_charge: Optional[int] = None, **kwargs) -> None:
+    def __init__(self, net_charge: Optional[int] = None, replay: bool = False, tune_gemms: bool = True, **kwargs) -> None:
         kwargs.pop("unit_style", None)
         super().__init__(**kwargs)
         self.pos_unit_factor = unit_conversion("nm", _default_unit(keys.POSITIONS))
         self.energy_unit_factor = unit_conversion(_default_unit(keys.TOTAL_ENERGY), "kJ/mol")
         self.forces_unit_factor = unit_conversion(_default_unit(keys.FORCES), "kJ/(mol*nm)")
         self.net_charge = net_charge
+        self._use_replay, self._tune_gemms, self._replay = replay, tune_gemms, None
 
     def forward(self, positions: torch.Tensor, atomic_numbers: torch.Tensor, box: Optional[torch.Tensor] = None,
                 pbc: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -125,6 +142,15 @@ class XPaiNNGMX(XPaiNN):
         }
         if self.net_charge is not None:
             data[keys.TOTAL_CHARGE] = torch.tensor([self.net_charge], device=positions.device)
+        if self._use_replay:
+            from ..runtime import GraphedModel
+            if self._replay is None:
+                self._replay = GraphedModel(_Core(self), compute_forces=True, compute_virial=False, tune_gemms=self._tune_gemms)
+            data[keys.POSITIONS] = positions.detach()
+            data[keys.BATCH_PTR] = torch.tensor([0, positions.shape[0]], dtype=torch.long, device=positions.device)
+            out = self._replay(data)
+            energy = _EnergyOfPositions.apply(positions, out[keys.TOTAL_ENERGY], out[keys.FORCES].clone())
+            return energy * self.energy_unit_factor
         data = compute_edge_data(data=data, compute_forces=True, compute_virial=False)
         for mod in self.mods.values():
             data = mod(data)
