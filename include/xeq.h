@@ -138,6 +138,14 @@ int xeq_radius_graph_pbc_fill_cl(int dtype, const void* pos_wrap, const int64_t*
 
 /* ------------------------------------------------------------ edge geometry */
 
+/* Neighbour-sorted permutation of a SYMMETRIC, center-sorted edge list whose neighbours are ascending and unique
+ * within a center (the open-boundary builders above emit exactly that: replaces the stable sort by neighbour that
+ * ops.EdgeGraph of the reference-side caller would otherwise need, cf. torch_scatter's index_add on edge_index[1],
+ * nn/xpainn.py:154-159).  rev[e] = position of the reverse edge; n_perm = rev and n_rowptr = c_rowptr.
+ * rev[e] = -1 where the reverse edge is missing (the list was not symmetric). */
+int xeq_reverse_edge_map(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, const int32_t* c_rowptr,
+                         int32_t* rev, void* stream);
+
 /* compute_edge_data (nn/basic.py:110-131): vec = pos[c] - pos[n] - cell_offsets @ cell[batch[n]],
  * dist = |vec|.  cell/cell_offsets/batch may be NULL (non-PBC).  batch == NULL with a
  * cell means single graph (cell[0], nn/basic.py:121-123). */

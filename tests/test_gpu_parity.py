@@ -162,7 +162,7 @@ def test_edge_graph_csr_views():
     # exclusive scan helper
     from xequinet_amd import lib
     from xequinet_amd.lib import call, ptr, stream
-    for n in (0, 1, 1023, 1024, 1025, 5000):
+    for n in (0, 1, 7, 1023, 1024, 1025, 5000, 8191, 8192, 8193, 40000):
         cnt = torch.randint(0, 7, (n,), dtype=torch.int32, device=DEV)
         out = torch.empty(n + 1, dtype=torch.int32, device=DEV)
         call("xeq_exclusive_scan_i32", ptr(cnt), n, ptr(out), stream())
@@ -484,6 +484,33 @@ def test_fused_message_is_bitwise_reproducible():
     b, _ = _message_case("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", torch.float32, False)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_edge_graph_reverse_edge_map_equals_stable_sort(monkeypatch):
+    """EdgeGraph(symmetric=True) (what NeighborTransform builds for open boundaries): the neighbour-sorted view from the
+    reverse-edge map is the permutation of the stable sort by neighbour, for the pair sweep and the cell-list builder,
+    with atoms that have no neighbour; a list that is not symmetric is reported with -1 entries."""
+    from xequinet_amd import ops
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.lib import call, ptr, stream
+
+    pos, z, ptr_np = orc.synth_qm9_batch(40, seed=4)
+    pos = pos.copy()
+    pos[5] += 100.0                       # an isolated atom
+    big = np.random.default_rng(3).uniform(0, 30, size=(1500, 3))
+    for p, pp, env in ((pos, ptr_np, "0"), (big, np.array([0, 1500]), "1")):
+        monkeypatch.setenv("XEQ_CELL_LIST", env)
+        b = NeighborTransform(5.0)(XequiBatch(_t(p, torch.float32), _t(np.ones(len(p), dtype=np.int32)), _t(pp)))
+        g = getattr(b, "_xeq_edge_graph")
+        ref = ops.EdgeGraph(b.edge_index, len(p))
+        assert g.c_perm is None and ref.c_perm is None
+        assert torch.equal(g.c_rowptr, ref.c_rowptr) and torch.equal(g.n_rowptr, ref.n_rowptr)
+        assert torch.equal(g.n_perm, ref.n_perm) and g.n_edges > 0
+    ei = _t(np.array([[0, 0, 1, 2], [1, 2, 0, 1]]))          # (0,2) has no reverse, (2,1) neither
+    rp = ops.csr_rowptr(ei[0].contiguous(), 3)
+    rev = torch.empty(4, dtype=torch.int32, device=DEV)
+    call("xeq_reverse_edge_map", ptr(ei), 4, 3, ptr(rp), ptr(rev), stream())
+    assert rev.tolist() == [2, -1, 0, -1]
 
 
 # -------------------------------------------------------------------- whole model

@@ -49,18 +49,26 @@ __global__ void k_csr_rowptr32(const int32_t* __restrict__ keys, int64_t n_keys,
   rowptr[i] = (int32_t)lo;
 }
 
-// single-workgroup scan with carry; n is O(nodes) and this runs once per graph build
+// single-workgroup scan with carry; n is O(nodes) and this runs once per graph build, in front of the host's
+// read-back of the edge count.  Each thread takes 8 consecutive counts, so a round covers 8192 entries.
 __global__ void __launch_bounds__(1024) k_exclusive_scan_i32(const int32_t* __restrict__ in, int64_t n,
                                                              int32_t* __restrict__ out) {
+  constexpr int IT = 8;
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry_s;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t == 0) carry_s = 0;
   __syncthreads();
-  for (int64_t base = 0; base < n; base += 1024) {
-    int64_t i = base + t;
-    int32_t v = i < n ? in[i] : 0;
-    int32_t incl = v;
+  for (int64_t base = 0; base < n; base += 1024 * IT) {
+    const int64_t i0 = base + (int64_t)t * IT;
+    int32_t v[IT];
+    int32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      v[k] = i0 + k < n ? in[i0 + k] : 0;
+      tot += v[k];
+    }
+    int32_t incl = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       int32_t u = __shfl_up(incl, o, 64);
@@ -70,13 +78,35 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan_i32(const int32_t* __re
     __syncthreads();
     int32_t woff = 0;
     for (int k = 0; k < w; ++k) woff += wsum[k];
-    int32_t carry = carry_s;
-    if (i < n) out[i] = carry + woff + incl - v;
+    const int32_t carry = carry_s;
+    int32_t run = carry + woff + incl - tot;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      if (i0 + k < n) out[i0 + k] = run;
+      run += v[k];
+    }
     __syncthreads();
     if (t == 1023) carry_s = carry + woff + incl;
     __syncthreads();
   }
   if (t == 0) out[n] = carry_s;
+}
+
+// n_perm of a SYMMETRIC center-sorted edge list with ascending, unique neighbours per center (what the open-boundary
+// builders emit): the neighbour-sorted order of edge (i -> j) is the position of its reverse edge (j -> i) in the
+// center-sorted list, found by binary search in segment j.  rev[e] = -1 when the reverse edge does not exist.
+__global__ void k_reverse_edge_map(const int64_t* __restrict__ center, const int64_t* __restrict__ nbr,
+                                   const int32_t* __restrict__ c_rowptr, int64_t E, int32_t* __restrict__ rev) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t i = center[e], j = nbr[e];
+  int32_t lo = c_rowptr[j], hi = c_rowptr[j + 1];
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (nbr[mid] < i) lo = mid + 1;
+    else hi = mid;
+  }
+  rev[e] = (lo < c_rowptr[j + 1] && nbr[lo] == i) ? lo : -1;
 }
 
 // ---------------------------------------------------------- non-PBC radius graph
@@ -589,6 +619,16 @@ int xeq_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* out, void*
   XEQ_CHECK_ARG(n >= 0, "xeq_exclusive_scan_i32: n < 0");
   hipLaunchKernelGGL(k_exclusive_scan_i32, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n, out);
   XEQ_CHECK_LAUNCH("xeq_exclusive_scan_i32");
+  return XEQ_OK;
+}
+
+int xeq_reverse_edge_map(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, const int32_t* c_rowptr,
+                         int32_t* rev, void* stream) {
+  XEQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 0, "xeq_reverse_edge_map: negative size");
+  if (n_edges == 0) return XEQ_OK;
+  hipLaunchKernelGGL(k_reverse_edge_map, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     edge_index, edge_index + n_edges, c_rowptr, n_edges, rev);
+  XEQ_CHECK_LAUNCH("xeq_reverse_edge_map");
   return XEQ_OK;
 }
 

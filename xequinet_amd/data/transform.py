@@ -1,10 +1,11 @@
 """``NeighborTransform`` -- mirror of ``xequinet/data/transform.py:21-69``."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import keys, ops
-from ..cluster import radius_graph
 from .radius_graph import radius_graph_pbc
 
 
@@ -37,10 +38,15 @@ class NeighborTransform:
         elif not has_pbc and not has_cell:
             if getattr(data, "edge_index", None) is not None:
                 return data
-            # unlimited neighbours, like max_num_neighbors = sum n_g^2 (data/transform.py:57)
-            data.edge_index = radius_graph(x=data.pos, r=self.cutoff, ptr=ptr)
+            # unlimited neighbours, like max_num_neighbors = sum n_g^2 (data/transform.py:57); same result as
+            # cluster.radius_graph, whose row pointer is kept: the list is symmetric with ascending neighbours, so the
+            # model's neighbour-sorted view is the reverse-edge map (no sort)
+            data.edge_index, rowptr = ops.radius_graph_raw(data.pos, ptr, self.cutoff)
+            setattr(data, keys.EDGE_GRAPH, ops.EdgeGraph(data.edge_index, data.pos.shape[0], center_sorted=True, ptr=ptr,
+                                                         c_rowptr=rowptr, symmetric=os.environ.get("XEQ_REVERSE_EDGE_MAP", "1") != "0"))
+            return data
         else:
             raise ValueError("PBC and cell must be both defined or both undefined.")
-        # both builders emit center-sorted edges: hand the CSR views to the model
+        # center-sorted edges: hand the CSR views to the model
         setattr(data, keys.EDGE_GRAPH, ops.EdgeGraph(data.edge_index, data.pos.shape[0], center_sorted=True, ptr=ptr))
         return data

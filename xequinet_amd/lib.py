@@ -28,6 +28,7 @@ _PROTOS = {
     "xeq_csr_by_key_workspace": [c_int64, c_int64],
     "xeq_csr_by_key": [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P],
     "xeq_exclusive_scan_i32": [_P, c_int64, _P, _P],
+    "xeq_reverse_edge_map": [_P, c_int64, c_int64, _P, _P, _P],
     "xeq_radius_graph_count": [c_int, _P, _P, c_int64, c_int64, c_double, _P, _P],
     "xeq_radius_graph_fill": [c_int, _P, _P, c_int64, c_int64, c_double, _P, c_int64, _P, _P],
     "xeq_radius_graph_bin_ids": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P],

@@ -82,11 +82,16 @@ class EdgeGraph:
     ``n_*``: CSR over neighbors (edge_index[1], keys.py:17) -- reverse pass.
     ``perm`` is None when the edge list is already sorted by that row.
     Index plumbing is one library call per unsorted row (``xeq_csr_by_key``: stable radix sort +
-    row pointer); a sorted row only needs ``xeq_csr_rowptr``.
+    row pointer); a sorted row only needs ``xeq_csr_rowptr`` (or the builder's own ``c_rowptr``).
+    ``symmetric=True`` is the promise of the open-boundary neighbour-list builders of this package: center-sorted,
+    neighbours ascending and unique per center, (i, j) present iff (j, i) is.  Then the neighbour-sorted order is
+    the reverse-edge map (``xeq_reverse_edge_map``, one binary search per edge) and needs no sort; the result is
+    the same permutation the stable sort gives.
     """
 
     def __init__(self, edge_index: torch.Tensor, n_nodes: int, center_sorted: Optional[bool] = None,
-                 ptr: Optional[torch.Tensor] = None) -> None:
+                 ptr: Optional[torch.Tensor] = None, c_rowptr: Optional[torch.Tensor] = None,
+                 symmetric: bool = False) -> None:
         require_hip(edge_index)
         self.ptr = ptr          # graph boundaries [G+1] (keys.BATCH_PTR), when the caller knows them
         self._wm = None
@@ -99,10 +104,19 @@ class EdgeGraph:
             center_sorted = bool((center[1:] >= center[:-1]).all()) if E > 1 else True
         if center_sorted:
             self.c_perm = None
-            self.c_rowptr = csr_rowptr(center, self.n_nodes)
+            if c_rowptr is not None:
+                assert c_rowptr.dtype == torch.int32 and c_rowptr.numel() == self.n_nodes + 1
+                self.c_rowptr = c_rowptr.contiguous()
+            else:
+                self.c_rowptr = csr_rowptr(center, self.n_nodes)
         else:
             self.c_rowptr, self.c_perm = csr_by_key(center, self.n_nodes)
-        self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes)
+        if symmetric and center_sorted:
+            self.n_rowptr = self.c_rowptr
+            self.n_perm = torch.empty(E, dtype=torch.int32, device=edge_index.device)
+            call("xeq_reverse_edge_map", lib.ptr(edge_index), E, self.n_nodes, lib.ptr(self.c_rowptr), lib.ptr(self.n_perm), stream())
+        else:
+            self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes)
 
     def wm_plan(self, reverse: bool, edges_per_stream: int = 128):
         """Stream table of the wave / matrix-core message kernels (xeq_message_{fwd,bwd}_wm): contiguous ranges of
