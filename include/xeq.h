@@ -310,10 +310,15 @@ int xeq_norm_bwd(int dtype, const void* s, const void* x, const void* ln_w, cons
  * pair buffer: cat[n, node_dim + u] = sqrt(sum_m V^2 + eps^2) - eps, p[n,u] = sum_m U V; and the reverse. */
 int xeq_uv_reduce_fwd(int dtype, const void* uv_bt, int64_t n, const int32_t mul[3], double eps, void* cat,
                       int64_t ld_cat, int node_dim, void* p, void* stream);
+/* Reverse: g_U = dL/dU of the output stage + g_p V, g_V = g_p U + g_v V / (v + eps).  The output stage's part is formed
+ * here as g_x_out[n,u,m] * a_vv[n,u] when g_x_out / a are given (then xeq_update_out_bwd is called with g_uv_bt = NULL);
+ * with both NULL it is read from the U columns of g_uv_bt, where xeq_update_out_bwd left it. */
 int xeq_uv_reduce_bwd(int dtype, const void* uv_bt, const void* g_p, const void* g_cat, int64_t ld_cat, int node_dim,
-                      int64_t n, const int32_t mul[3], double eps, void* g_uv_bt, void* stream);
+                      int64_t n, const int32_t mul[3], double eps, const void* g_x_out, const void* a, void* g_uv_bt,
+                      void* stream);
 /* Output stage of XPainnUpdate (nn/xpainn.py:218-229) with a = [a_vv C | a_sv F | a_ss F], ip = dot_lin(p):
- * s_out = s + a_sv*ip + a_ss, x_out = x + U (x) a_vv (x, x_out in e3nn layout); and the reverse. */
+ * s_out = s + a_sv*ip + a_ss, x_out = x + U (x) a_vv (x, x_out in e3nn layout); and the reverse
+ * (g_uv_bt may be NULL: dL/dU = g_x_out a_vv is then left to xeq_uv_reduce_bwd). */
 int xeq_update_out_fwd(int dtype, const void* s, const void* x, const void* uv_bt, const void* a, const void* ip,
                        int64_t n, int node_dim, const int32_t mul[3], void* s_out, void* x_out, void* stream);
 int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, const void* uv_bt, const void* a,

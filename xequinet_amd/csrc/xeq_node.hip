@@ -171,11 +171,13 @@ __global__ void k_uv_reduce_fwd(const T* __restrict__ uv_bt, int64_t N, Irreps i
   p[t] = uv;
 }
 
-// g_U += g_p V ;  g_V = g_p U + g_v V / (v + eps)      (g_uv_bt U-part holds dL/dU from the output stage)
+// g_U = dL/dU(output stage) + g_p V ;  g_V = g_p U + g_v V / (v + eps).  The output stage's part is either already in
+// the U columns of g_uv_bt (g_x_out == NULL: read-modify-write) or formed here as g_x_out[n, u, m] a_vv[n, u].
 template <typename T>
 __global__ void k_uv_reduce_bwd(const T* __restrict__ uv_bt, const T* __restrict__ g_p, const T* __restrict__ g_cat,
-                                int64_t ld_cat, int F, int64_t N, Irreps ir, T eps, T* __restrict__ g_uv_bt) {
-  const int C = ir.C();
+                                int64_t ld_cat, int F, int64_t N, Irreps ir, T eps, const T* __restrict__ g_x_out,
+                                const T* __restrict__ a, T* __restrict__ g_uv_bt) {
+  const int C = ir.C(), D = ir.D(), A = C + 2 * F;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N * C) return;
   const int64_t n = t / C;
@@ -190,7 +192,8 @@ __global__ void k_uv_reduce_bwd(const T* __restrict__ uv_bt, const T* __restrict
   for (int m = 0; m < 2 * l + 1; ++m) {
     const int64_t iu = bt.at(n, u, m, 1, 0), iv = bt.at(n, u, m, 1, 1);
     T U = uv_bt[iu], V = uv_bt[iv];
-    g_uv_bt[iu] += gp * V;
+    const T gu = g_x_out ? g_x_out[n * D + off + m] * a[n * A + u] : g_uv_bt[iu];
+    g_uv_bt[iu] = gu + gp * V;
     g_uv_bt[iv] = gp * U + gv * V;
   }
 }
@@ -238,7 +241,7 @@ __global__ void k_update_out_bwd(const T* __restrict__ g_s_out, const T* __restr
       const T gx = g_x_out[n * D + off + m];
       const int64_t iu = bt.at(n, f, m, 1, 0);
       acc += uv_bt[iu] * gx;
-      g_uv_bt[iu] = gx * avv;
+      if (g_uv_bt) g_uv_bt[iu] = gx * avv;
     }
     g_a[n * A + f] = acc;
   } else {  // scalar channel
@@ -302,7 +305,11 @@ __global__ void __launch_bounds__(256) k_uv_reduce_fwd_c(const T* __restrict__ u
   const ChanBT c = chan_bt(ir, N, u);
   const int64_t n0 = (int64_t)blockIdx.x * NPB;
   const int w2 = 2 * c.w;
-#pragma unroll 4
+#ifndef XEQ_UVF_UNROLL
+#define XEQ_UVF_UNROLL 4
+#endif
+  constexpr int UNROLL = XEQ_UVF_UNROLL;
+#pragma unroll UNROLL
   for (int j = 0; j < NPB; ++j) {
     const int64_t n = n0 + j;
     if (n >= N) break;
@@ -321,18 +328,26 @@ __global__ void __launch_bounds__(256) k_uv_reduce_fwd_c(const T* __restrict__ u
 template <typename T, int NPB>
 __global__ void __launch_bounds__(256) k_uv_reduce_bwd_c(const T* __restrict__ uv_bt, const T* __restrict__ g_p,
                                                           const T* __restrict__ g_cat, int64_t ld_cat, int F, int64_t N,
-                                                          Irreps ir, T eps, T* __restrict__ g_uv_bt) {
-  const int C = ir.C(), u = threadIdx.x;
+                                                          Irreps ir, T eps, const T* __restrict__ g_x_out,
+                                                          const T* __restrict__ a, T* __restrict__ g_uv_bt) {
+  const int C = ir.C(), D = ir.D(), A = C + 2 * F, u = threadIdx.x;
   if (u >= C) return;
   const ChanBT c = chan_bt(ir, N, u);
   const int64_t n0 = (int64_t)blockIdx.x * NPB;
   const int w2 = 2 * c.w;
-#pragma unroll 2
+  // measured (scratch/run_node_variants.sh, 18.6 k nodes): unroll 1 / 2 / 4 / 8 = 59 / 84 / 117 / 50 us at 90 / 133 / 230 / 52
+  // VGPRs: what the scheduler does with the unrolled loads decides the occupancy, and with it the time
+#ifndef XEQ_UVB_UNROLL
+#define XEQ_UVB_UNROLL 8
+#endif
+  constexpr int UNROLL = XEQ_UVB_UNROLL;
+#pragma unroll UNROLL
   for (int j = 0; j < NPB; ++j) {
     const int64_t n = n0 + j;
     if (n >= N) break;
     const int64_t r0 = c.base_uv + n * c.d * w2;
     const T gp = g_p[n * C + u], gc = g_cat[n * ld_cat + F + u];
+    const T avv = g_x_out ? a[n * A + u] : T(0);
     T U[5], V[5], GU[5];
     T vv = T(0);
 #pragma unroll
@@ -340,7 +355,7 @@ __global__ void __launch_bounds__(256) k_uv_reduce_bwd_c(const T* __restrict__ u
       if (m < c.d) {
         U[m] = uv_bt[r0 + m * w2];
         V[m] = uv_bt[r0 + m * w2 + c.w];
-        GU[m] = g_uv_bt[r0 + m * w2];
+        GU[m] = g_x_out ? g_x_out[n * D + c.off + m] * avv : g_uv_bt[r0 + m * w2];
         vv += V[m] * V[m];
       }
     }
@@ -380,7 +395,11 @@ __global__ void __launch_bounds__(256) k_update_out_fwd_c(const T* __restrict__ 
     const ChanBT c = chan_bt(ir, N, u);
     const int w2 = 2 * c.w;
     const int64_t ub = c.base_uv + (int64_t)m * w2;
-#pragma unroll 4
+#ifndef XEQ_UOF_UNROLL
+#define XEQ_UOF_UNROLL 4
+#endif
+    constexpr int UNROLL = XEQ_UOF_UNROLL;
+#pragma unroll UNROLL
     for (int j = 0; j < NPB; ++j) {
       const int64_t n = n0 + j;
       if (n >= N) break;
@@ -404,7 +423,11 @@ __global__ void __launch_bounds__(256) k_update_out_bwd_c(const T* __restrict__ 
   if (f < C) {
     const ChanBT c = chan_bt(ir, N, f);
     const int w2 = 2 * c.w;
-#pragma unroll 2
+#ifndef XEQ_UOB_UNROLL
+#define XEQ_UOB_UNROLL 8   // 41 us against 45 (unroll 2) and 62 (unroll 4: 104 VGPRs)
+#endif
+    constexpr int UNROLL = XEQ_UOB_UNROLL;
+#pragma unroll UNROLL
     for (int j = 0; j < NPB; ++j) {
       const int64_t n = n0 + j;
       if (n >= N) break;
@@ -423,7 +446,7 @@ __global__ void __launch_bounds__(256) k_update_out_bwd_c(const T* __restrict__ 
       for (int m = 0; m < 5; ++m) {
         if (m < c.d) {
           acc += U[m] * gx[m];
-          g_uv_bt[r0 + m * w2] = gx[m] * avv;
+          if (g_uv_bt) g_uv_bt[r0 + m * w2] = gx[m] * avv;
         }
       }
       g_a[n * A + f] = acc;
@@ -649,8 +672,12 @@ int xeq_norm_bwd(int dtype, const void* s, const void* x, const void* ln_w, cons
   // measured (QM9-1024): the element-per-lane kernel already moves its 230 MB at 4.1 TB/s (56 us); the
   // row-in-register form is latency-bound here (71-91 us) and stays opt-in for experiments
   // (MD-sized systems are latency-bound either way; there the row-in-register form has the shorter dependent chain)
+#ifndef XEQ_NORM_BWD_NPW
+#define XEQ_NORM_BWD_NPW 1
+#endif
   const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512 && (n < 8 * 1024 || getenv("XEQ_NORM_BWD_ROWREG") != nullptr);
-  const unsigned wgrid = (unsigned)((n + 3) / 4);
+  const int64_t per_wg = n >= 8 * 1024 ? 4 * XEQ_NORM_BWD_NPW : 4;
+  const unsigned wgrid = (unsigned)((n + per_wg - 1) / per_wg);
   XEQ_DISPATCH_FLOAT(dtype, {
     if (fast)
       hipLaunchKernelGGL((k_norm_bwd_r<T, 2, 8>), dim3(wgrid), dim3(256), 0, (hipStream_t)stream, (const T*)s, (const T*)x,
@@ -690,24 +717,26 @@ int xeq_uv_reduce_fwd(int dtype, const void* uv_bt, int64_t n, const int32_t mul
 }
 
 int xeq_uv_reduce_bwd(int dtype, const void* uv_bt, const void* g_p, const void* g_cat, int64_t ld_cat, int node_dim,
-                      int64_t n, const int32_t mul[3], double eps, void* g_uv_bt, void* stream) {
+                      int64_t n, const int32_t mul[3], double eps, const void* g_x_out, const void* a, void* g_uv_bt,
+                      void* stream) {
   XEQ_IR("xeq_uv_reduce_bwd");
+  XEQ_CHECK_ARG((g_x_out == nullptr) == (a == nullptr), "xeq_uv_reduce_bwd: g_x_out and a go together");
   if (n <= 0) return XEQ_OK;
   const int64_t total = n * ir.C();
   XEQ_DISPATCH_FLOAT(dtype, {
-    if (ir.C() <= 256)
-    {
+    if (ir.C() <= 256) {
       if (node_npb(n) == 1)
         hipLaunchKernelGGL((k_uv_reduce_bwd_c<T, 1>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const T*)uv_bt,
-                           (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps, (T*)g_uv_bt);
+                           (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps, (const T*)g_x_out, (const T*)a,
+                           (T*)g_uv_bt);
       else
         hipLaunchKernelGGL((k_uv_reduce_bwd_c<T, NODE_NPB>), dim3((unsigned)((n + NODE_NPB - 1) / NODE_NPB)), dim3(256), 0,
                            (hipStream_t)stream, (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir,
-                           (T)eps, (T*)g_uv_bt);
-    }
-    else
+                           (T)eps, (const T*)g_x_out, (const T*)a, (T*)g_uv_bt);
+    } else
       hipLaunchKernelGGL((k_uv_reduce_bwd<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                         (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps, (T*)g_uv_bt);
+                         (const T*)uv_bt, (const T*)g_p, (const T*)g_cat, ld_cat, node_dim, n, ir, (T)eps,
+                         (const T*)g_x_out, (const T*)a, (T*)g_uv_bt);
   });
   XEQ_CHECK_LAUNCH("xeq_uv_reduce_bwd");
   return XEQ_OK;

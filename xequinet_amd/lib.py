@@ -76,7 +76,7 @@ _PROTOS = {
     "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
     "xeq_norm_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
     "xeq_uv_reduce_fwd": [c_int, _P, c_int64, _I3, c_double, _P, c_int64, c_int, _P, _P],
-    "xeq_uv_reduce_bwd": [c_int, _P, _P, _P, c_int64, c_int, c_int64, _I3, c_double, _P, _P],
+    "xeq_uv_reduce_bwd": [c_int, _P, _P, _P, c_int64, c_int, c_int64, _I3, c_double, _P, _P, _P, _P],
     "xeq_update_out_fwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P],
     "xeq_update_out_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P, _P],
 }

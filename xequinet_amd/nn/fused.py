@@ -177,14 +177,15 @@ class UpdateBlock(Function):
         g_a = torch.empty_like(a)
         g_ip = torch.empty_like(ip)
         g_uv = torch.empty_like(uv)
+        # dL/dU of this stage (g_x_out a_vv) is formed inside xeq_uv_reduce_bwd: no write here, no read-modify-write there
         call("xeq_update_out_bwd", dtype_code(s), ptr(g_s_out), ptr(g_x_out), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(g_a),
-             ptr(g_ip), ptr(g_uv), stream())
+             ptr(g_ip), None, stream())
         g_p = torch.mm(g_ip, module.dot_lin.weight)
         lin3, act, lin4 = module.update_mlp[0], module.update_mlp[1], module.update_mlp[2]
         g_pre = _silu_bwd(torch.mm(g_a, lin4.weight), pre, act)
         g_cat = torch.mm(g_pre, lin3.weight)                                  # [g_shat | g_v]
         call("xeq_uv_reduce_bwd", dtype_code(s), ptr(uv), ptr(g_p), ptr(g_cat), F + C, F, n, mul3(mul), float(module.invariant.eps),
-             ptr(g_uv), stream())
+             ptr(g_x_out), ptr(a), ptr(g_uv), stream())
         packs, _ = _packed_uv(module)
         g_xhat = torch.empty(n * D, dtype=dt, device=dev)
         for (l, m, gb), (_, _, gub), W in zip(_bt_blocks(g_xhat, n, mul, 1), _bt_blocks(g_uv, n, mul, 2), packs):
