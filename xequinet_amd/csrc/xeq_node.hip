@@ -262,6 +262,19 @@ __global__ void k_update_out_bwd(const T* __restrict__ g_s_out, const T* __restr
 constexpr int NODE_NPB = 8;  // nodes per workgroup of the column kernels ...
 // ... and 1 when that would leave most of the chip idle (MD-sized systems: a 192-atom box is 24 workgroups at 8)
 static inline int node_npb(int64_t n) { return n >= 8 * 1024 ? NODE_NPB : 1; }
+// workgroup width (a multiple of 64 in [256, 512]) that covers `cols` columns with the fewest idle lanes: the default
+// model's output stage has 608 / 352 columns, i.e. 2 x 320 and 1 x 384 instead of 3 x 256 and 2 x 256
+static inline int node_block(int cols) {
+  int best = 256, waste = (cols + 255) / 256 * 256 - cols;
+  for (int bs = 320; bs <= 512; bs += 64) {
+    const int w = (cols + bs - 1) / bs * bs - cols;
+    if (w < waste) {
+      waste = w;
+      best = bs;
+    }
+  }
+  return best;
+}
 
 __device__ __forceinline__ float wave_total_n(float v) {
 #define XEQ_N_DPP(v, ctrl, rmask) \
@@ -372,14 +385,14 @@ __global__ void __launch_bounds__(256) k_uv_reduce_bwd_c(const T* __restrict__ u
 
 // update output stage: thread = flat column of [s (F) | x (D)], column blocks of 256
 template <typename T, int NPB>
-__global__ void __launch_bounds__(256) k_update_out_fwd_c(const T* __restrict__ s, const T* __restrict__ x,
+__global__ void __launch_bounds__(512) k_update_out_fwd_c(const T* __restrict__ s, const T* __restrict__ x,
                                                            const T* __restrict__ uv_bt, const T* __restrict__ a,
                                                            const T* __restrict__ ip, int64_t N, int F, Irreps ir,
                                                            int ncb, T* __restrict__ s_out, T* __restrict__ x_out) {
   const int D = ir.D(), C = ir.C(), A = C + 2 * F;
   const int cb = blockIdx.x % ncb;
   const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NPB;
-  const int f = cb * 256 + threadIdx.x;
+  const int f = cb * (int)blockDim.x + threadIdx.x;
   if (f >= F + D) return;
   if (f < F) {
 #pragma unroll 4
@@ -410,7 +423,7 @@ __global__ void __launch_bounds__(256) k_update_out_fwd_c(const T* __restrict__ 
 
 // thread = column of [gate channels (C) | scalar channels (F)]
 template <typename T, int NPB>
-__global__ void __launch_bounds__(256) k_update_out_bwd_c(const T* __restrict__ g_s_out, const T* __restrict__ g_x_out,
+__global__ void __launch_bounds__(512) k_update_out_bwd_c(const T* __restrict__ g_s_out, const T* __restrict__ g_x_out,
                                                            const T* __restrict__ uv_bt, const T* __restrict__ a,
                                                            const T* __restrict__ ip, int64_t N, int F, Irreps ir, int ncb,
                                                            T* __restrict__ g_a, T* __restrict__ g_ip,
@@ -418,7 +431,7 @@ __global__ void __launch_bounds__(256) k_update_out_bwd_c(const T* __restrict__ 
   const int D = ir.D(), C = ir.C(), A = C + 2 * F;
   const int cb = blockIdx.x % ncb;
   const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NPB;
-  const int f = cb * 256 + threadIdx.x;
+  const int f = cb * (int)blockDim.x + threadIdx.x;
   if (f >= C + F) return;
   if (f < C) {
     const ChanBT c = chan_bt(ir, N, f);
@@ -610,6 +623,98 @@ __global__ void __launch_bounds__(256) k_norm_bwd_r(const T* __restrict__ s, con
   }
 }
 
+// Reverse of the two norms with ONE reduction stage: the five wave sums a node needs (sum dy, sum dy yhat, sum gw xc and,
+// for the 0e mean, sum gw and sum xc over the scalar channels) do not depend on each other once the last one is
+// split as  sum_{0e} (r gw - coef xc) = r sum gw - coef sum xc,  so every load of the node is issued up front, the
+// sums run interleaved, and the node's row stays in registers for the output (one memory round trip per node
+// instead of four dependent ones).  NPW nodes per wave amortise the slot decoding.
+template <typename T, int SS, int XS>
+__global__ void __launch_bounds__(256) k_norm_bwd_f(const T* __restrict__ s, const T* __restrict__ x,
+                                                     const T* __restrict__ lnw, const T* __restrict__ eqw,
+                                                     const T* __restrict__ stats, int64_t N, int F, Irreps ir,
+                                                     const T* __restrict__ g_shat, int64_t ld_gs,
+                                                     const T* __restrict__ g_xhat_bt, const T* __restrict__ res_s,
+                                                     const T* __restrict__ res_x, T* __restrict__ g_s, T* __restrict__ g_x) {
+  const int D = ir.D(), C = ir.C(), m0 = ir.mul[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  T w_s[SS], w_x[XS];
+  uint32_t o_x[XS], st_x[XS];   // BT element offsets: the launcher checks N * D < 2^31
+#pragma unroll
+  for (int k = 0; k < SS; ++k) w_s[k] = (lane + 64 * k < F) ? lnw[lane + 64 * k] : T(0);
+#pragma unroll
+  for (int k = 0; k < XS; ++k) {
+    const int f = lane + 64 * k;
+    int u = 0, m = 0;
+    if (f < D) chan_of_flat(ir, f, u, m);
+    const ChanBT c = chan_bt(ir, N, u);
+    w_x[k] = f < D ? eqw[u] : T(0);
+    o_x[k] = (uint32_t)(c.base_x + (int64_t)m * c.w);
+    st_x[k] = (uint32_t)(c.d * c.w);
+  }
+  for (int64_t n = wid; n < N; n += nw) {
+    T yh[SS], dy[SS], xc[XS], gw[XS];
+    T rs[SS], rx[XS];   // residual rows ride along with the first (only) round of loads: 58 -> 41 -> 33 us with them
+#pragma unroll
+    for (int k = 0; k < SS; ++k) rs[k] = (res_s && lane + 64 * k < F) ? res_s[n * F + lane + 64 * k] : T(0);
+#pragma unroll
+    for (int k = 0; k < XS; ++k) rx[k] = (res_x && lane + 64 * k < D) ? res_x[n * D + lane + 64 * k] : T(0);
+    const T mean = stats[4 * n], rstd = stats[4 * n + 1], mean0 = stats[4 * n + 2], r = stats[4 * n + 3];
+#pragma unroll
+    for (int k = 0; k < SS; ++k) {
+      const int f = lane + 64 * k;
+      const bool ok = f < F;
+      yh[k] = ok ? s[n * F + f] : T(0);
+      dy[k] = ok ? g_shat[n * ld_gs + f] : T(0);
+    }
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+      const int f = lane + 64 * k;
+      const bool ok = f < D;
+      xc[k] = ok ? x[n * D + f] : T(0);
+      gw[k] = ok ? g_xhat_bt[o_x[k] + (uint32_t)n * st_x[k]] : T(0);
+    }
+    T a1 = T(0), a2 = T(0), dotp = T(0), sg0 = T(0), sx0 = T(0);
+#pragma unroll
+    for (int k = 0; k < SS; ++k) {
+      const bool ok = lane + 64 * k < F;
+      yh[k] = ok ? (yh[k] - mean) * rstd : T(0);
+      dy[k] *= w_s[k];
+      a1 += dy[k];
+      a2 += dy[k] * yh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+      const int f = lane + 64 * k;
+      const bool z = f < m0;
+      xc[k] = f < D ? xc[k] - (z ? mean0 : T(0)) : T(0);
+      gw[k] *= w_x[k];
+      dotp += gw[k] * xc[k];
+      sg0 += z ? gw[k] : T(0);
+      sx0 += z ? xc[k] : T(0);
+    }
+    a1 = wave_total_n(a1);
+    a2 = wave_total_n(a2);
+    dotp = wave_total_n(dotp);
+    sg0 = wave_total_n(sg0);
+    sx0 = wave_total_n(sx0);
+    a1 /= T(F);
+    a2 /= T(F);
+    const T coef = dotp * r * r * r / T(C);
+    const T gmean = m0 > 0 ? (r * sg0 - coef * sx0) / T(m0) : T(0);
+#pragma unroll
+    for (int k = 0; k < SS; ++k) {
+      const int f = lane + 64 * k;
+      if (f < F) g_s[n * F + f] = rstd * (dy[k] - a1 - yh[k] * a2) + rs[k];
+    }
+#pragma unroll
+    for (int k = 0; k < XS; ++k) {
+      const int f = lane + 64 * k;
+      if (f < D) g_x[n * D + f] = r * gw[k] - coef * xc[k] - (f < m0 ? gmean : T(0)) + rx[k];
+    }
+  }
+}
+
 static inline int irreps_from(const int32_t mul[3], Irreps& ir, const char* who) {
   for (int l = 0; l < 3; ++l) {
     if (mul[l] < 0) {
@@ -669,18 +774,18 @@ int xeq_norm_bwd(int dtype, const void* s, const void* x, const void* ln_w, cons
   XEQ_IR("xeq_norm_bwd");
   XEQ_CHECK_ARG(node_dim > 0 && ld_gs >= node_dim, "xeq_norm_bwd: bad node_dim / row stride");
   if (n <= 0) return XEQ_OK;
-  // measured (QM9-1024): the element-per-lane kernel already moves its 230 MB at 4.1 TB/s (56 us); the
-  // row-in-register form is latency-bound here (71-91 us) and stays opt-in for experiments
-  // (MD-sized systems are latency-bound either way; there the row-in-register form has the shorter dependent chain)
+  // measured (QM9-1024, scratch/run_node_variants.sh): element-per-lane kernel with four dependent passes 58 us; row in
+  // registers with four dependent reductions 76-93 us; row in registers with one fused reduction stage: see k_norm_bwd_f
 #ifndef XEQ_NORM_BWD_NPW
-#define XEQ_NORM_BWD_NPW 1
+#define XEQ_NORM_BWD_NPW 4
 #endif
-  const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512 && (n < 8 * 1024 || getenv("XEQ_NORM_BWD_ROWREG") != nullptr);
+  const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512 && n * (int64_t)ir.D() < (1ll << 31) &&
+                    getenv("XEQ_NORM_BWD_OLD") == nullptr;
   const int64_t per_wg = n >= 8 * 1024 ? 4 * XEQ_NORM_BWD_NPW : 4;
   const unsigned wgrid = (unsigned)((n + per_wg - 1) / per_wg);
   XEQ_DISPATCH_FLOAT(dtype, {
     if (fast)
-      hipLaunchKernelGGL((k_norm_bwd_r<T, 2, 8>), dim3(wgrid), dim3(256), 0, (hipStream_t)stream, (const T*)s, (const T*)x,
+      hipLaunchKernelGGL((k_norm_bwd_f<T, 2, 8>), dim3(wgrid), dim3(256), 0, (hipStream_t)stream, (const T*)s, (const T*)x,
                          (const T*)ln_w, (const T*)eq_w, (const T*)stats, n, node_dim, ir, (const T*)g_shat, ld_gs,
                          (const T*)g_xhat_bt, (const T*)res_s, (const T*)res_x, (T*)g_s, (T*)g_x);
     else
@@ -746,16 +851,17 @@ int xeq_update_out_fwd(int dtype, const void* s, const void* x, const void* uv_b
                        int64_t n, int node_dim, const int32_t mul[3], void* s_out, void* x_out, void* stream) {
   XEQ_IR("xeq_update_out_fwd");
   if (n <= 0) return XEQ_OK;
-  const int ncb = (node_dim + ir.D() + 255) / 256;
+  const int bs = 256;   // (2 x 320 for the 608 columns of the default model measured no better than 3 x 256)
+  const int ncb = (node_dim + ir.D() + bs - 1) / bs;
   const int npb = node_npb(n);
   const int64_t nblk = (n + npb - 1) / npb * ncb;
   XEQ_CHECK_ARG(nblk < (1ll << 31), "xeq_update_out_fwd: too many nodes for one launch");
   XEQ_DISPATCH_FLOAT(dtype, {
     if (npb == 1)
-      hipLaunchKernelGGL((k_update_out_fwd_c<T, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+      hipLaunchKernelGGL((k_update_out_fwd_c<T, 1>), dim3((unsigned)nblk), dim3(bs), 0, (hipStream_t)stream, (const T*)s,
                          (const T*)x, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir, ncb, (T*)s_out, (T*)x_out);
     else
-      hipLaunchKernelGGL((k_update_out_fwd_c<T, NODE_NPB>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const T*)s,
+      hipLaunchKernelGGL((k_update_out_fwd_c<T, NODE_NPB>), dim3((unsigned)nblk), dim3(bs), 0, (hipStream_t)stream, (const T*)s,
                          (const T*)x, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir, ncb, (T*)s_out, (T*)x_out);
   });
   XEQ_CHECK_LAUNCH("xeq_update_out_fwd");
@@ -767,17 +873,18 @@ int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, cons
                        void* g_uv_bt, void* stream) {
   XEQ_IR("xeq_update_out_bwd");
   if (n <= 0) return XEQ_OK;
-  const int ncb = (node_dim + ir.C() + 255) / 256;
+  const int bs = node_block(node_dim + ir.C());
+  const int ncb = (node_dim + ir.C() + bs - 1) / bs;
   const int npb = node_npb(n);
   const int64_t nblk = (n + npb - 1) / npb * ncb;
   XEQ_CHECK_ARG(nblk < (1ll << 31), "xeq_update_out_bwd: too many nodes for one launch");
   XEQ_DISPATCH_FLOAT(dtype, {
     if (npb == 1)
-      hipLaunchKernelGGL((k_update_out_bwd_c<T, 1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+      hipLaunchKernelGGL((k_update_out_bwd_c<T, 1>), dim3((unsigned)nblk), dim3(bs), 0, (hipStream_t)stream,
                          (const T*)g_s_out, (const T*)g_x_out, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir,
                          ncb, (T*)g_a, (T*)g_ip, (T*)g_uv_bt);
     else
-      hipLaunchKernelGGL((k_update_out_bwd_c<T, NODE_NPB>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+      hipLaunchKernelGGL((k_update_out_bwd_c<T, NODE_NPB>), dim3((unsigned)nblk), dim3(bs), 0, (hipStream_t)stream,
                          (const T*)g_s_out, (const T*)g_x_out, (const T*)uv_bt, (const T*)a, (const T*)ip, n, node_dim, ir,
                          ncb, (T*)g_a, (T*)g_ip, (T*)g_uv_bt);
   });
