@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--workload", default="qm9_1024", choices=["qm9_1024", "qm9_64", "md17_4096", "water_512"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel of the model part from the host in the timed region (default: the model part is "
+                         "a captured HIP graph, runtime.GraphedModel; the neighbour list is eager either way)")
     ap.add_argument("--no-gemm-autotune", action="store_true",
                     help="keep the libraries' default GEMM heuristics (xequinet_amd/tuning.py)")
     ap.add_argument("--gemm-results", default=None,
@@ -126,12 +129,25 @@ def main():
         from xequinet_amd.tuning import enable_gemm_autotune
         enable_gemm_autotune(results_file=args.gemm_results)   # every GEMM shape is timed once, during the warm-up steps
 
-    def step():
+    def step_eager():
         batch = XequiBatch(pos_d.detach(), z_d, ptr_d, pbc=pbc_d, cell=cell_d)
         batch = transform(batch)                       # HIP radius graph
         with torch.enable_grad():
             out = model(batch.to_dict(), compute_forces=True, compute_virial=False)
         return batch.edge_index.shape[1], out
+
+    if args.eager:
+        step = step_eager
+    else:
+        # the same kernels in the same order as one HIP-graph launch (results bitwise those of the eager path); the
+        # neighbour list stays eager: its edge count has to reach the host to size the edge arrays
+        from xequinet_amd.runtime import GraphedModel
+        graphed = GraphedModel(model, compute_forces=True, compute_virial=False, tune_gemms=False)
+
+        def step():
+            batch = XequiBatch(pos_d.detach(), z_d, ptr_d, pbc=pbc_d, cell=cell_d)
+            batch = transform(batch)
+            return batch.edge_index.shape[1], graphed(batch.to_dict())
 
     for _ in range(args.warmup):
         n_edges, out = step()
@@ -139,7 +155,7 @@ def main():
     n_atoms = pos_d.shape[0]
 
     # ---- timed region: exactly K steps between barrier + synchronize
-    ops.KERNEL_TIMER.reset(enabled=True)
+    ops.KERNEL_TIMER.reset(enabled=args.eager)
     xdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -150,7 +166,23 @@ def main():
     torch.cuda.synchronize()
     xdist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ops.KERNEL_TIMER.summary()           # HIP events recorded on the launch stream
+    if args.eager:
+        kernel_ms = ops.KERNEL_TIMER.summary()       # HIP events recorded on the launch stream, in the timed region
+        kernel_timing = "HIP events around every launch of the timed region, on the launch stream"
+    else:
+        # HIP offers no per-node event timing inside a graph launch on this stack (torch: "External events are disallowed
+        # in rocm"), so the message kernels' launch durations are read right after the timed region: the same kernels on
+        # the same inputs, launched from the host between HIP events on the launch stream
+        out_keep = {k: v.clone() for k, v in out.items()}
+        ops.KERNEL_TIMER.reset(enabled=True)
+        cal = max(1, min(args.steps, 10))
+        for _ in range(cal):
+            step_eager()
+        kernel_ms = ops.KERNEL_TIMER.summary()
+        kernel_ms = {k: {"launches": v["launches"], "total_ms": v["total_ms"] * args.steps / cal} for k, v in kernel_ms.items()}
+        kernel_timing = (f"HIP events around the kernel's launches in {cal} host-launched evaluations of the same batch right after the "
+                         "timed region (inside it the launches are nodes of one HIP graph, which HIP cannot time one by one here)")
+        out = out_keep
     ops.KERNEL_TIMER.reset(enabled=False)
 
     t_max, edges_total = xdist.reduce_timing(elapsed, edges_done, device=dev)
@@ -169,6 +201,8 @@ def main():
         if dom is not None:
             alg = {dom: alg_bwd if "bwd" in dom else alg_fwd}
             avg_ms = kernel_ms[dom]["total_ms"] / kernel_ms[dom]["launches"]
+            if not args.eager:
+                avg_ms = avg_ms * cal / args.steps      # undo the per-step rescaling above: a plain average over the launches
             achieved = alg[dom] / (avg_ms * 1e-3) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -179,7 +213,7 @@ def main():
             flops = (52.0e3 if "bwd" in dom else 26.0e3) * n_edges
             tfl = flops / (avg_ms * 1e-3) / 1e12
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "timing": kernel_timing,
                         "algorithmic_bytes_per_launch": alg[dom],
                         "matrix_pipe": {"algorithmic_flops_per_launch": flops, "achieved": tfl, "peak": F32_MATRIX_PEAK_TFLOPS,
                                         "unit": "TFLOP/s", "frac": tfl / F32_MATRIX_PEAK_TFLOPS, "dtype": "f32 (exact, v_mfma_f32_32x32x2_f32)"},
@@ -191,7 +225,8 @@ def main():
             "config": {"workload": f"{args.workload}: QM9-shape synthetic molecules per GPU, 5 A cutoff, default XPaiNN (865141 params, random init), "
                                    "neighbour list + energy + forces", "atoms_per_gpu": int(n_atoms), "edges_per_gpu": int(n_edges),
                        "parallelism": f"molecule shards x{world}, no collectives",
-                       "library_gemm_selection": "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)"},
+                       "library_gemm_selection": "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)",
+                       "launch": "host launch per kernel" if args.eager else "model part (forward + force backward) as one captured HIP graph per step; neighbour list launched from the host"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

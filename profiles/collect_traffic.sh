@@ -6,7 +6,7 @@ tag=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$c -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --gemm-results $R/gpurun_out/gemm_$tag.csv > $R/gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$c -- python3 $R/bench.py --eager --steps 4 --warmup 2 --no-cpu-baseline --gemm-results $R/gpurun_out/gemm_$tag.csv > $R/gpurun_out/pmc_${tag}_$c.log 2>&1
 done
 cd $R
 python3 profiles/summarise_traffic.py $tag gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE

@@ -490,8 +490,7 @@ __global__ void __launch_bounds__(256) k_norm_fwd_r(const T* __restrict__ s, con
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   // slot decoding, once per wave
   T w_s[SS], b_s[SS], w_x[XS], b_x[XS];
-  int64_t o_x[XS];  // BT offset of (n = 0)
-  int st_x[XS];     // BT node stride
+  uint32_t o_x[XS], st_x[XS];  // BT element offset of (n = 0) and node stride: the launcher checks N * D < 2^31
 #pragma unroll
   for (int k = 0; k < SS; ++k) {
     const int f = lane + 64 * k;
@@ -506,8 +505,8 @@ __global__ void __launch_bounds__(256) k_norm_fwd_r(const T* __restrict__ s, con
     const ChanBT c = chan_bt(ir, N, u);
     w_x[k] = f < D ? eqw[u] : T(0);
     b_x[k] = f < m0 ? eqb[f] : T(0);
-    o_x[k] = c.base_x + (int64_t)m * c.w;
-    st_x[k] = c.d * c.w;
+    o_x[k] = (uint32_t)(c.base_x + (int64_t)m * c.w);
+    st_x[k] = (uint32_t)(c.d * c.w);
   }
   for (int64_t n = wid; n < N; n += nw) {
     T sv[SS], xv[XS];
@@ -543,7 +542,7 @@ __global__ void __launch_bounds__(256) k_norm_fwd_r(const T* __restrict__ s, con
       if (lane + 64 * k < F) shat[n * ld_s + lane + 64 * k] = sv[k] * rstd * w_s[k] + b_s[k];
 #pragma unroll
     for (int k = 0; k < XS; ++k)
-      if (lane + 64 * k < D) xhat_bt[o_x[k] + n * st_x[k]] = xv[k] * r * w_x[k] + b_x[k];
+      if (lane + 64 * k < D) xhat_bt[o_x[k] + (uint32_t)n * st_x[k]] = xv[k] * r * w_x[k] + b_x[k];
     if (lane == 0) {
       stats[4 * n] = mean;
       stats[4 * n + 1] = rstd;
@@ -749,10 +748,13 @@ int xeq_norm_fwd(int dtype, const void* s, const void* x, const void* ln_w, cons
   XEQ_IR("xeq_norm_fwd");
   XEQ_CHECK_ARG(node_dim > 0 && ld_s >= node_dim, "xeq_norm_fwd: bad node_dim / row stride");
   if (n <= 0) return XEQ_OK;
-  const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512;  // row in registers: 2 + 8 slots per lane
+  const bool fast = do_norm && node_dim <= 128 && ir.D() <= 512 && n * (int64_t)ir.D() < (1ll << 31);  // row in registers: 2 + 8 slots per lane
   // ~4 nodes per wave: the slot decoding of a wave is amortised, every CU still gets >= 16 waves at 18k nodes
   // (small systems: one node per wave, so that a 192-atom box still spreads over 48 workgroups)
-  const int64_t per_wg = n >= 8 * 1024 ? 16 : 4;
+#ifndef XEQ_NORM_FWD_NPW
+#define XEQ_NORM_FWD_NPW 4
+#endif
+  const int64_t per_wg = n >= 8 * 1024 ? 4 * XEQ_NORM_FWD_NPW : 4;
   const unsigned wgrid = (unsigned)((n + per_wg - 1) / per_wg < 65536 ? (n + per_wg - 1) / per_wg : 65536);
   XEQ_DISPATCH_FLOAT(dtype, {
     if (fast)
