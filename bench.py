@@ -149,9 +149,23 @@ def main():
             batch = transform(batch)
             return batch.edge_index.shape[1], graphed(batch.to_dict())
 
-    for _ in range(args.warmup):
-        n_edges, out = step()
-    torch.cuda.synchronize()
+    try:
+        for _ in range(args.warmup):
+            n_edges, out = step()
+        torch.cuda.synchronize()
+    except RuntimeError as err:      # a failed capture must not cost the measurement: fall back to host launches
+        if args.eager:
+            raise
+        print(f"[bench] HIP-graph capture failed on rank {rank} ({err}); continuing with host launches", file=sys.stderr, flush=True)
+        args.eager, step = True, step_eager
+        for _ in range(args.warmup):
+            n_edges, out = step()
+        torch.cuda.synchronize()
+    if world > 1:                    # every rank must time the same mode
+        flag = torch.tensor([1 if args.eager else 0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if bool(flag.item()) and not args.eager:
+            args.eager, step = True, step_eager
     n_atoms = pos_d.shape[0]
 
     # ---- timed region: exactly K steps between barrier + synchronize

@@ -99,7 +99,9 @@ class GraphedModel:
                 self._run(static)
         torch.cuda.current_stream().wait_stream(side)
         c.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(c.graph):
+        # thread-local capture mode: HIP calls of other host threads (RCCL's watchdog in a multi-rank job) do not
+        # invalidate the capture
+        with torch.cuda.graph(c.graph, capture_error_mode="thread_local"):
             c.outputs = self._run(static)
         self.captures += 1
         return c
