@@ -122,6 +122,10 @@ __device__ __forceinline__ WmUnit wm_unit(const WmArgs& a, int u) {
 #define XEQ_WM_BWD_GR(NM) ((NM) == 5 ? 8 : 16)
 #endif
 // resident waves per SIMD the register allocation must allow
+// scheduling fences of the tile loops (dev switch: -D'XEQ_WM_SB()=' compiles them out)
+#ifndef XEQ_WM_SB
+#define XEQ_WM_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef XEQ_WM_FWD_WPE
 #define XEQ_WM_FWD_WPE 3
 #endif
@@ -433,13 +437,13 @@ __device__ __forceinline__ void wm_fwd_body(const WmArgs& a, int range, const Wm
     const WmIdx ixn = ix;
     wm_row<KS, 1, (NM > 1)>(a, ixn, hh, rec, nullptr, row);
     ix = wm_idx(a, lane, t + 2, e0, e1, e2);
-    __builtin_amdgcn_sched_barrier(0);
+    XEQ_WM_SB();
     {  // ---- pass X
       const f32x16 ds = wm_filter<KS>(R, Ws), de = wm_filter<KS>(R, We);
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += GR) {
         if (r0 > 0) {
-          __builtin_amdgcn_sched_barrier(0);
+          XEQ_WM_SB();
           load_group(r0);
         }
 #pragma unroll
@@ -685,17 +689,17 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     (void)nfirst;
     (void)nlast;
     ix = wm_idx(a, lane, t + 2, e0, e1, e2);
-    __builtin_amdgcn_sched_barrier(0);
+    XEQ_WM_SB();
     float pd[16];
     WM_STAMP(0);   // tile top: table reads, gathers and prefetches issued
     {  // ---- pass S
       const f32x16 ds = wm_filter<KS>(R, Ws), qs = wm_filter<KS>(Rd, Ws);
-      __builtin_amdgcn_sched_barrier(0);
+      XEQ_WM_SB();
       WM_STAMP(1);   // MFMAs of pass S issued
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += GR) {
         if (r0 > 0) {
-          __builtin_amdgcn_sched_barrier(0);
+          XEQ_WM_SB();
           load_group(r0);
         }
 #pragma unroll
@@ -751,19 +755,19 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     WM_STAMP(2);     // rows of pass S
     // the first rows of pass E fly under its MFMAs
     if (GR < 16) load_group(0);
-    __builtin_amdgcn_sched_barrier(0);
+    XEQ_WM_SB();
     {  // ---- pass E
       const f32x16 de = wm_filter<KS>(R, We), qe = wm_filter<KS>(Rd, We);
       if constexpr (!HAS_S) {   // last MFMAs of the tile are issued: the next tile's records take over their registers
-        __builtin_amdgcn_sched_barrier(0);
+        XEQ_WM_SB();
         wm_row<KS, 2, (NM > 1)>(a, ixn, hh, rec, drec, row);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      XEQ_WM_SB();
       WM_STAMP(3);   // MFMAs of pass E issued
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += GR) {
         if (r0 > 0) {
-          __builtin_amdgcn_sched_barrier(0);
+          XEQ_WM_SB();
           load_group(r0);
         }
 #pragma unroll
@@ -812,7 +816,7 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     WM_STAMP(4);     // rows of pass E
     if constexpr (HAS_S) {  // ---- pass M
       const f32x16 dm = wm_filter<KS>(R, Wm), qm = wm_filter<KS>(Rd, Wm);
-      __builtin_amdgcn_sched_barrier(0);
+      XEQ_WM_SB();
       wm_row<KS, 2, (NM > 1)>(a, ixn, hh, rec, drec, row);
       WM_STAMP(5);   // MFMAs of pass M issued
 #pragma unroll
