@@ -29,6 +29,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32 (= the f32 vector rate)
 
 
+WORKLOADS = {"qm9_1024": "1024 QM9-shape synthetic molecules", "qm9_64": "64 QM9-shape synthetic molecules",
+             "md17_4096": "4096 perturbed aspirin frames (MD17 shape)", "water_512": "one periodic box of 512 water molecules"}
+
+
 def make_workload(name: str, seed: int):
     from oracle import xpainn_oracle as orc  # synthetic-input generators only (pure numpy)
 
@@ -236,7 +240,7 @@ def main():
             "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: QM9-shape synthetic molecules per GPU, 5 A cutoff, default XPaiNN (865141 params, random init), "
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]} per GPU, 5 A cutoff, default XPaiNN (865141 params, random init), "
                                    "neighbour list + energy + forces", "atoms_per_gpu": int(n_atoms), "edges_per_gpu": int(n_edges),
                        "parallelism": f"molecule shards x{world}, no collectives",
                        "library_gemm_selection": "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)",
