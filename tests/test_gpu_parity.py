@@ -584,6 +584,34 @@ def test_model_qm9_batch_energy_forces(dtype):
     _check_model(model, oracle, pos, z, ptr, ei, dtype)
 
 
+def test_model_batch_with_lone_atoms_through_neighbor_transform():
+    """Edge cases of the whole pipeline (NeighborTransform -> symmetric EdgeGraph -> fused blocks): a one-atom molecule
+    in the middle of a batch, a far-away atom inside a molecule, and a batch that is only a lone atom (no edge at all);
+    energies / forces against the oracle, eager and through the HIP-graph replay."""
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.runtime import GraphedModel
+
+    model, oracle = _build(torch.float64)
+    gm = GraphedModel(model, tune_gemms=False)
+    pos, z, ptr = orc.synth_qm9_batch(4, seed=2)
+    cut = int(ptr[2])
+    pos = np.concatenate([pos[:cut], [[50.0, 50.0, 50.0]], pos[cut:]])        # a one-atom "molecule" as graph 2
+    z = np.concatenate([z[:cut], [8], z[cut:]])
+    ptr = np.concatenate([ptr[:3], ptr[2:] + 1])
+    pos[0] += 200.0                                                            # and an atom with no neighbour
+    cases = [(pos, z, ptr), (np.array([[0.0, 0.0, 0.0]]), np.array([6]), np.array([0, 1]))]
+    for p, zz, pp in cases:
+        b = NeighborTransform(5.0)(XequiBatch(_t(p, torch.float64), _t(zz.astype(np.int32)), _t(pp)))
+        ei = b.edge_index.cpu().numpy()
+        np.testing.assert_array_equal(ei, orc.radius_graph_canonical(p, pp, 5.0))
+        d = b.to_dict()
+        got, want = _check_model(lambda data, **kw: model({**d, "pos": data["pos"]}, **kw), oracle, p, zz, pp, ei, torch.float64)
+        rep = gm(d)
+        assert torch.equal(rep["energy"], got["energy"].detach()) and torch.equal(rep["forces"], got["forces"].detach())
+        assert got["energy"].shape == (len(pp) - 1,)
+    assert ei.shape[1] == 0 and float(got["forces"].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("kw", [
     dict(node_dim=32, node_irreps="32x0e+16x1o+8x2e", num_basis=8, cutoff=4.0, action_blocks=2, hidden_dim=16),
     dict(node_dim=16, node_irreps="16x1o", num_basis=8, cutoff=4.0, action_blocks=2, layer_norm=False, embed_basis="one-hot"),
