@@ -30,6 +30,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, e
 
 
 WORKLOADS = {"qm9_1024": "1024 QM9-shape synthetic molecules", "qm9_64": "64 QM9-shape synthetic molecules",
+             "qm9_8192": "8192 QM9-shape synthetic molecules (the per-GPU share of QM9-65k on 8 GPUs, SURVEY 8d-5)",
              "md17_4096": "4096 perturbed aspirin frames (MD17 shape)", "water_512": "one periodic box of 512 water molecules"}
 
 
@@ -39,8 +40,8 @@ def make_workload(name: str, seed: int):
     if name == "qm9_1024":
         pos, z, ptr = orc.synth_qm9_batch(1024, seed=seed)
         return pos, z, ptr, None
-    if name == "qm9_64":
-        pos, z, ptr = orc.synth_qm9_batch(64, seed=seed)
+    if name in ("qm9_64", "qm9_8192"):
+        pos, z, ptr = orc.synth_qm9_batch(int(name.split("_")[1]), seed=seed)
         return pos, z, ptr, None
     if name == "md17_4096":
         p0, z0, _ = orc.synth_aspirin()
@@ -91,7 +92,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="qm9_1024", choices=["qm9_1024", "qm9_64", "md17_4096", "water_512"])
+    ap.add_argument("--workload", default="qm9_1024", choices=list(WORKLOADS))
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true",
