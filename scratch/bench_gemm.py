@@ -1,6 +1,7 @@
-"""The model's dense contractions: the experimental xeq_gemm_f32 (scratch/xeq_gemm_experiment.hip, per wave tile) against the
-library GEMM (TunableOp picks).  Shelved: needs the kernel added to csrc/build.py and an ops.gemm wrapper; the result of the
-last run is scratch/bench_gemm_result.txt."""
+"""The model's dense contractions: the experimental xeq_gemm_f32 (scratch/xeq_gemm_lds_experiment.hip, per workgroup tile;
+the earlier LDS-free form is scratch/xeq_gemm_experiment.hip) against the library GEMM (TunableOp picks).  Shelved: needs the
+kernel in csrc/build.py, its prototype in lib.py / xeq.h and an ops.gemm wrapper; results of the last runs:
+scratch/bench_gemm_lds_result.txt, scratch/bench_gemm_result.txt."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xequinet_amd import ops
@@ -32,7 +33,7 @@ for name, mult, K, N, lay, has_b, act in SHAPES:
     refo = torch.nn.functional.silu(ref) if act else ref
     tl = t(lib_fn)
     res = []
-    for tile in (11, 12, 14, 21, 22, 0):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 0):
         fn = lambda: ops.gemm(x, w, b, lay, act, tile=tile)
         o = fn(); o = o[0] if act else o
         err = float((o.double() - refo).abs().max())

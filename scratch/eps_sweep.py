@@ -33,6 +33,10 @@ def case(name, pos, z, ptr, cell=None):
         out.append(f"eps {eps}: fwd {t['xeq_message_fwd_wm']:.1f} bwd {t['xeq_message_bwd_wm']:.1f}")
     print(f"{name} N={N} E={E} | " + " | ".join(out), flush=True)
 os.environ["XEQ_MESSAGE_IMPL"] = "wm"
+if os.environ.get("SWEEP_ONLY_BIG"):
+    pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234); case("qm9-1024", pos, z, ptr)
+    pos, z, ptr = orc.synth_qm9_batch(1024, seed=1235); case("qm9-1024b", pos, z, ptr)
+    sys.exit(0)
 pos, z, ptr = orc.synth_aspirin(); case("aspirin", pos, z, ptr)
 pos, z, ptr, cell = orc.synth_water_box(4, seed=5); case("water-64", pos, z, ptr, cell)
 pos, z, ptr = orc.synth_qm9_batch(64, seed=3); case("qm9-64", pos, z, ptr)
