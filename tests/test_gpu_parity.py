@@ -136,6 +136,30 @@ def test_radius_graph_pbc_pruned_equals_exhaustive(dtype):
             assert torch.equal(u, w), trial
 
 
+@pytest.mark.parametrize("dtype,npdt", [(torch.float32, np.float32), (torch.float64, np.float64)])
+def test_radius_graph_pbc_random_cells_equal_oracle(dtype, npdt):
+    """Beyond the four reference-generated fixtures: random triclinic cells (some smaller than the cutoff: two images per
+    axis), mixed periodic flags, several graphs per call, atoms outside the cell -- the public `radius_graph_pbc` against
+    the oracle restatement (itself pinned bit for bit by the fixtures): identical edges, offsets and order."""
+    from xequinet_amd.data import radius_graph_pbc
+
+    rng = np.random.default_rng(11)
+    cases = [((17, 9), 6.5, [True, True, True]), ((12,), 3.9, [True, True, True]), ((20, 5, 14), 7.0, [True, True, False]),
+             ((25,), 8.0, [True, False, False]), ((16, 16), 5.5, [False, True, True]), ((30,), 11.0, [False, False, False])]
+    for trial, (n_atoms, L, pbc) in enumerate(cases):
+        G = len(n_atoms)
+        cell = np.stack([np.eye(3) * L * rng.uniform(0.85, 1.25) + rng.normal(0, 0.1 * L, size=(3, 3)) for _ in range(G)]).astype(npdt)
+        pos = np.concatenate([rng.uniform(-0.3, 1.4, size=(n, 3)) @ c for n, c in zip(n_atoms, cell)]).astype(npdt)
+        want_ei, want_co = orc.radius_graph_pbc_oracle(pos, np.array(n_atoms), pbc, cell, 5.0)
+        if not any(pbc):
+            continue   # the reference routes fully open graphs to radius_graph (data/transform.py:40-64), not here
+        ei, co = radius_graph_pbc(_t(pos), _t(np.array(n_atoms)), torch.tensor([pbc] * G, device=DEV), _t(cell), 5.0)
+        assert ei.dtype == torch.int64 and co.dtype == dtype, trial
+        np.testing.assert_array_equal(ei.cpu().numpy(), want_ei, err_msg=f"trial {trial}")
+        np.testing.assert_array_equal(co.cpu().numpy(), want_co, err_msg=f"trial {trial}")
+        assert want_ei.shape[1] > 0, trial
+
+
 def test_single_radius_graph_golden():
     from xequinet_amd.data import single_radius_graph
 
