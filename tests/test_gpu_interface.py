@@ -205,6 +205,32 @@ def test_ase_calculator_molecule_and_periodic_box(replay):
     np.testing.assert_allclose(calc.results["stress"], voigt, rtol=0, atol=1e-9 * max(1.0, np.abs(voigt).max()))
 
 
+def test_ase_calculator_from_checkpoint_file(tmp_path):
+    """The reference's construction path (ase_calculator.py:46-73): `ckpt_file` holding `config` (model name, kwargs,
+    default units) and `model` (state dict, here with e3nn's weight-less bookkeeping entries a real checkpoint carries)."""
+    from xequinet_amd.interface import XequiCalculator
+    from xequinet_amd.interface.ase_calculator import _HAVE_ASE
+
+    if _HAVE_ASE:
+        pytest.skip("duck-typed Atoms stand-in is for images without ASE")
+    kw = dict(node_dim=32, node_irreps="32x0e+16x1o+8x2e", num_basis=8, cutoff=4.0, action_blocks=2, hidden_dim=16)
+    model, oracle = P._build(torch.float32, **kw)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sd["mods.message_0.rsh_conv.weight"] = torch.empty(0)                       # e3nn-only entries are dropped on load
+    sd["mods.update_0.invariant.tp.output_mask"] = torch.ones(56)
+    path = tmp_path / "model.pt"
+    torch.save({"config": {"model_name": "xpainn", "model_kwargs": kw, "default_units": {"energy": "kcal/mol"}}, "model": sd}, path)
+    calc = XequiCalculator(ckpt_file=str(path), device="cuda")
+    pos, z, ptr = orc.synth_aspirin()
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 4.0)
+    want = oracle(_oracle_in(pos, z, ptr, ei), compute_forces=True)
+    calc.calculate(_Atoms(pos, z), ["energy", "forces"])
+    kcal = 1.0 / FACTOR[("eV", "kcal/mol")]                                      # model units (kcal/mol) -> eV
+    np.testing.assert_allclose(calc.results["energy"], want["energy"].item() * kcal, rtol=1e-5, atol=1e-4 * kcal)
+    np.testing.assert_allclose(calc.results["forces"], want["forces"].numpy() * kcal, rtol=0, atol=1e-4 * kcal)
+    assert calc.model.cutoff_radius == 4.0 and next(calc.model.parameters()).is_cuda
+
+
 def test_replay_with_timed_gemm_selection_meets_the_fp32_parity_bar():
     """GraphedModel(tune_gemms=True), the MD default: library GEMM kernels are timed per shape in the warm-up runs and
     the captured graph uses the picks.  Which fp32 kernel wins varies from run to run, so the check is the parity bar
