@@ -267,8 +267,9 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
  *   (about 128 edges per stream: n_ranges = ceil(E / 256)).
  *   forward walks the edges sorted by center (c_rowptr[N+1]; c_perm[E] = edge id per slot of that order, NULL when
  *   edge_index is already center-sorted); the reverse pass walks them sorted by neighbor (n_rowptr, n_perm) and writes
- *   per-unit partials of dL/dd and dL/dY_lm into parts[xeq_message_wm_parts_floats(E, mul)];
- *   xeq_message_wm_edge_grad sums them in fixed order into grad_vec[E,3].  center / nbr = edge_index rows 0 / 1.
+ *   per-unit partials of dL/dd and dL/dY_lm into parts[xeq_message_wm_parts_floats(E, mul)], indexed by the SLOT of
+ *   that order (16 consecutive rows of a tile are one 64-byte store); xeq_message_wm_edge_grad, given the same n_perm,
+ *   sums them in fixed unit order into grad_vec[E,3] at the edge's own position.  center / nbr = edge_index rows 0 / 1.
  *   Nodes without edges keep s_in / x_in (forward) and get zero gradients (reverse). */
 int xeq_message_wm_supported(int num_basis, int node_dim, const int32_t mul[3]);   /* 1 / 0, not a status */
 int xeq_edge_basis_wm_width(int num_basis);
@@ -287,8 +288,8 @@ int xeq_message_bwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
                        const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,
                        void* grad_xhat, void* parts, int xhat_layout, void* stream);
 int64_t xeq_message_wm_parts_floats(int64_t n_edges, const int32_t mul[3]);   /* a size, not a status */
-int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul[3], const void* parts, void* grad_vec,
-                             void* stream);
+int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul[3], const void* parts, const int32_t* n_perm,
+                             void* grad_vec, void* stream);
 
 /* ------------------------------------------------- node-side fused elementwise stages
  * Internal "BT" layout of equivariant intermediates (xhat_layout = 1 above): block-major over

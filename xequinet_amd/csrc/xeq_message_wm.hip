@@ -578,7 +578,7 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
                                             const float* __restrict__ drec, const float* __restrict__ h,
                                             const float* __restrict__ xhat_, const float* __restrict__ grad_s,
                                             const float* __restrict__ grad_x, const float* wl, float* __restrict__ grad_h,
-                                            float* __restrict__ grad_xhat_, const WmParts parts, int* tbl) {
+                                            float* __restrict__ grad_xhat_, const WmParts parts, int* tbl, float* ysc) {
   constexpr bool HAS_S = NM == 1;
   constexpr int YOFF = NM == 3 ? 0 : 3;
   constexpr int GR = XEQ_WM_BWD_GR(NM);   // rows whose gathers are in flight together
@@ -611,7 +611,13 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
   float a_hs = 0.f, a_he = 0.f, a_hm = 0.f, a_x[NM];
 #pragma unroll
   for (int m = 0; m < NM; ++m) o_x[m] = a_x[m] = 0.f;
-  const bool writer = j == 31;   // lanes 31 / 63 hold the half's DPP totals
+  // wm_half_total leaves a half's total in its lanes 16..31: lane 16 + v keeps the total of row v, so the 16 rows of a
+  // tile go out as ONE 64-byte store per quantity, indexed by the row's SLOT of the walk order (consecutive rows are
+  // consecutive slots; xeq_message_wm_edge_grad maps slots back to edges).  Single-lane stores per row at the edge id
+  // were 4-byte partial-line writes: 236 MB of WRITE_SIZE per launch against 101 MB of results.
+  const int keep_v = j - 16;                                  // the row this lane keeps (lanes 16..31 of each half)
+  const bool writer = j == 31;                                // one lane per half parks the dL/dY totals in LDS
+  const int half_beg = hh ? e1 : e0, half_end = hh ? e2 : e1;
 
   using Row = WmRow<KS, 2, (NM > 1)>;
   WmIdx ix = wm_idx(a, lane, 0, e0, e1, e2);
@@ -628,6 +634,7 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     const int* trow = tbl + (t & 1) * (T_ROWS * 32) + 16 * hh;
     int* tnext = tbl + ((t + 1) & 1) * (T_ROWS * 32);
     const uint32_t mfirst = mk.first >> (4 * hh), mlast = mk.last >> (4 * hh), mvalid = mk.valid >> (4 * hh);
+    (void)mvalid;
     // ---- the rows of the owners whose segments START in this tile are needed by the first row of the segment: the
     //      first two starts of each half are fetched here, under the MFMAs (a third start in one tile -- segments
     //      shorter than 8 edges -- takes the blocking path below)
@@ -756,6 +763,8 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     // the first rows of pass E fly under its MFMAs
     if (GR < 16) load_group(0);
     XEQ_WM_SB();
+    const int my_slot = half_beg + 16 * t + keep_v;
+    const bool keeper = keep_v >= 0 && my_slot < half_end;      // lanes 16..31 of the half whose row exists
     {  // ---- pass E
       const f32x16 de = wm_filter<KS>(R, We), qe = wm_filter<KS>(Rd, We);
       if constexpr (!HAS_S) {   // last MFMAs of the tile are issued: the next tile's records take over their registers
@@ -773,11 +782,9 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
 #pragma unroll
         for (int c0 = r0; c0 < r0 + GR; c0 += 4) {
           float Yc[NM][4];
-          int eid[4];
           if constexpr (NM > 1) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) wm_tread<4>(trow, T_Y + YOFF + m, c0, Yc[m]);
-            wm_tread<4>(trow, T_EID, c0, eid);
           }
           const uint32_t any_first = (mk.first >> wm_bit(c0)) & 0xFFu, any_last = (mk.last >> wm_bit(c0)) & 0xFFu;
 #pragma unroll
@@ -797,13 +804,10 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
             pd[v] += o_he * dge * qe[v];
             if constexpr (NM > 1) {   // dL/dY_lm of the row's edge: sum over the unit's 32 channels
               const float wy = o_he * pe;
-              float ry[NM];
 #pragma unroll
-              for (int m = 0; m < NM; ++m) ry[m] = wm_half_total(wy * gx[gv][m]);
-              if (writer && ((mvalid >> wm_bit(v)) & 1u)) {
-                float* dst = NM == 3 ? parts.y1 : parts.y2;
-#pragma unroll
-                for (int m = 0; m < NM; ++m) dst[((int64_t)un.cb * NM + m) * E + eid[r]] = ry[m];
+              for (int m = 0; m < NM; ++m) {
+                const float ry = wm_half_total(wy * gx[gv][m]);
+                if (writer) ysc[m * 32 + 16 * hh + v] = ry;     // parked in the wave's LDS line, stored after the pass
               }
             }
             if (any_last) {
@@ -811,6 +815,13 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
             }
           }
         }
+      }
+    }
+    if constexpr (NM > 1) {
+      if (keeper) {
+        float* dst = NM == 3 ? parts.y1 : parts.y2;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) dst[((int64_t)un.cb * NM + m) * E + my_slot] = ysc[m * 32 + 16 * hh + keep_v];
       }
     }
     WM_STAMP(4);     // rows of pass E
@@ -841,16 +852,13 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
     }
     WM_STAMP(6);     // rows of pass M
     // ---- dL/dd of every row's edge: sum over the unit's 32 channels
+    float kp = 0.f;
 #pragma unroll
-    for (int v0 = 0; v0 < 16; v0 += 4) {
-      int eid[4];
-      wm_tread<4>(trow, T_EID, v0, eid);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float tot = wm_half_total(pd[v0 + r]);
-        if (writer && ((mvalid >> wm_bit(v0 + r)) & 1u)) parts.pd[(int64_t)unit * E + eid[r]] = tot;
-      }
+    for (int v = 0; v < 16; ++v) {
+      const float tot = wm_half_total(pd[v]);
+      kp = keep_v == v ? tot : kp;
     }
+    if (keeper) parts.pd[(int64_t)unit * E + my_slot] = kp;
     mk = wm_table<KS, 2, (NM > 1)>(lane, ixn, row, stride0, stride1, tnext);
     __builtin_amdgcn_wave_barrier();
     WM_STAMP(7);     // channel sums, partial writes, next tile's table
@@ -870,6 +878,7 @@ __global__ void __launch_bounds__(64 * WM_WAVES) __attribute__((amdgpu_waves_per
                                                                   float* __restrict__ grad_xhat, WmParts parts) {
   __shared__ int tbl_all[WM_WAVES][2 * T_ROWS * 32];
   __shared__ float wl[3 * KS * 64];
+  __shared__ float ysc_all[WM_WAVES][5 * 32];            // per wave: dL/dY_lm totals of a tile's rows (l > 0 units)
   int range, unit;
   wm_decode(a, a.nu[0] + a.nu[1] + a.nu[2], range, unit);
   const WmUnit un = wm_unit(a, unit);
@@ -877,13 +886,14 @@ __global__ void __launch_bounds__(64 * WM_WAVES) __attribute__((amdgpu_waves_per
   __syncthreads();
   if (range >= a.n_ranges) return;
   int* tbl = tbl_all[threadIdx.x >> 6];
+  float* ysc = ysc_all[threadIdx.x >> 6];
 #ifdef XEQ_WM_ONLY_L
   if (un.l == XEQ_WM_ONLY_L)
-    wm_bwd_body<2 * XEQ_WM_ONLY_L + 1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+    wm_bwd_body<2 * XEQ_WM_ONLY_L + 1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, ysc);
 #else
-  if (un.l == 0) wm_bwd_body<1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
-  else if (un.l == 1) wm_bwd_body<3, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
-  else wm_bwd_body<5, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+  if (un.l == 0) wm_bwd_body<1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, ysc);
+  else if (un.l == 1) wm_bwd_body<3, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, ysc);
+  else wm_bwd_body<5, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, ysc);
 #endif
 }
 
@@ -906,19 +916,22 @@ __global__ void k_wm_stream_ptr(const int32_t* __restrict__ rowptr, int64_t N, i
   sp[k] = (int32_t)lo;
 }
 
-// dL/dvec from the per-unit partials, summed in unit order (deterministic), chain rule of A1-A3
+// dL/dvec from the per-unit partials (indexed by slot of the reverse walk order), summed in unit order (deterministic),
+// chain rule of A1-A3
 __global__ void k_wm_edge_grad(const float* __restrict__ vec, int64_t E, int nu, int nu1, int nu2, const float* __restrict__ pd,
-                               const float* __restrict__ y1, const float* __restrict__ y2, float* __restrict__ grad_vec) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+                               const float* __restrict__ y1, const float* __restrict__ y2, const int32_t* __restrict__ perm,
+                               float* __restrict__ grad_vec) {
+  const int64_t sl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // slot of the reverse walk order
+  if (sl >= E) return;
+  const int64_t e = perm ? perm[sl] : sl;
   float gd = 0.f, q1[3] = {0.f, 0.f, 0.f}, q2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int u = 0; u < nu; ++u) gd += pd[(int64_t)u * E + e];
+  for (int u = 0; u < nu; ++u) gd += pd[(int64_t)u * E + sl];
   for (int u = 0; u < nu1; ++u)
 #pragma unroll
-    for (int m = 0; m < 3; ++m) q1[m] += y1[((int64_t)u * 3 + m) * E + e];
+    for (int m = 0; m < 3; ++m) q1[m] += y1[((int64_t)u * 3 + m) * E + sl];
   for (int u = 0; u < nu2; ++u)
 #pragma unroll
-    for (int m = 0; m < 5; ++m) q2[m] += y2[((int64_t)u * 5 + m) * E + e];
+    for (int m = 0; m < 5; ++m) q2[m] += y2[((int64_t)u * 5 + m) * E + sl];
   const EdgeGeom<float> g = edge_geom<float>(vec[3 * e], vec[3 * e + 1], vec[3 * e + 2]);
   float out[3];
   edge_grad<float>(g, gd, q1, q2, out);
@@ -1080,8 +1093,8 @@ int64_t xeq_message_wm_parts_floats(int64_t n_edges, const int32_t mul[3]) {
   return n_edges * (int64_t)(mul[0] / 32 + mul[1] / 32 + mul[2] / 32 + 3 * (mul[1] / 32) + 5 * (mul[2] / 32));
 }
 
-int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul[3], const void* parts, void* grad_vec,
-                             void* stream) {
+int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul[3], const void* parts, const int32_t* n_perm,
+                             void* grad_vec, void* stream) {
   XEQ_CHECK_ARG(n_edges >= 0 && mul[0] % 32 == 0 && mul[1] % 32 == 0 && mul[2] % 32 == 0, "xeq_message_wm_edge_grad: bad sizes");
   if (n_edges == 0) return XEQ_OK;
   const int nu1 = mul[1] / 32, nu2 = mul[2] / 32, nunits = mul[0] / 32 + nu1 + nu2;
@@ -1089,7 +1102,7 @@ int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul
   const float* y1 = pd + (int64_t)nunits * n_edges;
   const float* y2 = y1 + (int64_t)nu1 * 3 * n_edges;
   hipLaunchKernelGGL(k_wm_edge_grad, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)vec, n_edges, nunits, nu1, nu2, pd, y1, y2, (float*)grad_vec);
+                     (const float*)vec, n_edges, nunits, nu1, nu2, pd, y1, y2, n_perm, (float*)grad_vec);
   XEQ_CHECK_LAUNCH("xeq_message_wm_edge_grad");
   return XEQ_OK;
 }

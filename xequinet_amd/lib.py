@@ -72,7 +72,7 @@ _PROTOS = {
     "xeq_message_bwd_wm": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                            _I3, _P, _P, _P, c_int, _P],
     "xeq_message_wm_parts_floats": [c_int64, _I3],
-    "xeq_message_wm_edge_grad": [_P, c_int64, _I3, _P, _P, _P],
+    "xeq_message_wm_edge_grad": [_P, c_int64, _I3, _P, _P, _P, _P],
     "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
     "xeq_norm_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
     "xeq_uv_reduce_fwd": [c_int, _P, c_int64, _I3, c_double, _P, c_int64, c_int, _P, _P],

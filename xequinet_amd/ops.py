@@ -609,7 +609,7 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x):
                             ptr(plan["rowptr"]), ptr(plan["perm"]), ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(basis), ptr(dbasis),
                             ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul),
                             ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream())
-        call("xeq_message_wm_edge_grad", ptr(vec), graph.n_edges, mul3(mul), ptr(parts), ptr(g_vec), stream())
+        call("xeq_message_wm_edge_grad", ptr(vec), graph.n_edges, mul3(mul), ptr(parts), ptr(plan["perm"]), ptr(g_vec), stream())
     elif impl == "sb":
         KERNEL_TIMER.launch("xeq_message_bwd_sb", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),
                             ptr(graph.n_perm), ptr(graph.edge_index[0]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s),
