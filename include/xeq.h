@@ -204,7 +204,9 @@ int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n,
 
 /* ------------------------------------------------------------ fused message */
 
-/* XPainnMessage.forward lines nn/xpainn.py:140-159 in one pass over
+/* GENERIC form (64-bit offsets, f32 / f64, up to 256 channels per kind): the fallback for sizes and layouts the
+ * _wm and _sb forms below do not take.
+ * XPainnMessage.forward lines nn/xpainn.py:140-159 in one pass over
  * destination-sorted edges (K5-K7, K11-K16 of SURVEY 2.2):
  *   filter = (rbf(d) W^T + b) * fcut(d)                       :140
  *   g = h[nbr] * filter = [gate_state C | gate_edge C | msg_s F]  :142-148
@@ -241,6 +243,8 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
  * basis[E, W] / dbasis[E, W], W = xeq_edge_basis_width(B); dbasis may be NULL when only the forward
  * pass is needed.  Same semantics as xeq_message_fwd / xeq_message_bwd otherwise. */
 int xeq_edge_basis_width(int num_basis);
+/* 1 / 0: at most 256 channels per kind, num_basis <= 32, 32-bit element offsets (n_nodes max(H, D) < 2^31) */
+int xeq_message_sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]);
 int xeq_edge_basis(int dtype, const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis,
                    double cutoff, const void* p0, const void* p1, void* basis, void* dbasis, void* stream);
 int xeq_message_fwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* perm,
@@ -272,6 +276,9 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
  *   sums them in fixed unit order into grad_vec[E,3] at the edge's own position.  center / nbr = edge_index rows 0 / 1.
  *   Nodes without edges keep s_in / x_in (forward) and get zero gradients (reverse). */
 int xeq_message_wm_supported(int num_basis, int node_dim, const int32_t mul[3]);   /* 1 / 0, not a status */
+/* 1 when the configuration is supported AND n_nodes / n_edges fit the kernels' 32-bit byte offsets
+ * (n_nodes (F + 2C) 4 < 2^32, n_edges 288 < 2^32); a caller picks the _sb or the generic form otherwise */
+int xeq_message_wm_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]);
 int xeq_edge_basis_wm_width(int num_basis);
 int xeq_edge_basis_wm(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis, double cutoff,
                       const void* p0, const void* p1, void* basis, void* dbasis, void* stream);

@@ -2,14 +2,15 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd import ops
 from xequinet_amd.data import NeighborTransform, XequiBatch
 wl = sys.argv[1] if len(sys.argv) > 1 else "qm9"
 dev = "cuda"
 if wl == "qm9":
-    pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234); cell=None
+    pos, z, ptr = syn.synth_qm9_batch(1024, seed=1234); cell=None
 else:
-    pos, z, ptr, cell = orc.synth_water_box(8, seed=5)
+    pos, z, ptr, cell = syn.synth_water_box(8, seed=5)
 b = XequiBatch(torch.tensor(pos, dtype=torch.float32), torch.tensor(z), torch.tensor(ptr),
                pbc=None if cell is None else torch.tensor([[True]*3]), cell=None if cell is None else torch.tensor(cell, dtype=torch.float32)).to(dev)
 b = NeighborTransform(5.0)(b)

@@ -2,10 +2,11 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd import ops
 from xequinet_amd.data import NeighborTransform, XequiBatch
 dev = "cuda"
-pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234)
+pos, z, ptr = syn.synth_qm9_batch(1024, seed=1234)
 b = XequiBatch(torch.tensor(pos, dtype=torch.float32), torch.tensor(z), torch.tensor(ptr)).to(dev)
 b = NeighborTransform(5.0)(b)
 g = getattr(b, "_xeq_edge_graph")

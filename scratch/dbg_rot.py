@@ -1,10 +1,11 @@
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from tests.test_gpu_parity import _build, _t
 from xequinet_amd.data import NeighborTransform, XequiBatch
 model, _ = _build(torch.float32)
-pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234)
+pos, z, ptr = syn.synth_qm9_batch(1024, seed=1234)
 def run(p, zz, pp):
     b = NeighborTransform(5.0)(XequiBatch(_t(p, torch.float32), _t(zz), _t(pp)))
     with torch.enable_grad():

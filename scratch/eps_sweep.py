@@ -2,6 +2,7 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd import ops
 from xequinet_amd.data import NeighborTransform, XequiBatch
 dev = "cuda"
@@ -34,12 +35,12 @@ def case(name, pos, z, ptr, cell=None):
     print(f"{name} N={N} E={E} | " + " | ".join(out), flush=True)
 os.environ["XEQ_MESSAGE_IMPL"] = "wm"
 if os.environ.get("SWEEP_ONLY_BIG"):
-    pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234); case("qm9-1024", pos, z, ptr)
-    pos, z, ptr = orc.synth_qm9_batch(1024, seed=1235); case("qm9-1024b", pos, z, ptr)
+    pos, z, ptr = syn.synth_qm9_batch(1024, seed=1234); case("qm9-1024", pos, z, ptr)
+    pos, z, ptr = syn.synth_qm9_batch(1024, seed=1235); case("qm9-1024b", pos, z, ptr)
     sys.exit(0)
-pos, z, ptr = orc.synth_aspirin(); case("aspirin", pos, z, ptr)
-pos, z, ptr, cell = orc.synth_water_box(4, seed=5); case("water-64", pos, z, ptr, cell)
-pos, z, ptr = orc.synth_qm9_batch(64, seed=3); case("qm9-64", pos, z, ptr)
-pos, z, ptr, cell = orc.synth_water_box(8, seed=5); case("water-512", pos, z, ptr, cell)
-pos, z, ptr = orc.synth_qm9_batch(256, seed=3); case("qm9-256", pos, z, ptr)
-pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234); case("qm9-1024", pos, z, ptr)
+pos, z, ptr = syn.synth_aspirin(); case("aspirin", pos, z, ptr)
+pos, z, ptr, cell = syn.synth_water_box(4, seed=5); case("water-64", pos, z, ptr, cell)
+pos, z, ptr = syn.synth_qm9_batch(64, seed=3); case("qm9-64", pos, z, ptr)
+pos, z, ptr, cell = syn.synth_water_box(8, seed=5); case("water-512", pos, z, ptr, cell)
+pos, z, ptr = syn.synth_qm9_batch(256, seed=3); case("qm9-256", pos, z, ptr)
+pos, z, ptr = syn.synth_qm9_batch(1024, seed=1234); case("qm9-1024", pos, z, ptr)

@@ -1,13 +1,14 @@
 import os, sys, ctypes, subprocess, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd.data import NeighborTransform, XequiBatch
 so = "/tmp/gather_probe.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(ROOT, "scratch/gather_probe.hip"), "-o", so])
 hip = ctypes.CDLL("libamdhip64.so"); mod = ctypes.c_void_p(); 
 # simpler: use torch's cpp? fall back to hipModuleLoad on the code object inside the .so is awkward -> launch through hipLaunchKernel via symbol address
 lib = ctypes.CDLL(so)
-pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234)
+pos, z, ptr = syn.synth_qm9_batch(1024, seed=1234)
 b = NeighborTransform(5.0)(XequiBatch(torch.tensor(pos, dtype=torch.float32), torch.tensor(z), torch.tensor(ptr)).to("cuda"))
 g = getattr(b, "_xeq_edge_graph"); N, E = g.n_nodes, g.n_edges
 W = 1024

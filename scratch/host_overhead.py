@@ -2,13 +2,14 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd.data import NeighborTransform, XequiBatch
 from xequinet_amd.nn import resolve_model
 from xequinet_amd.tuning import enable_gemm_autotune
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = resolve_model("xpainn").eval().requires_grad_(False).to(dev)
-pos, z, ptr = orc.synth_qm9_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 1024, seed=1234)
+pos, z, ptr = syn.synth_qm9_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 1024, seed=1234)
 pos_d, z_d, ptr_d = torch.tensor(pos, dtype=torch.float32, device=dev), torch.tensor(z, device=dev), torch.tensor(ptr, device=dev)
 tr = NeighborTransform(5.0)
 if os.path.exists("gpurun_out/gemm_r01_h.csv"):

@@ -3,6 +3,7 @@ autograd forces), LAMMPS-style model (neighbour list given) eager vs HIP-graph r
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd.data import single_radius_graph
 from xequinet_amd.cluster import radius_graph
 from xequinet_amd.interface import XPaiNNGMX, XPaiNNLMP, XequiCalculator
@@ -41,6 +42,6 @@ def run(name, pos, z, cell=None):
             return torch.autograd.grad(e.sum(), x)[0]
         out[tag] = timeit(gstep)
     print(name, "E =", ei.shape[1], "|", ", ".join(f"{k} {v:.3f} ms" for k, v in out.items()), flush=True)
-pos, z, ptr = orc.synth_aspirin(); run("aspirin (21 atoms)", pos, z)
-pos, z, ptr, cell = orc.synth_water_box(4, seed=5); run("water-64 (192 atoms, PBC)", pos, z, cell)
-pos, z, ptr, cell = orc.synth_water_box(8, seed=5); run("water-512 (1536 atoms, PBC)", pos, z, cell)
+pos, z, ptr = syn.synth_aspirin(); run("aspirin (21 atoms)", pos, z)
+pos, z, ptr, cell = syn.synth_water_box(4, seed=5); run("water-64 (192 atoms, PBC)", pos, z, cell)
+pos, z, ptr, cell = syn.synth_water_box(8, seed=5); run("water-512 (1536 atoms, PBC)", pos, z, cell)

@@ -2,6 +2,7 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd.data import NeighborTransform, XequiBatch
 from xequinet_amd.nn import resolve_model
 from xequinet_amd.runtime import GraphedModel
@@ -25,9 +26,9 @@ def bench(name, pos, z, ptr, **kw):
         for _ in range(50): fn()
         torch.cuda.synchronize(); res[nm] = (time.perf_counter() - t0) / 50 * 1e3
     print(f"{name}: eager {res['eager']:.3f} ms, HIP-graph replay {res['graph']:.3f} ms per evaluation (neighbour list included)")
-pos, z, ptr = orc.synth_aspirin()
+pos, z, ptr = syn.synth_aspirin()
 bench("aspirin (21 atoms)", pos, z, ptr)
-pos, z, ptr = orc.synth_qm9_batch(16, seed=3)
+pos, z, ptr = syn.synth_qm9_batch(16, seed=3)
 bench("16 QM9-shape molecules", pos, z, ptr)
-pos, z, ptr, cell = orc.synth_water_box(4, seed=5)
+pos, z, ptr, cell = syn.synth_water_box(4, seed=5)
 bench("water-64 box (192 atoms, PBC)", pos, z, ptr, pbc=torch.tensor([[True, True, True]], device=dev), cell=torch.tensor(cell, dtype=torch.float32, device=dev))

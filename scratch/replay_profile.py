@@ -2,6 +2,7 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd.data import single_radius_graph
 from xequinet_amd.interface import XPaiNNLMP
 from xequinet_amd.utils import set_default_units
@@ -13,7 +14,7 @@ if len(sys.argv) > 2:   # file of library-GEMM picks: written by a first (un-pro
     enable_gemm_autotune(results_file=sys.argv[2])
 torch.manual_seed(0)
 m = XPaiNNLMP(unit_style="metal", replay=True).eval().requires_grad_(False).to(dev)
-pos, z, ptr, cell = orc.synth_water_box(n, seed=5)
+pos, z, ptr, cell = syn.synth_water_box(n, seed=5)
 p = torch.tensor(pos, dtype=torch.float32, device=dev); zz = torch.tensor(z, device=dev)
 c = torch.tensor(cell[0], dtype=torch.float32, device=dev); pbc = torch.tensor([True, True, True], device=dev)
 ei, co = single_radius_graph(p, pbc, c, 5.0)

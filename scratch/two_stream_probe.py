@@ -2,13 +2,14 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd.data import NeighborTransform, XequiBatch
 from xequinet_amd.nn import resolve_model
 from xequinet_amd.runtime import GraphedModel
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = resolve_model("xpainn").eval().requires_grad_(False).to(dev)
-pos, z, ptr = orc.synth_qm9_batch(1024, seed=1234)
+pos, z, ptr = syn.synth_qm9_batch(1024, seed=1234)
 tr = NeighborTransform(5.0)
 def mk(g0, g1):
     a, b = int(ptr[g0]), int(ptr[g1])

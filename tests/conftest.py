@@ -17,3 +17,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the achieved parity maxima of this session (tests/parity_record.py) next to the other GPU-box outputs."""
+    import json
+
+    from tests import parity_record
+
+    if not parity_record.RECORDS:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_r02.json"), "w") as f:
+        json.dump({"exitstatus": int(exitstatus), "records": parity_record.RECORDS}, f, indent=1)

@@ -29,6 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.dont_write_bytecode = True
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from oracle import xpainn_oracle as orc  # noqa: E402  (synthetic input generators only)
+from xequinet_amd.data import synthetic as syn
 
 
 def _install_shims():
@@ -110,11 +111,11 @@ def main():
     # ---- 3. radius_graph_pbc (data/radius_graph.py:35-192) -----------------------
     cases = {}
     # (a) 192-atom water-density cubic box
-    pos, z, ptr, cell = orc.synth_water_box(4, seed=5)
+    pos, z, ptr, cell = syn.synth_water_box(4, seed=5)
     cases["water192"] = (pos, np.array([192]), cell, [True, True, True], 5.0)
     # (b) two graphs, different cubic cells, un-wrapped positions (exercises :186-190)
-    p1, _, _, c1 = orc.synth_water_box(3, seed=6)
-    p2, _, _, c2 = orc.synth_water_box(2, seed=7)
+    p1, _, _, c1 = syn.synth_water_box(3, seed=6)
+    p2, _, _, c2 = syn.synth_water_box(2, seed=7)
     p1 = p1 + np.array([13.0, -7.5, 0.3])  # push outside the cell
     cases["two_graphs_unwrapped"] = (np.concatenate([p1, p2]), np.array([len(p1), len(p2)]),
                                      np.concatenate([c1, c2]), [True, True, True], 4.0)
@@ -136,7 +137,7 @@ def main():
                  cell=cell32.numpy(), pbc=np.array(pbc), cutoff=rc, edge_index=ei.numpy(), cell_offsets=co.numpy())
         print(name, "edges", ei.shape[1], "per atom %.2f" % (ei.shape[1] / len(pos)))
     # single_radius_graph (TorchScript variant, :195-275) on the cubic box
-    pos, z, ptr, cell = orc.synth_water_box(4, seed=5)
+    pos, z, ptr, cell = syn.synth_water_box(4, seed=5)
     ei, co = rg.single_radius_graph(torch.tensor(pos, dtype=torch.float32), torch.tensor([True, True, True]),
                                     torch.tensor(cell[0], dtype=torch.float32), 5.0)
     np.savez_compressed(os.path.join(HERE, "single_radius_graph_water192.npz"), edge_index=ei.numpy(), cell_offsets=co.numpy())
@@ -145,7 +146,7 @@ def main():
     for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
         torch.set_default_dtype(dt)
         # (a) aspirin-like, non-PBC, canonical all-pairs-within-5A graph
-        pos, z, ptr = orc.synth_aspirin()
+        pos, z, ptr = syn.synth_aspirin()
         ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
         data = {keys.POSITIONS: torch.tensor(pos, dtype=dt), keys.EDGE_INDEX: torch.tensor(ei)}
         out = basic.compute_edge_data(data, compute_forces=False)
@@ -175,7 +176,7 @@ def main():
     emb = painn.Embedding(node_dim=F_, num_basis=8, embed_basis="gfn2-xtb", aux_basis="aux56", cutoff=4.0)
     blocks = [(painn.PainnMessage(F_, 8), painn.PainnUpdate(F_)) for _ in range(2)]
     w_out = torch.randn(F_)
-    pos, z, ptr = orc.synth_qm9_batch(3, seed=99)
+    pos, z, ptr = syn.synth_qm9_batch(3, seed=99)
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 4.0)
     batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
     data = {

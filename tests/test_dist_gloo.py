@@ -7,11 +7,12 @@ import torch
 import torch.multiprocessing as mp
 
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 from xequinet_amd import dist as xdist
 
 
 def test_shard_by_edges_partitions_and_balances():
-    pos, z, ptr = orc.synth_qm9_batch(200, seed=3)
+    pos, z, ptr = syn.synth_qm9_batch(200, seed=3)
     n = np.diff(ptr)
     cost = n * (n - 1)
     for world in (1, 2, 3, 8, 16):
@@ -32,7 +33,7 @@ def _worker(rank, world, port, out):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r, lr, w = xdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
-    pos, z, ptr = orc.synth_qm9_batch(40, seed=1)
+    pos, z, ptr = syn.synth_qm9_batch(40, seed=1)
     g0, g1 = xdist.shard_by_edges(ptr, world)[rank]
     p, zz, pp = xdist.take_shard(pos, z, ptr, g0, g1)
     n = np.diff(pp)
@@ -50,8 +51,79 @@ def test_gloo_world2_timing_reduction():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    pos, z, ptr = orc.synth_qm9_batch(40, seed=1)
+    pos, z, ptr = syn.synth_qm9_batch(40, seed=1)
     n = np.diff(ptr)
     assert abs(out[0][0] - 0.2) < 1e-12 and abs(out[1][0] - 0.2) < 1e-12        # MAX over ranks
     assert out[0][1] == out[1][1] == float((n * (n - 1)).sum())                  # SUM over ranks: nothing lost
     assert out[0][2] + out[1][2] == len(pos)
+
+
+def test_plan_chunks_covers_and_respects_cap():
+    pos, z, ptr = syn.synth_qm9_batch(300, seed=4)
+    n = np.diff(ptr)
+    bound = n * (n - 1)
+    for cap in (50, 500, 5_000, 10**9):
+        chunks = xdist.plan_chunks(ptr, cap)
+        assert chunks[0][0] == 0 and chunks[-1][1] == 300 and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+        for g0, g1 in chunks:
+            assert g1 > g0 and (bound[g0:g1].sum() <= cap or g1 - g0 == 1)    # a single molecule may exceed the cap
+    assert xdist.plan_chunks(ptr, 10**9) == [(0, 300)]
+    sub = xdist.plan_chunks(ptr, 2_000, g0=40, g1=90)
+    assert sub[0][0] == 40 and sub[-1][1] == 90
+    assert xdist.plan_chunks(np.array([0]), 100) == [(0, 0)]                   # empty shard: one empty chunk
+
+
+def _tiny_oracle():
+    from xequinet_amd.nn import resolve_model
+
+    kw = dict(node_dim=16, node_irreps="16x0e+8x1o", num_basis=6, cutoff=4.0, action_blocks=1, hidden_dim=8)
+    torch.manual_seed(0)
+    model = resolve_model("xpainn", **kw)
+    sd = {k: v.detach().double().clone() for k, v in model.state_dict().items()}
+    return orc.XPaiNNOracle(sd, **kw)
+
+
+def _eval_oracle(oracle, pos, z, ptr):
+    if len(ptr) < 2:
+        return {"energy": np.zeros(0), "forces": np.zeros((0, 3))}
+    ei = orc.radius_graph_canonical(pos, ptr, 4.0)
+    batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    out = oracle({"pos": torch.tensor(pos), "atomic_numbers": torch.tensor(z.astype(np.int64)), "edge_index": torch.tensor(ei),
+                  "batch": torch.tensor(batch), "ptr": torch.tensor(ptr)}, compute_forces=True)
+    return {"energy": out["energy"].numpy(), "forces": out["forces"].numpy()}
+
+
+def _shard_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    xdist.init_from_env(backend="gloo")
+    torch.set_num_threads(2)
+    pos, z, ptr = syn.synth_qm9_batch(24, seed=6)
+    g0, g1 = xdist.shard_by_edges(ptr, world)[rank]
+    p, zz, pp = xdist.take_shard(pos, z, ptr, g0, g1)
+    # a shard is walked in chunks, as a rank does when its share exceeds the kernels' bound
+    parts = []
+    for c0, c1 in xdist.plan_chunks(pp, 400):
+        q, qz, qp = xdist.take_shard(p, zz, pp, c0, c1)
+        parts.append(_eval_oracle(_tiny_oracle(), q, qz, qp))
+    local = {k: np.concatenate([r[k] for r in parts]) for k in parts[0]}
+    whole = xdist.gather_shards(local, dst=0)        # the only exchange: results, after the evaluation
+    if rank == 0:
+        out["energy"], out["forces"] = whole["energy"], whole["forces"]
+    else:
+        assert whole is None
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_sharded_chunked_inference_equals_unsharded():
+    """BASELINE config 5 in small, on CPU: two ranks (gloo), each with its molecule range cut into chunks, the oracle as
+    the evaluator; gathered in rank order the energies / forces are those of the unsharded batch."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    pos, z, ptr = syn.synth_qm9_batch(24, seed=6)
+    want = _eval_oracle(_tiny_oracle(), pos, z, ptr)
+    np.testing.assert_allclose(out["energy"], want["energy"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["forces"], want["forces"], rtol=0, atol=1e-12)

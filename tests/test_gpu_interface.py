@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 
 from . import test_gpu_parity as P
 
@@ -57,7 +58,7 @@ def test_lammps_model_units_and_values(style, e_pair, f_pair, len_pair, replay):
     dtype = torch.float64
     model, oracle = _twin(XPaiNNLMP, dtype, unit_style=style, replay=replay, tune_gemms=False)
     assert type(resolve_jit_model("lmp", unit_style=style)) is XPaiNNLMP
-    pos, z, ptr = orc.synth_aspirin()
+    pos, z, ptr = syn.synth_aspirin()
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
     want = oracle(_oracle_in(pos, z, ptr, ei), compute_forces=True)
     e_fac = 1.0 if e_pair is None else (FACTOR[e_pair] if style == "real" else 1.0 / FACTOR[e_pair])
@@ -82,7 +83,7 @@ def test_lammps_model_periodic_virial_and_replay_is_bitwise():
 
     dtype = torch.float32
     f = P._load("radius_graph_pbc_water192.npz")
-    _, z, ptr, _ = orc.synth_water_box(4, seed=5)
+    _, z, ptr, _ = syn.synth_water_box(4, seed=5)
     eager, oracle = _twin(XPaiNNLMP, dtype, unit_style="real")
     fast, _ = _twin(XPaiNNLMP, dtype, unit_style="real", replay=True, tune_gemms=False)
     extra = {"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)}
@@ -115,13 +116,13 @@ def test_gromacs_model_energy_and_autograd_forces(periodic, replay):
     if periodic:
         f = P._load("single_radius_graph_water192.npz")
         a = P._load("radius_graph_pbc_water192.npz")
-        _, z, ptr, _ = orc.synth_water_box(4, seed=5)
+        _, z, ptr, _ = syn.synth_water_box(4, seed=5)
         pos, cell = a["pos"].astype(np.float64), a["cell"][0].astype(np.float64)
         ei, co = f["edge_index"], f["cell_offsets"].astype(np.float64)
         extra = {"cell": cell[None], "cell_offsets": co}
         box, pbc = P._t(cell / nm, dtype), torch.tensor([True, True, True], device=DEV)
     else:
-        pos, z, ptr = orc.synth_aspirin()
+        pos, z, ptr = syn.synth_aspirin()
         ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
         extra, box, pbc = None, None, None
     want = oracle(_oracle_in(pos, z, ptr, ei, extra), compute_forces=True)
@@ -181,7 +182,7 @@ def test_ase_calculator_molecule_and_periodic_box(replay):
     model, oracle = P._build(dtype)
     calc = XequiCalculator(model=model, dtype="float64", replay=replay, tune_gemms=False)
     # molecule: energy / energies / forces
-    pos, z, ptr = orc.synth_aspirin()
+    pos, z, ptr = syn.synth_aspirin()
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
     want = oracle(_oracle_in(pos, z, ptr, ei), compute_forces=True)
     for _ in range(2):
@@ -192,7 +193,7 @@ def test_ase_calculator_molecule_and_periodic_box(replay):
     assert "stress" not in calc.results
     # periodic water box, atoms shifted out of the cell: wrapped by the calculator; stress from the virial
     f = P._load("radius_graph_pbc_water192.npz")
-    _, zw, ptrw, _ = orc.synth_water_box(4, seed=5)
+    _, zw, ptrw, _ = syn.synth_water_box(4, seed=5)
     posw, cell = f["pos"].astype(np.float64), f["cell"][0].astype(np.float64)
     ei_w, co_w = f["edge_index"], f["cell_offsets"].astype(np.float64)
     wantw = oracle(_oracle_in(posw, zw, ptrw, ei_w, {"cell": cell[None], "cell_offsets": co_w}), compute_forces=True, compute_virial=True)
@@ -221,7 +222,7 @@ def test_ase_calculator_from_checkpoint_file(tmp_path):
     path = tmp_path / "model.pt"
     torch.save({"config": {"model_name": "xpainn", "model_kwargs": kw, "default_units": {"energy": "kcal/mol"}}, "model": sd}, path)
     calc = XequiCalculator(ckpt_file=str(path), device="cuda")
-    pos, z, ptr = orc.synth_aspirin()
+    pos, z, ptr = syn.synth_aspirin()
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 4.0)
     want = oracle(_oracle_in(pos, z, ptr, ei), compute_forces=True)
     calc.calculate(_Atoms(pos, z), ["energy", "forces"])
@@ -240,7 +241,7 @@ def test_replay_with_timed_gemm_selection_meets_the_fp32_parity_bar():
 
     dtype = torch.float32
     f = P._load("radius_graph_pbc_water192.npz")
-    _, z, ptr, _ = orc.synth_water_box(4, seed=5)
+    _, z, ptr, _ = syn.synth_water_box(4, seed=5)
     fast, oracle = _twin(XPaiNNLMP, dtype, unit_style="metal", replay=True, tune_gemms=True)
     extra = {"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)}
     try:

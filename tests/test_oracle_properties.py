@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import xpainn_oracle as orc
+from xequinet_amd.data import synthetic as syn
 
 IRREPS = "128x0e + 64x1o + 32x2e"
 
@@ -74,7 +75,7 @@ def _small_model(dtype=torch.float64, **kw):
 
 
 def _inputs(seed=3, n_mol=3):
-    pos, z, ptr = orc.synth_qm9_batch(n_mol, seed=seed)
+    pos, z, ptr = syn.synth_qm9_batch(n_mol, seed=seed)
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
     batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
     return pos, z, ptr, ei, batch

@@ -1,7 +1,10 @@
-// Fused XPaiNN message kernels (SURVEY 8a rows a3-a5, a10-a13, and their reverse
+// Fused XPaiNN message kernels, GENERIC form (SURVEY 8a rows a3-a5, a10-a13, and their reverse
 // pass for a16).  Reference dataflow: nn/xpainn.py:140-159.
 //
-// v1 mapping ("channel on the lane"):
+// This is the fallback for configurations neither xeq_message_wm.hip (f32, multiplicities in multiples of 32) nor
+// xeq_message_sb.hip (at most 256 channels) covers: any multiplicities, any node_dim, f32 and f64.
+//
+// Mapping ("channel on the lane"):
 //   * one 256-thread workgroup walks destination nodes (persistent grid,
 //     XCD-aware node->workgroup map so a molecule's rows stay in one L2);
 //   * thread t owns gate channel u = t (its gate_state and gate_edge filter rows
@@ -15,30 +18,7 @@
 //     CSR segment: no atomics, bitwise reproducible.
 #include "xeq_common.h"
 
-#include <stdlib.h>
-#include <string.h>
-
 namespace xeq {
-
-// xeq_message_mfma.hip
-bool mfma_path_supported(int dtype, int num_basis, int node_dim, const int32_t mul[3]);
-int message_fwd_mfma(int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* perm, const int64_t* nbr,
-                     const void* vec, const void* h, const void* xhat, const void* s_in, const void* x_in,
-                     const void* w_rbf, const void* b_rbf, const void* p0, const void* p1, int rbf_kind, int cutoff_kind,
-                     int num_basis, double cutoff, int node_dim, const int32_t mul[3], void* s_out, void* x_out,
-                     int xl, void* stream);
-int message_bwd_mfma(int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
-                     const int64_t* center, const void* vec, const void* h, const void* xhat, const void* grad_s,
-                     const void* grad_x, const void* w_rbf, const void* b_rbf, const void* p0, const void* p1,
-                     int rbf_kind, int cutoff_kind, int num_basis, double cutoff, int node_dim, const int32_t mul[3],
-                     void* grad_h, void* grad_xhat, void* grad_vec, int xl, void* stream);
-
-// XEQ_MESSAGE_IMPL=valu forces the generic channel-on-lane kernels of this file; default: MFMA kernels when supported
-static bool use_mfma(int dtype, int num_basis, int node_dim, const int32_t mul[3]) {
-  const char* env = getenv("XEQ_MESSAGE_IMPL");
-  if (env && strcmp(env, "valu") == 0) return false;
-  return mfma_path_supported(dtype, num_basis, node_dim, mul);
-}
 
 constexpr int EC = 32;    // edges staged per chunk
 constexpr int YS = 12;    // stride of the per-edge SH record: [1 | Y1(3) | Y2(5) | f | f' | pad]
@@ -367,12 +347,6 @@ int xeq_message_fwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                         mul, p1, a);
   if (rcode != XEQ_OK) return rcode;
   if (n_nodes == 0) return XEQ_OK;
-  if (use_mfma(dtype, num_basis, node_dim, mul)) {
-    message_fwd_mfma(n_nodes, n_edges, rowptr, perm, nbr, vec, h, xhat, s_in, x_in, w_rbf, b_rbf, p0, p1, rbf_kind,
-                     cutoff_kind, num_basis, cutoff, node_dim, mul, s_out, x_out, xhat_layout, stream);
-    XEQ_CHECK_LAUNCH("xeq_message_fwd (mfma)");
-    return XEQ_OK;
-  }
   a.rowptr = rowptr;
   a.perm = perm;
   a.other = nbr;
@@ -397,12 +371,6 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                         mul, p1, a);
   if (rcode != XEQ_OK) return rcode;
   if (n_nodes == 0) return XEQ_OK;
-  if (use_mfma(dtype, num_basis, node_dim, mul)) {
-    message_bwd_mfma(n_nodes, n_edges, n_rowptr, n_perm, center, vec, h, xhat, grad_s, grad_x, w_rbf, b_rbf, p0, p1,
-                     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul, grad_h, grad_xhat, grad_vec, xhat_layout, stream);
-    XEQ_CHECK_LAUNCH("xeq_message_bwd (mfma)");
-    return XEQ_OK;
-  }
   a.rowptr = n_rowptr;
   a.perm = n_perm;
   a.other = center;

@@ -411,6 +411,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
   }
 }
 
+// what the scalar-broadcast kernels cover: at most 256 channels per kind (one thread each) and 32-bit row offsets
+static bool sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
+  if (num_basis < 1 || num_basis > 32 || mul[0] < 0 || mul[1] < 0 || mul[2] < 0) return false;
+  const int64_t C = (int64_t)mul[0] + mul[1] + mul[2], D = (int64_t)mul[0] + 3 * mul[1] + 5 * mul[2], H = node_dim + 2 * C;
+  return C >= 1 && C <= 256 && node_dim >= 1 && node_dim <= 256 && n_nodes >= 0 && n_edges >= 0 &&
+         n_nodes * (H > D ? H : D) < (1ll << 31) && n_edges * (int64_t)eb_width(num_basis) < (1ll << 31);
+}
+
 static int sb_check(const char* who, int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3],
                     SbArgs& a) {
   XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (1ll << 31) && n_nodes < (1ll << 31), "%s: bad sizes", who);
@@ -462,6 +470,10 @@ using namespace xeq;
 extern "C" {
 
 int xeq_edge_basis_width(int num_basis) { return eb_width(num_basis); }
+
+int xeq_message_sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
+  return sb_fits(n_nodes, n_edges, num_basis, node_dim, mul) ? 1 : 0;
+}
 
 int xeq_edge_basis(int dtype, const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis,
                    double cutoff, const void* p0, const void* p1, void* basis, void* dbasis, void* stream) {

@@ -818,6 +818,10 @@ __device__ __forceinline__ void wm_bwd_body(const WmArgs& a, int range, int unit
       }
     }
     if constexpr (NM > 1) {
+      // lane 31 of each half wrote ysc, lanes 16..31 read it: order the LDS accesses inside the wave
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (keeper) {
         float* dst = NM == 3 ? parts.y1 : parts.y2;
 #pragma unroll
@@ -945,6 +949,12 @@ static bool wm_supported(int num_basis, int node_dim, const int32_t mul[3]) {
          mul[1] % 32 == 0 && mul[2] >= 0 && mul[2] % 32 == 0;
 }
 
+// sizes the 32-bit byte offsets of the kernels cover (rows of h: n_nodes * H * 4 bytes; records: n_edges * 288 bytes)
+static bool wm_fits(int64_t n_nodes, int64_t n_edges, int node_dim, const int32_t mul[3]) {
+  const int64_t H = node_dim + 2 * (int64_t)(mul[0] + mul[1] + mul[2]);
+  return n_nodes >= 0 && n_edges >= 0 && n_nodes * H * 4 < (1ll << 32) && n_edges * (int64_t)72 * 4 < (1ll << 32);
+}
+
 static int wm_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ranges, int num_basis, int node_dim,
                     const int32_t mul[3], WmArgs& a) {
   XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (1ll << 31) && n_nodes < (1ll << 31), "%s: bad sizes", who);
@@ -959,8 +969,7 @@ static int wm_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ran
   a.F = node_dim;
   a.H = a.F + 2 * a.C;
   a.B = num_basis;
-  XEQ_CHECK_ARG(n_nodes * (int64_t)a.H * 4 < (1ll << 32) && n_edges * (int64_t)72 * 4 < (1ll << 32),
-                "%s: tensors too large for 32-bit byte offsets (shard the batch)", who);
+  XEQ_CHECK_ARG(wm_fits(n_nodes, n_edges, node_dim, mul), "%s: tensors too large for 32-bit byte offsets (shard the batch)", who);
   for (int l = 0; l < 3; ++l) a.nu[l] = mul[l] / 32;
   a.n_nodes = n_nodes;
   a.n_edges = n_edges;
@@ -1016,6 +1025,10 @@ int xeq_edge_basis_wm(const void* vec, int64_t n_edges, int rbf_kind, int cutoff
 }
 
 int xeq_message_wm_supported(int num_basis, int node_dim, const int32_t mul[3]) { return wm_supported(num_basis, node_dim, mul) ? 1 : 0; }
+
+int xeq_message_wm_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
+  return wm_supported(num_basis, node_dim, mul) && wm_fits(n_nodes, n_edges, node_dim, mul) ? 1 : 0;
+}
 
 int xeq_message_wm_streams(const int32_t* rowptr, int64_t n_nodes, int64_t n_edges, int n_ranges, int32_t* stream_ptr,
                            void* stream) {

@@ -39,6 +39,40 @@ def shard_by_edges(ptr: Sequence[int], world_size: int, cost: Sequence[float] = 
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
+def plan_chunks(ptr: Sequence[int], max_edges: int, g0: int = 0, g1: int = None) -> List[Tuple[int, int]]:
+    """Cut molecules [g0, g1) into contiguous ranges whose edge count cannot exceed ``max_edges``.
+
+    The bound per molecule is n_g (n_g - 1) (every ordered pair inside the cutoff), so a range never overflows the
+    32-bit byte offsets of the matrix-core message kernels (xeq_message_wm_fits) whatever the geometry.  A single
+    molecule above the cap gets a range of its own (the kernels' own size check then decides)."""
+    ptr = np.asarray(ptr, dtype=np.int64)
+    g1 = len(ptr) - 1 if g1 is None else g1
+    n = np.diff(ptr[g0 : g1 + 1]).astype(np.int64)
+    bound = n * (n - 1)
+    out, start, acc = [], g0, 0
+    for i, b in enumerate(bound):
+        if acc + b > max_edges and g0 + i > start:
+            out.append((start, g0 + i))
+            start, acc = g0 + i, 0
+        acc += int(b)
+    if g1 > start or not out:
+        out.append((start, g1))
+    return out
+
+
+def gather_shards(local: dict, dst: int = 0):
+    """Concatenate per-rank result dicts of numpy arrays in rank order on ``dst`` (None elsewhere).  The ONLY exchange
+    of a sharded inference: after the evaluation, off the data path (results concatenated on the host)."""
+    if not dist.is_initialized():
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    box = [None] * world if rank == dst else None
+    dist.gather_object(local, box, dst=dst)
+    if rank != dst:
+        return None
+    return {k: np.concatenate([b[k] for b in box], axis=0) for k in box[0]}
+
+
 def take_shard(pos: np.ndarray, z: np.ndarray, ptr: np.ndarray, g0: int, g1: int):
     """Slice molecules [g0, g1) out of a batch (re-based ptr)."""
     a, b = int(ptr[g0]), int(ptr[g1])

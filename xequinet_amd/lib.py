@@ -64,6 +64,8 @@ _PROTOS = {
     "xeq_message_bwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P,
                            c_int, _P],
     "xeq_message_wm_supported": [c_int, c_int, _I3],
+    "xeq_message_wm_fits": [c_int64, c_int64, c_int, c_int, _I3],
+    "xeq_message_sb_fits": [c_int64, c_int64, c_int, c_int, _I3],
     "xeq_message_wm_streams": [_P, c_int64, c_int64, c_int, _P, _P],
     "xeq_edge_basis_wm_width": [c_int],
     "xeq_edge_basis_wm": [_P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],

@@ -20,8 +20,17 @@ from torch.autograd.function import once_differentiable
 from .. import lib, ops
 from ..lib import call, dtype_code, mul3, ptr, stream
 
-_NO_PARAM_GRAD = ("xequinet_amd: parameter gradients (training) are out of scope; "
-                  "call model.requires_grad_(False) / model.eval()")
+_NO_PARAM_GRAD = ("xequinet_amd: the fused blocks give gradients w.r.t. node features and edge vectors only (force "
+                  "evaluation); parameter gradients (training) are not implemented -- call model.eval()")
+
+
+def check_no_training(module: torch.nn.Module) -> None:
+    """Called by XPainnMessage / XPainnUpdate.forward BEFORE ``Function.apply`` (inside ``Function.forward`` grad mode
+    is always off, so a guard there never fires).  A module in training mode whose parameters ask for gradients would
+    silently get none from these blocks: refuse.  In eval mode (inference under ``torch.enable_grad()``, as
+    run/inference.py:44 does with default ``requires_grad=True`` parameters) the blocks run."""
+    if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(_NO_PARAM_GRAD)
 
 
 def _bt_blocks(buf: torch.Tensor, n: int, mul, width: int):
@@ -76,8 +85,6 @@ class MessageBlock(Function):
         lib.require_hip(s, x, vec)
         s, x, vec = s.contiguous(), x.contiguous(), vec.contiguous()
         F, mul = module.node_dim, module._mul
-        if any(p.requires_grad for p in module.parameters()) and torch.is_grad_enabled():
-            raise NotImplementedError(_NO_PARAM_GRAD)
         shat, xhat, stats, do_norm = _norm_fwd(s, x, module.norm, module.o3norm, F, mul)
         lin1, act, lin2 = module.scalar_mlp[0], module.scalar_mlp[1], module.scalar_mlp[2]
         pre = torch.addmm(lin1.bias, shat, lin1.weight.t())
@@ -134,8 +141,6 @@ class UpdateBlock(Function):
     def forward(ctx, s, x, module):
         lib.require_hip(s, x)
         s, x = s.contiguous(), x.contiguous()
-        if any(p.requires_grad for p in module.parameters()) and torch.is_grad_enabled():
-            raise NotImplementedError(_NO_PARAM_GRAD)
         n, D = x.shape
         F, mul = module.node_dim, module.node_irreps.mul3()
         C = sum(mul)

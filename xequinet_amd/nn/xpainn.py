@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import keys, o3, ops
 from .basic import Int2c1eEmbedding, edge_graph, resolve_activation
-from .fused import MessageBlock, UpdateBlock
+from .fused import MessageBlock, UpdateBlock, check_no_training
 from .o3layer import EquivariantDot, EquivariantLayerNorm, Invariant
 from .rbf import resolve_cutoff, resolve_rbf
 
@@ -120,6 +120,7 @@ class XPainnMessage(nn.Module):
         if rbf.num_basis != self.num_basis:
             raise ValueError(f"num_basis mismatch: embedding {rbf.num_basis} vs message {self.num_basis}")
         if self.fused:  # block-level path: explicit forward/reverse, see nn/fused.py
+            check_no_training(self)
             new_scalar, new_equi = MessageBlock.apply(ori_scalar, ori_equi, data[keys.EDGE_VECTOR], self, edge_graph(data), rbf, cutoff_fn)
         else:           # operator-level path (the reference's own op sequence on the drop-in ops)
             node_scalar = self.norm(ori_scalar)
@@ -171,6 +172,7 @@ class XPainnUpdate(nn.Module):
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if self.fused:
+            check_no_training(self)
             s_new, x_new = UpdateBlock.apply(data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT], self)
             data[keys.NODE_INVARIANT] = s_new
             data[keys.NODE_EQUIVARIANT] = x_new

@@ -95,6 +95,7 @@ class EdgeGraph:
         require_hip(edge_index)
         self.ptr = ptr          # graph boundaries [G+1] (keys.BATCH_PTR), when the caller knows them
         self._wm = None
+        self._basis = self._basis_wm = None   # per-edge records of the current geometry (edge_basis / edge_basis_wm)
         assert edge_index.dim() == 2 and edge_index.shape[0] == 2 and edge_index.dtype == torch.int64
         self.edge_index = edge_index = edge_index.contiguous()
         self.n_nodes = int(n_nodes)
@@ -291,6 +292,7 @@ class EdgeVectors(Function):
         cell, cell_offsets, batch = _c(cell), _c(cell_offsets), _c(batch)
         call("xeq_edge_vectors_fwd", dtype_code(pos), ptr(pos_c), ptr(graph.edge_index), E, ptr(cell), ptr(cell_offsets),
              ptr(batch), ptr(vec), ptr(dist), stream())
+        graph._basis = graph._basis_wm = None   # records of an earlier geometry on this graph
         ctx.graph = graph
         ctx.graph_ptr = graph_ptr
         ctx.n_graphs = None if strain is None else strain.shape[0]
@@ -489,13 +491,37 @@ def radial_basis(dist, rbf_kind: str, cutoff_kind: str, num_basis: int, cutoff: 
 
 
 # ------------------------------------------------------------------- fused message
+_MESSAGE_IMPLS = ("auto", "wm", "sb", "generic")
+
+
 def _message_impl() -> str:
     import os
 
     impl = os.environ.get("XEQ_MESSAGE_IMPL", "auto")
-    if impl not in ("auto", "wm", "sb", "mfma", "valu"):
-        raise ValueError(f"XEQ_MESSAGE_IMPL={impl!r}: expected auto | wm | sb | mfma | valu")
+    if impl == "valu":   # earlier name of the generic form
+        impl = "generic"
+    if impl not in _MESSAGE_IMPLS:
+        raise ValueError(f"XEQ_MESSAGE_IMPL={impl!r}: expected " + " | ".join(_MESSAGE_IMPLS))
     return impl
+
+
+def select_message_impl(dtype, n_nodes: int, n_edges: int, num_basis: int, node_dim: int, mul) -> str:
+    """Kernel family of the fused message for this configuration AND these sizes.  ``auto``: the wave / matrix-core
+    form (f32, multiplicities in multiples of 32, 32-bit byte offsets: ~1.8 M atoms / 14.9 M edges with the default
+    model), else the scalar-broadcast form (f32 / f64, at most 256 channels, 32-bit element offsets), else the generic
+    form (64-bit offsets).  An explicit XEQ_MESSAGE_IMPL is taken as is: its kernels raise when they do not fit."""
+    impl = _message_impl()
+    if impl != "auto":
+        if impl == "wm" and not wm_supported(dtype, num_basis, node_dim, mul):
+            raise RuntimeError("XEQ_MESSAGE_IMPL=wm: this configuration does not fit the matrix-core kernels "
+                               "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 31)")
+        return impl
+    L = lib.load()
+    if dtype == torch.float32 and L.xeq_message_wm_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
+        return "wm"
+    if L.xeq_message_sb_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
+        return "sb"
+    return "generic"
 
 
 def _wm_edges_per_stream(n_edges: int, n_nodes: int) -> int:
@@ -517,36 +543,44 @@ def wm_supported(dtype, num_basis, node_dim, mul) -> bool:
     return dtype == torch.float32 and bool(lib.load().xeq_message_wm_supported(int(num_basis), int(node_dim), mul3(mul)))
 
 
+def _basis_cache_hit(cached, vec, key):
+    """A cached record set is valid only for the very tensor it was computed from.  ``vec`` is written by a raw
+    HIP kernel into a fresh allocation, so its ``_version`` never moves and the caching allocator can hand the next
+    evaluation's vec the same address: identity of the tensor object is the test (the cache holds a reference, which
+    also keeps that address from being reused while the entry lives)."""
+    return cached is not None and cached[0] is vec and cached[1] == key
+
+
 def edge_basis_wm(vec, graph: "EdgeGraph", rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1):
     """Per-edge records of the wm kernels (xeq_edge_basis_wm), once per evaluation, cached on the graph."""
-    key = (vec.data_ptr(), vec._version, rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version)
+    key = (rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version)
     cached = getattr(graph, "_basis_wm", None)
-    if cached is not None and cached[0] == key:
-        return cached[1], cached[2]
+    if _basis_cache_hit(cached, vec, key):
+        return cached[2], cached[3]
     width = lib.load().xeq_edge_basis_wm_width(num_basis)
     E = vec.shape[0]
     basis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
     dbasis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
     call("xeq_edge_basis_wm", ptr(vec), E, lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff),
          ptr(p0), ptr(p1), ptr(basis), ptr(dbasis), stream())
-    graph._basis_wm = (key, basis, dbasis)
+    graph._basis_wm = (vec, key, basis, dbasis)
     return basis, dbasis
 
 
 def edge_basis(vec, graph: EdgeGraph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1):
     """Per-edge radial / angular records (xeq_edge_basis), computed once per evaluation and cached
     on the graph: the three message blocks and both directions share them."""
-    key = (vec.data_ptr(), vec._version, vec.dtype, rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version)
+    key = (vec.dtype, rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version)
     cached = getattr(graph, "_basis", None)
-    if cached is not None and cached[0] == key:
-        return cached[1], cached[2]
+    if _basis_cache_hit(cached, vec, key):
+        return cached[2], cached[3]
     width = lib.load().xeq_edge_basis_width(num_basis)
     E = vec.shape[0]
     basis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
     dbasis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
     call("xeq_edge_basis", dtype_code(vec), ptr(vec), E, lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis,
          float(cutoff), ptr(p0), ptr(p1), ptr(basis), ptr(dbasis), stream())
-    graph._basis = (key, basis, dbasis)
+    graph._basis = (vec, key, basis, dbasis)
     return basis, dbasis
 
 
@@ -564,13 +598,7 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
     assert h.shape == (N, node_dim + 2 * C) and xhat.numel() == N * D and vec.shape == (E, 3)
     assert s.shape == (N, node_dim) and x.shape == (N, D) and w_rbf.shape == (node_dim + 2 * C, num_basis)
     s_out, x_out = torch.empty_like(s), torch.empty_like(x)
-    impl = _message_impl()
-    if impl in ("auto", "wm"):
-        ok = wm_supported(h.dtype, num_basis, node_dim, mul)
-        if not ok and impl == "wm":
-            raise RuntimeError("XEQ_MESSAGE_IMPL=wm: this configuration does not fit the matrix-core kernels "
-                               "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 31)")
-        impl = "wm" if ok else "sb"
+    impl = select_message_impl(h.dtype, N, E, num_basis, node_dim, mul)
     if impl == "wm":
         basis, dbasis = edge_basis_wm(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
         plan = graph.wm_plan(False, _wm_edges_per_stream(E, N))
@@ -584,7 +612,7 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
                             ptr(graph.edge_index[1]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf), ptr(b_rbf),
                             num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
         return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, basis, dbasis), impl
-    # mfma | valu: the library picks the kernel family from XEQ_MESSAGE_IMPL
+    # generic form: 64-bit offsets, recomputes the per-edge quantities from vec
     KERNEL_TIMER.launch("xeq_message_fwd", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm),
                         ptr(graph.edge_index[1]), ptr(vec), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf), ptr(b_rbf),
                         ptr(p0), ptr(p1), lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff),

@@ -27,6 +27,7 @@ class _Captured:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.inputs: Dict[str, torch.Tensor] = {}
         self.edge_graph: Optional[ops.EdgeGraph] = None
+        self.derived_batch = False
         self.outputs: Dict[str, torch.Tensor] = {}
 
 
@@ -78,7 +79,8 @@ class GraphedModel:
     def _capture(self, data, eg: ops.EdgeGraph) -> _Captured:
         c = _Captured()
         c.inputs = {k: data[k].clone() for k in self._TENSOR_KEYS if k in data}
-        if keys.BATCH not in c.inputs:
+        c.derived_batch = keys.BATCH not in c.inputs
+        if c.derived_batch:
             ptr = c.inputs[keys.BATCH_PTR]
             counts = ptr[1:] - ptr[:-1]
             c.inputs[keys.BATCH] = torch.repeat_interleave(torch.arange(counts.numel(), device=ptr.device), counts,
@@ -88,13 +90,12 @@ class GraphedModel:
                                      ptr=c.inputs[keys.BATCH_PTR])
         static = dict(c.inputs)
         static[keys.EDGE_GRAPH] = c.edge_graph
-        if self.tune_gemms:
-            from .tuning import enable_gemm_autotune, gemm_autotune_enabled
-            if not gemm_autotune_enabled():
-                enable_gemm_autotune()
+        # library GEMM selection is timed during the warm-up only: TunableOp is a process-wide switch, so the state the
+        # host application had is restored afterwards (selections made here stay cached inside the libraries' wrapper)
+        from .tuning import gemm_autotune_scope
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):   # warm-up off the capture: library GEMM selection, lazy initialisation
+        with gemm_autotune_scope(self.tune_gemms), torch.cuda.stream(side):   # warm-up off the capture: GEMM selection, lazy init
             for _ in range(self.warmup):
                 self._run(static)
         torch.cuda.current_stream().wait_stream(side)
@@ -111,6 +112,11 @@ class GraphedModel:
         for k, t in c.inputs.items():
             if k in data:
                 t.copy_(data[k], non_blocking=True)
+        if c.derived_batch:   # the caller gave ptr only: the graph index per atom follows the CURRENT ptr
+            ptr = c.inputs[keys.BATCH_PTR]
+            counts = ptr[1:] - ptr[:-1]
+            c.inputs[keys.BATCH].copy_(torch.repeat_interleave(torch.arange(counts.numel(), device=ptr.device), counts,
+                                                               output_size=c.inputs[keys.POSITIONS].shape[0]))
         s = c.edge_graph
         s.c_rowptr.copy_(eg.c_rowptr, non_blocking=True)
         s.n_rowptr.copy_(eg.n_rowptr, non_blocking=True)
@@ -134,3 +140,48 @@ class GraphedModel:
         self._refresh(c, data, eg)
         c.graph.replay()
         return c.outputs
+
+
+# ----------------------------------------------------------------------------------------------- chunked evaluation
+WM_MAX_EDGES_PER_CHUNK = 8_000_000   # well inside the 14.9 M-edge bound of the matrix-core message kernels
+
+
+def evaluate_in_chunks(model, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, ptr_host=None,
+                       max_edges: int = WM_MAX_EDGES_PER_CHUNK, compute_forces: bool = True,
+                       runner=None) -> Dict[str, torch.Tensor]:
+    """Energy (+ forces) of a batch of independent open-boundary molecules of ANY size: molecules are evaluated in
+    contiguous ranges of at most ``max_edges`` edges (dist.plan_chunks) and the results concatenated.  Molecules do
+    not interact (the neighbour list never crosses graphs, data/transform.py:58-64; the readout is per graph,
+    nn/output.py:124), so the result is what one evaluation of the whole batch gives, bit for bit: every kernel's
+    per-node / per-graph sums walk the same edges in the same order.  ``runner(data_dict) -> out`` defaults to the
+    eager model call; pass a ``GraphedModel`` to replay recurring chunk shapes."""
+    from .data import NeighborTransform, XequiBatch
+    from .dist import plan_chunks
+
+    if ptr_host is None:
+        ptr_host = ptr.cpu().numpy()
+    chunks = plan_chunks(ptr_host, max_edges)
+    transform = NeighborTransform(model.cutoff_radius)
+    energies, atomic, forces, n_edges = [], [], [], 0
+    for g0, g1 in chunks:
+        a, b = int(ptr_host[g0]), int(ptr_host[g1])
+        batch = XequiBatch(pos[a:b].detach(), atomic_numbers[a:b], ptr[g0 : g1 + 1] - ptr[g0])
+        batch = transform(batch)
+        n_edges += int(batch.edge_index.shape[1])
+        if runner is not None:
+            out = runner(batch.to_dict())
+            out = {k: v.clone() for k, v in out.items()}   # a replayed graph owns its outputs
+        else:
+            with torch.enable_grad():
+                out = model(batch.to_dict(), compute_forces=compute_forces, compute_virial=False)
+        energies.append(out[keys.TOTAL_ENERGY].detach())
+        if keys.ATOMIC_ENERGIES in out:
+            atomic.append(out[keys.ATOMIC_ENERGIES].detach())
+        if compute_forces:
+            forces.append(out[keys.FORCES].detach())
+    res = {keys.TOTAL_ENERGY: torch.cat(energies), "n_edges": n_edges, "n_chunks": len(chunks)}
+    if atomic:
+        res[keys.ATOMIC_ENERGIES] = torch.cat(atomic)
+    if compute_forces:
+        res[keys.FORCES] = torch.cat(forces)
+    return res

@@ -13,7 +13,9 @@ import os
 
 import torch
 
-__all__ = ["enable_gemm_autotune", "gemm_autotune_enabled"]
+import contextlib
+
+__all__ = ["enable_gemm_autotune", "gemm_autotune_enabled", "gemm_autotune_scope"]
 
 
 def enable_gemm_autotune(max_tuning_ms: int = 100, results_file: str | None = None) -> bool:
@@ -38,3 +40,21 @@ def enable_gemm_autotune(max_tuning_ms: int = 100, results_file: str | None = No
 
 def gemm_autotune_enabled() -> bool:
     return torch.cuda.is_available() and torch.cuda.tunable.is_enabled()
+
+
+@contextlib.contextmanager
+def gemm_autotune_scope(active: bool = True):
+    """Time new GEMM shapes inside the block only, then put PyTorch's process-wide TunableOp switches back the way the
+    host application had them (a library must not leave every other GEMM of the process tuned at ~50 ms per shape)."""
+    if not active or not torch.cuda.is_available() or gemm_autotune_enabled():
+        yield
+        return
+    t = torch.cuda.tunable
+    was_enabled, was_tuning = t.is_enabled(), t.tuning_is_enabled()
+    enable_gemm_autotune()
+    try:
+        yield
+    finally:
+        # the lookup stays on (a selection is only applied while TunableOp is enabled: the captured graph and later
+        # eager calls use the kernels timed here), timing of NEW shapes goes back to what the application had: off
+        t.tuning_enable(was_tuning if was_enabled else False)
