@@ -1,0 +1,50 @@
+"""Micro-benchmark of the fused message kernels alone (QM9-1024 by default): python scratch/bench_wq.py [workload] impl [impl ...]"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xequinet_amd import ops
+from xequinet_amd.data import NeighborTransform, XequiBatch, synthetic as syn
+dev = "cuda"
+args = sys.argv[1:]
+wl = args.pop(0) if args and args[0] in syn.WORKLOADS else "qm9_1024"
+pos, z, ptr, cell = syn.make_workload(wl, 1234)
+kw = {} if cell is None else dict(pbc=torch.tensor([[True, True, True]], device=dev), cell=torch.tensor(cell, dtype=torch.float32, device=dev))
+b = XequiBatch(torch.tensor(pos, dtype=torch.float32), torch.tensor(z), torch.tensor(ptr)).to(dev)
+for k, v in kw.items(): setattr(b, k, v.reshape(-1, 3) if k == "pbc" else v.reshape(-1, 3, 3))
+b = NeighborTransform(5.0)(b)
+g = getattr(b, "_xeq_edge_graph")
+N, E = g.n_nodes, g.n_edges
+ei = b.edge_index
+vec = (b.pos[ei[0]] - b.pos[ei[1]]).contiguous()
+if cell is not None:
+    vec = vec - b.cell_offsets @ b.cell[0]
+torch.manual_seed(0)
+F_, mul = 128, (128, 64, 32); C, D, H, B = 224, 480, 576, 20
+h = torch.randn(N, H, device=dev); xhat = torch.randn(N, D, device=dev); s = torch.randn(N, F_, device=dev); x = torch.randn(N, D, device=dev)
+W = torch.randn(H, B, device=dev) / B**0.5; bias = torch.randn(H, device=dev)
+p0 = (torch.pi * torch.arange(1, B + 1, device=dev) / 5.0).float()
+gs = torch.randn(N, F_, device=dev); gx = torch.randn(N, D, device=dev)
+cfg = ("bessel", "cosine", B, 5.0, F_, mul)
+def run(impl):
+    os.environ["XEQ_MESSAGE_IMPL"] = impl
+    g._basis = g._basis_wm = None
+    for p in (g._wq or {}).values(): p["records"] = None
+    hh, xx, vv = h.clone().requires_grad_(), xhat.clone().requires_grad_(), vec.clone().requires_grad_()
+    so, xo = ops.FusedMessage.apply(hh, xx, vv, s, x, W, bias, p0, None, g, cfg)
+    ((so * gs).sum() + (xo * gx).sum()).backward()
+    return so.detach(), xo.detach(), hh.grad, xx.grad, vv.grad
+def timeit(impl, reps=10):
+    ops.KERNEL_TIMER.reset(True)
+    for _ in range(reps):
+        run(impl)
+    r = ops.KERNEL_TIMER.summary(); ops.KERNEL_TIMER.reset(False)
+    return {k: v["total_ms"] / v["launches"] * 1e3 for k, v in r.items()}
+print(f"{wl}: N={N} E={E} lib={os.environ.get('XEQ_LIB_PATH', 'in-tree')}")
+ref = run("sb")
+for impl in args or ["wq"]:
+    got = run(impl)
+    again = run(impl)
+    errs = []
+    for n, a, r, a2 in zip(["s_out", "x_out", "g_h", "g_xhat", "g_vec"], got, ref, again):
+        errs.append(f"{n} {float((a - r).abs().max()) / max(1.0, float(r.abs().max())):.1e}{'' if torch.equal(a, a2) else ' NOT-REPRODUCIBLE'}")
+    run(impl)
+    print(impl, {k: f"{v:.1f} us" for k, v in timeit(impl).items()}, "| rel err vs sb:", ", ".join(errs))

@@ -433,13 +433,16 @@ WM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("impl", ["wq", "wm"])
 @pytest.mark.parametrize("eps", ["16", "128", "100000"])
 @pytest.mark.parametrize("irreps,node_dim,B,rbf_kind,cutoff_kind,shuffle", WM_CASES)
-def test_fused_message_matrix_core_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff_kind, shuffle, eps, monkeypatch):
+def test_fused_message_matrix_core_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff_kind, shuffle, eps, impl, monkeypatch):
     """The wave / matrix-core kernels (xeq_message_{fwd,bwd}_wm, f32) against the fp64 oracle: every output of the
     forward pass and every gradient of the reverse pass, ragged molecules (3..29 atoms), shuffled edges, K = B + 1
-    from 9 to 32, and stream lengths from one tile per stream to one wave for the whole batch."""
-    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    from 9 to 32 (wq: up to 24), and stream lengths from one tile per stream to one wave for the whole batch."""
+    if impl == "wq" and B > 23:
+        pytest.skip("the wave / quad form takes num_basis <= 23")
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", impl)
     monkeypatch.setenv("XEQ_WM_EDGES_PER_STREAM", eps)
     got, want = _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, torch.float32, shuffle, n_mol=40)
     names = ["s_out", "x_out", "grad_h", "grad_xhat", "grad_vec", "grad_s", "grad_x"]
@@ -450,12 +453,13 @@ def test_fused_message_matrix_core_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * scale, err_msg=name)
 
 
-def test_fused_message_matrix_core_isolated_nodes_and_empty_graph(monkeypatch):
+@pytest.mark.parametrize("impl", ["wq", "wm"])
+def test_fused_message_matrix_core_isolated_nodes_and_empty_graph(impl, monkeypatch):
     """Nodes without edges keep their residual rows (forward) and get zero gradients (reverse); a batch without any
     edge at all runs through the same entry points."""
     from xequinet_amd import ops
 
-    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", impl)
     torch.manual_seed(3)
     mul, F, B, rc = (32, 32, 32), 32, 8, 3.0
     C, D, H = 96, 32 + 96 + 160, 32 + 192
@@ -483,13 +487,14 @@ def test_fused_message_matrix_core_isolated_nodes_and_empty_graph(monkeypatch):
         assert torch.isfinite(h.grad).all() and torch.isfinite(xhat.grad).all() and vec.grad.shape == (E, 3)
 
 
-def test_fused_message_matrix_core_matches_scalar_broadcast_and_is_reproducible(monkeypatch):
-    """wm against the sb kernels on the same f32 inputs (both are exact-f32 fmaf chains over the same terms; the
+@pytest.mark.parametrize("impl", ["wq", "wm"])
+def test_fused_message_matrix_core_matches_scalar_broadcast_and_is_reproducible(impl, monkeypatch):
+    """wq / wm against the sb kernels on the same f32 inputs (both are exact-f32 fmaf chains over the same terms; the
     k-order of the filter sum differs), and bitwise reproducibility of wm (register sums in CSR order)."""
     args = ("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", torch.float32, False)
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", "sb")
     ref, _ = _message_case(*args, n_mol=24)
-    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", impl)
     a, _ = _message_case(*args, n_mol=24)
     b, _ = _message_case(*args, n_mol=24)
     for u, v in zip(a, b):
@@ -706,7 +711,7 @@ def test_model_virial_pbc_and_molecules(dtype):
         assert "forces" not in only
 
 
-@pytest.mark.parametrize("impl", ["generic", "sb", "wm"])
+@pytest.mark.parametrize("impl", ["generic", "sb", "wm", "wq"])
 def test_model_message_kernel_families_agree(impl, monkeypatch):
     """The fused-message kernel families (generic, scalar-broadcast, wave / matrix-core) and the
     operator-level module path all reproduce the oracle on a molecule batch (fp32)."""
@@ -908,13 +913,14 @@ def test_auto_picks_a_kernel_family_that_fits(monkeypatch):
     monkeypatch.delenv("XEQ_MESSAGE_IMPL", raising=False)
     mul = (128, 64, 32)
     pick = lambda dt, n, e: ops.select_message_impl(dt, n, e, 20, 128, mul)
-    assert pick(torch.float32, 18_609, 311_994) == "wm"
-    assert pick(torch.float32, 1_200_000, 14_000_000) == "wm"
-    assert pick(torch.float32, 1_200_000, 15_000_000) == "sb"          # records: E * 288 B >= 2^32
+    assert pick(torch.float32, 18_609, 311_994) == "wq"
+    assert pick(torch.float32, 1_200_000, 14_000_000) == "wq"
+    assert pick(torch.float32, 1_200_000, 31_000_000) == "sb"          # records: padded slots * 128 B >= 2^32
     assert pick(torch.float32, 1_900_000, 1_000_000) == "sb"           # rows of h: N * 576 * 4 B >= 2^32
     assert pick(torch.float32, 4_000_000, 1_000_000) == "generic"      # N * 576 elements >= 2^31
     assert pick(torch.float64, 18_609, 311_994) == "sb"
     assert ops.select_message_impl(torch.float32, 100, 1000, 20, 96, (96, 48, 24)) == "sb"   # multiplicities not in 32s
+    assert ops.select_message_impl(torch.float32, 100, 1000, 30, 128, mul) == "wm"            # num_basis > 23
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
     with pytest.raises(RuntimeError):
         ops.select_message_impl(torch.float64, 100, 1000, 20, 128, mul)

@@ -1,0 +1,979 @@
+// Fused XPaiNN message kernels, "wave / quad" form (fp32; the default where the channel layout allows it).
+// Reference dataflow: nn/xpainn.py:140-159; reverse pass for nn/basic.py:143-159.
+//
+// Same arithmetic mapping as the wave / matrix-core form it replaces (xeq_message_wm.hip): the filter
+// phi_e = (W rho(d_e) + b) f(d_e) is an exact-f32 MFMA tile D[edge][channel] (v_mfma_f32_32x32x2_f32, K = B + 1),
+// a wave owns (range of nodes, 32 gate channels of one l), its two half-waves are two independent streams over
+// contiguous CSR segments, and the sum over the edges of a node is a running sum in registers that is stored once.
+//
+// What changed is the WALK ORDER, which removes the per-row bookkeeping that bounded the older form (19 vector
+// instructions per MFMA, 244 VGPRs, a divergent first/last branch per row):
+//
+//   * every node's edge list is padded to a multiple of FOUR slots ("quads"; padding slots carry an all-zero record,
+//     so their filter is exactly 0).  The four accumulator registers 4g .. 4g+3 of a lane are then the four rows of
+//     ONE quad, and a quad belongs to ONE node: segment starts and ends can only fall between quads.  The rows of a
+//     quad are plain FMAs into a quad sum; the segment logic (reset / residual / the node's only store) runs once
+//     per quad on half-uniform flags, 4x less often and branch-free except for the store.
+//   * the walk plan (xeq_message_wq_plan) is built once per graph, independent of the positions: per padded slot the
+//     gathered node and the edge id, per quad the owner node and its first / last flags, stream boundaries on quads.
+//     The per-edge records (xeq_edge_basis_wq) are written IN PADDED WALK ORDER, so a tile's A operand, its Y_lm and
+//     its indices are sequential loads with no dependent index chain.
+//   * what a whole quad shares comes from its owner: in the reverse pass the owner's rows (h, xhat) are per-quad
+//     constants, so products with them are hoisted out of the rows (l = 0: 7 vector instructions per row).
+//   * the per-edge sums over channels of the reverse pass (dL/dd, dL/dY_lm) use a register-halving DPP butterfly:
+//     16 rows x 32 lanes reduce in 48 instead of 80 cross-lane adds, and leave as one 64-byte store per quantity.
+#include "xeq_common.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace xeq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WQ_REC = 32;                 // floats per record: [12 even k | 12 odd k | Y1[3] Y2[5]]
+constexpr int WQ_KH = 12;                  // floats per k-parity half of a record
+constexpr uint32_t WQ_FIRST = 1u << 30, WQ_LAST = 1u << 31, WQ_OWNER = (1u << 30) - 1u;
+constexpr int WQ_WAVES = 4;                // waves per workgroup (independent of one another after the weight staging)
+
+// ------------------------------------------------------------------------------------------------ walk plan
+struct QuadCount {
+  const int32_t* rowptr;
+  int64_t n;
+  __host__ __device__ int32_t operator()(int64_t i) const { return i < n ? (rowptr[i + 1] - rowptr[i] + 3) >> 2 : 0; }
+};
+
+// one thread per slot of the walk order: its padded position, the pads behind a segment's last slot, the quad records
+__global__ void k_wq_fill(int64_t E, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
+                          const int64_t* __restrict__ owner, const int64_t* __restrict__ gather,
+                          const int32_t* __restrict__ qptr, int32_t* __restrict__ pgath, int32_t* __restrict__ peid,
+                          uint32_t* __restrict__ qinfo) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= E) return;
+  const int32_t eid = perm ? perm[s] : (int32_t)s;
+  const int64_t n = owner[eid];
+  const int32_t r0 = rowptr[n], deg = rowptr[n + 1] - r0, k = (int32_t)(s - r0), q0 = qptr[n], nq = (deg + 3) >> 2;
+  const int64_t p = 4 * (int64_t)q0 + k;
+  pgath[p] = (int32_t)gather[eid];
+  peid[p] = eid;
+  if (k == deg - 1)
+    for (int64_t pp = p + 1; pp < 4 * (int64_t)(q0 + nq); ++pp) {   // pads: zero record, gather the owner's own rows
+      pgath[pp] = (int32_t)n;
+      peid[pp] = -1;
+    }
+  if ((k & 3) == 0) {
+    const int32_t g = k >> 2;
+    qinfo[q0 + g] = (uint32_t)n | (g == 0 ? WQ_FIRST : 0u) | (g == nq - 1 ? WQ_LAST : 0u);
+  }
+}
+
+// sq[k] / sn[k]: first quad / node of stream k; boundaries sit on segment starts at about equal quad counts
+__global__ void k_wq_streams(const int32_t* __restrict__ qptr, int64_t N, int n_ranges, int32_t* __restrict__ sq,
+                             int32_t* __restrict__ sn) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > 2 * n_ranges) return;
+  const int64_t Q = qptr[N];
+  if (k == 2 * n_ranges) {
+    sq[k] = (int32_t)Q;
+    sn[k] = (int32_t)N;
+    return;
+  }
+  const int64_t target = (int64_t)k * Q / (2 * n_ranges);
+  int64_t lo = 0, hi = N;   // first n in [0, N] with qptr[n] >= target
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (qptr[mid] >= target) hi = mid;
+    else lo = mid + 1;
+  }
+  sq[k] = qptr[lo];
+  sn[k] = (int32_t)lo;
+}
+
+// records in padded walk order; val(k) = f rho_k (k < B) | f (k == B) | 0, derivative record likewise
+__global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
+                             const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
+                             const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
+                             float* __restrict__ drec) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p = t >> 5;
+  if (p >= pcap || p >= 4 * (int64_t)qptr[N]) return;
+  const int slot = (int)(t & 31);
+  const int32_t e = peid[p];
+  float v = 0.f, dv = 0.f;
+  if (e >= 0) {
+    const float rc = (float)rs.cutoff;
+    const EdgeGeom<float> g = edge_geom<float>(vec[3 * (int64_t)e], vec[3 * (int64_t)e + 1], vec[3 * (int64_t)e + 2]);
+    if (slot < 2 * WQ_KH) {
+      const int k = slot < WQ_KH ? 2 * slot : 2 * (slot - WQ_KH) + 1, B = rs.num_basis;
+      float f, df;
+      envelope<float>(rs.cutoff_kind, g.d, rc, f, df);
+      if (k < B) {
+        float rho, drho;
+        radial<float>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : 0.f, rho, drho);
+        v = f * rho;
+        dv = df * rho + f * drho;
+      } else if (k == B) {
+        v = f;
+        dv = df;
+      }
+    } else {
+      float y1[3], y2[5];
+      sph_harm_l12<float>(g, y1, y2);
+      const int q = slot - 2 * WQ_KH;
+      const float y[8] = {y1[0], y1[1], y1[2], y2[0], y2[1], y2[2], y2[3], y2[4]};
+      v = y[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) v = q == i ? y[i] : v;
+    }
+  }
+  rec[t] = v;
+  if (drec) drec[t] = dv;
+}
+
+// ------------------------------------------------------------------------------------------------ common
+struct WqArgs {
+  int64_t n_nodes, n_edges, pcap;
+  int n_ranges;
+  const int32_t* sq;       // [2 R + 1] quad boundaries of the streams (range w: streams 2w and 2w + 1)
+  const int32_t* sn;       // [2 R + 1] node boundaries of the streams
+  const int32_t* rowptr;   // [N + 1] CSR of the walk order (isolated nodes)
+  const int32_t* pgath;    // [P] gathered node per padded slot
+  const uint32_t* qinfo;   // [Q] owner | WQ_FIRST | WQ_LAST per quad
+  int F, C, D, H, B;
+  Irreps ir;
+  int xl;                  // layout of xhat / grad_xhat
+  int nu[3];               // 32-channel units per l
+};
+
+struct WqUnit {
+  int l, cb, u0, xbase;
+};
+__device__ __forceinline__ WqUnit wq_unit(const WqArgs& a, int u) {
+  WqUnit w;
+  if (u < a.nu[0]) {
+    w.l = 0;
+    w.cb = u;
+  } else if (u < a.nu[0] + a.nu[1]) {
+    w.l = 1;
+    w.cb = u - a.nu[0];
+  } else {
+    w.l = 2;
+    w.cb = u - a.nu[0] - a.nu[1];
+  }
+  const int cbase = w.l == 0 ? 0 : (w.l == 1 ? a.ir.mul[0] : a.ir.mul[0] + a.ir.mul[1]);
+  w.u0 = cbase + 32 * w.cb;
+  int l_, off;
+  a.ir.locate(w.u0, l_, off);
+  w.xbase = off;
+  return w;
+}
+
+// (range, unit) of this wave: the WQ_WAVES waves of a workgroup share a unit (its rbf_lin rows, staged once in LDS)
+// and take consecutive ranges; consecutive work items are the units of one group of ranges (they share its records
+// and index arrays) and are dealt to workgroups so that they run on one XCD (blocks b and b + 8 share one under
+// round-robin dispatch: speed only).
+__device__ __forceinline__ void wq_decode(const WqArgs& a, int nunits, int& range, int& unit) {
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int item = (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+  const int rgroup = item / nunits;   // padding blocks of the grid land beyond the last group: all their ranges are empty
+  unit = item - rgroup * nunits;
+  range = rgroup * WQ_WAVES + (threadIdx.x >> 6);
+}
+
+// rbf_lin rows of the unit as the B operand: wl[kind][s][lane], lane (j = lane & 31 -> channel, kh = lane >> 5)
+// holding W~[row][2 s + kh], W~[., B] = bias, zeros beyond.  kind 0: gate_state, 1: gate_edge, 2: scalar message.
+template <int KS>
+__device__ __forceinline__ void wq_stage_weights(const WqArgs& a, const WqUnit& un, const float* __restrict__ w,
+                                                 const float* __restrict__ b, float* wl) {
+  const int nkind = un.l == 0 ? 3 : 2, B = a.B;
+  for (int idx = threadIdx.x; idx < nkind * KS * 64; idx += blockDim.x) {
+    const int kind = idx / (KS * 64), rem = idx - kind * (KS * 64), sstep = rem >> 6, ln = rem & 63;
+    const int row = (kind == 0 ? un.u0 : (kind == 1 ? a.C + un.u0 : 2 * a.C + 32 * un.cb)) + (ln & 31);
+    const int k = 2 * sstep + (ln >> 5);
+    wl[idx] = k < B ? w[(int64_t)row * B + k] : (k == B ? b[row] : 0.f);
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ f32x16 wq_filter(const float (&R)[KS], const float* W) {
+  f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(R[s], W[s * 64], d, 0, 0, 0);
+  return d;
+}
+
+__device__ __forceinline__ float wq_ld(const float* __restrict__ base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void wq_st(float* __restrict__ base, uint32_t byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// The tile table (LDS, private to the wave, double-buffered).  Position p = 16 * half + v is row v of that half's
+// stream in this tile (v = accumulator register); quad slot c = 4 * half + g.
+//   [T_G0 + p], [T_G1 + p]      byte offsets of the row's two gathered node rows
+//   [T_Y + 32 m + p]            Y_lm of the row (m = 0..2: Y_1, 3..7: Y_2)
+//   [T_QOWN + c]                owner node of the quad
+//   [T_QKEEP + c]               0 where the quad starts a segment (running sums restart), else 1
+//   [T_QLAST + c]               1 where the quad ends a segment (the node's sums are stored)
+enum { T_G0 = 0, T_G1 = 32, T_Y = 64, T_QOWN = 320, T_QKEEP = 328, T_QLAST = 336, T_SIZE = 344 };
+
+// what a lane loads for the MFMA row it owns: i = lane & 31 -> half hr = (i >> 2) & 1, register v = 4 (i >> 3) + (i & 3)
+template <int KS, int NREC, bool WITH_Y>
+struct WqRow {
+  float R[NREC][KS];
+  f32x4 ya, yb;
+  int g;
+  uint32_t qi;
+};
+struct WqStreams {
+  int q0, q1, q2, ntiles;
+};
+template <int KS, int NREC, bool WITH_Y>
+__device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int lane, int t, const float* __restrict__ rec,
+                                       const float* __restrict__ drec, WqRow<KS, NREC, WITH_Y>& w) {
+  const int i = lane & 31, kh = lane >> 5, hr = (i >> 2) & 1, g = i >> 3;
+  const int qb = hr ? st.q1 : st.q0, qe = hr ? st.q2 : st.q1;
+  const int q = qb + 4 * t + g;
+  const bool valid = q < qe;
+  // invalid rows (beyond the stream's end) read slot 0 / quad 0 -- always in bounds -- and are then zeroed: no load sits
+  // behind a branch, so the waits of the tile loop stay counted
+  const uint32_t ps = valid ? 4u * (uint32_t)q + (uint32_t)(i & 3) : 0u;
+  const int gv = a.pgath[ps];
+  const uint32_t qv = a.qinfo[valid ? q : 0];
+  w.g = valid ? gv : 0;
+  w.qi = valid ? qv : 0u;
+  const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + kh * WQ_KH);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const f32x4 x = rp[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * c + r < KS) w.R[0][4 * c + r] = valid ? x[r] : 0.f;
+  }
+  if constexpr (NREC > 1) {
+    const f32x4* __restrict__ dp = reinterpret_cast<const f32x4*>(drec + (size_t)ps * WQ_REC + kh * WQ_KH);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x4 x = dp[c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * c + r < KS) w.R[1][4 * c + r] = valid ? x[r] : 0.f;
+    }
+  }
+  if constexpr (WITH_Y) {
+    const f32x4* __restrict__ yp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + 2 * WQ_KH);
+    w.ya = yp[0];
+    w.yb = yp[1];
+  }
+}
+template <int KS, int NREC, bool WITH_Y>
+__device__ __forceinline__ void wq_publish(int lane, const WqRow<KS, NREC, WITH_Y>& w, uint32_t stride0, uint32_t stride1,
+                                           int* tbl) {
+  if (lane < 32) {
+    const int i = lane, hr = (i >> 2) & 1, v = 4 * (i >> 3) + (i & 3), p = 16 * hr + v;
+    tbl[T_G0 + p] = (int)((uint32_t)w.g * stride0);
+    tbl[T_G1 + p] = (int)((uint32_t)w.g * stride1);
+    if constexpr (WITH_Y) {
+      float* tf = reinterpret_cast<float*>(tbl);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        tf[T_Y + 32 * q + p] = w.ya[q];
+        tf[T_Y + 32 * (4 + q) + p] = w.yb[q];
+      }
+    }
+    if ((i & 3) == 0) {
+      const int c = 4 * hr + (i >> 3);
+      tbl[T_QOWN + c] = (int)(w.qi & WQ_OWNER);
+      tbl[T_QKEEP + c] = (w.qi & WQ_FIRST) ? 0 : 1;
+      tbl[T_QLAST + c] = (w.qi & WQ_LAST) ? 1 : 0;
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void wq_tread4(const int* tbl, int idx, T (&out)[4]) {
+  static_assert(sizeof(T) == 4, "table entries are dwords");
+  typedef T vec4 __attribute__((ext_vector_type(4)));
+  const vec4 v = *reinterpret_cast<const vec4*>(reinterpret_cast<const T*>(tbl) + idx);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = v[i];
+}
+
+// per-lane byte columns of the unit
+struct WqCols {
+  uint32_t b_hs, b_hm, b_s, b_xe, b_x, xnode_b, xcomp_b;
+  int64_t x_base;
+};
+template <int NM>
+__device__ __forceinline__ WqCols wq_cols(const WqArgs& a, const WqUnit& un, int j) {
+  WqCols w;
+  const XAddr xa = xaddr(a.ir, a.n_nodes, un.u0, a.xl);
+  w.b_hs = 4u * (uint32_t)(un.u0 + j);
+  w.b_hm = 4u * (uint32_t)(2 * a.C + 32 * un.cb + j);
+  w.b_s = 4u * (uint32_t)(32 * un.cb + j);
+  w.b_xe = 4u * (uint32_t)(un.xbase + j * NM);
+  w.b_x = 4u * (uint32_t)(j * (a.xl == 0 ? NM : 1));
+  w.xnode_b = 4u * (uint32_t)xa.node;
+  w.xcomp_b = 4u * (uint32_t)xa.comp;
+  w.x_base = xa.off;
+  return w;
+}
+__device__ __forceinline__ WqStreams wq_streams(const WqArgs& a, int range) {
+  WqStreams s;
+  s.q0 = a.sq[2 * range];
+  s.q1 = a.sq[2 * range + 1];
+  s.q2 = a.sq[2 * range + 2];
+  const int l0 = s.q1 - s.q0, l1 = s.q2 - s.q1;
+  s.ntiles = ((l0 > l1 ? l0 : l1) + 3) >> 2;
+  return s;
+}
+// owner nodes of the wave's two streams that have no edge: fn(node) is called by all 64 lanes
+template <typename Fn>
+__device__ __forceinline__ void wq_for_isolated(const WqArgs& a, int range, int lane, Fn fn) {
+  const int n0 = a.sn[2 * range], n2 = a.sn[2 * range + 2];
+  for (int base = n0; base < n2; base += 64) {
+    const int n = base + lane;
+    unsigned long long mask = __ballot(n < n2 && a.rowptr[n] == a.rowptr[n + 1]);
+    while (mask) {
+      const int m = base + (__ffsll((long long)mask) - 1);
+      mask &= mask - 1;
+      fn(m);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+//   x_c += xhat[n] (h_state[n] phi_state) + Y (h_edge[n] phi_edge);   s_c += h_msg[n] phi_msg   (l = 0)
+template <int NM, int KS>
+__device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const WqUnit un, const float* __restrict__ rec,
+                                            const float* __restrict__ h, const float* __restrict__ xhat_,
+                                            const float* __restrict__ s_in, const float* __restrict__ x_in, const float* wl,
+                                            float* __restrict__ s_out, float* __restrict__ x_out, int* tbl) {
+  constexpr bool HAS_S = NM == 1;
+  constexpr int YOFF = NM == 3 ? 0 : 3;
+  const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+  const WqCols wc = wq_cols<NM>(a, un, j);
+  const uint32_t row_s = 4u * (uint32_t)a.F, row_x = 4u * (uint32_t)a.D;
+  wq_for_isolated(a, range, lane, [&](int m) {   // s_out = s_in, x_out = x_in on the unit's columns
+    if (hh == 0) {
+      if constexpr (HAS_S) wq_st(s_out, (uint32_t)m * row_s + wc.b_s, wq_ld(s_in, (uint32_t)m * row_s + wc.b_s));
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm)
+        wq_st(x_out, (uint32_t)m * row_x + wc.b_xe + 4u * mm, wq_ld(x_in, (uint32_t)m * row_x + wc.b_xe + 4u * mm));
+    }
+  });
+  const WqStreams st = wq_streams(a, range);
+  if (st.ntiles == 0) return;
+  const float* __restrict__ h_e = h + a.C;
+  const float* __restrict__ h_m = h + (2 * a.C + 32 * un.cb - un.u0);
+  const float* xhat_m[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) xhat_m[m] = xhat_ + wc.x_base + (int64_t)m * (wc.xcomp_b / 4);
+  const uint32_t stride0 = 4u * (uint32_t)a.H, stride1 = wc.xnode_b;
+  const float* Ws = wl + lane;
+  const float* We = wl + KS * 64 + lane;
+  const float* Wm = wl + 2 * KS * 64 + lane;
+
+  float acc_s = 0.f, acc_x[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) acc_x[m] = 0.f;
+
+  using Row = WqRow<KS, 1, (NM > 1)>;
+  Row row;
+  wq_row<KS, 1, (NM > 1)>(a, st, lane, 0, rec, nullptr, row);
+  wq_publish<KS, 1, (NM > 1)>(lane, row, stride0, stride1, tbl);
+  __builtin_amdgcn_wave_barrier();
+
+  for (int t = 0; t < st.ntiles; ++t) {
+    const int* tb = tbl + (t & 1) * T_SIZE;
+    int* tnext = tbl + ((t + 1) & 1) * T_SIZE;
+    float R[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) R[s] = row.R[0][s];
+    wq_row<KS, 1, (NM > 1)>(a, st, lane, t + 1, rec, nullptr, row);   // next tile's loads fly under this tile
+    const f32x16 ds = wq_filter<KS>(R, Ws), de = wq_filter<KS>(R, We);
+    f32x16 dm = ds;
+    if constexpr (HAS_S) dm = wq_filter<KS>(R, Wm);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int p0 = 16 * hh + 4 * g, c = 4 * hh + g;
+      uint32_t g0[4], g1[4];
+      wq_tread4<uint32_t>(tb, T_G0 + p0, g0);
+      wq_tread4<uint32_t>(tb, T_G1 + p0, g1);
+      const uint32_t own = (uint32_t)tb[T_QOWN + c];
+      const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
+      float hs[4], he[4], hm[4], xv[4][NM], res_x[NM], res_s = 0.f, Y[NM][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t oh = g0[r] + wc.b_hs, ox = g1[r] + wc.b_x;
+        hs[r] = wq_ld(h, oh);
+        he[r] = wq_ld(h_e, oh);
+        if constexpr (HAS_S) hm[r] = wq_ld(h_m, oh);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) xv[r][m] = wq_ld(xhat_m[m], ox);
+      }
+      const uint32_t ob = own * row_x + wc.b_xe, os = own * row_s + wc.b_s;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) res_x[m] = wq_ld(x_in, ob + 4u * m);   // the owner's residual row: read per quad
+      if constexpr (HAS_S) res_s = wq_ld(s_in, os);                       // (unconditional: no wait inside the store branch)
+      if constexpr (NM > 1) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) wq_tread4<float>(tb, T_Y + 32 * (YOFF + m) + p0, Y[m]);
+      }
+      float xq[NM], sq = 0.f;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) xq[m] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gs = hs[r] * ds[4 * g + r], ge = he[r] * de[4 * g + r];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) xq[m] += xv[r][m] * gs + (NM > 1 ? Y[m][r] : 1.f) * ge;
+        if constexpr (HAS_S) sq += hm[r] * dm[4 * g + r];
+      }
+#pragma unroll
+      for (int m = 0; m < NM; ++m) acc_x[m] = (keep ? acc_x[m] : 0.f) + xq[m];
+      if constexpr (HAS_S) acc_s = (keep ? acc_s : 0.f) + sq;
+      if (last) {   // the node's only store
+#pragma unroll
+        for (int m = 0; m < NM; ++m) wq_st(x_out, ob + 4u * m, res_x[m] + acc_x[m]);
+        if constexpr (HAS_S) wq_st(s_out, os, res_s + acc_s);
+      }
+    }
+    wq_publish<KS, 1, (NM > 1)>(lane, row, stride0, stride1, tnext);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// scheduling fence between the passes of a tile (dev switch: -D'XEQ_WQ_SB()=' compiles them out)
+#ifndef XEQ_WQ_SB
+#define XEQ_WQ_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef XEQ_WQ_FWD_WPE
+#define XEQ_WQ_FWD_WPE 3
+#endif
+#ifndef XEQ_WQ_BWD_WPE
+#define XEQ_WQ_BWD_WPE 3
+#endif
+
+template <int KS>
+__global__ void __launch_bounds__(64 * WQ_WAVES) __attribute__((amdgpu_waves_per_eu(XEQ_WQ_FWD_WPE)))
+k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restrict__ h, const float* __restrict__ xhat,
+                 const float* __restrict__ s_in, const float* __restrict__ x_in, const float* __restrict__ w_rbf,
+                 const float* __restrict__ b_rbf, float* __restrict__ s_out, float* __restrict__ x_out) {
+  __shared__ __attribute__((aligned(16))) int tbl_all[WQ_WAVES][2 * T_SIZE];
+  __shared__ float wl[3 * KS * 64];
+  int range, unit;
+  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], range, unit);
+  const WqUnit un = wq_unit(a, unit);
+  wq_stage_weights<KS>(a, un, w_rbf, b_rbf, wl);
+  __syncthreads();
+  if (range >= a.n_ranges) return;
+  int* tbl = tbl_all[threadIdx.x >> 6];
+  if (un.l == 0) wq_fwd_body<1, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
+  else if (un.l == 1) wq_fwd_body<3, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
+  else wq_fwd_body<5, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
+}
+
+// ------------------------------------------------------------------------------------------------ reverse
+struct WqParts {
+  float* pd;   // [NU][P]      per-unit partial of dL/dd, by padded slot of the reverse walk
+  float* y1;   // [nu1][3][P]  per-unit partial of dL/dY_1m
+  float* y2;   // [nu2][5][P]
+  int64_t P;   // row length (capacity of the padded order)
+};
+
+// Sums over the 32 lanes of each half-wave for the 16 rows of a tile, as a register-halving butterfly: at every step a
+// lane keeps half of its registers (chosen by one bit of its lane id) and adds the partner lane's copy of them, so
+// 8 + 4 + 2 + 1 = 15 (select, select, DPP add) triples replace sixteen five-step trees.  Staged so that a quad's four
+// rows collapse as soon as they exist (wq_red_ab: partners j ^ 1, j ^ 2), and the four quad results of a tile
+// collapse at its end (wq_red_cd: partners j ^ 4, j ^ 8, then the other 16-lane row).  Afterwards lane j of a half
+// holds the total of row  wq_red_row(j) = 4 (2 b2 + b3) + 2 b0 + b1  (b_k = bit k of j) over the half's 32 lanes.
+#define XEQ_WQ_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float wq_red_ab(float r0, float r1, float r2, float r3, bool b0, bool b1) {
+  const float a0 = (b0 ? r2 : r0) + XEQ_WQ_DPP(b0 ? r0 : r2, 0xB1);   // quad_perm [1,0,3,2]: lane j ^ 1
+  const float a1 = (b0 ? r3 : r1) + XEQ_WQ_DPP(b0 ? r1 : r3, 0xB1);
+  return (b1 ? a1 : a0) + XEQ_WQ_DPP(b1 ? a0 : a1, 0x4E);              // quad_perm [2,3,0,1]: lane j ^ 2
+}
+__device__ __forceinline__ float wq_xor4(float v) {   // lane j ^ 4: quad_perm [3,2,1,0] (j ^ 3) then row_half_mirror (j ^ 7)
+  const float t = XEQ_WQ_DPP(v, 0x1B);
+  return XEQ_WQ_DPP(t, 0x141);
+}
+__device__ __forceinline__ float wq_red_cd(float q0, float q1, float q2, float q3, bool b2, bool b3) {
+  const float c0 = (b2 ? q2 : q0) + wq_xor4(b2 ? q0 : q2);
+  const float c1 = (b2 ? q3 : q1) + wq_xor4(b2 ? q1 : q3);
+  float r = (b3 ? c1 : c0) + XEQ_WQ_DPP(b3 ? c0 : c1, 0x128);          // row_ror:8: lane j ^ 8
+  r += __shfl_xor(r, 16, 64);                                          // the half's other 16-lane row
+  return r;
+}
+__device__ __forceinline__ int wq_red_row(int j) { return 4 * (((j >> 2) & 1) * 2 + ((j >> 3) & 1)) + 2 * (j & 1) + ((j >> 1) & 1); }
+
+// One role of the reverse pass, in passes of two accumulators (value and d/dd filter of one kind).  Per quad the owner
+// (neighbor) node's rows are constants:
+//   pass S (state): u_m = sum_r phi_s[r] gx[r][m];  g_hs[n] += <xhat[n], u>;  g_xhat[n][m] += h_s[n] u_m
+//                   pd[r] = h_s[n] <xhat[n], gx[r]> phi_s'[r]
+//   pass E (edge):  g_he[n] += sum_r phi_e[r] <Y[r], gx[r]>;  pd[r] += h_e[n] <Y[r], gx[r]> phi_e'[r]
+//                   dL/dY_m[r] = sum_ch h_e[n] phi_e[r] gx[r][m]
+//   pass M (msg):   g_hm[n] += sum_r phi_m[r] gs[r];  pd[r] += h_m[n] gs[r] phi_m'[r]
+template <int NM, int KS>
+__device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit, const WqUnit un, const float* __restrict__ rec,
+                                            const float* __restrict__ drec, const float* __restrict__ h,
+                                            const float* __restrict__ xhat_, const float* __restrict__ grad_s,
+                                            const float* __restrict__ grad_x, const float* wl, float* __restrict__ grad_h,
+                                            float* __restrict__ grad_xhat_, const WqParts parts, int* tbl) {
+  constexpr bool HAS_S = NM == 1;
+  constexpr int YOFF = NM == 3 ? 0 : 3;
+  const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+  const WqCols wc = wq_cols<NM>(a, un, j);
+  const float* __restrict__ xhat = xhat_ + wc.x_base;
+  float* __restrict__ grad_xhat = grad_xhat_ + wc.x_base;
+  const uint32_t he_off = 4u * (uint32_t)a.C, row_h = 4u * (uint32_t)a.H;
+  wq_for_isolated(a, range, lane, [&](int m) {   // nobody's neighbor: zero gradients on the unit's columns
+    if (hh == 0) {
+      wq_st(grad_h, (uint32_t)m * row_h + wc.b_hs, 0.f);
+      wq_st(grad_h, (uint32_t)m * row_h + wc.b_hs + he_off, 0.f);
+      if constexpr (HAS_S) wq_st(grad_h, (uint32_t)m * row_h + wc.b_hm, 0.f);
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm) wq_st(grad_xhat, (uint32_t)m * wc.xnode_b + wc.b_x + mm * wc.xcomp_b, 0.f);
+    }
+  });
+  const WqStreams st = wq_streams(a, range);
+  if (st.ntiles == 0) return;
+  const uint32_t stride0 = 4u * (uint32_t)a.D, stride1 = 4u * (uint32_t)a.F;   // gathered rows: grad_x, grad_s of the center
+  const float* Ws = wl + lane;
+  const float* We = wl + KS * 64 + lane;
+  const float* Wm = wl + 2 * KS * 64 + lane;
+
+  float a_hs = 0.f, a_he = 0.f, a_hm = 0.f, a_x[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) a_x[m] = 0.f;
+  const int half_beg = hh ? st.q1 : st.q0, half_end = hh ? st.q2 : st.q1;
+  const bool b0 = j & 1, b1 = j & 2, b2 = j & 4, b3 = j & 8;
+  const int my_r = wq_red_row(j);   // the row of a tile whose channel sums this lane holds after the butterfly
+
+  using Row = WqRow<KS, 2, (NM > 1)>;
+  Row row;
+  wq_row<KS, 2, (NM > 1)>(a, st, lane, 0, rec, drec, row);
+  wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tbl);
+  __builtin_amdgcn_wave_barrier();
+
+  for (int t = 0; t < st.ntiles; ++t) {
+    const int* tb = tbl + (t & 1) * T_SIZE;
+    int* tnext = tbl + ((t + 1) & 1) * T_SIZE;
+    float R[KS], Rd[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      R[s] = row.R[0][s];
+      Rd[s] = row.R[1][s];
+    }
+    // gathered gradient rows of one quad (the center's grad_x, NM components per channel)
+    auto load_gx = [&](int g, float (&gxq)[4][NM]) {
+      uint32_t g0[4];
+      wq_tread4<uint32_t>(tb, T_G0 + 16 * hh + 4 * g, g0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) gxq[r][m] = wq_ld(grad_x, g0[r] + wc.b_xe + 4u * m);
+    };
+    float gxs[HAS_S ? 4 : 1][4][1];   // l = 0: the tile's grad_x rows stay in registers for passes S and E
+    if constexpr (HAS_S) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float tmp[4][NM];
+        load_gx(g, tmp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gxs[g][r][0] = tmp[r][0];
+      }
+    }
+    float pd[16];
+    {  // ---- pass S
+      float gxq[4][NM];
+      if constexpr (!HAS_S) load_gx(0, gxq);   // the first quad's rows fly under the MFMAs
+      const f32x16 ds = wq_filter<KS>(R, Ws), qs = wq_filter<KS>(Rd, Ws);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 4 * hh + g;
+        const uint32_t own = (uint32_t)tb[T_QOWN + c];
+        const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
+        const float o_hs = wq_ld(h, own * row_h + wc.b_hs);
+        float o_x[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) o_x[m] = wq_ld(xhat, own * wc.xnode_b + wc.b_x + m * wc.xcomp_b);
+        if constexpr (HAS_S) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gxq[r][0] = gxs[g][r][0];
+        }
+        float u[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) u[m] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = 4 * g + r;
+          float dgs = 0.f;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {
+            u[m] += ds[v] * gxq[r][m];
+            dgs += o_x[m] * gxq[r][m];
+          }
+          pd[v] = (o_hs * dgs) * qs[v];
+        }
+        if constexpr (!HAS_S) {
+          if (g < 3) load_gx(g + 1, gxq);   // rows of the next quad
+        }
+        float hsq = 0.f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) hsq += o_x[m] * u[m];
+        a_hs = (keep ? a_hs : 0.f) + hsq;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) a_x[m] = (keep ? a_x[m] : 0.f) + o_hs * u[m];
+        if (last) {
+          wq_st(grad_h, own * row_h + wc.b_hs, a_hs);
+          const uint32_t ox = own * wc.xnode_b + wc.b_x;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) wq_st(grad_xhat, ox + m * wc.xcomp_b, a_x[m]);
+        }
+        if constexpr (NM > 1) XEQ_WQ_SB();   // one quad's gathered rows in flight beside the one being consumed, not all four
+      }
+    }
+    XEQ_WQ_SB();   // accumulator lifetimes of the passes stay disjoint
+    const int my_q = half_beg + 4 * t + (my_r >> 2);                   // quad of the row this lane reports
+    const bool keeper = j < 16 && my_q < half_end;                     // one 16-lane row per half stores
+    const int64_t my_slot = 4 * (int64_t)my_q + (my_r & 3);
+    {  // ---- pass E
+      float gxq[4][NM];
+      if constexpr (!HAS_S) load_gx(0, gxq);
+      const f32x16 de = wq_filter<KS>(R, We), qe = wq_filter<KS>(Rd, We);
+      float pq[NM > 1 ? NM : 1][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int p0 = 16 * hh + 4 * g, c = 4 * hh + g;
+        const uint32_t own = (uint32_t)tb[T_QOWN + c];
+        const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
+        const float o_he = wq_ld(h, own * row_h + wc.b_hs + he_off);
+        if constexpr (HAS_S) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gxq[r][0] = gxs[g][r][0];
+        }
+        float dge[4], wy[4], heq = 0.f;   // dge[r] = <Y[r], gx[r]>, one component at a time (few live values)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dge[r] = NM > 1 ? 0.f : gxq[r][0];
+        if constexpr (NM > 1) {
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {
+            float Ym[4];
+            wq_tread4<float>(tb, T_Y + 32 * (YOFF + m) + p0, Ym);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dge[r] += Ym[r] * gxq[r][m];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = 4 * g + r;
+          heq += de[v] * dge[r];
+          pd[v] += (o_he * dge[r]) * qe[v];
+          wy[r] = o_he * de[v];
+        }
+        if constexpr (NM > 1) {   // dL/dY_lm of the quad's rows: first half of the sum over the unit's 32 channels
+#pragma unroll
+          for (int m = 0; m < NM; ++m)
+            pq[m][g] = wq_red_ab(wy[0] * gxq[0][m], wy[1] * gxq[1][m], wy[2] * gxq[2][m], wy[3] * gxq[3][m], b0, b1);
+        }
+        if constexpr (!HAS_S) {
+          if (g < 3) load_gx(g + 1, gxq);
+        }
+        a_he = (keep ? a_he : 0.f) + heq;
+        if (last) wq_st(grad_h, own * row_h + wc.b_hs + he_off, a_he);
+        if constexpr (NM > 1) XEQ_WQ_SB();
+      }
+      if constexpr (NM > 1) {
+        float* dst = NM == 3 ? parts.y1 : parts.y2;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const float tot = wq_red_cd(pq[m][0], pq[m][1], pq[m][2], pq[m][3], b2, b3);
+          if (keeper) dst[((int64_t)un.cb * NM + m) * parts.P + my_slot] = tot;
+        }
+      }
+    }
+    XEQ_WQ_SB();
+    if constexpr (HAS_S) {  // ---- pass M
+      float gsv[16];          // the centers' grad_s rows: only this pass reads them; they land under its MFMAs
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint32_t g1[4];
+        wq_tread4<uint32_t>(tb, T_G1 + 16 * hh + 4 * g, g1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gsv[4 * g + r] = wq_ld(grad_s, g1[r] + wc.b_s);
+      }
+      const f32x16 dm = wq_filter<KS>(R, Wm), qm = wq_filter<KS>(Rd, Wm);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = 4 * hh + g;
+        const uint32_t own = (uint32_t)tb[T_QOWN + c];
+        const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
+        const float o_hm = wq_ld(h, own * row_h + wc.b_hm);
+        float hmq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = 4 * g + r;
+          hmq += dm[v] * gsv[v];
+          pd[v] += (o_hm * gsv[v]) * qm[v];
+        }
+        a_hm = (keep ? a_hm : 0.f) + hmq;
+        if (last) wq_st(grad_h, own * row_h + wc.b_hm, a_hm);
+      }
+    }
+    XEQ_WQ_SB();
+    wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row);   // the next tile's records land under the channel sums
+    {  // ---- dL/dd of every row's edge: sum over the unit's 32 channels
+      float pq[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pq[g] = wq_red_ab(pd[4 * g], pd[4 * g + 1], pd[4 * g + 2], pd[4 * g + 3], b0, b1);
+      const float tot = wq_red_cd(pq[0], pq[1], pq[2], pq[3], b2, b3);
+      if (keeper) parts.pd[(int64_t)unit * parts.P + my_slot] = tot;
+    }
+    wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tnext);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(64 * WQ_WAVES) __attribute__((amdgpu_waves_per_eu(XEQ_WQ_BWD_WPE)))
+k_message_bwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restrict__ drec, const float* __restrict__ h,
+                 const float* __restrict__ xhat, const float* __restrict__ grad_s, const float* __restrict__ grad_x,
+                 const float* __restrict__ w_rbf, const float* __restrict__ b_rbf, float* __restrict__ grad_h,
+                 float* __restrict__ grad_xhat, WqParts parts) {
+  __shared__ __attribute__((aligned(16))) int tbl_all[WQ_WAVES][2 * T_SIZE];
+  __shared__ float wl[3 * KS * 64];
+  int range, unit;
+  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], range, unit);
+  const WqUnit un = wq_unit(a, unit);
+  wq_stage_weights<KS>(a, un, w_rbf, b_rbf, wl);
+  __syncthreads();
+  if (range >= a.n_ranges) return;
+  int* tbl = tbl_all[threadIdx.x >> 6];
+#ifdef XEQ_WQ_ONLY_L   // development: register budget of one role
+  if (un.l == XEQ_WQ_ONLY_L)
+    wq_bwd_body<2 * XEQ_WQ_ONLY_L + 1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+  return;
+#endif
+  if (un.l == 0) wq_bwd_body<1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+  else if (un.l == 1) wq_bwd_body<3, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+  else wq_bwd_body<5, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+}
+
+// dL/dvec from the per-unit partials (by padded slot of the reverse walk), summed in unit order (deterministic),
+// chain rule of A1-A3; one thread per padded slot, pads skipped
+__global__ void k_wq_edge_grad(const float* __restrict__ vec, const int32_t* __restrict__ peid, const int32_t* __restrict__ qptr,
+                               int64_t N, int64_t P, int nu, int nu1, int nu2, const float* __restrict__ pd,
+                               const float* __restrict__ y1, const float* __restrict__ y2, float* __restrict__ grad_vec) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P || p >= 4 * (int64_t)qptr[N]) return;
+  const int32_t e = peid[p];
+  if (e < 0) return;
+  float gd = 0.f, q1[3] = {0.f, 0.f, 0.f}, q2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < nu; ++u) gd += pd[(int64_t)u * P + p];
+  for (int u = 0; u < nu1; ++u)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) q1[m] += y1[((int64_t)u * 3 + m) * P + p];
+  for (int u = 0; u < nu2; ++u)
+#pragma unroll
+    for (int m = 0; m < 5; ++m) q2[m] += y2[((int64_t)u * 5 + m) * P + p];
+  const EdgeGeom<float> g = edge_geom<float>(vec[3 * (int64_t)e], vec[3 * (int64_t)e + 1], vec[3 * (int64_t)e + 2]);
+  float out[3];
+  edge_grad<float>(g, gd, q1, q2, out);
+  grad_vec[3 * (int64_t)e] = out[0];
+  grad_vec[3 * (int64_t)e + 1] = out[1];
+  grad_vec[3 * (int64_t)e + 2] = out[2];
+}
+
+static bool wq_supported(int num_basis, int node_dim, const int32_t mul[3]) {
+  return num_basis >= 1 && num_basis <= 23 && mul[0] == node_dim && mul[0] > 0 && mul[0] % 32 == 0 && mul[1] >= 0 &&
+         mul[1] % 32 == 0 && mul[2] >= 0 && mul[2] % 32 == 0;
+}
+// padded slots: at most E + 3 per node that has an edge; the capacity every buffer of a plan is sized for
+static int64_t wq_pcap(int64_t n_nodes, int64_t n_edges) {
+  const int64_t with_edges = n_nodes < n_edges ? n_nodes : n_edges;
+  return (n_edges + 3 * with_edges + 3) / 4 * 4;
+}
+// 32-bit byte offsets: rows of h (n_nodes * H * 4) and records (pcap * 128)
+static bool wq_fits(int64_t n_nodes, int64_t n_edges, int node_dim, const int32_t mul[3]) {
+  const int64_t H = node_dim + 2 * (int64_t)(mul[0] + mul[1] + mul[2]);
+  return n_nodes >= 0 && n_edges >= 0 && n_nodes * H * 4 < (1ll << 32) && wq_pcap(n_nodes, n_edges) * (int64_t)WQ_REC * 4 < (1ll << 32);
+}
+
+static int wq_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ranges, int num_basis, int node_dim,
+                    const int32_t mul[3], WqArgs& a) {
+  XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (1ll << 31) && n_nodes < (1ll << 30), "%s: bad sizes", who);
+  XEQ_CHECK_ARG(n_ranges >= 1, "%s: the stream table must cover every node (n_ranges >= 1)", who);
+  if (!wq_supported(num_basis, node_dim, mul)) {
+    xeq::set_error("%s: the wave / quad form needs node_dim == mul[0], multiplicities in multiples of 32 and num_basis <= 23", who);
+    return XEQ_ERR_UNSUPPORTED;
+  }
+  XEQ_CHECK_ARG(wq_fits(n_nodes, n_edges, node_dim, mul), "%s: tensors too large for 32-bit byte offsets (shard the batch)", who);
+  for (int l = 0; l < 3; ++l) a.ir.mul[l] = mul[l];
+  a.C = a.ir.C();
+  a.D = a.ir.D();
+  a.F = node_dim;
+  a.H = a.F + 2 * a.C;
+  a.B = num_basis;
+  for (int l = 0; l < 3; ++l) a.nu[l] = mul[l] / 32;
+  a.n_nodes = n_nodes;
+  a.n_edges = n_edges;
+  a.pcap = wq_pcap(n_nodes, n_edges);
+  a.n_ranges = n_ranges;
+  return XEQ_OK;
+}
+
+static unsigned wq_grid(int n_ranges, int nunits) {
+  int64_t blocks = (int64_t)((n_ranges + WQ_WAVES - 1) / WQ_WAVES) * nunits;   // one workgroup per (range group, unit)
+  if (blocks >= 64) blocks = (blocks + 7) / 8 * 8;   // multiple of 8: XCD-aware item order (wq_decode)
+  return (unsigned)blocks;
+}
+
+}  // namespace xeq
+
+using namespace xeq;
+
+// KS covers K = B + 1 (bias column) in steps of two
+#define XEQ_WQ_DISPATCH(KERNEL, ...)                                                                                   \
+  do {                                                                                                                 \
+    const int ks = (num_basis + 2) / 2;                                                                                \
+    if (ks <= 6) hipLaunchKernelGGL((KERNEL<6>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);      \
+    else if (ks <= 11) hipLaunchKernelGGL((KERNEL<11>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<12>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);             \
+  } while (0)
+
+extern "C" {
+
+int xeq_message_wq_supported(int num_basis, int node_dim, const int32_t mul[3]) { return wq_supported(num_basis, node_dim, mul) ? 1 : 0; }
+
+int xeq_message_wq_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
+  return wq_supported(num_basis, node_dim, mul) && n_nodes < (1ll << 30) && wq_fits(n_nodes, n_edges, node_dim, mul) ? 1 : 0;
+}
+
+int64_t xeq_message_wq_pcap(int64_t n_nodes, int64_t n_edges) { return wq_pcap(n_nodes, n_edges); }
+
+int64_t xeq_message_wq_plan_workspace(int64_t n_nodes) {
+  size_t temp = 0;
+  QuadCount op{nullptr, n_nodes};
+  hipcub::CountingInputIterator<int64_t> cnt(0);
+  hipcub::TransformInputIterator<int32_t, QuadCount, hipcub::CountingInputIterator<int64_t>> it(cnt, op);
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, temp, it, (int32_t*)nullptr, (int)(n_nodes + 1)) != hipSuccess) return -1;
+  return (int64_t)temp + 256;
+}
+
+int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_t* owner, const int64_t* gather,
+                        int64_t n_nodes, int64_t n_edges, int n_ranges, void* workspace, int64_t workspace_bytes,
+                        int32_t* qptr, int32_t* pgath, int32_t* peid, int32_t* qinfo, int32_t* sq, int32_t* sn, void* stream) {
+  XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_ranges >= 1 && n_nodes < (1ll << 30) && n_edges < (1ll << 31), "xeq_message_wq_plan: bad sizes");
+  const int64_t need = xeq_message_wq_plan_workspace(n_nodes);
+  XEQ_CHECK_ARG(need >= 0 && workspace_bytes >= need, "xeq_message_wq_plan: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
+  QuadCount op{rowptr, n_nodes};
+  hipcub::CountingInputIterator<int64_t> cnt(0);
+  hipcub::TransformInputIterator<int32_t, QuadCount, hipcub::CountingInputIterator<int64_t>> it(cnt, op);
+  size_t temp = (size_t)workspace_bytes;
+  if (hipcub::DeviceScan::ExclusiveSum(workspace, temp, it, qptr, (int)(n_nodes + 1), (hipStream_t)stream) != hipSuccess) {
+    xeq::set_error("xeq_message_wq_plan: scan failed");
+    return XEQ_ERR_LAUNCH;
+  }
+  if (n_edges > 0) {
+    hipLaunchKernelGGL(k_wq_fill, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_edges, rowptr,
+                       perm, owner, gather, (const int32_t*)qptr, pgath, peid, (uint32_t*)qinfo);
+    XEQ_CHECK_LAUNCH("xeq_message_wq_plan (fill)");
+  }
+  const int n = 2 * n_ranges + 1;
+  hipLaunchKernelGGL(k_wq_streams, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const int32_t*)qptr,
+                     n_nodes, n_ranges, sq, sn);
+  XEQ_CHECK_LAUNCH("xeq_message_wq_plan (streams)");
+  return XEQ_OK;
+}
+
+int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
+                      int rbf_kind, int cutoff_kind, int num_basis, double cutoff, const void* p0, const void* p1,
+                      void* basis, void* dbasis, void* stream) {
+  XEQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 0 && num_basis >= 1 && num_basis <= 23 && cutoff > 0, "xeq_edge_basis_wq: bad sizes");
+  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_edge_basis_wq: rbf kernel %d is not implemented", rbf_kind);
+  XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
+  XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
+  if (n_edges == 0) return XEQ_OK;
+  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * WQ_REC;
+  XEQ_CHECK_ARG(total < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
+  RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
+  hipLaunchKernelGGL(k_wq_records, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
+                     peid, qptr, n_nodes, pcap, rs, (const float*)p0, (const float*)p1, (float*)basis, (float*)dbasis);
+  XEQ_CHECK_LAUNCH("xeq_edge_basis_wq");
+  return XEQ_OK;
+}
+
+int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn,
+                       const int32_t* c_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis, const void* h,
+                       const void* xhat, const void* s_in, const void* x_in, const void* w_rbf, const void* b_rbf,
+                       int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out, int xhat_layout,
+                       void* stream) {
+  WqArgs a{};
+  int rcode = wq_check("xeq_message_fwd_wq", n_nodes, n_edges, n_ranges, num_basis, node_dim, mul, a);
+  if (rcode != XEQ_OK) return rcode;
+  if (n_nodes == 0) return XEQ_OK;
+  a.sq = sq;
+  a.sn = sn;
+  a.rowptr = c_rowptr;
+  a.pgath = pgath;
+  a.qinfo = (const uint32_t*)qinfo;
+  a.xl = xhat_layout;
+  const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
+  dim3 grid(wq_grid(n_ranges, nunits));
+  XEQ_WQ_DISPATCH(k_message_fwd_wq, a, (const float*)basis, (const float*)h, (const float*)xhat, (const float*)s_in,
+                  (const float*)x_in, (const float*)w_rbf, (const float*)b_rbf, (float*)s_out, (float*)x_out);
+  XEQ_CHECK_LAUNCH("xeq_message_fwd_wq");
+  return XEQ_OK;
+}
+
+int64_t xeq_message_wq_parts_floats(int64_t n_nodes, int64_t n_edges, const int32_t mul[3]) {
+  return wq_pcap(n_nodes, n_edges) * (int64_t)(mul[0] / 32 + mul[1] / 32 + mul[2] / 32 + 3 * (mul[1] / 32) + 5 * (mul[2] / 32));
+}
+
+int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn,
+                       const int32_t* n_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis,
+                       const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
+                       const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,
+                       void* grad_xhat, void* parts, int xhat_layout, void* stream) {
+  WqArgs a{};
+  int rcode = wq_check("xeq_message_bwd_wq", n_nodes, n_edges, n_ranges, num_basis, node_dim, mul, a);
+  if (rcode != XEQ_OK) return rcode;
+  if (n_nodes == 0) return XEQ_OK;
+  a.sq = sq;
+  a.sn = sn;
+  a.rowptr = n_rowptr;
+  a.pgath = pgath;
+  a.qinfo = (const uint32_t*)qinfo;
+  a.xl = xhat_layout;
+  const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
+  WqParts pr;
+  pr.P = a.pcap;
+  pr.pd = (float*)parts;
+  pr.y1 = pr.pd + (int64_t)nunits * pr.P;
+  pr.y2 = pr.y1 + (int64_t)a.nu[1] * 3 * pr.P;
+  dim3 grid(wq_grid(n_ranges, nunits));
+  XEQ_WQ_DISPATCH(k_message_bwd_wq, a, (const float*)basis, (const float*)dbasis, (const float*)h, (const float*)xhat,
+                  (const float*)grad_s, (const float*)grad_x, (const float*)w_rbf, (const float*)b_rbf, (float*)grad_h,
+                  (float*)grad_xhat, pr);
+  XEQ_CHECK_LAUNCH("xeq_message_bwd_wq");
+  return XEQ_OK;
+}
+
+int xeq_message_wq_edge_grad(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
+                             const int32_t mul[3], const void* parts, void* grad_vec, void* stream) {
+  XEQ_CHECK_ARG(n_edges >= 0 && mul[0] % 32 == 0 && mul[1] % 32 == 0 && mul[2] % 32 == 0, "xeq_message_wq_edge_grad: bad sizes");
+  if (n_edges == 0) return XEQ_OK;
+  const int64_t P = wq_pcap(n_nodes, n_edges);
+  const int nu1 = mul[1] / 32, nu2 = mul[2] / 32, nunits = mul[0] / 32 + nu1 + nu2;
+  const float* pd = (const float*)parts;
+  const float* y1 = pd + (int64_t)nunits * P;
+  const float* y2 = y1 + (int64_t)nu1 * 3 * P;
+  hipLaunchKernelGGL(k_wq_edge_grad, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
+                     peid, qptr, n_nodes, P, nunits, nu1, nu2, pd, y1, y2, (float*)grad_vec);
+  XEQ_CHECK_LAUNCH("xeq_message_wq_edge_grad");
+  return XEQ_OK;
+}
+
+}  // extern "C"

@@ -74,6 +74,18 @@ _PROTOS = {
     "xeq_message_bwd_wm": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                            _I3, _P, _P, _P, c_int, _P],
     "xeq_message_wm_parts_floats": [c_int64, _I3],
+    "xeq_message_wq_supported": [c_int, c_int, _I3],
+    "xeq_message_wq_fits": [c_int64, c_int64, c_int, c_int, _I3],
+    "xeq_message_wq_pcap": [c_int64, c_int64],
+    "xeq_message_wq_plan_workspace": [c_int64],
+    "xeq_message_wq_plan": [_P, _P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P],
+    "xeq_edge_basis_wq": [_P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
+    "xeq_message_fwd_wq": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3,
+                           _P, _P, c_int, _P],
+    "xeq_message_wq_parts_floats": [c_int64, c_int64, _I3],
+    "xeq_message_bwd_wq": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
+                           _I3, _P, _P, _P, c_int, _P],
+    "xeq_message_wq_edge_grad": [_P, c_int64, c_int64, _P, _P, _I3, _P, _P, _P],
     "xeq_message_wm_edge_grad": [_P, c_int64, _I3, _P, _P, _P, _P],
     "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
     "xeq_norm_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
@@ -83,7 +95,8 @@ _PROTOS = {
     "xeq_update_out_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P, _P],
 }
 # entry points that return a size, not a status
-_RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace"}
+_RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
+            "xeq_message_wq_parts_floats"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None

@@ -95,6 +95,7 @@ class EdgeGraph:
         require_hip(edge_index)
         self.ptr = ptr          # graph boundaries [G+1] (keys.BATCH_PTR), when the caller knows them
         self._wm = None
+        self._wq = None
         self._basis = self._basis_wm = None   # per-edge records of the current geometry (edge_basis / edge_basis_wm)
         assert edge_index.dim() == 2 and edge_index.shape[0] == 2 and edge_index.dtype == torch.int64
         self.edge_index = edge_index = edge_index.contiguous()
@@ -134,11 +135,47 @@ class EdgeGraph:
             plan = self._wm[key] = {"n_ranges": n_ranges, "stream_ptr": sp, "rowptr": rowptr, "perm": perm}
         return plan
 
-    def refresh_wm_plans(self) -> None:
-        """Recompute the cached stream tables in place after the CSR arrays were overwritten (HIP-graph replay)."""
+    def wq_plan(self, reverse: bool, edges_per_stream: int = 128):
+        """Walk plan of the wave / quad message kernels (xeq_message_wq_plan): every node's edge list padded to whole
+        quads (four slots), per padded slot the gathered node and the edge id, per quad the owner and its first / last
+        flags, stream boundaries on quads.  Depends on the graph only, not on the positions."""
+        key = (bool(reverse), int(edges_per_stream))
+        if self._wq is None:
+            self._wq = {}
+        plan = self._wq.get(key)
+        if plan is None:
+            L = lib.load()
+            N, E, dev = self.n_nodes, self.n_edges, self.edge_index.device
+            pcap = int(L.xeq_message_wq_pcap(N, E))
+            n_ranges = max(1, -(-E // (2 * edges_per_stream)))
+            i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+            plan = {"reverse": bool(reverse), "n_ranges": n_ranges, "pcap": pcap, "qptr": i32(N + 1), "pgath": i32(pcap),
+                    "peid": i32(pcap), "qinfo": i32(pcap // 4), "sq": i32(2 * n_ranges + 1), "sn": i32(2 * n_ranges + 1),
+                    "work": torch.empty(max(int(L.xeq_message_wq_plan_workspace(N)), 1), dtype=torch.uint8, device=dev),
+                    "records": None}
+            self._wq[key] = plan
+            self._build_wq_plan(plan)
+        return plan
+
+    def _build_wq_plan(self, plan) -> None:
+        rev = plan["reverse"]
+        rowptr, perm = (self.n_rowptr, self.n_perm) if rev else (self.c_rowptr, self.c_perm)
+        owner, gather = (self.edge_index[1], self.edge_index[0]) if rev else (self.edge_index[0], self.edge_index[1])
+        plan["rowptr"] = rowptr
+        call("xeq_message_wq_plan", ptr(rowptr), ptr(perm), ptr(owner), ptr(gather), self.n_nodes, self.n_edges, plan["n_ranges"],
+             ptr(plan["work"]), plan["work"].numel(), ptr(plan["qptr"]), ptr(plan["pgath"]), ptr(plan["peid"]), ptr(plan["qinfo"]),
+             ptr(plan["sq"]), ptr(plan["sn"]), stream())
+
+    def refresh_plans(self) -> None:
+        """Recompute the cached stream tables / walk plans in place after the CSR arrays were overwritten (HIP-graph
+        replay: same sizes, new contents)."""
         for plan in (self._wm or {}).values():
             call("xeq_message_wm_streams", ptr(plan["rowptr"]), self.n_nodes, self.n_edges, plan["n_ranges"],
                  ptr(plan["stream_ptr"]), stream())
+        for plan in (self._wq or {}).values():
+            self._build_wq_plan(plan)
+
+    refresh_wm_plans = refresh_plans   # earlier name
 
 
 _CELL_LIST_MIN_ATOMS = 512   # average atoms per graph from which the bin grid replaces the O(n_g^2) sweep
@@ -293,6 +330,8 @@ class EdgeVectors(Function):
         call("xeq_edge_vectors_fwd", dtype_code(pos), ptr(pos_c), ptr(graph.edge_index), E, ptr(cell), ptr(cell_offsets),
              ptr(batch), ptr(vec), ptr(dist), stream())
         graph._basis = graph._basis_wm = None   # records of an earlier geometry on this graph
+        for plan in (graph._wq or {}).values():
+            plan["records"] = None
         ctx.graph = graph
         ctx.graph_ptr = graph_ptr
         ctx.n_graphs = None if strain is None else strain.shape[0]
@@ -491,7 +530,7 @@ def radial_basis(dist, rbf_kind: str, cutoff_kind: str, num_basis: int, cutoff: 
 
 
 # ------------------------------------------------------------------- fused message
-_MESSAGE_IMPLS = ("auto", "wm", "sb", "generic")
+_MESSAGE_IMPLS = ("auto", "wq", "wm", "sb", "generic")
 
 
 def _message_impl() -> str:
@@ -506,17 +545,22 @@ def _message_impl() -> str:
 
 
 def select_message_impl(dtype, n_nodes: int, n_edges: int, num_basis: int, node_dim: int, mul) -> str:
-    """Kernel family of the fused message for this configuration AND these sizes.  ``auto``: the wave / matrix-core
-    form (f32, multiplicities in multiples of 32, 32-bit byte offsets: ~1.8 M atoms / 14.9 M edges with the default
-    model), else the scalar-broadcast form (f32 / f64, at most 256 channels, 32-bit element offsets), else the generic
+    """Kernel family of the fused message for this configuration AND these sizes.  ``auto``: the wave / quad matrix-core
+    form (f32, multiplicities in multiples of 32, num_basis <= 23, 32-bit byte offsets: ~1.8 M atoms / ~28 M padded edge
+    slots with the default model), else its predecessor wm (num_basis <= 31), else the scalar-broadcast form (f32 / f64, at most 256 channels, 32-bit element offsets), else the generic
     form (64-bit offsets).  An explicit XEQ_MESSAGE_IMPL is taken as is: its kernels raise when they do not fit."""
     impl = _message_impl()
     if impl != "auto":
         if impl == "wm" and not wm_supported(dtype, num_basis, node_dim, mul):
             raise RuntimeError("XEQ_MESSAGE_IMPL=wm: this configuration does not fit the matrix-core kernels "
                                "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 31)")
+        if impl == "wq" and not (dtype == torch.float32 and lib.load().xeq_message_wq_supported(int(num_basis), int(node_dim), mul3(mul))):
+            raise RuntimeError("XEQ_MESSAGE_IMPL=wq: this configuration does not fit the matrix-core kernels "
+                               "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 23)")
         return impl
     L = lib.load()
+    if dtype == torch.float32 and L.xeq_message_wq_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
+        return "wq"
     if dtype == torch.float32 and L.xeq_message_wm_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
         return "wm"
     if L.xeq_message_sb_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
@@ -567,6 +611,23 @@ def edge_basis_wm(vec, graph: "EdgeGraph", rbf_kind, cutoff_kind, num_basis, cut
     return basis, dbasis
 
 
+def edge_basis_wq(vec, plan, n_nodes, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv: bool):
+    """Per-edge records of the wave / quad kernels in the PADDED WALK ORDER of `plan` (xeq_edge_basis_wq), once per
+    evaluation and direction, cached on the plan: value records for the forward walk, value + d/dd records for the
+    reverse walk."""
+    key = (rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version, bool(deriv))
+    cached = plan["records"]
+    if _basis_cache_hit(cached, vec, key):
+        return cached[2], cached[3]
+    E = vec.shape[0]
+    basis = torch.empty((plan["pcap"], 32), dtype=vec.dtype, device=vec.device)
+    dbasis = torch.empty((plan["pcap"], 32), dtype=vec.dtype, device=vec.device) if deriv else None
+    call("xeq_edge_basis_wq", ptr(vec), n_nodes, E, ptr(plan["qptr"]), ptr(plan["peid"]), lib.RBF_KINDS[rbf_kind],
+         lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff), ptr(p0), ptr(p1), ptr(basis), ptr(dbasis), stream())
+    plan["records"] = (vec, key, basis, dbasis)
+    return basis, dbasis
+
+
 def edge_basis(vec, graph: EdgeGraph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1):
     """Per-edge radial / angular records (xeq_edge_basis), computed once per evaluation and cached
     on the graph: the three message blocks and both directions share them."""
@@ -599,6 +660,13 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
     assert s.shape == (N, node_dim) and x.shape == (N, D) and w_rbf.shape == (node_dim + 2 * C, num_basis)
     s_out, x_out = torch.empty_like(s), torch.empty_like(x)
     impl = select_message_impl(h.dtype, N, E, num_basis, node_dim, mul)
+    if impl == "wq":
+        plan = graph.wq_plan(False, _wm_edges_per_stream(E, N))
+        basis, _ = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv=False)
+        KERNEL_TIMER.launch("xeq_message_fwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["rowptr"]),
+                            ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf),
+                            ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
+        return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, None, None), impl
     if impl == "wm":
         basis, dbasis = edge_basis_wm(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
         plan = graph.wm_plan(False, _wm_edges_per_stream(E, N))
@@ -630,7 +698,17 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x):
     g_x = torch.zeros((graph.n_nodes, D), dtype=h.dtype, device=h.device) if g_x is None else g_x.contiguous()
     g_h, g_xhat = torch.empty_like(h), torch.empty_like(xhat)
     g_vec = torch.empty_like(vec)  # written at the edge's own position by every kernel family
-    if impl == "wm":
+    if impl == "wq":
+        N, E = graph.n_nodes, graph.n_edges
+        plan = graph.wq_plan(True, _wm_edges_per_stream(E, N))
+        basis, dbasis = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv=True)
+        parts = torch.empty(max(1, lib.load().xeq_message_wq_parts_floats(N, E, mul3(mul))), dtype=h.dtype, device=h.device)
+        KERNEL_TIMER.launch("xeq_message_bwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["rowptr"]),
+                            ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x),
+                            ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream())
+        call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), mul3(mul), ptr(parts), ptr(g_vec),
+             stream())
+    elif impl == "wm":
         plan = graph.wm_plan(True, _wm_edges_per_stream(graph.n_edges, graph.n_nodes))
         parts = torch.empty(lib.load().xeq_message_wm_parts_floats(graph.n_edges, mul3(mul)), dtype=h.dtype, device=h.device)
         KERNEL_TIMER.launch("xeq_message_bwd_wm", graph.n_nodes, graph.n_edges, plan["n_ranges"], ptr(plan["stream_ptr"]),

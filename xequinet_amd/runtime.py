@@ -123,7 +123,7 @@ class GraphedModel:
         s.n_perm.copy_(eg.n_perm, non_blocking=True)
         if s.c_perm is not None:
             s.c_perm.copy_(eg.c_perm, non_blocking=True)
-        s.refresh_wm_plans()
+        s.refresh_plans()
 
     # --------------------------------------------------------------------- call
     def __call__(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
