@@ -309,31 +309,38 @@ int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul
  *     neighbor; reverse: neighbor / center).  Outputs, sized for P = xeq_message_wq_pcap(N, E) padded slots:
  *     qptr[N+1] (first quad per node), pgath[P] (gathered node per padded slot), peid[P] (edge id, -1 for pads),
  *     qinfo[P/4] (owner | first << 30 | last << 31 per quad), sq / sn[2 n_ranges + 1] (quad / node boundaries of the
- *     streams, on segment starts at about equal quad counts).  workspace: xeq_message_wq_plan_workspace(N) bytes.
+ *     streams, on segment starts at about equal quad counts), win[2 ceil(n_ranges / xeq_message_wq_waves())] (per STEP = that many consecutive
+ *     ranges, walked together by the waves of a workgroup: first gathered node and row count of the window that
+ *     holds every node the step gathers from).  workspace: xeq_message_wq_plan_workspace(N) bytes.
  *     Depends on the graph only, not on the positions.
  *   xeq_edge_basis_wq: per-edge records IN PADDED WALK ORDER, basis / dbasis [P, 32] floats
  *     ([12 even k | 12 odd k | Y1[3] Y2[5]], value and d/dd; dbasis may be NULL), once per evaluation and direction.
- *   xeq_message_fwd_wq / _bwd_wq: as the _wm entries; rowptr is the CSR of the walk order (nodes without edges keep
+ *   xeq_message_fwd_wq / _bwd_wq: as the _wm entries.  A workgroup walks a chunk of steps; per step it stages the window's
+ *     rows (the unit's columns of h and xhat, or of grad_x and grad_s) in LDS with 16-byte loads when they fit 48 KB --
+ *     batches of molecules: a few molecules -- and the per-row gathers become LDS reads; a step whose window does not fit
+ *     (periodic systems, large graphs) gathers from global memory. rowptr is the CSR of the walk order (nodes without edges keep
  *     s_in / x_in, or get zero gradients).  parts[xeq_message_wq_parts_floats(N, E, mul)]: per-unit partials of dL/dd
  *     and dL/dY_lm by padded slot of the reverse walk; xeq_message_wq_edge_grad sums them in fixed unit order into
  *     grad_vec[E,3] at the edge's own position. */
 int xeq_message_wq_supported(int num_basis, int node_dim, const int32_t mul[3]);   /* 1 / 0, not a status */
 int xeq_message_wq_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]);   /* 1 / 0 */
 int64_t xeq_message_wq_pcap(int64_t n_nodes, int64_t n_edges);                      /* a size, not a status */
+int xeq_message_wq_waves(void);   /* ranges per step (= waves per workgroup): win holds 2 ceil(n_ranges / that) entries */
 int64_t xeq_message_wq_plan_workspace(int64_t n_nodes);                             /* bytes, -1 on failure */
 int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_t* owner, const int64_t* gather,
                         int64_t n_nodes, int64_t n_edges, int n_ranges, void* workspace, int64_t workspace_bytes,
-                        int32_t* qptr, int32_t* pgath, int32_t* peid, int32_t* qinfo, int32_t* sq, int32_t* sn, void* stream);
+                        int32_t* qptr, int32_t* pgath, int32_t* peid, int32_t* qinfo, int32_t* sq, int32_t* sn, int32_t* win,
+                        void* stream);
 int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
                       int rbf_kind, int cutoff_kind, int num_basis, double cutoff, const void* p0, const void* p1,
                       void* basis, void* dbasis, void* stream);
-int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn,
+int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* c_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis, const void* h,
                        const void* xhat, const void* s_in, const void* x_in, const void* w_rbf, const void* b_rbf,
                        int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out, int xhat_layout,
                        void* stream);
 int64_t xeq_message_wq_parts_floats(int64_t n_nodes, int64_t n_edges, const int32_t mul[3]);   /* a size, not a status */
-int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn,
+int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* n_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis,
                        const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
                        const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,

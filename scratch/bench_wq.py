@@ -48,3 +48,19 @@ for impl in args or ["wq"]:
         errs.append(f"{n} {float((a - r).abs().max()) / max(1.0, float(r.abs().max())):.1e}{'' if torch.equal(a, a2) else ' NOT-REPRODUCIBLE'}")
     run(impl)
     print(impl, {k: f"{v:.1f} us" for k, v in timeit(impl).items()}, "| rel err vs sb:", ", ".join(errs))
+if os.environ.get("XEQ_WQ_STAMPS"):
+    import ctypes
+    from xequinet_amd import lib
+    L = lib.load()
+    buf = (ctypes.c_ulonglong * 16)()
+    L.xeq_wq_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+    L.xeq_wq_debug_stamps(buf)            # clear
+    os.environ["XEQ_MESSAGE_IMPL"] = "wq"
+    hh, xx, vv = h.clone(), xhat.clone(), vec.clone()
+    ops.FusedMessage.apply(hh, xx, vv, s, x, W, bias, p0, None, g, cfg); torch.cuda.synchronize()
+    L.xeq_wq_debug_stamps(buf)
+    names = ["step head", "window staging", "barrier after staging", "body prologue", "wait for record", "phase A issue", "phase B issue",
+             "MFMA issue", "phase D rows+stores", "publish next table", "barrier after step"]
+    tot = sum(buf[:11]); nw = buf[15]
+    print(f"forward kernel, l = 0 waves ({nw}): cycles by phase, one launch; {tot / max(nw, 1):.0f} cycles per wave")
+    for n, v in zip(names, buf): print(f"  {n:26s} {v / tot * 100:5.1f} %   {v / max(nw, 1):9.0f} per wave")

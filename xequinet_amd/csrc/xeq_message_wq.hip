@@ -25,6 +25,7 @@
 #include "xeq_common.h"
 
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 namespace xeq {
 
@@ -35,7 +36,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int WQ_REC = 32;                 // floats per record: [12 even k | 12 odd k | Y1[3] Y2[5]]
 constexpr int WQ_KH = 12;                  // floats per k-parity half of a record
 constexpr uint32_t WQ_FIRST = 1u << 30, WQ_LAST = 1u << 31, WQ_OWNER = (1u << 30) - 1u;
-constexpr int WQ_WAVES = 4;                // waves per workgroup (independent of one another after the weight staging)
+#ifndef XEQ_WQ_WAVES
+#define XEQ_WQ_WAVES 4
+#endif
+constexpr int WQ_WAVES = XEQ_WQ_WAVES;     // waves per workgroup: they share the unit's weights and, step by step, the window
 
 // ------------------------------------------------------------------------------------------------ walk plan
 struct QuadCount {
@@ -90,6 +94,33 @@ __global__ void k_wq_streams(const int32_t* __restrict__ qptr, int64_t N, int n_
   sn[k] = (int32_t)lo;
 }
 
+// win[2 s], win[2 s + 1]: first gathered node and number of rows of the WINDOW of step s = the WQ_WAVES consecutive
+// ranges one workgroup walks together: every node its 2 WQ_WAVES streams gather from lies in [w0, w0 + rows).  One wave
+// per step.  For batches of molecules the window is the few molecules the step touches.
+__global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __restrict__ pgath, int n_ranges, int n_steps,
+                             int32_t* __restrict__ win) {
+  const int step = blockIdx.x, lane = threadIdx.x;
+  if (step >= n_steps) return;
+  const int k0 = 2 * WQ_WAVES * step, k1 = min(k0 + 2 * WQ_WAVES, 2 * n_ranges);
+  const int64_t p0 = 4 * (int64_t)sq[k0], p1 = 4 * (int64_t)sq[k1];
+  int lo = 0x7fffffff, hi = -1;
+  for (int64_t p = p0 + lane; p < p1; p += 64) {
+    const int g = pgath[p];
+    lo = g < lo ? g : lo;
+    hi = g > hi ? g : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if (lane == 0) {
+    win[2 * step] = hi >= 0 ? lo : 0;
+    win[2 * step + 1] = hi >= 0 ? hi - lo + 1 : 0;
+  }
+}
+
 // records in padded walk order; val(k) = f rho_k (k < B) | f (k == B) | 0, derivative record likewise
 __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
                              const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
@@ -140,6 +171,8 @@ struct WqArgs {
   const int32_t* rowptr;   // [N + 1] CSR of the walk order (isolated nodes)
   const int32_t* pgath;    // [P] gathered node per padded slot
   const uint32_t* qinfo;   // [Q] owner | WQ_FIRST | WQ_LAST per quad
+  const int32_t* win;      // [2 n_steps] window (first node, rows) of every step
+  int n_steps, steps_per_wg;
   int F, C, D, H, B;
   Irreps ir;
   int xl;                  // layout of xhat / grad_xhat
@@ -169,17 +202,23 @@ __device__ __forceinline__ WqUnit wq_unit(const WqArgs& a, int u) {
   return w;
 }
 
-// (range, unit) of this wave: the WQ_WAVES waves of a workgroup share a unit (its rbf_lin rows, staged once in LDS)
-// and take consecutive ranges; consecutive work items are the units of one group of ranges (they share its records
-// and index arrays) and are dealt to workgroups so that they run on one XCD (blocks b and b + 8 share one under
-// round-robin dispatch: speed only).
-__device__ __forceinline__ void wq_decode(const WqArgs& a, int nunits, int& range, int& unit) {
+// Work of a workgroup: (chunk of consecutive steps, unit).  A step is WQ_WAVES consecutive ranges, one per wave; the
+// waves share the unit (its rbf_lin rows, staged once in LDS) and, step by step, the window of gathered node rows.
+// Consecutive work items are the units of one chunk (they share its records and index arrays) and are dealt to
+// workgroups so that they run on one XCD (blocks b and b + 8 share one under round-robin dispatch: speed only).
+__device__ __forceinline__ void wq_decode(const WqArgs& a, int nunits, int& chunk, int& unit) {
   const int nb = gridDim.x, b = blockIdx.x;
   const int item = (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-  const int rgroup = item / nunits;   // padding blocks of the grid land beyond the last group: all their ranges are empty
-  unit = item - rgroup * nunits;
-  range = rgroup * WQ_WAVES + (threadIdx.x >> 6);
+  chunk = item / nunits;   // padding blocks of the grid land beyond the last chunk: no steps
+  unit = item - chunk * nunits;
 }
+
+// The window of a step in LDS: rows [w0, w0 + rows) of the gathered node arrays, restricted to the unit's columns, as
+// NSL pieces of 128 bytes per row.  Staged with 16-byte loads (8 lanes per piece), read back per row with 4-byte LDS
+// reads: a 64-lane dword load from global memory occupies the CU's texture addresser as long as a 16-byte one
+// (16 cycles), so the per-row gathers -- 92 per tile on average -- bound the older forms (MI355X: 1 750 cycles per
+// tile and CU measured, against 450 for the MFMAs); out of LDS the same reads cost 2 cycles each.
+constexpr int WQ_WIN_FLOATS = 12288;   // 48 KB per workgroup: two workgroups per CU
 
 // rbf_lin rows of the unit as the B operand: wl[kind][s][lane], lane (j = lane & 31 -> channel, kh = lane >> 5)
 // holding W~[row][2 s + kh], W~[., B] = bias, zeros beyond.  kind 0: gate_state, 1: gate_edge, 2: scalar message.
@@ -198,6 +237,11 @@ __device__ __forceinline__ void wq_stage_weights(const WqArgs& a, const WqUnit& 
 template <int KS>
 __device__ __forceinline__ f32x16 wq_filter(const float (&R)[KS], const float* W) {
   f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef XEQ_WQ_ABLATE_MFMA   // development: what the matrix instructions cost
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d[i] = R[i % KS] * W[0];
+  return d;
+#endif
 #pragma unroll
   for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(R[s], W[s * 64], d, 0, 0, 0);
   return d;
@@ -232,7 +276,7 @@ struct WqStreams {
 };
 template <int KS, int NREC, bool WITH_Y>
 __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int lane, int t, const float* __restrict__ rec,
-                                       const float* __restrict__ drec, WqRow<KS, NREC, WITH_Y>& w) {
+                                       const float* __restrict__ drec, WqRow<KS, NREC, WITH_Y>& w, int g_default = 0) {
   const int i = lane & 31, kh = lane >> 5, hr = (i >> 2) & 1, g = i >> 3;
   const int qb = hr ? st.q1 : st.q0, qe = hr ? st.q2 : st.q1;
   const int q = qb + 4 * t + g;
@@ -242,7 +286,7 @@ __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int
   const uint32_t ps = valid ? 4u * (uint32_t)q + (uint32_t)(i & 3) : 0u;
   const int gv = a.pgath[ps];
   const uint32_t qv = a.qinfo[valid ? q : 0];
-  w.g = valid ? gv : 0;
+  w.g = valid ? gv : g_default;
   w.qi = valid ? qv : 0u;
   const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + kh * WQ_KH);
 #pragma unroll
@@ -270,11 +314,16 @@ __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int
 }
 template <int KS, int NREC, bool WITH_Y>
 __device__ __forceinline__ void wq_publish(int lane, const WqRow<KS, NREC, WITH_Y>& w, uint32_t stride0, uint32_t stride1,
-                                           int* tbl) {
+                                           int* tbl, uint32_t gbase = 0u) {
   if (lane < 32) {
     const int i = lane, hr = (i >> 2) & 1, v = 4 * (i >> 3) + (i & 3), p = 16 * hr + v;
-    tbl[T_G0 + p] = (int)((uint32_t)w.g * stride0);
-    tbl[T_G1 + p] = (int)((uint32_t)w.g * stride1);
+#ifdef XEQ_WQ_ABLATE_GATHER   // development: every gather reads node 0 (cache-resident): what the gathers cost
+    tbl[T_G0 + p] = 0;
+    tbl[T_G1 + p] = 0;
+#else
+    tbl[T_G0 + p] = (int)(((uint32_t)w.g - gbase) * stride0);   // window mode: gbase = first row of the window
+    tbl[T_G1 + p] = (int)(((uint32_t)w.g - gbase) * stride1);
+#endif
     if constexpr (WITH_Y) {
       float* tf = reinterpret_cast<float*>(tbl);
 #pragma unroll
@@ -343,17 +392,81 @@ __device__ __forceinline__ void wq_for_isolated(const WqArgs& a, int range, int 
   }
 }
 
+// scheduling fence between the passes of a tile (dev switch: -D'XEQ_WQ_SB()=' compiles them out)
+#ifndef XEQ_WQ_SB
+#define XEQ_WQ_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+// fence between the phases of a forward tile (dev switch: -D'XEQ_WQ_FSB()=' lets the compiler interleave them)
+#ifndef XEQ_WQ_FSB
+#define XEQ_WQ_FSB() XEQ_WQ_SB()
+#endif
+
+// development (-DXEQ_WQ_STAMPS): cycles of the l = 0 waves per phase of the forward kernel, summed over a launch
+__device__ unsigned long long g_wq_stamps[16];
+#ifdef XEQ_WQ_STAMPS
+#define WQ_STAMP(i)                                                                                          \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    unsigned long long now_;                                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    st_[i] += now_ - last_;                                                                                  \
+    last_ = now_;                                                                                            \
+  } while (0)
+#else
+#define WQ_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ forward
+__device__ __forceinline__ float wq_lds(const float* win, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(win) + byte_off);
+}
+
+// window of the forward pass: per row the unit's pieces of h (gate_state | gate_edge | scalar message for l = 0) and of
+// xhat (NM pieces: component m in BT layout; the contiguous run of 32 NM floats in e3nn layout)
+template <int NM>
+__device__ __forceinline__ void wq_stage_fwd(const WqArgs& a, const WqUnit& un, const WqCols& wc, const float* __restrict__ h,
+                                             const float* __restrict__ xhat_, int w0, int nrows, float* win) {
+  constexpr int NH = NM == 1 ? 3 : 2, NSL = NH + NM;
+  const int total = nrows * NSL * 8;   // 16-byte chunks
+  const int64_t xnode = wc.xnode_b / 4, xcomp = a.xl == 0 ? 32 : wc.xcomp_b / 4;
+  constexpr int UN = 8;                // loads in flight per thread before the first LDS store
+  const int nthr = blockDim.x;
+  for (int base = threadIdx.x; base < total; base += UN * nthr) {
+    f32x4 v[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int idx = base + k * nthr;
+      const int piece = idx >> 3, chunk = idx & 7;
+      const int row = piece / NSL, sl = piece - row * NSL;
+      const int64_t n = w0 + (idx < total ? row : 0);
+      const float* src = sl < NH ? h + n * a.H + (sl == 0 ? un.u0 : (sl == 1 ? a.C + un.u0 : 2 * a.C + 32 * un.cb))
+                                 : xhat_ + wc.x_base + n * xnode + (sl - NH) * xcomp;
+      v[k] = *reinterpret_cast<const f32x4*>(src + 4 * chunk);   // a slot beyond the window re-reads row w0: in bounds
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int idx = base + k * nthr;
+      if (idx < total) *reinterpret_cast<f32x4*>(win + (idx >> 3) * 32 + 4 * (idx & 7)) = v[k];
+    }
+  }
+}
+
 //   x_c += xhat[n] (h_state[n] phi_state) + Y (h_edge[n] phi_edge);   s_c += h_msg[n] phi_msg   (l = 0)
-template <int NM, int KS>
-__device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const WqUnit un, const float* __restrict__ rec,
-                                            const float* __restrict__ h, const float* __restrict__ xhat_,
-                                            const float* __restrict__ s_in, const float* __restrict__ x_in, const float* wl,
-                                            float* __restrict__ s_out, float* __restrict__ x_out, int* tbl) {
+// WIN: the gathered rows of this step are in the LDS window (first node w0); otherwise they are read from global memory
+template <int NM, int KS, bool WIN>
+__device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const WqUnit un, const WqCols& wc,
+                                            const float* __restrict__ rec, const float* __restrict__ h,
+                                            const float* __restrict__ xhat_, const float* __restrict__ s_in,
+                                            const float* __restrict__ x_in, const float* wl, float* __restrict__ s_out,
+                                            float* __restrict__ x_out, int* tbl, const float* win, int w0,
+                                            unsigned long long* st_, unsigned long long& last_) {
   constexpr bool HAS_S = NM == 1;
   constexpr int YOFF = NM == 3 ? 0 : 3;
+  constexpr int NH = NM == 1 ? 3 : 2, ROWB = (NH + NM) * 128;
   const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-  const WqCols wc = wq_cols<NM>(a, un, j);
   const uint32_t row_s = 4u * (uint32_t)a.F, row_x = 4u * (uint32_t)a.D;
   wq_for_isolated(a, range, lane, [&](int m) {   // s_out = s_in, x_out = x_in on the unit's columns
     if (hh == 0) {
@@ -370,7 +483,12 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
   const float* xhat_m[NM];
 #pragma unroll
   for (int m = 0; m < NM; ++m) xhat_m[m] = xhat_ + wc.x_base + (int64_t)m * (wc.xcomp_b / 4);
-  const uint32_t stride0 = 4u * (uint32_t)a.H, stride1 = wc.xnode_b;
+  const uint32_t stride0 = WIN ? (uint32_t)ROWB : 4u * (uint32_t)a.H, stride1 = WIN ? 0u : wc.xnode_b;
+  const uint32_t gbase = WIN ? (uint32_t)w0 : 0u;
+  // window mode: byte offset of this lane's element of component m inside a row's xhat pieces
+  uint32_t lxm[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) lxm[m] = (uint32_t)(NH * 128) + (a.xl == 0 ? 4u * (uint32_t)(j * NM + m) : (uint32_t)(128 * m + 4 * j));
   const float* Ws = wl + lane;
   const float* We = wl + KS * 64 + lane;
   const float* Wm = wl + 2 * KS * 64 + lane;
@@ -381,98 +499,199 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
 
   using Row = WqRow<KS, 1, (NM > 1)>;
   Row row;
-  wq_row<KS, 1, (NM > 1)>(a, st, lane, 0, rec, nullptr, row);
-  wq_publish<KS, 1, (NM > 1)>(lane, row, stride0, stride1, tbl);
+  wq_row<KS, 1, (NM > 1)>(a, st, lane, 0, rec, nullptr, row, (int)gbase);
+  wq_publish<KS, 1, (NM > 1)>(lane, row, stride0, stride1, tbl, gbase);
   __builtin_amdgcn_wave_barrier();
 
+  // A tile runs as four phases with every load of the tile issued up front (two waves per SIMD: 256 registers), so a
+  // wave has ONE dependent wait per phase instead of one per quad (measured before: 52 % of a wave's cycles in
+  // s_waitcnt, 28 % in issue stalls behind its own MFMA chain, 12 k cycles per tile):
+  //   A  table entries of all 16 rows, the four owners' residual rows, the next tile's record (global, long latency)
+  //   B  the gathered rows of all 16 rows (LDS window, or global memory)
+  //   C  the MFMA chains of the filter
+  //   D  row arithmetic, quad by quad; the finished nodes' stores
   for (int t = 0; t < st.ntiles; ++t) {
     const int* tb = tbl + (t & 1) * T_SIZE;
     int* tnext = tbl + ((t + 1) & 1) * T_SIZE;
     float R[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) R[s] = row.R[0][s];
-    wq_row<KS, 1, (NM > 1)>(a, st, lane, t + 1, rec, nullptr, row);   // next tile's loads fly under this tile
-    const f32x16 ds = wq_filter<KS>(R, Ws), de = wq_filter<KS>(R, We);
-    f32x16 dm = ds;
-    if constexpr (HAS_S) dm = wq_filter<KS>(R, Wm);
+    WQ_STAMP(4);   // waiting for the tile's record
+    // ---- phase A
+    uint32_t g0[16], g1[WIN ? 1 : 16], ob[4], os[4];
+    int keep[4], last[4];
+    float res_x[4][NM], res_s[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int p0 = 16 * hh + 4 * g, c = 4 * hh + g;
-      uint32_t g0[4], g1[4];
-      wq_tread4<uint32_t>(tb, T_G0 + p0, g0);
-      wq_tread4<uint32_t>(tb, T_G1 + p0, g1);
-      const uint32_t own = (uint32_t)tb[T_QOWN + c];
-      const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
-      float hs[4], he[4], hm[4], xv[4][NM], res_x[NM], res_s = 0.f, Y[NM][4];
+      uint32_t t0[4];
+      wq_tread4<uint32_t>(tb, T_G0 + 16 * hh + 4 * g, t0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t oh = g0[r] + wc.b_hs, ox = g1[r] + wc.b_x;
-        hs[r] = wq_ld(h, oh);
-        he[r] = wq_ld(h_e, oh);
-        if constexpr (HAS_S) hm[r] = wq_ld(h_m, oh);
+      for (int r = 0; r < 4; ++r) g0[4 * g + r] = t0[r];
+      if constexpr (!WIN) {
+        uint32_t t1[4];
+        wq_tread4<uint32_t>(tb, T_G1 + 16 * hh + 4 * g, t1);
 #pragma unroll
-        for (int m = 0; m < NM; ++m) xv[r][m] = wq_ld(xhat_m[m], ox);
+        for (int r = 0; r < 4; ++r) g1[4 * g + r] = t1[r];
       }
-      const uint32_t ob = own * row_x + wc.b_xe, os = own * row_s + wc.b_s;
+      const uint32_t own = (uint32_t)tb[T_QOWN + 4 * hh + g];
+      keep[g] = tb[T_QKEEP + 4 * hh + g];
+      last[g] = tb[T_QLAST + 4 * hh + g];
+      ob[g] = own * row_x + wc.b_xe;
+      os[g] = own * row_s + wc.b_s;
 #pragma unroll
-      for (int m = 0; m < NM; ++m) res_x[m] = wq_ld(x_in, ob + 4u * m);   // the owner's residual row: read per quad
-      if constexpr (HAS_S) res_s = wq_ld(s_in, os);                       // (unconditional: no wait inside the store branch)
-      if constexpr (NM > 1) {
-#pragma unroll
-        for (int m = 0; m < NM; ++m) wq_tread4<float>(tb, T_Y + 32 * (YOFF + m) + p0, Y[m]);
-      }
-      float xq[NM], sq = 0.f;
-#pragma unroll
-      for (int m = 0; m < NM; ++m) xq[m] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float gs = hs[r] * ds[4 * g + r], ge = he[r] * de[4 * g + r];
-#pragma unroll
-        for (int m = 0; m < NM; ++m) xq[m] += xv[r][m] * gs + (NM > 1 ? Y[m][r] : 1.f) * ge;
-        if constexpr (HAS_S) sq += hm[r] * dm[4 * g + r];
-      }
-#pragma unroll
-      for (int m = 0; m < NM; ++m) acc_x[m] = (keep ? acc_x[m] : 0.f) + xq[m];
-      if constexpr (HAS_S) acc_s = (keep ? acc_s : 0.f) + sq;
-      if (last) {   // the node's only store
-#pragma unroll
-        for (int m = 0; m < NM; ++m) wq_st(x_out, ob + 4u * m, res_x[m] + acc_x[m]);
-        if constexpr (HAS_S) wq_st(s_out, os, res_s + acc_s);
-      }
+      for (int m = 0; m < NM; ++m) res_x[g][m] = wq_ld(x_in, ob[g] + 4u * m);   // the owner's residual row, read per quad
+      res_s[g] = HAS_S ? wq_ld(s_in, os[g]) : 0.f;
     }
-    wq_publish<KS, 1, (NM > 1)>(lane, row, stride0, stride1, tnext);
+    wq_row<KS, 1, (NM > 1)>(a, st, lane, t + 1, rec, nullptr, row, (int)gbase);   // next tile's record flies under this tile
+    XEQ_WQ_FSB();
+    WQ_STAMP(5);   // phase A issued
+    // ---- phases B, C, D; l = 2 gathers and consumes its rows in two halves of 8 (register budget)
+#ifdef XEQ_WQ_FWD_GR
+    constexpr int GR = NM == 5 && XEQ_WQ_FWD_GR > 4 ? XEQ_WQ_FWD_GR / 2 : XEQ_WQ_FWD_GR;
+#else
+    constexpr int GR = NM == 5 ? 8 : 16;
+#endif
+    f32x16 ds, de, dm;
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += GR) {
+      float hs[GR], he[GR], hm[HAS_S ? GR : 1], xv[GR][NM];
+#pragma unroll
+      for (int u = 0; u < GR; ++u) {
+        const int v = r0 + u;
+        if constexpr (WIN) {
+          const uint32_t oh = g0[v] + 4u * (uint32_t)j;
+          hs[u] = wq_lds(win, oh);
+          he[u] = wq_lds(win, oh + 128u);
+          if constexpr (HAS_S) hm[u] = wq_lds(win, oh + 256u);
+#pragma unroll
+          for (int m = 0; m < NM; ++m) xv[u][m] = wq_lds(win, g0[v] + lxm[m]);
+        } else {
+          const uint32_t oh = g0[v] + wc.b_hs, ox = g1[v] + wc.b_x;
+          hs[u] = wq_ld(h, oh);
+          he[u] = wq_ld(h_e, oh);
+          if constexpr (HAS_S) hm[u] = wq_ld(h_m, oh);
+#pragma unroll
+          for (int m = 0; m < NM; ++m) xv[u][m] = wq_ld(xhat_m[m], ox);
+        }
+      }
+      XEQ_WQ_FSB();
+      WQ_STAMP(6);   // phase B issued
+      if (r0 == 0) {   // ---- phase C
+        ds = wq_filter<KS>(R, Ws);
+        de = wq_filter<KS>(R, We);
+        dm = ds;
+        if constexpr (HAS_S) dm = wq_filter<KS>(R, Wm);
+        XEQ_WQ_FSB();
+        WQ_STAMP(7);   // MFMAs issued
+      }
+      // ---- phase D
+#pragma unroll
+      for (int g = r0 / 4; g < (r0 + GR) / 4; ++g) {
+        float Y[NM][4];
+        if constexpr (NM > 1) {
+#pragma unroll
+          for (int m = 0; m < NM; ++m) wq_tread4<float>(tb, T_Y + 32 * (YOFF + m) + 16 * hh + 4 * g, Y[m]);
+        }
+        float xq[NM], sq = 0.f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) xq[m] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = 4 * g + r, u = v - r0;
+          const float gs = hs[u] * ds[v], ge = he[u] * de[v];
+#pragma unroll
+          for (int m = 0; m < NM; ++m) xq[m] += xv[u][m] * gs + (NM > 1 ? Y[m][r] : 1.f) * ge;
+          if constexpr (HAS_S) sq += hm[u] * dm[v];
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc_x[m] = (keep[g] ? acc_x[m] : 0.f) + xq[m];
+        if constexpr (HAS_S) acc_s = (keep[g] ? acc_s : 0.f) + sq;
+        if (last[g]) {   // the node's only store
+#pragma unroll
+          for (int m = 0; m < NM; ++m) wq_st(x_out, ob[g] + 4u * m, res_x[g][m] + acc_x[m]);
+          if constexpr (HAS_S) wq_st(s_out, os[g], res_s[g] + acc_s);
+        }
+      }
+      if constexpr (GR < 16) XEQ_WQ_FSB();
+      WQ_STAMP(8);   // phase D: row arithmetic and stores
+    }
+    wq_publish<KS, 1, (NM > 1)>(lane, row, stride0, stride1, tnext, gbase);
     __builtin_amdgcn_wave_barrier();
+    WQ_STAMP(9);   // next table published
   }
 }
 
-// scheduling fence between the passes of a tile (dev switch: -D'XEQ_WQ_SB()=' compiles them out)
-#ifndef XEQ_WQ_SB
-#define XEQ_WQ_SB() __builtin_amdgcn_sched_barrier(0)
-#endif
 #ifndef XEQ_WQ_FWD_WPE
-#define XEQ_WQ_FWD_WPE 3
+#define XEQ_WQ_FWD_WPE 2
 #endif
 #ifndef XEQ_WQ_BWD_WPE
-#define XEQ_WQ_BWD_WPE 3
+#define XEQ_WQ_BWD_WPE 2
 #endif
+
+// one role of the forward kernel: the workgroup's steps, each with its window staged first when it fits
+template <int NM, int KS>
+__device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int chunk, const WqUnit un, const float* __restrict__ rec,
+                                            const float* __restrict__ h, const float* __restrict__ xhat,
+                                            const float* __restrict__ s_in, const float* __restrict__ x_in, const float* wl,
+                                            float* __restrict__ s_out, float* __restrict__ x_out, int* tbl, float* win) {
+  constexpr int NH = NM == 1 ? 3 : 2, ROWB = (NH + NM) * 128;
+  const WqCols wc = wq_cols<NM>(a, un, threadIdx.x & 31);
+  const int s_end = min((chunk + 1) * a.steps_per_wg, a.n_steps);
+  unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+#ifdef XEQ_WQ_STAMPS
+  last_ = __builtin_amdgcn_s_memtime();
+#endif
+  for (int step = chunk * a.steps_per_wg; step < s_end; ++step) {
+    const int w0 = a.win[2 * step], nrows = a.win[2 * step + 1];
+#ifdef XEQ_WQ_NO_WINDOW
+    const bool use_win = false;
+#else
+    const bool use_win = nrows > 0 && nrows * ROWB <= WQ_WIN_FLOATS * 4;   // workgroup-uniform
+#endif
+    WQ_STAMP(0);   // step head
+    if (use_win) wq_stage_fwd<NM>(a, un, wc, h, xhat, w0, nrows, win);
+    WQ_STAMP(1);   // window staged
+    __syncthreads();
+    WQ_STAMP(2);   // barrier behind the staging
+    const int range = step * WQ_WAVES + (threadIdx.x >> 6);
+    if (range < a.n_ranges) {
+      if (use_win) wq_fwd_body<NM, KS, true>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, w0, st_, last_);
+      else wq_fwd_body<NM, KS, false>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, 0, st_, last_);
+    }
+    WQ_STAMP(3);   // body prologue (isolated nodes, first record) -- what the tile stamps did not take
+    __syncthreads();   // the window and the tile tables are rewritten by the next step
+    WQ_STAMP(10);  // barrier behind the step
+  }
+#ifdef XEQ_WQ_STAMPS
+  if (NM == 1 && (threadIdx.x & 63) == 0) {
+    for (int i = 0; i < 11; ++i) atomicAdd(&g_wq_stamps[i], st_[i]);
+    atomicAdd(&g_wq_stamps[15], 1ull);
+  }
+#endif
+}
 
 template <int KS>
 __global__ void __launch_bounds__(64 * WQ_WAVES) __attribute__((amdgpu_waves_per_eu(XEQ_WQ_FWD_WPE)))
 k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restrict__ h, const float* __restrict__ xhat,
                  const float* __restrict__ s_in, const float* __restrict__ x_in, const float* __restrict__ w_rbf,
                  const float* __restrict__ b_rbf, float* __restrict__ s_out, float* __restrict__ x_out) {
+  __shared__ __attribute__((aligned(16))) float win[WQ_WIN_FLOATS];
   __shared__ __attribute__((aligned(16))) int tbl_all[WQ_WAVES][2 * T_SIZE];
   __shared__ float wl[3 * KS * 64];
-  int range, unit;
-  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], range, unit);
+  int chunk, unit;
+  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], chunk, unit);
+  if (chunk * a.steps_per_wg >= a.n_steps) return;   // padding block of the grid (workgroup-uniform)
   const WqUnit un = wq_unit(a, unit);
   wq_stage_weights<KS>(a, un, w_rbf, b_rbf, wl);
   __syncthreads();
-  if (range >= a.n_ranges) return;
   int* tbl = tbl_all[threadIdx.x >> 6];
-  if (un.l == 0) wq_fwd_body<1, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
-  else if (un.l == 1) wq_fwd_body<3, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
-  else wq_fwd_body<5, KS>(a, range, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl);
+#ifdef XEQ_WQ_ONLY_L   // development: register budget of one role
+  if (un.l == XEQ_WQ_ONLY_L) wq_fwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, chunk, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  return;
+#endif
+  if (un.l == 0) wq_fwd_role<1, KS>(a, chunk, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  else if (un.l == 1) wq_fwd_role<3, KS>(a, chunk, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  else wq_fwd_role<5, KS>(a, chunk, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
 }
 
 // ------------------------------------------------------------------------------------------------ reverse
@@ -515,16 +734,45 @@ __device__ __forceinline__ int wq_red_row(int j) { return 4 * (((j >> 2) & 1) * 
 //   pass E (edge):  g_he[n] += sum_r phi_e[r] <Y[r], gx[r]>;  pd[r] += h_e[n] <Y[r], gx[r]> phi_e'[r]
 //                   dL/dY_m[r] = sum_ch h_e[n] phi_e[r] gx[r][m]
 //   pass M (msg):   g_hm[n] += sum_r phi_m[r] gs[r];  pd[r] += h_m[n] gs[r] phi_m'[r]
-template <int NM, int KS>
-__device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit, const WqUnit un, const float* __restrict__ rec,
-                                            const float* __restrict__ drec, const float* __restrict__ h,
-                                            const float* __restrict__ xhat_, const float* __restrict__ grad_s,
-                                            const float* __restrict__ grad_x, const float* wl, float* __restrict__ grad_h,
-                                            float* __restrict__ grad_xhat_, const WqParts parts, int* tbl) {
+// window of the reverse pass: per row (center node) the unit's run of grad_x (32 NM floats, e3nn layout) and, for l = 0,
+// its 32 floats of grad_s
+template <int NM>
+__device__ __forceinline__ void wq_stage_bwd(const WqArgs& a, const WqUnit& un, const float* __restrict__ grad_s,
+                                             const float* __restrict__ grad_x, int w0, int nrows, float* win) {
+  constexpr int NSL = NM + (NM == 1 ? 1 : 0);
+  const int total = nrows * NSL * 8;   // 16-byte chunks
+  constexpr int UN = 8;                // loads in flight per thread before the first LDS store
+  const int nthr = blockDim.x;
+  for (int base = threadIdx.x; base < total; base += UN * nthr) {
+    f32x4 v[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int idx = base + k * nthr;
+      const int piece = idx >> 3, chunk = idx & 7;
+      const int row = piece / NSL, sl = piece - row * NSL;
+      const int64_t n = w0 + (idx < total ? row : 0);
+      const float* src = sl < NM ? grad_x + n * a.D + un.xbase + 32 * sl : grad_s + n * a.F + 32 * un.cb;
+      v[k] = *reinterpret_cast<const f32x4*>(src + 4 * chunk);
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int idx = base + k * nthr;
+      if (idx < total) *reinterpret_cast<f32x4*>(win + (idx >> 3) * 32 + 4 * (idx & 7)) = v[k];
+    }
+  }
+}
+
+template <int NM, int KS, bool WIN>
+__device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit, const WqUnit un, const WqCols& wc,
+                                            const float* __restrict__ rec, const float* __restrict__ drec,
+                                            const float* __restrict__ h, const float* __restrict__ xhat_,
+                                            const float* __restrict__ grad_s, const float* __restrict__ grad_x, const float* wl,
+                                            float* __restrict__ grad_h, float* __restrict__ grad_xhat_, const WqParts parts,
+                                            int* tbl, const float* win, int w0) {
   constexpr bool HAS_S = NM == 1;
   constexpr int YOFF = NM == 3 ? 0 : 3;
+  constexpr int ROWB = (NM + (HAS_S ? 1 : 0)) * 128;
   const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
-  const WqCols wc = wq_cols<NM>(a, un, j);
   const float* __restrict__ xhat = xhat_ + wc.x_base;
   float* __restrict__ grad_xhat = grad_xhat_ + wc.x_base;
   const uint32_t he_off = 4u * (uint32_t)a.C, row_h = 4u * (uint32_t)a.H;
@@ -539,7 +787,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   });
   const WqStreams st = wq_streams(a, range);
   if (st.ntiles == 0) return;
-  const uint32_t stride0 = 4u * (uint32_t)a.D, stride1 = 4u * (uint32_t)a.F;   // gathered rows: grad_x, grad_s of the center
+  // gathered rows: grad_x, grad_s of the center (window mode: one LDS row of ROWB bytes holds both)
+  const uint32_t stride0 = WIN ? (uint32_t)ROWB : 4u * (uint32_t)a.D, stride1 = WIN ? (uint32_t)ROWB : 4u * (uint32_t)a.F;
+  const uint32_t gbase = WIN ? (uint32_t)w0 : 0u;
+  const uint32_t lgx = 4u * (uint32_t)(j * NM), lgs = (uint32_t)(NM * 128 + 4 * j);   // window mode: lane offsets in a row
   const float* Ws = wl + lane;
   const float* We = wl + KS * 64 + lane;
   const float* Wm = wl + 2 * KS * 64 + lane;
@@ -553,8 +804,8 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 
   using Row = WqRow<KS, 2, (NM > 1)>;
   Row row;
-  wq_row<KS, 2, (NM > 1)>(a, st, lane, 0, rec, drec, row);
-  wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tbl);
+  wq_row<KS, 2, (NM > 1)>(a, st, lane, 0, rec, drec, row, (int)gbase);
+  wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tbl, gbase);
   __builtin_amdgcn_wave_barrier();
 
   for (int t = 0; t < st.ntiles; ++t) {
@@ -573,7 +824,8 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int m = 0; m < NM; ++m) gxq[r][m] = wq_ld(grad_x, g0[r] + wc.b_xe + 4u * m);
+        for (int m = 0; m < NM; ++m)
+          gxq[r][m] = WIN ? wq_lds(win, g0[r] + lgx + 4u * m) : wq_ld(grad_x, g0[r] + wc.b_xe + 4u * m);
     };
     float gxs[HAS_S ? 4 : 1][4][1];   // l = 0: the tile's grad_x rows stay in registers for passes S and E
     if constexpr (HAS_S) {
@@ -702,7 +954,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         uint32_t g1[4];
         wq_tread4<uint32_t>(tb, T_G1 + 16 * hh + 4 * g, g1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gsv[4 * g + r] = wq_ld(grad_s, g1[r] + wc.b_s);
+        for (int r = 0; r < 4; ++r) gsv[4 * g + r] = WIN ? wq_lds(win, g1[r] + lgs) : wq_ld(grad_s, g1[r] + wc.b_s);
       }
       const f32x16 dm = wq_filter<KS>(R, Wm), qm = wq_filter<KS>(Rd, Wm);
 #pragma unroll
@@ -723,7 +975,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       }
     }
     XEQ_WQ_SB();
-    wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row);   // the next tile's records land under the channel sums
+    wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // the next tile's records land under the channel sums
     {  // ---- dL/dd of every row's edge: sum over the unit's 32 channels
       float pq[4];
 #pragma unroll
@@ -731,8 +983,35 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       const float tot = wq_red_cd(pq[0], pq[1], pq[2], pq[3], b2, b3);
       if (keeper) parts.pd[(int64_t)unit * parts.P + my_slot] = tot;
     }
-    wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tnext);
+    wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tnext, gbase);
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int NM, int KS>
+__device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int chunk, int unit, const WqUnit un, const float* __restrict__ rec,
+                                            const float* __restrict__ drec, const float* __restrict__ h,
+                                            const float* __restrict__ xhat, const float* __restrict__ grad_s,
+                                            const float* __restrict__ grad_x, const float* wl, float* __restrict__ grad_h,
+                                            float* __restrict__ grad_xhat, const WqParts parts, int* tbl, float* win) {
+  constexpr int ROWB = (NM + (NM == 1 ? 1 : 0)) * 128;
+  const WqCols wc = wq_cols<NM>(a, un, threadIdx.x & 31);
+  const int s_end = min((chunk + 1) * a.steps_per_wg, a.n_steps);
+  for (int step = chunk * a.steps_per_wg; step < s_end; ++step) {
+    const int w0 = a.win[2 * step], nrows = a.win[2 * step + 1];
+#ifdef XEQ_WQ_NO_WINDOW
+    const bool use_win = false;
+#else
+    const bool use_win = nrows > 0 && nrows * ROWB <= WQ_WIN_FLOATS * 4;   // workgroup-uniform
+#endif
+    if (use_win) wq_stage_bwd<NM>(a, un, grad_s, grad_x, w0, nrows, win);
+    __syncthreads();
+    const int range = step * WQ_WAVES + (threadIdx.x >> 6);
+    if (range < a.n_ranges) {
+      if (use_win) wq_bwd_body<NM, KS, true>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, w0);
+      else wq_bwd_body<NM, KS, false>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, 0);
+    }
+    __syncthreads();
   }
 }
 
@@ -742,23 +1021,24 @@ k_message_bwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
                  const float* __restrict__ xhat, const float* __restrict__ grad_s, const float* __restrict__ grad_x,
                  const float* __restrict__ w_rbf, const float* __restrict__ b_rbf, float* __restrict__ grad_h,
                  float* __restrict__ grad_xhat, WqParts parts) {
+  __shared__ __attribute__((aligned(16))) float win[WQ_WIN_FLOATS];
   __shared__ __attribute__((aligned(16))) int tbl_all[WQ_WAVES][2 * T_SIZE];
   __shared__ float wl[3 * KS * 64];
-  int range, unit;
-  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], range, unit);
+  int chunk, unit;
+  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], chunk, unit);
+  if (chunk * a.steps_per_wg >= a.n_steps) return;   // padding block of the grid (workgroup-uniform)
   const WqUnit un = wq_unit(a, unit);
   wq_stage_weights<KS>(a, un, w_rbf, b_rbf, wl);
   __syncthreads();
-  if (range >= a.n_ranges) return;
   int* tbl = tbl_all[threadIdx.x >> 6];
 #ifdef XEQ_WQ_ONLY_L   // development: register budget of one role
   if (un.l == XEQ_WQ_ONLY_L)
-    wq_bwd_body<2 * XEQ_WQ_ONLY_L + 1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+    wq_bwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, chunk, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
   return;
 #endif
-  if (un.l == 0) wq_bwd_body<1, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
-  else if (un.l == 1) wq_bwd_body<3, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
-  else wq_bwd_body<5, KS>(a, range, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl);
+  if (un.l == 0) wq_bwd_role<1, KS>(a, chunk, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+  else if (un.l == 1) wq_bwd_role<3, KS>(a, chunk, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+  else wq_bwd_role<5, KS>(a, chunk, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
 }
 
 // dL/dvec from the per-unit partials (by padded slot of the reverse walk), summed in unit order (deterministic),
@@ -824,10 +1104,17 @@ static int wq_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ran
   return XEQ_OK;
 }
 
-static unsigned wq_grid(int n_ranges, int nunits) {
-  int64_t blocks = (int64_t)((n_ranges + WQ_WAVES - 1) / WQ_WAVES) * nunits;   // one workgroup per (range group, unit)
+// steps (WQ_WAVES ranges each) a workgroup walks: enough workgroups for ~6 per CU and unit mix, never fewer than one step
+static void wq_geometry(WqArgs& a, int nunits, unsigned& grid) {
+  a.n_steps = (a.n_ranges + WQ_WAVES - 1) / WQ_WAVES;
+  const int64_t want_chunks = (256 * 6 + nunits - 1) / nunits;
+  a.steps_per_wg = (int)((a.n_steps + want_chunks - 1) / want_chunks);
+  if (a.steps_per_wg < 1) a.steps_per_wg = 1;
+  const char* env = getenv("XEQ_WQ_STEPS_PER_WG");   // development
+  if (env && atoi(env) > 0) a.steps_per_wg = atoi(env);
+  int64_t blocks = (int64_t)((a.n_steps + a.steps_per_wg - 1) / a.steps_per_wg) * nunits;
   if (blocks >= 64) blocks = (blocks + 7) / 8 * 8;   // multiple of 8: XCD-aware item order (wq_decode)
-  return (unsigned)blocks;
+  grid = (unsigned)blocks;
 }
 
 }  // namespace xeq
@@ -853,6 +1140,8 @@ int xeq_message_wq_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int nod
 
 int64_t xeq_message_wq_pcap(int64_t n_nodes, int64_t n_edges) { return wq_pcap(n_nodes, n_edges); }
 
+int xeq_message_wq_waves(void) { return WQ_WAVES; }
+
 int64_t xeq_message_wq_plan_workspace(int64_t n_nodes) {
   size_t temp = 0;
   QuadCount op{nullptr, n_nodes};
@@ -864,7 +1153,8 @@ int64_t xeq_message_wq_plan_workspace(int64_t n_nodes) {
 
 int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_t* owner, const int64_t* gather,
                         int64_t n_nodes, int64_t n_edges, int n_ranges, void* workspace, int64_t workspace_bytes,
-                        int32_t* qptr, int32_t* pgath, int32_t* peid, int32_t* qinfo, int32_t* sq, int32_t* sn, void* stream) {
+                        int32_t* qptr, int32_t* pgath, int32_t* peid, int32_t* qinfo, int32_t* sq, int32_t* sn, int32_t* win,
+                        void* stream) {
   XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_ranges >= 1 && n_nodes < (1ll << 30) && n_edges < (1ll << 31), "xeq_message_wq_plan: bad sizes");
   const int64_t need = xeq_message_wq_plan_workspace(n_nodes);
   XEQ_CHECK_ARG(need >= 0 && workspace_bytes >= need, "xeq_message_wq_plan: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
@@ -885,6 +1175,10 @@ int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_
   hipLaunchKernelGGL(k_wq_streams, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const int32_t*)qptr,
                      n_nodes, n_ranges, sq, sn);
   XEQ_CHECK_LAUNCH("xeq_message_wq_plan (streams)");
+  const int n_steps = (n_ranges + WQ_WAVES - 1) / WQ_WAVES;
+  hipLaunchKernelGGL(k_wq_windows, dim3((unsigned)n_steps), dim3(64), 0, (hipStream_t)stream, (const int32_t*)sq,
+                     (const int32_t*)pgath, n_ranges, n_steps, win);
+  XEQ_CHECK_LAUNCH("xeq_message_wq_plan (windows)");
   return XEQ_OK;
 }
 
@@ -905,7 +1199,7 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   return XEQ_OK;
 }
 
-int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn,
+int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* c_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis, const void* h,
                        const void* xhat, const void* s_in, const void* x_in, const void* w_rbf, const void* b_rbf,
                        int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out, int xhat_layout,
@@ -920,8 +1214,11 @@ int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   a.pgath = pgath;
   a.qinfo = (const uint32_t*)qinfo;
   a.xl = xhat_layout;
+  a.win = win;
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
-  dim3 grid(wq_grid(n_ranges, nunits));
+  unsigned nblocks;
+  wq_geometry(a, nunits, nblocks);
+  dim3 grid(nblocks);
   XEQ_WQ_DISPATCH(k_message_fwd_wq, a, (const float*)basis, (const float*)h, (const float*)xhat, (const float*)s_in,
                   (const float*)x_in, (const float*)w_rbf, (const float*)b_rbf, (float*)s_out, (float*)x_out);
   XEQ_CHECK_LAUNCH("xeq_message_fwd_wq");
@@ -932,7 +1229,7 @@ int64_t xeq_message_wq_parts_floats(int64_t n_nodes, int64_t n_edges, const int3
   return wq_pcap(n_nodes, n_edges) * (int64_t)(mul[0] / 32 + mul[1] / 32 + mul[2] / 32 + 3 * (mul[1] / 32) + 5 * (mul[2] / 32));
 }
 
-int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn,
+int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* n_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis,
                        const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
                        const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,
@@ -953,11 +1250,22 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   pr.pd = (float*)parts;
   pr.y1 = pr.pd + (int64_t)nunits * pr.P;
   pr.y2 = pr.y1 + (int64_t)a.nu[1] * 3 * pr.P;
-  dim3 grid(wq_grid(n_ranges, nunits));
+  a.win = win;
+  unsigned nblocks;
+  wq_geometry(a, nunits, nblocks);
+  dim3 grid(nblocks);
   XEQ_WQ_DISPATCH(k_message_bwd_wq, a, (const float*)basis, (const float*)dbasis, (const float*)h, (const float*)xhat,
                   (const float*)grad_s, (const float*)grad_x, (const float*)w_rbf, (const float*)b_rbf, (float*)grad_h,
                   (float*)grad_xhat, pr);
   XEQ_CHECK_LAUNCH("xeq_message_bwd_wq");
+  return XEQ_OK;
+}
+
+/* development: read and clear the phase cycle counters of a -DXEQ_WQ_STAMPS build */
+int xeq_wq_debug_stamps(unsigned long long out[16]) {
+  unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wq_stamps), sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wq_stamps), zero, sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
   return XEQ_OK;
 }
 

@@ -151,6 +151,7 @@ class EdgeGraph:
             i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
             plan = {"reverse": bool(reverse), "n_ranges": n_ranges, "pcap": pcap, "qptr": i32(N + 1), "pgath": i32(pcap),
                     "peid": i32(pcap), "qinfo": i32(pcap // 4), "sq": i32(2 * n_ranges + 1), "sn": i32(2 * n_ranges + 1),
+                    "win": i32(2 * (-(-n_ranges // int(L.xeq_message_wq_waves())))),
                     "work": torch.empty(max(int(L.xeq_message_wq_plan_workspace(N)), 1), dtype=torch.uint8, device=dev),
                     "records": None}
             self._wq[key] = plan
@@ -164,7 +165,7 @@ class EdgeGraph:
         plan["rowptr"] = rowptr
         call("xeq_message_wq_plan", ptr(rowptr), ptr(perm), ptr(owner), ptr(gather), self.n_nodes, self.n_edges, plan["n_ranges"],
              ptr(plan["work"]), plan["work"].numel(), ptr(plan["qptr"]), ptr(plan["pgath"]), ptr(plan["peid"]), ptr(plan["qinfo"]),
-             ptr(plan["sq"]), ptr(plan["sn"]), stream())
+             ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), stream())
 
     def refresh_plans(self) -> None:
         """Recompute the cached stream tables / walk plans in place after the CSR arrays were overwritten (HIP-graph
@@ -583,6 +584,20 @@ def _wm_edges_per_stream(n_edges: int, n_nodes: int) -> int:
     return int(min(128, max(16, per_node, n_edges / 1500)))
 
 
+def _wq_edges_per_stream(n_edges: int, n_nodes: int) -> int:
+    """Edges per half-wave stream of the wq kernels.  A step (what the four waves of a workgroup walk together: eight
+    streams) should gather from few enough nodes for its window to fit LDS: 64 edges per stream is ~30 owner nodes and
+    a window of two to four QM9-size molecules.  Small systems get shorter streams, as for wm.  XEQ_WQ_EDGES_PER_STREAM
+    fixes it."""
+    import os
+
+    env = os.environ.get("XEQ_WQ_EDGES_PER_STREAM")
+    if env:
+        return max(16, int(env))
+    per_node = n_edges / max(1, n_nodes)
+    return int(min(64, max(16, per_node, n_edges / 1500)))
+
+
 def wm_supported(dtype, num_basis, node_dim, mul) -> bool:
     return dtype == torch.float32 and bool(lib.load().xeq_message_wm_supported(int(num_basis), int(node_dim), mul3(mul)))
 
@@ -661,9 +676,9 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
     s_out, x_out = torch.empty_like(s), torch.empty_like(x)
     impl = select_message_impl(h.dtype, N, E, num_basis, node_dim, mul)
     if impl == "wq":
-        plan = graph.wq_plan(False, _wm_edges_per_stream(E, N))
+        plan = graph.wq_plan(False, _wq_edges_per_stream(E, N))
         basis, _ = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv=False)
-        KERNEL_TIMER.launch("xeq_message_fwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["rowptr"]),
+        KERNEL_TIMER.launch("xeq_message_fwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), ptr(plan["rowptr"]),
                             ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf),
                             ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
         return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, None, None), impl
@@ -700,10 +715,10 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x):
     g_vec = torch.empty_like(vec)  # written at the edge's own position by every kernel family
     if impl == "wq":
         N, E = graph.n_nodes, graph.n_edges
-        plan = graph.wq_plan(True, _wm_edges_per_stream(E, N))
+        plan = graph.wq_plan(True, _wq_edges_per_stream(E, N))
         basis, dbasis = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv=True)
         parts = torch.empty(max(1, lib.load().xeq_message_wq_parts_floats(N, E, mul3(mul))), dtype=h.dtype, device=h.device)
-        KERNEL_TIMER.launch("xeq_message_bwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["rowptr"]),
+        KERNEL_TIMER.launch("xeq_message_bwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), ptr(plan["rowptr"]),
                             ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x),
                             ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream())
         call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), mul3(mul), ptr(parts), ptr(g_vec),
