@@ -243,7 +243,7 @@ def main():
     torch.cuda.synchronize()
     xdist.barrier()
     elapsed = time.perf_counter() - t0
-    eager_ms = None
+    eager_ms = native_ms = None
     if args.eager:
         kernel_ms = ops.KERNEL_TIMER.summary()       # HIP events recorded on the launch stream, in the timed region
         kernel_timing = "HIP events around every launch of the timed region, on the launch stream"
@@ -261,6 +261,27 @@ def main():
             step_eager()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - te) / cal * 1e3
+        if not sharded and cell is None and dtype == torch.float32:
+            # the same step through ONE registered operator (xeq::xpainn_eval, csrc/xeq_torch.cpp): every kernel enqueued
+            # from C++, nothing captured -- what a stream of batches with ever-new topologies pays
+            try:
+                from xequinet_amd.interface.scripted import XPaiNNNative
+                native = XPaiNNNative(model)
+
+                def step_native():
+                    batch = transform(XequiBatch(pos_d.detach(), z_d, ptr_d))
+                    return native(batch.pos, batch.atomic_numbers, batch.edge_index, batch.ptr, None, None, True, True, True, False)
+
+                step_native()
+                torch.cuda.synchronize()
+                tn = time.perf_counter()
+                for _ in range(cal):
+                    got = step_native()
+                torch.cuda.synchronize()
+                native_ms = (time.perf_counter() - tn) / cal * 1e3
+                assert torch.equal(got[2], out_keep["forces"]), "native operator and graph replay disagree"
+            except ImportError as err:
+                print(f"[bench] native operator not timed: {err}", file=sys.stderr, flush=True)
         ops.KERNEL_TIMER.reset(enabled=True)
         for _ in range(cal):
             step_eager()
@@ -308,6 +329,7 @@ def main():
         line = {
             "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_eager": eager_ms if eager_ms is not None else ms_per_step,
+            "ms_per_step_native_op": native_ms,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {syn.WORKLOADS[args.workload]} ({what}), 5 A cutoff, default XPaiNN (865141 params, "
@@ -316,7 +338,8 @@ def main():
                        "parallelism": f"molecule shards x{world}, no collectives", "chunks_rank0": n_chunks,
                        "library_gemm_selection": "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)",
                        "launch": "host launch per kernel" if args.eager else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host",
-                       "ms_per_step_eager": "the same step with every kernel launched from the host (what a stream of batches with ever-new edge counts pays), measured on rank 0 right after the timed region"},
+                       "ms_per_step_eager": "the same step with every kernel launched from the host through the Python modules, measured on rank 0 right after the timed region",
+                       "ms_per_step_native_op": "the same step as ONE registered operator (xeq::xpainn_eval: kernels enqueued from C++, no capture): what a stream of batches with ever-new edge counts pays"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -251,3 +251,100 @@ def test_replay_with_timed_gemm_selection_meets_the_fp32_parity_bar():
         torch.cuda.tunable.enable(False)
     assert fast._replay.captures == 1
     assert torch.equal(b["forces"], c["forces"]) and torch.equal(b["energy"], c["energy"])
+
+
+# ------------------------------------------------------------------ TorchScript front ends (registered xeq:: operators)
+def _native_vs_python(dtype, periodic):
+    """xeq::xpainn_eval (C++: csrc/xeq_torch.cpp) against the Python modules (nn/fused.py): same kernels, same order."""
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.interface.scripted import XPaiNNNative
+
+    model, _ = P._build(dtype)
+    native = XPaiNNNative(model)
+    if periodic:
+        f = P._load("radius_graph_pbc_water192.npz")
+        _, z, ptr, _ = syn.synth_water_box(4, seed=5)
+        data = {"pos": P._t(f["pos"], dtype), "atomic_numbers": P._t(z.astype(np.int32)), "edge_index": P._t(f["edge_index"]),
+                "ptr": P._t(ptr), "batch": P._t(np.zeros(len(z), dtype=np.int64)), "cell": P._t(f["cell"], dtype),
+                "cell_offsets": P._t(f["cell_offsets"], dtype)}
+        cs, sym = True, False
+    else:
+        pos, z, ptr = syn.synth_qm9_batch(24, seed=13)
+        b = NeighborTransform(5.0)(XequiBatch(P._t(pos, dtype), P._t(z), P._t(ptr)))
+        data = b.to_dict()
+        cs, sym = True, True
+    with torch.enable_grad():
+        want = model(dict(data), compute_forces=True, compute_virial=periodic)
+    got = native(data["pos"].detach(), data["atomic_numbers"], data["edge_index"], data["ptr"], data.get("cell"),
+                 data.get("cell_offsets"), cs, sym, True, periodic)
+    return got, want
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_native_operator_equals_python_modules_bitwise(dtype, periodic):
+    got, want = _native_vs_python(dtype, periodic)
+    assert torch.equal(got[0], want["energy"].detach()), (got[0] - want["energy"]).abs().max()
+    assert torch.equal(got[1], want["atomic_energies"].detach())
+    assert torch.equal(got[2], want["forces"].detach()), (got[2] - want["forces"]).abs().max()
+    if periodic:
+        assert torch.equal(got[3], want["virial"].detach()), (got[3] - want["virial"]).abs().max()
+
+
+def test_compile_model_scripts_saves_reloads_and_reproduces(tmp_path):
+    """run/jit_script.py:28-86: torch.jit.script of the LAMMPS front end, saved with `_extra_files`, reloaded, evaluated: the
+    eager XPaiNNLMP's energies and forces bit for bit; the GROMACS front end's energy and its autograd forces likewise."""
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.interface import XPaiNNGMX, XPaiNNLMP
+    from xequinet_amd.interface.scripted import compile_model
+
+    dtype = torch.float32
+    lmp, _ = _twin(XPaiNNLMP, dtype, unit_style="real")
+    path = str(tmp_path / "xpainn-lmp-real.jit")
+    compile_model(lmp, mode="lmp", unit_style="real", output_file=path)
+    extra = {"cutoff_radius": "", "n_species": "", "periodic_table": "", "fusion_strategy": ""}
+    loaded = torch.jit.load(path, _extra_files=extra)
+    assert float(extra["cutoff_radius"]) == pytest.approx(lmp.cutoff_radius) and int(extra["n_species"]) == 87
+    assert extra["periodic_table"].decode().split()[:3] == ["X", "H", "He"]
+    pos, z, ptr = syn.synth_qm9_batch(1, seed=3)
+    b = NeighborTransform(5.0)(XequiBatch(P._t(pos, dtype), P._t(z), P._t(ptr)))
+    data = {"pos": b.pos, "atomic_numbers": b.atomic_numbers, "edge_index": b.edge_index}
+    with torch.enable_grad():
+        want = lmp(dict(data), compute_forces=True, compute_virial=False)
+    got = loaded(dict(data), True, False)
+    assert set(got) == {"energy", "atomic_energies", "forces"}
+    assert torch.equal(got["energy"], want["energy"].detach()) and torch.equal(got["forces"], want["forces"].detach())
+
+    gmx, _ = _twin(XPaiNNGMX, dtype)
+    path = str(tmp_path / "xpainn-gmx.pt")
+    compile_model(gmx, mode="gmx", output_file=path)
+    loaded = torch.jit.load(path)
+    p_nm = (b.pos / 10.0).detach()
+    pa = p_nm.clone().requires_grad_()
+    ea = gmx(pa, b.atomic_numbers)
+    (fa,) = torch.autograd.grad(ea.sum(), pa)
+    pb = p_nm.clone().requires_grad_()
+    eb = loaded(pb, b.atomic_numbers)
+    (fb,) = torch.autograd.grad(eb.sum(), pb)
+    assert torch.equal(ea.detach(), eb.detach())
+    np.testing.assert_allclose(fb.cpu().numpy(), fa.cpu().numpy(), rtol=0, atol=2e-6 * float(fa.abs().max()))
+
+
+def test_native_operator_on_a_stream_of_new_topologies_matches_oracle():
+    """One operator call per batch, every batch with another edge count (nothing to replay): energies / forces against the
+    fp64 oracle."""
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.interface.scripted import XPaiNNNative
+
+    model, oracle = P._build(torch.float64)
+    native = XPaiNNNative(model)
+    seen = set()
+    for seed in (1, 2, 3):
+        pos, z, ptr = syn.synth_qm9_batch(5 + seed, seed=40 + seed)
+        b = NeighborTransform(5.0)(XequiBatch(P._t(pos, torch.float64), P._t(z), P._t(ptr)))
+        seen.add(b.edge_index.shape[1])
+        out = native(b.pos, b.atomic_numbers, b.edge_index, b.ptr, None, None, True, True, True, False)
+        want = oracle(_oracle_in(pos, z, ptr, b.edge_index.cpu().numpy()), compute_forces=True)
+        np.testing.assert_allclose(out[0].cpu().numpy(), want["energy"].numpy(), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(out[2].cpu().numpy(), want["forces"].numpy(), rtol=0, atol=1e-9)
+    assert len(seen) == 3

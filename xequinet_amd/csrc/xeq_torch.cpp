@@ -1,0 +1,511 @@
+// TorchScript-visible operators over the C ABI of libxeq_hip.so (include/xeq.h).
+//
+// Reference: the reference ships its models to LAMMPS / GROMACS as TorchScript files (run/jit_script.py:28-86 scripts
+// interface/jit_model.py:12-216 and saves it with `_extra_files`); its hot ops live in third-party extensions that are
+// themselves registered torch operators (torch_scatter, torch_cluster), so `torch.jit.script` sees schemas, not Python.
+// This file gives the HIP path the same footing: operators in the `xeq::` namespace with schemas, registered through
+// TORCH_LIBRARY, loadable from Python (`torch.ops.load_library`) and from a libtorch host program (dlopen before
+// torch::jit::load).
+//
+//   xeq::xpainn_eval      ONE operator for a whole energy (+ forces, + virial) evaluation of XPaiNN (nn/model.py:26-46):
+//                         edge geometry -> embedding -> n x [message + update] -> energy head -> explicit reverse pass.
+//                         Every stage is the same HIP kernel the Python modules launch (nn/fused.py is the Python twin of
+//                         this file and the two are compared bit for bit in tests/test_gpu_interface.py); the dense
+//                         contractions are ATen GEMMs.  Enqueued from C++: a batch with a never-seen topology costs its
+//                         GPU time plus ~150 native launches, no Python between kernels and no graph capture.
+//                         Autograd: `energy` is differentiable w.r.t. `pos` (backward = -forces), which is how the
+//                         GROMACS-style model hands forces to its caller (interface/jit_model.py:208-214).
+//   xeq::radius_graph     open-boundary neighbour list (data/transform.py:58-64), canonical (center, neighbor) order.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/library.h>
+
+#include <cmath>
+#include <vector>
+
+#include "../../include/xeq.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+#define XCALL(...)                                                                                  \
+  do {                                                                                              \
+    const int st_ = (__VA_ARGS__);                                                                  \
+    TORCH_CHECK(st_ == 0, "xequinet_amd: ", #__VA_ARGS__, " failed (", st_, "): ", xeq_last_error()); \
+  } while (0)
+
+void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+const void* P(const Tensor& t) { return t.defined() && t.numel() > 0 ? t.data_ptr() : (t.defined() ? t.data_ptr() : nullptr); }
+void* Pm(Tensor& t) { return t.defined() ? t.data_ptr() : nullptr; }
+int dcode(const Tensor& t) {
+  TORCH_CHECK(t.scalar_type() == at::kFloat || t.scalar_type() == at::kDouble, "xequinet_amd: float32 / float64 tensors only");
+  return t.scalar_type() == at::kFloat ? XEQ_F32 : XEQ_F64;
+}
+void need_hip(const Tensor& t, const char* what) {
+  TORCH_CHECK(t.is_cuda(), "xequinet_amd ops run on MI355X (HIP) tensors only and have no CPU fallback; ", what, " is on ", t.device());
+}
+
+// ---------------------------------------------------------------------------------------------- graph plumbing
+struct WqPlan {
+  int n_ranges = 0;
+  int64_t pcap = 0;
+  Tensor qptr, pgath, peid, qinfo, sq, sn, win, rowptr, work, basis, dbasis;
+};
+struct Graph {
+  int64_t N = 0, E = 0;
+  Tensor ei, c_rowptr, c_perm, n_rowptr, n_perm;   // c_perm undefined: edges already center-sorted
+  WqPlan fwd, rev;
+  Tensor sb_basis, sb_dbasis;
+};
+
+Tensor i32(int64_t n, const Tensor& like) { return at::empty({std::max<int64_t>(n, 1)}, like.options().dtype(at::kInt)); }
+
+void csr_by_key(const Tensor& keys, int64_t n_rows, Tensor& rowptr, Tensor& perm) {
+  const int64_t n = keys.numel(), bytes = xeq_csr_by_key_workspace(n, n_rows);
+  TORCH_CHECK(bytes >= 0, "xequinet_amd: csr_by_key: sizes out of range");
+  Tensor work = at::empty({std::max<int64_t>(bytes, 1)}, keys.options().dtype(at::kByte));
+  rowptr = i32(n_rows + 1, keys);
+  perm = i32(n, keys);
+  XCALL(xeq_csr_by_key((const int64_t*)keys.data_ptr(), n, n_rows, work.data_ptr(), bytes, (int32_t*)rowptr.data_ptr(),
+                       (int32_t*)perm.data_ptr(), cur_stream()));
+}
+
+Graph build_graph(const Tensor& edge_index, int64_t n_nodes, bool center_sorted, bool symmetric) {
+  Graph g;
+  g.N = n_nodes;
+  g.ei = edge_index.contiguous();
+  g.E = g.ei.size(1);
+  const Tensor center = g.ei.select(0, 0), nbr = g.ei.select(0, 1);
+  if (center_sorted) {
+    g.c_rowptr = i32(n_nodes + 1, g.ei);
+    XCALL(xeq_csr_rowptr((const int64_t*)center.data_ptr(), g.E, n_nodes, (int32_t*)g.c_rowptr.data_ptr(), cur_stream()));
+  } else {
+    csr_by_key(center, n_nodes, g.c_rowptr, g.c_perm);
+  }
+  if (symmetric && center_sorted) {
+    g.n_rowptr = g.c_rowptr;
+    g.n_perm = i32(g.E, g.ei);
+    XCALL(xeq_reverse_edge_map((const int64_t*)g.ei.data_ptr(), g.E, n_nodes, (const int32_t*)g.c_rowptr.data_ptr(),
+                               (int32_t*)g.n_perm.data_ptr(), cur_stream()));
+  } else {
+    csr_by_key(nbr, n_nodes, g.n_rowptr, g.n_perm);
+  }
+  return g;
+}
+
+int wq_edges_per_stream(int64_t E, int64_t N) {   // ops._wq_edges_per_stream
+  const double per_node = (double)E / std::max<int64_t>(1, N);
+  return (int)std::min(64.0, std::max({16.0, per_node, (double)E / 1500.0}));
+}
+
+void build_wq_plan(const Graph& g, bool reverse, WqPlan& p) {
+  const int eps = wq_edges_per_stream(g.E, g.N);
+  p.n_ranges = (int)std::max<int64_t>(1, (g.E + 2 * eps - 1) / (2 * eps));
+  p.pcap = xeq_message_wq_pcap(g.N, g.E);
+  const int waves = xeq_message_wq_waves();
+  p.qptr = i32(g.N + 1, g.ei);
+  p.pgath = i32(p.pcap, g.ei);
+  p.peid = i32(p.pcap, g.ei);
+  p.qinfo = i32(p.pcap / 4, g.ei);
+  p.sq = i32(2 * p.n_ranges + 1, g.ei);
+  p.sn = i32(2 * p.n_ranges + 1, g.ei);
+  p.win = i32(2 * ((p.n_ranges + waves - 1) / waves), g.ei);
+  const int64_t wbytes = xeq_message_wq_plan_workspace(g.N);
+  TORCH_CHECK(wbytes >= 0, "xequinet_amd: wq plan workspace");
+  p.work = at::empty({std::max<int64_t>(wbytes, 1)}, g.ei.options().dtype(at::kByte));
+  p.rowptr = reverse ? g.n_rowptr : g.c_rowptr;
+  const Tensor& perm = reverse ? g.n_perm : g.c_perm;
+  const Tensor owner = g.ei.select(0, reverse ? 1 : 0), gather = g.ei.select(0, reverse ? 0 : 1);
+  XCALL(xeq_message_wq_plan((const int32_t*)p.rowptr.data_ptr(), perm.defined() ? (const int32_t*)perm.data_ptr() : nullptr,
+                            (const int64_t*)owner.data_ptr(), (const int64_t*)gather.data_ptr(), g.N, g.E, p.n_ranges,
+                            p.work.data_ptr(), wbytes, (int32_t*)p.qptr.data_ptr(), (int32_t*)p.pgath.data_ptr(),
+                            (int32_t*)p.peid.data_ptr(), (int32_t*)p.qinfo.data_ptr(), (int32_t*)p.sq.data_ptr(),
+                            (int32_t*)p.sn.data_ptr(), (int32_t*)p.win.data_ptr(), cur_stream()));
+}
+
+// ---------------------------------------------------------------------------------------------- model description
+// iparams: [node_dim, mul0, mul1, mul2, num_basis, n_blocks, rbf_kind, cutoff_kind, layer_norm, embed_kind, xhat_unused]
+// fparams: [cutoff, invariant_eps]
+// params (flat, in this order; undefined-by-absence entries are passed as empty tensors):
+//   0 embed_table [87, A] (embed_kind 0) or embedding matrix [100, F] (embed_kind 1);  1 embed_w [F, A];  2 embed_b [F]
+//   3 rbf_p0 [B];  4 rbf_p1 [B] (gaussian std; empty for bessel)
+//   per block i (MSG = 5 + 27 i):
+//     +0 mlp0_w [F,F]  +1 mlp0_b  +2 mlp2_w [H,F]  +3 mlp2_b  +4 rbf_w [H,B]  +5 rbf_b  +6 ln_w  +7 ln_b  +8 eq_w [C]  +9 eq_b [F]
+//     +10 uv_pack_l0 [mul0, 2 mul0]  +11 uv_pack_l1  +12 uv_pack_l2  +13 uv_bias [2 F]
+//     +14 dot_w [F, C]  +15 mlp3_w [F, F+C]  +16 mlp3_b  +17 mlp4_w [C+2F, F]  +18 mlp4_b  +19 ln_w  +20 ln_b  +21 eq_w  +22 eq_b
+//     (+23..26 reserved)
+//   tail: out0_w [Hd, F], out0_b, out2_w [1, Hd], out2_b
+constexpr int P_BLOCK0 = 5, P_PER_BLOCK = 27;
+struct Hyper {
+  int F, mul[3], B, blocks, rbf_kind, cutoff_kind, layer_norm, embed_kind;
+  double cutoff, inv_eps;
+  int C() const { return mul[0] + mul[1] + mul[2]; }
+  int D() const { return mul[0] + 3 * mul[1] + 5 * mul[2]; }
+  int H() const { return F + 2 * C(); }
+};
+
+const Tensor* opt(const Tensor& t) { return t.defined() && t.numel() > 0 ? &t : nullptr; }
+const void* OP(const Tensor& t) { return t.defined() && t.numel() > 0 ? t.data_ptr() : nullptr; }
+
+// views of a BT buffer as plain matrices [n (2l+1), width * mul_l] per non-empty l  (nn/fused.py::_bt_blocks)
+struct BtBlock {
+  int l, m;
+  Tensor view;
+};
+std::vector<BtBlock> bt_blocks(const Tensor& buf, int64_t n, const int mul[3], int width) {
+  std::vector<BtBlock> out;
+  int64_t base = 0;
+  for (int l = 0; l < 3; ++l) {
+    const int d = 2 * l + 1, m = mul[l];
+    if (m > 0) out.push_back({l, m, buf.narrow(0, n * base * width, n * d * m * width).view({n * d, (int64_t)width * m})});
+    base += (int64_t)d * m;
+  }
+  return out;
+}
+
+struct NormOut {
+  Tensor shat, xhat, stats;
+};
+NormOut norm_fwd(const Hyper& hy, const Tensor& s, const Tensor& x, const Tensor& lw, const Tensor& lb, const Tensor& ew,
+                 const Tensor& eb, Tensor shat_out, int64_t ld) {
+  const int64_t n = x.size(0);
+  NormOut o;
+  if (!shat_out.defined()) {
+    shat_out = at::empty({n, hy.F}, s.options());
+    ld = hy.F;
+  }
+  o.shat = shat_out;
+  o.xhat = at::empty({n * hy.D()}, x.options());
+  o.stats = at::empty({n, 4}, s.options());
+  const int32_t mul[3] = {hy.mul[0], hy.mul[1], hy.mul[2]};
+  XCALL(xeq_norm_fwd(dcode(s), s.data_ptr(), x.data_ptr(), hy.layer_norm ? lw.data_ptr() : nullptr,
+                     hy.layer_norm ? lb.data_ptr() : nullptr, hy.layer_norm ? ew.data_ptr() : nullptr,
+                     hy.layer_norm ? eb.data_ptr() : nullptr, n, hy.F, mul, hy.layer_norm, o.shat.data_ptr(), ld,
+                     o.xhat.data_ptr(), o.stats.data_ptr(), cur_stream()));
+  return o;
+}
+void norm_bwd(const Hyper& hy, const Tensor& s, const Tensor& x, const Tensor& lw, const Tensor& ew, const Tensor& stats,
+              const Tensor& g_shat, int64_t ld, const Tensor& g_xhat, const Tensor& res_s, const Tensor& res_x, Tensor& g_s,
+              Tensor& g_x) {
+  const int64_t n = x.size(0);
+  g_s = at::empty_like(s);
+  g_x = at::empty_like(x);
+  const int32_t mul[3] = {hy.mul[0], hy.mul[1], hy.mul[2]};
+  XCALL(xeq_norm_bwd(dcode(s), s.data_ptr(), x.data_ptr(), hy.layer_norm ? lw.data_ptr() : nullptr,
+                     hy.layer_norm ? ew.data_ptr() : nullptr, stats.data_ptr(), n, hy.F, mul, hy.layer_norm, g_shat.data_ptr(), ld,
+                     g_xhat.data_ptr(), res_s.data_ptr(), res_x.data_ptr(), g_s.data_ptr(), g_x.data_ptr(), cur_stream()));
+}
+
+// what one block keeps for the reverse pass
+struct MsgSaved {
+  Tensor s, x, stats, pre, h, xhat;
+  int impl = 0;   // 0 wq, 1 sb
+};
+struct UpdSaved {
+  Tensor s, x, stats, uv, pre, a, ip;
+};
+
+// ---------------------------------------------------------------------------------------------- the evaluation
+std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_numbers, const Tensor& edge_index, const Tensor& ptr,
+                                     const c10::optional<Tensor>& cell_o, const c10::optional<Tensor>& cell_offsets_o,
+                                     const std::vector<Tensor>& prm, const std::vector<int64_t>& ip, const std::vector<double>& fp,
+                                     bool center_sorted, bool symmetric, bool compute_forces, bool compute_virial) {
+  need_hip(pos_in, "pos");
+  need_hip(edge_index, "edge_index");
+  TORCH_CHECK(ip.size() >= 10 && fp.size() >= 2, "xeq::xpainn_eval: malformed hyper-parameter lists");
+  Hyper hy;
+  hy.F = (int)ip[0];
+  hy.mul[0] = (int)ip[1];
+  hy.mul[1] = (int)ip[2];
+  hy.mul[2] = (int)ip[3];
+  hy.B = (int)ip[4];
+  hy.blocks = (int)ip[5];
+  hy.rbf_kind = (int)ip[6];
+  hy.cutoff_kind = (int)ip[7];
+  hy.layer_norm = (int)ip[8];
+  hy.embed_kind = (int)ip[9];
+  hy.cutoff = fp[0];
+  hy.inv_eps = fp[1];
+  TORCH_CHECK((int64_t)prm.size() == P_BLOCK0 + (int64_t)P_PER_BLOCK * hy.blocks + 4, "xeq::xpainn_eval: expected ",
+              P_BLOCK0 + P_PER_BLOCK * hy.blocks + 4, " parameter tensors, got ", prm.size());
+  TORCH_CHECK(edge_index.dim() == 2 && edge_index.size(0) == 2 && edge_index.scalar_type() == at::kLong, "edge_index must be int64 [2, E]");
+  const Tensor pos = pos_in.detach().contiguous();
+  const auto fopt = pos.options();
+  const int dt = dcode(pos);
+  const int64_t N = pos.size(0), G = ptr.numel() - 1;
+  const int C = hy.C(), D = hy.D(), H = hy.H(), F = hy.F;
+  const int32_t mul[3] = {hy.mul[0], hy.mul[1], hy.mul[2]};
+  const Tensor ptr64 = ptr.to(at::kLong).contiguous();
+  void* st = cur_stream();
+
+  Graph g = build_graph(edge_index, N, center_sorted, symmetric);
+  const int64_t E = g.E;
+
+  // ---- edge geometry (nn/basic.py:110-131)
+  Tensor cell, cell_offsets, batch;
+  const bool has_cell = cell_o.has_value() && cell_o->defined();
+  if (has_cell) {
+    TORCH_CHECK(cell_offsets_o.has_value() && cell_offsets_o->defined(), "cell without cell_offsets");
+    cell = cell_o->to(pos.scalar_type()).contiguous();
+    cell_offsets = cell_offsets_o->to(pos.scalar_type()).contiguous();
+    if (G > 1) {
+      const Tensor counts = ptr64.slice(0, 1) - ptr64.slice(0, 0, G);
+      batch = at::repeat_interleave(at::arange(G, ptr64.options()), counts, 0, N);
+    }
+  }
+  Tensor vec = at::empty({E, 3}, fopt), dist = at::empty({E}, fopt);
+  XCALL(xeq_edge_vectors_fwd(dt, pos.data_ptr(), (const int64_t*)g.ei.data_ptr(), E, has_cell ? cell.data_ptr() : nullptr,
+                             has_cell ? cell_offsets.data_ptr() : nullptr, batch.defined() ? (const int64_t*)batch.data_ptr() : nullptr,
+                             vec.data_ptr(), dist.data_ptr(), st));
+
+  // ---- embedding (nn/xpainn.py:55-83)
+  Tensor s;
+  if (hy.embed_kind == 0) s = at::addmm(prm[2], prm[0].index_select(0, atomic_numbers.to(at::kLong)), prm[1].t());
+  else s = prm[0].index_select(0, atomic_numbers.to(at::kLong));
+  Tensor x = at::zeros({N, D}, fopt);
+  const Tensor& p0 = prm[3];
+  const Tensor& p1 = prm[4];
+
+  // ---- which message kernels (ops.select_message_impl, without the wm / generic forms)
+  int impl;
+  if (dt == XEQ_F32 && xeq_message_wq_fits(N, E, hy.B, F, mul)) impl = 0;
+  else if (xeq_message_sb_fits(N, E, hy.B, F, mul)) impl = 1;
+  else TORCH_CHECK(false, "xeq::xpainn_eval: this configuration / size needs the generic message kernels: use the Python modules");
+  if (impl == 0) {
+    build_wq_plan(g, false, g.fwd);
+    g.fwd.basis = at::empty({g.fwd.pcap, 32}, fopt);
+    XCALL(xeq_edge_basis_wq(vec.data_ptr(), N, E, (const int32_t*)g.fwd.qptr.data_ptr(), (const int32_t*)g.fwd.peid.data_ptr(),
+                            hy.rbf_kind, hy.cutoff_kind, hy.B, hy.cutoff, p0.data_ptr(), OP(p1), g.fwd.basis.data_ptr(), nullptr, st));
+  } else {
+    const int w = xeq_edge_basis_width(hy.B);
+    g.sb_basis = at::empty({E, w}, fopt);
+    g.sb_dbasis = at::empty({E, w}, fopt);
+    XCALL(xeq_edge_basis(dt, vec.data_ptr(), E, hy.rbf_kind, hy.cutoff_kind, hy.B, hy.cutoff, p0.data_ptr(), OP(p1),
+                         g.sb_basis.data_ptr(), g.sb_dbasis.data_ptr(), st));
+  }
+
+  std::vector<MsgSaved> msv(hy.blocks);
+  std::vector<UpdSaved> usv(hy.blocks);
+  for (int b = 0; b < hy.blocks; ++b) {
+    const Tensor* q = &prm[P_BLOCK0 + P_PER_BLOCK * b];
+    {  // ---- XPainnMessage.forward (nn/xpainn.py:128-161; nn/fused.py::MessageBlock)
+      MsgSaved& m = msv[b];
+      m.s = s;
+      m.x = x;
+      NormOut no = norm_fwd(hy, s, x, q[6], q[7], q[8], q[9], Tensor(), 0);
+      m.stats = no.stats;
+      m.xhat = no.xhat;
+      m.pre = at::addmm(q[1], no.shat, q[0].t());
+      m.h = at::addmm(q[3], at::silu(m.pre), q[2].t());
+      Tensor s_out = at::empty_like(s), x_out = at::empty_like(x);
+      m.impl = impl;
+      if (impl == 0) {
+        XCALL(xeq_message_fwd_wq(N, E, g.fwd.n_ranges, (const int32_t*)g.fwd.sq.data_ptr(), (const int32_t*)g.fwd.sn.data_ptr(),
+                                 (const int32_t*)g.fwd.win.data_ptr(), (const int32_t*)g.fwd.rowptr.data_ptr(),
+                                 (const int32_t*)g.fwd.pgath.data_ptr(), (const int32_t*)g.fwd.qinfo.data_ptr(), g.fwd.basis.data_ptr(),
+                                 m.h.data_ptr(), m.xhat.data_ptr(), s.data_ptr(), x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B,
+                                 F, mul, s_out.data_ptr(), x_out.data_ptr(), 1, st));
+      } else {
+        XCALL(xeq_message_fwd_sb(dt, N, E, (const int32_t*)g.c_rowptr.data_ptr(),
+                                 g.c_perm.defined() ? (const int32_t*)g.c_perm.data_ptr() : nullptr,
+                                 (const int64_t*)g.ei.select(0, 1).data_ptr(), g.sb_basis.data_ptr(), m.h.data_ptr(), m.xhat.data_ptr(),
+                                 s.data_ptr(), x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B, F, mul, s_out.data_ptr(),
+                                 x_out.data_ptr(), 1, st));
+      }
+      s = s_out;
+      x = x_out;
+    }
+    {  // ---- XPainnUpdate.forward (nn/xpainn.py:206-231; nn/fused.py::UpdateBlock)
+      UpdSaved& u = usv[b];
+      u.s = s;
+      u.x = x;
+      Tensor cat = at::empty({N, F + C}, fopt);
+      NormOut no = norm_fwd(hy, s, x, q[19], q[20], q[21], q[22], cat, F + C);
+      u.stats = no.stats;
+      u.uv = at::empty({2 * N * D}, fopt);
+      auto xb = bt_blocks(no.xhat, N, hy.mul, 1), ub = bt_blocks(u.uv, N, hy.mul, 2);
+      for (size_t k = 0; k < xb.size(); ++k) {
+        const Tensor& W = q[10 + xb[k].l];
+        if (xb[k].l == 0 && q[13].numel() > 0) at::addmm_out(ub[k].view, q[13], xb[k].view, W);
+        else at::mm_out(ub[k].view, xb[k].view, W);
+      }
+      Tensor p = at::empty({N, C}, fopt);
+      XCALL(xeq_uv_reduce_fwd(dt, u.uv.data_ptr(), N, mul, hy.inv_eps, cat.data_ptr(), F + C, F, p.data_ptr(), st));
+      u.pre = at::addmm(q[16], cat, q[15].t());
+      u.a = at::addmm(q[18], at::silu(u.pre), q[17].t());
+      u.ip = at::mm(p, q[14].t());
+      Tensor s_out = at::empty_like(s), x_out = at::empty_like(x);
+      XCALL(xeq_update_out_fwd(dt, s.data_ptr(), x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
+                               s_out.data_ptr(), x_out.data_ptr(), st));
+      s = s_out;
+      x = x_out;
+    }
+  }
+  // ---- EnergyOut.forward (nn/output.py:114-128)
+  const Tensor* t = &prm[P_BLOCK0 + P_PER_BLOCK * hy.blocks];
+  const Tensor pre_o = at::addmm(t[1], s, t[0].t());
+  const Tensor atomic = at::addmm(t[3], at::silu(pre_o), t[2].t()).reshape({-1});
+  Tensor energy = at::empty({G}, fopt);
+  XCALL(xeq_segment_sum(dt, atomic.data_ptr(), (const int64_t*)ptr64.data_ptr(), G, 1, energy.data_ptr(), st));
+
+  Tensor forces, virial;
+  if (compute_forces || compute_virial) {
+    // ---- explicit reverse pass: dE/ds of the head, then the blocks backwards, then the edge geometry (nn/basic.py:143-199)
+    Tensor g_s = at::mm(at::silu_backward(t[2].expand({N, t[2].size(1)}), pre_o), t[0]);   // dE_i/d atomic_i = 1
+    Tensor g_x = at::zeros({N, D}, fopt);
+    Tensor g_vec_total;
+    if (impl == 0) {
+      build_wq_plan(g, true, g.rev);
+      g.rev.basis = at::empty({g.rev.pcap, 32}, fopt);
+      g.rev.dbasis = at::empty({g.rev.pcap, 32}, fopt);
+      XCALL(xeq_edge_basis_wq(vec.data_ptr(), N, E, (const int32_t*)g.rev.qptr.data_ptr(), (const int32_t*)g.rev.peid.data_ptr(),
+                              hy.rbf_kind, hy.cutoff_kind, hy.B, hy.cutoff, p0.data_ptr(), OP(p1), g.rev.basis.data_ptr(),
+                              g.rev.dbasis.data_ptr(), st));
+    }
+    for (int b = hy.blocks - 1; b >= 0; --b) {
+      const Tensor* q = &prm[P_BLOCK0 + P_PER_BLOCK * b];
+      {  // UpdateBlock.backward
+        const UpdSaved& u = usv[b];
+        Tensor g_a = at::empty_like(u.a), g_ip = at::empty_like(u.ip), g_uv = at::empty_like(u.uv);
+        XCALL(xeq_update_out_bwd(dt, g_s.data_ptr(), g_x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
+                                 g_a.data_ptr(), g_ip.data_ptr(), nullptr, st));
+        const Tensor g_p = at::mm(g_ip, q[14]);
+        const Tensor g_pre = at::silu_backward(at::mm(g_a, q[17]), u.pre);
+        const Tensor g_cat = at::mm(g_pre, q[15]);
+        XCALL(xeq_uv_reduce_bwd(dt, u.uv.data_ptr(), g_p.data_ptr(), g_cat.data_ptr(), F + C, F, N, mul, hy.inv_eps, g_x.data_ptr(),
+                                u.a.data_ptr(), g_uv.data_ptr(), st));
+        Tensor g_xhat = at::empty({N * D}, fopt);
+        auto gb = bt_blocks(g_xhat, N, hy.mul, 1), gub = bt_blocks(g_uv, N, hy.mul, 2);
+        for (size_t k = 0; k < gb.size(); ++k) at::mm_out(gb[k].view, gub[k].view, q[10 + gb[k].l].t());
+        Tensor ns, nx;
+        norm_bwd(hy, u.s, u.x, q[19], q[21], u.stats, g_cat, F + C, g_xhat, g_s, g_x, ns, nx);
+        g_s = ns;
+        g_x = nx;
+      }
+      {  // MessageBlock.backward
+        const MsgSaved& m = msv[b];
+        Tensor g_h = at::empty_like(m.h), g_xhat = at::empty_like(m.xhat), g_vec = at::empty_like(vec);
+        if (m.impl == 0) {
+          Tensor parts = at::empty({std::max<int64_t>(1, xeq_message_wq_parts_floats(N, E, mul))}, fopt);
+          XCALL(xeq_message_bwd_wq(N, E, g.rev.n_ranges, (const int32_t*)g.rev.sq.data_ptr(), (const int32_t*)g.rev.sn.data_ptr(),
+                                   (const int32_t*)g.rev.win.data_ptr(), (const int32_t*)g.rev.rowptr.data_ptr(),
+                                   (const int32_t*)g.rev.pgath.data_ptr(), (const int32_t*)g.rev.qinfo.data_ptr(),
+                                   g.rev.basis.data_ptr(), g.rev.dbasis.data_ptr(), m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(),
+                                   g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B, F, mul, g_h.data_ptr(), g_xhat.data_ptr(),
+                                   parts.data_ptr(), 1, st));
+          XCALL(xeq_message_wq_edge_grad(vec.data_ptr(), N, E, (const int32_t*)g.rev.qptr.data_ptr(),
+                                         (const int32_t*)g.rev.peid.data_ptr(), mul, parts.data_ptr(), g_vec.data_ptr(), st));
+        } else {
+          XCALL(xeq_message_bwd_sb(dt, N, E, (const int32_t*)g.n_rowptr.data_ptr(), (const int32_t*)g.n_perm.data_ptr(),
+                                   (const int64_t*)g.ei.select(0, 0).data_ptr(), g.sb_basis.data_ptr(), g.sb_dbasis.data_ptr(),
+                                   m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(), g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
+                                   hy.B, F, mul, g_h.data_ptr(), g_xhat.data_ptr(), g_vec.data_ptr(), 1, st));
+        }
+        g_vec_total = g_vec_total.defined() ? g_vec_total + g_vec : g_vec;
+        const Tensor g_pre = at::silu_backward(at::mm(g_h, q[2]), m.pre);
+        const Tensor g_shat = at::mm(g_pre, q[0]);
+        Tensor ns, nx;
+        norm_bwd(hy, m.s, m.x, q[6], q[8], m.stats, g_shat, F, g_xhat, g_s, g_x, ns, nx);
+        g_s = ns;
+        g_x = nx;
+      }
+    }
+    if (!g_vec_total.defined()) g_vec_total = at::zeros_like(vec);
+    g_vec_total = g_vec_total.contiguous();
+    if (compute_forces) {
+      Tensor grad_pos = at::empty({N, 3}, fopt);
+      XCALL(xeq_edge_vectors_bwd(dt, g_vec_total.data_ptr(), N, (const int32_t*)g.c_rowptr.data_ptr(),
+                                 g.c_perm.defined() ? (const int32_t*)g.c_perm.data_ptr() : nullptr,
+                                 (const int32_t*)g.n_rowptr.data_ptr(), (const int32_t*)g.n_perm.data_ptr(), grad_pos.data_ptr(), st));
+      forces = grad_pos.neg();
+    }
+    if (compute_virial) {   // sym(sum_e vec_e (x) dE/dvec_e) per graph, edges walked center-sorted (ops.EdgeVectors.backward)
+      Tensor outer = (vec.unsqueeze(2) * g_vec_total.unsqueeze(1)).reshape({-1, 9});
+      if (g.c_perm.defined()) outer = outer.index_select(0, g.c_perm.to(at::kLong));
+      const Tensor eptr = g.c_rowptr.to(at::kLong).index_select(0, ptr64).contiguous();
+      outer = outer.contiguous();
+      Tensor msum = at::empty({G, 9}, fopt);
+      XCALL(xeq_segment_sum(dt, outer.data_ptr(), (const int64_t*)eptr.data_ptr(), G, 9, msum.data_ptr(), st));
+      msum = msum.view({G, 3, 3});
+      virial = (0.5 * (msum + msum.transpose(1, 2))).neg();
+    }
+  }
+  if (!forces.defined()) forces = at::empty({0, 3}, fopt);
+  if (!virial.defined()) virial = at::empty({0, 3, 3}, fopt);
+  return {energy, atomic, forces, virial};
+}
+
+// autograd wrapper: energy (and nothing else) is differentiable w.r.t. pos; backward = -forces * grad_energy[graph]
+class XpainnEvalFn : public torch::autograd::Function<XpainnEvalFn> {
+ public:
+  static variable_list forward(AutogradContext* ctx, const Tensor& pos, const Tensor& atomic_numbers, const Tensor& edge_index,
+                               const Tensor& ptr, const c10::optional<Tensor>& cell, const c10::optional<Tensor>& cell_offsets,
+                               std::vector<Tensor> prm, std::vector<int64_t> ip, std::vector<double> fp, bool center_sorted,
+                               bool symmetric, bool compute_forces, bool compute_virial) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const bool need = compute_forces || pos.requires_grad();
+    auto out = xpainn_eval_impl(pos, atomic_numbers, edge_index, ptr, cell, cell_offsets, prm, ip, fp, center_sorted, symmetric, need,
+                                compute_virial);
+    ctx->save_for_backward({out[2], ptr});
+    ctx->mark_non_differentiable({out[1], out[2], out[3]});
+    return {out[0], out[1], out[2], out[3]};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor& forces = saved[0];
+    const Tensor ptr = saved[1].to(at::kLong);
+    Tensor g_pos;
+    if (grads[0].defined() && forces.size(0) > 0) {
+      const int64_t G = ptr.numel() - 1, N = forces.size(0);
+      const Tensor counts = ptr.slice(0, 1) - ptr.slice(0, 0, G);
+      const Tensor per_atom = at::repeat_interleave(grads[0].reshape({-1}), counts, 0, N);
+      g_pos = forces.neg() * per_atom.unsqueeze(1);
+    }
+    variable_list r(13);
+    r[0] = g_pos;
+    return r;
+  }
+};
+
+std::vector<Tensor> xpainn_eval(const Tensor& pos, const Tensor& atomic_numbers, const Tensor& edge_index, const Tensor& ptr,
+                                const c10::optional<Tensor>& cell, const c10::optional<Tensor>& cell_offsets, std::vector<Tensor> prm,
+                                std::vector<int64_t> ip, std::vector<double> fp, bool center_sorted, bool symmetric,
+                                bool compute_forces, bool compute_virial) {
+  return XpainnEvalFn::apply(pos, atomic_numbers, edge_index, ptr, cell, cell_offsets, prm, ip, fp, center_sorted, symmetric,
+                             compute_forces, compute_virial);
+}
+
+// open-boundary neighbour list; one device-to-host read of the edge count, as the reference's nonzero()
+std::tuple<Tensor, Tensor> radius_graph(const Tensor& pos_in, const Tensor& ptr, double cutoff) {
+  need_hip(pos_in, "pos");
+  const Tensor pos = pos_in.detach().contiguous();
+  const Tensor ptr64 = ptr.to(at::kLong).contiguous();
+  const int64_t N = pos.size(0), G = ptr64.numel() - 1;
+  const int dt = dcode(pos);
+  Tensor deg = i32(N, ptr64), rowptr = i32(N + 1, ptr64);
+  void* st = cur_stream();
+  XCALL(xeq_radius_graph_count(dt, pos.data_ptr(), (const int64_t*)ptr64.data_ptr(), G, N, cutoff, (int32_t*)deg.data_ptr(), st));
+  XCALL(xeq_exclusive_scan_i32((const int32_t*)deg.data_ptr(), N, (int32_t*)rowptr.data_ptr(), st));
+  const int64_t E = N > 0 ? (int64_t)rowptr[N].item<int32_t>() : 0;
+  Tensor ei = at::empty({2, E}, ptr64.options());
+  XCALL(xeq_radius_graph_fill(dt, pos.data_ptr(), (const int64_t*)ptr64.data_ptr(), G, N, cutoff, (const int32_t*)rowptr.data_ptr(), E,
+                              (int64_t*)ei.data_ptr(), st));
+  return {ei, rowptr.narrow(0, 0, N + 1)};
+}
+
+}  // namespace
+
+TORCH_LIBRARY(xeq, m) {
+  m.def(
+      "xpainn_eval(Tensor pos, Tensor atomic_numbers, Tensor edge_index, Tensor ptr, Tensor? cell, Tensor? cell_offsets, "
+      "Tensor[] params, int[] iparams, float[] fparams, bool center_sorted, bool symmetric, bool compute_forces, "
+      "bool compute_virial) -> Tensor[]");
+  m.def("radius_graph(Tensor pos, Tensor ptr, float cutoff) -> (Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(xeq, Autograd, m) { m.impl("xpainn_eval", xpainn_eval); }
+TORCH_LIBRARY_IMPL(xeq, CompositeExplicitAutograd, m) { m.impl("radius_graph", radius_graph); }
