@@ -202,6 +202,17 @@ int xeq_segment_sum(int dtype, const void* src, const int64_t* ptr, int64_t n_se
 int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n, int64_t width, void* out,
                     int64_t n_out, void* stream);
 
+/* One instruction of a general Clebsch-Gordan e3nn.o3.TensorProduct (nn/tp.py:20-107 builds the instruction lists;
+ * nn/xe3net.py:133-146 'uuu', nn/output.py:411-421 'uuw'):
+ *   out[n, off_out + w (2 l3 + 1) + k] += coeff * sum_{u,v} W[..] sum_{i,j} cg[i,j,k] x1[n, off1 + u (2 l1 + 1) + i] x2[n, off2 + v (2 l2 + 1) + j]
+ * mode: 0 uvw, 1 uvu, 2 uvv, 3 uuw, 4 uuu, 5 uvuv (e3nn connection modes: which of u, v, w are tied); cg = the real
+ * Wigner-3j table [2 l1 + 1, 2 l2 + 1, 2 l3 + 1] (device memory, dtype of x); weight NULL = unweighted path, otherwise
+ * the path's weights in e3nn's order, shared (weight_stride 0) or one set per sample (weight_stride = floats per sample).
+ * The launches of a product's paths accumulate into a zero-initialised `out` in stream order: deterministic. */
+int xeq_tensor_product_path(int dtype, const void* x1, const void* x2, int64_t n, int dim1, int dim2, int dim_out, int off1,
+                            int off2, int off_out, int mul1, int mul2, int mul_out, int l1, int l2, int l3, int mode,
+                            const void* cg, const void* weight, int64_t weight_stride, double coeff, void* out, void* stream);
+
 /* ------------------------------------------------------------ fused message */
 
 /* GENERIC form (64-bit offsets, f32 / f64, up to 256 channels per kind): the fallback for sizes and layouts the

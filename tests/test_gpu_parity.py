@@ -568,7 +568,7 @@ def _build(dtype, **kw):
     return model.to(dtype).to(DEV), orc.XPaiNNOracle(sd, **kw)
 
 
-def _check_model(model, oracle, pos, z, ptr, ei, dtype, extra=None, etol=None, ftol=None, label=None):
+def _check_model(model, oracle, pos, z, ptr, ei, dtype, extra=None, etol=None, ftol=None, label=None, p99tol=None):
     batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
     ref_in = {"pos": torch.tensor(pos, dtype=torch.float64), "atomic_numbers": torch.tensor(z.astype(np.int64)),
               "edge_index": torch.tensor(ei), "batch": torch.tensor(batch), "ptr": torch.tensor(ptr)}
@@ -603,7 +603,7 @@ def _check_model(model, oracle, pos, z, ptr, ei, dtype, extra=None, etol=None, f
                                bound_dF_max=F32_FORCE_MAX, bound_dF_p99=F32_FORCE_P99, dtype="f32 HIP vs f64 oracle"))
         assert np.all(dE <= 1e-5 * np.abs(Eref) + 1e-4), (E - Eref)
         assert dF.max() <= (F32_FORCE_MAX if ftol is None else ftol), dF.max()
-        assert np.quantile(dF, 0.99) <= F32_FORCE_P99, np.quantile(dF, 0.99)
+        assert np.quantile(dF, 0.99) <= (F32_FORCE_P99 if p99tol is None else p99tol), np.quantile(dF, 0.99)
     return got, want
 
 
@@ -670,8 +670,11 @@ def test_model_pbc_water_energy_forces(dtype):
     model, oracle = _build(dtype)
     f = _load("radius_graph_pbc_water192.npz")
     pos, z, ptr, cell = syn.synth_water_box(4, seed=5)
+    # 192 atoms at ~54 neighbours each: the densest graph of the suite and only 576 force components, so the 99th
+    # percentile is its 6th largest error; measured 0.9e-4 .. 1.6e-4 (the fp32 oracle itself: ~2e-4 here): 3e-4
     _check_model(model, oracle, f["pos"].astype(np.float64), z, ptr, f["edge_index"], dtype,
-                 extra={"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)})
+                 extra={"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)},
+                 label="water_192 (periodic, golden edge list)", p99tol=3e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])

@@ -121,45 +121,47 @@ __global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __re
   }
 }
 
-// records in padded walk order; val(k) = f rho_k (k < B) | f (k == B) | 0, derivative record likewise
+// records in padded walk order; val(k) = f rho_k (k < B) | f (k == B) | 0, derivative record likewise.  Eight threads per
+// slot, one 16-byte store each: the geometry and the envelope are evaluated once per four values, not once per value
 __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
                              const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
                              const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
                              float* __restrict__ drec) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p = t >> 5;
+  const int64_t p = t >> 3;
   if (p >= pcap || p >= 4 * (int64_t)qptr[N]) return;
-  const int slot = (int)(t & 31);
+  const int grp = (int)(t & 7);   // floats [4 grp, 4 grp + 4) of the record: 0-2 even k, 3-5 odd k, 6-7 Y
   const int32_t e = peid[p];
-  float v = 0.f, dv = 0.f;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
   if (e >= 0) {
     const float rc = (float)rs.cutoff;
     const EdgeGeom<float> g = edge_geom<float>(vec[3 * (int64_t)e], vec[3 * (int64_t)e + 1], vec[3 * (int64_t)e + 2]);
-    if (slot < 2 * WQ_KH) {
-      const int k = slot < WQ_KH ? 2 * slot : 2 * (slot - WQ_KH) + 1, B = rs.num_basis;
+    if (grp < 6) {
+      const int B = rs.num_basis;
       float f, df;
       envelope<float>(rs.cutoff_kind, g.d, rc, f, df);
-      if (k < B) {
-        float rho, drho;
-        radial<float>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : 0.f, rho, drho);
-        v = f * rho;
-        dv = df * rho + f * drho;
-      } else if (k == B) {
-        v = f;
-        dv = df;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int slot = 4 * grp + c, k = slot < WQ_KH ? 2 * slot : 2 * (slot - WQ_KH) + 1;
+        if (k < B) {
+          float rho, drho;
+          radial<float>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : 0.f, rho, drho);
+          v[c] = f * rho;
+          dv[c] = df * rho + f * drho;
+        } else if (k == B) {
+          v[c] = f;
+          dv[c] = df;
+        }
       }
     } else {
       float y1[3], y2[5];
       sph_harm_l12<float>(g, y1, y2);
-      const int q = slot - 2 * WQ_KH;
-      const float y[8] = {y1[0], y1[1], y1[2], y2[0], y2[1], y2[2], y2[3], y2[4]};
-      v = y[0];
-#pragma unroll
-      for (int i = 1; i < 8; ++i) v = q == i ? y[i] : v;
+      if (grp == 6) v = f32x4{y1[0], y1[1], y1[2], y2[0]};
+      else v = f32x4{y2[1], y2[2], y2[3], y2[4]};
     }
   }
-  rec[t] = v;
-  if (drec) drec[t] = dv;
+  *reinterpret_cast<f32x4*>(rec + 4 * t) = v;
+  if (drec) *reinterpret_cast<f32x4*>(drec + 4 * t) = dv;
 }
 
 // ------------------------------------------------------------------------------------------------ common
@@ -598,10 +600,12 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int v = 4 * g + r, u = v - r0;
+          // explicit fma chains (this file is built with -ffp-contract=off): the window and the global instantiation of
+          // this body must round alike, or a node's result would depend on which one its step took
           const float gs = hs[u] * ds[v], ge = he[u] * de[v];
 #pragma unroll
-          for (int m = 0; m < NM; ++m) xq[m] += xv[u][m] * gs + (NM > 1 ? Y[m][r] : 1.f) * ge;
-          if constexpr (HAS_S) sq += hm[u] * dm[v];
+          for (int m = 0; m < NM; ++m) xq[m] = __builtin_fmaf(xv[u][m], gs, NM > 1 ? __builtin_fmaf(Y[m][r], ge, xq[m]) : xq[m] + ge);
+          if constexpr (HAS_S) sq = __builtin_fmaf(hm[u], dm[v], sq);
         }
 #pragma unroll
         for (int m = 0; m < NM; ++m) acc_x[m] = (keep[g] ? acc_x[m] : 0.f) + xq[m];
@@ -864,8 +868,8 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
           float dgs = 0.f;
 #pragma unroll
           for (int m = 0; m < NM; ++m) {
-            u[m] += ds[v] * gxq[r][m];
-            dgs += o_x[m] * gxq[r][m];
+            u[m] = __builtin_fmaf(ds[v], gxq[r][m], u[m]);
+            dgs = __builtin_fmaf(o_x[m], gxq[r][m], dgs);
           }
           pd[v] = (o_hs * dgs) * qs[v];
         }
@@ -874,10 +878,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         }
         float hsq = 0.f;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) hsq += o_x[m] * u[m];
+        for (int m = 0; m < NM; ++m) hsq = __builtin_fmaf(o_x[m], u[m], hsq);
         a_hs = (keep ? a_hs : 0.f) + hsq;
 #pragma unroll
-        for (int m = 0; m < NM; ++m) a_x[m] = (keep ? a_x[m] : 0.f) + o_hs * u[m];
+        for (int m = 0; m < NM; ++m) a_x[m] = __builtin_fmaf(o_hs, u[m], keep ? a_x[m] : 0.f);
         if (last) {
           wq_st(grad_h, own * row_h + wc.b_hs, a_hs);
           const uint32_t ox = own * wc.xnode_b + wc.b_x;
@@ -915,14 +919,14 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
             float Ym[4];
             wq_tread4<float>(tb, T_Y + 32 * (YOFF + m) + p0, Ym);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dge[r] += Ym[r] * gxq[r][m];
+            for (int r = 0; r < 4; ++r) dge[r] = __builtin_fmaf(Ym[r], gxq[r][m], dge[r]);
           }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int v = 4 * g + r;
-          heq += de[v] * dge[r];
-          pd[v] += (o_he * dge[r]) * qe[v];
+          heq = __builtin_fmaf(de[v], dge[r], heq);
+          pd[v] = __builtin_fmaf(o_he * dge[r], qe[v], pd[v]);
           wy[r] = o_he * de[v];
         }
         if constexpr (NM > 1) {   // dL/dY_lm of the quad's rows: first half of the sum over the unit's 32 channels
@@ -967,8 +971,8 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int v = 4 * g + r;
-          hmq += dm[v] * gsv[v];
-          pd[v] += (o_hm * gsv[v]) * qm[v];
+          hmq = __builtin_fmaf(dm[v], gsv[v], hmq);
+          pd[v] = __builtin_fmaf(o_hm * gsv[v], qm[v], pd[v]);
         }
         a_hm = (keep ? a_hm : 0.f) + hmq;
         if (last) wq_st(grad_h, own * row_h + wc.b_hm, a_hm);
@@ -1190,8 +1194,8 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
   if (n_edges == 0) return XEQ_OK;
-  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * WQ_REC;
-  XEQ_CHECK_ARG(total < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
+  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * 8;   // eight threads per record
+  XEQ_CHECK_ARG(pcap * WQ_REC < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
   hipLaunchKernelGGL(k_wq_records, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
                      peid, qptr, n_nodes, pcap, rs, (const float*)p0, (const float*)p1, (float*)basis, (float*)dbasis);

@@ -53,6 +53,8 @@ _PROTOS = {
     "xeq_eqln_fwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
     "xeq_eqln_bwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
     "xeq_segment_sum": [c_int, _P, _P, c_int64, c_int64, _P, _P],
+    "xeq_tensor_product_path": [c_int, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_int, _P, _P, c_int64, c_double, _P, _P],
     "xeq_scatter_add": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, _P],
     "xeq_message_fwd": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                         c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, c_int, _P],
