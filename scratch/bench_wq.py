@@ -52,15 +52,18 @@ if os.environ.get("XEQ_WQ_STAMPS"):
     import ctypes
     from xequinet_amd import lib
     L = lib.load()
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     L.xeq_wq_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
     L.xeq_wq_debug_stamps(buf)            # clear
-    os.environ["XEQ_MESSAGE_IMPL"] = "wq"
-    hh, xx, vv = h.clone(), xhat.clone(), vec.clone()
-    ops.FusedMessage.apply(hh, xx, vv, s, x, W, bias, p0, None, g, cfg); torch.cuda.synchronize()
+    run("wq"); torch.cuda.synchronize()
     L.xeq_wq_debug_stamps(buf)
-    names = ["step head", "window staging", "barrier after staging", "body prologue", "wait for record", "phase A issue", "phase B issue",
-             "MFMA issue", "phase D rows+stores", "publish next table", "barrier after step"]
-    tot = sum(buf[:11]); nw = buf[15]
-    print(f"forward kernel, l = 0 waves ({nw}): cycles by phase, one launch; {tot / max(nw, 1):.0f} cycles per wave")
-    for n, v in zip(names, buf): print(f"  {n:26s} {v / tot * 100:5.1f} %   {v / max(nw, 1):9.0f} per wave")
+    fn = ["step head", "window staging", "barrier after staging", "body prologue", "wait for record", "phase A issue", "phase B issue",
+          "MFMA issue", "phase D rows+stores", "publish next table", "barrier after step"]
+    bn = ["step head", "window staging", "barrier after staging", "body prologue", "wait for records", "tile top (gathers issued)",
+          "MFMA issue (3 passes)", "rows pass S", "rows pass E (+dY sums)", "rows pass M", "barrier after step", "dL/dd channel sums",
+          "publish next table"]
+    for title, names, off, cnt in (("forward kernel, l = 0 waves", fn, 0, buf[15]), ("reverse kernel, waves of one l", bn, 16, buf[31])):
+        vals = [buf[off + i] for i in range(len(names))]
+        tot = sum(vals)
+        print(f"{title} ({cnt}): cycles by phase, one launch; {tot / max(cnt, 1):.0f} cycles per wave")
+        for n, v in zip(names, vals): print(f"  {n:28s} {v / max(tot, 1) * 100:5.1f} %   {v / max(cnt, 1):9.0f} per wave")

@@ -404,7 +404,7 @@ __device__ __forceinline__ void wq_for_isolated(const WqArgs& a, int range, int 
 #endif
 
 // development (-DXEQ_WQ_STAMPS): cycles of the l = 0 waves per phase of the forward kernel, summed over a launch
-__device__ unsigned long long g_wq_stamps[16];
+__device__ unsigned long long g_wq_stamps[32];
 #ifdef XEQ_WQ_STAMPS
 #define WQ_STAMP(i)                                                                                          \
   do {                                                                                                       \
@@ -772,7 +772,8 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
                                             const float* __restrict__ h, const float* __restrict__ xhat_,
                                             const float* __restrict__ grad_s, const float* __restrict__ grad_x, const float* wl,
                                             float* __restrict__ grad_h, float* __restrict__ grad_xhat_, const WqParts parts,
-                                            int* tbl, const float* win, int w0) {
+                                            int* tbl, const float* win, int w0, unsigned long long* st_,
+                                            unsigned long long& last_) {
   constexpr bool HAS_S = NM == 1;
   constexpr int YOFF = NM == 3 ? 0 : 3;
   constexpr int ROWB = (NM + (HAS_S ? 1 : 0)) * 128;
@@ -821,6 +822,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       R[s] = row.R[0][s];
       Rd[s] = row.R[1][s];
     }
+    WQ_STAMP(4);   // waiting for the tile's records
     // gathered gradient rows of one quad (the center's grad_x, NM components per channel)
     auto load_gx = [&](int g, float (&gxq)[4][NM]) {
       uint32_t g0[4];
@@ -842,10 +844,17 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       }
     }
     float pd[16];
+    WQ_STAMP(5);   // tile top: gathers issued
+    // l > 0: the gathered rows are read one component at a time (four rows x one m), used and dropped: out of the LDS
+    // window a re-read costs 2 cycles, while holding a quad's 4 x NM values (next to the filters, pd and the per-quad
+    // partial sums) spilled 114 registers in the l = 2 role
+    auto gx4 = [&](const uint32_t (&g0)[4], int m, float (&gv)[4]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gv[r] = WIN ? wq_lds(win, g0[r] + lgx + 4u * m) : wq_ld(grad_x, g0[r] + wc.b_xe + 4u * m);
+    };
     {  // ---- pass S
-      float gxq[4][NM];
-      if constexpr (!HAS_S) load_gx(0, gxq);   // the first quad's rows fly under the MFMAs
       const f32x16 ds = wq_filter<KS>(R, Ws), qs = wq_filter<KS>(Rd, Ws);
+      WQ_STAMP(6);   // MFMA issue (all passes)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = 4 * hh + g;
@@ -855,27 +864,27 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         float o_x[NM];
 #pragma unroll
         for (int m = 0; m < NM; ++m) o_x[m] = wq_ld(xhat, own * wc.xnode_b + wc.b_x + m * wc.xcomp_b);
-        if constexpr (HAS_S) {
+        uint32_t g0[4];
+        if constexpr (!HAS_S) wq_tread4<uint32_t>(tb, T_G0 + 16 * hh + 4 * g, g0);
+        float u[NM], dgs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gxq[r][0] = gxs[g][r][0];
-        }
-        float u[NM];
+        for (int m = 0; m < NM; ++m) {
+          float gv[4];
+          if constexpr (HAS_S) {
 #pragma unroll
-        for (int m = 0; m < NM; ++m) u[m] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int v = 4 * g + r;
-          float dgs = 0.f;
-#pragma unroll
-          for (int m = 0; m < NM; ++m) {
-            u[m] = __builtin_fmaf(ds[v], gxq[r][m], u[m]);
-            dgs = __builtin_fmaf(o_x[m], gxq[r][m], dgs);
+            for (int r = 0; r < 4; ++r) gv[r] = gxs[g][r][0];
+          } else {
+            gx4(g0, m, gv);
           }
-          pd[v] = (o_hs * dgs) * qs[v];
+          u[m] = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            u[m] = __builtin_fmaf(ds[4 * g + r], gv[r], u[m]);
+            dgs[r] = __builtin_fmaf(o_x[m], gv[r], dgs[r]);
+          }
         }
-        if constexpr (!HAS_S) {
-          if (g < 3) load_gx(g + 1, gxq);   // rows of the next quad
-        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pd[4 * g + r] = (o_hs * dgs[r]) * qs[4 * g + r];
         float hsq = 0.f;
 #pragma unroll
         for (int m = 0; m < NM; ++m) hsq = __builtin_fmaf(o_x[m], u[m], hsq);
@@ -888,17 +897,17 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
           for (int m = 0; m < NM; ++m) wq_st(grad_xhat, ox + m * wc.xcomp_b, a_x[m]);
         }
-        if constexpr (NM > 1) XEQ_WQ_SB();   // one quad's gathered rows in flight beside the one being consumed, not all four
+        if constexpr (NM > 1) XEQ_WQ_SB();
       }
     }
     XEQ_WQ_SB();   // accumulator lifetimes of the passes stay disjoint
+    WQ_STAMP(7);   // rows of pass S
     const int my_q = half_beg + 4 * t + (my_r >> 2);                   // quad of the row this lane reports
     const bool keeper = j < 16 && my_q < half_end;                     // one 16-lane row per half stores
     const int64_t my_slot = 4 * (int64_t)my_q + (my_r & 3);
     {  // ---- pass E
-      float gxq[4][NM];
-      if constexpr (!HAS_S) load_gx(0, gxq);
       const f32x16 de = wq_filter<KS>(R, We), qe = wq_filter<KS>(Rd, We);
+      WQ_STAMP(6);
       float pq[NM > 1 ? NM : 1][4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -906,20 +915,19 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         const uint32_t own = (uint32_t)tb[T_QOWN + c];
         const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
         const float o_he = wq_ld(h, own * row_h + wc.b_hs + he_off);
-        if constexpr (HAS_S) {
+        uint32_t g0[4];
+        if constexpr (!HAS_S) wq_tread4<uint32_t>(tb, T_G0 + p0, g0);
+        float dge[4], heq = 0.f;   // dge[r] = <Y[r], gx[r]>, one component at a time
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gxq[r][0] = gxs[g][r][0];
-        }
-        float dge[4], wy[4], heq = 0.f;   // dge[r] = <Y[r], gx[r]>, one component at a time (few live values)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dge[r] = NM > 1 ? 0.f : gxq[r][0];
+        for (int r = 0; r < 4; ++r) dge[r] = NM > 1 ? 0.f : gxs[HAS_S ? g : 0][r][0];
         if constexpr (NM > 1) {
 #pragma unroll
           for (int m = 0; m < NM; ++m) {
-            float Ym[4];
+            float Ym[4], gv[4];
             wq_tread4<float>(tb, T_Y + 32 * (YOFF + m) + p0, Ym);
+            gx4(g0, m, gv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dge[r] = __builtin_fmaf(Ym[r], gxq[r][m], dge[r]);
+            for (int r = 0; r < 4; ++r) dge[r] = __builtin_fmaf(Ym[r], gv[r], dge[r]);
           }
         }
 #pragma unroll
@@ -927,19 +935,33 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
           const int v = 4 * g + r;
           heq = __builtin_fmaf(de[v], dge[r], heq);
           pd[v] = __builtin_fmaf(o_he * dge[r], qe[v], pd[v]);
-          wy[r] = o_he * de[v];
-        }
-        if constexpr (NM > 1) {   // dL/dY_lm of the quad's rows: first half of the sum over the unit's 32 channels
-#pragma unroll
-          for (int m = 0; m < NM; ++m)
-            pq[m][g] = wq_red_ab(wy[0] * gxq[0][m], wy[1] * gxq[1][m], wy[2] * gxq[2][m], wy[3] * gxq[3][m], b0, b1);
-        }
-        if constexpr (!HAS_S) {
-          if (g < 3) load_gx(g + 1, gxq);
         }
         a_he = (keep ? a_he : 0.f) + heq;
         if (last) wq_st(grad_h, own * row_h + wc.b_hs + he_off, a_he);
         if constexpr (NM > 1) XEQ_WQ_SB();
+      }
+      if constexpr (NM > 1) {
+        // dL/dY_lm of every row's edge, in a second walk over the quads: the d/dd filter is dead by now, which is the
+        // room the per-quad partial sums need (one walk spilled 48 registers in the l = 2 role)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int p0 = 16 * hh + 4 * g;
+          const uint32_t own = (uint32_t)tb[T_QOWN + 4 * hh + g];
+          const float o_he = wq_ld(h, own * row_h + wc.b_hs + he_off);
+          uint32_t g0[4];
+          wq_tread4<uint32_t>(tb, T_G0 + p0, g0);
+          float wy[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wy[r] = o_he * de[4 * g + r];
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {   // first half of the sum over the unit's 32 channels
+            float gv[4];
+            gx4(g0, m, gv);
+            pq[m][g] = wq_red_ab(wy[0] * gv[0], wy[1] * gv[1], wy[2] * gv[2], wy[3] * gv[3], b0, b1);
+            if constexpr (NM == 5) XEQ_WQ_SB();   // one component's butterfly at a time
+          }
+          XEQ_WQ_SB();
+        }
       }
       if constexpr (NM > 1) {
         float* dst = NM == 3 ? parts.y1 : parts.y2;
@@ -951,6 +973,8 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       }
     }
     XEQ_WQ_SB();
+    if constexpr (!HAS_S) wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // next tile's records
+    WQ_STAMP(8);   // rows of pass E (+ dL/dY sums)
     if constexpr (HAS_S) {  // ---- pass M
       float gsv[16];          // the centers' grad_s rows: only this pass reads them; they land under its MFMAs
 #pragma unroll
@@ -961,6 +985,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         for (int r = 0; r < 4; ++r) gsv[4 * g + r] = WIN ? wq_lds(win, g1[r] + lgs) : wq_ld(grad_s, g1[r] + wc.b_s);
       }
       const f32x16 dm = wq_filter<KS>(R, Wm), qm = wq_filter<KS>(Rd, Wm);
+      XEQ_WQ_SB();
+      wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // last MFMAs issued: next tile's records
+      XEQ_WQ_SB();
+      WQ_STAMP(6);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = 4 * hh + g;
@@ -979,7 +1007,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       }
     }
     XEQ_WQ_SB();
-    wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // the next tile's records land under the channel sums
+    WQ_STAMP(9);   // rows of pass M
     {  // ---- dL/dd of every row's edge: sum over the unit's 32 channels
       float pq[4];
 #pragma unroll
@@ -987,8 +1015,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       const float tot = wq_red_cd(pq[0], pq[1], pq[2], pq[3], b2, b3);
       if (keeper) parts.pd[(int64_t)unit * parts.P + my_slot] = tot;
     }
+    WQ_STAMP(11);  // dL/dd channel sums
     wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tnext, gbase);
     __builtin_amdgcn_wave_barrier();
+    WQ_STAMP(12);  // next table published
   }
 }
 
@@ -1001,6 +1031,10 @@ __device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int chunk, int unit
   constexpr int ROWB = (NM + (NM == 1 ? 1 : 0)) * 128;
   const WqCols wc = wq_cols<NM>(a, un, threadIdx.x & 31);
   const int s_end = min((chunk + 1) * a.steps_per_wg, a.n_steps);
+  unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+#ifdef XEQ_WQ_STAMPS
+  last_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int step = chunk * a.steps_per_wg; step < s_end; ++step) {
     const int w0 = a.win[2 * step], nrows = a.win[2 * step + 1];
 #ifdef XEQ_WQ_NO_WINDOW
@@ -1008,15 +1042,29 @@ __device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int chunk, int unit
 #else
     const bool use_win = nrows > 0 && nrows * ROWB <= WQ_WIN_FLOATS * 4;   // workgroup-uniform
 #endif
+    WQ_STAMP(0);
     if (use_win) wq_stage_bwd<NM>(a, un, grad_s, grad_x, w0, nrows, win);
+    WQ_STAMP(1);
     __syncthreads();
+    WQ_STAMP(2);
     const int range = step * WQ_WAVES + (threadIdx.x >> 6);
     if (range < a.n_ranges) {
-      if (use_win) wq_bwd_body<NM, KS, true>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, w0);
-      else wq_bwd_body<NM, KS, false>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, 0);
+      if (use_win) wq_bwd_body<NM, KS, true>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, w0, st_, last_);
+      else wq_bwd_body<NM, KS, false>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, 0, st_, last_);
     }
+    WQ_STAMP(3);
     __syncthreads();
+    WQ_STAMP(10);
   }
+#ifdef XEQ_WQ_STAMPS
+#ifndef XEQ_WQ_STAMP_L
+#define XEQ_WQ_STAMP_L 0
+#endif
+  if (NM == 2 * XEQ_WQ_STAMP_L + 1 && (threadIdx.x & 63) == 0) {   // reverse-kernel stamps go to slots 16..31 of the counter array
+    for (int i = 0; i < 13; ++i) atomicAdd(&g_wq_stamps[16 + i], st_[i]);
+    atomicAdd(&g_wq_stamps[31], 1ull);
+  }
+#endif
 }
 
 template <int KS>
@@ -1266,8 +1314,8 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
 }
 
 /* development: read and clear the phase cycle counters of a -DXEQ_WQ_STAMPS build */
-int xeq_wq_debug_stamps(unsigned long long out[16]) {
-  unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int xeq_wq_debug_stamps(unsigned long long out[32]) {
+  unsigned long long zero[32] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wq_stamps), sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_wq_stamps), zero, sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
   return XEQ_OK;
