@@ -394,6 +394,28 @@ int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, cons
                        const void* ip, int64_t n, int node_dim, const int32_t mul[3], void* g_a, void* g_ip,
                        void* g_uv_bt, void* stream);
 
+/* ---- two-layer scalar MLPs on the matrix cores (f32, hidden width 128) ----------------------------
+ * Replace nn.Sequential(Linear, SiLU, Linear) of XPainnMessage.scalar_mlp (nn/xpainn.py:103-107) and
+ * XPainnUpdate.update_mlp (nn/xpainn.py:177-181) and their input gradients: one launch each, the hidden
+ * activations stay on chip.  Weights are read from a packed copy in matrix-core fragment order with the bias as one
+ * more k-group (xeq_mlp_pack; xeq_mlp_packed_floats(n_out, k_in) floats):
+ *   packed W1  = pack(lin1.weight [128, k1], lin1.bias, transposed = 0)     forward stage 1
+ *   packed W2  = pack(lin2.weight [n2, 128], lin2.bias, transposed = 0)     forward stage 2
+ *   packed W2t = pack(lin2.weight viewed as [k_in = n2][n_out = 128], NULL, transposed = 1)   reverse stage 1
+ *   packed W1t = pack(lin1.weight viewed as [k_in = 128][n_out = k1], NULL, transposed = 1)   reverse stage 2
+ * xeq_mlp2_supported: 1 when the kernels take (dtype, k1, hidden, n2): f32, hidden 128, k1 % 32 == 0 (it is the
+ * reverse pass's output width), n2 % 32 == 0. */
+int xeq_mlp2_supported(int dtype, int k1, int hidden, int n2);
+int64_t xeq_mlp_packed_floats(int n_out, int k_in);
+int xeq_mlp_pack(const float* w, const float* bias, int n_out, int k_in, int transposed, float* packed, void* stream);
+/* y[n, n2] (row stride ldy, % 4 == 0) = silu(x[n, k1] (row stride ldx, % 4 == 0) W1^T + b1) W2^T + b2;
+ * pre[n, 128] = the pre-activation, kept for the reverse pass. */
+int xeq_mlp2_fwd(const float* x, int64_t ldx, int64_t n, int k1, const float* w1_packed, const float* w2_packed, int n2,
+                 float* pre, float* y, int64_t ldy, void* stream);
+/* gx[n, n2] = ((g[n, k1] W2) * silu'(pre)) W1 with k1 = the forward's n2 and n2 = the forward's k1. */
+int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2t_packed, const float* pre,
+                 const float* w1t_packed, int n2, float* gx, int64_t ldgx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,95 @@
+"""GPU parity of the matrix-core two-layer MLPs (xeq_mlp2_fwd / _bwd, csrc/xeq_mlp.hip) through the C ABI against an fp64
+restatement of nn.Sequential(Linear, SiLU, Linear) (nn/xpainn.py:103-107, :177-181) and of its input gradient.
+
+Tolerance: exact-f32 products with f32 accumulation over k <= 576 terms of O(1) operands: |err| <= 2e-5 absolute (the library
+GEMM chain it replaces sits at 3e-6..6e-6 on the same inputs)."""
+import numpy as np
+import pytest
+import torch
+
+from xequinet_amd import lib
+from xequinet_amd.lib import call, ptr, stream
+from xequinet_amd.nn import fused
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 2e-5
+
+
+def _seq(k1, n2, seed):
+    torch.manual_seed(seed)
+    seq = torch.nn.Sequential(torch.nn.Linear(k1, 128), torch.nn.SiLU(), torch.nn.Linear(128, n2)).to(DEV)
+    with torch.no_grad():
+        seq[0].bias.normal_()
+        seq[2].bias.normal_()
+    return seq.requires_grad_(False)
+
+
+def _ref(seq, x, g):
+    xd = x.double().requires_grad_(True)
+    w1, b1, w2, b2 = (t.double() for t in (seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias))
+    pre = xd @ w1.t() + b1
+    y = torch.nn.functional.silu(pre) @ w2.t() + b2
+    (gx,) = torch.autograd.grad(y, xd, g.double())
+    return pre.detach(), y.detach(), gx
+
+
+# the four stacks of the default model (message / update, forward k1 -> n2), ragged row counts around the 32-row tile, one row
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 777, 4100])
+@pytest.mark.parametrize("k1,n2", [(128, 576), (352, 480), (128, 32), (32, 128)])
+def test_mlp2_matches_fp64(n, k1, n2):
+    seq = _seq(k1, n2, seed=n + k1)
+    x = torch.randn(n, k1, device=DEV)
+    g = torch.randn(n, n2, device=DEV)
+    pre, y = fused._mlp_fwd(seq, x)
+    gx = fused._mlp_bwd(seq, g, pre)
+    assert getattr(seq, "_xeq_mlp_pack", None) is not None, "the matrix-core path did not run"
+    pre_r, y_r, gx_r = _ref(seq, x, g)
+    for name, got, ref in (("pre", pre, pre_r), ("y", y, y_r), ("grad_x", gx, gx_r)):
+        err = (got.double() - ref).abs().max().item()
+        assert err <= TOL, f"{name}: {err:.2e}"
+
+
+def test_mlp2_strided_rows_and_row_count_invariance():
+    """The update MLP reads [shat | v] rows out of a wider buffer; a row's result does not depend on how many rows ride along."""
+    seq = _seq(352, 480, seed=7)
+    wide = torch.randn(300, 400, device=DEV)          # row stride 400, first 352 columns are the input
+    x = wide[:, :352]
+    pre, y = fused._mlp_fwd(seq, x)
+    pre_c, y_c = fused._mlp_fwd(seq, x.contiguous())
+    assert torch.equal(pre, pre_c) and torch.equal(y, y_c)
+    pre_h, y_h = fused._mlp_fwd(seq, x[:45].contiguous())
+    assert torch.equal(pre[:45], pre_h) and torch.equal(y[:45], y_h)
+
+
+def test_mlp2_repacks_when_a_weight_changes():
+    seq = _seq(128, 576, seed=3)
+    x = torch.randn(64, 128, device=DEV)
+    _, y0 = fused._mlp_fwd(seq, x)
+    with torch.no_grad():
+        seq[2].bias.add_(1.0)
+    _, y1 = fused._mlp_fwd(seq, x)
+    np.testing.assert_allclose((y1 - y0).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_mlp2_falls_back_for_other_stacks():
+    """Another activation or f64 goes to the library GEMMs (same numbers as eager torch)."""
+    seq = torch.nn.Sequential(torch.nn.Linear(128, 128), torch.nn.Tanh(), torch.nn.Linear(128, 576)).to(DEV).requires_grad_(False)
+    x = torch.randn(50, 128, device=DEV)
+    pre, y = fused._mlp_fwd(seq, x)
+    assert getattr(seq, "_xeq_mlp_pack", None) is None
+    torch.testing.assert_close(y, seq(x))
+    seq64 = _seq(128, 576, seed=1).double()
+    x64 = x.double()
+    torch.testing.assert_close(fused._mlp_fwd(seq64, x64)[1], seq64(x64))
+
+
+def test_mlp2_rejects_bad_sizes():
+    w = torch.zeros(1024, device=DEV)
+    with pytest.raises(RuntimeError, match="xeq_mlp_pack"):
+        call("xeq_mlp_pack", ptr(w), None, 30, 8, 0, ptr(w), stream())
+    with pytest.raises(RuntimeError, match="xeq_mlp2_fwd"):
+        call("xeq_mlp2_fwd", ptr(w), 6, 4, 8, ptr(w), ptr(w), 32, ptr(w), ptr(w), 32, stream())   # row stride not 16-byte
+    assert lib.load().xeq_mlp2_supported(lib.XEQ_F32, 128, 64, 576) == 0
+    assert lib.load().xeq_mlp2_supported(lib.XEQ_F32, 8, 128, 576) == 0
+    assert lib.load().xeq_mlp2_supported(lib.XEQ_F64, 128, 128, 576) == 0

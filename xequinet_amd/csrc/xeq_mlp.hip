@@ -1,0 +1,416 @@
+// Two-layer scalar MLPs of XPainnMessage / XPainnUpdate on the matrix cores, one launch each:
+//   forward   Y  = silu(X W1^T + b1) W2^T + b2          (nn/xpainn.py:103-107 scalar_mlp, :177-181 update_mlp)
+//   reverse   GX = ((G W2) * silu'(pre)) W1              (input gradients only: force evaluation, nn/basic.py:143-159)
+// Both are T = E(X B1 + c1), Y = T B2 + c2 with a 128-wide hidden T that never leaves the chip.
+//
+// Work split: a workgroup (4 waves) owns 32 consecutive rows (nodes).  Exact-f32 v_mfma_f32_32x32x2_f32 tiles
+// D[column][row] (the weight fragment is the A operand, so a lane holds four consecutive columns of one row per register
+// quad and every store is 16 bytes wide); wave w computes hidden columns [32 w, 32 w + 32) in stage 1 and the output tiles w, w + 4, ... in
+// stage 2.  A operands (rows) come from LDS: the X tile is staged in 64-column chunks (double buffered), the hidden
+// tile is written once by its producers.  B operands (weights) are private to a wave, so they go global -> register
+// directly from a PACKED copy in fragment order, packed[tile][k-group][lane][4]
+//   = W[32 tile + (lane & 31)][8 group + 4 (lane >> 5) + j],
+// one coalesced 16-byte load per lane for four MFMA steps (the k order inside a group of 8 is a permutation, applied to
+// both operands).  Results do not depend on the number of rows: every row sees the same summation order.
+#include <type_traits>
+
+#include "xeq_common.h"
+
+namespace xeq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MLP_SB() __builtin_amdgcn_sched_barrier(0)
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains this wave's global stores and prefetches (vmcnt(0))
+#define MLP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+constexpr int MLP_ROWS = 32;
+constexpr int MLP_H = 128;        // hidden width (node_dim of the default and of every shipped configuration)
+constexpr int MLP_CK = 64;        // staged columns per chunk
+constexpr int MLP_XLD = MLP_CK + 4;
+constexpr int MLP_TLD = MLP_H + 4;
+
+struct MlpArgs {
+  const float* X;      // [n, ldx]
+  int64_t ldx, n;
+  int K1, N2;
+  const float* W1p;    // packed [MLP_H / 32][K1 / 8 + 1][64][4] (last group: the bias)
+  const float* W2p;    // packed [N2 / 32][MLP_H / 8 + 1][64][4]
+  int bias1, bias2;    // whether the bias groups are non-zero
+  float* pre;          // [n, MLP_H]: written (forward) / read (reverse)
+  float* Y;            // [n, ldy]
+  int64_t ldy;
+};
+
+__global__ void k_mlp_pack(const float* __restrict__ W, const float* __restrict__ bias, int n_out, int k_in, int transposed,
+                           float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the packed buffer
+  const int groups = k_in / 8 + 1;                                      // + the bias group
+  const int64_t total = (int64_t)(n_out / 32) * groups * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const int64_t tq = idx >> 6;
+  const int q = (int)(tq % groups), t = (int)(tq / groups);
+  const int n = 32 * t + (lane & 31), k0 = 8 * q + 4 * (lane >> 5);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q == groups - 1) {
+    if (bias && (lane >> 5) == 0) v.x = bias[n];
+  } else {
+    float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv[j] = transposed ? W[(int64_t)(k0 + j) * n_out + n] : W[(int64_t)n * k_in + k0 + j];
+  }
+  reinterpret_cast<float4*>(out)[idx] = v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {  // aten silu_backward: sig (1 + x (1 - sig))
+  const float sig = 1.f / (1.f + __expf(-x));
+  return sig * (1.f + x * (1.f - sig));
+}
+
+__device__ __forceinline__ float4 keep4(bool ok, const float4& v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+
+// Development aid (-DXEQ_MLP_STAMPS): core-clock and 100 MHz real-time stamps around the body of every workgroup, summed;
+// the quotient is the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ unsigned long long g_mlp_stamps[8];
+__device__ unsigned long long g_mlp_wg[4096 * 4];   // XEQ_MLP_STAMPS: per workgroup (hw id, xcc id, real-time start, end)
+#ifdef XEQ_MLP_STAMPS
+#define MLP_STAMP(core, real)                                                                \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(core), "=s"(real)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#endif
+
+template <bool REVERSE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) k_mlp2(MlpArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][MLP_ROWS * MLP_XLD];
+  __shared__ __attribute__((aligned(16))) float Ts[MLP_ROWS * MLP_TLD];
+#ifdef XEQ_MLP_PAD   // development: extra LDS per workgroup, to cap the workgroups a CU takes
+  __shared__ float pad_[XEQ_MLP_PAD];
+  if (a.n < 0) pad_[threadIdx.x] = 0.f, a.Y[0] = pad_[threadIdx.x ^ 1];
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches, scalar tile addresses
+  const int i = lane & 31, kh = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * MLP_ROWS;
+#ifdef XEQ_MLP_STAMPS
+  unsigned long long c0_, r0_, c1_, r1_;
+  MLP_STAMP(c0_, r0_);
+#endif
+#ifdef XEQ_MLP_WGREC   // development: start / end of every workgroup (wave 0) in 100 MHz ticks, and where it ran
+  unsigned long long wg_t0_;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0_)::"memory");
+#endif
+
+  // ---- stage 1: T[32, 128] = X[32, K1] B1 + c1, hidden tile `wave` ---------------------------------------------
+  const int n_chunks = (a.K1 + MLP_CK - 1) / MLP_CK;
+  const int g1 = a.K1 / 8;
+  // staging: 32 rows x 16 float4 per chunk = 512 float4, two per thread
+  const int sr = tid >> 4, sc = (tid & 15) * 4;
+  // global addresses: a workgroup-uniform 64-bit base plus a 32-bit lane offset (rows of one tile span < 2^31 elements);
+  // every load is issued unconditionally from a clamped address (no branches around loads: the waits then count loads in
+  // issue order and the prefetches stay in flight), out-of-range rows / columns are zeroed on their way into LDS
+  const int rows_here = (int)min((int64_t)MLP_ROWS, a.n - row0);
+  const float* __restrict__ xb = a.X + row0 * a.ldx;
+  float* __restrict__ preb = a.pre + row0 * MLP_H;
+  float* __restrict__ yo = a.Y + row0 * a.ldy;
+  const unsigned ldx32 = (unsigned)a.ldx, ldy32 = (unsigned)a.ldy;
+  const unsigned r0c = (unsigned)min(sr, rows_here - 1) * ldx32, r1c = (unsigned)min(sr + 16, rows_here - 1) * ldx32;
+  const bool r0ok = sr < rows_here, r1ok = sr + 16 < rows_here;
+  const bool row_ok = i < rows_here;
+  const unsigned ic = (unsigned)min(i, rows_here - 1);
+  auto fetch = [&](int c, float4& v0, float4& v1) {
+    const int colc = min(MLP_CK * c + sc, a.K1 - 4);
+    v0 = *reinterpret_cast<const float4*>(xb + (r0c + (unsigned)colc));
+    v1 = *reinterpret_cast<const float4*>(xb + (r1c + (unsigned)colc));
+  };
+  auto stash = [&](int c, const float4& v0, const float4& v1) {
+    const bool cok = MLP_CK * c + sc < a.K1;
+    *reinterpret_cast<float4*>(&Xs[c & 1][sr * MLP_XLD + sc]) = keep4(r0ok && cok, v0);
+    *reinterpret_cast<float4*>(&Xs[c & 1][(sr + 16) * MLP_XLD + sc]) = keep4(r1ok && cok, v1);
+  };
+  const float4* w1 = reinterpret_cast<const float4*>(a.W1p) + (int64_t)wave * (g1 + 1) * 64;   // wave-uniform base, lane offset in the load
+  auto fetch_w = [&](float4 (&b)[8], int g0) {   // four k-groups from g0 on
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = w1[min(g0 + q, g1 - 1) * 64 + lane];   // past K1: any finite weight, the staged rows are zero there
+  };
+
+  // accumulator layout (weights as the A operand): lane (node = i, kh), register 4 g + e <-> column 8 g + 4 kh + e of the
+  // tile: four consecutive columns of one row per register quad, i.e. 16-byte stores / LDS writes straight from registers
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc0[r] = 0.f;
+    acc1[r] = 0.f;
+  }
+  // the bias rides in the product: one extra k step whose weight fragment is the bias (k slot 0) against a row of ones,
+  // so it arrives with the weight stream instead of as a separate load that later waits behind this wave's stores
+  const float one_k0 = kh == 0 ? 1.f : 0.f;
+  float bias_a = 0.f;
+  if (a.bias1) bias_a = reinterpret_cast<const float*>(w1 + (int64_t)g1 * 64 + lane)[0];
+  float4 pv[4];   // reverse: silu'(pre) needs the forward's pre-activations of this tile; fetched under the chunk loop
+  if (REVERSE) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pv[g] = *reinterpret_cast<const float4*>(preb + (ic * MLP_H + (unsigned)(32 * wave + 8 * g + 4 * kh)));
+  }
+  float4 x0, x1, B0[8], B1[8];   // weight fragments: ping-pong buffers, fetched half a chunk (stage 1) / a quarter pass (stage 2) ahead
+  fetch(0, x0, x1);
+  fetch_w(B0, 0);
+  stash(0, x0, x1);
+  MLP_LDS_BARRIER();
+#ifdef XEQ_MLP_STAMPS
+  unsigned long long cp1_, rp1_; MLP_STAMP(cp1_, rp1_);
+#endif
+  for (int c = 0; c < n_chunks; ++c) {
+    const bool more = c + 1 < n_chunks;
+    if (more) fetch(c + 1, x0, x1);
+    const float* xs = &Xs[c & 1][i * MLP_XLD + 4 * kh];
+    auto half = [&](const float4 (&b)[8], int h) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 xv = *reinterpret_cast<const float4*>(xs + 8 * (4 * h + q));   // columns past K1 are staged as zeros
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, xv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, xv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].z, xv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, xv.w, acc1, 0, 0, 0);
+      }
+    };
+    fetch_w(B1, 8 * c + 4);
+    MLP_SB();   // keep the fetches ahead of the MFMA block they overlap (the scheduler otherwise sinks them to their use)
+    half(B0, 0);
+    MLP_SB();
+    fetch_w(B0, 8 * c + 8);
+    MLP_SB();
+    half(B1, 1);
+    MLP_SB();
+    if (more) stash(c + 1, x0, x1);
+    MLP_LDS_BARRIER();
+  }
+  if (a.bias1) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, one_k0, acc0, 0, 0, 0);
+#ifdef XEQ_MLP_STAMPS
+  unsigned long long cp2_, rp2_; MLP_STAMP(cp2_, rp2_);
+#endif
+
+  // stage 2 walks this wave's output tiles wave, wave + 4, ... two at a time (pairs share the row fragments), each tile
+  // pass in four quarters of 4 k-groups whose weights are fetched one quarter ahead (ping-pong register buffers).
+  const int nt2 = a.N2 / 32;
+  constexpr int G2 = MLP_H / 8;  // 16 k-groups
+  const float4* w2 = reinterpret_cast<const float4*>(a.W2p);
+  auto fetch_q = [&](float4 (&b)[8], int t0, bool two, int qq) {
+#ifdef XEQ_MLP_ABLATE_W   // development: no weight traffic in stage 2 (results are wrong)
+    if (a.n >= 0) return;
+#endif
+    const float4* wa = w2 + ((int64_t)t0 * (G2 + 1) + 4 * qq) * 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = wa[q * 64 + lane];
+    if (two) {
+      const float4* wb = wa + (int64_t)4 * (G2 + 1) * 64;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[4 + q] = wb[q * 64 + lane];
+    }
+  };
+  int t0 = wave;
+  if (t0 < nt2) fetch_q(B0, t0, t0 + 4 < nt2, 0);
+
+  // elementwise stage on the hidden tile, then to LDS as the row operand of stage 2
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int col = 32 * wave + 8 * g + 4 * kh;
+    float4 t = make_float4(acc0[4 * g] + acc1[4 * g], acc0[4 * g + 1] + acc1[4 * g + 1], acc0[4 * g + 2] + acc1[4 * g + 2],
+                           acc0[4 * g + 3] + acc1[4 * g + 3]);
+    float4 v;
+    if (!REVERSE) {
+      if (row_ok) *reinterpret_cast<float4*>(preb + ((unsigned)i * MLP_H + (unsigned)col)) = t;
+      v = make_float4(silu_f(t.x), silu_f(t.y), silu_f(t.z), silu_f(t.w));
+    } else {
+      v = make_float4(t.x * silu_grad_f(pv[g].x), t.y * silu_grad_f(pv[g].y), t.z * silu_grad_f(pv[g].z), t.w * silu_grad_f(pv[g].w));
+    }
+    *reinterpret_cast<float4*>(&Ts[i * MLP_TLD + col]) = v;
+  }
+  MLP_LDS_BARRIER();
+#ifdef XEQ_MLP_STAMPS
+  unsigned long long cp3_, cx_, cy_, rx_, st2c_ = 0; MLP_STAMP(cp3_, rx_);
+#endif
+
+  const float* ts = &Ts[i * MLP_TLD + 4 * kh];
+  auto pass = [&](auto two_c, int tt) {
+    constexpr bool TWO = decltype(two_c)::value;
+    const int tn = tt + 8;
+    f32x16 ya, yb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ya[r] = 0.f;
+      yb[r] = 0.f;   // single tile: the odd k steps accumulate here
+    }
+    float bias_ya = 0.f, bias_yb = 0.f;
+    if (a.bias2) {
+      bias_ya = reinterpret_cast<const float*>(w2 + ((int64_t)tt * (G2 + 1) + G2) * 64 + lane)[0];
+      if (TWO) bias_yb = reinterpret_cast<const float*>(w2 + ((int64_t)(tt + 4) * (G2 + 1) + G2) * 64 + lane)[0];
+    }
+#ifdef XEQ_MLP_STAMPS
+    MLP_STAMP(cy_, rx_);
+#endif
+    auto quarter = [&](const float4 (&b)[8], int qq) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#ifdef XEQ_MLP_ABLATE_LDS   // development: no LDS reads in stage 2 (results are wrong)
+        const float4 tv = make_float4(1.f, 2.f, 3.f, (float)q);
+#else
+        const float4 tv = *reinterpret_cast<const float4*>(ts + 8 * (4 * qq + q));
+#endif
+        if (TWO) {
+          ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, tv.x, ya, 0, 0, 0);
+          yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[4 + q].x, tv.x, yb, 0, 0, 0);
+          ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, tv.y, ya, 0, 0, 0);
+          yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[4 + q].y, tv.y, yb, 0, 0, 0);
+          ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].z, tv.z, ya, 0, 0, 0);
+          yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[4 + q].z, tv.z, yb, 0, 0, 0);
+          ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, tv.w, ya, 0, 0, 0);
+          yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[4 + q].w, tv.w, yb, 0, 0, 0);
+        } else {
+          ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, tv.x, ya, 0, 0, 0);
+          yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, tv.y, yb, 0, 0, 0);
+          ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].z, tv.z, ya, 0, 0, 0);
+          yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, tv.w, yb, 0, 0, 0);
+        }
+      }
+    };
+    fetch_q(B1, tt, TWO, 1);
+    MLP_SB();
+    quarter(B0, 0);
+    MLP_SB();
+    fetch_q(B0, tt, TWO, 2);
+    MLP_SB();
+    quarter(B1, 1);
+    MLP_SB();
+    fetch_q(B1, tt, TWO, 3);
+    MLP_SB();
+    quarter(B0, 2);
+    MLP_SB();
+    if (tn < nt2) fetch_q(B0, tn, tn + 4 < nt2, 0);
+    MLP_SB();
+    quarter(B1, 3);
+    if (a.bias2) {
+      ya = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_ya, one_k0, ya, 0, 0, 0);
+      if (TWO) yb = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_yb, one_k0, yb, 0, 0, 0);
+    }
+    MLP_SB();
+#ifdef XEQ_MLP_STAMPS
+    MLP_STAMP(cx_, rx_); st2c_ += cx_ - cy_;
+#endif
+#ifdef XEQ_MLP_ABLATE_ST   // development: only one of the 16-byte stores per tile (results are wrong)
+    if (row_ok && ya[0] == 12345.f) {
+#else
+    if (row_ok) {
+#endif
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned o = (unsigned)i * ldy32 + (unsigned)(32 * tt + 8 * g + 4 * kh);
+        if (TWO) {
+          *reinterpret_cast<float4*>(yo + o) = make_float4(ya[4 * g], ya[4 * g + 1], ya[4 * g + 2], ya[4 * g + 3]);
+          *reinterpret_cast<float4*>(yo + o + 128u) = make_float4(yb[4 * g], yb[4 * g + 1], yb[4 * g + 2], yb[4 * g + 3]);
+        } else {
+          *reinterpret_cast<float4*>(yo + o) = make_float4(ya[4 * g] + yb[4 * g], ya[4 * g + 1] + yb[4 * g + 1], ya[4 * g + 2] + yb[4 * g + 2],
+                                                           ya[4 * g + 3] + yb[4 * g + 3]);
+        }
+      }
+    }
+  };
+  for (; t0 + 4 < nt2; t0 += 8) pass(std::true_type{}, t0);
+  if (t0 < nt2) pass(std::false_type{}, t0);
+#ifdef XEQ_MLP_WGREC
+  if (tid == 0 && blockIdx.x < 4096) {
+    unsigned long long wg_t1_;
+    unsigned hw, xcc;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(wg_t1_), "=s"(hw), "=s"(xcc)::"memory");
+    g_mlp_wg[4 * blockIdx.x + 0] = hw;
+    g_mlp_wg[4 * blockIdx.x + 1] = xcc;
+    g_mlp_wg[4 * blockIdx.x + 2] = wg_t0_;
+    g_mlp_wg[4 * blockIdx.x + 3] = wg_t1_;
+  }
+#endif
+#ifdef XEQ_MLP_STAMPS
+  MLP_STAMP(c1_, r1_);
+  if (tid == 0) {
+    atomicAdd(&g_mlp_stamps[0], c1_ - c0_);
+    atomicAdd(&g_mlp_stamps[1], r1_ - r0_);
+    atomicAdd(&g_mlp_stamps[2], 1ull);
+    atomicAdd(&g_mlp_stamps[3], cp1_ - c0_);     // prologue: first fetches, first barrier
+    atomicAdd(&g_mlp_stamps[4], cp2_ - cp1_);    // stage-1 chunk loop
+    atomicAdd(&g_mlp_stamps[5], cp3_ - cp2_);    // hidden-tile epilogue + barrier
+    atomicAdd(&g_mlp_stamps[6], st2c_);          // stage-2 MFMA quarters
+    atomicAdd(&g_mlp_stamps[7], c1_ - cp3_);     // stage 2 in total
+  }
+#endif
+}
+
+static int mlp_check(const char* name, int64_t n, int k1, int n2, int64_t ldx, int64_t ldy) {
+  XEQ_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) * MLP_ROWS, "%s: n = %lld out of range", name, (long long)n);
+  XEQ_CHECK_ARG(k1 > 0 && k1 % 8 == 0 && n2 > 0 && n2 % 32 == 0, "%s: needs k1 %% 8 == 0 and n2 %% 32 == 0 (got %d, %d)", name, k1, n2);
+  XEQ_CHECK_ARG(ldx >= k1 && ldx % 4 == 0 && ldy >= n2 && ldy % 4 == 0, "%s: row strides (%lld, %lld) do not fit (%d, %d) / 16-byte rows", name,
+                (long long)ldx, (long long)ldy, k1, n2);
+  return XEQ_OK;
+}
+
+}  // namespace xeq
+
+using namespace xeq;
+
+extern "C" {
+
+int xeq_mlp_debug_stamps(unsigned long long out[8]) {   // development only (see XEQ_MLP_STAMPS); reads and clears
+  unsigned long long zero[8] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_stamps), sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_stamps), zero, sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
+  return XEQ_OK;
+}
+
+int xeq_mlp_debug_wg(unsigned long long* out) {   // development only: 4096 x 4
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_wg), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? XEQ_OK : XEQ_ERR_LAUNCH;
+}
+
+int xeq_mlp2_supported(int dtype, int k1, int hidden, int n2) {
+  return dtype == XEQ_F32 && hidden == MLP_H && k1 > 0 && k1 % 32 == 0 && n2 > 0 && n2 % 32 == 0;   // k1 is the reverse pass's n2
+}
+
+int64_t xeq_mlp_packed_floats(int n_out, int k_in) { return (int64_t)(n_out / 32) * (k_in / 8 + 1) * 256; }
+
+int xeq_mlp_pack(const float* w, const float* bias, int n_out, int k_in, int transposed, float* out, void* stream) {
+  XEQ_CHECK_ARG(w && out, "xeq_mlp_pack: null buffer");
+  XEQ_CHECK_ARG(n_out > 0 && n_out % 32 == 0 && k_in > 0 && k_in % 8 == 0, "xeq_mlp_pack: needs n_out %% 32 == 0 and k_in %% 8 == 0 (got %d, %d)",
+                n_out, k_in);
+  const int64_t total = xeq_mlp_packed_floats(n_out, k_in) / 4;
+  hipLaunchKernelGGL(k_mlp_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, n_out, k_in, transposed, out);
+  XEQ_CHECK_LAUNCH("xeq_mlp_pack");
+  return XEQ_OK;
+}
+
+int xeq_mlp2_fwd(const float* x, int64_t ldx, int64_t n, int k1, const float* w1p, const float* w2p, int n2, float* pre, float* y,
+                 int64_t ldy, void* stream) {
+  if (int rc = mlp_check("xeq_mlp2_fwd", n, k1, n2, ldx, ldy)) return rc;
+  XEQ_CHECK_ARG(n == 0 || (x && w1p && w2p && pre && y), "xeq_mlp2_fwd: null buffer");
+  if (n == 0) return XEQ_OK;
+  MlpArgs a{x, ldx, n, k1, n2, w1p, w2p, 1, 1, pre, y, ldy};
+  hipLaunchKernelGGL(k_mlp2<false>, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+  XEQ_CHECK_LAUNCH("xeq_mlp2_fwd");
+  return XEQ_OK;
+}
+
+int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2tp, const float* pre, const float* w1tp, int n2,
+                 float* gx, int64_t ldgx, void* stream) {
+  if (int rc = mlp_check("xeq_mlp2_bwd", n, k1, n2, ldg, ldgx)) return rc;
+  XEQ_CHECK_ARG(n == 0 || (g && w2tp && w1tp && pre && gx), "xeq_mlp2_bwd: null buffer");
+  if (n == 0) return XEQ_OK;
+  MlpArgs a{g, ldg, n, k1, n2, w2tp, w1tp, 0, 0, const_cast<float*>(pre), gx, ldgx};
+  hipLaunchKernelGGL(k_mlp2<true>, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+  XEQ_CHECK_LAUNCH("xeq_mlp2_bwd");
+  return XEQ_OK;
+}
+
+}  // extern "C"

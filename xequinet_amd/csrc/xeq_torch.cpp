@@ -10,8 +10,8 @@
 //   xeq::xpainn_eval      ONE operator for a whole energy (+ forces, + virial) evaluation of XPaiNN (nn/model.py:26-46):
 //                         edge geometry -> embedding -> n x [message + update] -> energy head -> explicit reverse pass.
 //                         Every stage is the same HIP kernel the Python modules launch (nn/fused.py is the Python twin of
-//                         this file and the two are compared bit for bit in tests/test_gpu_interface.py); the dense
-//                         contractions are ATen GEMMs.  Enqueued from C++: a batch with a never-seen topology costs its
+//                         this file and the two are compared bit for bit in tests/test_gpu_interface.py); the scalar MLPs
+//                         are xeq_mlp2_fwd / _bwd, the o3.Linear contractions ATen GEMMs.  Enqueued from C++: a batch with a never-seen topology costs its
 //                         GPU time plus ~150 native launches, no Python between kernels and no graph capture.
 //                         Autograd: `energy` is differentiable w.r.t. `pos` (backward = -forces), which is how the
 //                         GROMACS-style model hands forces to its caller (interface/jit_model.py:208-214).
@@ -22,6 +22,8 @@
 #include <torch/library.h>
 
 #include <cmath>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/xeq.h"
@@ -47,6 +49,67 @@ int dcode(const Tensor& t) {
 }
 void need_hip(const Tensor& t, const char* what) {
   TORCH_CHECK(t.is_cuda(), "xequinet_amd ops run on MI355X (HIP) tensors only and have no CPU fallback; ", what, " is on ", t.device());
+}
+
+// ---------------------------------------------------------------------------------------------- two-layer MLPs
+// Linear-SiLU-Linear on the matrix cores (xeq_mlp2_fwd / _bwd, csrc/xeq_mlp.hip); nn/fused.py::_mlp_fwd / _mlp_bwd are the
+// Python twins.  The fragment-order weight copies are cached per weight tensor and rebuilt when a version counter moves.
+struct MlpPacks {
+  int64_t key[8];
+  Tensor w1p, w2p, w2tp, w1tp;
+};
+const MlpPacks* mlp_packs(const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2) {
+  if (w1.scalar_type() != at::kFloat || b1.numel() == 0 || b2.numel() == 0 ||
+      !xeq_mlp2_supported(XEQ_F32, (int)w1.size(1), (int)w1.size(0), (int)w2.size(0)))
+    return nullptr;
+  static std::mutex mu;
+  static std::unordered_map<const void*, MlpPacks> cache;
+  const int64_t key[8] = {(int64_t)w1._version(), (int64_t)(intptr_t)w1.data_ptr(), (int64_t)b1._version(), (int64_t)(intptr_t)b1.data_ptr(),
+                          (int64_t)w2._version(), (int64_t)(intptr_t)w2.data_ptr(), (int64_t)b2._version(), (int64_t)(intptr_t)b2.data_ptr()};
+  std::lock_guard<std::mutex> lock(mu);
+  MlpPacks& e = cache[w1.data_ptr()];
+  bool same = e.w1p.defined();
+  for (int i = 0; i < 8 && same; ++i) same = e.key[i] == key[i];
+  if (!same) {
+    const int h = (int)w1.size(0), k1 = (int)w1.size(1), n2 = (int)w2.size(0);
+    const Tensor w1c = w1.detach().contiguous(), w2c = w2.detach().contiguous();
+    auto pack = [&](const Tensor& w, const Tensor* bias, int n_out, int k_in, int transposed) {
+      Tensor out = at::empty({xeq_mlp_packed_floats(n_out, k_in)}, w.options());
+      XCALL(xeq_mlp_pack((const float*)w.data_ptr(), bias ? (const float*)bias->data_ptr() : nullptr, n_out, k_in, transposed,
+                         (float*)out.data_ptr(), cur_stream()));
+      return out;
+    };
+    e.w1p = pack(w1c, &b1, h, k1, 0);
+    e.w2p = pack(w2c, &b2, n2, h, 0);
+    e.w2tp = pack(w2c, nullptr, h, n2, 1);
+    e.w1tp = pack(w1c, nullptr, k1, h, 1);
+    for (int i = 0; i < 8; ++i) e.key[i] = key[i];
+  }
+  return &e;
+}
+// x: [n, k1] rows with stride ldx (a column slice of a wider buffer is fine)
+void mlp_fwd(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, Tensor& pre, Tensor& y) {
+  const MlpPacks* pk = (x.stride(1) == 1 && x.stride(0) % 4 == 0) ? mlp_packs(w1, b1, w2, b2) : nullptr;
+  if (!pk) {
+    pre = at::addmm(b1, x, w1.t());
+    y = at::addmm(b2, at::silu(pre), w2.t());
+    return;
+  }
+  const int64_t n = x.size(0);
+  pre = at::empty({n, w1.size(0)}, x.options());
+  y = at::empty({n, w2.size(0)}, x.options());
+  XCALL(xeq_mlp2_fwd((const float*)x.data_ptr(), x.stride(0), n, (int)w1.size(1), (const float*)pk->w1p.data_ptr(),
+                     (const float*)pk->w2p.data_ptr(), (int)w2.size(0), (float*)pre.data_ptr(), (float*)y.data_ptr(), w2.size(0), cur_stream()));
+}
+Tensor mlp_bwd(const Tensor& g_y, const Tensor& pre, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2) {
+  const MlpPacks* pk = mlp_packs(w1, b1, w2, b2);
+  if (!pk) return at::mm(at::silu_backward(at::mm(g_y, w2), pre), w1);
+  const Tensor g = g_y.contiguous();
+  const int64_t n = g.size(0);
+  Tensor g_x = at::empty({n, w1.size(1)}, g.options());
+  XCALL(xeq_mlp2_bwd((const float*)g.data_ptr(), g.size(1), n, (int)g.size(1), (const float*)pk->w2tp.data_ptr(), (const float*)pre.data_ptr(),
+                     (const float*)pk->w1tp.data_ptr(), (int)w1.size(1), (float*)g_x.data_ptr(), w1.size(1), cur_stream()));
+  return g_x;
 }
 
 // ---------------------------------------------------------------------------------------------- graph plumbing
@@ -299,8 +362,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       NormOut no = norm_fwd(hy, s, x, q[6], q[7], q[8], q[9], Tensor(), 0);
       m.stats = no.stats;
       m.xhat = no.xhat;
-      m.pre = at::addmm(q[1], no.shat, q[0].t());
-      m.h = at::addmm(q[3], at::silu(m.pre), q[2].t());
+      mlp_fwd(no.shat, q[0], q[1], q[2], q[3], m.pre, m.h);
       Tensor s_out = at::empty_like(s), x_out = at::empty_like(x);
       m.impl = impl;
       if (impl == 0) {
@@ -335,8 +397,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       }
       Tensor p = at::empty({N, C}, fopt);
       XCALL(xeq_uv_reduce_fwd(dt, u.uv.data_ptr(), N, mul, hy.inv_eps, cat.data_ptr(), F + C, F, p.data_ptr(), st));
-      u.pre = at::addmm(q[16], cat, q[15].t());
-      u.a = at::addmm(q[18], at::silu(u.pre), q[17].t());
+      mlp_fwd(cat, q[15], q[16], q[17], q[18], u.pre, u.a);
       u.ip = at::mm(p, q[14].t());
       Tensor s_out = at::empty_like(s), x_out = at::empty_like(x);
       XCALL(xeq_update_out_fwd(dt, s.data_ptr(), x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
@@ -374,8 +435,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         XCALL(xeq_update_out_bwd(dt, g_s.data_ptr(), g_x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
                                  g_a.data_ptr(), g_ip.data_ptr(), nullptr, st));
         const Tensor g_p = at::mm(g_ip, q[14]);
-        const Tensor g_pre = at::silu_backward(at::mm(g_a, q[17]), u.pre);
-        const Tensor g_cat = at::mm(g_pre, q[15]);
+        const Tensor g_cat = mlp_bwd(g_a, u.pre, q[15], q[16], q[17], q[18]);
         XCALL(xeq_uv_reduce_bwd(dt, u.uv.data_ptr(), g_p.data_ptr(), g_cat.data_ptr(), F + C, F, N, mul, hy.inv_eps, g_x.data_ptr(),
                                 u.a.data_ptr(), g_uv.data_ptr(), st));
         Tensor g_xhat = at::empty({N * D}, fopt);
@@ -406,8 +466,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                                    hy.B, F, mul, g_h.data_ptr(), g_xhat.data_ptr(), g_vec.data_ptr(), 1, st));
         }
         g_vec_total = g_vec_total.defined() ? g_vec_total + g_vec : g_vec;
-        const Tensor g_pre = at::silu_backward(at::mm(g_h, q[2]), m.pre);
-        const Tensor g_shat = at::mm(g_pre, q[0]);
+        const Tensor g_shat = mlp_bwd(g_h, m.pre, q[0], q[1], q[2], q[3]);
         Tensor ns, nx;
         norm_bwd(hy, m.s, m.x, q[6], q[8], m.stats, g_shat, F, g_xhat, g_s, g_x, ns, nx);
         g_s = ns;

@@ -96,10 +96,15 @@ _PROTOS = {
     "xeq_uv_reduce_bwd": [c_int, _P, _P, _P, c_int64, c_int, c_int64, _I3, c_double, _P, _P, _P, _P],
     "xeq_update_out_fwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P],
     "xeq_update_out_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, _P, _P, _P, _P],
+    "xeq_mlp2_supported": [c_int, c_int, c_int, c_int],
+    "xeq_mlp_packed_floats": [c_int, c_int],
+    "xeq_mlp_pack": [_P, _P, c_int, c_int, c_int, _P, _P],
+    "xeq_mlp2_fwd": [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P, c_int64, _P],
+    "xeq_mlp2_bwd": [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, c_int64, _P],
 }
 # entry points that return a size, not a status
 _RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
-            "xeq_message_wq_parts_floats"}
+            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None

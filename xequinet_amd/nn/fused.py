@@ -1,7 +1,8 @@
 """Block-level fused paths of XPainnMessage / XPainnUpdate.
 
 One ``torch.autograd.Function`` per block: every elementwise stage is a hand-written HIP
-kernel (``xeq_node.hip``), the dense contractions are plain library GEMMs on contiguous
+kernel (``xeq_node.hip``), the two-layer scalar MLPs and their input gradients are one matrix-core
+launch each (``xeq_mlp.hip``), the o3.Linear contractions are plain library GEMMs on contiguous
 views of the internal BT layout, and the reverse pass is explicit (no autograd graph of
 small ops).  Semantics are those of nn/xpainn.py:128-161 and :206-231 of the reference;
 gradients are provided w.r.t. the node features and the edge vectors only (force
@@ -77,6 +78,65 @@ def _silu_bwd(g, pre, act):
     return out
 
 
+def _mlp_packs(seq: torch.nn.Sequential):
+    """Matrix-core fragment-order copies of a Linear-SiLU-Linear stack for ``xeq_mlp2_fwd / _bwd`` (forward pair with the
+    biases folded in, transposed pair for the input gradients), cached on the module and refreshed when a weight changes.
+    None when the kernels do not take the stack (other activation, f64, widths): the caller then runs the library GEMMs."""
+    lin1, act, lin2 = seq[0], seq[1], seq[2]
+    w1, w2 = lin1.weight, lin2.weight
+    if not (isinstance(act, torch.nn.SiLU) and w1.dtype == torch.float32 and lin1.bias is not None and lin2.bias is not None
+            and lib.load().xeq_mlp2_supported(lib.XEQ_F32, w1.shape[1], w1.shape[0], w2.shape[0])):
+        return None
+    key = (w1._version, w1.data_ptr(), lin1.bias._version, lin1.bias.data_ptr(), w2._version, w2.data_ptr(), lin2.bias._version,
+           lin2.bias.data_ptr())
+    cache = getattr(seq, "_xeq_mlp_pack", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+
+    def pack(w, bias, n_out, k_in, transposed):
+        out = torch.empty(lib.load().xeq_mlp_packed_floats(n_out, k_in), dtype=torch.float32, device=w.device)
+        call("xeq_mlp_pack", ptr(w), ptr(bias), n_out, k_in, int(transposed), ptr(out), stream())
+        return out
+
+    with torch.no_grad():
+        h, k1 = w1.shape
+        n2 = w2.shape[0]
+        w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
+        packs = (pack(w1c, lin1.bias.detach(), h, k1, False), pack(w2c, lin2.bias.detach(), n2, h, False),
+                 pack(w2c, None, h, n2, True), pack(w1c, None, k1, h, True))     # reverse: W2 as [k = n2][n = h], W1 as [k = h][n = k1]
+    seq._xeq_mlp_pack = (key, packs)
+    return packs
+
+
+def _mlp_fwd(seq, x):
+    """(pre, y) of Linear-SiLU-Linear on rows of x ([n, k1], row stride = x.stride(0))."""
+    lin1, act, lin2 = seq[0], seq[1], seq[2]
+    packs = _mlp_packs(seq) if x.is_cuda and x.stride(1) == 1 and x.stride(0) % 4 == 0 else None
+    if packs is None:
+        pre = torch.addmm(lin1.bias, x, lin1.weight.t())
+        return pre, torch.addmm(lin2.bias, act(pre), lin2.weight.t())
+    n, k1 = x.shape
+    n2 = lin2.weight.shape[0]
+    pre = torch.empty((n, lin1.weight.shape[0]), dtype=x.dtype, device=x.device)
+    y = torch.empty((n, n2), dtype=x.dtype, device=x.device)
+    call("xeq_mlp2_fwd", ptr(x), x.stride(0), n, k1, ptr(packs[0]), ptr(packs[1]), n2, ptr(pre), ptr(y), n2, stream())
+    return pre, y
+
+
+def _mlp_bwd(seq, g_y, pre):
+    """dL/dx of Linear-SiLU-Linear from dL/dy and the saved pre-activation."""
+    lin1, act, lin2 = seq[0], seq[1], seq[2]
+    packs = _mlp_packs(seq) if g_y.is_cuda else None
+    if packs is None:
+        return torch.mm(_silu_bwd(torch.mm(g_y, lin2.weight), pre, act), lin1.weight)
+    g_y = g_y.contiguous()
+    n, n2 = g_y.shape
+    k1 = lin1.weight.shape[1]
+    g_x = torch.empty((n, k1), dtype=g_y.dtype, device=g_y.device)
+    call("xeq_mlp2_bwd", ptr(g_y), n2, n, n2, ptr(packs[2]), ptr(pre), ptr(packs[3]), k1, ptr(g_x), k1, stream())
+    return g_x
+
+
 class MessageBlock(Function):
     """XPainnMessage.forward (nn/xpainn.py:128-161): norms -> scalar_mlp -> fused message kernel."""
 
@@ -86,9 +146,7 @@ class MessageBlock(Function):
         s, x, vec = s.contiguous(), x.contiguous(), vec.contiguous()
         F, mul = module.node_dim, module._mul
         shat, xhat, stats, do_norm = _norm_fwd(s, x, module.norm, module.o3norm, F, mul)
-        lin1, act, lin2 = module.scalar_mlp[0], module.scalar_mlp[1], module.scalar_mlp[2]
-        pre = torch.addmm(lin1.bias, shat, lin1.weight.t())
-        h = torch.addmm(lin2.bias, act(pre), lin2.weight.t())
+        pre, h = _mlp_fwd(module.scalar_mlp, shat)
         p0, p1 = rbf.params()
         cfg = (rbf.kind, cutoff_fn.kind, module.num_basis, float(cutoff_fn.cutoff), F, mul, 1)  # xhat in BT layout
         s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, module.rbf_lin.weight, module.rbf_lin.bias,
@@ -108,9 +166,7 @@ class MessageBlock(Function):
         it = iter(t[:-4])
         msg_saved = tuple(None if is_none else next(it) for is_none in ctx.none_mask)
         g_h, g_xhat, g_vec, g_s_res, g_x_res = ops.message_backward(msg_saved, ctx.graph, ctx.cfg, ctx.impl, g_s_out, g_x_out)
-        lin1, act, lin2 = module.scalar_mlp[0], module.scalar_mlp[1], module.scalar_mlp[2]
-        g_pre = _silu_bwd(torch.mm(g_h, lin2.weight), pre, act)
-        g_shat = torch.mm(g_pre, lin1.weight)
+        g_shat = _mlp_bwd(module.scalar_mlp, g_h, pre)
         g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_shat, F, g_xhat, g_s_res, g_x_res)
         return g_s, g_x, g_vec, None, None, None, None
 
@@ -157,9 +213,7 @@ class UpdateBlock(Function):
         p = torch.empty((n, C), dtype=dt, device=dev)
         eps = module.invariant.eps
         call("xeq_uv_reduce_fwd", dtype_code(s), ptr(uv), n, mul3(mul), float(eps), ptr(cat), F + C, F, ptr(p), stream())
-        lin3, act, lin4 = module.update_mlp[0], module.update_mlp[1], module.update_mlp[2]
-        pre = torch.addmm(lin3.bias, cat, lin3.weight.t())
-        a = torch.addmm(lin4.bias, act(pre), lin4.weight.t())                # [a_vv C | a_sv F | a_ss F]
+        pre, a = _mlp_fwd(module.update_mlp, cat)                             # a = [a_vv C | a_sv F | a_ss F]
         ip = torch.mm(p, module.dot_lin.weight.t())
         s_out, x_out = torch.empty_like(s), torch.empty_like(x)
         call("xeq_update_out_fwd", dtype_code(s), ptr(s), ptr(x), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(s_out),
@@ -186,9 +240,7 @@ class UpdateBlock(Function):
         call("xeq_update_out_bwd", dtype_code(s), ptr(g_s_out), ptr(g_x_out), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(g_a),
              ptr(g_ip), None, stream())
         g_p = torch.mm(g_ip, module.dot_lin.weight)
-        lin3, act, lin4 = module.update_mlp[0], module.update_mlp[1], module.update_mlp[2]
-        g_pre = _silu_bwd(torch.mm(g_a, lin4.weight), pre, act)
-        g_cat = torch.mm(g_pre, lin3.weight)                                  # [g_shat | g_v]
+        g_cat = _mlp_bwd(module.update_mlp, g_a, pre)                         # [g_shat | g_v]
         call("xeq_uv_reduce_bwd", dtype_code(s), ptr(uv), ptr(g_p), ptr(g_cat), F + C, F, n, mul3(mul), float(module.invariant.eps),
              ptr(g_x_out), ptr(a), ptr(g_uv), stream())
         packs, _ = _packed_uv(module)
