@@ -416,6 +416,19 @@ int xeq_mlp2_fwd(const float* x, int64_t ldx, int64_t n, int k1, const float* w1
 int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2t_packed, const float* pre,
                  const float* w1t_packed, int n2, float* gx, int64_t ldgx, void* stream);
 
+/* ---- first half of XPainnUpdate.forward in one launch (f32; mul_l in {0, 32, 64, 128}, node_dim <= 128, D <= 504) -------
+ * nn.LayerNorm(s) and EquivariantLayerNorm(x) (nn/xpainn.py:208-209), U = update_U(xhat), V = update_V(xhat) (o3.Linear,
+ * nn/xpainn.py:211-212), v = Invariant(V), p = EquivariantDot(U, V) (nn/xpainn.py:214, :222).  Replaces xeq_norm_fwd + the
+ * three GEMMs + xeq_uv_reduce_fwd; outputs as theirs: cat[n, :node_dim] = shat, cat[n, node_dim:node_dim + C] = v (row stride
+ * ld_cat), p[n, C], the U|V pair buffer uv_bt (BT layout), stats[n, 4].  w_packed_l = xeq_mlp_pack([W_U | W_V] / sqrt(mul_l)
+ * viewed [k_in = mul_l][n_out = 2 mul_l], bias = [b_U | b_V] for l = 0 (has_bias) else NULL, transposed = 1); NULL for an
+ * absent block.  xeq_update_uv_supported: 1 when the kernel takes the layout. */
+int xeq_update_uv_supported(int dtype, int node_dim, const int32_t mul[3]);
+int xeq_update_uv_fwd(const float* s, const float* x, const float* ln_w, const float* ln_b, const float* eq_w, const float* eq_b,
+                      int64_t n, int node_dim, const int32_t mul[3], int do_norm, const float* w_packed0, const float* w_packed1,
+                      const float* w_packed2, int has_bias, double eps, float* cat, int64_t ld_cat, float* p, float* uv_bt,
+                      float* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

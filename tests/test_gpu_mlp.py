@@ -93,3 +93,43 @@ def test_mlp2_rejects_bad_sizes():
     assert lib.load().xeq_mlp2_supported(lib.XEQ_F32, 128, 64, 576) == 0
     assert lib.load().xeq_mlp2_supported(lib.XEQ_F32, 8, 128, 576) == 0
     assert lib.load().xeq_mlp2_supported(lib.XEQ_F64, 128, 128, 576) == 0
+
+
+# ---- first half of XPainnUpdate.forward in one launch (xeq_update_uv_fwd, csrc/xeq_update.hip) -------------------------
+@pytest.mark.parametrize("n", [1, 31, 33, 1000])
+@pytest.mark.parametrize("irreps,layer_norm", [("128x0e + 64x1o + 32x2e", True), ("128x0e + 64x1o + 32x2e", False), ("64x0e + 32x1o", True)])
+def test_update_block_fused_front_matches_the_kernel_chain(monkeypatch, n, irreps, layer_norm):
+    """norm -> U, V -> v, p on the matrix cores against the separate kernels + library GEMMs it replaces (the reference's
+    op sequence nn/xpainn.py:208-222), through the whole block: forward outputs and the input gradients."""
+    from xequinet_amd.nn.xpainn import XPainnUpdate
+
+    torch.manual_seed(n)
+    node_dim = 128 if irreps.startswith("128") else 64
+    blk = XPainnUpdate(node_dim=node_dim, node_irreps=irreps, layer_norm=layer_norm).to(DEV).eval().requires_grad_(False)
+    with torch.no_grad():
+        for prm in blk.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.3 * torch.randn_like(prm))
+    D = blk.node_irreps.dim
+    s0, x0 = torch.randn(n, node_dim, device=DEV), torch.randn(n, D, device=DEV)
+    gs, gx = torch.randn(n, node_dim, device=DEV), torch.randn(n, D, device=DEV)
+
+    def run(block, dtype):
+        s, x = s0.to(dtype).requires_grad_(True), x0.to(dtype).requires_grad_(True)
+        with torch.enable_grad():
+            so, xo = fused.UpdateBlock.apply(s, x, block)
+            g = torch.autograd.grad([so, xo], [s, x], [gs.to(dtype), gx.to(dtype)])
+        return so.detach().double(), xo.detach().double(), g[0].double(), g[1].double()
+
+    got = run(blk, torch.float32)
+    if node_dim == 128:
+        assert getattr(blk, "_uv_frag", None) is not None, "the fused front did not run"
+    monkeypatch.setattr(fused, "_packed_uv_frag", lambda module: None)
+    chain = run(blk, torch.float32)
+    import copy
+    exact = run(copy.deepcopy(blk).double(), torch.float64)      # the kernel chain in f64
+    # both f32 paths sit at rounding distance from the f64 result; the fused one may not be further than the chain it replaces
+    for name, a_, c_, e_ in zip(("s_out", "x_out", "grad_s", "grad_x"), got, chain, exact):
+        err, err_chain = (a_ - e_).abs().max().item(), (c_ - e_).abs().max().item()
+        scale = max(1.0, e_.abs().max().item())
+        assert err <= max(3.0 * err_chain, 2e-5 * scale), f"{name}: fused {err:.2e}, chain {err_chain:.2e} (scale {scale:.1f})"

@@ -251,3 +251,20 @@ def test_torchscript_front_ends_script_save_and_reload_without_a_gpu(tmp_path):
     finally:
         U.DEFAULT_UNITS_MAP.clear()
         U.DEFAULT_UNITS_MAP.update(saved)
+
+
+def test_models_and_irreps_survive_deepcopy_and_pickle():
+    """copy.deepcopy(model) (EMA copies, the reference's checkpoint handling) must work: irreps are tuple subclasses."""
+    import copy
+    import pickle
+
+    from xequinet_amd import o3, tp
+    from xequinet_amd.nn import resolve_model
+
+    for mod in (o3, tp):
+        ir = mod.Irrep(1, -1)
+        assert copy.deepcopy(ir) == ir and pickle.loads(pickle.dumps(ir)) == ir
+        assert copy.deepcopy(mod.Irreps("128x0e + 64x1o + 32x2e")) == mod.Irreps("128x0e + 64x1o + 32x2e")
+    model = resolve_model("xpainn")
+    twin = copy.deepcopy(model)
+    assert [k for k in twin.state_dict()] == [k for k in model.state_dict()]

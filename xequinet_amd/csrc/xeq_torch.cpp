@@ -112,6 +112,41 @@ Tensor mlp_bwd(const Tensor& g_y, const Tensor& pre, const Tensor& w1, const Ten
   return g_x;
 }
 
+// [W_U | W_V] / sqrt(mul) blocks (prm layout: one [mul, 2 mul] tensor per l, empty when absent) in fragment order for
+// xeq_update_uv_fwd; nn/fused.py::_packed_uv_frag is the Python twin.  Cached per weight tensor like the MLP packs.
+struct UvFrag {
+  int64_t key[8];
+  Tensor w[3];
+};
+const UvFrag* uv_frag(const Tensor* q /* [W0, W1, W2, bias pair] */, int node_dim, const int32_t mul[3]) {
+  if (q[0].scalar_type() != at::kFloat || !xeq_update_uv_supported(XEQ_F32, node_dim, mul)) return nullptr;
+  static std::mutex mu;
+  static std::unordered_map<const void*, UvFrag> cache;
+  int64_t key[8];
+  for (int i = 0; i < 4; ++i) {
+    key[2 * i] = q[i].numel() > 0 ? (int64_t)q[i]._version() : -1;
+    key[2 * i + 1] = q[i].numel() > 0 ? (int64_t)(intptr_t)q[i].data_ptr() : 0;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  int first = 0;
+  while (first < 3 && mul[first] == 0) ++first;
+  UvFrag& e = cache[q[first].data_ptr()];
+  bool same = e.w[first].defined();
+  for (int i = 0; i < 8 && same; ++i) same = e.key[i] == key[i];
+  if (!same) {
+    for (int l = 0; l < 3; ++l) {
+      e.w[l] = Tensor();
+      if (mul[l] == 0) continue;
+      const Tensor W = q[l].detach().contiguous();   // [k_in = mul][n_out = 2 mul]
+      e.w[l] = at::empty({xeq_mlp_packed_floats(2 * mul[l], mul[l])}, W.options());
+      XCALL(xeq_mlp_pack((const float*)W.data_ptr(), (l == 0 && q[3].numel() > 0) ? (const float*)q[3].data_ptr() : nullptr, 2 * mul[l],
+                         mul[l], 1, (float*)e.w[l].data_ptr(), cur_stream()));
+    }
+    for (int i = 0; i < 8; ++i) e.key[i] = key[i];
+  }
+  return &e;
+}
+
 // ---------------------------------------------------------------------------------------------- graph plumbing
 struct WqPlan {
   int n_ranges = 0;
@@ -386,17 +421,27 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       u.s = s;
       u.x = x;
       Tensor cat = at::empty({N, F + C}, fopt);
-      NormOut no = norm_fwd(hy, s, x, q[19], q[20], q[21], q[22], cat, F + C);
-      u.stats = no.stats;
       u.uv = at::empty({2 * N * D}, fopt);
-      auto xb = bt_blocks(no.xhat, N, hy.mul, 1), ub = bt_blocks(u.uv, N, hy.mul, 2);
-      for (size_t k = 0; k < xb.size(); ++k) {
-        const Tensor& W = q[10 + xb[k].l];
-        if (xb[k].l == 0 && q[13].numel() > 0) at::addmm_out(ub[k].view, q[13], xb[k].view, W);
-        else at::mm_out(ub[k].view, xb[k].view, W);
-      }
       Tensor p = at::empty({N, C}, fopt);
-      XCALL(xeq_uv_reduce_fwd(dt, u.uv.data_ptr(), N, mul, hy.inv_eps, cat.data_ptr(), F + C, F, p.data_ptr(), st));
+      if (const UvFrag* fr = uv_frag(&q[10], F, mul)) {   // norms -> U, V -> v, p in one matrix-core launch
+        u.stats = at::empty({N, 4}, fopt);
+        auto fp = [](const Tensor& t) { return t.defined() ? (const float*)t.data_ptr() : nullptr; };
+        XCALL(xeq_update_uv_fwd((const float*)s.data_ptr(), (const float*)x.data_ptr(), hy.layer_norm ? fp(q[19]) : nullptr,
+                                hy.layer_norm ? fp(q[20]) : nullptr, hy.layer_norm ? fp(q[21]) : nullptr,
+                                hy.layer_norm ? fp(q[22]) : nullptr, N, F, mul, hy.layer_norm, fp(fr->w[0]), fp(fr->w[1]), fp(fr->w[2]),
+                                q[13].numel() > 0, hy.inv_eps, (float*)cat.data_ptr(), F + C, (float*)p.data_ptr(),
+                                (float*)u.uv.data_ptr(), (float*)u.stats.data_ptr(), st));
+      } else {
+        NormOut no = norm_fwd(hy, s, x, q[19], q[20], q[21], q[22], cat, F + C);
+        u.stats = no.stats;
+        auto xb = bt_blocks(no.xhat, N, hy.mul, 1), ub = bt_blocks(u.uv, N, hy.mul, 2);
+        for (size_t k = 0; k < xb.size(); ++k) {
+          const Tensor& W = q[10 + xb[k].l];
+          if (xb[k].l == 0 && q[13].numel() > 0) at::addmm_out(ub[k].view, q[13], xb[k].view, W);
+          else at::mm_out(ub[k].view, xb[k].view, W);
+        }
+        XCALL(xeq_uv_reduce_fwd(dt, u.uv.data_ptr(), N, mul, hy.inv_eps, cat.data_ptr(), F + C, F, p.data_ptr(), st));
+      }
       mlp_fwd(cat, q[15], q[16], q[17], q[18], u.pre, u.a);
       u.ip = at::mm(p, q[14].t());
       Tensor s_out = at::empty_like(s), x_out = at::empty_like(x);

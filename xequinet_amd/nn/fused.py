@@ -190,6 +190,29 @@ def _packed_uv(module) -> Tuple[list, torch.Tensor]:
     return packs, bias
 
 
+def _packed_uv_frag(module):
+    """The [W_U | W_V] / sqrt(mul) blocks in matrix-core fragment order for ``xeq_update_uv_fwd`` (one per l, None for an
+    absent block; the l = 0 pack carries the bias pair), or None when the kernel does not take the layout."""
+    mul = module.node_irreps.mul3()
+    wu = module.update_U.weight
+    if wu.dtype != torch.float32 or not lib.load().xeq_update_uv_supported(lib.XEQ_F32, module.node_dim, mul3(mul)):
+        return None
+    packs, bias = _packed_uv(module)                     # refreshed there when a weight changes
+    cache = getattr(module, "_uv_frag", None)
+    if cache is not None and cache[0] is packs:
+        return cache[1], cache[2]
+    frag, it = [None, None, None], iter(packs)
+    for l, m in enumerate(mul):
+        if m == 0:
+            continue
+        W = next(it)                                     # [mul, 2 mul] = [k_in][n_out]
+        out = torch.empty(lib.load().xeq_mlp_packed_floats(2 * m, m), dtype=torch.float32, device=W.device)
+        call("xeq_mlp_pack", ptr(W), ptr(bias if l == 0 else None), 2 * m, m, 1, ptr(out), stream())
+        frag[l] = out
+    module._uv_frag = (packs, frag, bias is not None)
+    return frag, bias is not None
+
+
 class UpdateBlock(Function):
     """XPainnUpdate.forward (nn/xpainn.py:206-231)."""
 
@@ -202,17 +225,26 @@ class UpdateBlock(Function):
         C = sum(mul)
         dt, dev = s.dtype, s.device
         cat = torch.empty((n, F + C), dtype=dt, device=dev)                  # [shat | v]  (nn/xpainn.py:215)
-        _, xhat, stats, do_norm = _norm_fwd(s, x, module.norm, module.o3norm, F, mul, shat_out=cat, ld=F + C)
-        packs, bias = _packed_uv(module)
         uv = torch.empty(2 * n * D, dtype=dt, device=dev)                    # U|V pair buffer, BT layout
-        for (l, m, xb), (_, _, ub), W in zip(_bt_blocks(xhat, n, mul, 1), _bt_blocks(uv, n, mul, 2), packs):
-            if l == 0 and bias is not None:
-                torch.addmm(bias, xb, W, out=ub)
-            else:
-                torch.mm(xb, W, out=ub)
         p = torch.empty((n, C), dtype=dt, device=dev)
         eps = module.invariant.eps
-        call("xeq_uv_reduce_fwd", dtype_code(s), ptr(uv), n, mul3(mul), float(eps), ptr(cat), F + C, F, ptr(p), stream())
+        frag = _packed_uv_frag(module)
+        if frag is not None:     # norms -> U, V -> v, p in one matrix-core launch (xeq_update.hip)
+            do_norm = int(not isinstance(module.norm, torch.nn.Identity))
+            stats = torch.empty((n, 4), dtype=dt, device=dev)
+            lw, lb, ew, eb = ((module.norm.weight, module.norm.bias, module.o3norm.affine_weight, module.o3norm.affine_bias)
+                              if do_norm else (None,) * 4)
+            call("xeq_update_uv_fwd", ptr(s), ptr(x), ptr(lw), ptr(lb), ptr(ew), ptr(eb), n, F, mul3(mul), do_norm, ptr(frag[0][0]),
+                 ptr(frag[0][1]), ptr(frag[0][2]), int(frag[1]), float(eps), ptr(cat), F + C, ptr(p), ptr(uv), ptr(stats), stream())
+        else:
+            _, xhat, stats, do_norm = _norm_fwd(s, x, module.norm, module.o3norm, F, mul, shat_out=cat, ld=F + C)
+            packs, bias = _packed_uv(module)
+            for (l, m, xb), (_, _, ub), W in zip(_bt_blocks(xhat, n, mul, 1), _bt_blocks(uv, n, mul, 2), packs):
+                if l == 0 and bias is not None:
+                    torch.addmm(bias, xb, W, out=ub)
+                else:
+                    torch.mm(xb, W, out=ub)
+            call("xeq_uv_reduce_fwd", dtype_code(s), ptr(uv), n, mul3(mul), float(eps), ptr(cat), F + C, F, ptr(p), stream())
         pre, a = _mlp_fwd(module.update_mlp, cat)                             # a = [a_vv C | a_sv F | a_ss F]
         ip = torch.mm(p, module.dot_lin.weight.t())
         s_out, x_out = torch.empty_like(s), torch.empty_like(x)

@@ -33,6 +33,9 @@ class Irrep(tuple):
     def __new__(cls, l: int, p: int):
         return super().__new__(cls, (int(l), int(p)))
 
+    def __getnewargs__(self):   # copy.deepcopy / pickle of modules that hold irreps (tuple subclasses rebuild through __new__)
+        return (self[0], self[1])
+
     @property
     def l(self) -> int:
         return self[0]
