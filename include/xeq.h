@@ -428,6 +428,17 @@ int xeq_update_uv_fwd(const float* s, const float* x, const float* ln_w, const f
                       int64_t n, int node_dim, const int32_t mul[3], int do_norm, const float* w_packed0, const float* w_packed1,
                       const float* w_packed2, int has_bias, double eps, float* cat, int64_t ld_cat, float* p, float* uv_bt,
                       float* stats, void* stream);
+/* Reverse of the above in one launch (replaces xeq_uv_reduce_bwd + three GEMMs + xeq_norm_bwd):
+ *   g_U = g_x_out a_vv + g_p V,  g_V = g_p U + g_v V / sqrt(sum_m V^2 + eps^2)   (g_v = g_cat[:, node_dim:], a_vv = a[:, :C])
+ *   g_xhat = g_U W_U^T + g_V W_V^T;  g_s = g_s_out + LN^T(g_cat[:, :node_dim]),  g_x = g_x_out + EqLN^T(g_xhat).
+ * wt_packed_l = xeq_mlp_pack([W_U | W_V] / sqrt(mul_l) as [n_out = mul_l][k_in = 2 mul_l], NULL, transposed = 0).
+ * Split form (g_xhat_bt != NULL): stops after the contraction and writes dL/dxhat in BT layout for xeq_norm_bwd (g_s_out, s,
+ * x, stats, ln_w, eq_w, g_s, g_x unused; the workgroup then needs 50 KB of LDS instead of 113 KB). */
+int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, int64_t ld_cat, const float* g_x_out,
+                      const float* g_s_out, const float* a, int64_t ld_a, const float* s, const float* x, const float* stats,
+                      const float* ln_w, const float* eq_w, int64_t n, int node_dim, const int32_t mul[3], int do_norm,
+                      const float* wt_packed0, const float* wt_packed1, const float* wt_packed2, double eps, float* g_s, float* g_x,
+                      float* g_xhat_bt, void* stream);
 
 #ifdef __cplusplus
 }

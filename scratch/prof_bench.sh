@@ -3,12 +3,12 @@
 tag=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o p -- python3 $R/bench.py --steps 40 --warmup 5 > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
+XEQ_NO_GEMM_TUNING=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o p -- python3 $R/bench.py --steps 40 --warmup 5 > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
 cd $R
 python3 - <<PY > gpurun_out/prof_$tag.txt
 import csv, glob, json, re
 f = glob.glob("gpurun_out/prof_$tag/**/*kernel_stats.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
+rows = [r for r in csv.DictReader(open(f)) if not r["Name"].startswith("Cijk") or True]
 calls = {r["Name"]: int(r["Calls"]) for r in rows}
 ev = max(c for n, c in calls.items() if "k_message_fwd" in n) / 3
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -22,6 +22,5 @@ for k, v in sorted(g.items(), key=lambda x: -x[1][0]):
     print(f"{v[0]:8.1f} us {v[1]:6.1f} launches  {k}")
 print("launches per evaluation", sum(v[1] for v in g.values()))
 PY
-cp $f gpurun_out/prof_${tag}_kernel_stats.csv
 rm -rf gpurun_out/prof_$tag
 cat gpurun_out/prof_$tag.txt

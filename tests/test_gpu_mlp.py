@@ -97,13 +97,17 @@ def test_mlp2_rejects_bad_sizes():
 
 # ---- first half of XPainnUpdate.forward in one launch (xeq_update_uv_fwd, csrc/xeq_update.hip) -------------------------
 @pytest.mark.parametrize("n", [1, 31, 33, 1000])
+@pytest.mark.parametrize("fuse_norm_bwd", [True, False])
 @pytest.mark.parametrize("irreps,layer_norm", [("128x0e + 64x1o + 32x2e", True), ("128x0e + 64x1o + 32x2e", False), ("64x0e + 32x1o", True)])
-def test_update_block_fused_front_matches_the_kernel_chain(monkeypatch, n, irreps, layer_norm):
+def test_update_block_fused_front_matches_the_kernel_chain(monkeypatch, n, irreps, layer_norm, fuse_norm_bwd):
     """norm -> U, V -> v, p on the matrix cores against the separate kernels + library GEMMs it replaces (the reference's
-    op sequence nn/xpainn.py:208-222), through the whole block: forward outputs and the input gradients."""
+    op sequence nn/xpainn.py:208-222), through the whole block: forward outputs and the input gradients (the reverse pass
+    runs xeq_update_uv_bwd in its fused and its split form)."""
     from xequinet_amd.nn.xpainn import XPainnUpdate
 
     torch.manual_seed(n)
+    if not fuse_norm_bwd:   # the reverse kernel's split form (what batches beyond one tile per CU take)
+        monkeypatch.setattr(fused, "UV_BWD_FUSE_NORM_MAX_NODES", 0)
     node_dim = 128 if irreps.startswith("128") else 64
     blk = XPainnUpdate(node_dim=node_dim, node_irreps=irreps, layer_norm=layer_norm).to(DEV).eval().requires_grad_(False)
     with torch.no_grad():

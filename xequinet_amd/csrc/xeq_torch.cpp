@@ -116,8 +116,9 @@ Tensor mlp_bwd(const Tensor& g_y, const Tensor& pre, const Tensor& w1, const Ten
 // xeq_update_uv_fwd; nn/fused.py::_packed_uv_frag is the Python twin.  Cached per weight tensor like the MLP packs.
 struct UvFrag {
   int64_t key[8];
-  Tensor w[3];
+  Tensor w[3], wt[3];   // forward ([k_in = mul][n_out = 2 mul], biases folded) and reverse ([n_out = mul][k_in = 2 mul]) packs
 };
+constexpr int64_t UV_BWD_FUSE_NORM_MAX_NODES = 32 * 256;   // nn/fused.py::UV_BWD_FUSE_NORM_MAX_NODES
 const UvFrag* uv_frag(const Tensor* q /* [W0, W1, W2, bias pair] */, int node_dim, const int32_t mul[3]) {
   if (q[0].scalar_type() != at::kFloat || !xeq_update_uv_supported(XEQ_F32, node_dim, mul)) return nullptr;
   static std::mutex mu;
@@ -136,11 +137,14 @@ const UvFrag* uv_frag(const Tensor* q /* [W0, W1, W2, bias pair] */, int node_di
   if (!same) {
     for (int l = 0; l < 3; ++l) {
       e.w[l] = Tensor();
+      e.wt[l] = Tensor();
       if (mul[l] == 0) continue;
       const Tensor W = q[l].detach().contiguous();   // [k_in = mul][n_out = 2 mul]
       e.w[l] = at::empty({xeq_mlp_packed_floats(2 * mul[l], mul[l])}, W.options());
       XCALL(xeq_mlp_pack((const float*)W.data_ptr(), (l == 0 && q[3].numel() > 0) ? (const float*)q[3].data_ptr() : nullptr, 2 * mul[l],
                          mul[l], 1, (float*)e.w[l].data_ptr(), cur_stream()));
+      e.wt[l] = at::empty({xeq_mlp_packed_floats(mul[l], 2 * mul[l])}, W.options());
+      XCALL(xeq_mlp_pack((const float*)W.data_ptr(), nullptr, mul[l], 2 * mul[l], 0, (float*)e.wt[l].data_ptr(), cur_stream()));
     }
     for (int i = 0; i < 8; ++i) e.key[i] = key[i];
   }
@@ -476,18 +480,39 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       const Tensor* q = &prm[P_BLOCK0 + P_PER_BLOCK * b];
       {  // UpdateBlock.backward
         const UpdSaved& u = usv[b];
-        Tensor g_a = at::empty_like(u.a), g_ip = at::empty_like(u.ip), g_uv = at::empty_like(u.uv);
+        Tensor g_a = at::empty_like(u.a), g_ip = at::empty_like(u.ip);
         XCALL(xeq_update_out_bwd(dt, g_s.data_ptr(), g_x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
                                  g_a.data_ptr(), g_ip.data_ptr(), nullptr, st));
         const Tensor g_p = at::mm(g_ip, q[14]);
         const Tensor g_cat = mlp_bwd(g_a, u.pre, q[15], q[16], q[17], q[18]);
-        XCALL(xeq_uv_reduce_bwd(dt, u.uv.data_ptr(), g_p.data_ptr(), g_cat.data_ptr(), F + C, F, N, mul, hy.inv_eps, g_x.data_ptr(),
-                                u.a.data_ptr(), g_uv.data_ptr(), st));
-        Tensor g_xhat = at::empty({N * D}, fopt);
-        auto gb = bt_blocks(g_xhat, N, hy.mul, 1), gub = bt_blocks(g_uv, N, hy.mul, 2);
-        for (size_t k = 0; k < gb.size(); ++k) at::mm_out(gb[k].view, gub[k].view, q[10 + gb[k].l].t());
         Tensor ns, nx;
-        norm_bwd(hy, u.s, u.x, q[19], q[21], u.stats, g_cat, F + C, g_xhat, g_s, g_x, ns, nx);
+        const UvFrag* fr = g_cat.is_contiguous() ? uv_frag(&q[10], F, mul) : nullptr;
+        if (fr) {   // dL/dU, dL/dV -> dL/dxhat (-> reverse of both norms) in one matrix-core launch
+          auto fp = [](const Tensor& t) { return t.defined() ? (const float*)t.data_ptr() : nullptr; };
+          const bool fuse = N <= UV_BWD_FUSE_NORM_MAX_NODES;
+          Tensor g_xhat;
+          if (fuse) {
+            ns = at::empty_like(u.s);
+            nx = at::empty_like(u.x);
+          } else {
+            g_xhat = at::empty({N * D}, fopt);
+          }
+          XCALL(xeq_update_uv_bwd((const float*)u.uv.data_ptr(), (const float*)g_p.data_ptr(), (const float*)g_cat.data_ptr(), F + C,
+                                  (const float*)g_x.data_ptr(), (const float*)g_s.data_ptr(), (const float*)u.a.data_ptr(), u.a.size(1),
+                                  (const float*)u.s.data_ptr(), (const float*)u.x.data_ptr(), (const float*)u.stats.data_ptr(),
+                                  hy.layer_norm ? fp(q[19]) : nullptr, hy.layer_norm ? fp(q[21]) : nullptr, N, F, mul, hy.layer_norm,
+                                  fp(fr->wt[0]), fp(fr->wt[1]), fp(fr->wt[2]), hy.inv_eps, fuse ? (float*)ns.data_ptr() : nullptr,
+                                  fuse ? (float*)nx.data_ptr() : nullptr, fuse ? nullptr : (float*)g_xhat.data_ptr(), st));
+          if (!fuse) norm_bwd(hy, u.s, u.x, q[19], q[21], u.stats, g_cat, F + C, g_xhat, g_s, g_x, ns, nx);
+        } else {
+          Tensor g_uv = at::empty_like(u.uv);
+          XCALL(xeq_uv_reduce_bwd(dt, u.uv.data_ptr(), g_p.data_ptr(), g_cat.data_ptr(), F + C, F, N, mul, hy.inv_eps, g_x.data_ptr(),
+                                  u.a.data_ptr(), g_uv.data_ptr(), st));
+          Tensor g_xhat = at::empty({N * D}, fopt);
+          auto gb = bt_blocks(g_xhat, N, hy.mul, 1), gub = bt_blocks(g_uv, N, hy.mul, 2);
+          for (size_t k = 0; k < gb.size(); ++k) at::mm_out(gb[k].view, gub[k].view, q[10 + gb[k].l].t());
+          norm_bwd(hy, u.s, u.x, q[19], q[21], u.stats, g_cat, F + C, g_xhat, g_s, g_x, ns, nx);
+        }
         g_s = ns;
         g_x = nx;
       }

@@ -320,6 +320,295 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
   }
 }
 
+// ================================================================================================================
+// Reverse of the front half, one launch:  (dL/dp, dL/dv, dL/dU of the output stage, dL/dshat) -> dL/ds, dL/dx.
+//   g_U = g_x_out a_vv + g_p V ;  g_V = g_p U + g_v V / sqrt(sum_m V^2 + eps^2)          (xeq_uv_reduce_bwd)
+//   g_xhat = g_U W_U^T + g_V W_V^T  (/ sqrt(mul), per l and m)                            (three library GEMMs)
+//   g_s = g_s_out + LN^T(g_shat) ;  g_x = g_x_out + EqLN^T(g_xhat)                        (xeq_norm_bwd)
+// Per block l the [g_U | g_V] rows of the 32 nodes are formed in LDS (phase 1), contracted against the packed
+// [W_U | W_V]^T on the matrix cores into the g_xhat tile, also in LDS (phase 2); the norms' reverse then runs with 8 lanes
+// per node as in the forward kernel (phase 3).  Nothing but g_s and g_x is written.
+struct UvBwdArgs {
+  const float *uv, *g_p, *g_cat, *g_x_out, *g_s_out, *a, *s, *x, *stats, *lnw, *eqw;
+  int64_t ld_cat, ld_a, n;
+  int do_norm, F;
+  Irreps ir;
+  const float* wt[3];   // packed [W_U | W_V]^T / sqrt(mul_l): xeq_mlp_pack(n_out = mul_l, k_in = 2 mul_l, transposed = 0)
+  float eps;
+  float *g_s, *g_x;
+  float* g_xhat;        // split form (FUSE = 0): dL/dxhat in BT layout, the norms' reverse is left to xeq_norm_bwd
+};
+
+// phase 1 of block L (D_L = 2L+1 components, channels in quads): [g_U | g_V] rows into bf[node][m][2 mul]
+template <int D_L>
+__device__ __forceinline__ void uvb_form(const UvBwdArgs& a, float* bf, int BLD, int mul, int base, int goff, int F, int Dtot,
+                                         int64_t row0, int rows_here, int tid) {
+  const int quads = mul >> 2, items = UV_ROWS * quads;
+  const float e2 = a.eps * a.eps;
+  for (int it = tid; it < items; it += 256) {
+    const int node = it / quads, ch = 4 * (it - node * quads);
+    const bool ok = node < rows_here;
+    const int64_t gn = row0 + min(node, rows_here - 1);
+    const float* ur = a.uv + a.n * 2 * base + gn * D_L * 2 * mul + ch;
+    float4 U[D_L], V[D_L], gx4[D_L];
+#pragma unroll
+    for (int m = 0; m < D_L; ++m) {
+      U[m] = *reinterpret_cast<const float4*>(ur + m * 2 * mul);
+      V[m] = *reinterpret_cast<const float4*>(ur + m * 2 * mul + mul);
+      gx4[m] = *reinterpret_cast<const float4*>(a.g_x_out + gn * Dtot + base + ch * D_L + 4 * m);   // 4 D_L contiguous floats
+    }
+    const float4 gp = *reinterpret_cast<const float4*>(a.g_p + gn * (int64_t)a.ir.C() + goff + ch);
+    const float4 gc = *reinterpret_cast<const float4*>(a.g_cat + gn * a.ld_cat + F + goff + ch);
+    const float4 av = *reinterpret_cast<const float4*>(a.a + gn * a.ld_a + goff + ch);
+    float vv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < D_L; ++m) {
+      vv[0] = __builtin_fmaf(V[m].x, V[m].x, vv[0]);
+      vv[1] = __builtin_fmaf(V[m].y, V[m].y, vv[1]);
+      vv[2] = __builtin_fmaf(V[m].z, V[m].z, vv[2]);
+      vv[3] = __builtin_fmaf(V[m].w, V[m].w, vv[3]);
+    }
+    const float gpv[4] = {gp.x, gp.y, gp.z, gp.w}, avv[4] = {av.x, av.y, av.z, av.w};
+    const float gv[4] = {gc.x / sqrtf(vv[0] + e2), gc.y / sqrtf(vv[1] + e2), gc.z / sqrtf(vv[2] + e2), gc.w / sqrtf(vv[3] + e2)};
+    float gxf[4 * D_L];   // g_x_out of (channel e, component m) at e D_L + m
+#pragma unroll
+    for (int m = 0; m < D_L; ++m) {
+      gxf[4 * m] = gx4[m].x;
+      gxf[4 * m + 1] = gx4[m].y;
+      gxf[4 * m + 2] = gx4[m].z;
+      gxf[4 * m + 3] = gx4[m].w;
+    }
+    float* row = bf + node * BLD + ch;
+#pragma unroll
+    for (int m = 0; m < D_L; ++m) {
+      const float u4[4] = {U[m].x, U[m].y, U[m].z, U[m].w}, v4[4] = {V[m].x, V[m].y, V[m].z, V[m].w};
+      float gu[4], gw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gu[e] = ok ? __builtin_fmaf(gxf[e * D_L + m], avv[e], gpv[e] * v4[e]) : 0.f;
+        gw[e] = ok ? __builtin_fmaf(gpv[e], u4[e], gv[e] * v4[e]) : 0.f;
+      }
+      *reinterpret_cast<float4*>(row + m * 2 * mul) = make_float4(gu[0], gu[1], gu[2], gu[3]);
+      *reinterpret_cast<float4*>(row + m * 2 * mul + mul) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+    }
+  }
+}
+
+// phase 2 of block l: g_xhat[node][l][m][k] = sum_c bf[node][m][c] WT[k][c], c over the 2 mul columns; jobs (m, tile of 32 k)
+template <int GQ, bool TO_LDS>   // quarters of 4 k-groups: 2 mul / 32
+__device__ __forceinline__ void uvb_contract(const UvBwdArgs& a, const float* bf, int BLD, float* gt, int XLD, int l, int mul,
+                                             int base, int wave, int lane, int64_t row0, int rows_here) {
+  const int i = lane & 31, kh = lane >> 5;
+  const int T = mul >> 5, d = 2 * l + 1, G = 4 * GQ;
+  for (int job = wave; job < d * T; job += 4) {
+    const int m = job / T, t = job - m * T;
+    const float4* wT = reinterpret_cast<const float4*>(a.wt[l]) + (int64_t)t * (G + 1) * 64;
+    const float* bs = bf + i * BLD + m * 2 * mul + 4 * kh;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = 0.f;
+      acc1[r] = 0.f;
+    }
+    float4 W0[4], W1[4];
+    auto fetch = [&](float4 (&w)[4], int qq) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = wT[(4 * qq + q) * 64 + lane];
+    };
+    auto steps = [&](const float4 (&w)[4], int qq) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 xv = *reinterpret_cast<const float4*>(bs + 8 * (4 * qq + q));
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q].x, xv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q].y, xv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q].z, xv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[q].w, xv.w, acc1, 0, 0, 0);
+      }
+    };
+    fetch(W0, 0);
+#pragma unroll
+    for (int qq = 0; qq < GQ; qq += 2) {
+      fetch(W1, qq + 1);
+      UV_SB();
+      steps(W0, qq);
+      UV_SB();
+      if (qq + 2 < GQ) fetch(W0, qq + 2);
+      UV_SB();
+      steps(W1, qq + 1);
+      UV_SB();
+    }
+    float* o = TO_LDS ? gt + i * XLD + base + m * mul + 32 * t + 4 * kh
+                      : a.g_xhat + a.n * base + ((row0 + i) * d + m) * mul + 32 * t + 4 * kh;   // BT block l, row (node, m)
+    if (TO_LDS || i < rows_here) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(o + 8 * g) = make_float4(acc0[4 * g] + acc1[4 * g], acc0[4 * g + 1] + acc1[4 * g + 1],
+                                                            acc0[4 * g + 2] + acc1[4 * g + 2], acc0[4 * g + 3] + acc1[4 * g + 3]);
+    }
+  }
+}
+
+template <int M0, int M1, int M2, int FF, int NORM, bool FUSE>
+__global__ void __launch_bounds__(256) k_update_uv_bwd(UvBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int m0 = M0 >= 0 ? M0 : a.ir.mul[0], m1 = M1 >= 0 ? M1 : a.ir.mul[1], m2 = M2 >= 0 ? M2 : a.ir.mul[2];
+  const int F = FF >= 0 ? FF : a.F;
+  const bool do_norm = NORM >= 0 ? (NORM != 0) : (a.do_norm != 0);
+  const int D = m0 + 3 * m1 + 5 * m2, C = m0 + m1 + m2, XLD = D + 4;
+  const int bw = max(2 * m0, max(6 * m1, 10 * m2)), BLD = bw + 4;   // widest [g_U | g_V] row of a block
+  float* gt = lds;                                    // [32][XLD]  g_xhat tile, [node][l][m][k] (fused form only)
+  float* bf = gt + (FUSE ? UV_ROWS * XLD : 0);        // [32][BLD]  [g_U | g_V] rows of the current block
+  float* lnw = bf + UV_ROWS * BLD;        // [F], then eq_w [C]
+  float* eqw = lnw + F;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * UV_ROWS;
+  const int rows_here = (int)min((int64_t)UV_ROWS, a.n - row0);
+  if (FUSE && do_norm) {
+    for (int f = tid; f < F; f += 256) lnw[f] = a.lnw[f];
+    for (int f = tid; f < C; f += 256) eqw[f] = a.eqw[f];
+  }
+  // ---- phases 1 and 2, block by block
+  if (m0 > 0) {
+    uvb_form<1>(a, bf, BLD, m0, 0, 0, F, D, row0, rows_here, tid);
+    UV_LDS_BARRIER();
+    if (m0 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here);
+    else if (m0 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here);
+    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here);
+    UV_LDS_BARRIER();
+  }
+  if (m1 > 0) {
+    uvb_form<3>(a, bf, BLD, m1, m0, m0, F, D, row0, rows_here, tid);
+    UV_LDS_BARRIER();
+    if (m1 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here);
+    else if (m1 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here);
+    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here);
+    UV_LDS_BARRIER();
+  }
+  if (m2 > 0) {
+    uvb_form<5>(a, bf, BLD, m2, m0 + 3 * m1, m0 + m1, F, D, row0, rows_here, tid);
+    UV_LDS_BARRIER();
+    if (m2 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here);
+    else if (m2 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here);
+    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here);
+    UV_LDS_BARRIER();
+  }
+  if (!FUSE) return;
+  // ---- phase 3: reverse of both norms, 8 lanes per node
+  const int node = tid >> 3, sub = tid & 7;
+  if (node >= rows_here) return;
+  const int64_t gn = row0 + node;
+  const float4* sr = reinterpret_cast<const float4*>(a.s + gn * F);
+  const float4* xr = reinterpret_cast<const float4*>(a.x + gn * D);
+  const float4* gsr = reinterpret_cast<const float4*>(a.g_cat + gn * a.ld_cat);
+  const float4* rsr = reinterpret_cast<const float4*>(a.g_s_out + gn * F);
+  const float4* rxr = reinterpret_cast<const float4*>(a.g_x_out + gn * D);
+  const float4 st = *reinterpret_cast<const float4*>(a.stats + 4 * gn);
+  const float mean = st.x, rstd = st.y, mean0 = st.z, r = st.w;
+  // g_s
+  {
+    float4 dy[UV_MAXS4], yh[UV_MAXS4];
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < UV_MAXS4; ++k) {
+      const int idx = sub + 8 * k, f0 = 4 * idx;
+      const bool v = f0 < F;
+      const float4 g = gsr[v ? idx : 0], sv = sr[v ? idx : 0];
+      if (do_norm) {
+        const float4 w = *reinterpret_cast<const float4*>(lnw + (v ? f0 : 0));
+        dy[k] = make_float4(v ? g.x * w.x : 0.f, v ? g.y * w.y : 0.f, v ? g.z * w.z : 0.f, v ? g.w * w.w : 0.f);
+        yh[k] = make_float4(v ? (sv.x - mean) * rstd : 0.f, v ? (sv.y - mean) * rstd : 0.f, v ? (sv.z - mean) * rstd : 0.f,
+                            v ? (sv.w - mean) * rstd : 0.f);
+        a1 += (dy[k].x + dy[k].y) + (dy[k].z + dy[k].w);
+        a2 += (dy[k].x * yh[k].x + dy[k].y * yh[k].y) + (dy[k].z * yh[k].z + dy[k].w * yh[k].w);
+      } else {
+        dy[k] = g;
+      }
+    }
+    if (do_norm) {
+      a1 = sum8(a1) / (float)F;
+      a2 = sum8(a2) / (float)F;
+    }
+#pragma unroll
+    for (int k = 0; k < UV_MAXS4; ++k) {
+      const int idx = sub + 8 * k;
+      if (4 * idx >= F) continue;
+      const float4 rs = rsr[idx];
+      float4 o = dy[k];
+      if (do_norm)
+        o = make_float4(rstd * (o.x - a1 - yh[k].x * a2), rstd * (o.y - a1 - yh[k].y * a2), rstd * (o.z - a1 - yh[k].z * a2),
+                        rstd * (o.w - a1 - yh[k].w * a2));
+      *reinterpret_cast<float4*>(a.g_s + gn * F + 4 * idx) = make_float4(o.x + rs.x, o.y + rs.y, o.z + rs.z, o.w + rs.w);
+    }
+  }
+  // g_x: gather this node's g_xhat row from the tile in e3nn order, times the affine weight
+  {
+    const float* grow = gt + node * XLD;
+    float4 gw[UV_MAXX4], xc[UV_MAXX4];   // g_xhat eq_w and the centred row
+    float dotp = 0.f, gsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < UV_MAXX4; ++k) {
+      const int idx = sub + 8 * k, f0 = 4 * idx;
+      if (f0 >= D) {
+        gw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xc[k] = gw[k];
+        continue;
+      }
+      const float4 xv = xr[idx];
+      float g[4];
+      if (f0 < m0) {
+        const float4 t = *reinterpret_cast<const float4*>(grow + f0);
+        g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+        if (do_norm) {
+          const float4 w = *reinterpret_cast<const float4*>(eqw + f0);
+          g[0] *= w.x; g[1] *= w.y; g[2] *= w.z; g[3] *= w.w;
+        }
+        xc[k] = make_float4(xv.x - mean0, xv.y - mean0, xv.z - mean0, xv.w - mean0);
+      } else {
+        const bool is1 = f0 < m0 + 3 * m1;
+        const int dl = is1 ? 3 : 5, mul = is1 ? m1 : m2, off = is1 ? m0 : m0 + 3 * m1, u0 = is1 ? m0 : m0 + m1;
+        const int rr0 = f0 - off;
+        int up = is1 ? rr0 / 3 : rr0 / 5, m = rr0 - up * dl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          g[e] = grow[off + m * mul + up];
+          if (do_norm) g[e] *= eqw[u0 + up];
+          ++m;
+          if (m == dl) {
+            m = 0;
+            ++up;
+          }
+        }
+        xc[k] = xv;
+      }
+      gw[k] = make_float4(g[0], g[1], g[2], g[3]);
+      dotp += (gw[k].x * xc[k].x + gw[k].y * xc[k].y) + (gw[k].z * xc[k].z + gw[k].w * xc[k].w);
+    }
+    float coef = 0.f, gmean = 0.f;
+    if (do_norm) {
+      coef = sum8(dotp) * r * r * r / (float)C;
+#pragma unroll
+      for (int k = 0; k < UV_MAXX4; ++k)
+        if (4 * (sub + 8 * k) < m0)
+          gsum += ((r * gw[k].x - coef * xc[k].x) + (r * gw[k].y - coef * xc[k].y)) + ((r * gw[k].z - coef * xc[k].z) + (r * gw[k].w - coef * xc[k].w));
+      gmean = m0 > 0 ? sum8(gsum) / (float)m0 : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < UV_MAXX4; ++k) {
+      const int idx = sub + 8 * k, f0 = 4 * idx;
+      if (f0 >= D) continue;
+      const float4 rx = rxr[idx];
+      float4 o = gw[k];
+      if (do_norm) {
+        const float gm = f0 < m0 ? gmean : 0.f;
+        o = make_float4(r * o.x - coef * xc[k].x - gm, r * o.y - coef * xc[k].y - gm, r * o.z - coef * xc[k].z - gm,
+                        r * o.w - coef * xc[k].w - gm);
+      }
+      *reinterpret_cast<float4*>(a.g_x + gn * D + f0) = make_float4(o.x + rx.x, o.y + rx.y, o.z + rx.z, o.w + rx.w);
+    }
+  }
+}
+
 static bool uv_shape_ok(int node_dim, const Irreps& ir) {
   for (int l = 0; l < 3; ++l)
     if (!(ir.mul[l] == 0 || ir.mul[l] == 32 || ir.mul[l] == 64 || ir.mul[l] == 128)) return false;
@@ -378,6 +667,55 @@ int xeq_update_uv_fwd(const float* s, const float* x, const float* ln_w, const f
   else
     hipLaunchKernelGGL((k_update_uv_fwd<-1, -1, -1, -1, -1>), grid, dim3(256), lds, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_update_uv_fwd");
+  return XEQ_OK;
+}
+
+int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, int64_t ld_cat, const float* g_x_out,
+                      const float* g_s_out, const float* a, int64_t ld_a, const float* s, const float* x, const float* stats,
+                      const float* ln_w, const float* eq_w, int64_t n, int node_dim, const int32_t mul[3], int do_norm,
+                      const float* wt_packed0, const float* wt_packed1, const float* wt_packed2, double eps, float* g_s, float* g_x,
+                      float* g_xhat_bt, void* stream) {
+  XEQ_CHECK_ARG(xeq_update_uv_supported(XEQ_F32, node_dim, mul), "xeq_update_uv_bwd: unsupported layout (node_dim %d, mul %d %d %d)",
+                node_dim, mul[0], mul[1], mul[2]);
+  Irreps ir{{mul[0], mul[1], mul[2]}};
+  XEQ_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) * UV_ROWS / 64, "xeq_update_uv_bwd: n = %lld out of range", (long long)n);
+  XEQ_CHECK_ARG(ld_cat >= node_dim + ir.C() && ld_cat % 4 == 0 && ld_a >= ir.C() && ld_a % 4 == 0,
+                "xeq_update_uv_bwd: row strides (%lld, %lld) do not hold the rows in 16-byte units", (long long)ld_cat, (long long)ld_a);
+  if (n == 0) return XEQ_OK;
+  const float* wt[3] = {wt_packed0, wt_packed1, wt_packed2};
+  for (int l = 0; l < 3; ++l) XEQ_CHECK_ARG(mul[l] == 0 || wt[l], "xeq_update_uv_bwd: packed weights of l = %d missing", l);
+  const bool fuse = g_xhat_bt == nullptr;
+  XEQ_CHECK_ARG(uv_bt && g_p && g_cat && g_x_out && a, "xeq_update_uv_bwd: null buffer");
+  XEQ_CHECK_ARG(!fuse || (g_s_out && s && x && stats && g_s && g_x && (!do_norm || (ln_w && eq_w))), "xeq_update_uv_bwd: null buffer (fused form)");
+  UvBwdArgs b;
+  b.uv = uv_bt; b.g_p = g_p; b.g_cat = g_cat; b.g_x_out = g_x_out; b.g_s_out = g_s_out; b.a = a; b.s = s; b.x = x; b.stats = stats;
+  b.lnw = ln_w; b.eqw = eq_w; b.ld_cat = ld_cat; b.ld_a = ld_a; b.n = n; b.do_norm = do_norm; b.F = node_dim; b.ir = ir;
+  for (int l = 0; l < 3; ++l) b.wt[l] = wt[l];
+  b.eps = (float)eps; b.g_s = g_s; b.g_x = g_x; b.g_xhat = g_xhat_bt;
+  int bw = 2 * mul[0];
+  if (6 * mul[1] > bw) bw = 6 * mul[1];
+  if (10 * mul[2] > bw) bw = 10 * mul[2];
+  const size_t lds = ((fuse ? (size_t)UV_ROWS * (ir.D() + 4) : 0) + (size_t)UV_ROWS * (bw + 4) + node_dim + ir.C()) * sizeof(float);
+  const dim3 grid((unsigned)((n + UV_ROWS - 1) / UV_ROWS));
+  static bool attr_set = false;   // more than 64 KB of dynamic LDS (fused form): opt in once per instantiation
+  if (!attr_set) {
+    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_uv_bwd<128, 64, 32, 128, 1, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_uv_bwd<-1, -1, -1, -1, -1, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    XEQ_CHECK_ARG(e0 == hipSuccess && e1 == hipSuccess, "xeq_update_uv_bwd: cannot raise the dynamic LDS limit: %s",
+                  hipGetErrorString(e0 != hipSuccess ? e0 : e1));
+    attr_set = true;
+  }
+  const bool dflt = mul[0] == 128 && mul[1] == 64 && mul[2] == 32 && node_dim == 128 && do_norm;
+  if (fuse) {
+    if (dflt) hipLaunchKernelGGL((k_update_uv_bwd<128, 64, 32, 128, 1, true>), grid, dim3(256), lds, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL((k_update_uv_bwd<-1, -1, -1, -1, -1, true>), grid, dim3(256), lds, (hipStream_t)stream, b);
+  } else {
+    if (dflt) hipLaunchKernelGGL((k_update_uv_bwd<128, 64, 32, 128, 1, false>), grid, dim3(256), lds, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL((k_update_uv_bwd<-1, -1, -1, -1, -1, false>), grid, dim3(256), lds, (hipStream_t)stream, b);
+  }
+  XEQ_CHECK_LAUNCH("xeq_update_uv_bwd");
   return XEQ_OK;
 }
 

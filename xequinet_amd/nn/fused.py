@@ -200,8 +200,8 @@ def _packed_uv_frag(module):
     packs, bias = _packed_uv(module)                     # refreshed there when a weight changes
     cache = getattr(module, "_uv_frag", None)
     if cache is not None and cache[0] is packs:
-        return cache[1], cache[2]
-    frag, it = [None, None, None], iter(packs)
+        return cache[1], cache[2], cache[3]
+    frag, frag_t, it = [None, None, None], [None, None, None], iter(packs)
     for l, m in enumerate(mul):
         if m == 0:
             continue
@@ -209,8 +209,17 @@ def _packed_uv_frag(module):
         out = torch.empty(lib.load().xeq_mlp_packed_floats(2 * m, m), dtype=torch.float32, device=W.device)
         call("xeq_mlp_pack", ptr(W), ptr(bias if l == 0 else None), 2 * m, m, 1, ptr(out), stream())
         frag[l] = out
-    module._uv_frag = (packs, frag, bias is not None)
-    return frag, bias is not None
+        out_t = torch.empty(lib.load().xeq_mlp_packed_floats(m, 2 * m), dtype=torch.float32, device=W.device)
+        call("xeq_mlp_pack", ptr(W), None, m, 2 * m, 0, ptr(out_t), stream())   # reverse: the same rows as [n_out = mul][k_in = 2 mul]
+        frag_t[l] = out_t
+    module._uv_frag = (packs, frag, bias is not None, frag_t)
+    return frag, bias is not None, frag_t
+
+
+# xeq_update_uv_bwd with the norms' reverse inside (113 KB of LDS: one workgroup per CU) up to one 32-node tile per CU, split
+# off to xeq_norm_bwd (50 KB: three per CU) beyond (MI355X, 18 k nodes: 99 us fused, 92 us split, 146 us the kernel chain;
+# 1.5 k nodes: 24 / 28 / 95 us).  The C++ operator (csrc/xeq_torch.cpp) applies the same rule.
+UV_BWD_FUSE_NORM_MAX_NODES = 32 * 256
 
 
 class UpdateBlock(Function):
@@ -267,12 +276,27 @@ class UpdateBlock(Function):
         g_x_out = torch.zeros_like(x) if g_x_out is None else g_x_out.contiguous()
         g_a = torch.empty_like(a)
         g_ip = torch.empty_like(ip)
-        g_uv = torch.empty_like(uv)
         # dL/dU of this stage (g_x_out a_vv) is formed inside xeq_uv_reduce_bwd: no write here, no read-modify-write there
         call("xeq_update_out_bwd", dtype_code(s), ptr(g_s_out), ptr(g_x_out), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(g_a),
              ptr(g_ip), None, stream())
         g_p = torch.mm(g_ip, module.dot_lin.weight)
         g_cat = _mlp_bwd(module.update_mlp, g_a, pre)                         # [g_shat | g_v]
+        frag = _packed_uv_frag(module)
+        if frag is not None and g_cat.is_contiguous():   # dL/dU, dL/dV -> dL/dxhat -> reverse of both norms in one matrix-core launch
+            lw, ew = (module.norm.weight, module.o3norm.affine_weight) if ctx.do_norm else (None, None)
+            if n <= UV_BWD_FUSE_NORM_MAX_NODES:
+                g_s, g_x = torch.empty_like(s), torch.empty_like(x)
+                g_xhat = None
+            else:
+                g_s = g_x = None
+                g_xhat = torch.empty(n * D, dtype=dt, device=dev)
+            call("xeq_update_uv_bwd", ptr(uv), ptr(g_p), ptr(g_cat), F + C, ptr(g_x_out), ptr(g_s_out), ptr(a), a.shape[1], ptr(s), ptr(x),
+                 ptr(stats), ptr(lw), ptr(ew), n, F, mul3(mul), int(ctx.do_norm), ptr(frag[2][0]), ptr(frag[2][1]), ptr(frag[2][2]),
+                 float(module.invariant.eps), ptr(g_s), ptr(g_x), ptr(g_xhat), stream())
+            if g_xhat is not None:
+                g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_cat, F + C, g_xhat, g_s_out, g_x_out)
+            return g_s, g_x, None
+        g_uv = torch.empty_like(uv)
         call("xeq_uv_reduce_bwd", dtype_code(s), ptr(uv), ptr(g_p), ptr(g_cat), F + C, F, n, mul3(mul), float(module.invariant.eps),
              ptr(g_x_out), ptr(a), ptr(g_uv), stream())
         packs, _ = _packed_uv(module)
