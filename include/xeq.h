@@ -59,6 +59,11 @@ int xeq_csr_by_key(const int64_t* keys, int64_t n_keys, int64_t n_rows, void* wo
 
 /* Exclusive prefix sum of int32 counts[n] into out[n+1] (out[n] = total). */
 int xeq_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* out, void* stream);
+/* The same scan grid-wide (decoupled look-back), for large n; `workspace`: device scratch of at least
+ * xeq_exclusive_scan_i32_workspace(n) bytes (-1: n out of range).  The form above runs in ONE workgroup and needs none. */
+int64_t xeq_exclusive_scan_i32_workspace(int64_t n);
+int xeq_exclusive_scan_i32_ws(const int32_t* counts, int64_t n, int32_t* out, void* workspace, int64_t workspace_bytes,
+                              void* stream);
 
 /* Replaces torch_cluster.radius_graph at data/transform.py:58-64 (non-PBC):
  * same-graph pairs with d^2 < r^2 (strict), no self loops, unlimited neighbours.

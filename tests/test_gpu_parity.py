@@ -927,3 +927,23 @@ def test_auto_picks_a_kernel_family_that_fits(monkeypatch):
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
     with pytest.raises(RuntimeError):
         ops.select_message_impl(torch.float64, 100, 1000, 20, 128, mul)
+
+
+@pytest.mark.parametrize("n", [0, 1, 8191, 8193, 100003])
+def test_exclusive_scan_grid_wide_matches_numpy(n):
+    """xeq_exclusive_scan_i32_ws (grid-wide) and xeq_exclusive_scan_i32 (one workgroup): rowptr of the neighbour counts, bit-exact."""
+    from xequinet_amd import lib
+    from xequinet_amd.lib import call, ptr, stream
+    from xequinet_amd.ops import _exclusive_scan
+
+    rng = np.random.default_rng(n)
+    deg = rng.integers(0, 40, size=n).astype(np.int32)
+    want = np.concatenate([[0], np.cumsum(deg, dtype=np.int64)]).astype(np.int32)
+    d = _t(deg) if n else torch.empty(0, dtype=torch.int32, device=DEV)
+    out = torch.empty(n + 1, dtype=torch.int32, device=DEV)
+    _exclusive_scan(d, n, out)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    out1 = torch.empty(n + 1, dtype=torch.int32, device=DEV)
+    call("xeq_exclusive_scan_i32", ptr(d), n, ptr(out1), stream())
+    np.testing.assert_array_equal(out1.cpu().numpy(), want)
+    assert lib.load().xeq_exclusive_scan_i32_workspace(-1) == -1

@@ -622,6 +622,41 @@ int xeq_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* out, void*
   return XEQ_OK;
 }
 
+// grid-wide form: hipCUB's decoupled look-back scan over n + 1 items (item n reads as 0, so out[n] is the total)
+namespace {
+struct ScanIn {
+  const int32_t* in;
+  int64_t n;
+  __host__ __device__ int32_t operator()(int64_t i) const { return i < n ? in[i] : 0; }
+};
+using ScanIter = hipcub::TransformInputIterator<int32_t, ScanIn, hipcub::CountingInputIterator<int64_t>>;
+}  // namespace
+
+int64_t xeq_exclusive_scan_i32_workspace(int64_t n) {
+  if (n < 0 || n >= ((int64_t)1 << 31) - 1) return -1;
+  size_t temp = 0;
+  ScanIter it(hipcub::CountingInputIterator<int64_t>(0), ScanIn{nullptr, n});
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, temp, it, (int32_t*)nullptr, (int)(n + 1), (hipStream_t)0) != hipSuccess) return -1;
+  return (int64_t)(temp + 16);
+}
+
+int xeq_exclusive_scan_i32_ws(const int32_t* counts, int64_t n, int32_t* out, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) - 1, "xeq_exclusive_scan_i32_ws: n = %lld out of range", (long long)n);
+  const int64_t need = xeq_exclusive_scan_i32_workspace(n);
+  XEQ_CHECK_ARG(out && workspace && need >= 0 && workspace_bytes >= need, "xeq_exclusive_scan_i32_ws: workspace of %lld bytes, %lld needed",
+                (long long)workspace_bytes, (long long)need);
+  XEQ_CHECK_ARG(n == 0 || counts, "xeq_exclusive_scan_i32_ws: null input");
+  size_t temp = (size_t)workspace_bytes;
+  ScanIter it(hipcub::CountingInputIterator<int64_t>(0), ScanIn{counts, n});
+  const hipError_t e = hipcub::DeviceScan::ExclusiveSum(workspace, temp, it, out, (int)(n + 1), (hipStream_t)stream);
+  if (e != hipSuccess) {
+    xeq::set_error("xeq_exclusive_scan_i32_ws: %s", hipGetErrorString(e));
+    return XEQ_ERR_LAUNCH;
+  }
+  return XEQ_OK;
+}
+
 int xeq_reverse_edge_map(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, const int32_t* c_rowptr,
                          int32_t* rev, void* stream) {
   XEQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 0, "xeq_reverse_edge_map: negative size");

@@ -618,7 +618,10 @@ std::tuple<Tensor, Tensor> radius_graph(const Tensor& pos_in, const Tensor& ptr,
   Tensor deg = i32(N, ptr64), rowptr = i32(N + 1, ptr64);
   void* st = cur_stream();
   XCALL(xeq_radius_graph_count(dt, pos.data_ptr(), (const int64_t*)ptr64.data_ptr(), G, N, cutoff, (int32_t*)deg.data_ptr(), st));
-  XCALL(xeq_exclusive_scan_i32((const int32_t*)deg.data_ptr(), N, (int32_t*)rowptr.data_ptr(), st));
+  const int64_t scan_bytes = xeq_exclusive_scan_i32_workspace(N);
+  TORCH_CHECK(scan_bytes >= 0, "xeq::radius_graph: too many nodes");
+  Tensor scan_work = at::empty({std::max<int64_t>(scan_bytes, 1)}, pos.options().dtype(at::kByte));
+  XCALL(xeq_exclusive_scan_i32_ws((const int32_t*)deg.data_ptr(), N, (int32_t*)rowptr.data_ptr(), scan_work.data_ptr(), scan_bytes, st));
   const int64_t E = N > 0 ? (int64_t)rowptr[N].item<int32_t>() : 0;
   Tensor ei = at::empty({2, E}, ptr64.options());
   XCALL(xeq_radius_graph_fill(dt, pos.data_ptr(), (const int64_t*)ptr64.data_ptr(), G, N, cutoff, (const int32_t*)rowptr.data_ptr(), E,

@@ -28,6 +28,8 @@ _PROTOS = {
     "xeq_csr_by_key_workspace": [c_int64, c_int64],
     "xeq_csr_by_key": [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P],
     "xeq_exclusive_scan_i32": [_P, c_int64, _P, _P],
+    "xeq_exclusive_scan_i32_workspace": [c_int64],
+    "xeq_exclusive_scan_i32_ws": [_P, c_int64, _P, _P, c_int64, _P],
     "xeq_reverse_edge_map": [_P, c_int64, c_int64, _P, _P, _P],
     "xeq_radius_graph_count": [c_int, _P, _P, c_int64, c_int64, c_double, _P, _P],
     "xeq_radius_graph_fill": [c_int, _P, _P, c_int64, c_int64, c_double, _P, c_int64, _P, _P],
@@ -108,7 +110,7 @@ _PROTOS = {
 }
 # entry points that return a size, not a status
 _RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
-            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats"}
+            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None

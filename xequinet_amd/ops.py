@@ -53,6 +53,13 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 # --------------------------------------------------------------------------- graph
+def _exclusive_scan(deg: torch.Tensor, n: int, rowptr: torch.Tensor) -> None:
+    """rowptr[0..n] = exclusive prefix sum of deg[0..n) (rowptr[n] = total), grid-wide (xeq_exclusive_scan_i32_ws)."""
+    nbytes = lib.load().xeq_exclusive_scan_i32_workspace(n)
+    work = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=deg.device)
+    call("xeq_exclusive_scan_i32_ws", ptr(deg), n, ptr(rowptr), ptr(work), int(nbytes), stream())
+
+
 def csr_by_key(keys: torch.Tensor, n_rows: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """(rowptr[n_rows+1], perm[E]) of an unsorted int64 index row: stable radix sort + row pointer in one library call."""
     require_hip(keys)
@@ -215,7 +222,7 @@ def _radius_graph_cell_list(pos, ptr_, cutoff):
     rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     call("xeq_radius_graph_count_cl", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(lo), ptr(inv_w), ptr(nb), ptr(bin_base),
          ptr(bin_start), ptr(bin_atom), ptr(deg), stream())
-    call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+    _exclusive_scan(deg, N, rowptr)
     E = int(rowptr[-1].item()) if N > 0 else 0
     edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
     tmp_keys = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
@@ -237,7 +244,7 @@ def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tu
     rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     dt = dtype_code(pos)
     call("xeq_radius_graph_count", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(deg), stream())
-    call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+    _exclusive_scan(deg, N, rowptr)
     E = int(rowptr[-1].item()) if N > 0 else 0  # one host sync, as in the reference's nonzero()
     edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
     call("xeq_radius_graph_fill", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(rowptr), E, ptr(edge_index), stream())
@@ -269,7 +276,7 @@ def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):
         rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         call("xeq_radius_graph_pbc_count_cl", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), n_cells, float(cutoff), ptr(recip),
              ptr(thr), mul3(reps), ptr(nbins), ptr(bin_base), ptr(bin_start), ptr(bin_atom), ptr(deg), stream())
-        call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+        _exclusive_scan(deg, N, rowptr)
         E = int(rowptr[-1].item()) if N > 0 else 0
         edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
         cell_offsets = torch.empty((E, 3), dtype=pos_wrap.dtype, device=dev)
@@ -288,7 +295,7 @@ def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):
         rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         call("xeq_radius_graph_pbc_count_pruned", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), n_cells, float(cutoff), ptr(recip),
              ptr(thr), mul3(reps), ptr(deg), stream())
-        call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+        _exclusive_scan(deg, N, rowptr)
         E = int(rowptr[-1].item()) if N > 0 else 0
         edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
         cell_offsets = torch.empty((E, 3), dtype=pos_wrap.dtype, device=dev)
@@ -302,7 +309,7 @@ def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):
     deg = torch.empty(N, dtype=torch.int32, device=dev)
     rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     call("xeq_radius_graph_pbc_count", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), n_cells, float(cutoff), ptr(deg), stream())
-    call("xeq_exclusive_scan_i32", ptr(deg), N, ptr(rowptr), stream())
+    _exclusive_scan(deg, N, rowptr)
     E = int(rowptr[-1].item()) if N > 0 else 0
     edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
     cell_offsets = torch.empty((E, 3), dtype=pos_wrap.dtype, device=dev)
