@@ -536,6 +536,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                                    hy.B, F, mul, g_h.data_ptr(), g_xhat.data_ptr(), g_vec.data_ptr(), 1, st));
         }
         g_vec_total = g_vec_total.defined() ? g_vec_total + g_vec : g_vec;
+        if (b == 0) break;   // the first block's node features (embedding, zeros) do not depend on the positions
         const Tensor g_shat = mlp_bwd(g_h, m.pre, q[0], q[1], q[2], q[3]);
         Tensor ns, nx;
         norm_bwd(hy, m.s, m.x, q[6], q[8], m.stats, g_shat, F, g_xhat, g_s, g_x, ns, nx);
