@@ -214,8 +214,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
       for (int q = 0; q < 4; ++q) b[4 + q] = wb[q * 64 + lane];
     }
   };
-  int t0 = wave;
-  if (t0 < nt2) fetch_q(B0, t0, t0 + 4 < nt2, 0);
+  // few row tiles (MD-sized systems): gridDim.y workgroups share a tile, each redoes stage 1 and takes every gridDim.y-th
+  // group of four output tiles (one per wave), so one tile's latency is not one workgroup's whole serial MFMA chain
+  const int parts = __builtin_amdgcn_readfirstlane((int)gridDim.y), part = __builtin_amdgcn_readfirstlane((int)blockIdx.y);
+  int t0 = wave + 4 * part;
+  if (t0 < nt2) fetch_q(B0, t0, parts == 1 && t0 + 4 < nt2, 0);
 
   // elementwise stage on the hidden tile, then to LDS as the row operand of stage 2
 #pragma unroll
@@ -225,7 +228,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
                            acc0[4 * g + 3] + acc1[4 * g + 3]);
     float4 v;
     if (!REVERSE) {
-      if (row_ok) *reinterpret_cast<float4*>(preb + ((unsigned)i * MLP_H + (unsigned)col)) = t;
+      if (row_ok && part == 0) *reinterpret_cast<float4*>(preb + ((unsigned)i * MLP_H + (unsigned)col)) = t;
       v = make_float4(silu_f(t.x), silu_f(t.y), silu_f(t.z), silu_f(t.w));
     } else {
       v = make_float4(t.x * silu_grad_f(pv[g].x), t.y * silu_grad_f(pv[g].y), t.z * silu_grad_f(pv[g].z), t.w * silu_grad_f(pv[g].w));
@@ -238,14 +241,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 #endif
 
   const float* ts = &Ts[i * MLP_TLD + 4 * kh];
-  auto pass = [&](auto two_c, int tt) {
+  auto pass = [&](auto two_c, int tt, int tn, bool tn_two) {   // tn: the tile (pair) this wave takes next
     constexpr bool TWO = decltype(two_c)::value;
-    const int tn = tt + 8;
     f32x16 ya, yb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       ya[r] = 0.f;
-      yb[r] = 0.f;   // single tile: the odd k steps accumulate here
+      yb[r] = 0.f;
     }
     float bias_ya = 0.f, bias_yb = 0.f;
     if (a.bias2) {
@@ -273,10 +275,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
           ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, tv.w, ya, 0, 0, 0);
           yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[4 + q].w, tv.w, yb, 0, 0, 0);
         } else {
+          // one chain, the order of the paired form (a tile's sums do not depend on which form computed it): the f32 MFMA's
+          // dependent-accumulator latency equals its issue interval (64 cycles)
           ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, tv.x, ya, 0, 0, 0);
-          yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, tv.y, yb, 0, 0, 0);
+          ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, tv.y, ya, 0, 0, 0);
           ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].z, tv.z, ya, 0, 0, 0);
-          yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, tv.w, yb, 0, 0, 0);
+          ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, tv.w, ya, 0, 0, 0);
         }
       }
     };
@@ -292,7 +296,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     MLP_SB();
     quarter(B0, 2);
     MLP_SB();
-    if (tn < nt2) fetch_q(B0, tn, tn + 4 < nt2, 0);
+    if (tn < nt2) fetch_q(B0, tn, tn_two, 0);
     MLP_SB();
     quarter(B1, 3);
     if (a.bias2) {
@@ -315,14 +319,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
           *reinterpret_cast<float4*>(yo + o) = make_float4(ya[4 * g], ya[4 * g + 1], ya[4 * g + 2], ya[4 * g + 3]);
           *reinterpret_cast<float4*>(yo + o + 128u) = make_float4(yb[4 * g], yb[4 * g + 1], yb[4 * g + 2], yb[4 * g + 3]);
         } else {
-          *reinterpret_cast<float4*>(yo + o) = make_float4(ya[4 * g] + yb[4 * g], ya[4 * g + 1] + yb[4 * g + 1], ya[4 * g + 2] + yb[4 * g + 2],
-                                                           ya[4 * g + 3] + yb[4 * g + 3]);
+          *reinterpret_cast<float4*>(yo + o) = make_float4(ya[4 * g], ya[4 * g + 1], ya[4 * g + 2], ya[4 * g + 3]);
         }
       }
     }
   };
-  for (; t0 + 4 < nt2; t0 += 8) pass(std::true_type{}, t0);
-  if (t0 < nt2) pass(std::false_type{}, t0);
+  if (parts == 1) {
+    for (; t0 + 4 < nt2; t0 += 8) pass(std::true_type{}, t0, t0 + 8, t0 + 12 < nt2);
+    if (t0 < nt2) pass(std::false_type{}, t0, nt2, false);
+  } else {
+    for (; t0 < nt2; t0 += 4 * parts) pass(std::false_type{}, t0, t0 + 4 * parts, false);
+  }
 #ifdef XEQ_MLP_WGREC
   if (tid == 0 && blockIdx.x < 4096) {
     unsigned long long wg_t1_;
@@ -348,6 +355,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     atomicAdd(&g_mlp_stamps[7], c1_ - cp3_);     // stage 2 in total
   }
 #endif
+}
+
+// workgroups per row tile: 1 once the tiles alone fill the chip; for few tiles, up to one per group of four output tiles
+static unsigned mlp_parts(int64_t n, int n2) {
+  const int64_t tiles = (n + MLP_ROWS - 1) / MLP_ROWS;
+  const int groups = (n2 / 32 + 3) / 4;
+  if (tiles * 2 > 256 || groups < 2) return 1;
+  int64_t p = 256 / tiles;
+  if (p > groups) p = groups;
+  return (unsigned)(p < 1 ? 1 : p);
 }
 
 static int mlp_check(const char* name, int64_t n, int k1, int n2, int64_t ldx, int64_t ldy) {
@@ -397,7 +414,7 @@ int xeq_mlp2_fwd(const float* x, int64_t ldx, int64_t n, int k1, const float* w1
   XEQ_CHECK_ARG(n == 0 || (x && w1p && w2p && pre && y), "xeq_mlp2_fwd: null buffer");
   if (n == 0) return XEQ_OK;
   MlpArgs a{x, ldx, n, k1, n2, w1p, w2p, 1, 1, pre, y, ldy};
-  hipLaunchKernelGGL(k_mlp2<false>, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_mlp2<false>, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS), mlp_parts(n, n2)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_fwd");
   return XEQ_OK;
 }
@@ -408,7 +425,7 @@ int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2
   XEQ_CHECK_ARG(n == 0 || (g && w2tp && w1tp && pre && gx), "xeq_mlp2_bwd: null buffer");
   if (n == 0) return XEQ_OK;
   MlpArgs a{g, ldg, n, k1, n2, w2tp, w1tp, 0, 0, const_cast<float*>(pre), gx, ldgx};
-  hipLaunchKernelGGL(k_mlp2<true>, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_mlp2<true>, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS), mlp_parts(n, n2)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_bwd");
   return XEQ_OK;
 }

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
           o = make_float4((o.x - mean) * rstd * w.x + b.x, (o.y - mean) * rstd * w.y + b.y, (o.z - mean) * rstd * w.z + b.z,
                           (o.w - mean) * rstd * w.w + b.w);
         }
-        *reinterpret_cast<float4*>(a.cat + gn * a.ld_cat + f0) = o;
+        if (blockIdx.y == 0) *reinterpret_cast<float4*>(a.cat + gn * a.ld_cat + f0) = o;
       }
     }
     // xhat -> LDS, e3nn (channel-major, m-minor) re-laid as [l][m][channel]; rows past n are written as zeros
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
         }
       }
     }
-    if (ok && sub == 0) *reinterpret_cast<float4*>(a.stats + 4 * gn) = make_float4(mean, rstd, mean0, r);
+    if (ok && sub == 0 && blockIdx.y == 0) *reinterpret_cast<float4*>(a.stats + 4 * gn) = make_float4(mean, rstd, mean0, r);
   }
   UV_LDS_BARRIER();
 
@@ -311,7 +311,9 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
 #ifdef XEQ_UV_NO_B   // development: norms only
   if (a.n >= 0) return;
 #endif
-  for (int jj = wave; jj < a.n_jobs; jj += 4) {
+  // few node tiles (MD-sized systems): gridDim.y workgroups share a tile, each repeats phase A and takes every gridDim.y-th job
+  const int parts = __builtin_amdgcn_readfirstlane((int)gridDim.y), part = __builtin_amdgcn_readfirstlane((int)blockIdx.y);
+  for (int jj = part + parts * wave; jj < a.n_jobs; jj += 4 * parts) {
     const int l = a.job_l[jj], t = a.job_t[jj];
     const int mul = l == 0 ? m0 : (l == 1 ? m1 : m2);
     if (mul == 128) uv_job<16>(a, xh, XLD, l, t, row0, rows_here, lane);
@@ -400,7 +402,8 @@ __device__ __forceinline__ void uvb_contract(const UvBwdArgs& a, const float* bf
                                              int base, int wave, int lane, int64_t row0, int rows_here) {
   const int i = lane & 31, kh = lane >> 5;
   const int T = mul >> 5, d = 2 * l + 1, G = 4 * GQ;
-  for (int job = wave; job < d * T; job += 4) {
+  const int parts = __builtin_amdgcn_readfirstlane((int)gridDim.y), part = __builtin_amdgcn_readfirstlane((int)blockIdx.y);
+  for (int job = part + parts * wave; job < d * T; job += 4 * parts) {
     const int m = job / T, t = job - m * T;
     const float4* wT = reinterpret_cast<const float4*>(a.wt[l]) + (int64_t)t * (G + 1) * 64;
     const float* bs = bf + i * BLD + m * 2 * mul + 4 * kh;
@@ -609,6 +612,15 @@ __global__ void __launch_bounds__(256) k_update_uv_bwd(UvBwdArgs a) {
   }
 }
 
+// workgroups per node tile: 1 once the tiles alone fill the chip; for few tiles, up to one per job
+static unsigned uv_parts(int64_t n, int jobs) {
+  const int64_t tiles = (n + UV_ROWS - 1) / UV_ROWS;
+  if (tiles * 2 > 256 || jobs < 2) return 1;
+  int64_t p = 256 / tiles;
+  if (p > jobs) p = jobs;
+  return (unsigned)(p < 1 ? 1 : p);
+}
+
 static bool uv_shape_ok(int node_dim, const Irreps& ir) {
   for (int l = 0; l < 3; ++l)
     if (!(ir.mul[l] == 0 || ir.mul[l] == 32 || ir.mul[l] == 64 || ir.mul[l] == 128)) return false;
@@ -661,7 +673,7 @@ int xeq_update_uv_fwd(const float* s, const float* x, const float* ln_w, const f
       ++a.n_jobs;
     }
   const size_t lds = ((size_t)UV_ROWS * (ir.D() + 4) + 2 * node_dim + ir.C() + mul[0]) * sizeof(float);
-  const dim3 grid((unsigned)((n + UV_ROWS - 1) / UV_ROWS));
+  const dim3 grid((unsigned)((n + UV_ROWS - 1) / UV_ROWS), uv_parts(n, a.n_jobs));
   if (mul[0] == 128 && mul[1] == 64 && mul[2] == 32 && node_dim == 128 && do_norm)   // the default model (nn/model.py: 128x0e + 64x1o + 32x2e)
     hipLaunchKernelGGL((k_update_uv_fwd<128, 64, 32, 128, 1>), grid, dim3(256), lds, (hipStream_t)stream, a);
   else
@@ -696,7 +708,10 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
   if (6 * mul[1] > bw) bw = 6 * mul[1];
   if (10 * mul[2] > bw) bw = 10 * mul[2];
   const size_t lds = ((fuse ? (size_t)UV_ROWS * (ir.D() + 4) : 0) + (size_t)UV_ROWS * (bw + 4) + node_dim + ir.C()) * sizeof(float);
-  const dim3 grid((unsigned)((n + UV_ROWS - 1) / UV_ROWS));
+  int min_jobs = 1 << 30;   // jobs of the smallest block: (2l+1) mul_l / 32
+  for (int l = 0; l < 3; ++l)
+    if (mul[l] > 0 && (2 * l + 1) * mul[l] / 32 < min_jobs) min_jobs = (2 * l + 1) * mul[l] / 32;
+  const dim3 grid((unsigned)((n + UV_ROWS - 1) / UV_ROWS), fuse ? 1u : uv_parts(n, min_jobs));
   static bool attr_set = false;   // more than 64 KB of dynamic LDS (fused form): opt in once per instantiation
   if (!attr_set) {
     const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_uv_bwd<128, 64, 32, 128, 1, true>),
