@@ -208,6 +208,43 @@ __device__ __forceinline__ void edge_grad(const EdgeGeom<T>& g, T gd, const T* p
   out[2] = gdd * g.z + s * (Gz - Gr * g.z);
 }
 
+// ---- node tiles of the matrix-core node kernels (xeq_mlp.hip, xeq_update.hip) ---------------------------------------
+// A launch costs (rounds of one workgroup per CU) x (time of a lone workgroup), so whole tiles run one workgroup each while
+// they come in multiples of the CU count, and the remainder (or everything, for MD-sized systems) is SPLIT: `split` workgroups
+// share a tile, each repeats its cheap first phase and takes every split-th group of output tiles / jobs.
+// Workgroup b < n_full: tile b alone; else tile n_full + (b - n_full) / split, part (b - n_full) % split.
+struct TileSplit {
+  int n_full, split;
+  __host__ __device__ unsigned grid(int64_t tiles) const { return (unsigned)(n_full + (tiles - n_full) * split); }
+  __device__ __forceinline__ void decode(int b, int& tile, int& part, int& parts) const {
+    if (b < n_full) {
+      tile = b;
+      part = 0;
+      parts = 1;
+    } else {
+      const int r = b - n_full;
+      tile = n_full + r / split;
+      part = r - (tile - n_full) * split;
+      parts = split;
+    }
+  }
+};
+// max_split: the number of pieces the second phase can be cut into (>= 1); 256 CUs (MI355X)
+inline TileSplit tile_split(int64_t tiles, int max_split) {
+  TileSplit t{(int)tiles, 1};
+  if (max_split < 2 || tiles <= 0) return t;
+  const int64_t cus = 256, rem = tiles % cus;
+  if (tiles * 2 <= cus) {                 // few tiles: split them all
+    t.n_full = 0;
+    t.split = (int)(cus / tiles < max_split ? cus / tiles : max_split);
+  } else if (rem > 0 && rem * 2 <= cus) { // a short last round: split its tiles over the CUs it would leave idle
+    t.n_full = (int)(tiles - rem);
+    t.split = (int)(cus / rem < max_split ? cus / rem : max_split);
+  }
+  if (t.split < 1) t.split = 1;
+  return t;
+}
+
 // ---- wave64 helpers ---------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

@@ -39,6 +39,7 @@ struct MlpArgs {
   float* pre;          // [n, MLP_H]: written (forward) / read (reverse)
   float* Y;            // [n, ldy]
   int64_t ldy;
+  TileSplit ts;        // workgroup -> (row tile, part of its output tiles)
 };
 
 __global__ void k_mlp_pack(const float* __restrict__ W, const float* __restrict__ bias, int n_out, int k_in, int transposed,
@@ -97,7 +98,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches, scalar tile addresses
   const int i = lane & 31, kh = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * MLP_ROWS;
+  int tile_, part_, parts_;
+  a.ts.decode((int)blockIdx.x, tile_, part_, parts_);
+  const int64_t row0 = (int64_t)tile_ * MLP_ROWS;
 #ifdef XEQ_MLP_STAMPS
   unsigned long long c0_, r0_, c1_, r1_;
   MLP_STAMP(c0_, r0_);
@@ -214,9 +217,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
       for (int q = 0; q < 4; ++q) b[4 + q] = wb[q * 64 + lane];
     }
   };
-  // few row tiles (MD-sized systems): gridDim.y workgroups share a tile, each redoes stage 1 and takes every gridDim.y-th
+  // split tiles (TileSplit, xeq_common.h): `parts` workgroups share the row tile, each redoes stage 1 and takes every parts-th
   // group of four output tiles (one per wave), so one tile's latency is not one workgroup's whole serial MFMA chain
-  const int parts = __builtin_amdgcn_readfirstlane((int)gridDim.y), part = __builtin_amdgcn_readfirstlane((int)blockIdx.y);
+  const int parts = __builtin_amdgcn_readfirstlane(parts_), part = __builtin_amdgcn_readfirstlane(part_);
   int t0 = wave + 4 * part;
   if (t0 < nt2) fetch_q(B0, t0, parts == 1 && t0 + 4 < nt2, 0);
 
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
                            acc0[4 * g + 3] + acc1[4 * g + 3]);
     float4 v;
     if (!REVERSE) {
-      if (row_ok && part == 0) *reinterpret_cast<float4*>(preb + ((unsigned)i * MLP_H + (unsigned)col)) = t;
+      if (row_ok && part_ == 0) *reinterpret_cast<float4*>(preb + ((unsigned)i * MLP_H + (unsigned)col)) = t;
       v = make_float4(silu_f(t.x), silu_f(t.y), silu_f(t.z), silu_f(t.w));
     } else {
       v = make_float4(t.x * silu_grad_f(pv[g].x), t.y * silu_grad_f(pv[g].y), t.z * silu_grad_f(pv[g].z), t.w * silu_grad_f(pv[g].w));
@@ -357,16 +360,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 #endif
 }
 
-// workgroups per row tile: 1 once the tiles alone fill the chip; for few tiles, up to one per group of four output tiles
-static unsigned mlp_parts(int64_t n, int n2) {
-  const int64_t tiles = (n + MLP_ROWS - 1) / MLP_ROWS;
-  const int groups = (n2 / 32 + 3) / 4;
-  if (tiles * 2 > 256 || groups < 2) return 1;
-  int64_t p = 256 / tiles;
-  if (p > groups) p = groups;
-  return (unsigned)(p < 1 ? 1 : p);
-}
-
 static int mlp_check(const char* name, int64_t n, int k1, int n2, int64_t ldx, int64_t ldy) {
   XEQ_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) * MLP_ROWS, "%s: n = %lld out of range", name, (long long)n);
   XEQ_CHECK_ARG(k1 > 0 && k1 % 8 == 0 && n2 > 0 && n2 % 32 == 0, "%s: needs k1 %% 8 == 0 and n2 %% 32 == 0 (got %d, %d)", name, k1, n2);
@@ -413,8 +406,9 @@ int xeq_mlp2_fwd(const float* x, int64_t ldx, int64_t n, int k1, const float* w1
   if (int rc = mlp_check("xeq_mlp2_fwd", n, k1, n2, ldx, ldy)) return rc;
   XEQ_CHECK_ARG(n == 0 || (x && w1p && w2p && pre && y), "xeq_mlp2_fwd: null buffer");
   if (n == 0) return XEQ_OK;
-  MlpArgs a{x, ldx, n, k1, n2, w1p, w2p, 1, 1, pre, y, ldy};
-  hipLaunchKernelGGL(k_mlp2<false>, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS), mlp_parts(n, n2)), dim3(256), 0, (hipStream_t)stream, a);
+  const int64_t tiles = (n + MLP_ROWS - 1) / MLP_ROWS;
+  MlpArgs a{x, ldx, n, k1, n2, w1p, w2p, 1, 1, pre, y, ldy, tile_split(tiles, (n2 / 32 + 3) / 4)};
+  hipLaunchKernelGGL(k_mlp2<false>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_fwd");
   return XEQ_OK;
 }
@@ -424,8 +418,9 @@ int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2
   if (int rc = mlp_check("xeq_mlp2_bwd", n, k1, n2, ldg, ldgx)) return rc;
   XEQ_CHECK_ARG(n == 0 || (g && w2tp && w1tp && pre && gx), "xeq_mlp2_bwd: null buffer");
   if (n == 0) return XEQ_OK;
-  MlpArgs a{g, ldg, n, k1, n2, w2tp, w1tp, 0, 0, const_cast<float*>(pre), gx, ldgx};
-  hipLaunchKernelGGL(k_mlp2<true>, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS), mlp_parts(n, n2)), dim3(256), 0, (hipStream_t)stream, a);
+  const int64_t tiles = (n + MLP_ROWS - 1) / MLP_ROWS;
+  MlpArgs a{g, ldg, n, k1, n2, w2tp, w1tp, 0, 0, const_cast<float*>(pre), gx, ldgx, tile_split(tiles, (n2 / 32 + 3) / 4)};
+  hipLaunchKernelGGL(k_mlp2<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_bwd");
   return XEQ_OK;
 }

@@ -43,6 +43,7 @@ struct UvFwdArgs {
   float* stats;
   int n_jobs;
   unsigned char job_l[UV_MAXJOBS], job_t[UV_MAXJOBS];
+  TileSplit ts;         // workgroup -> (node tile, part of its jobs)
 };
 
 __device__ __forceinline__ float sum8(float v) {   // over the 8 lanes of a node
@@ -188,7 +189,9 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
   const int D = m0 + 3 * m1 + 5 * m2, C = m0 + m1 + m2, XLD = D + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t row0 = (int64_t)blockIdx.x * UV_ROWS;
+  int tile_, part_, parts_;
+  a.ts.decode((int)blockIdx.x, tile_, part_, parts_);
+  const int64_t row0 = (int64_t)tile_ * UV_ROWS;
   const int rows_here = (int)min((int64_t)UV_ROWS, a.n - row0);
   // norm parameters into LDS first ([ln_w F | ln_b F | eq_w C | eq_b m0], behind the tile): phase A then has ONE round
   // trip to global memory in its dependency chain (the rows), not three
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
           o = make_float4((o.x - mean) * rstd * w.x + b.x, (o.y - mean) * rstd * w.y + b.y, (o.z - mean) * rstd * w.z + b.z,
                           (o.w - mean) * rstd * w.w + b.w);
         }
-        if (blockIdx.y == 0) *reinterpret_cast<float4*>(a.cat + gn * a.ld_cat + f0) = o;
+        if (part_ == 0) *reinterpret_cast<float4*>(a.cat + gn * a.ld_cat + f0) = o;
       }
     }
     // xhat -> LDS, e3nn (channel-major, m-minor) re-laid as [l][m][channel]; rows past n are written as zeros
@@ -303,7 +306,7 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
         }
       }
     }
-    if (ok && sub == 0 && blockIdx.y == 0) *reinterpret_cast<float4*>(a.stats + 4 * gn) = make_float4(mean, rstd, mean0, r);
+    if (ok && sub == 0 && part_ == 0) *reinterpret_cast<float4*>(a.stats + 4 * gn) = make_float4(mean, rstd, mean0, r);
   }
   UV_LDS_BARRIER();
 
@@ -311,8 +314,8 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
 #ifdef XEQ_UV_NO_B   // development: norms only
   if (a.n >= 0) return;
 #endif
-  // few node tiles (MD-sized systems): gridDim.y workgroups share a tile, each repeats phase A and takes every gridDim.y-th job
-  const int parts = __builtin_amdgcn_readfirstlane((int)gridDim.y), part = __builtin_amdgcn_readfirstlane((int)blockIdx.y);
+  // split tiles (TileSplit, xeq_common.h): `parts` workgroups share the node tile, each repeats phase A and takes every parts-th job
+  const int parts = __builtin_amdgcn_readfirstlane(parts_), part = __builtin_amdgcn_readfirstlane(part_);
   for (int jj = part + parts * wave; jj < a.n_jobs; jj += 4 * parts) {
     const int l = a.job_l[jj], t = a.job_t[jj];
     const int mul = l == 0 ? m0 : (l == 1 ? m1 : m2);
@@ -338,6 +341,7 @@ struct UvBwdArgs {
   const float* wt[3];   // packed [W_U | W_V]^T / sqrt(mul_l): xeq_mlp_pack(n_out = mul_l, k_in = 2 mul_l, transposed = 0)
   float eps;
   float *g_s, *g_x;
+  TileSplit ts;         // workgroup -> (node tile, part of each block's jobs); split form only
   float* g_xhat;        // split form (FUSE = 0): dL/dxhat in BT layout, the norms' reverse is left to xeq_norm_bwd
 };
 
@@ -399,10 +403,9 @@ __device__ __forceinline__ void uvb_form(const UvBwdArgs& a, float* bf, int BLD,
 // phase 2 of block l: g_xhat[node][l][m][k] = sum_c bf[node][m][c] WT[k][c], c over the 2 mul columns; jobs (m, tile of 32 k)
 template <int GQ, bool TO_LDS>   // quarters of 4 k-groups: 2 mul / 32
 __device__ __forceinline__ void uvb_contract(const UvBwdArgs& a, const float* bf, int BLD, float* gt, int XLD, int l, int mul,
-                                             int base, int wave, int lane, int64_t row0, int rows_here) {
+                                             int base, int wave, int lane, int64_t row0, int rows_here, int part, int parts) {
   const int i = lane & 31, kh = lane >> 5;
   const int T = mul >> 5, d = 2 * l + 1, G = 4 * GQ;
-  const int parts = __builtin_amdgcn_readfirstlane((int)gridDim.y), part = __builtin_amdgcn_readfirstlane((int)blockIdx.y);
   for (int job = part + parts * wave; job < d * T; job += 4 * parts) {
     const int m = job / T, t = job - m * T;
     const float4* wT = reinterpret_cast<const float4*>(a.wt[l]) + (int64_t)t * (G + 1) * 64;
@@ -465,7 +468,10 @@ __global__ void __launch_bounds__(256) k_update_uv_bwd(UvBwdArgs a) {
   float* eqw = lnw + F;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t row0 = (int64_t)blockIdx.x * UV_ROWS;
+  int tile_, part_, parts_;
+  a.ts.decode((int)blockIdx.x, tile_, part_, parts_);
+  const int part = __builtin_amdgcn_readfirstlane(part_), parts = __builtin_amdgcn_readfirstlane(parts_);
+  const int64_t row0 = (int64_t)tile_ * UV_ROWS;
   const int rows_here = (int)min((int64_t)UV_ROWS, a.n - row0);
   if (FUSE && do_norm) {
     for (int f = tid; f < F; f += 256) lnw[f] = a.lnw[f];
@@ -475,25 +481,25 @@ __global__ void __launch_bounds__(256) k_update_uv_bwd(UvBwdArgs a) {
   if (m0 > 0) {
     uvb_form<1>(a, bf, BLD, m0, 0, 0, F, D, row0, rows_here, tid);
     UV_LDS_BARRIER();
-    if (m0 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here);
-    else if (m0 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here);
-    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here);
+    if (m0 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here, part, parts);
+    else if (m0 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here, part, parts);
+    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 0, m0, 0, wave, lane, row0, rows_here, part, parts);
     UV_LDS_BARRIER();
   }
   if (m1 > 0) {
     uvb_form<3>(a, bf, BLD, m1, m0, m0, F, D, row0, rows_here, tid);
     UV_LDS_BARRIER();
-    if (m1 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here);
-    else if (m1 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here);
-    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here);
+    if (m1 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here, part, parts);
+    else if (m1 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here, part, parts);
+    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 1, m1, m0, wave, lane, row0, rows_here, part, parts);
     UV_LDS_BARRIER();
   }
   if (m2 > 0) {
     uvb_form<5>(a, bf, BLD, m2, m0 + 3 * m1, m0 + m1, F, D, row0, rows_here, tid);
     UV_LDS_BARRIER();
-    if (m2 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here);
-    else if (m2 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here);
-    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here);
+    if (m2 == 128) uvb_contract<8, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here, part, parts);
+    else if (m2 == 64) uvb_contract<4, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here, part, parts);
+    else uvb_contract<2, FUSE>(a, bf, BLD, gt, XLD, 2, m2, m0 + 3 * m1, wave, lane, row0, rows_here, part, parts);
     UV_LDS_BARRIER();
   }
   if (!FUSE) return;
@@ -612,15 +618,6 @@ __global__ void __launch_bounds__(256) k_update_uv_bwd(UvBwdArgs a) {
   }
 }
 
-// workgroups per node tile: 1 once the tiles alone fill the chip; for few tiles, up to one per job
-static unsigned uv_parts(int64_t n, int jobs) {
-  const int64_t tiles = (n + UV_ROWS - 1) / UV_ROWS;
-  if (tiles * 2 > 256 || jobs < 2) return 1;
-  int64_t p = 256 / tiles;
-  if (p > jobs) p = jobs;
-  return (unsigned)(p < 1 ? 1 : p);
-}
-
 static bool uv_shape_ok(int node_dim, const Irreps& ir) {
   for (int l = 0; l < 3; ++l)
     if (!(ir.mul[l] == 0 || ir.mul[l] == 32 || ir.mul[l] == 64 || ir.mul[l] == 128)) return false;
@@ -673,7 +670,9 @@ int xeq_update_uv_fwd(const float* s, const float* x, const float* ln_w, const f
       ++a.n_jobs;
     }
   const size_t lds = ((size_t)UV_ROWS * (ir.D() + 4) + 2 * node_dim + ir.C() + mul[0]) * sizeof(float);
-  const dim3 grid((unsigned)((n + UV_ROWS - 1) / UV_ROWS), uv_parts(n, a.n_jobs));
+  const int64_t tiles = (n + UV_ROWS - 1) / UV_ROWS;
+  a.ts = tile_split(tiles, a.n_jobs);
+  const dim3 grid(a.ts.grid(tiles));
   if (mul[0] == 128 && mul[1] == 64 && mul[2] == 32 && node_dim == 128 && do_norm)   // the default model (nn/model.py: 128x0e + 64x1o + 32x2e)
     hipLaunchKernelGGL((k_update_uv_fwd<128, 64, 32, 128, 1>), grid, dim3(256), lds, (hipStream_t)stream, a);
   else
@@ -711,7 +710,9 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
   int min_jobs = 1 << 30;   // jobs of the smallest block: (2l+1) mul_l / 32
   for (int l = 0; l < 3; ++l)
     if (mul[l] > 0 && (2 * l + 1) * mul[l] / 32 < min_jobs) min_jobs = (2 * l + 1) * mul[l] / 32;
-  const dim3 grid((unsigned)((n + UV_ROWS - 1) / UV_ROWS), fuse ? 1u : uv_parts(n, min_jobs));
+  const int64_t tiles = (n + UV_ROWS - 1) / UV_ROWS;
+  b.ts = tile_split(tiles, fuse ? 1 : min_jobs);
+  const dim3 grid(b.ts.grid(tiles));
   static bool attr_set = false;   // more than 64 KB of dynamic LDS (fused form): opt in once per instantiation
   if (!attr_set) {
     const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_uv_bwd<128, 64, 32, 128, 1, true>),
