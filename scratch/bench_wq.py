@@ -67,3 +67,30 @@ if os.environ.get("XEQ_WQ_STAMPS"):
         tot = sum(vals)
         print(f"{title} ({cnt}): cycles by phase, one launch; {tot / max(cnt, 1):.0f} cycles per wave")
         for n, v in zip(names, vals): print(f"  {n:28s} {v / max(tot, 1) * 100:5.1f} %   {v / max(cnt, 1):9.0f} per wave")
+
+if os.environ.get("XEQ_WQ_ROLE_TIME"):   # workgroup timeline of the reverse kernel (a -DXEQ_WQ_ROLE_TIME build)
+    import collections, ctypes
+    from xequinet_amd import lib as _lib
+    L = _lib.load()
+    wg = (ctypes.c_ulonglong * (8192 * 4))()
+    L.xeq_wq_debug_wg(wg)
+    run("wq"); torch.cuda.synchronize()
+    L.xeq_wq_debug_wg(wg)
+    recs = [(wg[4*b] & 0xffffffff, wg[4*b] >> 32, wg[4*b+1] & 0xf, wg[4*b+2], wg[4*b+3]) for b in range(8192) if wg[4*b+3]]
+    t0 = min(r[3] for r in recs); t1 = max(r[4] for r in recs)
+    percu = collections.defaultdict(list)
+    for hw, l, xcc, a_, b_ in recs:
+        percu[(xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)].append(((a_ - t0) / 100, (b_ - t0) / 100, int(l)))
+    busy = sum(b_ - a_ for v in percu.values() for a_, b_, _ in v)
+    print(f"reverse kernel (last launch): {len(recs)} workgroups on {len(percu)} CUs, span {(t1 - t0) / 100:.1f} us, workgroup-time / (span x 2 slots x CUs) = {busy / ((t1 - t0) / 100 * 2 * len(percu)):.2f}")
+    ends = sorted(max(b_ for _, b_, _ in v) for v in percu.values())
+    print(f"   CU finish times (us): min {ends[0]:.0f}, 10 % {ends[len(ends)//10]:.0f}, median {ends[len(ends)//2]:.0f}, 90 % {ends[9*len(ends)//10]:.0f}, max {ends[-1]:.0f}; workgroups per CU: {sorted(collections.Counter(len(v) for v in percu.values()).items())}")
+    dur = collections.defaultdict(list)
+    for v in percu.values():
+        for a_, b_, l in v: dur[l].append(b_ - a_)
+    print("   workgroup durations (us) by l:", {l: (round(min(d)), round(sorted(d)[len(d)//2]), round(max(d))) for l, d in sorted(dur.items())})
+    byx = collections.defaultdict(list)
+    for cu, v in percu.items(): byx[cu[0]].append(max(b_ for _, b_, _ in v))
+    print("   latest finish per XCD:", {x: round(max(v)) for x, v in sorted(byx.items())})
+    for cu, v in list(sorted(percu.items(), key=lambda kv: -max(b_ for _, b_, _ in kv[1])))[:2]:
+        print("   latest CU", cu, [(round(a_), round(b_), l) for a_, b_, l in sorted(v)])

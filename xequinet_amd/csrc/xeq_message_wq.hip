@@ -174,7 +174,10 @@ struct WqArgs {
   const int32_t* pgath;    // [P] gathered node per padded slot
   const uint32_t* qinfo;   // [Q] owner | WQ_FIRST | WQ_LAST per quad
   const int32_t* win;      // [2 n_steps] window (first node, rows) of every step
-  int n_steps, steps_per_wg;
+  int n_steps, steps_per_wg;   // steps_per_wg: steps of a LONG chunk
+  int regions, region_steps;   // the steps are cut in `regions` contiguous regions (one per XCD when the grid is XCD-mapped)
+  int lvl_chunks[3], lvl_spw[3], lvl_start[3];   // per region: three runs of chunks, long to short (chunks, steps per chunk, first
+                                                 // step): the grid ends on short workgroups (a region's last chunks start last)
   int F, C, D, H, B;
   Irreps ir;
   int xl;                  // layout of xhat / grad_xhat
@@ -208,11 +211,30 @@ __device__ __forceinline__ WqUnit wq_unit(const WqArgs& a, int u) {
 // waves share the unit (its rbf_lin rows, staged once in LDS) and, step by step, the window of gathered node rows.
 // Consecutive work items are the units of one chunk (they share its records and index arrays) and are dealt to
 // workgroups so that they run on one XCD (blocks b and b + 8 share one under round-robin dispatch: speed only).
-__device__ __forceinline__ void wq_decode(const WqArgs& a, int nunits, int& chunk, int& unit) {
-  const int nb = gridDim.x, b = blockIdx.x;
-  const int item = (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-  chunk = item / nunits;   // padding blocks of the grid land beyond the last chunk: no steps
-  unit = item - chunk * nunits;
+__device__ __forceinline__ void wq_decode(const WqArgs& a, int nunits, int& s0, int& s1, int& unit) {
+  const int b = blockIdx.x;
+  int region, j;   // region and item index inside it
+  if (a.regions == 8) {
+    region = b & 7;
+    j = b >> 3;
+  } else {
+    region = 0;
+    j = b;
+  }
+  const int c = j / nunits;   // chunk inside the region
+  unit = nunits - 1 - (j - c * nunits);   // a chunk's l = 2 unit first, its l = 0 units last
+  const int base = region * a.region_steps, rend = min(base + a.region_steps, a.n_steps);
+  s0 = s1 = 0;   // padding block of the grid: no steps
+  int cc = c;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    if (cc >= 0 && cc < a.lvl_chunks[v]) {
+      const int lend = v < 2 ? base + a.lvl_start[v + 1] : rend;
+      s0 = base + a.lvl_start[v] + cc * a.lvl_spw[v];
+      s1 = min(s0 + a.lvl_spw[v], min(lend, rend));
+    }
+    cc -= a.lvl_chunks[v];
+  }
 }
 
 // The window of a step in LDS: rows [w0, w0 + rows) of the gathered node arrays, restricted to the unit's columns, as
@@ -405,6 +427,7 @@ __device__ __forceinline__ void wq_for_isolated(const WqArgs& a, int range, int 
 
 // development (-DXEQ_WQ_STAMPS): cycles of the l = 0 waves per phase of the forward kernel, summed over a launch
 __device__ unsigned long long g_wq_stamps[32];
+__device__ unsigned long long g_wq_wg[8192 * 4];   // -DXEQ_WQ_ROLE_TIME: per workgroup of the reverse kernel (hw id | l << 32, xcc id, start, end in 100 MHz ticks)
 #ifdef XEQ_WQ_STAMPS
 #define WQ_STAMP(i)                                                                                          \
   do {                                                                                                       \
@@ -634,18 +657,17 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
 
 // one role of the forward kernel: the workgroup's steps, each with its window staged first when it fits
 template <int NM, int KS>
-__device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int chunk, const WqUnit un, const float* __restrict__ rec,
+__device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_end, const WqUnit un, const float* __restrict__ rec,
                                             const float* __restrict__ h, const float* __restrict__ xhat,
                                             const float* __restrict__ s_in, const float* __restrict__ x_in, const float* wl,
                                             float* __restrict__ s_out, float* __restrict__ x_out, int* tbl, float* win) {
   constexpr int NH = NM == 1 ? 3 : 2, ROWB = (NH + NM) * 128;
   const WqCols wc = wq_cols<NM>(a, un, threadIdx.x & 31);
-  const int s_end = min((chunk + 1) * a.steps_per_wg, a.n_steps);
   unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
 #ifdef XEQ_WQ_STAMPS
   last_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (int step = chunk * a.steps_per_wg; step < s_end; ++step) {
+  for (int step = s_beg; step < s_end; ++step) {
     const int w0 = a.win[2 * step], nrows = a.win[2 * step + 1];
 #ifdef XEQ_WQ_NO_WINDOW
     const bool use_win = false;
@@ -682,20 +704,20 @@ k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
   __shared__ __attribute__((aligned(16))) float win[WQ_WIN_FLOATS];
   __shared__ __attribute__((aligned(16))) int tbl_all[WQ_WAVES][2 * T_SIZE];
   __shared__ float wl[3 * KS * 64];
-  int chunk, unit;
-  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], chunk, unit);
-  if (chunk * a.steps_per_wg >= a.n_steps) return;   // padding block of the grid (workgroup-uniform)
+  int s_beg, s_end, unit;
+  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], s_beg, s_end, unit);
+  if (s_beg >= s_end) return;   // padding block of the grid / empty chunk of a short region (workgroup-uniform)
   const WqUnit un = wq_unit(a, unit);
   wq_stage_weights<KS>(a, un, w_rbf, b_rbf, wl);
   __syncthreads();
   int* tbl = tbl_all[threadIdx.x >> 6];
 #ifdef XEQ_WQ_ONLY_L   // development: register budget of one role
-  if (un.l == XEQ_WQ_ONLY_L) wq_fwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, chunk, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  if (un.l == XEQ_WQ_ONLY_L) wq_fwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
   return;
 #endif
-  if (un.l == 0) wq_fwd_role<1, KS>(a, chunk, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
-  else if (un.l == 1) wq_fwd_role<3, KS>(a, chunk, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
-  else wq_fwd_role<5, KS>(a, chunk, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  if (un.l == 0) wq_fwd_role<1, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  else if (un.l == 1) wq_fwd_role<3, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  else wq_fwd_role<5, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
 }
 
 // ------------------------------------------------------------------------------------------------ reverse
@@ -1023,19 +1045,18 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 }
 
 template <int NM, int KS>
-__device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int chunk, int unit, const WqUnit un, const float* __restrict__ rec,
+__device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int s_beg, int s_end, int unit, const WqUnit un, const float* __restrict__ rec,
                                             const float* __restrict__ drec, const float* __restrict__ h,
                                             const float* __restrict__ xhat, const float* __restrict__ grad_s,
                                             const float* __restrict__ grad_x, const float* wl, float* __restrict__ grad_h,
                                             float* __restrict__ grad_xhat, const WqParts parts, int* tbl, float* win) {
   constexpr int ROWB = (NM + (NM == 1 ? 1 : 0)) * 128;
   const WqCols wc = wq_cols<NM>(a, un, threadIdx.x & 31);
-  const int s_end = min((chunk + 1) * a.steps_per_wg, a.n_steps);
   unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
 #ifdef XEQ_WQ_STAMPS
   last_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (int step = chunk * a.steps_per_wg; step < s_end; ++step) {
+  for (int step = s_beg; step < s_end; ++step) {
     const int w0 = a.win[2 * step], nrows = a.win[2 * step + 1];
 #ifdef XEQ_WQ_NO_WINDOW
     const bool use_win = false;
@@ -1076,21 +1097,37 @@ k_message_bwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
   __shared__ __attribute__((aligned(16))) float win[WQ_WIN_FLOATS];
   __shared__ __attribute__((aligned(16))) int tbl_all[WQ_WAVES][2 * T_SIZE];
   __shared__ float wl[3 * KS * 64];
-  int chunk, unit;
-  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], chunk, unit);
-  if (chunk * a.steps_per_wg >= a.n_steps) return;   // padding block of the grid (workgroup-uniform)
+  int s_beg, s_end, unit;
+  wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], s_beg, s_end, unit);
+  if (s_beg >= s_end) return;   // padding block of the grid / empty chunk of a short region (workgroup-uniform)
   const WqUnit un = wq_unit(a, unit);
   wq_stage_weights<KS>(a, un, w_rbf, b_rbf, wl);
   __syncthreads();
   int* tbl = tbl_all[threadIdx.x >> 6];
 #ifdef XEQ_WQ_ONLY_L   // development: register budget of one role
   if (un.l == XEQ_WQ_ONLY_L)
-    wq_bwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, chunk, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+    wq_bwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
   return;
 #endif
-  if (un.l == 0) wq_bwd_role<1, KS>(a, chunk, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
-  else if (un.l == 1) wq_bwd_role<3, KS>(a, chunk, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
-  else wq_bwd_role<5, KS>(a, chunk, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+#ifdef XEQ_WQ_ROLE_TIME   // development: where and when every workgroup of the production body ran
+  unsigned long long rr0_;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr0_)::"memory");
+#endif
+  if (un.l == 0) wq_bwd_role<1, KS>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+  else if (un.l == 1) wq_bwd_role<3, KS>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+  else wq_bwd_role<5, KS>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+#ifdef XEQ_WQ_ROLE_TIME
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned long long rr1_;
+    unsigned hw, xcc;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(rr1_), "=s"(hw), "=s"(xcc)::"memory");
+    g_wq_wg[4 * blockIdx.x + 0] = hw | ((unsigned long long)un.l << 32);
+    g_wq_wg[4 * blockIdx.x + 1] = xcc;
+    g_wq_wg[4 * blockIdx.x + 2] = rr0_;
+    g_wq_wg[4 * blockIdx.x + 3] = rr1_;
+  }
+#endif
 }
 
 // dL/dvec from the per-unit partials (by padded slot of the reverse walk), summed in unit order (deterministic),
@@ -1156,7 +1193,11 @@ static int wq_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ran
   return XEQ_OK;
 }
 
-// steps (WQ_WAVES ranges each) a workgroup walks: enough workgroups for ~6 per CU and unit mix, never fewer than one step
+// Steps (WQ_WAVES ranges each) a workgroup walks.  Long chunks sized for ~6 workgroups per CU and unit mix over the first 70 % of a
+// region's steps, then chunks a third as long: a launch is 5-6 workgroups per CU, each 100-190 us long (the l = 2 unit of a chunk
+// runs 1.8x its l = 0 units), and with equal chunks the CUs finished between 300 and 457 us of a 457 us launch (QM9-1024 reverse
+// pass, workgroup timeline); the short chunks fill that ragged end.  Regions keep the XCD mapping: block b runs on XCD b % 8 under
+// round-robin dispatch (speed only), so region b % 8 is one XCD's contiguous share of the walk and ITS last chunks are the short ones.
 static void wq_geometry(WqArgs& a, int nunits, unsigned& grid) {
   a.n_steps = (a.n_ranges + WQ_WAVES - 1) / WQ_WAVES;
   const int64_t want_chunks = (256 * 6 + nunits - 1) / nunits;
@@ -1164,9 +1205,31 @@ static void wq_geometry(WqArgs& a, int nunits, unsigned& grid) {
   if (a.steps_per_wg < 1) a.steps_per_wg = 1;
   const char* env = getenv("XEQ_WQ_STEPS_PER_WG");   // development
   if (env && atoi(env) > 0) a.steps_per_wg = atoi(env);
-  int64_t blocks = (int64_t)((a.n_steps + a.steps_per_wg - 1) / a.steps_per_wg) * nunits;
-  if (blocks >= 64) blocks = (blocks + 7) / 8 * 8;   // multiple of 8: XCD-aware item order (wq_decode)
-  grid = (unsigned)blocks;
+  double frac = 0.8, frac2 = 0.2;
+  int div = 3;
+  const char* ef = getenv("XEQ_WQ_TAPER_FRAC");       // development
+  const char* ef2 = getenv("XEQ_WQ_TAPER_FRAC2");
+  const char* ed = getenv("XEQ_WQ_TAPER_DIV");
+  if (ef) frac = atof(ef);
+  if (ef2) frac2 = atof(ef2);
+  if (ed && atoi(ed) > 0) div = atoi(ed);
+  const int64_t plain_blocks = (int64_t)((a.n_steps + a.steps_per_wg - 1) / a.steps_per_wg) * nunits;
+  a.regions = plain_blocks >= 64 ? 8 : 1;
+  a.region_steps = (a.n_steps + a.regions - 1) / a.regions;
+  const int spw[3] = {a.steps_per_wg, a.steps_per_wg / div < 1 ? 1 : a.steps_per_wg / div, 1};
+  const double share[3] = {frac, frac2, 1.0};
+  int start = 0;
+  for (int v = 0; v < 3; ++v) {
+    a.lvl_spw[v] = spw[v];
+    a.lvl_start[v] = start;
+    int chunks = v < 2 ? (int)(share[v] * a.region_steps / spw[v]) : (a.region_steps - start + spw[v] - 1) / spw[v];
+    if (start + (int64_t)chunks * spw[v] > a.region_steps) chunks = (a.region_steps - start + spw[v] - 1) / spw[v];
+    if (chunks < 0) chunks = 0;
+    a.lvl_chunks[v] = chunks;
+    start += chunks * spw[v];
+    if (start > a.region_steps) start = a.region_steps;
+  }
+  grid = (unsigned)((int64_t)a.regions * (a.lvl_chunks[0] + a.lvl_chunks[1] + a.lvl_chunks[2]) * nunits);
 }
 
 }  // namespace xeq
@@ -1314,6 +1377,13 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
 }
 
 /* development: read and clear the phase cycle counters of a -DXEQ_WQ_STAMPS build */
+int xeq_wq_debug_wg(unsigned long long* out) {   // development (-DXEQ_WQ_ROLE_TIME): 8192 x 4, read and clear
+  static unsigned long long zero[8192 * 4];
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wq_wg), sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wq_wg), zero, sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
+  return XEQ_OK;
+}
+
 int xeq_wq_debug_stamps(unsigned long long out[32]) {
   unsigned long long zero[32] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wq_stamps), sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
