@@ -427,7 +427,7 @@ __device__ __forceinline__ void wq_for_isolated(const WqArgs& a, int range, int 
 
 // development (-DXEQ_WQ_STAMPS): cycles of the l = 0 waves per phase of the forward kernel, summed over a launch
 __device__ unsigned long long g_wq_stamps[32];
-__device__ unsigned long long g_wq_wg[8192 * 4];   // -DXEQ_WQ_ROLE_TIME: per workgroup of the reverse kernel (hw id | l << 32, xcc id, start, end in 100 MHz ticks)
+__device__ unsigned long long g_wq_wg[8192 * 4];   // -DXEQ_WQ_ROLE_TIME / _FWD: per workgroup of the reverse / forward kernel (hw id | l << 32, xcc id, start, end in 100 MHz ticks)
 #ifdef XEQ_WQ_STAMPS
 #define WQ_STAMP(i)                                                                                          \
   do {                                                                                                       \
@@ -715,9 +715,25 @@ k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
   if (un.l == XEQ_WQ_ONLY_L) wq_fwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
   return;
 #endif
+#ifdef XEQ_WQ_ROLE_TIME_FWD   // development: where and when every workgroup of the production body ran
+  unsigned long long rr0_;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr0_)::"memory");
+#endif
   if (un.l == 0) wq_fwd_role<1, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
   else if (un.l == 1) wq_fwd_role<3, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
   else wq_fwd_role<5, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+#ifdef XEQ_WQ_ROLE_TIME_FWD
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned long long rr1_;
+    unsigned hw, xcc;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(rr1_), "=s"(hw), "=s"(xcc)::"memory");
+    g_wq_wg[4 * blockIdx.x + 0] = hw | ((unsigned long long)un.l << 32);
+    g_wq_wg[4 * blockIdx.x + 1] = xcc;
+    g_wq_wg[4 * blockIdx.x + 2] = rr0_;
+    g_wq_wg[4 * blockIdx.x + 3] = rr1_;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ reverse
