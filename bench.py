@@ -143,10 +143,11 @@ def main():
     from xequinet_amd.data import NeighborTransform, XequiBatch
     from xequinet_amd.nn import resolve_model
 
-    rank, local_rank, world = xdist.init_from_env()
+    # rehearsal of the multi-rank path on a one-GPU box: XEQ_BENCH_BACKEND=gloo XEQ_BENCH_DEVICE=0 (every rank on that device)
+    rank, local_rank, world = xdist.init_from_env(os.environ.get("XEQ_BENCH_BACKEND"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", int(os.environ.get("XEQ_BENCH_DEVICE", local_rank)))
     torch.cuda.set_device(dev)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
 
