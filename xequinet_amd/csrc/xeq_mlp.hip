@@ -3,15 +3,16 @@
 //   reverse   GX = ((G W2) * silu'(pre)) W1              (input gradients only: force evaluation, nn/basic.py:143-159)
 // Both are T = E(X B1 + c1), Y = T B2 + c2 with a 128-wide hidden T that never leaves the chip.
 //
-// Work split: a workgroup (4 waves) owns 32 consecutive rows (nodes).  Exact-f32 v_mfma_f32_32x32x2_f32 tiles
-// D[column][row] (the weight fragment is the A operand, so a lane holds four consecutive columns of one row per register
-// quad and every store is 16 bytes wide); wave w computes hidden columns [32 w, 32 w + 32) in stage 1 and the output tiles w, w + 4, ... in
-// stage 2.  A operands (rows) come from LDS: the X tile is staged in 64-column chunks (double buffered), the hidden
-// tile is written once by its producers.  B operands (weights) are private to a wave, so they go global -> register
-// directly from a PACKED copy in fragment order, packed[tile][k-group][lane][4]
-//   = W[32 tile + (lane & 31)][8 group + 4 (lane >> 5) + j],
-// one coalesced 16-byte load per lane for four MFMA steps (the k order inside a group of 8 is a permutation, applied to
-// both operands).  Results do not depend on the number of rows: every row sees the same summation order.
+// Work split: a workgroup (4 waves) owns 32 consecutive rows (nodes); few tiles, or the tiles of a short last round, are shared
+// by several workgroups (TileSplit, xeq_common.h).  Exact-f32 v_mfma_f32_32x32x2_f32 tiles D[column][row]: the WEIGHT fragment is
+// the A operand, so a lane holds four consecutive columns of one row per register quad and every store / LDS write is 16 bytes
+// wide.  Wave w computes hidden columns [32 w, 32 w + 32) in stage 1 and the output tiles w, w + 4, ... in stage 2.  The row
+// operands (shared by the waves) come from LDS: the X tile is staged in 64-column chunks (double buffered), the hidden tile is
+// written once by its producers.  The weight operands are private to a wave, so they go global -> register directly from a PACKED
+// copy in fragment order, packed[tile][k-group][lane][4] = W[32 tile + (lane & 31)][8 group + 4 (lane >> 5) + j], one coalesced
+// 16-byte load per lane for four MFMA steps (the k order inside a group of 8 is a permutation, applied to both operands); the
+// bias is one more k-group, multiplied by a row of ones.  Results do not depend on the number of rows: every row sees the same
+// summation order in every form.
 #include <type_traits>
 
 #include "xeq_common.h"
@@ -91,10 +92,6 @@ template <bool REVERSE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) k_mlp2(MlpArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[2][MLP_ROWS * MLP_XLD];
   __shared__ __attribute__((aligned(16))) float Ts[MLP_ROWS * MLP_TLD];
-#ifdef XEQ_MLP_PAD   // development: extra LDS per workgroup, to cap the workgroups a CU takes
-  __shared__ float pad_[XEQ_MLP_PAD];
-  if (a.n < 0) pad_[threadIdx.x] = 0.f, a.Y[0] = pad_[threadIdx.x ^ 1];
-#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches, scalar tile addresses
   const int i = lane & 31, kh = lane >> 5;
@@ -205,9 +202,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   constexpr int G2 = MLP_H / 8;  // 16 k-groups
   const float4* w2 = reinterpret_cast<const float4*>(a.W2p);
   auto fetch_q = [&](float4 (&b)[8], int t0, bool two, int qq) {
-#ifdef XEQ_MLP_ABLATE_W   // development: no weight traffic in stage 2 (results are wrong)
-    if (a.n >= 0) return;
-#endif
     const float4* wa = w2 + ((int64_t)t0 * (G2 + 1) + 4 * qq) * 64;
 #pragma unroll
     for (int q = 0; q < 4; ++q) b[q] = wa[q * 64 + lane];
@@ -263,11 +257,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     auto quarter = [&](const float4 (&b)[8], int qq) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-#ifdef XEQ_MLP_ABLATE_LDS   // development: no LDS reads in stage 2 (results are wrong)
-        const float4 tv = make_float4(1.f, 2.f, 3.f, (float)q);
-#else
         const float4 tv = *reinterpret_cast<const float4*>(ts + 8 * (4 * qq + q));
-#endif
         if (TWO) {
           ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, tv.x, ya, 0, 0, 0);
           yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[4 + q].x, tv.x, yb, 0, 0, 0);
@@ -310,11 +300,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 #ifdef XEQ_MLP_STAMPS
     MLP_STAMP(cx_, rx_); st2c_ += cx_ - cy_;
 #endif
-#ifdef XEQ_MLP_ABLATE_ST   // development: only one of the 16-byte stores per tile (results are wrong)
-    if (row_ok && ya[0] == 12345.f) {
-#else
     if (row_ok) {
-#endif
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const unsigned o = (unsigned)i * ldy32 + (unsigned)(32 * tt + 8 * g + 4 * kh);

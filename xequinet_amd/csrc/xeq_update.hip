@@ -146,11 +146,7 @@ __device__ __forceinline__ void uv_job(const UvFwdArgs& a, const float* xh, int 
       U = __builtin_amdgcn_mfma_f32_32x32x2f32(bu, one_k0, U, 0, 0, 0);
       V = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, one_k0, V, 0, 0, 0);
     }
-#ifdef XEQ_UV_NO_ST   // development: no U|V stores
-    if (row_ok && U[0] == 12345.f) {
-#else
     if (row_ok) {
-#endif
       const unsigned o = (unsigned)(i * d + m) * (unsigned)(2 * mul) + (unsigned)(32 * t + 4 * kh);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -311,9 +307,6 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
   UV_LDS_BARRIER();
 
   // ---- phase B: the o3.Linear pair on the matrix cores, v and p from the accumulators
-#ifdef XEQ_UV_NO_B   // development: norms only
-  if (a.n >= 0) return;
-#endif
   // split tiles (TileSplit, xeq_common.h): `parts` workgroups share the node tile, each repeats phase A and takes every parts-th job
   const int parts = __builtin_amdgcn_readfirstlane(parts_), part = __builtin_amdgcn_readfirstlane(part_);
   for (int jj = part + parts * wave; jj < a.n_jobs; jj += 4 * parts) {
