@@ -411,6 +411,9 @@ int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, cons
  * xeq_mlp2_supported: 1 when the kernels take (dtype, k1, hidden, n2): f32, hidden 128, k1 % 32 == 0 (it is the
  * reverse pass's output width), n2 % 32 == 0. */
 int xeq_mlp2_supported(int dtype, int k1, int hidden, int n2);
+/* Work split of the node kernels (host logic): out = {tiles with one workgroup each, workgroups per remaining tile, grid size}
+ * for `tiles` 32-node tiles whose second phase can be cut in at most `max_split` pieces. */
+int xeq_node_tile_split(int64_t tiles, int max_split, int64_t out[3]);
 int64_t xeq_mlp_packed_floats(int n_out, int k_in);
 int xeq_mlp_pack(const float* w, const float* bias, int n_out, int k_in, int transposed, float* packed, void* stream);
 /* y[n, n2] (row stride ldy, % 4 == 0) = silu(x[n, k1] (row stride ldx, % 4 == 0) W1^T + b1) W2^T + b2;

@@ -268,3 +268,33 @@ def test_models_and_irreps_survive_deepcopy_and_pickle():
     model = resolve_model("xpainn")
     twin = copy.deepcopy(model)
     assert [k for k in twin.state_dict()] == [k for k in model.state_dict()]
+
+
+def test_node_tile_split_covers_every_tile_once():
+    """TileSplit (csrc/xeq_common.h): whole tiles one workgroup each in multiples of the CU count, a short remainder - or everything
+    at MD sizes - shared by `split` workgroups; every (tile, part) pair appears exactly once in the grid."""
+    import ctypes
+
+    from xequinet_amd import lib
+
+    L = lib.load()
+    out = (ctypes.c_int64 * 3)()
+    for tiles in (0, 1, 7, 100, 128, 129, 255, 256, 257, 320, 384, 385, 511, 576, 1000, 4608):
+        for max_split in (1, 2, 5, 7):
+            assert L.xeq_node_tile_split(tiles, max_split, out) == 0
+            n_full, split, grid = out[0], out[1], out[2]
+            assert 0 <= n_full <= tiles and 1 <= split <= max(1, max_split)
+            assert grid == n_full + (tiles - n_full) * split
+            seen = set()
+            for b in range(grid):                       # the device-side decode, restated
+                if b < n_full:
+                    seen.add((b, 0))
+                else:
+                    r = b - n_full
+                    seen.add((n_full + r // split, r % split))
+            want = {(t, 0) for t in range(n_full)} | {(t, p) for t in range(n_full, tiles) for p in range(split)}
+            assert seen == want
+            if split > 1:                               # split tiles never outnumber the CUs they are spread over
+                assert (tiles - n_full) * split <= 256
+    assert L.xeq_node_tile_split(576, 5, out) == 0 and (out[0], out[1]) == (512, 4)     # QM9-1024: 64 tiles of the third round x 4
+    assert L.xeq_node_tile_split(1, 5, out) == 0 and (out[0], out[1]) == (0, 5)         # aspirin: one tile, five workgroups

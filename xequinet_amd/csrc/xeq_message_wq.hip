@@ -242,7 +242,10 @@ __device__ __forceinline__ void wq_decode(const WqArgs& a, int nunits, int& s0, 
 // reads: a 64-lane dword load from global memory occupies the CU's texture addresser as long as a 16-byte one
 // (16 cycles), so the per-row gathers -- 92 per tile on average -- bound the older forms (MI355X: 1 750 cycles per
 // tile and CU measured, against 450 for the MFMAs); out of LDS the same reads cost 2 cycles each.
-constexpr int WQ_WIN_FLOATS = 12288;   // 48 KB per workgroup: two workgroups per CU
+#ifndef XEQ_WQ_WIN_FLOATS
+#define XEQ_WQ_WIN_FLOATS 12288
+#endif
+constexpr int WQ_WIN_FLOATS = XEQ_WQ_WIN_FLOATS;   // 48 KB per workgroup: two workgroups per CU
 
 // rbf_lin rows of the unit as the B operand: wl[kind][s][lane], lane (j = lane & 31 -> channel, kh = lane >> 5)
 // holding W~[row][2 s + kh], W~[., B] = bias, zeros beyond.  kind 0: gate_state, 1: gate_edge, 2: scalar message.

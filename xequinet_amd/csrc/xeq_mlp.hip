@@ -371,6 +371,17 @@ int xeq_mlp_debug_wg(unsigned long long* out) {   // development only: 4096 x 4
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_wg), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? XEQ_OK : XEQ_ERR_LAUNCH;
 }
 
+/* How a launch of the node kernels cuts `tiles` 32-node tiles into workgroups (TileSplit, xeq_common.h): out = {tiles run by one
+ * workgroup each, workgroups per remaining tile, grid size}.  Host logic only; what tests/test_host_logic.py checks. */
+int xeq_node_tile_split(int64_t tiles, int max_split, int64_t out[3]) {
+  XEQ_CHECK_ARG(tiles >= 0 && tiles < ((int64_t)1 << 31) && out, "xeq_node_tile_split: bad arguments");
+  const TileSplit t = tile_split(tiles, max_split);
+  out[0] = t.n_full;
+  out[1] = t.split;
+  out[2] = t.grid(tiles);
+  return XEQ_OK;
+}
+
 int xeq_mlp2_supported(int dtype, int k1, int hidden, int n2) {
   return dtype == XEQ_F32 && hidden == MLP_H && k1 > 0 && k1 % 32 == 0 && n2 > 0 && n2 % 32 == 0;   // k1 is the reverse pass's n2
 }

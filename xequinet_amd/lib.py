@@ -103,6 +103,7 @@ _PROTOS = {
     "xeq_update_uv_bwd": [_P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, _P, _P, c_double,
                           _P, _P, _P, _P],
     "xeq_mlp2_supported": [c_int, c_int, c_int, c_int],
+    "xeq_node_tile_split": [c_int64, c_int, ctypes.POINTER(c_int64)],
     "xeq_mlp_packed_floats": [c_int, c_int],
     "xeq_mlp_pack": [_P, _P, c_int, c_int, c_int, _P, _P],
     "xeq_mlp2_fwd": [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P, c_int64, _P],
