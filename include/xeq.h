@@ -392,7 +392,7 @@ int xeq_uv_reduce_bwd(int dtype, const void* uv_bt, const void* g_p, const void*
                       void* stream);
 /* Output stage of XPainnUpdate (nn/xpainn.py:218-229) with a = [a_vv C | a_sv F | a_ss F], ip = dot_lin(p):
  * s_out = s + a_sv*ip + a_ss, x_out = x + U (x) a_vv (x, x_out in e3nn layout); and the reverse
- * (g_uv_bt may be NULL: dL/dU = g_x_out a_vv is then left to xeq_uv_reduce_bwd). */
+ * (g_uv_bt may be NULL: dL/dU = g_x_out a_vv is then left to xeq_uv_reduce_bwd; g_x_out may be NULL: zero). */
 int xeq_update_out_fwd(int dtype, const void* s, const void* x, const void* uv_bt, const void* a, const void* ip,
                        int64_t n, int node_dim, const int32_t mul[3], void* s_out, void* x_out, void* stream);
 int xeq_update_out_bwd(int dtype, const void* g_s_out, const void* g_x_out, const void* uv_bt, const void* a,
@@ -440,6 +440,7 @@ int xeq_update_uv_fwd(const float* s, const float* x, const float* ln_w, const f
  *   g_U = g_x_out a_vv + g_p V,  g_V = g_p U + g_v V / sqrt(sum_m V^2 + eps^2)   (g_v = g_cat[:, node_dim:], a_vv = a[:, :C])
  *   g_xhat = g_U W_U^T + g_V W_V^T;  g_s = g_s_out + LN^T(g_cat[:, :node_dim]),  g_x = g_x_out + EqLN^T(g_xhat).
  * wt_packed_l = xeq_mlp_pack([W_U | W_V] / sqrt(mul_l) as [n_out = mul_l][k_in = 2 mul_l], NULL, transposed = 0).
+ * g_x_out may be NULL (the block's equivariant output has no consumer: the last block of a force evaluation): zero.
  * Split form (g_xhat_bt != NULL): stops after the contraction and writes dL/dxhat in BT layout for xeq_norm_bwd (g_s_out, s,
  * x, stats, ln_w, eq_w, g_s, g_x unused; the workgroup then needs 50 KB of LDS instead of 113 KB). */
 int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, int64_t ld_cat, const float* g_x_out,

@@ -137,3 +137,31 @@ def test_update_block_fused_front_matches_the_kernel_chain(monkeypatch, n, irrep
         err, err_chain = (a_ - e_).abs().max().item(), (c_ - e_).abs().max().item()
         scale = max(1.0, e_.abs().max().item())
         assert err <= max(3.0 * err_chain, 2e-5 * scale), f"{name}: fused {err:.2e}, chain {err_chain:.2e} (scale {scale:.1f})"
+
+
+@pytest.mark.parametrize("n", [33, 1000, 9000])
+def test_update_block_without_a_consumer_of_x_out(monkeypatch, n):
+    """Last block of a force evaluation: the head reads s_out only, dL/dx_out arrives as None and the reverse kernels skip its
+    terms -- same gradients as with an explicit zero (fused and split reverse forms, and the kernel chain)."""
+    from xequinet_amd.nn.xpainn import XPainnUpdate
+
+    torch.manual_seed(n)
+    blk = XPainnUpdate().to(DEV).eval().requires_grad_(False)
+    D = blk.node_irreps.dim
+    s0, x0 = torch.randn(n, 128, device=DEV), torch.randn(n, D, device=DEV)
+    gs = torch.randn(n, 128, device=DEV)
+
+    def run(explicit_zero):
+        s, x = s0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        with torch.enable_grad():
+            so, xo = fused.UpdateBlock.apply(s, x, blk)
+            if explicit_zero:
+                return torch.autograd.grad([so, xo], [s, x], [gs, torch.zeros_like(xo)])
+            return torch.autograd.grad([so], [s, x], [gs])
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    monkeypatch.setattr(fused, "_packed_uv_frag", lambda module: None)   # the elementwise kernels + library GEMMs
+    c = run(False)   # sanity against the chain (rounding-level agreement is pinned against f64 in the test above)
+    for got, ref in zip(a, c):
+        assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())

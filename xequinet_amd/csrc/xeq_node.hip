@@ -433,7 +433,13 @@ __global__ void __launch_bounds__(512) k_update_out_bwd_c(const T* __restrict__ 
   const int64_t n0 = (int64_t)(blockIdx.x / ncb) * NPB;
   const int f = cb * (int)blockDim.x + threadIdx.x;
   if (f >= C + F) return;
-  if (f < C) {
+  if (f < C && g_x_out == nullptr) {   // the block's equivariant output has no consumer (last block of a force evaluation): zeros
+    for (int j = 0; j < NPB; ++j) {
+      const int64_t n = n0 + j;
+      if (n >= N) break;
+      g_a[n * A + f] = T(0);
+    }
+  } else if (f < C) {
     const ChanBT c = chan_bt(ir, N, f);
     const int w2 = 2 * c.w;
 #ifndef XEQ_UOB_UNROLL

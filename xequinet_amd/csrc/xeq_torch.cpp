@@ -299,7 +299,8 @@ void norm_bwd(const Hyper& hy, const Tensor& s, const Tensor& x, const Tensor& l
   const int32_t mul[3] = {hy.mul[0], hy.mul[1], hy.mul[2]};
   XCALL(xeq_norm_bwd(dcode(s), s.data_ptr(), x.data_ptr(), hy.layer_norm ? lw.data_ptr() : nullptr,
                      hy.layer_norm ? ew.data_ptr() : nullptr, stats.data_ptr(), n, hy.F, mul, hy.layer_norm, g_shat.data_ptr(), ld,
-                     g_xhat.data_ptr(), res_s.data_ptr(), res_x.data_ptr(), g_s.data_ptr(), g_x.data_ptr(), cur_stream()));
+                     g_xhat.data_ptr(), res_s.defined() ? res_s.data_ptr() : nullptr, res_x.defined() ? res_x.data_ptr() : nullptr,
+                     g_s.data_ptr(), g_x.data_ptr(), cur_stream()));
 }
 
 // what one block keeps for the reverse pass
@@ -483,7 +484,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   if (compute_forces || compute_virial) {
     // ---- explicit reverse pass: dE/ds of the head, then the blocks backwards, then the edge geometry (nn/basic.py:143-199)
     Tensor g_s = at::mm(at::silu_backward(t[2].expand({N, t[2].size(1)}), pre_o), t[0]);   // dE_i/d atomic_i = 1
-    Tensor g_x = at::zeros({N, D}, fopt);
+    Tensor g_x;   // undefined = zero: the head reads the scalars only, the last block's equivariant output has no consumer
     Tensor g_vec_total;
     if (impl == 0) {
       build_wq_plan(g, true, g.rev);
@@ -498,7 +499,8 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       {  // UpdateBlock.backward
         const UpdSaved& u = usv[b];
         Tensor g_a = at::empty_like(u.a), g_ip = at::empty_like(u.ip);
-        XCALL(xeq_update_out_bwd(dt, g_s.data_ptr(), g_x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
+        const void* gx_ptr = g_x.defined() ? g_x.data_ptr() : nullptr;
+        XCALL(xeq_update_out_bwd(dt, g_s.data_ptr(), gx_ptr, u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
                                  g_a.data_ptr(), g_ip.data_ptr(), nullptr, st));
         const Tensor g_p = at::mm(g_ip, q[14]);
         const Tensor g_cat = mlp_bwd(g_a, u.pre, q[15], q[16], q[17], q[18]);
@@ -515,7 +517,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
             g_xhat = at::empty({N * D}, fopt);
           }
           XCALL(xeq_update_uv_bwd((const float*)u.uv.data_ptr(), (const float*)g_p.data_ptr(), (const float*)g_cat.data_ptr(), F + C,
-                                  (const float*)g_x.data_ptr(), (const float*)g_s.data_ptr(), (const float*)u.a.data_ptr(), u.a.size(1),
+                                  (const float*)gx_ptr, (const float*)g_s.data_ptr(), (const float*)u.a.data_ptr(), u.a.size(1),
                                   (const float*)u.s.data_ptr(), (const float*)u.x.data_ptr(), (const float*)u.stats.data_ptr(),
                                   hy.layer_norm ? fp(q[19]) : nullptr, hy.layer_norm ? fp(q[21]) : nullptr, N, F, mul, hy.layer_norm,
                                   fp(fr->wt[0]), fp(fr->wt[1]), fp(fr->wt[2]), hy.inv_eps, fuse ? (float*)ns.data_ptr() : nullptr,
@@ -523,6 +525,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
           if (!fuse) norm_bwd(hy, u.s, u.x, q[19], q[21], u.stats, g_cat, F + C, g_xhat, g_s, g_x, ns, nx);
         } else {
           Tensor g_uv = at::empty_like(u.uv);
+          if (!g_x.defined()) g_x = at::zeros({N, D}, fopt);   // the kernel chain wants the tensor
           XCALL(xeq_uv_reduce_bwd(dt, u.uv.data_ptr(), g_p.data_ptr(), g_cat.data_ptr(), F + C, F, N, mul, hy.inv_eps, g_x.data_ptr(),
                                   u.a.data_ptr(), g_uv.data_ptr(), st));
           Tensor g_xhat = at::empty({N * D}, fopt);

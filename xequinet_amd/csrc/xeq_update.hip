@@ -354,7 +354,8 @@ __device__ __forceinline__ void uvb_form(const UvBwdArgs& a, float* bf, int BLD,
     for (int m = 0; m < D_L; ++m) {
       U[m] = *reinterpret_cast<const float4*>(ur + m * 2 * mul);
       V[m] = *reinterpret_cast<const float4*>(ur + m * 2 * mul + mul);
-      gx4[m] = *reinterpret_cast<const float4*>(a.g_x_out + gn * Dtot + base + ch * D_L + 4 * m);   // 4 D_L contiguous floats
+      gx4[m] = a.g_x_out ? *reinterpret_cast<const float4*>(a.g_x_out + gn * Dtot + base + ch * D_L + 4 * m)   // 4 D_L contiguous floats
+                         : make_float4(0.f, 0.f, 0.f, 0.f);   // no consumer of the block's equivariant output: dL/dx_out = 0
     }
     const float4 gp = *reinterpret_cast<const float4*>(a.g_p + gn * (int64_t)a.ir.C() + goff + ch);
     const float4 gc = *reinterpret_cast<const float4*>(a.g_cat + gn * a.ld_cat + F + goff + ch);
@@ -504,7 +505,7 @@ __global__ void __launch_bounds__(256) k_update_uv_bwd(UvBwdArgs a) {
   const float4* xr = reinterpret_cast<const float4*>(a.x + gn * D);
   const float4* gsr = reinterpret_cast<const float4*>(a.g_cat + gn * a.ld_cat);
   const float4* rsr = reinterpret_cast<const float4*>(a.g_s_out + gn * F);
-  const float4* rxr = reinterpret_cast<const float4*>(a.g_x_out + gn * D);
+  const float4* rxr = a.g_x_out ? reinterpret_cast<const float4*>(a.g_x_out + gn * D) : nullptr;
   const float4 st = *reinterpret_cast<const float4*>(a.stats + 4 * gn);
   const float mean = st.x, rstd = st.y, mean0 = st.z, r = st.w;
   // g_s
@@ -599,7 +600,7 @@ __global__ void __launch_bounds__(256) k_update_uv_bwd(UvBwdArgs a) {
     for (int k = 0; k < UV_MAXX4; ++k) {
       const int idx = sub + 8 * k, f0 = 4 * idx;
       if (f0 >= D) continue;
-      const float4 rx = rxr[idx];
+      const float4 rx = rxr ? rxr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 o = gw[k];
       if (do_norm) {
         const float gm = f0 < m0 ? gmean : 0.f;
@@ -689,7 +690,7 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
   const float* wt[3] = {wt_packed0, wt_packed1, wt_packed2};
   for (int l = 0; l < 3; ++l) XEQ_CHECK_ARG(mul[l] == 0 || wt[l], "xeq_update_uv_bwd: packed weights of l = %d missing", l);
   const bool fuse = g_xhat_bt == nullptr;
-  XEQ_CHECK_ARG(uv_bt && g_p && g_cat && g_x_out && a, "xeq_update_uv_bwd: null buffer");
+  XEQ_CHECK_ARG(uv_bt && g_p && g_cat && a, "xeq_update_uv_bwd: null buffer");   // g_x_out may be NULL: zero
   XEQ_CHECK_ARG(!fuse || (g_s_out && s && x && stats && g_s && g_x && (!do_norm || (ln_w && eq_w))), "xeq_update_uv_bwd: null buffer (fused form)");
   UvBwdArgs b;
   b.uv = uv_bt; b.g_p = g_p; b.g_cat = g_cat; b.g_x_out = g_x_out; b.g_s_out = g_s_out; b.a = a; b.s = s; b.x = x; b.stats = stats;

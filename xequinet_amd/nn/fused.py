@@ -265,6 +265,7 @@ class UpdateBlock(Function):
              ptr(x_out), stream())
         ctx.save_for_backward(s, x, stats, uv, pre, a, ip)
         ctx.module, ctx.do_norm = module, do_norm
+        ctx.set_materialize_grads(False)   # an output without a consumer (the last block's x_out: the head reads s only) arrives as None
         return s_out, x_out
 
     @staticmethod
@@ -277,7 +278,7 @@ class UpdateBlock(Function):
         C = sum(mul)
         dt, dev = s.dtype, s.device
         g_s_out = torch.zeros_like(s) if g_s_out is None else g_s_out.contiguous()
-        g_x_out = torch.zeros_like(x) if g_x_out is None else g_x_out.contiguous()
+        g_x_out = None if g_x_out is None else g_x_out.contiguous()   # None = zero: the kernels skip its terms
         g_a = torch.empty_like(a)
         g_ip = torch.empty_like(ip)
         # dL/dU of this stage (g_x_out a_vv) is formed inside xeq_uv_reduce_bwd: no write here, no read-modify-write there
@@ -301,6 +302,8 @@ class UpdateBlock(Function):
                 g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_cat, F + C, g_xhat, g_s_out, g_x_out)
             return g_s, g_x, None
         g_uv = torch.empty_like(uv)
+        if g_x_out is None:
+            g_x_out = torch.zeros_like(x)   # the kernel chain wants the tensor
         call("xeq_uv_reduce_bwd", dtype_code(s), ptr(uv), ptr(g_p), ptr(g_cat), F + C, F, n, mul3(mul), float(module.invariant.eps),
              ptr(g_x_out), ptr(a), ptr(g_uv), stream())
         packs, _ = _packed_uv(module)
