@@ -391,7 +391,7 @@ int xeq_uv_reduce_bwd(int dtype, const void* uv_bt, const void* g_p, const void*
                       int64_t n, const int32_t mul[3], double eps, const void* g_x_out, const void* a, void* g_uv_bt,
                       void* stream);
 /* Output stage of XPainnUpdate (nn/xpainn.py:218-229) with a = [a_vv C | a_sv F | a_ss F], ip = dot_lin(p):
- * s_out = s + a_sv*ip + a_ss, x_out = x + U (x) a_vv (x, x_out in e3nn layout); and the reverse
+ * s_out = s + a_sv*ip + a_ss, x_out = x + U (x) a_vv (x, x_out in e3nn layout; x_out may be NULL: not computed); and the reverse
  * (g_uv_bt may be NULL: dL/dU = g_x_out a_vv is then left to xeq_uv_reduce_bwd; g_x_out may be NULL: zero). */
 int xeq_update_out_fwd(int dtype, const void* s, const void* x, const void* uv_bt, const void* a, const void* ip,
                        int64_t n, int node_dim, const int32_t mul[3], void* s_out, void* x_out, void* stream);

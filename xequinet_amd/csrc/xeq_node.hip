@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(512) k_update_out_fwd_c(const T* __restrict__ 
       if (n >= N) break;
       s_out[n * F + f] = s[n * F + f] + a[n * A + C + f] * ip[n * F + f] + a[n * A + C + F + f];
     }
-  } else {
+  } else if (x_out != nullptr) {   // (NULL: nobody reads the block's equivariant output -- the last block in front of a scalar head)
     const int fx = f - F;
     int u, m;
     chan_of_flat(ir, fx, u, m);

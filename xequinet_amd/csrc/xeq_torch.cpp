@@ -466,9 +466,10 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       }
       mlp_fwd(cat, q[15], q[16], q[17], q[18], u.pre, u.a);
       u.ip = at::mm(p, q[14].t());
-      Tensor s_out = at::empty_like(s), x_out = at::empty_like(x);
+      const bool last = b == hy.blocks - 1;   // the energy head reads the scalars only: the last equivariant output has no consumer
+      Tensor s_out = at::empty_like(s), x_out = last ? Tensor() : at::empty_like(x);
       XCALL(xeq_update_out_fwd(dt, s.data_ptr(), x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
-                               s_out.data_ptr(), x_out.data_ptr(), st));
+                               s_out.data_ptr(), last ? nullptr : x_out.data_ptr(), st));
       s = s_out;
       x = x_out;
     }

@@ -260,7 +260,8 @@ class UpdateBlock(Function):
             call("xeq_uv_reduce_fwd", dtype_code(s), ptr(uv), n, mul3(mul), float(eps), ptr(cat), F + C, F, ptr(p), stream())
         pre, a = _mlp_fwd(module.update_mlp, cat)                             # a = [a_vv C | a_sv F | a_ss F]
         ip = torch.mm(p, module.dot_lin.weight.t())
-        s_out, x_out = torch.empty_like(s), torch.empty_like(x)
+        # (the last block in front of a scalar-only head: nobody reads its equivariant output, nn/model.py marks the module)
+        s_out, x_out = torch.empty_like(s), (None if getattr(module, "equivariant_output_unused", False) else torch.empty_like(x))
         call("xeq_update_out_fwd", dtype_code(s), ptr(s), ptr(x), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(s_out),
              ptr(x_out), stream())
         ctx.save_for_backward(s, x, stats, uv, pre, a, ip)

@@ -101,6 +101,10 @@ class XPaiNN(BaseModel):
             output = resolve_output(mode, **kwargs)
             self.mods[f"output_{mode}"] = output
             self.extra_properties.extend(output.extra_properties)
+        # the heads built here read the node scalars only (nn/output.py:114-128), so the last update block's equivariant output has
+        # no consumer: it is not computed (data[NODE_EQUIVARIANT] is None behind that block) and its gradient is not formed
+        if action_blocks > 0 and all(not getattr(self.mods[f"output_{m}"], "reads_equivariant", False) for m in output_modes):
+            self.mods[f"update_{action_blocks - 1}"].equivariant_output_unused = True
 
 
 def resolve_model(model_name: str, **kwargs) -> BaseModel:

@@ -169,6 +169,9 @@ class XPainnUpdate(nn.Module):
         self.norm = nn.LayerNorm(self.node_dim) if layer_norm else nn.Identity()
         self.o3norm = EquivariantLayerNorm(self.node_irreps) if layer_norm else nn.Identity()
         self.fused = True  # False: run the reference's op sequence on the operator-level drop-ins
+        # set by the model on its last update block when no head reads the equivariant features: they are then not computed
+        # (data[NODE_EQUIVARIANT] is None behind the block)
+        self.equivariant_output_unused = False
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if self.fused:
