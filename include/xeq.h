@@ -356,6 +356,7 @@ int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
                        int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out, int xhat_layout,
                        void* stream);
 int64_t xeq_message_wq_parts_floats(int64_t n_nodes, int64_t n_edges, const int32_t mul[3]);   /* a size, not a status */
+/* grad_h / grad_xhat may both be NULL: only the per-edge partials (dL/dvec) are formed. */
 int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* n_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis,
                        const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,

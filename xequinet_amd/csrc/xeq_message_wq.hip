@@ -822,8 +822,9 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   const float* __restrict__ xhat = xhat_ + wc.x_base;
   float* __restrict__ grad_xhat = grad_xhat_ + wc.x_base;
   const uint32_t he_off = 4u * (uint32_t)a.C, row_h = 4u * (uint32_t)a.H;
+  const bool node_grads = grad_h != nullptr;   // NULL: only dL/dvec is wanted (first block of a force evaluation)
   wq_for_isolated(a, range, lane, [&](int m) {   // nobody's neighbor: zero gradients on the unit's columns
-    if (hh == 0) {
+    if (hh == 0 && node_grads) {
       wq_st(grad_h, (uint32_t)m * row_h + wc.b_hs, 0.f);
       wq_st(grad_h, (uint32_t)m * row_h + wc.b_hs + he_off, 0.f);
       if constexpr (HAS_S) wq_st(grad_h, (uint32_t)m * row_h + wc.b_hm, 0.f);
@@ -932,7 +933,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         a_hs = (keep ? a_hs : 0.f) + hsq;
 #pragma unroll
         for (int m = 0; m < NM; ++m) a_x[m] = __builtin_fmaf(o_hs, u[m], keep ? a_x[m] : 0.f);
-        if (last) {
+        if (last && node_grads) {
           wq_st(grad_h, own * row_h + wc.b_hs, a_hs);
           const uint32_t ox = own * wc.xnode_b + wc.b_x;
 #pragma unroll
@@ -978,7 +979,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
           pd[v] = __builtin_fmaf(o_he * dge[r], qe[v], pd[v]);
         }
         a_he = (keep ? a_he : 0.f) + heq;
-        if (last) wq_st(grad_h, own * row_h + wc.b_hs + he_off, a_he);
+        if (last && node_grads) wq_st(grad_h, own * row_h + wc.b_hs + he_off, a_he);
         if constexpr (NM > 1) XEQ_WQ_SB();
       }
       if constexpr (NM > 1) {
@@ -1044,7 +1045,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
           pd[v] = __builtin_fmaf(o_hm * gsv[v], qm[v], pd[v]);
         }
         a_hm = (keep ? a_hm : 0.f) + hmq;
-        if (last) wq_st(grad_h, own * row_h + wc.b_hm, a_hm);
+        if (last && node_grads) wq_st(grad_h, own * row_h + wc.b_hm, a_hm);
       }
     }
     XEQ_WQ_SB();

@@ -539,15 +539,17 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       }
       {  // MessageBlock.backward
         const MsgSaved& m = msv[b];
-        Tensor g_h = at::empty_like(m.h), g_xhat = at::empty_like(m.xhat), g_vec = at::empty_like(vec);
+        const bool node_grads = b > 0 || m.impl != 0;   // first block: only dL/dvec leaves it, the wq kernel then stores no node gradients
+        Tensor g_h = node_grads ? at::empty_like(m.h) : Tensor(), g_xhat = node_grads ? at::empty_like(m.xhat) : Tensor();
+        Tensor g_vec = at::empty_like(vec);
         if (m.impl == 0) {
           Tensor parts = at::empty({std::max<int64_t>(1, xeq_message_wq_parts_floats(N, E, mul))}, fopt);
           XCALL(xeq_message_bwd_wq(N, E, g.rev.n_ranges, (const int32_t*)g.rev.sq.data_ptr(), (const int32_t*)g.rev.sn.data_ptr(),
                                    (const int32_t*)g.rev.win.data_ptr(), (const int32_t*)g.rev.rowptr.data_ptr(),
                                    (const int32_t*)g.rev.pgath.data_ptr(), (const int32_t*)g.rev.qinfo.data_ptr(),
                                    g.rev.basis.data_ptr(), g.rev.dbasis.data_ptr(), m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(),
-                                   g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B, F, mul, g_h.data_ptr(), g_xhat.data_ptr(),
-                                   parts.data_ptr(), 1, st));
+                                   g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B, F, mul, node_grads ? g_h.data_ptr() : nullptr,
+                                   node_grads ? g_xhat.data_ptr() : nullptr, parts.data_ptr(), 1, st));
           XCALL(xeq_message_wq_edge_grad(vec.data_ptr(), N, E, (const int32_t*)g.rev.qptr.data_ptr(),
                                          (const int32_t*)g.rev.peid.data_ptr(), mul, parts.data_ptr(), g_vec.data_ptr(), st));
         } else {

@@ -165,8 +165,10 @@ class MessageBlock(Function):
         s, x, stats, pre = t[-4:]
         it = iter(t[:-4])
         msg_saved = tuple(None if is_none else next(it) for is_none in ctx.none_mask)
-        g_h, g_xhat, g_vec, g_s_res, g_x_res = ops.message_backward(msg_saved, ctx.graph, ctx.cfg, ctx.impl, g_s_out, g_x_out)
-        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+        node_grads = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        g_h, g_xhat, g_vec, g_s_res, g_x_res = ops.message_backward(msg_saved, ctx.graph, ctx.cfg, ctx.impl, g_s_out, g_x_out,
+                                                                    node_grads=node_grads)
+        if not node_grads:
             # first block of a force evaluation: its node features are the embedding of the atomic numbers and zeros, neither
             # depends on the positions; only dL/dvec leaves this block (no MLP / norm reverse launches)
             return None, None, g_vec, None, None, None, None

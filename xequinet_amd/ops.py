@@ -710,15 +710,17 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
     return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, None, None), impl
 
 
-def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x):
-    """Reverse pass of the fused message: (grad_h, grad_xhat, grad_vec, grad_s, grad_x)."""
+def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_grads: bool = True):
+    """Reverse pass of the fused message: (grad_h, grad_xhat, grad_vec, grad_s, grad_x).  node_grads=False: only grad_vec is
+    wanted (the first block of a force evaluation); the wq kernel then stores no node gradients and None is returned for them."""
     h, xhat, vec, w_rbf, b_rbf, p0, p1, basis, dbasis = saved
     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = cfg[:6]
     xl = int(cfg[6]) if len(cfg) > 6 else 0
     D = mul[0] + 3 * mul[1] + 5 * mul[2]
     g_s = torch.zeros((graph.n_nodes, node_dim), dtype=h.dtype, device=h.device) if g_s is None else g_s.contiguous()
     g_x = torch.zeros((graph.n_nodes, D), dtype=h.dtype, device=h.device) if g_x is None else g_x.contiguous()
-    g_h, g_xhat = torch.empty_like(h), torch.empty_like(xhat)
+    skip = impl == "wq" and not node_grads
+    g_h, g_xhat = (None, None) if skip else (torch.empty_like(h), torch.empty_like(xhat))
     g_vec = torch.empty_like(vec)  # written at the edge's own position by every kernel family
     if impl == "wq":
         N, E = graph.n_nodes, graph.n_edges
