@@ -62,6 +62,24 @@ def test_mlp2_strided_rows_and_row_count_invariance():
     assert torch.equal(pre[:45], pre_h) and torch.equal(y[:45], y_h)
 
 
+@pytest.mark.parametrize("k1,n2", [(128, 576), (352, 480)])
+def test_mlp2_64_row_form_gives_the_same_rows(k1, n2):
+    """From 16 384 rows on a workgroup owns 64 rows (two row tiles share every weight fragment); a row's sums do not depend on the
+    form that computed them: bit-equal to the 32-row form, forward and reverse, ragged tail included."""
+    seq = _seq(k1, n2, seed=11)
+    n = 16384 + 37
+    x = torch.randn(n, k1, device=DEV)
+    g = torch.randn(n, n2, device=DEV)
+    pre, y = fused._mlp_fwd(seq, x)
+    gx = fused._mlp_bwd(seq, g, pre)
+    for lo, hi in ((0, 300), (16100, n)):       # the same rows through the 32-row form
+        pre_s, y_s = fused._mlp_fwd(seq, x[lo:hi].contiguous())
+        gx_s = fused._mlp_bwd(seq, g[lo:hi].contiguous(), pre_s)
+        assert torch.equal(pre[lo:hi], pre_s) and torch.equal(y[lo:hi], y_s) and torch.equal(gx[lo:hi], gx_s)
+    pre_r, y_r, gx_r = _ref(seq, x[:2000], g[:2000])
+    assert (y[:2000].double() - y_r).abs().max().item() <= TOL and (gx[:2000].double() - gx_r).abs().max().item() <= TOL
+
+
 def test_mlp2_repacks_when_a_weight_changes():
     seq = _seq(128, 576, seed=3)
     x = torch.randn(64, 128, device=DEV)

@@ -346,6 +346,201 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 #endif
 }
 
+// ---- 64 rows per workgroup -------------------------------------------------------------------------------------------
+// The 32-row form reads every weight once per 32 rows: 360 KB per workgroup out of L2 for the message MLP, 207 MB per launch at
+// 18 k nodes, and with every CU streaming at once the chip's L2 delivers ~7.5 TB/s (scratch/mfma_mix_probe.hip: eight 16-byte
+// weight loads per 32 MFMAs slow the MFMA stream by 27 % at one or three waves per SIMD alike).  Two row tiles per workgroup share
+// each weight fragment: half the weight traffic per MFMA, the matrix pipe is the bound again.  Same sums per row as the 32-row form
+// (same k order, same even / odd accumulators in stage 1), so which form ran does not show in the results.  Used from one full
+// round of 64-row tiles on (n >= 16 384); below that the 32-row form keeps more CUs busy.
+template <bool REVERSE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) k_mlp2_r64(MlpArgs a) {
+  constexpr int R = 64;
+  __shared__ __attribute__((aligned(16))) float Xs[2][R * MLP_XLD];
+  __shared__ __attribute__((aligned(16))) float Ts[R * MLP_TLD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, kh = lane >> 5;
+  int tile_, part_, parts_;
+  a.ts.decode((int)blockIdx.x, tile_, part_, parts_);
+  const int64_t row0 = (int64_t)tile_ * R;
+  const int rows_here = (int)min((int64_t)R, a.n - row0);
+  const int n_chunks = (a.K1 + MLP_CK - 1) / MLP_CK;
+  const int g1 = a.K1 / 8;
+  const int sr = tid >> 4, sc = (tid & 15) * 4;   // staging: 64 rows x 16 float4 per chunk, four per thread (rows sr + 16 k)
+  const float* __restrict__ xb = a.X + row0 * a.ldx;
+  float* __restrict__ preb = a.pre + row0 * MLP_H;
+  float* __restrict__ yo = a.Y + row0 * a.ldy;
+  const unsigned ldx32 = (unsigned)a.ldx, ldy32 = (unsigned)a.ldy;
+  unsigned rc[4];
+  bool rok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rc[k] = (unsigned)min(sr + 16 * k, rows_here - 1) * ldx32;
+    rok[k] = sr + 16 * k < rows_here;
+  }
+  auto fetch = [&](int c, float4 (&v)[4]) {
+    const int colc = min(MLP_CK * c + sc, a.K1 - 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(xb + (rc[k] + (unsigned)colc));
+  };
+  auto stash = [&](int c, const float4 (&v)[4]) {
+    const bool cok = MLP_CK * c + sc < a.K1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(&Xs[c & 1][(sr + 16 * k) * MLP_XLD + sc]) = keep4(rok[k] && cok, v[k]);
+  };
+  const float4* w1 = reinterpret_cast<const float4*>(a.W1p) + (int64_t)wave * (g1 + 1) * 64;
+  auto fetch_w = [&](float4 (&b)[4], int g0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = w1[min(g0 + q, g1 - 1) * 64 + lane];
+  };
+  f32x16 acc[2][2];   // [row tile][even / odd k steps]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+  }
+  const float one_k0 = kh == 0 ? 1.f : 0.f;
+  float bias_a = 0.f;
+  if (a.bias1) bias_a = reinterpret_cast<const float*>(w1 + (int64_t)g1 * 64 + lane)[0];
+  float4 pv[2][4];
+  if (REVERSE) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pv[rt][g] = *reinterpret_cast<const float4*>(preb + ((unsigned)min(32 * rt + i, rows_here - 1) * MLP_H + (unsigned)(32 * wave + 8 * g + 4 * kh)));
+  }
+  float4 xv[4], B0[4], B1[4];
+  fetch(0, xv);
+  fetch_w(B0, 0);
+  stash(0, xv);
+  MLP_LDS_BARRIER();
+  for (int c = 0; c < n_chunks; ++c) {
+    const bool more = c + 1 < n_chunks;
+    if (more) fetch(c + 1, xv);
+    const float* xs = &Xs[c & 1][i * MLP_XLD + 4 * kh];
+    auto half = [&](const float4 (&b)[4], int h) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 x0 = *reinterpret_cast<const float4*>(xs + 8 * (4 * h + q));
+        const float4 x1 = *reinterpret_cast<const float4*>(xs + 32 * MLP_XLD + 8 * (4 * h + q));
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, x0.x, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, x1.x, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, x0.y, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, x1.y, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].z, x0.z, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].z, x1.z, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, x0.w, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, x1.w, acc[1][1], 0, 0, 0);
+      }
+    };
+    fetch_w(B1, 8 * c + 4);
+    MLP_SB();
+    half(B0, 0);
+    MLP_SB();
+    fetch_w(B0, 8 * c + 8);
+    MLP_SB();
+    half(B1, 1);
+    MLP_SB();
+    if (more) stash(c + 1, xv);
+    MLP_LDS_BARRIER();
+  }
+  if (a.bias1) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, one_k0, acc[0][0], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, one_k0, acc[1][0], 0, 0, 0);
+  }
+  const int nt2 = a.N2 / 32;
+  constexpr int G2 = MLP_H / 8;
+  const float4* w2 = reinterpret_cast<const float4*>(a.W2p);
+  auto fetch_q = [&](float4 (&b)[4], int t, int qq) {
+    const float4* wa = w2 + ((int64_t)t * (G2 + 1) + 4 * qq) * 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = wa[q * 64 + lane];
+  };
+  const int parts = __builtin_amdgcn_readfirstlane(parts_), part = __builtin_amdgcn_readfirstlane(part_);
+  int t0 = wave + 4 * part;
+  if (t0 < nt2) fetch_q(B0, t0, 0);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = 32 * rt + i;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 32 * wave + 8 * g + 4 * kh;
+      const float4 t = make_float4(acc[rt][0][4 * g] + acc[rt][1][4 * g], acc[rt][0][4 * g + 1] + acc[rt][1][4 * g + 1],
+                                   acc[rt][0][4 * g + 2] + acc[rt][1][4 * g + 2], acc[rt][0][4 * g + 3] + acc[rt][1][4 * g + 3]);
+      float4 v;
+      if (!REVERSE) {
+        if (row < rows_here && part_ == 0) *reinterpret_cast<float4*>(preb + ((unsigned)row * MLP_H + (unsigned)col)) = t;
+        v = make_float4(silu_f(t.x), silu_f(t.y), silu_f(t.z), silu_f(t.w));
+      } else {
+        v = make_float4(t.x * silu_grad_f(pv[rt][g].x), t.y * silu_grad_f(pv[rt][g].y), t.z * silu_grad_f(pv[rt][g].z),
+                        t.w * silu_grad_f(pv[rt][g].w));
+      }
+      *reinterpret_cast<float4*>(&Ts[row * MLP_TLD + col]) = v;
+    }
+  }
+  MLP_LDS_BARRIER();
+  const float* ts = &Ts[i * MLP_TLD + 4 * kh];
+  for (; t0 < nt2; t0 += 4 * parts) {
+    const int tn = t0 + 4 * parts;
+    f32x16 ya, yb;   // the tile's rows 0..31 and 32..63
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ya[r] = 0.f;
+      yb[r] = 0.f;
+    }
+    float bias_y = 0.f;
+    if (a.bias2) bias_y = reinterpret_cast<const float*>(w2 + ((int64_t)t0 * (G2 + 1) + G2) * 64 + lane)[0];
+    auto quarter = [&](const float4 (&b)[4], int qq) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 u0 = *reinterpret_cast<const float4*>(ts + 8 * (4 * qq + q));
+        const float4 u1 = *reinterpret_cast<const float4*>(ts + 32 * MLP_TLD + 8 * (4 * qq + q));
+        ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, u0.x, ya, 0, 0, 0);
+        yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].x, u1.x, yb, 0, 0, 0);
+        ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, u0.y, ya, 0, 0, 0);
+        yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].y, u1.y, yb, 0, 0, 0);
+        ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].z, u0.z, ya, 0, 0, 0);
+        yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].z, u1.z, yb, 0, 0, 0);
+        ya = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, u0.w, ya, 0, 0, 0);
+        yb = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q].w, u1.w, yb, 0, 0, 0);
+      }
+    };
+    fetch_q(B1, t0, 1);
+    MLP_SB();
+    quarter(B0, 0);
+    MLP_SB();
+    fetch_q(B0, t0, 2);
+    MLP_SB();
+    quarter(B1, 1);
+    MLP_SB();
+    fetch_q(B1, t0, 3);
+    MLP_SB();
+    quarter(B0, 2);
+    MLP_SB();
+    if (tn < nt2) fetch_q(B0, tn, 0);
+    MLP_SB();
+    quarter(B1, 3);
+    if (a.bias2) {
+      ya = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_y, one_k0, ya, 0, 0, 0);
+      yb = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_y, one_k0, yb, 0, 0, 0);
+    }
+    MLP_SB();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned o = (unsigned)i * ldy32 + (unsigned)(32 * t0 + 8 * g + 4 * kh);
+      if (i < rows_here) *reinterpret_cast<float4*>(yo + o) = make_float4(ya[4 * g], ya[4 * g + 1], ya[4 * g + 2], ya[4 * g + 3]);
+      if (32 + i < rows_here) *reinterpret_cast<float4*>(yo + o + 32u * ldy32) = make_float4(yb[4 * g], yb[4 * g + 1], yb[4 * g + 2], yb[4 * g + 3]);
+    }
+  }
+}
+
+constexpr int64_t MLP_R64_MIN_ROWS = 64 * 256;   // one full round of 64-row tiles
+// ... and an output wide enough (>= 4 groups of four tiles) that a short last round can be split: measured at 18 k nodes, 64-row
+// against 32-row form: 576 outputs 46.6 / 49.6 us, 480: 56.5 / 56.5, 352: 60.1 / 55.8, 128: 57.5 / 49.3; at 147 k nodes 280 / 332
+// (576 outputs) and 278 / 278 (128 outputs: the reverse forms are not bound by their weight stream)
+static bool mlp_use_r64(int64_t n, int n2) { return n >= MLP_R64_MIN_ROWS && (n2 / 32 + 3) / 4 >= 4; }
+
 static int mlp_check(const char* name, int64_t n, int k1, int n2, int64_t ldx, int64_t ldy) {
   XEQ_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) * MLP_ROWS, "%s: n = %lld out of range", name, (long long)n);
   XEQ_CHECK_ARG(k1 > 0 && k1 % 8 == 0 && n2 > 0 && n2 % 32 == 0, "%s: needs k1 %% 8 == 0 and n2 %% 32 == 0 (got %d, %d)", name, k1, n2);
@@ -403,9 +598,11 @@ int xeq_mlp2_fwd(const float* x, int64_t ldx, int64_t n, int k1, const float* w1
   if (int rc = mlp_check("xeq_mlp2_fwd", n, k1, n2, ldx, ldy)) return rc;
   XEQ_CHECK_ARG(n == 0 || (x && w1p && w2p && pre && y), "xeq_mlp2_fwd: null buffer");
   if (n == 0) return XEQ_OK;
-  const int64_t tiles = (n + MLP_ROWS - 1) / MLP_ROWS;
+  const bool r64 = mlp_use_r64(n, n2);
+  const int64_t tiles = r64 ? (n + 63) / 64 : (n + MLP_ROWS - 1) / MLP_ROWS;
   MlpArgs a{x, ldx, n, k1, n2, w1p, w2p, 1, 1, pre, y, ldy, tile_split(tiles, (n2 / 32 + 3) / 4)};
-  hipLaunchKernelGGL(k_mlp2<false>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
+  if (r64) hipLaunchKernelGGL(k_mlp2_r64<false>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_mlp2<false>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_fwd");
   return XEQ_OK;
 }
@@ -415,9 +612,11 @@ int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2
   if (int rc = mlp_check("xeq_mlp2_bwd", n, k1, n2, ldg, ldgx)) return rc;
   XEQ_CHECK_ARG(n == 0 || (g && w2tp && w1tp && pre && gx), "xeq_mlp2_bwd: null buffer");
   if (n == 0) return XEQ_OK;
-  const int64_t tiles = (n + MLP_ROWS - 1) / MLP_ROWS;
+  const bool r64 = mlp_use_r64(n, n2);
+  const int64_t tiles = r64 ? (n + 63) / 64 : (n + MLP_ROWS - 1) / MLP_ROWS;
   MlpArgs a{g, ldg, n, k1, n2, w2tp, w1tp, 0, 0, const_cast<float*>(pre), gx, ldgx, tile_split(tiles, (n2 / 32 + 3) / 4)};
-  hipLaunchKernelGGL(k_mlp2<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
+  if (r64) hipLaunchKernelGGL(k_mlp2_r64<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_mlp2<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_bwd");
   return XEQ_OK;
 }
