@@ -103,6 +103,9 @@ class GraphedModel:
         # thread-local capture mode: HIP calls of other host threads (RCCL's watchdog in a multi-rank job) do not
         # invalidate the capture
         with torch.cuda.graph(c.graph, capture_error_mode="thread_local"):
+            # the walk plans / stream tables of the message kernels depend on the neighbour list only; rebuilding them is part of
+            # the replayed graph (fixed sizes, in place over the static CSR arrays), not a dozen host launches in front of it
+            c.edge_graph.refresh_plans()
             c.outputs = self._run(static)
         self.captures += 1
         return c
@@ -123,7 +126,6 @@ class GraphedModel:
         s.n_perm.copy_(eg.n_perm, non_blocking=True)
         if s.c_perm is not None:
             s.c_perm.copy_(eg.c_perm, non_blocking=True)
-        s.refresh_plans()
 
     # --------------------------------------------------------------------- call
     def __call__(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
