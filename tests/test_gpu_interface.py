@@ -348,3 +348,30 @@ def test_native_operator_on_a_stream_of_new_topologies_matches_oracle():
         np.testing.assert_allclose(out[0].cpu().numpy(), want["energy"].numpy(), rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(out[2].cpu().numpy(), want["forces"].numpy(), rtol=0, atol=1e-9)
     assert len(seen) == 3
+
+
+def test_native_operator_never_reuses_the_weight_packs_of_a_dead_model():
+    """The operator caches matrix-core weight copies per parameter tensor.  A deleted model's parameter addresses are handed to the
+    next model of the same shapes (same version counters): the cache must notice that its owners died."""
+    import gc
+
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.interface.scripted import XPaiNNNative
+    from xequinet_amd.nn import resolve_model
+
+    pos, z, ptr = syn.synth_qm9_batch(6, seed=77)
+    b = NeighborTransform(5.0)(XequiBatch(P._t(pos, torch.float32), P._t(z), P._t(ptr)))
+    energies = []
+    for seed in (0, 1, 2):
+        torch.manual_seed(seed)
+        model = resolve_model("xpainn").eval().requires_grad_(False).to(DEV)
+        native = XPaiNNNative(model)
+        got = native(b.pos, b.atomic_numbers, b.edge_index, b.ptr, None, None, True, True, True, False)
+        with torch.enable_grad():
+            want = model(b.to_dict(), compute_forces=True, compute_virial=False)
+        assert torch.equal(got[0], want["energy"].detach()) and torch.equal(got[2], want["forces"].detach()), f"model {seed}"
+        energies.append(got[0].clone())
+        del model, native, got, want
+        gc.collect()
+        torch.cuda.empty_cache()
+    assert not torch.equal(energies[0], energies[1]) and not torch.equal(energies[1], energies[2])

@@ -54,8 +54,28 @@ void need_hip(const Tensor& t, const char* what) {
 // ---------------------------------------------------------------------------------------------- two-layer MLPs
 // Linear-SiLU-Linear on the matrix cores (xeq_mlp2_fwd / _bwd, csrc/xeq_mlp.hip); nn/fused.py::_mlp_fwd / _mlp_bwd are the
 // Python twins.  The fragment-order weight copies are cached per weight tensor and rebuilt when a version counter moves.
+// An entry is valid only while the tensors it was packed from are ALIVE (weak references): a freed parameter's address is
+// reused by the allocator, typically by the next model's parameter of the same shape with the same version count.
+using WeakImpl = c10::weak_intrusive_ptr<c10::TensorImpl>;
+struct Owners {
+  std::vector<WeakImpl> refs;
+  void set(std::initializer_list<const Tensor*> ts) {
+    refs.clear();
+    for (const Tensor* t : ts) refs.emplace_back(t->defined() ? WeakImpl(t->getIntrusivePtr()) : WeakImpl(at::Tensor().getIntrusivePtr()));
+  }
+  bool same(std::initializer_list<const Tensor*> ts) const {
+    if (refs.size() != ts.size()) return false;
+    size_t i = 0;
+    for (const Tensor* t : ts) {
+      auto sp = refs[i++].lock();
+      if (!sp || sp.get() != t->unsafeGetTensorImpl()) return false;
+    }
+    return true;
+  }
+};
 struct MlpPacks {
   int64_t key[8];
+  Owners owners;
   Tensor w1p, w2p, w2tp, w1tp;
 };
 const MlpPacks* mlp_packs(const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2) {
@@ -68,7 +88,7 @@ const MlpPacks* mlp_packs(const Tensor& w1, const Tensor& b1, const Tensor& w2, 
                           (int64_t)w2._version(), (int64_t)(intptr_t)w2.data_ptr(), (int64_t)b2._version(), (int64_t)(intptr_t)b2.data_ptr()};
   std::lock_guard<std::mutex> lock(mu);
   MlpPacks& e = cache[w1.data_ptr()];
-  bool same = e.w1p.defined();
+  bool same = e.w1p.defined() && e.owners.same({&w1, &b1, &w2, &b2});
   for (int i = 0; i < 8 && same; ++i) same = e.key[i] == key[i];
   if (!same) {
     const int h = (int)w1.size(0), k1 = (int)w1.size(1), n2 = (int)w2.size(0);
@@ -83,6 +103,7 @@ const MlpPacks* mlp_packs(const Tensor& w1, const Tensor& b1, const Tensor& w2, 
     e.w2p = pack(w2c, &b2, n2, h, 0);
     e.w2tp = pack(w2c, nullptr, h, n2, 1);
     e.w1tp = pack(w1c, nullptr, k1, h, 1);
+    e.owners.set({&w1, &b1, &w2, &b2});
     for (int i = 0; i < 8; ++i) e.key[i] = key[i];
   }
   return &e;
@@ -116,6 +137,7 @@ Tensor mlp_bwd(const Tensor& g_y, const Tensor& pre, const Tensor& w1, const Ten
 // xeq_update_uv_fwd; nn/fused.py::_packed_uv_frag is the Python twin.  Cached per weight tensor like the MLP packs.
 struct UvFrag {
   int64_t key[8];
+  Owners owners;
   Tensor w[3], wt[3];   // forward ([k_in = mul][n_out = 2 mul], biases folded) and reverse ([n_out = mul][k_in = 2 mul]) packs
 };
 constexpr int64_t UV_BWD_FUSE_NORM_MAX_NODES = 32 * 256;   // nn/fused.py::UV_BWD_FUSE_NORM_MAX_NODES
@@ -132,7 +154,7 @@ const UvFrag* uv_frag(const Tensor* q /* [W0, W1, W2, bias pair] */, int node_di
   int first = 0;
   while (first < 3 && mul[first] == 0) ++first;
   UvFrag& e = cache[q[first].data_ptr()];
-  bool same = e.w[first].defined();
+  bool same = e.w[first].defined() && e.owners.same({&q[0], &q[1], &q[2], &q[3]});
   for (int i = 0; i < 8 && same; ++i) same = e.key[i] == key[i];
   if (!same) {
     for (int l = 0; l < 3; ++l) {
@@ -146,6 +168,7 @@ const UvFrag* uv_frag(const Tensor* q /* [W0, W1, W2, bias pair] */, int node_di
       e.wt[l] = at::empty({xeq_mlp_packed_floats(mul[l], 2 * mul[l])}, W.options());
       XCALL(xeq_mlp_pack((const float*)W.data_ptr(), nullptr, mul[l], 2 * mul[l], 0, (float*)e.wt[l].data_ptr(), cur_stream()));
     }
+    e.owners.set({&q[0], &q[1], &q[2], &q[3]});
     for (int i = 0; i < 8; ++i) e.key[i] = key[i];
   }
   return &e;
