@@ -12,6 +12,7 @@
 // channels for every m with exact-f32 v_mfma_f32_32x32x2_f32 (weights as the A operand: a lane holds four consecutive
 // channels of one node per register quad, so every store is 16 bytes), from weights packed in fragment order
 // (xeq_mlp_pack of [W_U | W_V] / sqrt(mul), the l = 0 biases as one more k-group).
+#include <mutex>
 #include <type_traits>
 
 #include "xeq_common.h"
@@ -707,16 +708,16 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
   const int64_t tiles = (n + UV_ROWS - 1) / UV_ROWS;
   b.ts = tile_split(tiles, fuse ? 1 : min_jobs);
   const dim3 grid(b.ts.grid(tiles));
-  static bool attr_set = false;   // more than 64 KB of dynamic LDS (fused form): opt in once per instantiation
-  if (!attr_set) {
+  static std::once_flag attr_once;   // more than 64 KB of dynamic LDS (fused form): opt in once per process
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
     const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_uv_bwd<128, 64, 32, 128, 1, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_uv_bwd<-1, -1, -1, -1, -1, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    XEQ_CHECK_ARG(e0 == hipSuccess && e1 == hipSuccess, "xeq_update_uv_bwd: cannot raise the dynamic LDS limit: %s",
-                  hipGetErrorString(e0 != hipSuccess ? e0 : e1));
-    attr_set = true;
-  }
+    attr_err = e0 != hipSuccess ? e0 : e1;
+  });
+  XEQ_CHECK_ARG(attr_err == hipSuccess, "xeq_update_uv_bwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr_err));
   const bool dflt = mul[0] == 128 && mul[1] == 64 && mul[2] == 32 && node_dim == 128 && do_norm;
   if (fuse) {
     if (dflt) hipLaunchKernelGGL((k_update_uv_bwd<128, 64, 32, 128, 1, true>), grid, dim3(256), lds, (hipStream_t)stream, b);
