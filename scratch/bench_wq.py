@@ -5,7 +5,7 @@ from xequinet_amd import ops
 from xequinet_amd.data import NeighborTransform, XequiBatch, synthetic as syn
 dev = "cuda"
 args = sys.argv[1:]
-wl = args.pop(0) if args and args[0] in syn.WORKLOADS else "qm9_1024"
+wl = args.pop(0) if args and (args[0] in syn.WORKLOADS or args[0].startswith("qm9_")) else "qm9_1024"
 pos, z, ptr, cell = syn.make_workload(wl, 1234)
 kw = {} if cell is None else dict(pbc=torch.tensor([[True, True, True]], device=dev), cell=torch.tensor(cell, dtype=torch.float32, device=dev))
 b = XequiBatch(torch.tensor(pos, dtype=torch.float32), torch.tensor(z), torch.tensor(ptr)).to(dev)

@@ -909,7 +909,7 @@ def test_reused_edge_graph_follows_new_positions():
 
 
 def test_auto_picks_a_kernel_family_that_fits(monkeypatch):
-    """XEQ_MESSAGE_IMPL=auto looks at the sizes too: beyond the 32-bit byte offsets of the matrix-core kernels it takes
+    """XEQ_MESSAGE_IMPL=auto looks at the sizes too: sb where it is the faster family (ops.prefers_sb), beyond the 32-bit byte offsets of the matrix-core kernels it takes
     the scalar-broadcast form, beyond that one's 32-bit element offsets the generic form; f64 never takes wm."""
     from xequinet_amd import ops
 
@@ -923,7 +923,10 @@ def test_auto_picks_a_kernel_family_that_fits(monkeypatch):
     assert pick(torch.float32, 4_000_000, 1_000_000) == "generic"      # N * 576 elements >= 2^31
     assert pick(torch.float64, 18_609, 311_994) == "sb"
     assert ops.select_message_impl(torch.float32, 100, 1000, 20, 96, (96, 48, 24)) == "sb"   # multiplicities not in 32s
-    assert ops.select_message_impl(torch.float32, 100, 1000, 30, 128, mul) == "wm"            # num_basis > 23
+    assert ops.select_message_impl(torch.float32, 10_000, 100_000, 30, 128, mul) == "wm"      # num_basis > 23
+    assert pick(torch.float32, 1_536, 82_996) == "sb"                  # dense neighbourhoods (water box): sb is the faster family there
+    assert pick(torch.float32, 21, 360) == "sb"                        # one small molecule: launch-bound, sb needs no walk plan
+    assert pick(torch.float32, 1_175, 19_984) == "wq"                  # 64 QM9-shaped molecules: wq from there on
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
     with pytest.raises(RuntimeError):
         ops.select_message_impl(torch.float64, 100, 1000, 20, 128, mul)

@@ -552,8 +552,17 @@ def _message_impl() -> str:
     return impl
 
 
+def prefers_sb(n_nodes: int, n_edges: int) -> bool:
+    """Where the scalar-broadcast kernels beat the matrix-core ones (measured, MI355X): dense neighbourhoods (>= 40 edges per atom:
+    a water box at 54 runs its reverse pass in 169 us against 191) and graphs of a few thousand edges at most (one small molecule:
+    the step is launch-bound and sb needs no walk plan; aspirin replay 0.80 against 0.86 ms).  QM9-shaped batches (17 edges per
+    atom) are faster on wq at every size from 64 molecules up.  csrc/xeq_torch.cpp applies the same rule."""
+    return n_edges >= 40 * max(1, n_nodes) or n_edges < 4096
+
+
 def select_message_impl(dtype, n_nodes: int, n_edges: int, num_basis: int, node_dim: int, mul) -> str:
-    """Kernel family of the fused message for this configuration AND these sizes.  ``auto``: the wave / quad matrix-core
+    """Kernel family of the fused message for this configuration AND these sizes.  ``auto``: the scalar-broadcast form where it is
+    the faster one (``prefers_sb``), else the wave / quad matrix-core
     form (f32, multiplicities in multiples of 32, num_basis <= 23, 32-bit byte offsets: ~1.8 M atoms / ~28 M padded edge
     slots with the default model), else its predecessor wm (num_basis <= 31), else the scalar-broadcast form (f32 / f64, at most 256 channels, 32-bit element offsets), else the generic
     form (64-bit offsets).  An explicit XEQ_MESSAGE_IMPL is taken as is: its kernels raise when they do not fit."""
@@ -567,6 +576,8 @@ def select_message_impl(dtype, n_nodes: int, n_edges: int, num_basis: int, node_
                                "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 23)")
         return impl
     L = lib.load()
+    if prefers_sb(n_nodes, n_edges) and L.xeq_message_sb_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
+        return "sb"
     if dtype == torch.float32 and L.xeq_message_wq_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
         return "wq"
     if dtype == torch.float32 and L.xeq_message_wm_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
