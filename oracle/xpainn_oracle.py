@@ -391,7 +391,11 @@ class XPaiNNOracle:
         data["energy"] = energy
         return data
 
-    def forward(self, data: Dict[str, Tensor], compute_forces: bool = True, compute_virial: bool = False) -> Dict[str, Tensor]:
+    def forward(self, data: Dict[str, Tensor], compute_forces: bool = True, compute_virial: bool = False,
+                training: bool = False) -> Dict[str, Tensor]:
+        """``training=True`` is ``model.train()``: the property gradients keep their graph (create_graph=training,
+        basic.py:143-159) and nothing is detached, so a loss on energies / forces / virial can be differentiated w.r.t.
+        the entries of ``sd``."""
         data = dict(data)
         data[POSITIONS] = data[POSITIONS].detach().clone()
         data = compute_edge_data(data, compute_forces, compute_virial)
@@ -404,17 +408,17 @@ class XPaiNNOracle:
         ones = [torch.ones_like(data["energy"])]
         if compute_forces and compute_virial:
             # compute_forces_and_virial (basic.py:181-199)
-            g, gs = torch.autograd.grad([data["energy"]], [data[POSITIONS], data["strain"]], ones)
+            g, gs = torch.autograd.grad([data["energy"]], [data[POSITIONS], data["strain"]], ones, create_graph=training)
             out["forces"], out["virial"] = -g, -gs
         elif compute_forces:
             # compute_forces_only (basic.py:143-159)
-            (g,) = torch.autograd.grad([data["energy"]], [data[POSITIONS]], ones)
+            (g,) = torch.autograd.grad([data["energy"]], [data[POSITIONS]], ones, create_graph=training)
             out["forces"] = -g
         elif compute_virial:
             # compute_virial_only (basic.py:162-178)
-            (gs,) = torch.autograd.grad([data["energy"]], [data["strain"]], ones)
+            (gs,) = torch.autograd.grad([data["energy"]], [data["strain"]], ones, create_graph=training)
             out["virial"] = -gs
-        return {k: v.detach() for k, v in out.items()}
+        return out if training else {k: v.detach() for k, v in out.items()}
 
     __call__ = forward
 

@@ -127,3 +127,92 @@ def test_gloo_world2_sharded_chunked_inference_equals_unsharded():
     want = _eval_oracle(_tiny_oracle(), pos, z, ptr)
     np.testing.assert_allclose(out["energy"], want["energy"], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(out["forces"], want["forces"], rtol=0, atol=1e-12)
+
+
+# ---- data-parallel optimisation step (xequinet_amd/train.py; run/train.py:185-190, utils/trainer.py:290-308) -----------------
+class _Toy(torch.nn.Module):
+    """Stand-in with the BaseModel call contract (data dict, compute_forces, compute_virial) -> result dict: the XPaiNN
+    training pass itself runs on device tensors only (tests/test_gpu_training.py covers it, two ranks included)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.lin = torch.nn.Linear(3, 1)
+
+    def forward(self, data, compute_forces=True, compute_virial=False):
+        pos = data["pos"].requires_grad_()
+        atom = self.lin(pos * pos).reshape(-1)
+        n_mol = data["ptr"].numel() - 1
+        energy = torch.zeros(n_mol, dtype=atom.dtype).index_add(0, data["batch"], atom)
+        out = {"energy": energy}
+        if compute_forces:
+            (g,) = torch.autograd.grad([energy], [pos], [torch.ones_like(energy)], create_graph=self.training)
+            out["forces"] = -g
+        return out
+
+
+def _toy_batch(rank):
+    g = torch.Generator().manual_seed(10 + rank)
+    pos = torch.randn(12, 3, generator=g, dtype=torch.float64)
+    ptr = torch.tensor([0, 5, 12])
+    data = {"pos": pos, "batch": torch.repeat_interleave(torch.arange(2), ptr[1:] - ptr[:-1]), "ptr": ptr}
+    tgt = {"energy": torch.randn(2, generator=g, dtype=torch.float64), "forces": torch.randn(12, 3, generator=g, dtype=torch.float64), "ptr": ptr}
+    return data, tgt
+
+
+_W = {"energy/atom": 1.0, "forces": 2.0}
+
+
+def _train_worker(rank, world, port, out):
+    from xequinet_amd import train
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    xdist.init_from_env(backend="gloo")
+    model = _Toy().double()
+    ddp = train.wrap_ddp(model)
+    assert ddp is not model
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+    data, tgt = _toy_batch(rank)
+    loss, result = train.train_step(ddp, data, tgt, opt, _W)
+    out[rank] = (loss.item(), model.lin.weight.grad.numpy().copy(), model.lin.weight.detach().numpy().copy())
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_train_step_averages_gradients_and_keeps_replicas_equal():
+    from xequinet_amd import train
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_train_worker, args=(2, port, out), nprocs=2, join=True)
+    grads = []
+    for rank in range(2):        # the same two batches without a process group
+        model = _Toy().double().train()
+        data, tgt = _toy_batch(rank)
+        loss, _ = train.weighted_loss(model(data, True, False), tgt, _W)
+        loss.backward()
+        grads.append(model.lin.weight.grad.numpy())
+        assert abs(loss.item() - out[rank][0]) < 1e-12
+    mean = 0.5 * (grads[0] + grads[1])
+    np.testing.assert_allclose(out[0][1], mean, rtol=1e-12, atol=1e-14)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    model = _Toy().double()
+    np.testing.assert_allclose(out[0][2], model.lin.weight.detach().numpy() - 0.1 * mean, rtol=1e-12)
+
+
+def test_weighted_loss_terms():
+    from xequinet_amd import train
+
+    ptr = torch.tensor([0, 2, 5])
+    res = {"energy": torch.tensor([2.0, 6.0]), "forces": torch.zeros(5, 3)}
+    tgt = {"energy": torch.tensor([0.0, 0.0]), "forces": torch.ones(5, 3), "ptr": ptr}
+    total, terms = train.weighted_loss(res, tgt, {"energy/atom": 2.0, "forces": 0.5}, "l2")
+    assert abs(terms["energy/atom"].item() - (1.0 + 4.0) / 2) < 1e-12 and abs(terms["forces"].item() - 1.0) < 1e-12
+    assert abs(total.item() - (2.0 * 2.5 + 0.5)) < 1e-12
+    assert abs(train.weighted_loss(res, tgt, {"energy": 1.0}, "mae")[0].item() - 4.0) < 1e-12
+    import pytest
+    with pytest.raises(ValueError):
+        train.weighted_loss(res, tgt, {})
+    with pytest.raises(ValueError):
+        train.weighted_loss(res, {"energy": torch.zeros(3)}, {"energy": 1.0})

@@ -1,0 +1,168 @@
+"""Training pass on the GPU: parameter gradients and the double backward of a force / virial loss
+(nn/basic.py:143-199 with create_graph=training, utils/trainer.py:290-308), against the fp64 oracle differentiated by
+autograd w.r.t. its own state-dict entries, plus the data-parallel step (run/train.py:185-190) with two ranks on one card.
+
+Tolerances: fp64 model vs fp64 oracle, relative to the largest entry of each gradient: 1e-8 (two different op orders of
+the same arithmetic); fp32 training pass vs the fused inference kernels on energies / forces: the fp32 bounds of
+tests/test_gpu_parity.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import xpainn_oracle as orc
+from xequinet_amd import keys, train
+from xequinet_amd.data import synthetic as syn
+from xequinet_amd.nn import resolve_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SMALL = dict(node_dim=128, node_irreps="128x0e + 64x1o + 32x2e", action_blocks=2, hidden_dim=64)
+
+
+def _model(dtype, seed=0, **kw):
+    torch.manual_seed(seed)
+    model = resolve_model("xpainn", **kw)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith(("norm.weight", "affine_weight")):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif name.endswith(("bias", "affine_bias")):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    return model.to(dtype).to(DEV)
+
+
+def _batch(n_mol, seed, dtype, periodic=False):
+    if periodic:
+        pos, z, ptr, cell = syn.synth_water_box(3, seed=seed)              # 81 atoms, cubic box of 9.3 A
+        ei, off = orc.radius_graph_pbc_oracle(pos, np.array([len(pos)]), [True, True, True], cell, 5.0)
+        extra = {"cell": cell, "cell_offsets": off}
+    else:
+        pos, z, ptr = syn.synth_qm9_batch(n_mol, seed=seed)
+        ei, extra = orc.radius_graph_canonical(pos, ptr, 5.0), {}
+    batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    host = {"pos": torch.tensor(pos, dtype=torch.float64), "atomic_numbers": torch.tensor(z.astype(np.int64)),
+            "edge_index": torch.tensor(ei), "batch": torch.tensor(batch), "ptr": torch.tensor(ptr)}
+    for k, v in extra.items():
+        host[k] = torch.tensor(v, dtype=torch.float64)
+    dev = {k: (v.to(dtype) if v.is_floating_point() else v).to(DEV) for k, v in host.items()}
+    return host, dev
+
+
+def _targets(host, seed, virial):
+    g = torch.Generator().manual_seed(seed)
+    n_mol, n = host["ptr"].numel() - 1, host["pos"].shape[0]
+    t = {keys.TOTAL_ENERGY: torch.randn(n_mol, generator=g, dtype=torch.float64),
+         keys.FORCES: torch.randn(n, 3, generator=g, dtype=torch.float64), keys.BATCH_PTR: host["ptr"]}
+    if virial:
+        t[keys.VIRIAL] = torch.randn(n_mol, 3, 3, generator=g, dtype=torch.float64)
+    return t
+
+
+@pytest.mark.parametrize("case", ["energy", "energy+forces", "periodic energy+forces+virial"])
+def test_parameter_gradients_match_the_oracle(case):
+    periodic = case.startswith("periodic")
+    weights = {keys.TOTAL_ENERGY: 1.0}
+    if "forces" in case:
+        weights[keys.FORCES] = 10.0
+    if "virial" in case:
+        weights[keys.VIRIAL] = 0.5
+    model = _model(torch.float64, **SMALL).train()
+    host, dev = _batch(6, 5, torch.float64, periodic)
+    tgt = _targets(host, 7, keys.VIRIAL in weights)
+    result = model(dict(dev), keys.FORCES in weights, keys.VIRIAL in weights)
+    loss, _ = train.weighted_loss(result, {k: v.to(DEV) for k, v in tgt.items()}, weights)
+    loss.backward()
+
+    sd = {k: v.detach().cpu().double().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    want = orc.XPaiNNOracle(sd, **SMALL)(host, keys.FORCES in weights, keys.VIRIAL in weights, training=True)
+    ref_loss, _ = train.weighted_loss(want, tgt, weights)
+    names = [n for n, _ in model.named_parameters()]
+    ref_grads = torch.autograd.grad(ref_loss, [sd[n] for n in names], allow_unused=True)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-9 * max(1.0, abs(ref_loss.item()))
+    checked = 0
+    for (name, p), g_ref in zip(model.named_parameters(), ref_grads):
+        if g_ref is None:      # e.g. the head's last bias under a forces-only loss
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, name
+            continue
+        g_ref = g_ref.reshape(p.shape)
+        err = (p.grad.cpu() - g_ref).abs().max().item()
+        assert err <= 1e-8 * max(1e-6, g_ref.abs().max().item()), f"{name}: {err:.2e} of {g_ref.abs().max().item():.2e}"
+        checked += 1
+    assert checked >= len(names) - 1 and checked > 40
+
+
+def test_training_pass_gives_the_inference_numbers():
+    """Same weights, same batch: train mode (differentiable form) against eval mode (the fused kernels), fp32."""
+    model = _model(torch.float32, action_blocks=3)
+    host, dev = _batch(48, 3, torch.float32)
+    model.eval()
+    with torch.enable_grad():
+        want = model(dict(dev), True, False)
+    model.train()
+    got = model(dict(dev), True, False)
+    assert got[keys.FORCES].requires_grad          # create_graph=training
+    dE = (got[keys.TOTAL_ENERGY] - want[keys.TOTAL_ENERGY]).abs().max().item()
+    dF = (got[keys.FORCES] - want[keys.FORCES]).abs()
+    assert dE <= 1e-5 * want[keys.TOTAL_ENERGY].abs().max().item() + 1e-4
+    assert dF.max().item() <= 1e-3 and torch.quantile(dF.flatten(), 0.99).item() <= 1e-4
+
+
+def test_frozen_model_in_train_mode_stays_on_the_fused_path():
+    model = _model(torch.float32, action_blocks=1).requires_grad_(False).train()
+    _, dev = _batch(4, 2, torch.float32)
+    with torch.enable_grad():
+        out = model(dict(dev), True, False)
+    assert not out[keys.FORCES].requires_grad
+
+
+def test_train_step_lowers_the_loss():
+    model = _model(torch.float32, **SMALL)
+    host, dev = _batch(16, 9, torch.float32)
+    tgt = {k: (v.float() if v.is_floating_point() else v).to(DEV) for k, v in _targets(host, 1, False).items()}
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    w = {keys.ENERGY_PER_ATOM: 1.0, keys.FORCES: 1.0}
+    losses = [train.train_step(model, dev, tgt, opt, w, grad_clip=10.0)[0].item() for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+# ---- two ranks on one card: DistributedDataParallel over gloo with device tensors -------------------------------------------
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model = _model(torch.float64, **SMALL).train()
+    ddp = train.wrap_ddp(model, local_rank=0)
+    host, dev = _batch(4, 100 + rank, torch.float64)             # every rank its own molecules
+    tgt = {k: v.to(DEV) for k, v in _targets(host, 50 + rank, False).items()}
+    w = {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 3.0}
+    loss, _ = train.weighted_loss(ddp(dict(dev), True, False), tgt, w)
+    loss.backward()
+    out[rank] = {n: p.grad.cpu().numpy() for n, p in model.named_parameters()}
+    torch.distributed.destroy_process_group()
+
+
+def test_ddp_two_ranks_average_the_gradients():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    # the same two batches in this process, one after the other
+    grads = []
+    for rank in range(2):
+        model = _model(torch.float64, **SMALL).train()
+        host, dev = _batch(4, 100 + rank, torch.float64)
+        tgt = {k: v.to(DEV) for k, v in _targets(host, 50 + rank, False).items()}
+        loss, _ = train.weighted_loss(model(dict(dev), True, False), tgt, {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 3.0})
+        loss.backward()
+        grads.append({n: p.grad.cpu().numpy() for n, p in model.named_parameters()})
+    for n in grads[0]:
+        mean = 0.5 * (grads[0][n] + grads[1][n])
+        scale = max(1e-6, np.abs(mean).max())
+        assert np.abs(out[0][n] - mean).max() <= 1e-10 * scale, n
+        assert np.array_equal(out[0][n], out[1][n]), n            # every rank holds the same averaged gradient

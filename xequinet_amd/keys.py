@@ -32,6 +32,7 @@ ATOMIC_ENERGIES: Final[str] = "atomic_energies"
 TOTAL_ENERGY: Final[str] = "energy"
 FORCES: Final[str] = "forces"
 VIRIAL: Final[str] = "virial"
+ENERGY_PER_ATOM: Final[str] = "energy/atom"     # loss-only property (utils/loss.py:59-67)
 
 TOTAL_CHARGE: Final[str] = "charge"
 

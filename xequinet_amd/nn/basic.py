@@ -90,21 +90,17 @@ def compute_edge_data(
 
 def compute_forces_only(energy: torch.Tensor, pos: torch.Tensor, training: bool = True) -> torch.Tensor:
     """nn/basic.py:143-159"""
-    if training:
-        raise NotImplementedError("xequinet_amd: create_graph=True (training double backward) is out of scope; use model.eval()")
     grad_outputs: Optional[List[Optional[torch.Tensor]]] = [torch.ones_like(energy)]
-    pos_grad = torch.autograd.grad(outputs=[energy], inputs=[pos], grad_outputs=grad_outputs, retain_graph=False,
-                                   create_graph=False, allow_unused=True)[0]
+    pos_grad = torch.autograd.grad(outputs=[energy], inputs=[pos], grad_outputs=grad_outputs, retain_graph=training,
+                                   create_graph=training, allow_unused=True)[0]
     if pos_grad is None:
         pos_grad = torch.zeros_like(pos)
     return -1.0 * pos_grad
 
 
 def _grad(energy, inputs, training):
-    if training:
-        raise NotImplementedError("xequinet_amd: create_graph=True (training double backward) is out of scope; use model.eval()")
-    grads = torch.autograd.grad(outputs=[energy], inputs=inputs, grad_outputs=[torch.ones_like(energy)], retain_graph=False,
-                                create_graph=False, allow_unused=True)
+    grads = torch.autograd.grad(outputs=[energy], inputs=inputs, grad_outputs=[torch.ones_like(energy)], retain_graph=training,
+                                create_graph=training, allow_unused=True)
     return [torch.zeros_like(x) if g is None else g for g, x in zip(grads, inputs)]
 
 

@@ -6,7 +6,8 @@ launch each (``xeq_mlp.hip``), the o3.Linear contractions are plain library GEMM
 views of the internal BT layout, and the reverse pass is explicit (no autograd graph of
 small ops).  Semantics are those of nn/xpainn.py:128-161 and :206-231 of the reference;
 gradients are provided w.r.t. the node features and the edge vectors only (force
-evaluation, nn/basic.py:143-159) -- parameter gradients raise.
+evaluation, nn/basic.py:143-159); a training pass (parameter gradients, double backward) takes
+the differentiable form of the blocks in nn/training.py instead.
 """
 from __future__ import annotations
 
@@ -20,19 +21,6 @@ from torch.autograd.function import once_differentiable
 
 from .. import lib, ops
 from ..lib import call, dtype_code, mul3, ptr, stream
-
-_NO_PARAM_GRAD = ("xequinet_amd: the fused blocks give gradients w.r.t. node features and edge vectors only (force "
-                  "evaluation); parameter gradients (training) are not implemented -- call model.eval()")
-
-
-def check_no_training(module: torch.nn.Module) -> None:
-    """Called by XPainnMessage / XPainnUpdate.forward BEFORE ``Function.apply`` (inside ``Function.forward`` grad mode
-    is always off, so a guard there never fires).  A module in training mode whose parameters ask for gradients would
-    silently get none from these blocks: refuse.  In eval mode (inference under ``torch.enable_grad()``, as
-    run/inference.py:44 does with default ``requires_grad=True`` parameters) the blocks run."""
-    if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError(_NO_PARAM_GRAD)
-
 
 def _bt_blocks(buf: torch.Tensor, n: int, mul, width: int):
     """Views of the BT buffer as plain row-major matrices [n (2l+1), width * mul_l] per non-empty block."""

@@ -8,6 +8,7 @@ from typing import Dict, Iterable, List, Optional, Union
 import torch
 import torch.nn as nn
 
+from . import training
 from .basic import compute_edge_data, compute_properties
 from .output import resolve_output
 from .xpainn import XEmbedding, XPainnMessage, XPainnUpdate
@@ -31,14 +32,22 @@ class BaseModel(nn.Module):
         compute_forces: bool = True,
         compute_virial: bool = False,
     ) -> Dict[str, torch.Tensor]:
-        data = compute_edge_data(data=data, compute_forces=compute_forces, compute_virial=compute_virial)
+        # a training pass (train mode, parameters asking for gradients) runs every block in its differentiable form so
+        # that the force evaluation can itself be differentiated (create_graph=training, nn/basic.py:143-159); everything
+        # else is the fused inference path
+        train_pass = training.wants_training_pass(self)
+        data[training.TRAIN_PASS] = train_pass
+        if train_pass:
+            data = training.edge_data(data, compute_forces=compute_forces, compute_virial=compute_virial)
+        else:
+            data = compute_edge_data(data=data, compute_forces=compute_forces, compute_virial=compute_virial)
         for mod in self.mods.values():
             data = mod(data)
         result = compute_properties(
             data=data,
             compute_forces=compute_forces,
             compute_virial=compute_virial,
-            training=self.training,
+            training=train_pass,
             extra_properties=self.extra_properties,
         )
         return result

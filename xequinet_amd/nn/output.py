@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from .. import keys
 from ..scatter import scatter_sum
+from . import training
 from .basic import resolve_activation
 
 
@@ -47,6 +48,8 @@ class EnergyOut(OutputModule):
         self.extra_properties = [keys.TOTAL_ENERGY, keys.ATOMIC_ENERGIES]
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if training.active(self, data):
+            return training.energy_out(self, data)
         batch = data[keys.BATCH]
         node_scalar = data[keys.NODE_INVARIANT]
         atom_eng_out = self.out_mlp(node_scalar).reshape(-1)

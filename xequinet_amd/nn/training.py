@@ -1,0 +1,231 @@
+"""Training pass of the XPaiNN energy path: parameter gradients and the double backward of a force loss.
+
+The fused inference blocks (nn/fused.py) carry an explicit reverse pass w.r.t. node features and edge vectors only.
+A training step needs dL/dtheta and, when forces enter the loss, the derivative of the force evaluation itself
+(``create_graph=training``, nn/basic.py:143-159).  This module is that pass: the reference's op sequence of every block
+(nn/basic.py:60-140, nn/xpainn.py:57-83, :128-161, :206-231, nn/o3layer.py:12-171, nn/output.py:114-128) written on
+differentiable device tensor operations, so autograd supplies both orders.  It runs on the GPU (device memory, library
+GEMMs, ATen elementwise / index kernels); it is not on the inference hot path and does not use the hand-written
+kernels, and it refuses host tensors like every other entry of the package.
+
+Layout: node features keep the reference's flat irreps layout [N, sum mul (2l+1)], channel-major inside a block; the
+per-edge spherical harmonics are kept once per l ([E, 2l+1]) instead of the reference's mul-fold copies [E, 480].
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F_
+
+from .. import keys, lib
+
+TRAIN_PASS = "_xeq_train_pass"      # data-dict flag set by BaseModel.forward: every block of this pass takes the training form
+_RSH = "_xeq_train_rsh"             # per-l list of Y_l [E, 2l+1] written by the embedding
+
+
+def wants_training_pass(module: torch.nn.Module) -> bool:
+    """A module in training mode whose parameters ask for gradients, with autograd recording."""
+    return module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+def active(module: torch.nn.Module, data: Dict[str, torch.Tensor]) -> bool:
+    flag = data.get(TRAIN_PASS)
+    return wants_training_pass(module) if flag is None else bool(flag)
+
+
+def _blocks(x: torch.Tensor, irreps) -> List[torch.Tensor]:
+    """[N, mul, 2l+1] views of the flat layout, one per block."""
+    return [x[:, off : off + mul * (2 * l + 1)].reshape(x.shape[0], mul, 2 * l + 1) for mul, l, off, _ in irreps.blocks()]
+
+
+def _flat(parts: List[torch.Tensor]) -> torch.Tensor:
+    return torch.cat([p.reshape(p.shape[0], -1) for p in parts], dim=-1)
+
+
+# ---- edge geometry (nn/basic.py:60-140) ---------------------------------------------------------------------------------
+def edge_data(data: Dict[str, torch.Tensor], compute_forces: bool, compute_virial: bool) -> Dict[str, torch.Tensor]:
+    pos = data[keys.POSITIONS]
+    lib.require_hip(pos)
+    ei = data[keys.EDGE_INDEX]
+    if keys.BATCH not in data:
+        data[keys.BATCH] = torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device)
+        data[keys.BATCH_PTR] = torch.tensor([0, pos.shape[0]], dtype=torch.long, device=pos.device)
+    batch = data[keys.BATCH].long()
+    n_graphs = data[keys.BATCH_PTR].numel() - 1
+    has_cell = keys.CELL in data
+    cell = data[keys.CELL] if has_cell else None
+    if compute_forces:
+        pos.requires_grad_()
+    strain = torch.zeros((n_graphs, 3, 3), dtype=pos.dtype, device=pos.device)
+    if compute_virial:
+        strain.requires_grad_()
+        sym = 0.5 * (strain + strain.transpose(1, 2))
+        pos = pos + torch.bmm(pos.unsqueeze(1), sym.index_select(0, batch)).squeeze(1)
+        if has_cell:
+            cell = cell + torch.bmm(cell, sym)
+    center, neighbor = ei[keys.CENTER_IDX].long(), ei[keys.NEIGHBOR_IDX].long()
+    vectors = pos.index_select(0, center) - pos.index_select(0, neighbor)
+    if has_cell:
+        offsets = data[keys.CELL_OFFSETS].to(pos.dtype)
+        cell_e = cell.index_select(0, batch.index_select(0, neighbor))
+        vectors = vectors - torch.einsum("ni,nij->nj", offsets, cell_e)
+    data.update({keys.EDGE_LENGTH: torch.linalg.norm(vectors, dim=-1), keys.EDGE_VECTOR: vectors, keys.STRAIN: strain})
+    return data
+
+
+# ---- radial basis, envelope, spherical harmonics (nn/rbf.py, nn/xpainn.py:66-74) ------------------------------------------
+def radial_basis(rbf: torch.nn.Module, dist: torch.Tensor) -> torch.Tensor:
+    """dist [E, 1] -> [E, num_basis]; the basis parameters (freq / mean, std) are trainable as in the reference."""
+    if rbf.kind == "bessel":        # nn/rbf.py:148-152
+        return rbf.coeff * torch.sin(rbf.freq * dist) / (dist + rbf.eps)
+    if rbf.kind == "gaussian":      # nn/rbf.py:128-131
+        std = rbf.std.abs() + rbf.eps
+        return torch.exp(-0.5 * ((dist - rbf.mean) / std) ** 2) / (std * math.sqrt(2 * math.pi))
+    raise NotImplementedError(f"radial basis {rbf.kind}")
+
+
+def envelope(cutoff_fn: torch.nn.Module, dist: torch.Tensor) -> torch.Tensor:
+    rc = cutoff_fn.cutoff
+    if cutoff_fn.kind == "cosine":          # nn/rbf.py:43-57
+        val = 0.5 * (torch.cos(math.pi * dist / rc) + 1.0)
+    elif cutoff_fn.kind == "polynomial":    # nn/rbf.py:60-73, order 3
+        r = dist / rc
+        val = 1.0 - 10.0 * r**3 + 15.0 * r**4 - 6.0 * r**5
+    else:
+        raise NotImplementedError(f"cutoff function {cutoff_fn.kind}")
+    return torch.where(dist < rc, val, torch.zeros_like(dist))
+
+
+def spherical_harmonics(vectors: torch.Tensor, lmax: int) -> List[torch.Tensor]:
+    """Component-normalised Y_l of the unit edge vector for l = 0..lmax in the order the reference gets from
+    ``sph_harm(vectors[:, [1, 2, 0]])``: e3nn's (x, y, z) are the edge vector's (y, z, x)."""
+    u = vectors / torch.linalg.norm(vectors, dim=-1, keepdim=True).clamp_min(1e-12)
+    x, y, z = u[:, 1], u[:, 2], u[:, 0]
+    out = [torch.ones_like(x).unsqueeze(-1)]
+    if lmax >= 1:
+        out.append(math.sqrt(3.0) * torch.stack([x, y, z], dim=-1))
+    if lmax >= 2:
+        c15, c5 = math.sqrt(15.0), math.sqrt(5.0)
+        out.append(torch.stack([c15 * x * z, c15 * x * y, c5 * (y * y - 0.5 * (x * x + z * z)), c15 * y * z,
+                                0.5 * c15 * (z * z - x * x)], dim=-1))
+    if lmax >= 3:
+        raise NotImplementedError("l > 2")
+    return out
+
+
+def embedding(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """XEmbedding.forward (nn/xpainn.py:57-83)."""
+    z = data[keys.ATOMIC_NUMBERS]
+    vectors = data[keys.EDGE_VECTOR]
+    lib.require_hip(vectors)
+    s = module.embedding(z.long() if isinstance(module.embedding, torch.nn.Embedding) else z)
+    dist = data[keys.EDGE_LENGTH].unsqueeze(-1)
+    data[keys.NODE_INVARIANT] = s
+    data[keys.RADIAL_BASIS_FUNCTION] = radial_basis(module.rbf, dist)
+    data[keys.ENVELOPE_FUNCTION] = envelope(module.cutoff_fn, dist)
+    data[_RSH] = spherical_harmonics(vectors, module.node_irreps.lmax)
+    data[keys.NODE_EQUIVARIANT] = torch.zeros((s.shape[0], module.node_irreps.dim), dtype=s.dtype, device=s.device)
+    return data
+
+
+# ---- normalisation (nn.LayerNorm, nn/o3layer.py:145-171) -------------------------------------------------------------------
+def equivariant_layer_norm(norm, x: torch.Tensor) -> torch.Tensor:
+    irreps = norm.irreps
+    parts = _blocks(x, irreps)
+    is_scalar = [ir.l == 0 and ir.p == 1 for _, ir in irreps]
+    n_scalar = sum(mul for (mul, _), sc in zip(irreps, is_scalar) if sc)
+    mean = sum(p.sum(dim=(1, 2)) for p, sc in zip(parts, is_scalar) if sc) / n_scalar           # over all even scalars
+    parts = [p - mean.view(-1, 1, 1) if sc else p for p, sc in zip(parts, is_scalar)]
+    sq = torch.cat([(p * p).sum(-1) for p in parts], dim=-1)                                    # [N, num_irreps]
+    inv_rms = torch.rsqrt(sq.mean(dim=1, keepdim=True) + norm.eps).unsqueeze(-1)
+    out, ch, sc_off = [], 0, 0
+    for p, sc in zip(parts, is_scalar):
+        mul = p.shape[1]
+        q = p * inv_rms * norm.affine_weight[ch : ch + mul].view(1, mul, 1)
+        if sc:
+            q = q + norm.affine_bias[sc_off : sc_off + mul].view(1, mul, 1)
+            sc_off += mul
+        out.append(q)
+        ch += mul
+    return _flat(out)
+
+
+def _norms(module, s: torch.Tensor, x: torch.Tensor):
+    if isinstance(module.norm, torch.nn.Identity):
+        return s, x
+    return module.norm(s), equivariant_layer_norm(module.o3norm, x)
+
+
+# ---- message (nn/xpainn.py:128-161) --------------------------------------------------------------------------------------------
+def message(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    s0, x0 = data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT]
+    lib.require_hip(s0)
+    irreps, C = module.node_irreps, module.node_num_irreps
+    ei = data[keys.EDGE_INDEX]
+    center, neighbor = ei[keys.CENTER_IDX].long(), ei[keys.NEIGHBOR_IDX].long()
+    s, x = _norms(module, s0, x0)
+    scalar_out = module.scalar_mlp(s)
+    filt = module.rbf_lin(data[keys.RADIAL_BASIS_FUNCTION]) * data[keys.ENVELOPE_FUNCTION]
+    filt = scalar_out.index_select(0, neighbor) * filt
+    gate_state, gate_edge, msg_s = torch.split(filt, [C, C, module.node_dim], dim=-1)
+    x_j = _blocks(x.index_select(0, neighbor), irreps)
+    rsh = data[_RSH]
+    msg_x, ch = [], 0
+    for (mul, ir), xb in zip(irreps, x_j):
+        gs = gate_state[:, ch : ch + mul].unsqueeze(-1)
+        ge = gate_edge[:, ch : ch + mul].unsqueeze(-1)
+        msg_x.append(xb * gs + rsh[ir.l].unsqueeze(1) * ge)        # l x 0e -> l, component normalisation: factor 1
+        ch += mul
+    data[keys.NODE_INVARIANT] = s0.index_add(0, center, msg_s)
+    data[keys.NODE_EQUIVARIANT] = x0.index_add(0, center, _flat(msg_x))
+    return data
+
+
+# ---- update (nn/xpainn.py:206-231) -----------------------------------------------------------------------------------------------
+def o3_linear(lin, x: torch.Tensor) -> List[torch.Tensor]:
+    """o3.Linear(irreps, irreps, biases=True): out[w, m] = mul^-1/2 sum_u W_l[u, w] x[u, m] (+ bias on 0e), per block."""
+    out, woff, boff = [], 0, 0
+    for (mul, ir), xb in zip(lin.irreps_in, _blocks(x, lin.irreps_in)):
+        W = lin.weight[woff : woff + mul * mul].view(mul, mul)
+        woff += mul * mul
+        ob = torch.einsum("uw,num->nwm", W, xb) * (1.0 / math.sqrt(mul))
+        if ir.l == 0 and ir.p == 1 and lin.bias.numel() > 0:
+            ob = ob + lin.bias[boff : boff + mul].view(1, mul, 1)
+            boff += mul
+        out.append(ob)
+    return out
+
+
+def update(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    s0, x0 = data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT]
+    lib.require_hip(s0)
+    C, F = module.node_num_irreps, module.node_dim
+    s, x = _norms(module, s0, x0)
+    U, V = o3_linear(module.update_U, x), o3_linear(module.update_V, x)
+    eps = module.invariant.eps
+    v_norm = torch.cat([torch.sqrt((v * v).sum(-1) + eps**2) - eps for v in V], dim=-1)          # Invariant, o3layer.py:40-44
+    a_vv, a_sv, a_ss = torch.split(module.update_mlp(torch.cat([s, v_norm], dim=-1)), [C, F, F], dim=-1)
+    d_x, ch = [], 0
+    for u in U:
+        mul = u.shape[1]
+        d_x.append(u * a_vv[:, ch : ch + mul].unsqueeze(-1))
+        ch += mul
+    inner = module.dot_lin(torch.cat([(u * v).sum(-1) for u, v in zip(U, V)], dim=-1))           # EquivariantDot + dot_lin
+    data[keys.NODE_INVARIANT] = s0 + a_sv * inner + a_ss
+    data[keys.NODE_EQUIVARIANT] = x0 + _flat(d_x)
+    return data
+
+
+# ---- energy head (nn/output.py:114-128) --------------------------------------------------------------------------------------------
+def energy_out(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    lib.require_hip(data[keys.NODE_INVARIANT])
+    atom = module.out_mlp(data[keys.NODE_INVARIANT]).reshape(-1)
+    if keys.ATOMIC_ENERGIES in data:
+        atom = data[keys.ATOMIC_ENERGIES] + atom
+    n_graphs = data[keys.BATCH_PTR].numel() - 1
+    total = torch.zeros(n_graphs, dtype=atom.dtype, device=atom.device).index_add(0, data[keys.BATCH].long(), atom)
+    data[keys.ATOMIC_ENERGIES] = atom
+    data[keys.TOTAL_ENERGY] = total
+    return data

@@ -15,7 +15,8 @@ import torch.nn as nn
 
 from .. import keys, o3, ops
 from .basic import Int2c1eEmbedding, edge_graph, resolve_activation
-from .fused import MessageBlock, UpdateBlock, check_no_training
+from . import training
+from .fused import MessageBlock, UpdateBlock
 from .o3layer import EquivariantDot, EquivariantLayerNorm, Invariant
 from .rbf import resolve_cutoff, resolve_rbf
 
@@ -56,6 +57,8 @@ class XEmbedding(nn.Module):
         self.materialize_edge_basis = materialize_edge_basis
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if training.active(self, data):   # parameter gradients / double backward: the differentiable form
+            return training.embedding(self, data)
         atomic_numbers = data[keys.ATOMIC_NUMBERS]
         vectors = data[keys.EDGE_VECTOR]
         ops.lib.require_hip(vectors)
@@ -112,6 +115,8 @@ class XPainnMessage(nn.Module):
         self.fused = True  # False: run the reference's op sequence on the operator-level drop-ins
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if training.active(self, data):
+            return training.message(self, data)
         ori_scalar = data[keys.NODE_INVARIANT]
         ori_equi = data[keys.NODE_EQUIVARIANT]
         if RADIAL_SPEC not in data:
@@ -120,7 +125,6 @@ class XPainnMessage(nn.Module):
         if rbf.num_basis != self.num_basis:
             raise ValueError(f"num_basis mismatch: embedding {rbf.num_basis} vs message {self.num_basis}")
         if self.fused:  # block-level path: explicit forward/reverse, see nn/fused.py
-            check_no_training(self)
             new_scalar, new_equi = MessageBlock.apply(ori_scalar, ori_equi, data[keys.EDGE_VECTOR], self, edge_graph(data), rbf, cutoff_fn)
         else:           # operator-level path (the reference's own op sequence on the drop-in ops)
             node_scalar = self.norm(ori_scalar)
@@ -174,8 +178,9 @@ class XPainnUpdate(nn.Module):
         self.equivariant_output_unused = False
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if training.active(self, data):
+            return training.update(self, data)
         if self.fused:
-            check_no_training(self)
             s_new, x_new = UpdateBlock.apply(data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT], self)
             data[keys.NODE_INVARIANT] = s_new
             data[keys.NODE_EQUIVARIANT] = x_new
