@@ -1,0 +1,32 @@
+"""Training-step time of the differentiable pass (nn/training.py) on one GPU: QM9-shaped batch, Adam, l2 loss.
+usage: python scratch/bench_train.py [n_mol] [energy|forces]"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from xequinet_amd import keys, train
+from xequinet_amd.data import synthetic as syn, NeighborTransform, XequiBatch
+from xequinet_amd.nn import resolve_model
+
+n_mol = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+mode = sys.argv[2] if len(sys.argv) > 2 else "forces"
+dev = "cuda"
+pos, z, ptr = syn.synth_qm9_batch(n_mol, seed=1234)
+b = NeighborTransform(5.0)(XequiBatch(torch.tensor(pos, dtype=torch.float32, device=dev), torch.tensor(z, device=dev), torch.tensor(ptr, device=dev)))
+data = b.to_dict()
+E = data["edge_index"].shape[1]
+torch.manual_seed(0)
+model = resolve_model("xpainn").to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+g = torch.Generator().manual_seed(0)
+tgt = {keys.TOTAL_ENERGY: torch.randn(n_mol, generator=g).to(dev), keys.FORCES: torch.randn(len(pos), 3, generator=g).to(dev), keys.BATCH_PTR: data["ptr"]}
+w = {keys.TOTAL_ENERGY: 1.0} if mode == "energy" else {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 10.0}
+def step():
+    d = {k: v for k, v in data.items() if not k.startswith("_")}
+    d["pos"] = d["pos"].detach().clone()
+    return train.train_step(model, d, tgt, opt, w)[0]
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+K = 10
+for _ in range(K): l = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+print(f"train step ({mode} loss) n_mol={n_mol} N={len(pos)} E={E}: {dt*1e3:.2f} ms/step, {E/dt/1e6:.1f} M edges/s, peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss {l.item():.4f}")
