@@ -356,7 +356,13 @@ int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
                        int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out, int xhat_layout,
                        void* stream);
 int64_t xeq_message_wq_parts_floats(int64_t n_nodes, int64_t n_edges, const int32_t mul[3]);   /* a size, not a status */
-/* grad_h / grad_xhat may both be NULL: only the per-edge partials (dL/dvec) are formed. */
+/* grad_h / grad_xhat may both be NULL: only the per-edge partials (dL/dvec) are formed.
+ * xhat_layout of the _wq entries carries an optional hint: xhat_layout | XEQ_XHAT_HIGHER_L_ZERO promises that xhat is zero on
+ * every l > 0 column.  That is the model's first message block (XEmbedding hands over x = 0, nn/xpainn.py:76-81, and the
+ * equivariant layer norm of zero is zero off the 0e columns): the forward kernel then drops the gate_state term of the l > 0
+ * units with its filter and gathers (bit-identical results), the reverse kernel (with grad_h NULL) drops the value filters
+ * and pass S of the l > 0 units.  The other kernel families accept the hint and ignore it. */
+#define XEQ_XHAT_HIGHER_L_ZERO 2
 int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* n_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis,
                        const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,

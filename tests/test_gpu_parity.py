@@ -950,3 +950,55 @@ def test_exclusive_scan_grid_wide_matches_numpy(n):
     call("xeq_exclusive_scan_i32", ptr(d), n, ptr(out1), stream())
     np.testing.assert_array_equal(out1.cpu().numpy(), want)
     assert lib.load().xeq_exclusive_scan_i32_workspace(-1) == -1
+
+
+@pytest.mark.parametrize("irreps,node_dim,B", [("128x0e + 64x1o + 32x2e", 128, 20), ("32x0e + 64x2e", 32, 17), ("64x0e + 32x1o + 32x2e", 64, 8)])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_wq_first_block_hint_changes_nothing(irreps, node_dim, B, layout, monkeypatch):
+    """XEQ_XHAT_HIGHER_L_ZERO (include/xeq.h): with xhat zero on the l > 0 columns -- the model's first message block --
+    the hinted kernels skip the gate_state terms there and, in a force evaluation, the value filters of the reverse pass.
+    Forward: the same bits as the general kernel; reverse (no node gradients): dL/dvec to rounding (the order of the
+    per-edge sums is unchanged, a zero term is left out)."""
+    from xequinet_amd import lib, ops
+
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wq")
+    rng = np.random.default_rng(5)
+    pos, z, ptr = syn.synth_qm9_batch(40, seed=21)
+    rc = 4.0
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, rc)
+    N, E = len(pos), ei.shape[1]
+    mul = [0, 0, 0]
+    for m_, l_, _ in orc.parse_irreps(irreps):
+        mul[l_] = m_
+    C, D = sum(mul), mul[0] + 3 * mul[1] + 5 * mul[2]
+    H = node_dim + 2 * C
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    h, s = f32(rng.normal(size=(N, H))), f32(rng.normal(size=(N, node_dim)))
+    x = torch.zeros(N, D, device=DEV)
+    xhat = torch.zeros(N, D, device=DEV)
+    bias0 = f32(rng.normal(size=mul[0]))
+    if layout == 0:
+        xhat[:, : mul[0]] = bias0                                # e3nn layout: the 0e block leads every row
+    else:
+        xhat = xhat.reshape(-1)
+        xhat[: N * mul[0]] = bias0.repeat(N)                     # BT layout: block l = 0 is [N, mul0] row-major
+    W, b = f32(rng.normal(size=(H, B)) / math.sqrt(B)), f32(rng.normal(size=(H,)))
+    p0 = f32(math.pi * np.arange(1, B + 1) / rc).view(1, -1)
+    vec = f32(pos[ei[0]] - pos[ei[1]])
+    gs, gx = f32(rng.normal(size=(N, node_dim))), f32(rng.normal(size=(N, D)))
+    outs = []
+    for hint in (0, lib.XHAT_HIGHER_L_ZERO):
+        graph = ops.EdgeGraph(_t(ei), N, ptr=_t(ptr))
+        cfg = ("bessel", "cosine", B, rc, node_dim, tuple(mul), layout | hint)
+        s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, W, b, p0, None, graph, cfg)
+        assert impl == "wq"
+        g_h, g_xhat, g_vec, _, _ = ops.message_backward(saved, graph, cfg, impl, gs, gx, node_grads=False)
+        assert g_h is None and g_xhat is None
+        g_full = ops.message_backward(saved, graph, cfg, impl, gs, gx, node_grads=True)
+        outs.append((s_out, x_out, g_vec, g_full))
+    (s0, x0, v0, f0), (s1, x1, v1, f1) = outs
+    assert torch.equal(s0, s1) and torch.equal(x0, x1)
+    scale = v0.abs().max().item()
+    assert (v0 - v1).abs().max().item() <= 2e-6 * scale
+    for a_, b_ in zip(f0, f1):      # with node gradients wanted the hint does not apply to the reverse kernel
+        assert torch.equal(a_, b_)

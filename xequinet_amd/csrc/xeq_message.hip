@@ -350,7 +350,7 @@ int xeq_message_fwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
   a.rowptr = rowptr;
   a.perm = perm;
   a.other = nbr;
-  a.xl = xhat_layout;
+  a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
   dim3 grid(msg_grid(n_nodes));
   XEQ_DISPATCH_FLOAT(dtype, {
     XEQ_MSG_DISPATCH_B(k_message_fwd, a, (const T*)vec, (const T*)h, (const T*)xhat, (const T*)s_in,
@@ -374,7 +374,7 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
   a.rowptr = n_rowptr;
   a.perm = n_perm;
   a.other = center;
-  a.xl = xhat_layout;
+  a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
   dim3 grid(msg_grid(n_nodes));
   XEQ_DISPATCH_FLOAT(dtype, {
     XEQ_MSG_DISPATCH_B(k_message_bwd, a, (const T*)vec, (const T*)h, (const T*)xhat, (const T*)grad_s,

@@ -503,7 +503,7 @@ int xeq_message_fwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.rowptr = rowptr;
   a.perm = perm;
   a.other = nbr;
-  a.xl = xhat_layout;
+  a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
   XEQ_SB_DISPATCH(k_message_fwd_sb, 2, 2, a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)s_in, (const T*)x_in,
                   (const T*)w_rbf, (const T*)b_rbf, (T*)s_out, (T*)x_out);
@@ -523,7 +523,7 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.rowptr = n_rowptr;
   a.perm = n_perm;
   a.other = center;
-  a.xl = xhat_layout;
+  a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
   XEQ_SB_DISPATCH(k_message_bwd_sb, 1, 1, a, (const T*)basis, (const T*)dbasis, (const T*)h, (const T*)xhat,
                   (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat,

@@ -1054,7 +1054,7 @@ int xeq_message_fwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   a.perm = c_perm;
   a.owner = center;
   a.gather = nbr;
-  a.xl = xhat_layout;
+  a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
   XEQ_CHECK_ARG(n_ranges >= 1, "%s: the stream table must cover every node (n_ranges >= 1)", "xeq_message_wm");
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
   dim3 grid(wm_grid(n_ranges, nunits));
@@ -1078,7 +1078,7 @@ int xeq_message_bwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   a.perm = n_perm;
   a.owner = nbr;
   a.gather = center;
-  a.xl = xhat_layout;
+  a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
   XEQ_CHECK_ARG(n_ranges >= 1, "%s: the stream table must cover every node (n_ranges >= 1)", "xeq_message_wm");
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
   WmParts pr;

@@ -454,10 +454,20 @@ __device__ __forceinline__ float wq_lds(const float* win, uint32_t byte_off) {
 
 // window of the forward pass: per row the unit's pieces of h (gate_state | gate_edge | scalar message for l = 0) and of
 // xhat (NM pieces: component m in BT layout; the contiguous run of 32 NM floats in e3nn layout)
-template <int NM>
+// XZ (l > 0 only): xhat is zero on the unit's columns (first block of the model), so only the gate_edge piece is staged
+template <int NM, bool XZ>
 __device__ __forceinline__ void wq_stage_fwd(const WqArgs& a, const WqUnit& un, const WqCols& wc, const float* __restrict__ h,
                                              const float* __restrict__ xhat_, int w0, int nrows, float* win) {
   constexpr int NH = NM == 1 ? 3 : 2, NSL = NH + NM;
+  if constexpr (XZ && NM > 1) {
+    const int total = nrows * 8;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+      const int row = idx >> 3, chunk = idx & 7;
+      *reinterpret_cast<f32x4*>(win + (row * NSL + 1) * 32 + 4 * chunk) =
+          *reinterpret_cast<const f32x4*>(h + (int64_t)(w0 + row) * a.H + a.C + un.u0 + 4 * chunk);
+    }
+    return;
+  }
   const int total = nrows * NSL * 8;   // 16-byte chunks
   const int64_t xnode = wc.xnode_b / 4, xcomp = a.xl == 0 ? 32 : wc.xcomp_b / 4;
   constexpr int UN = 8;                // loads in flight per thread before the first LDS store
@@ -484,7 +494,7 @@ __device__ __forceinline__ void wq_stage_fwd(const WqArgs& a, const WqUnit& un, 
 
 //   x_c += xhat[n] (h_state[n] phi_state) + Y (h_edge[n] phi_edge);   s_c += h_msg[n] phi_msg   (l = 0)
 // WIN: the gathered rows of this step are in the LDS window (first node w0); otherwise they are read from global memory
-template <int NM, int KS, bool WIN>
+template <int NM, int KS, bool WIN, bool XZ>
 __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const WqUnit un, const WqCols& wc,
                                             const float* __restrict__ rec, const float* __restrict__ h,
                                             const float* __restrict__ xhat_, const float* __restrict__ s_in,
@@ -492,6 +502,7 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
                                             float* __restrict__ x_out, int* tbl, const float* win, int w0,
                                             unsigned long long* st_, unsigned long long& last_) {
   constexpr bool HAS_S = NM == 1;
+  constexpr bool NO_STATE = XZ && NM > 1;   // xhat = 0 on these columns: the gate_state term vanishes with its filter and gathers
   constexpr int YOFF = NM == 3 ? 0 : 3;
   constexpr int NH = NM == 1 ? 3 : 2, ROWB = (NH + NM) * 128;
   const int lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
@@ -588,25 +599,30 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
         const int v = r0 + u;
         if constexpr (WIN) {
           const uint32_t oh = g0[v] + 4u * (uint32_t)j;
-          hs[u] = wq_lds(win, oh);
+          if constexpr (!NO_STATE) hs[u] = wq_lds(win, oh);
           he[u] = wq_lds(win, oh + 128u);
           if constexpr (HAS_S) hm[u] = wq_lds(win, oh + 256u);
+          if constexpr (!NO_STATE) {
 #pragma unroll
-          for (int m = 0; m < NM; ++m) xv[u][m] = wq_lds(win, g0[v] + lxm[m]);
+            for (int m = 0; m < NM; ++m) xv[u][m] = wq_lds(win, g0[v] + lxm[m]);
+          }
         } else {
           const uint32_t oh = g0[v] + wc.b_hs, ox = g1[v] + wc.b_x;
-          hs[u] = wq_ld(h, oh);
+          if constexpr (!NO_STATE) hs[u] = wq_ld(h, oh);
           he[u] = wq_ld(h_e, oh);
           if constexpr (HAS_S) hm[u] = wq_ld(h_m, oh);
+          if constexpr (!NO_STATE) {
 #pragma unroll
-          for (int m = 0; m < NM; ++m) xv[u][m] = wq_ld(xhat_m[m], ox);
+            for (int m = 0; m < NM; ++m) xv[u][m] = wq_ld(xhat_m[m], ox);
+          }
         }
       }
       XEQ_WQ_FSB();
       WQ_STAMP(6);   // phase B issued
       if (r0 == 0) {   // ---- phase C
-        ds = wq_filter<KS>(R, Ws);
         de = wq_filter<KS>(R, We);
+        ds = de;
+        if constexpr (!NO_STATE) ds = wq_filter<KS>(R, Ws);
         dm = ds;
         if constexpr (HAS_S) dm = wq_filter<KS>(R, Wm);
         XEQ_WQ_FSB();
@@ -628,9 +644,15 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
           const int v = 4 * g + r, u = v - r0;
           // explicit fma chains (this file is built with -ffp-contract=off): the window and the global instantiation of
           // this body must round alike, or a node's result would depend on which one its step took
-          const float gs = hs[u] * ds[v], ge = he[u] * de[v];
+          const float ge = he[u] * de[v];
+          if constexpr (NO_STATE) {   // fma(0, gs, c) = c: the same bits as the general form on xhat = 0
 #pragma unroll
-          for (int m = 0; m < NM; ++m) xq[m] = __builtin_fmaf(xv[u][m], gs, NM > 1 ? __builtin_fmaf(Y[m][r], ge, xq[m]) : xq[m] + ge);
+            for (int m = 0; m < NM; ++m) xq[m] = __builtin_fmaf(Y[m][r], ge, xq[m]);
+          } else {
+            const float gs = hs[u] * ds[v];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) xq[m] = __builtin_fmaf(xv[u][m], gs, NM > 1 ? __builtin_fmaf(Y[m][r], ge, xq[m]) : xq[m] + ge);
+          }
           if constexpr (HAS_S) sq = __builtin_fmaf(hm[u], dm[v], sq);
         }
 #pragma unroll
@@ -659,7 +681,7 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
 #endif
 
 // one role of the forward kernel: the workgroup's steps, each with its window staged first when it fits
-template <int NM, int KS>
+template <int NM, int KS, bool XZ>
 __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_end, const WqUnit un, const float* __restrict__ rec,
                                             const float* __restrict__ h, const float* __restrict__ xhat,
                                             const float* __restrict__ s_in, const float* __restrict__ x_in, const float* wl,
@@ -678,14 +700,14 @@ __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_en
     const bool use_win = nrows > 0 && nrows * ROWB <= WQ_WIN_FLOATS * 4;   // workgroup-uniform
 #endif
     WQ_STAMP(0);   // step head
-    if (use_win) wq_stage_fwd<NM>(a, un, wc, h, xhat, w0, nrows, win);
+    if (use_win) wq_stage_fwd<NM, XZ>(a, un, wc, h, xhat, w0, nrows, win);
     WQ_STAMP(1);   // window staged
     __syncthreads();
     WQ_STAMP(2);   // barrier behind the staging
     const int range = step * WQ_WAVES + (threadIdx.x >> 6);
     if (range < a.n_ranges) {
-      if (use_win) wq_fwd_body<NM, KS, true>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, w0, st_, last_);
-      else wq_fwd_body<NM, KS, false>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, 0, st_, last_);
+      if (use_win) wq_fwd_body<NM, KS, true, XZ>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, w0, st_, last_);
+      else wq_fwd_body<NM, KS, false, XZ>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, 0, st_, last_);
     }
     WQ_STAMP(3);   // body prologue (isolated nodes, first record) -- what the tile stamps did not take
     __syncthreads();   // the window and the tile tables are rewritten by the next step
@@ -699,7 +721,9 @@ __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_en
 #endif
 }
 
-template <int KS>
+// XZ: xhat is zero on every l > 0 column (the model's first message block: XEmbedding hands over x = 0, and the
+// equivariant layer norm of zero is zero there); the l = 0 role is the general one
+template <int KS, bool XZ>
 __global__ void __launch_bounds__(64 * WQ_WAVES) __attribute__((amdgpu_waves_per_eu(XEQ_WQ_FWD_WPE)))
 k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restrict__ h, const float* __restrict__ xhat,
                  const float* __restrict__ s_in, const float* __restrict__ x_in, const float* __restrict__ w_rbf,
@@ -715,16 +739,16 @@ k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
   __syncthreads();
   int* tbl = tbl_all[threadIdx.x >> 6];
 #ifdef XEQ_WQ_ONLY_L   // development: register budget of one role
-  if (un.l == XEQ_WQ_ONLY_L) wq_fwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  if (un.l == XEQ_WQ_ONLY_L) wq_fwd_role<2 * XEQ_WQ_ONLY_L + 1, KS, XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
   return;
 #endif
 #ifdef XEQ_WQ_ROLE_TIME_FWD   // development: where and when every workgroup of the production body ran
   unsigned long long rr0_;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr0_)::"memory");
 #endif
-  if (un.l == 0) wq_fwd_role<1, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
-  else if (un.l == 1) wq_fwd_role<3, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
-  else wq_fwd_role<5, KS>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  if (un.l == 0) wq_fwd_role<1, KS, false>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  else if (un.l == 1) wq_fwd_role<3, KS, XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  else wq_fwd_role<5, KS, XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
 #ifdef XEQ_WQ_ROLE_TIME_FWD
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
     unsigned long long rr1_;
@@ -807,7 +831,7 @@ __device__ __forceinline__ void wq_stage_bwd(const WqArgs& a, const WqUnit& un, 
   }
 }
 
-template <int NM, int KS, bool WIN>
+template <int NM, int KS, bool WIN, bool FIRST>
 __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit, const WqUnit un, const WqCols& wc,
                                             const float* __restrict__ rec, const float* __restrict__ drec,
                                             const float* __restrict__ h, const float* __restrict__ xhat_,
@@ -822,7 +846,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   const float* __restrict__ xhat = xhat_ + wc.x_base;
   float* __restrict__ grad_xhat = grad_xhat_ + wc.x_base;
   const uint32_t he_off = 4u * (uint32_t)a.C, row_h = 4u * (uint32_t)a.H;
-  const bool node_grads = grad_h != nullptr;   // NULL: only dL/dvec is wanted (first block of a force evaluation)
+  // grad_h NULL: only dL/dvec is wanted (first block of a force evaluation).  FIRST knows it at compile time (the value
+  // filters, the owners' sums and their stores drop out as dead code) and knows xhat = 0 on the l > 0 columns (pass S,
+  // whose every term carries a factor xhat, is not run there)
+  const bool node_grads = !FIRST && grad_h != nullptr;
   wq_for_isolated(a, range, lane, [&](int m) {   // nobody's neighbor: zero gradients on the unit's columns
     if (hh == 0 && node_grads) {
       wq_st(grad_h, (uint32_t)m * row_h + wc.b_hs, 0.f);
@@ -894,7 +921,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
       for (int r = 0; r < 4; ++r) gv[r] = WIN ? wq_lds(win, g0[r] + lgx + 4u * m) : wq_ld(grad_x, g0[r] + wc.b_xe + 4u * m);
     };
-    {  // ---- pass S
+    if constexpr (FIRST && NM > 1) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) pd[v] = 0.f;
+    } else {  // ---- pass S
       const f32x16 ds = wq_filter<KS>(R, Ws), qs = wq_filter<KS>(Rd, Ws);
       WQ_STAMP(6);   // MFMA issue (all passes)
 #pragma unroll
@@ -1064,7 +1094,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   }
 }
 
-template <int NM, int KS>
+template <int NM, int KS, bool FIRST>
 __device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int s_beg, int s_end, int unit, const WqUnit un, const float* __restrict__ rec,
                                             const float* __restrict__ drec, const float* __restrict__ h,
                                             const float* __restrict__ xhat, const float* __restrict__ grad_s,
@@ -1090,8 +1120,8 @@ __device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int s_beg, int s_en
     WQ_STAMP(2);
     const int range = step * WQ_WAVES + (threadIdx.x >> 6);
     if (range < a.n_ranges) {
-      if (use_win) wq_bwd_body<NM, KS, true>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, w0, st_, last_);
-      else wq_bwd_body<NM, KS, false>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, 0, st_, last_);
+      if (use_win) wq_bwd_body<NM, KS, true, FIRST>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, w0, st_, last_);
+      else wq_bwd_body<NM, KS, false, FIRST>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, 0, st_, last_);
     }
     WQ_STAMP(3);
     __syncthreads();
@@ -1108,7 +1138,9 @@ __device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int s_beg, int s_en
 #endif
 }
 
-template <int KS>
+// FIRST: the model's first message block in a force evaluation -- no node gradients are wanted (grad_h, grad_xhat NULL)
+// and xhat is zero on every l > 0 column
+template <int KS, bool FIRST>
 __global__ void __launch_bounds__(64 * WQ_WAVES) __attribute__((amdgpu_waves_per_eu(XEQ_WQ_BWD_WPE)))
 k_message_bwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restrict__ drec, const float* __restrict__ h,
                  const float* __restrict__ xhat, const float* __restrict__ grad_s, const float* __restrict__ grad_x,
@@ -1126,16 +1158,16 @@ k_message_bwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
   int* tbl = tbl_all[threadIdx.x >> 6];
 #ifdef XEQ_WQ_ONLY_L   // development: register budget of one role
   if (un.l == XEQ_WQ_ONLY_L)
-    wq_bwd_role<2 * XEQ_WQ_ONLY_L + 1, KS>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+    wq_bwd_role<2 * XEQ_WQ_ONLY_L + 1, KS, FIRST>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
   return;
 #endif
 #ifdef XEQ_WQ_ROLE_TIME   // development: where and when every workgroup of the production body ran
   unsigned long long rr0_;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr0_)::"memory");
 #endif
-  if (un.l == 0) wq_bwd_role<1, KS>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
-  else if (un.l == 1) wq_bwd_role<3, KS>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
-  else wq_bwd_role<5, KS>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+  if (un.l == 0) wq_bwd_role<1, KS, FIRST>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+  else if (un.l == 1) wq_bwd_role<3, KS, FIRST>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
+  else wq_bwd_role<5, KS, FIRST>(a, s_beg, s_end, unit, un, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win);
 #ifdef XEQ_WQ_ROLE_TIME
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
     unsigned long long rr1_;
@@ -1257,12 +1289,17 @@ static void wq_geometry(WqArgs& a, int nunits, unsigned& grid) {
 using namespace xeq;
 
 // KS covers K = B + 1 (bias column) in steps of two
-#define XEQ_WQ_DISPATCH(KERNEL, ...)                                                                                   \
-  do {                                                                                                                 \
-    const int ks = (num_basis + 2) / 2;                                                                                \
-    if (ks <= 6) hipLaunchKernelGGL((KERNEL<6>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);      \
-    else if (ks <= 11) hipLaunchKernelGGL((KERNEL<11>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<12>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);             \
+#define XEQ_WQ_DISPATCH_KS(KERNEL, FLAG, ...)                                                                                \
+  do {                                                                                                                       \
+    const int ks = (num_basis + 2) / 2;                                                                                      \
+    if (ks <= 6) hipLaunchKernelGGL((KERNEL<6, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);      \
+    else if (ks <= 11) hipLaunchKernelGGL((KERNEL<11, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<12, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);             \
+  } while (0)
+#define XEQ_WQ_DISPATCH(KERNEL, flag, ...)                   \
+  do {                                                       \
+    if (flag) XEQ_WQ_DISPATCH_KS(KERNEL, true, __VA_ARGS__); \
+    else XEQ_WQ_DISPATCH_KS(KERNEL, false, __VA_ARGS__);     \
   } while (0)
 
 extern "C" {
@@ -1348,13 +1385,14 @@ int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   a.rowptr = c_rowptr;
   a.pgath = pgath;
   a.qinfo = (const uint32_t*)qinfo;
-  a.xl = xhat_layout;
+  a.xl = xhat_layout & 1;
+  const bool x_zero = (xhat_layout & XEQ_XHAT_HIGHER_L_ZERO) != 0;
   a.win = win;
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
   unsigned nblocks;
   wq_geometry(a, nunits, nblocks);
   dim3 grid(nblocks);
-  XEQ_WQ_DISPATCH(k_message_fwd_wq, a, (const float*)basis, (const float*)h, (const float*)xhat, (const float*)s_in,
+  XEQ_WQ_DISPATCH(k_message_fwd_wq, x_zero, a, (const float*)basis, (const float*)h, (const float*)xhat, (const float*)s_in,
                   (const float*)x_in, (const float*)w_rbf, (const float*)b_rbf, (float*)s_out, (float*)x_out);
   XEQ_CHECK_LAUNCH("xeq_message_fwd_wq");
   return XEQ_OK;
@@ -1378,7 +1416,8 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   a.rowptr = n_rowptr;
   a.pgath = pgath;
   a.qinfo = (const uint32_t*)qinfo;
-  a.xl = xhat_layout;
+  a.xl = xhat_layout & 1;
+  const bool first = (xhat_layout & XEQ_XHAT_HIGHER_L_ZERO) != 0 && grad_h == nullptr;
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
   WqParts pr;
   pr.P = a.pcap;
@@ -1389,7 +1428,7 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   unsigned nblocks;
   wq_geometry(a, nunits, nblocks);
   dim3 grid(nblocks);
-  XEQ_WQ_DISPATCH(k_message_bwd_wq, a, (const float*)basis, (const float*)dbasis, (const float*)h, (const float*)xhat,
+  XEQ_WQ_DISPATCH(k_message_bwd_wq, first, a, (const float*)basis, (const float*)dbasis, (const float*)h, (const float*)xhat,
                   (const float*)grad_s, (const float*)grad_x, (const float*)w_rbf, (const float*)b_rbf, (float*)grad_h,
                   (float*)grad_xhat, pr);
   XEQ_CHECK_LAUNCH("xeq_message_bwd_wq");

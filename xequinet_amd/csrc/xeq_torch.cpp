@@ -452,7 +452,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                                  (const int32_t*)g.fwd.win.data_ptr(), (const int32_t*)g.fwd.rowptr.data_ptr(),
                                  (const int32_t*)g.fwd.pgath.data_ptr(), (const int32_t*)g.fwd.qinfo.data_ptr(), g.fwd.basis.data_ptr(),
                                  m.h.data_ptr(), m.xhat.data_ptr(), s.data_ptr(), x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B,
-                                 F, mul, s_out.data_ptr(), x_out.data_ptr(), 1, st));
+                                 F, mul, s_out.data_ptr(), x_out.data_ptr(), b == 0 ? (1 | XEQ_XHAT_HIGHER_L_ZERO) : 1, st));   // block 0: x = 0
       } else {
         XCALL(xeq_message_fwd_sb(dt, N, E, (const int32_t*)g.c_rowptr.data_ptr(),
                                  g.c_perm.defined() ? (const int32_t*)g.c_perm.data_ptr() : nullptr,
@@ -574,7 +574,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                                    (const int32_t*)g.rev.pgath.data_ptr(), (const int32_t*)g.rev.qinfo.data_ptr(),
                                    g.rev.basis.data_ptr(), g.rev.dbasis.data_ptr(), m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(),
                                    g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B, F, mul, node_grads ? g_h.data_ptr() : nullptr,
-                                   node_grads ? g_xhat.data_ptr() : nullptr, parts.data_ptr(), 1, st));
+                                   node_grads ? g_xhat.data_ptr() : nullptr, parts.data_ptr(), b == 0 ? (1 | XEQ_XHAT_HIGHER_L_ZERO) : 1, st));
           XCALL(xeq_message_wq_edge_grad(vec.data_ptr(), N, E, (const int32_t*)g.rev.qptr.data_ptr(),
                                          (const int32_t*)g.rev.peid.data_ptr(), mul, parts.data_ptr(), g_vec.data_ptr(), st));
         } else {

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XEQ_LIB_PATH") or os.path.join(_HERE, "libxeq_hip.so")   # XEQ_LIB_PATH: development builds
 
 XEQ_F32, XEQ_F64 = 0, 1
+XHAT_HIGHER_L_ZERO = 2   # XEQ_XHAT_HIGHER_L_ZERO of include/xeq.h: hint bit on the xhat_layout argument of the wq message kernels
 RBF_KINDS = {"bessel": 0, "gaussian": 1}
 CUTOFF_KINDS = {"cosine": 0, "polynomial": 1}
 

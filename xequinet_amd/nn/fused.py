@@ -136,7 +136,9 @@ class MessageBlock(Function):
         shat, xhat, stats, do_norm = _norm_fwd(s, x, module.norm, module.o3norm, F, mul)
         pre, h = _mlp_fwd(module.scalar_mlp, shat)
         p0, p1 = rbf.params()
-        cfg = (rbf.kind, cutoff_fn.kind, module.num_basis, float(cutoff_fn.cutoff), F, mul, 1)  # xhat in BT layout
+        # xhat in BT layout; behind XEmbedding x is zero, hence xhat is zero on every l > 0 column (include/xeq.h)
+        xl = 1 | (lib.XHAT_HIGHER_L_ZERO if module.equivariant_input_zero else 0)
+        cfg = (rbf.kind, cutoff_fn.kind, module.num_basis, float(cutoff_fn.cutoff), F, mul, xl)
         s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, module.rbf_lin.weight, module.rbf_lin.bias,
                                                         p0, p1, graph, cfg)
         ctx.none_mask = [t is None for t in saved]

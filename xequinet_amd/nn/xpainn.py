@@ -113,6 +113,9 @@ class XPainnMessage(nn.Module):
         self.o3norm = EquivariantLayerNorm(self.node_irreps) if layer_norm else nn.Identity()
         self._mul = self.node_irreps.mul3()
         self.fused = True  # False: run the reference's op sequence on the operator-level drop-ins
+        # set by the model on its first message block: the equivariant features it receives are XEmbedding's zeros
+        # (nn/xpainn.py:76-81), so every term that carries a factor xhat_{l>0} is skipped by the kernels
+        self.equivariant_input_zero = False
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if training.active(self, data):
