@@ -1,7 +1,7 @@
 """Per-evaluation table from a rocprofv3 kernel_stats.csv of bench.py: python scratch/stats_table.py <csv>"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = max(int(r["Calls"]) for r in rows if "k_message_fwd" in r["Name"]) / 3
+ev = sum(int(r["Calls"]) for r in rows if "k_message_fwd" in r["Name"]) / 3   # three message blocks per evaluation
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"evaluations {ev:.0f}; kernel time per evaluation {tot / ev / 1e3:.1f} us")
 g = {}

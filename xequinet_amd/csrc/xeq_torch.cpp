@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <mutex>
+#include <optional>
 #include <unordered_map>
 #include <vector>
 
@@ -54,21 +55,31 @@ void need_hip(const Tensor& t, const char* what) {
 // ---------------------------------------------------------------------------------------------- two-layer MLPs
 // Linear-SiLU-Linear on the matrix cores (xeq_mlp2_fwd / _bwd, csrc/xeq_mlp.hip); nn/fused.py::_mlp_fwd / _mlp_bwd are the
 // Python twins.  The fragment-order weight copies are cached per weight tensor and rebuilt when a version counter moves.
-// An entry is valid only while the tensors it was packed from are ALIVE (weak references): a freed parameter's address is
+// An entry is valid only while the storage it was packed from is ALIVE (weak references): a freed parameter's address is
 // reused by the allocator, typically by the next model's parameter of the same shape with the same version count.
-using WeakImpl = c10::weak_intrusive_ptr<c10::TensorImpl>;
+// The references are to the STORAGE (not the tensor object): XPaiNNNative hands over fresh views of one flat parameter
+// buffer on every call -- same storage, same address, shared version counter -- and those must hit the cache.
+using WeakStore = c10::weak_intrusive_ptr<c10::StorageImpl>;
 struct Owners {
-  std::vector<WeakImpl> refs;
+  std::vector<std::optional<WeakStore>> refs;   // nullopt: an undefined tensor (absent bias)
   void set(std::initializer_list<const Tensor*> ts) {
     refs.clear();
-    for (const Tensor* t : ts) refs.emplace_back(t->defined() ? WeakImpl(t->getIntrusivePtr()) : WeakImpl(at::Tensor().getIntrusivePtr()));
+    for (const Tensor* t : ts) {
+      if (t->defined() && t->has_storage()) refs.emplace_back(t->storage().getWeakStorageImpl());
+      else refs.emplace_back(std::nullopt);
+    }
   }
   bool same(std::initializer_list<const Tensor*> ts) const {
     if (refs.size() != ts.size()) return false;
     size_t i = 0;
     for (const Tensor* t : ts) {
-      auto sp = refs[i++].lock();
-      if (!sp || sp.get() != t->unsafeGetTensorImpl()) return false;
+      const bool d = t->defined() && t->has_storage();
+      if (d != refs[i].has_value()) return false;
+      if (d) {
+        auto sp = refs[i]->lock();
+        if (!sp || sp.get() != t->storage().unsafeGetStorageImpl()) return false;
+      }
+      ++i;
     }
     return true;
   }
