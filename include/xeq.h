@@ -207,6 +207,13 @@ int xeq_segment_sum(int dtype, const void* src, const int64_t* ptr, int64_t n_se
 int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n, int64_t width, void* out,
                     int64_t n_out, void* stream);
 
+/* Up to XEQ_COPY_MANY_MAX device-to-device copies in ONE launch: dst[i][0 .. bytes[i]) = src[i][...] (whole aligned 4-byte
+ * words, buffers must not overlap).  src / dst / bytes are HOST arrays.  HIP-graph replay (runtime.GraphedModel) refreshes
+ * the captured inputs of an evaluation with it -- the per-step tensor hand-over the reference does with `data.to(device)`
+ * (run/inference.py:39). */
+#define XEQ_COPY_MANY_MAX 16
+int xeq_copy_many(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);
+
 /* One instruction of a general Clebsch-Gordan e3nn.o3.TensorProduct (nn/tp.py:20-107 builds the instruction lists;
  * nn/xe3net.py:133-146 'uuu', nn/output.py:411-421 'uuw'):
  *   out[n, off_out + w (2 l3 + 1) + k] += coeff * sum_{u,v} W[..] sum_{i,j} cg[i,j,k] x1[n, off1 + u (2 l1 + 1) + i] x2[n, off2 + v (2 l2 + 1) + j]

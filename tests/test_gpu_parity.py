@@ -1002,3 +1002,28 @@ def test_wq_first_block_hint_changes_nothing(irreps, node_dim, B, layout, monkey
     assert (v0 - v1).abs().max().item() <= 2e-6 * scale
     for a_, b_ in zip(f0, f1):      # with node gradients wanted the hint does not apply to the reverse kernel
         assert torch.equal(a_, b_)
+
+
+def test_copy_many_one_launch_for_a_list_of_copies():
+    """ops.copy_many / xeq_copy_many: what HIP-graph replay refreshes its captured inputs with.  Sizes from one word to a few
+    MB, 4-byte aligned views (the narrow path), more buffers than one launch takes, and the Tensor.copy_ fall-backs."""
+    from xequinet_amd import ops
+
+    g = torch.Generator(device=DEV).manual_seed(0)
+    pairs = []
+    for i, n in enumerate([1, 3, 4, 17, 1000, 4096, 65537, 1 << 20, 5, 12, 999, 2, 8, 16, 33, 64, 127, 300001, 7]):
+        dt = (torch.float32, torch.int32, torch.int64, torch.float64)[i % 4]
+        src = torch.randint(-1000, 1000, (n + 1,), device=DEV, generator=g).to(dt)
+        dst = torch.zeros(n + 1, dtype=dt, device=DEV)
+        if i % 3 == 0:
+            src, dst = src[1:], dst[1:]                    # 4-byte (or 8-byte) aligned, not 16
+        else:
+            src, dst = src[:n], dst[:n]
+        pairs.append((dst, src))
+    mism = (torch.zeros(10, dtype=torch.int64, device=DEV), torch.arange(10, dtype=torch.int32, device=DEV))   # dtype conversion
+    strided = (torch.zeros(6, 2, device=DEV), torch.arange(24., device=DEV).reshape(6, 4)[:, ::2])             # non-contiguous source
+    ops.copy_many(pairs + [mism, strided])
+    for dst, src in pairs:
+        assert torch.equal(dst, src)
+    assert torch.equal(mism[0], mism[1].long()) and torch.equal(strided[0], strided[1])
+    ops.copy_many([])

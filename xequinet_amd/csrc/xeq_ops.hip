@@ -324,6 +324,29 @@ static inline int check_irreps(const int32_t mul[3], Irreps& ir, const char* who
   return XEQ_OK;
 }
 
+// several small device-to-device copies in one launch (blockIdx.y = buffer); HIP-graph replay refreshes its captured
+// inputs with it instead of a dozen 3 us copy launches
+struct CopyMany {
+  const char* src[XEQ_COPY_MANY_MAX];
+  char* dst[XEQ_COPY_MANY_MAX];
+  int64_t bytes[XEQ_COPY_MANY_MAX];
+  bool wide[XEQ_COPY_MANY_MAX];
+};
+__global__ void k_copy_many(CopyMany cm) {
+  const int b = blockIdx.y;
+  const int64_t bytes = cm.bytes[b];
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  if (cm.wide[b]) {
+    const uint4* s = reinterpret_cast<const uint4*>(cm.src[b]);
+    uint4* d = reinterpret_cast<uint4*>(cm.dst[b]);
+    for (int64_t i = i0; i < bytes / 16; i += stride) d[i] = s[i];
+  } else {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(cm.src[b]);
+    uint32_t* d = reinterpret_cast<uint32_t*>(cm.dst[b]);
+    for (int64_t i = i0; i < bytes / 4; i += stride) d[i] = s[i];
+  }
+}
+
 }  // namespace xeq
 
 using namespace xeq;
@@ -482,6 +505,29 @@ int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n,
                        (const T*)src, index, n, width, (T*)out, n_out);
   });
   XEQ_CHECK_LAUNCH("xeq_scatter_add");
+  return XEQ_OK;
+}
+
+/* development-free plumbing: see include/xeq.h */
+int xeq_copy_many(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && n <= XEQ_COPY_MANY_MAX, "xeq_copy_many: %d buffers (at most %d)", n, XEQ_COPY_MANY_MAX);
+  xeq::CopyMany cm{};
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    XEQ_CHECK_ARG(bytes[i] >= 0 && bytes[i] % 4 == 0 && ((uintptr_t)src[i] % 4 == 0) && ((uintptr_t)dst[i] % 4 == 0),
+                  "xeq_copy_many: buffer %d is not a whole number of aligned 4-byte words", i);
+    cm.src[i] = (const char*)src[i];
+    cm.dst[i] = (char*)dst[i];
+    cm.bytes[i] = bytes[i];
+    cm.wide[i] = bytes[i] % 16 == 0 && (uintptr_t)src[i] % 16 == 0 && (uintptr_t)dst[i] % 16 == 0;
+    most = bytes[i] > most ? bytes[i] : most;
+  }
+  if (n == 0 || most == 0) return XEQ_OK;
+  // 16 bytes per thread and trip; the widest buffer takes at most 64 workgroups per trip of the grid-stride loop
+  const int64_t wg = (most / 16 + 255) / 256;
+  hipLaunchKernelGGL(xeq::k_copy_many, dim3((unsigned)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg)), (unsigned)n), dim3(256), 0,
+                     (hipStream_t)stream, cm);
+  XEQ_CHECK_LAUNCH("xeq_copy_many");
   return XEQ_OK;
 }
 

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XEQ_LIB_PATH") or os.path.join(_HERE, "libxeq_hip.so")   # XEQ_LIB_PATH: development builds
 
 XEQ_F32, XEQ_F64 = 0, 1
+COPY_MANY_MAX = 16       # XEQ_COPY_MANY_MAX of include/xeq.h
 XHAT_HIGHER_L_ZERO = 2   # XEQ_XHAT_HIGHER_L_ZERO of include/xeq.h: hint bit on the xhat_layout argument of the wq message kernels
 RBF_KINDS = {"bessel": 0, "gaussian": 1}
 CUTOFF_KINDS = {"cosine": 0, "polynomial": 1}
@@ -56,6 +57,7 @@ _PROTOS = {
     "xeq_eqln_fwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
     "xeq_eqln_bwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
     "xeq_segment_sum": [c_int, _P, _P, c_int64, c_int64, _P, _P],
+    "xeq_copy_many": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), _P],
     "xeq_tensor_product_path": [c_int, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, _P, _P, c_int64, c_double, _P, _P],
     "xeq_scatter_add": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, _P],

@@ -678,6 +678,29 @@ def edge_basis(vec, graph: EdgeGraph, rbf_kind, cutoff_kind, num_basis, cutoff, 
     return basis, dbasis
 
 
+def copy_many(pairs) -> None:
+    """dst.copy_(src) for a list of (dst, src) device tensors in ONE launch (xeq_copy_many) -- same dtype, same number of
+    elements, both contiguous; anything else takes Tensor.copy_."""
+    import ctypes
+
+    fast = []
+    for dst, src in pairs:
+        if (dst.is_cuda and src.is_cuda and dst.device == src.device and dst.dtype == src.dtype and dst.numel() == src.numel()
+                and dst.is_contiguous() and src.is_contiguous() and (dst.numel() * dst.element_size()) % 4 == 0):
+            if dst.numel() > 0 and dst.data_ptr() != src.data_ptr():
+                fast.append((dst, src))
+        else:
+            dst.copy_(src, non_blocking=True)
+    cap = lib.COPY_MANY_MAX
+    for i in range(0, len(fast), cap):
+        grp = fast[i : i + cap]
+        n = len(grp)
+        srcs = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t in grp])
+        dsts = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in grp])
+        sizes = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t, _ in grp])
+        call("xeq_copy_many", n, srcs, dsts, sizes, stream())
+
+
 def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg):
     """Launch the fused message kernel.  cfg = (rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul[, xhat_layout]).
     Returns (s_out, x_out, saved, impl): `saved` is what message_backward needs."""

@@ -112,20 +112,18 @@ class GraphedModel:
 
     @staticmethod
     def _refresh(c: _Captured, data, eg: ops.EdgeGraph) -> None:
-        for k, t in c.inputs.items():
-            if k in data:
-                t.copy_(data[k], non_blocking=True)
+        """The new inputs and CSR arrays go into the captured buffers in one launch (ops.copy_many)."""
+        pairs = [(t, data[k]) for k, t in c.inputs.items() if k in data]
+        s = c.edge_graph
+        pairs += [(s.c_rowptr, eg.c_rowptr), (s.n_rowptr, eg.n_rowptr), (s.n_perm, eg.n_perm)]
+        if s.c_perm is not None:
+            pairs.append((s.c_perm, eg.c_perm))
+        ops.copy_many(pairs)
         if c.derived_batch:   # the caller gave ptr only: the graph index per atom follows the CURRENT ptr
             ptr = c.inputs[keys.BATCH_PTR]
             counts = ptr[1:] - ptr[:-1]
             c.inputs[keys.BATCH].copy_(torch.repeat_interleave(torch.arange(counts.numel(), device=ptr.device), counts,
                                                                output_size=c.inputs[keys.POSITIONS].shape[0]))
-        s = c.edge_graph
-        s.c_rowptr.copy_(eg.c_rowptr, non_blocking=True)
-        s.n_rowptr.copy_(eg.n_rowptr, non_blocking=True)
-        s.n_perm.copy_(eg.n_perm, non_blocking=True)
-        if s.c_perm is not None:
-            s.c_perm.copy_(eg.c_perm, non_blocking=True)
 
     # --------------------------------------------------------------------- call
     def __call__(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
