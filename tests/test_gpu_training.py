@@ -63,15 +63,20 @@ def _targets(host, seed, virial):
     return t
 
 
-@pytest.mark.parametrize("case", ["energy", "energy+forces", "periodic energy+forces+virial"])
+VARIANT = dict(node_dim=64, node_irreps="64x0e + 32x1o + 32x2e", action_blocks=2, hidden_dim=32, num_basis=12,
+               rbf_kernel="gaussian", cutoff_fn="polynomial", layer_norm=False, activation="tanh")
+
+
+@pytest.mark.parametrize("case", ["energy", "energy+forces", "periodic energy+forces+virial", "variant energy+forces"])
 def test_parameter_gradients_match_the_oracle(case):
     periodic = case.startswith("periodic")
+    cfg = VARIANT if case.startswith("variant") else SMALL   # variant: gaussian basis (trainable mean / std), polynomial envelope, no layer norm, tanh
     weights = {keys.TOTAL_ENERGY: 1.0}
     if "forces" in case:
         weights[keys.FORCES] = 10.0
     if "virial" in case:
         weights[keys.VIRIAL] = 0.5
-    model = _model(torch.float64, **SMALL).train()
+    model = _model(torch.float64, **cfg).train()
     host, dev = _batch(6, 5, torch.float64, periodic)
     tgt = _targets(host, 7, keys.VIRIAL in weights)
     result = model(dict(dev), keys.FORCES in weights, keys.VIRIAL in weights)
@@ -79,7 +84,7 @@ def test_parameter_gradients_match_the_oracle(case):
     loss.backward()
 
     sd = {k: v.detach().cpu().double().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
-    want = orc.XPaiNNOracle(sd, **SMALL)(host, keys.FORCES in weights, keys.VIRIAL in weights, training=True)
+    want = orc.XPaiNNOracle(sd, **cfg)(host, keys.FORCES in weights, keys.VIRIAL in weights, training=True)
     ref_loss, _ = train.weighted_loss(want, tgt, weights)
     names = [n for n, _ in model.named_parameters()]
     ref_grads = torch.autograd.grad(ref_loss, [sd[n] for n in names], allow_unused=True)
@@ -93,7 +98,7 @@ def test_parameter_gradients_match_the_oracle(case):
         err = (p.grad.cpu() - g_ref).abs().max().item()
         assert err <= 1e-8 * max(1e-6, g_ref.abs().max().item()), f"{name}: {err:.2e} of {g_ref.abs().max().item():.2e}"
         checked += 1
-    assert checked >= len(names) - 1 and checked > 40
+    assert checked >= len(names) - 1 and checked >= 38     # 38 parameter tensors without layer norms, 54 with
 
 
 def test_training_pass_gives_the_inference_numbers():
