@@ -74,19 +74,11 @@ class XEmbedding(nn.Module):
             with torch.no_grad():  # [x, y, z] -> [y, z, x]  (nn/xpainn.py:71-74)
                 data[keys.SPHERICAL_HARMONICS] = self.sph_harm(vectors.detach()[:, [1, 2, 0]])
 
-        data[keys.NODE_EQUIVARIANT] = self._zero_equivariant(node_invariant)
+        node_equivariant = torch.zeros(
+            (node_invariant.shape[0], self.node_irreps.dim), dtype=node_invariant.dtype, device=node_invariant.device
+        )
+        data[keys.NODE_EQUIVARIANT] = node_equivariant
         return data
-
-    def _zero_equivariant(self, like: torch.Tensor) -> torch.Tensor:
-        """The all-zero initial equivariant features (nn/xpainn.py:76-81).  Nothing on the inference path writes into them
-        (every block returns new tensors), so one buffer per shape is kept and handed out again instead of filling 1.9 kB per
-        atom on every evaluation; autograd never sees it (it does not require grad)."""
-        n = like.shape[0]
-        z = getattr(self, "_zeros", None)
-        if z is None or z.shape[0] != n or z.dtype != like.dtype or z.device != like.device:
-            z = torch.zeros((n, self.node_irreps.dim), dtype=like.dtype, device=like.device)
-            self._zeros = z
-        return z
 
 
 class XPainnMessage(nn.Module):
