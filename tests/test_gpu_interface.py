@@ -375,3 +375,35 @@ def test_native_operator_never_reuses_the_weight_packs_of_a_dead_model():
         gc.collect()
         torch.cuda.empty_cache()
     assert not torch.equal(energies[0], energies[1]) and not torch.equal(energies[1], energies[2])
+
+
+def test_replay_follows_a_weight_update():
+    """A captured graph reads packed weight copies made at capture time; an in-place update of the parameters drops the graphs
+    (runtime.GraphedModel._parameter_state), so replay and the eager model keep agreeing."""
+    from xequinet_amd import runtime
+    from xequinet_amd.data import NeighborTransform, XequiBatch, synthetic as syn
+    from xequinet_amd.nn import resolve_model
+
+    torch.manual_seed(0)
+    model = resolve_model("xpainn", action_blocks=2).eval().requires_grad_(False).to("cuda")
+    pos, z, ptr = syn.synth_qm9_batch(8, seed=4)
+    batch = NeighborTransform(5.0)(XequiBatch(torch.tensor(pos, dtype=torch.float32, device="cuda"), torch.tensor(z, device="cuda"),
+                                              torch.tensor(ptr, device="cuda")))
+    g = runtime.GraphedModel(model, tune_gemms=False)
+
+    def both():
+        r = {k: v.clone() for k, v in g(batch.to_dict()).items()}
+        with torch.enable_grad():
+            e = model(batch.to_dict(), compute_forces=True, compute_virial=False)
+        return r, e
+
+    r0, e0 = both()
+    assert torch.equal(r0["forces"], e0["forces"]) and g.captures == 1
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.05)
+    r1, e1 = both()
+    assert g.captures == 2
+    assert torch.equal(r1["forces"], e1["forces"]) and not torch.equal(r1["forces"], r0["forces"])
+    r2, _ = both()
+    assert g.captures == 2 and torch.equal(r2["forces"], r1["forces"])

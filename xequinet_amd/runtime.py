@@ -54,8 +54,23 @@ class GraphedModel:
         self.warmup = warmup
         self._cache: "OrderedDict[tuple, _Captured]" = OrderedDict()
         self.captures = 0
+        self._tracked = None
+        self._param_state = self._parameter_state()
 
     # ------------------------------------------------------------------ helpers
+    def _parameter_state(self) -> tuple:
+        """Version counters of every parameter / buffer.  A captured graph reads the matrix-core kernels' PACKED weight copies
+        (made when the graph was captured) next to the live tensors the library GEMMs read: after an in-place update
+        (optimizer step, load_state_dict) a replay would mix old and new weights, so the graphs are dropped and re-captured.
+        The tensor list is taken once (walking the module tree costs more than a small evaluation); replacing parameter
+        OBJECTS of a captured model needs a new GraphedModel."""
+        if self._tracked is None:
+            m = self.model
+            while not isinstance(m, torch.nn.Module) and hasattr(m, "model"):    # a plain callable around a module (md_model._Core)
+                m = m.model
+            self._tracked = (list(m.parameters()) + list(m.buffers())) if isinstance(m, torch.nn.Module) else []
+        return tuple([t._version for t in self._tracked])
+
     def _signature(self, data, eg: ops.EdgeGraph) -> tuple:
         pos = data[keys.POSITIONS]
         return (tuple(pos.shape), pos.dtype, pos.device.index, int(data[keys.EDGE_INDEX].shape[1]),
@@ -127,6 +142,10 @@ class GraphedModel:
 
     # --------------------------------------------------------------------- call
     def __call__(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        state = self._parameter_state()
+        if state != self._param_state:      # weights changed since the graphs were captured
+            self._cache.clear()
+            self._param_state = state
         eg = self._edge_graph(data)
         sig = self._signature(data, eg)
         c = self._cache.get(sig)
