@@ -89,7 +89,7 @@ def test_tensor_product_kernel_matches_oracle(mode, has_w, shared, dtype, tol):
     got = mod(x.to(dtype).cuda(), y.to(dtype).cuda(), None if (w is None or (shared and has_w)) else w.to(dtype).cuda())
     assert got.shape == (x.shape[0], out.dim)
     scale = max(1.0, float(want.abs().max()))
-    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(got.detach().cpu().double().numpy(), want.numpy(), rtol=0, atol=tol * scale)
 
 
 @pytest.mark.gpu
@@ -110,10 +110,10 @@ def test_tensor_product_is_equivariant_and_normalised():
     for improper in (False, True):
         wv = RNG.normal(size=3)
         D1, D2, Do = D(in1, wv, improper), D(in2, wv, improper), D(out, wv, improper)
-        a = mod((x @ D1.T).cuda(), (y @ D2.T).cuda()).cpu()
-        b = mod(x.cuda(), y.cuda()).cpu() @ Do.T
+        a = mod((x @ D1.T).cuda(), (y @ D2.T).cuda()).detach().cpu()
+        b = mod(x.cuda(), y.cuda()).detach().cpu() @ Do.T
         np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-10)
-    z = mod(x.cuda(), y.cuda()).cpu()
+    z = mod(x.cuda(), y.cuda()).detach().cpu()
     assert 0.2 < float(z.pow(2).mean()) < 5.0
     # l x l -> 0e is the scaled dot product, 1o x 1o -> 1e the cross product (in the (y, z, x) component order)
     one = tp.TensorProduct("1x1o", "1x1o", "1x0e+1x1e", [(0, 0, 0, "uuu", False, 1.0), (0, 0, 1, "uuu", False, 1.0)]).to("cuda")
@@ -122,3 +122,52 @@ def test_tensor_product_is_equivariant_and_normalised():
     np.testing.assert_allclose(np.abs(r[:, 0]), np.abs((u * v).sum(1).numpy()) / math.sqrt(3), atol=1e-12)
     cross = np.cross(u.numpy(), v.numpy())[:, [1, 2, 0]]
     assert min(np.abs(r[:, 1:] - cross / math.sqrt(2)).max(), np.abs(r[:, 1:] + cross / math.sqrt(2)).max()) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,has_w,shared", [("uuu", True, True), ("uuu", False, True), ("uuw", True, False), ("uuw", True, True),
+                                               ("uvw", True, True), ("uvw", True, False), ("uvu", True, True), ("uvu", True, False),
+                                               ("uvv", True, False), ("uvv", True, True)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 3e-5)])
+def test_tensor_product_gradients_match_oracle(mode, has_w, shared, dtype, tol):
+    """dL/dx1, dL/dx2 (the same kernel on a permuted 3j table, tp._REVERSE) and dL/dW against the oracle's einsums
+    differentiated by autograd, L = <out, G> with a random G."""
+    mod, in1, in2, out, ins, x, y, w, _ = _case(mode, has_w, shared)
+    g = torch.Generator().manual_seed(11)
+    G = torch.randn(x.shape[0], out.dim, generator=g, dtype=torch.float64)
+    # oracle (fp64, CPU)
+    xr, yr = x.clone().requires_grad_(), y.clone().requires_grad_()
+    wr = None if w is None else w.clone().requires_grad_()
+    l_of = lambda irr: [(m, ir.l) for m, ir in irr]
+    ref = tpo.tensor_product(l_of(in1), l_of(in2), l_of(out), ins, tp.wigner_3j, xr, yr, wr, shared_weights=shared)
+    want = torch.autograd.grad((ref * G).sum(), [t for t in (xr, yr, wr) if t is not None])
+    # HIP
+    mod = mod.to("cuda")
+    xg, yg = x.to(dtype).cuda().requires_grad_(), y.to(dtype).cuda().requires_grad_()
+    if w is None:
+        wg, leaves = None, [xg, yg]
+    elif shared:                      # internal weights: the module's parameter
+        with torch.no_grad():
+            mod.weight.copy_(w)
+        mod = mod.to(dtype)
+        wg, leaves = None, [xg, yg, mod.weight]
+    else:
+        wg = w.to(dtype).cuda().requires_grad_()
+        leaves = [xg, yg, wg]
+    res = mod(xg, yg, wg)
+    got = torch.autograd.grad((res * G.to(dtype).cuda()).sum(), leaves)
+    assert len(got) == len(want)
+    for name, a, b in zip(("grad_x1", "grad_x2", "grad_w"), got, want):
+        scale = max(1.0, float(b.abs().max()))
+        np.testing.assert_allclose(a.detach().cpu().double().numpy(), b.numpy(), rtol=0, atol=tol * scale, err_msg=name)
+
+
+@pytest.mark.gpu
+def test_tensor_product_outer_mode_is_forward_only():
+    mod, in1, in2, out, ins, x, y, w, want = _case("uvuv", False, True)
+    mod = mod.to("cuda")
+    xg = x.cuda().requires_grad_()
+    res = mod(xg, y.cuda())
+    np.testing.assert_allclose(res.detach().cpu().numpy(), want.numpy(), atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        res.sum().backward()
