@@ -46,7 +46,9 @@ traffic = {}
 for k, n, f, wr in rows:
     for sym, name in alias.items():
         if sym in k:
-            traffic[name] = (2 * f + wr) * 1024
+            # the wq kernels' first-block forms (second template argument true) are separate kernels with their own traffic
+            first = sym.endswith("_wq") and ", true>" in k.split("(")[0]
+            traffic[name + ("_first" if first else "")] = (2 * f + wr) * 1024
 tfile = os.path.join(ROOT, "profiles", "traffic.json")
 allw = json.load(open(tfile)) if os.path.exists(tfile) else {}
 allw["qm9_1024"] = traffic

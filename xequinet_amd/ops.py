@@ -30,7 +30,8 @@ class _KernelTimer:
         self.enabled = enabled
         self.events = {}
 
-    def launch(self, name: str, *args) -> None:
+    def launch(self, name: str, *args, label: Optional[str] = None) -> None:
+        """``label``: the key the launch is booked under (default: the entry point's name)."""
         if not self.enabled:
             call(name, *args)
             return
@@ -38,7 +39,7 @@ class _KernelTimer:
         a.record()
         call(name, *args)
         b.record()
-        self.events.setdefault(name, []).append((a, b))
+        self.events.setdefault(label or name, []).append((a, b))
 
     def summary(self):
         torch.cuda.synchronize()
@@ -721,7 +722,8 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
         basis, _ = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv=False)
         KERNEL_TIMER.launch("xeq_message_fwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), ptr(plan["rowptr"]),
                             ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf),
-                            ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
+                            ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream(),
+                            label="xeq_message_fwd_wq_first" if xl & lib.XHAT_HIGHER_L_ZERO else None)   # the first-block form moves fewer bytes
         return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, None, None), impl
     if impl == "wm":
         basis, dbasis = edge_basis_wm(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
@@ -763,7 +765,8 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
         parts = torch.empty(max(1, lib.load().xeq_message_wq_parts_floats(N, E, mul3(mul))), dtype=h.dtype, device=h.device)
         KERNEL_TIMER.launch("xeq_message_bwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), ptr(plan["rowptr"]),
                             ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x),
-                            ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream())
+                            ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream(),
+                            label="xeq_message_bwd_wq_first" if (skip and xl & lib.XHAT_HIGHER_L_ZERO) else None)
         call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), mul3(mul), ptr(parts), ptr(g_vec),
              stream())
     elif impl == "wm":
