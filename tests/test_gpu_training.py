@@ -169,5 +169,6 @@ def test_ddp_two_ranks_average_the_gradients():
     for n in grads[0]:
         mean = 0.5 * (grads[0][n] + grads[1][n])
         scale = max(1e-6, np.abs(mean).max())
-        assert np.abs(out[0][n] - mean).max() <= 1e-10 * scale, n
+        # the training pass aggregates with index_add (f64 atomics: the order of a node's sum differs from run to run)
+        assert np.abs(out[0][n] - mean).max() <= 1e-8 * scale, n
         assert np.array_equal(out[0][n], out[1][n]), n            # every rank holds the same averaged gradient
