@@ -176,9 +176,17 @@ def main():
         from xequinet_amd.tuning import enable_gemm_autotune
         enable_gemm_autotune(results_file=args.gemm_results)   # every GEMM shape is timed once, during the warm-up steps
 
+    # the collated batch (positions, atomic numbers, graph pointer and the per-atom graph index: what the reference's
+    # DataLoader hands over with `data.to(device)`, run/inference.py:39) is resident before the timed region; a step takes a
+    # shallow copy of it (no device work), builds the neighbour list and evaluates the model
+    import copy
+    collated = XequiBatch(pos_d.detach(), z_d, ptr_d, pbc=pbc_d, cell=cell_d)
+
+    def new_batch():
+        return copy.copy(collated)
+
     def step_eager():
-        batch = XequiBatch(pos_d.detach(), z_d, ptr_d, pbc=pbc_d, cell=cell_d)
-        batch = transform(batch)                       # HIP radius graph
+        batch = transform(new_batch())                 # HIP radius graph
         with torch.enable_grad():
             out = model(batch.to_dict(), compute_forces=True, compute_virial=False)
         return batch.edge_index.shape[1], out
@@ -206,8 +214,7 @@ def main():
         graphed = runtime.GraphedModel(model, compute_forces=True, compute_virial=False, tune_gemms=False)
 
         def step():
-            batch = XequiBatch(pos_d.detach(), z_d, ptr_d, pbc=pbc_d, cell=cell_d)
-            batch = transform(batch)
+            batch = transform(new_batch())
             return batch.edge_index.shape[1], graphed(batch.to_dict())
 
     try:
@@ -271,7 +278,7 @@ def main():
                 native = XPaiNNNative(model)
 
                 def step_native():
-                    batch = transform(XequiBatch(pos_d.detach(), z_d, ptr_d))
+                    batch = transform(new_batch())
                     return native(batch.pos, batch.atomic_numbers, batch.edge_index, batch.ptr, None, None, True, True, True, False)
 
                 for _ in range(3):
@@ -358,6 +365,7 @@ def main():
                                    "random init), neighbour list + energy + forces",
                        "atoms_rank0": int(n_atoms), "edges_rank0": int(n_edges), "edges_all_ranks_per_step": edges_total / args.steps,
                        "parallelism": f"molecule shards x{world}, no collectives", "chunks_rank0": n_chunks,
+                       "resident_inputs": "the collated batch (positions, atomic numbers, graph pointer, per-atom graph index); every step builds its neighbour list and evaluates the model",
                        "library_gemm_selection": "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)",
                        "launch": "host launch per kernel" if args.eager else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host",
                        "ms_per_step_eager": "the same step with every kernel launched from the host through the Python modules, measured on rank 0 right after the timed region",
