@@ -133,31 +133,41 @@ __device__ __forceinline__ int64_t graph_of(const int64_t* __restrict__ ptr, int
   return lo;
 }
 
+// One wave per center, lane = candidate neighbour (64 at a time in ascending index: a ballot + prefix popcount keeps the
+// (center, neighbor) order).  A thread per center walking its molecule in a dependent loop took 13 + 7 us (count + fill) for
+// the 335 k distance checks of QM9-1024 on a third of the CUs.
 template <typename T, bool FILL>
 __global__ void k_radius_graph(const T* __restrict__ pos, const int64_t* __restrict__ ptr, int64_t n_graphs,
                                int64_t n_nodes, T r2, int32_t* __restrict__ deg,
                                const int32_t* __restrict__ rowptr, int64_t n_edges,
                                int64_t* __restrict__ edge_index) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= n_nodes) return;
-  int64_t g = graph_of(ptr, n_graphs, i);
-  int64_t a = ptr[g], b = ptr[g + 1];
-  T xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  const int64_t g = graph_of(ptr, n_graphs, i);
+  const int64_t a = ptr[g], b = ptr[g + 1];
+  const T xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
   int32_t cnt = 0;
   int64_t w = FILL ? (int64_t)rowptr[i] : 0;
-  for (int64_t j = a; j < b; ++j) {
-    T dx = sub_rn<T>(xi, pos[3 * j]), dy = sub_rn<T>(yi, pos[3 * j + 1]), dz = sub_rn<T>(zi, pos[3 * j + 2]);
-    T d2 = add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz));
-    if (d2 < r2 && j != i) {
-      if (FILL) {
-        edge_index[w] = i;            // center
-        edge_index[n_edges + w] = j;  // neighbor
-        ++w;
-      }
-      ++cnt;
+  for (int64_t j0 = a; j0 < b; j0 += 64) {
+    const int64_t j = j0 + lane;
+    bool hit = false;
+    if (j < b) {
+      T dx = sub_rn<T>(xi, pos[3 * j]), dy = sub_rn<T>(yi, pos[3 * j + 1]), dz = sub_rn<T>(zi, pos[3 * j + 2]);
+      T d2 = add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz));
+      hit = d2 < r2 && j != i;
     }
+    const unsigned long long m = __ballot(hit);
+    if (FILL && hit) {
+      const int64_t p = w + __popcll(m & ((1ull << lane) - 1ull));
+      edge_index[p] = i;            // center
+      edge_index[n_edges + p] = j;  // neighbor
+    }
+    const int pc = __popcll(m);
+    w += pc;
+    cnt += pc;
   }
-  if (!FILL) deg[i] = cnt;
+  if (!FILL && lane == 0) deg[i] = cnt;
 }
 
 // -------------------------------------------------------------- PBC radius graph
@@ -674,7 +684,7 @@ int xeq_radius_graph_count(int dtype, const void* pos, const int64_t* ptr, int64
   XEQ_CHECK_ARG(n_graphs > 0, "xeq_radius_graph_count: nodes without graphs");
   XEQ_DISPATCH_FLOAT(dtype, {
     T rc = (T)cutoff;
-    hipLaunchKernelGGL((k_radius_graph<T, false>), dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL((k_radius_graph<T, false>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, (const T*)pos, ptr, n_graphs, n_nodes, rc * rc, deg,
                        (const int32_t*)nullptr, (int64_t)0, (int64_t*)nullptr);
   });
@@ -689,7 +699,7 @@ int xeq_radius_graph_fill(int dtype, const void* pos, const int64_t* ptr, int64_
   if (n_nodes == 0 || n_edges == 0) return XEQ_OK;
   XEQ_DISPATCH_FLOAT(dtype, {
     T rc = (T)cutoff;
-    hipLaunchKernelGGL((k_radius_graph<T, true>), dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL((k_radius_graph<T, true>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, (const T*)pos, ptr, n_graphs, n_nodes, rc * rc, (int32_t*)nullptr,
                        rowptr, n_edges, edge_index);
   });
