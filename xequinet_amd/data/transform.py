@@ -18,10 +18,8 @@ class NeighborTransform:
         num_graphs = data.num_graphs if hasattr(data, keys.NUM_GRAPHS) else 1
         if num_graphs > 1:
             assert hasattr(data, keys.BATCH)
-            n_nodes_per_graph = data.ptr[1:] - data.ptr[:-1]
             ptr = data.ptr
         else:
-            n_nodes_per_graph = torch.tensor([data.pos.shape[0]], device=device)
             ptr = torch.tensor([0, data.pos.shape[0]], dtype=torch.int64, device=device)
 
         has_pbc = hasattr(data, keys.PBC) and bool(data.pbc.any())
@@ -30,6 +28,7 @@ class NeighborTransform:
         if has_pbc and has_cell:
             if getattr(data, "edge_index", None) is not None and getattr(data, "cell_offsets", None) is not None:
                 return data
+            n_nodes_per_graph = ptr[1:] - ptr[:-1]     # (only the periodic search takes the counts)
             edge_index, cell_offsets = radius_graph_pbc(
                 pos=data.pos, n_nodes_per_graph=n_nodes_per_graph, cell=data.cell, pbc=data.pbc, cutoff=self.cutoff,
             )

@@ -54,9 +54,16 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 # --------------------------------------------------------------------------- graph
+_SCAN_BYTES = {}
+
+
 def _exclusive_scan(deg: torch.Tensor, n: int, rowptr: torch.Tensor) -> None:
     """rowptr[0..n] = exclusive prefix sum of deg[0..n) (rowptr[n] = total), grid-wide (xeq_exclusive_scan_i32_ws)."""
-    nbytes = lib.load().xeq_exclusive_scan_i32_workspace(n)
+    nbytes = _SCAN_BYTES.get(n)
+    if nbytes is None:      # a pure function of n: asked once per size (the neighbour lists sit in front of every evaluation)
+        nbytes = _SCAN_BYTES[n] = lib.load().xeq_exclusive_scan_i32_workspace(n)
+        if len(_SCAN_BYTES) > 4096:
+            _SCAN_BYTES.clear()
     work = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=deg.device)
     call("xeq_exclusive_scan_i32_ws", ptr(deg), n, ptr(rowptr), ptr(work), int(nbytes), stream())
 
