@@ -90,6 +90,10 @@ int xeq_radius_graph_fill_cl(int dtype, const void* pos, const int64_t* ptr, int
                              const int32_t* bin_start, const int32_t* bin_atom, const int32_t* rowptr, int64_t n_edges,
                              int64_t* tmp_keys, int64_t* edge_index, void* stream);
 
+/* wrap_positions (data/radius_graph.py:6-32) for every atom: fractional = pos cell_inv[g], shift = floor(fractional) on the periodic
+ * axes (pbc[a] != 0), pos_wrap = (fractional - shift) cell[g].  cell / cell_inv [G, 3, 3] row-major (rows = lattice vectors). */
+int xeq_pbc_wrap(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, const void* cell,
+                 const void* cell_inv, const int32_t pbc[3], void* pos_wrap, void* shift, void* stream);
 /* Replaces the cdist/nonzero search of radius_graph_pbc (data/radius_graph.py:118-126,
  * 162-181).  The caller supplies what the reference computes on the host side:
  * wrapped positions pos_wrap[N,3] (:111), per-graph image translation vectors

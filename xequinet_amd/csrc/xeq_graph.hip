@@ -170,6 +170,35 @@ __global__ void k_radius_graph(const T* __restrict__ pos, const int64_t* __restr
   if (!FILL && lane == 0) deg[i] = cnt;
 }
 
+// Wrap positions into the unit cell (data/radius_graph.py:6-32): fractional = pos cell^-1, shift = floor(fractional) on the
+// periodic axes, pos_wrap = (fractional - shift) cell.  One thread per atom; the per-graph inverse comes from the host (the cell
+// is a handful of numbers: its inverse, the image counts and the image table are formed there in one round trip instead of
+// ~40 tiny device launches).
+template <typename T>
+__global__ void k_pbc_wrap(const T* __restrict__ pos, const int64_t* __restrict__ ptr, int64_t n_graphs, int64_t n_nodes,
+                           const T* __restrict__ cell, const T* __restrict__ cell_inv, int px, int py, int pz,
+                           T* __restrict__ pos_wrap, T* __restrict__ shift) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const int64_t g = graph_of(ptr, n_graphs, i);
+  const T* M = cell + 9 * g;
+  const T* Mi = cell_inv + 9 * g;
+  const T p0 = pos[3 * i], p1 = pos[3 * i + 1], p2 = pos[3 * i + 2];
+  const int per[3] = {px, py, pz};
+  T f[3], s[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f[k] = add_rn<T>(add_rn<T>(mul_rn<T>(p0, Mi[k]), mul_rn<T>(p1, Mi[3 + k])), mul_rn<T>(p2, Mi[6 + k]));
+    s[k] = per[k] ? floor(f[k]) : T(0);
+    f[k] = sub_rn<T>(f[k], s[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    pos_wrap[3 * i + k] = add_rn<T>(add_rn<T>(mul_rn<T>(f[0], M[k]), mul_rn<T>(f[1], M[3 + k])), mul_rn<T>(f[2], M[6 + k]));
+    shift[3 * i + k] = s[k];
+  }
+}
+
 // -------------------------------------------------------------- PBC radius graph
 // One wave per center.  Candidate keys k = (j - a) * n_cells + c are swept in
 // ascending order 64 at a time; a ballot + prefix popcount keeps the reference's
@@ -704,6 +733,20 @@ int xeq_radius_graph_fill(int dtype, const void* pos, const int64_t* ptr, int64_
                        rowptr, n_edges, edge_index);
   });
   XEQ_CHECK_LAUNCH("xeq_radius_graph_fill");
+  return XEQ_OK;
+}
+
+int xeq_pbc_wrap(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, const void* cell,
+                 const void* cell_inv, const int32_t pbc[3], void* pos_wrap, void* shift, void* stream) {
+  XEQ_CHECK_ARG(n_graphs >= 0 && n_nodes >= 0, "xeq_pbc_wrap: negative size");
+  if (n_nodes == 0) return XEQ_OK;
+  XEQ_CHECK_ARG(n_graphs > 0, "xeq_pbc_wrap: nodes without graphs");
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_pbc_wrap<T>), dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const T*)pos, ptr,
+                       n_graphs, n_nodes, (const T*)cell, (const T*)cell_inv, (int)pbc[0], (int)pbc[1], (int)pbc[2], (T*)pos_wrap,
+                       (T*)shift);
+  });
+  XEQ_CHECK_LAUNCH("xeq_pbc_wrap");
   return XEQ_OK;
 }
 

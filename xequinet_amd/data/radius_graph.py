@@ -31,7 +31,8 @@ def wrap_positions(pos: torch.Tensor, cell: torch.Tensor, n_nodes_per_graph: tor
 
 
 _PRUNE_MARGIN = 1e-3  # on |f_a - n_a|: far above the rounding of f, far below any lattice spacing
-_CELL_LIST_MIN_ATOMS = 512   # average atoms per graph from which the bin grid replaces the O(n_g^2) pair sweep
+_CELL_LIST_MIN_ATOMS = 4096  # average atoms per graph from which the bin grid replaces the O(n_g^2) pair sweep (water boxes on
+                             # MI355X: the sweep's search is 68 us at 1 536 atoms and grows with n^2, the bin grid costs 190 us + O(n))
 _CELL_LIST_MAX_BINS = 64     # per axis
 
 
@@ -77,11 +78,66 @@ def _image_counts(cell: torch.Tensor, pbc: List[bool], cutoff: float, with_prune
     return reps, (recip, thr, reps)
 
 
+def _host_cell_tables(cell: torch.Tensor, pbc_: List[bool], cutoff: float, with_inverse: bool):
+    """Everything the periodic search derives from the cells alone, formed ON THE HOST in one round trip and uploaded as one
+    buffer: image counts per axis (data/radius_graph.py:61-89), the image table and its Cartesian offsets per graph (:93-104),
+    the reciprocal rows / thresholds of the image-pruned kernels and (for wrapping, :6-32) the inverse cells.  The cells are
+    9 numbers per graph; as device tensor operations this was ~40 launches and three round trips (0.5 ms in front of a 0.07 ms
+    search).  Arithmetic in the cells' own dtype, in the reference's order of operations.
+
+    -> reps [3] (ints), n_cells, dict of device tensors: cell_offsets [n_cells, 3], pbc_offsets [G, n_cells, 3], recip [G, 3, 3],
+       thr [G, 3], cell_inv [G, 3, 3] (or None)."""
+    import numpy as np
+
+    c = cell.detach().cpu().numpy()                                   # the round trip
+    dt = c.dtype
+    G = c.shape[0]
+    cross = [np.cross(c[:, 1], c[:, 2]), np.cross(c[:, 2], c[:, 0]), np.cross(c[:, 0], c[:, 1])]
+    vol = np.sum(c[:, 0] * cross[0], axis=-1, keepdims=True).astype(dt)
+    inv_min, reps = [], []
+    for ax in range(3):
+        d = np.sqrt(np.sum(np.square((cross[ax] / vol).astype(dt)), axis=-1)).astype(dt)
+        inv_min.append(d)
+        reps.append(int(np.ceil(dt.type(cutoff) * d).max()) if pbc_[ax] else 0)
+    recip = np.stack([(cr / vol).astype(dt) for cr in cross], axis=1)                    # [G, 3(axis), 3]
+    thr = (dt.type(cutoff) * np.stack(inv_min, axis=1) + dt.type(_PRUNE_MARGIN)).astype(dt)   # [G, 3]
+    axes = [np.arange(-r, r + 1, dtype=dt) for r in reps]
+    grid = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, 3)          # cartesian_prod order: first axis slowest
+    n_cells = grid.shape[0]
+    offs = np.einsum("ci,gij->gcj", grid, c).astype(dt)                                  # bmm(unit_cell_batch, cell)
+    parts = [grid.ravel(), offs.ravel(), recip.ravel(), thr.ravel()]
+    if with_inverse:
+        parts.append(np.linalg.inv(c).astype(dt).ravel())
+    flat = torch.from_numpy(np.ascontiguousarray(np.concatenate(parts))).to(cell.device)   # one upload
+    out, o = {}, 0
+    for name, shape in (("cell_offsets", (n_cells, 3)), ("pbc_offsets", (G, n_cells, 3)), ("recip", (G, 3, 3)), ("thr", (G, 3)),
+                        ("cell_inv", (G, 3, 3))):
+        if name == "cell_inv" and not with_inverse:
+            out[name] = None
+            continue
+        n = int(np.prod(shape))
+        out[name] = flat[o:o + n].view(shape)
+        o += n
+    return reps, n_cells, out
+
+
+def _wrap_on_device(pos: torch.Tensor, ptr: torch.Tensor, cell: torch.Tensor, cell_inv: torch.Tensor, pbc_: List[bool]):
+    """wrap_positions in one launch (xeq_pbc_wrap)."""
+    from ..lib import call, dtype_code, mul3, ptr as p_, stream
+
+    pos = pos.detach().contiguous()
+    pos_wrap, shift = torch.empty_like(pos), torch.empty_like(pos)
+    call("xeq_pbc_wrap", dtype_code(pos), p_(pos), p_(ptr), ptr.numel() - 1, pos.shape[0], p_(cell.contiguous()), p_(cell_inv),
+         mul3([int(v) for v in pbc_]), p_(pos_wrap), p_(shift), stream())
+    return pos_wrap, shift
+
+
 @torch.no_grad()
 def radius_graph_pbc(pos: torch.Tensor, n_nodes_per_graph: torch.Tensor, pbc: torch.Tensor, cell: torch.Tensor,
-                     cutoff: float, return_rowptr: bool = False):
+                     cutoff: float, return_rowptr: bool = False, ptr: torch.Tensor = None):
     """Same signature and outputs as the reference (:35-192): ``edge_index`` [2,E] int64
-    center-major, then (neighbor * n_cells + cell) ascending; ``cell_offsets`` [E,3]."""
+    center-major, then (neighbor * n_cells + cell) ascending; ``cell_offsets`` [E,3].  ``ptr``: the graph pointer when
+    the caller has it (it is the cumulative sum of ``n_nodes_per_graph``)."""
     ops.lib.require_hip(pos, cell)
     device, dtype = pos.device, pos.dtype
     batch_size = n_nodes_per_graph.shape[0]
@@ -89,21 +145,21 @@ def radius_graph_pbc(pos: torch.Tensor, n_nodes_per_graph: torch.Tensor, pbc: to
     pbc_cpu = pbc.detach().cpu()
     assert torch.all(pbc_cpu[0] == pbc_cpu), "PBC must be the same for all graphs"
     pbc_ = pbc_cpu[0].tolist()
-    n_nodes_per_graph = n_nodes_per_graph.to(device)
+    cell = cell.to(dtype)
 
-    max_rep, prune = _image_counts(cell, pbc_, cutoff, with_prune=True)
-    cells_per_dim = [torch.arange(-rep, rep + 1, device=device, dtype=dtype) for rep in max_rep]
-    cell_offsets = torch.cartesian_prod(*cells_per_dim).reshape(-1, 3)  # [n_cells, 3]
-    n_cells = cell_offsets.shape[0]
-    unit_cell_batch = cell_offsets.view(1, n_cells, 3).expand(batch_size, -1, -1).contiguous()
-    pbc_offsets = torch.bmm(unit_cell_batch, cell)  # [G, n_cells, 3]
-
-    pos_wrap, shift = wrap_positions(pos, cell, n_nodes_per_graph, pbc_)
-    ptr = torch.zeros(batch_size + 1, dtype=torch.int64, device=device)
-    ptr[1:] = torch.cumsum(n_nodes_per_graph, dim=0)
+    max_rep, n_cells, tab = _host_cell_tables(cell, pbc_, cutoff, with_inverse=any(pbc_))
+    if ptr is None:
+        ptr = torch.zeros(batch_size + 1, dtype=torch.int64, device=device)
+        ptr[1:] = torch.cumsum(n_nodes_per_graph.to(device), dim=0)
+    ptr = ptr.to(torch.int64).contiguous()
+    if any(pbc_):
+        pos_wrap, shift = _wrap_on_device(pos, ptr, cell, tab["cell_inv"], pbc_)
+    else:
+        pos_wrap, shift = pos, torch.zeros_like(pos)
+    prune = (tab["recip"], tab["thr"], max_rep)
     if _use_cell_list(pos.shape[0], batch_size):
         prune = _with_bins(prune, pbc_)
-    edge_index, offsets, rowptr = ops.radius_graph_pbc_raw(pos_wrap, ptr, pbc_offsets, cell_offsets, shift, cutoff, prune=prune)
+    edge_index, offsets, rowptr = ops.radius_graph_pbc_raw(pos_wrap, ptr, tab["pbc_offsets"], tab["cell_offsets"], shift, cutoff, prune=prune)
     if return_rowptr:
         return edge_index, offsets, rowptr
     return edge_index, offsets
@@ -112,14 +168,11 @@ def radius_graph_pbc(pos: torch.Tensor, n_nodes_per_graph: torch.Tensor, pbc: to
 def single_radius_graph(pos: torch.Tensor, pbc: torch.Tensor, cell: torch.Tensor, cutoff: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """Single-graph variant (:195-275): no wrapping, cell [3,3], pbc [3]."""
     ops.lib.require_hip(pos, cell)
-    device, dtype = pos.device, pos.dtype
+    device = pos.device
     pbc_ = [bool(v) for v in pbc.detach().cpu().tolist()]
-    max_rep, prune = _image_counts(cell.unsqueeze(0), pbc_, cutoff, with_prune=True)
-    cells_per_dim = [torch.arange(-rep, rep + 1, device=device, dtype=dtype) for rep in max_rep]
-    cell_offsets = torch.cartesian_prod(*cells_per_dim).reshape(-1, 3)
-    pbc_offsets = torch.mm(cell_offsets, cell).unsqueeze(0)
+    max_rep, n_cells, tab = _host_cell_tables(cell.to(pos.dtype).unsqueeze(0), pbc_, cutoff, with_inverse=False)
     ptr = torch.tensor([0, pos.shape[0]], dtype=torch.int64, device=device)
     # positions are NOT wrapped here (:195-275), so the bin grid (fractional coordinates in [0, 1)) does not apply
-    edge_index, offsets, _ = ops.radius_graph_pbc_raw(pos.detach(), ptr, pbc_offsets, cell_offsets, torch.zeros_like(pos), cutoff,
-                                                      prune=prune)
+    edge_index, offsets, _ = ops.radius_graph_pbc_raw(pos.detach(), ptr, tab["pbc_offsets"], tab["cell_offsets"], torch.zeros_like(pos),
+                                                      cutoff, prune=(tab["recip"], tab["thr"], max_rep))
     return edge_index, offsets

@@ -30,7 +30,7 @@ class NeighborTransform:
                 return data
             n_nodes_per_graph = ptr[1:] - ptr[:-1]     # (only the periodic search takes the counts)
             edge_index, cell_offsets = radius_graph_pbc(
-                pos=data.pos, n_nodes_per_graph=n_nodes_per_graph, cell=data.cell, pbc=data.pbc, cutoff=self.cutoff,
+                pos=data.pos, n_nodes_per_graph=n_nodes_per_graph, cell=data.cell, pbc=data.pbc, cutoff=self.cutoff, ptr=ptr,
             )
             data.edge_index = edge_index
             data.cell_offsets = cell_offsets
