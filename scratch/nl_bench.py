@@ -5,7 +5,7 @@ from oracle import xpainn_oracle as orc
 from xequinet_amd.data import synthetic as syn
 from xequinet_amd.data import radius_graph_pbc
 dev = "cuda"
-for k in (8, 16, 24):
+for k in (8, 11, 14, 16, 24):
     pos, z, ptr, cell = syn.synth_water_box(k, seed=5)
     p = torch.tensor(pos, dtype=torch.float32, device=dev); c = torch.tensor(cell, dtype=torch.float32, device=dev).reshape(1, 3, 3)
     n = torch.tensor([len(pos)], device=dev); pbc = torch.tensor([[True, True, True]], device=dev)

@@ -31,8 +31,8 @@ def wrap_positions(pos: torch.Tensor, cell: torch.Tensor, n_nodes_per_graph: tor
 
 
 _PRUNE_MARGIN = 1e-3  # on |f_a - n_a|: far above the rounding of f, far below any lattice spacing
-_CELL_LIST_MIN_ATOMS = 4096  # average atoms per graph from which the bin grid replaces the O(n_g^2) pair sweep (water boxes on
-                             # MI355X: the sweep's search is 68 us at 1 536 atoms and grows with n^2, the bin grid costs 190 us + O(n))
+_CELL_LIST_MIN_ATOMS = 6144  # average atoms per graph from which the bin grid replaces the O(n_g^2) pair sweep (water boxes on
+                             # MI355X, scratch/nl_bench.py: 3 993 atoms 0.43 vs 0.53 ms, 8 232 atoms 0.72 vs 0.65 ms)
 _CELL_LIST_MAX_BINS = 64     # per axis
 
 
