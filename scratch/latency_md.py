@@ -34,6 +34,16 @@ def run(name, pos, z, cell=None):
             with torch.enable_grad():
                 return m({"pos": p, "atomic_numbers": zz, "edge_index": ei, **extra}, True, False)["forces"]
         out[tag] = timeit(step)
+        if replay:      # the engine hands over a DIFFERENT list every step (here: two orders of the same pairs, alternating)
+            alt = [ei, ei.flip(1).contiguous()]
+            ex = [extra, {k: (v.flip(0).contiguous() if k == "cell_offsets" else v) for k, v in extra.items()}]
+            cnt = [0]
+            def step_new():
+                cnt[0] += 1
+                i = cnt[0] & 1
+                with torch.enable_grad():
+                    return m({"pos": p, "atomic_numbers": zz, "edge_index": alt[i], **ex[i]}, True, False)["forces"]
+            out["lmp replay, new list every step"] = timeit(step_new)
     for tag, replay in (("gmx eager (search + energy + autograd)", False), ("gmx replay", True)):
         g = mk(XPaiNNGMX, replay=replay)
         def gstep():

@@ -407,3 +407,52 @@ def test_replay_follows_a_weight_update():
     assert torch.equal(r1["forces"], e1["forces"]) and not torch.equal(r1["forces"], r0["forces"])
     r2, _ = both()
     assert g.captures == 2 and torch.equal(r2["forces"], r1["forces"])
+
+
+def test_lammps_replay_reuses_an_unchanged_neighbour_list():
+    """XPaiNNLMP(replay=True): when the engine hands over the same list again (positions moved), the sorted views held by the
+    captured graph are reused (GraphedModel.reuse_unchanged_topology); a different list of the same length rebuilds them.
+    Every step equals the eager model."""
+    from xequinet_amd.cluster import radius_graph
+    from xequinet_amd.data import synthetic as syn
+    from xequinet_amd.interface import XPaiNNLMP
+
+    torch.manual_seed(0)
+    pos, z, _ = syn.synth_aspirin()
+    p0 = torch.tensor(pos, dtype=torch.float32, device="cuda")
+    zz = torch.tensor(z, device="cuda")
+    kw = dict(unit_style="metal", action_blocks=2)
+    torch.manual_seed(1)
+    fast = XPaiNNLMP(replay=True, tune_gemms=False, **kw).eval().requires_grad_(False).to("cuda")
+    torch.manual_seed(1)
+    ref = XPaiNNLMP(replay=False, **kw).eval().requires_grad_(False).to("cuda")
+    ei = radius_graph(p0, 5.0, ptr=torch.tensor([0, len(z)], device="cuda"))
+    perm = torch.randperm(ei.shape[1], device="cuda")
+    lists = [ei, ei.clone(), ei.clone(), ei[:, perm].contiguous(), ei[:, perm].contiguous(), ei]     # same, same, same, reordered, same, back
+    g = torch.Generator(device="cuda").manual_seed(3)
+    built = []
+    import xequinet_amd.ops as ops_mod
+    orig = ops_mod.EdgeGraph.__init__
+
+    def counting(self, *a, **k):
+        built.append(1)
+        return orig(self, *a, **k)
+
+    ops_mod.EdgeGraph.__init__ = counting
+    try:
+        for step, e in enumerate(lists):
+            p = p0 + 0.02 * torch.randn(p0.shape, device="cuda", generator=g)
+            n_before = len(built)
+            with torch.enable_grad():
+                a = fast({"pos": p.clone(), "atomic_numbers": zz, "edge_index": e}, True, False)
+            n_fast = len(built) - n_before
+            with torch.enable_grad():
+                b = ref({"pos": p.clone(), "atomic_numbers": zz, "edge_index": e}, True, False)
+            assert torch.allclose(a["energy"], b["energy"], rtol=1e-5, atol=1e-5), step
+            assert (a["forces"] - b["forces"]).abs().max().item() <= 2e-4, step
+            if step in (1, 2, 4):
+                assert n_fast == 0, f"step {step}: the unchanged list was rebuilt"
+            if step in (3, 5):
+                assert n_fast >= 1, f"step {step}: a changed list must be rebuilt"
+    finally:
+        ops_mod.EdgeGraph.__init__ = orig

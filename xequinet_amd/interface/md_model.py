@@ -54,7 +54,7 @@ class XPaiNNLMP(XPaiNN):
             if (self._replay is None or self._replay.compute_forces != compute_forces
                     or self._replay.compute_virial != compute_virial):
                 self._replay = GraphedModel(_Core(self), compute_forces=compute_forces, compute_virial=compute_virial,
-                                            tune_gemms=self._tune_gemms)
+                                            tune_gemms=self._tune_gemms, reuse_unchanged_topology=True)
             if keys.BATCH_PTR not in data:
                 n = data[keys.POSITIONS].shape[0]
                 data[keys.BATCH_PTR] = torch.tensor([0, n], dtype=torch.long, device=data[keys.POSITIONS].device)

@@ -41,13 +41,19 @@ class GraphedModel:
     _TENSOR_KEYS = (keys.POSITIONS, keys.ATOMIC_NUMBERS, keys.EDGE_INDEX, keys.BATCH, keys.BATCH_PTR, keys.CELL, keys.CELL_OFFSETS)
 
     def __init__(self, model: torch.nn.Module, compute_forces: bool = True, compute_virial: bool = False,
-                 max_graphs: int = 8, warmup: int = 2, tune_gemms: bool = True) -> None:
+                 max_graphs: int = 8, warmup: int = 2, tune_gemms: bool = True, reuse_unchanged_topology: bool = False) -> None:
         """``tune_gemms``: time the library GEMM candidates of every new shape once during the warm-up runs
         (``tuning.enable_gemm_autotune``; PyTorch TunableOp, a process-wide switch).  The libraries' default picks
         for few-hundred-row operands are tiles of 128-256 rows on one or two workgroups (35 us per GEMM at 192
         atoms); the timed picks take ~5 us, which halves the replay time of MD-sized systems."""
         self.model = model
         self.tune_gemms = tune_gemms
+        # MD engines hand over a neighbour list every step that is, for small systems, the same list for many steps (every atom
+        # of a 21-atom molecule sees every other one): comparing it with the list the last replayed graph holds (one kernel and
+        # a round trip) is cheaper than rebuilding the sorted views (a dozen launches and their own round trip).  Off by
+        # default: a stream of ever-new lists would only pay for the comparison.
+        self.reuse_unchanged_topology = reuse_unchanged_topology
+        self._last: Optional[_Captured] = None
         self.compute_forces = compute_forces
         self.compute_virial = compute_virial
         self.max_graphs = max_graphs
@@ -145,7 +151,15 @@ class GraphedModel:
         state = self._parameter_state()
         if state != self._param_state:      # weights changed since the graphs were captured
             self._cache.clear()
+            self._last = None
             self._param_state = state
+        c = self._last
+        if (self.reuse_unchanged_topology and c is not None and keys.EDGE_GRAPH not in data
+                and self._same_topology(c, data)):
+            # same list as the last replay: the captured CSR arrays and plans are current, only the other inputs move
+            ops.copy_many([(t, data[k]) for k, t in c.inputs.items() if k in data and k != keys.EDGE_INDEX])
+            c.graph.replay()
+            return c.outputs
         eg = self._edge_graph(data)
         sig = self._signature(data, eg)
         c = self._cache.get(sig)
@@ -158,7 +172,20 @@ class GraphedModel:
             self._cache.move_to_end(sig)
         self._refresh(c, data, eg)
         c.graph.replay()
+        self._last = c if self._cache.get(sig) is c else None
         return c.outputs
+
+    @staticmethod
+    def _same_topology(c: _Captured, data) -> bool:
+        ei, ref = data[keys.EDGE_INDEX], c.inputs[keys.EDGE_INDEX]
+        if ei.shape != ref.shape or ei.dtype != ref.dtype:
+            return False
+        for k in (keys.POSITIONS, keys.BATCH_PTR, keys.CELL_OFFSETS, keys.CELL):
+            if (k in data) != (k in c.inputs) or (k in data and (data[k].shape != c.inputs[k].shape or data[k].dtype != c.inputs[k].dtype)):
+                return False
+        if c.derived_batch and keys.BATCH_PTR in data and not torch.equal(data[keys.BATCH_PTR], c.inputs[keys.BATCH_PTR]):
+            return False
+        return bool(torch.equal(ei, ref))
 
 
 # ----------------------------------------------------------------------------------------------- chunked evaluation
