@@ -165,14 +165,17 @@ def radius_graph_pbc(pos: torch.Tensor, n_nodes_per_graph: torch.Tensor, pbc: to
     return edge_index, offsets
 
 
-def single_radius_graph(pos: torch.Tensor, pbc: torch.Tensor, cell: torch.Tensor, cutoff: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Single-graph variant (:195-275): no wrapping, cell [3,3], pbc [3]."""
+def single_radius_graph(pos: torch.Tensor, pbc: torch.Tensor, cell: torch.Tensor, cutoff: float, return_rowptr: bool = False):
+    """Single-graph variant (:195-275): no wrapping, cell [3,3], pbc [3].  ``return_rowptr``: also the CSR row pointer of the
+    (center-sorted) list, which the search has anyway."""
     ops.lib.require_hip(pos, cell)
     device = pos.device
     pbc_ = [bool(v) for v in pbc.detach().cpu().tolist()]
     max_rep, n_cells, tab = _host_cell_tables(cell.to(pos.dtype).unsqueeze(0), pbc_, cutoff, with_inverse=False)
     ptr = torch.tensor([0, pos.shape[0]], dtype=torch.int64, device=device)
     # positions are NOT wrapped here (:195-275), so the bin grid (fractional coordinates in [0, 1)) does not apply
-    edge_index, offsets, _ = ops.radius_graph_pbc_raw(pos.detach(), ptr, tab["pbc_offsets"], tab["cell_offsets"], torch.zeros_like(pos),
-                                                      cutoff, prune=(tab["recip"], tab["thr"], max_rep))
+    edge_index, offsets, rowptr = ops.radius_graph_pbc_raw(pos.detach(), ptr, tab["pbc_offsets"], tab["cell_offsets"], torch.zeros_like(pos),
+                                                           cutoff, prune=(tab["recip"], tab["thr"], max_rep))
+    if return_rowptr:
+        return edge_index, offsets, rowptr
     return edge_index, offsets

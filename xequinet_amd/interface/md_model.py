@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .. import keys
+from .. import keys, ops
 from ..data.radius_graph import single_radius_graph
 from ..nn.basic import compute_edge_data, compute_properties
 from ..nn.model import BaseModel, XPaiNN
@@ -131,7 +131,8 @@ class XPaiNNGMX(XPaiNN):
         if pbc is None:
             pbc = torch.zeros(3, dtype=torch.bool, device=positions.device)
         with torch.no_grad():
-            edge_index, cell_offsets = single_radius_graph(pos=positions, cell=cell, pbc=pbc, cutoff=self.cutoff_radius)
+            edge_index, cell_offsets, rowptr = single_radius_graph(pos=positions, cell=cell, pbc=pbc, cutoff=self.cutoff_radius,
+                                                                   return_rowptr=True)
         data = {
             keys.POSITIONS: positions,
             keys.ATOMIC_NUMBERS: atomic_numbers,
@@ -139,6 +140,8 @@ class XPaiNNGMX(XPaiNN):
             keys.PBC: pbc.unsqueeze(0),
             keys.EDGE_INDEX: edge_index,
             keys.CELL_OFFSETS: cell_offsets,
+            # the search's list is center-sorted and comes with its row pointer: no sortedness check, no second pass over it
+            keys.EDGE_GRAPH: ops.EdgeGraph(edge_index, positions.shape[0], center_sorted=True, c_rowptr=rowptr),
         }
         if self.net_charge is not None:
             data[keys.TOTAL_CHARGE] = torch.tensor([self.net_charge], device=positions.device)
