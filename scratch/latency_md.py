@@ -44,6 +44,15 @@ def run(name, pos, z, cell=None):
                 with torch.enable_grad():
                     return m({"pos": p, "atomic_numbers": zz, "edge_index": alt[i], **ex[i]}, True, False)["forces"]
             out["lmp replay, new list every step"] = timeit(step_new)
+    try:    # the scriptable model: the whole evaluation enqueued from C++ (xeq::xpainn_eval), no capture
+        from xequinet_amd.interface.scripted import XPaiNNLMPScript
+        torch.manual_seed(0)
+        sm = XPaiNNLMPScript(mk(XPaiNNLMP, unit_style="metal"), unit_style="metal")
+        def sstep():
+            return sm({"pos": p, "atomic_numbers": zz, "edge_index": ei, **{k: v for k, v in extra.items() if k != "pbc"}}, True, False)["forces"]
+        out["lmp scripted (one registered operator)"] = timeit(sstep)
+    except Exception as err:
+        out["lmp scripted: " + str(err)[:60]] = float("nan")
     for tag, replay in (("gmx eager (search + energy + autograd)", False), ("gmx replay", True)):
         g = mk(XPaiNNGMX, replay=replay)
         def gstep():
