@@ -298,3 +298,31 @@ def test_node_tile_split_covers_every_tile_once():
                 assert (tiles - n_full) * split <= 256
     assert L.xeq_node_tile_split(576, 5, out) == 0 and (out[0], out[1]) == (512, 4)     # QM9-1024: 64 tiles of the third round x 4
     assert L.xeq_node_tile_split(1, 5, out) == 0 and (out[0], out[1]) == (0, 5)         # aspirin: one tile, five workgroups
+
+
+def test_host_cell_tables_match_the_device_operation_forms():
+    """data/radius_graph._host_cell_tables (numpy, one round trip) against the tensor-operation forms it replaced in front of the
+    periodic search (_image_counts, cartesian_prod + bmm, linalg.inv): image counts per axis, image table in cartesian_prod order,
+    Cartesian image offsets, reciprocal rows, pruning thresholds, inverse cells -- random triclinic cells, mixed periodic flags."""
+    import numpy as np
+    import torch
+    from xequinet_amd.data import radius_graph as rg
+
+    g = torch.Generator().manual_seed(0)
+    for dtype, tol in ((torch.float64, 1e-13), (torch.float32, 2e-6)):
+        for pbc in ([True, True, True], [True, False, True], [False, False, True]):
+            cell = (torch.eye(3).unsqueeze(0) * torch.tensor([6.0, 9.0, 14.0]) + 1.5 * torch.randn(4, 3, 3, generator=g)).to(dtype)
+            reps, n_cells, tab = rg._host_cell_tables(cell, pbc, 5.0, with_inverse=True)
+            want_reps, (recip, thr, _) = rg._image_counts(cell, pbc, 5.0, with_prune=True)
+            assert reps == want_reps
+            axes = [torch.arange(-r, r + 1, dtype=dtype) for r in reps]
+            grid = torch.cartesian_prod(*axes).reshape(-1, 3)
+            assert n_cells == grid.shape[0] and torch.equal(tab["cell_offsets"], grid)
+            offs = torch.bmm(grid.view(1, -1, 3).expand(4, -1, -1).contiguous(), cell)
+            for name, got, want in (("pbc_offsets", tab["pbc_offsets"], offs), ("recip", tab["recip"], recip), ("thr", tab["thr"], thr),
+                                    ("cell_inv", tab["cell_inv"], torch.linalg.inv(cell))):
+                assert got.dtype == dtype and got.shape == want.shape, name
+                scale = max(1.0, float(want.abs().max()))
+                assert float((got - want).abs().max()) <= tol * scale, name
+    _, _, tab = rg._host_cell_tables(cell, [True, True, True], 5.0, with_inverse=False)
+    assert tab["cell_inv"] is None
