@@ -180,7 +180,7 @@ class GraphedModel:
         ei, ref = data[keys.EDGE_INDEX], c.inputs[keys.EDGE_INDEX]
         if ei.shape != ref.shape or ei.dtype != ref.dtype:
             return False
-        for k in (keys.POSITIONS, keys.BATCH_PTR, keys.CELL_OFFSETS, keys.CELL):
+        for k in (keys.POSITIONS, keys.ATOMIC_NUMBERS, keys.BATCH_PTR, keys.CELL_OFFSETS, keys.CELL) + (() if c.derived_batch else (keys.BATCH,)):
             if (k in data) != (k in c.inputs) or (k in data and (data[k].shape != c.inputs[k].shape or data[k].dtype != c.inputs[k].dtype)):
                 return False
         if c.derived_batch and keys.BATCH_PTR in data and not torch.equal(data[keys.BATCH_PTR], c.inputs[keys.BATCH_PTR]):
