@@ -2,8 +2,9 @@
 
 Every op here launches a hand-written HIP kernel from libxeq_hip.so on the
 current HIP stream.  Backward passes are explicit HIP kernels too (first order
-only: the force evaluation ``-dE/dpos`` of nn/basic.py:143-159 in eval mode;
-``create_graph=True`` training is out of scope and raises).
+only: the force evaluation ``-dE/dpos`` of nn/basic.py:143-159 in eval mode; a
+training pass -- parameter gradients, ``create_graph=True`` -- takes the differentiable form of
+the blocks in nn/training.py and does not come through these ops).
 """
 from __future__ import annotations
 
@@ -482,7 +483,7 @@ class EqLayerNorm(Function):
     @once_differentiable
     def backward(ctx, go):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            raise NotImplementedError("xequinet_amd: parameter gradients (training) are out of scope; "
+            raise NotImplementedError("xequinet_amd: this operator has no parameter gradients (the training pass is nn/training.py); "
                                       "call model.requires_grad_(False) / model.eval()")
         x, weight = ctx.saved_tensors
         go = go.contiguous()
@@ -811,7 +812,7 @@ class FusedMessage(Function):
     @once_differentiable
     def backward(ctx, g_s, g_x):
         if any(ctx.needs_input_grad[5:9]):
-            raise NotImplementedError("xequinet_amd: parameter gradients (training) are out of scope; "
+            raise NotImplementedError("xequinet_amd: this operator has no parameter gradients (the training pass is nn/training.py); "
                                       "call model.requires_grad_(False) / model.eval()")
         g_h, g_xhat, g_vec, g_s, g_x = message_backward(ctx.saved_tensors, ctx.graph, ctx.cfg, ctx.impl, g_s, g_x)
         return g_h, g_xhat, g_vec, g_s, g_x, None, None, None, None, None, None
