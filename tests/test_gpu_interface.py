@@ -456,3 +456,41 @@ def test_lammps_replay_reuses_an_unchanged_neighbour_list():
                 assert n_fast >= 1, f"step {step}: a changed list must be rebuilt"
     finally:
         ops_mod.EdgeGraph.__init__ = orig
+
+
+def test_ase_calculator_native_operator_gives_the_module_numbers():
+    """XequiCalculator(native=True): the evaluation is one registered operator (xeq::xpainn_eval) -- same kernels in the same
+    order as the Python modules, so energy, atomic energies, forces and stress are bit-identical; molecule and periodic box."""
+    import time
+    from xequinet_amd.interface import XequiCalculator
+    from xequinet_amd.interface.ase_calculator import _HAVE_ASE
+
+    if _HAVE_ASE:
+        pytest.skip("duck-typed Atoms stand-in is for images without ASE")
+    model, _ = P._build(torch.float32)
+    plain = XequiCalculator(model=model, dtype="float32")
+    fast = XequiCalculator(model=model, dtype="float32", native=True)
+    pos, z, _ = syn.synth_aspirin()
+    f = P._load("radius_graph_pbc_water192.npz")
+    _, zw, _, _ = syn.synth_water_box(4, seed=5)
+    cell = f["cell"][0].astype(np.float64)
+    systems = [(_Atoms(pos, z), ["energy", "forces"]), (_Atoms(f["pos"].astype(np.float64), zw, cell, (True, True, True)), None)]
+    for atoms, props in systems:
+        plain.calculate(atoms, props)
+        fast.calculate(atoms, props)
+        assert fast._native is not None
+        assert set(plain.results) == set(fast.results)
+        for k in plain.results:
+            assert np.array_equal(np.asarray(plain.results[k]), np.asarray(fast.results[k])), k
+    # and it is the faster path for a small molecule (host-bound either way; generous margin)
+    atoms = systems[0][0]
+    def timed(calc):
+        for _ in range(3):
+            calc.calculate(atoms, ["energy", "forces"])
+        t0 = time.perf_counter()
+        for _ in range(20):
+            calc.calculate(atoms, ["energy", "forces"])
+        return (time.perf_counter() - t0) / 20
+    t_plain, t_fast = timed(plain), timed(fast)
+    print(f"ASE-style step on aspirin: modules {t_plain * 1e3:.2f} ms, native operator {t_fast * 1e3:.2f} ms")
+    assert t_fast < t_plain
