@@ -494,3 +494,25 @@ def test_ase_calculator_native_operator_gives_the_module_numbers():
     t_plain, t_fast = timed(plain), timed(fast)
     print(f"ASE-style step on aspirin: modules {t_plain * 1e3:.2f} ms, native operator {t_fast * 1e3:.2f} ms")
     assert t_fast < t_plain
+
+
+def test_lammps_model_native_operator_option():
+    """XPaiNNLMP(native=True) against the same model through the Python modules: bit-identical energies and forces."""
+    from xequinet_amd.cluster import radius_graph
+    from xequinet_amd.interface import XPaiNNLMP
+
+    pos, z, _ = syn.synth_aspirin()
+    p = torch.tensor(pos, dtype=torch.float32, device="cuda")
+    zz = torch.tensor(z, device="cuda")
+    ei = radius_graph(p, 5.0, ptr=torch.tensor([0, len(z)], device="cuda"))
+    torch.manual_seed(1)
+    a = XPaiNNLMP(unit_style="real", native=True, action_blocks=2).eval().requires_grad_(False).to("cuda")
+    torch.manual_seed(1)
+    b = XPaiNNLMP(unit_style="real", action_blocks=2).eval().requires_grad_(False).to("cuda")
+    for _ in range(2):
+        with torch.enable_grad():
+            ra = a({"pos": p.clone(), "atomic_numbers": zz, "edge_index": ei}, True, False)
+            rb = b({"pos": p.clone(), "atomic_numbers": zz, "edge_index": ei}, True, False)
+        assert a._native is not None
+        assert torch.equal(ra["energy"], rb["energy"]) and torch.equal(ra["forces"], rb["forces"])
+    assert "_native" not in dict(a.named_modules()) and len(a.state_dict()) == len(b.state_dict())

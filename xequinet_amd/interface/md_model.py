@@ -36,7 +36,10 @@ class XPaiNNLMP(XPaiNN):
     LAMMPS units.  ``cutoff_radius`` is converted to LAMMPS units for the caller that builds the list."""
 
     def __init__(self, unit_style: str = "metal", net_charge: Optional[int] = None, replay: bool = False,
-                 tune_gemms: bool = True, **kwargs) -> None:
+                 tune_gemms: bool = True, native: bool = False, **kwargs) -> None:
+        """``replay``: HIP-graph replay per (atoms, edges) signature.  ``native``: an evaluation is one registered operator
+        (``xeq::xpainn_eval``, every kernel enqueued from C++: the numbers of the Python modules at a third of their host
+        time; fp32, a copy of the parameters is taken at first use) -- what ``interface.scripted.XPaiNNLMPScript`` runs."""
         super().__init__(**kwargs)
         lammps_units = keys.LAMMPS_UNIT_STYLE[unit_style]
         self.pos_unit_factor = unit_conversion(lammps_units[keys.POSITIONS], _default_unit(keys.POSITIONS))        # LAMMPS -> model
@@ -47,8 +50,25 @@ class XPaiNNLMP(XPaiNN):
         self._replay = None
         self._use_replay = replay
         self._tune_gemms = tune_gemms
+        self._use_native, self._native = native, None
 
     def _evaluate(self, data, compute_forces: bool, compute_virial: bool) -> Dict[str, torch.Tensor]:
+        if self._use_native and not self._use_replay and data[keys.POSITIONS].dtype == torch.float32:
+            if self._native is None:
+                from .scripted import XPaiNNNative
+                object.__setattr__(self, "_native", XPaiNNNative(self))     # (not a sub-module: it holds a copy of the parameters)
+            pos = data[keys.POSITIONS]
+            ptr = data.get(keys.BATCH_PTR)
+            if ptr is None:
+                ptr = torch.tensor([0, pos.shape[0]], dtype=torch.long, device=pos.device)
+            out = self._native(pos, data[keys.ATOMIC_NUMBERS], data[keys.EDGE_INDEX], ptr, data.get(keys.CELL), data.get(keys.CELL_OFFSETS),
+                               False, False, compute_forces, compute_virial)
+            result = {keys.TOTAL_ENERGY: out[0], keys.ATOMIC_ENERGIES: out[1]}
+            if compute_forces:
+                result[keys.FORCES] = out[2]
+            if compute_virial:
+                result[keys.VIRIAL] = out[3]
+            return result
         if self._use_replay:
             from ..runtime import GraphedModel
             if (self._replay is None or self._replay.compute_forces != compute_forces
