@@ -129,7 +129,7 @@ class MessageBlock(Function):
     """XPainnMessage.forward (nn/xpainn.py:128-161): norms -> scalar_mlp -> fused message kernel."""
 
     @staticmethod
-    def forward(ctx, s, x, vec, module, graph, rbf, cutoff_fn):
+    def forward(ctx, s, x, vec, module, graph, rbf, cutoff_fn, x_is_zero=False):
         lib.require_hip(s, x, vec)
         s, x, vec = s.contiguous(), x.contiguous(), vec.contiguous()
         F, mul = module.node_dim, module._mul
@@ -137,7 +137,7 @@ class MessageBlock(Function):
         pre, h = _mlp_fwd(module.scalar_mlp, shat)
         p0, p1 = rbf.params()
         # xhat in BT layout; behind XEmbedding x is zero, hence xhat is zero on every l > 0 column (include/xeq.h)
-        xl = 1 | (lib.XHAT_HIGHER_L_ZERO if module.equivariant_input_zero else 0)
+        xl = 1 | (lib.XHAT_HIGHER_L_ZERO if x_is_zero else 0)
         cfg = (rbf.kind, cutoff_fn.kind, module.num_basis, float(cutoff_fn.cutoff), F, mul, xl)
         s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, module.rbf_lin.weight, module.rbf_lin.bias,
                                                         p0, p1, graph, cfg)
@@ -161,10 +161,10 @@ class MessageBlock(Function):
         if not node_grads:
             # first block of a force evaluation: its node features are the embedding of the atomic numbers and zeros, neither
             # depends on the positions; only dL/dvec leaves this block (no MLP / norm reverse launches)
-            return None, None, g_vec, None, None, None, None
+            return None, None, g_vec, None, None, None, None, None
         g_shat = _mlp_bwd(module.scalar_mlp, g_h, pre)
         g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_shat, F, g_xhat, g_s_res, g_x_res)
-        return g_s, g_x, g_vec, None, None, None, None
+        return g_s, g_x, g_vec, None, None, None, None, None
 
 
 def _packed_uv(module) -> Tuple[list, torch.Tensor]:

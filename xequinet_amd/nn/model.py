@@ -102,8 +102,6 @@ class XPaiNN(BaseModel):
             self.mods[f"update_{i}"] = XPainnUpdate(
                 node_dim=node_dim, node_irreps=node_irreps, activation=activation, layer_norm=layer_norm,
             )
-        if action_blocks > 0:   # message_0 directly follows the embedding, whose equivariant features are zeros
-            self.mods["message_0"].equivariant_input_zero = True
         if output_modes is None:
             output_modes = ["energy"]
         elif isinstance(output_modes, str) or not isinstance(output_modes, Iterable):

@@ -22,6 +22,10 @@ from .rbf import resolve_cutoff, resolve_rbf
 
 # private data-dict entry: (rbf module, cutoff module) of the embedding, read by the fused message blocks
 RADIAL_SPEC = "_xeq_radial_spec"
+# private data-dict entry written by XEmbedding next to its all-zero equivariant features and consumed by the FIRST message block
+# behind it: the block then knows xhat is zero on the l > 0 columns and the kernels skip every term with that factor
+# (include/xeq.h, XEQ_XHAT_HIGHER_L_ZERO).  A tag on the data, not on a module: whatever else produces the features does not set it
+EQUIVARIANT_IS_ZERO = "_xeq_equivariant_is_zero"
 
 
 class XEmbedding(nn.Module):
@@ -78,6 +82,7 @@ class XEmbedding(nn.Module):
             (node_invariant.shape[0], self.node_irreps.dim), dtype=node_invariant.dtype, device=node_invariant.device
         )
         data[keys.NODE_EQUIVARIANT] = node_equivariant
+        data[EQUIVARIANT_IS_ZERO] = True
         return data
 
 
@@ -113,11 +118,9 @@ class XPainnMessage(nn.Module):
         self.o3norm = EquivariantLayerNorm(self.node_irreps) if layer_norm else nn.Identity()
         self._mul = self.node_irreps.mul3()
         self.fused = True  # False: run the reference's op sequence on the operator-level drop-ins
-        # set by the model on its first message block: the equivariant features it receives are XEmbedding's zeros
-        # (nn/xpainn.py:76-81), so every term that carries a factor xhat_{l>0} is skipped by the kernels
-        self.equivariant_input_zero = False
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        x_is_zero = bool(data.pop(EQUIVARIANT_IS_ZERO, False))     # consumed by the first block behind the embedding, whatever its path
         if training.active(self, data):
             return training.message(self, data)
         ori_scalar = data[keys.NODE_INVARIANT]
@@ -128,7 +131,8 @@ class XPainnMessage(nn.Module):
         if rbf.num_basis != self.num_basis:
             raise ValueError(f"num_basis mismatch: embedding {rbf.num_basis} vs message {self.num_basis}")
         if self.fused:  # block-level path: explicit forward/reverse, see nn/fused.py
-            new_scalar, new_equi = MessageBlock.apply(ori_scalar, ori_equi, data[keys.EDGE_VECTOR], self, edge_graph(data), rbf, cutoff_fn)
+            new_scalar, new_equi = MessageBlock.apply(ori_scalar, ori_equi, data[keys.EDGE_VECTOR], self, edge_graph(data), rbf, cutoff_fn,
+                                                      x_is_zero)
         else:           # operator-level path (the reference's own op sequence on the drop-in ops)
             node_scalar = self.norm(ori_scalar)
             node_equi = self.o3norm(ori_equi)
