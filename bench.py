@@ -3,7 +3,7 @@
 (neighbour list + 3 message/update blocks forward + force backward), fp32, random-init weights,
 synthetic inputs (xequinet_amd/data/synthetic.py).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload qm9_1024 | qm9_65536 | ...]
+    python bench.py [--gpus N --steps K --warmup W] [--workload qm9_1024 | qm9_65536 | ...]     (N > 1: starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -137,6 +137,20 @@ def main():
                          "when it already exists -- used by profiles/collect_stats.sh so that the trace holds no tuning kernels")
     ap.add_argument("--max-chunk-edges", type=int, default=None, help="edge cap per chunk of a sharded workload")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything in this process touches the GPU
+        # (a child process per rank under torch.distributed.run -- never a re-exec of a process that has initialised HIP);
+        # rank 0's JSON line passes through, this process exits with the launcher's code
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     from xequinet_amd import dist as xdist
     from xequinet_amd import ops, runtime

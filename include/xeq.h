@@ -90,6 +90,19 @@ int xeq_radius_graph_fill_cl(int dtype, const void* pos, const int64_t* ptr, int
                              const int32_t* bin_start, const int32_t* bin_atom, const int32_t* rowptr, int64_t n_edges,
                              int64_t* tmp_keys, int64_t* edge_index, void* stream);
 
+/* Everything the periodic search derives from the cells alone (HOST function: host pointers in and out, no device work).
+ * Replaces the host-side preparation of data/radius_graph.py: images per axis reps[a] = max_g ceil(cutoff |a_j x a_k| / V)
+ * on the periodic axes, 0 on the open ones (:61-89); the image table grid[n_cells, 3] in cartesian_prod order, first axis
+ * slowest (:93-97); its Cartesian offsets offs[G, n_cells, 3] = grid cell[g] (:98-104); and, for the image-pruned kernels
+ * below, recip[G, 3, 3] = rows a_j x a_k / V and thr[G, 3] = cutoff |recip_a| + 1e-3.  Arithmetic in the cells' own dtype
+ * with every operation rounded once (no contraction), in the order written here, so that every caller -- the Python front
+ * (data/radius_graph.py of this package) and the registered operator xeq::radius_graph_pbc -- hands the search kernels the
+ * same bits.  Two phases: xeq_pbc_image_counts gives reps (n_cells = prod (2 reps + 1)); xeq_pbc_tables_host fills
+ * out[] = grid | offs | recip | thr, (3 + 3 G) n_cells + 12 G values of `dtype`. */
+int xeq_pbc_image_counts(int dtype, const void* cell_host, int64_t n_graphs, const int32_t pbc[3], double cutoff, int32_t reps[3]);
+int xeq_pbc_tables_host(int dtype, const void* cell_host, int64_t n_graphs, const int32_t reps[3], double cutoff, void* out_host,
+                        int64_t out_count);
+
 /* wrap_positions (data/radius_graph.py:6-32) for every atom: fractional = pos cell_inv[g], shift = floor(fractional) on the periodic
  * axes (pbc[a] != 0), pos_wrap = (fractional - shift) cell[g].  cell / cell_inv [G, 3, 3] row-major (rows = lattice vectors). */
 int xeq_pbc_wrap(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes, const void* cell,

@@ -2,11 +2,13 @@
 
 The HIP path runs each configuration AT FULL SIZE in fp32; the fp64 CPU oracle is then run on a random subset of the
 molecules / frames of the very same batch (the whole box for the periodic configuration) and explicit bounds are
-asserted on exactly those: |dE| <= 1e-5 |E| + 1e-4; |dF| <= 1e-4 on 99 % of the components, <= 1e-3 on all (model units).  Molecules of a batch do not
-interact, so a molecule's oracle result does not depend on which other molecules the oracle sees.
+asserted on exactly those: |dE| <= 1e-5 |E| + 1e-4; |dF| within max(1e-4, 1.5 x the error of the fp32 oracle on the same
+molecules), at the maximum and at the 99th percentile (tests/test_gpu_parity.py::f32_force_bounds: the HIP path is no worse
+than the reference's own arithmetic at the reference's own precision).  Molecules of a batch do not interact, so a
+molecule's oracle result does not depend on which other molecules the oracle sees.
 
 Every comparison appends its achieved maxima to PARITY; tests/conftest.py writes them to
-``gpurun_out/parity_r02.json`` at the end of the session (copied to ``profiles/``).
+``gpurun_out/parity_r03.json`` at the end of the session (copied to ``profiles/``).
 """
 import numpy as np
 import pytest
@@ -16,14 +18,14 @@ from oracle import xpainn_oracle as orc
 from xequinet_amd.data import synthetic as syn
 
 from tests import parity_record
-from tests.test_gpu_parity import DEV, F32_FORCE_MAX, F32_FORCE_P99, _build, _t
+from tests.test_gpu_parity import DEV, _build, _t, f32_force_bounds
 
 pytestmark = pytest.mark.gpu
 
 E_RTOL, E_ATOL = 1e-5, 1e-4
 N_SAMPLE = 64
-# forces (model units): 99 % of the components within BASELINE.md's 1e-4, every component within 1e-3; why not a flat
-# 1e-4, and the measured maxima (8e-5 .. 2.2e-4 on these configurations): tests/test_gpu_parity.py::_check_model
+# forces (model units): tests/test_gpu_parity.py::f32_force_bounds
+SAME_BATCH_FORCE_MAX = 2e-3    # the same molecule in two batches (see test_chunked_equals_unchunked)
 
 
 def _hip_eval(model, pos, z, ptr, cell=None, chunked=False):
@@ -47,21 +49,24 @@ def _oracle_subset(oracle, pos, z, ptr, mols):
     pp = np.concatenate([[0], np.cumsum(np.diff(ptr)[mols])]).astype(np.int64)
     ei = orc.radius_graph_canonical(p, pp, 5.0)
     batch = np.repeat(np.arange(len(mols)), np.diff(pp))
-    want = oracle({"pos": torch.tensor(p.astype(np.float64)), "atomic_numbers": torch.tensor(z[idx].astype(np.int64)),
-                   "edge_index": torch.tensor(ei), "batch": torch.tensor(batch), "ptr": torch.tensor(pp)}, compute_forces=True)
-    return idx, want["energy"].numpy(), want["forces"].numpy(), ei.shape[1]
+    ref_in = {"pos": torch.tensor(p.astype(np.float64)), "atomic_numbers": torch.tensor(z[idx].astype(np.int64)),
+              "edge_index": torch.tensor(ei), "batch": torch.tensor(batch), "ptr": torch.tensor(pp)}
+    want = oracle(ref_in, compute_forces=True)
+    return idx, want["energy"].numpy(), want["forces"].numpy(), ei.shape[1], ref_in
 
 
-def _compare(name, E, F, Eref, Fref, extra):
+def _compare(name, E, F, Eref, Fref, extra, oracle, ref_in):
     dE, dF = np.abs(E - Eref), np.abs(F - Fref)
+    b_max, b_p99, e32_max, e32_p99 = f32_force_bounds(oracle, ref_in, Fref)
     rec = dict(config=name, max_abs_dE=float(dE.max()), max_dE_over_bound=float((dE / (E_RTOL * np.abs(Eref) + E_ATOL)).max()),
                max_abs_dF=float(dF.max()), max_abs_F=float(np.abs(Fref).max()), max_abs_E=float(np.abs(Eref).max()),
                p99_abs_dF=float(np.quantile(dF, 0.99)), p999_abs_dF=float(np.quantile(dF, 0.999)),
-               bound_dE=f"{E_RTOL}*|E|+{E_ATOL}", bound_dF_max=F32_FORCE_MAX, bound_dF_p99=F32_FORCE_P99,
+               bound_dE=f"{E_RTOL}*|E|+{E_ATOL}", bound_dF_max=b_max, bound_dF_p99=b_p99,
+               oracle32_max_abs_dF=e32_max, oracle32_p99_abs_dF=e32_p99,
                dtype="f32 HIP vs f64 oracle", **extra)
     parity_record.add(rec)
     assert np.all(dE <= E_RTOL * np.abs(Eref) + E_ATOL), rec
-    assert dF.max() <= F32_FORCE_MAX and np.quantile(dF, 0.99) <= F32_FORCE_P99, rec
+    assert dF.max() <= b_max and np.quantile(dF, 0.99) <= b_p99, rec
 
 
 @pytest.mark.parametrize("name,n_mol,n_atoms,n_edges,chunked", [
@@ -78,10 +83,10 @@ def test_full_size_against_oracle(name, n_mol, n_atoms, n_edges, chunked):
     assert n_edges is None or e_hip == n_edges
     assert E.shape == (n_mol,) and F.shape == (len(pos), 3) and np.isfinite(E).all() and np.isfinite(F).all()
     mols = np.sort(np.random.default_rng(7).choice(n_mol, size=N_SAMPLE, replace=False))
-    idx, Eref, Fref, e_sub = _oracle_subset(oracle, pos, z, ptr, mols)
+    idx, Eref, Fref, e_sub, ref_in = _oracle_subset(oracle, pos, z, ptr, mols)
     _compare(name, E[mols], F[idx], Eref, Fref,
              dict(atoms=int(len(pos)), edges=int(e_hip), graphs=int(n_mol), compared_graphs=int(len(mols)), compared_atoms=int(len(idx)),
-                  compared_edges=int(e_sub)))
+                  compared_edges=int(e_sub)), oracle, ref_in)
 
 
 def test_chunked_equals_unchunked():
@@ -89,7 +94,7 @@ def test_chunked_equals_unchunked():
     of the same batch: identical edge count.  Every HIP kernel of this library gives a node / graph the same bits in
     any batch (fixed walk order per node), but the dense contractions are library GEMMs, which pick another kernel
     (another summation order) for another row count: energies / forces agree to fp32 rounding THROUGH the model, which
-    is the F32_FORCE_MAX of an ill-conditioned molecule, not bit for bit (measured: 1.2e-3 max, 96 % of the components
+    is SAME_BATCH_FORCE_MAX on an ill-conditioned molecule, not bit for bit (measured: 1.2e-3 max, 96 % of the components
     within 4e-6)."""
     model, _ = _build(torch.float32)
     pos, z, ptr = syn.synth_qm9_batch(512, seed=99)
@@ -100,7 +105,7 @@ def test_chunked_equals_unchunked():
                            max_abs_dF=float(np.abs(F - Fc).max()), bitwise=bool(np.array_equal(E, Ec) and np.array_equal(F, Fc))))
     np.testing.assert_allclose(Ec, E, rtol=1e-5, atol=1e-4)
     dF = np.abs(Fc - F)
-    assert dF.max() <= 2 * F32_FORCE_MAX and np.quantile(dF, 0.9) <= 1e-5, (dF.max(), np.quantile(dF, 0.9))
+    assert dF.max() <= SAME_BATCH_FORCE_MAX and np.quantile(dF, 0.9) <= 1e-5, (dF.max(), np.quantile(dF, 0.9))
 
 
 def test_sharded_equals_unsharded():
@@ -124,7 +129,7 @@ def test_sharded_equals_unsharded():
                                max_abs_dF=float(np.abs(F - Fs).max()), bitwise=bool(np.array_equal(E, Es) and np.array_equal(F, Fs))))
         np.testing.assert_allclose(Es, E, rtol=1e-5, atol=1e-4)      # library GEMM picks differ with the row count, see above
         dF = np.abs(Fs - F)
-        assert dF.max() <= 2 * F32_FORCE_MAX and np.quantile(dF, 0.9) <= 1e-5, (dF.max(), np.quantile(dF, 0.9))
+        assert dF.max() <= SAME_BATCH_FORCE_MAX and np.quantile(dF, 0.9) <= 1e-5, (dF.max(), np.quantile(dF, 0.9))
 
 
 def test_water_512_whole_box_against_oracle():
@@ -138,8 +143,32 @@ def test_water_512_whole_box_against_oracle():
     co = b.cell_offsets.cpu().double().numpy()
     p32 = pos.astype(np.float32).astype(np.float64)
     c32 = cell.astype(np.float32).astype(np.float64)
-    want = oracle({"pos": torch.tensor(p32), "atomic_numbers": torch.tensor(z.astype(np.int64)), "edge_index": torch.tensor(ei),
-                   "batch": torch.zeros(len(pos), dtype=torch.long), "ptr": torch.tensor(ptr), "cell": torch.tensor(c32),
-                   "cell_offsets": torch.tensor(co)}, compute_forces=True)
+    ref_in = {"pos": torch.tensor(p32), "atomic_numbers": torch.tensor(z.astype(np.int64)), "edge_index": torch.tensor(ei),
+              "batch": torch.zeros(len(pos), dtype=torch.long), "ptr": torch.tensor(ptr), "cell": torch.tensor(c32),
+              "cell_offsets": torch.tensor(co)}
+    want = oracle(ref_in, compute_forces=True)
     _compare("water_512", E, F, want["energy"].numpy(), want["forces"].numpy(),
-             dict(atoms=1536, edges=int(n_edges), graphs=1, compared_graphs=1, compared_atoms=1536, compared_edges=int(n_edges)))
+             dict(atoms=1536, edges=int(n_edges), graphs=1, compared_graphs=1, compared_atoms=1536, compared_edges=int(n_edges)),
+             oracle, ref_in)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver starts N = 1) must start its two ranks itself,
+    before anything touches the GPU, and rank 0 prints the one JSON line.  Rehearsed on this one card: both ranks on
+    device 0, gloo for the two reductions (XEQ_BENCH_BACKEND / XEQ_BENCH_DEVICE are bench.py's rehearsal switches)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(XEQ_BENCH_BACKEND="gloo", XEQ_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-gemm-autotune"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["edges_all_ranks_per_step"] > 1.9 * line["config"]["edges_rank0"]

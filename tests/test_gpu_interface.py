@@ -330,6 +330,57 @@ def test_compile_model_scripts_saves_reloads_and_reproduces(tmp_path):
     np.testing.assert_allclose(fb.cpu().numpy(), fa.cpu().numpy(), rtol=0, atol=2e-6 * float(fa.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_scripted_gromacs_model_searches_periodic_boxes(dtype, tmp_path):
+    """interface/jit_model.py:183-214 scripted: `single_radius_graph` runs INSIDE the model for a periodic box.  The registered
+    operator xeq::radius_graph_pbc gives the reference's list bit for bit (the reference-generated fixture of the 192-atom
+    water box; the Python search on a 1 536-atom box and on the triclinic fixture's cell), and the scripted, saved and
+    reloaded GROMACS model returns the Python XPaiNNGMX's energy bit for bit, its autograd forces to rounding of the unit
+    factor, on all three."""
+    from xequinet_amd.data import single_radius_graph
+    from xequinet_amd.interface import XPaiNNGMX
+    from xequinet_amd.interface.scripted import compile_model, load_torch_library
+
+    load_torch_library()
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    nm = FACTOR[("nm", "Angstrom")]
+    gmx, _ = _twin(XPaiNNGMX, dtype)
+    path = str(tmp_path / "xpainn-gmx-pbc.pt")
+    compile_model(gmx, mode="gmx", output_file=path)
+    loaded = torch.jit.load(path)
+
+    a = P._load("radius_graph_pbc_water192.npz")
+    f = P._load("single_radius_graph_water192.npz")
+    _, z192, _, _ = syn.synth_water_box(4, seed=5)
+    pos512, z512, _, cell512 = syn.make_workload("water_512", seed=0)
+    t = P._load("radius_graph_pbc_triclinic40.npz")
+    rng = np.random.default_rng(3)
+    cases = [("water_192", a["pos"], z192, a["cell"][0], [True, True, True], f),
+             ("water_512", pos512, z512, np.asarray(cell512).reshape(-1, 3, 3)[0], [True, True, True], None),
+             ("triclinic40", t["pos"], rng.choice([1, 6, 8], size=len(t["pos"])), t["cell"][0], [bool(v) for v in np.asarray(t["pbc"]).reshape(-1, 3)[0]], None),
+             ("slab (open along z)", a["pos"], z192, a["cell"][0], [True, True, False], None)]
+    for name, pos, z, cell, pbc, fixture in cases:
+        pos_t, cell_t = P._t(pos.astype(npdt)), P._t(cell.astype(npdt))
+        pbc_t = torch.tensor(pbc, device=DEV)
+        ei, co, rowptr = torch.ops.xeq.radius_graph_pbc(pos_t, cell_t, pbc_t, 5.0)
+        ei_py, co_py, rp_py = single_radius_graph(pos_t, pbc_t, cell_t, 5.0, return_rowptr=True)
+        assert torch.equal(ei, ei_py) and torch.equal(co, co_py) and torch.equal(rowptr, rp_py), name
+        assert ei.shape[1] > 0 and ei.dtype == torch.int64 and co.dtype == dtype, name
+        if fixture is not None and dtype == torch.float32:   # the fixture was generated by the reference in its default dtype
+            np.testing.assert_array_equal(ei.cpu().numpy(), fixture["edge_index"])
+            np.testing.assert_array_equal(co.cpu().numpy(), fixture["cell_offsets"])
+        zt = P._t(np.asarray(z).astype(np.int64))
+        box = cell_t / nm
+        pa = (pos_t / nm).detach().clone().requires_grad_()
+        ea = gmx(pa, zt, box, pbc_t)
+        (fa,) = torch.autograd.grad(ea.sum(), pa)
+        pb = (pos_t / nm).detach().clone().requires_grad_()
+        eb = loaded(pb, zt, box, pbc_t)
+        (fb,) = torch.autograd.grad(eb.sum(), pb)
+        assert torch.equal(ea.detach(), eb.detach()), (name, ea, eb)
+        np.testing.assert_allclose(fb.cpu().numpy(), fa.cpu().numpy(), rtol=0, atol=2e-6 * float(fa.abs().max()), err_msg=name)
+
+
 def test_native_operator_on_a_stream_of_new_topologies_matches_oracle():
     """One operator call per batch, every batch with another edge count (nothing to replay): energies / forces against the
     fp64 oracle."""

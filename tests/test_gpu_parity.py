@@ -3,8 +3,9 @@ committed golden fixtures.  Run on the MI355X box:  pytest tests -m gpu
 
 Tolerances:
   fp64: energies/forces/features 1e-10 relative-ish (pure rounding differences)
-  fp32: energies |dE| <= 1e-5 |E| + 1e-4; forces |dF| <= 1e-4 on 99 % of the components and <= 1e-3 on all
-        (model units; why not a flat 1e-4: _check_model)
+  fp32: energies |dE| <= 1e-5 |E| + 1e-4; forces: THE tolerance is f32_force_bounds() below -- the HIP path may be no
+        worse than the reference's own arithmetic run in fp32 on the same inputs (the oracle in fp32 against the oracle
+        in fp64): max |dF| <= max(1e-4, 1.5 max |F_oracle32 - F_oracle64|), and the same at the 99th percentile
   integer outputs (edge_index, cell_offsets): bit-exact
 """
 import math
@@ -23,7 +24,30 @@ pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 DEV = "cuda"
-F32_FORCE_MAX, F32_FORCE_P99 = 1e-3, 1e-4   # fp32 force bounds in model units, see _check_model
+F32_FORCE_FLOOR = 1e-4      # the stated fp32 force tolerance (model units)
+F32_ORACLE_FACTOR = 1.5     # ... widened only to 1.5 x the error of the reference's own arithmetic in fp32 on the same inputs
+
+
+def f32_twin(oracle):
+    """The same oracle with fp32 weights: the reference's op sequence (nn/xpainn.py:128-231, nn/basic.py:143-159) at the
+    reference's default precision (utils/config.py:58)."""
+    twin = getattr(oracle, "_f32_twin", None)
+    if twin is None:
+        sd32 = {k: (v.float() if v.is_floating_point() else v) for k, v in oracle.sd.items()}
+        twin = oracle._f32_twin = orc.XPaiNNOracle(sd32, **getattr(oracle, "_kw", {}))
+    return twin
+
+
+def f32_force_bounds(oracle, ref_in, Fref):
+    """(bound_max, bound_p99, err32_max, err32_p99): the fp32 oracle evaluated on the very inputs of the fp64 oracle.
+    err32 = |F_oracle32 - F_oracle64| is what fp32 rounding does to the reference's own arithmetic on these atoms (this
+    random-init model is ill-conditioned on a few of them); the HIP path has to stay within 1.5 x that, or within
+    BASELINE.md's 1e-4 where the fp32 oracle is better than that."""
+    in32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in ref_in.items()}
+    F32 = f32_twin(oracle)(in32, compute_forces=True)["forces"].double().numpy()
+    err = np.abs(F32 - Fref)
+    e_max, e_p99 = float(err.max()), float(np.quantile(err, 0.99))
+    return max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_max), max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_p99), e_max, e_p99
 
 
 def _load(name):
@@ -565,10 +589,12 @@ def _build(dtype, **kw):
         elif name.endswith(("bias", "affine_bias")):
             p.copy_(0.1 * torch.randn(p.shape, generator=g))
     sd = {k: v.detach().double().clone() for k, v in model.state_dict().items()}
-    return model.to(dtype).to(DEV), orc.XPaiNNOracle(sd, **kw)
+    oracle = orc.XPaiNNOracle(sd, **kw)
+    oracle._kw = kw
+    return model.to(dtype).to(DEV), oracle
 
 
-def _check_model(model, oracle, pos, z, ptr, ei, dtype, extra=None, etol=None, ftol=None, label=None, p99tol=None):
+def _check_model(model, oracle, pos, z, ptr, ei, dtype, extra=None, label=None):
     batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
     ref_in = {"pos": torch.tensor(pos, dtype=torch.float64), "atomic_numbers": torch.tensor(z.astype(np.int64)),
               "edge_index": torch.tensor(ei), "batch": torch.tensor(batch), "ptr": torch.tensor(ptr)}
@@ -588,22 +614,19 @@ def _check_model(model, oracle, pos, z, ptr, ei, dtype, extra=None, etol=None, f
         np.testing.assert_allclose(Fg, Fref, rtol=0, atol=1e-9 * max(1.0, np.abs(Fref).max()))
         np.testing.assert_allclose(got["atomic_energies"].detach().cpu().numpy(), want["atomic_energies"].numpy(), rtol=1e-10, atol=1e-10)
     else:
-        # fp32 tolerances, explicit (achieved maxima of every call: profiles/parity_r02.json):
+        # fp32 tolerances (achieved maxima of every call: profiles/parity_r03.json):
         #   |dE| <= 1e-5 |E| + 1e-4                                  (achieved <= 0.02 of it)
-        #   |dF| <= F32_FORCE_P99 = 1e-4 on 99 % of the components   (BASELINE.md's number)
-        #   |dF| <= F32_FORCE_MAX = 1e-3 on every component
-        # BASELINE.md's flat 1e-4 was written before any fp32 number existed: this random-init model is ill-conditioned
-        # on a few molecules (the SAME molecule's fp32 forces move by up to 1.2e-3 when only the library's GEMM kernel
-        # changes, and the reference's own arithmetic in fp32 -- the oracle run in fp32 -- is 5e-4 from fp64 at the
-        # worst atom of 256 QM9-shape molecules, 1.8e-4 at the 99.9th percentile); measured HIP maxima: 8e-5 .. 5e-4.
+        #   |dF|: f32_force_bounds() -- max and 99th percentile within max(1e-4, 1.5 x the fp32 oracle's own error on these inputs)
         dE, dF = np.abs(E - Eref), np.abs(Fg - Fref)
+        b_max, b_p99, e32_max, e32_p99 = f32_force_bounds(oracle, ref_in, Fref)
         parity_record.add(dict(config=label or f"model check N={len(pos)} E={ei.shape[1]}", max_abs_dE=float(dE.max()),
                                max_dE_over_bound=float((dE / (1e-5 * np.abs(Eref) + 1e-4)).max()), max_abs_dF=float(dF.max()),
                                p99_abs_dF=float(np.quantile(dF, 0.99)), max_abs_F=float(np.abs(Fref).max()),
-                               bound_dF_max=F32_FORCE_MAX, bound_dF_p99=F32_FORCE_P99, dtype="f32 HIP vs f64 oracle"))
+                               oracle32_max_abs_dF=e32_max, oracle32_p99_abs_dF=e32_p99,
+                               bound_dF_max=b_max, bound_dF_p99=b_p99, dtype="f32 HIP vs f64 oracle"))
         assert np.all(dE <= 1e-5 * np.abs(Eref) + 1e-4), (E - Eref)
-        assert dF.max() <= (F32_FORCE_MAX if ftol is None else ftol), dF.max()
-        assert np.quantile(dF, 0.99) <= (F32_FORCE_P99 if p99tol is None else p99tol), np.quantile(dF, 0.99)
+        assert dF.max() <= b_max, (dF.max(), b_max, e32_max)
+        assert np.quantile(dF, 0.99) <= b_p99, (np.quantile(dF, 0.99), b_p99, e32_p99)
     return got, want
 
 
@@ -671,10 +694,10 @@ def test_model_pbc_water_energy_forces(dtype):
     f = _load("radius_graph_pbc_water192.npz")
     pos, z, ptr, cell = syn.synth_water_box(4, seed=5)
     # 192 atoms at ~54 neighbours each: the densest graph of the suite and only 576 force components, so the 99th
-    # percentile is its 6th largest error; measured 0.9e-4 .. 1.6e-4 (the fp32 oracle itself: ~2e-4 here): 3e-4
+    # percentile is its 6th largest error (the fp32 oracle itself: ~2e-4 here, which is what the bound follows)
     _check_model(model, oracle, f["pos"].astype(np.float64), z, ptr, f["edge_index"], dtype,
                  extra={"cell": f["cell"].astype(np.float64), "cell_offsets": f["cell_offsets"].astype(np.float64)},
-                 label="water_192 (periodic, golden edge list)", p99tol=3e-4)
+                 label="water_192 (periodic, golden edge list)")
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])

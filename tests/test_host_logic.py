@@ -225,7 +225,8 @@ def test_torchscript_front_ends_script_save_and_reload_without_a_gpu(tmp_path):
     from xequinet_amd.utils import units as U
 
     load_torch_library()
-    assert hasattr(torch.ops.xeq, "xpainn_eval") and hasattr(torch.ops.xeq, "radius_graph")
+    assert hasattr(torch.ops.xeq, "xpainn_eval") and hasattr(torch.ops.xeq, "radius_graph") and hasattr(torch.ops.xeq, "radius_graph_pbc")
+    assert "Tensor pos, Tensor cell, Tensor pbc, float cutoff" in str(torch.ops.xeq.radius_graph_pbc.default._schema)
     schema = str(torch.ops.xeq.xpainn_eval.default._schema)
     assert "Tensor[] params" in schema and "-> Tensor[]" in schema
     saved = dict(U.DEFAULT_UNITS_MAP)

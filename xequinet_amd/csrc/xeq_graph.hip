@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <cmath>
+
 #include <hipcub/hipcub.hpp>
 
 #include "xeq_common.h"
@@ -599,6 +601,95 @@ __global__ void k_sort_segment_plain(const int64_t* __restrict__ tmp_keys, const
 
 using namespace xeq;
 
+// ---- host-side cell tables of the periodic search (xeq_pbc_image_counts / xeq_pbc_tables_host, include/xeq.h) ----
+// Every operation is rounded once in T, in the order written (volatile temporaries keep the host compiler from contracting or
+// re-associating under -ffp-contract=fast): the Python front and the registered operator both call these, so the search
+// kernels see the same bits from either.
+namespace xeq {
+template <typename T>
+struct CellGeom {
+  T cross[3][3];   // a_1 x a_2, a_2 x a_0, a_0 x a_1
+  T vol;
+  T recip[3][3];   // cross[ax] / vol
+  T inv_min[3];    // |recip[ax]|
+};
+template <typename T>
+static inline T rnd(T v) {
+  volatile T t = v;
+  return t;
+}
+template <typename T>
+static void cell_geom(const T* c, CellGeom<T>& g) {   // c: [3][3] row-major, rows = lattice vectors
+  const int jj[3] = {1, 2, 0}, kk[3] = {2, 0, 1};
+  for (int ax = 0; ax < 3; ++ax) {
+    const T* a = c + 3 * jj[ax];
+    const T* b = c + 3 * kk[ax];
+    g.cross[ax][0] = rnd<T>(rnd<T>(a[1] * b[2]) - rnd<T>(a[2] * b[1]));
+    g.cross[ax][1] = rnd<T>(rnd<T>(a[2] * b[0]) - rnd<T>(a[0] * b[2]));
+    g.cross[ax][2] = rnd<T>(rnd<T>(a[0] * b[1]) - rnd<T>(a[1] * b[0]));
+  }
+  T v = rnd<T>(c[0] * g.cross[0][0]);
+  v = rnd<T>(v + rnd<T>(c[1] * g.cross[0][1]));
+  v = rnd<T>(v + rnd<T>(c[2] * g.cross[0][2]));
+  g.vol = v;
+  for (int ax = 0; ax < 3; ++ax) {
+    T q = T(0);
+    for (int j = 0; j < 3; ++j) {
+      g.recip[ax][j] = rnd<T>(g.cross[ax][j] / g.vol);
+      const T sq = rnd<T>(g.recip[ax][j] * g.recip[ax][j]);
+      q = j == 0 ? sq : rnd<T>(q + sq);
+    }
+    g.inv_min[ax] = rnd<T>(std::sqrt(q));
+  }
+}
+template <typename T>
+static void image_counts(const T* cell, int64_t G, const int32_t pbc[3], double cutoff, int32_t reps[3]) {
+  for (int ax = 0; ax < 3; ++ax) reps[ax] = 0;
+  for (int64_t g = 0; g < G; ++g) {
+    CellGeom<T> cg;
+    cell_geom<T>(cell + 9 * g, cg);
+    for (int ax = 0; ax < 3; ++ax) {
+      if (!pbc[ax]) continue;
+      const T r = std::ceil(rnd<T>((T)cutoff * cg.inv_min[ax]));
+      const int32_t ri = (r > T(0) && r < T(1 << 20)) ? (int32_t)r : (r > T(0) ? (1 << 20) : 0);   // (a degenerate cell: caught by the caller's size check)
+      if (ri > reps[ax]) reps[ax] = ri;
+    }
+  }
+}
+template <typename T>
+static void tables_host(const T* cell, int64_t G, const int32_t reps[3], double cutoff, T* out) {
+  const int64_t n0 = 2 * reps[0] + 1, n1 = 2 * reps[1] + 1, n2 = 2 * reps[2] + 1, nc = n0 * n1 * n2;
+  T* grid = out;
+  T* offs = grid + 3 * nc;
+  T* recip = offs + 3 * nc * G;
+  T* thr = recip + 9 * G;
+  int64_t c = 0;
+  for (int64_t i0 = -reps[0]; i0 <= reps[0]; ++i0)
+    for (int64_t i1 = -reps[1]; i1 <= reps[1]; ++i1)
+      for (int64_t i2 = -reps[2]; i2 <= reps[2]; ++i2, ++c) {
+        grid[3 * c] = (T)i0;
+        grid[3 * c + 1] = (T)i1;
+        grid[3 * c + 2] = (T)i2;
+      }
+  for (int64_t g = 0; g < G; ++g) {
+    const T* a = cell + 9 * g;
+    for (int64_t k = 0; k < nc; ++k)
+      for (int j = 0; j < 3; ++j) {
+        T v = rnd<T>(grid[3 * k] * a[j]);
+        v = rnd<T>(v + rnd<T>(grid[3 * k + 1] * a[3 + j]));
+        v = rnd<T>(v + rnd<T>(grid[3 * k + 2] * a[6 + j]));
+        offs[(g * nc + k) * 3 + j] = v;
+      }
+    CellGeom<T> cg;
+    cell_geom<T>(a, cg);
+    for (int ax = 0; ax < 3; ++ax) {
+      for (int j = 0; j < 3; ++j) recip[9 * g + 3 * ax + j] = cg.recip[ax][j];
+      thr[3 * g + ax] = rnd<T>(rnd<T>((T)cutoff * cg.inv_min[ax]) + (T)1e-3);
+    }
+  }
+}
+}  // namespace xeq
+
 extern "C" {
 
 int xeq_version(void) { return 100; }
@@ -733,6 +824,29 @@ int xeq_radius_graph_fill(int dtype, const void* pos, const int64_t* ptr, int64_
                        rowptr, n_edges, edge_index);
   });
   XEQ_CHECK_LAUNCH("xeq_radius_graph_fill");
+  return XEQ_OK;
+}
+
+int xeq_pbc_image_counts(int dtype, const void* cell_host, int64_t n_graphs, const int32_t pbc[3], double cutoff, int32_t reps[3]) {
+  XEQ_CHECK_ARG(n_graphs >= 1 && cell_host != nullptr && cutoff > 0, "xeq_pbc_image_counts: bad arguments");
+  if (dtype == XEQ_F32) xeq::image_counts<float>((const float*)cell_host, n_graphs, pbc, cutoff, reps);
+  else if (dtype == XEQ_F64) xeq::image_counts<double>((const double*)cell_host, n_graphs, pbc, cutoff, reps);
+  else XEQ_CHECK_ARG(false, "xeq_pbc_image_counts: dtype %d", dtype);
+  XEQ_CHECK_ARG(reps[0] <= 64 && reps[1] <= 64 && reps[2] <= 64, "xeq_pbc_image_counts: %d x %d x %d images per axis (degenerate cell?)",
+                (int)reps[0], (int)reps[1], (int)reps[2]);
+  return XEQ_OK;
+}
+
+int xeq_pbc_tables_host(int dtype, const void* cell_host, int64_t n_graphs, const int32_t reps[3], double cutoff, void* out_host,
+                        int64_t out_count) {
+  XEQ_CHECK_ARG(n_graphs >= 1 && cell_host != nullptr && out_host != nullptr && reps[0] >= 0 && reps[1] >= 0 && reps[2] >= 0,
+                "xeq_pbc_tables_host: bad arguments");
+  const int64_t nc = (int64_t)(2 * reps[0] + 1) * (2 * reps[1] + 1) * (2 * reps[2] + 1);
+  XEQ_CHECK_ARG(out_count == (3 + 3 * n_graphs) * nc + 12 * n_graphs, "xeq_pbc_tables_host: out[] holds %lld values, need %lld",
+                (long long)out_count, (long long)((3 + 3 * n_graphs) * nc + 12 * n_graphs));
+  if (dtype == XEQ_F32) xeq::tables_host<float>((const float*)cell_host, n_graphs, reps, cutoff, (float*)out_host);
+  else if (dtype == XEQ_F64) xeq::tables_host<double>((const double*)cell_host, n_graphs, reps, cutoff, (double*)out_host);
+  else XEQ_CHECK_ARG(false, "xeq_pbc_tables_host: dtype %d", dtype);
   return XEQ_OK;
 }
 

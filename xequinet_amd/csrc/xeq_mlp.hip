@@ -64,9 +64,16 @@ __global__ void k_mlp_pack(const float* __restrict__ W, const float* __restrict_
   reinterpret_cast<float4*>(out)[idx] = v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// exp: the library's expf (<= 1 ulp, what the reference's SiLU evaluates); -DXEQ_SILU_FAST: the hardware exp2 path (~2 ulp + the
+// rounding of x log2 e), kept as a development switch for the accuracy / time comparison of DESIGN section 2
+#ifdef XEQ_SILU_FAST
+__device__ __forceinline__ float silu_exp(float x) { return __expf(x); }
+#else
+__device__ __forceinline__ float silu_exp(float x) { return expf(x); }
+#endif
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + silu_exp(-x)); }
 __device__ __forceinline__ float silu_grad_f(float x) {  // aten silu_backward: sig (1 + x (1 - sig))
-  const float sig = 1.f / (1.f + __expf(-x));
+  const float sig = 1.f / (1.f + silu_exp(-x));
   return sig * (1.f + x * (1.f - sig));
 }
 

@@ -16,6 +16,9 @@
 //                         Autograd: `energy` is differentiable w.r.t. `pos` (backward = -forces), which is how the
 //                         GROMACS-style model hands forces to its caller (interface/jit_model.py:208-214).
 //   xeq::radius_graph     open-boundary neighbour list (data/transform.py:58-64), canonical (center, neighbor) order.
+//   xeq::radius_graph_pbc periodic single-system neighbour list with the reference's order and cell offsets
+//                         (data/radius_graph.py:195-275 `single_radius_graph`, called inside the scripted GROMACS model,
+//                         interface/jit_model.py:183-195).
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
@@ -689,6 +692,47 @@ std::tuple<Tensor, Tensor> radius_graph(const Tensor& pos_in, const Tensor& ptr,
   return {ei, rowptr.narrow(0, 0, N + 1)};
 }
 
+// periodic neighbour list of ONE system (data/radius_graph.py:195-275): positions are not wrapped, cell [3, 3], pbc [3].
+// The twin of data.radius_graph.single_radius_graph of this package: the same host tables (xeq_pbc_image_counts /
+// xeq_pbc_tables_host) and the same image-pruned search kernels, hence the same list bit for bit.  Two round trips, as there:
+// the cell (9 numbers) comes to the host for the image counts, and the edge count sizes the output (the reference's nonzero()).
+std::tuple<Tensor, Tensor, Tensor> radius_graph_pbc(const Tensor& pos_in, const Tensor& cell_in, const Tensor& pbc_in, double cutoff) {
+  need_hip(pos_in, "pos");
+  TORCH_CHECK(cell_in.dim() == 2 && cell_in.size(0) == 3 && cell_in.size(1) == 3, "xeq::radius_graph_pbc: cell must be [3, 3]");
+  TORCH_CHECK(pbc_in.numel() == 3, "xeq::radius_graph_pbc: pbc must hold three flags");
+  const Tensor pos = pos_in.detach().contiguous();
+  const int dt = dcode(pos);
+  const int64_t N = pos.size(0);
+  const Tensor cell_h = cell_in.detach().to(pos.scalar_type()).to(at::kCPU).contiguous();   // round trip 1
+  const Tensor pbc_h = pbc_in.detach().to(at::kCPU).to(at::kInt).reshape({3}).contiguous();
+  const int32_t pbc[3] = {pbc_h.data_ptr<int32_t>()[0] != 0, pbc_h.data_ptr<int32_t>()[1] != 0, pbc_h.data_ptr<int32_t>()[2] != 0};
+  int32_t reps[3];
+  XCALL(xeq_pbc_image_counts(dt, cell_h.data_ptr(), 1, pbc, cutoff, reps));
+  const int64_t nc = (int64_t)(2 * reps[0] + 1) * (2 * reps[1] + 1) * (2 * reps[2] + 1), n_tab = 6 * nc + 12;
+  Tensor tab_h = at::empty({n_tab}, cell_h.options());
+  XCALL(xeq_pbc_tables_host(dt, cell_h.data_ptr(), 1, reps, cutoff, tab_h.data_ptr(), n_tab));
+  const Tensor tab = tab_h.to(pos.device());                                                 // one upload
+  const Tensor grid = tab.narrow(0, 0, 3 * nc), offs = tab.narrow(0, 3 * nc, 3 * nc), recip = tab.narrow(0, 6 * nc, 9),
+               thr = tab.narrow(0, 6 * nc + 9, 3);
+  const Tensor ptr64 = at::tensor({(int64_t)0, N}, at::TensorOptions().dtype(at::kLong)).to(pos.device());
+  const Tensor shift = at::zeros_like(pos);
+  Tensor deg = i32(N, ptr64), rowptr = i32(N + 1, ptr64);
+  void* st = cur_stream();
+  XCALL(xeq_radius_graph_pbc_count_pruned(dt, pos.data_ptr(), (const int64_t*)ptr64.data_ptr(), 1, N, offs.data_ptr(), nc, cutoff,
+                                          recip.data_ptr(), thr.data_ptr(), reps, (int32_t*)deg.data_ptr(), st));
+  const int64_t scan_bytes = xeq_exclusive_scan_i32_workspace(N);
+  TORCH_CHECK(scan_bytes >= 0, "xeq::radius_graph_pbc: too many nodes");
+  Tensor scan_work = at::empty({std::max<int64_t>(scan_bytes, 1)}, pos.options().dtype(at::kByte));
+  XCALL(xeq_exclusive_scan_i32_ws((const int32_t*)deg.data_ptr(), N, (int32_t*)rowptr.data_ptr(), scan_work.data_ptr(), scan_bytes, st));
+  const int64_t E = N > 0 ? (int64_t)rowptr[N].item<int32_t>() : 0;                          // round trip 2
+  Tensor ei = at::empty({2, E}, ptr64.options());
+  Tensor cell_offsets = at::empty({E, 3}, pos.options());
+  XCALL(xeq_radius_graph_pbc_fill_pruned(dt, pos.data_ptr(), (const int64_t*)ptr64.data_ptr(), 1, N, offs.data_ptr(), grid.data_ptr(),
+                                         shift.data_ptr(), nc, cutoff, recip.data_ptr(), thr.data_ptr(), reps,
+                                         (const int32_t*)rowptr.data_ptr(), E, (int64_t*)ei.data_ptr(), cell_offsets.data_ptr(), st));
+  return {ei, cell_offsets, rowptr};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(xeq, m) {
@@ -697,7 +741,11 @@ TORCH_LIBRARY(xeq, m) {
       "Tensor[] params, int[] iparams, float[] fparams, bool center_sorted, bool symmetric, bool compute_forces, "
       "bool compute_virial) -> Tensor[]");
   m.def("radius_graph(Tensor pos, Tensor ptr, float cutoff) -> (Tensor, Tensor)");
+  m.def("radius_graph_pbc(Tensor pos, Tensor cell, Tensor pbc, float cutoff) -> (Tensor, Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(xeq, Autograd, m) { m.impl("xpainn_eval", xpainn_eval); }
-TORCH_LIBRARY_IMPL(xeq, CompositeExplicitAutograd, m) { m.impl("radius_graph", radius_graph); }
+TORCH_LIBRARY_IMPL(xeq, CompositeExplicitAutograd, m) {
+  m.impl("radius_graph", radius_graph);
+  m.impl("radius_graph_pbc", radius_graph_pbc);
+}

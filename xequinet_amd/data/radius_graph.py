@@ -83,32 +83,32 @@ def _host_cell_tables(cell: torch.Tensor, pbc_: List[bool], cutoff: float, with_
     buffer: image counts per axis (data/radius_graph.py:61-89), the image table and its Cartesian offsets per graph (:93-104),
     the reciprocal rows / thresholds of the image-pruned kernels and (for wrapping, :6-32) the inverse cells.  The cells are
     9 numbers per graph; as device tensor operations this was ~40 launches and three round trips (0.5 ms in front of a 0.07 ms
-    search).  Arithmetic in the cells' own dtype, in the reference's order of operations.
+    search).  The tables come from the C ABI's host functions (``xeq_pbc_image_counts`` / ``xeq_pbc_tables_host``: the cells'
+    own dtype, every operation rounded once, in the reference's order of operations) -- the same functions the registered
+    operator ``xeq::radius_graph_pbc`` calls, so the scripted and the Python models search with the same bits.
 
     -> reps [3] (ints), n_cells, dict of device tensors: cell_offsets [n_cells, 3], pbc_offsets [G, n_cells, 3], recip [G, 3, 3],
        thr [G, 3], cell_inv [G, 3, 3] (or None)."""
+    import ctypes
+
     import numpy as np
 
-    c = cell.detach().cpu().numpy()                                   # the round trip
+    from ..lib import call, dtype_code, mul3
+
+    c = np.ascontiguousarray(cell.detach().cpu().numpy())             # the round trip
     dt = c.dtype
     G = c.shape[0]
-    cross = [np.cross(c[:, 1], c[:, 2]), np.cross(c[:, 2], c[:, 0]), np.cross(c[:, 0], c[:, 1])]
-    vol = np.sum(c[:, 0] * cross[0], axis=-1, keepdims=True).astype(dt)
-    inv_min, reps = [], []
-    for ax in range(3):
-        d = np.sqrt(np.sum(np.square((cross[ax] / vol).astype(dt)), axis=-1)).astype(dt)
-        inv_min.append(d)
-        reps.append(int(np.ceil(dt.type(cutoff) * d).max()) if pbc_[ax] else 0)
-    recip = np.stack([(cr / vol).astype(dt) for cr in cross], axis=1)                    # [G, 3(axis), 3]
-    thr = (dt.type(cutoff) * np.stack(inv_min, axis=1) + dt.type(_PRUNE_MARGIN)).astype(dt)   # [G, 3]
-    axes = [np.arange(-r, r + 1, dtype=dt) for r in reps]
-    grid = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, 3)          # cartesian_prod order: first axis slowest
-    n_cells = grid.shape[0]
-    offs = np.einsum("ci,gij->gcj", grid, c).astype(dt)                                  # bmm(unit_cell_batch, cell)
-    parts = [grid.ravel(), offs.ravel(), recip.ravel(), thr.ravel()]
+    code = dtype_code(cell)
+    reps_c = (ctypes.c_int32 * 3)()
+    call("xeq_pbc_image_counts", code, ctypes.c_void_p(c.ctypes.data), G, mul3([int(v) for v in pbc_]), float(cutoff), reps_c)
+    reps = [int(v) for v in reps_c]
+    n_cells = (2 * reps[0] + 1) * (2 * reps[1] + 1) * (2 * reps[2] + 1)
+    n_tab = (3 + 3 * G) * n_cells + 12 * G
+    flat_h = np.empty(n_tab + (9 * G if with_inverse else 0), dtype=dt)
+    call("xeq_pbc_tables_host", code, ctypes.c_void_p(c.ctypes.data), G, reps_c, float(cutoff), ctypes.c_void_p(flat_h.ctypes.data), n_tab)
     if with_inverse:
-        parts.append(np.linalg.inv(c).astype(dt).ravel())
-    flat = torch.from_numpy(np.ascontiguousarray(np.concatenate(parts))).to(cell.device)   # one upload
+        flat_h[n_tab:] = np.linalg.inv(c).astype(dt).ravel()
+    flat = torch.from_numpy(flat_h).to(cell.device)                   # one upload
     out, o = {}, 0
     for name, shape in (("cell_offsets", (n_cells, 3)), ("pbc_offsets", (G, n_cells, 3)), ("recip", (G, 3, 3)), ("thr", (G, 3)),
                         ("cell_inv", (G, 3, 3))):

@@ -169,8 +169,9 @@ class XPaiNNLMPScript(nn.Module):
 class XPaiNNGMXScript(nn.Module):
     """Scriptable XPaiNN for GROMACS' NNPot interface (interface/jit_model.py:148-216): positions in nm in, energy in kJ/mol
     out, the caller differentiates the energy (``xeq::xpainn_eval`` hands its forces to autograd).  The neighbour search runs
-    inside the model; the scripted form covers open boundaries (``xeq::radius_graph``) -- a periodic box is searched by the
-    Python ``XPaiNNGMX`` (``data.radius_graph.single_radius_graph``)."""
+    inside the model under ``no_grad`` (jit_model.py:183-195): ``xeq::radius_graph_pbc`` for a periodic box -- the reference's
+    ``single_radius_graph`` order and cell offsets, the same list the Python ``XPaiNNGMX`` searches, bit for bit --
+    ``xeq::radius_graph`` for open boundaries."""
 
     def __init__(self, model) -> None:
         super().__init__()
@@ -182,13 +183,21 @@ class XPaiNNGMXScript(nn.Module):
 
     def forward(self, positions: torch.Tensor, atomic_numbers: torch.Tensor, box: Optional[torch.Tensor] = None,
                 pbc: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if pbc is not None:
-            if bool(pbc.any()):
-                raise RuntimeError("XPaiNNGMXScript: periodic boxes are searched by the Python XPaiNNGMX")
         pos = positions * self.pos_unit_factor
         ptr = torch.tensor([0, pos.shape[0]], dtype=torch.long, device=pos.device)
-        edge_index, _ = torch.ops.xeq.radius_graph(pos, ptr, self.cutoff_radius)
-        out = self.core(pos, atomic_numbers, edge_index, ptr, None, None, True, True, False, False)
+        periodic = False
+        if pbc is not None and box is not None:
+            periodic = bool(pbc.any())
+        if periodic:
+            assert box is not None and pbc is not None
+            cell = box * self.pos_unit_factor
+            with torch.no_grad():
+                edge_index, cell_offsets, _ = torch.ops.xeq.radius_graph_pbc(pos, cell, pbc, self.cutoff_radius)
+            out = self.core(pos, atomic_numbers, edge_index, ptr, cell.unsqueeze(0), cell_offsets, True, False, False, False)
+        else:
+            with torch.no_grad():
+                edge_index, _ = torch.ops.xeq.radius_graph(pos, ptr, self.cutoff_radius)
+            out = self.core(pos, atomic_numbers, edge_index, ptr, None, None, True, True, False, False)
         return out[0] * self.energy_unit_factor
 
 

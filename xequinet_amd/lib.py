@@ -38,6 +38,8 @@ _PROTOS = {
     "xeq_radius_graph_bin_ids": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P],
     "xeq_radius_graph_count_cl": [c_int, _P, _P, c_int64, c_int64, c_double, _P, _P, _P, _P, _P, _P, _P, _P],
     "xeq_radius_graph_fill_cl": [c_int, _P, _P, c_int64, c_int64, c_double, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P],
+    "xeq_pbc_image_counts": [c_int, _P, c_int64, _I3, c_double, _I3],
+    "xeq_pbc_tables_host": [c_int, _P, c_int64, _I3, c_double, _P, c_int64],
     "xeq_pbc_wrap": [c_int, _P, _P, c_int64, c_int64, _P, _P, _I3, _P, _P, _P],
     "xeq_radius_graph_pbc_count": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, c_double, _P, _P],
     "xeq_radius_graph_pbc_fill": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, c_int64, c_double, _P, c_int64, _P, _P, _P],
