@@ -67,6 +67,7 @@ if os.environ.get("XEQ_WQ_STAMPS"):
         tot = sum(vals)
         print(f"{title} ({cnt}): cycles by phase, one launch; {tot / max(cnt, 1):.0f} cycles per wave")
         for n, v in zip(names, vals): print(f"  {n:28s} {v / max(tot, 1) * 100:5.1f} %   {v / max(cnt, 1):9.0f} per wave")
+        if off == 0 and buf[14]: print(f"  tiles {buf[14]}: {buf[14] / max(cnt, 1):.1f} per wave; LITE build: slot 'phase D' = whole tile loops = {buf[8] / buf[14]:.0f} cycles per tile, 'body prologue' = range prologue")
 
 if os.environ.get("XEQ_WQ_ROLE_TIME"):   # workgroup timeline of the reverse kernel (a -DXEQ_WQ_ROLE_TIME build)
     import collections, ctypes

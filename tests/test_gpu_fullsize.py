@@ -23,7 +23,7 @@ from tests.test_gpu_parity import DEV, _build, _t, f32_force_bounds
 pytestmark = pytest.mark.gpu
 
 E_RTOL, E_ATOL = 1e-5, 1e-4
-N_SAMPLE = 64
+N_SAMPLE = 256   # molecules / frames the oracle evaluates: the error distribution is heavy-tailed, 64 draws leave the maximum to chance
 # forces (model units): tests/test_gpu_parity.py::f32_force_bounds
 SAME_BATCH_FORCE_MAX = 2e-3    # the same molecule in two batches (see test_chunked_equals_unchunked)
 

@@ -38,27 +38,37 @@ def f32_twin(oracle):
     return twin
 
 
+F32_ORACLE_ORDERS = 4       # members of the fp32 oracle's ensemble (edge orders), see f32_force_bounds
+
+
 def f32_force_bounds(oracle, ref_in, Fref):
     """(bound_max, bound_p99, err32_max, err32_p99): the fp32 oracle evaluated on the very inputs of the fp64 oracle.
-    err32 = |F_oracle32 - F_oracle64| is what fp32 rounding does to the reference's own arithmetic on these atoms (this
-    random-init model is ill-conditioned on a few of them); the HIP path has to stay within 1.5 x that, or within
-    BASELINE.md's 1e-4 where the fp32 oracle is better than that."""
+
+    err32 = |F_oracle32 - F_oracle64| is what fp32 rounding does to the reference's own arithmetic on these atoms.  This
+    random-init model is ill-conditioned on a few molecules (on 384 QM9-shape molecules the fp32 oracle's error is 3e-7 at
+    the median, 1e-6 at the 90th percentile, 2e-4 at the 99.9th and 8e-4 at the worst atom; the HIP path: 3e-7, 1e-6, 1.8e-4,
+    4.5e-4 -- profiles/parity_r03.json), and which atom is worst moves with the summation order: the reference's fp32
+    result is a SET (its index_add, nn/xpainn.py:156-159, is an atomic scatter on a GPU: SURVEY a13), so err32 is taken as
+    the envelope over F32_ORACLE_ORDERS legitimate edge orders (as given, reversed, two fixed permutations).  The HIP path
+    has to stay within 1.5 x that at the maximum and at the 99th percentile, or within BASELINE.md's 1e-4 where the fp32
+    oracle is better than that."""
+    twin = f32_twin(oracle)
     in32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in ref_in.items()}
-    F32 = f32_twin(oracle)(in32, compute_forces=True)["forces"].double().numpy()
-    err = np.abs(F32 - Fref)
+    ei = in32["edge_index"]
+    n_e = ei.shape[1]
+    rng = np.random.default_rng(20261004)
+    err = None
+    for member in range(F32_ORACLE_ORDERS):
+        perm = (torch.arange(n_e) if member == 0 else torch.arange(n_e - 1, -1, -1) if member == 1
+                else torch.as_tensor(rng.permutation(n_e)))
+        run = dict(in32)
+        run["edge_index"] = ei[:, perm]
+        if "cell_offsets" in run:
+            run["cell_offsets"] = run["cell_offsets"][perm]
+        e = np.abs(twin(run, compute_forces=True)["forces"].double().numpy() - Fref)
+        err = e if err is None else np.maximum(err, e)
     e_max, e_p99 = float(err.max()), float(np.quantile(err, 0.99))
     return max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_max), max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_p99), e_max, e_p99
-
-
-def _load(name):
-    return np.load(os.path.join(G, name))
-
-
-def _t(a, dtype=None):
-    t = torch.as_tensor(np.asarray(a))
-    if dtype is not None:
-        t = t.to(dtype)
-    return t.to(DEV)
 
 
 # ----------------------------------------------------------------------------- graph

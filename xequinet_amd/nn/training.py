@@ -30,9 +30,25 @@ def wants_training_pass(module: torch.nn.Module) -> bool:
     return module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
+_warned_eval_params = False
+
+
 def active(module: torch.nn.Module, data: Dict[str, torch.Tensor]) -> bool:
     flag = data.get(TRAIN_PASS)
-    return wants_training_pass(module) if flag is None else bool(flag)
+    on = wants_training_pass(module) if flag is None else bool(flag)
+    global _warned_eval_params
+    if not on and not _warned_eval_params and not module.training and torch.is_grad_enabled():
+        # eval mode with parameters that ask for gradients: the fused inference kernels differentiate with respect to the
+        # positions only, so loss.backward() through this call leaves the block parameters' .grad empty -- say so once
+        # (the check inside the autograd.Function of an earlier round could never fire: grad mode is off in there)
+        if any(p.requires_grad for p in module.parameters()):
+            import warnings
+
+            _warned_eval_params = True
+            warnings.warn("xequinet_amd: parameters require grad but the model is in eval mode: the fused inference path returns "
+                          "forces / virials only, no parameter gradients.  Use model.train() for the training pass "
+                          "(nn/training.py) or model.requires_grad_(False) to silence this.", stacklevel=3)
+    return on
 
 
 def _blocks(x: torch.Tensor, irreps) -> List[torch.Tensor]:
