@@ -95,3 +95,40 @@ if os.environ.get("XEQ_WQ_ROLE_TIME"):   # workgroup timeline of the reverse ker
     print("   latest finish per XCD:", {x: round(max(v)) for x, v in sorted(byx.items())})
     for cu, v in list(sorted(percu.items(), key=lambda kv: -max(b_ for _, b_, _ in kv[1])))[:2]:
         print("   latest CU", cu, [(round(a_), round(b_), l) for a_, b_, l in sorted(v)])
+
+if os.environ.get("XEQ_WQ_STEP_TIME"):   # per-step timeline of the workgroups (a -DXEQ_WQ_STEP_TIME (forward) or -DXEQ_WQ_STEP_TIME_BWD build)
+    import ctypes
+    from xequinet_amd import lib as _lib
+    L = _lib.load()
+    buf = (ctypes.c_uint * (8192 * 32))()
+    L.xeq_wq_debug_steps(buf)
+    run("wq"); torch.cuda.synchronize()
+    L.xeq_wq_debug_steps(buf)
+    raw = np.frombuffer(buf, dtype=np.uint32).reshape(8192, 4, 8)
+    lval = (raw[:, :, 7] >> 30).astype(int)
+    a = raw.astype(np.float64)
+    a[:, :, 7] = (raw[:, :, 7] & 0x3fffffff)
+    a /= 100.0   # us
+    ok = a[:, :, 7] > 0
+    med = lambda x: float(np.median(x))
+    for l in range(3):
+        for st in range(3):
+            m = ok[:, st] & (lval[:, st] == l)
+            if not m.any(): continue
+            r = a[m, st]
+            stage, bar1, body, bar2 = r[:, 1] - r[:, 0], r[:, 2] - r[:, 1], r[:, 3:7].max(1) - r[:, 2], r[:, 7] - r[:, 3:7].max(1)
+            skew = r[:, 3:7].max(1) - r[:, 3:7].min(1)
+            tot = r[:, 7] - r[:, 0]
+            print(f"l={l} step {st} ({int(m.sum())} wgs): total {med(tot):.2f} us = staging {med(stage):.2f} + barrier {med(bar1):.2f} + slowest range {med(body):.2f} + end barrier {med(bar2):.2f}; "
+                  f"skew {med(skew):.2f}; mean range {med((r[:, 3:7] - r[:, 2:3]).mean(1)):.2f}")
+if os.environ.get("XEQ_WQ_LOOP_TIME"):   # where a range's time goes: prologue (before the tile loop) against the tile loop
+    import ctypes
+    from xequinet_amd import lib as _lib
+    L = _lib.load()
+    run("wq"); torch.cuda.synchronize()
+    lp = (ctypes.c_ulonglong * (8192 * 4))(); lp2 = (ctypes.c_ulonglong * (8192 * 8))()
+    L.xeq_wq_debug_loop(lp, lp2)
+    lp = np.frombuffer(lp, dtype=np.uint64).reshape(8192, 4).astype(np.float64); lp2 = np.frombuffer(lp2, dtype=np.uint64).reshape(8192, 8).astype(np.float64)
+    m = (lp > 0) & (lp2[:, :4] > 0) & (lp2[:, 4:] > lp)
+    pro = (lp - lp2[:, :4])[m] / 100.0; loop = (lp2[:, 4:] - lp)[m] / 100.0
+    print(f"last range of {int(m.sum())} waves: prologue (barrier -> tile loop) median {np.median(pro):.2f} us (p90 {np.quantile(pro, .9):.2f}), tile loop median {np.median(loop):.2f} us (p90 {np.quantile(loop, .9):.2f})")

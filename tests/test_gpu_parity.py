@@ -71,6 +71,17 @@ def f32_force_bounds(oracle, ref_in, Fref):
     return max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_max), max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_p99), e_max, e_p99
 
 
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+def _t(a, dtype=None):
+    t = torch.as_tensor(np.asarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
 # ----------------------------------------------------------------------------- graph
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_radius_graph_nonpbc_bit_exact(dtype):

@@ -22,6 +22,11 @@
 //     constants, so products with them are hoisted out of the rows (l = 0: 7 vector instructions per row).
 //   * the per-edge sums over channels of the reverse pass (dL/dd, dL/dY_lm) use a register-halving DPP butterfly:
 //     16 rows x 32 lanes reduce in 48 instead of 80 cross-lane adds, and leave as one 64-byte store per quantity.
+//
+// This source is compiled TWICE (csrc/build.py): as it stands for the walk plan, the records and the forward kernel (LLVM's
+// max-ILP machine scheduler: forward launch 201 against 212 us), and through xeq_message_wq_bwd.hip with XEQ_WQ_PART_BWD
+// defined for the reverse kernel and the edge gradients (default scheduler, which weighs register pressure: reverse launch
+// 355 against 368 us).  Everything above the kernels is shared text.
 #include "xeq_common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -41,6 +46,7 @@ constexpr uint32_t WQ_FIRST = 1u << 30, WQ_LAST = 1u << 31, WQ_OWNER = (1u << 30
 #endif
 constexpr int WQ_WAVES = XEQ_WQ_WAVES;     // waves per workgroup: they share the unit's weights and, step by step, the window
 
+#ifndef XEQ_WQ_PART_BWD   // the forward half of this file (see the note at its top): plan, records, forward kernel
 // ------------------------------------------------------------------------------------------------ walk plan
 struct QuadCount {
   const int32_t* rowptr;
@@ -164,6 +170,7 @@ __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __res
   if (drec) *reinterpret_cast<f32x4*>(drec + 4 * t) = dv;
 }
 
+#endif
 // ------------------------------------------------------------------------------------------------ common
 struct WqArgs {
   int64_t n_nodes, n_edges, pcap;
@@ -427,10 +434,20 @@ __device__ __forceinline__ void wq_for_isolated(const WqArgs& a, int range, int 
 #ifndef XEQ_WQ_FSB
 #define XEQ_WQ_FSB() XEQ_WQ_SB()
 #endif
+// fences between the quads / passes of a REVERSE tile: none by default since round 3 (this file's reverse half is built with the
+// default, register-pressure-aware machine scheduler: with the owner rows fetched at the tile top it orders the loads of a tile
+// better than the fenced max-ILP stream did -- reverse launch 404 -> 355 us on QM9-1024; -DXEQ_WQ_RSB_ON restores the fences)
+#ifdef XEQ_WQ_RSB_ON
+#define XEQ_WQ_RSB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define XEQ_WQ_RSB() \
+  do {               \
+  } while (0)
+#endif
 
 // development (-DXEQ_WQ_STAMPS): cycles of the l = 0 waves per phase of the forward kernel, summed over a launch
-__device__ unsigned long long g_wq_stamps[32];
-__device__ unsigned long long g_wq_wg[8192 * 4];   // -DXEQ_WQ_ROLE_TIME / _FWD: per workgroup of the reverse / forward kernel (hw id | l << 32, xcc id, start, end in 100 MHz ticks)
+static __device__ unsigned long long g_wq_stamps[32];   // (static: each half of the file has its own)
+static __device__ unsigned long long g_wq_wg[8192 * 4];   // -DXEQ_WQ_ROLE_TIME / _FWD: per workgroup of the reverse / forward kernel (hw id | l << 32, xcc id, start, end in 100 MHz ticks)
 #ifdef XEQ_WQ_STAMPS
 #define WQ_STAMP(i)                                                                                          \
   do {                                                                                                       \
@@ -447,10 +464,18 @@ __device__ unsigned long long g_wq_wg[8192 * 4];   // -DXEQ_WQ_ROLE_TIME / _FWD:
   } while (0)
 #endif
 
-// ------------------------------------------------------------------------------------------------ forward
 __device__ __forceinline__ float wq_lds(const float* win, uint32_t byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(win) + byte_off);
 }
+#ifndef XEQ_WQ_FWD_WPE
+#define XEQ_WQ_FWD_WPE 2
+#endif
+#ifndef XEQ_WQ_BWD_WPE
+#define XEQ_WQ_BWD_WPE 2
+#endif
+
+#ifndef XEQ_WQ_PART_BWD
+// ------------------------------------------------------------------------------------------------ forward
 
 // window of the forward pass: per row the unit's pieces of h (gate_state | gate_edge | scalar message for l = 0) and of
 // xhat (NM pieces: component m in BT layout; the contiguous run of 32 NM floats in e3nn layout)
@@ -673,12 +698,6 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
   }
 }
 
-#ifndef XEQ_WQ_FWD_WPE
-#define XEQ_WQ_FWD_WPE 2
-#endif
-#ifndef XEQ_WQ_BWD_WPE
-#define XEQ_WQ_BWD_WPE 2
-#endif
 
 // one role of the forward kernel: the workgroup's steps, each with its window staged first when it fits
 template <int NM, int KS, bool XZ>
@@ -763,6 +782,8 @@ k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
 #endif
 }
 
+#endif
+#ifdef XEQ_WQ_PART_BWD    // the reverse half: reverse kernel, edge gradients
 // ------------------------------------------------------------------------------------------------ reverse
 struct WqParts {
   float* pd;   // [NU][P]      per-unit partial of dL/dd, by padded slot of the reverse walk
@@ -913,6 +934,23 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       }
     }
     float pd[16];
+    // l > 0: the owners' rows (h_state, h_edge, xhat of the unit's columns) of the tile's four quads, fetched HERE, once.  Round 2
+    // loaded them quad by quad inside the passes, behind scheduling fences between the quads: a load issued in a quad was waited
+    // for in that quad -- twelve exposed global round trips per tile (step timeline of round 3, QM9-1024: a range of the l = 1 /
+    // l = 2 units took 41 / 55 us against 28 us for l = 0, whose loads the scheduler hoists by itself; 34 / 43 us now).
+    float oq_hs[NM > 1 ? 4 : 1], oq_he[NM > 1 ? 4 : 1], oq_x[NM > 1 ? 4 : 1][NM];
+    if constexpr (NM > 1) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint32_t own = (uint32_t)tb[T_QOWN + 4 * hh + g];
+        oq_he[g] = wq_ld(h, own * row_h + wc.b_hs + he_off);
+        if constexpr (!FIRST) {
+          oq_hs[g] = wq_ld(h, own * row_h + wc.b_hs);
+#pragma unroll
+          for (int m = 0; m < NM; ++m) oq_x[g][m] = wq_ld(xhat, own * wc.xnode_b + wc.b_x + m * wc.xcomp_b);
+        }
+      }
+    }
     WQ_STAMP(5);   // tile top: gathers issued
     // l > 0: the gathered rows are read one component at a time (four rows x one m), used and dropped: out of the LDS
     // window a re-read costs 2 cycles, while holding a quad's 4 x NM values (next to the filters, pd and the per-quad
@@ -932,10 +970,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         const int c = 4 * hh + g;
         const uint32_t own = (uint32_t)tb[T_QOWN + c];
         const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
-        const float o_hs = wq_ld(h, own * row_h + wc.b_hs);
+        const float o_hs = NM > 1 ? oq_hs[NM > 1 ? g : 0] : wq_ld(h, own * row_h + wc.b_hs);
         float o_x[NM];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) o_x[m] = wq_ld(xhat, own * wc.xnode_b + wc.b_x + m * wc.xcomp_b);
+        for (int m = 0; m < NM; ++m) o_x[m] = NM > 1 ? oq_x[NM > 1 ? g : 0][m] : wq_ld(xhat, own * wc.xnode_b + wc.b_x + m * wc.xcomp_b);
         uint32_t g0[4];
         if constexpr (!HAS_S) wq_tread4<uint32_t>(tb, T_G0 + 16 * hh + 4 * g, g0);
         float u[NM], dgs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -969,10 +1007,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
           for (int m = 0; m < NM; ++m) wq_st(grad_xhat, ox + m * wc.xcomp_b, a_x[m]);
         }
-        if constexpr (NM > 1) XEQ_WQ_SB();
+        if constexpr (NM > 1) XEQ_WQ_RSB();
       }
     }
-    XEQ_WQ_SB();   // accumulator lifetimes of the passes stay disjoint
+    XEQ_WQ_RSB();   // accumulator lifetimes of the passes stay disjoint
     WQ_STAMP(7);   // rows of pass S
     const int my_q = half_beg + 4 * t + (my_r >> 2);                   // quad of the row this lane reports
     const bool keeper = j < 16 && my_q < half_end;                     // one 16-lane row per half stores
@@ -986,7 +1024,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         const int p0 = 16 * hh + 4 * g, c = 4 * hh + g;
         const uint32_t own = (uint32_t)tb[T_QOWN + c];
         const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
-        const float o_he = wq_ld(h, own * row_h + wc.b_hs + he_off);
+        const float o_he = NM > 1 ? oq_he[NM > 1 ? g : 0] : wq_ld(h, own * row_h + wc.b_hs + he_off);
         uint32_t g0[4];
         if constexpr (!HAS_S) wq_tread4<uint32_t>(tb, T_G0 + p0, g0);
         float dge[4], heq = 0.f;   // dge[r] = <Y[r], gx[r]>, one component at a time
@@ -1010,7 +1048,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         }
         a_he = (keep ? a_he : 0.f) + heq;
         if (last && node_grads) wq_st(grad_h, own * row_h + wc.b_hs + he_off, a_he);
-        if constexpr (NM > 1) XEQ_WQ_SB();
+        if constexpr (NM > 1) XEQ_WQ_RSB();
       }
       if constexpr (NM > 1) {
         // dL/dY_lm of every row's edge, in a second walk over the quads: the d/dd filter is dead by now, which is the
@@ -1018,8 +1056,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int p0 = 16 * hh + 4 * g;
-          const uint32_t own = (uint32_t)tb[T_QOWN + 4 * hh + g];
-          const float o_he = wq_ld(h, own * row_h + wc.b_hs + he_off);
+          const float o_he = oq_he[NM > 1 ? g : 0];
           uint32_t g0[4];
           wq_tread4<uint32_t>(tb, T_G0 + p0, g0);
           float wy[4];
@@ -1030,9 +1067,9 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
             float gv[4];
             gx4(g0, m, gv);
             pq[m][g] = wq_red_ab(wy[0] * gv[0], wy[1] * gv[1], wy[2] * gv[2], wy[3] * gv[3], b0, b1);
-            if constexpr (NM == 5) XEQ_WQ_SB();   // one component's butterfly at a time
+            if constexpr (NM == 5) XEQ_WQ_RSB();   // one component's butterfly at a time
           }
-          XEQ_WQ_SB();
+          XEQ_WQ_RSB();
         }
       }
       if constexpr (NM > 1) {
@@ -1044,7 +1081,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         }
       }
     }
-    XEQ_WQ_SB();
+    XEQ_WQ_RSB();
     if constexpr (!HAS_S) wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // next tile's records
     WQ_STAMP(8);   // rows of pass E (+ dL/dY sums)
     if constexpr (HAS_S) {  // ---- pass M
@@ -1057,9 +1094,9 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         for (int r = 0; r < 4; ++r) gsv[4 * g + r] = WIN ? wq_lds(win, g1[r] + lgs) : wq_ld(grad_s, g1[r] + wc.b_s);
       }
       const f32x16 dm = wq_filter<KS>(R, Wm), qm = wq_filter<KS>(Rd, Wm);
-      XEQ_WQ_SB();
+      XEQ_WQ_RSB();
       wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // last MFMAs issued: next tile's records
-      XEQ_WQ_SB();
+      XEQ_WQ_RSB();
       WQ_STAMP(6);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1078,7 +1115,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         if (last && node_grads) wq_st(grad_h, own * row_h + wc.b_hm, a_hm);
       }
     }
-    XEQ_WQ_SB();
+    XEQ_WQ_RSB();
     WQ_STAMP(9);   // rows of pass M
     {  // ---- dL/dd of every row's edge: sum over the unit's 32 channels
       float pq[4];
@@ -1207,6 +1244,7 @@ __global__ void k_wq_edge_grad(const float* __restrict__ vec, const int32_t* __r
   grad_vec[3 * (int64_t)e + 2] = out[2];
 }
 
+#endif
 static bool wq_supported(int num_basis, int node_dim, const int32_t mul[3]) {
   return num_basis >= 1 && num_basis <= 23 && mul[0] == node_dim && mul[0] > 0 && mul[0] % 32 == 0 && mul[1] >= 0 &&
          mul[1] % 32 == 0 && mul[2] >= 0 && mul[2] % 32 == 0;
@@ -1304,6 +1342,7 @@ using namespace xeq;
 
 extern "C" {
 
+#ifndef XEQ_WQ_PART_BWD
 int xeq_message_wq_supported(int num_basis, int node_dim, const int32_t mul[3]) { return wq_supported(num_basis, node_dim, mul) ? 1 : 0; }
 
 int xeq_message_wq_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
@@ -1398,6 +1437,8 @@ int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   return XEQ_OK;
 }
 
+#endif
+#ifdef XEQ_WQ_PART_BWD
 int64_t xeq_message_wq_parts_floats(int64_t n_nodes, int64_t n_edges, const int32_t mul[3]) {
   return wq_pcap(n_nodes, n_edges) * (int64_t)(mul[0] / 32 + mul[1] / 32 + mul[2] / 32 + 3 * (mul[1] / 32) + 5 * (mul[2] / 32));
 }
@@ -1435,21 +1476,28 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   return XEQ_OK;
 }
 
+#endif
+#ifdef XEQ_WQ_PART_BWD
+#define XEQ_WQ_DBG(name) name##_bwd
+#else
+#define XEQ_WQ_DBG(name) name
+#endif
 /* development: read and clear the phase cycle counters of a -DXEQ_WQ_STAMPS build */
-int xeq_wq_debug_wg(unsigned long long* out) {   // development (-DXEQ_WQ_ROLE_TIME): 8192 x 4, read and clear
+int XEQ_WQ_DBG(xeq_wq_debug_wg)(unsigned long long* out) {   // development (-DXEQ_WQ_ROLE_TIME): 8192 x 4, read and clear
   static unsigned long long zero[8192 * 4];
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wq_wg), sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_wq_wg), zero, sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
   return XEQ_OK;
 }
 
-int xeq_wq_debug_stamps(unsigned long long out[32]) {
+int XEQ_WQ_DBG(xeq_wq_debug_stamps)(unsigned long long out[32]) {
   unsigned long long zero[32] = {0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wq_stamps), sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_wq_stamps), zero, sizeof(zero)) != hipSuccess) return XEQ_ERR_LAUNCH;
   return XEQ_OK;
 }
 
+#ifdef XEQ_WQ_PART_BWD
 int xeq_message_wq_edge_grad(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
                              const int32_t mul[3], const void* parts, void* grad_vec, void* stream) {
   XEQ_CHECK_ARG(n_edges >= 0 && mul[0] % 32 == 0 && mul[1] % 32 == 0 && mul[2] % 32 == 0, "xeq_message_wq_edge_grad: bad sizes");
@@ -1465,4 +1513,5 @@ int xeq_message_wq_edge_grad(const void* vec, int64_t n_nodes, int64_t n_edges, 
   return XEQ_OK;
 }
 
+#endif
 }  // extern "C"
