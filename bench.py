@@ -136,6 +136,13 @@ def main():
                     help="file of library-GEMM selections: written by a run that times them, replayed (no timing launches) "
                          "when it already exists -- used by profiles/collect_stats.sh so that the trace holds no tuning kernels")
     ap.add_argument("--max-chunk-edges", type=int, default=None, help="edge cap per chunk of a sharded workload")
+    ap.add_argument("--replay-model-only", action="store_true",
+                    help="round 2's launch mode: the model part as a captured graph per (atoms, edges) signature, the neighbour list "
+                         "launched from the host with its edge count read back (default since round 3 for open-boundary workloads: "
+                         "neighbour list + model as ONE graph over capacity-sized arrays, runtime.GraphedStep)")
+    ap.add_argument("--vary-batch", type=int, default=0, metavar="K",
+                    help="feed K different draws of the workload in turn (different atom and edge counts every step) through the "
+                         "one captured graph")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -222,6 +229,25 @@ def main():
         step = step_eager if graphed is None else (lambda: step_chunked(graphed))
     elif args.eager:
         step = step_eager
+    elif cell is None and not args.replay_model_only:
+        # neighbour list + model as ONE captured graph (runtime.GraphedStep): arrays sized by a capacity, the edge count stays on
+        # the device, nothing is read back inside a step.  --vary-batch K: K different draws of the workload (their own atom and
+        # edge counts) take turns through the same graph
+        draws = [(pos_d, z_d, ptr_d, ptr)]
+        for k in range(1, max(1, args.vary_batch)):
+            p_k, z_k, ptr_k, _ = syn.make_workload(args.workload, seed=4321 + 97 * k + rank)
+            draws.append((torch.tensor(p_k, dtype=dtype, device=dev), torch.tensor(z_k, device=dev), torch.tensor(ptr_k, device=dev), ptr_k))
+        cap = (max(d[0].shape[0] for d in draws) + 64, len(ptr) - 1, max(runtime.pair_capacity(d[3]) for d in draws))
+        gstep = runtime.GraphedStep(model, cap, compute_forces=True)
+        edge_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        turn = [0]
+
+        def step():
+            p_k, z_k, ptr_k, _ = draws[turn[0] % len(draws)]
+            turn[0] += 1
+            out = gstep(p_k, z_k, ptr_k)
+            edge_total.add_(out["n_edges"])            # stays on the device; read once behind the timed region
+            return None, out
     else:
         # the same kernels in the same order as one HIP-graph launch (results bitwise those of the eager path); the
         # neighbour list stays eager: its edge count has to reach the host to size the edge arrays
@@ -231,6 +257,7 @@ def main():
             batch = transform(new_batch())
             return batch.edge_index.shape[1], graphed(batch.to_dict())
 
+    whole_step = not sharded and not args.eager and cell is None and not args.replay_model_only
     try:
         # set-up, not a timed or counted step: the first evaluation times the library GEMM candidates (TunableOp) and
         # captures the HIP graph; the W warm-up steps and the K timed steps that follow are all plain steps
@@ -238,6 +265,8 @@ def main():
         for _ in range(args.warmup):
             n_edges, out = step()
         torch.cuda.synchronize()
+        if whole_step:
+            n_edges = int(out["n_edges"].item())
     except RuntimeError as err:      # a failed capture must not cost the measurement: fall back to host launches
         if args.eager:
             raise
@@ -257,14 +286,20 @@ def main():
     ops.KERNEL_TIMER.reset(enabled=args.eager)
     xdist.barrier()
     torch.cuda.synchronize()
+    if whole_step:
+        edge_total.zero_()
+        turn[0] = 0
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     edges_done = 0
     for _ in range(args.steps):
-        n_edges, out = step()
-        edges_done += n_edges
+        n_step, out = step()
+        edges_done += n_step if n_step is not None else 0
     torch.cuda.synchronize()
     xdist.barrier()
     elapsed = time.perf_counter() - t0
+    if whole_step:
+        edges_done = int(edge_total.item())   # the device-side counts of the K timed steps
     eager_ms = native_ms = None
     if args.eager:
         kernel_ms = ops.KERNEL_TIMER.summary()       # HIP events recorded on the launch stream, in the timed region
@@ -303,7 +338,11 @@ def main():
                     got = step_native()
                 torch.cuda.synchronize()
                 native_ms = (time.perf_counter() - tn) / cal * 1e3
-                assert torch.equal(got[2], out_keep["forces"]), "native operator and graph replay disagree"
+                if whole_step:   # the captured step works on the padded batch (another row count for the remaining library GEMMs)
+                    if max(1, args.vary_batch) == 1:
+                        assert float((got[2] - out_keep["forces"]).abs().max()) <= 2e-3, "native operator and graph replay disagree"
+                else:
+                    assert torch.equal(got[2], out_keep["forces"]), "native operator and graph replay disagree"
             except ImportError as err:
                 print(f"[bench] native operator not timed: {err}", file=sys.stderr, flush=True)
         ops.KERNEL_TIMER.reset(enabled=True)
@@ -381,7 +420,9 @@ def main():
                        "parallelism": f"molecule shards x{world}, no collectives", "chunks_rank0": n_chunks,
                        "resident_inputs": "the collated batch (positions, atomic numbers, graph pointer, per-atom graph index); every step builds its neighbour list and evaluates the model",
                        "library_gemm_selection": "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)",
-                       "launch": "host launch per kernel" if args.eager else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host",
+                       "launch": ("host launch per kernel" if args.eager else
+                                  f"neighbour list + model as ONE captured HIP graph over capacity-sized arrays, edge count on the device (runtime.GraphedStep; {max(1, args.vary_batch)} different draw(s) of the workload in turn)"
+                                  if whole_step else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host"),
                        "ms_per_step_eager": "the same step with every kernel launched from the host through the Python modules, measured on rank 0 right after the timed region",
                        "ms_per_step_native_op": "the same step as ONE registered operator (xeq::xpainn_eval: kernels enqueued from C++, no capture): what a stream of batches with ever-new edge counts pays"},
             "roofline": roofline,

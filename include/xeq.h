@@ -70,6 +70,11 @@ int xeq_exclusive_scan_i32_ws(const int32_t* counts, int64_t n, int32_t* out, vo
  * Phase 1 writes deg[N]; the caller scans it (xeq_exclusive_scan_i32), reads
  * E = rowptr[N] back, allocates edge_index[2,E]; phase 2 fills it in canonical
  * order: sorted by center (row 0), then neighbor (row 1). */
+/* Capacity form (round 3): the edge count need not reach the host.  Pass a CAPACITY as n_edges (edge_index [2, capacity], never
+ * written past) and hand the same capacity to xeq_reverse_edge_map, xeq_edge_vectors_fwd and the wq message entry points: every
+ * walk over the list is bounded by rowptr[n_nodes] on the device, slots behind it keep whatever valid node ids they held (zero-
+ * initialise the buffer once).  This is what lets neighbour list + model run as ONE captured HIP graph for batches of changing
+ * edge counts (xequinet_amd/runtime.py::GraphedStep); an open-boundary list never exceeds sum_g n_g (n_g - 1). */
 int xeq_radius_graph_count(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,
                            double cutoff, int32_t* deg, void* stream);
 int xeq_radius_graph_fill(int dtype, const void* pos, const int64_t* ptr, int64_t n_graphs, int64_t n_nodes,

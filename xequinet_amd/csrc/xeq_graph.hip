@@ -98,9 +98,9 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan_i32(const int32_t* __re
 // builders emit): the neighbour-sorted order of edge (i -> j) is the position of its reverse edge (j -> i) in the
 // center-sorted list, found by binary search in segment j.  rev[e] = -1 when the reverse edge does not exist.
 __global__ void k_reverse_edge_map(const int64_t* __restrict__ center, const int64_t* __restrict__ nbr,
-                                   const int32_t* __restrict__ c_rowptr, int64_t E, int32_t* __restrict__ rev) {
+                                   const int32_t* __restrict__ c_rowptr, int64_t E, int64_t N, int32_t* __restrict__ rev) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+  if (e >= E || e >= c_rowptr[N]) return;   // E may be a capacity: the list itself ends at c_rowptr[N] (device-side count)
   const int64_t i = center[e], j = nbr[e];
   int32_t lo = c_rowptr[j], hi = c_rowptr[j + 1];
   while (lo < hi) {
@@ -162,8 +162,10 @@ __global__ void k_radius_graph(const T* __restrict__ pos, const int64_t* __restr
     const unsigned long long m = __ballot(hit);
     if (FILL && hit) {
       const int64_t p = w + __popcll(m & ((1ull << lane) - 1ull));
-      edge_index[p] = i;            // center
-      edge_index[n_edges + p] = j;  // neighbor
+      if (p < n_edges) {              // n_edges: the row length of edge_index -- the edge count, or a capacity (never written past)
+        edge_index[p] = i;            // center
+        edge_index[n_edges + p] = j;  // neighbor
+      }
     }
     const int pc = __popcll(m);
     w += pc;
@@ -792,7 +794,7 @@ int xeq_reverse_edge_map(const int64_t* edge_index, int64_t n_edges, int64_t n_n
   XEQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 0, "xeq_reverse_edge_map: negative size");
   if (n_edges == 0) return XEQ_OK;
   hipLaunchKernelGGL(k_reverse_edge_map, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     edge_index, edge_index + n_edges, c_rowptr, n_edges, rev);
+                     edge_index, edge_index + n_edges, c_rowptr, n_edges, n_nodes, rev);
   XEQ_CHECK_LAUNCH("xeq_reverse_edge_map");
   return XEQ_OK;
 }

@@ -55,12 +55,12 @@ struct QuadCount {
 };
 
 // one thread per slot of the walk order: its padded position, the pads behind a segment's last slot, the quad records
-__global__ void k_wq_fill(int64_t E, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
+__global__ void k_wq_fill(int64_t E, int64_t n_nodes, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
                           const int64_t* __restrict__ owner, const int64_t* __restrict__ gather,
                           const int32_t* __restrict__ qptr, int32_t* __restrict__ pgath, int32_t* __restrict__ peid,
                           uint32_t* __restrict__ qinfo) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= E) return;
+  if (s >= E || s >= rowptr[n_nodes]) return;   // E may be a capacity: the walk ends at rowptr[N] (device-side edge count)
   const int32_t eid = perm ? perm[s] : (int32_t)s;
   const int64_t n = owner[eid];
   const int32_t r0 = rowptr[n], deg = rowptr[n + 1] - r0, k = (int32_t)(s - r0), q0 = qptr[n], nq = (deg + 3) >> 2;
@@ -1378,7 +1378,7 @@ int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_
     return XEQ_ERR_LAUNCH;
   }
   if (n_edges > 0) {
-    hipLaunchKernelGGL(k_wq_fill, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_edges, rowptr,
+    hipLaunchKernelGGL(k_wq_fill, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_edges, n_nodes, rowptr,
                        perm, owner, gather, (const int32_t*)qptr, pgath, peid, (uint32_t*)qinfo);
     XEQ_CHECK_LAUNCH("xeq_message_wq_plan (fill)");
   }

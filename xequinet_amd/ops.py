@@ -260,6 +260,27 @@ def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tu
     return edge_index, rowptr
 
 
+def radius_graph_capacity(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float, edge_index: torch.Tensor) -> torch.Tensor:
+    """Non-PBC neighbour list into a caller-owned ``edge_index`` [2, capacity] WITHOUT reading the edge count back: returns the
+    row pointer [N + 1] (``rowptr[N]`` is the count, on the device).  Slots behind the count keep their old contents, which must
+    be valid node ids (zero-initialise the buffer once).  Every kernel downstream bounds its walk by the row pointer, so the
+    whole evaluation can sit in one captured HIP graph (runtime.GraphedStep).  The pair sweep only (graphs of many atoms go
+    through the cell list, whose bin count is a host value)."""
+    require_hip(pos, ptr_, edge_index)
+    pos = pos.detach().contiguous()
+    ptr_ = ptr_.to(torch.int64).contiguous()
+    assert edge_index.dim() == 2 and edge_index.shape[0] == 2 and edge_index.dtype == torch.int64 and edge_index.is_contiguous()
+    N, G, cap = pos.shape[0], ptr_.numel() - 1, int(edge_index.shape[1])
+    dev = pos.device
+    deg = torch.empty(N, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    dt = dtype_code(pos)
+    call("xeq_radius_graph_count", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(deg), stream())
+    _exclusive_scan(deg, N, rowptr)
+    call("xeq_radius_graph_fill", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(rowptr), cap, ptr(edge_index), stream())
+    return rowptr
+
+
 def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):
     """PBC neighbour search over precomputed images (see xeq_radius_graph_pbc_* in xeq.h).
     prune = (recip[G,3,3], thr[G,3], reps) selects the image-pruned kernels (same edges, same order)."""

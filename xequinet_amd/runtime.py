@@ -188,6 +188,119 @@ class GraphedModel:
         return bool(torch.equal(ei, ref))
 
 
+# ----------------------------------------------------------------------------------------------- whole step as one graph
+def pair_capacity(ptr_host) -> int:
+    """Upper bound of an open-boundary neighbour list: every ordered pair inside a graph, sum_g n_g (n_g - 1)."""
+    import numpy as np
+
+    n = np.diff(np.asarray(ptr_host, dtype=np.int64))
+    return int((n * (n - 1)).sum())
+
+
+class GraphedStep:
+    """Neighbour list + model as ONE captured HIP graph that does not depend on the edge count (open boundaries).
+
+    ``GraphedModel`` replays the model per (atoms, edges) signature and leaves the neighbour list outside the graph, because the
+    list's edge count sizes the edge arrays and has to reach the host (as the reference's ``nonzero`` does,
+    data/radius_graph.py:124-125; torch_cluster, data/transform.py:58-64): a stream of batches with ever-new edge counts
+    re-captures every time.  Here every array is sized by a CAPACITY -- atoms, graphs, edges -- the count / scan / fill kernels,
+    the reverse-edge map, the walk plans, the records and the model all run inside the graph, and the true edge count stays
+    on the device (``rowptr[N]`` bounds every walk; the tail of the edge arrays is never read as an edge).  A batch smaller
+    than the capacity is padded: trailing atoms with atomic number 0 in one trailing graph, 100 A apart (no edges; their
+    energies / forces are cut off the result).  Results are bitwise those of the eager path on the padded batch.
+
+    ``capacity = (n_atoms, n_graphs, n_edges)``; ``n_edges`` must bound the list: ``pair_capacity(ptr)`` always does.
+    A batch beyond the capacity raises (make a larger GraphedStep)."""
+
+    PAD_SPACING = 100.0
+
+    def __init__(self, model: torch.nn.Module, capacity, cutoff: Optional[float] = None, compute_forces: bool = True, warmup: int = 2,
+                 device=None, dtype=None) -> None:
+        self.model = model
+        self.n_atoms, self.n_graphs, self.n_edges = (int(c) for c in capacity)
+        self.n_graphs += 1                                   # + the padding graph
+        self.cutoff = float(model.cutoff_radius if cutoff is None else cutoff)
+        self.compute_forces = compute_forces
+        p = next(model.parameters())
+        dev = p.device if device is None else torch.device(device)
+        dt = p.dtype if dtype is None else dtype
+        N, G, E = self.n_atoms, self.n_graphs, self.n_edges
+        self.pos = torch.zeros((N, 3), dtype=dt, device=dev)
+        self.z = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+        self.batch = torch.zeros(N, dtype=torch.int64, device=dev)
+        self.edge_index = torch.zeros((2, max(E, 1)), dtype=torch.int64, device=dev)   # zero = a valid node id in every unused slot
+        self.pad_pos = (torch.arange(N, dtype=torch.float64, device=dev) * self.PAD_SPACING + 1.0e4).to(dt)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.outputs: Dict[str, torch.Tensor] = {}
+        self.rowptr: Optional[torch.Tensor] = None
+        self.warmup = warmup
+        self.captures = 0
+        self._sizes = (0, 0)
+
+    # -- the step on the static buffers (what is captured)
+    def _step(self) -> Dict[str, torch.Tensor]:
+        rowptr = ops.radius_graph_capacity(self.pos, self.ptr, self.cutoff, self.edge_index)
+        eg = ops.EdgeGraph(self.edge_index, self.n_atoms, center_sorted=True, ptr=self.ptr, c_rowptr=rowptr, symmetric=True)
+        data = {keys.POSITIONS: self.pos.detach(), keys.ATOMIC_NUMBERS: self.z, keys.EDGE_INDEX: self.edge_index, keys.BATCH: self.batch,
+                keys.BATCH_PTR: self.ptr, keys.EDGE_GRAPH: eg}
+        with torch.enable_grad():
+            out = self.model(data, compute_forces=self.compute_forces, compute_virial=False)
+        res = {k: v.detach() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        res["n_edges"] = rowptr[self.n_atoms:]              # device-side edge count (a view of the row pointer's last entry)
+        return res
+
+    def _load(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor]) -> None:
+        """The batch into the static buffers, padded to the capacity; device work only (five small launches, no read-back)."""
+        n, g = int(pos.shape[0]), int(ptr.numel() - 1)
+        if n > self.n_atoms or g > self.n_graphs - 1:
+            raise ValueError(f"GraphedStep: batch of {n} atoms / {g} graphs exceeds the capacity {self.n_atoms} / {self.n_graphs - 1}")
+        N, G = self.n_atoms, self.n_graphs
+        self.pos[:n].copy_(pos.detach(), non_blocking=True)
+        self.z[:n].copy_(atomic_numbers.to(torch.int32), non_blocking=True)
+        self.ptr[: g + 1].copy_(ptr.to(torch.int64), non_blocking=True)
+        if (n, g) != self._sizes:                            # the padding moves only when the batch's sizes do
+            self.pos[n:, 0].copy_(self.pad_pos[: N - n])
+            self.pos[n:, 1:].zero_()
+            self.z[n:].zero_()
+            self.ptr[g + 1 : G].fill_(n)                     # empty graphs between the batch and the padding graph
+            self.ptr[G].fill_(N)
+            self.batch[n:].fill_(G - 1)
+            self._sizes = (n, g)
+        if batch is not None:
+            self.batch[:n].copy_(batch.to(torch.int64), non_blocking=True)
+        else:
+            counts = ptr[1:] - ptr[:-1]
+            self.batch[:n].copy_(torch.repeat_interleave(torch.arange(g, device=ptr.device), counts, output_size=n))
+
+    def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor] = None,
+                 ptr_host=None) -> Dict[str, torch.Tensor]:
+        """-> {energy [G], atomic_energies [n], forces [n, 3], n_edges [1] (device)}: views of the graph's output buffers,
+        overwritten by the next call.  ``ptr_host`` (optional): checks the edge capacity against the batch on the host."""
+        if ptr_host is not None and pair_capacity(ptr_host) > self.n_edges:
+            raise ValueError(f"GraphedStep: the batch may hold {pair_capacity(ptr_host)} edges, the capacity is {self.n_edges}")
+        self._load(pos, atomic_numbers, ptr, batch)
+        if self.graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self._step()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.outputs = self._step()
+            self.captures += 1
+        self.graph.replay()
+        n, g = int(pos.shape[0]), int(ptr.numel() - 1)
+        out = {keys.TOTAL_ENERGY: self.outputs[keys.TOTAL_ENERGY][:g], "n_edges": self.outputs["n_edges"]}
+        if keys.ATOMIC_ENERGIES in self.outputs:
+            out[keys.ATOMIC_ENERGIES] = self.outputs[keys.ATOMIC_ENERGIES][:n]
+        if keys.FORCES in self.outputs:
+            out[keys.FORCES] = self.outputs[keys.FORCES][:n]
+        return out
+
+
 # ----------------------------------------------------------------------------------------------- chunked evaluation
 WM_MAX_EDGES_PER_CHUNK = 8_000_000   # well inside the 14.9 M-edge bound of the matrix-core message kernels
 
