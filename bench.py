@@ -233,19 +233,20 @@ def main():
         # neighbour list + model as ONE captured graph (runtime.GraphedStep): arrays sized by a capacity, the edge count stays on
         # the device, nothing is read back inside a step.  --vary-batch K: K different draws of the workload (their own atom and
         # edge counts) take turns through the same graph
-        draws = [(pos_d, z_d, ptr_d, ptr)]
+        draws = [(pos_d, z_d, ptr_d, ptr, collated.batch)]     # the collated batch: per-atom graph index included, as before
         for k in range(1, max(1, args.vary_batch)):
             p_k, z_k, ptr_k, _ = syn.make_workload(args.workload, seed=4321 + 97 * k + rank)
-            draws.append((torch.tensor(p_k, dtype=dtype, device=dev), torch.tensor(z_k, device=dev), torch.tensor(ptr_k, device=dev), ptr_k))
+            b_k = XequiBatch(torch.tensor(p_k, dtype=dtype, device=dev), torch.tensor(z_k, device=dev), torch.tensor(ptr_k, device=dev))
+            draws.append((b_k.pos, b_k.atomic_numbers, b_k.ptr, ptr_k, b_k.batch))
         cap = (max(d[0].shape[0] for d in draws) + 64, len(ptr) - 1, max(runtime.pair_capacity(d[3]) for d in draws))
         gstep = runtime.GraphedStep(model, cap, compute_forces=True)
         edge_total = torch.zeros(1, dtype=torch.int64, device=dev)
         turn = [0]
 
         def step():
-            p_k, z_k, ptr_k, _ = draws[turn[0] % len(draws)]
+            p_k, z_k, ptr_k, _, b_k = draws[turn[0] % len(draws)]
             turn[0] += 1
-            out = gstep(p_k, z_k, ptr_k)
+            out = gstep(p_k, z_k, ptr_k, batch=b_k)
             edge_total.add_(out["n_edges"])            # stays on the device; read once behind the timed region
             return None, out
     else:

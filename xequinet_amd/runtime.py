@@ -230,13 +230,11 @@ class GraphedStep:
         self.ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
         self.batch = torch.zeros(N, dtype=torch.int64, device=dev)
         self.edge_index = torch.zeros((2, max(E, 1)), dtype=torch.int64, device=dev)   # zero = a valid node id in every unused slot
-        self.pad_pos = (torch.arange(N, dtype=torch.float64, device=dev) * self.PAD_SPACING + 1.0e4).to(dt)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.outputs: Dict[str, torch.Tensor] = {}
         self.rowptr: Optional[torch.Tensor] = None
         self.warmup = warmup
         self.captures = 0
-        self._sizes = (0, 0)
 
     # -- the step on the static buffers (what is captured)
     def _step(self) -> Dict[str, torch.Tensor]:
@@ -251,27 +249,19 @@ class GraphedStep:
         return res
 
     def _load(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor]) -> None:
-        """The batch into the static buffers, padded to the capacity; device work only (five small launches, no read-back)."""
+        """The batch into the static buffers, padded to the capacity: one launch (xeq_load_padded_batch), no read-back."""
+        from .lib import call, dtype_code, ptr as p_, stream
+
         n, g = int(pos.shape[0]), int(ptr.numel() - 1)
         if n > self.n_atoms or g > self.n_graphs - 1:
             raise ValueError(f"GraphedStep: batch of {n} atoms / {g} graphs exceeds the capacity {self.n_atoms} / {self.n_graphs - 1}")
-        N, G = self.n_atoms, self.n_graphs
-        self.pos[:n].copy_(pos.detach(), non_blocking=True)
-        self.z[:n].copy_(atomic_numbers.to(torch.int32), non_blocking=True)
-        self.ptr[: g + 1].copy_(ptr.to(torch.int64), non_blocking=True)
-        if (n, g) != self._sizes:                            # the padding moves only when the batch's sizes do
-            self.pos[n:, 0].copy_(self.pad_pos[: N - n])
-            self.pos[n:, 1:].zero_()
-            self.z[n:].zero_()
-            self.ptr[g + 1 : G].fill_(n)                     # empty graphs between the batch and the padding graph
-            self.ptr[G].fill_(N)
-            self.batch[n:].fill_(G - 1)
-            self._sizes = (n, g)
-        if batch is not None:
-            self.batch[:n].copy_(batch.to(torch.int64), non_blocking=True)
-        else:
+        if batch is None:
             counts = ptr[1:] - ptr[:-1]
-            self.batch[:n].copy_(torch.repeat_interleave(torch.arange(g, device=ptr.device), counts, output_size=n))
+            batch = torch.repeat_interleave(torch.arange(g, device=ptr.device), counts, output_size=n)
+        pos_c = pos.detach().to(self.pos.dtype).contiguous()
+        z_c, ptr_c, batch_c = atomic_numbers.to(torch.int32).contiguous(), ptr.to(torch.int64).contiguous(), batch.to(torch.int64).contiguous()
+        call("xeq_load_padded_batch", dtype_code(pos_c), p_(pos_c), p_(z_c), p_(ptr_c), p_(batch_c), n, g, self.n_atoms, self.n_graphs,
+             1.0e4, self.PAD_SPACING, p_(self.pos), p_(self.z), p_(self.ptr), p_(self.batch), stream())
 
     def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor] = None,
                  ptr_host=None) -> Dict[str, torch.Tensor]:
