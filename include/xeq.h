@@ -233,6 +233,20 @@ int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n,
  * words, buffers must not overlap).  src / dst / bytes are HOST arrays.  HIP-graph replay (runtime.GraphedModel) refreshes
  * the captured inputs of an evaluation with it -- the per-step tensor hand-over the reference does with `data.to(device)`
  * (run/inference.py:39). */
+/* Single f32 linear layers on the matrix cores, y = act(x W^T + b) (csrc/xeq_linear.hip): the node-side contractions that are
+ * not two-layer MLPs -- dot_lin (nn/xpainn.py:191-193, :222-223) and its input gradient, the embedding Linear(56, 128) on the
+ * gathered table rows (nn/xpainn.py:43-48, nn/basic.py:57: `row_index` = atomic numbers gathers the rows of x), the energy
+ * head's first layer (nn/output.py:104-118).  w_packed: xeq_mlp_pack(W, b, n_out, k_in, transposed) -- transposed = 1 with
+ * W given as [k_in][n_out] turns the same weight into the input-gradient product.  k_in % 8 == 0, <= 256; n_out % 32 == 0, <= 256;
+ * act 0 none / 1 SiLU; pre (optional) receives the pre-activation.  A row's sums run in one fixed order whatever n is.
+ * xeq_head_dot: out[n] = <hidden[n, :], w2> + b2 (the head's last layer, nn/output.py:104-106); xeq_head_bwd_hidden: its
+ * reverse with the SiLU in front, g_hidden[n, j] = g_atomic[n] w2[j] silu'(pre[n, j]) (g_atomic NULL: ones). */
+int xeq_linear_supported(int dtype, int k_in, int n_out);
+int xeq_linear_fwd(const void* x, int64_t ldx, int64_t n, int k_in, const int32_t* row_index, const void* w_packed, int n_out,
+                   int has_bias, int act, void* pre, void* y, int64_t ldy, void* stream);
+int xeq_head_dot(const void* hidden, int64_t n, int hidden_dim, const void* w2, const void* b2, void* out, void* stream);
+int xeq_head_bwd_hidden(const void* pre, int64_t n, int hidden_dim, const void* w2, const void* g_atomic, void* g_hidden, void* stream);
+
 /* A batch of n atoms in g graphs into arrays of n_cap atoms / g_cap graphs in ONE launch (runtime.GraphedStep: neighbour list +
  * model as one captured graph over capacity-sized arrays): atoms n .. n_cap - 1 get atomic number 0, positions
  * (pad0 + spacing (i - n), 0, 0) -- no two within any cutoff -- and sit alone in graph g_cap - 1; graphs g .. g_cap - 2 are empty.

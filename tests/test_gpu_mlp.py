@@ -183,3 +183,53 @@ def test_update_block_without_a_consumer_of_x_out(monkeypatch, n):
     c = run(False)   # sanity against the chain (rounding-level agreement is pinned against f64 in the test above)
     for got, ref in zip(a, c):
         assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
+# ---- single linear layers (csrc/xeq_linear.hip): dot_lin both ways, the embedding with its table gather, the energy head ----
+@pytest.mark.parametrize("n", [1, 31, 33, 1000])
+@pytest.mark.parametrize("k_in,n_out,bias", [(224, 128, False), (128, 224, False), (56, 128, True), (128, 64, True), (64, 128, False)])
+def test_linear_matches_fp64_and_does_not_depend_on_the_batch(n, k_in, n_out, bias):
+    torch.manual_seed(n + k_in)
+    lin = torch.nn.Linear(k_in, n_out, bias=bias).to(DEV).requires_grad_(False)
+    if bias:
+        lin.bias.normal_()
+    x = torch.randn(n, k_in, device=DEV)
+    y = fused.linear_module_fwd(lin, x)
+    ref = x.double() @ lin.weight.double().t() + (lin.bias.double() if bias else 0.0)
+    assert y.shape == (n, n_out) and float((y.double() - ref).abs().max()) <= TOL
+    # the same rows inside a larger batch, at another offset: the same bits
+    big = torch.cat([torch.randn(45, k_in, device=DEV), x, torch.randn(19, k_in, device=DEV)])
+    assert torch.equal(fused.linear_module_fwd(lin, big)[45:45 + n], y)
+    # input gradient through the transposed pack of the same weight
+    g = torch.randn(n, n_out, device=DEV)
+    gx = fused.linear_module_bwd(lin, g)
+    assert float((gx.double() - g.double() @ lin.weight.double()).abs().max()) <= TOL
+
+
+def test_embedding_lookup_and_energy_head_kernels():
+    from xequinet_amd.nn import resolve_model
+
+    torch.manual_seed(3)
+    model = resolve_model("xpainn").eval().requires_grad_(False).to(DEV)
+    emb = model.mods["embedding"]
+    z = torch.randint(0, 87, (999,), device=DEV, dtype=torch.int32)
+    got = emb._embed(z)
+    lin = emb.embedding[1]
+    with torch.no_grad():
+        lin.bias.normal_()
+    got = emb._embed(z)
+    ref = emb.embedding[0].embed_ten[z.long()].double() @ lin.weight.double().t() + lin.bias.double()
+    assert float((got.double() - ref).abs().max()) <= TOL * max(1.0, float(ref.abs().max()))
+    assert torch.equal(emb._embed(z[100:200]), got[100:200])
+    # energy head: Linear(128, 64) - SiLU - Linear(64, 1), values and input gradient
+    head = model.mods["output_energy"].out_mlp
+    s = torch.randn(777, 128, device=DEV, requires_grad=True)
+    assert fused.EnergyHead.supported(head, s)
+    e = fused.EnergyHead.apply(s, head)
+    g = torch.randn(777, device=DEV)
+    (gs,) = torch.autograd.grad(e, s, g)
+    sd = s.detach().double().requires_grad_(True)
+    w1, b1, w2, b2 = (t.double() for t in (head[0].weight, head[0].bias, head[2].weight, head[2].bias))
+    er = (torch.nn.functional.silu(sd @ w1.t() + b1) @ w2.t() + b2).reshape(-1)
+    (gr,) = torch.autograd.grad(er, sd, g.double())
+    assert float((e.double() - er).abs().max()) <= TOL and float((gs.double() - gr).abs().max()) <= TOL

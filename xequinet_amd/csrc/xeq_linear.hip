@@ -1,0 +1,176 @@
+// Single linear layers of the node side on the matrix cores: the contractions round 2 still gave to library GEMMs.
+//   dot_lin                Linear(224, 128, bias=False) on <U, V> and its input gradient   (nn/xpainn.py:191-193, :222-223)
+//   embedding              Linear(56, 128) on the gathered table rows                      (nn/xpainn.py:43-48, nn/basic.py:57)
+//   energy head            Linear(128, 64) - SiLU - Linear(64, 1) and its input gradient   (nn/output.py:104-118)
+// Why own kernels for 0.13 ms of library time: a library picks another GEMM kernel -- another summation order -- for another row
+// count, so the same molecule got other bits in another batch (sharded against unsharded, chunked against whole: 4e-4 in the
+// forces of an ill-conditioned molecule).  Here a row's sums run in one fixed order whatever the batch: with these entries the
+// whole f32 path is batch-independent bit for bit.
+//
+// Design: the MLP kernels' conventions (xeq_mlp.hip).  A workgroup (4 waves) owns 32 consecutive rows; exact-f32
+// v_mfma_f32_32x32x2_f32 tiles D[column][row] with the WEIGHT fragment as the A operand, read global -> register from the copy
+// xeq_mlp_pack makes (packed[tile][k-group][lane][4], the bias as one more k-group against a row of ones); the row operand is
+// staged once in LDS (K <= 256) with 16-byte loads, optionally gathered through a row index (the embedding table lookup).
+// Wave w computes output tiles w, w + 4.  These are small products (K <= 224, at most 8 output tiles): one k-chain per tile.
+#include "xeq_common.h"
+
+namespace xeq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LIN_ROWS = 32;
+constexpr int LIN_KMAX = 256;
+constexpr int LIN_XLD = LIN_KMAX + 4;
+
+struct LinArgs {
+  const float* X;           // [*, ldx]
+  const int32_t* row_index; // optional: row r of the operand is X[row_index[r]]
+  int64_t ldx, n;
+  int K, n_out;
+  const float* Wp;          // packed [n_out / 32][K / 8 + 1][64][4]
+  int has_bias, act;        // act: 0 none, 1 SiLU
+  float* pre;               // optional [n, n_out]: the pre-activation (what the reverse pass of a SiLU layer needs)
+  float* Y;                 // [n, ldy]
+  int64_t ldy;
+};
+
+__device__ __forceinline__ float lin_silu(float x) { return x / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) k_linear(LinArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[LIN_ROWS * LIN_XLD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, kh = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * LIN_ROWS;
+  const int rows_here = (int)min((int64_t)LIN_ROWS, a.n - row0);
+  const int k4 = a.K >> 2;   // float4 per row
+  for (int idx = tid; idx < LIN_ROWS * k4; idx += 256) {
+    const int r = idx / k4, c4 = idx - r * k4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows_here) {
+      int64_t src = row0 + r;
+      if (a.row_index) src = a.row_index[src];
+      v = *reinterpret_cast<const float4*>(a.X + src * a.ldx + 4 * c4);
+    }
+    *reinterpret_cast<float4*>(&Xs[r * LIN_XLD + 4 * c4]) = v;
+  }
+  __syncthreads();
+  const int G = a.K >> 3, nt = a.n_out >> 5;
+  const float one_k0 = kh == 0 ? 1.f : 0.f;
+  const float* xs = &Xs[i * LIN_XLD + 4 * kh];
+  const bool row_ok = i < rows_here;
+  for (int t = wave; t < nt; t += 4) {
+    const float4* wp = reinterpret_cast<const float4*>(a.Wp) + (int64_t)t * (G + 1) * 64 + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 w = wp[0];
+    for (int q = 0; q < G; ++q) {
+      const float4 wn = wp[(q + 1 < G ? q + 1 : q) * 64];   // next group's fragment flies under this group's MFMAs
+      const float4 xv = *reinterpret_cast<const float4*>(xs + 8 * q);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xv.w, acc, 0, 0, 0);
+      w = wn;
+    }
+    if (a.has_bias) {
+      const float bias_a = reinterpret_cast<const float*>(wp + (int64_t)G * 64)[0];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, one_k0, acc, 0, 0, 0);
+    }
+    if (row_ok) {
+      const int64_t row = row0 + i;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = 32 * t + 8 * g + 4 * kh;
+        float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        if (a.pre) *reinterpret_cast<float4*>(a.pre + row * a.n_out + col) = v;
+        if (a.act == 1) v = make_float4(lin_silu(v.x), lin_silu(v.y), lin_silu(v.z), lin_silu(v.w));
+        *reinterpret_cast<float4*>(a.Y + row * a.ldy + col) = v;
+      }
+    }
+  }
+}
+
+// atomic energies of the head's last layer: out[n] = <hidden[n, :], w2> + b2 (+ add[n]); one 16-lane group per node, H <= 64 x 16
+__global__ void k_head_dot(const float* __restrict__ hidden, int64_t n, int H, const float* __restrict__ w2, const float* __restrict__ b2,
+                           float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t node = t >> 4;
+  const int sub = (int)(t & 15);
+  float acc = 0.f;
+  if (node < n)
+    for (int c = 4 * sub; c < H; c += 64) {   // fixed order per node: lane `sub` takes columns 4 sub + 64 k .. + 3
+      const float4 h = *reinterpret_cast<const float4*>(hidden + node * H + c);
+      const float4 w = *reinterpret_cast<const float4*>(w2 + c);
+      acc = fmaf(h.x, w.x, acc);
+      acc = fmaf(h.y, w.y, acc);
+      acc = fmaf(h.z, w.z, acc);
+      acc = fmaf(h.w, w.w, acc);
+    }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (node < n && sub == 0) out[node] = acc + (b2 ? b2[0] : 0.f);
+}
+
+// reverse of the head's last two stages: g_hidden[n, j] = g_atomic[n] w2[j] silu'(pre[n, j])   (g_atomic NULL: ones, dE/d atomic_i = 1)
+__global__ void k_head_bwd_hidden(const float* __restrict__ pre, int64_t n, int H, const float* __restrict__ w2,
+                                  const float* __restrict__ g_atomic, float* __restrict__ g_hidden) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4
+  const int h4 = H >> 2;
+  if (t >= n * h4) return;
+  const int64_t node = t / h4;
+  const int c = 4 * (int)(t - node * h4);
+  const float ga = g_atomic ? g_atomic[node] : 1.f;
+  const float4 p = *reinterpret_cast<const float4*>(pre + node * H + c);
+  const float4 w = *reinterpret_cast<const float4*>(w2 + c);
+  auto dsilu = [](float x) {   // aten silu_backward: sig (1 + x (1 - sig))
+    const float sig = 1.f / (1.f + expf(-x));
+    return sig * (1.f + x * (1.f - sig));
+  };
+  *reinterpret_cast<float4*>(g_hidden + node * H + c) =
+      make_float4(ga * w.x * dsilu(p.x), ga * w.y * dsilu(p.y), ga * w.z * dsilu(p.z), ga * w.w * dsilu(p.w));
+}
+
+}  // namespace xeq
+
+using namespace xeq;
+
+extern "C" {
+
+int xeq_linear_supported(int dtype, int k_in, int n_out) {
+  return dtype == XEQ_F32 && k_in >= 8 && k_in % 8 == 0 && k_in <= LIN_KMAX && n_out >= 32 && n_out % 32 == 0 && n_out <= 256 ? 1 : 0;
+}
+
+int xeq_linear_fwd(const void* x, int64_t ldx, int64_t n, int k_in, const int32_t* row_index, const void* w_packed, int n_out,
+                   int has_bias, int act, void* pre, void* y, int64_t ldy, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && xeq_linear_supported(XEQ_F32, k_in, n_out), "xeq_linear_fwd: K = %d (multiple of 8, <= %d), n_out = %d (multiple of 32, <= 256)",
+                k_in, LIN_KMAX, n_out);
+  XEQ_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= k_in && ldy >= n_out && (act == 0 || act == 1), "xeq_linear_fwd: row strides must be multiples of four floats");
+  if (n == 0) return XEQ_OK;
+  LinArgs a{(const float*)x, row_index, ldx, n, k_in, n_out, (const float*)w_packed, has_bias, act, (float*)pre, (float*)y, ldy};
+  hipLaunchKernelGGL(k_linear, dim3((unsigned)((n + LIN_ROWS - 1) / LIN_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+  XEQ_CHECK_LAUNCH("xeq_linear_fwd");
+  return XEQ_OK;
+}
+
+int xeq_head_dot(const void* hidden, int64_t n, int hidden_dim, const void* w2, const void* b2, void* out, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && hidden_dim >= 4 && hidden_dim % 4 == 0, "xeq_head_dot: hidden width %d", hidden_dim);
+  if (n == 0) return XEQ_OK;
+  hipLaunchKernelGGL(k_head_dot, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)hidden, n,
+                     hidden_dim, (const float*)w2, (const float*)b2, (float*)out);
+  XEQ_CHECK_LAUNCH("xeq_head_dot");
+  return XEQ_OK;
+}
+
+int xeq_head_bwd_hidden(const void* pre, int64_t n, int hidden_dim, const void* w2, const void* g_atomic, void* g_hidden, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && hidden_dim >= 4 && hidden_dim % 4 == 0, "xeq_head_bwd_hidden: hidden width %d", hidden_dim);
+  if (n == 0) return XEQ_OK;
+  const int64_t total = n * (hidden_dim / 4);
+  hipLaunchKernelGGL(k_head_bwd_hidden, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)pre, n,
+                     hidden_dim, (const float*)w2, (const float*)g_atomic, (float*)g_hidden);
+  XEQ_CHECK_LAUNCH("xeq_head_bwd_hidden");
+  return XEQ_OK;
+}
+
+}  // extern "C"

@@ -147,6 +147,66 @@ Tensor mlp_bwd(const Tensor& g_y, const Tensor& pre, const Tensor& w1, const Ten
   return g_x;
 }
 
+// Single linear layers (dot_lin, the embedding, the head's first layer) through xeq_linear_fwd (csrc/xeq_linear.hip);
+// nn/fused.py::_linear_pack / _linear / linear_module_fwd / linear_module_bwd are the Python twins.  Packs cached per weight.
+struct LinPack {
+  int64_t key[4];
+  Owners owners;
+  Tensor fwd, bwd;
+};
+const LinPack* lin_pack(const Tensor& w, const Tensor& b) {
+  const int n_out = (int)w.size(0), k_in = (int)w.size(1);
+  if (w.scalar_type() != at::kFloat || !xeq_linear_supported(XEQ_F32, k_in, n_out)) return nullptr;
+  const bool has_bwd = xeq_linear_supported(XEQ_F32, n_out, k_in) != 0;   // (the embedding's 56 inputs: forward only, nobody differentiates it)
+  static std::mutex mu;
+  static std::unordered_map<const void*, LinPack> cache;
+  const bool hb = b.defined() && b.numel() > 0;
+  const int64_t key[4] = {(int64_t)w._version(), (int64_t)(intptr_t)w.data_ptr(), hb ? (int64_t)b._version() : -1, hb ? (int64_t)(intptr_t)b.data_ptr() : 0};
+  std::lock_guard<std::mutex> lock(mu);
+  LinPack& e = cache[w.data_ptr()];
+  bool same = e.fwd.defined() && e.owners.same({&w, &b});
+  for (int i = 0; i < 4 && same; ++i) same = e.key[i] == key[i];
+  if (!same) {
+    const Tensor wc = w.detach().contiguous();
+    e.fwd = at::empty({xeq_mlp_packed_floats(n_out, k_in)}, w.options());
+    XCALL(xeq_mlp_pack((const float*)wc.data_ptr(), hb ? (const float*)b.data_ptr() : nullptr, n_out, k_in, 0, (float*)e.fwd.data_ptr(), cur_stream()));
+    e.bwd = Tensor();
+    if (has_bwd) {
+      e.bwd = at::empty({xeq_mlp_packed_floats(k_in, n_out)}, w.options());
+      XCALL(xeq_mlp_pack((const float*)wc.data_ptr(), nullptr, k_in, n_out, 1, (float*)e.bwd.data_ptr(), cur_stream()));
+    }
+    e.owners.set({&w, &b});
+    for (int i = 0; i < 4; ++i) e.key[i] = key[i];
+  }
+  return &e;
+}
+// y = act(x W^T + b); row_index (int32, optional) gathers the rows of x; pre (optional) receives the pre-activation
+Tensor linear_fwd(const Tensor& x, const Tensor& w, const Tensor& b, int act = 0, const Tensor* row_index = nullptr, Tensor* pre = nullptr) {
+  const bool hb = b.defined() && b.numel() > 0;
+  const LinPack* pk = (x.dim() == 2 && x.stride(1) == 1 && x.stride(0) % 4 == 0) ? lin_pack(w, b) : nullptr;
+  if (!pk) {
+    const Tensor xr = row_index ? x.index_select(0, row_index->to(at::kLong)) : x;
+    Tensor y = hb ? at::addmm(b, xr, w.t()) : at::mm(xr, w.t());
+    if (pre) *pre = y;
+    return act == 1 ? at::silu(y) : y;
+  }
+  const int64_t n = row_index ? row_index->numel() : x.size(0);
+  Tensor y = at::empty({n, w.size(0)}, x.options());
+  if (pre) *pre = at::empty({n, w.size(0)}, x.options());
+  XCALL(xeq_linear_fwd(x.data_ptr(), x.stride(0), n, (int)w.size(1), row_index ? (const int32_t*)row_index->data_ptr() : nullptr,
+                       pk->fwd.data_ptr(), (int)w.size(0), hb, act, pre ? pre->data_ptr() : nullptr, y.data_ptr(), w.size(0), cur_stream()));
+  return y;
+}
+Tensor linear_bwd(const Tensor& g_in, const Tensor& w, const Tensor& b) {   // dL/dx = g W
+  const LinPack* pk = lin_pack(w, b);
+  if (!pk || !pk->bwd.defined()) return at::mm(g_in, w);
+  const Tensor g = g_in.contiguous();
+  Tensor gx = at::empty({g.size(0), w.size(1)}, g.options());
+  XCALL(xeq_linear_fwd(g.data_ptr(), g.stride(0), g.size(0), (int)w.size(0), nullptr, pk->bwd.data_ptr(), (int)w.size(1), 0, 0, nullptr,
+                       gx.data_ptr(), w.size(1), cur_stream()));
+  return gx;
+}
+
 // [W_U | W_V] / sqrt(mul) blocks (prm layout: one [mul, 2 mul] tensor per l, empty when absent) in fragment order for
 // xeq_update_uv_fwd; nn/fused.py::_packed_uv_frag is the Python twin.  Cached per weight tensor like the MLP packs.
 struct UvFrag {
@@ -154,7 +214,7 @@ struct UvFrag {
   Owners owners;
   Tensor w[3], wt[3];   // forward ([k_in = mul][n_out = 2 mul], biases folded) and reverse ([n_out = mul][k_in = 2 mul]) packs
 };
-constexpr int64_t UV_BWD_FUSE_NORM_MAX_NODES = 32 * 256;   // nn/fused.py::UV_BWD_FUSE_NORM_MAX_NODES
+constexpr int64_t UV_BWD_FUSE_NORM_MAX_NODES = 0;   // nn/fused.py::UV_BWD_FUSE_NORM_MAX_NODES (never fused: batch-independent bits)
 const UvFrag* uv_frag(const Tensor* q /* [W0, W1, W2, bias pair] */, int node_dim, const int32_t mul[3]) {
   if (q[0].scalar_type() != at::kFloat || !xeq_update_uv_supported(XEQ_F32, node_dim, mul)) return nullptr;
   static std::mutex mu;
@@ -404,7 +464,10 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
 
   // ---- embedding (nn/xpainn.py:55-83)
   Tensor s;
-  if (hy.embed_kind == 0) s = at::addmm(prm[2], prm[0].index_select(0, atomic_numbers.to(at::kLong)), prm[1].t());
+  if (hy.embed_kind == 0) {
+    const Tensor z32 = atomic_numbers.to(at::kInt).contiguous();
+    s = linear_fwd(prm[0], prm[1], prm[2], 0, &z32);   // table lookup + Linear in one launch (nn/xpainn.py::XEmbedding._embed)
+  }
   else s = prm[0].index_select(0, atomic_numbers.to(at::kLong));
   Tensor x = at::zeros({N, D}, fopt);
   const Tensor& p0 = prm[3];
@@ -504,7 +567,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         XCALL(xeq_uv_reduce_fwd(dt, u.uv.data_ptr(), N, mul, hy.inv_eps, cat.data_ptr(), F + C, F, p.data_ptr(), st));
       }
       mlp_fwd(cat, q[15], q[16], q[17], q[18], u.pre, u.a);
-      u.ip = at::mm(p, q[14].t());
+      u.ip = linear_fwd(p, q[14], Tensor());
       const bool last = b == hy.blocks - 1;   // the energy head reads the scalars only: the last equivariant output has no consumer
       Tensor s_out = at::empty_like(s), x_out = last ? Tensor() : at::empty_like(x);
       XCALL(xeq_update_out_fwd(dt, s.data_ptr(), x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
@@ -515,15 +578,32 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   }
   // ---- EnergyOut.forward (nn/output.py:114-128)
   const Tensor* t = &prm[P_BLOCK0 + P_PER_BLOCK * hy.blocks];
-  const Tensor pre_o = at::addmm(t[1], s, t[0].t());
-  const Tensor atomic = at::addmm(t[3], at::silu(pre_o), t[2].t()).reshape({-1});
+  // (nn/fused.py::EnergyHead is the Python twin: the same kernels where they take the layer, the library GEMMs elsewhere)
+  const LinPack* head_pk = dt == XEQ_F32 && t[0].size(0) % 4 == 0 && t[2].size(0) == 1 ? lin_pack(t[0], t[1]) : nullptr;
+  const bool head_native = head_pk != nullptr && head_pk->bwd.defined();
+  Tensor pre_o, atomic;
+  if (head_native) {
+    const Tensor hidden = linear_fwd(s, t[0], t[1], 1, nullptr, &pre_o);
+    atomic = at::empty({N}, fopt);
+    XCALL(xeq_head_dot(hidden.data_ptr(), N, (int)t[0].size(0), t[2].data_ptr(), t[3].data_ptr(), atomic.data_ptr(), st));
+  } else {
+    pre_o = at::addmm(t[1], s, t[0].t());
+    atomic = at::addmm(t[3], at::silu(pre_o), t[2].t()).reshape({-1});
+  }
   Tensor energy = at::empty({G}, fopt);
   XCALL(xeq_segment_sum(dt, atomic.data_ptr(), (const int64_t*)ptr64.data_ptr(), G, 1, energy.data_ptr(), st));
 
   Tensor forces, virial;
   if (compute_forces || compute_virial) {
     // ---- explicit reverse pass: dE/ds of the head, then the blocks backwards, then the edge geometry (nn/basic.py:143-199)
-    Tensor g_s = at::mm(at::silu_backward(t[2].expand({N, t[2].size(1)}), pre_o), t[0]);   // dE_i/d atomic_i = 1
+    Tensor g_s;   // dE_i/d atomic_i = 1
+    if (head_native) {
+      Tensor g_hidden = at::empty_like(pre_o);
+      XCALL(xeq_head_bwd_hidden(pre_o.data_ptr(), N, (int)pre_o.size(1), t[2].data_ptr(), nullptr, g_hidden.data_ptr(), st));
+      g_s = linear_bwd(g_hidden, t[0], t[1]);
+    } else {
+      g_s = at::mm(at::silu_backward(t[2].expand({N, t[2].size(1)}), pre_o), t[0]);
+    }
     Tensor g_x;   // undefined = zero: the head reads the scalars only, the last block's equivariant output has no consumer
     Tensor g_vec_total;
     if (impl == 0) {
@@ -542,7 +622,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         const void* gx_ptr = g_x.defined() ? g_x.data_ptr() : nullptr;
         XCALL(xeq_update_out_bwd(dt, g_s.data_ptr(), gx_ptr, u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
                                  g_a.data_ptr(), g_ip.data_ptr(), nullptr, st));
-        const Tensor g_p = at::mm(g_ip, q[14]);
+        const Tensor g_p = linear_bwd(g_ip, q[14], Tensor());
         const Tensor g_cat = mlp_bwd(g_a, u.pre, q[15], q[16], q[17], q[18]);
         Tensor ns, nx;
         const UvFrag* fr = g_cat.is_contiguous() ? uv_frag(&q[10], F, mul) : nullptr;

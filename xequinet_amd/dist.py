@@ -49,15 +49,35 @@ def plan_chunks(ptr: Sequence[int], max_edges: int, g0: int = 0, g1: int = None)
     g1 = len(ptr) - 1 if g1 is None else g1
     n = np.diff(ptr[g0 : g1 + 1]).astype(np.int64)
     bound = n * (n - 1)
-    out, start, acc = [], g0, 0
-    for i, b in enumerate(bound):
-        if acc + b > max_edges and g0 + i > start:
-            out.append((start, g0 + i))
-            start, acc = g0 + i, 0
-        acc += int(b)
-    if g1 > start or not out:
-        out.append((start, g1))
-    return out
+
+    def cut(cap: int) -> List[Tuple[int, int]]:
+        out, start, acc = [], g0, 0
+        for i, b in enumerate(bound):
+            if acc + b > cap and g0 + i > start:
+                out.append((start, g0 + i))
+                start, acc = g0 + i, 0
+            acc += int(b)
+        if g1 > start or not out:
+            out.append((start, g1))
+        return out
+
+    # the fewest ranges the cap allows, then the smallest cap that still gives that many: ranges of about equal size instead
+    # of full ones and a small remainder (a remainder of a few thousand edges would also take another kernel family than
+    # its siblings, ops.prefers_sb, and with it other bits)
+    ranges = cut(int(max_edges))
+    k, total = len(ranges), int(bound.sum())
+    if k > 1:
+        lo, hi = max(int(bound.max()), -(-total // k)), int(max_edges)
+        if lo > hi:          # a molecule above the cap: the first cut stands
+            return ranges
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if len(cut(mid)) <= k:
+                hi = mid
+            else:
+                lo = mid + 1
+        ranges = cut(lo)
+    return ranges
 
 
 def gather_shards(local: dict, dst: int = 0):

@@ -60,6 +60,10 @@ _PROTOS = {
     "xeq_eqln_fwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
     "xeq_eqln_bwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
     "xeq_segment_sum": [c_int, _P, _P, c_int64, c_int64, _P, _P],
+    "xeq_linear_supported": [c_int, c_int, c_int],
+    "xeq_linear_fwd": [_P, c_int64, c_int64, c_int, _P, _P, c_int, c_int, c_int, _P, _P, c_int64, _P],
+    "xeq_head_dot": [_P, c_int64, c_int, _P, _P, _P, _P],
+    "xeq_head_bwd_hidden": [_P, c_int64, c_int, _P, _P, _P, _P],
     "xeq_load_padded_batch": [c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_double, c_double, _P, _P, _P, _P, _P],
     "xeq_copy_many": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), _P],
     "xeq_tensor_product_path": [c_int, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

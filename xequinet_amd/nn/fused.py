@@ -125,6 +125,87 @@ def _mlp_bwd(seq, g_y, pre):
     return g_x
 
 
+def _linear_pack(mod_or_key, weight: torch.Tensor, bias, transposed: bool):
+    """Fragment-order copy of one Linear's weight for ``xeq_linear_fwd`` (forward: W as [n_out, k_in] with its bias; ``transposed``:
+    the same weight as the input-gradient product, [k_in = n_out of the layer][n_out = k_in of the layer], no bias), cached on the
+    module and refreshed when the weight changes.  None when the kernel does not take the layer (f64, widths)."""
+    n_out, k_in = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
+    if weight.dtype != torch.float32 or not weight.is_cuda or not lib.load().xeq_linear_supported(lib.XEQ_F32, k_in, n_out):
+        return None
+    key = (weight._version, weight.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), transposed)
+    name = "_xeq_lin_pack_t" if transposed else "_xeq_lin_pack"
+    cache = getattr(mod_or_key, name, None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    with torch.no_grad():
+        out = torch.empty(lib.load().xeq_mlp_packed_floats(n_out, k_in), dtype=torch.float32, device=weight.device)
+        call("xeq_mlp_pack", ptr(weight.detach().contiguous()), ptr(None if (bias is None or transposed) else bias.detach().contiguous()),
+             n_out, k_in, int(transposed), ptr(out), stream())
+    setattr(mod_or_key, name, (key, out))
+    return out
+
+
+def _linear(x: torch.Tensor, pack: torch.Tensor, k_in: int, n_out: int, has_bias: bool, act: int = 0, row_index=None, want_pre: bool = False):
+    """y = act(x W^T + b) on rows of x (row stride x.stride(0)) through ``xeq_linear_fwd``; -> (y, pre or None)."""
+    n = x.shape[0] if row_index is None else row_index.shape[0]
+    y = torch.empty((n, n_out), dtype=torch.float32, device=x.device)
+    pre = torch.empty((n, n_out), dtype=torch.float32, device=x.device) if want_pre else None
+    call("xeq_linear_fwd", ptr(x), x.stride(0), n, k_in, ptr(row_index), ptr(pack), n_out, int(has_bias), act, ptr(pre), ptr(y), n_out, stream())
+    return y, pre
+
+
+def linear_module_fwd(lin: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """A bias-free or biased nn.Linear on the matrix cores when the kernel takes it, else the library GEMM (f64, other widths)."""
+    pack = _linear_pack(lin, lin.weight, lin.bias, False) if (x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0) else None
+    if pack is None:
+        return torch.nn.functional.linear(x, lin.weight, lin.bias)
+    return _linear(x, pack, lin.weight.shape[1], lin.weight.shape[0], lin.bias is not None)[0]
+
+
+def linear_module_bwd(lin: torch.nn.Linear, g: torch.Tensor) -> torch.Tensor:
+    """dL/dx of y = x W^T (+ b): g W, through the transposed pack of the same weight."""
+    g = g.contiguous()
+    pack = _linear_pack(lin, lin.weight, None, True) if g.is_cuda else None
+    if pack is None:
+        return torch.mm(g, lin.weight)
+    return _linear(g, pack, lin.weight.shape[0], lin.weight.shape[1], False)[0]
+
+
+class EnergyHead(Function):
+    """EnergyOut's MLP on node scalars (nn/output.py:104-118): Linear - SiLU - Linear(., 1) -> atomic energies [n], with the
+    explicit reverse pass of a force evaluation (input gradient only).  HIP kernels throughout: a row's sums do not depend on
+    the batch it sits in."""
+
+    @staticmethod
+    def supported(seq: torch.nn.Sequential, s: torch.Tensor) -> bool:
+        lin1, act, lin2 = seq[0], seq[1], seq[2]
+        return (isinstance(act, torch.nn.SiLU) and s.is_cuda and s.dtype == torch.float32 and lin1.bias is not None and lin2.weight.shape[0] == 1
+                and lin1.weight.shape[0] % 4 == 0 and bool(lib.load().xeq_linear_supported(lib.XEQ_F32, lin1.weight.shape[1], lin1.weight.shape[0]))
+                and bool(lib.load().xeq_linear_supported(lib.XEQ_F32, lin1.weight.shape[0], lin1.weight.shape[1])))
+
+    @staticmethod
+    def forward(ctx, s, seq):
+        lin1, lin2 = seq[0], seq[2]
+        s = s.contiguous()
+        H = lin1.weight.shape[0]
+        hidden, pre = _linear(s, _linear_pack(lin1, lin1.weight, lin1.bias, False), lin1.weight.shape[1], H, True, act=1, want_pre=True)
+        out = torch.empty(s.shape[0], dtype=s.dtype, device=s.device)
+        w2 = lin2.weight.detach().reshape(-1).contiguous()
+        call("xeq_head_dot", ptr(hidden), s.shape[0], H, ptr(w2), ptr(lin2.bias), ptr(out), stream())
+        ctx.save_for_backward(pre, w2)
+        ctx.seq = seq
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        pre, w2 = ctx.saved_tensors
+        lin1 = ctx.seq[0]
+        g_hidden = torch.empty_like(pre)
+        call("xeq_head_bwd_hidden", ptr(pre), pre.shape[0], pre.shape[1], ptr(w2), ptr(g_out.contiguous()), ptr(g_hidden), stream())
+        return linear_module_bwd(lin1, g_hidden), None
+
+
 class MessageBlock(Function):
     """XPainnMessage.forward (nn/xpainn.py:128-161): norms -> scalar_mlp -> fused message kernel."""
 
@@ -212,10 +293,12 @@ def _packed_uv_frag(module):
     return frag, bias is not None, frag_t
 
 
-# xeq_update_uv_bwd with the norms' reverse inside (113 KB of LDS: one workgroup per CU) up to one 32-node tile per CU, split
-# off to xeq_norm_bwd (50 KB: three per CU) beyond (MI355X, 18 k nodes: 99 us fused, 92 us split, 146 us the kernel chain;
-# 1.5 k nodes: 24 / 28 / 95 us).  The C++ operator (csrc/xeq_torch.cpp) applies the same rule.
-UV_BWD_FUSE_NORM_MAX_NODES = 32 * 256
+# xeq_update_uv_bwd can run the norms' reverse inside (113 KB of LDS: one workgroup per CU; 24 against 28 us at 1.5 k nodes) or leave
+# it to xeq_norm_bwd (50 KB: three per CU; 92 against 99 us at 18 k nodes).  The two forms reduce a row in different orders, so a
+# switch by node count made a node's bits depend on its batch (6e-7 in the forces between a 9 k-node batch and its 2 k-node
+# chunks, found once the last library GEMM was gone): since round 3 the split form runs at every size (0 = never fuse).
+# The C++ operator (csrc/xeq_torch.cpp) applies the same rule.
+UV_BWD_FUSE_NORM_MAX_NODES = 0
 
 
 class UpdateBlock(Function):
@@ -251,7 +334,7 @@ class UpdateBlock(Function):
                     torch.mm(xb, W, out=ub)
             call("xeq_uv_reduce_fwd", dtype_code(s), ptr(uv), n, mul3(mul), float(eps), ptr(cat), F + C, F, ptr(p), stream())
         pre, a = _mlp_fwd(module.update_mlp, cat)                             # a = [a_vv C | a_sv F | a_ss F]
-        ip = torch.mm(p, module.dot_lin.weight.t())
+        ip = linear_module_fwd(module.dot_lin, p)
         # (the last block in front of a scalar-only head: nobody reads its equivariant output, nn/model.py marks the module)
         s_out, x_out = torch.empty_like(s), (None if getattr(module, "equivariant_output_unused", False) else torch.empty_like(x))
         call("xeq_update_out_fwd", dtype_code(s), ptr(s), ptr(x), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(s_out),
@@ -277,7 +360,7 @@ class UpdateBlock(Function):
         # dL/dU of this stage (g_x_out a_vv) is formed inside xeq_uv_reduce_bwd: no write here, no read-modify-write there
         call("xeq_update_out_bwd", dtype_code(s), ptr(g_s_out), ptr(g_x_out), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(g_a),
              ptr(g_ip), None, stream())
-        g_p = torch.mm(g_ip, module.dot_lin.weight)
+        g_p = linear_module_bwd(module.dot_lin, g_ip)
         g_cat = _mlp_bwd(module.update_mlp, g_a, pre)                         # [g_shat | g_v]
         frag = _packed_uv_frag(module)
         if frag is not None and g_cat.is_contiguous():   # dL/dU, dL/dV -> dL/dxhat -> reverse of both norms in one matrix-core launch

@@ -52,7 +52,12 @@ class EnergyOut(OutputModule):
             return training.energy_out(self, data)
         batch = data[keys.BATCH]
         node_scalar = data[keys.NODE_INVARIANT]
-        atom_eng_out = self.out_mlp(node_scalar).reshape(-1)
+        from .fused import EnergyHead
+
+        if EnergyHead.supported(self.out_mlp, node_scalar):    # matrix-core kernels, explicit reverse pass (nn/fused.py)
+            atom_eng_out = EnergyHead.apply(node_scalar, self.out_mlp)
+        else:                                                  # f64, other activations / widths: library GEMMs
+            atom_eng_out = self.out_mlp(node_scalar).reshape(-1)
         if keys.ATOMIC_ENERGIES in data:
             atomic_energies = data[keys.ATOMIC_ENERGIES] + atom_eng_out
         else:

@@ -60,6 +60,20 @@ class XEmbedding(nn.Module):
         self.cutoff_fn = resolve_cutoff(cutoff_fn, cutoff)
         self.materialize_edge_basis = materialize_edge_basis
 
+    def _embed(self, atomic_numbers: torch.Tensor) -> torch.Tensor:
+        """nn/xpainn.py:62: table rows of the atomic numbers through Linear(embed_dim, node_dim) -- one matrix-core launch that
+        gathers the rows itself (csrc/xeq_linear.hip) where the kernel takes the layer, else lookup + library GEMM."""
+        if isinstance(self.embedding, nn.Embedding):
+            return self.embedding(atomic_numbers.long())
+        from .fused import _linear, _linear_pack
+
+        table, lin = self.embedding[0].embed_ten, self.embedding[1]
+        if (atomic_numbers.is_cuda and table.dtype == torch.float32 and table.stride(0) % 4 == 0
+                and (pack := _linear_pack(lin, lin.weight, lin.bias, False)) is not None):
+            z = atomic_numbers.to(torch.int32).contiguous()
+            return _linear(table, pack, lin.weight.shape[1], lin.weight.shape[0], lin.bias is not None, row_index=z)[0]
+        return self.embedding(atomic_numbers)
+
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if training.active(self, data):   # parameter gradients / double backward: the differentiable form
             return training.embedding(self, data)
@@ -67,7 +81,7 @@ class XEmbedding(nn.Module):
         vectors = data[keys.EDGE_VECTOR]
         ops.lib.require_hip(vectors)
 
-        node_invariant = self.embedding(atomic_numbers.long() if isinstance(self.embedding, nn.Embedding) else atomic_numbers)
+        node_invariant = self._embed(atomic_numbers)
         data[keys.NODE_INVARIANT] = node_invariant
         data[RADIAL_SPEC] = (self.rbf, self.cutoff_fn)
 
