@@ -38,8 +38,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WQ_REC = 32;                 // floats per record: [12 even k | 12 odd k | Y1[3] Y2[5]]
-constexpr int WQ_KH = 12;                  // floats per k-parity half of a record
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// The filter contraction, split (round 3).  phi[e][ch] = sum_k rho~[e][k] W[ch][k] was K + 1 = 21 exact-f32 MFMA steps (11 x
+// v_mfma_f32_32x32x2_f32 = 704 matrix-pipe cycles per 32 x 32 tile), and the tile loops of these kernels run within 80 % of that
+// pipe bound (two waves share a SIMD's pipe; step timeline of round 3).  The f32 MFMA runs at 1/16 of the bf16 rate, so the first
+// sixteen k now go through bf16 MFMAs on operands split three ways, x = hi + mid + lo with bf16 parts (8 + 8 + 8 significant
+// bits, exact): six products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid of v_mfma_f32_32x32x16_bf16 (32 cycles each, f32
+// accumulate) leave out mid lo, lo mid, lo lo = 2^-24 of a product, the size of one f32 rounding; the remaining k (16 .. B - 1)
+// and the bias column stay exact-f32 steps.  K = 21: 6 x 32 + 3 x 64 = 384 pipe cycles instead of 704.
+constexpr int WQ_REC = 40;                 // dwords per record (160 B): [kh][hi | mid | lo][4] bf16 packs of k = 8 kh .. 8 kh + 7,
+                                           // [kh][4] f32 tail (q = 2 s + kh -> k = 16 + q, then the envelope for the bias), Y1[3] Y2[5]
+constexpr int WQ_TAIL = 24, WQ_Y = 32;     // dword offsets of the f32 tail and of Y inside a record
+__device__ __forceinline__ uint32_t wq_bf16_rne(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// x = hi + mid + lo, each a bf16 (round to nearest even of what is left): returns the three 16-bit patterns
+__device__ __forceinline__ void wq_split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = wq_bf16_rne(x);
+  const float r1 = x - __uint_as_float(hi << 16);
+  mid = wq_bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float(mid << 16);
+  lo = wq_bf16_rne(r2);
+}
+// value at tail position q of a record / weight row: k = 16 + q while k < B, then the bias column, then zeros
+__device__ __forceinline__ int wq_tail_k(int q, int B) { return 16 + q < B ? 16 + q : (16 + q == (B > 16 ? B : 16) ? -1 : -2); }
 constexpr uint32_t WQ_FIRST = 1u << 30, WQ_LAST = 1u << 31, WQ_OWNER = (1u << 30) - 1u;
 #ifndef XEQ_WQ_WAVES
 #define XEQ_WQ_WAVES 4
@@ -127,42 +151,69 @@ __global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __re
   }
 }
 
-// records in padded walk order; val(k) = f rho_k (k < B) | f (k == B) | 0, derivative record likewise.  Eight threads per
-// slot, one 16-byte store each: the geometry and the envelope are evaluated once per four values, not once per value
+// records in padded walk order (layout: WQ_REC above); val(k) = f rho_k, the bias column's multiplier is f; derivative record
+// likewise.  Ten threads per slot, one 16-byte store each.
 __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
                              const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
                              const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
                              float* __restrict__ drec) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p = t >> 3;
+  const int64_t p = t / 10;
   if (p >= pcap || p >= 4 * (int64_t)qptr[N]) return;
-  const int grp = (int)(t & 7);   // floats [4 grp, 4 grp + 4) of the record: 0-2 even k, 3-5 odd k, 6-7 Y
+  const int grp = (int)(t - 10 * p);   // 0-5: bf16 packs [kh = grp / 3][split = grp % 3]; 6-7: f32 tail of kh = grp - 6; 8-9: Y
   const int32_t e = peid[p];
   f32x4 v = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
   if (e >= 0) {
     const float rc = (float)rs.cutoff;
     const EdgeGeom<float> g = edge_geom<float>(vec[3 * (int64_t)e], vec[3 * (int64_t)e + 1], vec[3 * (int64_t)e + 2]);
-    if (grp < 6) {
-      const int B = rs.num_basis;
+    const int B = rs.num_basis;
+    if (grp < 8) {
       float f, df;
       envelope<float>(rs.cutoff_kind, g.d, rc, f, df);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int slot = 4 * grp + c, k = slot < WQ_KH ? 2 * slot : 2 * (slot - WQ_KH) + 1;
-        if (k < B) {
+      auto value = [&](int k, float& val, float& dval) {   // k >= 0: basis function k; -1: the bias column; -2: nothing
+        val = dval = 0.f;
+        if (k >= 0 && k < B) {
           float rho, drho;
           radial<float>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : 0.f, rho, drho);
-          v[c] = f * rho;
-          dv[c] = df * rho + f * drho;
-        } else if (k == B) {
-          v[c] = f;
-          dv[c] = df;
+          val = f * rho;
+          dval = df * rho + f * drho;
+        } else if (k == -1) {
+          val = f;
+          dval = df;
+        }
+      };
+      if (grp < 6) {
+        const int kh = grp / 3, split = grp - 3 * kh;
+        uint32_t w[4] = {0u, 0u, 0u, 0u}, dw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          float val, dval;
+          value(8 * kh + jj < B ? 8 * kh + jj : -2, val, dval);
+          uint32_t a3[3], d3[3];
+          wq_split3(val, a3[0], a3[1], a3[2]);
+          wq_split3(dval, d3[0], d3[1], d3[2]);
+          w[jj >> 1] |= a3[split] << (16 * (jj & 1));
+          dw[jj >> 1] |= d3[split] << (16 * (jj & 1));
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = __uint_as_float(w[c]);
+          dv[c] = __uint_as_float(dw[c]);
+        }
+      } else {
+        const int kh = grp - 6;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float val, dval;
+          value(wq_tail_k(2 * c + kh, B), val, dval);
+          v[c] = val;
+          dv[c] = dval;
         }
       }
     } else {
       float y1[3], y2[5];
       sph_harm_l12<float>(g, y1, y2);
-      if (grp == 6) v = f32x4{y1[0], y1[1], y1[2], y2[0]};
+      if (grp == 8) v = f32x4{y1[0], y1[1], y1[2], y2[0]};
       else v = f32x4{y2[1], y2[2], y2[3], y2[4]};
     }
   }
@@ -254,30 +305,60 @@ __device__ __forceinline__ void wq_decode(const WqArgs& a, int nunits, int& s0, 
 #endif
 constexpr int WQ_WIN_FLOATS = XEQ_WQ_WIN_FLOATS;   // 48 KB per workgroup: two workgroups per CU
 
-// rbf_lin rows of the unit as the B operand: wl[kind][s][lane], lane (j = lane & 31 -> channel, kh = lane >> 5)
-// holding W~[row][2 s + kh], W~[., B] = bias, zeros beyond.  kind 0: gate_state, 1: gate_edge, 2: scalar message.
+// rbf_lin rows of the unit as the B operands, per kind (0: gate_state, 1: gate_edge, 2: scalar message) WQ_WK<KS> floats:
+//   [split][lane][4]   bf16 packs of W[row][8 kh + j], j = 0..7 (lane: j = lane & 31 -> channel row, kh = lane >> 5); 3 x 64 x 4
+//   [s][lane]          f32 tail: position q = 2 s + kh (wq_tail_k: k = 16 + q, then the bias, then zeros); KS x 64
+template <int KS>
+constexpr int WQ_WK = 3 * 64 * 4 + KS * 64;
 template <int KS>
 __device__ __forceinline__ void wq_stage_weights(const WqArgs& a, const WqUnit& un, const float* __restrict__ w,
                                                  const float* __restrict__ b, float* wl) {
   const int nkind = un.l == 0 ? 3 : 2, B = a.B;
+  auto row_of = [&](int kind, int ln) { return (kind == 0 ? un.u0 : (kind == 1 ? a.C + un.u0 : 2 * a.C + 32 * un.cb)) + (ln & 31); };
+  for (int idx = threadIdx.x; idx < nkind * 3 * 64; idx += blockDim.x) {   // one 16-byte pack per thread and trip
+    const int kind = idx / 192, rem = idx - 192 * kind, split = rem >> 6, ln = rem & 63;
+    const int row = row_of(kind, ln), kh = ln >> 5;
+    uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int k = 8 * kh + jj;
+      uint32_t a3[3];
+      wq_split3(k < B ? w[(int64_t)row * B + k] : 0.f, a3[0], a3[1], a3[2]);
+      pk[jj >> 1] |= a3[split] << (16 * (jj & 1));
+    }
+    *reinterpret_cast<f32x4*>(wl + kind * WQ_WK<KS> + 4 * (64 * split + ln)) =
+        f32x4{__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])};
+  }
   for (int idx = threadIdx.x; idx < nkind * KS * 64; idx += blockDim.x) {
     const int kind = idx / (KS * 64), rem = idx - kind * (KS * 64), sstep = rem >> 6, ln = rem & 63;
-    const int row = (kind == 0 ? un.u0 : (kind == 1 ? a.C + un.u0 : 2 * a.C + 32 * un.cb)) + (ln & 31);
-    const int k = 2 * sstep + (ln >> 5);
-    wl[idx] = k < B ? w[(int64_t)row * B + k] : (k == B ? b[row] : 0.f);
+    const int row = row_of(kind, ln), k = wq_tail_k(2 * sstep + (ln >> 5), B);
+    wl[kind * WQ_WK<KS> + 768 + rem] = k >= 0 ? w[(int64_t)row * B + k] : (k == -1 ? b[row] : 0.f);
   }
 }
 
+// what a lane holds of the record of the MFMA row it owns: the three bf16 packs of its eight k and KS tail values
 template <int KS>
-__device__ __forceinline__ f32x16 wq_filter(const float (&R)[KS], const float* W) {
+struct WqR {
+  f32x4 b[3];
+  float f[KS];
+};
+// W: the kind's block of the staged weights, + 4 lane for the packs / + 768 + lane for the tail (wq_wptr)
+template <int KS>
+__device__ __forceinline__ f32x16 wq_filter(const WqR<KS>& R, const float* W, int lane) {
   f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#ifdef XEQ_WQ_ABLATE_MFMA   // development: what the matrix instructions cost
+  const f32x4* Wb = reinterpret_cast<const f32x4*>(W) + lane;
+  const bf16x8 ah = __builtin_bit_cast(bf16x8, R.b[0]), am = __builtin_bit_cast(bf16x8, R.b[1]), al = __builtin_bit_cast(bf16x8, R.b[2]);
+  const bf16x8 bh = __builtin_bit_cast(bf16x8, Wb[0]), bm = __builtin_bit_cast(bf16x8, Wb[64]), bl = __builtin_bit_cast(bf16x8, Wb[128]);
+  // small terms first
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
+  const float* Wf = W + 768 + lane;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) d[i] = R[i % KS] * W[0];
-  return d;
-#endif
-#pragma unroll
-  for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(R[s], W[s * 64], d, 0, 0, 0);
+  for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(R.f[s], Wf[s * 64], d, 0, 0, 0);
   return d;
 }
 
@@ -300,7 +381,7 @@ enum { T_G0 = 0, T_G1 = 32, T_Y = 64, T_QOWN = 320, T_QKEEP = 328, T_QLAST = 336
 // what a lane loads for the MFMA row it owns: i = lane & 31 -> half hr = (i >> 2) & 1, register v = 4 (i >> 3) + (i & 3)
 template <int KS, int NREC, bool WITH_Y>
 struct WqRow {
-  float R[NREC][KS];
+  WqR<KS> R[NREC];
   f32x4 ya, yb;
   int g;
   uint32_t qi;
@@ -308,6 +389,19 @@ struct WqRow {
 struct WqStreams {
   int q0, q1, q2, ntiles;
 };
+template <int KS>
+__device__ __forceinline__ void wq_load_rec(const float* __restrict__ rec, uint32_t ps, int kh, bool valid, WqR<KS>& R) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + 12 * kh);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const f32x4 x = rp[c];
+    R.b[c] = valid ? x : zero;
+  }
+  const f32x4 tl = *reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + WQ_TAIL + 4 * kh);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) R.f[s] = valid ? tl[s] : 0.f;
+}
 template <int KS, int NREC, bool WITH_Y>
 __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int lane, int t, const float* __restrict__ rec,
                                        const float* __restrict__ drec, WqRow<KS, NREC, WITH_Y>& w, int g_default = 0) {
@@ -322,26 +416,10 @@ __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int
   const uint32_t qv = a.qinfo[valid ? q : 0];
   w.g = valid ? gv : g_default;
   w.qi = valid ? qv : 0u;
-  const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + kh * WQ_KH);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const f32x4 x = rp[c];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (4 * c + r < KS) w.R[0][4 * c + r] = valid ? x[r] : 0.f;
-  }
-  if constexpr (NREC > 1) {
-    const f32x4* __restrict__ dp = reinterpret_cast<const f32x4*>(drec + (size_t)ps * WQ_REC + kh * WQ_KH);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const f32x4 x = dp[c];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * c + r < KS) w.R[1][4 * c + r] = valid ? x[r] : 0.f;
-    }
-  }
+  wq_load_rec<KS>(rec, ps, kh, valid, w.R[0]);
+  if constexpr (NREC > 1) wq_load_rec<KS>(drec, ps, kh, valid, w.R[1]);
   if constexpr (WITH_Y) {
-    const f32x4* __restrict__ yp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + 2 * WQ_KH);
+    const f32x4* __restrict__ yp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + WQ_Y);
     w.ya = yp[0];
     w.yb = yp[1];
   }
@@ -553,9 +631,9 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
   uint32_t lxm[NM];
 #pragma unroll
   for (int m = 0; m < NM; ++m) lxm[m] = (uint32_t)(NH * 128) + (a.xl == 0 ? 4u * (uint32_t)(j * NM + m) : (uint32_t)(128 * m + 4 * j));
-  const float* Ws = wl + lane;
-  const float* We = wl + KS * 64 + lane;
-  const float* Wm = wl + 2 * KS * 64 + lane;
+  const float* Ws = wl;
+  const float* We = wl + WQ_WK<KS>;
+  const float* Wm = wl + 2 * WQ_WK<KS>;
 
   float acc_s = 0.f, acc_x[NM];
 #pragma unroll
@@ -577,9 +655,7 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
   for (int t = 0; t < st.ntiles; ++t) {
     const int* tb = tbl + (t & 1) * T_SIZE;
     int* tnext = tbl + ((t + 1) & 1) * T_SIZE;
-    float R[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) R[s] = row.R[0][s];
+    const WqR<KS> R = row.R[0];
     WQ_STAMP(4);   // waiting for the tile's record
     // ---- phase A
     uint32_t g0[16], g1[WIN ? 1 : 16], ob[4], os[4];
@@ -645,11 +721,11 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
       XEQ_WQ_FSB();
       WQ_STAMP(6);   // phase B issued
       if (r0 == 0) {   // ---- phase C
-        de = wq_filter<KS>(R, We);
+        de = wq_filter<KS>(R, We, lane);
         ds = de;
-        if constexpr (!NO_STATE) ds = wq_filter<KS>(R, Ws);
+        if constexpr (!NO_STATE) ds = wq_filter<KS>(R, Ws, lane);
         dm = ds;
-        if constexpr (HAS_S) dm = wq_filter<KS>(R, Wm);
+        if constexpr (HAS_S) dm = wq_filter<KS>(R, Wm, lane);
         XEQ_WQ_FSB();
         WQ_STAMP(7);   // MFMAs issued
       }
@@ -749,7 +825,7 @@ k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
                  const float* __restrict__ b_rbf, float* __restrict__ s_out, float* __restrict__ x_out) {
   __shared__ __attribute__((aligned(16))) float win[WQ_WIN_FLOATS];
   __shared__ __attribute__((aligned(16))) int tbl_all[WQ_WAVES][2 * T_SIZE];
-  __shared__ float wl[3 * KS * 64];
+  __shared__ __attribute__((aligned(16))) float wl[3 * WQ_WK<KS>];
   int s_beg, s_end, unit;
   wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], s_beg, s_end, unit);
   if (s_beg >= s_end) return;   // padding block of the grid / empty chunk of a short region (workgroup-uniform)
@@ -886,9 +962,9 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   const uint32_t stride0 = WIN ? (uint32_t)ROWB : 4u * (uint32_t)a.D, stride1 = WIN ? (uint32_t)ROWB : 4u * (uint32_t)a.F;
   const uint32_t gbase = WIN ? (uint32_t)w0 : 0u;
   const uint32_t lgx = 4u * (uint32_t)(j * NM), lgs = (uint32_t)(NM * 128 + 4 * j);   // window mode: lane offsets in a row
-  const float* Ws = wl + lane;
-  const float* We = wl + KS * 64 + lane;
-  const float* Wm = wl + 2 * KS * 64 + lane;
+  const float* Ws = wl;
+  const float* We = wl + WQ_WK<KS>;
+  const float* Wm = wl + 2 * WQ_WK<KS>;
 
   float a_hs = 0.f, a_he = 0.f, a_hm = 0.f, a_x[NM];
 #pragma unroll
@@ -906,12 +982,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   for (int t = 0; t < st.ntiles; ++t) {
     const int* tb = tbl + (t & 1) * T_SIZE;
     int* tnext = tbl + ((t + 1) & 1) * T_SIZE;
-    float R[KS], Rd[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      R[s] = row.R[0][s];
-      Rd[s] = row.R[1][s];
-    }
+    const WqR<KS> R = row.R[0], Rd = row.R[1];
     WQ_STAMP(4);   // waiting for the tile's records
     // gathered gradient rows of one quad (the center's grad_x, NM components per channel)
     auto load_gx = [&](int g, float (&gxq)[4][NM]) {
@@ -963,7 +1034,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
       for (int v = 0; v < 16; ++v) pd[v] = 0.f;
     } else {  // ---- pass S
-      const f32x16 ds = wq_filter<KS>(R, Ws), qs = wq_filter<KS>(Rd, Ws);
+      const f32x16 ds = wq_filter<KS>(R, Ws, lane), qs = wq_filter<KS>(Rd, Ws, lane);
       WQ_STAMP(6);   // MFMA issue (all passes)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1016,7 +1087,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
     const bool keeper = j < 16 && my_q < half_end;                     // one 16-lane row per half stores
     const int64_t my_slot = 4 * (int64_t)my_q + (my_r & 3);
     {  // ---- pass E
-      const f32x16 de = wq_filter<KS>(R, We), qe = wq_filter<KS>(Rd, We);
+      const f32x16 de = wq_filter<KS>(R, We, lane), qe = wq_filter<KS>(Rd, We, lane);
       WQ_STAMP(6);
       float pq[NM > 1 ? NM : 1][4];
 #pragma unroll
@@ -1093,7 +1164,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
         for (int r = 0; r < 4; ++r) gsv[4 * g + r] = WIN ? wq_lds(win, g1[r] + lgs) : wq_ld(grad_s, g1[r] + wc.b_s);
       }
-      const f32x16 dm = wq_filter<KS>(R, Wm), qm = wq_filter<KS>(Rd, Wm);
+      const f32x16 dm = wq_filter<KS>(R, Wm, lane), qm = wq_filter<KS>(Rd, Wm, lane);
       XEQ_WQ_RSB();
       wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // last MFMAs issued: next tile's records
       XEQ_WQ_RSB();
@@ -1185,7 +1256,7 @@ k_message_bwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
                  float* __restrict__ grad_xhat, WqParts parts) {
   __shared__ __attribute__((aligned(16))) float win[WQ_WIN_FLOATS];
   __shared__ __attribute__((aligned(16))) int tbl_all[WQ_WAVES][2 * T_SIZE];
-  __shared__ float wl[3 * KS * 64];
+  __shared__ __attribute__((aligned(16))) float wl[3 * WQ_WK<KS>];
   int s_beg, s_end, unit;
   wq_decode(a, a.nu[0] + a.nu[1] + a.nu[2], s_beg, s_end, unit);
   if (s_beg >= s_end) return;   // padding block of the grid / empty chunk of a short region (workgroup-uniform)
@@ -1326,13 +1397,13 @@ static void wq_geometry(WqArgs& a, int nunits, unsigned& grid) {
 
 using namespace xeq;
 
-// KS covers K = B + 1 (bias column) in steps of two
+// KS: exact-f32 steps of the filter's tail -- the basis functions from k = 16 on and the bias column, two per step
 #define XEQ_WQ_DISPATCH_KS(KERNEL, FLAG, ...)                                                                                \
   do {                                                                                                                       \
-    const int ks = (num_basis + 2) / 2;                                                                                      \
-    if (ks <= 6) hipLaunchKernelGGL((KERNEL<6, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);      \
-    else if (ks <= 11) hipLaunchKernelGGL((KERNEL<11, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<12, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);             \
+    const int ks = ((num_basis > 16 ? num_basis - 16 : 0) + 2) / 2;                                                          \
+    if (ks <= 1) hipLaunchKernelGGL((KERNEL<1, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);      \
+    else if (ks <= 3) hipLaunchKernelGGL((KERNEL<3, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<4, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);              \
   } while (0)
 #define XEQ_WQ_DISPATCH(KERNEL, flag, ...)                   \
   do {                                                       \
@@ -1352,6 +1423,8 @@ int xeq_message_wq_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int nod
 int64_t xeq_message_wq_pcap(int64_t n_nodes, int64_t n_edges) { return wq_pcap(n_nodes, n_edges); }
 
 int xeq_message_wq_waves(void) { return WQ_WAVES; }
+
+int xeq_message_wq_record_floats(void) { return WQ_REC; }
 
 int64_t xeq_message_wq_plan_workspace(int64_t n_nodes) {
   size_t temp = 0;
@@ -1401,7 +1474,7 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
   if (n_edges == 0) return XEQ_OK;
-  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * 8;   // eight threads per record
+  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * 10;   // ten threads per record
   XEQ_CHECK_ARG(pcap * WQ_REC < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
   hipLaunchKernelGGL(k_wq_records, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,

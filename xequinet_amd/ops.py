@@ -683,8 +683,9 @@ def edge_basis_wq(vec, plan, n_nodes, rbf_kind, cutoff_kind, num_basis, cutoff, 
     if _basis_cache_hit(cached, vec, key):
         return cached[2], cached[3]
     E = vec.shape[0]
-    basis = torch.empty((plan["pcap"], 32), dtype=vec.dtype, device=vec.device)
-    dbasis = torch.empty((plan["pcap"], 32), dtype=vec.dtype, device=vec.device) if deriv else None
+    width = int(lib.load().xeq_message_wq_record_floats())
+    basis = torch.empty((plan["pcap"], width), dtype=vec.dtype, device=vec.device)
+    dbasis = torch.empty((plan["pcap"], width), dtype=vec.dtype, device=vec.device) if deriv else None
     call("xeq_edge_basis_wq", ptr(vec), n_nodes, E, ptr(plan["qptr"]), ptr(plan["peid"]), lib.RBF_KINDS[rbf_kind],
          lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff), ptr(p0), ptr(p1), ptr(basis), ptr(dbasis), stream())
     plan["records"] = (vec, key, basis, dbasis)
