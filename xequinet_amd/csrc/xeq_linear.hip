@@ -64,15 +64,19 @@ __global__ void __launch_bounds__(256) k_linear(LinArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float4 w = wp[0];
+    // weight fragments four k-groups ahead of their MFMAs (an L2 round trip is ~500 cycles, a group's four MFMAs 256)
+    float4 w0 = wp[0], w1 = wp[(1 < G ? 1 : G - 1) * 64], w2 = wp[(2 < G ? 2 : G - 1) * 64], w3 = wp[(3 < G ? 3 : G - 1) * 64];
     for (int q = 0; q < G; ++q) {
-      const float4 wn = wp[(q + 1 < G ? q + 1 : q) * 64];   // next group's fragment flies under this group's MFMAs
+      const float4 wn = wp[(q + 4 < G ? q + 4 : G - 1) * 64];
       const float4 xv = *reinterpret_cast<const float4*>(xs + 8 * q);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xv.w, acc, 0, 0, 0);
-      w = wn;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, xv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, xv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, xv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, xv.w, acc, 0, 0, 0);
+      w0 = w1;
+      w1 = w2;
+      w2 = w3;
+      w3 = wn;
     }
     if (a.has_bias) {
       const float bias_a = reinterpret_cast<const float*>(wp + (int64_t)G * 64)[0];

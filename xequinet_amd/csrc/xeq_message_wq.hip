@@ -152,73 +152,96 @@ __global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __re
 }
 
 // records in padded walk order (layout: WQ_REC above); val(k) = f rho_k, the bias column's multiplier is f; derivative record
-// likewise.  Ten threads per slot, one 16-byte store each.
+// likewise.  Six threads per slot: two (one per k half) evaluate eight basis functions each and store their three bf16 packs,
+// two the f32 tail, two the harmonics.
 __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
                              const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
                              const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
                              float* __restrict__ drec) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p = t / 10;
+  const int64_t p = t / 6;
   if (p >= pcap || p >= 4 * (int64_t)qptr[N]) return;
-  const int grp = (int)(t - 10 * p);   // 0-5: bf16 packs [kh = grp / 3][split = grp % 3]; 6-7: f32 tail of kh = grp - 6; 8-9: Y
+  const int grp = (int)(t - 6 * p);   // 0-1: bf16 packs of k half kh = grp; 2-3: f32 tail of kh = grp - 2; 4-5: Y
   const int32_t e = peid[p];
-  f32x4 v = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-  if (e >= 0) {
-    const float rc = (float)rs.cutoff;
-    const EdgeGeom<float> g = edge_geom<float>(vec[3 * (int64_t)e], vec[3 * (int64_t)e + 1], vec[3 * (int64_t)e + 2]);
-    const int B = rs.num_basis;
-    if (grp < 8) {
-      float f, df;
-      envelope<float>(rs.cutoff_kind, g.d, rc, f, df);
-      auto value = [&](int k, float& val, float& dval) {   // k >= 0: basis function k; -1: the bias column; -2: nothing
-        val = dval = 0.f;
-        if (k >= 0 && k < B) {
-          float rho, drho;
-          radial<float>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : 0.f, rho, drho);
-          val = f * rho;
-          dval = df * rho + f * drho;
-        } else if (k == -1) {
-          val = f;
-          dval = df;
-        }
-      };
-      if (grp < 6) {
-        const int kh = grp / 3, split = grp - 3 * kh;
-        uint32_t w[4] = {0u, 0u, 0u, 0u}, dw[4] = {0u, 0u, 0u, 0u};
+  float* __restrict__ out = rec + p * WQ_REC;
+  float* __restrict__ dout = drec ? drec + p * WQ_REC : nullptr;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if (e < 0) {   // padding slot: an all-zero record (its filter is exactly 0)
+    if (grp < 2) {
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          float val, dval;
-          value(8 * kh + jj < B ? 8 * kh + jj : -2, val, dval);
-          uint32_t a3[3], d3[3];
-          wq_split3(val, a3[0], a3[1], a3[2]);
-          wq_split3(dval, d3[0], d3[1], d3[2]);
-          w[jj >> 1] |= a3[split] << (16 * (jj & 1));
-          dw[jj >> 1] |= d3[split] << (16 * (jj & 1));
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          v[c] = __uint_as_float(w[c]);
-          dv[c] = __uint_as_float(dw[c]);
-        }
-      } else {
-        const int kh = grp - 6;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float val, dval;
-          value(wq_tail_k(2 * c + kh, B), val, dval);
-          v[c] = val;
-          dv[c] = dval;
-        }
+      for (int c = 0; c < 3; ++c) {
+        *reinterpret_cast<f32x4*>(out + 12 * grp + 4 * c) = zero;
+        if (dout) *reinterpret_cast<f32x4*>(dout + 12 * grp + 4 * c) = zero;
       }
     } else {
-      float y1[3], y2[5];
-      sph_harm_l12<float>(g, y1, y2);
-      if (grp == 8) v = f32x4{y1[0], y1[1], y1[2], y2[0]};
-      else v = f32x4{y2[1], y2[2], y2[3], y2[4]};
+      const int off = grp < 4 ? WQ_TAIL + 4 * (grp - 2) : WQ_Y + 4 * (grp - 4);
+      *reinterpret_cast<f32x4*>(out + off) = zero;
+      if (dout) *reinterpret_cast<f32x4*>(dout + off) = zero;
     }
+    return;
   }
-  *reinterpret_cast<f32x4*>(rec + 4 * t) = v;
-  if (drec) *reinterpret_cast<f32x4*>(drec + 4 * t) = dv;
+  const float rc = (float)rs.cutoff;
+  const EdgeGeom<float> g = edge_geom<float>(vec[3 * (int64_t)e], vec[3 * (int64_t)e + 1], vec[3 * (int64_t)e + 2]);
+  const int B = rs.num_basis;
+  if (grp >= 4) {
+    float y1[3], y2[5];
+    sph_harm_l12<float>(g, y1, y2);
+    const f32x4 v = grp == 4 ? f32x4{y1[0], y1[1], y1[2], y2[0]} : f32x4{y2[1], y2[2], y2[3], y2[4]};
+    *reinterpret_cast<f32x4*>(out + WQ_Y + 4 * (grp - 4)) = v;
+    if (dout) *reinterpret_cast<f32x4*>(dout + WQ_Y + 4 * (grp - 4)) = zero;
+    return;
+  }
+  float f, df;
+  envelope<float>(rs.cutoff_kind, g.d, rc, f, df);
+  auto value = [&](int k, float& val, float& dval) {   // k >= 0: basis function k; -1: the bias column; -2: nothing
+    val = dval = 0.f;
+    if (k >= 0 && k < B) {
+      float rho, drho;
+      radial<float>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : 0.f, rho, drho);
+      val = f * rho;
+      dval = df * rho + f * drho;
+    } else if (k == -1) {
+      val = f;
+      dval = df;
+    }
+  };
+  if (grp < 2) {
+    const int kh = grp;
+    uint32_t w[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, dw[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      float val, dval;
+      value(8 * kh + jj < B ? 8 * kh + jj : -2, val, dval);
+      uint32_t a3[3], d3[3];
+      wq_split3(val, a3[0], a3[1], a3[2]);
+      wq_split3(dval, d3[0], d3[1], d3[2]);
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) {
+        w[sp][jj >> 1] |= a3[sp] << (16 * (jj & 1));
+        dw[sp][jj >> 1] |= d3[sp] << (16 * (jj & 1));
+      }
+    }
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+      *reinterpret_cast<f32x4*>(out + 12 * kh + 4 * sp) =
+          f32x4{__uint_as_float(w[sp][0]), __uint_as_float(w[sp][1]), __uint_as_float(w[sp][2]), __uint_as_float(w[sp][3])};
+      if (dout)
+        *reinterpret_cast<f32x4*>(dout + 12 * kh + 4 * sp) =
+            f32x4{__uint_as_float(dw[sp][0]), __uint_as_float(dw[sp][1]), __uint_as_float(dw[sp][2]), __uint_as_float(dw[sp][3])};
+    }
+  } else {
+    const int kh = grp - 2;
+    f32x4 v, dv;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float val, dval;
+      value(wq_tail_k(2 * c + kh, B), val, dval);
+      v[c] = val;
+      dv[c] = dval;
+    }
+    *reinterpret_cast<f32x4*>(out + WQ_TAIL + 4 * kh) = v;
+    if (dout) *reinterpret_cast<f32x4*>(dout + WQ_TAIL + 4 * kh) = dv;
+  }
 }
 
 #endif
@@ -1474,7 +1497,7 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
   if (n_edges == 0) return XEQ_OK;
-  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * 10;   // ten threads per record
+  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * 6;   // six threads per record
   XEQ_CHECK_ARG(pcap * WQ_REC < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
   hipLaunchKernelGGL(k_wq_records, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
