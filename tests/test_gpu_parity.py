@@ -967,13 +967,13 @@ def test_auto_picks_a_kernel_family_that_fits(monkeypatch):
     pick = lambda dt, n, e: ops.select_message_impl(dt, n, e, 20, 128, mul)
     assert pick(torch.float32, 18_609, 311_994) == "wq"
     assert pick(torch.float32, 1_200_000, 14_000_000) == "wq"
-    assert pick(torch.float32, 1_200_000, 31_000_000) == "sb"          # records: padded slots * 128 B >= 2^32
+    assert pick(torch.float32, 1_200_000, 31_000_000) == "sb"          # records: padded slots * 160 B >= 2^32
     assert pick(torch.float32, 1_900_000, 1_000_000) == "sb"           # rows of h: N * 576 * 4 B >= 2^32
     assert pick(torch.float32, 4_000_000, 1_000_000) == "generic"      # N * 576 elements >= 2^31
     assert pick(torch.float64, 18_609, 311_994) == "sb"
     assert ops.select_message_impl(torch.float32, 100, 1000, 20, 96, (96, 48, 24)) == "sb"   # multiplicities not in 32s
     assert ops.select_message_impl(torch.float32, 10_000, 100_000, 30, 128, mul) == "wm"      # num_basis > 23
-    assert pick(torch.float32, 1_536, 82_996) == "sb"                  # dense neighbourhoods (water box): sb is the faster family there
+    assert pick(torch.float32, 1_536, 82_996) == "wq"                  # dense neighbourhoods (water box): wq too since the split-bf16 filter
     assert pick(torch.float32, 21, 360) == "sb"                        # one small molecule: launch-bound, sb needs no walk plan
     assert pick(torch.float32, 1_175, 19_984) == "wq"                  # 64 QM9-shaped molecules: wq from there on
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")

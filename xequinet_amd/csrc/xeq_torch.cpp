@@ -492,7 +492,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
 
   // ---- which message kernels (ops.select_message_impl, without the wm / generic forms)
   int impl;
-  const bool prefers_sb = E >= 40 * std::max<int64_t>(1, N) || E < 4096;   // ops.prefers_sb: dense neighbourhoods, tiny graphs
+  const bool prefers_sb = E < 4096;   // ops.prefers_sb: tiny graphs (launch-bound; sb needs no walk plan)
   if (prefers_sb && xeq_message_sb_fits(N, E, hy.B, F, mul)) impl = 1;
   else if (dt == XEQ_F32 && xeq_message_wq_fits(N, E, hy.B, F, mul)) impl = 0;
   else if (xeq_message_sb_fits(N, E, hy.B, F, mul)) impl = 1;

@@ -583,11 +583,11 @@ def _message_impl() -> str:
 
 
 def prefers_sb(n_nodes: int, n_edges: int) -> bool:
-    """Where the scalar-broadcast kernels beat the matrix-core ones (measured, MI355X): dense neighbourhoods (>= 40 edges per atom:
-    a water box at 54 runs its reverse pass in 169 us against 191) and graphs of a few thousand edges at most (one small molecule:
-    the step is launch-bound and sb needs no walk plan; aspirin replay 0.80 against 0.86 ms).  QM9-shaped batches (17 edges per
-    atom) are faster on wq at every size from 64 molecules up.  csrc/xeq_torch.cpp applies the same rule."""
-    return n_edges >= 40 * max(1, n_nodes) or n_edges < 4096
+    """Where the scalar-broadcast kernels beat the matrix-core ones (measured, MI355X): graphs of a few thousand edges at most (one
+    small molecule: the step is launch-bound and sb needs no walk plan; aspirin replay 0.80 against 0.86 ms).  Round 2 also sent
+    dense neighbourhoods (>= 40 edges per atom) here; with the split-bf16 filter of round 3 the wq kernels win there too (water-512:
+    message kernels 0.49 against 0.74 ms per evaluation, step 1.42 against 1.60 ms).  csrc/xeq_torch.cpp applies the same rule."""
+    return n_edges < 4096
 
 
 def select_message_impl(dtype, n_nodes: int, n_edges: int, num_basis: int, node_dim: int, mul) -> str:
