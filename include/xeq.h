@@ -302,6 +302,23 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
                     const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec, int xhat_layout,
                     void* stream);
 
+/* Parameter gradients of the radial filter for a TRAINING pass (rbf_lin.weight / .bias, nn/xpainn.py:117,140; the trainable
+ * basis parameters freq, nn/rbf.py:143-146, or mean / std, :121-125) -- what autograd gets in the reference by differentiating
+ * through the materialised filter[E, 576] (nn/basic.py:154-155 with create_graph=training, utils/trainer.py:295-302).  Same walk
+ * and operands as xeq_message_bwd (neighbor-sorted CSR, center = edge_index row 0, grad_s / grad_x = dL/ds_out, dL/dx_out);
+ * writes parts[n_parts][H][3 B + 1] (n_parts = xeq_message_param_grad_parts(n_nodes)), per filter row c:
+ *   [0, B)        sum_e G f rho_k             -> dL/dW[c, k] after the sum over parts
+ *   [B]           sum_e G f                   -> dL/db[c]
+ *   [B+1, 2B+1)   sum_e G f d rho_k / d p0_k  -> dL/dp0_k = sum_c W[c, k] (.)
+ *   [2B+1, 3B+1)  sum_e G f d rho_k / d p1_k  -> dL/dp1_k likewise (zeros for the Bessel basis)
+ * with G[e, c] = dL/dfilter_out[e, c] h[nbr(e), c].  f32 and f64; node_dim and the channel count at most 256 each. */
+int xeq_message_param_grad_parts(int64_t n_nodes);
+int xeq_message_param_grad(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                           const int64_t* center, const void* vec, const void* h, const void* xhat, const void* grad_s,
+                           const void* grad_x, const void* p0, const void* p1, int rbf_kind, int cutoff_kind, int num_basis,
+                           double cutoff, int node_dim, const int32_t mul[3], int xhat_layout, int n_parts, void* parts,
+                           void* stream);
+
 /* "Scalar broadcast" form of the fused message (default path, f32 and f64).  The per-edge quantities
  * every channel shares -- f*rho_k(d), f, Y_lm, and their d/dd companions -- are evaluated once per
  * model evaluation into 4*(roundup(B,4)+12)-byte records (xeq_edge_basis), shared by all message

@@ -1,5 +1,6 @@
-"""Training-step time of the differentiable pass (nn/training.py) on one GPU: QM9-shaped batch, Adam, l2 loss.
-usage: python scratch/bench_train.py [n_mol] [energy|forces]"""
+"""Training-step time on one GPU: QM9-shaped batch, Adam, l2 loss.  An energy loss takes the native pass (fused kernels with parameter
+gradients, nn/fused.py); `energy-aten` forces the differentiable form of the same step (nn/training.py), as `forces` needs anyway.
+usage: python scratch/bench_train.py [n_mol] [energy|energy-aten|forces]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -19,7 +20,8 @@ model = resolve_model("xpainn").to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 g = torch.Generator().manual_seed(0)
 tgt = {keys.TOTAL_ENERGY: torch.randn(n_mol, generator=g).to(dev), keys.FORCES: torch.randn(len(pos), 3, generator=g).to(dev), keys.BATCH_PTR: data["ptr"]}
-w = {keys.TOTAL_ENERGY: 1.0} if mode == "energy" else {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 10.0}
+w = {keys.TOTAL_ENERGY: 1.0} if mode.startswith("energy") else {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 10.0}
+model.native_training = mode != "energy-aten"
 def step():
     d = {k: v for k, v in data.items() if not k.startswith("_")}
     d["pos"] = d["pos"].detach().clone()

@@ -67,8 +67,11 @@ VARIANT = dict(node_dim=64, node_irreps="64x0e + 32x1o + 32x2e", action_blocks=2
                rbf_kernel="gaussian", cutoff_fn="polynomial", layer_norm=False, activation="tanh")
 
 
-@pytest.mark.parametrize("case", ["energy", "energy+forces", "periodic energy+forces+virial", "variant energy+forces"])
+@pytest.mark.parametrize("case", ["energy", "variant energy", "periodic energy", "energy (differentiable form)", "energy+forces",
+                                  "periodic energy+forces+virial", "variant energy+forces"])
 def test_parameter_gradients_match_the_oracle(case):
+    """An energy-only loss takes the NATIVE training pass (fused kernels + xeq_message_param_grad, nn/fused.py); forces / virial in
+    the loss need second order and take the differentiable form (nn/training.py)."""
     periodic = case.startswith("periodic")
     cfg = VARIANT if case.startswith("variant") else SMALL   # variant: gaussian basis (trainable mean / std), polynomial envelope, no layer norm, tanh
     weights = {keys.TOTAL_ENERGY: 1.0}
@@ -77,9 +80,13 @@ def test_parameter_gradients_match_the_oracle(case):
     if "virial" in case:
         weights[keys.VIRIAL] = 0.5
     model = _model(torch.float64, **cfg).train()
+    model.native_training = "differentiable" not in case
     host, dev = _batch(6, 5, torch.float64, periodic)
     tgt = _targets(host, 7, keys.VIRIAL in weights)
-    result = model(dict(dev), keys.FORCES in weights, keys.VIRIAL in weights)
+    data = dict(dev)
+    result = model(data, keys.FORCES in weights, keys.VIRIAL in weights)
+    from xequinet_amd.nn import training as tr
+    assert bool(data[tr.PARAM_GRADS]) == (model.native_training and keys.FORCES not in weights and keys.VIRIAL not in weights)
     loss, _ = train.weighted_loss(result, {k: v.to(DEV) for k, v in tgt.items()}, weights)
     loss.backward()
 
@@ -115,6 +122,28 @@ def test_training_pass_gives_the_inference_numbers():
     dF = (got[keys.FORCES] - want[keys.FORCES]).abs()
     assert dE <= 1e-5 * want[keys.TOTAL_ENERGY].abs().max().item() + 1e-4
     assert dF.max().item() <= 1e-3 and torch.quantile(dF.flatten(), 0.99).item() <= 1e-4
+
+
+@pytest.mark.parametrize("cfg_name", ["default", "variant"])
+def test_native_training_pass_in_fp32_against_the_differentiable_form(cfg_name):
+    """fp32, a batch large enough for the matrix-core message kernels (wq): the native pass and the ATen form of the same step give
+    the same loss and parameter gradients to fp32 round-off (relative to each gradient's largest entry)."""
+    cfg = dict(action_blocks=3) if cfg_name == "default" else VARIANT
+    host, dev = _batch(64, 3, torch.float32)
+    tgt = {k: (v.float() if v.is_floating_point() else v).to(DEV) for k, v in _targets(host, 1, False).items()}
+    grads, losses = [], []
+    for native in (True, False):
+        model = _model(torch.float32, **cfg).train()
+        model.native_training = native
+        loss, _ = train.weighted_loss(model(dict(dev), False, False), tgt, {keys.TOTAL_ENERGY: 1.0})
+        loss.backward()
+        losses.append(loss.item())
+        grads.append({n: p.grad.double().cpu() for n, p in model.named_parameters()})
+    assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[1]))
+    assert set(grads[0]) == set(grads[1])
+    for n, g in grads[1].items():
+        err = (grads[0][n] - g).abs().max().item()
+        assert err <= 2e-4 * max(1e-6, g.abs().max().item()), f"{n}: {err:.2e} of {g.abs().max().item():.2e}"
 
 
 def test_frozen_model_in_train_mode_stays_on_the_fused_path():

@@ -157,6 +157,29 @@ __device__ __forceinline__ void radial(int kind, T d, T rc, T p0, T p1, T& rho, 
   }
 }
 
+// d rho_k / d p0 and d rho_k / d p1 of the same bases: the trainable basis parameters (freq: nn/rbf.py:143-146; mean, std:
+// nn/rbf.py:121-125) -- what a training pass contracts dL/d rho with (nn/training.py, xeq_message_param_grad)
+template <typename T>
+__device__ __forceinline__ void radial_dparam(int kind, T d, T rc, T p0, T p1, T& d0, T& d1) {
+  const T eps = T(1e-5);
+  if (kind == XEQ_RBF_BESSEL) {
+    T coeff = sqrt_<T>(T(2) / rc);
+    T s, c;
+    sincos_<T>(p0 * d, &s, &c);
+    d0 = coeff * d * c / (d + eps);
+    d1 = T(0);
+  } else {
+    T sd = abs_<T>(p1) + eps;
+    T coeff = T(1) / (sd * T(2.5066282746310002));
+    T z = (d - p0) / sd;
+    T rho = coeff * exp_<T>(-T(0.5) * z * z);
+    d0 = rho * z / sd;
+    // rho = exp(-z^2/2) / (sd sqrt(2 pi)), sd = |p1| + eps: d rho / d sd = rho (z^2 - 1) / sd; d|p1| / d p1 = sign (0 at 0, as autograd's abs)
+    T sg = p1 > T(0) ? T(1) : (p1 < T(0) ? T(-1) : T(0));
+    d1 = rho * (z * z - T(1)) / sd * sg;
+  }
+}
+
 // Geometry of one edge.  rhat = r / max(|r|, 1e-12) (F.normalize, e3nn normalize=True).
 template <typename T>
 struct EdgeGeom {

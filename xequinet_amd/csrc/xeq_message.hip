@@ -292,6 +292,132 @@ __global__ void __launch_bounds__(256) k_message_bwd(MsgArgs a, const T* __restr
   }
 }
 
+// ---- parameter gradients of the radial filter (training pass) -------------------------------------------------------
+// filter[e, c] = (sum_k W[c, k] rho_k(d_e) + b[c]) f(d_e)   (nn/xpainn.py:140), filter_out = h[nbr] * filter.  With
+//   G[e, c] = dL/dfilter_out[e, c] h[nbr(e), c]:   dL/dfilter_out = <grad_x[ctr], xhat[nbr]>_m (gate_state rows), <grad_x[ctr], Y(e)>_m
+//   (gate_edge rows), grad_s[ctr] (msg_s rows) -- the same products the reverse kernel forms for dL/dh,
+// the launch writes per workgroup and filter row c
+//   parts[p][c][0..B)       sum_e G f rho_k              -> dL/dW[c, k]
+//   parts[p][c][B]          sum_e G f                    -> dL/db[c]
+//   parts[p][c][B+1..2B+1)  sum_e G f d rho_k / d p0_k   -> dL/dp0_k = sum_c W[c, k] (.)      (freq / mean)
+//   parts[p][c][2B+1..3B+1) sum_e G f d rho_k / d p1_k   -> dL/dp1_k likewise                 (std; zero for the Bessel basis)
+// and the caller adds the parts up (a fixed order: bitwise reproducible).  This is the only parameter gradient of the model that is
+// not a contraction over saved NODE tensors (the [E, 576] operand never exists).  Mapping as k_message_bwd: a workgroup walks source
+// nodes, a thread owns one filter row of its role (blockIdx.y: 0 gate_state, 1 gate_edge, 2 msg_s) with 3 B + 1 running sums in
+// registers; the per-edge factors are computed once per chunk by spare lanes and broadcast through LDS.
+template <typename T, int MAXB, bool HAS_P1>
+__global__ void __launch_bounds__(256) k_message_param_grad(MsgArgs a, const T* __restrict__ vec, const T* __restrict__ h,
+                                                            const T* __restrict__ xhat, const T* __restrict__ grad_s,
+                                                            const T* __restrict__ grad_x, const T* __restrict__ p0,
+                                                            const T* __restrict__ p1, T* __restrict__ parts) {
+  __shared__ T sh_rf[EC][MAXB];
+  __shared__ T sh_q0[EC][MAXB];
+  __shared__ T sh_q1[HAS_P1 ? EC : 1][MAXB];
+  __shared__ T sh_y[EC][YS];
+  __shared__ T sh_d[EC];
+  __shared__ int32_t sh_ctr[EC];
+  const int t = threadIdx.x, role = blockIdx.y;
+  const int B = a.rs.num_basis, C = a.C, F = a.F, D = a.D, H = a.H;
+  const bool active = role == 2 ? t < F : t < C;
+  const int row = role * C + t;   // filter row: [gate_state C | gate_edge C | msg_s F]
+  int l = 0, off = 0;
+  if (role < 2 && active) a.ir.locate(t, l, off);
+  const int nm = (role < 2 && active) ? 2 * l + 1 : 0;
+  const int yoff = l == 0 ? 0 : (l == 1 ? 1 : 4);
+  const XAddr xa = xaddr(a.ir, a.n_nodes, (role < 2 && active) ? t : 0, a.xl);
+  const T rc = (T)a.rs.cutoff;
+  T aw[MAXB], a0[MAXB], a1[HAS_P1 ? MAXB : 1], ab = T(0);
+#pragma unroll
+  for (int k = 0; k < MAXB; ++k) aw[k] = a0[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < (HAS_P1 ? MAXB : 1); ++k) a1[k] = T(0);
+  for (int idx = t; idx < EC * MAXB; idx += blockDim.x) {
+    sh_rf[idx / MAXB][idx % MAXB] = T(0);
+    sh_q0[idx / MAXB][idx % MAXB] = T(0);
+    if (HAS_P1) sh_q1[idx / MAXB][idx % MAXB] = T(0);
+  }
+  __syncthreads();
+
+  XcdWalk walk(a.n_nodes, a.chunk);
+  for (int64_t n = walk.next(); n >= 0; n = walk.next()) {
+    const int32_t e0 = a.rowptr[n], e1 = a.rowptr[n + 1];
+    const T hrow = active ? h[n * H + row] : T(0);
+    T xh[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) xh[m] = (role == 0 && m < nm) ? xhat[xa.off + n * xa.node + m * xa.comp] : T(0);
+    for (int32_t base = e0; base < e1; base += EC) {
+      const int cnt = min(EC, e1 - base);
+      __syncthreads();   // previous chunk fully consumed
+      if (t < cnt) {
+        const int32_t e = a.perm ? a.perm[base + t] : base + t;
+        EdgeGeom<T> g = edge_geom<T>(vec[3 * (int64_t)e], vec[3 * (int64_t)e + 1], vec[3 * (int64_t)e + 2]);
+        T y1[3], y2[5], f, df;
+        sph_harm_l12<T>(g, y1, y2);
+        envelope<T>(a.rs.cutoff_kind, g.d, rc, f, df);
+        sh_y[t][0] = T(1);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) sh_y[t][1 + m] = y1[m];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) sh_y[t][4 + m] = y2[m];
+        sh_y[t][9] = f;
+        sh_d[t] = g.d;
+        sh_ctr[t] = (int32_t)a.other[e];
+      }
+      __syncthreads();
+      for (int idx = t; idx < cnt * B; idx += blockDim.x) {
+        const int j = idx / B, k = idx - j * B;
+        const T d = sh_d[j], f = sh_y[j][9];
+        const T q0 = p0[k], q1 = p1 ? p1[k] : T(0);
+        T rho, drho, d0, d1;
+        radial<T>(a.rs.rbf_kind, d, rc, q0, q1, rho, drho);
+        radial_dparam<T>(a.rs.rbf_kind, d, rc, q0, q1, d0, d1);
+        sh_rf[j][k] = f * rho;
+        sh_q0[j][k] = f * d0;
+        if (HAS_P1) sh_q1[j][k] = f * d1;
+      }
+      __syncthreads();
+      for (int j = 0; j < cnt; ++j) {
+        const int64_t c = sh_ctr[j];
+        T dg;
+        if (role == 2) {
+          dg = active ? grad_s[c * F + t] : T(0);
+        } else {
+          dg = T(0);
+#pragma unroll
+          for (int m = 0; m < 5; ++m) {
+            if (m < nm) {
+              const T gx = grad_x[c * D + off + m];
+              dg += (role == 0 ? xh[m] : sh_y[j][yoff + m]) * gx;
+            }
+          }
+        }
+        const T G = hrow * dg;
+        ab += G * sh_y[j][9];
+#pragma unroll
+        for (int k = 0; k < MAXB; ++k) {
+          aw[k] += G * sh_rf[j][k];
+          a0[k] += G * sh_q0[j][k];
+        }
+        if (HAS_P1) {
+#pragma unroll
+          for (int k = 0; k < MAXB; ++k) a1[k] += G * sh_q1[j][k];
+        }
+      }
+    }
+  }
+  if (active) {
+    T* out = parts + ((int64_t)blockIdx.x * H + row) * (3 * B + 1);
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k)
+      if (k < B) {
+        out[k] = aw[k];
+        out[B + 1 + k] = a0[k];
+        out[2 * B + 1 + k] = HAS_P1 ? a1[HAS_P1 ? k : 0] : T(0);
+      }
+    out[B] = ab;
+  }
+}
+
 static int check_msg(const char* who, int64_t n_nodes, int64_t n_edges, int num_basis, double cutoff,
                      int rbf_kind, int cutoff_kind, int node_dim, const int32_t mul[3], const void* p1,
                      MsgArgs& a) {
@@ -385,5 +511,48 @@ int xeq_message_bwd(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* 
   return XEQ_OK;
 }
 
+
+int xeq_message_param_grad_parts(int64_t n_nodes) {
+  const int64_t g = 256 * 2;
+  return (int)(n_nodes < g ? (n_nodes > 0 ? n_nodes : 1) : g);
+}
+
+int xeq_message_param_grad(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                           const int64_t* center, const void* vec, const void* h, const void* xhat, const void* grad_s,
+                           const void* grad_x, const void* p0, const void* p1, int rbf_kind, int cutoff_kind, int num_basis,
+                           double cutoff, int node_dim, const int32_t mul[3], int xhat_layout, int n_parts, void* parts,
+                           void* stream) {
+  MsgArgs a{};
+  int rcode = check_msg("xeq_message_param_grad", n_nodes, n_edges, num_basis, cutoff, rbf_kind, cutoff_kind, node_dim, mul, p1, a);
+  if (rcode != XEQ_OK) return rcode;
+  XEQ_CHECK_ARG(n_parts == xeq_message_param_grad_parts(n_nodes), "xeq_message_param_grad: parts must hold xeq_message_param_grad_parts(n_nodes) = %d blocks, got %d",
+                xeq_message_param_grad_parts(n_nodes), n_parts);
+  a.rowptr = n_rowptr;
+  a.perm = n_perm;
+  a.other = center;
+  a.xl = xhat_layout & 1;
+  const size_t bytes = (size_t)n_parts * a.H * (3 * num_basis + 1) * (dtype == XEQ_F64 ? 8 : 4);
+  if (n_nodes == 0) {   // nothing to walk: the sums are zero
+    if (hipMemsetAsync(parts, 0, bytes, (hipStream_t)stream) != hipSuccess) return XEQ_ERR_LAUNCH;
+    return XEQ_OK;
+  }
+  dim3 grid((unsigned)n_parts, 3);
+#define XEQ_PG_LAUNCH(MAXB, P1)                                                                                                   \
+  hipLaunchKernelGGL((k_message_param_grad<T, MAXB, P1>), grid, dim3(256), 0, (hipStream_t)stream, a, (const T*)vec, (const T*)h, \
+                     (const T*)xhat, (const T*)grad_s, (const T*)grad_x, (const T*)p0, (const T*)p1, (T*)parts)
+#define XEQ_PG_DISPATCH(P1)                                \
+  do {                                                     \
+    if (num_basis <= 8) XEQ_PG_LAUNCH(8, P1);              \
+    else if (num_basis <= 16) XEQ_PG_LAUNCH(16, P1);       \
+    else if (num_basis <= 20) XEQ_PG_LAUNCH(20, P1);       \
+    else XEQ_PG_LAUNCH(32, P1);                            \
+  } while (0)
+  XEQ_DISPATCH_FLOAT(dtype, {
+    if (rbf_kind == XEQ_RBF_GAUSSIAN) XEQ_PG_DISPATCH(true);
+    else XEQ_PG_DISPATCH(false);
+  });
+  XEQ_CHECK_LAUNCH("xeq_message_param_grad");
+  return XEQ_OK;
+}
 
 }  // extern "C"

@@ -5,9 +5,14 @@ kernel (``xeq_node.hip``), the two-layer scalar MLPs and their input gradients a
 launch each (``xeq_mlp.hip``), the o3.Linear contractions are plain library GEMMs on contiguous
 views of the internal BT layout, and the reverse pass is explicit (no autograd graph of
 small ops).  Semantics are those of nn/xpainn.py:128-161 and :206-231 of the reference;
-gradients are provided w.r.t. the node features and the edge vectors only (force
-evaluation, nn/basic.py:143-159); a training pass (parameter gradients, double backward) takes
-the differentiable form of the blocks in nn/training.py instead.
+gradients are provided w.r.t. the node features and the edge vectors (force evaluation,
+nn/basic.py:143-159) and, when a block is given its parameters as trailing inputs (the native
+training pass of an energy loss, nn/model.py), w.r.t. those parameters as well: the radial
+filter's gradients come from ``xeq_message_param_grad`` (the only one that is not a contraction
+over saved node tensors), every other weight gradient is a library GEMM / column sum over node
+tensors the forward pass keeps anyway.  A loss on forces or virials needs the derivative of
+the reverse pass itself: that training pass takes the differentiable form of the blocks in
+nn/training.py instead.
 """
 from __future__ import annotations
 
@@ -125,6 +130,61 @@ def _mlp_bwd(seq, g_y, pre):
     return g_x
 
 
+# ---- parameter gradients (native training pass of an energy loss) ------------------------------------------------------------
+def message_params(module, rbf) -> list:
+    """The parameters of an XPainnMessage in the order MessageBlock takes them as trailing inputs (and returns their gradients)."""
+    ps = []
+    if not isinstance(module.norm, torch.nn.Identity):
+        ps += [module.norm.weight, module.norm.bias, module.o3norm.affine_weight, module.o3norm.affine_bias]
+    m = module.scalar_mlp
+    ps += [m[0].weight, m[0].bias, m[2].weight, m[2].bias, module.rbf_lin.weight, module.rbf_lin.bias]
+    ps += [p for p in rbf.params() if p is not None]
+    return ps
+
+
+def update_params(module) -> list:
+    ps = []
+    if not isinstance(module.norm, torch.nn.Identity):
+        ps += [module.norm.weight, module.norm.bias, module.o3norm.affine_weight, module.o3norm.affine_bias]
+    m = module.update_mlp
+    ps += [module.update_U.weight, module.update_U.bias, module.update_V.weight, module.update_V.bias,
+           m[0].weight, m[0].bias, m[2].weight, m[2].bias, module.dot_lin.weight]
+    return ps
+
+
+def _mlp_param_grads(seq, x_in, pre, g_y):
+    """Linear - act - Linear on rows: (dW1, db1, dW2, db2, dL/dx) from the input, the saved pre-activation and dL/dy."""
+    lin1, act, lin2 = seq[0], seq[1], seq[2]
+    hidden = act(pre)
+    d_w2, d_b2 = torch.mm(g_y.t(), hidden), g_y.sum(0)
+    g_pre = _silu_bwd(torch.mm(g_y, lin2.weight), pre, act)
+    d_w1, d_b1 = torch.mm(g_pre.t(), x_in), g_pre.sum(0)
+    return d_w1, d_b1, d_w2, d_b2, torch.mm(g_pre, lin1.weight)
+
+
+def _norm_param_grads(s, x, stats, g_shat, g_xhat, node_dim, mul):
+    """dL/d(LayerNorm weight, bias) and dL/d(EquivariantLayerNorm affine_weight, affine_bias) from the block inputs, the saved
+    statistics (mean, rstd, mean of the 0e block, rsqrt of the mean square norm: xeq_node.hip) and the gradients of the normalised
+    features (g_shat [n, F] rows, g_xhat in the BT layout)."""
+    n = x.shape[0]
+    mean, rstd, mean0, r = stats.unbind(1)
+    d_lnw = (g_shat * ((s - mean[:, None]) * rstd[:, None])).sum(0)
+    d_lnb = g_shat.sum(0)
+    d_eqw, d_eqb, off = [], None, 0
+    for l, m in enumerate(mul):
+        d = 2 * l + 1
+        if m == 0:
+            continue
+        xb = x[:, off : off + m * d].view(n, m, d)
+        gb = g_xhat[n * off : n * (off + m * d)].view(n, d, m)
+        if l == 0:
+            xb = xb - mean0[:, None, None]
+            d_eqb = gb.sum((0, 1))
+        d_eqw.append(torch.einsum("ndm,nmd,n->m", gb, xb, r))
+        off += m * d
+    return d_lnw, d_lnb, torch.cat(d_eqw), d_eqb
+
+
 def _linear_pack(mod_or_key, weight: torch.Tensor, bias, transposed: bool):
     """Fragment-order copy of one Linear's weight for ``xeq_linear_fwd`` (forward: W as [n_out, k_in] with its bias; ``transposed``:
     the same weight as the input-gradient product, [k_in = n_out of the layer][n_out = k_in of the layer], no bias), cached on the
@@ -184,7 +244,12 @@ class EnergyHead(Function):
                 and bool(lib.load().xeq_linear_supported(lib.XEQ_F32, lin1.weight.shape[0], lin1.weight.shape[1])))
 
     @staticmethod
-    def forward(ctx, s, seq):
+    def params(seq) -> list:
+        return [seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias]
+
+    @staticmethod
+    def forward(ctx, s, seq, *params):
+        """``params`` = EnergyHead.params(seq) when their gradients are wanted (training pass), else nothing."""
         lin1, lin2 = seq[0], seq[2]
         s = s.contiguous()
         H = lin1.weight.shape[0]
@@ -192,38 +257,66 @@ class EnergyHead(Function):
         out = torch.empty(s.shape[0], dtype=s.dtype, device=s.device)
         w2 = lin2.weight.detach().reshape(-1).contiguous()
         call("xeq_head_dot", ptr(hidden), s.shape[0], H, ptr(w2), ptr(lin2.bias), ptr(out), stream())
-        ctx.save_for_backward(pre, w2)
+        ctx.train = len(params) > 0
+        ctx.save_for_backward(pre, w2, *((s, hidden) if ctx.train else ()))
         ctx.seq = seq
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_out):
-        pre, w2 = ctx.saved_tensors
+        pre, w2 = ctx.saved_tensors[:2]
         lin1 = ctx.seq[0]
-        g_hidden = torch.empty_like(pre)
-        call("xeq_head_bwd_hidden", ptr(pre), pre.shape[0], pre.shape[1], ptr(w2), ptr(g_out.contiguous()), ptr(g_hidden), stream())
-        return linear_module_bwd(lin1, g_hidden), None
+        g_out = g_out.contiguous()
+        g_pre = torch.empty_like(pre)    # dL/d(pre-activation of the hidden layer)
+        call("xeq_head_bwd_hidden", ptr(pre), pre.shape[0], pre.shape[1], ptr(w2), ptr(g_out), ptr(g_pre), stream())
+        g_s = linear_module_bwd(lin1, g_pre)
+        if not ctx.train:
+            return g_s, None
+        s, hidden = ctx.saved_tensors[2:]
+        return (g_s, None, torch.mm(g_pre.t(), s), g_pre.sum(0), torch.mv(hidden.t(), g_out).view(1, -1), g_out.sum().view(1))
+
+
+class EmbeddingLinear(Function):
+    """Table rows of the atomic numbers through Linear(embed_dim, node_dim) (nn/xpainn.py:62) as XEmbedding._embed launches it, with
+    the Linear's parameter gradients for a training pass (the table is a buffer, the atomic numbers are integers)."""
+
+    @staticmethod
+    def forward(ctx, z32, table, lin, weight, bias):
+        out = _linear(table, _linear_pack(lin, weight, bias, False), weight.shape[1], weight.shape[0], bias is not None, row_index=z32)[0]
+        ctx.save_for_backward(z32, table)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        z32, table = ctx.saved_tensors
+        rows = table.index_select(0, z32.long())
+        return None, None, None, torch.mm(g.t(), rows), (g.sum(0) if ctx.has_bias else None)
 
 
 class MessageBlock(Function):
     """XPainnMessage.forward (nn/xpainn.py:128-161): norms -> scalar_mlp -> fused message kernel."""
 
     @staticmethod
-    def forward(ctx, s, x, vec, module, graph, rbf, cutoff_fn, x_is_zero=False):
+    def forward(ctx, s, x, vec, module, graph, rbf, cutoff_fn, x_is_zero=False, *params):
+        """``params`` = message_params(module, rbf) when their gradients are wanted (training pass), else nothing."""
         lib.require_hip(s, x, vec)
         s, x, vec = s.contiguous(), x.contiguous(), vec.contiguous()
         F, mul = module.node_dim, module._mul
         shat, xhat, stats, do_norm = _norm_fwd(s, x, module.norm, module.o3norm, F, mul)
         pre, h = _mlp_fwd(module.scalar_mlp, shat)
         p0, p1 = rbf.params()
+        ctx.p_shapes = (p0.shape, None if p1 is None else p1.shape)
         # xhat in BT layout; behind XEmbedding x is zero, hence xhat is zero on every l > 0 column (include/xeq.h)
         xl = 1 | (lib.XHAT_HIGHER_L_ZERO if x_is_zero else 0)
         cfg = (rbf.kind, cutoff_fn.kind, module.num_basis, float(cutoff_fn.cutoff), F, mul, xl)
         s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, module.rbf_lin.weight, module.rbf_lin.bias,
                                                         p0, p1, graph, cfg)
         ctx.none_mask = [t is None for t in saved]
-        ctx.save_for_backward(*[t for t in saved if t is not None], s, x, stats, pre)
+        ctx.train = len(params) > 0
+        ctx.save_for_backward(*[t for t in saved if t is not None], *((shat,) if ctx.train else ()), s, x, stats, pre)
         ctx.module, ctx.do_norm, ctx.graph, ctx.cfg, ctx.impl = module, do_norm, graph, cfg, impl
         return s_out, x_out
 
@@ -234,18 +327,30 @@ class MessageBlock(Function):
         F, mul = module.node_dim, module._mul
         t = list(ctx.saved_tensors)
         s, x, stats, pre = t[-4:]
-        it = iter(t[:-4])
+        shat = t[-5] if ctx.train else None
+        it = iter(t[: -5 if ctx.train else -4])
         msg_saved = tuple(None if is_none else next(it) for is_none in ctx.none_mask)
-        node_grads = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        node_grads = ctx.train or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         g_h, g_xhat, g_vec, g_s_res, g_x_res = ops.message_backward(msg_saved, ctx.graph, ctx.cfg, ctx.impl, g_s_out, g_x_out,
                                                                     node_grads=node_grads)
         if not node_grads:
             # first block of a force evaluation: its node features are the embedding of the atomic numbers and zeros, neither
             # depends on the positions; only dL/dvec leaves this block (no MLP / norm reverse launches)
             return None, None, g_vec, None, None, None, None, None
-        g_shat = _mlp_bwd(module.scalar_mlp, g_h, pre)
+        if not ctx.train:
+            g_shat = _mlp_bwd(module.scalar_mlp, g_h, pre)
+            g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_shat, F, g_xhat, g_s_res, g_x_res)
+            return g_s, g_x, g_vec, None, None, None, None, None
+        # training pass: the same reverse kernels for the input gradients, plus the parameter gradients in message_params' order
+        d_wr, d_br, d_p0, d_p1 = ops.message_param_grad(msg_saved, ctx.graph, ctx.cfg, g_s_res, g_x_res)
+        d_w1, d_b1, d_w2, d_b2, g_shat = _mlp_param_grads(module.scalar_mlp, shat, pre, g_h)
         g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_shat, F, g_xhat, g_s_res, g_x_res)
-        return g_s, g_x, g_vec, None, None, None, None, None
+        p0, p1 = msg_saved[5], msg_saved[6]
+        grads = list(_norm_param_grads(s, x, stats, g_shat, g_xhat, F, mul)) if ctx.do_norm else []
+        grads += [d_w1, d_b1, d_w2, d_b2, d_wr, d_br, d_p0.view(ctx.p_shapes[0])]
+        if p1 is not None:
+            grads.append(d_p1.view(ctx.p_shapes[1]))
+        return (g_s, g_x, g_vec, None, None, None, None, None, *grads)
 
 
 def _packed_uv(module) -> Tuple[list, torch.Tensor]:
@@ -305,7 +410,8 @@ class UpdateBlock(Function):
     """XPainnUpdate.forward (nn/xpainn.py:206-231)."""
 
     @staticmethod
-    def forward(ctx, s, x, module):
+    def forward(ctx, s, x, module, *params):
+        """``params`` = update_params(module) when their gradients are wanted (training pass), else nothing."""
         lib.require_hip(s, x)
         s, x = s.contiguous(), x.contiguous()
         n, D = x.shape
@@ -339,7 +445,8 @@ class UpdateBlock(Function):
         s_out, x_out = torch.empty_like(s), (None if getattr(module, "equivariant_output_unused", False) else torch.empty_like(x))
         call("xeq_update_out_fwd", dtype_code(s), ptr(s), ptr(x), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(s_out),
              ptr(x_out), stream())
-        ctx.save_for_backward(s, x, stats, uv, pre, a, ip)
+        ctx.train = len(params) > 0
+        ctx.save_for_backward(s, x, stats, uv, pre, a, ip, *((cat, p) if ctx.train else ()))
         ctx.module, ctx.do_norm = module, do_norm
         ctx.set_materialize_grads(False)   # an output without a consumer (the last block's x_out: the head reads s only) arrives as None
         return s_out, x_out
@@ -348,7 +455,7 @@ class UpdateBlock(Function):
     @once_differentiable
     def backward(ctx, g_s_out, g_x_out):
         module = ctx.module
-        s, x, stats, uv, pre, a, ip = ctx.saved_tensors
+        s, x, stats, uv, pre, a, ip = ctx.saved_tensors[:7]
         n, D = x.shape
         F, mul = module.node_dim, module.node_irreps.mul3()
         C = sum(mul)
@@ -361,6 +468,8 @@ class UpdateBlock(Function):
         call("xeq_update_out_bwd", dtype_code(s), ptr(g_s_out), ptr(g_x_out), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(g_a),
              ptr(g_ip), None, stream())
         g_p = linear_module_bwd(module.dot_lin, g_ip)
+        if ctx.train:
+            return UpdateBlock._backward_with_params(ctx, g_s_out, g_x_out, g_a, g_ip, g_p)
         g_cat = _mlp_bwd(module.update_mlp, g_a, pre)                         # [g_shat | g_v]
         frag = _packed_uv_frag(module)
         if frag is not None and g_cat.is_contiguous():   # dL/dU, dL/dV -> dL/dxhat -> reverse of both norms in one matrix-core launch
@@ -388,3 +497,39 @@ class UpdateBlock(Function):
             torch.mm(gub, W.t(), out=gb)
         g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_cat, F + C, g_xhat, g_s_out, g_x_out)
         return g_s, g_x, None
+
+    @staticmethod
+    def _backward_with_params(ctx, g_s_out, g_x_out, g_a, g_ip, g_p):
+        """Training pass: the unfused reverse chain (dL/dU, dL/dV exist as a tensor there), the weight gradients as GEMMs over
+        node tensors, in update_params' order."""
+        module = ctx.module
+        s, x, stats, uv, pre, a, ip, cat, p = ctx.saved_tensors
+        n, D = x.shape
+        F, mul = module.node_dim, module.node_irreps.mul3()
+        C = sum(mul)
+        d_dot = torch.mm(g_ip.t(), p)
+        d_w1, d_b1, d_w2, d_b2, g_cat = _mlp_param_grads(module.update_mlp, cat, pre, g_a)   # g_cat = [g_shat | g_v]
+        if g_x_out is None:
+            g_x_out = torch.zeros_like(x)
+        g_uv = torch.empty_like(uv)
+        call("xeq_uv_reduce_bwd", dtype_code(s), ptr(uv), ptr(g_p), ptr(g_cat), F + C, F, n, mul3(mul), float(module.invariant.eps),
+             ptr(g_x_out), ptr(a), ptr(g_uv), stream())
+        _, xhat, _, _ = _norm_fwd(s, x, module.norm, module.o3norm, F, mul)     # recomputed: one launch, the forward did not keep it
+        packs, bias = _packed_uv(module)
+        g_xhat = torch.empty(n * D, dtype=s.dtype, device=s.device)
+        d_wu, d_wv, d_bu, d_bv = [], [], None, None
+        for (l, m, gb), (_, _, gub), (_, _, xb), W in zip(_bt_blocks(g_xhat, n, mul, 1), _bt_blocks(g_uv, n, mul, 2),
+                                                          _bt_blocks(xhat, n, mul, 1), packs):
+            torch.mm(gub, W.t(), out=gb)
+            d_pack = torch.mm(xb.t(), gub) / math.sqrt(m)        # [mul, 2 mul]: [dL/dW_U | dL/dW_V] of this l
+            d_wu.append(d_pack[:, :m].reshape(-1))
+            d_wv.append(d_pack[:, m:].reshape(-1))
+            if l == 0 and bias is not None:
+                col = gub.sum(0)
+                d_bu, d_bv = col[:m], col[m:]
+        g_s, g_x = _norm_bwd(s, x, module.norm, module.o3norm, stats, ctx.do_norm, F, mul, g_cat, F + C, g_xhat, g_s_out, g_x_out)
+        grads = list(_norm_param_grads(s, x, stats, g_cat[:, :F], g_xhat, F, mul)) if ctx.do_norm else []
+        zero_b = lambda b: torch.zeros_like(b)
+        grads += [torch.cat(d_wu), d_bu if d_bu is not None else zero_b(module.update_U.bias),
+                  torch.cat(d_wv), d_bv if d_bv is not None else zero_b(module.update_V.bias), d_w1, d_b1, d_w2, d_b2, d_dot]
+        return (g_s, g_x, None, *grads)

@@ -25,6 +25,7 @@ class BaseModel(nn.Module):
         super().__init__()
         self.mods = nn.ModuleDict()
         self.extra_properties = []
+        self.native_training = True   # False: an energy-only training pass takes the differentiable form too (nn/training.py)
 
     def forward(
         self,
@@ -32,10 +33,14 @@ class BaseModel(nn.Module):
         compute_forces: bool = True,
         compute_virial: bool = False,
     ) -> Dict[str, torch.Tensor]:
-        # a training pass (train mode, parameters asking for gradients) runs every block in its differentiable form so
-        # that the force evaluation can itself be differentiated (create_graph=training, nn/basic.py:143-159); everything
-        # else is the fused inference path
+        # a training pass (train mode, parameters asking for gradients) whose result carries forces or a virial runs every block
+        # in its differentiable form so that the force evaluation can itself be differentiated (create_graph=training,
+        # nn/basic.py:143-159); with energies only (no second order) the blocks stay on the fused kernels and return their
+        # parameter gradients themselves (nn/fused.py); everything else is the fused inference path
         train_pass = training.wants_training_pass(self)
+        native = train_pass and not compute_forces and not compute_virial and self.native_training and training.native_pass_supported(self)
+        data[training.PARAM_GRADS] = native
+        train_pass = train_pass and not native
         data[training.TRAIN_PASS] = train_pass
         if train_pass:
             data = training.edge_data(data, compute_forces=compute_forces, compute_virial=compute_virial)

@@ -55,7 +55,8 @@ class EnergyOut(OutputModule):
         from .fused import EnergyHead
 
         if EnergyHead.supported(self.out_mlp, node_scalar):    # matrix-core kernels, explicit reverse pass (nn/fused.py)
-            atom_eng_out = EnergyHead.apply(node_scalar, self.out_mlp)
+            params = EnergyHead.params(self.out_mlp) if data.get(training.PARAM_GRADS, False) else ()
+            atom_eng_out = EnergyHead.apply(node_scalar, self.out_mlp, *params)
         else:                                                  # f64, other activations / widths: library GEMMs
             atom_eng_out = self.out_mlp(node_scalar).reshape(-1)
         if keys.ATOMIC_ENERGIES in data:

@@ -23,6 +23,14 @@ from .. import keys, lib
 
 TRAIN_PASS = "_xeq_train_pass"      # data-dict flag set by BaseModel.forward: every block of this pass takes the training form
 _RSH = "_xeq_train_rsh"             # per-l list of Y_l [E, 2l+1] written by the embedding
+# data-dict flag set by BaseModel.forward for a training pass whose loss reads energies only (no forces, no virial): the blocks stay on
+# the fused HIP kernels and hand their parameters to the block functions, which return the parameter gradients (nn/fused.py)
+PARAM_GRADS = "_xeq_param_grads"
+
+
+def native_pass_supported(model: torch.nn.Module) -> bool:
+    """Every block of the model has the fused form with parameter gradients (the blocks of this package with ``fused`` on)."""
+    return all(getattr(m, "fused", True) for m in model.modules())
 
 
 def wants_training_pass(module: torch.nn.Module) -> bool:

@@ -16,7 +16,7 @@ import torch.nn as nn
 from .. import keys, o3, ops
 from .basic import Int2c1eEmbedding, edge_graph, resolve_activation
 from . import training
-from .fused import MessageBlock, UpdateBlock
+from .fused import EmbeddingLinear, MessageBlock, UpdateBlock, message_params, update_params
 from .o3layer import EquivariantDot, EquivariantLayerNorm, Invariant
 from .rbf import resolve_cutoff, resolve_rbf
 
@@ -60,7 +60,7 @@ class XEmbedding(nn.Module):
         self.cutoff_fn = resolve_cutoff(cutoff_fn, cutoff)
         self.materialize_edge_basis = materialize_edge_basis
 
-    def _embed(self, atomic_numbers: torch.Tensor) -> torch.Tensor:
+    def _embed(self, atomic_numbers: torch.Tensor, param_grads: bool = False) -> torch.Tensor:
         """nn/xpainn.py:62: table rows of the atomic numbers through Linear(embed_dim, node_dim) -- one matrix-core launch that
         gathers the rows itself (csrc/xeq_linear.hip) where the kernel takes the layer, else lookup + library GEMM."""
         if isinstance(self.embedding, nn.Embedding):
@@ -71,6 +71,8 @@ class XEmbedding(nn.Module):
         if (atomic_numbers.is_cuda and table.dtype == torch.float32 and table.stride(0) % 4 == 0
                 and (pack := _linear_pack(lin, lin.weight, lin.bias, False)) is not None):
             z = atomic_numbers.to(torch.int32).contiguous()
+            if param_grads:   # training pass: the same launch with the Linear's parameter gradients behind it
+                return EmbeddingLinear.apply(z, table, lin, lin.weight, lin.bias)
             return _linear(table, pack, lin.weight.shape[1], lin.weight.shape[0], lin.bias is not None, row_index=z)[0]
         return self.embedding(atomic_numbers)
 
@@ -81,7 +83,7 @@ class XEmbedding(nn.Module):
         vectors = data[keys.EDGE_VECTOR]
         ops.lib.require_hip(vectors)
 
-        node_invariant = self._embed(atomic_numbers)
+        node_invariant = self._embed(atomic_numbers, bool(data.get(training.PARAM_GRADS, False)))
         data[keys.NODE_INVARIANT] = node_invariant
         data[RADIAL_SPEC] = (self.rbf, self.cutoff_fn)
 
@@ -145,8 +147,9 @@ class XPainnMessage(nn.Module):
         if rbf.num_basis != self.num_basis:
             raise ValueError(f"num_basis mismatch: embedding {rbf.num_basis} vs message {self.num_basis}")
         if self.fused:  # block-level path: explicit forward/reverse, see nn/fused.py
+            params = message_params(self, rbf) if data.get(training.PARAM_GRADS, False) else ()
             new_scalar, new_equi = MessageBlock.apply(ori_scalar, ori_equi, data[keys.EDGE_VECTOR], self, edge_graph(data), rbf, cutoff_fn,
-                                                      x_is_zero)
+                                                      x_is_zero, *params)
         else:           # operator-level path (the reference's own op sequence on the drop-in ops)
             node_scalar = self.norm(ori_scalar)
             node_equi = self.o3norm(ori_equi)
@@ -202,7 +205,8 @@ class XPainnUpdate(nn.Module):
         if training.active(self, data):
             return training.update(self, data)
         if self.fused:
-            s_new, x_new = UpdateBlock.apply(data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT], self)
+            params = update_params(self) if data.get(training.PARAM_GRADS, False) else ()
+            s_new, x_new = UpdateBlock.apply(data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT], self, *params)
             data[keys.NODE_INVARIANT] = s_new
             data[keys.NODE_EQUIVARIANT] = x_new
             return data

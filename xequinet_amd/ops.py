@@ -820,6 +820,27 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
     return g_h, g_xhat, g_vec, g_s, g_x
 
 
+def message_param_grad(saved, graph: EdgeGraph, cfg, g_s, g_x):
+    """Parameter gradients of the radial filter of one message block (training pass): (dL/dW_rbf [H, B], dL/db_rbf [H], dL/dp0 [B],
+    dL/dp1 [B] or None) from what message_forward saved and dL/ds_out, dL/dx_out -- ``xeq_message_param_grad`` (one launch, per-workgroup
+    partial sums) and the sum over its parts."""
+    h, xhat, vec, w_rbf, b_rbf, p0, p1 = saved[:7]
+    rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = cfg[:6]
+    xl = int(cfg[6]) if len(cfg) > 6 else 0
+    N, E, B, H = graph.n_nodes, graph.n_edges, num_basis, h.shape[1]
+    n_parts = int(lib.load().xeq_message_param_grad_parts(N))
+    parts = torch.empty((n_parts, H, 3 * B + 1), dtype=h.dtype, device=h.device)
+    KERNEL_TIMER.launch("xeq_message_param_grad", dtype_code(h), N, E, ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(graph.edge_index[0]),
+                        ptr(vec), ptr(h), ptr(xhat), ptr(g_s.contiguous()), ptr(g_x.contiguous()), ptr(p0), ptr(p1),
+                        lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], B, float(cutoff), node_dim, mul3(mul), xl & 1, n_parts,
+                        ptr(parts), stream())
+    total = parts.sum(0)
+    d_w, d_b = total[:, :B], total[:, B]
+    d_p0 = (w_rbf * total[:, B + 1 : 2 * B + 1]).sum(0)
+    d_p1 = None if p1 is None else (w_rbf * total[:, 2 * B + 1 :]).sum(0)
+    return d_w, d_b, d_p0, d_p1
+
+
 class FusedMessage(Function):
     """nn/xpainn.py:140-159 in one kernel; see xeq_message_fwd / xeq_message_bwd."""
 
