@@ -247,6 +247,12 @@ int xeq_linear_fwd(const void* x, int64_t ldx, int64_t n, int k_in, const int32_
 int xeq_head_dot(const void* hidden, int64_t n, int hidden_dim, const void* w2, const void* b2, void* out, void* stream);
 int xeq_head_bwd_hidden(const void* pre, int64_t n, int hidden_dim, const void* w2, const void* g_atomic, void* g_hidden, void* stream);
 
+/* Weight gradient of a linear layer for a TRAINING pass (what autograd forms as grad_output^T @ input for nn.Linear, utils/trainer.py:
+ * 295-302; the o3.Linear blocks likewise): parts[c][M][K] = sum over the rows of chunk c of a[row, 0..M)^T b[row, 0..K), f32, rows
+ * with strides lda / ldb; n_chunks = xeq_wgrad_chunks(n, M, K); dW = sum over c (fixed order: reproducible bit for bit). */
+int xeq_wgrad_chunks(int64_t n, int m, int k);
+int xeq_wgrad(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t n, int m, int k, int n_chunks, void* parts, void* stream);
+
 /* A batch of n atoms in g graphs into arrays of n_cap atoms / g_cap graphs in ONE launch (runtime.GraphedStep: neighbour list +
  * model as one captured graph over capacity-sized arrays): atoms n .. n_cap - 1 get atomic number 0, positions
  * (pad0 + spacing (i - n), 0, 0) -- no two within any cutoff -- and sit alone in graph g_cap - 1; graphs g .. g_cap - 2 are empty.

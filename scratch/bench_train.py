@@ -3,7 +3,8 @@ gradients, nn/fused.py); `energy-aten` forces the differentiable form of the sam
 usage: python scratch/bench_train.py [n_mol] [energy|energy-aten|forces]"""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xequinet_amd import keys, train
 from xequinet_amd.data import synthetic as syn, NeighborTransform, XequiBatch
 from xequinet_amd.nn import resolve_model

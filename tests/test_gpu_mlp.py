@@ -233,3 +233,19 @@ def test_embedding_lookup_and_energy_head_kernels():
     er = (torch.nn.functional.silu(sd @ w1.t() + b1) @ w2.t() + b2).reshape(-1)
     (gr,) = torch.autograd.grad(er, sd, g.double())
     assert float((e.double() - er).abs().max()) <= TOL and float((gs.double() - gr).abs().max()) <= TOL
+
+
+@pytest.mark.parametrize("n,m,k", [(18609, 576, 128), (18609, 128, 352), (1001, 128, 56), (777, 64, 128), (5, 32, 32), (0, 64, 64),
+                                   (55827, 64, 128)])
+def test_weight_gradient_kernel_matches_fp64(n, m, k):
+    """xeq_wgrad (training pass): a^T b over the node rows against the fp64 product, strided row views, repeatable bit for bit."""
+    g = torch.Generator().manual_seed(n + m + k)
+    a_full = torch.randn((n, m + 8), generator=g).to("cuda")
+    b_full = torch.randn((n, k + 4), generator=g).to("cuda")
+    a, b = a_full[:, 4 : 4 + m], b_full[:, :k]       # row strides m + 8 / k + 4
+    got = fused._wgrad(a, b)
+    want = torch.mm(a.double().t(), b.double())
+    scale = max(1.0, want.abs().max().item())
+    assert got.shape == (m, k) and (got.double() - want).abs().max().item() <= 2e-6 * scale * max(1.0, n ** 0.5 / 30)
+    assert torch.equal(got, fused._wgrad(a, b))
+    assert torch.equal(fused._wgrad(a.double(), b.double()), want)     # f64: the library product

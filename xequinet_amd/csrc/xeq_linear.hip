@@ -136,6 +136,73 @@ __global__ void k_head_bwd_hidden(const float* __restrict__ pre, int64_t n, int 
       make_float4(ga * w.x * dsilu(p.x), ga * w.y * dsilu(p.y), ga * w.z * dsilu(p.z), ga * w.w * dsilu(p.w));
 }
 
+// ---- weight gradients of a training pass: dW[M, K] = A[n, M]^T B[n, K] over the n node rows ----------------------------------------
+// (A = dL/dy rows, B = the layer's input rows: nn.Linear's weight gradient; the o3.Linear blocks likewise on the BT views.)  The
+// reduction runs over the LONG dimension (n = 18 k rows against M, K <= 576; the library takes 60-130 us per product here,
+// scratch/bench_wgrad.py, and another summation order for another row count); here the rows are cut into chunks, a wave owns a 64 x 64 block of dW for one chunk -- four exact-f32 32x32x2 tiles, each MFMA taking
+// two rows, the operands read straight from global memory (consecutive waves of a workgroup share the chunk: L1 / L2 hits) -- and
+// writes parts[chunk][M][K]; the caller sums the parts in chunk order: fixed summation order, bitwise reproducible.
+struct WgradArgs {
+  const float* A;
+  const float* B;
+  int64_t lda, ldb, n, rows_per_chunk;
+  int M, K, bm, bk, n_chunks;
+  float* parts;
+};
+
+__global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
+  const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nblocks = a.bm * a.bk;
+  const int64_t chunk = wave / nblocks;
+  if (chunk >= a.n_chunks) return;
+  const int blk = (int)(wave - chunk * nblocks);
+  const int m0 = 64 * (blk / a.bk), k0 = 64 * (blk % a.bk);
+  const int64_t r0 = chunk * a.rows_per_chunk, r1 = min(a.n, r0 + a.rows_per_chunk);
+  const bool am0 = m0 + i < a.M, am1 = m0 + 32 + i < a.M, bk0 = k0 + i < a.K, bk1 = k0 + 32 + i < a.K;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+  const float* pa = a.A + m0 + i;
+  const float* pb = a.B + k0 + i;
+  constexpr int UN = 4;   // row pairs in flight
+  for (int64_t r = r0; r < r1; r += 2 * UN) {
+    float va0[UN], va1[UN], vb0[UN], vb1[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t row = r + 2 * u + kh;
+      const bool ok = row < r1;
+      va0[u] = (ok && am0) ? pa[row * a.lda] : 0.f;
+      va1[u] = (ok && am1) ? pa[row * a.lda + 32] : 0.f;
+      vb0[u] = (ok && bk0) ? pb[row * a.ldb] : 0.f;
+      vb1[u] = (ok && bk1) ? pb[row * a.ldb + 32] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0[u], vb0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0[u], vb1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1[u], vb0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1[u], vb1[u], acc[1][1], 0, 0, 0);
+    }
+  }
+  float* out = a.parts + chunk * (int64_t)a.M * a.K;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int col = k0 + 32 * v + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowm = m0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (rowm < a.M && col < a.K) out[(int64_t)rowm * a.K + col] = acc[u][v][r];
+      }
+    }
+}
+
 }  // namespace xeq
 
 using namespace xeq;
@@ -174,6 +241,27 @@ int xeq_head_bwd_hidden(const void* pre, int64_t n, int hidden_dim, const void* 
   hipLaunchKernelGGL(k_head_bwd_hidden, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)pre, n,
                      hidden_dim, (const float*)w2, (const float*)g_atomic, (float*)g_hidden);
   XEQ_CHECK_LAUNCH("xeq_head_bwd_hidden");
+  return XEQ_OK;
+}
+
+/* chunks xeq_wgrad cuts n rows into for an [M, K] gradient: enough (block, chunk) waves for ~2 per SIMD, at least 128 rows each */
+int xeq_wgrad_chunks(int64_t n, int m, int k) {
+  const int64_t blocks = (int64_t)((m + 63) / 64) * ((k + 63) / 64);
+  int64_t c = (2048 + blocks - 1) / blocks, cmax = (n + 127) / 128;
+  if (c > cmax) c = cmax;
+  return (int)(c < 1 ? 1 : c);
+}
+
+int xeq_wgrad(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t n, int m, int k, int n_chunks, void* parts, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && m >= 1 && k >= 1 && lda >= m && ldb >= k, "xeq_wgrad: bad shape n = %lld, M = %d, K = %d", (long long)n, m, k);
+  XEQ_CHECK_ARG(n_chunks == xeq_wgrad_chunks(n, m, k), "xeq_wgrad: parts must hold xeq_wgrad_chunks(n, M, K) = %d blocks, got %d",
+                xeq_wgrad_chunks(n, m, k), n_chunks);
+  WgradArgs w{(const float*)a, (const float*)b, lda, ldb, n, (n + n_chunks - 1) / n_chunks, m, k, (m + 63) / 64, (k + 63) / 64, n_chunks,
+              (float*)parts};
+  if (w.rows_per_chunk & 1) ++w.rows_per_chunk;   // an MFMA takes two rows: chunks start on even rows
+  const int64_t waves = (int64_t)w.bm * w.bk * n_chunks;
+  hipLaunchKernelGGL(k_wgrad, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w);
+  XEQ_CHECK_LAUNCH("xeq_wgrad");
   return XEQ_OK;
 }
 
