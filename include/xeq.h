@@ -325,6 +325,24 @@ int xeq_message_param_grad(int dtype, int64_t n_nodes, int64_t n_edges, const in
                            double cutoff, int node_dim, const int32_t mul[3], int xhat_layout, int n_parts, void* parts,
                            void* stream);
 
+/* The same parameter gradients on the matrix cores (csrc/xeq_train.hip; f32, node_dim and multiplicities in multiples of 32, a table
+ * row of 64 floats: xeq_message_param_grad_mc_supported).  xeq_param_basis writes, once per training step, the per-edge rows
+ *   tab[e][W] = f(d_e) [rho_k (B) | 1 | d rho_k/d p0 (B) | d rho_k/d p1 (B, gaussian basis only)], zero padding to a multiple of 4, Y_1 (3), Y_2 (5)
+ * (W = xeq_param_basis_width: whole 128-byte lines) in the order of the edge list; xeq_message_param_grad_mc contracts them with G[e, c] formed on the fly:
+ * parts[n_parts][H][64], columns as xeq_message_param_grad's (the caller sums over the parts).  center / nbr = edge_index rows 0 / 1;
+ * any edge order (center-sorted lists gather best). */
+int xeq_message_param_grad_mc_supported(int dtype, int rbf_kind, int num_basis, int node_dim, const int32_t mul[3]);
+int xeq_param_basis_width(int rbf_kind, int num_basis);
+int xeq_message_param_grad_mc_parts(int64_t n_edges, int node_dim, const int32_t mul[3]);
+int xeq_param_basis(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis, double cutoff, const void* p0,
+                    const void* p1, void* tab, void* stream);
+int xeq_message_param_grad_mc(int64_t n_nodes, int64_t n_edges, const int64_t* center, const int64_t* nbr, const void* tab, const void* h,
+                              const void* xhat, const void* grad_s, const void* grad_x, int rbf_kind, int num_basis, int node_dim,
+                              const int32_t mul[3], int xhat_layout, int grad_x_layout, int n_parts, void* parts, void* stream);
+/* f32 x[n_nodes, D] in the e3nn mul_ir layout -> the internal BT layout (per l a row-major [N (2l+1), mul_l] matrix; layout 1 of the
+ * xhat_layout / grad_x_layout arguments): the gradient kernel's gathers of dL/dx_out rows are contiguous over the channels there. */
+int xeq_to_bt(const void* x, int64_t n_nodes, const int32_t mul[3], void* out, void* stream);
+
 /* "Scalar broadcast" form of the fused message (default path, f32 and f64).  The per-edge quantities
  * every channel shares -- f*rho_k(d), f, Y_lm, and their d/dd companions -- are evaluated once per
  * model evaluation into 4*(roundup(B,4)+12)-byte records (xeq_edge_basis), shared by all message

@@ -33,3 +33,7 @@ K = 10
 for _ in range(K): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 print(f"train step ({mode} loss) n_mol={n_mol} N={len(pos)} E={E}: {dt*1e3:.2f} ms/step, {E/dt/1e6:.1f} M edges/s, peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss {l.item():.4f}")
+from xequinet_amd import ops
+ops.KERNEL_TIMER.reset(enabled=True)
+for _ in range(5): step()
+print({k: f"{v['total_ms'] / v['launches'] * 1e3:.0f} us x {v['launches'] / 5:.0f}" for k, v in ops.KERNEL_TIMER.summary().items()})

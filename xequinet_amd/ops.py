@@ -828,7 +828,29 @@ def message_param_grad(saved, graph: EdgeGraph, cfg, g_s, g_x):
     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = cfg[:6]
     xl = int(cfg[6]) if len(cfg) > 6 else 0
     N, E, B, H = graph.n_nodes, graph.n_edges, num_basis, h.shape[1]
-    n_parts = int(lib.load().xeq_message_param_grad_parts(N))
+    L = lib.load()
+    if h.is_cuda and L.xeq_message_param_grad_mc_supported(dtype_code(h), lib.RBF_KINDS[rbf_kind], B, node_dim, mul3(mul)):
+        # matrix-core form (csrc/xeq_train.hip): per-edge rows once per geometry and parameter state, shared by the blocks
+        key = (rbf_kind, cutoff_kind, B, float(cutoff), p0.data_ptr(), p0._version, None if p1 is None else p1._version)
+        cached = getattr(graph, "_param_basis", None)
+        if _basis_cache_hit(cached, vec, key):
+            tab = cached[2]
+        else:
+            tab = torch.empty((E, int(L.xeq_param_basis_width(lib.RBF_KINDS[rbf_kind], B))), dtype=h.dtype, device=h.device)
+            call("xeq_param_basis", ptr(vec), E, lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], B, float(cutoff), ptr(p0), ptr(p1),
+                 ptr(tab), stream())
+            graph._param_basis = (vec, key, tab)
+        n_parts = int(L.xeq_message_param_grad_mc_parts(E, node_dim, mul3(mul)))
+        parts = torch.empty((n_parts, H, 64), dtype=h.dtype, device=h.device)
+        g_x_bt = torch.empty(g_x.numel(), dtype=h.dtype, device=h.device)     # dL/dx_out rows contiguous over the channels
+        call("xeq_to_bt", ptr(g_x.contiguous()), N, mul3(mul), ptr(g_x_bt), stream())
+        KERNEL_TIMER.launch("xeq_message_param_grad_mc", N, E, ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(tab), ptr(h), ptr(xhat),
+                            ptr(g_s.contiguous()), ptr(g_x_bt), lib.RBF_KINDS[rbf_kind], B, node_dim, mul3(mul), xl & 1, 1, n_parts,
+                            ptr(parts), stream())
+        total = parts.sum(0)
+        d_p1 = None if p1 is None else (w_rbf * total[:, 2 * B + 1 : 3 * B + 1]).sum(0)
+        return total[:, :B], total[:, B], (w_rbf * total[:, B + 1 : 2 * B + 1]).sum(0), d_p1
+    n_parts = int(L.xeq_message_param_grad_parts(N))
     parts = torch.empty((n_parts, H, 3 * B + 1), dtype=h.dtype, device=h.device)
     KERNEL_TIMER.launch("xeq_message_param_grad", dtype_code(h), N, E, ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(graph.edge_index[0]),
                         ptr(vec), ptr(h), ptr(xhat), ptr(g_s.contiguous()), ptr(g_x.contiguous()), ptr(p0), ptr(p1),
@@ -847,6 +869,7 @@ class FusedMessage(Function):
     @staticmethod
     def forward(ctx, h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg):
         s_out, x_out, saved, impl = message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph, cfg)
+        ctx.p_shapes = (p0.shape, None if p1 is None else p1.shape)
         ctx.save_for_backward(*saved)
         ctx.graph, ctx.cfg, ctx.impl = graph, cfg, impl
         return s_out, x_out
@@ -854,8 +877,11 @@ class FusedMessage(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g_s, g_x):
-        if any(ctx.needs_input_grad[5:9]):
-            raise NotImplementedError("xequinet_amd: this operator has no parameter gradients (the training pass is nn/training.py); "
-                                      "call model.requires_grad_(False) / model.eval()")
-        g_h, g_xhat, g_vec, g_s, g_x = message_backward(ctx.saved_tensors, ctx.graph, ctx.cfg, ctx.impl, g_s, g_x)
-        return g_h, g_xhat, g_vec, g_s, g_x, None, None, None, None, None, None
+        saved = ctx.saved_tensors
+        g_h, g_xhat, g_vec, g_s, g_x = message_backward(saved, ctx.graph, ctx.cfg, ctx.impl, g_s, g_x)
+        d_w = d_b = d_p0 = d_p1 = None
+        if any(ctx.needs_input_grad[5:9]):   # first order only: a loss on forces differentiates the reverse pass itself (nn/training.py)
+            d_w, d_b, d_p0, d_p1 = message_param_grad(saved, ctx.graph, ctx.cfg, g_s, g_x)
+            d_p0 = d_p0.view(ctx.p_shapes[0])
+            d_p1 = None if d_p1 is None else d_p1.view(ctx.p_shapes[1])
+        return g_h, g_xhat, g_vec, g_s, g_x, d_w, d_b, d_p0, d_p1, None, None
