@@ -50,16 +50,18 @@ def plan_chunks(ptr: Sequence[int], max_edges: int, g0: int = 0, g1: int = None)
     n = np.diff(ptr[g0 : g1 + 1]).astype(np.int64)
     bound = n * (n - 1)
 
+    csum = np.concatenate([[0], np.cumsum(bound)])
+
     def cut(cap: int) -> List[Tuple[int, int]]:
-        out, start, acc = [], g0, 0
-        for i, b in enumerate(bound):
-            if acc + b > cap and g0 + i > start:
-                out.append((start, g0 + i))
-                start, acc = g0 + i, 0
-            acc += int(b)
-        if g1 > start or not out:
-            out.append((start, g1))
-        return out
+        # greedy: a range takes molecules while their bounds fit under the cap (at least one); one searchsorted per range --
+        # this runs per evaluation on 65 k molecules (runtime.evaluate_in_chunks), a Python loop per molecule cost 90 ms there
+        out, start, n_mol = [], 0, len(bound)
+        while start < n_mol:
+            end = int(np.searchsorted(csum, csum[start] + cap, side="right")) - 1
+            end = min(max(end, start + 1), n_mol)
+            out.append((g0 + start, g0 + end))
+            start = end
+        return out or [(g0, g1)]
 
     # the fewest ranges the cap allows, then the smallest cap that still gives that many: ranges of about equal size instead
     # of full ones and a small remainder (a remainder of a few thousand edges would also take another kernel family than
