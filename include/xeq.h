@@ -456,13 +456,21 @@ int64_t xeq_message_wq_parts_floats(int64_t n_nodes, int64_t n_edges, const int3
  * units with its filter and gathers (bit-identical results), the reverse kernel (with grad_h NULL) drops the value filters
  * and pass S of the l > 0 units.  The other kernel families accept the hint and ignore it. */
 #define XEQ_XHAT_HIGHER_L_ZERO 2
+/* xeq_message_bwd_wq only: xhat_layout | XEQ_WQ_MIRROR_WALK walks the FORWARD plan (center-sorted CSR, owner = center, gathered =
+ * neighbor) and its records: every slot (i <- j) then stands for its mirror edge (j <- i), whose neighbor is the owner and whose
+ * center is the gathered node -- the edges a reverse walk visits for node i, in the same order, when the list is symmetric with
+ * neighbours ascending per center (what the open-boundary builders of this library write).  The mirror's vector is the negative of
+ * the slot's: same distance, same Y_2, Y_1 negated (done at the load), so the results are the reverse plan's bit for bit, and the
+ * reverse plan and its records are never built.  xeq_message_wq_edge_grad then takes `mirror` = the reverse-edge map
+ * (xeq_reverse_edge_map: position of edge (j, i) for edge (i, j)) to write each slot's gradient to the mirror edge; NULL otherwise. */
+#define XEQ_WQ_MIRROR_WALK 4
 int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* n_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis,
                        const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
                        const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,
                        void* grad_xhat, void* parts, int xhat_layout, void* stream);
 int xeq_message_wq_edge_grad(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
-                             const int32_t mul[3], const void* parts, void* grad_vec, void* stream);
+                             const int32_t* mirror, const int32_t mul[3], const void* parts, void* grad_vec, void* stream);
 
 /* ------------------------------------------------- node-side fused elementwise stages
  * Internal "BT" layout of equivariant intermediates (xhat_layout = 1 above): block-major over

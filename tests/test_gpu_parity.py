@@ -1098,3 +1098,49 @@ def test_copy_many_one_launch_for_a_list_of_copies():
         assert torch.equal(dst, src)
     assert torch.equal(mism[0], mism[1].long()) and torch.equal(strided[0], strided[1])
     ops.copy_many([])
+
+
+@pytest.mark.parametrize("first_block", [False, True])
+def test_wq_reverse_mirror_walk_is_the_reverse_plan_bit_for_bit(first_block, monkeypatch):
+    """Symmetric center-sorted lists (what NeighborTransform builds for open boundaries): the reverse wq kernel walks the FORWARD
+    plan and records, every slot standing for its mirror edge (XEQ_WQ_MIRROR_WALK) -- no reverse plan, no reverse records.  Same
+    edges in the same order with the same bits (the mirror's vector is the negated vector): every gradient equals the reverse-plan
+    walk's bit for bit, general and first-block forms."""
+    from xequinet_amd import lib, ops
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wq")
+    pos, z, ptr = syn.synth_qm9_batch(96, seed=5)
+    b = NeighborTransform(5.0)(XequiBatch(_t(pos.astype(np.float32)), _t(z), _t(ptr)))
+    ei, N = b.edge_index, len(pos)
+    E = ei.shape[1]
+    mul, F, B, rc = (128, 64, 32), 128, 20, 5.0
+    C, D = 224, 480
+    H = F + 2 * C
+    g = torch.Generator().manual_seed(11)
+    r = lambda *shape: torch.randn(*shape, generator=g).to(DEV)
+    h, s, x = r(N, H), r(N, F), r(N, D)
+    xhat = r(N * D)
+    if first_block:                      # zero on the l > 0 columns (BT layout: the l = 0 block comes first)
+        xhat[N * mul[0]:] = 0
+    W, bias = r(H, B) / math.sqrt(B), r(H)
+    p0 = (math.pi * torch.arange(1, B + 1, device=DEV) / rc).float().view(1, -1)
+    gs, gx = r(N, F), r(N, D)
+    vec = (b.pos[ei[0]] - b.pos[ei[1]]).contiguous()
+    cfg = ("bessel", "cosine", B, rc, F, mul, 1 | (lib.XHAT_HIGHER_L_ZERO if first_block else 0))
+    results = []
+    for mirror in (True, False):
+        graph = ops.EdgeGraph(ei, N, center_sorted=True, ptr=b.ptr, symmetric=True)
+        assert graph.mirror_walk
+        graph.mirror_walk = mirror
+        s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, W, bias, p0, None, graph, cfg, want_backward=True)
+        assert impl == "wq"
+        for node_grads in ((True, False) if first_block else (True,)):
+            out = ops.message_backward(saved, graph, cfg, impl, gs, gx, node_grads=node_grads)
+            results.append((mirror, node_grads, [s_out, x_out] + [t for t in out[:3] if t is not None]))
+        assert (graph._wq is not None) and ((True, ops._wq_edges_per_stream(E, N)) in graph._wq) == (not mirror)   # no reverse plan under the mirror walk
+    half = len(results) // 2
+    for (m1, n1, a), (m2, n2, c) in zip(results[:half], results[half:]):
+        assert m1 and not m2 and n1 == n2 and len(a) == len(c)
+        for u, v in zip(a, c):
+            assert torch.equal(u, v)

@@ -262,6 +262,7 @@ struct WqArgs {
   int F, C, D, H, B;
   Irreps ir;
   int xl;                  // layout of xhat / grad_xhat
+  int mirror;              // reverse pass over the FORWARD plan of a symmetric list: every slot stands for its mirror edge (Y_1 negated)
   int nu[3];               // 32-channel units per l
 };
 
@@ -445,6 +446,11 @@ __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int
     const f32x4* __restrict__ yp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + WQ_Y);
     w.ya = yp[0];
     w.yb = yp[1];
+    if (a.mirror) {   // the mirror edge's vector is the negative of the slot's: d and Y_2 are the same bits, Y_1 changes sign
+      w.ya[0] = -w.ya[0];
+      w.ya[1] = -w.ya[1];
+      w.ya[2] = -w.ya[2];
+    }
   }
 }
 template <int KS, int NREC, bool WITH_Y>
@@ -1315,13 +1321,15 @@ k_message_bwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
 
 // dL/dvec from the per-unit partials (by padded slot of the reverse walk), summed in unit order (deterministic),
 // chain rule of A1-A3; one thread per padded slot, pads skipped
-__global__ void k_wq_edge_grad(const float* __restrict__ vec, const int32_t* __restrict__ peid, const int32_t* __restrict__ qptr,
-                               int64_t N, int64_t P, int nu, int nu1, int nu2, const float* __restrict__ pd,
-                               const float* __restrict__ y1, const float* __restrict__ y2, float* __restrict__ grad_vec) {
+__global__ void k_wq_edge_grad(const float* __restrict__ vec, const int32_t* __restrict__ peid, const int32_t* __restrict__ mirror,
+                               const int32_t* __restrict__ qptr, int64_t N, int64_t P, int nu, int nu1, int nu2,
+                               const float* __restrict__ pd, const float* __restrict__ y1, const float* __restrict__ y2,
+                               float* __restrict__ grad_vec) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P || p >= 4 * (int64_t)qptr[N]) return;
-  const int32_t e = peid[p];
+  int32_t e = peid[p];
   if (e < 0) return;
+  if (mirror) e = mirror[e];   // mirror walk: the slot's partials belong to the reverse edge
   float gd = 0.f, q1[3] = {0.f, 0.f, 0.f}, q2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int u = 0; u < nu; ++u) gd += pd[(int64_t)u * P + p];
   for (int u = 0; u < nu1; ++u)
@@ -1554,6 +1562,7 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   a.pgath = pgath;
   a.qinfo = (const uint32_t*)qinfo;
   a.xl = xhat_layout & 1;
+  a.mirror = (xhat_layout & XEQ_WQ_MIRROR_WALK) ? 1 : 0;
   const bool first = (xhat_layout & XEQ_XHAT_HIGHER_L_ZERO) != 0 && grad_h == nullptr;
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
   WqParts pr;
@@ -1595,7 +1604,7 @@ int XEQ_WQ_DBG(xeq_wq_debug_stamps)(unsigned long long out[32]) {
 
 #ifdef XEQ_WQ_PART_BWD
 int xeq_message_wq_edge_grad(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
-                             const int32_t mul[3], const void* parts, void* grad_vec, void* stream) {
+                             const int32_t* mirror, const int32_t mul[3], const void* parts, void* grad_vec, void* stream) {
   XEQ_CHECK_ARG(n_edges >= 0 && mul[0] % 32 == 0 && mul[1] % 32 == 0 && mul[2] % 32 == 0, "xeq_message_wq_edge_grad: bad sizes");
   if (n_edges == 0) return XEQ_OK;
   const int64_t P = wq_pcap(n_nodes, n_edges);
@@ -1604,7 +1613,7 @@ int xeq_message_wq_edge_grad(const void* vec, int64_t n_nodes, int64_t n_edges, 
   const float* y1 = pd + (int64_t)nunits * P;
   const float* y2 = y1 + (int64_t)nu1 * 3 * P;
   hipLaunchKernelGGL(k_wq_edge_grad, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
-                     peid, qptr, n_nodes, P, nunits, nu1, nu2, pd, y1, y2, (float*)grad_vec);
+                     peid, mirror, qptr, n_nodes, P, nunits, nu1, nu2, pd, y1, y2, (float*)grad_vec);
   XEQ_CHECK_LAUNCH("xeq_message_wq_edge_grad");
   return XEQ_OK;
 }

@@ -256,6 +256,7 @@ struct WqPlan {
 };
 struct Graph {
   int64_t N = 0, E = 0;
+  bool mirror = false;   // symmetric center-sorted list: the reverse wq kernel walks the forward plan (XEQ_WQ_MIRROR_WALK), ops.EdgeGraph.mirror_walk
   Tensor ei, c_rowptr, c_perm, n_rowptr, n_perm;   // c_perm undefined: edges already center-sorted
   WqPlan fwd, rev;
   Tensor sb_basis, sb_dbasis;
@@ -285,6 +286,7 @@ Graph build_graph(const Tensor& edge_index, int64_t n_nodes, bool center_sorted,
   } else {
     csr_by_key(center, n_nodes, g.c_rowptr, g.c_perm);
   }
+  g.mirror = symmetric && center_sorted;
   if (symmetric && center_sorted) {
     g.n_rowptr = g.c_rowptr;
     g.n_perm = i32(g.E, g.ei);
@@ -500,8 +502,11 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   if (impl == 0) {
     build_wq_plan(g, false, g.fwd);
     g.fwd.basis = at::empty({g.fwd.pcap, xeq_message_wq_record_floats()}, fopt);
+    // a reverse pass over the same plan (mirror walk) follows: its derivative records come out of the same launch (ops.message_forward)
+    if (g.mirror && (compute_forces || compute_virial)) g.fwd.dbasis = at::empty({g.fwd.pcap, xeq_message_wq_record_floats()}, fopt);
     XCALL(xeq_edge_basis_wq(vec.data_ptr(), N, E, (const int32_t*)g.fwd.qptr.data_ptr(), (const int32_t*)g.fwd.peid.data_ptr(),
-                            hy.rbf_kind, hy.cutoff_kind, hy.B, hy.cutoff, p0.data_ptr(), OP(p1), g.fwd.basis.data_ptr(), nullptr, st));
+                            hy.rbf_kind, hy.cutoff_kind, hy.B, hy.cutoff, p0.data_ptr(), OP(p1), g.fwd.basis.data_ptr(),
+                            g.fwd.dbasis.defined() ? g.fwd.dbasis.data_ptr() : nullptr, st));
   } else {
     const int w = xeq_edge_basis_width(hy.B);
     g.sb_basis = at::empty({E, w}, fopt);
@@ -606,7 +611,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
     }
     Tensor g_x;   // undefined = zero: the head reads the scalars only, the last block's equivariant output has no consumer
     Tensor g_vec_total;
-    if (impl == 0) {
+    if (impl == 0 && !g.mirror) {
       build_wq_plan(g, true, g.rev);
       g.rev.basis = at::empty({g.rev.pcap, xeq_message_wq_record_floats()}, fopt);
       g.rev.dbasis = at::empty({g.rev.pcap, xeq_message_wq_record_floats()}, fopt);
@@ -663,14 +668,17 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         Tensor g_vec = at::empty_like(vec);
         if (m.impl == 0) {
           Tensor parts = at::empty({std::max<int64_t>(1, xeq_message_wq_parts_floats(N, E, mul))}, fopt);
-          XCALL(xeq_message_bwd_wq(N, E, g.rev.n_ranges, (const int32_t*)g.rev.sq.data_ptr(), (const int32_t*)g.rev.sn.data_ptr(),
-                                   (const int32_t*)g.rev.win.data_ptr(), (const int32_t*)g.rev.rowptr.data_ptr(),
-                                   (const int32_t*)g.rev.pgath.data_ptr(), (const int32_t*)g.rev.qinfo.data_ptr(),
-                                   g.rev.basis.data_ptr(), g.rev.dbasis.data_ptr(), m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(),
+          const WqPlan& w = g.mirror ? g.fwd : g.rev;
+          const int xl_bwd = (b == 0 ? (1 | XEQ_XHAT_HIGHER_L_ZERO) : 1) | (g.mirror ? XEQ_WQ_MIRROR_WALK : 0);
+          XCALL(xeq_message_bwd_wq(N, E, w.n_ranges, (const int32_t*)w.sq.data_ptr(), (const int32_t*)w.sn.data_ptr(),
+                                   (const int32_t*)w.win.data_ptr(), (const int32_t*)w.rowptr.data_ptr(),
+                                   (const int32_t*)w.pgath.data_ptr(), (const int32_t*)w.qinfo.data_ptr(),
+                                   w.basis.data_ptr(), w.dbasis.data_ptr(), m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(),
                                    g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B, F, mul, node_grads ? g_h.data_ptr() : nullptr,
-                                   node_grads ? g_xhat.data_ptr() : nullptr, parts.data_ptr(), b == 0 ? (1 | XEQ_XHAT_HIGHER_L_ZERO) : 1, st));
-          XCALL(xeq_message_wq_edge_grad(vec.data_ptr(), N, E, (const int32_t*)g.rev.qptr.data_ptr(),
-                                         (const int32_t*)g.rev.peid.data_ptr(), mul, parts.data_ptr(), g_vec.data_ptr(), st));
+                                   node_grads ? g_xhat.data_ptr() : nullptr, parts.data_ptr(), xl_bwd, st));
+          XCALL(xeq_message_wq_edge_grad(vec.data_ptr(), N, E, (const int32_t*)w.qptr.data_ptr(), (const int32_t*)w.peid.data_ptr(),
+                                         g.mirror ? (const int32_t*)g.n_perm.data_ptr() : nullptr, mul, parts.data_ptr(),
+                                         g_vec.data_ptr(), st));
         } else {
           XCALL(xeq_message_bwd_sb(dt, N, E, (const int32_t*)g.n_rowptr.data_ptr(), (const int32_t*)g.n_perm.data_ptr(),
                                    (const int64_t*)g.ei.select(0, 0).data_ptr(), g.sb_basis.data_ptr(), g.sb_dbasis.data_ptr(),

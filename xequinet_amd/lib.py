@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("XEQ_LIB_PATH") or os.path.join(_HERE, "libxeq_hip.so"
 XEQ_F32, XEQ_F64 = 0, 1
 COPY_MANY_MAX = 16       # XEQ_COPY_MANY_MAX of include/xeq.h
 XHAT_HIGHER_L_ZERO = 2   # XEQ_XHAT_HIGHER_L_ZERO of include/xeq.h: hint bit on the xhat_layout argument of the wq message kernels
+WQ_MIRROR_WALK = 4       # XEQ_WQ_MIRROR_WALK: the reverse wq kernel walks the forward plan of a symmetric list
 RBF_KINDS = {"bessel": 0, "gaussian": 1}
 CUTOFF_KINDS = {"cosine": 0, "polynomial": 1}
 
@@ -113,7 +114,7 @@ _PROTOS = {
     "xeq_message_wq_parts_floats": [c_int64, c_int64, _I3],
     "xeq_message_bwd_wq": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                            _I3, _P, _P, _P, c_int, _P],
-    "xeq_message_wq_edge_grad": [_P, c_int64, c_int64, _P, _P, _I3, _P, _P, _P],
+    "xeq_message_wq_edge_grad": [_P, c_int64, c_int64, _P, _P, _P, _I3, _P, _P, _P],
     "xeq_message_wm_edge_grad": [_P, c_int64, _I3, _P, _P, _P, _P],
     "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
     "xeq_norm_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],

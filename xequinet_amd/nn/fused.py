@@ -326,7 +326,7 @@ class MessageBlock(Function):
         xl = 1 | (lib.XHAT_HIGHER_L_ZERO if x_is_zero else 0)
         cfg = (rbf.kind, cutoff_fn.kind, module.num_basis, float(cutoff_fn.cutoff), F, mul, xl)
         s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, module.rbf_lin.weight, module.rbf_lin.bias,
-                                                        p0, p1, graph, cfg)
+                                                        p0, p1, graph, cfg, want_backward=any(ctx.needs_input_grad))
         ctx.none_mask = [t is None for t in saved]
         ctx.train = len(params) > 0
         ctx.save_for_backward(*[t for t in saved if t is not None], *((shat,) if ctx.train else ()), s, x, stats, pre)

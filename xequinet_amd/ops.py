@@ -129,6 +129,9 @@ class EdgeGraph:
                 self.c_rowptr = csr_rowptr(center, self.n_nodes)
         else:
             self.c_rowptr, self.c_perm = csr_by_key(center, self.n_nodes)
+        # symmetric, center-sorted list: the reverse wq kernel walks the FORWARD plan (every slot stands for its mirror edge), n_perm
+        # is the mirror map (include/xeq.h, XEQ_WQ_MIRROR_WALK)
+        self.mirror_walk = bool(symmetric and center_sorted)
         if symmetric and center_sorted:
             self.n_rowptr = self.c_rowptr
             self.n_perm = torch.empty(E, dtype=torch.int32, device=edge_index.device)
@@ -678,9 +681,9 @@ def edge_basis_wq(vec, plan, n_nodes, rbf_kind, cutoff_kind, num_basis, cutoff, 
     """Per-edge records of the wave / quad kernels in the PADDED WALK ORDER of `plan` (xeq_edge_basis_wq), once per
     evaluation and direction, cached on the plan: value records for the forward walk, value + d/dd records for the
     reverse walk."""
-    key = (rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version, bool(deriv))
+    key = (rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version)
     cached = plan["records"]
-    if _basis_cache_hit(cached, vec, key):
+    if _basis_cache_hit(cached, vec, key) and (cached[3] is not None or not deriv):   # records with derivatives serve both requests
         return cached[2], cached[3]
     E = vec.shape[0]
     width = int(lib.load().xeq_message_wq_record_floats())
@@ -732,9 +735,11 @@ def copy_many(pairs) -> None:
         call("xeq_copy_many", n, srcs, dsts, sizes, stream())
 
 
-def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg):
+def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg, want_backward: bool = False):
     """Launch the fused message kernel.  cfg = (rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul[, xhat_layout]).
-    Returns (s_out, x_out, saved, impl): `saved` is what message_backward needs."""
+    Returns (s_out, x_out, saved, impl): `saved` is what message_backward needs.  ``want_backward``: a reverse pass will follow
+    (wq on a symmetric list: the derivative records are then written by the same launch as the value records, the reverse kernel
+    walks this plan)."""
     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = cfg[:6]
     xl = int(cfg[6]) if len(cfg) > 6 else 0  # layout of xhat / grad_xhat: 0 e3nn, 1 BT
     require_hip(h, xhat, vec, s, x, w_rbf, b_rbf, p0)
@@ -749,7 +754,8 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
     impl = select_message_impl(h.dtype, N, E, num_basis, node_dim, mul)
     if impl == "wq":
         plan = graph.wq_plan(False, _wq_edges_per_stream(E, N))
-        basis, _ = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv=False)
+        basis, _ = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1,
+                                 deriv=bool(want_backward and getattr(graph, "mirror_walk", False)))
         KERNEL_TIMER.launch("xeq_message_fwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), ptr(plan["rowptr"]),
                             ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf),
                             ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream(),
@@ -790,15 +796,17 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
     g_vec = torch.empty_like(vec)  # written at the edge's own position by every kernel family
     if impl == "wq":
         N, E = graph.n_nodes, graph.n_edges
-        plan = graph.wq_plan(True, _wq_edges_per_stream(E, N))
+        mirror = getattr(graph, "mirror_walk", False)      # symmetric list: the forward plan and its records serve both directions
+        plan = graph.wq_plan(not mirror, _wq_edges_per_stream(E, N))
         basis, dbasis = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv=True)
+        xl_bwd = xl | (lib.WQ_MIRROR_WALK if mirror else 0)
         parts = torch.empty(max(1, lib.load().xeq_message_wq_parts_floats(N, E, mul3(mul))), dtype=h.dtype, device=h.device)
         KERNEL_TIMER.launch("xeq_message_bwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), ptr(plan["rowptr"]),
                             ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x),
-                            ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream(),
+                            ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl_bwd, stream(),
                             label="xeq_message_bwd_wq_first" if (skip and xl & lib.XHAT_HIGHER_L_ZERO) else None)
-        call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), mul3(mul), ptr(parts), ptr(g_vec),
-             stream())
+        call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), ptr(graph.n_perm if mirror else None),
+             mul3(mul), ptr(parts), ptr(g_vec), stream())
     elif impl == "wm":
         plan = graph.wm_plan(True, _wm_edges_per_stream(graph.n_edges, graph.n_nodes))
         parts = torch.empty(lib.load().xeq_message_wm_parts_floats(graph.n_edges, mul3(mul)), dtype=h.dtype, device=h.device)
@@ -868,7 +876,8 @@ class FusedMessage(Function):
 
     @staticmethod
     def forward(ctx, h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg):
-        s_out, x_out, saved, impl = message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph, cfg)
+        s_out, x_out, saved, impl = message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph, cfg,
+                                                    want_backward=any(ctx.needs_input_grad))
         ctx.p_shapes = (p0.shape, None if p1 is None else p1.shape)
         ctx.save_for_backward(*saved)
         ctx.graph, ctx.cfg, ctx.impl = graph, cfg, impl

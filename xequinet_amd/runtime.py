@@ -80,7 +80,7 @@ class GraphedModel:
     def _signature(self, data, eg: ops.EdgeGraph) -> tuple:
         pos = data[keys.POSITIONS]
         return (tuple(pos.shape), pos.dtype, pos.device.index, int(data[keys.EDGE_INDEX].shape[1]),
-                int(data[keys.BATCH_PTR].numel()), keys.CELL in data, eg.c_perm is None)
+                int(data[keys.BATCH_PTR].numel()), keys.CELL in data, eg.c_perm is None, eg.mirror_walk)
 
     @staticmethod
     def _edge_graph(data) -> ops.EdgeGraph:
@@ -108,7 +108,7 @@ class GraphedModel:
                                                            output_size=c.inputs[keys.POSITIONS].shape[0])
         # a private EdgeGraph over the captured edge_index; its CSR arrays are refreshed in place before every replay
         c.edge_graph = ops.EdgeGraph(c.inputs[keys.EDGE_INDEX], eg.n_nodes, center_sorted=eg.c_perm is None,
-                                     ptr=c.inputs[keys.BATCH_PTR])
+                                     ptr=c.inputs[keys.BATCH_PTR], symmetric=eg.mirror_walk)
         static = dict(c.inputs)
         static[keys.EDGE_GRAPH] = c.edge_graph
         # library GEMM selection is timed during the warm-up only: TunableOp is a process-wide switch, so the state the
