@@ -165,7 +165,7 @@ def test_train_step_lowers_the_loss():
 
 
 # ---- two ranks on one card: DistributedDataParallel over gloo with device tensors -------------------------------------------
-def _ddp_worker(rank, world, port, out):
+def _ddp_worker(rank, world, port, out, with_forces=True):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
@@ -173,26 +173,30 @@ def _ddp_worker(rank, world, port, out):
     ddp = train.wrap_ddp(model, local_rank=0)
     host, dev = _batch(4, 100 + rank, torch.float64)             # every rank its own molecules
     tgt = {k: v.to(DEV) for k, v in _targets(host, 50 + rank, False).items()}
-    w = {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 3.0}
-    loss, _ = train.weighted_loss(ddp(dict(dev), True, False), tgt, w)
+    w = {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 3.0} if with_forces else {keys.TOTAL_ENERGY: 1.0}
+    loss, _ = train.weighted_loss(ddp(dict(dev), with_forces, False), tgt, w)
     loss.backward()
     out[rank] = {n: p.grad.cpu().numpy() for n, p in model.named_parameters()}
     torch.distributed.destroy_process_group()
 
 
-def test_ddp_two_ranks_average_the_gradients():
+@pytest.mark.parametrize("with_forces", [True, False])
+def test_ddp_two_ranks_average_the_gradients(with_forces):
+    """with_forces=False: an energy loss, i.e. the NATIVE training pass under DistributedDataParallel (its gradient hooks see the
+    parameter gradients the fused block functions return)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = mp.Manager().dict()
-    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, port, out, with_forces), nprocs=2, join=True)
     # the same two batches in this process, one after the other
     grads = []
     for rank in range(2):
         model = _model(torch.float64, **SMALL).train()
         host, dev = _batch(4, 100 + rank, torch.float64)
         tgt = {k: v.to(DEV) for k, v in _targets(host, 50 + rank, False).items()}
-        loss, _ = train.weighted_loss(model(dict(dev), True, False), tgt, {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 3.0})
+        w = {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 3.0} if with_forces else {keys.TOTAL_ENERGY: 1.0}
+        loss, _ = train.weighted_loss(model(dict(dev), with_forces, False), tgt, w)
         loss.backward()
         grads.append({n: p.grad.cpu().numpy() for n, p in model.named_parameters()})
     for n in grads[0]:
