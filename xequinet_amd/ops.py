@@ -377,6 +377,9 @@ class EdgeVectors(Function):
         ctx.graph_ptr = graph_ptr
         ctx.n_graphs = None if strain is None else strain.shape[0]
         ctx.save_for_backward(vec, dist)
+        # an output nobody differentiated through arrives as None in backward, not as a zero tensor: the fused blocks read `vec`
+        # only, and a materialised zero dL/ddist cost four elementwise launches per evaluation to add nothing
+        ctx.set_materialize_grads(False)
         return vec, dist
 
     @staticmethod
@@ -520,10 +523,12 @@ class SegmentSum(Function):
     """out[g] = sum_{i in [ptr[g], ptr[g+1])} src[i]  (scatter_sum over a sorted batch index)."""
 
     @staticmethod
-    def forward(ctx, src, ptr_):
+    def forward(ctx, src, ptr_, index=None):
+        """``index`` (optional): the sorted segment index per row (keys.BATCH) -- the reverse pass is then one gather."""
         require_hip(src, ptr_)
         src = src.contiguous()
         ptr_ = ptr_.to(torch.int64).contiguous()
+        ctx.index = index
         G = ptr_.numel() - 1
         width = 1
         for d in src.shape[1:]:
@@ -538,8 +543,10 @@ class SegmentSum(Function):
     @once_differentiable
     def backward(ctx, go):
         (ptr_,) = ctx.saved_tensors
+        if ctx.index is not None and ctx.index.shape[0] == ctx.n:
+            return go.index_select(0, ctx.index.long()), None, None   # (repeat_interleave: subtract, scan, search, gather)
         counts = ptr_[1:] - ptr_[:-1]
-        return torch.repeat_interleave(go, counts, dim=0, output_size=ctx.n), None
+        return torch.repeat_interleave(go, counts, dim=0, output_size=ctx.n), None, None
 
 
 def scatter_add(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:

@@ -20,7 +20,7 @@ def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: Opti
     if reduce not in ("sum", "add"):
         raise NotImplementedError(f"scatter: reduce={reduce!r} is not on the XPaiNN path")
     if ptr is not None:
-        return ops.SegmentSum.apply(src, ptr)
+        return ops.SegmentSum.apply(src, ptr, index if (index is not None and index.dim() == 1) else None)
     if src.requires_grad:
         raise NotImplementedError("scatter without ptr is forward-only; pass ptr for a differentiable segmented sum")
     if dim_size is None:
