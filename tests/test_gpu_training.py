@@ -108,6 +108,50 @@ def test_parameter_gradients_match_the_oracle(case):
     assert checked >= len(names) - 1 and checked >= 38     # 38 parameter tensors without layer norms, 54 with
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_native_training_pass_with_atoms_that_have_no_neighbour(dtype):
+    """A lone atom, a pair beyond the cutoff and an ordinary molecule in one batch: isolated nodes contribute no filter gradient and
+    their node-side gradients come out right (f64: against the oracle; f32, the matrix-core forms: against the differentiable form)."""
+    pos0, z0, ptr0 = syn.synth_qm9_batch(2, seed=21)
+    pos = np.concatenate([pos0, [[30.0, 0.0, 0.0]], [[60.0, 0.0, 0.0], [60.0, 8.0, 0.0]]])
+    z = np.concatenate([z0, [8], [1, 6]])
+    ptr = np.concatenate([ptr0, [ptr0[-1] + 1, ptr0[-1] + 3]])
+    ei = orc.radius_graph_canonical(pos, ptr, 5.0)
+    batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    host = {"pos": torch.tensor(pos, dtype=torch.float64), "atomic_numbers": torch.tensor(z.astype(np.int64)),
+            "edge_index": torch.tensor(ei), "batch": torch.tensor(batch), "ptr": torch.tensor(ptr)}
+    dev = {k: (v.to(dtype) if v.is_floating_point() else v).to(DEV) for k, v in host.items()}
+    tgt = _targets(host, 3, False)
+    w = {keys.TOTAL_ENERGY: 1.0}
+    model = _model(dtype, **SMALL).train()
+    data = dict(dev)
+    loss, _ = train.weighted_loss(model(data, False, False), {k: (v.to(dtype) if v.is_floating_point() else v).to(DEV) for k, v in tgt.items()}, w)
+    loss.backward()
+    from xequinet_amd.nn import training as tr
+    assert data[tr.PARAM_GRADS]
+    if dtype == torch.float64:
+        sd = {k: v.detach().cpu().double().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+        ref_loss, _ = train.weighted_loss(orc.XPaiNNOracle(sd, **SMALL)(host, False, False, training=True), tgt, w)
+        names = [n for n, _ in model.named_parameters()]
+        ref = dict(zip(names, torch.autograd.grad(ref_loss, [sd[n] for n in names], allow_unused=True)))
+        tol = 1e-8
+    else:
+        other = _model(dtype, **SMALL).train()
+        other.native_training = False
+        ref_loss, _ = train.weighted_loss(other(dict(dev), False, False), {k: (v.to(dtype) if v.is_floating_point() else v).to(DEV) for k, v in tgt.items()}, w)
+        ref_loss.backward()
+        ref = {n: p.grad for n, p in other.named_parameters()}
+        tol = 2e-4
+    for n, p in model.named_parameters():
+        g_ref = ref[n]
+        if g_ref is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, n
+            continue
+        g_ref = g_ref.reshape(p.shape).double().cpu()
+        err = (p.grad.double().cpu() - g_ref).abs().max().item()
+        assert err <= tol * max(1e-6, g_ref.abs().max().item()), f"{n}: {err:.2e} of {g_ref.abs().max().item():.2e}"
+
+
 def test_training_pass_gives_the_inference_numbers():
     """Same weights, same batch: train mode (differentiable form) against eval mode (the fused kernels), fp32."""
     model = _model(torch.float32, action_blocks=3)
