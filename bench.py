@@ -249,6 +249,19 @@ def main():
             out = gstep(p_k, z_k, ptr_k, batch=b_k)
             edge_total.add_(out["n_edges"])            # stays on the device; read once behind the timed region
             return None, out
+    elif cell is not None and len(ptr) == 2 and not args.replay_model_only:
+        # ONE periodic system: search + model as one captured graph over capacity-sized edge arrays (runtime.GraphedStepPBC); the
+        # capacity comes from one sized search in front (a quarter more room than that list needs), checked behind the timed region
+        n0 = int(transform(new_batch()).edge_index.shape[1])
+        gpbc = runtime.GraphedStepPBC(model, pos_d.shape[0], int(1.25 * n0) + 1024, compute_forces=True)
+        pbc_list = [bool(v) for v in pbc_d.reshape(-1, 3)[0].tolist()]
+        edge_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        turn = [0]
+
+        def step():
+            out = gpbc(pos_d, z_d, cell_d.reshape(-1, 3, 3)[0], pbc_list, check=False)
+            edge_total.add_(out["n_edges"])
+            return None, out
     else:
         # the same kernels in the same order as one HIP-graph launch (results bitwise those of the eager path); the
         # neighbour list stays eager: its edge count has to reach the host to size the edge arrays
@@ -258,7 +271,7 @@ def main():
             batch = transform(new_batch())
             return batch.edge_index.shape[1], graphed(batch.to_dict())
 
-    whole_step = not sharded and not args.eager and cell is None and not args.replay_model_only
+    whole_step = not sharded and not args.eager and (cell is None or len(ptr) == 2) and not args.replay_model_only
     try:
         # set-up, not a timed or counted step: the first evaluation times the library GEMM candidates (TunableOp) and
         # captures the HIP graph; the W warm-up steps and the K timed steps that follow are all plain steps
@@ -301,6 +314,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if whole_step:
         edges_done = int(edge_total.item())   # the device-side counts of the K timed steps
+        if cell is not None:
+            assert not gpbc.overflowed(), "the periodic list outgrew its capacity inside the timed region"
     eager_ms = native_ms = None
     if args.eager:
         kernel_ms = ops.KERNEL_TIMER.summary()       # HIP events recorded on the launch stream, in the timed region
@@ -428,7 +443,8 @@ def main():
                        "library_gemm_selection": ("no library GEMM on the f32 path since round 3 (every contraction is an xeq kernel)" if dtype == torch.float32 else
                                                   "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)"),
                        "launch": ("host launch per kernel" if args.eager else
-                                  f"neighbour list + model as ONE captured HIP graph over capacity-sized arrays, edge count on the device (runtime.GraphedStep; {max(1, args.vary_batch)} different draw(s) of the workload in turn)"
+                                  (f"neighbour list + model as ONE captured HIP graph over capacity-sized arrays, edge count on the device (runtime.GraphedStep; {max(1, args.vary_batch)} different draw(s) of the workload in turn)"
+                                   if cell is None else "periodic neighbour search + model as ONE captured HIP graph over capacity-sized edge arrays, edge count on the device (runtime.GraphedStepPBC)")
                                   if whole_step else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host"),
                        "ms_per_step_eager": "the same step with every kernel launched from the host through the Python modules, measured on rank 0 right after the timed region",
                        "ms_per_step_native_op": "the same step as ONE registered operator (xeq::xpainn_eval: kernels enqueued from C++, no capture): what a stream of batches with ever-new edge counts pays"},

@@ -56,6 +56,12 @@ int xeq_csr_rowptr(const int64_t* keys, int64_t n_keys, int64_t n_rows, int32_t*
 int64_t xeq_csr_by_key_workspace(int64_t n_keys, int64_t n_rows);
 int xeq_csr_by_key(const int64_t* keys, int64_t n_keys, int64_t n_rows, void* workspace, int64_t workspace_bytes,
                    int32_t* rowptr, int32_t* perm, void* stream);
+/* The same for a CAPACITY-sized key array whose first *n_valid entries are edges (n_valid: device pointer, e.g. the last entry of the
+ * center row pointer of a list written without reading its size back): the slots behind them sort to the end as row n_rows, so
+ * rowptr[n_rows] = *n_valid and no walk reaches them.  Workspace: xeq_csr_by_key_workspace(n_keys, n_rows + 1).  What lets a
+ * periodic neighbour list and its reverse view sit inside one captured HIP graph (runtime.GraphedStepPBC). */
+int xeq_csr_by_key_bounded(const int64_t* keys, int64_t n_keys, int64_t n_rows, const int32_t* n_valid, void* workspace,
+                           int64_t workspace_bytes, int32_t* rowptr, int32_t* perm, void* stream);
 
 /* Exclusive prefix sum of int32 counts[n] into out[n+1] (out[n] = total). */
 int xeq_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* out, void* stream);

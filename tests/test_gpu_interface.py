@@ -567,3 +567,64 @@ def test_lammps_model_native_operator_option():
         assert a._native is not None
         assert torch.equal(ra["energy"], rb["energy"]) and torch.equal(ra["forces"], rb["forces"])
     assert "_native" not in dict(a.named_modules()) and len(a.state_dict()) == len(b.state_dict())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_gromacs_model_whole_step_graph_follows_a_trajectory(dtype, monkeypatch):
+    """XPaiNNGMX(replay=True, whole_step=True): neighbour search + evaluation as ONE captured graph over capacity-sized edge arrays
+    (runtime.GraphedStepPBC).  A short trajectory (positions move, the edge count with them; the box breathes): every step's energy
+    equals the eager model's bit for bit and the forces to the unit factor's rounding, on one capture; a capacity that is too small
+    re-captures with more room and gives the same numbers; another image count per axis (a much smaller box) re-captures."""
+    from xequinet_amd.interface import XPaiNNGMX
+
+    if dtype == torch.float32:   # `auto` picks the family by the edge count it knows: the true one (eager) or the capacity (graph);
+        monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wq")   # near 4 096 edges they could differ, and with them the last bits
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    nm = FACTOR[("nm", "Angstrom")]
+    eager, _ = _twin(XPaiNNGMX, dtype)
+    fast, _ = _twin(XPaiNNGMX, dtype, replay=True, whole_step=True, tune_gemms=False)
+    fast.load_state_dict(eager.state_dict())
+    a = P._load("radius_graph_pbc_water192.npz")
+    _, z192, _, _ = syn.synth_water_box(4, seed=5)
+    pos512, z512, _, cell512 = syn.make_workload("water_512", seed=0)
+    pos81, z81, _, cell81 = syn.synth_water_box(3, seed=2)
+    rng = np.random.default_rng(8)
+    cases = [("water_192", a["pos"], z192, a["cell"][0], [True, True, True]),
+             ("water_512", pos512, z512, np.asarray(cell512).reshape(-1, 3, 3)[0], [True, True, True]),
+             ("81 atoms, box < 2 cutoffs", pos81, z81, np.asarray(cell81).reshape(-1, 3, 3)[0], [True, True, True]),
+             ("slab (open along z)", a["pos"], z192, a["cell"][0], [True, True, False])]
+    for name, pos0, z, cell0, pbc in cases:
+        z_t, pbc_t = P._t(np.asarray(z).astype(np.int64)), torch.tensor(pbc, device=DEV)
+        fast._step_graph = None
+        counts = []
+        for step in range(5):
+            pos = pos0 + 0.05 * step * rng.normal(size=pos0.shape)
+            cell = cell0 * (1.0 + 0.002 * step)                                   # the box breathes: same image counts, new tables
+            outs = []
+            for model in (eager, fast):
+                x = P._t((pos / nm).astype(npdt)).requires_grad_(True)
+                e = model(x, z_t, P._t((cell / nm).astype(npdt)), pbc_t)
+                (g,) = torch.autograd.grad(e.sum(), x)
+                outs.append((e.detach().clone(), g.clone()))
+            assert torch.equal(outs[0][0], outs[1][0]), (name, step)
+            scale = outs[0][1].abs().max().item()
+            assert (outs[0][1] - outs[1][1]).abs().max().item() <= 16 * torch.finfo(dtype).eps * scale, (name, step)   # (two unit factors applied in another order)
+            counts.append(int(fast._step_graph.outputs["n_edges"].item()))
+        assert fast._step_graph.captures == 1, name
+        assert len(set(counts)) > 1, (name, counts)                              # the edge count did move under the one graph
+        # a capacity far too small: cut lists are detected, the graph re-captured with more room, same numbers
+        from xequinet_amd.runtime import GraphedStepPBC
+        from xequinet_amd.interface.md_model import _Core
+        small = GraphedStepPBC(_Core(fast), len(pos0), 64, cutoff=fast.cutoff_radius)
+        fast._step_graph = small
+        x = P._t((pos / nm).astype(npdt)).requires_grad_(True)
+        e = fast(x, z_t, P._t((cell / nm).astype(npdt)), pbc_t)
+        assert torch.equal(e.detach(), outs[0][0]) and small.captures >= 2 and small.n_edges >= counts[-1], name
+    # a box of another size class: more images per axis -> another table, another graph
+    g = fast._step_graph
+    caps = g.captures
+    x = P._t((a["pos"] / nm).astype(npdt)).requires_grad_(True)
+    half = P._t((a["cell"][0] * 0.3 / nm).astype(npdt))
+    e1 = fast(x, P._t(np.asarray(z192).astype(np.int64)), half, torch.tensor([True, True, False], device=DEV))
+    e0 = eager(x, P._t(np.asarray(z192).astype(np.int64)), half, torch.tensor([True, True, False], device=DEV))
+    assert fast._step_graph.captures > caps and torch.equal(e0.detach(), e1.detach())

@@ -39,6 +39,14 @@ __global__ void k_sort_prepare(const int64_t* __restrict__ keys, int64_t n, int3
   k32[i] = (int32_t)keys[i];
   iota[i] = (int32_t)i;
 }
+// capacity form: only the first *n_valid keys are edges; the slots behind them sort to the end as row n_rows
+__global__ void k_sort_prepare_bounded(const int64_t* __restrict__ keys, int64_t n, const int32_t* __restrict__ n_valid, int32_t n_rows,
+                                       int32_t* __restrict__ k32, int32_t* __restrict__ iota) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  k32[i] = i < (int64_t)n_valid[0] ? (int32_t)keys[i] : n_rows;
+  iota[i] = (int32_t)i;
+}
 __global__ void k_csr_rowptr32(const int32_t* __restrict__ keys, int64_t n_keys, int64_t n_rows, int32_t* __restrict__ rowptr) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_rows) return;
@@ -345,10 +353,12 @@ __global__ void k_radius_graph_pbc_img(const T* __restrict__ pw, const int64_t* 
             T dx = sub_rn<T>(xi, bx), dy = sub_rn<T>(yi, by), dz = sub_rn<T>(zi, bz);
             T D = sqrt_<T>(add_rn<T>(add_rn<T>(mul_rn<T>(dx, dx), mul_rn<T>(dy, dy)), mul_rn<T>(dz, dz)));
             if ((D < rc) && (D > T(0.01))) {
-              edge_index[p] = i;
-              edge_index[n_edges + p] = j;
-              for (int ax = 0; ax < 3; ++ax)
-                cell_offsets[3 * p + ax] = cells[3 * c + ax] + (shift[3 * i + ax] - shift[3 * j + ax]);
+              if (p < n_edges) {   // (capacity form: a list that outgrew its buffers is cut, the row pointer still tells its size)
+                edge_index[p] = i;
+                edge_index[n_edges + p] = j;
+                for (int ax = 0; ax < 3; ++ax)
+                  cell_offsets[3 * p + ax] = cells[3 * c + ax] + (shift[3 * i + ax] - shift[3 * j + ax]);
+              }
               ++p;
             }
           }
@@ -744,6 +754,33 @@ int xeq_csr_by_key(const int64_t* keys, int64_t n_keys, int64_t n_rows, void* wo
   hipLaunchKernelGGL(k_csr_rowptr32, dim3((unsigned)((n_rows + 256) / 256)), dim3(256), 0, st, (const int32_t*)k_out, n_keys,
                      n_rows, rowptr);
   XEQ_CHECK_LAUNCH("xeq_csr_by_key");
+  return XEQ_OK;
+}
+
+int xeq_csr_by_key_bounded(const int64_t* keys, int64_t n_keys, int64_t n_rows, const int32_t* n_valid, void* workspace,
+                           int64_t workspace_bytes, int32_t* rowptr, int32_t* perm, void* stream) {
+  XEQ_CHECK_ARG(n_keys >= 0 && n_rows >= 0 && n_keys < (1ll << 31) && n_rows < (1ll << 31) - 1 && n_valid != nullptr, "xeq_csr_by_key_bounded: bad sizes");
+  const int64_t need = xeq_csr_by_key_workspace(n_keys, n_rows + 1);
+  XEQ_CHECK_ARG(workspace_bytes >= need, "xeq_csr_by_key_bounded: workspace of %lld bytes, need %lld (xeq_csr_by_key_workspace(n_keys, n_rows + 1))",
+                (long long)workspace_bytes, (long long)need);
+  hipStream_t st = (hipStream_t)stream;
+  char* w = (char*)workspace;
+  const size_t seg = align256((size_t)n_keys * 4);
+  int32_t* k_in = (int32_t*)w;
+  int32_t* k_out = (int32_t*)(w + seg);
+  int32_t* v_in = (int32_t*)(w + 2 * seg);
+  void* temp = w + 3 * seg;
+  size_t temp_bytes = (size_t)(workspace_bytes - 3 * (int64_t)seg);
+  if (n_keys > 0) {
+    hipLaunchKernelGGL(k_sort_prepare_bounded, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, st, keys, n_keys, n_valid,
+                       (int32_t)n_rows, k_in, v_in);
+    hipError_t e_ = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const int32_t*)k_in, k_out, (const int32_t*)v_in, perm,
+                                                       (int)n_keys, 0, sort_bits(n_rows + 1), st);
+    XEQ_CHECK_ARG(e_ == hipSuccess, "xeq_csr_by_key_bounded: radix sort failed: %s", hipGetErrorString(e_));
+  }
+  hipLaunchKernelGGL(k_csr_rowptr32, dim3((unsigned)((n_rows + 256) / 256)), dim3(256), 0, st, (const int32_t*)k_out, n_keys,
+                     n_rows, rowptr);
+  XEQ_CHECK_LAUNCH("xeq_csr_by_key_bounded");
   return XEQ_OK;
 }
 

@@ -89,16 +89,27 @@ def _host_cell_tables(cell: torch.Tensor, pbc_: List[bool], cutoff: float, with_
 
     -> reps [3] (ints), n_cells, dict of device tensors: cell_offsets [n_cells, 3], pbc_offsets [G, n_cells, 3], recip [G, 3, 3],
        thr [G, 3], cell_inv [G, 3, 3] (or None)."""
+    import numpy as np
+
+    c = np.ascontiguousarray(cell.detach().cpu().numpy())             # the round trip
+    reps, n_cells, flat_h = host_cell_tables_np(c, pbc_, cutoff, with_inverse, dtype_code_of=cell)
+    flat = torch.from_numpy(flat_h).to(cell.device)                   # one upload
+    return reps, n_cells, split_cell_tables(flat, c.shape[0], n_cells, with_inverse)
+
+
+def host_cell_tables_np(c, pbc_: List[bool], cutoff: float, with_inverse: bool, dtype_code_of: torch.Tensor):
+    """The host half of _host_cell_tables on a numpy copy of the cells [G, 3, 3]: -> (reps [3], n_cells, flat host array).  The
+    flat array is what is uploaded (split_cell_tables names its pieces); a caller that keeps the tables in static device memory
+    (runtime.GraphedStepPBC) copies it there when the cell changes."""
     import ctypes
 
     import numpy as np
 
     from ..lib import call, dtype_code, mul3
 
-    c = np.ascontiguousarray(cell.detach().cpu().numpy())             # the round trip
     dt = c.dtype
     G = c.shape[0]
-    code = dtype_code(cell)
+    code = dtype_code(dtype_code_of)
     reps_c = (ctypes.c_int32 * 3)()
     call("xeq_pbc_image_counts", code, ctypes.c_void_p(c.ctypes.data), G, mul3([int(v) for v in pbc_]), float(cutoff), reps_c)
     reps = [int(v) for v in reps_c]
@@ -108,7 +119,14 @@ def _host_cell_tables(cell: torch.Tensor, pbc_: List[bool], cutoff: float, with_
     call("xeq_pbc_tables_host", code, ctypes.c_void_p(c.ctypes.data), G, reps_c, float(cutoff), ctypes.c_void_p(flat_h.ctypes.data), n_tab)
     if with_inverse:
         flat_h[n_tab:] = np.linalg.inv(c).astype(dt).ravel()
-    flat = torch.from_numpy(flat_h).to(cell.device)                   # one upload
+    return reps, n_cells, flat_h
+
+
+def split_cell_tables(flat: torch.Tensor, G: int, n_cells: int, with_inverse: bool):
+    """Views of the uploaded table buffer: cell_offsets [n_cells, 3], pbc_offsets [G, n_cells, 3], recip [G, 3, 3], thr [G, 3],
+    cell_inv [G, 3, 3] (or None)."""
+    import numpy as np
+
     out, o = {}, 0
     for name, shape in (("cell_offsets", (n_cells, 3)), ("pbc_offsets", (G, n_cells, 3)), ("recip", (G, 3, 3)), ("thr", (G, 3)),
                         ("cell_inv", (G, 3, 3))):
@@ -118,7 +136,7 @@ def _host_cell_tables(cell: torch.Tensor, pbc_: List[bool], cutoff: float, with_
         n = int(np.prod(shape))
         out[name] = flat[o:o + n].view(shape)
         o += n
-    return reps, n_cells, out
+    return out
 
 
 def _wrap_on_device(pos: torch.Tensor, ptr: torch.Tensor, cell: torch.Tensor, cell_inv: torch.Tensor, pbc_: List[bool]):

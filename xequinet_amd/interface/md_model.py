@@ -132,9 +132,14 @@ class XPaiNNGMX(XPaiNN):
     evaluation (energy and forces) runs as one HIP-graph launch after the neighbour search, and the caller's
     ``backward`` receives those forces."""
 
-    def __init__(self, net_charge: Optional[int] = None, replay: bool = False, tune_gemms: bool = True, **kwargs) -> None:
+    def __init__(self, net_charge: Optional[int] = None, replay: bool = False, tune_gemms: bool = True, whole_step: bool = False,
+                 **kwargs) -> None:
+        """``replay``: the evaluation behind the search as one HIP-graph launch per (atoms, edges) signature.  ``whole_step`` (with
+        ``replay``): search AND evaluation as one graph over capacity-sized edge arrays (runtime.GraphedStepPBC): no edge count
+        read back in front of the model, no re-capture when the count moves -- what a trajectory wants."""
         kwargs.pop("unit_style", None)
         super().__init__(**kwargs)
+        self._whole_step, self._step_graph = bool(whole_step), None
         self.pos_unit_factor = unit_conversion("nm", _default_unit(keys.POSITIONS))
         self.energy_unit_factor = unit_conversion(_default_unit(keys.TOTAL_ENERGY), "kJ/mol")
         self.forces_unit_factor = unit_conversion(_default_unit(keys.FORCES), "kJ/(mol*nm)")
@@ -150,6 +155,16 @@ class XPaiNNGMX(XPaiNN):
             cell = box * self.pos_unit_factor
         if pbc is None:
             pbc = torch.zeros(3, dtype=torch.bool, device=positions.device)
+        if self._use_replay and self._whole_step and self.net_charge is None:
+            from ..runtime import GraphedStepPBC
+            if self._step_graph is None or self._step_graph.n_atoms != positions.shape[0]:
+                with torch.no_grad():     # one sized search for the capacity: a quarter more room than the first list needs
+                    ei0, _ = single_radius_graph(pos=positions, cell=cell, pbc=pbc, cutoff=self.cutoff_radius)
+                self._step_graph = GraphedStepPBC(_Core(self), positions.shape[0], int(1.25 * ei0.shape[1]) + 1024,
+                                                  cutoff=self.cutoff_radius, compute_forces=True)
+            out = self._step_graph(positions.detach(), atomic_numbers, cell, pbc)
+            energy = _EnergyOfPositions.apply(positions, out[keys.TOTAL_ENERGY].clone(), out[keys.FORCES].clone())
+            return energy * self.energy_unit_factor
         with torch.no_grad():
             edge_index, cell_offsets, rowptr = single_radius_graph(pos=positions, cell=cell, pbc=pbc, cutoff=self.cutoff_radius,
                                                                    return_rowptr=True)

@@ -30,6 +30,7 @@ _PROTOS = {
     "xeq_csr_rowptr": [_P, c_int64, c_int64, _P, _P],
     "xeq_csr_by_key_workspace": [c_int64, c_int64],
     "xeq_csr_by_key": [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P],
+    "xeq_csr_by_key_bounded": [_P, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P],
     "xeq_exclusive_scan_i32": [_P, c_int64, _P, _P],
     "xeq_exclusive_scan_i32_workspace": [c_int64],
     "xeq_exclusive_scan_i32_ws": [_P, c_int64, _P, _P, c_int64, _P],

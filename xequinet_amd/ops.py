@@ -69,18 +69,24 @@ def _exclusive_scan(deg: torch.Tensor, n: int, rowptr: torch.Tensor) -> None:
     call("xeq_exclusive_scan_i32_ws", ptr(deg), n, ptr(rowptr), ptr(work), int(nbytes), stream())
 
 
-def csr_by_key(keys: torch.Tensor, n_rows: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(rowptr[n_rows+1], perm[E]) of an unsorted int64 index row: stable radix sort + row pointer in one library call."""
+def csr_by_key(keys: torch.Tensor, n_rows: int, n_valid: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rowptr[n_rows+1], perm[E]) of an unsorted int64 index row: stable radix sort + row pointer in one library call.
+    ``n_valid`` (int32 device tensor, first element): the keys are a capacity-sized array whose first n_valid entries count; the
+    rest sorts behind every row (xeq_csr_by_key_bounded) -- no size is read back."""
     require_hip(keys)
     keys = keys.contiguous()
     n = keys.numel()
-    nbytes = lib.load().xeq_csr_by_key_workspace(n, n_rows)
+    nbytes = lib.load().xeq_csr_by_key_workspace(n, n_rows + (0 if n_valid is None else 1))
     if nbytes < 0:
         raise ValueError("csr_by_key: sizes out of range")
     work = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=keys.device)
     rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=keys.device)
     perm = torch.empty(n, dtype=torch.int32, device=keys.device)
-    call("xeq_csr_by_key", ptr(keys), n, n_rows, ptr(work), int(nbytes), ptr(rowptr), ptr(perm), stream())
+    if n_valid is None:
+        call("xeq_csr_by_key", ptr(keys), n, n_rows, ptr(work), int(nbytes), ptr(rowptr), ptr(perm), stream())
+    else:
+        assert n_valid.dtype == torch.int32 and n_valid.is_cuda and n_valid.numel() >= 1
+        call("xeq_csr_by_key_bounded", ptr(keys), n, n_rows, ptr(n_valid), ptr(work), int(nbytes), ptr(rowptr), ptr(perm), stream())
     return rowptr, perm
 
 
@@ -107,7 +113,7 @@ class EdgeGraph:
 
     def __init__(self, edge_index: torch.Tensor, n_nodes: int, center_sorted: Optional[bool] = None,
                  ptr: Optional[torch.Tensor] = None, c_rowptr: Optional[torch.Tensor] = None,
-                 symmetric: bool = False) -> None:
+                 symmetric: bool = False, capacity_form: bool = False) -> None:
         require_hip(edge_index)
         self.ptr = ptr          # graph boundaries [G+1] (keys.BATCH_PTR), when the caller knows them
         self._wm = None
@@ -136,6 +142,11 @@ class EdgeGraph:
             self.n_rowptr = self.c_rowptr
             self.n_perm = torch.empty(E, dtype=torch.int32, device=edge_index.device)
             call("xeq_reverse_edge_map", lib.ptr(edge_index), E, self.n_nodes, lib.ptr(self.c_rowptr), lib.ptr(self.n_perm), stream())
+        elif capacity_form:
+            # edge_index is a capacity-sized buffer, the edge count sits in c_rowptr[N] on the device (radius_graph_pbc_capacity):
+            # the neighbor-sorted view skips the slots behind it
+            assert center_sorted and c_rowptr is not None
+            self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes, n_valid=self.c_rowptr[self.n_nodes:])
         else:
             self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes)
 
@@ -349,6 +360,35 @@ def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):
     call("xeq_radius_graph_pbc_fill", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), ptr(cells), ptr(shift), n_cells,
          float(cutoff), ptr(rowptr), E, ptr(edge_index), ptr(cell_offsets), stream())
     return edge_index, cell_offsets, rowptr
+
+
+def radius_graph_pbc_capacity(pos_wrap, ptr_, img, cells, shift, cutoff, prune, edge_index: torch.Tensor, cell_offsets: torch.Tensor):
+    """The image-pruned periodic search of radius_graph_pbc_raw into caller-owned ``edge_index`` [2, capacity] / ``cell_offsets``
+    [capacity, 3] WITHOUT reading the edge count back: returns (row pointer [N + 1], count [1]) on the device; a count above the
+    capacity means the list was cut (the row pointer is cut with it) -- the caller checks it when it reads its results.  Same edges in the same
+    order as the sized form.  The pair sweep only (the bin grid's size is a host value)."""
+    require_hip(pos_wrap, ptr_, img, cells, shift, edge_index, cell_offsets)
+    recip, thr, reps = prune
+    pos_wrap, img, cells, shift = (t.contiguous() for t in (pos_wrap, img, cells, shift))
+    recip, thr = recip.to(pos_wrap.dtype).contiguous(), thr.to(pos_wrap.dtype).contiguous()
+    ptr_ = ptr_.to(torch.int64).contiguous()
+    assert edge_index.dim() == 2 and edge_index.shape[0] == 2 and edge_index.dtype == torch.int64 and edge_index.is_contiguous()
+    N, G, n_cells, cap = pos_wrap.shape[0], ptr_.numel() - 1, cells.shape[0], int(edge_index.shape[1])
+    assert cell_offsets.shape == (cap, 3) and cell_offsets.dtype == pos_wrap.dtype and cell_offsets.is_contiguous()
+    dev, dt = pos_wrap.device, dtype_code(pos_wrap)
+    deg = torch.empty(N, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    call("xeq_radius_graph_pbc_count_pruned", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), n_cells, float(cutoff), ptr(recip),
+         ptr(thr), mul3(reps), ptr(deg), stream())
+    _exclusive_scan(deg, N, rowptr)
+    # every kernel downstream walks by this row pointer: a list that outgrew the capacity must not lead them past the buffers.  The
+    # true count is kept aside for the caller's check, the row pointer is cut at the capacity (rows behind it become empty; the fill
+    # writes nothing at or past `cap`): the step's results are then wrong but every access stays in bounds
+    count = rowptr[N:].clone()
+    rowptr.clamp_(max=cap)
+    call("xeq_radius_graph_pbc_fill_pruned", dt, ptr(pos_wrap), ptr(ptr_), G, N, ptr(img), ptr(cells), ptr(shift), n_cells,
+         float(cutoff), ptr(recip), ptr(thr), mul3(reps), ptr(rowptr), cap, ptr(edge_index), ptr(cell_offsets), stream())
+    return rowptr, count
 
 
 # ------------------------------------------------------------------- edge geometry

@@ -291,6 +291,129 @@ class GraphedStep:
         return out
 
 
+class GraphedStepPBC:
+    """Neighbour search + model of ONE periodic (or open) system as one captured HIP graph: what an MD engine that hands over
+    positions and a box per step runs (the GROMACS-style model, interface/jit_model.py:183-216: ``single_radius_graph`` inside
+    ``forward``, then the evaluation).
+
+    ``GraphedModel`` behind an eager search pays, per step, the search's launches from the host, the read-back of the edge count
+    that sizes the edge arrays (the reference's ``nonzero``, data/radius_graph.py:124-125) and the sort of the neighbor view.
+    Here the edge arrays have a CAPACITY; the search (``ops.radius_graph_pbc_capacity``: image-pruned pair sweep, positions not
+    wrapped, as ``single_radius_graph`` does), the neighbor-sorted view (``xeq_csr_by_key_bounded``), walk plans, records and the
+    model are ONE graph, the edge count stays on the device.  What does reach the host per step is the box (9 numbers, compared
+    with the captured one: the cell-only tables are formed on the host, ``host_cell_tables_np``, and copied into static memory when
+    the box moved; another image count per axis re-captures) and -- with ``check=True``, the default -- the edge count next to the
+    results the caller reads anyway: a list that outgrew the capacity (``n_edges > capacity``: the kernels cut it, nothing is
+    written out of bounds) re-captures with half as much room again and re-runs the step.
+
+    Same kernels in the same order as the eager GROMACS-style model: bit-identical results (tests/test_gpu_interface.py)."""
+
+    GROWTH = 1.5
+
+    def __init__(self, model, n_atoms: int, edge_capacity: int, cutoff: Optional[float] = None,
+                 compute_forces: bool = True, warmup: int = 2) -> None:
+        """``model``: a BaseModel, or any callable ``(data, compute_forces, compute_virial) -> results`` that wraps one in ``.model``
+        (the MD front ends' unit-free core)."""
+        self.model = model
+        net = model if isinstance(model, torch.nn.Module) else model.model
+        self.n_atoms, self.n_edges = int(n_atoms), int(edge_capacity)
+        self.cutoff = float(net.cutoff_radius if cutoff is None else cutoff)
+        self.compute_forces = compute_forces
+        p = next(net.parameters())
+        self.device, self.dtype = p.device, p.dtype
+        N = self.n_atoms
+        self.pos = torch.zeros((N, 3), dtype=self.dtype, device=self.device)
+        self.shift = torch.zeros((N, 3), dtype=self.dtype, device=self.device)          # positions are not wrapped (jit_model.py:189-195)
+        self.z = torch.zeros(N, dtype=torch.int32, device=self.device)
+        self.cell = torch.zeros((1, 3, 3), dtype=self.dtype, device=self.device)
+        self.ptr = torch.tensor([0, N], dtype=torch.int64, device=self.device)
+        self.batch = torch.zeros(N, dtype=torch.int64, device=self.device)
+        self.warmup = warmup
+        self.captures = 0
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.outputs: Dict[str, torch.Tensor] = {}
+        self._cell_host = None
+        self._pbc = None
+        self._reps = None
+        self._tab_flat: Optional[torch.Tensor] = None
+        self._alloc_edges()
+
+    def _alloc_edges(self) -> None:
+        E = max(self.n_edges, 1)
+        self.edge_index = torch.zeros((2, E), dtype=torch.int64, device=self.device)    # zero = a valid node id in every unused slot
+        self.cell_offsets = torch.zeros((E, 3), dtype=self.dtype, device=self.device)
+
+    def _step(self) -> Dict[str, torch.Tensor]:
+        from .data.radius_graph import split_cell_tables
+
+        n_cells = (2 * self._reps[0] + 1) * (2 * self._reps[1] + 1) * (2 * self._reps[2] + 1)
+        tab = split_cell_tables(self._tab_flat, 1, n_cells, False)
+        rowptr, count = ops.radius_graph_pbc_capacity(self.pos, self.ptr, tab["pbc_offsets"], tab["cell_offsets"], self.shift, self.cutoff,
+                                                      (tab["recip"], tab["thr"], self._reps), self.edge_index, self.cell_offsets)
+        eg = ops.EdgeGraph(self.edge_index, self.n_atoms, center_sorted=True, ptr=self.ptr, c_rowptr=rowptr, capacity_form=True)
+        data = {keys.POSITIONS: self.pos.detach(), keys.ATOMIC_NUMBERS: self.z, keys.CELL: self.cell, keys.EDGE_INDEX: self.edge_index,
+                keys.CELL_OFFSETS: self.cell_offsets, keys.BATCH: self.batch, keys.BATCH_PTR: self.ptr, keys.EDGE_GRAPH: eg}
+        with torch.enable_grad():
+            out = self.model(data, compute_forces=self.compute_forces, compute_virial=False)
+        res = {k: v.detach() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        res["n_edges"] = count                              # device-side edge count of the FULL list (above the capacity: see check)
+        return res
+
+    def _load_cell(self, cell: torch.Tensor, pbc) -> None:
+        """Box and periodicity of this step: the tables follow the box; a new image count or periodicity drops the graph."""
+        import numpy as np
+
+        from .data.radius_graph import host_cell_tables_np
+
+        c = np.ascontiguousarray(cell.detach().to(self.dtype).reshape(1, 3, 3).cpu().numpy())     # the step's one small round trip
+        pbc_ = [bool(v) for v in (pbc.detach().cpu().tolist() if isinstance(pbc, torch.Tensor) else pbc)]
+        if self._cell_host is not None and pbc_ == self._pbc and np.array_equal(c, self._cell_host):
+            return
+        reps, n_cells, flat_h = host_cell_tables_np(c, pbc_, self.cutoff, False, dtype_code_of=self.cell)
+        flat = torch.from_numpy(flat_h)
+        if self._tab_flat is None or reps != self._reps or flat.numel() != self._tab_flat.numel():
+            self._tab_flat = flat.to(self.device)
+            self.graph = None                                # another image table: another graph
+        else:
+            self._tab_flat.copy_(flat, non_blocking=False)
+        self._reps, self._pbc, self._cell_host = reps, pbc_, c
+        self.cell.copy_(torch.from_numpy(c))
+
+    def _run(self) -> None:
+        if self.graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self._step()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.outputs = self._step()
+            self.captures += 1
+        self.graph.replay()
+
+    def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, cell: torch.Tensor, pbc, check: bool = True) -> Dict[str, torch.Tensor]:
+        """-> {energy [1], atomic_energies [n], forces [n, 3], n_edges [1] (device)}: the graph's output buffers, overwritten by the
+        next call.  ``check=False`` leaves the capacity check to the caller (``overflowed()``), e.g. behind a timed loop."""
+        if pos.shape[0] != self.n_atoms:
+            raise ValueError(f"GraphedStepPBC: {pos.shape[0]} atoms, captured for {self.n_atoms}")
+        self._load_cell(cell, pbc)
+        ops.copy_many([(self.pos, pos.detach().to(self.dtype)), (self.z, atomic_numbers.to(torch.int32))])
+        self._run()
+        if check:
+            while self.overflowed():
+                self.n_edges = int(self.GROWTH * max(self.n_edges, int(self.outputs["n_edges"].item()))) + 64
+                self._alloc_edges()
+                self.graph = None
+                self._run()
+        return dict(self.outputs)
+
+    def overflowed(self) -> bool:
+        """The last step's list did not fit the edge capacity (reads the device-side count: a synchronisation)."""
+        return int(self.outputs["n_edges"].item()) > self.n_edges
+
+
 # ----------------------------------------------------------------------------------------------- chunked evaluation
 WM_MAX_EDGES_PER_CHUNK = 8_000_000   # well inside the 14.9 M-edge bound of the matrix-core message kernels
 
