@@ -53,8 +53,9 @@ def run(name, pos, z, cell=None):
         out["lmp scripted (one registered operator)"] = timeit(sstep)
     except Exception as err:
         out["lmp scripted: " + str(err)[:60]] = float("nan")
-    for tag, replay in (("gmx eager (search + energy + autograd)", False), ("gmx replay", True)):
-        g = mk(XPaiNNGMX, replay=replay)
+    for tag, replay, whole in (("gmx eager (search + energy + autograd)", False, False), ("gmx replay", True, False),
+                               ("gmx whole-step graph (search inside the graph)", True, True)):
+        g = mk(XPaiNNGMX, replay=replay, whole_step=whole)
         def gstep():
             x = (p / 10).requires_grad_(True)
             e = g(x, zz, None if c is None else c / 10, pbc)
