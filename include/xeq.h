@@ -349,6 +349,16 @@ int xeq_message_param_grad_mc(int64_t n_nodes, int64_t n_edges, const int64_t* c
  * xhat_layout / grad_x_layout arguments): the gradient kernel's gathers of dL/dx_out rows are contiguous over the channels there. */
 int xeq_to_bt(const void* x, int64_t n_nodes, const int32_t mul[3], void* out, void* stream);
 
+/* Launch policy, stated ONCE for every front (the Python modules' ops.select_message_impl / ops._wq_edges_per_stream and the
+ * registered operator xeq::xpainn_eval call these): the kernel family `auto` takes for a configuration and these sizes, and the
+ * stream length of a wq walk plan (n_ranges = ceil(E / (2 x edges_per_stream))). */
+#define XEQ_FAMILY_WQ 0
+#define XEQ_FAMILY_SB 1
+#define XEQ_FAMILY_WM 2
+#define XEQ_FAMILY_GENERIC 3
+int xeq_message_auto_family(int dtype, int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]);
+int xeq_message_wq_edges_per_stream(int64_t n_nodes, int64_t n_edges);
+
 /* "Scalar broadcast" form of the fused message (default path, f32 and f64).  The per-edge quantities
  * every channel shares -- f*rho_k(d), f, Y_lm, and their d/dd companions -- are evaluated once per
  * model evaluation into 4*(roundup(B,4)+12)-byte records (xeq_edge_basis), shared by all message

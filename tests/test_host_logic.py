@@ -327,3 +327,32 @@ def test_host_cell_tables_match_the_device_operation_forms():
                 assert float((got - want).abs().max()) <= tol * scale, name
     _, _, tab = rg._host_cell_tables(cell, [True, True, True], 5.0, with_inverse=False)
     assert tab["cell_inv"] is None
+
+
+def test_launch_policy_is_stated_once_in_the_c_abi():
+    """xeq_message_auto_family / xeq_message_wq_edges_per_stream: host functions of the C ABI that the Python modules
+    (ops.select_message_impl, ops._wq_edges_per_stream) and the registered operator both call -- no second copy of the rule."""
+    import ctypes
+
+    from xequinet_amd import lib
+
+    L = lib.load()
+    mul = (ctypes.c_int32 * 3)(128, 64, 32)
+    fam = lambda dt, n, e, b=20: int(L.xeq_message_auto_family(dt, n, e, b, 128, mul))
+    WQ, SB, WM, GENERIC = 0, 1, 2, 3
+    assert fam(lib.XEQ_F32, 21, 360) == SB                    # one small molecule: launch-bound, no walk plan
+    assert fam(lib.XEQ_F32, 18609, 311994) == WQ              # QM9-1024
+    assert fam(lib.XEQ_F32, 1536, 82996) == WQ                # dense periodic box (round 3: wq wins there too)
+    assert fam(lib.XEQ_F64, 18609, 311994) == SB              # f64
+    assert fam(lib.XEQ_F32, 18609, 311994, 31) == WM          # num_basis beyond the wq form
+    assert fam(lib.XEQ_F32, 3_000_000, 150_000_000) == GENERIC   # beyond every 32-bit offset
+    assert fam(lib.XEQ_F32, 2_500_000, 40_000_000) in (SB, GENERIC)
+    eps = lambda n, e: int(L.xeq_message_wq_edges_per_stream(n, e))
+    assert eps(18609, 311994) == 64 and eps(192, 10390) == 54 and eps(21, 360) == 17 and eps(10, 20) == 16
+    import inspect
+
+    from xequinet_amd import ops
+    src = inspect.getsource(ops.select_message_impl) + inspect.getsource(ops._wq_edges_per_stream)
+    assert "xeq_message_auto_family" in src and "xeq_message_wq_edges_per_stream" in src
+    cpp = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xequinet_amd", "csrc", "xeq_torch.cpp")).read()
+    assert "xeq_message_auto_family" in cpp and "xeq_message_wq_edges_per_stream" in cpp and "E < 4096" not in cpp

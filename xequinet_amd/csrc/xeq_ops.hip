@@ -360,6 +360,32 @@ using namespace xeq;
 
 extern "C" {
 
+/* ---- launch policy shared by every front (Python modules, registered operator): ONE statement of the rules ---------------- */
+int xeq_message_auto_family(int dtype, int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
+  // tiny graphs are launch-bound and the scalar-broadcast kernels need no walk plan; everything else that fits takes the wave / quad
+  // matrix-core kernels (since the split-bf16 filter also the dense periodic boxes), then their predecessor wm (num_basis 24..31),
+  // then sb (f64, other channel layouts), then the generic 64-bit form
+  const bool f32 = dtype == XEQ_F32;
+  const bool sb_fits = xeq_message_sb_fits(n_nodes, n_edges, num_basis, node_dim, mul) != 0;
+  if (n_edges < 4096 && sb_fits) return XEQ_FAMILY_SB;
+  if (f32 && xeq_message_wq_fits(n_nodes, n_edges, num_basis, node_dim, mul)) return XEQ_FAMILY_WQ;
+  if (f32 && xeq_message_wm_fits(n_nodes, n_edges, num_basis, node_dim, mul)) return XEQ_FAMILY_WM;
+  if (sb_fits) return XEQ_FAMILY_SB;
+  return XEQ_FAMILY_GENERIC;
+}
+
+int xeq_message_wq_edges_per_stream(int64_t n_nodes, int64_t n_edges) {
+  // a step (eight half-wave streams) should gather from few enough nodes for its window to fit LDS: 64 edges per stream is ~30 owner
+  // nodes; small systems get shorter streams so that the launch still spreads over the chip, never below the mean segment length
+  const double per_node = (double)n_edges / (double)(n_nodes > 0 ? n_nodes : 1);
+  double v = per_node > 16.0 ? per_node : 16.0;
+  const double spread = (double)n_edges / 1500.0;
+  if (spread > v) v = spread;
+  if (v > 64.0) v = 64.0;
+  return (int)v;
+}
+
+
 int xeq_edge_vectors_fwd(int dtype, const void* pos, const int64_t* edge_index, int64_t n_edges,
                          const void* cell, const void* cell_offsets, const int64_t* batch, void* vec, void* dist,
                          void* stream) {

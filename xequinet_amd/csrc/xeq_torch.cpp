@@ -298,13 +298,8 @@ Graph build_graph(const Tensor& edge_index, int64_t n_nodes, bool center_sorted,
   return g;
 }
 
-int wq_edges_per_stream(int64_t E, int64_t N) {   // ops._wq_edges_per_stream
-  const double per_node = (double)E / std::max<int64_t>(1, N);
-  return (int)std::min(64.0, std::max({16.0, per_node, (double)E / 1500.0}));
-}
-
 void build_wq_plan(const Graph& g, bool reverse, WqPlan& p) {
-  const int eps = wq_edges_per_stream(g.E, g.N);
+  const int eps = xeq_message_wq_edges_per_stream(g.N, g.E);   // (the C ABI states the rule; ops._wq_edges_per_stream asks it too)
   p.n_ranges = (int)std::max<int64_t>(1, (g.E + 2 * eps - 1) / (2 * eps));
   p.pcap = xeq_message_wq_pcap(g.N, g.E);
   const int waves = xeq_message_wq_waves();
@@ -494,10 +489,11 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
 
   // ---- which message kernels (ops.select_message_impl, without the wm / generic forms)
   int impl;
-  const bool prefers_sb = E < 4096;   // ops.prefers_sb: tiny graphs (launch-bound; sb needs no walk plan)
-  if (prefers_sb && xeq_message_sb_fits(N, E, hy.B, F, mul)) impl = 1;
-  else if (dt == XEQ_F32 && xeq_message_wq_fits(N, E, hy.B, F, mul)) impl = 0;
-  else if (xeq_message_sb_fits(N, E, hy.B, F, mul)) impl = 1;
+  // the family rule is the C ABI's (xeq_message_auto_family: the Python modules ask the same function); this operator carries the
+  // wq and sb sequences
+  const int family = xeq_message_auto_family(dt, N, E, hy.B, F, mul);
+  if (family == XEQ_FAMILY_WQ) impl = 0;
+  else if (family == XEQ_FAMILY_SB || (family == XEQ_FAMILY_WM && xeq_message_sb_fits(N, E, hy.B, F, mul))) impl = 1;   // (no wm sequence here)
   else TORCH_CHECK(false, "xeq::xpainn_eval: this configuration / size needs the generic message kernels: use the Python modules");
   if (impl == 0) {
     build_wq_plan(g, false, g.fwd);

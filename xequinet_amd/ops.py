@@ -632,11 +632,20 @@ def _message_impl() -> str:
     return impl
 
 
+def dtype_code_of(dtype) -> int:
+    if dtype == torch.float32:
+        return lib.XEQ_F32
+    if dtype == torch.float64:
+        return lib.XEQ_F64
+    raise TypeError(f"xequinet_amd supports float32/float64, got {dtype}")
+
+
 def prefers_sb(n_nodes: int, n_edges: int) -> bool:
     """Where the scalar-broadcast kernels beat the matrix-core ones (measured, MI355X): graphs of a few thousand edges at most (one
     small molecule: the step is launch-bound and sb needs no walk plan; aspirin replay 0.80 against 0.86 ms).  Round 2 also sent
     dense neighbourhoods (>= 40 edges per atom) here; with the split-bf16 filter of round 3 the wq kernels win there too (water-512:
-    message kernels 0.49 against 0.74 ms per evaluation, step 1.42 against 1.60 ms).  csrc/xeq_torch.cpp applies the same rule."""
+    message kernels 0.49 against 0.74 ms per evaluation, step 1.42 against 1.60 ms).  The rule is stated once, in the C ABI
+    (``xeq_message_auto_family``: every front calls it); this is its first clause for callers that only want to know."""
     return n_edges < 4096
 
 
@@ -655,16 +664,9 @@ def select_message_impl(dtype, n_nodes: int, n_edges: int, num_basis: int, node_
             raise RuntimeError("XEQ_MESSAGE_IMPL=wq: this configuration does not fit the matrix-core kernels "
                                "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 23)")
         return impl
-    L = lib.load()
-    if prefers_sb(n_nodes, n_edges) and L.xeq_message_sb_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
-        return "sb"
-    if dtype == torch.float32 and L.xeq_message_wq_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
-        return "wq"
-    if dtype == torch.float32 and L.xeq_message_wm_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
-        return "wm"
-    if L.xeq_message_sb_fits(int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul)):
-        return "sb"
-    return "generic"
+    # the rule itself lives in the C ABI (xeq_message_auto_family), shared with the registered operator
+    code = lib.load().xeq_message_auto_family(dtype_code_of(dtype), int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul))
+    return ("wq", "sb", "wm", "generic")[int(code)]
 
 
 def _wm_edges_per_stream(n_edges: int, n_nodes: int) -> int:
@@ -692,8 +694,7 @@ def _wq_edges_per_stream(n_edges: int, n_nodes: int) -> int:
     env = os.environ.get("XEQ_WQ_EDGES_PER_STREAM")
     if env:
         return max(16, int(env))
-    per_node = n_edges / max(1, n_nodes)
-    return int(min(64, max(16, per_node, n_edges / 1500)))
+    return int(lib.load().xeq_message_wq_edges_per_stream(int(n_nodes), int(n_edges)))   # (the C ABI states the rule)
 
 
 def wm_supported(dtype, num_basis, node_dim, mul) -> bool:
