@@ -75,7 +75,15 @@ constexpr int WQ_WAVES = XEQ_WQ_WAVES;     // waves per workgroup: they share th
 struct QuadCount {
   const int32_t* rowptr;
   int64_t n;
-  __host__ __device__ int32_t operator()(int64_t i) const { return i < n ? (rowptr[i + 1] - rowptr[i] + 3) >> 2 : 0; }
+  // a node without an edge still gets ONE quad (four padding slots: zero records, gathering its own rows): it then takes the
+  // ordinary path -- its running sums are exact zeros, its store writes s_out = s_in / zero gradients -- and the plan spreads such
+  // nodes over the ranges by their quads.  (They used to be picked up range by range in a serial loop of one wave: the 400 padding
+  // atoms of a capacity-sized batch sat behind the LAST range and cost 5 % of a step, 2 000 of them doubled it.)
+  __host__ __device__ int32_t operator()(int64_t i) const {
+    if (i >= n) return 0;
+    const int32_t deg = rowptr[i + 1] - rowptr[i];
+    return deg > 0 ? (deg + 3) >> 2 : 1;
+  }
 };
 
 // one thread per slot of the walk order: its padded position, the pads behind a segment's last slot, the quad records
@@ -84,7 +92,19 @@ __global__ void k_wq_fill(int64_t E, int64_t n_nodes, const int32_t* __restrict_
                           const int32_t* __restrict__ qptr, int32_t* __restrict__ pgath, int32_t* __restrict__ peid,
                           uint32_t* __restrict__ qinfo) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= E || s >= rowptr[n_nodes]) return;   // E may be a capacity: the walk ends at rowptr[N] (device-side edge count)
+  if (s >= E) {   // threads E .. E + N - 1: the lone quad of a node without an edge
+    const int64_t n = s - E;
+    if (n < n_nodes && rowptr[n] == rowptr[n + 1]) {
+      const int64_t q0 = qptr[n];
+      for (int i = 0; i < 4; ++i) {
+        pgath[4 * q0 + i] = (int32_t)n;
+        peid[4 * q0 + i] = -1;
+      }
+      qinfo[q0] = (uint32_t)n | WQ_FIRST | WQ_LAST;
+    }
+    return;
+  }
+  if (s >= rowptr[n_nodes]) return;   // E may be a capacity: the walk ends at rowptr[N] (device-side edge count)
   const int32_t eid = perm ? perm[s] : (int32_t)s;
   const int64_t n = owner[eid];
   const int32_t r0 = rowptr[n], deg = rowptr[n + 1] - r0, k = (int32_t)(s - r0), q0 = qptr[n], nq = (deg + 3) >> 2;
@@ -519,19 +539,9 @@ __device__ __forceinline__ WqStreams wq_streams(const WqArgs& a, int range) {
   return s;
 }
 // owner nodes of the wave's two streams that have no edge: fn(node) is called by all 64 lanes
+// (nodes without an edge own a quad of padding slots since round 3 -- QuadCount above -- and take the ordinary path; nothing to do here)
 template <typename Fn>
-__device__ __forceinline__ void wq_for_isolated(const WqArgs& a, int range, int lane, Fn fn) {
-  const int n0 = a.sn[2 * range], n2 = a.sn[2 * range + 2];
-  for (int base = n0; base < n2; base += 64) {
-    const int n = base + lane;
-    unsigned long long mask = __ballot(n < n2 && a.rowptr[n] == a.rowptr[n + 1]);
-    while (mask) {
-      const int m = base + (__ffsll((long long)mask) - 1);
-      mask &= mask - 1;
-      fn(m);
-    }
-  }
-}
+__device__ __forceinline__ void wq_for_isolated(const WqArgs&, int, int, Fn) {}
 
 // scheduling fence between the passes of a tile (dev switch: -D'XEQ_WQ_SB()=' compiles them out)
 #ifndef XEQ_WQ_SB
@@ -1351,11 +1361,8 @@ static bool wq_supported(int num_basis, int node_dim, const int32_t mul[3]) {
   return num_basis >= 1 && num_basis <= 23 && mul[0] == node_dim && mul[0] > 0 && mul[0] % 32 == 0 && mul[1] >= 0 &&
          mul[1] % 32 == 0 && mul[2] >= 0 && mul[2] % 32 == 0;
 }
-// padded slots: at most E + 3 per node that has an edge; the capacity every buffer of a plan is sized for
-static int64_t wq_pcap(int64_t n_nodes, int64_t n_edges) {
-  const int64_t with_edges = n_nodes < n_edges ? n_nodes : n_edges;
-  return (n_edges + 3 * with_edges + 3) / 4 * 4;
-}
+// padded slots: at most deg + 3 per node that has an edge, four per node that has none; the capacity every buffer of a plan is sized for
+static int64_t wq_pcap(int64_t n_nodes, int64_t n_edges) { return (n_edges + 4 * n_nodes + 3) / 4 * 4; }
 // 32-bit byte offsets: rows of h (n_nodes * H * 4) and records (pcap * 128)
 static bool wq_fits(int64_t n_nodes, int64_t n_edges, int node_dim, const int32_t mul[3]) {
   const int64_t H = node_dim + 2 * (int64_t)(mul[0] + mul[1] + mul[2]);
@@ -1481,9 +1488,9 @@ int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_
     xeq::set_error("xeq_message_wq_plan: scan failed");
     return XEQ_ERR_LAUNCH;
   }
-  if (n_edges > 0) {
-    hipLaunchKernelGGL(k_wq_fill, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_edges, n_nodes, rowptr,
-                       perm, owner, gather, (const int32_t*)qptr, pgath, peid, (uint32_t*)qinfo);
+  if (n_edges + n_nodes > 0) {
+    hipLaunchKernelGGL(k_wq_fill, dim3((unsigned)((n_edges + n_nodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_edges, n_nodes,
+                       rowptr, perm, owner, gather, (const int32_t*)qptr, pgath, peid, (uint32_t*)qinfo);
     XEQ_CHECK_LAUNCH("xeq_message_wq_plan (fill)");
   }
   const int n = 2 * n_ranges + 1;
@@ -1504,7 +1511,7 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_edge_basis_wq: rbf kernel %d is not implemented", rbf_kind);
   XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
-  if (n_edges == 0) return XEQ_OK;
+  if (n_edges == 0 && n_nodes == 0) return XEQ_OK;   // (no edge at all: the nodes' lone quads still need their zero records)
   const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * 6;   // six threads per record
   XEQ_CHECK_ARG(pcap * WQ_REC < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
