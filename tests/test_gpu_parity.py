@@ -404,11 +404,23 @@ def test_radial_and_scatter_ops():
 
 
 # ------------------------------------------------------------------- fused message
-def _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, dtype, shuffle, seed=0, with_ptr=False, n_mol=6):
+def _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, dtype, shuffle, seed=0, with_ptr=False, n_mol=6, lone_atoms=0):
     from xequinet_amd import ops
 
     rng = np.random.default_rng(seed)
     pos, z, ptr = syn.synth_qm9_batch(n_mol, seed=seed + 10)
+    if lone_atoms:   # atoms without any neighbour, as graphs of their own, in runs between the molecules and behind the last one
+        where = np.sort(rng.integers(0, n_mol + 1, size=lone_atoms))
+        chunks, cuts, far = [], [0], 0
+        for g in range(n_mol + 1):
+            for _ in range(int((where == g).sum())):
+                far += 1
+                chunks.append(np.array([[1000.0 * far, -500.0, 250.0]]))
+                cuts.append(cuts[-1] + 1)
+            if g < n_mol:
+                chunks.append(pos[ptr[g]:ptr[g + 1]])
+                cuts.append(cuts[-1] + int(ptr[g + 1] - ptr[g]))
+        pos, ptr = np.concatenate(chunks), np.array(cuts, dtype=np.int64)
     rc = 4.0
     ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, rc)
     if shuffle:
@@ -494,6 +506,22 @@ def test_fused_message_parameter_gradients(irreps, node_dim, B, rbf_kind, cutoff
         a, b = a.detach().cpu().double().numpy(), b.detach().numpy()
         assert a.shape == b.shape, name
         np.testing.assert_allclose(a, b, rtol=tol, atol=tol * max(1.0, np.abs(b).max()), err_msg=name)
+
+
+@pytest.mark.parametrize("impl", ["wq", "auto"])
+def test_fused_message_with_many_atoms_that_have_no_neighbour(impl, monkeypatch):
+    """300 lone atoms scattered through (and behind) 40 molecules: in the wq walk plan each owns one quad of padding slots and takes
+    the ordinary path (residual rows kept, zero gradients); every output and gradient, parameter gradients included, against the
+    oracle, and the lone atoms' rows bit for bit."""
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", impl)
+    got, want = _message_case("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", torch.float32, False, n_mol=40, lone_atoms=300)
+    names = ["s_out", "x_out", "grad_h", "grad_xhat", "grad_vec", "grad_s", "grad_x", "grad_W", "grad_b", "grad_p0"]
+    for name, a, b in zip(names, got, want):
+        a, b = a.detach().cpu().double().numpy(), b.detach().numpy()
+        np.testing.assert_allclose(a, b, rtol=3e-5, atol=3e-5 * max(1.0, np.abs(b).max()), err_msg=name)
+    lone = np.abs(want[2].numpy()).sum(1) == 0       # nobody's neighbour: the oracle's dL/dh row is exactly zero
+    assert lone.sum() >= 300
+    assert not got[2].detach().cpu().numpy()[lone].any() and not got[3].detach().cpu().numpy()[lone].any()
 
 
 WM_CASES = [
