@@ -73,6 +73,23 @@ def test_plan_chunks_covers_and_respects_cap():
     assert xdist.plan_chunks(np.array([0]), 100) == [(0, 0)]                   # empty shard: one empty chunk
 
 
+def test_plan_chunks_is_balanced_and_cheap_at_65k_molecules():
+    """The chunk planner runs in front of EVERY chunked evaluation (runtime.evaluate_in_chunks): 65 536 molecules must cost about a
+    millisecond, not a Python loop per molecule (that was 90 ms of a 240 ms step), and the ranges come out equal to a few percent."""
+    import time
+
+    _, _, ptr = syn.synth_qm9_batch(4096, seed=9)
+    ptr = np.concatenate([ptr[:-1] + k * ptr[-1] for k in range(16)] + [[16 * ptr[-1]]])
+    n = np.diff(ptr)
+    bound = n * (n - 1)
+    xdist.plan_chunks(ptr, 8_000_000)
+    t0 = time.perf_counter()
+    chunks = xdist.plan_chunks(ptr, 8_000_000)
+    assert time.perf_counter() - t0 < 0.05
+    sizes = [int(bound[a:b].sum()) for a, b in chunks]
+    assert len(chunks) == -(-int(bound.sum()) // 8_000_000) and max(sizes) <= 8_000_000 and max(sizes) - min(sizes) <= 0.02 * max(sizes)
+
+
 def _tiny_oracle():
     from xequinet_amd.nn import resolve_model
 
