@@ -838,7 +838,7 @@ __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_en
     WQ_STAMP(1);   // window staged
     __syncthreads();
     WQ_STAMP(2);   // barrier behind the staging
-    const int range = step * WQ_WAVES + (threadIdx.x >> 6);
+    const int range = step * WQ_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: the stream bounds become scalar loads)
     if (range < a.n_ranges) {
       if (use_win) wq_fwd_body<NM, KS, true, XZ>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, w0, st_, last_);
       else wq_fwd_body<NM, KS, false, XZ>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, 0, st_, last_);
@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int s_beg, int s_en
     WQ_STAMP(1);
     __syncthreads();
     WQ_STAMP(2);
-    const int range = step * WQ_WAVES + (threadIdx.x >> 6);
+    const int range = step * WQ_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: the stream bounds become scalar loads)
     if (range < a.n_ranges) {
       if (use_win) wq_bwd_body<NM, KS, true, FIRST>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, w0, st_, last_);
       else wq_bwd_body<NM, KS, false, FIRST>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, 0, st_, last_);
