@@ -345,6 +345,14 @@ int xeq_param_basis(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_k
 int xeq_message_param_grad_mc(int64_t n_nodes, int64_t n_edges, const int64_t* center, const int64_t* nbr, const void* tab, const void* h,
                               const void* xhat, const void* grad_s, const void* grad_x, int rbf_kind, int num_basis, int node_dim,
                               const int32_t mul[3], int xhat_layout, int grad_x_layout, int n_parts, void* parts, void* stream);
+/* Affine-parameter gradients of a block's two norms for a TRAINING pass (nn.LayerNorm weight / bias on the scalars,
+ * EquivariantLayerNorm affine_weight / affine_bias, nn/o3layer.py:145-171), f32: from the block inputs s [n, F], x [n, D], the
+ * statistics stats [n, 4] the forward norm kernel wrote, dL/dshat rows (stride ld_gs) and dL/dxhat in the BT layout.
+ * parts[n_chunks][2 F + C + mul0] = [d ln_w | d ln_b | d eq_w | d eq_b] per row chunk (n_chunks = xeq_norm_param_grad_chunks(n));
+ * the caller sums the chunks (fixed order). */
+int xeq_norm_param_grad_chunks(int64_t n_nodes);
+int xeq_norm_param_grad(const void* s, const void* x, const void* stats, const void* g_shat, int64_t ld_gs, const void* g_xhat_bt,
+                        int64_t n_nodes, int node_dim, const int32_t mul[3], int n_chunks, void* parts, void* stream);
 /* f32 x[n_nodes, D] in the e3nn mul_ir layout -> the internal BT layout (per l a row-major [N (2l+1), mul_l] matrix; layout 1 of the
  * xhat_layout / grad_x_layout arguments): the gradient kernel's gathers of dL/dx_out rows are contiguous over the channels there. */
 int xeq_to_bt(const void* x, int64_t n_nodes, const int32_t mul[3], void* out, void* stream);

@@ -95,6 +95,54 @@ __global__ void k_to_bt(const float* __restrict__ x, int64_t N, Irreps ir, float
   out[N * base + (n * (2 * l + 1) + m) * ir.mul[l] + up] = x[t];
 }
 
+// Affine-parameter gradients of the two norms of a block (nn.LayerNorm on the scalars, EquivariantLayerNorm on x: nn/o3layer.py:145-171)
+// from the block inputs, the statistics the forward kernel kept (mean, rstd, mean of the 0e block, r = rsqrt(mean square norm)) and the
+// gradients of the normalised features (g_shat rows with stride ld, g_xhat in the BT layout):
+//   d ln_w[f] = sum_n g_shat[n, f] (s[n, f] - mean[n]) rstd[n]        d ln_b[f] = sum_n g_shat[n, f]
+//   d eq_w[u] = sum_n r[n] sum_m g_xhat[n, u, m] (x[n, u, m] - [l = 0] mean0[n])        d eq_b[u] = sum_n g_xhat[n, u, 0]   (0e channels)
+// parts[chunk][2 F + C + m0]; the caller sums the chunks.  As device tensor operations these were six reductions and a dozen
+// elementwise launches per norm (six norms per training step).
+__global__ void __launch_bounds__(256) k_norm_param_grad(const float* __restrict__ s, const float* __restrict__ x,
+                                                         const float* __restrict__ stats, const float* __restrict__ g_shat, int64_t ld,
+                                                         const float* __restrict__ g_xhat, int64_t N, int F, Irreps ir,
+                                                         int64_t rows_per_chunk, float* __restrict__ parts) {
+  const int C = ir.C(), D = ir.D(), m0 = ir.mul[0];
+  const int W = 2 * F + C + m0;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(N, r0 + rows_per_chunk);
+  float* out = parts + (int64_t)blockIdx.x * W;
+  for (int col = threadIdx.x; col < F + C; col += blockDim.x) {
+    if (col < F) {
+      float aw = 0.f, ab = 0.f;
+      for (int64_t n = r0; n < r1; ++n) {
+        const float g = g_shat[n * ld + col];
+        aw += g * ((s[n * F + col] - stats[4 * n]) * stats[4 * n + 1]);
+        ab += g;
+      }
+      out[col] = aw;
+      out[F + col] = ab;
+    } else {
+      const int u = col - F;
+      int l, off;
+      ir.locate(u, l, off);
+      const int nm = 2 * l + 1;
+      const XAddr ga = xaddr(ir, N, u, 1);
+      float aw = 0.f, ab = 0.f;
+      for (int64_t n = r0; n < r1; ++n) {
+        const float mean0 = l == 0 ? stats[4 * n + 2] : 0.f, r = stats[4 * n + 3];
+        float acc = 0.f;
+        for (int m = 0; m < nm; ++m) {
+          const float g = g_xhat[ga.off + n * ga.node + (int64_t)m * ga.comp];
+          acc += g * (x[n * D + off + m] - mean0);
+          if (l == 0) ab += g;
+        }
+        aw += r * acc;
+      }
+      out[2 * F + u] = aw;
+      if (u < m0) out[2 * F + C + u] = ab;
+    }
+  }
+}
+
 struct PgArgs {
   int64_t n_nodes, n_edges, edges_per_part;
   const int64_t* center;
@@ -322,6 +370,24 @@ int xeq_param_basis(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_k
   hipLaunchKernelGGL(k_param_basis, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec, n_edges,
                      RadialSpec{rbf_kind, cutoff_kind, num_basis, cutoff}, (const float*)p0, (const float*)p1, (float*)tab);
   XEQ_CHECK_LAUNCH("xeq_param_basis");
+  return XEQ_OK;
+}
+
+int xeq_norm_param_grad_chunks(int64_t n_nodes) {
+  const int64_t c = (n_nodes + 63) / 64;          // at least 64 rows per chunk, at most two workgroups per CU
+  return (int)(c < 1 ? 1 : (c > 512 ? 512 : c));
+}
+
+int xeq_norm_param_grad(const void* s, const void* x, const void* stats, const void* g_shat, int64_t ld_gs, const void* g_xhat_bt,
+                        int64_t n_nodes, int node_dim, const int32_t mul[3], int n_chunks, void* parts, void* stream) {
+  XEQ_CHECK_ARG(n_nodes >= 0 && node_dim >= 1 && mul[0] >= 0 && mul[1] >= 0 && mul[2] >= 0 && ld_gs >= node_dim, "xeq_norm_param_grad: bad sizes");
+  XEQ_CHECK_ARG(n_chunks == xeq_norm_param_grad_chunks(n_nodes), "xeq_norm_param_grad: parts must hold xeq_norm_param_grad_chunks(n) = %d rows, got %d",
+                xeq_norm_param_grad_chunks(n_nodes), n_chunks);
+  Irreps ir{{mul[0], mul[1], mul[2]}};
+  const int64_t rows = (n_nodes + n_chunks - 1) / n_chunks;
+  hipLaunchKernelGGL(k_norm_param_grad, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (const float*)s, (const float*)x,
+                     (const float*)stats, (const float*)g_shat, ld_gs, (const float*)g_xhat_bt, n_nodes, node_dim, ir, rows, (float*)parts);
+  XEQ_CHECK_LAUNCH("xeq_norm_param_grad");
   return XEQ_OK;
 }
 

@@ -180,6 +180,15 @@ def _norm_param_grads(s, x, stats, g_shat, g_xhat, node_dim, mul):
     statistics (mean, rstd, mean of the 0e block, rsqrt of the mean square norm: xeq_node.hip) and the gradients of the normalised
     features (g_shat [n, F] rows, g_xhat in the BT layout)."""
     n = x.shape[0]
+    if s.is_cuda and s.dtype == torch.float32 and g_shat.stride(1) == 1:
+        # one launch + one sum over the row chunks (csrc/xeq_train.hip) instead of six reductions and a dozen elementwise launches
+        F, C, m0 = node_dim, sum(mul), mul[0]
+        chunks = int(lib.load().xeq_norm_param_grad_chunks(n))
+        parts = torch.empty((chunks, 2 * F + C + m0), dtype=torch.float32, device=s.device)
+        call("xeq_norm_param_grad", ptr(s.contiguous()), ptr(x.contiguous()), ptr(stats), ptr(g_shat), g_shat.stride(0), ptr(g_xhat), n, F,
+             mul3(mul), chunks, ptr(parts), stream())
+        tot = parts.sum(0)
+        return tot[:F], tot[F : 2 * F], tot[2 * F : 2 * F + C], tot[2 * F + C :]
     mean, rstd, mean0, r = stats.unbind(1)
     d_lnw = (g_shat * ((s - mean[:, None]) * rstd[:, None])).sum(0)
     d_lnb = g_shat.sum(0)
