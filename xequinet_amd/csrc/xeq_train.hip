@@ -374,8 +374,10 @@ int xeq_param_basis(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_k
 }
 
 int xeq_norm_param_grad_chunks(int64_t n_nodes) {
-  const int64_t c = (n_nodes + 63) / 64;          // at least 64 rows per chunk, at most two workgroups per CU
-  return (int)(c < 1 ? 1 : (c > 512 ? 512 : c));
+  // a thread walks its chunk's rows serially (one dependent load round trip per row): short chunks -- 16 rows -- keep that walk at
+  // ~25 us; 73 rows took 128 us per launch
+  const int64_t c = (n_nodes + 15) / 16;
+  return (int)(c < 1 ? 1 : (c > 4096 ? 4096 : c));
 }
 
 int xeq_norm_param_grad(const void* s, const void* x, const void* stats, const void* g_shat, int64_t ld_gs, const void* g_xhat_bt,
