@@ -26,6 +26,9 @@ RADIAL_SPEC = "_xeq_radial_spec"
 # behind it: the block then knows xhat is zero on the l > 0 columns and the kernels skip every term with that factor
 # (include/xeq.h, XEQ_XHAT_HIGHER_L_ZERO).  A tag on the data, not on a module: whatever else produces the features does not set it
 EQUIVARIANT_IS_ZERO = "_xeq_equivariant_is_zero"
+# private data-dict entry a caller with static buffers (runtime.GraphedStep*) may set: an all-zero [n_atoms, irreps.dim] tensor nobody
+# writes to, used as the start value of the equivariant features instead of a fresh zero fill per evaluation
+ZERO_EQUIVARIANT = "_xeq_zero_equivariant"
 
 
 class XEmbedding(nn.Module):
@@ -94,9 +97,12 @@ class XEmbedding(nn.Module):
             with torch.no_grad():  # [x, y, z] -> [y, z, x]  (nn/xpainn.py:71-74)
                 data[keys.SPHERICAL_HARMONICS] = self.sph_harm(vectors.detach()[:, [1, 2, 0]])
 
-        node_equivariant = torch.zeros(
-            (node_invariant.shape[0], self.node_irreps.dim), dtype=node_invariant.dtype, device=node_invariant.device
-        )
+        node_equivariant = data.pop(ZERO_EQUIVARIANT, None)
+        if (node_equivariant is None or node_equivariant.shape != (node_invariant.shape[0], self.node_irreps.dim)
+                or node_equivariant.dtype != node_invariant.dtype or node_equivariant.device != node_invariant.device):
+            node_equivariant = torch.zeros(
+                (node_invariant.shape[0], self.node_irreps.dim), dtype=node_invariant.dtype, device=node_invariant.device
+            )
         data[keys.NODE_EQUIVARIANT] = node_equivariant
         data[EQUIVARIANT_IS_ZERO] = True
         return data
