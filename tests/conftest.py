@@ -12,6 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle is most of the GPU suite's wall time, and on a host with hundreds of logical cores torch's default thread count
+    # makes it several times SLOWER (bench.py's cpu_baseline tuning: 16 threads 31 k edges/s, 128 threads 6.5 k edges/s)
+    try:
+        import torch
+
+        if (os.cpu_count() or 1) > 16:
+            torch.set_num_threads(16)
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

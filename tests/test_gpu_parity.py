@@ -42,6 +42,9 @@ def f32_twin(oracle):
 F32_ORACLE_ORDERS = 4       # members of the fp32 oracle's ensemble (edge orders), see f32_force_bounds; 16 below 2 000 atoms
 
 
+_F32_BOUNDS_CACHE = {}
+
+
 def f32_force_bounds(oracle, ref_in, Fref):
     """(bound_max, bound_p99, err32_max, err32_p99): the fp32 oracle evaluated on the very inputs of the fp64 oracle.
 
@@ -51,18 +54,23 @@ def f32_force_bounds(oracle, ref_in, Fref):
     4.5e-4 -- profiles/parity_r03.json), and which atom is worst moves with the summation order: the reference's fp32
     result is a SET (its index_add, nn/xpainn.py:156-159, is an atomic scatter on a GPU: SURVEY a13), so err32 is taken as
     the envelope over F32_ORACLE_ORDERS legitimate edge orders (as given, reversed, fixed permutations; four times
-    as many for small batches, where one ill-conditioned atom is the whole tail: its error is that atom's conditioning times
+    as many for small systems (under 30 k edges), where one ill-conditioned atom is the whole tail: its error is that atom's conditioning times
     one draw of the rounding noise, and a single HIP draw exceeds 1.5 x the largest of four reference draws one time in
     fifty -- with sixteen, one time in five hundred).  The HIP path
     has to stay within 1.5 x that at the maximum and at the 99th percentile, or within BASELINE.md's 1e-4 where the fp32
     oracle is better than that."""
-    twin = f32_twin(oracle)
     in32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in ref_in.items()}
     ei = in32["edge_index"]
     n_e = ei.shape[1]
+    # the same reference inputs come back several times in a session (one check per kernel family, replay and eager forms): the
+    # ensemble is a property of the inputs and the weights, evaluated once (the CPU oracle is what the GPU suite's wall time is)
+    key = (hash(np.ascontiguousarray(Fref).tobytes()), n_e, tuple(Fref.shape))
+    if key in _F32_BOUNDS_CACHE:
+        return _F32_BOUNDS_CACHE[key]
+    twin = f32_twin(oracle)
     rng = np.random.default_rng(20261004)
     err = None
-    n_members = F32_ORACLE_ORDERS * (4 if Fref.shape[0] < 2000 else 1)
+    n_members = F32_ORACLE_ORDERS * (4 if n_e < 30000 else 1)   # small systems: one ill-conditioned atom is the whole tail (see above)
     for member in range(n_members):
         perm = (torch.arange(n_e) if member == 0 else torch.arange(n_e - 1, -1, -1) if member == 1
                 else torch.as_tensor(rng.permutation(n_e)))
@@ -73,7 +81,9 @@ def f32_force_bounds(oracle, ref_in, Fref):
         e = np.abs(twin(run, compute_forces=True)["forces"].double().numpy() - Fref)
         err = e if err is None else np.maximum(err, e)
     e_max, e_p99 = float(err.max()), float(np.quantile(err, 0.99))
-    return max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR_MAX * e_max), max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_p99), e_max, e_p99
+    out = (max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR_MAX * e_max), max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_p99), e_max, e_p99)
+    _F32_BOUNDS_CACHE[key] = out
+    return out
 
 
 def _load(name):
