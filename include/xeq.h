@@ -336,7 +336,8 @@ int xeq_message_param_grad(int dtype, int64_t n_nodes, int64_t n_edges, const in
  *   tab[e][W] = f(d_e) [rho_k (B) | 1 | d rho_k/d p0 (B) | d rho_k/d p1 (B, gaussian basis only)], zero padding to a multiple of 4, Y_1 (3), Y_2 (5)
  * (W = xeq_param_basis_width: whole 128-byte lines) in the order of the edge list; xeq_message_param_grad_mc contracts them with G[e, c] formed on the fly:
  * parts[n_parts][H][64], columns as xeq_message_param_grad's (the caller sums over the parts).  center / nbr = edge_index rows 0 / 1;
- * any edge order (center-sorted lists gather best). */
+ * any edge order (center-sorted lists gather best).  n_valid (optional, device pointer): the edge count of a capacity-sized list whose
+ * size never reached the host (a training step captured as one HIP graph, train.GraphedTrainStep): edges behind it are not walked. */
 int xeq_message_param_grad_mc_supported(int dtype, int rbf_kind, int num_basis, int node_dim, const int32_t mul[3]);
 int xeq_param_basis_width(int rbf_kind, int num_basis);
 int xeq_message_param_grad_mc_parts(int64_t n_edges, int node_dim, const int32_t mul[3]);
@@ -344,7 +345,8 @@ int xeq_param_basis(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_k
                     const void* p1, void* tab, void* stream);
 int xeq_message_param_grad_mc(int64_t n_nodes, int64_t n_edges, const int64_t* center, const int64_t* nbr, const void* tab, const void* h,
                               const void* xhat, const void* grad_s, const void* grad_x, int rbf_kind, int num_basis, int node_dim,
-                              const int32_t mul[3], int xhat_layout, int grad_x_layout, int n_parts, void* parts, void* stream);
+                              const int32_t mul[3], int xhat_layout, int grad_x_layout, const int32_t* n_valid, int n_parts, void* parts,
+                              void* stream);
 /* Affine-parameter gradients of a block's two norms for a TRAINING pass (nn.LayerNorm weight / bias on the scalars,
  * EquivariantLayerNorm affine_weight / affine_bias, nn/o3layer.py:145-171), f32: from the block inputs s [n, F], x [n, D], the
  * statistics stats [n, 4] the forward norm kernel wrote, dL/dshat rows (stride ld_gs) and dL/dxhat in the BT layout.

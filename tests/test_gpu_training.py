@@ -190,6 +190,40 @@ def test_native_training_pass_in_fp32_against_the_differentiable_form(cfg_name):
         assert err <= 2e-4 * max(1e-6, g.abs().max().item()), f"{n}: {err:.2e} of {g.abs().max().item():.2e}"
 
 
+def test_training_step_as_one_graph_follows_the_host_launched_steps():
+    """train.GraphedTrainStep: neighbour list + native energy pass + Adam as ONE captured graph over capacity-sized arrays.  Three
+    different batches (other atom, graph and edge counts) through the one capture; a twin model stepped by ``train_step`` on the
+    same batches sees the same losses and ends with the same parameters (to fp32 rounding: the captured loss sums its graphs in
+    another order)."""
+    from xequinet_amd import runtime
+
+    torch.manual_seed(0)
+    batches = []
+    for k, n_mol in enumerate((40, 33, 48)):
+        host, dev = _batch(n_mol, 30 + k, torch.float32)
+        tgt = _targets(host, 60 + k, False)
+        batches.append((host, dev, tgt))
+    cap = (max(b[0]["pos"].shape[0] for b in batches) + 8, max(b[0]["ptr"].numel() - 1 for b in batches),
+           max(runtime.pair_capacity(b[0]["ptr"].numpy()) for b in batches))
+    fast, slow = _model(torch.float32, **SMALL).train(), _model(torch.float32, **SMALL).train()
+    slow.load_state_dict(fast.state_dict())
+    opt_f = torch.optim.Adam(fast.parameters(), lr=1e-3, capturable=True)
+    opt_s = torch.optim.Adam(slow.parameters(), lr=1e-3, capturable=True)
+    step = train.GraphedTrainStep(fast, opt_f, cap)
+    for host, dev, tgt in batches + batches[:1]:
+        loss_f = step(dev["pos"], dev["atomic_numbers"], dev["ptr"], tgt[keys.TOTAL_ENERGY].float().to(DEV), batch=dev["batch"]).item()
+        data = {k: v for k, v in dev.items()}
+        from xequinet_amd.data import NeighborTransform, XequiBatch
+        b = NeighborTransform(5.0)(XequiBatch(dev["pos"], dev["atomic_numbers"], dev["ptr"]))
+        t = {keys.TOTAL_ENERGY: tgt[keys.TOTAL_ENERGY].float().to(DEV), keys.BATCH_PTR: dev["ptr"]}
+        loss_s = train.train_step(slow, b.to_dict(), t, opt_s, {keys.TOTAL_ENERGY: 1.0})[0].item()
+        assert abs(loss_f - loss_s) <= 2e-5 * max(1.0, abs(loss_s)), (loss_f, loss_s)
+    assert step.captures == 1
+    for (n, p), (_, q) in zip(fast.named_parameters(), slow.named_parameters()):
+        scale = max(1e-3, q.abs().max().item())
+        assert (p - q).abs().max().item() <= 2e-4 * scale, n
+
+
 def test_frozen_model_in_train_mode_stays_on_the_fused_path():
     model = _model(torch.float32, action_blocks=1).requires_grad_(False).train()
     _, dev = _batch(4, 2, torch.float32)

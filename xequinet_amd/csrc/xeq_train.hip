@@ -153,6 +153,7 @@ struct PgArgs {
   PbLayout L;
   int tiles_c, tiles_f, n_tiles;   // 32-row tiles: C / 32 per gate role, F / 32 for msg_s
   int n_parts;
+  const int32_t* n_valid;          // optional: device-side edge count of a capacity-sized list (edges behind it are not walked)
 };
 
 constexpr int PG_CH = 16;        // edges a wave stages at a time
@@ -209,7 +210,8 @@ __global__ void __launch_bounds__(256) XEQ_PG_OCC k_message_param_grad_mc(PgArgs
   // the workgroup's edges in chunks of 16, dealt to the four waves in turn: the workgroup -- and the other tiles of the part, which
   // start with it -- moves through the range as one narrow window (what has to stay in L2)
   const int64_t w0 = (int64_t)part * a.edges_per_part;
-  const int s1 = (int)(min(a.n_edges, w0 + a.edges_per_part) - w0);   // edges of the part: positions below are relative to w0 (32-bit)
+  const int64_t n_live = a.n_valid ? min(a.n_edges, (int64_t)a.n_valid[0]) : a.n_edges;
+  const int s1 = (int)max((int64_t)0, min(n_live, w0 + a.edges_per_part) - w0);   // edges of the part: positions below are relative to w0 (32-bit)
   const int s0 = min(s1, wave * PG_CH);
   const float4* tabp = reinterpret_cast<const float4*>(tab) + w0 * 16;
   const int64_t* ctrp = a.center + w0;
@@ -405,7 +407,8 @@ int xeq_to_bt(const void* x, int64_t n_nodes, const int32_t mul[3], void* out, v
 
 int xeq_message_param_grad_mc(int64_t n_nodes, int64_t n_edges, const int64_t* center, const int64_t* nbr, const void* tab, const void* h,
                               const void* xhat, const void* grad_s, const void* grad_x, int rbf_kind, int num_basis, int node_dim,
-                              const int32_t mul[3], int xhat_layout, int grad_x_layout, int n_parts, void* parts, void* stream) {
+                              const int32_t mul[3], int xhat_layout, int grad_x_layout, const int32_t* n_valid, int n_parts, void* parts,
+                              void* stream) {
   XEQ_CHECK_ARG(xeq_message_param_grad_mc_supported(XEQ_F32, rbf_kind, num_basis, node_dim, mul),
                 "xeq_message_param_grad_mc: f32, node_dim and multiplicities in multiples of 32, table and harmonics within 64 columns (num_basis %d)", num_basis);
   XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_parts == xeq_message_param_grad_mc_parts(n_edges, node_dim, mul),
@@ -428,6 +431,7 @@ int xeq_message_param_grad_mc(int64_t n_nodes, int64_t n_edges, const int64_t* c
   a.tiles_f = a.F / 32;
   a.n_tiles = 2 * a.tiles_c + a.tiles_f;
   a.n_parts = n_parts;
+  a.n_valid = n_valid;
   a.edges_per_part = ((n_edges + n_parts - 1) / n_parts + 1) & ~(int64_t)1;
   hipLaunchKernelGGL(k_message_param_grad_mc, dim3((unsigned)(a.n_tiles * ((n_parts + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)stream, a, (const float*)tab,
                      (const float*)h, (const float*)xhat, (const float*)grad_s, (const float*)grad_x, (float*)parts);

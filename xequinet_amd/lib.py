@@ -84,7 +84,7 @@ _PROTOS = {
     "xeq_param_basis_width": [c_int, c_int],
     "xeq_message_param_grad_mc_parts": [c_int64, c_int, _I3],
     "xeq_param_basis": [_P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P],
-    "xeq_message_param_grad_mc": [c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _I3, c_int, c_int, c_int, _P, _P],
+    "xeq_message_param_grad_mc": [c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _I3, c_int, c_int, _P, c_int, _P, _P],
     "xeq_to_bt": [_P, c_int64, _I3, _P, _P],
     "xeq_norm_param_grad_chunks": [c_int64],
     "xeq_norm_param_grad": [_P, _P, _P, _P, c_int64, _P, c_int64, c_int, _I3, c_int, _P, _P],

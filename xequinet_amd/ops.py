@@ -138,6 +138,9 @@ class EdgeGraph:
         # symmetric, center-sorted list: the reverse wq kernel walks the FORWARD plan (every slot stands for its mirror edge), n_perm
         # is the mirror map (include/xeq.h, XEQ_WQ_MIRROR_WALK)
         self.mirror_walk = bool(symmetric and center_sorted)
+        # set by callers whose edge_index is a capacity-sized buffer (runtime.GraphedStep*, train.GraphedTrainStep): the true edge count
+        # is c_rowptr[N] on the device; kernels that walk edges by index rather than by row pointer are handed that pointer
+        self.edge_count_on_device = False
         if symmetric and center_sorted:
             self.n_rowptr = self.c_rowptr
             self.n_perm = torch.empty(E, dtype=torch.int32, device=edge_index.device)
@@ -901,8 +904,8 @@ def message_param_grad(saved, graph: EdgeGraph, cfg, g_s, g_x):
         g_x_bt = torch.empty(g_x.numel(), dtype=h.dtype, device=h.device)     # dL/dx_out rows contiguous over the channels
         call("xeq_to_bt", ptr(g_x.contiguous()), N, mul3(mul), ptr(g_x_bt), stream())
         KERNEL_TIMER.launch("xeq_message_param_grad_mc", N, E, ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(tab), ptr(h), ptr(xhat),
-                            ptr(g_s.contiguous()), ptr(g_x_bt), lib.RBF_KINDS[rbf_kind], B, node_dim, mul3(mul), xl & 1, 1, n_parts,
-                            ptr(parts), stream())
+                            ptr(g_s.contiguous()), ptr(g_x_bt), lib.RBF_KINDS[rbf_kind], B, node_dim, mul3(mul), xl & 1, 1,
+                            ptr(graph.c_rowptr[N:]) if getattr(graph, "edge_count_on_device", False) else None, n_parts, ptr(parts), stream())
         total = parts.sum(0)
         d_p1 = None if p1 is None else (w_rbf * total[:, 2 * B + 1 : 3 * B + 1]).sum(0)
         return total[:, :B], total[:, B], (w_rbf * total[:, B + 1 : 2 * B + 1]).sum(0), d_p1

@@ -69,3 +69,110 @@ def train_step(model: torch.nn.Module, data: Dict[str, torch.Tensor], target: Di
         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
     optimizer.step()
     return loss.detach(), {k: v.detach() for k, v in result.items()}
+
+
+class GraphedTrainStep:
+    """One optimisation step on an ENERGY loss -- neighbour list, forward pass, loss, the native reverse pass with its parameter
+    gradients (nn/fused.py) and the optimizer's update -- as ONE captured HIP graph that does not depend on the batch's edge count.
+
+    What ``train_step`` costs on the host for this model is ~400 kernel launches through Python and autograd per step (9.8 ms per
+    QM9-1024 step where the GPU needs 8.5); a captured step is one launch.  The arrays have a capacity as in ``runtime.GraphedStep``
+    (atoms, graphs, edges <= sum n_g (n_g - 1)); a batch is padded in one launch, the padding atoms sit in one trailing graph whose
+    energy is masked out of the loss, so they receive no gradient.  The loss is the reference's weighted l2 / l1 loss on ``energy`` or
+    ``energy_per_atom`` (utils/loss.py:47-110, utils/trainer.py:295-302); forces in the loss need the differentiable pass and are not
+    captured here.
+
+    The optimizer must keep its state on the device (``torch.optim.Adam(..., capturable=True)``).  The warm-up iterations in front of
+    the capture are real steps on the first batch; model and optimizer are put back to their state before them, so the first
+    replayed step is the first update."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, capacity, prop: str = keys.TOTAL_ENERGY,
+                 loss_fn: str = "l2", cutoff: Optional[float] = None, warmup: int = 3) -> None:
+        from . import runtime
+
+        if prop not in (keys.TOTAL_ENERGY, keys.ENERGY_PER_ATOM):
+            raise ValueError("GraphedTrainStep captures an energy loss (energy or energy_per_atom)")
+        if loss_fn.lower() not in ("l2", "mse", "l1", "mae"):
+            raise ValueError(f"GraphedTrainStep: loss {loss_fn!r}")
+        for grp in optimizer.param_groups:
+            if not grp.get("capturable", False):
+                raise ValueError("GraphedTrainStep needs an optimizer whose state lives on the device (capturable=True)")
+        self.model, self.optimizer, self.prop, self.loss_fn = model, optimizer, prop, loss_fn.lower()
+        self._gs = runtime.GraphedStep(model, capacity, cutoff=cutoff, compute_forces=False, warmup=0)   # static buffers + padded loads
+        g = self._gs
+        dev, dt = g.pos.device, g.pos.dtype
+        self.target = torch.zeros(g.n_graphs, dtype=dt, device=dev)
+        self.mask = torch.zeros(g.n_graphs, dtype=dt, device=dev)         # 1 for the batch's graphs, 0 for the padding graph / unused slots
+        self.warmup = warmup
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.loss: Optional[torch.Tensor] = None
+        self.captures = 0
+
+    def _body(self) -> torch.Tensor:
+        from . import ops
+
+        g = self._gs
+        rowptr = ops.radius_graph_capacity(g.pos, g.ptr, g.cutoff, g.edge_index)
+        eg = ops.EdgeGraph(g.edge_index, g.n_atoms, center_sorted=True, ptr=g.ptr, c_rowptr=rowptr, symmetric=True)
+        eg.edge_count_on_device = True
+        data = {keys.POSITIONS: g.pos.detach(), keys.ATOMIC_NUMBERS: g.z, keys.EDGE_INDEX: g.edge_index, keys.BATCH: g.batch,
+                keys.BATCH_PTR: g.ptr, keys.EDGE_GRAPH: eg}
+        energy = self.model(data, False, False)[keys.TOTAL_ENERGY]
+        diff = energy - self.target
+        if self.prop == keys.ENERGY_PER_ATOM:
+            diff = diff / (g.ptr[1:] - g.ptr[:-1]).clamp(min=1).to(diff.dtype)
+        per_graph = diff * diff if self.loss_fn in ("l2", "mse") else diff.abs()
+        loss = (per_graph * self.mask).sum() / self.mask.sum()            # the mean over the batch's own graphs
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _capture(self) -> None:
+        import copy
+        import gc
+
+        self.model.train()
+        model_state = copy.deepcopy(self.model.state_dict())
+        opt_saved = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.optimizer.state.items()}
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # every iteration in front of the capture on THIS stream (an AccumulateGrad node kept alive
+            for _ in range(self.warmup):   # from another stream breaks the capture)
+                self.optimizer.zero_grad(set_to_none=True)
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # back to the state in front of the warm-up, IN PLACE: the optimizer's state tensors must exist before the capture (created
+        # inside it, their zero-initialisation would be replayed with every step)
+        self.model.load_state_dict(model_state)
+        with torch.no_grad():
+            for p, st in self.optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if p in opt_saved and k in opt_saved[p]:
+                            v.copy_(opt_saved[p][k])
+                        else:
+                            v.zero_()
+        gc.collect()
+        self.graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+        self.captures += 1
+        # the capture itself ran no kernel; the replay below is the first update
+
+    def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, target_energy: torch.Tensor,
+                 batch: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One step on this batch; returns the loss (a device scalar owned by the graph, overwritten by the next call)."""
+        g = self._gs
+        n_graphs = int(ptr.numel() - 1)
+        g._load(pos, atomic_numbers, ptr, batch)
+        self.target.zero_()
+        self.target[:n_graphs] = target_energy.to(self.target.dtype)
+        self.mask.zero_()
+        self.mask[:n_graphs] = 1.0
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        return self.loss
