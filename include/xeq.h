@@ -255,9 +255,12 @@ int xeq_head_bwd_hidden(const void* pre, int64_t n, int hidden_dim, const void* 
 
 /* Weight gradient of a linear layer for a TRAINING pass (what autograd forms as grad_output^T @ input for nn.Linear, utils/trainer.py:
  * 295-302; the o3.Linear blocks likewise): parts[c][M][K] = sum over the rows of chunk c of a[row, 0..M)^T b[row, 0..K), f32, rows
- * with strides lda / ldb; n_chunks = xeq_wgrad_chunks(n, M, K); dW = sum over c (fixed order: reproducible bit for bit). */
+ * with strides lda / ldb; n_chunks = xeq_wgrad_chunks(n, M, K); dW = sum over c (fixed order: reproducible bit for bit).  with_bias:
+ * every chunk's block is followed by M more floats, the column sums of a over the chunk's rows (the layer's bias gradient): parts is
+ * [n_chunks][M K + M]. */
 int xeq_wgrad_chunks(int64_t n, int m, int k);
-int xeq_wgrad(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t n, int m, int k, int n_chunks, void* parts, void* stream);
+int xeq_wgrad(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t n, int m, int k, int with_bias, int n_chunks, void* parts,
+              void* stream);
 
 /* A batch of n atoms in g graphs into arrays of n_cap atoms / g_cap graphs in ONE launch (runtime.GraphedStep: neighbour list +
  * model as one captured graph over capacity-sized arrays): atoms n .. n_cap - 1 get atomic number 0, positions

@@ -249,3 +249,7 @@ def test_weight_gradient_kernel_matches_fp64(n, m, k):
     assert got.shape == (m, k) and (got.double() - want).abs().max().item() <= 2e-6 * scale * max(1.0, n ** 0.5 / 30)
     assert torch.equal(got, fused._wgrad(a, b))
     assert torch.equal(fused._wgrad(a.double(), b.double()), want)     # f64: the library product
+    got_w, got_b = fused._wgrad(a, b, with_bias=True)                  # bias gradient (column sums of a) out of the same launch
+    assert torch.equal(got_w, got)
+    want_b = a.double().sum(0)
+    assert got_b.shape == (m,) and (got_b.double() - want_b).abs().max().item() <= 2e-6 * max(1.0, want_b.abs().max().item()) * max(1.0, n ** 0.5 / 30)

@@ -147,6 +147,7 @@ struct WgradArgs {
   const float* B;
   int64_t lda, ldb, n, rows_per_chunk;
   int M, K, bm, bk, n_chunks;
+  int with_bias;     // also the column sums of A (the layer's bias gradient): M more floats behind each chunk's [M, K] block
   float* parts;
 };
 
@@ -170,6 +171,7 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
   const float* pa = a.A + m0 + i;
   const float* pb = a.B + k0 + i;
   constexpr int UN = 4;   // row pairs in flight
+  float sa0 = 0.f, sa1 = 0.f;   // column sums of A over this lane's rows (bias gradient; used by the k0 = 0 blocks)
   for (int64_t r = r0; r < r1; r += 2 * UN) {
     float va0[UN], va1[UN], vb0[UN], vb1[UN];
 #pragma unroll
@@ -183,13 +185,24 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
+      sa0 += va0[u];
+      sa1 += va1[u];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0[u], vb0[u], acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0[u], vb1[u], acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1[u], vb0[u], acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1[u], vb1[u], acc[1][1], 0, 0, 0);
     }
   }
-  float* out = a.parts + chunk * (int64_t)a.M * a.K;
+  const int64_t stride = (int64_t)a.M * a.K + (a.with_bias ? a.M : 0);
+  float* out = a.parts + chunk * stride;
+  if (a.with_bias && k0 == 0) {   // one column block per row block writes the sums: odd + even rows of the chunk
+    sa0 += __shfl_xor(sa0, 32, 64);
+    sa1 += __shfl_xor(sa1, 32, 64);
+    if (kh == 0) {
+      if (am0) out[(int64_t)a.M * a.K + m0 + i] = sa0;
+      if (am1) out[(int64_t)a.M * a.K + m0 + 32 + i] = sa1;
+    }
+  }
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -252,12 +265,13 @@ int xeq_wgrad_chunks(int64_t n, int m, int k) {
   return (int)(c < 1 ? 1 : c);
 }
 
-int xeq_wgrad(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t n, int m, int k, int n_chunks, void* parts, void* stream) {
+int xeq_wgrad(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t n, int m, int k, int with_bias, int n_chunks, void* parts,
+              void* stream) {
   XEQ_CHECK_ARG(n >= 0 && m >= 1 && k >= 1 && lda >= m && ldb >= k, "xeq_wgrad: bad shape n = %lld, M = %d, K = %d", (long long)n, m, k);
   XEQ_CHECK_ARG(n_chunks == xeq_wgrad_chunks(n, m, k), "xeq_wgrad: parts must hold xeq_wgrad_chunks(n, M, K) = %d blocks, got %d",
                 xeq_wgrad_chunks(n, m, k), n_chunks);
   WgradArgs w{(const float*)a, (const float*)b, lda, ldb, n, (n + n_chunks - 1) / n_chunks, m, k, (m + 63) / 64, (k + 63) / 64, n_chunks,
-              (float*)parts};
+              with_bias ? 1 : 0, (float*)parts};
   if (w.rows_per_chunk & 1) ++w.rows_per_chunk;   // an MFMA takes two rows: chunks start on even rows
   const int64_t waves = (int64_t)w.bm * w.bk * n_chunks;
   hipLaunchKernelGGL(k_wgrad, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w);

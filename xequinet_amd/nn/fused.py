@@ -152,26 +152,30 @@ def update_params(module) -> list:
     return ps
 
 
-def _wgrad(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a^T b over the rows (a [n, M], b [n, K] -> [M, K]): the weight gradient of a linear layer from dL/dy rows and input rows.
+def _wgrad(a: torch.Tensor, b: torch.Tensor, with_bias: bool = False):
+    """a^T b over the rows (a [n, M], b [n, K] -> [M, K]): the weight gradient of a linear layer from dL/dy rows and input rows;
+    ``with_bias``: -> (a^T b, column sums of a [M]) = (dL/dW, dL/dbias) out of the same launch and the same sum over the parts.
     f32 on the GPU: ``xeq_wgrad`` (row chunks on the matrix cores, parts summed in a fixed order); else the library product."""
     if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
-        return torch.mm(a.t(), b)
+        d_w = torch.mm(a.t(), b)
+        return (d_w, a.sum(0)) if with_bias else d_w
     n, M = a.shape
     K = b.shape[1]
     chunks = int(lib.load().xeq_wgrad_chunks(n, M, K))
-    parts = torch.empty((chunks, M, K), dtype=torch.float32, device=a.device)
-    call("xeq_wgrad", ptr(a), a.stride(0), ptr(b), b.stride(0), n, M, K, chunks, ptr(parts), stream())
-    return parts.sum(0) if chunks > 1 else parts[0]
+    parts = torch.empty((chunks, M * K + (M if with_bias else 0)), dtype=torch.float32, device=a.device)
+    call("xeq_wgrad", ptr(a), a.stride(0), ptr(b), b.stride(0), n, M, K, int(with_bias), chunks, ptr(parts), stream())
+    tot = parts.sum(0) if chunks > 1 else parts[0]
+    d_w = tot[: M * K].view(M, K)
+    return (d_w, tot[M * K :]) if with_bias else d_w
 
 
 def _mlp_param_grads(seq, x_in, pre, g_y):
     """Linear - act - Linear on rows: (dW1, db1, dW2, db2, dL/dx) from the input, the saved pre-activation and dL/dy."""
     lin1, act, lin2 = seq[0], seq[1], seq[2]
     hidden = act(pre)
-    d_w2, d_b2 = _wgrad(g_y, hidden), g_y.sum(0)
+    d_w2, d_b2 = _wgrad(g_y, hidden, with_bias=True)
     g_pre = _silu_bwd(torch.mm(g_y, lin2.weight), pre, act)
-    d_w1, d_b1 = _wgrad(g_pre, x_in), g_pre.sum(0)
+    d_w1, d_b1 = _wgrad(g_pre, x_in, with_bias=True)
     return d_w1, d_b1, d_w2, d_b2, torch.mm(g_pre, lin1.weight)
 
 
@@ -296,7 +300,7 @@ class EnergyHead(Function):
         if not ctx.train:
             return g_s, None
         s, hidden = ctx.saved_tensors[2:]
-        return (g_s, None, _wgrad(g_pre, s), g_pre.sum(0), torch.mv(hidden.t(), g_out).view(1, -1), g_out.sum().view(1))
+        return (g_s, None, *_wgrad(g_pre, s, with_bias=True), torch.mv(hidden.t(), g_out).view(1, -1), g_out.sum().view(1))
 
 
 class EmbeddingLinear(Function):
@@ -315,7 +319,8 @@ class EmbeddingLinear(Function):
     def backward(ctx, g):
         z32, table = ctx.saved_tensors
         rows = table.index_select(0, z32.long())
-        return None, None, None, _wgrad(g.contiguous(), rows), (g.sum(0) if ctx.has_bias else None)
+        d_w, d_b = _wgrad(g.contiguous(), rows, with_bias=True)
+        return None, None, None, d_w, (d_b if ctx.has_bias else None)
 
 
 class MessageBlock(Function):
