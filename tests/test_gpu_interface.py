@@ -628,3 +628,29 @@ def test_gromacs_model_whole_step_graph_follows_a_trajectory(dtype, monkeypatch)
     e1 = fast(x, P._t(np.asarray(z192).astype(np.int64)), half, torch.tensor([True, True, False], device=DEV))
     e0 = eager(x, P._t(np.asarray(z192).astype(np.int64)), half, torch.tensor([True, True, False], device=DEV))
     assert fast._step_graph.captures > caps and torch.equal(e0.detach(), e1.detach())
+
+
+def test_gromacs_model_whole_step_graph_without_a_box():
+    """No box, no periodic axis (an isolated molecule under GROMACS' NNPot): the whole-step graph searches with one image (rep 0 on
+    every axis) and returns the eager model's energy bit for bit, forces to the unit factors' rounding, along a short trajectory."""
+    from xequinet_amd.interface import XPaiNNGMX
+
+    dtype = torch.float32
+    nm = FACTOR[("nm", "Angstrom")]
+    eager, _ = _twin(XPaiNNGMX, dtype)
+    fast, _ = _twin(XPaiNNGMX, dtype, replay=True, whole_step=True, tune_gemms=False)
+    fast.load_state_dict(eager.state_dict())
+    pos0, z, _ = syn.synth_aspirin()
+    z_t = P._t(np.asarray(z).astype(np.int64))
+    rng = np.random.default_rng(4)
+    for step in range(4):
+        pos = pos0 + 0.03 * step * rng.normal(size=pos0.shape)
+        outs = []
+        for model in (eager, fast):
+            x = P._t((pos / nm).astype(np.float32)).requires_grad_(True)
+            e = model(x, z_t, None, None)
+            (g,) = torch.autograd.grad(e.sum(), x)
+            outs.append((e.detach().clone(), g.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]), step
+        assert (outs[0][1] - outs[1][1]).abs().max().item() <= 16 * torch.finfo(dtype).eps * outs[0][1].abs().max().item(), step
+    assert fast._step_graph.captures == 1
