@@ -40,6 +40,25 @@ def test_c_abi_argument_errors_are_reported_without_a_gpu():
     assert rc == 1 and b"not implemented" in handle.xeq_last_error()
     rc = handle.xeq_segment_sum(5, None, None, 3, 4, None, None)  # bad dtype code
     assert rc == 1
+    # round-3 entries: training-pass kernels, the bounded CSR sort
+    odd = lib.mul3((100, 64, 32))                                      # multiplicities outside the matrix-core forms
+    assert handle.xeq_message_param_grad_mc_supported(lib.XEQ_F32, 0, 20, 128, mul) == 1
+    assert handle.xeq_message_param_grad_mc_supported(lib.XEQ_F32, 0, 20, 128, odd) == 0
+    assert handle.xeq_message_param_grad_mc_supported(lib.XEQ_F64, 0, 20, 128, mul) == 0
+    assert handle.xeq_message_param_grad_mc_supported(lib.XEQ_F32, 1, 20, 128, mul) == 0       # gaussian, B = 20: 61 columns + harmonics > 64
+    assert handle.xeq_param_basis_width(0, 20) == 64
+    rc = handle.xeq_message_param_grad_mc(10, 10, None, None, None, None, None, None, None, 0, 20, 128, odd, 1, 1, None, 1, None, None)
+    assert rc == 1 and b"multiples of 32" in handle.xeq_last_error()
+    rc = handle.xeq_message_param_grad_mc(10, 10, None, None, None, None, None, None, None, 0, 20, 128, mul, 1, 1, None, 7, None, None)
+    assert rc == 1 and b"xeq_message_param_grad_mc_parts" in handle.xeq_last_error()
+    rc = handle.xeq_wgrad(None, 4, None, 4, 100, 8, 8, 0, 3, None, None)                       # rows strides below the widths
+    assert rc == 1 and b"bad shape" in handle.xeq_last_error()
+    rc = handle.xeq_wgrad(None, 8, None, 8, 100, 8, 8, 0, 3, None, None)                       # wrong chunk count
+    assert rc == 1 and b"xeq_wgrad_chunks" in handle.xeq_last_error()
+    assert handle.xeq_wgrad_chunks(18609, 576, 128) == 114 and handle.xeq_wgrad_chunks(5, 32, 32) == 1
+    rc = handle.xeq_csr_by_key_bounded(None, 10, 5, None, None, 0, None, None, None)           # no device-side count
+    assert rc == 1 and b"bad sizes" in handle.xeq_last_error()
+    assert handle.xeq_message_wq_pcap(100, 1000) == 1400                                        # E + 4 N: a quad for every node without an edge
 
 
 def test_irreps_mirror():
