@@ -208,8 +208,8 @@ __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __res
     sph_harm_l12<float>(g, y1, y2);
     const f32x4 v = grp == 4 ? f32x4{y1[0], y1[1], y1[2], y2[0]} : f32x4{y2[1], y2[2], y2[3], y2[4]};
     *reinterpret_cast<f32x4*>(out + WQ_Y + 4 * (grp - 4)) = v;
-    if (dout) *reinterpret_cast<f32x4*>(dout + WQ_Y + 4 * (grp - 4)) = zero;
-    return;
+    if (dout) *reinterpret_cast<f32x4*>(dout + WQ_Y + 4 * (grp - 4)) = v;   // the reverse kernel reads Y next to the derivatives: its
+    return;                                                                  // first-block form then never touches the value record
   }
   float f, df;
   envelope<float>(rs.cutoff_kind, g.d, rc, f, df);
@@ -463,7 +463,8 @@ __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int
   wq_load_rec<KS>(rec, ps, kh, valid, w.R[0]);
   if constexpr (NREC > 1) wq_load_rec<KS>(drec, ps, kh, valid, w.R[1]);
   if constexpr (WITH_Y) {
-    const f32x4* __restrict__ yp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + WQ_Y);
+    const float* __restrict__ ysrc = NREC > 1 ? drec : rec;   // (both records carry Y)
+    const f32x4* __restrict__ yp = reinterpret_cast<const f32x4*>(ysrc + (size_t)ps * WQ_REC + WQ_Y);
     w.ya = yp[0];
     w.yb = yp[1];
     if (a.mirror) {   // the mirror edge's vector is the negative of the slot's: d and Y_2 are the same bits, Y_1 changes sign
