@@ -586,6 +586,34 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
                       const float* wt_packed0, const float* wt_packed1, const float* wt_packed2, double eps, float* g_s, float* g_x,
                       float* g_xhat_bt, void* stream);
 
+/* ---- the per-node chain between two message aggregations as ONE launch per direction (round 4; csrc/xeq_nodeblock.hip) -------------
+ * f32, the default layout (node_dim 128, 128x0e + 64x1o + 32x2e: xeq_node_block_supported).  A wave owns 32 nodes and keeps their
+ * activations in the matrix cores' accumulator layout; every contraction runs on bf16 MFMAs over three-way split operands
+ * (six products per k-step, f32 accumulation); the weights stream through LDS from a copy packed in consumption order.
+ *
+ * xeq_node_block_fwd = XPainnUpdate.forward (nn/xpainn.py:206-231: both norms, o3.Linear U / V, Invariant, EquivariantDot, update_mlp,
+ * dot_lin, residual update) and, when h_next != NULL, the front half of the NEXT XPainnMessage.forward (nn/xpainn.py:128-139: both
+ * norms of (s_out, x_out) and scalar_mlp).  It replaces xeq_update_uv_fwd + xeq_mlp2_fwd + xeq_linear_fwd + xeq_update_out_fwd
+ * (+ xeq_norm_fwd + xeq_mlp2_fwd of the next block) and writes what they wrote, in their layouts: uv_bt (U|V pair buffer, BT),
+ * stats [n, 4], pre [n, F] (update_mlp hidden pre-activation), a [n, C + 2 F], ip [n, F] (dot_lin output), s_out [n, F], x_out [n, D]
+ * (NULL: no consumer), and for the next block stats_next [n, 4], xhat_next (BT), pre_next [n, F], h_next [n, F + 2 C].
+ * packed: xeq_node_block_pack_fwd(update_mlp[0].weight [F, F + C], [W_U | W_V] / sqrt(mul_l) as [mul_l, 2 mul_l] for l = 0, 1, 2,
+ * dot_lin.weight [F, C], update_mlp[2].weight [C + 2 F, F], next scalar_mlp[0].weight [F, F] and [2].weight [F + 2 C, F] (both
+ * NULL: without the next block), out, stream); out holds xeq_node_block_fwd_tiles(with_tail) * 3072 bytes.
+ * b_uv = [update_U.bias | update_V.bias] ([2 F]) or NULL. */
+int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]);
+int64_t xeq_node_block_fwd_tiles(int with_tail);
+int xeq_node_block_pack_fwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,
+                            const float* w1_next, const float* w2_next, void* out, void* stream);
+int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* ln_w, const float* ln_b, const float* eq_w, const float* eq_b,
+                       const float* b_uv, const float* b3, const float* b4, double eps, const void* packed, float* uv_bt, float* stats,
+                       float* pre, float* a, float* ip, float* s_out, float* x_out, const float* ln_w_next, const float* ln_b_next,
+                       const float* eq_w_next, const float* eq_b_next, const float* b1_next, const float* b2_next, float* stats_next,
+                       float* xhat_next, float* pre_next, float* h_next, void* stream);
+/* test entry: y [n, 32 n_ot] = x [n, 128] W^T (W [32 n_ot, 128]) through the kernel's primitives; form 0 (n_ot = 4): chunk
+ * accumulation, form 1: one output tile at a time; packed_scratch: 8 n_ot * 3072 bytes */
+int xeq_node_block_linear_test(const float* x, int64_t n, const float* w, int n_ot, int form, void* packed_scratch, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,173 @@
+"""Fused node-block kernels (csrc/xeq_nodeblock.hip) against the f64 oracle's restatement of XPainnUpdate.forward
+(nn/xpainn.py:206-231) and the front half of XPainnMessage.forward (nn/xpainn.py:128-139), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F_
+
+pytestmark = pytest.mark.gpu
+
+MUL = (128, 64, 32)
+IRREPS = "128x0e + 64x1o + 32x2e"
+F, C, D = 128, 224, 480
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _bt_to_mulir(buf, n, width):
+    """BT buffer (width = 1: xhat-like, 2: the U|V pair buffer) -> list of mul_ir tensors [n, D] (one per column group)."""
+    outs = [[] for _ in range(width)]
+    base = 0
+    for l, mul in enumerate(MUL):
+        d = 2 * l + 1
+        blk = buf[n * base * width: n * (base + d * mul) * width].view(n, d, width * mul)
+        for k in range(width):
+            outs[k].append(blk[:, :, k * mul:(k + 1) * mul].permute(0, 2, 1).reshape(n, mul * d))
+        base += d * mul
+    return [torch.cat(o, 1) for o in outs]
+
+
+def _close(name, got, ref, tol):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"{name}: max abs err {err:.3e} (scale {scale:.3e}, tol {tol:.1e})"
+    return err / scale
+
+
+@pytest.mark.parametrize("form,n_ot", [(0, 4), (1, 4), (1, 7), (1, 18)])
+@pytest.mark.parametrize("n", [1, 77, 128, 300])
+def test_linear_primitives(form, n_ot, n):
+    """Fragment maps, three-way split arithmetic and the weight ring: y = x W^T with asymmetric random operands."""
+    from xequinet_amd.lib import call, ptr, stream
+
+    torch.manual_seed(3 + n + n_ot)
+    x = torch.randn(n, 128, device=_dev()) * torch.logspace(-3, 2, 128, device=_dev())[None, :]
+    w = torch.randn(32 * n_ot, 128, device=_dev())
+    scratch = torch.empty(8 * n_ot * 3072 + 4 * 3072, dtype=torch.uint8, device=_dev())
+    y = torch.full((n, 32 * n_ot), float("nan"), device=_dev())
+    call("xeq_node_block_linear_test", ptr(x), n, ptr(w), n_ot, form, ptr(scratch), ptr(y), stream())
+    torch.cuda.synchronize()
+    ref = x.double() @ w.double().t()
+    mag = x.double().abs() @ w.double().abs().t()      # the bound is relative to sum |x| |w| (f32 accumulation)
+    err = ((y.double() - ref).abs() / mag).max().item()
+    assert err <= 3e-7, err
+
+
+def _modules(seed):
+    from xequinet_amd.nn.xpainn import XPainnMessage, XPainnUpdate
+
+    torch.manual_seed(seed)
+    upd = XPainnUpdate(node_dim=F, node_irreps=IRREPS)
+    msg = XPainnMessage(node_dim=F, node_irreps=IRREPS)
+    with torch.no_grad():   # non-trivial affine parameters and biases
+        for mod in (upd, msg):
+            mod.norm.weight.uniform_(0.5, 1.5)
+            mod.norm.bias.normal_(0, 0.3)
+            mod.o3norm.affine_weight.uniform_(0.5, 1.5)
+            mod.o3norm.affine_bias.normal_(0, 0.3)
+        upd.update_U.bias.normal_(0, 0.3)
+        upd.update_V.bias.normal_(0, 0.3)
+    return upd, msg
+
+
+def _reference(upd, msg, s, x):
+    """f64 restatement with the oracle's operator definitions."""
+    from oracle import xpainn_oracle as orc
+
+    sd = {k: v.detach().double().cpu() for k, v in upd.state_dict().items()}
+    s, x = s.double().cpu(), x.double().cpu()
+    n = s.shape[0]
+    out = {}
+    mean = s.mean(1)
+    var = s.var(1, unbiased=False)
+    x0 = x[:, :MUL[0]]
+    mean0 = x0.mean(1)
+    xc = x.clone()
+    xc[:, :MUL[0]] -= mean0[:, None]
+    sq = torch.zeros(n, dtype=torch.float64)
+    off = 0
+    for l, mul in enumerate(MUL):
+        d = 2 * l + 1
+        sq += (xc[:, off:off + mul * d] ** 2).sum(1)
+        off += mul * d
+    rr = 1.0 / torch.sqrt(sq / C + 1e-5)
+    out["stats"] = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5), mean0, rr], 1)
+    shat = F_.layer_norm(s, (F,), sd["norm.weight"], sd["norm.bias"], 1e-5)
+    xhat = orc.equivariant_layer_norm(IRREPS, x, sd["o3norm.affine_weight"], sd["o3norm.affine_bias"])
+    U = orc.o3_linear(IRREPS, xhat, sd["update_U.weight"], sd["update_U.bias"])
+    V = orc.o3_linear(IRREPS, xhat, sd["update_V.weight"], sd["update_V.bias"])
+    out["U"], out["V"] = U, V
+    v = orc.invariant(IRREPS, V, eps=upd.invariant.eps)
+    pre = F_.linear(torch.cat([shat, v], -1), sd["update_mlp.0.weight"], sd["update_mlp.0.bias"])
+    out["pre"] = pre
+    a = F_.linear(F_.silu(pre), sd["update_mlp.2.weight"], sd["update_mlp.2.bias"])
+    out["a"] = a
+    a_vv, a_sv, a_ss = torch.split(a, [C, F, F], dim=-1)
+    ip = F_.linear(orc.equivariant_dot(IRREPS, U, V), sd["dot_lin.weight"])
+    out["ip"] = ip
+    s2 = s + a_sv * ip + a_ss
+    x2 = x + orc.elementwise_tp(IRREPS, U, a_vv)
+    out["s_out"], out["x_out"] = s2, x2
+    if msg is not None:
+        md = {k: v.detach().double().cpu() for k, v in msg.state_dict().items()}
+        shat2 = F_.layer_norm(s2, (F,), md["norm.weight"], md["norm.bias"], 1e-5)
+        out["xhat2"] = orc.equivariant_layer_norm(IRREPS, x2, md["o3norm.affine_weight"], md["o3norm.affine_bias"])
+        pre2 = F_.linear(shat2, md["scalar_mlp.0.weight"], md["scalar_mlp.0.bias"])
+        out["pre2"] = pre2
+        out["h2"] = F_.linear(F_.silu(pre2), md["scalar_mlp.2.weight"], md["scalar_mlp.2.bias"])
+        x20 = x2[:, :MUL[0]]
+        m20 = x20.mean(1)
+        xc2 = x2.clone()
+        xc2[:, :MUL[0]] -= m20[:, None]
+        out["stats2"] = torch.stack([s2.mean(1), 1.0 / torch.sqrt(s2.var(1, unbiased=False) + 1e-5), m20,
+                                     1.0 / torch.sqrt((xc2 ** 2).sum(1) / C + 1e-5)], 1)
+    return out
+
+
+@pytest.mark.parametrize("n", [5, 128, 333])
+@pytest.mark.parametrize("tail", [True, False])
+def test_node_block_forward_matches_f64(n, tail):
+    from xequinet_amd.nn import nodeblock
+
+    upd, msg = _modules(11)
+    upd, msg = upd.to(_dev()), msg.to(_dev())
+    assert nodeblock.supported(upd, msg)
+    torch.manual_seed(100 + n)
+    s = torch.randn(n, F, device=_dev()) * 1.5 + 0.2
+    x = torch.randn(n, D, device=_dev()) * 0.8
+    got = nodeblock.node_block_fwd(s, x, upd, msg if tail else None, want_x=True)
+    torch.cuda.synchronize()
+    ref = _reference(upd, msg if tail else None, s, x)
+    U, V = _bt_to_mulir(got["uv"], n, 2)
+    tol = 3e-6
+    worst = {}
+    worst["U"] = _close("U", U, ref["U"], tol)
+    worst["V"] = _close("V", V, ref["V"], tol)
+    for k in ("stats", "pre", "a", "ip", "s_out", "x_out"):
+        worst[k] = _close(k, got[k], ref[k], tol)
+    if tail:
+        (xhat2,) = _bt_to_mulir(got["xhat2"], n, 1)
+        worst["xhat2"] = _close("xhat2", xhat2, ref["xhat2"], tol)
+        for k in ("stats2", "pre2", "h2"):
+            worst[k] = _close(k, got[k], ref[k], tol)
+    print("relative errors:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_node_block_forward_rows_do_not_depend_on_the_batch():
+    """A node's bits are the same whatever rows share its wave (sharded / chunked / padded batches agree bit for bit)."""
+    from xequinet_amd.nn import nodeblock
+
+    upd, msg = _modules(12)
+    upd, msg = upd.to(_dev()), msg.to(_dev())
+    torch.manual_seed(5)
+    s = torch.randn(300, F, device=_dev())
+    x = torch.randn(300, D, device=_dev())
+    full = nodeblock.node_block_fwd(s, x, upd, msg)
+    part = nodeblock.node_block_fwd(s[37:171].contiguous(), x[37:171].contiguous(), upd, msg)
+    torch.cuda.synchronize()
+    for k in ("s_out", "x_out", "h2", "pre2", "a", "ip", "pre"):
+        assert torch.equal(full[k][37:171], part[k]), k

@@ -1,0 +1,820 @@
+// The per-node chain between two message aggregations of XPaiNN as ONE launch per direction (round 4):
+//
+//   forward   XPainnUpdate.forward (nn/xpainn.py:206-231): LayerNorm + EquivariantLayerNorm (nn/o3layer.py:145-171), o3.Linear U and V
+//             (:211-212), Invariant(V) (nn/o3layer.py:39-44), EquivariantDot(U, V) (:104-109), update_mlp (:215-216), dot_lin
+//             (:222-223), the residual update (:225-229) -- followed, for every block but the last, by the front half of the NEXT
+//             XPainnMessage.forward (nn/xpainn.py:128-139): its two norms and scalar_mlp.
+//   reverse   the same chain backwards for the force evaluation (nn/basic.py:143-159): input gradients only.
+//
+// It replaces, per block and direction, xeq_update_uv_* + xeq_mlp2_* (x2) + xeq_linear_* + xeq_update_out_* + xeq_norm_* (six or seven
+// launches that re-read [N, 480..1056] tensors between them) by one launch that reads (s, x) and writes what the message kernel and
+// the reverse pass read.
+//
+// Design (MI355X): ACTIVATION-STATIONARY.  A wave owns 32 nodes and keeps every activation of theirs in registers in the matrix
+// cores' accumulator layout (lane = node | channel half, register = channel: one 32-channel tile is 16 VGPRs), so that the result
+// of one product is the B operand of the next without any data movement between lanes (v_mfma_f32_32x32x16_bf16, D = W X with the
+// WEIGHT tile as the A operand: the k order inside a 16-wide step is permuted identically in the packed weights).  Every layer
+// norm, SiLU, invariant and residual is then plain per-lane arithmetic (a row reduction is an in-lane sum plus one exchange between
+// the two half-waves).  The weights are what streams: packed once per weight version in CONSUMPTION order (one linear array of
+// 3 KB tiles, xeq_node_block_pack), pulled by the four waves of a workgroup through a three-stage LDS ring (each wave fetches one
+// tile of a four-tile stage, one barrier per stage) and read by every wave as A fragments.  One workgroup = 4 waves = 128 nodes
+// reads the block's ~1.7 MB of packed weights once (the 32-row kernels read them once per 32 nodes).
+//
+// Arithmetic: every contraction runs on bf16 MFMAs over operands split three ways (x = hi + mid + lo, bf16 each, exact to 24 bits),
+// six products per k-step with f32 accumulation (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; what is left out is 2^-26 of a
+// product with round-to-nearest splits, below one f32 rounding): 192 instead of 512 matrix-pipe cycles per 32 x 32 x 16 tile of the
+// exact-f32 MFMA.  A row's sums do not depend on the rows it shares a wave with, so sharded / chunked / padded batches agree bit for
+// bit as before.
+#include <vector>
+
+#include "xeq_common.h"
+
+namespace xeq {
+namespace nb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// default XPaiNN layout (nn/model.py:57-70): node_dim 128, 128x0e + 64x1o + 32x2e
+constexpr int F = 128, M0 = 128, M1 = 64, M2 = 32, C = M0 + M1 + M2, D = M0 + 3 * M1 + 5 * M2;
+constexpr int HM = F + 2 * C;    // scalar_mlp output (576)
+constexpr int AU = C + 2 * F;    // update_mlp output (480)
+constexpr int ROWS_WG = 128;     // 4 waves x 32 nodes
+constexpr int TILE_U4 = 192;     // one packed weight tile: 3 splits x 64 lanes x 16 B
+constexpr int RING_STAGES = 3, STAGE_TILES = 4;
+constexpr int RING_BYTES = RING_STAGES * STAGE_TILES * TILE_U4 * 16;
+
+#define NB_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+struct Frag {   // one k-step (16 channels) of an operand, split three ways
+  bf16x8 hi, mid, lo;
+};
+
+// k-step s (0, 1) of a 32-channel activation tile in accumulator layout: element j of this lane is register 8 s + j
+template <int S>
+__device__ __forceinline__ Frag split_k(const f32x16& t) {
+  f32x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = t[8 * S + j];
+  Frag f;
+  f.hi = __builtin_convertvector(v, bf16x8);
+  const f32x8 r1 = v - __builtin_convertvector(f.hi, f32x8);
+  f.mid = __builtin_convertvector(r1, bf16x8);
+  const f32x8 r2 = r1 - __builtin_convertvector(f.mid, f32x8);
+  f.lo = __builtin_convertvector(r2, bf16x8);
+  return f;
+}
+
+// acc += W X over one k-step: small terms first
+__device__ __forceinline__ void mfma6(f32x16& acc, const Frag& w, const Frag& x) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, acc, 0, 0, 0);
+}
+
+// The weight stream: tiles in consumption order, four per stage, three stages in LDS.  Stage j is fetched into registers while
+// stage j - 2 is consumed, written to LDS at the boundary j - 2 -> j - 1 (one barrier per boundary: it publishes that write and
+// tells every wave that stage j - 2's slot is free for the write of the boundary after it).
+struct WStream {
+  const uint4* __restrict__ g;
+  uint4* ring;
+  int t, n_tiles, lane, wave;
+  uint4 pf0, pf1, pf2;
+  __device__ __forceinline__ void issue(int stage) {
+    int tile = stage * STAGE_TILES + wave;
+    tile = tile < n_tiles ? tile : n_tiles - 1;
+    const uint4* p = g + (int64_t)tile * TILE_U4 + lane;
+    pf0 = p[0];
+    pf1 = p[64];
+    pf2 = p[128];
+  }
+  __device__ __forceinline__ void commit(int stage) {
+    uint4* q = ring + ((stage % RING_STAGES) * STAGE_TILES + wave) * TILE_U4 + lane;
+    q[0] = pf0;
+    q[64] = pf1;
+    q[128] = pf2;
+  }
+  __device__ __forceinline__ void init(const uint4* g_, uint4* ring_, int n_tiles_, int lane_, int wave_) {
+    g = g_;
+    ring = ring_;
+    n_tiles = n_tiles_;
+    lane = lane_;
+    wave = wave_;
+    t = 0;
+    issue(0);
+    commit(0);
+    issue(1);
+    commit(1);
+    NB_LDS_BARRIER();
+    issue(2);
+  }
+  __device__ __forceinline__ Frag next() {
+    if ((t & (STAGE_TILES - 1)) == 0 && t > 0) {
+      const int j = t / STAGE_TILES;
+      commit(j + 1);
+      NB_LDS_BARRIER();
+      issue(j + 2);
+    }
+    const uint4* q = ring + (((t / STAGE_TILES) % RING_STAGES) * STAGE_TILES + (t & (STAGE_TILES - 1))) * TILE_U4 + lane;
+    Frag f;
+    f.hi = __builtin_bit_cast(bf16x8, q[0]);
+    f.mid = __builtin_bit_cast(bf16x8, q[64]);
+    f.lo = __builtin_bit_cast(bf16x8, q[128]);
+    ++t;
+    return f;
+  }
+};
+
+// acc[ot] += W[ot-th row tile, this k tile] T for NOT output tiles and one 32-channel activation tile; program order (s, ot)
+template <int NOT>
+__device__ __forceinline__ void accum_tile(WStream& w, f32x16 (&acc)[NOT], const f32x16& T) {
+  const Frag f0 = split_k<0>(T);
+#pragma unroll
+  for (int ot = 0; ot < NOT; ++ot) mfma6(acc[ot], w.next(), f0);
+  const Frag f1 = split_k<1>(T);
+#pragma unroll
+  for (int ot = 0; ot < NOT; ++ot) mfma6(acc[ot], w.next(), f1);
+}
+
+// one output tile over NK k-steps whose fragments are resident; program order (k-step)
+template <int NK>
+__device__ __forceinline__ void out_tile(WStream& w, f32x16& acc, const Frag (&fx)[NK]) {
+#pragma unroll
+  for (int k = 0; k < NK; ++k) mfma6(acc, w.next(), fx[k]);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// 32 consecutive channels starting at c0 of a row-major row (or of a parameter vector) in accumulator layout:
+// register 4 g + e <-> channel c0 + 8 g + 4 h + e
+__device__ __forceinline__ f32x16 ld_tile(const float* __restrict__ row, int c0, int h) {
+  f32x16 t;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c0 + 8 * g + 4 * h);
+    t[4 * g] = v.x;
+    t[4 * g + 1] = v.y;
+    t[4 * g + 2] = v.z;
+    t[4 * g + 3] = v.w;
+  }
+  return t;
+}
+__device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, const f32x16& t, bool ok) {
+  if (!ok) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(row + c0 + 8 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+}
+// e3nn mul_ir rows (channel-major, m-minor): the DL components of 32 channels of one l > 0 block; `blk` = the block's first float
+// of the row + DL * 32 * tile
+template <int DL>
+__device__ __forceinline__ void ld_xm(const float* __restrict__ blk, int h, f32x16 (&X)[DL]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* p = blk + DL * (8 * g + 4 * h);
+    float flat[4 * DL];
+#pragma unroll
+    for (int q = 0; q < DL; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+      flat[4 * q] = v.x;
+      flat[4 * q + 1] = v.y;
+      flat[4 * q + 2] = v.z;
+      flat[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < DL; ++m) X[m][4 * g + e] = flat[DL * e + m];
+  }
+}
+template <int DL>
+__device__ __forceinline__ void st_xm(float* __restrict__ blk, int h, const f32x16 (&X)[DL], bool ok) {
+  if (!ok) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float* p = blk + DL * (8 * g + 4 * h);
+    float flat[4 * DL];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < DL; ++m) flat[DL * e + m] = X[m][4 * g + e];
+#pragma unroll
+    for (int q = 0; q < DL; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(flat[4 * q], flat[4 * q + 1], flat[4 * q + 2], flat[4 * q + 3]);
+  }
+}
+
+__device__ __forceinline__ float sum16(const f32x16& t) {
+  return (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) + (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+}
+__device__ __forceinline__ float sumsq16(const f32x16& t, float c) {
+  float a = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float d = t[r] - c;
+    a = __builtin_fmaf(d, d, a);
+  }
+  return a;
+}
+// the node's row lives in lanes n and n + 32
+__device__ __forceinline__ float row_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// exp: the library's expf (what the other node kernels evaluate; csrc/xeq_mlp.hip)
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {  // aten silu_backward: sig (1 + x (1 - sig))
+  const float sig = 1.f / (1.f + expf(-x));
+  return sig * (1.f + x * (1.f - sig));
+}
+
+// ------------------------------------------------------------------------------------------------ packed weight programs
+// A program is the list of weight tiles in the order a kernel consumes them, described by segments over source matrices.
+// Tile (o0, k0) of a source holds value(o0 + r, k0 + 8 (j >> 2) + 4 h + (j & 3)) in element j of lane (r = lane & 31, h = lane >> 5):
+// the k order of an accumulator tile used as the B operand (cdna_hip_programming.md, accumulator as the next operand).
+struct Seg {
+  int src;                      // source matrix
+  int o0, n_ot, o_stride;       // output (row) tiles: o0 + i o_stride, in units of 32
+  int k0, n_kt, k_stride;       // k tiles of 32 channels (two k-steps each)
+  int order;                    // 0: (kt, s, ot)   1: (ot, kt, s)
+};
+constexpr int MAX_SEGS = 56, MAX_SRCS = 8;
+struct Src {
+  const float* p;
+  int ld, transposed;   // value(o, k) = transposed ? p[k ld + o] : p[o ld + k]
+  float scale;
+};
+struct PackArgs {
+  Src src[MAX_SRCS];
+  Seg seg[MAX_SEGS];
+  int n_segs;
+  uint4* out;
+};
+
+__global__ void __launch_bounds__(64) k_nb_pack(PackArgs a) {
+  int tile = blockIdx.x, si = 0;
+  for (; si < a.n_segs; ++si) {
+    const int nt = a.seg[si].n_ot * a.seg[si].n_kt * 2;
+    if (tile < nt) break;
+    tile -= nt;
+  }
+  if (si >= a.n_segs) {   // padding tiles behind the program: zeros
+    for (int sp = 0; sp < 3; ++sp) a.out[(int64_t)blockIdx.x * TILE_U4 + sp * 64 + threadIdx.x] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const Seg sg = a.seg[si];
+  int ot, kt, s;
+  if (sg.order == 0) {
+    ot = tile % sg.n_ot;
+    s = (tile / sg.n_ot) & 1;
+    kt = tile / (2 * sg.n_ot);
+  } else {
+    s = tile & 1;
+    kt = (tile >> 1) % sg.n_kt;
+    ot = tile / (2 * sg.n_kt);
+  }
+  const Src sr = a.src[sg.src];
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int o = 32 * (sg.o0 + ot * sg.o_stride) + r;
+  const int kb = 32 * (sg.k0 + kt * sg.k_stride) + 16 * s;
+  uint32_t hi[8], mid[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kb + 8 * (j >> 2) + 4 * h + (j & 3);
+    const float v = (sr.transposed ? sr.p[(int64_t)k * sr.ld + o] : sr.p[(int64_t)o * sr.ld + k]) * sr.scale;
+    const __bf16 bh = (__bf16)v;
+    const float r1 = v - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    const __bf16 bl = (__bf16)r2;
+    hi[j] = __builtin_bit_cast(unsigned short, bh);
+    mid[j] = __builtin_bit_cast(unsigned short, bm);
+    lo[j] = __builtin_bit_cast(unsigned short, bl);
+  }
+  uint4* o4 = a.out + (int64_t)blockIdx.x * TILE_U4 + lane;
+  o4[0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+  o4[64] = make_uint4(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16), mid[4] | (mid[5] << 16), mid[6] | (mid[7] << 16));
+  o4[128] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+}
+
+static int seg_tiles(const std::vector<Seg>& v) {
+  int n = 0;
+  for (const Seg& s : v) n += s.n_ot * s.n_kt * 2;
+  return n;
+}
+static int padded_tiles(int n) { return (n + STAGE_TILES - 1) / STAGE_TILES * STAGE_TILES; }
+
+// forward sources: 0 W3 = update_mlp[0].weight [F, F + C]; 1..3 [W_U | W_V] / sqrt(mul_l) as [k_in = mul_l][n_out = 2 mul_l];
+// 4 dot_lin.weight [F, C]; 5 W4 = update_mlp[2].weight [AU, F]; 6 W1' = next scalar_mlp[0].weight [F, F]; 7 W2' = next scalar_mlp[2].weight [HM, F]
+enum { S_W3 = 0, S_UV0 = 1, S_UV1 = 2, S_UV2 = 3, S_DOT = 4, S_W4 = 5, S_W1N = 6, S_W2N = 7 };
+static void program_fwd(bool tail, std::vector<Seg>& p) {
+  p.clear();
+  p.push_back({S_W3, 0, 4, 1, 0, 4, 1, 0});                        // hidden += W3[:, shat]
+  for (int c = 0; c < 4; ++c) {                                     // l = 0: U_c, V_c over the 4 k tiles, then v_c, p_c
+    p.push_back({S_UV0, c, 2, M0 / 32, 0, 4, 1, 0});
+    p.push_back({S_W3, 0, 4, 1, 4 + c, 1, 1, 0});
+    p.push_back({S_DOT, 0, 4, 1, c, 1, 1, 0});
+  }
+  for (int m = 0; m < 3; ++m)                                       // l = 1: per m and channel tile
+    for (int c = 0; c < 2; ++c) p.push_back({S_UV1, c, 2, M1 / 32, 0, 2, 1, 0});
+  for (int c = 0; c < 2; ++c) {
+    p.push_back({S_W3, 0, 4, 1, 8 + c, 1, 1, 0});
+    p.push_back({S_DOT, 0, 4, 1, 4 + c, 1, 1, 0});
+  }
+  for (int m = 0; m < 5; ++m) p.push_back({S_UV2, 0, 2, M2 / 32, 0, 1, 1, 0});   // l = 2
+  p.push_back({S_W3, 0, 4, 1, 10, 1, 1, 0});
+  p.push_back({S_DOT, 0, 4, 1, 6, 1, 1, 0});
+  p.push_back({S_W4, 0, 7, 1, 0, 4, 1, 1});                        // a_vv tiles
+  for (int c = 0; c < 4; ++c) p.push_back({S_W4, 7 + c, 2, 4, 0, 4, 1, 1});   // (a_sv, a_ss) of scalar tile c
+  if (tail) {
+    p.push_back({S_W1N, 0, 4, 1, 0, 4, 1, 0});
+    p.push_back({S_W2N, 0, HM / 32, 1, 0, 4, 1, 1});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ test kernel
+// y = x W^T on the primitives above (both program orders): what tests/test_gpu_nodeblock.py checks the fragment maps, the split
+// arithmetic and the weight ring with.  x [n, 128], W [NOT * 32, 128]; form 0: accum_tile, form 1: out_tile.
+struct LinTestArgs {
+  const float* x;
+  int64_t n;
+  const uint4* wp;
+  int n_tiles, n_ot, form;
+  float* y;
+};
+__global__ void __launch_bounds__(256, 1) k_nb_linear_test(LinTestArgs a) {
+  extern __shared__ uint4 ring[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * 32 + n;
+  const bool ok = node < a.n;
+  const int64_t row = ok ? node : a.n - 1;
+  WStream w;
+  w.init(a.wp, ring, a.n_tiles, lane, wave);
+  const float* xr = a.x + row * 128;
+  float* yr = a.y + row * (32 * a.n_ot);
+  f32x16 X[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) X[t] = ld_tile(xr, 32 * t, h);
+  if (a.form == 0) {   // 4 output tiles, program (kt, s, ot)
+    f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accum_tile<4>(w, acc, X[t]);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) st_tile(yr, 32 * ot, h, acc[ot], ok);
+  } else {             // n_ot output tiles, program (ot, kt, s)
+    Frag fx[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fx[2 * t] = split_k<0>(X[t]);
+      fx[2 * t + 1] = split_k<1>(X[t]);
+    }
+    for (int ot = 0; ot < a.n_ot; ++ot) {
+      f32x16 acc = zero16();
+      out_tile<8>(w, acc, fx);
+      st_tile(yr, 32 * ot, h, acc, ok);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct FwdArgs {
+  int64_t n;
+  const float *s, *x;                    // block inputs [n, F], [n, D] (e3nn mul_ir)
+  const float *lnw, *lnb, *eqw, *eqb;    // norms of the update block
+  const float* b_uv;                     // [2 F]: update_U.bias | update_V.bias, or NULL
+  const float *b3, *b4;                  // update_mlp biases
+  float eps;                             // Invariant eps
+  const uint4* wp;                       // packed program
+  int n_tiles;
+  float *uv, *stats, *pre, *a, *ip;      // saved for the reverse pass: U|V pair buffer (BT), norm statistics, hidden pre-activation, update_mlp output, dot_lin output
+  float *s_out, *x_out;                  // block outputs (x_out may be NULL: no consumer)
+  // front half of the next message block (TAIL)
+  const float *lnw2, *lnb2, *eqw2, *eqb2, *b1n, *b2n;
+  float *stats2, *xhat2, *pre2, *h2;     // xhat2 in BT layout
+};
+
+template <bool TAIL>
+__global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
+  extern __shared__ uint4 ring[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * 32 + n;
+  const bool ok = node < a.n;
+  const int64_t row = ok ? node : a.n - 1;
+  const int64_t N = a.n;
+  WStream w;
+  w.init(a.wp, ring, a.n_tiles, lane, wave);
+  const float* __restrict__ srow = a.s + row * F;
+  const float* __restrict__ xrow = a.x + row * D;
+  const bool wx = a.x_out != nullptr;
+  const float e1 = a.eps, e2 = a.eps * a.eps;
+
+  f32x16 HID[4] = {zero16(), zero16(), zero16(), zero16()};   // update_mlp hidden pre-activation, accumulated chunk by chunk
+  f32x16 IP[4] = {zero16(), zero16(), zero16(), zero16()};    // dot_lin(p)
+  float mean, rstd, mean0, rr;
+
+  {  // ---- LayerNorm(s) (nn.LayerNorm: biased variance, eps 1e-5) -> first K chunk of update_mlp[0]
+    f32x16 S[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) S[t] = ld_tile(srow, 32 * t, h);
+    mean = row_sum((sum16(S[0]) + sum16(S[1])) + (sum16(S[2]) + sum16(S[3]))) * (1.f / F);
+    const float var = row_sum((sumsq16(S[0], mean) + sumsq16(S[1], mean)) + (sumsq16(S[2], mean) + sumsq16(S[3], mean))) * (1.f / F);
+    rstd = 1.f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 wv = ld_tile(a.lnw, 32 * t, h), bv = ld_tile(a.lnb, 32 * t, h);
+      f32x16 sh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sh[r] = (S[t][r] - mean) * rstd * wv[r] + bv[r];
+      accum_tile<4>(w, HID, sh);
+    }
+  }
+  // ---- EquivariantLayerNorm statistics (nn/o3layer.py:145-171): 0e channels centred, one rms over all channels
+  {
+    f32x16 X0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) X0[t] = ld_tile(xrow, 32 * t, h);
+    mean0 = row_sum((sum16(X0[0]) + sum16(X0[1])) + (sum16(X0[2]) + sum16(X0[3]))) * (1.f / M0);
+    float q = (sumsq16(X0[0], mean0) + sumsq16(X0[1], mean0)) + (sumsq16(X0[2], mean0) + sumsq16(X0[3], mean0));
+#pragma unroll
+    for (int t = 0; t < M1 / 32; ++t) {
+      f32x16 X[3];
+      ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
+      q += (sumsq16(X[0], 0.f) + sumsq16(X[1], 0.f)) + sumsq16(X[2], 0.f);
+    }
+    {
+      f32x16 X[5];
+      ld_xm<5>(xrow + M0 + 3 * M1, h, X);
+      q += ((sumsq16(X[0], 0.f) + sumsq16(X[1], 0.f)) + (sumsq16(X[2], 0.f) + sumsq16(X[3], 0.f))) + sumsq16(X[4], 0.f);
+    }
+    rr = 1.f / sqrtf(row_sum(q) * (1.f / C) + 1e-5f);
+    if (ok && h == 0) *reinterpret_cast<float4*>(a.stats + 4 * row) = make_float4(mean, rstd, mean0, rr);
+    // ---- l = 0: U, V (o3.Linear with bias), v = |V|, p = U V per channel tile
+    Frag fx[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 wv = ld_tile(a.eqw, 32 * t, h), bv = ld_tile(a.eqb, 32 * t, h);
+      f32x16 xh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xh[r] = (X0[t][r] - mean0) * rr * wv[r] + bv[r];
+      fx[2 * t] = split_k<0>(xh);
+      fx[2 * t + 1] = split_k<1>(xh);
+    }
+    float* __restrict__ uvr = a.uv + row * (2 * M0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x16 U = zero16(), V = zero16();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        mfma6(U, w.next(), fx[k]);
+        mfma6(V, w.next(), fx[k]);
+      }
+      if (a.b_uv) {
+        const f32x16 bu = ld_tile(a.b_uv, 32 * c, h), bv = ld_tile(a.b_uv + F, 32 * c, h);
+        U += bu;
+        V += bv;
+      }
+      st_tile(uvr, 32 * c, h, U, ok);
+      st_tile(uvr, M0 + 32 * c, h, V, ok);
+      f32x16 v, p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v[r] = sqrtf(__builtin_fmaf(V[r], V[r], e2)) - e1;
+        p[r] = U[r] * V[r];
+      }
+      accum_tile<4>(w, HID, v);
+      accum_tile<4>(w, IP, p);
+    }
+  }
+  {  // ---- l = 1
+    f32x16 X1[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X1[t]);
+      const f32x16 wv = ld_tile(a.eqw, M0 + 32 * t, h);
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X1[t][m][r] = X1[t][m][r] * rr * wv[r];
+    }
+    f32x16 VSQ[2] = {zero16(), zero16()}, PP[2] = {zero16(), zero16()};
+    float* __restrict__ uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      Frag fx[4] = {split_k<0>(X1[0][m]), split_k<1>(X1[0][m]), split_k<0>(X1[1][m]), split_k<1>(X1[1][m])};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f32x16 U = zero16(), V = zero16();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          mfma6(U, w.next(), fx[k]);
+          mfma6(V, w.next(), fx[k]);
+        }
+        st_tile(uvb + m * 2 * M1, 32 * c, h, U, ok);
+        st_tile(uvb + m * 2 * M1, M1 + 32 * c, h, V, ok);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          VSQ[c][r] = __builtin_fmaf(V[r], V[r], VSQ[c][r]);
+          PP[c][r] = __builtin_fmaf(U[r], V[r], PP[c][r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x16 v;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = sqrtf(VSQ[c][r] + e2) - e1;
+      accum_tile<4>(w, HID, v);
+      accum_tile<4>(w, IP, PP[c]);
+    }
+  }
+  {  // ---- l = 2
+    f32x16 X2[5];
+    ld_xm<5>(xrow + M0 + 3 * M1, h, X2);
+    const f32x16 wv = ld_tile(a.eqw, M0 + M1, h);
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X2[m][r] = X2[m][r] * rr * wv[r];
+    f32x16 VSQ = zero16(), PP = zero16();
+    float* __restrict__ uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      Frag fx[2] = {split_k<0>(X2[m]), split_k<1>(X2[m])};
+      f32x16 U = zero16(), V = zero16();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        mfma6(U, w.next(), fx[k]);
+        mfma6(V, w.next(), fx[k]);
+      }
+      st_tile(uvb + m * 2 * M2, 0, h, U, ok);
+      st_tile(uvb + m * 2 * M2, M2, h, V, ok);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        VSQ[r] = __builtin_fmaf(V[r], V[r], VSQ[r]);
+        PP[r] = __builtin_fmaf(U[r], V[r], PP[r]);
+      }
+    }
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = sqrtf(VSQ[r] + e2) - e1;
+    accum_tile<4>(w, HID, v);
+    accum_tile<4>(w, IP, PP);
+  }
+  // ---- hidden layer of update_mlp: bias, SiLU; dot_lin output kept for the scalar update
+  Frag fh[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    HID[t] += ld_tile(a.b3, 32 * t, h);
+    st_tile(a.pre + row * F, 32 * t, h, HID[t], ok);
+    st_tile(a.ip + row * F, 32 * t, h, IP[t], ok);
+    f32x16 hv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hv[r] = silu_f(HID[t][r]);
+    fh[2 * t] = split_k<0>(hv);
+    fh[2 * t + 1] = split_k<1>(hv);
+  }
+  float* __restrict__ arow = a.a + row * AU;
+  float* __restrict__ xor_ = wx ? a.x_out + row * D : nullptr;
+  float q2 = 0.f;      // TAIL: sum of squares of the new l > 0 features
+  f32x16 XN0[4];       // TAIL: new 0e features (two-pass statistics)
+  // ---- a_vv tiles and the equivariant residual update x_out = x + U a_vv (nn/xpainn.py:218-219, 229)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f32x16 av = zero16();
+    out_tile<8>(w, av, fh);
+    av += ld_tile(a.b4, 32 * c, h);
+    st_tile(arow, 32 * c, h, av, ok);
+    if (wx) {
+      const f32x16 U = ld_tile(a.uv + row * (2 * M0), 32 * c, h), X0 = ld_tile(xrow, 32 * c, h);
+      f32x16 xn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xn[r] = __builtin_fmaf(U[r], av[r], X0[r]);
+      st_tile(xor_, 32 * c, h, xn, ok);
+      if (TAIL) XN0[c] = xn;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    f32x16 av = zero16();
+    out_tile<8>(w, av, fh);
+    av += ld_tile(a.b4, M0 + 32 * c, h);
+    st_tile(arow, M0 + 32 * c, h, av, ok);
+    if (wx) {
+      f32x16 X[3];
+      ld_xm<3>(xrow + M0 + 3 * 32 * c, h, X);
+      const float* uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const f32x16 U = ld_tile(uvb + m * 2 * M1, 32 * c, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[m][r] = __builtin_fmaf(U[r], av[r], X[m][r]);
+        if (TAIL) q2 += sumsq16(X[m], 0.f);
+      }
+      st_xm<3>(xor_ + M0 + 3 * 32 * c, h, X, ok);
+    }
+  }
+  {
+    f32x16 av = zero16();
+    out_tile<8>(w, av, fh);
+    av += ld_tile(a.b4, M0 + M1, h);
+    st_tile(arow, M0 + M1, h, av, ok);
+    if (wx) {
+      f32x16 X[5];
+      ld_xm<5>(xrow + M0 + 3 * M1, h, X);
+      const float* uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const f32x16 U = ld_tile(uvb + m * 2 * M2, 0, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[m][r] = __builtin_fmaf(U[r], av[r], X[m][r]);
+        if (TAIL) q2 += sumsq16(X[m], 0.f);
+      }
+      st_xm<5>(xor_ + M0 + 3 * M1, h, X, ok);
+    }
+  }
+  // ---- (a_sv, a_ss) per scalar tile and the scalar residual update s_out = s + a_sv dot_lin(p) + a_ss (nn/xpainn.py:221-228)
+  f32x16 SN[4];
+  float* __restrict__ sor = a.s_out + row * F;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f32x16 asv = zero16(), ass = zero16();
+    out_tile<8>(w, asv, fh);
+    out_tile<8>(w, ass, fh);
+    asv += ld_tile(a.b4, C + 32 * c, h);
+    ass += ld_tile(a.b4, C + F + 32 * c, h);
+    st_tile(arow, C + 32 * c, h, asv, ok);
+    st_tile(arow, C + F + 32 * c, h, ass, ok);
+    const f32x16 S = ld_tile(srow, 32 * c, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) SN[c][r] = (S[r] + asv[r] * IP[c][r]) + ass[r];
+    st_tile(sor, 32 * c, h, SN[c], ok);
+  }
+  if (!TAIL) return;
+
+  // ======== front half of the next message block (nn/xpainn.py:128-139): both norms of (s_out, x_out), scalar_mlp
+  const float mean_n = row_sum((sum16(SN[0]) + sum16(SN[1])) + (sum16(SN[2]) + sum16(SN[3]))) * (1.f / F);
+  const float var_n = row_sum((sumsq16(SN[0], mean_n) + sumsq16(SN[1], mean_n)) + (sumsq16(SN[2], mean_n) + sumsq16(SN[3], mean_n))) * (1.f / F);
+  const float rstd_n = 1.f / sqrtf(var_n + 1e-5f);
+  f32x16 HN[4] = {zero16(), zero16(), zero16(), zero16()};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 wv = ld_tile(a.lnw2, 32 * t, h), bv = ld_tile(a.lnb2, 32 * t, h);
+    f32x16 sh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sh[r] = (SN[t][r] - mean_n) * rstd_n * wv[r] + bv[r];
+    accum_tile<4>(w, HN, sh);
+  }
+  const float mean0_n = row_sum((sum16(XN0[0]) + sum16(XN0[1])) + (sum16(XN0[2]) + sum16(XN0[3]))) * (1.f / M0);
+  const float qn = q2 + ((sumsq16(XN0[0], mean0_n) + sumsq16(XN0[1], mean0_n)) + (sumsq16(XN0[2], mean0_n) + sumsq16(XN0[3], mean0_n)));
+  const float rr_n = 1.f / sqrtf(row_sum(qn) * (1.f / C) + 1e-5f);
+  if (ok && h == 0) *reinterpret_cast<float4*>(a.stats2 + 4 * row) = make_float4(mean_n, rstd_n, mean0_n, rr_n);
+  // xhat of the next block, BT layout: block l at N base_l, row (node, m), channels contiguous
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 wv = ld_tile(a.eqw2, 32 * t, h), bv = ld_tile(a.eqb2, 32 * t, h);
+    f32x16 xh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xh[r] = (XN0[t][r] - mean0_n) * rr_n * wv[r] + bv[r];
+    st_tile(a.xhat2 + row * M0, 32 * t, h, xh, ok);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f32x16 X[3];
+    ld_xm<3>(xor_ + M0 + 3 * 32 * t, h, X);   // this lane's own stores of a moment ago
+    const f32x16 wv = ld_tile(a.eqw2, M0 + 32 * t, h);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[m][r] = X[m][r] * rr_n * wv[r];
+      st_tile(a.xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h, X[m], ok);
+    }
+  }
+  {
+    f32x16 X[5];
+    ld_xm<5>(xor_ + M0 + 3 * M1, h, X);
+    const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[m][r] = X[m][r] * rr_n * wv[r];
+      st_tile(a.xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h, X[m], ok);
+    }
+  }
+  Frag fn[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    HN[t] += ld_tile(a.b1n, 32 * t, h);
+    st_tile(a.pre2 + row * F, 32 * t, h, HN[t], ok);
+    f32x16 hv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hv[r] = silu_f(HN[t][r]);
+    fn[2 * t] = split_k<0>(hv);
+    fn[2 * t + 1] = split_k<1>(hv);
+  }
+  float* __restrict__ hrow = a.h2 + row * HM;
+  for (int ot = 0; ot < HM / 32; ++ot) {
+    f32x16 acc = zero16();
+    out_tile<8>(w, acc, fn);
+    acc += ld_tile(a.b2n, 32 * ot, h);
+    st_tile(hrow, 32 * ot, h, acc, ok);
+  }
+}
+
+static bool shape_ok(int node_dim, const int32_t mul[3]) { return node_dim == F && mul[0] == M0 && mul[1] == M1 && mul[2] == M2; }
+
+}  // namespace nb
+}  // namespace xeq
+
+using namespace xeq;
+using namespace xeq::nb;
+
+extern "C" {
+
+int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]) { return dtype == XEQ_F32 && mul && shape_ok(node_dim, mul); }
+
+/* tiles (3 KB each) of the packed forward program: kind 0 with the next message block's front half, 1 without */
+int64_t xeq_node_block_fwd_tiles(int with_tail) {
+  std::vector<Seg> p;
+  program_fwd(with_tail != 0, p);
+  return padded_tiles(seg_tiles(p));
+}
+
+static int run_pack(const std::vector<Seg>& p, const Src* srcs, int n_srcs, void* out, void* stream, const char* who) {
+  XEQ_CHECK_ARG((int)p.size() <= MAX_SEGS && n_srcs <= MAX_SRCS, "%s: program too long", who);
+  PackArgs pa;
+  for (int i = 0; i < n_srcs; ++i) pa.src[i] = srcs[i];
+  for (int i = n_srcs; i < MAX_SRCS; ++i) pa.src[i] = Src{nullptr, 0, 0, 0.f};
+  for (size_t i = 0; i < p.size(); ++i) pa.seg[i] = p[i];
+  pa.n_segs = (int)p.size();
+  pa.out = (uint4*)out;
+  const int tiles = padded_tiles(seg_tiles(p));
+  hipLaunchKernelGGL(k_nb_pack, dim3(tiles), dim3(64), 0, (hipStream_t)stream, pa);
+  XEQ_CHECK_LAUNCH(who);
+  return XEQ_OK;
+}
+
+/* Packed forward program of one update block (+ the next message block's scalar_mlp when w1n / w2n are given).
+ * w3 [F, F + C], uv_l = [W_U | W_V] / sqrt(mul_l) as [mul_l, 2 mul_l] (nn/fused.py::_packed_uv), dot [F, C], w4 [C + 2 F, F],
+ * w1n [F, F], w2n [F + 2 C, F]: all row-major contiguous f32.  out: xeq_node_block_fwd_tiles(..) * 3072 bytes. */
+int xeq_node_block_pack_fwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,
+                            const float* w1n, const float* w2n, void* out, void* stream) {
+  XEQ_CHECK_ARG(w3 && uv0 && uv1 && uv2 && dot && w4 && out && ((w1n == nullptr) == (w2n == nullptr)), "xeq_node_block_pack_fwd: null buffer");
+  const bool tail = w1n != nullptr;
+  std::vector<Seg> p;
+  program_fwd(tail, p);
+  const Src srcs[8] = {{w3, F + C, 0, 1.f}, {uv0, 2 * M0, 1, 1.f}, {uv1, 2 * M1, 1, 1.f}, {uv2, 2 * M2, 1, 1.f},
+                       {dot, C, 0, 1.f},    {w4, F, 0, 1.f},       {w1n, F, 0, 1.f},      {w2n, F, 0, 1.f}};
+  return run_pack(p, srcs, 8, out, stream, "xeq_node_block_pack_fwd");
+}
+
+/* XPainnUpdate.forward (nn/xpainn.py:206-231) and, when h_next is given, the front half of the next XPainnMessage.forward
+ * (nn/xpainn.py:128-139) in one launch.  Saved for the reverse pass in the layouts the older kernels use: uv_bt (U|V pair buffer),
+ * stats [n, 4], pre [n, F], a [n, C + 2 F], ip [n, F]; outputs s_out, x_out (NULL: the equivariant output has no consumer);
+ * next block: stats_next [n, 4], xhat_next (BT), pre_next [n, F], h_next [n, F + 2 C]. */
+int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* ln_w, const float* ln_b, const float* eq_w, const float* eq_b,
+                       const float* b_uv, const float* b3, const float* b4, double eps, const void* packed, float* uv_bt, float* stats,
+                       float* pre, float* a, float* ip, float* s_out, float* x_out, const float* ln_w_next, const float* ln_b_next,
+                       const float* eq_w_next, const float* eq_b_next, const float* b1_next, const float* b2_next, float* stats_next,
+                       float* xhat_next, float* pre_next, float* h_next, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) / (2 * D), "xeq_node_block_fwd: n = %lld out of range", (long long)n);
+  if (n == 0) return XEQ_OK;
+  const bool tail = h_next != nullptr;
+  XEQ_CHECK_ARG(s && x && ln_w && ln_b && eq_w && eq_b && b3 && b4 && packed && uv_bt && stats && pre && a && ip && s_out,
+                "xeq_node_block_fwd: null buffer");
+  XEQ_CHECK_ARG(!tail || (x_out && ln_w_next && ln_b_next && eq_w_next && eq_b_next && b1_next && b2_next && stats_next && xhat_next && pre_next),
+                "xeq_node_block_fwd: null buffer (next block)");
+  FwdArgs fa;
+  fa.n = n; fa.s = s; fa.x = x; fa.lnw = ln_w; fa.lnb = ln_b; fa.eqw = eq_w; fa.eqb = eq_b; fa.b_uv = b_uv; fa.b3 = b3; fa.b4 = b4;
+  fa.eps = (float)eps; fa.wp = (const uint4*)packed; fa.n_tiles = (int)xeq_node_block_fwd_tiles(tail);
+  fa.uv = uv_bt; fa.stats = stats; fa.pre = pre; fa.a = a; fa.ip = ip; fa.s_out = s_out; fa.x_out = x_out;
+  fa.lnw2 = ln_w_next; fa.lnb2 = ln_b_next; fa.eqw2 = eq_w_next; fa.eqb2 = eq_b_next; fa.b1n = b1_next; fa.b2n = b2_next;
+  fa.stats2 = stats_next; fa.xhat2 = xhat_next; fa.pre2 = pre_next; fa.h2 = h_next;
+  const dim3 grid((unsigned)((n + ROWS_WG - 1) / ROWS_WG));
+  if (tail) hipLaunchKernelGGL(k_node_block_fwd<true>, grid, dim3(256), RING_BYTES, (hipStream_t)stream, fa);
+  else hipLaunchKernelGGL(k_node_block_fwd<false>, grid, dim3(256), RING_BYTES, (hipStream_t)stream, fa);
+  XEQ_CHECK_LAUNCH("xeq_node_block_fwd");
+  return XEQ_OK;
+}
+
+/* development / test entry: y = x W^T through the kernel primitives (x [n, 128], W [32 n_ot, 128]); form 0 needs n_ot = 4 */
+int xeq_node_block_linear_test(const float* x, int64_t n, const float* w, int n_ot, int form, void* packed_scratch, float* y, void* stream) {
+  XEQ_CHECK_ARG(x && w && packed_scratch && y && n > 0 && n_ot > 0 && n_ot <= 18 && (form == 1 || n_ot == 4), "xeq_node_block_linear_test: bad arguments");
+  std::vector<Seg> p;
+  p.push_back({0, 0, n_ot, 1, 0, 4, 1, form});
+  const Src srcs[1] = {{w, 128, 0, 1.f}};
+  if (int rc = run_pack(p, srcs, 1, packed_scratch, stream, "xeq_node_block_linear_test")) return rc;
+  LinTestArgs la{x, n, (const uint4*)packed_scratch, padded_tiles(seg_tiles(p)), n_ot, form, y};
+  hipLaunchKernelGGL(k_nb_linear_test, dim3((unsigned)((n + ROWS_WG - 1) / ROWS_WG)), dim3(256), RING_BYTES, (hipStream_t)stream, la);
+  XEQ_CHECK_LAUNCH("xeq_node_block_linear_test");
+  return XEQ_OK;
+}
+
+}  // extern "C"
