@@ -600,16 +600,31 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
  * packed: xeq_node_block_pack_fwd(update_mlp[0].weight [F, F + C], [W_U | W_V] / sqrt(mul_l) as [mul_l, 2 mul_l] for l = 0, 1, 2,
  * dot_lin.weight [F, C], update_mlp[2].weight [C + 2 F, F], next scalar_mlp[0].weight [F, F] and [2].weight [F + 2 C, F] (both
  * NULL: without the next block), out, stream); out holds xeq_node_block_fwd_tiles(with_tail) * 3072 bytes.
- * b_uv = [update_U.bias | update_V.bias] ([2 F]) or NULL. */
+ * b_uv = [update_U.bias | update_V.bias] ([2 F]) or NULL; p_scratch: [n, C] floats (EquivariantDot(U, V), read back by dot_lin). */
 int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]);
 int64_t xeq_node_block_fwd_tiles(int with_tail);
 int xeq_node_block_pack_fwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,
                             const float* w1_next, const float* w2_next, void* out, void* stream);
 int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* ln_w, const float* ln_b, const float* eq_w, const float* eq_b,
-                       const float* b_uv, const float* b3, const float* b4, double eps, const void* packed, float* uv_bt, float* stats,
+                       const float* b_uv, const float* b3, const float* b4, double eps, const void* packed, float* p_scratch, float* uv_bt, float* stats,
                        float* pre, float* a, float* ip, float* s_out, float* x_out, const float* ln_w_next, const float* ln_b_next,
                        const float* eq_w_next, const float* eq_b_next, const float* b1_next, const float* b2_next, float* stats_next,
                        float* xhat_next, float* pre_next, float* h_next, void* stream);
+/* Reverse of xeq_node_block_fwd for a force evaluation (input gradients only, nn/basic.py:143-159): replaces xeq_mlp2_bwd + xeq_norm_bwd
+ * of the next message block and xeq_update_out_bwd + xeq_linear_fwd (dot_lin^T) + xeq_mlp2_bwd + xeq_update_uv_bwd + xeq_norm_bwd of the
+ * update block.  With the next block's front half (g_h != NULL): g_h [n, F + 2 C] and g_xhat_next (BT) are the gradients of h_next /
+ * xhat_next, g_s_in / g_x_in the gradients that reach s_out / x_out directly (the message kernel's residual path), and s_out, x_out,
+ * stats_next, pre_next what the forward launch wrote.  Without it: g_s_in = dL/ds_out, g_x_in = dL/dx_out or NULL (zero: the last
+ * block of a force evaluation; packed with with_gx = 0).  Scratch (caller-owned): gxo [n, D] (front half only), gp [n, C], gv [n, C],
+ * gw [n, D].  Output: g_s [n, F], g_x [n, D].  packed: xeq_node_block_pack_bwd of the same weight tensors as the forward pack. */
+int64_t xeq_node_block_bwd_tiles(int with_tail, int with_gx);
+int xeq_node_block_pack_bwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,
+                            const float* w1_next, const float* w2_next, int with_gx, void* out, void* stream);
+int xeq_node_block_bwd(int64_t n, const float* g_h, const float* g_xhat_next, const float* g_s_in, const float* g_x_in, const float* s_out,
+                       const float* x_out, const float* stats_next, const float* pre_next, const float* ln_w_next, const float* eq_w_next,
+                       const float* uv_bt, const float* a, const float* ip, const float* pre, const float* s, const float* x,
+                       const float* stats, const float* ln_w, const float* eq_w, double eps, const void* packed, float* gxo, float* gp,
+                       float* gv, float* gw, float* g_s, float* g_x, void* stream);
 /* test entry: y [n, 32 n_ot] = x [n, 128] W^T (W [32 n_ot, 128]) through the kernel's primitives; form 0 (n_ot = 4): chunk
  * accumulation, form 1: one output tile at a time; packed_scratch: 8 n_ot * 3072 bytes */
 int xeq_node_block_linear_test(const float* x, int64_t n, const float* w, int n_ot, int form, void* packed_scratch, float* y, void* stream);

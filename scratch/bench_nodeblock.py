@@ -1,6 +1,6 @@
 """Time the fused node-block forward kernel at QM9-1024 size (N = 18 609) and a few other sizes."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.test_gpu_nodeblock import _modules, F, D
 from xequinet_amd.nn import nodeblock
 

@@ -38,7 +38,7 @@ def _close(name, got, ref, tol):
     return err / scale
 
 
-@pytest.mark.parametrize("form,n_ot", [(0, 4), (1, 4), (1, 7), (1, 18)])
+@pytest.mark.parametrize("form,n_ot", [(0, 4), (1, 4), (1, 7), (1, 18), (2, 4), (2, 18)])
 @pytest.mark.parametrize("n", [1, 77, 128, 300])
 def test_linear_primitives(form, n_ot, n):
     """Fragment maps, three-way split arithmetic and the weight ring: y = x W^T with asymmetric random operands."""
@@ -171,3 +171,70 @@ def test_node_block_forward_rows_do_not_depend_on_the_batch():
     torch.cuda.synchronize()
     for k in ("s_out", "x_out", "h2", "pre2", "a", "ip", "pre"):
         assert torch.equal(full[k][37:171], part[k]), k
+
+
+def _reference_diff(upd, msg, s, x):
+    """The same restatement as a differentiable f64 function of (s, x) -> (s_out, x_out[, h2, xhat2 (e3nn layout)])."""
+    from oracle import xpainn_oracle as orc
+
+    sd = {k: v.detach().double().cpu() for k, v in upd.state_dict().items()}
+    shat = F_.layer_norm(s, (F,), sd["norm.weight"], sd["norm.bias"], 1e-5)
+    xhat = orc.equivariant_layer_norm(IRREPS, x, sd["o3norm.affine_weight"], sd["o3norm.affine_bias"])
+    U = orc.o3_linear(IRREPS, xhat, sd["update_U.weight"], sd["update_U.bias"])
+    V = orc.o3_linear(IRREPS, xhat, sd["update_V.weight"], sd["update_V.bias"])
+    v = orc.invariant(IRREPS, V, eps=upd.invariant.eps)
+    a = F_.linear(F_.silu(F_.linear(torch.cat([shat, v], -1), sd["update_mlp.0.weight"], sd["update_mlp.0.bias"])),
+                  sd["update_mlp.2.weight"], sd["update_mlp.2.bias"])
+    a_vv, a_sv, a_ss = torch.split(a, [C, F, F], dim=-1)
+    ip = F_.linear(orc.equivariant_dot(IRREPS, U, V), sd["dot_lin.weight"])
+    s2 = s + a_sv * ip + a_ss
+    x2 = x + orc.elementwise_tp(IRREPS, U, a_vv)
+    if msg is None:
+        return s2, x2
+    md = {k: v.detach().double().cpu() for k, v in msg.state_dict().items()}
+    shat2 = F_.layer_norm(s2, (F,), md["norm.weight"], md["norm.bias"], 1e-5)
+    xhat2 = orc.equivariant_layer_norm(IRREPS, x2, md["o3norm.affine_weight"], md["o3norm.affine_bias"])
+    h2 = F_.linear(F_.silu(F_.linear(shat2, md["scalar_mlp.0.weight"], md["scalar_mlp.0.bias"])), md["scalar_mlp.2.weight"],
+                   md["scalar_mlp.2.bias"])
+    return s2, x2, h2, xhat2
+
+
+def _mulir_to_bt(t):
+    """[n, D] e3nn layout -> flat BT buffer"""
+    n = t.shape[0]
+    parts, off = [], 0
+    for l, mul in enumerate(MUL):
+        d = 2 * l + 1
+        parts.append(t[:, off:off + mul * d].reshape(n, mul, d).permute(0, 2, 1).reshape(-1))
+        off += mul * d
+    return torch.cat(parts)
+
+
+@pytest.mark.parametrize("n", [5, 128, 333])
+@pytest.mark.parametrize("mode", ["tail", "gx", "last"])
+def test_node_block_backward_matches_f64_autograd(n, mode):
+    from xequinet_amd.nn import nodeblock
+
+    upd, msg = _modules(21)
+    upd, msg = upd.to(_dev()), msg.to(_dev())
+    tail = mode == "tail"
+    torch.manual_seed(200 + n)
+    s = torch.randn(n, F, device=_dev()) * 1.5 + 0.2
+    x = torch.randn(n, D, device=_dev()) * 0.8
+    saved = nodeblock.node_block_fwd(s, x, upd, msg if tail else None, want_x=True)
+    g_s_in = torch.randn(n, F, device=_dev())
+    g_x_in = torch.randn(n, D, device=_dev()) if mode != "last" else None
+    g_h = torch.randn(n, F + 2 * C, device=_dev()) if tail else None
+    g_xh = torch.randn(n, D, device=_dev()) if tail else None        # e3nn layout; handed over in BT
+    g_s, g_x = nodeblock.node_block_bwd(saved, s, x, upd, msg if tail else None, g_s_in, g_x_in,
+                                        g_h, _mulir_to_bt(g_xh) if tail else None)
+    torch.cuda.synchronize()
+    sd_, xd_ = s.double().cpu().requires_grad_(), x.double().cpu().requires_grad_()
+    outs = _reference_diff(upd, msg if tail else None, sd_, xd_)
+    cot = [g_s_in.double().cpu(), g_x_in.double().cpu() if g_x_in is not None else torch.zeros(n, D, dtype=torch.float64)]
+    if tail:
+        cot += [g_h.double().cpu(), g_xh.double().cpu()]
+    ref_s, ref_x = torch.autograd.grad(outs, (sd_, xd_), cot)
+    e1 = _close("g_s", g_s, ref_s, 2e-5)   # f32 chain; 1 / |V| of the invariant conditions the tail
+    e2 = _close("g_x", g_x, ref_x, 2e-5)
+    print(f"relative errors: g_s {e1:.1e}, g_x {e2:.1e}")

@@ -42,10 +42,40 @@ constexpr int HM = F + 2 * C;    // scalar_mlp output (576)
 constexpr int AU = C + 2 * F;    // update_mlp output (480)
 constexpr int ROWS_WG = 128;     // 4 waves x 32 nodes
 constexpr int TILE_U4 = 192;     // one packed weight tile: 3 splits x 64 lanes x 16 B
-constexpr int RING_STAGES = 3, STAGE_TILES = 4;
+#ifndef XEQ_NB_STAGE
+#define XEQ_NB_STAGE 4
+#endif
+constexpr int RING_STAGES = 3, STAGE_TILES = XEQ_NB_STAGE;   // tiles per stage: a multiple of 4 (each wave fetches STAGE_TILES / 4 tiles of a stage)
+constexpr int PF = STAGE_TILES / 4;
 constexpr int RING_BYTES = RING_STAGES * STAGE_TILES * TILE_U4 * 16;
 
 #define NB_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Development aid (-DXEQ_NB_STAMPS): core-clock stamps at the phase boundaries of the forward / reverse kernels, per (workgroup, wave)
+// (cdna_hip_programming.md section 7, in-kernel stamps).  Read back through xeq_node_block_debug_stamps.
+constexpr int NB_STAMPS = 24;
+__device__ unsigned long long g_nb_stamps[1024 * 4 * NB_STAMPS];
+#ifdef XEQ_NB_STAMPS
+#define NB_STAMP(i)                                                                                          \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    unsigned long long t_;                                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                               \
+    if (lane == 0 && blockIdx.x < 1024) g_nb_stamps[((int)blockIdx.x * 4 + wave) * NB_STAMPS + (i)] = t_;    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+#define NB_RSTAMP(i)                                                                                         \
+  do {                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    unsigned long long t_;                                                                                   \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+    if (lane == 0 && blockIdx.x < 1024) g_nb_stamps[((int)blockIdx.x * 4 + wave) * NB_STAMPS + (i)] = t_;    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+#else
+#define NB_STAMP(i)
+#define NB_RSTAMP(i)
+#endif
 
 struct Frag {   // one k-step (16 channels) of an operand, split three ways
   bf16x8 hi, mid, lo;
@@ -83,20 +113,37 @@ struct WStream {
   const uint4* __restrict__ g;
   uint4* ring;
   int t, n_tiles, lane, wave;
-  uint4 pf0, pf1, pf2;
+  uint4 pf[PF][3];
+  Frag cur, nxt;   // fragments of tiles t and t + 1, read from LDS two calls ahead of their use (one wave per SIMD: nothing else hides the LDS latency)
   __device__ __forceinline__ void issue(int stage) {
-    int tile = stage * STAGE_TILES + wave;
-    tile = tile < n_tiles ? tile : n_tiles - 1;
-    const uint4* p = g + (int64_t)tile * TILE_U4 + lane;
-    pf0 = p[0];
-    pf1 = p[64];
-    pf2 = p[128];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      int tile = stage * STAGE_TILES + 4 * i + wave;
+      tile = tile < n_tiles ? tile : n_tiles - 1;
+#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 4   // experiment: always the same four tiles (vector-L1 hits)
+      tile = wave;
+#endif
+      const uint4* p = g + (int64_t)tile * TILE_U4 + lane;
+      pf[i][0] = p[0];
+      pf[i][1] = p[64];
+      pf[i][2] = p[128];
+    }
   }
   __device__ __forceinline__ void commit(int stage) {
-    uint4* q = ring + ((stage % RING_STAGES) * STAGE_TILES + wave) * TILE_U4 + lane;
-    q[0] = pf0;
-    q[64] = pf1;
-    q[128] = pf2;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      uint4* q = ring + ((stage % RING_STAGES) * STAGE_TILES + 4 * i + wave) * TILE_U4 + lane;
+      q[0] = pf[i][0];
+      q[64] = pf[i][1];
+      q[128] = pf[i][2];
+    }
+  }
+  __device__ __forceinline__ void read(int tile) {   // -> nxt
+    const uint4* q = ring + (((tile / STAGE_TILES) % RING_STAGES) * STAGE_TILES + (tile & (STAGE_TILES - 1))) * TILE_U4 + lane;
+    nxt.hi = __builtin_bit_cast(bf16x8, q[0]);
+    nxt.mid = __builtin_bit_cast(bf16x8, q[64]);
+    nxt.lo = __builtin_bit_cast(bf16x8, q[128]);
+    __builtin_amdgcn_sched_barrier(0);   // nothing crosses: the reads are issued in front of the products of the two tiles before
   }
   __device__ __forceinline__ void init(const uint4* g_, uint4* ring_, int n_tiles_, int lane_, int wave_) {
     g = g_;
@@ -111,21 +158,36 @@ struct WStream {
     commit(1);
     NB_LDS_BARRIER();
     issue(2);
+    __builtin_amdgcn_sched_barrier(0);
+    read(0);
+    cur = nxt;
+    read(1);
   }
+  // the fragments of the next tile of the program.  At a stage boundary (the tile handed out was the last of its stage) the fetched
+  // stage is written to LDS, the barrier publishes it and frees the oldest slot, and the fetch of the stage after it is issued.
+  // Tiles t + 1 and t + 2 are on their way from LDS meanwhile (their stages were published one boundary earlier).
   __device__ __forceinline__ Frag next() {
-    if ((t & (STAGE_TILES - 1)) == 0 && t > 0) {
+    const Frag r = cur;
+    cur = nxt;
+    ++t;
+#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 1   // experiment: no LDS reads, no stage boundaries
+    return r;
+#endif
+#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 2   // experiment: LDS reads, no stage boundaries
+    read((t + 1) & 7);
+    return r;
+#endif
+    if ((t & (STAGE_TILES - 1)) == 0) {
       const int j = t / STAGE_TILES;
       commit(j + 1);
       NB_LDS_BARRIER();
+#if !(defined(XEQ_NB_EXP) && XEQ_NB_EXP == 3)   // experiment 3: no fetch
       issue(j + 2);
+#endif
+      __builtin_amdgcn_sched_barrier(0);   // the fetch stays HERE, a whole stage ahead of its commit (the scheduler otherwise sinks it to its use)
     }
-    const uint4* q = ring + (((t / STAGE_TILES) % RING_STAGES) * STAGE_TILES + (t & (STAGE_TILES - 1))) * TILE_U4 + lane;
-    Frag f;
-    f.hi = __builtin_bit_cast(bf16x8, q[0]);
-    f.mid = __builtin_bit_cast(bf16x8, q[64]);
-    f.lo = __builtin_bit_cast(bf16x8, q[128]);
-    ++t;
-    return f;
+    read(t + 1);
+    return r;
   }
 };
 
@@ -145,6 +207,33 @@ template <int NK>
 __device__ __forceinline__ void out_tile(WStream& w, f32x16& acc, const Frag (&fx)[NK]) {
 #pragma unroll
   for (int k = 0; k < NK; ++k) mfma6(acc, w.next(), fx[k]);
+}
+
+// two accumulators fed from two weight tiles against the same operand fragment, products interleaved: a dependent
+// v_mfma_f32_32x32x16_bf16 does not issue back to back (measured: 55 cycles per product in a single chain, 32 when two chains alternate)
+__device__ __forceinline__ void mfma6x2(f32x16& a0, f32x16& a1, const Frag& w0, const Frag& w1, const Frag& x) {
+  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.lo, x.hi, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.lo, x.hi, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, x.lo, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, x.lo, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.mid, x.mid, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.mid, x.mid, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.mid, x.hi, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.mid, x.hi, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, x.mid, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, x.mid, a1, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, x.hi, a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, x.hi, a1, 0, 0, 0);
+}
+// two output tiles over NK resident k-steps; program order (k-step, tile of the pair)
+template <int NK>
+__device__ __forceinline__ void out_pair(WStream& w, f32x16& a0, f32x16& a1, const Frag (&fx)[NK]) {
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const Frag w0 = w.next();
+    const Frag w1 = w.next();
+    mfma6x2(a0, a1, w0, w1, fx[k]);
+  }
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -308,7 +397,7 @@ static int seg_tiles(const std::vector<Seg>& v) {
   for (const Seg& s : v) n += s.n_ot * s.n_kt * 2;
   return n;
 }
-static int padded_tiles(int n) { return (n + STAGE_TILES - 1) / STAGE_TILES * STAGE_TILES; }
+static int padded_tiles(int n) { return (n + STAGE_TILES - 1) / STAGE_TILES * STAGE_TILES + STAGE_TILES; }   // + one stage of zeros: the lookahead read
 
 // forward sources: 0 W3 = update_mlp[0].weight [F, F + C]; 1..3 [W_U | W_V] / sqrt(mul_l) as [k_in = mul_l][n_out = 2 mul_l];
 // 4 dot_lin.weight [F, C]; 5 W4 = update_mlp[2].weight [AU, F]; 6 W1' = next scalar_mlp[0].weight [F, F]; 7 W2' = next scalar_mlp[2].weight [HM, F]
@@ -319,18 +408,14 @@ static void program_fwd(bool tail, std::vector<Seg>& p) {
   for (int c = 0; c < 4; ++c) {                                     // l = 0: U_c, V_c over the 4 k tiles, then v_c, p_c
     p.push_back({S_UV0, c, 2, M0 / 32, 0, 4, 1, 0});
     p.push_back({S_W3, 0, 4, 1, 4 + c, 1, 1, 0});
-    p.push_back({S_DOT, 0, 4, 1, c, 1, 1, 0});
   }
   for (int m = 0; m < 3; ++m)                                       // l = 1: per m and channel tile
     for (int c = 0; c < 2; ++c) p.push_back({S_UV1, c, 2, M1 / 32, 0, 2, 1, 0});
-  for (int c = 0; c < 2; ++c) {
-    p.push_back({S_W3, 0, 4, 1, 8 + c, 1, 1, 0});
-    p.push_back({S_DOT, 0, 4, 1, 4 + c, 1, 1, 0});
-  }
+  for (int c = 0; c < 2; ++c) p.push_back({S_W3, 0, 4, 1, 8 + c, 1, 1, 0});
   for (int m = 0; m < 5; ++m) p.push_back({S_UV2, 0, 2, M2 / 32, 0, 1, 1, 0});   // l = 2
   p.push_back({S_W3, 0, 4, 1, 10, 1, 1, 0});
-  p.push_back({S_DOT, 0, 4, 1, 6, 1, 1, 0});
   p.push_back({S_W4, 0, 7, 1, 0, 4, 1, 1});                        // a_vv tiles
+  p.push_back({S_DOT, 0, 4, 1, 0, 7, 1, 0});                       // dot_lin over the seven p tiles
   for (int c = 0; c < 4; ++c) p.push_back({S_W4, 7 + c, 2, 4, 0, 4, 1, 1});   // (a_sv, a_ss) of scalar tile c
   if (tail) {
     p.push_back({S_W1N, 0, 4, 1, 0, 4, 1, 0});
@@ -355,6 +440,8 @@ __global__ void __launch_bounds__(256, 1) k_nb_linear_test(LinTestArgs a) {
   const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * 32 + n;
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
+  NB_STAMP(0);
+  NB_RSTAMP(4);
   WStream w;
   w.init(a.wp, ring, a.n_tiles, lane, wave);
   const float* xr = a.x + row * 128;
@@ -375,11 +462,30 @@ __global__ void __launch_bounds__(256, 1) k_nb_linear_test(LinTestArgs a) {
       fx[2 * t] = split_k<0>(X[t]);
       fx[2 * t + 1] = split_k<1>(X[t]);
     }
+    NB_STAMP(1);
+    if (a.form == 2) {   // pairs of output tiles, program (pair; kt, s, member)
+      for (int ot = 0; ot < a.n_ot; ot += 2) {
+        f32x16 a0 = zero16(), a1 = zero16();
+        out_pair<8>(w, a0, a1, fx);
+#ifdef XEQ_NB_TEST_NOSTORE
+        if (a0[0] == 12345.678f) { st_tile(yr, 32 * ot, h, a0, ok); st_tile(yr, 32 * ot + 32, h, a1, ok); }
+#else
+        st_tile(yr, 32 * ot, h, a0, ok);
+        st_tile(yr, 32 * ot + 32, h, a1, ok);
+#endif
+      }
+    } else
     for (int ot = 0; ot < a.n_ot; ++ot) {
       f32x16 acc = zero16();
       out_tile<8>(w, acc, fx);
+#ifdef XEQ_NB_TEST_NOSTORE
+      if (acc[0] == 12345.678f) st_tile(yr, 32 * ot, h, acc, ok);
+#else
       st_tile(yr, 32 * ot, h, acc, ok);
+#endif
     }
+    NB_STAMP(2);
+    NB_RSTAMP(5);
   }
 }
 
@@ -393,6 +499,7 @@ struct FwdArgs {
   float eps;                             // Invariant eps
   const uint4* wp;                       // packed program
   int n_tiles;
+  float* p;                              // [n, C] scratch: EquivariantDot(U, V), read back by the dot_lin sweep
   float *uv, *stats, *pre, *a, *ip;      // saved for the reverse pass: U|V pair buffer (BT), norm statistics, hidden pre-activation, update_mlp output, dot_lin output
   float *s_out, *x_out;                  // block outputs (x_out may be NULL: no consumer)
   // front half of the next message block (TAIL)
@@ -409,21 +516,25 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
   const int64_t N = a.n;
+  NB_STAMP(0);
   WStream w;
   w.init(a.wp, ring, a.n_tiles, lane, wave);
+  NB_STAMP(1);
   const float* __restrict__ srow = a.s + row * F;
   const float* __restrict__ xrow = a.x + row * D;
+  float* __restrict__ prow = a.p + row * C;
   const bool wx = a.x_out != nullptr;
   const float e1 = a.eps, e2 = a.eps * a.eps;
 
   f32x16 HID[4] = {zero16(), zero16(), zero16(), zero16()};   // update_mlp hidden pre-activation, accumulated chunk by chunk
-  f32x16 IP[4] = {zero16(), zero16(), zero16(), zero16()};    // dot_lin(p)
   float mean, rstd, mean0, rr;
-
+  f32x16 X0[4];
   {  // ---- LayerNorm(s) (nn.LayerNorm: biased variance, eps 1e-5) -> first K chunk of update_mlp[0]
     f32x16 S[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) S[t] = ld_tile(srow, 32 * t, h);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) X0[t] = ld_tile(xrow, 32 * t, h);   // in flight under the products below
     mean = row_sum((sum16(S[0]) + sum16(S[1])) + (sum16(S[2]) + sum16(S[3]))) * (1.f / F);
     const float var = row_sum((sumsq16(S[0], mean) + sumsq16(S[1], mean)) + (sumsq16(S[2], mean) + sumsq16(S[3], mean))) * (1.f / F);
     rstd = 1.f / sqrtf(var + 1e-5f);
@@ -436,27 +547,25 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
       accum_tile<4>(w, HID, sh);
     }
   }
+  NB_STAMP(2);
   // ---- EquivariantLayerNorm statistics (nn/o3layer.py:145-171): 0e channels centred, one rms over all channels
   {
-    f32x16 X0[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) X0[t] = ld_tile(xrow, 32 * t, h);
     mean0 = row_sum((sum16(X0[0]) + sum16(X0[1])) + (sum16(X0[2]) + sum16(X0[3]))) * (1.f / M0);
     float q = (sumsq16(X0[0], mean0) + sumsq16(X0[1], mean0)) + (sumsq16(X0[2], mean0) + sumsq16(X0[3], mean0));
-#pragma unroll
-    for (int t = 0; t < M1 / 32; ++t) {
-      f32x16 X[3];
-      ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
-      q += (sumsq16(X[0], 0.f) + sumsq16(X[1], 0.f)) + sumsq16(X[2], 0.f);
-    }
     {
-      f32x16 X[5];
-      ld_xm<5>(xrow + M0 + 3 * M1, h, X);
-      q += ((sumsq16(X[0], 0.f) + sumsq16(X[1], 0.f)) + (sumsq16(X[2], 0.f) + sumsq16(X[3], 0.f))) + sumsq16(X[4], 0.f);
+      f32x16 Xa[3], Xb[3], Xc[5];
+      ld_xm<3>(xrow + M0, h, Xa);
+      ld_xm<3>(xrow + M0 + 3 * 32, h, Xb);
+      ld_xm<5>(xrow + M0 + 3 * M1, h, Xc);
+      q += (sumsq16(Xa[0], 0.f) + sumsq16(Xa[1], 0.f)) + sumsq16(Xa[2], 0.f);
+      q += (sumsq16(Xb[0], 0.f) + sumsq16(Xb[1], 0.f)) + sumsq16(Xb[2], 0.f);
+      q += ((sumsq16(Xc[0], 0.f) + sumsq16(Xc[1], 0.f)) + (sumsq16(Xc[2], 0.f) + sumsq16(Xc[3], 0.f))) + sumsq16(Xc[4], 0.f);
     }
     rr = 1.f / sqrtf(row_sum(q) * (1.f / C) + 1e-5f);
     if (ok && h == 0) *reinterpret_cast<float4*>(a.stats + 4 * row) = make_float4(mean, rstd, mean0, rr);
-    // ---- l = 0: U, V (o3.Linear with bias), v = |V|, p = U V per channel tile
+  }
+  NB_STAMP(3);
+  {  // ---- l = 0: U, V (o3.Linear with bias), v = |V|, p = U V per channel tile
     Frag fx[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -470,17 +579,19 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     float* __restrict__ uvr = a.uv + row * (2 * M0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+      f32x16 bu = zero16(), bv = zero16();
+      if (a.b_uv) {
+        bu = ld_tile(a.b_uv, 32 * c, h);
+        bv = ld_tile(a.b_uv + F, 32 * c, h);
+      }
       f32x16 U = zero16(), V = zero16();
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         mfma6(U, w.next(), fx[k]);
         mfma6(V, w.next(), fx[k]);
       }
-      if (a.b_uv) {
-        const f32x16 bu = ld_tile(a.b_uv, 32 * c, h), bv = ld_tile(a.b_uv + F, 32 * c, h);
-        U += bu;
-        V += bv;
-      }
+      U += bu;
+      V += bv;
       st_tile(uvr, 32 * c, h, U, ok);
       st_tile(uvr, M0 + 32 * c, h, V, ok);
       f32x16 v, p;
@@ -489,10 +600,11 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
         v[r] = sqrtf(__builtin_fmaf(V[r], V[r], e2)) - e1;
         p[r] = U[r] * V[r];
       }
+      st_tile(prow, 32 * c, h, p, ok);
       accum_tile<4>(w, HID, v);
-      accum_tile<4>(w, IP, p);
     }
   }
+  NB_STAMP(4);
   {  // ---- l = 1
     f32x16 X1[2][3];
 #pragma unroll
@@ -528,13 +640,14 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+      st_tile(prow, M0 + 32 * c, h, PP[c], ok);
       f32x16 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = sqrtf(VSQ[c][r] + e2) - e1;
       accum_tile<4>(w, HID, v);
-      accum_tile<4>(w, IP, PP[c]);
     }
   }
+  NB_STAMP(5);
   {  // ---- l = 2
     f32x16 X2[5];
     ld_xm<5>(xrow + M0 + 3 * M1, h, X2);
@@ -562,107 +675,151 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
         PP[r] = __builtin_fmaf(U[r], V[r], PP[r]);
       }
     }
+    st_tile(prow, M0 + M1, h, PP, ok);
     f32x16 v;
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = sqrtf(VSQ[r] + e2) - e1;
     accum_tile<4>(w, HID, v);
-    accum_tile<4>(w, IP, PP);
   }
-  // ---- hidden layer of update_mlp: bias, SiLU; dot_lin output kept for the scalar update
+  NB_STAMP(6);
+  // ---- hidden layer of update_mlp: bias, SiLU
   Frag fh[8];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     HID[t] += ld_tile(a.b3, 32 * t, h);
     st_tile(a.pre + row * F, 32 * t, h, HID[t], ok);
-    st_tile(a.ip + row * F, 32 * t, h, IP[t], ok);
     f32x16 hv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hv[r] = silu_f(HID[t][r]);
     fh[2 * t] = split_k<0>(hv);
     fh[2 * t + 1] = split_k<1>(hv);
   }
+  NB_STAMP(7);
   float* __restrict__ arow = a.a + row * AU;
   float* __restrict__ xor_ = wx ? a.x_out + row * D : nullptr;
   float q2 = 0.f;      // TAIL: sum of squares of the new l > 0 features
   f32x16 XN0[4];       // TAIL: new 0e features (two-pass statistics)
-  // ---- a_vv tiles and the equivariant residual update x_out = x + U a_vv (nn/xpainn.py:218-219, 229)
+  // ---- a_vv tiles and the equivariant residual update x_out = x + U a_vv (nn/xpainn.py:218-219, 229); the epilogue's operands
+  // (U of this lane's own stores, x, the bias) are requested in front of the tile's products
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
+    const f32x16 b4v = ld_tile(a.b4, 32 * c, h);
+    f32x16 U = zero16(), X0c = zero16();
+    if (wx) {
+      U = ld_tile(a.uv + row * (2 * M0), 32 * c, h);
+      X0c = ld_tile(xrow, 32 * c, h);
+    }
     f32x16 av = zero16();
     out_tile<8>(w, av, fh);
-    av += ld_tile(a.b4, 32 * c, h);
+    av += b4v;
     st_tile(arow, 32 * c, h, av, ok);
     if (wx) {
-      const f32x16 U = ld_tile(a.uv + row * (2 * M0), 32 * c, h), X0 = ld_tile(xrow, 32 * c, h);
       f32x16 xn;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xn[r] = __builtin_fmaf(U[r], av[r], X0[r]);
+      for (int r = 0; r < 16; ++r) xn[r] = __builtin_fmaf(U[r], av[r], X0c[r]);
       st_tile(xor_, 32 * c, h, xn, ok);
       if (TAIL) XN0[c] = xn;
     }
   }
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    f32x16 av = zero16();
-    out_tile<8>(w, av, fh);
-    av += ld_tile(a.b4, M0 + 32 * c, h);
-    st_tile(arow, M0 + 32 * c, h, av, ok);
+    const f32x16 b4v = ld_tile(a.b4, M0 + 32 * c, h);
+    f32x16 X[3], U[3];
     if (wx) {
-      f32x16 X[3];
       ld_xm<3>(xrow + M0 + 3 * 32 * c, h, X);
       const float* uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
 #pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const f32x16 U = ld_tile(uvb + m * 2 * M1, 32 * c, h);
+      for (int m = 0; m < 3; ++m) U[m] = ld_tile(uvb + m * 2 * M1, 32 * c, h);
+    }
+    f32x16 av = zero16();
+    out_tile<8>(w, av, fh);
+    av += b4v;
+    st_tile(arow, M0 + 32 * c, h, av, ok);
+    if (wx) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) X[m][r] = __builtin_fmaf(U[r], av[r], X[m][r]);
+      for (int m = 0; m < 3; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[m][r] = __builtin_fmaf(U[m][r], av[r], X[m][r]);
         if (TAIL) q2 += sumsq16(X[m], 0.f);
       }
       st_xm<3>(xor_ + M0 + 3 * 32 * c, h, X, ok);
     }
   }
   {
-    f32x16 av = zero16();
-    out_tile<8>(w, av, fh);
-    av += ld_tile(a.b4, M0 + M1, h);
-    st_tile(arow, M0 + M1, h, av, ok);
+    const f32x16 b4v = ld_tile(a.b4, M0 + M1, h);
+    f32x16 X[5], U[5];
     if (wx) {
-      f32x16 X[5];
       ld_xm<5>(xrow + M0 + 3 * M1, h, X);
       const float* uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
 #pragma unroll
-      for (int m = 0; m < 5; ++m) {
-        const f32x16 U = ld_tile(uvb + m * 2 * M2, 0, h);
+      for (int m = 0; m < 5; ++m) U[m] = ld_tile(uvb + m * 2 * M2, 0, h);
+    }
+    f32x16 av = zero16();
+    out_tile<8>(w, av, fh);
+    av += b4v;
+    st_tile(arow, M0 + M1, h, av, ok);
+    if (wx) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) X[m][r] = __builtin_fmaf(U[r], av[r], X[m][r]);
+      for (int m = 0; m < 5; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[m][r] = __builtin_fmaf(U[m][r], av[r], X[m][r]);
         if (TAIL) q2 += sumsq16(X[m], 0.f);
       }
       st_xm<5>(xor_ + M0 + 3 * M1, h, X, ok);
     }
+  }
+  NB_STAMP(8);
+  // ---- dot_lin over the p tiles this lane stored (nn/xpainn.py:222-223)
+  f32x16 IP[4] = {zero16(), zero16(), zero16(), zero16()};
+  {
+    f32x16 P[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) P[t] = ld_tile(prow, 32 * t, h);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) accum_tile<4>(w, IP, P[t]);
   }
   // ---- (a_sv, a_ss) per scalar tile and the scalar residual update s_out = s + a_sv dot_lin(p) + a_ss (nn/xpainn.py:221-228)
   f32x16 SN[4];
   float* __restrict__ sor = a.s_out + row * F;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
+    const f32x16 bsv = ld_tile(a.b4, C + 32 * c, h), bss = ld_tile(a.b4, C + F + 32 * c, h), S = ld_tile(srow, 32 * c, h);
+    st_tile(a.ip + row * F, 32 * c, h, IP[c], ok);
     f32x16 asv = zero16(), ass = zero16();
     out_tile<8>(w, asv, fh);
     out_tile<8>(w, ass, fh);
-    asv += ld_tile(a.b4, C + 32 * c, h);
-    ass += ld_tile(a.b4, C + F + 32 * c, h);
+    asv += bsv;
+    ass += bss;
     st_tile(arow, C + 32 * c, h, asv, ok);
     st_tile(arow, C + F + 32 * c, h, ass, ok);
-    const f32x16 S = ld_tile(srow, 32 * c, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) SN[c][r] = (S[r] + asv[r] * IP[c][r]) + ass[r];
     st_tile(sor, 32 * c, h, SN[c], ok);
   }
+  NB_STAMP(9);
   if (!TAIL) return;
 
   // ======== front half of the next message block (nn/xpainn.py:128-139): both norms of (s_out, x_out), scalar_mlp
   const float mean_n = row_sum((sum16(SN[0]) + sum16(SN[1])) + (sum16(SN[2]) + sum16(SN[3]))) * (1.f / F);
   const float var_n = row_sum((sumsq16(SN[0], mean_n) + sumsq16(SN[1], mean_n)) + (sumsq16(SN[2], mean_n) + sumsq16(SN[3], mean_n))) * (1.f / F);
   const float rstd_n = 1.f / sqrtf(var_n + 1e-5f);
+  const float mean0_n = row_sum((sum16(XN0[0]) + sum16(XN0[1])) + (sum16(XN0[2]) + sum16(XN0[3]))) * (1.f / M0);
+  const float qn = q2 + ((sumsq16(XN0[0], mean0_n) + sumsq16(XN0[1], mean0_n)) + (sumsq16(XN0[2], mean0_n) + sumsq16(XN0[3], mean0_n)));
+  const float rr_n = 1.f / sqrtf(row_sum(qn) * (1.f / C) + 1e-5f);
+  if (ok && h == 0) *reinterpret_cast<float4*>(a.stats2 + 4 * row) = make_float4(mean_n, rstd_n, mean0_n, rr_n);
+  // xhat of the next block, BT layout (block l at N base_l, row (node, m), channels contiguous): the 0e block from registers now,
+  // the l > 0 blocks from this lane's own x_out stores, requested here and finished under the products of scalar_mlp
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 wv = ld_tile(a.eqw2, 32 * t, h), bv = ld_tile(a.eqb2, 32 * t, h);
+    f32x16 xh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xh[r] = (XN0[t][r] - mean0_n) * rr_n * wv[r] + bv[r];
+    st_tile(a.xhat2 + row * M0, 32 * t, h, xh, ok);
+  }
+  f32x16 XA[3], XB[3];
+  ld_xm<3>(xor_ + M0, h, XA);
+  ld_xm<3>(xor_ + M0 + 3 * 32, h, XB);
   f32x16 HN[4] = {zero16(), zero16(), zero16(), zero16()};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -672,42 +829,23 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     for (int r = 0; r < 16; ++r) sh[r] = (SN[t][r] - mean_n) * rstd_n * wv[r] + bv[r];
     accum_tile<4>(w, HN, sh);
   }
-  const float mean0_n = row_sum((sum16(XN0[0]) + sum16(XN0[1])) + (sum16(XN0[2]) + sum16(XN0[3]))) * (1.f / M0);
-  const float qn = q2 + ((sumsq16(XN0[0], mean0_n) + sumsq16(XN0[1], mean0_n)) + (sumsq16(XN0[2], mean0_n) + sumsq16(XN0[3], mean0_n)));
-  const float rr_n = 1.f / sqrtf(row_sum(qn) * (1.f / C) + 1e-5f);
-  if (ok && h == 0) *reinterpret_cast<float4*>(a.stats2 + 4 * row) = make_float4(mean_n, rstd_n, mean0_n, rr_n);
-  // xhat of the next block, BT layout: block l at N base_l, row (node, m), channels contiguous
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const f32x16 wv = ld_tile(a.eqw2, 32 * t, h), bv = ld_tile(a.eqb2, 32 * t, h);
-    f32x16 xh;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xh[r] = (XN0[t][r] - mean0_n) * rr_n * wv[r] + bv[r];
-    st_tile(a.xhat2 + row * M0, 32 * t, h, xh, ok);
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    f32x16 X[3];
-    ld_xm<3>(xor_ + M0 + 3 * 32 * t, h, X);   // this lane's own stores of a moment ago
-    const f32x16 wv = ld_tile(a.eqw2, M0 + 32 * t, h);
+  NB_STAMP(10);
+  {
+    const f32x16 wa = ld_tile(a.eqw2, M0, h), wb = ld_tile(a.eqw2, M0 + 32, h);
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) X[m][r] = X[m][r] * rr_n * wv[r];
-      st_tile(a.xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h, X[m], ok);
+      for (int r = 0; r < 16; ++r) {
+        XA[m][r] = XA[m][r] * rr_n * wa[r];
+        XB[m][r] = XB[m][r] * rr_n * wb[r];
+      }
+      st_tile(a.xhat2 + N * M0 + (row * 3 + m) * M1, 0, h, XA[m], ok);
+      st_tile(a.xhat2 + N * M0 + (row * 3 + m) * M1, 32, h, XB[m], ok);
     }
   }
-  {
-    f32x16 X[5];
-    ld_xm<5>(xor_ + M0 + 3 * M1, h, X);
-    const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) X[m][r] = X[m][r] * rr_n * wv[r];
-      st_tile(a.xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h, X[m], ok);
-    }
-  }
+  f32x16 XC[5];
+  ld_xm<5>(xor_ + M0 + 3 * M1, h, XC);
+  NB_STAMP(11);
   Frag fn[8];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -719,12 +857,493 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     fn[2 * t] = split_k<0>(hv);
     fn[2 * t + 1] = split_k<1>(hv);
   }
+  NB_STAMP(12);
   float* __restrict__ hrow = a.h2 + row * HM;
-  for (int ot = 0; ot < HM / 32; ++ot) {
+  {
     f32x16 acc = zero16();
+    const f32x16 b2v = ld_tile(a.b2n, 0, h);
     out_tile<8>(w, acc, fn);
-    acc += ld_tile(a.b2n, 32 * ot, h);
+    acc += b2v;
+    st_tile(hrow, 0, h, acc, ok);
+    const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) XC[m][r] = XC[m][r] * rr_n * wv[r];
+      st_tile(a.xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h, XC[m], ok);
+    }
+  }
+  f32x16 b2v = ld_tile(a.b2n, 32, h);
+  for (int ot = 1; ot < HM / 32; ++ot) {
+    f32x16 acc = zero16();
+#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 5
+    out_tile<8>(w, acc, fn);
+#else
+    const f32x16 bcur = b2v;
+    if (ot + 1 < HM / 32) b2v = ld_tile(a.b2n, 32 * (ot + 1), h);
+    out_tile<8>(w, acc, fn);
+    acc += bcur;
+#endif
+#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 6
+    if (acc[0] == 12345.678f)
+#endif
     st_tile(hrow, 32 * ot, h, acc, ok);
+  }
+  NB_STAMP(13);
+}
+
+// ------------------------------------------------------------------------------------------------ reverse
+// backward sources: 0 W2' = next scalar_mlp[2].weight [HM, F]; 1 W1' = next scalar_mlp[0].weight [F, F]; 2 W4 = update_mlp[2].weight
+// [AU, F]; 3 W3 = update_mlp[0].weight [F, F + C]; 4 dot_lin.weight [F, C] (all used transposed: out = the layer's input channel);
+// 5..7 [W_U | W_V] / sqrt(mul_l) as [mul_l][2 mul_l] (rows = xhat channel = the reverse product's output)
+enum { B_W2N = 0, B_W1N = 1, B_W4 = 2, B_W3 = 3, B_DOT = 4, B_UV0 = 5, B_UV1 = 6, B_UV2 = 7 };
+static void program_bwd(bool tail, bool gx, std::vector<Seg>& p) {
+  p.clear();
+  if (tail) {
+    p.push_back({B_W2N, 0, 4, 1, 0, HM / 32, 1, 0});   // g_hidden' += W2'^T[:, h tile] g_h
+    p.push_back({B_W1N, 0, 4, 1, 0, 4, 1, 1});         // g_shat' tiles
+  }
+  if (gx) p.push_back({B_W4, 0, 4, 1, 0, 7, 1, 0});     // g_hidden += W4^T[:, a_vv tiles]
+  p.push_back({B_W4, 0, 4, 1, 7, 8, 1, 0});             //           += W4^T[:, a_sv | a_ss tiles]
+  p.push_back({B_W3, 0, 4, 1, 0, 4, 1, 1});             // g_shat tiles
+  p.push_back({B_DOT, 0, 7, 1, 0, 4, 1, 1});            // g_p tiles
+  p.push_back({B_W3, 4, 7, 1, 0, 4, 1, 1});             // g_v tiles
+  for (int c = 0; c < 4; ++c) p.push_back({B_UV0, 0, 4, 1, c, 2, M0 / 32, 0});            // g_xhat_0 += W_U^T g_U_c + W_V^T g_V_c
+  for (int c = 0; c < 2; ++c)
+    for (int m = 0; m < 3; ++m) p.push_back({B_UV1, 0, 2, 1, c, 2, M1 / 32, 0});
+  for (int m = 0; m < 5; ++m) p.push_back({B_UV2, 0, 1, 1, 0, 2, M2 / 32, 0});
+}
+
+struct BwdArgs {
+  int64_t n;
+  // gradients arriving: with the next block's front half (TAIL) g_h [n, HM], g_xhat (BT) and the residual-path gradients
+  // g_s_in = dL/ds_out, g_x_in = dL/dx_out as the message kernel's reverse leaves them; without it g_s_in / g_x_in are the totals
+  // (g_x_in NULL: zero)
+  const float *g_h, *g_xhat2, *g_s_in, *g_x_in;
+  const float *s_out, *x_out, *stats2, *pre2, *lnw2, *eqw2;   // TAIL: saved by the forward launch
+  const float *uv, *a, *ip, *pre, *s, *x, *stats, *lnw, *eqw; // update block: saved tensors and norm weights
+  float eps;
+  const uint4* wp;
+  int n_tiles;
+  float *gxo, *gp, *gv, *gw;    // scratch: total dL/dx_out [n, D], dL/dp [n, C], dL/dv [n, C], dL/dxhat * eq_w [n, D] (e3nn layout)
+  float *g_s, *g_x;             // dL/ds, dL/dx of the block's inputs
+};
+
+// LayerNorm reverse on four scalar tiles: G[t] = rstd (dy - mean(dy) - yh mean(dy yh)) + res[t], dy = g w, yh = (s - mean) rstd
+__device__ __forceinline__ void ln_bwd(f32x16 (&G)[4], const f32x16 (&g)[4], const float* __restrict__ srow, const float* __restrict__ lnw,
+                                       float mean, float rstd, const f32x16 (&res)[4], int h) {
+  f32x16 dy[4], yh[4];
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dy[t][r] = g[t][r] * wv[r];
+      yh[t][r] = (sv[r] - mean) * rstd;
+      a1 += dy[t][r];
+      a2 = __builtin_fmaf(dy[t][r], yh[t][r], a2);
+    }
+  }
+  a1 = row_sum(a1) * (1.f / F);
+  a2 = row_sum(a2) * (1.f / F);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[t][r] = rstd * (dy[t][r] - a1 - yh[t][r] * a2) + res[t][r];
+}
+
+template <bool TAIL, bool GX>
+__global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
+  extern __shared__ uint4 ring[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * 32 + n;
+  const bool ok = node < a.n;
+  const int64_t row = ok ? node : a.n - 1;
+  const int64_t N = a.n;
+  WStream w;
+  w.init(a.wp, ring, a.n_tiles, lane, wave);
+  const float e2 = a.eps * a.eps;
+  float* __restrict__ gxo = a.gxo + row * D;   // total dL/dx_out of this node (GX)
+
+  f32x16 GS[4];   // total dL/ds_out
+  if (TAIL) {
+    // ---- reverse of scalar_mlp (nn/xpainn.py:139): g_hidden' = (W2'^T g_h) silu'(pre'), g_shat' = W1'^T g_hidden'
+    f32x16 GH[4] = {zero16(), zero16(), zero16(), zero16()};
+    const float* __restrict__ ghr = a.g_h + row * HM;
+    f32x16 gt = ld_tile(ghr, 0, h);
+    for (int kt = 0; kt < HM / 32; ++kt) {
+      const f32x16 cur = gt;
+      if (kt + 1 < HM / 32) gt = ld_tile(ghr, 32 * (kt + 1), h);
+      accum_tile<4>(w, GH, cur);
+    }
+    Frag fg[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 pv = ld_tile(a.pre2 + row * F, 32 * t, h);
+      f32x16 gv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gv[r] = GH[t][r] * silu_grad_f(pv[r]);
+      fg[2 * t] = split_k<0>(gv);
+      fg[2 * t + 1] = split_k<1>(gv);
+    }
+    f32x16 gsh[4] = {zero16(), zero16(), zero16(), zero16()}, res[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      res[t] = ld_tile(a.g_s_in + row * F, 32 * t, h);
+      out_tile<8>(w, gsh[t], fg);
+    }
+    const float4 st2 = *reinterpret_cast<const float4*>(a.stats2 + 4 * row);
+    ln_bwd(GS, gsh, a.s_out + row * F, a.lnw2, st2.x, st2.y, res, h);
+    // ---- reverse of the next block's EquivariantLayerNorm (nn/o3layer.py:145-171) on x_out: two sweeps over the row
+    const float mean0 = st2.z, r2 = st2.w;
+    const float* __restrict__ xo = a.x_out + row * D;
+    const float* __restrict__ gxi = a.g_x_in + row * D;
+    float dotp = 0.f, sgw0 = 0.f, sxc0 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_tile(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float gw = g[r] * wv[r], xc = xv[r] - mean0;
+        dotp = __builtin_fmaf(gw, xc, dotp);
+        sgw0 += gw;
+        sxc0 += xc;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 X[3];
+      ld_xm<3>(xo + M0 + 3 * 32 * t, h, X);
+      const f32x16 wv = ld_tile(a.eqw2, M0 + 32 * t, h);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const f32x16 g = ld_tile(a.g_xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dotp = __builtin_fmaf(g[r] * wv[r], X[m][r], dotp);
+      }
+    }
+    {
+      f32x16 X[5];
+      ld_xm<5>(xo + M0 + 3 * M1, h, X);
+      const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const f32x16 g = ld_tile(a.g_xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dotp = __builtin_fmaf(g[r] * wv[r], X[m][r], dotp);
+      }
+    }
+    const float coef = row_sum(dotp) * r2 * r2 * r2 * (1.f / C);
+    const float gmean = (r2 * row_sum(sgw0) - coef * row_sum(sxc0)) * (1.f / M0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_tile(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h),
+                   rv = ld_tile(gxi, 32 * t, h);
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = ((r2 * (g[r] * wv[r]) - coef * (xv[r] - mean0)) - gmean) + rv[r];
+      st_tile(gxo, 32 * t, h, o, ok);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 X[3], R[3];
+      ld_xm<3>(xo + M0 + 3 * 32 * t, h, X);
+      ld_xm<3>(gxi + M0 + 3 * 32 * t, h, R);
+      const f32x16 wv = ld_tile(a.eqw2, M0 + 32 * t, h);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const f32x16 g = ld_tile(a.g_xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[m][r] = (r2 * (g[r] * wv[r]) - coef * X[m][r]) + R[m][r];
+      }
+      st_xm<3>(gxo + M0 + 3 * 32 * t, h, X, ok);
+    }
+    {
+      f32x16 X[5], R[5];
+      ld_xm<5>(xo + M0 + 3 * M1, h, X);
+      ld_xm<5>(gxi + M0 + 3 * M1, h, R);
+      const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const f32x16 g = ld_tile(a.g_xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[m][r] = (r2 * (g[r] * wv[r]) - coef * X[m][r]) + R[m][r];
+      }
+      st_xm<5>(gxo + M0 + 3 * M1, h, X, ok);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) GS[t] = ld_tile(a.g_s_in + row * F, 32 * t, h);
+    if (GX) gxo = const_cast<float*>(a.g_x_in) + row * D;   // the totals arrive in the caller's tensor: read only
+  }
+
+  // ---- reverse of the output stage (nn/xpainn.py:218-229) into the reverse of update_mlp[2]: g_hidden += W4^T[:, chunk] g_a[chunk]
+  f32x16 GHID[4] = {zero16(), zero16(), zero16(), zero16()};
+  const float* __restrict__ arow = a.a + row * AU;
+  if (GX) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // g_a_vv = sum_m g_x_out U
+      const f32x16 U = ld_tile(a.uv + row * (2 * M0), 32 * c, h), G = ld_tile(gxo, 32 * c, h);
+      f32x16 ga;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] = G[r] * U[r];
+      accum_tile<4>(w, GHID, ga);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x16 G[3];
+      ld_xm<3>(gxo + M0 + 3 * 32 * c, h, G);
+      const float* uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
+      f32x16 ga = zero16();
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const f32x16 U = ld_tile(uvb + m * 2 * M1, 32 * c, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[r] = __builtin_fmaf(G[m][r], U[r], ga[r]);
+      }
+      accum_tile<4>(w, GHID, ga);
+    }
+    {
+      f32x16 G[5];
+      ld_xm<5>(gxo + M0 + 3 * M1, h, G);
+      const float* uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
+      f32x16 ga = zero16();
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const f32x16 U = ld_tile(uvb + m * 2 * M2, 0, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[r] = __builtin_fmaf(G[m][r], U[r], ga[r]);
+      }
+      accum_tile<4>(w, GHID, ga);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {   // g_a_sv = g_s_out ip
+    const f32x16 ipv = ld_tile(a.ip + row * F, 32 * c, h);
+    f32x16 ga;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ga[r] = GS[c][r] * ipv[r];
+    accum_tile<4>(w, GHID, ga);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) accum_tile<4>(w, GHID, GS[c]);   // g_a_ss = g_s_out
+  // ---- g_hidden silu'(pre) -> fragments; g_ip = g_s_out a_sv -> fragments
+  Frag fgh[8], fgi[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 pv = ld_tile(a.pre + row * F, 32 * t, h), asv = ld_tile(arow, C + 32 * t, h);
+    f32x16 gv, gi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      gv[r] = GHID[t][r] * silu_grad_f(pv[r]);
+      gi[r] = GS[t][r] * asv[r];
+    }
+    fgh[2 * t] = split_k<0>(gv);
+    fgh[2 * t + 1] = split_k<1>(gv);
+    fgi[2 * t] = split_k<0>(gi);
+    fgi[2 * t + 1] = split_k<1>(gi);
+  }
+  const float4 st = *reinterpret_cast<const float4*>(a.stats + 4 * row);
+  {  // ---- g_shat = W3^T[:F] g_hidden -> LayerNorm reverse -> g_s
+    f32x16 gsh[4] = {zero16(), zero16(), zero16(), zero16()}, G[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out_tile<8>(w, gsh[t], fgh);
+    ln_bwd(G, gsh, a.s + row * F, a.lnw, st.x, st.y, GS, h);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) st_tile(a.g_s + row * F, 32 * t, h, G[t], ok);
+  }
+  // ---- g_p = dot_lin^T g_ip and g_v = W3^T[F:] g_hidden, seven channel tiles each, parked in scratch for the per-block sweeps
+  float* __restrict__ gpr = a.gp + row * C;
+  float* __restrict__ gvr = a.gv + row * C;
+  for (int t = 0; t < 7; ++t) {
+    f32x16 acc = zero16();
+    out_tile<8>(w, acc, fgi);
+    st_tile(gpr, 32 * t, h, acc, ok);
+  }
+  for (int t = 0; t < 7; ++t) {
+    f32x16 acc = zero16();
+    out_tile<8>(w, acc, fgh);
+    st_tile(gvr, 32 * t, h, acc, ok);
+  }
+  // ---- per block l: g_U = g_x_out a_vv + g_p V, g_V = g_p U + g_v V / sqrt(sum_m V^2 + eps^2) (nn/o3layer.py:39-44, 104-109),
+  // g_xhat = W_U^T g_U + W_V^T g_V; times the affine weight into scratch, with the sums the norm's reverse needs
+  const float mean0 = st.z, rr = st.w;
+  const float* __restrict__ xrow = a.x + row * D;
+  float* __restrict__ gwr = a.gw + row * D;
+  float dotp = 0.f, sgw0 = 0.f, sxc0 = 0.f;
+  {
+    f32x16 GXH[4] = {zero16(), zero16(), zero16(), zero16()};
+    const float* uvr = a.uv + row * (2 * M0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x16 U = ld_tile(uvr, 32 * c, h), V = ld_tile(uvr, M0 + 32 * c, h), gp = ld_tile(gpr, 32 * c, h), gv = ld_tile(gvr, 32 * c, h);
+      f32x16 gU, gV;
+      if (GX) {
+        const f32x16 G = ld_tile(gxo, 32 * c, h), av = ld_tile(arow, 32 * c, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gU[r] = __builtin_fmaf(G[r], av[r], gp[r] * V[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gU[r] = gp[r] * V[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gV[r] = __builtin_fmaf(gp[r], U[r], gv[r] / sqrtf(__builtin_fmaf(V[r], V[r], e2)) * V[r]);
+      accum_tile<4>(w, GXH, gU);
+      accum_tile<4>(w, GXH, gV);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 wv = ld_tile(a.eqw, 32 * t, h), xv = ld_tile(xrow, 32 * t, h);
+      f32x16 gw;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        gw[r] = GXH[t][r] * wv[r];
+        const float xc = xv[r] - mean0;
+        dotp = __builtin_fmaf(gw[r], xc, dotp);
+        sgw0 += gw[r];
+        sxc0 += xc;
+      }
+      st_tile(gwr, 32 * t, h, gw, ok);
+    }
+  }
+  {
+    f32x16 GXH[3][2];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      GXH[m][0] = zero16();
+      GXH[m][1] = zero16();
+    }
+    const float* uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const f32x16 gp = ld_tile(gpr, M0 + 32 * c, h), gv = ld_tile(gvr, M0 + 32 * c, h);
+      f32x16 U[3], V[3], G[3];
+      f32x16 vv = zero16();
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        U[m] = ld_tile(uvb + m * 2 * M1, 32 * c, h);
+        V[m] = ld_tile(uvb + m * 2 * M1, M1 + 32 * c, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = __builtin_fmaf(V[m][r], V[m][r], vv[r]);
+      }
+      f32x16 av = zero16();
+      if (GX) {
+        ld_xm<3>(gxo + M0 + 3 * 32 * c, h, G);
+        av = ld_tile(arow, M0 + 32 * c, h);
+      }
+      f32x16 gvn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gvn[r] = gv[r] / sqrtf(vv[r] + e2);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        f32x16 gU, gV;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          gU[r] = GX ? __builtin_fmaf(G[m][r], av[r], gp[r] * V[m][r]) : gp[r] * V[m][r];
+          gV[r] = __builtin_fmaf(gp[r], U[m][r], gvn[r] * V[m][r]);
+        }
+        accum_tile<2>(w, GXH[m], gU);
+        accum_tile<2>(w, GXH[m], gV);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 X[3], GW[3];
+      ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
+      const f32x16 wv = ld_tile(a.eqw, M0 + 32 * t, h);
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          GW[m][r] = GXH[m][t][r] * wv[r];
+          dotp = __builtin_fmaf(GW[m][r], X[m][r], dotp);
+        }
+      st_xm<3>(gwr + M0 + 3 * 32 * t, h, GW, ok);
+    }
+  }
+  {
+    f32x16 GXH[5][1];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) GXH[m][0] = zero16();
+    const float* uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
+    const f32x16 gp = ld_tile(gpr, M0 + M1, h), gv = ld_tile(gvr, M0 + M1, h);
+    f32x16 G[5];
+    f32x16 av = zero16();
+    if (GX) {
+      ld_xm<5>(gxo + M0 + 3 * M1, h, G);
+      av = ld_tile(arow, M0 + M1, h);
+    }
+    f32x16 vv = zero16();
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const f32x16 V = ld_tile(uvb + m * 2 * M2, M2, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vv[r] = __builtin_fmaf(V[r], V[r], vv[r]);
+    }
+    f32x16 gvn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gvn[r] = gv[r] / sqrtf(vv[r] + e2);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const f32x16 U = ld_tile(uvb + m * 2 * M2, 0, h), V = ld_tile(uvb + m * 2 * M2, M2, h);
+      f32x16 gU, gV;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        gU[r] = GX ? __builtin_fmaf(G[m][r], av[r], gp[r] * V[r]) : gp[r] * V[r];
+        gV[r] = __builtin_fmaf(gp[r], U[r], gvn[r] * V[r]);
+      }
+      accum_tile<1>(w, GXH[m], gU);
+      accum_tile<1>(w, GXH[m], gV);
+    }
+    f32x16 X[5], GW[5];
+    ld_xm<5>(xrow + M0 + 3 * M1, h, X);
+    const f32x16 wv = ld_tile(a.eqw, M0 + M1, h);
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        GW[m][r] = GXH[m][0][r] * wv[r];
+        dotp = __builtin_fmaf(GW[m][r], X[m][r], dotp);
+      }
+    st_xm<5>(gwr + M0 + 3 * M1, h, GW, ok);
+  }
+  // ---- EquivariantLayerNorm reverse of the update block's norm: g_x = r gw - coef xc - [0e] gmean + g_x_out
+  const float coef = row_sum(dotp) * rr * rr * rr * (1.f / C);
+  const float gmean = (rr * row_sum(sgw0) - coef * row_sum(sxc0)) * (1.f / M0);
+  float* __restrict__ gxr = a.g_x + row * D;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 gw = ld_tile(gwr, 32 * t, h), xv = ld_tile(xrow, 32 * t, h);
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = (rr * gw[r] - coef * (xv[r] - mean0)) - gmean;
+    if (GX) o += ld_tile(gxo, 32 * t, h);
+    st_tile(gxr, 32 * t, h, o, ok);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f32x16 X[3], GW[3], R[3];
+    ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
+    ld_xm<3>(gwr + M0 + 3 * 32 * t, h, GW);
+    if (GX) ld_xm<3>(gxo + M0 + 3 * 32 * t, h, R);
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[m][r] = (rr * GW[m][r] - coef * X[m][r]) + (GX ? R[m][r] : 0.f);
+    st_xm<3>(gxr + M0 + 3 * 32 * t, h, X, ok);
+  }
+  {
+    f32x16 X[5], GW[5], R[5];
+    ld_xm<5>(xrow + M0 + 3 * M1, h, X);
+    ld_xm<5>(gwr + M0 + 3 * M1, h, GW);
+    if (GX) ld_xm<5>(gxo + M0 + 3 * M1, h, R);
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[m][r] = (rr * GW[m][r] - coef * X[m][r]) + (GX ? R[m][r] : 0.f);
+    st_xm<5>(gxr + M0 + 3 * M1, h, X, ok);
   }
 }
 
@@ -780,21 +1399,21 @@ int xeq_node_block_pack_fwd(const float* w3, const float* uv0, const float* uv1,
  * stats [n, 4], pre [n, F], a [n, C + 2 F], ip [n, F]; outputs s_out, x_out (NULL: the equivariant output has no consumer);
  * next block: stats_next [n, 4], xhat_next (BT), pre_next [n, F], h_next [n, F + 2 C]. */
 int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* ln_w, const float* ln_b, const float* eq_w, const float* eq_b,
-                       const float* b_uv, const float* b3, const float* b4, double eps, const void* packed, float* uv_bt, float* stats,
+                       const float* b_uv, const float* b3, const float* b4, double eps, const void* packed, float* p_scratch, float* uv_bt, float* stats,
                        float* pre, float* a, float* ip, float* s_out, float* x_out, const float* ln_w_next, const float* ln_b_next,
                        const float* eq_w_next, const float* eq_b_next, const float* b1_next, const float* b2_next, float* stats_next,
                        float* xhat_next, float* pre_next, float* h_next, void* stream) {
   XEQ_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) / (2 * D), "xeq_node_block_fwd: n = %lld out of range", (long long)n);
   if (n == 0) return XEQ_OK;
   const bool tail = h_next != nullptr;
-  XEQ_CHECK_ARG(s && x && ln_w && ln_b && eq_w && eq_b && b3 && b4 && packed && uv_bt && stats && pre && a && ip && s_out,
+  XEQ_CHECK_ARG(s && x && ln_w && ln_b && eq_w && eq_b && b3 && b4 && packed && p_scratch && uv_bt && stats && pre && a && ip && s_out,
                 "xeq_node_block_fwd: null buffer");
   XEQ_CHECK_ARG(!tail || (x_out && ln_w_next && ln_b_next && eq_w_next && eq_b_next && b1_next && b2_next && stats_next && xhat_next && pre_next),
                 "xeq_node_block_fwd: null buffer (next block)");
   FwdArgs fa;
   fa.n = n; fa.s = s; fa.x = x; fa.lnw = ln_w; fa.lnb = ln_b; fa.eqw = eq_w; fa.eqb = eq_b; fa.b_uv = b_uv; fa.b3 = b3; fa.b4 = b4;
   fa.eps = (float)eps; fa.wp = (const uint4*)packed; fa.n_tiles = (int)xeq_node_block_fwd_tiles(tail);
-  fa.uv = uv_bt; fa.stats = stats; fa.pre = pre; fa.a = a; fa.ip = ip; fa.s_out = s_out; fa.x_out = x_out;
+  fa.p = p_scratch; fa.uv = uv_bt; fa.stats = stats; fa.pre = pre; fa.a = a; fa.ip = ip; fa.s_out = s_out; fa.x_out = x_out;
   fa.lnw2 = ln_w_next; fa.lnb2 = ln_b_next; fa.eqw2 = eq_w_next; fa.eqb2 = eq_b_next; fa.b1n = b1_next; fa.b2n = b2_next;
   fa.stats2 = stats_next; fa.xhat2 = xhat_next; fa.pre2 = pre_next; fa.h2 = h_next;
   const dim3 grid((unsigned)((n + ROWS_WG - 1) / ROWS_WG));
@@ -804,11 +1423,70 @@ int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* l
   return XEQ_OK;
 }
 
+/* tiles of the packed reverse program: with_tail (the next message block's front half is reversed too), with_gx (dL/dx_out is
+ * not zero: every block but the last of a force evaluation) */
+int64_t xeq_node_block_bwd_tiles(int with_tail, int with_gx) {
+  std::vector<Seg> p;
+  program_bwd(with_tail != 0, with_gx != 0 || with_tail != 0, p);
+  return padded_tiles(seg_tiles(p));
+}
+
+/* Packed reverse program: the same weight tensors as xeq_node_block_pack_fwd, contracted transposed. */
+int xeq_node_block_pack_bwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,
+                            const float* w1n, const float* w2n, int with_gx, void* out, void* stream) {
+  XEQ_CHECK_ARG(w3 && uv0 && uv1 && uv2 && dot && w4 && out && ((w1n == nullptr) == (w2n == nullptr)), "xeq_node_block_pack_bwd: null buffer");
+  const bool tail = w1n != nullptr;
+  std::vector<Seg> p;
+  program_bwd(tail, tail || with_gx != 0, p);
+  const Src srcs[8] = {{w2n, F, 1, 1.f},     {w1n, F, 1, 1.f},      {w4, F, 1, 1.f},       {w3, F + C, 1, 1.f},
+                       {dot, C, 1, 1.f},     {uv0, 2 * M0, 0, 1.f}, {uv1, 2 * M1, 0, 1.f}, {uv2, 2 * M2, 0, 1.f}};
+  return run_pack(p, srcs, 8, out, stream, "xeq_node_block_pack_bwd");
+}
+
+/* Reverse of xeq_node_block_fwd for a force evaluation (input gradients only, nn/basic.py:143-159).
+ * With the next block's front half (g_h != NULL): g_h [n, F + 2 C] and g_xhat (BT) are the gradients of h_next / xhat_next, g_s_in /
+ * g_x_in the gradients that reach s_out / x_out directly (the message kernel's residual path); s_out, x_out, stats_next, pre_next as
+ * the forward launch wrote them.  Without it: g_s_in = dL/ds_out, g_x_in = dL/dx_out or NULL (zero).
+ * Scratch: gxo [n, D] (unused without the front half), gp [n, C], gv [n, C], gw [n, D].  Output: g_s [n, F], g_x [n, D]. */
+int xeq_node_block_bwd(int64_t n, const float* g_h, const float* g_xhat_next, const float* g_s_in, const float* g_x_in, const float* s_out,
+                       const float* x_out, const float* stats_next, const float* pre_next, const float* ln_w_next, const float* eq_w_next,
+                       const float* uv_bt, const float* a, const float* ip, const float* pre, const float* s, const float* x,
+                       const float* stats, const float* ln_w, const float* eq_w, double eps, const void* packed, float* gxo, float* gp,
+                       float* gv, float* gw, float* g_s, float* g_x, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) / (2 * D), "xeq_node_block_bwd: n = %lld out of range", (long long)n);
+  if (n == 0) return XEQ_OK;
+  const bool tail = g_h != nullptr, gx = tail || g_x_in != nullptr;
+  XEQ_CHECK_ARG(g_s_in && uv_bt && a && ip && pre && s && x && stats && ln_w && eq_w && packed && gp && gv && gw && g_s && g_x,
+                "xeq_node_block_bwd: null buffer");
+  XEQ_CHECK_ARG(!tail || (g_xhat_next && g_x_in && s_out && x_out && stats_next && pre_next && ln_w_next && eq_w_next && gxo),
+                "xeq_node_block_bwd: null buffer (next block)");
+  BwdArgs b;
+  b.n = n; b.g_h = g_h; b.g_xhat2 = g_xhat_next; b.g_s_in = g_s_in; b.g_x_in = g_x_in; b.s_out = s_out; b.x_out = x_out;
+  b.stats2 = stats_next; b.pre2 = pre_next; b.lnw2 = ln_w_next; b.eqw2 = eq_w_next; b.uv = uv_bt; b.a = a; b.ip = ip; b.pre = pre;
+  b.s = s; b.x = x; b.stats = stats; b.lnw = ln_w; b.eqw = eq_w; b.eps = (float)eps; b.wp = (const uint4*)packed;
+  b.n_tiles = (int)xeq_node_block_bwd_tiles(tail, gx); b.gxo = gxo; b.gp = gp; b.gv = gv; b.gw = gw; b.g_s = g_s; b.g_x = g_x;
+  const dim3 grid((unsigned)((n + ROWS_WG - 1) / ROWS_WG));
+  if (tail) hipLaunchKernelGGL((k_node_block_bwd<true, true>), grid, dim3(256), RING_BYTES, (hipStream_t)stream, b);
+  else if (gx) hipLaunchKernelGGL((k_node_block_bwd<false, true>), grid, dim3(256), RING_BYTES, (hipStream_t)stream, b);
+  else hipLaunchKernelGGL((k_node_block_bwd<false, false>), grid, dim3(256), RING_BYTES, (hipStream_t)stream, b);
+  XEQ_CHECK_LAUNCH("xeq_node_block_bwd");
+  return XEQ_OK;
+}
+
+/* development only (XEQ_NB_STAMPS builds): out[1024 * 4 * 24] core-clock stamps per (workgroup, wave) */
+int xeq_node_block_debug_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nb_stamps), sizeof(unsigned long long) * 1024 * 4 * NB_STAMPS) == hipSuccess ? XEQ_OK : XEQ_ERR_LAUNCH;
+}
+
 /* development / test entry: y = x W^T through the kernel primitives (x [n, 128], W [32 n_ot, 128]); form 0 needs n_ot = 4 */
 int xeq_node_block_linear_test(const float* x, int64_t n, const float* w, int n_ot, int form, void* packed_scratch, float* y, void* stream) {
-  XEQ_CHECK_ARG(x && w && packed_scratch && y && n > 0 && n_ot > 0 && n_ot <= 18 && (form == 1 || n_ot == 4), "xeq_node_block_linear_test: bad arguments");
+  XEQ_CHECK_ARG(x && w && packed_scratch && y && n > 0 && n_ot > 0 && n_ot <= 18 && (form == 1 || (form == 2 && n_ot % 2 == 0) || (form == 0 && n_ot == 4)),
+                "xeq_node_block_linear_test: bad arguments");
   std::vector<Seg> p;
-  p.push_back({0, 0, n_ot, 1, 0, 4, 1, form});
+  if (form == 2)
+    for (int j = 0; j < n_ot / 2; ++j) p.push_back({0, 2 * j, 2, 1, 0, 4, 1, 0});
+  else
+    p.push_back({0, 0, n_ot, 1, 0, 4, 1, form});
   const Src srcs[1] = {{w, 128, 0, 1.f}};
   if (int rc = run_pack(p, srcs, 1, packed_scratch, stream, "xeq_node_block_linear_test")) return rc;
   LinTestArgs la{x, n, (const uint4*)packed_scratch, padded_tiles(seg_tiles(p)), n_ot, form, y};

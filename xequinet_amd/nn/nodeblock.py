@@ -105,7 +105,7 @@ def node_block_fwd(s: torch.Tensor, x: torch.Tensor, update, message=None, want_
     tail = message is not None
     assert want_x or not tail
     o = {
-        "uv": torch.empty(2 * n * D, **f32), "stats": torch.empty((n, 4), **f32), "pre": torch.empty((n, F), **f32),
+        "p": torch.empty((n, C), **f32), "uv": torch.empty(2 * n * D, **f32), "stats": torch.empty((n, 4), **f32), "pre": torch.empty((n, F), **f32),
         "a": torch.empty((n, C + 2 * F), **f32), "ip": torch.empty((n, F), **f32), "s_out": torch.empty((n, F), **f32),
         "x_out": torch.empty((n, D), **f32) if want_x else None,
     }
@@ -116,9 +116,61 @@ def node_block_fwd(s: torch.Tensor, x: torch.Tensor, update, message=None, want_
     nm = message
     call("xeq_node_block_fwd", n, ptr(s), ptr(x), ptr(update.norm.weight), ptr(update.norm.bias), ptr(update.o3norm.affine_weight),
          ptr(update.o3norm.affine_bias), ptr(_uv_bias(update)), ptr(m[0].bias), ptr(m[2].bias), float(update.invariant.eps), ptr(packed),
-         ptr(o["uv"]), ptr(o["stats"]), ptr(o["pre"]), ptr(o["a"]), ptr(o["ip"]), ptr(o["s_out"]), ptr(o["x_out"]),
+         ptr(o["p"]), ptr(o["uv"]), ptr(o["stats"]), ptr(o["pre"]), ptr(o["a"]), ptr(o["ip"]), ptr(o["s_out"]), ptr(o["x_out"]),
          ptr(nm.norm.weight if tail else None), ptr(nm.norm.bias if tail else None), ptr(nm.o3norm.affine_weight if tail else None),
          ptr(nm.o3norm.affine_bias if tail else None), ptr(nm.scalar_mlp[0].bias if tail else None),
          ptr(nm.scalar_mlp[2].bias if tail else None), ptr(o.get("stats2")), ptr(o.get("xhat2")), ptr(o.get("pre2")), ptr(o.get("h2")),
          stream())
     return o
+
+
+def packed_bwd(update, message=None, with_gx: bool = True) -> torch.Tensor:
+    """The reverse weight program of (update block, next message block or None), cached on the update module."""
+    from .fused import _packed_uv
+
+    m = update.update_mlp
+    ws = [m[0].weight, update.update_U.weight, update.update_V.weight, update.dot_lin.weight, m[2].weight]
+    if message is not None:
+        ws += [message.scalar_mlp[0].weight, message.scalar_mlp[2].weight]
+    with_gx = bool(with_gx or message is not None)
+    key = (_versions(*ws), pack_epoch(), id(message), with_gx)
+    cache = getattr(update, "_xeq_nb_bwd", None)
+    if cache is None:
+        cache = update._xeq_nb_bwd = {}
+    hit = cache.get(with_gx)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        uv, _ = _packed_uv(update)
+        tiles = int(lib.load().xeq_node_block_bwd_tiles(int(message is not None), int(with_gx)))
+        out = torch.empty(tiles * TILE_BYTES, dtype=torch.uint8, device=m[0].weight.device)
+        w1n = message.scalar_mlp[0].weight.detach().contiguous() if message is not None else None
+        w2n = message.scalar_mlp[2].weight.detach().contiguous() if message is not None else None
+        keep = [m[0].weight.detach().contiguous(), update.dot_lin.weight.detach().contiguous(), m[2].weight.detach().contiguous()]
+        call("xeq_node_block_pack_bwd", ptr(keep[0]), ptr(uv[0]), ptr(uv[1]), ptr(uv[2]), ptr(keep[1]), ptr(keep[2]), ptr(w1n), ptr(w2n),
+             int(with_gx), ptr(out), stream())
+    cache[with_gx] = (key, out)
+    return out
+
+
+def node_block_bwd(saved: dict, s: torch.Tensor, x: torch.Tensor, update, message, g_s_in: torch.Tensor, g_x_in: Optional[torch.Tensor],
+                   g_h: Optional[torch.Tensor] = None, g_xhat: Optional[torch.Tensor] = None):
+    """Reverse of ``node_block_fwd`` (input gradients).  ``saved``: what the forward launch returned.  With the next block's front
+    half: g_h, g_xhat (BT) are the gradients of h2 / xhat2 and g_s_in / g_x_in those reaching s_out / x_out directly."""
+    n, D = x.shape
+    F = update.node_dim
+    C = update.node_irreps.num_irreps
+    f32 = dict(dtype=torch.float32, device=s.device)
+    tail = message is not None
+    assert tail == (g_h is not None)
+    packed = packed_bwd(update, message, with_gx=g_x_in is not None)
+    g_s, g_x = torch.empty((n, F), **f32), torch.empty((n, D), **f32)
+    gxo = torch.empty((n, D), **f32) if tail else None
+    gp, gv, gw = torch.empty((n, C), **f32), torch.empty((n, C), **f32), torch.empty((n, D), **f32)
+    cont = lambda t: None if t is None else t.contiguous()
+    call("xeq_node_block_bwd", n, ptr(cont(g_h)), ptr(cont(g_xhat)), ptr(cont(g_s_in)), ptr(cont(g_x_in)), ptr(saved["s_out"] if tail else None),
+         ptr(saved["x_out"] if tail else None), ptr(saved.get("stats2")), ptr(saved.get("pre2")),
+         ptr(message.norm.weight if tail else None), ptr(message.o3norm.affine_weight if tail else None), ptr(saved["uv"]), ptr(saved["a"]),
+         ptr(saved["ip"]), ptr(saved["pre"]), ptr(s), ptr(x), ptr(saved["stats"]), ptr(update.norm.weight), ptr(update.o3norm.affine_weight),
+         float(update.invariant.eps), ptr(packed), ptr(gxo), ptr(gp), ptr(gv), ptr(gw), ptr(g_s), ptr(g_x), stream())
+    return g_s, g_x
