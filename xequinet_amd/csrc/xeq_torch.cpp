@@ -25,6 +25,7 @@
 #include <torch/library.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <optional>
 #include <unordered_map>
@@ -246,6 +247,62 @@ const UvFrag* uv_frag(const Tensor* q /* [W0, W1, W2, bias pair] */, int node_di
     for (int i = 0; i < 8; ++i) e.key[i] = key[i];
   }
   return &e;
+}
+
+// ---------------------------------------------------------------------------------------------- fused node blocks
+// One launch per direction for an update block and the front half of the message block behind it (csrc/xeq_nodeblock.hip;
+// nn/nodeblock.py / nn/fused.py::NodeBlock are the Python twins).  The packed weight programs are cached per update_mlp weight.
+struct NbPacks {
+  std::vector<int64_t> key;
+  Owners owners;
+  Tensor fwd, bwd, bias_uv;
+};
+// q: the block's parameters (layout below), qn: the next block's (nullptr: no front half); gx: dL/dx_out is not zero
+const NbPacks* nb_packs(const Tensor* q, const Tensor* qn, bool gx) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, NbPacks> cache[4];
+  const bool tail = qn != nullptr;
+  std::vector<const Tensor*> ws = {&q[15], &q[10], &q[11], &q[12], &q[14], &q[17], &q[13]};
+  if (tail) {
+    ws.push_back(&qn[0]);
+    ws.push_back(&qn[2]);
+  }
+  std::vector<int64_t> key;
+  for (const Tensor* t : ws) {
+    key.push_back(t->defined() ? (int64_t)t->_version() : -1);
+    key.push_back(t->defined() && t->numel() > 0 ? (int64_t)(intptr_t)t->data_ptr() : 0);
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  NbPacks& e = cache[(tail ? 2 : 0) + (gx ? 1 : 0)][q[15].data_ptr()];
+  bool same = e.fwd.defined() && e.key == key;
+  if (same) {
+    if (tail) same = e.owners.same({ws[0], ws[1], ws[2], ws[3], ws[4], ws[5], ws[6], ws[7], ws[8]});
+    else same = e.owners.same({ws[0], ws[1], ws[2], ws[3], ws[4], ws[5], ws[6]});
+  }
+  if (!same) {
+    const auto bopt = q[15].options().dtype(at::kByte);
+    const Tensor w3 = q[15].detach().contiguous(), dot = q[14].detach().contiguous(), w4 = q[17].detach().contiguous();
+    const Tensor uv0 = q[10].contiguous(), uv1 = q[11].contiguous(), uv2 = q[12].contiguous();
+    Tensor w1n, w2n;
+    if (tail) {
+      w1n = qn[0].detach().contiguous();
+      w2n = qn[2].detach().contiguous();
+    }
+    auto fp = [](const Tensor& t) { return t.defined() ? (const float*)t.data_ptr() : nullptr; };
+    e.fwd = at::empty({xeq_node_block_fwd_tiles(tail) * 3072}, bopt);
+    XCALL(xeq_node_block_pack_fwd(fp(w3), fp(uv0), fp(uv1), fp(uv2), fp(dot), fp(w4), fp(w1n), fp(w2n), e.fwd.data_ptr(), cur_stream()));
+    e.bwd = at::empty({xeq_node_block_bwd_tiles(tail, gx) * 3072}, bopt);
+    XCALL(xeq_node_block_pack_bwd(fp(w3), fp(uv0), fp(uv1), fp(uv2), fp(dot), fp(w4), fp(w1n), fp(w2n), gx, e.bwd.data_ptr(), cur_stream()));
+    e.bias_uv = q[13].numel() > 0 ? q[13].detach().contiguous() : Tensor();
+    if (tail) e.owners.set({ws[0], ws[1], ws[2], ws[3], ws[4], ws[5], ws[6], ws[7], ws[8]});
+    else e.owners.set({ws[0], ws[1], ws[2], ws[3], ws[4], ws[5], ws[6]});
+    e.key = key;
+  }
+  return &e;
+}
+bool nb_enabled() {
+  const char* v = getenv("XEQ_NODE_BLOCK");
+  return !(v && v[0] == '0');
 }
 
 // ---------------------------------------------------------------------------------------------- graph plumbing
@@ -511,11 +568,13 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                          g.sb_basis.data_ptr(), g.sb_dbasis.data_ptr(), st));
   }
 
+  // fused node blocks: f32, the default layout, layer norms on (nn/nodeblock.py::supported)
+  const bool nb_ok = dt == XEQ_F32 && hy.layer_norm && nb_enabled() && xeq_node_block_supported(XEQ_F32, F, mul);
   for (int b = 0; b < hy.blocks; ++b) {
     const Tensor* q = &prm[P_BLOCK0 + P_PER_BLOCK * b];
     {  // ---- XPainnMessage.forward (nn/xpainn.py:128-161; nn/fused.py::MessageBlock)
       MsgSaved& m = msv[b];
-      if (b > 0) {   // (block 0: done above)
+      if (b > 0 && !m.h.defined()) {   // (block 0: done above; behind a fused node block: done by its launch)
         m.s = s;
         m.x = x;
         NormOut no = norm_fwd(hy, s, x, q[6], q[7], q[8], q[9], Tensor(), 0);
@@ -545,6 +604,40 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       UpdSaved& u = usv[b];
       u.s = s;
       u.x = x;
+      const bool last_blk = b == hy.blocks - 1;
+      if (nb_ok) {   // the whole block, and the front half of the next message block, in one launch (nn/fused.py::NodeBlock)
+        const Tensor* qn = last_blk ? nullptr : &prm[P_BLOCK0 + P_PER_BLOCK * (b + 1)];
+        const NbPacks* pk = nb_packs(q, qn, !last_blk);
+        auto fp = [](const Tensor& t) { return t.defined() ? (const float*)t.data_ptr() : nullptr; };
+        auto fpm = [](Tensor& t) { return t.defined() ? (float*)t.data_ptr() : nullptr; };
+        u.uv = at::empty({2 * N * D}, fopt);
+        u.stats = at::empty({N, 4}, fopt);
+        u.pre = at::empty({N, F}, fopt);
+        u.a = at::empty({N, C + 2 * F}, fopt);
+        u.ip = at::empty({N, F}, fopt);
+        Tensor p_scr = at::empty({N, C}, fopt);
+        Tensor s_out = at::empty_like(s), x_out = last_blk ? Tensor() : at::empty_like(x);
+        MsgSaved* mn = last_blk ? nullptr : &msv[b + 1];
+        if (mn) {
+          mn->stats = at::empty({N, 4}, fopt);
+          mn->xhat = at::empty({N * D}, fopt);
+          mn->pre = at::empty({N, F}, fopt);
+          mn->h = at::empty({N, H}, fopt);
+        }
+        XCALL(xeq_node_block_fwd(N, fp(s), fp(x), fp(q[19]), fp(q[20]), fp(q[21]), fp(q[22]), fp(pk->bias_uv), fp(q[16]), fp(q[18]),
+                                 hy.inv_eps, pk->fwd.data_ptr(), fpm(p_scr), fpm(u.uv), fpm(u.stats), fpm(u.pre), fpm(u.a), fpm(u.ip),
+                                 fpm(s_out), fpm(x_out), qn ? fp(qn[6]) : nullptr, qn ? fp(qn[7]) : nullptr, qn ? fp(qn[8]) : nullptr,
+                                 qn ? fp(qn[9]) : nullptr, qn ? fp(qn[1]) : nullptr, qn ? fp(qn[3]) : nullptr,
+                                 mn ? fpm(mn->stats) : nullptr, mn ? fpm(mn->xhat) : nullptr, mn ? fpm(mn->pre) : nullptr,
+                                 mn ? fpm(mn->h) : nullptr, st));
+        s = s_out;
+        x = x_out;
+        if (mn) {
+          mn->s = s;
+          mn->x = x;
+        }
+        continue;
+      }
       Tensor cat = at::empty({N, F + C}, fopt);
       u.uv = at::empty({2 * N * D}, fopt);
       Tensor p = at::empty({N, C}, fopt);
@@ -615,9 +708,31 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                               hy.rbf_kind, hy.cutoff_kind, hy.B, hy.cutoff, p0.data_ptr(), OP(p1), g.rev.basis.data_ptr(),
                               g.rev.dbasis.data_ptr(), st));
     }
+    Tensor pend_gh, pend_gxhat;   // gradients of the next block's (h, xhat): reversed by the node block of the update in front of it
     for (int b = hy.blocks - 1; b >= 0; --b) {
       const Tensor* q = &prm[P_BLOCK0 + P_PER_BLOCK * b];
-      {  // UpdateBlock.backward
+      if (nb_ok) {  // NodeBlock.backward
+        const UpdSaved& u = usv[b];
+        const bool last_blk = b == hy.blocks - 1;
+        const Tensor* qn = last_blk ? nullptr : &prm[P_BLOCK0 + P_PER_BLOCK * (b + 1)];
+        const NbPacks* pk = nb_packs(q, qn, !last_blk);
+        const MsgSaved* mn = last_blk ? nullptr : &msv[b + 1];
+        auto fp = [](const Tensor& t) { return t.defined() ? (const float*)t.data_ptr() : nullptr; };
+        Tensor ns = at::empty_like(u.s), nx = at::empty_like(u.x);
+        Tensor gxo = last_blk ? Tensor() : at::empty({N, D}, fopt);
+        Tensor gp = at::empty({N, C}, fopt), gv = at::empty({N, C}, fopt), gw = at::empty({N, D}, fopt);
+        if (!last_blk && !g_x.defined()) g_x = at::zeros({N, D}, fopt);
+        XCALL(xeq_node_block_bwd(N, fp(pend_gh), fp(pend_gxhat), fp(g_s), fp(g_x), mn ? fp(mn->s) : nullptr, mn ? fp(mn->x) : nullptr,
+                                 mn ? fp(mn->stats) : nullptr, mn ? fp(mn->pre) : nullptr, qn ? fp(qn[6]) : nullptr,
+                                 qn ? fp(qn[8]) : nullptr, fp(u.uv), fp(u.a), fp(u.ip), fp(u.pre), fp(u.s), fp(u.x), fp(u.stats), fp(q[19]),
+                                 fp(q[21]), hy.inv_eps, pk->bwd.data_ptr(), gxo.defined() ? (float*)gxo.data_ptr() : nullptr,
+                                 (float*)gp.data_ptr(), (float*)gv.data_ptr(), (float*)gw.data_ptr(), (float*)ns.data_ptr(),
+                                 (float*)nx.data_ptr(), st));
+        g_s = ns;
+        g_x = nx;
+        pend_gh = Tensor();
+        pend_gxhat = Tensor();
+      } else {  // UpdateBlock.backward
         const UpdSaved& u = usv[b];
         Tensor g_a = at::empty_like(u.a), g_ip = at::empty_like(u.ip);
         const void* gx_ptr = g_x.defined() ? g_x.data_ptr() : nullptr;
@@ -683,6 +798,11 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         }
         g_vec_total = g_vec_total.defined() ? g_vec_total + g_vec : g_vec;
         if (b == 0) break;   // the first block's node features (embedding, zeros) do not depend on the positions
+        if (nb_ok) {         // the front half of this block is reversed by the node block of update b - 1; g_s, g_x: the residual path
+          pend_gh = g_h;
+          pend_gxhat = g_xhat;
+          continue;
+        }
         const Tensor g_shat = mlp_bwd(g_h, m.pre, q[0], q[1], q[2], q[3]);
         Tensor ns, nx;
         norm_bwd(hy, m.s, m.x, q[6], q[8], m.stats, g_shat, F, g_xhat, g_s, g_x, ns, nx);

@@ -425,6 +425,49 @@ def _packed_uv_frag(module):
     return frag, bias is not None, frag_t
 
 
+class NodeBlock(Function):
+    """XPainnUpdate.forward (nn/xpainn.py:206-231) and, for every block but the last, the front half of the NEXT
+    XPainnMessage.forward (nn/xpainn.py:128-139: both norms, scalar_mlp) as ONE launch per direction (csrc/xeq_nodeblock.hip).
+    Outputs (s_out, x_out[, h_next, xhat_next]): the message kernel of the next block takes all four (ops.FusedMessage), so its
+    reverse hands all four gradients back in one call."""
+
+    @staticmethod
+    def forward(ctx, s, x, update, message):
+        from . import nodeblock
+
+        lib.require_hip(s, x)
+        s, x = s.contiguous(), x.contiguous()
+        want_x = message is not None or not getattr(update, "equivariant_output_unused", False)
+        o = nodeblock.node_block_fwd(s, x, update, message, want_x=want_x)
+        ctx.update, ctx.message = update, message
+        ctx.keys = [k for k in ("uv", "stats", "pre", "a", "ip", "s_out", "x_out", "stats2", "pre2") if o.get(k) is not None]
+        ctx.save_for_backward(s, x, *[o[k] for k in ctx.keys])
+        ctx.set_materialize_grads(False)
+        if message is None:
+            return o["s_out"], o["x_out"]
+        return o["s_out"], o["x_out"], o["h2"], o["xhat2"]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_s_out, g_x_out, g_h=None, g_xhat=None):
+        from . import nodeblock
+
+        s, x = ctx.saved_tensors[:2]
+        saved = dict(zip(ctx.keys, ctx.saved_tensors[2:]))
+        message = ctx.message
+        if g_s_out is None:
+            g_s_out = torch.zeros_like(s)
+        if message is not None:
+            if g_h is None:
+                g_h = torch.zeros((s.shape[0], message.hidden_dim), dtype=s.dtype, device=s.device)
+            if g_xhat is None:
+                g_xhat = torch.zeros(x.numel(), dtype=x.dtype, device=x.device)
+            if g_x_out is None:
+                g_x_out = torch.zeros_like(x)
+        g_s, g_x = nodeblock.node_block_bwd(saved, s, x, ctx.update, message, g_s_out, g_x_out, g_h, g_xhat)
+        return g_s, g_x, None, None
+
+
 # xeq_update_uv_bwd can run the norms' reverse inside (113 KB of LDS: one workgroup per CU; 24 against 28 us at 1.5 k nodes) or leave
 # it to xeq_norm_bwd (50 KB: three per CU; 92 against 99 us at 18 k nodes).  The two forms reduce a row in different orders, so a
 # switch by node count made a node's bits depend on its batch (6e-7 in the forces between a 9 k-node batch and its 2 k-node

@@ -107,6 +107,8 @@ class XPaiNN(BaseModel):
             self.mods[f"update_{i}"] = XPainnUpdate(
                 node_dim=node_dim, node_irreps=node_irreps, activation=activation, layer_norm=layer_norm,
             )
+        for i in range(action_blocks - 1):   # an update block launches the front half of the message block behind it (nn/fused.py::NodeBlock)
+            self.mods[f"update_{i}"]._next_message = [self.mods[f"message_{i + 1}"]]
         if output_modes is None:
             output_modes = ["energy"]
         elif isinstance(output_modes, str) or not isinstance(output_modes, Iterable):

@@ -16,7 +16,8 @@ import torch.nn as nn
 from .. import keys, o3, ops
 from .basic import Int2c1eEmbedding, edge_graph, resolve_activation
 from . import training
-from .fused import EmbeddingLinear, MessageBlock, UpdateBlock, message_params, update_params
+from . import nodeblock
+from .fused import EmbeddingLinear, MessageBlock, NodeBlock, UpdateBlock, message_params, update_params
 from .o3layer import EquivariantDot, EquivariantLayerNorm, Invariant
 from .rbf import resolve_cutoff, resolve_rbf
 
@@ -29,6 +30,10 @@ EQUIVARIANT_IS_ZERO = "_xeq_equivariant_is_zero"
 # private data-dict entry a caller with static buffers (runtime.GraphedStep*) may set: an all-zero [n_atoms, irreps.dim] tensor nobody
 # writes to, used as the start value of the equivariant features instead of a fresh zero fill per evaluation
 ZERO_EQUIVARIANT = "_xeq_zero_equivariant"
+# private data-dict entry written by an XPainnUpdate that ran the fused node-block launch (csrc/xeq_nodeblock.hip) together with the
+# front half of the message block behind it: (s, x, h, xhat) -- the block's outputs and the next block's scalar_mlp output and
+# normalised equivariant features (BT layout).  The message block consumes it when (s, x) are the tensors it is handed.
+PRESTAGE = "_xeq_message_prestage"
 
 
 class XEmbedding(nn.Module):
@@ -152,7 +157,14 @@ class XPainnMessage(nn.Module):
         rbf, cutoff_fn = data[RADIAL_SPEC]
         if rbf.num_basis != self.num_basis:
             raise ValueError(f"num_basis mismatch: embedding {rbf.num_basis} vs message {self.num_basis}")
-        if self.fused:  # block-level path: explicit forward/reverse, see nn/fused.py
+        pre = data.pop(PRESTAGE, None)
+        if self.fused and pre is not None and pre[0] is ori_scalar and pre[1] is ori_equi and not data.get(training.PARAM_GRADS, False):
+            # norms and scalar_mlp came out of the update block's launch: the message kernel alone is left (nn/fused.py::NodeBlock)
+            p0, p1 = rbf.params()
+            cfg = (rbf.kind, cutoff_fn.kind, self.num_basis, float(cutoff_fn.cutoff), self.node_dim, self._mul, 1)
+            new_scalar, new_equi = ops.FusedMessage.apply(pre[2], pre[3], data[keys.EDGE_VECTOR], ori_scalar, ori_equi,
+                                                          self.rbf_lin.weight, self.rbf_lin.bias, p0, p1, edge_graph(data), cfg)
+        elif self.fused:  # block-level path: explicit forward/reverse, see nn/fused.py
             params = message_params(self, rbf) if data.get(training.PARAM_GRADS, False) else ()
             new_scalar, new_equi = MessageBlock.apply(ori_scalar, ori_equi, data[keys.EDGE_VECTOR], self, edge_graph(data), rbf, cutoff_fn,
                                                       x_is_zero, *params)
@@ -206,10 +218,31 @@ class XPainnUpdate(nn.Module):
         # set by the model on its last update block when no head reads the equivariant features: they are then not computed
         # (data[NODE_EQUIVARIANT] is None behind the block)
         self.equivariant_output_unused = False
+        # set by the model: [the message block that follows this update block] (a plain list: not a registered sub-module); its norms
+        # and scalar_mlp then run inside this block's launch
+        self._next_message = []
+
+    def _node_block_ok(self, data) -> bool:
+        """One fused launch per direction for the whole block (nn/fused.py::NodeBlock): f32 on the GPU, the default layout, no
+        parameter gradients wanted (the native training pass keeps the kernels that save what the weight gradients read)."""
+        import os
+
+        s = data[keys.NODE_INVARIANT]
+        return (os.environ.get("XEQ_NODE_BLOCK", "1") != "0" and s.is_cuda and s.dtype == torch.float32
+                and not data.get(training.PARAM_GRADS, False) and nodeblock.supported(self))
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if training.active(self, data):
             return training.update(self, data)
+        if self.fused and self._node_block_ok(data):
+            nxt = self._next_message[0] if self._next_message else None
+            if nxt is not None and not (nxt.fused and nodeblock.supported(self, nxt)):
+                nxt = None
+            out = NodeBlock.apply(data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT], self, nxt)
+            data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT] = out[0], out[1]
+            if nxt is not None:
+                data[PRESTAGE] = out
+            return data
         if self.fused:
             params = update_params(self) if data.get(training.PARAM_GRADS, False) else ()
             s_new, x_new = UpdateBlock.apply(data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT], self, *params)
