@@ -594,14 +594,18 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
  * xeq_node_block_fwd = XPainnUpdate.forward (nn/xpainn.py:206-231: both norms, o3.Linear U / V, Invariant, EquivariantDot, update_mlp,
  * dot_lin, residual update) and, when h_next != NULL, the front half of the NEXT XPainnMessage.forward (nn/xpainn.py:128-139: both
  * norms of (s_out, x_out) and scalar_mlp).  It replaces xeq_update_uv_fwd + xeq_mlp2_fwd + xeq_linear_fwd + xeq_update_out_fwd
- * (+ xeq_norm_fwd + xeq_mlp2_fwd of the next block) and writes what they wrote, in their layouts: uv_bt (U|V pair buffer, BT),
- * stats [n, 4], pre [n, F] (update_mlp hidden pre-activation), a [n, C + 2 F], ip [n, F] (dot_lin output), s_out [n, F], x_out [n, D]
- * (NULL: no consumer), and for the next block stats_next [n, 4], xhat_next (BT), pre_next [n, F], h_next [n, F + 2 C].
+ * (+ xeq_norm_fwd + xeq_mlp2_fwd of the next block).  What other kernels read keeps their layouts: s_out [n, F], x_out [n, D] (NULL: no
+ * consumer), stats [n, 4], and for the next block stats_next [n, 4], xhat_next (BT), h_next [n, F + 2 C].  What only the reverse launch
+ * reads is INTERNAL: uv (U|V), pre (update_mlp hidden pre-activation), a (update_mlp output), ip (dot_lin output), pre_next and the
+ * scratch p -- xeq_node_block_rows(n) rows each (whole workgroups of 128 nodes) in the wave-native layout [block of 32 nodes][tile of
+ * 32 channels][register quad][lane][4 floats], in which every wave access is 1 KB of consecutive bytes (tile numbering:
+ * csrc/xeq_nodeblock.hip, uv_tile / x_tile; nn/nodeblock.py::native_to_rows turns one into rows).
  * packed: xeq_node_block_pack_fwd(update_mlp[0].weight [F, F + C], [W_U | W_V] / sqrt(mul_l) as [mul_l, 2 mul_l] for l = 0, 1, 2,
  * dot_lin.weight [F, C], update_mlp[2].weight [C + 2 F, F], next scalar_mlp[0].weight [F, F] and [2].weight [F + 2 C, F] (both
  * NULL: without the next block), out, stream); out holds xeq_node_block_fwd_tiles(with_tail) * 3072 bytes.
  * b_uv = [update_U.bias | update_V.bias] ([2 F]) or NULL; p_scratch: [n, C] floats (EquivariantDot(U, V), read back by dot_lin). */
 int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]);
+int64_t xeq_node_block_rows(int64_t n);
 int64_t xeq_node_block_fwd_tiles(int with_tail);
 int xeq_node_block_pack_fwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,
                             const float* w1_next, const float* w2_next, void* out, void* stream);
@@ -615,8 +619,8 @@ int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* l
  * update block.  With the next block's front half (g_h != NULL): g_h [n, F + 2 C] and g_xhat_next (BT) are the gradients of h_next /
  * xhat_next, g_s_in / g_x_in the gradients that reach s_out / x_out directly (the message kernel's residual path), and s_out, x_out,
  * stats_next, pre_next what the forward launch wrote.  Without it: g_s_in = dL/ds_out, g_x_in = dL/dx_out or NULL (zero: the last
- * block of a force evaluation; packed with with_gx = 0).  Scratch (caller-owned): gxo [n, D] (front half only), gp [n, C], gv [n, C],
- * gw [n, D].  Output: g_s [n, F], g_x [n, D].  packed: xeq_node_block_pack_bwd of the same weight tensors as the forward pack. */
+ * block of a force evaluation; packed with with_gx = 0).  Scratch (caller-owned, xeq_node_block_rows(n) rows each, internal layout):
+ * gxo [., D] (whenever dL/dx_out is not zero), gp [., C], gv [., C], gw [., D].  Output: g_s [n, F], g_x [n, D].  packed: xeq_node_block_pack_bwd of the same weight tensors as the forward pack. */
 int64_t xeq_node_block_bwd_tiles(int with_tail, int with_gx);
 int xeq_node_block_pack_bwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,
                             const float* w1_next, const float* w2_next, int with_gx, void* out, void* stream);

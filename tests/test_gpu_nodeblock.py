@@ -29,6 +29,21 @@ def _bt_to_mulir(buf, n, width):
     return [torch.cat(o, 1) for o in outs]
 
 
+def _uv_native_to_mulir(buf, n):
+    """The U|V buffer in the kernels' internal layout (tile numbering of csrc/xeq_nodeblock.hip::uv_tile) -> (U, V) in e3nn layout."""
+    from xequinet_amd.nn import nodeblock
+
+    rows = nodeblock.native_to_rows(buf, n, 2 * D).view(n, 2 * D // 32, 32)    # [n, tile, channel in tile]
+    U, V = [], []
+    tile = lambda l, m, v, c: 4 * v + c if l == 0 else (8 + 4 * m + 2 * v + c if l == 1 else 20 + 2 * m + v)
+    for l, mul in enumerate(MUL):
+        d = 2 * l + 1
+        for v, out in ((0, U), (1, V)):
+            blk = torch.stack([torch.cat([rows[:, tile(l, m, v, c)] for c in range(mul // 32)], 1) for m in range(d)], 2)   # [n, mul, d]
+            out.append(blk.reshape(n, mul * d))
+    return torch.cat(U, 1), torch.cat(V, 1)
+
+
 def _close(name, got, ref, tol):
     got = got.detach().double().cpu()
     ref = ref.detach().double().cpu()
@@ -142,7 +157,9 @@ def test_node_block_forward_matches_f64(n, tail):
     got = nodeblock.node_block_fwd(s, x, upd, msg if tail else None, want_x=True)
     torch.cuda.synchronize()
     ref = _reference(upd, msg if tail else None, s, x)
-    U, V = _bt_to_mulir(got["uv"], n, 2)
+    U, V = _uv_native_to_mulir(got["uv"], n)
+    for k, width in (("pre", F), ("a", C + 2 * F), ("ip", F)) + ((("pre2", F),) if tail else ()):
+        got[k] = nodeblock.native_to_rows(got[k], n, width)
     tol = 3e-6
     worst = {}
     worst["U"] = _close("U", U, ref["U"], tol)
@@ -169,8 +186,10 @@ def test_node_block_forward_rows_do_not_depend_on_the_batch():
     full = nodeblock.node_block_fwd(s, x, upd, msg)
     part = nodeblock.node_block_fwd(s[37:171].contiguous(), x[37:171].contiguous(), upd, msg)
     torch.cuda.synchronize()
-    for k in ("s_out", "x_out", "h2", "pre2", "a", "ip", "pre"):
+    for k in ("s_out", "x_out", "h2"):
         assert torch.equal(full[k][37:171], part[k]), k
+    for k, width in (("pre2", F), ("a", C + 2 * F), ("ip", F), ("pre", F)):
+        assert torch.equal(nodeblock.native_to_rows(full[k], 300, width)[37:171], nodeblock.native_to_rows(part[k], 134, width)), k
 
 
 def _reference_diff(upd, msg, s, x):

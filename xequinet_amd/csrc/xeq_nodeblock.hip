@@ -263,6 +263,32 @@ __device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, 
   for (int g = 0; g < 4; ++g)
     *reinterpret_cast<float4*>(row + c0 + 8 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
 }
+// Tensors that only these kernels read and write (the forward launch's hand-over to the reverse launch, scratch) use a layout in which
+// every wave access is 1 KB of consecutive bytes: [wave block of 32 nodes][tile][register quad][lane][4 floats].  (A row-major
+// tile access touches 32 rows with 32 bytes each: the texture addresser pays per row, and these kernels move ~10 KB per node.)
+__device__ __forceinline__ f32x16 ld_nat(const float* __restrict__ wb, int t, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(wb + t * 1024) + lane;
+  f32x16 r;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = p[64 * g];
+    r[4 * g] = v.x;
+    r[4 * g + 1] = v.y;
+    r[4 * g + 2] = v.z;
+    r[4 * g + 3] = v.w;
+  }
+  return r;
+}
+__device__ __forceinline__ void st_nat(float* __restrict__ wb, int t, int lane, const f32x16& v) {
+  float4* p = reinterpret_cast<float4*>(wb + t * 1024) + lane;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) p[64 * g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+// tile numbers: the U|V buffer (l, component m, 0 U / 1 V, channel tile c) and equivariant rows (l, m, c)
+constexpr int UV_TILES = 2 * D / 32, X_TILES = D / 32, A_TILES = AU / 32, P_TILES = C / 32, S_TILES = F / 32;
+__device__ __forceinline__ constexpr int uv_tile(int l, int m, int v, int c) { return l == 0 ? 4 * v + c : (l == 1 ? 8 + 4 * m + 2 * v + c : 20 + 2 * m + v); }
+__device__ __forceinline__ constexpr int x_tile(int l, int m, int c) { return l == 0 ? c : (l == 1 ? 4 + 3 * c + m : 10 + m); }
+
 // e3nn mul_ir rows (channel-major, m-minor): the DL components of 32 channels of one l > 0 block; `blk` = the block's first float
 // of the row + DL * 32 * tile
 template <int DL>
@@ -522,7 +548,12 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   NB_STAMP(1);
   const float* __restrict__ srow = a.s + row * F;
   const float* __restrict__ xrow = a.x + row * D;
-  float* __restrict__ prow = a.p + row * C;
+  const int64_t wblk = (int64_t)blockIdx.x * 4 + wave;   // this wave's block of 32 nodes in the internal layout
+  float* __restrict__ pw = a.p + wblk * (P_TILES * 1024);
+  float* __restrict__ uvw = a.uv + wblk * (UV_TILES * 1024);
+  float* __restrict__ prew = a.pre + wblk * (S_TILES * 1024);
+  float* __restrict__ ipw = a.ip + wblk * (S_TILES * 1024);
+  float* __restrict__ aw = a.a + wblk * (A_TILES * 1024);
   const bool wx = a.x_out != nullptr;
   const float e1 = a.eps, e2 = a.eps * a.eps;
 
@@ -576,7 +607,6 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
       fx[2 * t] = split_k<0>(xh);
       fx[2 * t + 1] = split_k<1>(xh);
     }
-    float* __restrict__ uvr = a.uv + row * (2 * M0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       f32x16 bu = zero16(), bv = zero16();
@@ -592,15 +622,15 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
       }
       U += bu;
       V += bv;
-      st_tile(uvr, 32 * c, h, U, ok);
-      st_tile(uvr, M0 + 32 * c, h, V, ok);
+      st_nat(uvw, uv_tile(0, 0, 0, c), lane, U);
+      st_nat(uvw, uv_tile(0, 0, 1, c), lane, V);
       f32x16 v, p;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         v[r] = sqrtf(__builtin_fmaf(V[r], V[r], e2)) - e1;
         p[r] = U[r] * V[r];
       }
-      st_tile(prow, 32 * c, h, p, ok);
+      st_nat(pw, c, lane, p);
       accum_tile<4>(w, HID, v);
     }
   }
@@ -617,7 +647,6 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
         for (int r = 0; r < 16; ++r) X1[t][m][r] = X1[t][m][r] * rr * wv[r];
     }
     f32x16 VSQ[2] = {zero16(), zero16()}, PP[2] = {zero16(), zero16()};
-    float* __restrict__ uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       Frag fx[4] = {split_k<0>(X1[0][m]), split_k<1>(X1[0][m]), split_k<0>(X1[1][m]), split_k<1>(X1[1][m])};
@@ -629,8 +658,8 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
           mfma6(U, w.next(), fx[k]);
           mfma6(V, w.next(), fx[k]);
         }
-        st_tile(uvb + m * 2 * M1, 32 * c, h, U, ok);
-        st_tile(uvb + m * 2 * M1, M1 + 32 * c, h, V, ok);
+        st_nat(uvw, uv_tile(1, m, 0, c), lane, U);
+        st_nat(uvw, uv_tile(1, m, 1, c), lane, V);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           VSQ[c][r] = __builtin_fmaf(V[r], V[r], VSQ[c][r]);
@@ -640,7 +669,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      st_tile(prow, M0 + 32 * c, h, PP[c], ok);
+      st_nat(pw, 4 + c, lane, PP[c]);
       f32x16 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = sqrtf(VSQ[c][r] + e2) - e1;
@@ -657,7 +686,6 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) X2[m][r] = X2[m][r] * rr * wv[r];
     f32x16 VSQ = zero16(), PP = zero16();
-    float* __restrict__ uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
       Frag fx[2] = {split_k<0>(X2[m]), split_k<1>(X2[m])};
@@ -667,15 +695,15 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
         mfma6(U, w.next(), fx[k]);
         mfma6(V, w.next(), fx[k]);
       }
-      st_tile(uvb + m * 2 * M2, 0, h, U, ok);
-      st_tile(uvb + m * 2 * M2, M2, h, V, ok);
+      st_nat(uvw, uv_tile(2, m, 0, 0), lane, U);
+      st_nat(uvw, uv_tile(2, m, 1, 0), lane, V);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         VSQ[r] = __builtin_fmaf(V[r], V[r], VSQ[r]);
         PP[r] = __builtin_fmaf(U[r], V[r], PP[r]);
       }
     }
-    st_tile(prow, M0 + M1, h, PP, ok);
+    st_nat(pw, 6, lane, PP);
     f32x16 v;
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = sqrtf(VSQ[r] + e2) - e1;
@@ -687,7 +715,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     HID[t] += ld_tile(a.b3, 32 * t, h);
-    st_tile(a.pre + row * F, 32 * t, h, HID[t], ok);
+    st_nat(prew, t, lane, HID[t]);
     f32x16 hv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hv[r] = silu_f(HID[t][r]);
@@ -695,7 +723,6 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     fh[2 * t + 1] = split_k<1>(hv);
   }
   NB_STAMP(7);
-  float* __restrict__ arow = a.a + row * AU;
   float* __restrict__ xor_ = wx ? a.x_out + row * D : nullptr;
   float q2 = 0.f;      // TAIL: sum of squares of the new l > 0 features
   f32x16 XN0[4];       // TAIL: new 0e features (two-pass statistics)
@@ -706,13 +733,13 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     const f32x16 b4v = ld_tile(a.b4, 32 * c, h);
     f32x16 U = zero16(), X0c = zero16();
     if (wx) {
-      U = ld_tile(a.uv + row * (2 * M0), 32 * c, h);
+      U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane);
       X0c = ld_tile(xrow, 32 * c, h);
     }
     f32x16 av = zero16();
     out_tile<8>(w, av, fh);
     av += b4v;
-    st_tile(arow, 32 * c, h, av, ok);
+    st_nat(aw, c, lane, av);
     if (wx) {
       f32x16 xn;
 #pragma unroll
@@ -727,14 +754,13 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     f32x16 X[3], U[3];
     if (wx) {
       ld_xm<3>(xrow + M0 + 3 * 32 * c, h, X);
-      const float* uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
 #pragma unroll
-      for (int m = 0; m < 3; ++m) U[m] = ld_tile(uvb + m * 2 * M1, 32 * c, h);
+      for (int m = 0; m < 3; ++m) U[m] = ld_nat(uvw, uv_tile(1, m, 0, c), lane);
     }
     f32x16 av = zero16();
     out_tile<8>(w, av, fh);
     av += b4v;
-    st_tile(arow, M0 + 32 * c, h, av, ok);
+    st_nat(aw, 4 + c, lane, av);
     if (wx) {
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
@@ -750,14 +776,13 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     f32x16 X[5], U[5];
     if (wx) {
       ld_xm<5>(xrow + M0 + 3 * M1, h, X);
-      const float* uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
 #pragma unroll
-      for (int m = 0; m < 5; ++m) U[m] = ld_tile(uvb + m * 2 * M2, 0, h);
+      for (int m = 0; m < 5; ++m) U[m] = ld_nat(uvw, uv_tile(2, m, 0, 0), lane);
     }
     f32x16 av = zero16();
     out_tile<8>(w, av, fh);
     av += b4v;
-    st_tile(arow, M0 + M1, h, av, ok);
+    st_nat(aw, 6, lane, av);
     if (wx) {
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
@@ -774,7 +799,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   {
     f32x16 P[7];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) P[t] = ld_tile(prow, 32 * t, h);
+    for (int t = 0; t < 7; ++t) P[t] = ld_nat(pw, t, lane);
 #pragma unroll
     for (int t = 0; t < 7; ++t) accum_tile<4>(w, IP, P[t]);
   }
@@ -784,14 +809,14 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const f32x16 bsv = ld_tile(a.b4, C + 32 * c, h), bss = ld_tile(a.b4, C + F + 32 * c, h), S = ld_tile(srow, 32 * c, h);
-    st_tile(a.ip + row * F, 32 * c, h, IP[c], ok);
+    st_nat(ipw, c, lane, IP[c]);
     f32x16 asv = zero16(), ass = zero16();
     out_tile<8>(w, asv, fh);
     out_tile<8>(w, ass, fh);
     asv += bsv;
     ass += bss;
-    st_tile(arow, C + 32 * c, h, asv, ok);
-    st_tile(arow, C + F + 32 * c, h, ass, ok);
+    st_nat(aw, 7 + c, lane, asv);
+    st_nat(aw, 11 + c, lane, ass);
 #pragma unroll
     for (int r = 0; r < 16; ++r) SN[c][r] = (S[r] + asv[r] * IP[c][r]) + ass[r];
     st_tile(sor, 32 * c, h, SN[c], ok);
@@ -850,7 +875,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     HN[t] += ld_tile(a.b1n, 32 * t, h);
-    st_tile(a.pre2 + row * F, 32 * t, h, HN[t], ok);
+    st_nat(a.pre2 + wblk * (S_TILES * 1024), t, lane, HN[t]);
     f32x16 hv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hv[r] = silu_f(HN[t][r]);
@@ -906,8 +931,8 @@ static void program_bwd(bool tail, bool gx, std::vector<Seg>& p) {
   if (gx) p.push_back({B_W4, 0, 4, 1, 0, 7, 1, 0});     // g_hidden += W4^T[:, a_vv tiles]
   p.push_back({B_W4, 0, 4, 1, 7, 8, 1, 0});             //           += W4^T[:, a_sv | a_ss tiles]
   p.push_back({B_W3, 0, 4, 1, 0, 4, 1, 1});             // g_shat tiles
-  p.push_back({B_DOT, 0, 7, 1, 0, 4, 1, 1});            // g_p tiles
   p.push_back({B_W3, 4, 7, 1, 0, 4, 1, 1});             // g_v tiles
+  p.push_back({B_DOT, 0, 7, 1, 0, 4, 1, 1});            // g_p tiles
   for (int c = 0; c < 4; ++c) p.push_back({B_UV0, 0, 4, 1, c, 2, M0 / 32, 0});            // g_xhat_0 += W_U^T g_U_c + W_V^T g_V_c
   for (int c = 0; c < 2; ++c)
     for (int m = 0; m < 3; ++m) p.push_back({B_UV1, 0, 2, 1, c, 2, M1 / 32, 0});
@@ -929,28 +954,29 @@ struct BwdArgs {
   float *g_s, *g_x;             // dL/ds, dL/dx of the block's inputs
 };
 
-// LayerNorm reverse on four scalar tiles: G[t] = rstd (dy - mean(dy) - yh mean(dy yh)) + res[t], dy = g w, yh = (s - mean) rstd
-__device__ __forceinline__ void ln_bwd(f32x16 (&G)[4], const f32x16 (&g)[4], const float* __restrict__ srow, const float* __restrict__ lnw,
-                                       float mean, float rstd, const f32x16 (&res)[4], int h) {
-  f32x16 dy[4], yh[4];
+// LayerNorm reverse on four scalar tiles, in place: g <- rstd (dy - mean(dy) - yh mean(dy yh)) + res, dy = g w, yh = (s - mean) rstd
+// (two sweeps over the row's s and weight tiles: they are re-read rather than held)
+__device__ __forceinline__ void ln_bwd(f32x16 (&g)[4], const float* __restrict__ srow, const float* __restrict__ lnw, float mean, float rstd,
+                                       const f32x16 (&res)[4], int h) {
   float a1 = 0.f, a2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const f32x16 wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      dy[t][r] = g[t][r] * wv[r];
-      yh[t][r] = (sv[r] - mean) * rstd;
-      a1 += dy[t][r];
-      a2 = __builtin_fmaf(dy[t][r], yh[t][r], a2);
+      const float dy = g[t][r] * wv[r];
+      a1 += dy;
+      a2 = __builtin_fmaf(dy, (sv[r] - mean) * rstd, a2);
     }
   }
   a1 = row_sum(a1) * (1.f / F);
   a2 = row_sum(a2) * (1.f / F);
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) G[t][r] = rstd * (dy[t][r] - a1 - yh[t][r] * a2) + res[t][r];
+    for (int r = 0; r < 16; ++r) g[t][r] = rstd * (g[t][r] * wv[r] - a1 - ((sv[r] - mean) * rstd) * a2) + res[t][r];
+  }
 }
 
 template <bool TAIL, bool GX>
@@ -965,7 +991,15 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   WStream w;
   w.init(a.wp, ring, a.n_tiles, lane, wave);
   const float e2 = a.eps * a.eps;
-  float* __restrict__ gxo = a.gxo + row * D;   // total dL/dx_out of this node (GX)
+  const int64_t wblk = (int64_t)blockIdx.x * 4 + wave;   // this wave's block of 32 nodes in the internal layout
+  float* __restrict__ gxow = a.gxo + wblk * (X_TILES * 1024);   // total dL/dx_out (GX)
+  float* __restrict__ gww = a.gw + wblk * (X_TILES * 1024);
+  float* __restrict__ gpw = a.gp + wblk * (P_TILES * 1024);
+  float* __restrict__ gvw = a.gv + wblk * (P_TILES * 1024);
+  const float* __restrict__ uvw = a.uv + wblk * (UV_TILES * 1024);
+  const float* __restrict__ aw = a.a + wblk * (A_TILES * 1024);
+  const float* __restrict__ prew = a.pre + wblk * (S_TILES * 1024);
+  const float* __restrict__ ipw = a.ip + wblk * (S_TILES * 1024);
 
   f32x16 GS[4];   // total dL/ds_out
   if (TAIL) {
@@ -981,7 +1015,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     Frag fg[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 pv = ld_tile(a.pre2 + row * F, 32 * t, h);
+      const f32x16 pv = ld_nat(a.pre2 + wblk * (S_TILES * 1024), t, lane);
       f32x16 gv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gv[r] = GH[t][r] * silu_grad_f(pv[r]);
@@ -995,7 +1029,9 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
       out_tile<8>(w, gsh[t], fg);
     }
     const float4 st2 = *reinterpret_cast<const float4*>(a.stats2 + 4 * row);
-    ln_bwd(GS, gsh, a.s_out + row * F, a.lnw2, st2.x, st2.y, res, h);
+    ln_bwd(gsh, a.s_out + row * F, a.lnw2, st2.x, st2.y, res, h);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) GS[t] = gsh[t];
     // ---- reverse of the next block's EquivariantLayerNorm (nn/o3layer.py:145-171) on x_out: two sweeps over the row
     const float mean0 = st2.z, r2 = st2.w;
     const float* __restrict__ xo = a.x_out + row * D;
@@ -1044,7 +1080,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
       f32x16 o;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = ((r2 * (g[r] * wv[r]) - coef * (xv[r] - mean0)) - gmean) + rv[r];
-      st_tile(gxo, 32 * t, h, o, ok);
+      st_nat(gxow, x_tile(0, 0, t), lane, o);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1058,7 +1094,8 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) X[m][r] = (r2 * (g[r] * wv[r]) - coef * X[m][r]) + R[m][r];
       }
-      st_xm<3>(gxo + M0 + 3 * 32 * t, h, X, ok);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) st_nat(gxow, x_tile(1, m, t), lane, X[m]);
     }
     {
       f32x16 X[5], R[5];
@@ -1071,21 +1108,36 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) X[m][r] = (r2 * (g[r] * wv[r]) - coef * X[m][r]) + R[m][r];
       }
-      st_xm<5>(gxo + M0 + 3 * M1, h, X, ok);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) st_nat(gxow, x_tile(2, m, 0), lane, X[m]);
     }
   } else {
 #pragma unroll
     for (int t = 0; t < 4; ++t) GS[t] = ld_tile(a.g_s_in + row * F, 32 * t, h);
-    if (GX) gxo = const_cast<float*>(a.g_x_in) + row * D;   // the totals arrive in the caller's tensor: read only
+    if (GX) {   // the totals arrive in the caller's e3nn rows: into the internal layout once
+      const float* __restrict__ gxi = a.g_x_in + row * D;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st_nat(gxow, x_tile(0, 0, t), lane, ld_tile(gxi, 32 * t, h));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 R[3];
+        ld_xm<3>(gxi + M0 + 3 * 32 * t, h, R);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) st_nat(gxow, x_tile(1, m, t), lane, R[m]);
+      }
+      f32x16 R[5];
+      ld_xm<5>(gxi + M0 + 3 * M1, h, R);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) st_nat(gxow, x_tile(2, m, 0), lane, R[m]);
+    }
   }
 
   // ---- reverse of the output stage (nn/xpainn.py:218-229) into the reverse of update_mlp[2]: g_hidden += W4^T[:, chunk] g_a[chunk]
   f32x16 GHID[4] = {zero16(), zero16(), zero16(), zero16()};
-  const float* __restrict__ arow = a.a + row * AU;
   if (GX) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {   // g_a_vv = sum_m g_x_out U
-      const f32x16 U = ld_tile(a.uv + row * (2 * M0), 32 * c, h), G = ld_tile(gxo, 32 * c, h);
+      const f32x16 U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane), G = ld_nat(gxow, x_tile(0, 0, c), lane);
       f32x16 ga;
 #pragma unroll
       for (int r = 0; r < 16; ++r) ga[r] = G[r] * U[r];
@@ -1093,35 +1145,29 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      f32x16 G[3];
-      ld_xm<3>(gxo + M0 + 3 * 32 * c, h, G);
-      const float* uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
       f32x16 ga = zero16();
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        const f32x16 U = ld_tile(uvb + m * 2 * M1, 32 * c, h);
+        const f32x16 U = ld_nat(uvw, uv_tile(1, m, 0, c), lane), G = ld_nat(gxow, x_tile(1, m, c), lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ga[r] = __builtin_fmaf(G[m][r], U[r], ga[r]);
+        for (int r = 0; r < 16; ++r) ga[r] = __builtin_fmaf(G[r], U[r], ga[r]);
       }
       accum_tile<4>(w, GHID, ga);
     }
     {
-      f32x16 G[5];
-      ld_xm<5>(gxo + M0 + 3 * M1, h, G);
-      const float* uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
       f32x16 ga = zero16();
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
-        const f32x16 U = ld_tile(uvb + m * 2 * M2, 0, h);
+        const f32x16 U = ld_nat(uvw, uv_tile(2, m, 0, 0), lane), G = ld_nat(gxow, x_tile(2, m, 0), lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ga[r] = __builtin_fmaf(G[m][r], U[r], ga[r]);
+        for (int r = 0; r < 16; ++r) ga[r] = __builtin_fmaf(G[r], U[r], ga[r]);
       }
       accum_tile<4>(w, GHID, ga);
     }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {   // g_a_sv = g_s_out ip
-    const f32x16 ipv = ld_tile(a.ip + row * F, 32 * c, h);
+    const f32x16 ipv = ld_nat(ipw, c, lane);
     f32x16 ga;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ga[r] = GS[c][r] * ipv[r];
@@ -1129,59 +1175,63 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) accum_tile<4>(w, GHID, GS[c]);   // g_a_ss = g_s_out
-  // ---- g_hidden silu'(pre) -> fragments; g_ip = g_s_out a_sv -> fragments
-  Frag fgh[8], fgi[8];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const f32x16 pv = ld_tile(a.pre + row * F, 32 * t, h), asv = ld_tile(arow, C + 32 * t, h);
-    f32x16 gv, gi;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      gv[r] = GHID[t][r] * silu_grad_f(pv[r]);
-      gi[r] = GS[t][r] * asv[r];
-    }
-    fgh[2 * t] = split_k<0>(gv);
-    fgh[2 * t + 1] = split_k<1>(gv);
-    fgi[2 * t] = split_k<0>(gi);
-    fgi[2 * t + 1] = split_k<1>(gi);
-  }
   const float4 st = *reinterpret_cast<const float4*>(a.stats + 4 * row);
-  {  // ---- g_shat = W3^T[:F] g_hidden -> LayerNorm reverse -> g_s
-    f32x16 gsh[4] = {zero16(), zero16(), zero16(), zero16()}, G[4];
+  {  // ---- g_hidden silu'(pre) -> fragments; g_shat = W3^T[:F] g_hidden -> LayerNorm reverse -> g_s; g_v = W3^T[F:] g_hidden
+    Frag fgh[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) out_tile<8>(w, gsh[t], fgh);
-    ln_bwd(G, gsh, a.s + row * F, a.lnw, st.x, st.y, GS, h);
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 pv = ld_nat(prew, t, lane);
+      f32x16 gv;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) st_tile(a.g_s + row * F, 32 * t, h, G[t], ok);
+      for (int r = 0; r < 16; ++r) gv[r] = GHID[t][r] * silu_grad_f(pv[r]);
+      fgh[2 * t] = split_k<0>(gv);
+      fgh[2 * t + 1] = split_k<1>(gv);
+    }
+    {
+      f32x16 gsh[4] = {zero16(), zero16(), zero16(), zero16()};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) out_tile<8>(w, gsh[t], fgh);
+      ln_bwd(gsh, a.s + row * F, a.lnw, st.x, st.y, GS, h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st_tile(a.g_s + row * F, 32 * t, h, gsh[t], ok);
+    }
+    for (int t = 0; t < 7; ++t) {   // parked in scratch for the per-block sweeps
+      f32x16 acc = zero16();
+      out_tile<8>(w, acc, fgh);
+      st_nat(gvw, t, lane, acc);
+    }
   }
-  // ---- g_p = dot_lin^T g_ip and g_v = W3^T[F:] g_hidden, seven channel tiles each, parked in scratch for the per-block sweeps
-  float* __restrict__ gpr = a.gp + row * C;
-  float* __restrict__ gvr = a.gv + row * C;
-  for (int t = 0; t < 7; ++t) {
-    f32x16 acc = zero16();
-    out_tile<8>(w, acc, fgi);
-    st_tile(gpr, 32 * t, h, acc, ok);
-  }
-  for (int t = 0; t < 7; ++t) {
-    f32x16 acc = zero16();
-    out_tile<8>(w, acc, fgh);
-    st_tile(gvr, 32 * t, h, acc, ok);
+  {  // ---- g_ip = g_s_out a_sv -> fragments; g_p = dot_lin^T g_ip, seven channel tiles
+    Frag fgi[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x16 asv = ld_nat(aw, 7 + t, lane);
+      f32x16 gi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gi[r] = GS[t][r] * asv[r];
+      fgi[2 * t] = split_k<0>(gi);
+      fgi[2 * t + 1] = split_k<1>(gi);
+    }
+    for (int t = 0; t < 7; ++t) {
+      f32x16 acc = zero16();
+      out_tile<8>(w, acc, fgi);
+      st_nat(gpw, t, lane, acc);
+    }
   }
   // ---- per block l: g_U = g_x_out a_vv + g_p V, g_V = g_p U + g_v V / sqrt(sum_m V^2 + eps^2) (nn/o3layer.py:39-44, 104-109),
   // g_xhat = W_U^T g_U + W_V^T g_V; times the affine weight into scratch, with the sums the norm's reverse needs
   const float mean0 = st.z, rr = st.w;
   const float* __restrict__ xrow = a.x + row * D;
-  float* __restrict__ gwr = a.gw + row * D;
   float dotp = 0.f, sgw0 = 0.f, sxc0 = 0.f;
   {
     f32x16 GXH[4] = {zero16(), zero16(), zero16(), zero16()};
-    const float* uvr = a.uv + row * (2 * M0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const f32x16 U = ld_tile(uvr, 32 * c, h), V = ld_tile(uvr, M0 + 32 * c, h), gp = ld_tile(gpr, 32 * c, h), gv = ld_tile(gvr, 32 * c, h);
+      const f32x16 U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane), V = ld_nat(uvw, uv_tile(0, 0, 1, c), lane), gp = ld_nat(gpw, c, lane),
+                   gv = ld_nat(gvw, c, lane);
       f32x16 gU, gV;
       if (GX) {
-        const f32x16 G = ld_tile(gxo, 32 * c, h), av = ld_tile(arow, 32 * c, h);
+        const f32x16 G = ld_nat(gxow, x_tile(0, 0, c), lane), av = ld_nat(aw, c, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) gU[r] = __builtin_fmaf(G[r], av[r], gp[r] * V[r]);
       } else {
@@ -1205,7 +1255,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
         sgw0 += gw[r];
         sxc0 += xc;
       }
-      st_tile(gwr, 32 * t, h, gw, ok);
+      st_nat(gww, x_tile(0, 0, t), lane, gw);
     }
   }
   {
@@ -1215,23 +1265,23 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
       GXH[m][0] = zero16();
       GXH[m][1] = zero16();
     }
-    const float* uvb = a.uv + N * 2 * M0 + row * (3 * 2 * M1);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const f32x16 gp = ld_tile(gpr, M0 + 32 * c, h), gv = ld_tile(gvr, M0 + 32 * c, h);
+      const f32x16 gp = ld_nat(gpw, 4 + c, lane), gv = ld_nat(gvw, 4 + c, lane);
       f32x16 U[3], V[3], G[3];
       f32x16 vv = zero16();
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        U[m] = ld_tile(uvb + m * 2 * M1, 32 * c, h);
-        V[m] = ld_tile(uvb + m * 2 * M1, M1 + 32 * c, h);
+        U[m] = ld_nat(uvw, uv_tile(1, m, 0, c), lane);
+        V[m] = ld_nat(uvw, uv_tile(1, m, 1, c), lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) vv[r] = __builtin_fmaf(V[m][r], V[m][r], vv[r]);
       }
       f32x16 av = zero16();
       if (GX) {
-        ld_xm<3>(gxo + M0 + 3 * 32 * c, h, G);
-        av = ld_tile(arow, M0 + 32 * c, h);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) G[m] = ld_nat(gxow, x_tile(1, m, c), lane);
+        av = ld_nat(aw, 4 + c, lane);
       }
       f32x16 gvn;
 #pragma unroll
@@ -1260,25 +1310,26 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
           GW[m][r] = GXH[m][t][r] * wv[r];
           dotp = __builtin_fmaf(GW[m][r], X[m][r], dotp);
         }
-      st_xm<3>(gwr + M0 + 3 * 32 * t, h, GW, ok);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) st_nat(gww, x_tile(1, m, t), lane, GW[m]);
     }
   }
   {
     f32x16 GXH[5][1];
 #pragma unroll
     for (int m = 0; m < 5; ++m) GXH[m][0] = zero16();
-    const float* uvb = a.uv + N * 2 * (M0 + 3 * M1) + row * (5 * 2 * M2);
-    const f32x16 gp = ld_tile(gpr, M0 + M1, h), gv = ld_tile(gvr, M0 + M1, h);
+    const f32x16 gp = ld_nat(gpw, 6, lane), gv = ld_nat(gvw, 6, lane);
     f32x16 G[5];
     f32x16 av = zero16();
     if (GX) {
-      ld_xm<5>(gxo + M0 + 3 * M1, h, G);
-      av = ld_tile(arow, M0 + M1, h);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) G[m] = ld_nat(gxow, x_tile(2, m, 0), lane);
+      av = ld_nat(aw, 6, lane);
     }
     f32x16 vv = zero16();
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      const f32x16 V = ld_tile(uvb + m * 2 * M2, M2, h);
+      const f32x16 V = ld_nat(uvw, uv_tile(2, m, 1, 0), lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) vv[r] = __builtin_fmaf(V[r], V[r], vv[r]);
     }
@@ -1287,7 +1338,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     for (int r = 0; r < 16; ++r) gvn[r] = gv[r] / sqrtf(vv[r] + e2);
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      const f32x16 U = ld_tile(uvb + m * 2 * M2, 0, h), V = ld_tile(uvb + m * 2 * M2, M2, h);
+      const f32x16 U = ld_nat(uvw, uv_tile(2, m, 0, 0), lane), V = ld_nat(uvw, uv_tile(2, m, 1, 0), lane);
       f32x16 gU, gV;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1307,7 +1358,8 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
         GW[m][r] = GXH[m][0][r] * wv[r];
         dotp = __builtin_fmaf(GW[m][r], X[m][r], dotp);
       }
-    st_xm<5>(gwr + M0 + 3 * M1, h, GW, ok);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) st_nat(gww, x_tile(2, m, 0), lane, GW[m]);
   }
   // ---- EquivariantLayerNorm reverse of the update block's norm: g_x = r gw - coef xc - [0e] gmean + g_x_out
   const float coef = row_sum(dotp) * rr * rr * rr * (1.f / C);
@@ -1315,19 +1367,22 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   float* __restrict__ gxr = a.g_x + row * D;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const f32x16 gw = ld_tile(gwr, 32 * t, h), xv = ld_tile(xrow, 32 * t, h);
+    const f32x16 gw = ld_nat(gww, x_tile(0, 0, t), lane), xv = ld_tile(xrow, 32 * t, h);
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = (rr * gw[r] - coef * (xv[r] - mean0)) - gmean;
-    if (GX) o += ld_tile(gxo, 32 * t, h);
+    if (GX) o += ld_nat(gxow, x_tile(0, 0, t), lane);
     st_tile(gxr, 32 * t, h, o, ok);
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     f32x16 X[3], GW[3], R[3];
     ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
-    ld_xm<3>(gwr + M0 + 3 * 32 * t, h, GW);
-    if (GX) ld_xm<3>(gxo + M0 + 3 * 32 * t, h, R);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      GW[m] = ld_nat(gww, x_tile(1, m, t), lane);
+      if (GX) R[m] = ld_nat(gxow, x_tile(1, m, t), lane);
+    }
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -1337,8 +1392,11 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   {
     f32x16 X[5], GW[5], R[5];
     ld_xm<5>(xrow + M0 + 3 * M1, h, X);
-    ld_xm<5>(gwr + M0 + 3 * M1, h, GW);
-    if (GX) ld_xm<5>(gxo + M0 + 3 * M1, h, R);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      GW[m] = ld_nat(gww, x_tile(2, m, 0), lane);
+      if (GX) R[m] = ld_nat(gxow, x_tile(2, m, 0), lane);
+    }
 #pragma unroll
     for (int m = 0; m < 5; ++m)
 #pragma unroll
@@ -1356,6 +1414,9 @@ using namespace xeq;
 using namespace xeq::nb;
 
 extern "C" {
+
+/* rows of the kernels' internal tensors (uv, p, pre, a, ip, pre_next; gxo, gp, gv, gw): whole workgroups of 128 nodes */
+int64_t xeq_node_block_rows(int64_t n) { return (n + ROWS_WG - 1) / ROWS_WG * ROWS_WG; }
 
 int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]) { return dtype == XEQ_F32 && mul && shape_ok(node_dim, mul); }
 
@@ -1458,8 +1519,9 @@ int xeq_node_block_bwd(int64_t n, const float* g_h, const float* g_xhat_next, co
   const bool tail = g_h != nullptr, gx = tail || g_x_in != nullptr;
   XEQ_CHECK_ARG(g_s_in && uv_bt && a && ip && pre && s && x && stats && ln_w && eq_w && packed && gp && gv && gw && g_s && g_x,
                 "xeq_node_block_bwd: null buffer");
-  XEQ_CHECK_ARG(!tail || (g_xhat_next && g_x_in && s_out && x_out && stats_next && pre_next && ln_w_next && eq_w_next && gxo),
+  XEQ_CHECK_ARG(!tail || (g_xhat_next && g_x_in && s_out && x_out && stats_next && pre_next && ln_w_next && eq_w_next),
                 "xeq_node_block_bwd: null buffer (next block)");
+  XEQ_CHECK_ARG(!gx || gxo, "xeq_node_block_bwd: gxo scratch missing");
   BwdArgs b;
   b.n = n; b.g_h = g_h; b.g_xhat2 = g_xhat_next; b.g_s_in = g_s_in; b.g_x_in = g_x_in; b.s_out = s_out; b.x_out = x_out;
   b.stats2 = stats_next; b.pre2 = pre_next; b.lnw2 = ln_w_next; b.eqw2 = eq_w_next; b.uv = uv_bt; b.a = a; b.ip = ip; b.pre = pre;

@@ -610,18 +610,19 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         const NbPacks* pk = nb_packs(q, qn, !last_blk);
         auto fp = [](const Tensor& t) { return t.defined() ? (const float*)t.data_ptr() : nullptr; };
         auto fpm = [](Tensor& t) { return t.defined() ? (float*)t.data_ptr() : nullptr; };
-        u.uv = at::empty({2 * N * D}, fopt);
+        const int64_t NR = xeq_node_block_rows(N);   // internal tensors: whole workgroups, wave-native layout
+        u.uv = at::empty({2 * NR * D}, fopt);
         u.stats = at::empty({N, 4}, fopt);
-        u.pre = at::empty({N, F}, fopt);
-        u.a = at::empty({N, C + 2 * F}, fopt);
-        u.ip = at::empty({N, F}, fopt);
-        Tensor p_scr = at::empty({N, C}, fopt);
+        u.pre = at::empty({NR, F}, fopt);
+        u.a = at::empty({NR, C + 2 * F}, fopt);
+        u.ip = at::empty({NR, F}, fopt);
+        Tensor p_scr = at::empty({NR, C}, fopt);
         Tensor s_out = at::empty_like(s), x_out = last_blk ? Tensor() : at::empty_like(x);
         MsgSaved* mn = last_blk ? nullptr : &msv[b + 1];
         if (mn) {
           mn->stats = at::empty({N, 4}, fopt);
           mn->xhat = at::empty({N * D}, fopt);
-          mn->pre = at::empty({N, F}, fopt);
+          mn->pre = at::empty({NR, F}, fopt);
           mn->h = at::empty({N, H}, fopt);
         }
         XCALL(xeq_node_block_fwd(N, fp(s), fp(x), fp(q[19]), fp(q[20]), fp(q[21]), fp(q[22]), fp(pk->bias_uv), fp(q[16]), fp(q[18]),
@@ -719,8 +720,9 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         const MsgSaved* mn = last_blk ? nullptr : &msv[b + 1];
         auto fp = [](const Tensor& t) { return t.defined() ? (const float*)t.data_ptr() : nullptr; };
         Tensor ns = at::empty_like(u.s), nx = at::empty_like(u.x);
-        Tensor gxo = last_blk ? Tensor() : at::empty({N, D}, fopt);
-        Tensor gp = at::empty({N, C}, fopt), gv = at::empty({N, C}, fopt), gw = at::empty({N, D}, fopt);
+        const int64_t NR = xeq_node_block_rows(N);
+        Tensor gxo = last_blk ? Tensor() : at::empty({NR, D}, fopt);
+        Tensor gp = at::empty({NR, C}, fopt), gv = at::empty({NR, C}, fopt), gw = at::empty({NR, D}, fopt);
         if (!last_blk && !g_x.defined()) g_x = at::zeros({N, D}, fopt);
         XCALL(xeq_node_block_bwd(N, fp(pend_gh), fp(pend_gxhat), fp(g_s), fp(g_x), mn ? fp(mn->s) : nullptr, mn ? fp(mn->x) : nullptr,
                                  mn ? fp(mn->stats) : nullptr, mn ? fp(mn->pre) : nullptr, qn ? fp(qn[6]) : nullptr,

@@ -139,6 +139,7 @@ _PROTOS = {
     "xeq_mlp2_bwd": [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, c_int64, _P],
     "xeq_node_block_supported": [c_int, c_int, _I3],
     "xeq_node_block_fwd_tiles": [c_int],
+    "xeq_node_block_rows": [c_int64],
     "xeq_node_block_pack_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "xeq_node_block_fwd": [c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                            _P, _P, _P, _P, _P],
@@ -150,7 +151,7 @@ _PROTOS = {
 }
 # entry points that return a size, not a status
 _RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
-            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles"}
+            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None

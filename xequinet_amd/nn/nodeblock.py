@@ -104,13 +104,14 @@ def node_block_fwd(s: torch.Tensor, x: torch.Tensor, update, message=None, want_
     packed = packed_fwd(update, message)
     tail = message is not None
     assert want_x or not tail
+    rows = int(lib.load().xeq_node_block_rows(n))   # internal tensors: whole workgroups, wave-native layout (include/xeq.h)
     o = {
-        "p": torch.empty((n, C), **f32), "uv": torch.empty(2 * n * D, **f32), "stats": torch.empty((n, 4), **f32), "pre": torch.empty((n, F), **f32),
-        "a": torch.empty((n, C + 2 * F), **f32), "ip": torch.empty((n, F), **f32), "s_out": torch.empty((n, F), **f32),
-        "x_out": torch.empty((n, D), **f32) if want_x else None,
+        "p": torch.empty((rows, C), **f32), "uv": torch.empty(2 * rows * D, **f32), "stats": torch.empty((n, 4), **f32),
+        "pre": torch.empty((rows, F), **f32), "a": torch.empty((rows, C + 2 * F), **f32), "ip": torch.empty((rows, F), **f32),
+        "s_out": torch.empty((n, F), **f32), "x_out": torch.empty((n, D), **f32) if want_x else None,
     }
     if tail:
-        o.update(stats2=torch.empty((n, 4), **f32), xhat2=torch.empty(n * D, **f32), pre2=torch.empty((n, F), **f32),
+        o.update(stats2=torch.empty((n, 4), **f32), xhat2=torch.empty(n * D, **f32), pre2=torch.empty((rows, F), **f32),
                  h2=torch.empty((n, F + 2 * C), **f32))
     m = update.update_mlp
     nm = message
@@ -165,8 +166,9 @@ def node_block_bwd(saved: dict, s: torch.Tensor, x: torch.Tensor, update, messag
     assert tail == (g_h is not None)
     packed = packed_bwd(update, message, with_gx=g_x_in is not None)
     g_s, g_x = torch.empty((n, F), **f32), torch.empty((n, D), **f32)
-    gxo = torch.empty((n, D), **f32) if tail else None
-    gp, gv, gw = torch.empty((n, C), **f32), torch.empty((n, C), **f32), torch.empty((n, D), **f32)
+    rows = int(lib.load().xeq_node_block_rows(n))
+    gxo = torch.empty((rows, D), **f32) if (tail or g_x_in is not None) else None
+    gp, gv, gw = torch.empty((rows, C), **f32), torch.empty((rows, C), **f32), torch.empty((rows, D), **f32)
     cont = lambda t: None if t is None else t.contiguous()
     call("xeq_node_block_bwd", n, ptr(cont(g_h)), ptr(cont(g_xhat)), ptr(cont(g_s_in)), ptr(cont(g_x_in)), ptr(saved["s_out"] if tail else None),
          ptr(saved["x_out"] if tail else None), ptr(saved.get("stats2")), ptr(saved.get("pre2")),
@@ -174,3 +176,12 @@ def node_block_bwd(saved: dict, s: torch.Tensor, x: torch.Tensor, update, messag
          ptr(saved["ip"]), ptr(saved["pre"]), ptr(s), ptr(x), ptr(saved["stats"]), ptr(update.norm.weight), ptr(update.o3norm.affine_weight),
          float(update.invariant.eps), ptr(packed), ptr(gxo), ptr(gp), ptr(gv), ptr(gw), ptr(g_s), ptr(g_x), stream())
     return g_s, g_x
+
+
+def native_to_rows(buf: torch.Tensor, n: int, width: int) -> torch.Tensor:
+    """An internal tensor of the node-block kernels ([block of 32 nodes][tile][quad][lane][4], include/xeq.h) as plain rows [n, width]
+    in tile order (tests / debugging)."""
+    k = width // 32
+    wb = buf.numel() // (k * 1024)
+    t = buf.reshape(wb, k, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(wb * 32, width)
+    return t[:n]
