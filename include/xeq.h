@@ -605,6 +605,9 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
  * NULL: without the next block), out, stream); out holds xeq_node_block_fwd_tiles(with_tail) * 3072 bytes.
  * b_uv = [update_U.bias | update_V.bias] ([2 F]) or NULL; p_scratch: [n, C] floats (EquivariantDot(U, V), read back by dot_lin). */
 int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]);
+/* launch policy (host only): 1 when an evaluation of n nodes should take the fused launches (n >= XEQ_NODE_BLOCK_MIN_NODES, default
+ * 12 288; XEQ_NODE_BLOCK=0: never).  Below that the chain of small kernels is faster (a fused launch is one serial chain per wave). */
+int xeq_node_block_auto(int64_t n);
 int64_t xeq_node_block_rows(int64_t n);
 int64_t xeq_node_block_fwd_tiles(int with_tail);
 int xeq_node_block_pack_fwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,

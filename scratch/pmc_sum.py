@@ -5,7 +5,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "message" not in k and "probe" not in k and "mlp2" not in k:
+            if "message" not in k and "probe" not in k and "mlp2" not in k and "node_block" not in k:
                 continue
             k = k.split("<")[0].split("(")[0][-28:]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -21,3 +21,4 @@ for i, nm in enumerate(names):
     print(f"{nm:12s} median {np.median(d[:, :, i]):9.0f}  min {d[:, :, i].min():9.0f} max {d[:, :, i].max():9.0f}")
 t0 = st[:, :, 0].min()
 print("start spread", (st[:, :, 0].max() - t0), "end spread", st[:, :, 13].max() - t0, st[:, :, 13].min() - t0)
+print("per wave: cycles waiting for the fetched stage + its LDS write", np.median(st[:, :, 14]), " at the stage barrier", np.median(st[:, :, 15]), "of", np.median(st[:, :, 13] - st[:, :, 0]))

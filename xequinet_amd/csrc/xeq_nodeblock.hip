@@ -25,6 +25,8 @@
 // product with round-to-nearest splits, below one f32 rounding): 192 instead of 512 matrix-pipe cycles per 32 x 32 x 16 tile of the
 // exact-f32 MFMA.  A row's sums do not depend on the rows it shares a wave with, so sharded / chunked / padded batches agree bit for
 // bit as before.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "xeq_common.h"
@@ -114,6 +116,9 @@ struct WStream {
   uint4* ring;
   int t, n_tiles, lane, wave;
   uint4 pf[PF][3];
+#ifdef XEQ_NB_STAMPS
+  unsigned long long t_commit = 0, t_barrier = 0;   // cycles waiting for the fetched stage / at the stage barrier
+#endif
   Frag cur, nxt;   // fragments of tiles t and t + 1, read from LDS two calls ahead of their use (one wave per SIMD: nothing else hides the LDS latency)
   __device__ __forceinline__ void issue(int stage) {
 #pragma unroll
@@ -179,8 +184,19 @@ struct WStream {
 #endif
     if ((t & (STAGE_TILES - 1)) == 0) {
       const int j = t / STAGE_TILES;
+#ifdef XEQ_NB_STAMPS
+      unsigned long long b0_, b1_, b2_;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b0_)::"memory");
+      commit(j + 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b1_)::"memory");
+      NB_LDS_BARRIER();
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b2_)::"memory");
+      t_commit += b1_ - b0_;
+      t_barrier += b2_ - b1_;
+#else
       commit(j + 1);
       NB_LDS_BARRIER();
+#endif
 #if !(defined(XEQ_NB_EXP) && XEQ_NB_EXP == 3)   // experiment 3: no fetch
       issue(j + 2);
 #endif
@@ -236,6 +252,56 @@ __device__ __forceinline__ void out_pair(WStream& w, f32x16& a0, f32x16& a1, con
   }
 }
 
+// A set of operand fragments (up to 8 k-steps = 128 channels of this wave's 32 nodes) parked in a wave-private LDS area: the products
+// that sweep many output tiles over the same operand read it from there, step by step, instead of holding 96 registers -- the loops
+// over output tiles then stay rolled and small.  (LDS operations of one wave execute in order: no barrier between put and get.)
+constexpr int PARK_STEPS = 8, PARK_U4 = PARK_STEPS * TILE_U4;
+constexpr int LDS_BYTES = RING_BYTES + 4 * PARK_U4 * 16;
+struct Park {
+  uint4* fb;
+  __device__ __forceinline__ void put(int k, const Frag& f) const {
+    fb[(3 * k) * 64] = __builtin_bit_cast(uint4, f.hi);
+    fb[(3 * k + 1) * 64] = __builtin_bit_cast(uint4, f.mid);
+    fb[(3 * k + 2) * 64] = __builtin_bit_cast(uint4, f.lo);
+  }
+  __device__ __forceinline__ Frag get(int k) const {
+    Frag f;
+    f.hi = __builtin_bit_cast(bf16x8, fb[(3 * k) * 64]);
+    f.mid = __builtin_bit_cast(bf16x8, fb[(3 * k + 1) * 64]);
+    f.lo = __builtin_bit_cast(bf16x8, fb[(3 * k + 2) * 64]);
+    return f;
+  }
+  template <int T>   // both k-steps of 32-channel tile number T of the set
+  __device__ __forceinline__ void put_tile(const f32x16& v) const {
+    put(2 * T, split_k<0>(v));
+    put(2 * T + 1, split_k<1>(v));
+  }
+};
+// one output tile over NK parked k-steps; program order (k-step)
+template <int NK>
+__device__ __forceinline__ void out_tile_p(WStream& w, f32x16& acc, const Park& pk) {
+  Frag b = pk.get(0);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const Frag bn = pk.get(k + 1 < NK ? k + 1 : k);
+    mfma6(acc, w.next(), b);
+    b = bn;
+  }
+}
+// two output tiles over NK parked k-steps, products interleaved; program order (k-step, tile of the pair)
+template <int NK>
+__device__ __forceinline__ void out_pair_p(WStream& w, f32x16& a0, f32x16& a1, const Park& pk) {
+  Frag b = pk.get(0);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const Frag bn = pk.get(k + 1 < NK ? k + 1 : k);
+    const Frag w0 = w.next();
+    const Frag w1 = w.next();
+    mfma6x2(a0, a1, w0, w1, b);
+    b = bn;
+  }
+}
+
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -247,6 +313,10 @@ __device__ __forceinline__ f32x16 zero16() {
 // register 4 g + e <-> channel c0 + 8 g + 4 h + e
 __device__ __forceinline__ f32x16 ld_tile(const float* __restrict__ row, int c0, int h) {
   f32x16 t;
+#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 8 || XEQ_NB_EXP == 9)
+  for (int r = 0; r < 16; ++r) t[r] = 0.25f * (float)(c0 + r + h);
+  return t;
+#endif
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float4 v = *reinterpret_cast<const float4*>(row + c0 + 8 * g + 4 * h);
@@ -258,6 +328,9 @@ __device__ __forceinline__ f32x16 ld_tile(const float* __restrict__ row, int c0,
   return t;
 }
 __device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, const f32x16& t, bool ok) {
+#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 7 || XEQ_NB_EXP == 9)
+  if (t[0] != 12345.678f) return;
+#endif
   if (!ok) return;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -269,6 +342,10 @@ __device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, 
 __device__ __forceinline__ f32x16 ld_nat(const float* __restrict__ wb, int t, int lane) {
   const float4* p = reinterpret_cast<const float4*>(wb + t * 1024) + lane;
   f32x16 r;
+#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 8 || XEQ_NB_EXP == 9)
+  for (int q = 0; q < 16; ++q) r[q] = 0.25f * (float)(t + q + lane);
+  return r;
+#endif
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float4 v = p[64 * g];
@@ -280,6 +357,9 @@ __device__ __forceinline__ f32x16 ld_nat(const float* __restrict__ wb, int t, in
   return r;
 }
 __device__ __forceinline__ void st_nat(float* __restrict__ wb, int t, int lane, const f32x16& v) {
+#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 7 || XEQ_NB_EXP == 9)
+  if (v[0] != 12345.678f) return;
+#endif
   float4* p = reinterpret_cast<float4*>(wb + t * 1024) + lane;
 #pragma unroll
   for (int g = 0; g < 4; ++g) p[64 * g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
@@ -293,6 +373,11 @@ __device__ __forceinline__ constexpr int x_tile(int l, int m, int c) { return l 
 // of the row + DL * 32 * tile
 template <int DL>
 __device__ __forceinline__ void ld_xm(const float* __restrict__ blk, int h, f32x16 (&X)[DL]) {
+#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 8 || XEQ_NB_EXP == 9)
+  for (int m = 0; m < DL; ++m)
+    for (int r = 0; r < 16; ++r) X[m][r] = 0.125f * (float)(m + r + h);
+  return;
+#endif
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float* p = blk + DL * (8 * g + 4 * h);
@@ -313,6 +398,9 @@ __device__ __forceinline__ void ld_xm(const float* __restrict__ blk, int h, f32x
 }
 template <int DL>
 __device__ __forceinline__ void st_xm(float* __restrict__ blk, int h, const f32x16 (&X)[DL], bool ok) {
+#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 7 || XEQ_NB_EXP == 9)
+  if (X[0][0] != 12345.678f) return;
+#endif
   if (!ok) return;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -442,10 +530,10 @@ static void program_fwd(bool tail, std::vector<Seg>& p) {
   p.push_back({S_W3, 0, 4, 1, 10, 1, 1, 0});
   p.push_back({S_W4, 0, 7, 1, 0, 4, 1, 1});                        // a_vv tiles
   p.push_back({S_DOT, 0, 4, 1, 0, 7, 1, 0});                       // dot_lin over the seven p tiles
-  for (int c = 0; c < 4; ++c) p.push_back({S_W4, 7 + c, 2, 4, 0, 4, 1, 1});   // (a_sv, a_ss) of scalar tile c
+  for (int c = 0; c < 4; ++c) p.push_back({S_W4, 7 + c, 2, 4, 0, 4, 1, 0});   // (a_sv, a_ss) of scalar tile c, interleaved
   if (tail) {
     p.push_back({S_W1N, 0, 4, 1, 0, 4, 1, 0});
-    p.push_back({S_W2N, 0, HM / 32, 1, 0, 4, 1, 1});
+    for (int j = 0; j < HM / 64; ++j) p.push_back({S_W2N, 2 * j, 2, 1, 0, 4, 1, 0});   // scalar_mlp[2]: pairs of output tiles
   }
 }
 
@@ -545,6 +633,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   NB_STAMP(0);
   WStream w;
   w.init(a.wp, ring, a.n_tiles, lane, wave);
+  const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
   NB_STAMP(1);
   const float* __restrict__ srow = a.s + row * F;
   const float* __restrict__ xrow = a.x + row * D;
@@ -559,28 +648,28 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 
   f32x16 HID[4] = {zero16(), zero16(), zero16(), zero16()};   // update_mlp hidden pre-activation, accumulated chunk by chunk
   float mean, rstd, mean0, rr;
-  f32x16 X0[4];
-  {  // ---- LayerNorm(s) (nn.LayerNorm: biased variance, eps 1e-5) -> first K chunk of update_mlp[0]
-    f32x16 S[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) S[t] = ld_tile(srow, 32 * t, h);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) X0[t] = ld_tile(xrow, 32 * t, h);   // in flight under the products below
-    mean = row_sum((sum16(S[0]) + sum16(S[1])) + (sum16(S[2]) + sum16(S[3]))) * (1.f / F);
-    const float var = row_sum((sumsq16(S[0], mean) + sumsq16(S[1], mean)) + (sumsq16(S[2], mean) + sumsq16(S[3], mean))) * (1.f / F);
-    rstd = 1.f / sqrtf(var + 1e-5f);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x16 wv = ld_tile(a.lnw, 32 * t, h), bv = ld_tile(a.lnb, 32 * t, h);
-      f32x16 sh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sh[r] = (S[t][r] - mean) * rstd * wv[r] + bv[r];
-      accum_tile<4>(w, HID, sh);
-    }
-  }
-  NB_STAMP(2);
-  // ---- EquivariantLayerNorm statistics (nn/o3layer.py:145-171): 0e channels centred, one rms over all channels
   {
+    f32x16 X0[4];
+    {  // ---- LayerNorm(s) (nn.LayerNorm: biased variance, eps 1e-5) -> first K chunk of update_mlp[0]
+      f32x16 S[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) S[t] = ld_tile(srow, 32 * t, h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) X0[t] = ld_tile(xrow, 32 * t, h);   // in flight under the products below
+      mean = row_sum((sum16(S[0]) + sum16(S[1])) + (sum16(S[2]) + sum16(S[3]))) * (1.f / F);
+      const float var = row_sum((sumsq16(S[0], mean) + sumsq16(S[1], mean)) + (sumsq16(S[2], mean) + sumsq16(S[3], mean))) * (1.f / F);
+      rstd = 1.f / sqrtf(var + 1e-5f);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x16 wv = ld_tile(a.lnw, 32 * t, h), bv = ld_tile(a.lnb, 32 * t, h);
+        f32x16 sh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sh[r] = (S[t][r] - mean) * rstd * wv[r] + bv[r];
+        accum_tile<4>(w, HID, sh);
+      }
+    }
+    NB_STAMP(2);
+    // ---- EquivariantLayerNorm statistics (nn/o3layer.py:145-171): 0e channels centred, one rms over all channels
     mean0 = row_sum((sum16(X0[0]) + sum16(X0[1])) + (sum16(X0[2]) + sum16(X0[3]))) * (1.f / M0);
     float q = (sumsq16(X0[0], mean0) + sumsq16(X0[1], mean0)) + (sumsq16(X0[2], mean0) + sumsq16(X0[3], mean0));
     {
@@ -594,45 +683,39 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     }
     rr = 1.f / sqrtf(row_sum(q) * (1.f / C) + 1e-5f);
     if (ok && h == 0) *reinterpret_cast<float4*>(a.stats + 4 * row) = make_float4(mean, rstd, mean0, rr);
-  }
-  NB_STAMP(3);
-  {  // ---- l = 0: U, V (o3.Linear with bias), v = |V|, p = U V per channel tile
-    Frag fx[8];
+    NB_STAMP(3);
+    // ---- l = 0: normalised features -> parked fragments
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const f32x16 wv = ld_tile(a.eqw, 32 * t, h), bv = ld_tile(a.eqb, 32 * t, h);
       f32x16 xh;
 #pragma unroll
       for (int r = 0; r < 16; ++r) xh[r] = (X0[t][r] - mean0) * rr * wv[r] + bv[r];
-      fx[2 * t] = split_k<0>(xh);
-      fx[2 * t + 1] = split_k<1>(xh);
+      pk.put(2 * t, split_k<0>(xh));
+      pk.put(2 * t + 1, split_k<1>(xh));
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      f32x16 bu = zero16(), bv = zero16();
-      if (a.b_uv) {
-        bu = ld_tile(a.b_uv, 32 * c, h);
-        bv = ld_tile(a.b_uv + F, 32 * c, h);
-      }
-      f32x16 U = zero16(), V = zero16();
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        mfma6(U, w.next(), fx[k]);
-        mfma6(V, w.next(), fx[k]);
-      }
-      U += bu;
-      V += bv;
-      st_nat(uvw, uv_tile(0, 0, 0, c), lane, U);
-      st_nat(uvw, uv_tile(0, 0, 1, c), lane, V);
-      f32x16 v, p;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        v[r] = sqrtf(__builtin_fmaf(V[r], V[r], e2)) - e1;
-        p[r] = U[r] * V[r];
-      }
-      st_nat(pw, c, lane, p);
-      accum_tile<4>(w, HID, v);
+  }
+  // ---- l = 0: U, V (o3.Linear with bias), v = |V|, p = U V per channel tile
+  for (int c = 0; c < 4; ++c) {
+    f32x16 bu = zero16(), bv = zero16();
+    if (a.b_uv) {
+      bu = ld_tile(a.b_uv, 32 * c, h);
+      bv = ld_tile(a.b_uv + F, 32 * c, h);
     }
+    f32x16 U = zero16(), V = zero16();
+    out_pair_p<8>(w, U, V, pk);
+    U += bu;
+    V += bv;
+    st_nat(uvw, uv_tile(0, 0, 0, c), lane, U);
+    st_nat(uvw, uv_tile(0, 0, 1, c), lane, V);
+    f32x16 v, p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      v[r] = sqrtf(__builtin_fmaf(V[r], V[r], e2)) - e1;
+      p[r] = U[r] * V[r];
+    }
+    st_nat(pw, c, lane, p);
+    accum_tile<4>(w, HID, v);
   }
   NB_STAMP(4);
   {  // ---- l = 1
@@ -649,15 +732,14 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     f32x16 VSQ[2] = {zero16(), zero16()}, PP[2] = {zero16(), zero16()};
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      Frag fx[4] = {split_k<0>(X1[0][m]), split_k<1>(X1[0][m]), split_k<0>(X1[1][m]), split_k<1>(X1[1][m])};
+      pk.put(0, split_k<0>(X1[0][m]));
+      pk.put(1, split_k<1>(X1[0][m]));
+      pk.put(2, split_k<0>(X1[1][m]));
+      pk.put(3, split_k<1>(X1[1][m]));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         f32x16 U = zero16(), V = zero16();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          mfma6(U, w.next(), fx[k]);
-          mfma6(V, w.next(), fx[k]);
-        }
+        out_pair_p<4>(w, U, V, pk);
         st_nat(uvw, uv_tile(1, m, 0, c), lane, U);
         st_nat(uvw, uv_tile(1, m, 1, c), lane, V);
 #pragma unroll
@@ -688,13 +770,10 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     f32x16 VSQ = zero16(), PP = zero16();
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      Frag fx[2] = {split_k<0>(X2[m]), split_k<1>(X2[m])};
+      pk.put(0, split_k<0>(X2[m]));
+      pk.put(1, split_k<1>(X2[m]));
       f32x16 U = zero16(), V = zero16();
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        mfma6(U, w.next(), fx[k]);
-        mfma6(V, w.next(), fx[k]);
-      }
+      out_pair_p<2>(w, U, V, pk);
       st_nat(uvw, uv_tile(2, m, 0, 0), lane, U);
       st_nat(uvw, uv_tile(2, m, 1, 0), lane, V);
 #pragma unroll
@@ -710,8 +789,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     accum_tile<4>(w, HID, v);
   }
   NB_STAMP(6);
-  // ---- hidden layer of update_mlp: bias, SiLU
-  Frag fh[8];
+  // ---- hidden layer of update_mlp: bias, SiLU -> parked fragments
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     HID[t] += ld_tile(a.b3, 32 * t, h);
@@ -719,16 +797,14 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     f32x16 hv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hv[r] = silu_f(HID[t][r]);
-    fh[2 * t] = split_k<0>(hv);
-    fh[2 * t + 1] = split_k<1>(hv);
+    pk.put(2 * t, split_k<0>(hv));
+    pk.put(2 * t + 1, split_k<1>(hv));
   }
   NB_STAMP(7);
   float* __restrict__ xor_ = wx ? a.x_out + row * D : nullptr;
-  float q2 = 0.f;      // TAIL: sum of squares of the new l > 0 features
-  f32x16 XN0[4];       // TAIL: new 0e features (two-pass statistics)
+  float q2 = 0.f, s0 = 0.f;   // TAIL: sum of squares of the new l > 0 features, sum of the new 0e features
   // ---- a_vv tiles and the equivariant residual update x_out = x + U a_vv (nn/xpainn.py:218-219, 229); the epilogue's operands
   // (U of this lane's own stores, x, the bias) are requested in front of the tile's products
-#pragma unroll
   for (int c = 0; c < 4; ++c) {
     const f32x16 b4v = ld_tile(a.b4, 32 * c, h);
     f32x16 U = zero16(), X0c = zero16();
@@ -737,7 +813,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
       X0c = ld_tile(xrow, 32 * c, h);
     }
     f32x16 av = zero16();
-    out_tile<8>(w, av, fh);
+    out_tile_p<8>(w, av, pk);
     av += b4v;
     st_nat(aw, c, lane, av);
     if (wx) {
@@ -745,10 +821,9 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) xn[r] = __builtin_fmaf(U[r], av[r], X0c[r]);
       st_tile(xor_, 32 * c, h, xn, ok);
-      if (TAIL) XN0[c] = xn;
+      if (TAIL) s0 += sum16(xn);
     }
   }
-#pragma unroll
   for (int c = 0; c < 2; ++c) {
     const f32x16 b4v = ld_tile(a.b4, M0 + 32 * c, h);
     f32x16 X[3], U[3];
@@ -758,7 +833,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
       for (int m = 0; m < 3; ++m) U[m] = ld_nat(uvw, uv_tile(1, m, 0, c), lane);
     }
     f32x16 av = zero16();
-    out_tile<8>(w, av, fh);
+    out_tile_p<8>(w, av, pk);
     av += b4v;
     st_nat(aw, 4 + c, lane, av);
     if (wx) {
@@ -780,7 +855,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
       for (int m = 0; m < 5; ++m) U[m] = ld_nat(uvw, uv_tile(2, m, 0, 0), lane);
     }
     f32x16 av = zero16();
-    out_tile<8>(w, av, fh);
+    out_tile_p<8>(w, av, pk);
     av += b4v;
     st_nat(aw, 6, lane, av);
     if (wx) {
@@ -797,11 +872,12 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   // ---- dot_lin over the p tiles this lane stored (nn/xpainn.py:222-223)
   f32x16 IP[4] = {zero16(), zero16(), zero16(), zero16()};
   {
-    f32x16 P[7];
-#pragma unroll
-    for (int t = 0; t < 7; ++t) P[t] = ld_nat(pw, t, lane);
-#pragma unroll
-    for (int t = 0; t < 7; ++t) accum_tile<4>(w, IP, P[t]);
+    f32x16 pt = ld_nat(pw, 0, lane);
+    for (int t = 0; t < 7; ++t) {
+      const f32x16 cur = pt;
+      if (t + 1 < 7) pt = ld_nat(pw, t + 1, lane);
+      accum_tile<4>(w, IP, cur);
+    }
   }
   // ---- (a_sv, a_ss) per scalar tile and the scalar residual update s_out = s + a_sv dot_lin(p) + a_ss (nn/xpainn.py:221-228)
   f32x16 SN[4];
@@ -811,8 +887,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     const f32x16 bsv = ld_tile(a.b4, C + 32 * c, h), bss = ld_tile(a.b4, C + F + 32 * c, h), S = ld_tile(srow, 32 * c, h);
     st_nat(ipw, c, lane, IP[c]);
     f32x16 asv = zero16(), ass = zero16();
-    out_tile<8>(w, asv, fh);
-    out_tile<8>(w, ass, fh);
+    out_pair_p<8>(w, asv, ass, pk);
     asv += bsv;
     ass += bss;
     st_nat(aw, 7 + c, lane, asv);
@@ -828,23 +903,11 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   const float mean_n = row_sum((sum16(SN[0]) + sum16(SN[1])) + (sum16(SN[2]) + sum16(SN[3]))) * (1.f / F);
   const float var_n = row_sum((sumsq16(SN[0], mean_n) + sumsq16(SN[1], mean_n)) + (sumsq16(SN[2], mean_n) + sumsq16(SN[3], mean_n))) * (1.f / F);
   const float rstd_n = 1.f / sqrtf(var_n + 1e-5f);
-  const float mean0_n = row_sum((sum16(XN0[0]) + sum16(XN0[1])) + (sum16(XN0[2]) + sum16(XN0[3]))) * (1.f / M0);
-  const float qn = q2 + ((sumsq16(XN0[0], mean0_n) + sumsq16(XN0[1], mean0_n)) + (sumsq16(XN0[2], mean0_n) + sumsq16(XN0[3], mean0_n)));
-  const float rr_n = 1.f / sqrtf(row_sum(qn) * (1.f / C) + 1e-5f);
-  if (ok && h == 0) *reinterpret_cast<float4*>(a.stats2 + 4 * row) = make_float4(mean_n, rstd_n, mean0_n, rr_n);
-  // xhat of the next block, BT layout (block l at N base_l, row (node, m), channels contiguous): the 0e block from registers now,
-  // the l > 0 blocks from this lane's own x_out stores, requested here and finished under the products of scalar_mlp
+  const float mean0_n = row_sum(s0) * (1.f / M0);
+  // the new 0e features (this lane's own stores) once more for the centred second moment, the l > 0 blocks for xhat
+  f32x16 XN0[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const f32x16 wv = ld_tile(a.eqw2, 32 * t, h), bv = ld_tile(a.eqb2, 32 * t, h);
-    f32x16 xh;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xh[r] = (XN0[t][r] - mean0_n) * rr_n * wv[r] + bv[r];
-    st_tile(a.xhat2 + row * M0, 32 * t, h, xh, ok);
-  }
-  f32x16 XA[3], XB[3];
-  ld_xm<3>(xor_ + M0, h, XA);
-  ld_xm<3>(xor_ + M0 + 3 * 32, h, XB);
+  for (int t = 0; t < 4; ++t) XN0[t] = ld_tile(xor_, 32 * t, h);
   f32x16 HN[4] = {zero16(), zero16(), zero16(), zero16()};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -855,23 +918,20 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     accum_tile<4>(w, HN, sh);
   }
   NB_STAMP(10);
-  {
-    const f32x16 wa = ld_tile(a.eqw2, M0, h), wb = ld_tile(a.eqw2, M0 + 32, h);
+  const float qn = q2 + ((sumsq16(XN0[0], mean0_n) + sumsq16(XN0[1], mean0_n)) + (sumsq16(XN0[2], mean0_n) + sumsq16(XN0[3], mean0_n)));
+  const float rr_n = 1.f / sqrtf(row_sum(qn) * (1.f / C) + 1e-5f);
+  if (ok && h == 0) *reinterpret_cast<float4*>(a.stats2 + 4 * row) = make_float4(mean_n, rstd_n, mean0_n, rr_n);
+  // xhat of the next block, BT layout (block l at N base_l, row (node, m), channels contiguous)
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 wv = ld_tile(a.eqw2, 32 * t, h), bv = ld_tile(a.eqb2, 32 * t, h);
+    f32x16 xh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        XA[m][r] = XA[m][r] * rr_n * wa[r];
-        XB[m][r] = XB[m][r] * rr_n * wb[r];
-      }
-      st_tile(a.xhat2 + N * M0 + (row * 3 + m) * M1, 0, h, XA[m], ok);
-      st_tile(a.xhat2 + N * M0 + (row * 3 + m) * M1, 32, h, XB[m], ok);
-    }
+    for (int r = 0; r < 16; ++r) xh[r] = (XN0[t][r] - mean0_n) * rr_n * wv[r] + bv[r];
+    st_tile(a.xhat2 + row * M0, 32 * t, h, xh, ok);
   }
-  f32x16 XC[5];
-  ld_xm<5>(xor_ + M0 + 3 * M1, h, XC);
   NB_STAMP(11);
-  Frag fn[8];
+  // hidden layer of scalar_mlp -> parked fragments
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     HN[t] += ld_tile(a.b1n, 32 * t, h);
@@ -879,17 +939,15 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     f32x16 hv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hv[r] = silu_f(HN[t][r]);
-    fn[2 * t] = split_k<0>(hv);
-    fn[2 * t + 1] = split_k<1>(hv);
+    pk.put(2 * t, split_k<0>(hv));
+    pk.put(2 * t + 1, split_k<1>(hv));
   }
   NB_STAMP(12);
+  // scalar_mlp[2], two output tiles at a time; the l > 0 blocks of xhat (from this lane's own x_out stores) ride along
   float* __restrict__ hrow = a.h2 + row * HM;
   {
-    f32x16 acc = zero16();
-    const f32x16 b2v = ld_tile(a.b2n, 0, h);
-    out_tile<8>(w, acc, fn);
-    acc += b2v;
-    st_tile(hrow, 0, h, acc, ok);
+    f32x16 XC[5];
+    ld_xm<5>(xor_ + M0 + 3 * M1, h, XC);
     const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
@@ -898,23 +956,36 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
       st_tile(a.xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h, XC[m], ok);
     }
   }
-  f32x16 b2v = ld_tile(a.b2n, 32, h);
-  for (int ot = 1; ot < HM / 32; ++ot) {
-    f32x16 acc = zero16();
-#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 5
-    out_tile<8>(w, acc, fn);
-#else
-    const f32x16 bcur = b2v;
-    if (ot + 1 < HM / 32) b2v = ld_tile(a.b2n, 32 * (ot + 1), h);
-    out_tile<8>(w, acc, fn);
-    acc += bcur;
-#endif
-#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 6
-    if (acc[0] == 12345.678f)
-#endif
-    st_tile(hrow, 32 * ot, h, acc, ok);
+  for (int j = 0; j < HM / 64; ++j) {
+    const f32x16 b0 = ld_tile(a.b2n, 64 * j, h), b1 = ld_tile(a.b2n, 64 * j + 32, h);
+    f32x16 XA[3];
+    f32x16 wa = zero16();
+    if (j < 2) {
+      ld_xm<3>(xor_ + M0 + 3 * 32 * j, h, XA);
+      wa = ld_tile(a.eqw2, M0 + 32 * j, h);
+    }
+    f32x16 a0 = zero16(), a1 = zero16();
+    out_pair_p<8>(w, a0, a1, pk);
+    a0 += b0;
+    a1 += b1;
+    st_tile(hrow, 64 * j, h, a0, ok);
+    st_tile(hrow, 64 * j + 32, h, a1, ok);
+    if (j < 2) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) XA[m][r] = XA[m][r] * rr_n * wa[r];
+        st_tile(a.xhat2 + N * M0 + (row * 3 + m) * M1, 32 * j, h, XA[m], ok);
+      }
+    }
   }
   NB_STAMP(13);
+#ifdef XEQ_NB_STAMPS
+  if (lane == 0 && blockIdx.x < 1024) {
+    g_nb_stamps[((int)blockIdx.x * 4 + wave) * NB_STAMPS + 14] = w.t_commit;
+    g_nb_stamps[((int)blockIdx.x * 4 + wave) * NB_STAMPS + 15] = w.t_barrier;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ reverse
@@ -990,6 +1061,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   const int64_t N = a.n;
   WStream w;
   w.init(a.wp, ring, a.n_tiles, lane, wave);
+  const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
   const float e2 = a.eps * a.eps;
   const int64_t wblk = (int64_t)blockIdx.x * 4 + wave;   // this wave's block of 32 nodes in the internal layout
   float* __restrict__ gxow = a.gxo + wblk * (X_TILES * 1024);   // total dL/dx_out (GX)
@@ -1012,21 +1084,20 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
       if (kt + 1 < HM / 32) gt = ld_tile(ghr, 32 * (kt + 1), h);
       accum_tile<4>(w, GH, cur);
     }
-    Frag fg[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const f32x16 pv = ld_nat(a.pre2 + wblk * (S_TILES * 1024), t, lane);
       f32x16 gv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gv[r] = GH[t][r] * silu_grad_f(pv[r]);
-      fg[2 * t] = split_k<0>(gv);
-      fg[2 * t + 1] = split_k<1>(gv);
+      pk.put(2 * t, split_k<0>(gv));
+      pk.put(2 * t + 1, split_k<1>(gv));
     }
     f32x16 gsh[4] = {zero16(), zero16(), zero16(), zero16()}, res[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       res[t] = ld_tile(a.g_s_in + row * F, 32 * t, h);
-      out_tile<8>(w, gsh[t], fg);
+      out_tile_p<8>(w, gsh[t], pk);
     }
     const float4 st2 = *reinterpret_cast<const float4*>(a.stats2 + 4 * row);
     ln_bwd(gsh, a.s_out + row * F, a.lnw2, st2.x, st2.y, res, h);
@@ -1177,44 +1248,42 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   for (int c = 0; c < 4; ++c) accum_tile<4>(w, GHID, GS[c]);   // g_a_ss = g_s_out
   const float4 st = *reinterpret_cast<const float4*>(a.stats + 4 * row);
   {  // ---- g_hidden silu'(pre) -> fragments; g_shat = W3^T[:F] g_hidden -> LayerNorm reverse -> g_s; g_v = W3^T[F:] g_hidden
-    Frag fgh[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const f32x16 pv = ld_nat(prew, t, lane);
       f32x16 gv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gv[r] = GHID[t][r] * silu_grad_f(pv[r]);
-      fgh[2 * t] = split_k<0>(gv);
-      fgh[2 * t + 1] = split_k<1>(gv);
+      pk.put(2 * t, split_k<0>(gv));
+      pk.put(2 * t + 1, split_k<1>(gv));
     }
     {
       f32x16 gsh[4] = {zero16(), zero16(), zero16(), zero16()};
 #pragma unroll
-      for (int t = 0; t < 4; ++t) out_tile<8>(w, gsh[t], fgh);
+      for (int t = 0; t < 4; ++t) out_tile_p<8>(w, gsh[t], pk);
       ln_bwd(gsh, a.s + row * F, a.lnw, st.x, st.y, GS, h);
 #pragma unroll
       for (int t = 0; t < 4; ++t) st_tile(a.g_s + row * F, 32 * t, h, gsh[t], ok);
     }
     for (int t = 0; t < 7; ++t) {   // parked in scratch for the per-block sweeps
       f32x16 acc = zero16();
-      out_tile<8>(w, acc, fgh);
+      out_tile_p<8>(w, acc, pk);
       st_nat(gvw, t, lane, acc);
     }
   }
   {  // ---- g_ip = g_s_out a_sv -> fragments; g_p = dot_lin^T g_ip, seven channel tiles
-    Frag fgi[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const f32x16 asv = ld_nat(aw, 7 + t, lane);
       f32x16 gi;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gi[r] = GS[t][r] * asv[r];
-      fgi[2 * t] = split_k<0>(gi);
-      fgi[2 * t + 1] = split_k<1>(gi);
+      pk.put(2 * t, split_k<0>(gi));
+      pk.put(2 * t + 1, split_k<1>(gi));
     }
     for (int t = 0; t < 7; ++t) {
       f32x16 acc = zero16();
-      out_tile<8>(w, acc, fgi);
+      out_tile_p<8>(w, acc, pk);
       st_nat(gpw, t, lane, acc);
     }
   }
@@ -1405,6 +1474,22 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   }
 }
 
+// more than 64 KB of dynamic LDS (weight ring + the waves' fragment areas): opt in once per process
+static hipError_t raise_lds() {
+  static hipError_t err = [] {
+    const void* fns[] = {reinterpret_cast<const void*>(&k_node_block_fwd<true>), reinterpret_cast<const void*>(&k_node_block_fwd<false>),
+                         reinterpret_cast<const void*>(&k_node_block_bwd<true, true>), reinterpret_cast<const void*>(&k_node_block_bwd<false, true>),
+                         reinterpret_cast<const void*>(&k_node_block_bwd<false, false>)};
+    hipError_t e = hipSuccess;
+    for (const void* f : fns) {
+      const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (r != hipSuccess) e = r;
+    }
+    return e;
+  }();
+  return err;
+}
+
 static bool shape_ok(int node_dim, const int32_t mul[3]) { return node_dim == F && mul[0] == M0 && mul[1] == M1 && mul[2] == M2; }
 
 }  // namespace nb
@@ -1414,6 +1499,19 @@ using namespace xeq;
 using namespace xeq::nb;
 
 extern "C" {
+
+/* Launch policy, stated once for both fronts (nn/xpainn.py, csrc/xeq_torch.cpp): whether a force evaluation of n nodes takes the fused
+ * node-block launches.  One wave owns 32 nodes and walks the whole chain alone on its SIMD (512 registers: nothing shares the SIMD to
+ * hide its stalls), so a launch takes about as long for 1 500 nodes as for 18 000 (~0.2 ms): below XEQ_NODE_BLOCK_MIN_NODES (default
+ * 12 288) the chain of small kernels, which spreads a few tiles over many workgroups, is the faster path (profiles/r04_nodeblock.txt).
+ * XEQ_NODE_BLOCK=0 switches the fused launches off. */
+int xeq_node_block_auto(int64_t n) {
+  const char* off = getenv("XEQ_NODE_BLOCK");
+  if (off && off[0] == '0') return 0;
+  int64_t min_nodes = 12288;
+  if (const char* v = getenv("XEQ_NODE_BLOCK_MIN_NODES")) min_nodes = atoll(v);
+  return n >= min_nodes;
+}
 
 /* rows of the kernels' internal tensors (uv, p, pre, a, ip, pre_next; gxo, gp, gv, gw): whole workgroups of 128 nodes */
 int64_t xeq_node_block_rows(int64_t n) { return (n + ROWS_WG - 1) / ROWS_WG * ROWS_WG; }
@@ -1478,8 +1576,9 @@ int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* l
   fa.lnw2 = ln_w_next; fa.lnb2 = ln_b_next; fa.eqw2 = eq_w_next; fa.eqb2 = eq_b_next; fa.b1n = b1_next; fa.b2n = b2_next;
   fa.stats2 = stats_next; fa.xhat2 = xhat_next; fa.pre2 = pre_next; fa.h2 = h_next;
   const dim3 grid((unsigned)((n + ROWS_WG - 1) / ROWS_WG));
-  if (tail) hipLaunchKernelGGL(k_node_block_fwd<true>, grid, dim3(256), RING_BYTES, (hipStream_t)stream, fa);
-  else hipLaunchKernelGGL(k_node_block_fwd<false>, grid, dim3(256), RING_BYTES, (hipStream_t)stream, fa);
+  XEQ_CHECK_ARG(raise_lds() == hipSuccess, "xeq_node_block_fwd: cannot raise the dynamic LDS limit");
+  if (tail) hipLaunchKernelGGL(k_node_block_fwd<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, fa);
+  else hipLaunchKernelGGL(k_node_block_fwd<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, fa);
   XEQ_CHECK_LAUNCH("xeq_node_block_fwd");
   return XEQ_OK;
 }
@@ -1528,9 +1627,10 @@ int xeq_node_block_bwd(int64_t n, const float* g_h, const float* g_xhat_next, co
   b.s = s; b.x = x; b.stats = stats; b.lnw = ln_w; b.eqw = eq_w; b.eps = (float)eps; b.wp = (const uint4*)packed;
   b.n_tiles = (int)xeq_node_block_bwd_tiles(tail, gx); b.gxo = gxo; b.gp = gp; b.gv = gv; b.gw = gw; b.g_s = g_s; b.g_x = g_x;
   const dim3 grid((unsigned)((n + ROWS_WG - 1) / ROWS_WG));
-  if (tail) hipLaunchKernelGGL((k_node_block_bwd<true, true>), grid, dim3(256), RING_BYTES, (hipStream_t)stream, b);
-  else if (gx) hipLaunchKernelGGL((k_node_block_bwd<false, true>), grid, dim3(256), RING_BYTES, (hipStream_t)stream, b);
-  else hipLaunchKernelGGL((k_node_block_bwd<false, false>), grid, dim3(256), RING_BYTES, (hipStream_t)stream, b);
+  XEQ_CHECK_ARG(raise_lds() == hipSuccess, "xeq_node_block_bwd: cannot raise the dynamic LDS limit");
+  if (tail) hipLaunchKernelGGL((k_node_block_bwd<true, true>), grid, dim3(256), LDS_BYTES, (hipStream_t)stream, b);
+  else if (gx) hipLaunchKernelGGL((k_node_block_bwd<false, true>), grid, dim3(256), LDS_BYTES, (hipStream_t)stream, b);
+  else hipLaunchKernelGGL((k_node_block_bwd<false, false>), grid, dim3(256), LDS_BYTES, (hipStream_t)stream, b);
   XEQ_CHECK_LAUNCH("xeq_node_block_bwd");
   return XEQ_OK;
 }

@@ -300,10 +300,6 @@ const NbPacks* nb_packs(const Tensor* q, const Tensor* qn, bool gx) {
   }
   return &e;
 }
-bool nb_enabled() {
-  const char* v = getenv("XEQ_NODE_BLOCK");
-  return !(v && v[0] == '0');
-}
 
 // ---------------------------------------------------------------------------------------------- graph plumbing
 struct WqPlan {
@@ -569,7 +565,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   }
 
   // fused node blocks: f32, the default layout, layer norms on (nn/nodeblock.py::supported)
-  const bool nb_ok = dt == XEQ_F32 && hy.layer_norm && nb_enabled() && xeq_node_block_supported(XEQ_F32, F, mul);
+  const bool nb_ok = dt == XEQ_F32 && hy.layer_norm && xeq_node_block_supported(XEQ_F32, F, mul) && xeq_node_block_auto(N);
   for (int b = 0; b < hy.blocks; ++b) {
     const Tensor* q = &prm[P_BLOCK0 + P_PER_BLOCK * b];
     {  // ---- XPainnMessage.forward (nn/xpainn.py:128-161; nn/fused.py::MessageBlock)

@@ -225,11 +225,9 @@ class XPainnUpdate(nn.Module):
     def _node_block_ok(self, data) -> bool:
         """One fused launch per direction for the whole block (nn/fused.py::NodeBlock): f32 on the GPU, the default layout, no
         parameter gradients wanted (the native training pass keeps the kernels that save what the weight gradients read)."""
-        import os
-
         s = data[keys.NODE_INVARIANT]
-        return (os.environ.get("XEQ_NODE_BLOCK", "1") != "0" and s.is_cuda and s.dtype == torch.float32
-                and not data.get(training.PARAM_GRADS, False) and nodeblock.supported(self))
+        return (s.is_cuda and s.dtype == torch.float32 and not data.get(training.PARAM_GRADS, False) and nodeblock.supported(self)
+                and bool(ops.lib.load().xeq_node_block_auto(s.shape[0])))   # the size rule is the C ABI's (both fronts ask it)
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if training.active(self, data):
