@@ -586,6 +586,16 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
                       const float* wt_packed0, const float* wt_packed1, const float* wt_packed2, double eps, float* g_s, float* g_x,
                       float* g_xhat_bt, void* stream);
 
+/* Epoch of the packed weight copies: every pack cache (nn/fused.py, nn/nodeblock.py, csrc/xeq_torch.cpp) keys on it next to the version
+ * counters of the tensors it packed; what changes parameters without bumping those counters (a replayed captured optimizer step,
+ * train.GraphedTrainStep) calls xeq_pack_epoch_bump and the next evaluation repacks.  Host only. */
+long long xeq_pack_epoch(void);
+void xeq_pack_epoch_bump(void);
+/* Capacity form of the open-boundary list: count[0] = raw[n_nodes] (the true edge count); rowptr = raw when the list fits `capacity`,
+ * all zeros (an EMPTY list) when it does not -- a cut list would not be symmetric and the symmetric shortcuts downstream index by the
+ * reverse edge (replaces the unguarded row pointer of round 3: a list that outgrew its arrays now leads no kernel past a buffer). */
+int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream);
+
 /* ---- the per-node chain between two message aggregations as ONE launch per direction (round 4; csrc/xeq_nodeblock.hip) -------------
  * f32, the default layout (node_dim 128, 128x0e + 64x1o + 32x2e: xeq_node_block_supported).  A wave owns 32 nodes and keeps their
  * activations in the matrix cores' accumulator layout; every contraction runs on bf16 MFMAs over three-way split operands

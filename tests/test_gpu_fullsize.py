@@ -194,7 +194,7 @@ def test_whole_step_graph_replays_batches_of_changing_sizes():
         assert torch.equal(step.edge_index[:, :ne], b.edge_index)
         seen.add((n, ne))
         # eager evaluation of the padded batch (the step's own static buffers): bit for bit
-        rowptr = ops.radius_graph_capacity(step.pos, step.ptr, 5.0, step.edge_index)
+        rowptr, _ = ops.radius_graph_capacity(step.pos, step.ptr, 5.0, step.edge_index)
         eg = ops.EdgeGraph(step.edge_index, step.n_atoms, center_sorted=True, ptr=step.ptr, c_rowptr=rowptr, symmetric=True)
         with torch.enable_grad():
             want = model({keys.POSITIONS: step.pos.detach().clone(), keys.ATOMIC_NUMBERS: step.z, keys.EDGE_INDEX: step.edge_index,
@@ -208,3 +208,59 @@ def test_whole_step_graph_replays_batches_of_changing_sizes():
     with pytest.raises(ValueError):
         pos, z, ptr = syn.synth_qm9_batch(g_cap + 1, seed=9)
         step(_t(pos, torch.float32), _t(z), _t(ptr))
+
+
+def test_capacity_list_that_outgrows_its_arrays_becomes_empty_and_reports_the_true_count():
+    """The open-boundary list in its capacity form (ops.radius_graph_capacity, runtime.GraphedStep): a list that outgrows the edge
+    arrays is replaced by an EMPTY list -- the row pointer never points behind the buffers and no symmetric shortcut sees a cut list,
+    so no downstream kernel walks out of bounds -- and the true count comes back next to it (advisor, round 3: the row pointer used
+    to be left unguarded)."""
+    from xequinet_amd import ops
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.nn import resolve_model
+    from xequinet_amd.runtime import GraphedStep, pair_capacity
+
+    pos, z, ptr = syn.synth_qm9_batch(24, seed=3)
+    full = pair_capacity(ptr)
+    b = NeighborTransform(5.0)(XequiBatch(_t(pos, torch.float32), _t(z), _t(ptr)))
+    true_edges = b.edge_index.shape[1]
+    cap = true_edges // 2
+    edge_index = torch.zeros((2, cap), dtype=torch.int64, device=DEV)
+    rowptr, count = ops.radius_graph_capacity(_t(pos, torch.float32), _t(ptr), 5.0, edge_index)
+    assert int(count.item()) == true_edges and int(rowptr.abs().max().item()) == 0
+    big = torch.zeros((2, true_edges + 7), dtype=torch.int64, device=DEV)
+    rowptr2, count2 = ops.radius_graph_capacity(_t(pos, torch.float32), _t(ptr), 5.0, big)
+    assert int(count2.item()) == true_edges == int(rowptr2[-1].item()) and torch.equal(big[:, :true_edges], b.edge_index)
+    # the whole step on such a capacity: finite results of the empty list, nothing faults, and the step says so
+    model = resolve_model("xpainn", action_blocks=2).to(DEV).eval().requires_grad_(False)
+    step = GraphedStep(model, (len(pos), len(ptr) - 1, cap))
+    out = step(_t(pos, torch.float32), _t(z), _t(ptr))
+    assert torch.isfinite(out["energy"]).all() and torch.isfinite(out["forces"]).all() and step.overflowed()
+    step_ok = GraphedStep(model, (len(pos), len(ptr) - 1, full))
+    step_ok(_t(pos, torch.float32), _t(z), _t(ptr))
+    assert not step_ok.overflowed()
+
+
+def test_whole_step_graph_follows_a_weight_update():
+    """runtime.GraphedStep captures behind warm-up runs that already filled the packed-weight caches: the pack kernels are not in
+    the graph.  It now tracks the parameters' version counters (and the pack epoch) and re-captures when they moved (advisor,
+    round 3: replays used to mix live weights with stale packed copies)."""
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.nn import resolve_model
+    from xequinet_amd.runtime import GraphedStep, pair_capacity
+
+    torch.manual_seed(5)
+    model = resolve_model("xpainn", action_blocks=2).to(DEV).eval().requires_grad_(False)
+    pos, z, ptr = syn.synth_qm9_batch(16, seed=4)
+    step = GraphedStep(model, (len(pos), len(ptr) - 1, pair_capacity(ptr)))
+    args = (_t(pos, torch.float32), _t(z), _t(ptr))
+    before = step(*args)["energy"].clone()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.02)
+    after = step(*args)["energy"].clone()
+    assert step.captures == 2 and not torch.equal(before, after)
+    b = NeighborTransform(5.0)(XequiBatch(*args))
+    with torch.enable_grad():
+        want = model(b.to_dict(), compute_forces=True)
+    assert torch.equal(after, want["energy"].detach())

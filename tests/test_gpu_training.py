@@ -224,6 +224,40 @@ def test_training_step_as_one_graph_follows_the_host_launched_steps():
         assert (p - q).abs().max().item() <= 2e-4 * scale, n
 
 
+def test_evaluations_between_graphed_training_steps_see_the_current_weights():
+    """Replays of train.GraphedTrainStep update the weights in place without bumping their version counters; the packed weight
+    copies (MLP, U|V, linear, node-block programs; Python and C++ caches) key on those counters.  The step now bumps the pack
+    epoch (include/xeq.h) after every replay, so an evaluation BETWEEN replays repacks: graphed steps, eval, more graphed steps,
+    eval -- each evaluation equals that of a fresh twin holding the same parameters (advisor, round 3, high)."""
+    from xequinet_amd import runtime
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+
+    torch.manual_seed(1)
+    host, dev = _batch(40, 31, torch.float32)
+    tgt = _targets(host, 61, False)[keys.TOTAL_ENERGY].float().to(DEV)
+    cap = (host["pos"].shape[0] + 8, host["ptr"].numel() - 1, runtime.pair_capacity(host["ptr"].numpy()))
+    model = _model(torch.float32, **SMALL).train()
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3, capturable=True)
+    step = train.GraphedTrainStep(model, opt, cap)
+    b = NeighborTransform(5.0)(XequiBatch(dev["pos"], dev["atomic_numbers"], dev["ptr"]))
+    seen = []
+    for round_ in range(3):
+        for _ in range(2):
+            step(dev["pos"], dev["atomic_numbers"], dev["ptr"], tgt, batch=dev["batch"])
+        model.eval()
+        with torch.enable_grad():
+            got = model(b.to_dict(), compute_forces=True)
+        twin = _model(torch.float32, **SMALL).eval()
+        twin.load_state_dict(model.state_dict())
+        with torch.enable_grad():
+            want = twin(b.to_dict(), compute_forces=True)
+        assert torch.equal(got[keys.TOTAL_ENERGY].detach(), want[keys.TOTAL_ENERGY].detach()), round_
+        assert torch.equal(got[keys.FORCES], want[keys.FORCES]), round_
+        seen.append(got[keys.TOTAL_ENERGY].detach().clone())
+        model.train()
+    assert step.captures == 1 and not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
 def test_frozen_model_in_train_mode_stays_on_the_fused_path():
     model = _model(torch.float32, action_blocks=1).requires_grad_(False).train()
     _, dev = _batch(4, 2, torch.float32)

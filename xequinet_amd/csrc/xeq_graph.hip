@@ -609,6 +609,14 @@ __global__ void k_sort_segment_plain(const int64_t* __restrict__ tmp_keys, const
   }
 }
 
+__global__ void k_rowptr_guard(const int32_t* __restrict__ raw, int64_t n, int32_t cap, int32_t* __restrict__ rowptr, int32_t* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const int32_t total = raw[n];          // (read-only input: no thread writes what another reads)
+  if (i == n) count[0] = total;
+  rowptr[i] = total > cap ? 0 : raw[i];
+}
+
 }  // namespace xeq
 
 using namespace xeq;
@@ -863,6 +871,19 @@ int xeq_radius_graph_fill(int dtype, const void* pos, const int64_t* ptr, int64_
                        rowptr, n_edges, edge_index);
   });
   XEQ_CHECK_LAUNCH("xeq_radius_graph_fill");
+  return XEQ_OK;
+}
+
+/* Capacity form of the open-boundary list (runtime.GraphedStep): count[0] = raw[n_nodes], the true edge count, and rowptr = raw when the
+ * list fits the capacity, ALL ZEROS (an empty list) when it does not.  A list cut at the capacity would no longer be symmetric, and the
+ * symmetric shortcuts downstream (reverse-edge map, mirror walk) index by the reverse edge; an empty list is safe for every kernel.
+ * The caller compares count with the capacity when it reads the results (GraphedStep.overflowed).  One launch, out of place. */
+int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream) {
+  XEQ_CHECK_ARG(raw && rowptr && raw != rowptr && count && n_nodes >= 0 && capacity >= 0 && capacity < ((int64_t)1 << 31),
+                "xeq_rowptr_guard: bad arguments");
+  hipLaunchKernelGGL(xeq::k_rowptr_guard, dim3((unsigned)((n_nodes + 256) / 256)), dim3(256), 0, (hipStream_t)stream, raw, n_nodes,
+                     (int32_t)capacity, rowptr, count);
+  XEQ_CHECK_LAUNCH("xeq_rowptr_guard");
   return XEQ_OK;
 }
 

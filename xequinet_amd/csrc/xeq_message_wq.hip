@@ -1343,6 +1343,7 @@ __global__ void k_wq_edge_grad(const float* __restrict__ vec, const int32_t* __r
   int32_t e = peid[p];
   if (e < 0) return;
   if (mirror) e = mirror[e];   // mirror walk: the slot's partials belong to the reverse edge
+  if (e < 0) return;           // (a list wrongly promised as symmetric: xeq_reverse_edge_map wrote -1 for the missing reverse edge)
   float gd = 0.f, q1[3] = {0.f, 0.f, 0.f}, q2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int u = 0; u < nu; ++u) gd += pd[(int64_t)u * P + p];
   for (int u = 0; u < nu1; ++u)

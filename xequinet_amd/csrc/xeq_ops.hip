@@ -358,7 +358,18 @@ using namespace xeq;
     if (rc_ != XEQ_OK) return rc_;            \
   }
 
+#include <atomic>
+static std::atomic<long long> g_pack_epoch{0};
+
 extern "C" {
+
+/* Epoch of the packed weight copies (fragment-order copies of nn.Linear / o3.Linear weights that the matrix-core kernels read).  Every
+ * pack cache -- nn/fused.py, nn/nodeblock.py, csrc/xeq_torch.cpp -- keys on it next to the tensors' version counters: whatever changes
+ * parameters behind autograd's back (a captured optimizer step replayed as a graph, train.GraphedTrainStep) bumps it, and the next
+ * evaluation repacks. */
+long long xeq_pack_epoch(void) { return g_pack_epoch.load(); }
+void xeq_pack_epoch_bump(void) { g_pack_epoch.fetch_add(1); }
+
 
 /* ---- launch policy shared by every front (Python modules, registered operator): ONE statement of the rules ---------------- */
 int xeq_message_auto_family(int dtype, int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {

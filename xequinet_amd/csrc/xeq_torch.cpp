@@ -99,7 +99,7 @@ const MlpPacks* mlp_packs(const Tensor& w1, const Tensor& b1, const Tensor& w2, 
     return nullptr;
   static std::mutex mu;
   static std::unordered_map<const void*, MlpPacks> cache;
-  const int64_t key[8] = {(int64_t)w1._version(), (int64_t)(intptr_t)w1.data_ptr(), (int64_t)b1._version(), (int64_t)(intptr_t)b1.data_ptr(),
+  const int64_t key[8] = {(int64_t)w1._version() + ((int64_t)xeq_pack_epoch() << 32), (int64_t)(intptr_t)w1.data_ptr(), (int64_t)b1._version(), (int64_t)(intptr_t)b1.data_ptr(),
                           (int64_t)w2._version(), (int64_t)(intptr_t)w2.data_ptr(), (int64_t)b2._version(), (int64_t)(intptr_t)b2.data_ptr()};
   std::lock_guard<std::mutex> lock(mu);
   MlpPacks& e = cache[w1.data_ptr()];
@@ -162,7 +162,7 @@ const LinPack* lin_pack(const Tensor& w, const Tensor& b) {
   static std::mutex mu;
   static std::unordered_map<const void*, LinPack> cache;
   const bool hb = b.defined() && b.numel() > 0;
-  const int64_t key[4] = {(int64_t)w._version(), (int64_t)(intptr_t)w.data_ptr(), hb ? (int64_t)b._version() : -1, hb ? (int64_t)(intptr_t)b.data_ptr() : 0};
+  const int64_t key[4] = {(int64_t)w._version() + ((int64_t)xeq_pack_epoch() << 32), (int64_t)(intptr_t)w.data_ptr(), hb ? (int64_t)b._version() : -1, hb ? (int64_t)(intptr_t)b.data_ptr() : 0};
   std::lock_guard<std::mutex> lock(mu);
   LinPack& e = cache[w.data_ptr()];
   bool same = e.fwd.defined() && e.owners.same({&w, &b});
@@ -222,7 +222,7 @@ const UvFrag* uv_frag(const Tensor* q /* [W0, W1, W2, bias pair] */, int node_di
   static std::unordered_map<const void*, UvFrag> cache;
   int64_t key[8];
   for (int i = 0; i < 4; ++i) {
-    key[2 * i] = q[i].numel() > 0 ? (int64_t)q[i]._version() : -1;
+    key[2 * i] = q[i].numel() > 0 ? (int64_t)q[i]._version() + ((int64_t)xeq_pack_epoch() << 32) : -1;
     key[2 * i + 1] = q[i].numel() > 0 ? (int64_t)(intptr_t)q[i].data_ptr() : 0;
   }
   std::lock_guard<std::mutex> lock(mu);
@@ -269,7 +269,7 @@ const NbPacks* nb_packs(const Tensor* q, const Tensor* qn, bool gx) {
   }
   std::vector<int64_t> key;
   for (const Tensor* t : ws) {
-    key.push_back(t->defined() ? (int64_t)t->_version() : -1);
+    key.push_back(t->defined() ? (int64_t)t->_version() + ((int64_t)xeq_pack_epoch() << 32) : -1);
     key.push_back(t->defined() && t->numel() > 0 ? (int64_t)(intptr_t)t->data_ptr() : 0);
   }
   std::lock_guard<std::mutex> lock(mu);

@@ -137,6 +137,9 @@ _PROTOS = {
     "xeq_mlp_pack": [_P, _P, c_int, c_int, c_int, _P, _P],
     "xeq_mlp2_fwd": [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P, c_int64, _P],
     "xeq_mlp2_bwd": [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, c_int64, _P],
+    "xeq_pack_epoch": [],
+    "xeq_pack_epoch_bump": [],
+    "xeq_rowptr_guard": [_P, c_int64, c_int64, _P, _P, _P],
     "xeq_node_block_supported": [c_int, c_int, _I3],
     "xeq_node_block_fwd_tiles": [c_int],
     "xeq_node_block_rows": [c_int64],
@@ -152,7 +155,7 @@ _PROTOS = {
 }
 # entry points that return a size, not a status
 _RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
-            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows"}
+            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None
@@ -177,6 +180,16 @@ def load() -> ctypes.CDLL:
         fn.restype = c_int64 if name in _RET_I64 else c_int
     _lib = lib
     return lib
+
+
+def pack_epoch() -> int:
+    """Epoch of the packed weight copies (include/xeq.h): part of every pack-cache key."""
+    return int(load().xeq_pack_epoch())
+
+
+def bump_pack_epoch() -> None:
+    """Parameters changed behind autograd's back (a replayed captured optimizer step): every pack cache misses from here on."""
+    load().xeq_pack_epoch_bump()
 
 
 def call(name: str, *args) -> None:

@@ -81,7 +81,7 @@ def _mlp_packs(seq: torch.nn.Sequential):
             and lib.load().xeq_mlp2_supported(lib.XEQ_F32, w1.shape[1], w1.shape[0], w2.shape[0])):
         return None
     key = (w1._version, w1.data_ptr(), lin1.bias._version, lin1.bias.data_ptr(), w2._version, w2.data_ptr(), lin2.bias._version,
-           lin2.bias.data_ptr())
+           lin2.bias.data_ptr(), lib.pack_epoch())
     cache = getattr(seq, "_xeq_mlp_pack", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -218,7 +218,7 @@ def _linear_pack(mod_or_key, weight: torch.Tensor, bias, transposed: bool):
     n_out, k_in = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
     if weight.dtype != torch.float32 or not weight.is_cuda or not lib.load().xeq_linear_supported(lib.XEQ_F32, k_in, n_out):
         return None
-    key = (weight._version, weight.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), transposed)
+    key = (weight._version, weight.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), transposed, lib.pack_epoch())
     name = "_xeq_lin_pack_t" if transposed else "_xeq_lin_pack"
     cache = getattr(mod_or_key, name, None)
     if cache is not None and cache[0] == key:
@@ -265,7 +265,8 @@ class EnergyHead(Function):
     @staticmethod
     def supported(seq: torch.nn.Sequential, s: torch.Tensor) -> bool:
         lin1, act, lin2 = seq[0], seq[1], seq[2]
-        return (isinstance(act, torch.nn.SiLU) and s.is_cuda and s.dtype == torch.float32 and lin1.bias is not None and lin2.weight.shape[0] == 1
+        return (isinstance(act, torch.nn.SiLU) and s.is_cuda and s.dtype == torch.float32 and lin1.bias is not None and lin2.bias is not None
+                and lin2.weight.shape[0] == 1
                 and lin1.weight.shape[0] % 4 == 0 and bool(lib.load().xeq_linear_supported(lib.XEQ_F32, lin1.weight.shape[1], lin1.weight.shape[0]))
                 and bool(lib.load().xeq_linear_supported(lib.XEQ_F32, lin1.weight.shape[0], lin1.weight.shape[1])))
 
@@ -383,7 +384,8 @@ class MessageBlock(Function):
 def _packed_uv(module) -> Tuple[list, torch.Tensor]:
     """[W_U | W_V] / sqrt(mul) per l ([mul, 2 mul]) and the 0e bias pair, cached on the module."""
     wu, wv = module.update_U.weight, module.update_V.weight
-    key = (wu._version, wv._version, wu.data_ptr(), wv.data_ptr(), module.update_U.bias._version, module.update_V.bias._version, wu.dtype)
+    key = (wu._version, wv._version, wu.data_ptr(), wv.data_ptr(), module.update_U.bias._version, module.update_V.bias._version, wu.dtype,
+           lib.pack_epoch())
     cache = getattr(module, "_uv_pack", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]

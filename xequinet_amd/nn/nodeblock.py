@@ -3,7 +3,7 @@ reference) together with the front half of the next XPainnMessage.forward (nn/xp
 backwards for the force evaluation (nn/basic.py:143-159).
 
 The packed weight programs are cached per (update module, next message module) and rebuilt when any weight moves
-(``pack_epoch`` covers in-place updates that do not bump tensor versions, e.g. a captured optimizer step).
+(``lib.pack_epoch`` covers in-place updates that do not bump tensor versions, e.g. a replayed captured optimizer step).
 """
 from __future__ import annotations
 
@@ -15,16 +15,7 @@ from .. import lib
 from ..lib import call, mul3, ptr, stream
 
 TILE_BYTES = 3072
-# bumped by anything that changes parameters behind autograd's back (train.GraphedTrainStep replays): every pack cache keys on it
-_pack_epoch = [0]
-
-
-def bump_pack_epoch() -> None:
-    _pack_epoch[0] += 1
-
-
-def pack_epoch() -> int:
-    return _pack_epoch[0]
+pack_epoch = lib.pack_epoch   # every pack cache keys on it next to the tensors' version counters (include/xeq.h)
 
 
 def supported(update, message=None) -> bool:

@@ -277,9 +277,11 @@ def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tu
     return edge_index, rowptr
 
 
-def radius_graph_capacity(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float, edge_index: torch.Tensor) -> torch.Tensor:
-    """Non-PBC neighbour list into a caller-owned ``edge_index`` [2, capacity] WITHOUT reading the edge count back: returns the
-    row pointer [N + 1] (``rowptr[N]`` is the count, on the device).  Slots behind the count keep their old contents, which must
+def radius_graph_capacity(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float, edge_index: torch.Tensor):
+    """Non-PBC neighbour list into a caller-owned ``edge_index`` [2, capacity] WITHOUT reading the edge count back: returns
+    (row pointer [N + 1], count [1]) on the device.  ``count`` is the true edge count; a list that outgrew the capacity is replaced
+    by an EMPTY one (row pointer all zeros: no kernel walks past a buffer, and the symmetric shortcuts downstream never see a cut,
+    asymmetric list) -- ``count > capacity`` tells the caller, who reads it next to the results.  Slots behind the count keep their old contents, which must
     be valid node ids (zero-initialise the buffer once).  Every kernel downstream bounds its walk by the row pointer, so the
     whole evaluation can sit in one captured HIP graph (runtime.GraphedStep).  The pair sweep only (graphs of many atoms go
     through the cell list, whose bin count is a host value)."""
@@ -293,9 +295,12 @@ def radius_graph_capacity(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float, 
     rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     dt = dtype_code(pos)
     call("xeq_radius_graph_count", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(deg), stream())
-    _exclusive_scan(deg, N, rowptr)
+    raw = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    _exclusive_scan(deg, N, raw)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    call("xeq_rowptr_guard", ptr(raw), N, cap, ptr(rowptr), ptr(count), stream())
     call("xeq_radius_graph_fill", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(rowptr), cap, ptr(edge_index), stream())
-    return rowptr
+    return rowptr, count
 
 
 def radius_graph_pbc_raw(pos_wrap, ptr_, img, cells, shift, cutoff, prune=None):

@@ -19,7 +19,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import keys, ops
+from . import keys, lib, ops
 
 
 class _Captured:
@@ -75,7 +75,7 @@ class GraphedModel:
             while not isinstance(m, torch.nn.Module) and hasattr(m, "model"):    # a plain callable around a module (md_model._Core)
                 m = m.model
             self._tracked = (list(m.parameters()) + list(m.buffers())) if isinstance(m, torch.nn.Module) else []
-        return tuple([t._version for t in self._tracked])
+        return tuple([t._version for t in self._tracked]) + (lib.pack_epoch(),)
 
     def _signature(self, data, eg: ops.EdgeGraph) -> tuple:
         pos = data[keys.POSITIONS]
@@ -189,6 +189,19 @@ class GraphedModel:
 
 
 # ----------------------------------------------------------------------------------------------- whole step as one graph
+def _params_state(step) -> tuple:
+    """Version counters of the model's parameters and buffers plus the pack epoch (include/xeq.h): a captured graph holds the packed
+    weight copies of the moment it was captured (the pack kernels ran in the warm-up, outside the graph), so a step object
+    re-captures when any of them moved (optimizer step, load_state_dict, a replayed captured training step)."""
+    tracked = getattr(step, "_tracked_params", None)
+    if tracked is None:
+        m = step.model
+        while not isinstance(m, torch.nn.Module) and hasattr(m, "model"):
+            m = m.model
+        tracked = step._tracked_params = (list(m.parameters()) + list(m.buffers())) if isinstance(m, torch.nn.Module) else []
+    return tuple([t._version for t in tracked]) + (lib.pack_epoch(),)
+
+
 def pair_capacity(ptr_host) -> int:
     """Upper bound of an open-boundary neighbour list: every ordered pair inside a graph, sum_g n_g (n_g - 1)."""
     import numpy as np
@@ -251,10 +264,16 @@ class GraphedStep:
         self.rowptr: Optional[torch.Tensor] = None
         self.warmup = warmup
         self.captures = 0
+        self._param_state = None
+
+    def overflowed(self) -> bool:
+        """Whether the last step's neighbour list outgrew the edge capacity (reads the device-side count: a synchronisation).  The
+        kernels cut such a list at the capacity -- nothing is written out of bounds -- but its results are those of the cut list."""
+        return bool(self.outputs) and int(self.outputs["n_edges"].item()) > self.n_edges
 
     # -- the step on the static buffers (what is captured)
     def _step(self) -> Dict[str, torch.Tensor]:
-        rowptr = ops.radius_graph_capacity(self.pos, self.ptr, self.cutoff, self.edge_index)
+        rowptr, count = ops.radius_graph_capacity(self.pos, self.ptr, self.cutoff, self.edge_index)
         eg = ops.EdgeGraph(self.edge_index, self.n_atoms, center_sorted=True, ptr=self.ptr, c_rowptr=rowptr, symmetric=True)
         data = {keys.POSITIONS: self.pos.detach(), keys.ATOMIC_NUMBERS: self.z, keys.EDGE_INDEX: self.edge_index, keys.BATCH: self.batch,
                 keys.BATCH_PTR: self.ptr, keys.EDGE_GRAPH: eg}
@@ -262,7 +281,7 @@ class GraphedStep:
         with torch.enable_grad():
             out = self.model(data, compute_forces=self.compute_forces, compute_virial=False)
         res = {k: v.detach() for k, v in out.items() if isinstance(v, torch.Tensor)}
-        res["n_edges"] = rowptr[self.n_atoms:]              # device-side edge count (a view of the row pointer's last entry)
+        res["n_edges"] = count                              # device-side TRUE edge count (the row pointer itself is cut at the capacity)
         return res
 
     def _load(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor]) -> None:
@@ -287,6 +306,10 @@ class GraphedStep:
         if ptr_host is not None and pair_capacity(ptr_host) > self.n_edges:
             raise ValueError(f"GraphedStep: the batch may hold {pair_capacity(ptr_host)} edges, the capacity is {self.n_edges}")
         self._load(pos, atomic_numbers, ptr, batch)
+        state = _params_state(self)
+        if self.graph is not None and state != self._param_state:   # weights moved since the capture: its packed copies are stale
+            self.graph = None
+        self._param_state = state
         if self.graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -398,6 +421,10 @@ class GraphedStepPBC:
         self.cell.copy_(torch.from_numpy(c))
 
     def _run(self) -> None:
+        state = _params_state(self)
+        if self.graph is not None and state != getattr(self, "_param_state", None):   # weights moved: the captured packed copies are stale
+            self.graph = None
+        self._param_state = state
         if self.graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

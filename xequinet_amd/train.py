@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F_
 
-from . import keys
+from . import keys, lib
 
 _LOSSES = {"l1": F_.l1_loss, "mae": F_.l1_loss, "l2": F_.mse_loss, "mse": F_.mse_loss, "smoothl1": F_.smooth_l1_loss}
 
@@ -82,7 +82,11 @@ class GraphedTrainStep:
     ``energy_per_atom`` (utils/loss.py:47-110, utils/trainer.py:295-302); forces in the loss need the differentiable pass and are not
     captured here.
 
-    The optimizer must keep its state on the device (``torch.optim.Adam(..., capturable=True)``).  The warm-up iterations in front of
+    The optimizer must keep its state on the device (``torch.optim.Adam(..., capturable=True)``).  Python-float hyper-parameters
+    (``lr``, betas, ``weight_decay``) are baked into the graph at capture: a scheduler or warm-up that rewrites
+    ``param_groups[...]['lr']`` has no effect on replays unless ``lr`` is a device tensor (``Adam(lr=torch.tensor(...),
+    capturable=True)``, updated in place) -- ``set_lr`` does that update and re-captures when ``lr`` is a plain float.  Gradient
+    clipping and EMA (utils/trainer.py:303-308 of the reference) are NOT part of the captured step.  The warm-up iterations in front of
     the capture are real steps on the first batch; model and optimizer are put back to their state before them, so the first
     replayed step is the first update."""
 
@@ -107,12 +111,23 @@ class GraphedTrainStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.loss: Optional[torch.Tensor] = None
         self.captures = 0
+        self._count = None
+
+    def set_lr(self, lr: float) -> None:
+        """A new learning rate for the next steps: written into a tensor-valued ``lr`` in place (the captured graph reads it), a
+        float-valued one is replaced and the graph re-captured."""
+        for grp in self.optimizer.param_groups:
+            if torch.is_tensor(grp["lr"]):
+                grp["lr"].fill_(float(lr))
+            else:
+                grp["lr"] = float(lr)
+                self.graph = None
 
     def _body(self) -> torch.Tensor:
         from . import ops
 
         g = self._gs
-        rowptr = ops.radius_graph_capacity(g.pos, g.ptr, g.cutoff, g.edge_index)
+        rowptr, self._count = ops.radius_graph_capacity(g.pos, g.ptr, g.cutoff, g.edge_index)   # (cut at the capacity: no walk leaves a buffer)
         eg = ops.EdgeGraph(g.edge_index, g.n_atoms, center_sorted=True, ptr=g.ptr, c_rowptr=rowptr, symmetric=True)
         eg.edge_count_on_device = True
         data = {keys.POSITIONS: g.pos.detach(), keys.ATOMIC_NUMBERS: g.z, keys.EDGE_INDEX: g.edge_index, keys.BATCH: g.batch,
@@ -175,4 +190,11 @@ class GraphedTrainStep:
         if self.graph is None:
             self._capture()
         self.graph.replay()
+        # the replay moved the weights in place without touching their version counters: every cached packed copy (nn/fused.py,
+        # nn/nodeblock.py, csrc/xeq_torch.cpp) and every captured inference graph (runtime.Graphed*) is stale from here on
+        lib.bump_pack_epoch()
         return self.loss
+
+    def overflowed(self) -> bool:
+        """Whether the last step's neighbour list outgrew the edge capacity (a synchronisation; the list is cut, never overrun)."""
+        return self._count is not None and int(self._count.item()) > self._gs.n_edges
