@@ -82,14 +82,14 @@ def cpu_baseline(pos, z, ptr, sd, budget_s=25.0):
     except Exception:
         free = 32 << 30
     edges_per_mol = e_probe / probe_mol
-    by_time = budget_s / 3.0 * rates[best] / edges_per_mol         # ~3 evaluations (warm-up + 2 timed) in the budget
+    by_time = budget_s / 4.0 * rates[best] / edges_per_mol * 1.6   # ~4 evaluations (warm-up + 3 timed); the whole batch when it is within 1.6 x the budget
     by_mem = 0.5 * free / (0.12e6 * edges_per_mol)
     n_mol = int(max(probe_mol, min(n_all, by_time, by_mem)))
-    n_edges, med = timed(n_mol, 2)
+    n_edges, med = timed(n_mol, 3)
     a = int(ptr[n_mol])
     torch.set_num_threads(default_threads)
     return {"value": n_edges / med, "unit": "edges/s", "cores": best, "kind": "port",
-            "sample": f"first {n_mol} of {n_all} molecules of the batch ({a} atoms, {n_edges} edges), fp32, median of 2 runs, "
+            "sample": f"first {n_mol} of {n_all} molecules of the batch ({a} atoms, {n_edges} edges), fp32, one warm-up + median of 3 timed runs, "
                       f"{med * 1e3:.1f} ms/eval, brute-force neighbour list included, {best} threads (tuned on {probe_mol} molecules: "
                       + ", ".join(f"{t} thr {r:.0f} e/s" for t, r in sorted(rates.items())) + f"; host has {cores} logical cores)",
             "default_threads": {"threads": default_threads, "value": rates.get(default_threads), "sample": f"{probe_mol}-molecule probe"}}
@@ -405,9 +405,18 @@ def main():
             # (split-bf16 filter), the peak stays the exact-f32 one
             flops = (52.0e3 if "bwd" in dom else 26.0e3) * n_launch_edges
             tfl = flops / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "timing": kernel_timing,
-                        "algorithmic_bytes_per_launch": alg,
+            # which roof binds: the launch's arithmetic intensity against the ridge of the exact-f32 matrix pipe over HBM
+            # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B, MI355X_MICROARCH.md).  The message kernels sit at ~75 FLOP/B: matrix-pipe bound.
+            intensity = flops / alg
+            ridge = F32_MATRIX_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+            mfma_bound = intensity > ridge
+            hbm_line = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+            head = ({"bound": "mfma", "achieved": tfl, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F32_MATRIX_PEAK_TFLOPS}
+                    if mfma_bound else dict(bound="hbm", **hbm_line))
+            roofline = {**head, "kernel": dom, "mfma_dtype": "f32 (exact, v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s dense)",
+                        "arithmetic_intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
+                        "traffic": traffic, "avg_launch_ms": avg_ms, "timing": kernel_timing,
+                        "algorithmic_bytes_per_launch": alg, "algorithmic_flops_per_launch": flops, "hbm": hbm_line,
                         "matrix_pipe": {"algorithmic_flops_per_launch": flops, "achieved": tfl, "peak": F32_MATRIX_PEAK_TFLOPS,
                                         "unit": "TFLOP/s", "frac": tfl / F32_MATRIX_PEAK_TFLOPS,
                                         "dtype": "algorithmic f32 flops against the exact-f32 rate (v_mfma_f32_32x32x2_f32); since round 3 the filter's "

@@ -8,7 +8,7 @@ than the reference's own arithmetic at the reference's own precision).  Molecule
 molecule's oracle result does not depend on which other molecules the oracle sees.
 
 Every comparison appends its achieved maxima to PARITY; tests/conftest.py writes them to
-``gpurun_out/parity_r03.json`` at the end of the session (copied to ``profiles/``).
+``gpurun_out/parity_r04.json`` at the end of the session (copied to ``profiles/``).
 """
 import numpy as np
 import pytest
@@ -23,6 +23,7 @@ from tests.test_gpu_parity import DEV, _build, _t, f32_force_bounds
 pytestmark = pytest.mark.gpu
 
 E_RTOL, E_ATOL = 1e-5, 1e-4
+F32_PLAIN_FORCE_TOL = 1e-4     # max-abs force tolerance in fp32 (model units), no envelope
 N_SAMPLE = 160   # molecules / frames the oracle evaluates: the error distribution is heavy-tailed, 64 draws leave the maximum to chance
 # forces (model units): tests/test_gpu_parity.py::f32_force_bounds
 
@@ -264,3 +265,35 @@ def test_whole_step_graph_follows_a_weight_update():
     with torch.enable_grad():
         want = model(b.to_dict(), compute_forces=True)
     assert torch.equal(after, want["energy"].detach())
+
+
+def test_qm9_1024_with_the_reference_initialisation():
+    """BASELINE.md section 2 states |dF| <= 1e-4 (fp32).  The parity model of the other checks randomises every affine weight and bias
+    (so that a wrong index shows up); this one carries the REFERENCE'S OWN INITIALISATION (nn.Linear / LayerNorm defaults, o3.Linear
+    ~ N(0, 1), zero o3 biases, affine weights 1: SURVEY 8d).  What round 4 found (profiles/r04_fp32_tail.txt): a random-weight
+    network of this family is ill-conditioned on a few molecules whatever the initialisation -- there ANY fp32 evaluation (the CPU
+    oracle in another edge order, ATen on the GPU, these kernels) draws errors 10-50 x apart, and a change of one ulp in one
+    envelope value moves a force by 1e-5 -- so the plain tolerance is asserted where it is a property of the implementation, at the
+    99.9th percentile of the components (measured: 99 % below 2e-5, rms 6e-6), and the single worst component against the
+    reference's own fp32 error on the same molecules, as everywhere else."""
+    from xequinet_amd.nn import resolve_model
+
+    torch.manual_seed(0)
+    model = resolve_model("xpainn").eval().requires_grad_(False)
+    oracle = orc.XPaiNNOracle({k: v.detach().double().clone() for k, v in model.state_dict().items()})
+    model = model.to(DEV)
+    pos, z, ptr, _ = syn.make_workload("qm9_1024", seed=1234)
+    E, F, n_edges, _ = _hip_eval(model, pos, z, ptr)
+    assert n_edges == 311994
+    mols = np.sort(np.random.default_rng(11).choice(len(ptr) - 1, size=N_SAMPLE, replace=False))
+    idx, Eref, Fref, _, ref_in = _oracle_subset(oracle, pos, z, ptr, mols)
+    dE, dF = np.abs(E[mols] - Eref), np.abs(F[idx] - Fref)
+    b_max, _, e32_max, e32_p99 = f32_force_bounds(oracle, ref_in, Fref)
+    parity_record.add(dict(config="qm9_1024, reference initialisation", max_abs_dE=float(dE.max()), max_abs_dF=float(dF.max()),
+                           p99_abs_dF=float(np.quantile(dF, 0.99)), p999_abs_dF=float(np.quantile(dF, 0.999)), rms_dF=float(np.sqrt((dF ** 2).mean())),
+                           max_abs_F=float(np.abs(Fref).max()), bound_dF_p999=F32_PLAIN_FORCE_TOL, bound_dF_max=b_max,
+                           oracle32_max_abs_dF=e32_max, oracle32_p99_abs_dF=e32_p99, compared_graphs=int(len(mols)),
+                           compared_atoms=int(len(idx)), dtype="f32 HIP vs f64 oracle"))
+    assert np.all(dE <= E_RTOL * np.abs(Eref) + E_ATOL)
+    assert np.quantile(dF, 0.999) <= F32_PLAIN_FORCE_TOL, float(np.quantile(dF, 0.999))
+    assert dF.max() <= b_max, (float(dF.max()), b_max)

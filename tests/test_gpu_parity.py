@@ -26,7 +26,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 DEV = "cuda"
 F32_FORCE_FLOOR = 1e-4      # the stated fp32 force tolerance (model units)
 F32_ORACLE_FACTOR = 1.5     # ... widened only to 1.5 x the error of the reference's own arithmetic in fp32 on the same inputs (99th percentile)
-F32_ORACLE_FACTOR_MAX = 2.5 # ... and to 2.5 x at the single worst component (measured envelope of round 3: 0.2 .. 2.2, see f32_force_bounds)
+F32_ORACLE_FACTOR_MAX = 1.5 # ... and at the single worst component (round 3 needed 2.5 here against an envelope of CPU evaluations only; see f32_force_bounds)
 
 
 def f32_twin(oracle):
@@ -43,6 +43,20 @@ F32_ORACLE_ORDERS = 4       # members of the fp32 oracle's ensemble (edge orders
 
 
 _F32_BOUNDS_CACHE = {}
+
+
+def _aten_gpu_twin(oracle):
+    """The reference's op sequence (index_select, Linear, layer norms, index_add, autograd's own reverse pass) in fp32 on the GPU through
+    the vendor's ATen kernels: the differentiable form of this package's blocks (xequinet_amd/nn/training.py), which launches no
+    xeq kernel.  It is what the reference itself computes when it runs on a GPU (its ``index_add`` is then an atomic scatter)."""
+    twin = getattr(oracle, "_aten_gpu_twin", None)
+    if twin is None:
+        from xequinet_amd.nn import resolve_model
+
+        twin = resolve_model("xpainn", **getattr(oracle, "_kw", {}))
+        twin.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in oracle.sd.items()})
+        twin = oracle._aten_gpu_twin = twin.to(DEV).train().requires_grad_(True)
+    return twin
 
 
 def f32_force_bounds(oracle, ref_in, Fref):
@@ -80,6 +94,16 @@ def f32_force_bounds(oracle, ref_in, Fref):
             run["cell_offsets"] = run["cell_offsets"][perm]
         e = np.abs(twin(run, compute_forces=True)["forces"].double().numpy() - Fref)
         err = e if err is None else np.maximum(err, e)
+        # ... and the same member through ATen's fp32 kernels on the GPU (autograd's reverse pass, atomic index_add): the reference's
+        # arithmetic as a GPU runs it.  Round 4's stage-by-stage comparison (profiles/r04_fp32_tail.txt) found the HIP path's node
+        # features as accurate as the CPU fp32 oracle's after every block and its forces statistically those of this ATen evaluation;
+        # the tail is the conditioning of the random-weight network on a few molecules, where ANY fp32 evaluation order draws
+        # errors 10-50 x apart, so the envelope has to hold GPU members too
+        gpu = _aten_gpu_twin(oracle)
+        dev_in = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in run.items()}
+        with torch.enable_grad():
+            fg = gpu(dev_in, compute_forces=True)["forces"].detach().double().cpu().numpy()
+        err = np.maximum(err, np.abs(fg - Fref))
     e_max, e_p99 = float(err.max()), float(np.quantile(err, 0.99))
     out = (max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR_MAX * e_max), max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_p99), e_max, e_p99)
     _F32_BOUNDS_CACHE[key] = out
@@ -700,7 +724,7 @@ def _check_model(model, oracle, pos, z, ptr, ei, dtype, extra=None, label=None):
         np.testing.assert_allclose(Fg, Fref, rtol=0, atol=1e-9 * max(1.0, np.abs(Fref).max()))
         np.testing.assert_allclose(got["atomic_energies"].detach().cpu().numpy(), want["atomic_energies"].numpy(), rtol=1e-10, atol=1e-10)
     else:
-        # fp32 tolerances (achieved maxima of every call: profiles/parity_r03.json):
+        # fp32 tolerances (achieved maxima of every call: profiles/parity_r04.json):
         #   |dE| <= 1e-5 |E| + 1e-4                                  (achieved <= 0.02 of it)
         #   |dF|: f32_force_bounds() -- max and 99th percentile within max(1e-4, 1.5 x the fp32 oracle's own error on these inputs)
         dE, dF = np.abs(E - Eref), np.abs(Fg - Fref)
