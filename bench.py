@@ -30,7 +30,8 @@ import torch
 METRIC = "edges/sec + achieved HBM GB/s, energy+force inference, QM9-shape batch"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32 (= the f32 vector rate)
-SHARDED = ("qm9_65536",)        # workloads that are ONE batch sharded over the ranks (strong scaling)
+SHARDED = ("qm9_65536", "qm9_8192_sharded")   # workloads that are ONE batch sharded over the ranks (strong scaling); the second: the
+                                               # 8192-molecule batch cut over the ranks, the size a one-card rehearsal of the sharded path can afford
 
 
 def _oracle_eval(orc, oracle, p, zz, pp):
@@ -107,7 +108,7 @@ def _load_sharded_batch(name, seed):
             return d["pos"], d["z"], d["ptr"]
         except Exception:
             pass
-    pos, z, ptr, _ = syn.make_workload(name, seed)
+    pos, z, ptr, _ = syn.make_workload(name.replace("_sharded", ""), seed)
     try:
         tmp = f"{path}.{os.getpid()}.npz"
         np.savez(tmp, pos=pos, z=z, ptr=ptr)

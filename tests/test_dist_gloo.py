@@ -90,6 +90,48 @@ def test_plan_chunks_is_balanced_and_cheap_at_65k_molecules():
     assert len(chunks) == -(-int(bound.sum()) // 8_000_000) and max(sizes) <= 8_000_000 and max(sizes) - min(sizes) <= 0.02 * max(sizes)
 
 
+def test_qm9_65536_plan_for_eight_ranks_is_balanced():
+    """BASELINE config 5 at its real width, host side only: 65 536 QM9-shape molecules cut for 8 ranks (dist.shard_by_edges) and
+    every shard cut into chunks under the message kernels' offset bound (dist.plan_chunks, what runtime.evaluate_in_chunks walks).
+    Balanced on planned edges to 2 %; every molecule in exactly one range; the chunk counts per rank are equal.  (Molecule sizes
+    from the workload's recipe, n = clip(round(N(18, 3)), 3, 29): the planner only looks at the sizes.)"""
+    rng = np.random.default_rng(1234)
+    n = np.clip(np.rint(rng.normal(18, 3, size=65536)), 3, 29).astype(np.int64)
+    ptr = np.concatenate([[0], np.cumsum(n)])
+    cost = n * (n - 1)
+    shards = xdist.shard_by_edges(ptr, 8)
+    assert shards[0][0] == 0 and shards[-1][1] == 65536 and all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+    planned = np.array([cost[a:b].sum() for a, b in shards], dtype=np.float64)
+    assert planned.max() / planned.mean() <= 1.02, planned / planned.mean()
+    n_chunks = []
+    for a, b in shards:
+        chunks = xdist.plan_chunks(ptr, 8_000_000, a, b)
+        assert chunks[0][0] == a and chunks[-1][1] == b and all(x[1] == y[0] for x, y in zip(chunks, chunks[1:]))
+        sizes = [int(cost[x:y].sum()) for x, y in chunks]
+        assert max(sizes) <= 8_000_000 and max(sizes) - min(sizes) <= 0.03 * max(sizes)
+        n_chunks.append(len(chunks))
+    assert len(set(n_chunks)) == 1, n_chunks     # the same number of evaluations on every rank (no rank waits a whole chunk for another)
+    # the same batch on one rank (the g = 1 point of the scaling curve): chunks of about the same size as the 8-rank ones
+    one = xdist.plan_chunks(ptr, 8_000_000)
+    assert len(one) == -(-int(cost.sum()) // 8_000_000)
+
+
+def test_init_from_env_binds_the_device_before_the_process_group(monkeypatch):
+    """One process per GPU under torchrun (run/train.py:74-77 of the reference): LOCAL_RANK selects the device BEFORE the RCCL
+    communicator is created and before anything allocates -- a rank that initialises the group on device 0 first leaves a context
+    (and the communicator's buffers) on the wrong GPU."""
+    calls = []
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(("set_device", d)))
+    monkeypatch.setattr(xdist.dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(xdist.dist, "init_process_group", lambda **kw: calls.append(("init", kw["backend"], kw["rank"], kw["world_size"])))
+    assert xdist.init_from_env("nccl") == (5, 5, 8)
+    assert calls == [("set_device", 5), ("init", "nccl", 5, 8)]
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1"   # (the container's hostname may not resolve)
+
+
 def _tiny_oracle():
     from xequinet_amd.nn import resolve_model
 

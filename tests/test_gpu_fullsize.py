@@ -170,6 +170,30 @@ def test_bench_starts_its_own_ranks():
     assert line["config"]["edges_all_ranks_per_step"] > 1.9 * line["config"]["edges_rank0"]
 
 
+def test_bench_shards_one_batch_over_four_ranks_on_one_card():
+    """`bench.py --workload qm9_8192 --gpus 4` (one 8192-molecule batch -- the per-GPU share of BASELINE config 5 -- cut by molecule over
+    four ranks, strong scaling) rehearsed on this one card over gloo: every rank on device 0, the two reductions of the contract
+    (max time, sum of edges) across four processes.  (The pool allows six GPU processes at once: the eight-rank run is the driver's.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(XEQ_BENCH_BACKEND="gloo", XEQ_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "qm9_8192_sharded", "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-gemm-autotune"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["value"] > 0
+    # the four shards together hold the whole batch; rank 0's share is a quarter to a few percent (balanced on planned edges)
+    total = line["config"]["edges_all_ranks_per_step"]
+    assert 0.23 * total <= line["config"]["edges_rank0"] <= 0.27 * total, line["config"]
+
+
 def test_whole_step_graph_replays_batches_of_changing_sizes():
     """runtime.GraphedStep: neighbour list + model as ONE captured graph over capacity-sized arrays, the edge count on the device.
     Four batches with different atom / graph / edge counts go through one capture; each result is, bit for bit, the eager

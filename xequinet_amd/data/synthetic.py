@@ -88,6 +88,7 @@ WORKLOADS = {
     "qm9_64": "64 QM9-shape synthetic molecules",
     "qm9_8192": "8192 QM9-shape synthetic molecules (the per-GPU share of QM9-65k on 8 GPUs, SURVEY 8d-5)",
     "qm9_65536": "65536 QM9-shape synthetic molecules, ONE batch sharded by molecule over the GPUs (SURVEY 8d-5)",
+    "qm9_8192_sharded": "8192 QM9-shape synthetic molecules, ONE batch sharded by molecule over the GPUs (rehearsal size of SURVEY 8d-5)",
     "md17_4096": "4096 perturbed aspirin frames (MD17 shape)",
     "water_512": "one periodic box of 512 water molecules",
 }
@@ -96,7 +97,7 @@ WORKLOADS = {
 def make_workload(name: str, seed: int = 1234):
     """(pos[N,3] f64, z[N] i32, ptr[G+1] i64, cell[1,3,3] | None) of a named workload."""
     if name.startswith("qm9_"):
-        pos, z, ptr = synth_qm9_batch(int(name.split("_")[1]), seed=seed)
+        pos, z, ptr = synth_qm9_batch(int(name.split("_")[1]), seed=seed)   # ("qm9_8192_sharded": the same batch as "qm9_8192")
         return pos, z, ptr, None
     if name == "md17_4096":
         pos, z, ptr = synth_md17_frames(4096, seed=11 + seed)
