@@ -105,12 +105,23 @@ def test_chunked_equals_unchunked():
     assert np.array_equal(Ec, E) and np.array_equal(Fc, F), (np.abs(E - Ec).max(), np.abs(F - Fc).max())
 
 
-def test_sharded_equals_unsharded():
+@pytest.mark.parametrize("node_block", ["by size", "always", "never"])
+def test_sharded_equals_unsharded(node_block, monkeypatch):
     """BASELINE config 5 in small: the batch cut by dist.shard_by_edges for 1/2/4/8 ranks, every shard evaluated on
     this one GPU, results concatenated in rank order == the unsharded evaluation BIT FOR BIT (no collective: ranks are
-    independent; no library GEMM left whose pick depends on the shard's row count)."""
+    independent; no library GEMM left whose pick depends on the shard's row count).
+
+    The fused node-block launches (round 4) and the chain of small kernels they replace round differently, and
+    `xeq_node_block_auto` chooses between them by the node count of an evaluation: the bits are those of the unsharded run as long
+    as every shard sits on the same side of that threshold ("by size": all below it here), or when the choice is pinned for the
+    job -- XEQ_NODE_BLOCK_MIN_NODES=0 ("always": every shard through the fused launches, which give a node the same sums in the
+    same order wherever it sits) or XEQ_NODE_BLOCK=0 ("never")."""
     from xequinet_amd import dist as xdist
 
+    if node_block == "always":
+        monkeypatch.setenv("XEQ_NODE_BLOCK_MIN_NODES", "0")
+    elif node_block == "never":
+        monkeypatch.setenv("XEQ_NODE_BLOCK", "0")
     model, _ = _build(torch.float32)
     pos, z, ptr = syn.synth_qm9_batch(256, seed=5)
     E, F, e_all, _ = _hip_eval(model, pos, z, ptr)
@@ -123,7 +134,7 @@ def test_sharded_equals_unsharded():
             edges += ne
         Es, Fs = np.concatenate(Es), np.concatenate(Fs)
         assert edges == e_all and Es.shape == E.shape and Fs.shape == F.shape
-        parity_record.add(dict(config=f"qm9_256 sharded x{world} vs unsharded", max_abs_dE=float(np.abs(E - Es).max()),
+        parity_record.add(dict(config=f"qm9_256 sharded x{world} vs unsharded (node block {node_block})", max_abs_dE=float(np.abs(E - Es).max()),
                                max_abs_dF=float(np.abs(F - Fs).max()), bitwise=bool(np.array_equal(E, Es) and np.array_equal(F, Fs))))
         assert np.array_equal(Es, E) and np.array_equal(Fs, F), (world, np.abs(E - Es).max(), np.abs(F - Fs).max())
 
