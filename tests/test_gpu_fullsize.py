@@ -139,6 +139,36 @@ def test_sharded_equals_unsharded(node_block, monkeypatch):
         assert np.array_equal(Es, E) and np.array_equal(Fs, F), (world, np.abs(E - Es).max(), np.abs(F - Fs).max())
 
 
+def test_qm9_65536_on_one_gpu_in_chunks():
+    """BASELINE config 5 at FULL size on one GPU (what a single rank does with the whole 65 536-molecule batch: 1.18 M atoms, 19.6 M
+    edges, above the message kernels' 32-bit offsets, so runtime.evaluate_in_chunks walks it in three ranges).  The oracle cannot
+    finish this size, so the checks are the size-independent properties of the path: every number finite, the edge count of the
+    batch's own generator (the figure bench.py reports for the same seed), no net force on any molecule (translation invariance of
+    E(pos): sum_i F_i = 0 per graph), and the first molecules' results equal to those of the same molecules evaluated alone."""
+    from xequinet_amd.runtime import evaluate_in_chunks
+
+    model, _ = _build(torch.float32)
+    pos, z, ptr, _ = syn.make_workload("qm9_65536", seed=1234)
+    assert len(ptr) - 1 == 65536 and len(pos) == 1178952
+    out = evaluate_in_chunks(model, _t(pos, torch.float32), _t(z), _t(ptr), ptr_host=ptr)
+    E, F = out["energy"], out["forces"]
+    assert out["n_chunks"] >= 3 and out["n_edges"] == 19617584, (out["n_chunks"], out["n_edges"])
+    assert E.shape == (65536,) and F.shape == (len(pos), 3)
+    assert bool(torch.isfinite(E).all()) and bool(torch.isfinite(F).all())
+    graph = torch.repeat_interleave(torch.arange(65536, device=DEV), _t(np.diff(ptr)))
+    net = torch.zeros(65536, 3, device=DEV, dtype=torch.float64).index_add_(0, graph, F.double())
+    scale = float(F.abs().max())
+    parity_record.add(dict(config="qm9_65536 on one GPU in chunks (properties)", atoms=int(len(pos)), edges=int(out["n_edges"]), chunks=int(out["n_chunks"]),
+                           max_abs_net_force_per_molecule=float(net.abs().max()), max_abs_F=scale))
+    assert float(net.abs().max()) <= 2e-4 * max(1.0, scale), float(net.abs().max())
+    # the first 48 molecules alone (another batch, another kernel policy by size: fp32 agreement, not bits)
+    g = 48
+    a = int(ptr[g])
+    E1, F1, _, _ = _hip_eval(model, pos[:a], z[:a], ptr[: g + 1])
+    dE, dF = np.abs(E[:g].cpu().double().numpy() - E1), np.abs(F[:a].cpu().double().numpy() - F1)
+    assert np.all(dE <= E_RTOL * np.abs(E1) + E_ATOL) and dF.max() <= 2e-3, (dE.max(), dF.max())
+
+
 def test_water_512_whole_box_against_oracle():
     """BASELINE config 4 (periodic, ~51 neighbours per atom) at full size: the whole box through the fp64 oracle, on the
     edge list the HIP neighbour search produced (itself bit-exact against the reference's order on the golden boxes)."""
