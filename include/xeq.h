@@ -273,6 +273,26 @@ int xeq_load_padded_batch(int dtype, const void* pos, const int32_t* z, const in
 #define XEQ_COPY_MANY_MAX 16
 int xeq_copy_many(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);
 
+/* ALL instructions of a general Clebsch-Gordan e3nn.o3.TensorProduct in one launch (round 4; nn/tp.py:20-107 builds the instruction lists;
+ * nn/xe3net.py:133-146 'uuu' with shared weights, nn/output.py:411-421 'uuw' with one weight set per sample):
+ *   out[n, off_out + w (2 l3 + 1) + k] = sum_paths coeff_p sum_{u,v} W_p[..] sum_{i,j} cg_p[i,j,k] x1[n, off1 + u (2 l1 + 1) + i] x2[n, off2 + v (2 l2 + 1) + j]
+ * A workgroup stages the x1 / x2 rows of a tile of nodes and every 3j table in LDS; a thread owns an output element (a block of four w for
+ * 'uvw' / 'uuw', where the bilinear form is shared by all w) and walks the paths into its block in table order: one store per element, no
+ * read-modify-write, deterministic.  paths: n_paths x 10 ints (off1, off2, off_out, mul1, mul2, mul_out, l1, l2, l3, mode: 0 uvw, 1 uvu,
+ * 2 uvv, 3 uuw, 4 uuu, 5 uvuv), sorted by off_out, at most 40 paths into at most 16 blocks per launch; cg: the paths' real Wigner-3j tables
+ * one behind the other (device, dtype of x), cg_off[p] / cg_floats; w_off[p]: first weight of path p in `weight` (-1: unweighted), shared
+ * (weight_stride 0) or per sample; coeff[p] (host).  The reverse passes w.r.t. x1 / x2 are the same entry on (grad_out, x2) / (x1, grad_out)
+ * with permuted tables and the connection mode of the transposed contraction (xequinet_amd/tp.py::_REVERSE).
+ * xeq_tensor_product_wgrad: dL/dW of the weighted paths (same table; w_off increasing, w_numel[p] weights per path): shared = 1 writes
+ * parts [xeq_tensor_product_wgrad_chunks(n), w_total] (the caller adds the chunks in order), shared = 0 writes dW [n, w_total]. */
+int xeq_tensor_product(int dtype, const void* x1, const void* x2, int64_t n, int dim1, int dim2, int dim_out, int n_paths,
+                       const int32_t* paths, const void* cg, const int32_t* cg_off, int cg_floats, const void* weight, int64_t weight_stride,
+                       const int32_t* w_off, const double* coeff, void* out, void* stream);
+int64_t xeq_tensor_product_wgrad_chunks(int64_t n);
+int xeq_tensor_product_wgrad(int dtype, const void* x1, const void* x2, const void* g, int64_t n, int dim1, int dim2, int dim_out, int n_paths,
+                             const int32_t* paths, const void* cg, const int32_t* cg_off, const int32_t* w_off, const int32_t* w_numel, int w_total,
+                             const double* coeff, int shared, void* parts, void* stream);
+
 /* One instruction of a general Clebsch-Gordan e3nn.o3.TensorProduct (nn/tp.py:20-107 builds the instruction lists;
  * nn/xe3net.py:133-146 'uuu', nn/output.py:411-421 'uuw'):
  *   out[n, off_out + w (2 l3 + 1) + k] += coeff * sum_{u,v} W[..] sum_{i,j} cg[i,j,k] x1[n, off1 + u (2 l1 + 1) + i] x2[n, off2 + v (2 l2 + 1) + j]

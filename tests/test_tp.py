@@ -171,3 +171,46 @@ def test_tensor_product_outer_mode_is_forward_only():
     np.testing.assert_allclose(res.detach().cpu().numpy(), want.numpy(), atol=1e-12)
     with pytest.raises(NotImplementedError):
         res.sum().backward()
+
+
+def _reference_products(ch):
+    """The two general products the reference builds: SelfMixTP's 'uuu' product with shared internal weights (nn/xe3net.py:118-146)
+    and the Cartesian-tensor head's 'uuw' product with one weight set per sample (nn/output.py:411-421)."""
+    hid = tp.Irreps([(ch, (l, (-1) ** l)) for l in range(3)])
+    mix = [(ch, (0, 1))] + [(ch, (l, s)) for l in range(2, 4) for s in (-1, 1)] + [(ch, (4, 1))]
+    out, ins = tp.get_feasible_tp(hid, hid, tp.Irreps(mix), "uuu")
+    selfmix = tp.TensorProduct(hid, hid, out, ins, internal_weights=True, shared_weights=True)
+    out2, ins2 = tp.get_feasible_tp(out, out, tp.Irreps("1x0e+1x2e"), "uuw")
+    head = tp.TensorProduct(out, out, out2, ins2, internal_weights=False, shared_weights=False)
+    return selfmix, head
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["selfmix", "head", "uvv", "uvu", "uvw", "uuw"])
+def test_all_paths_in_one_launch_equal_one_launch_per_path(which):
+    """xeq_tensor_product (round 4: every path of a pass in one launch -- a thread per (node, u) for the tied modes, an element per
+    thread otherwise -- and a native weight gradient) against the round-2 form (xeq_tensor_product_path per instruction, weight
+    gradients through einsum) on the same module: output and all three gradients, including output blocks that several paths with
+    DIFFERENT multiplicities end in (the reverse pass of 'uvv')."""
+    torch.manual_seed(3)
+    n = 257
+    if which in ("selfmix", "head"):
+        mod = _reference_products(70)[0 if which == "selfmix" else 1]     # 70 channels: more than one lane round per node
+        mod = mod.double().cuda()
+        x = torch.randn(n, mod.irreps_in1.dim, dtype=torch.float64, device="cuda", requires_grad=True)
+        y = torch.randn(n, mod.irreps_in2.dim, dtype=torch.float64, device="cuda", requires_grad=True)
+        w = None if mod.internal_weights else torch.randn(n, mod.weight_numel, dtype=torch.float64, device="cuda", requires_grad=True)
+    else:
+        mod, in1, in2, out, ins, x, y, w, _ = _case(which, True, which != "uuw", n=n)
+        mod = mod.cuda()
+        x, y = x.cuda().requires_grad_(), y.cuda().requires_grad_()
+        w = None if mod.internal_weights else w.cuda().requires_grad_()
+    got = {}
+    for fused in (False, True):
+        mod.fused = fused
+        o = mod(x, y) if w is None else mod(x, y, w)
+        g = torch.cos(torch.arange(o.numel(), device="cuda", dtype=torch.float64)).reshape(o.shape)
+        got[fused] = [o.detach()] + list(torch.autograd.grad(o, [x, y] + ([w] if w is not None else [mod.weight]), g))
+    assert mod._fused_table("fwd", x) is not None
+    for name, a, b in zip(("out", "grad_x1", "grad_x2", "grad_w"), got[True], got[False]):
+        assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max())), name

@@ -72,6 +72,12 @@ _PROTOS = {
     "xeq_copy_many": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), _P],
     "xeq_tensor_product_path": [c_int, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, _P, _P, c_int64, c_double, _P, _P],
+    "xeq_tensor_product": [c_int, _P, _P, c_int64, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int32), _P, ctypes.POINTER(ctypes.c_int32),
+                           c_int, _P, c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_double), _P, _P],
+    "xeq_tensor_product_wgrad": [c_int, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int32), _P,
+                                 ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), c_int,
+                                 ctypes.POINTER(c_double), c_int, _P, _P],
+    "xeq_tensor_product_wgrad_chunks": [c_int64],
     "xeq_scatter_add": [c_int, _P, _P, c_int64, c_int64, _P, c_int64, _P],
     "xeq_message_fwd": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                         c_int, c_int, c_int, c_double, c_int, _I3, _P, _P, c_int, _P],
@@ -155,7 +161,7 @@ _PROTOS = {
 }
 # entry points that return a size, not a status
 _RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
-            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch"}
+            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch", "xeq_tensor_product_wgrad_chunks"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None
