@@ -324,6 +324,34 @@ class EmbeddingLinear(Function):
         return None, None, None, d_w, (d_b if ctx.has_bias else None)
 
 
+def first_block_front(module, z: torch.Tensor, rows: torch.Tensor, n: int):
+    """(h, xhat) of the model's FIRST message block from the element table: behind XEmbedding s = rows[Z] and x = 0, so LayerNorm,
+    EquivariantLayerNorm and scalar_mlp (nn/xpainn.py:128-139) are functions of the element alone.  They run on the table rows (once per
+    weight version: the same xeq_norm_fwd / xeq_mlp2_fwd launches, which give a row the same bits in any batch) and are gathered by atomic
+    number: two row gathers and one fill per evaluation instead of two node-sized launches.  xhat is in BT layout; its l > 0 blocks are the
+    equivariant norm of zero: zero.  None when the block is not the layout the table form covers."""
+    F, mul = module.node_dim, module._mul
+    D = sum(m * (2 * l + 1) for l, m in enumerate(mul))
+    if rows.dtype != torch.float32 or mul[0] != F or isinstance(module.norm, torch.nn.Identity):
+        return None
+    mlp = module.scalar_mlp
+    key = (rows.data_ptr(), rows._version, module.norm.weight._version, module.norm.bias._version, module.o3norm.affine_weight._version,
+           module.o3norm.affine_bias._version, mlp[0].weight._version, mlp[0].bias._version, mlp[2].weight._version, mlp[2].bias._version,
+           lib.pack_epoch())
+    cache = getattr(module, "_element_front", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            zt = rows.shape[0]
+            shat, xhat_t, _, _ = _norm_fwd(rows, torch.zeros((zt, D), dtype=rows.dtype, device=rows.device), module.norm, module.o3norm, F, mul)
+            _, h_t = _mlp_fwd(mlp, shat)
+            cache = module._element_front = (key, h_t, xhat_t[: zt * F].view(zt, F).contiguous())
+    _, h_t, xhat0_t = cache
+    h = h_t.index_select(0, z)
+    xhat = torch.zeros(n * D, dtype=rows.dtype, device=rows.device)
+    torch.index_select(xhat0_t, 0, z, out=xhat[: n * F].view(n, F))
+    return h, xhat
+
+
 class MessageBlock(Function):
     """XPainnMessage.forward (nn/xpainn.py:128-161): norms -> scalar_mlp -> fused message kernel."""
 

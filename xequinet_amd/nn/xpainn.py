@@ -8,7 +8,7 @@ never exist.
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable
+from typing import Dict, Iterable, Optional
 
 import torch
 import torch.nn as nn
@@ -34,6 +34,7 @@ ZERO_EQUIVARIANT = "_xeq_zero_equivariant"
 # front half of the message block behind it: (s, x, h, xhat) -- the block's outputs and the next block's scalar_mlp output and
 # normalised equivariant features (BT layout).  The message block consumes it when (s, x) are the tensors it is handed.
 PRESTAGE = "_xeq_message_prestage"
+ELEMENT_ROWS = "_xeq_element_rows"   # (atomic numbers, embedding of every table row, the gathered node features): see XEmbedding.forward
 
 
 class XEmbedding(nn.Module):
@@ -84,6 +85,29 @@ class XEmbedding(nn.Module):
             return _linear(table, pack, lin.weight.shape[1], lin.weight.shape[0], lin.bias is not None, row_index=z)[0]
         return self.embedding(atomic_numbers)
 
+    def _embedded_rows(self, atomic_numbers: torch.Tensor) -> Optional[torch.Tensor]:
+        """Linear(table) for EVERY row of the element table [Z_max + 1, node_dim], cached per weight version, or None where the
+        per-node launch is the only form (training pass, nn.Embedding tables, CPU tensors)."""
+        if isinstance(self.embedding, nn.Embedding) or not atomic_numbers.is_cuda:
+            return None
+        from .fused import _linear, _linear_pack
+
+        table, lin = self.embedding[0].embed_ten, self.embedding[1]
+        if table.dtype != torch.float32 or table.stride(0) % 4 != 0:
+            return None
+        key = (lin.weight._version, None if lin.bias is None else lin.bias._version, table._version, table.data_ptr(), lin.weight.data_ptr(),
+               ops.lib.pack_epoch())
+        cache = getattr(self, "_rows_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        pack = _linear_pack(lin, lin.weight, lin.bias, False)
+        if pack is None:
+            return None
+        with torch.no_grad():
+            rows = _linear(table, pack, lin.weight.shape[1], lin.weight.shape[0], lin.bias is not None)[0]
+        self._rows_cache = (key, rows)
+        return rows
+
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         if training.active(self, data):   # parameter gradients / double backward: the differentiable form
             return training.embedding(self, data)
@@ -91,7 +115,17 @@ class XEmbedding(nn.Module):
         vectors = data[keys.EDGE_VECTOR]
         ops.lib.require_hip(vectors)
 
-        node_invariant = self._embed(atomic_numbers, bool(data.get(training.PARAM_GRADS, False)))
+        rows = None if data.get(training.PARAM_GRADS, False) else self._embedded_rows(atomic_numbers)
+        if rows is not None:
+            # Behind the embedding a node's features are a function of its ELEMENT alone (nn/xpainn.py:62, 76-81: s = Linear(table[Z]),
+            # x = 0), and so are the norms and scalar_mlp of the first message block: they are evaluated once per table row (cached per
+            # weight version) and gathered by atomic number, here and in the first XPainnMessage (nn/fused.py::first_block_front).
+            # The kernels give a row the same bits in any batch, so the results are those of the per-node launches.
+            z = atomic_numbers.long()
+            node_invariant = rows.index_select(0, z)
+            data[ELEMENT_ROWS] = (z, rows, node_invariant)
+        else:
+            node_invariant = self._embed(atomic_numbers, bool(data.get(training.PARAM_GRADS, False)))
         data[keys.NODE_INVARIANT] = node_invariant
         data[RADIAL_SPEC] = (self.rbf, self.cutoff_fn)
 
@@ -158,10 +192,18 @@ class XPainnMessage(nn.Module):
         if rbf.num_basis != self.num_basis:
             raise ValueError(f"num_basis mismatch: embedding {rbf.num_basis} vs message {self.num_basis}")
         pre = data.pop(PRESTAGE, None)
+        elem = data.pop(ELEMENT_ROWS, None)
+        if (self.fused and pre is None and elem is not None and x_is_zero and elem[2] is ori_scalar and not data.get(training.PARAM_GRADS, False)
+                and not ori_scalar.requires_grad and not ori_equi.requires_grad):
+            from .fused import first_block_front
+
+            front = first_block_front(self, elem[0], elem[1], ori_scalar.shape[0])
+            if front is not None:   # norms and scalar_mlp of the first block from the element table: the message kernel alone is left
+                pre = (ori_scalar, ori_equi, front[0], front[1], ops.lib.XHAT_HIGHER_L_ZERO)
         if self.fused and pre is not None and pre[0] is ori_scalar and pre[1] is ori_equi and not data.get(training.PARAM_GRADS, False):
             # norms and scalar_mlp came out of the update block's launch: the message kernel alone is left (nn/fused.py::NodeBlock)
             p0, p1 = rbf.params()
-            cfg = (rbf.kind, cutoff_fn.kind, self.num_basis, float(cutoff_fn.cutoff), self.node_dim, self._mul, 1)
+            cfg = (rbf.kind, cutoff_fn.kind, self.num_basis, float(cutoff_fn.cutoff), self.node_dim, self._mul, 1 | (pre[4] if len(pre) > 4 else 0))
             new_scalar, new_equi = ops.FusedMessage.apply(pre[2], pre[3], data[keys.EDGE_VECTOR], ori_scalar, ori_equi,
                                                           self.rbf_lin.weight, self.rbf_lin.bias, p0, p1, edge_graph(data), cfg)
         elif self.fused:  # block-level path: explicit forward/reverse, see nn/fused.py

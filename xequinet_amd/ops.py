@@ -943,7 +943,10 @@ class FusedMessage(Function):
     @once_differentiable
     def backward(ctx, g_s, g_x):
         saved = ctx.saved_tensors
-        g_h, g_xhat, g_vec, g_s, g_x = message_backward(saved, ctx.graph, ctx.cfg, ctx.impl, g_s, g_x)
+        # no node input asks for a gradient: the model's first block in a force evaluation (its node features do not depend on the
+        # positions, nn/xpainn.py first-block table) -- only dL/dvec is formed
+        node_grads = any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
+        g_h, g_xhat, g_vec, g_s, g_x = message_backward(saved, ctx.graph, ctx.cfg, ctx.impl, g_s, g_x, node_grads=node_grads)
         d_w = d_b = d_p0 = d_p1 = None
         if any(ctx.needs_input_grad[5:9]):   # first order only: a loss on forces differentiates the reverse pass itself (nn/training.py)
             d_w, d_b, d_p0, d_p1 = message_param_grad(saved, ctx.graph, ctx.cfg, g_s, g_x)
