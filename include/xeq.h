@@ -470,7 +470,7 @@ int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul
  *     ranges, walked together by the waves of a workgroup: first gathered node and row count of the window that
  *     holds every node the step gathers from).  workspace: xeq_message_wq_plan_workspace(N) bytes.
  *     Depends on the graph only, not on the positions.
- *   xeq_edge_basis_wq: per-edge records IN PADDED WALK ORDER, basis / dbasis [P, xeq_message_wq_record_floats()] floats
+ *   xeq_edge_basis_wq: per-edge records IN PADDED WALK ORDER, basis / dbasis [P, xeq_message_wq_record_floats_for(num_basis)] floats
  *     ([12 even k | 12 odd k | Y1[3] Y2[5]], value and d/dd; dbasis may be NULL), once per evaluation and direction.
  *   xeq_message_fwd_wq / _bwd_wq: as the _wm entries.  A workgroup walks a chunk of steps; per step it stages the window's
  *     rows (the unit's columns of h and xhat, or of grad_x and grad_s) in LDS with 16-byte loads when they fit 48 KB --
@@ -483,6 +483,7 @@ int xeq_message_wq_supported(int num_basis, int node_dim, const int32_t mul[3]);
 int xeq_message_wq_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]);   /* 1 / 0 */
 int64_t xeq_message_wq_pcap(int64_t n_nodes, int64_t n_edges);                      /* a size, not a status */
 int xeq_message_wq_waves(void);
+int xeq_message_wq_record_floats_for(int num_basis);   /* floats per padded slot of a record buffer: 40 up to 23 basis functions, 48 up to 31 */
 int xeq_message_wq_record_floats(void);   /* floats per padded slot of a record buffer (basis / dbasis of xeq_edge_basis_wq) */   /* ranges per step (= waves per workgroup): win holds 2 ceil(n_ranges / that) entries */
 int64_t xeq_message_wq_plan_workspace(int64_t n_nodes);                             /* bytes, -1 on failure */
 int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_t* owner, const int64_t* gather,

@@ -573,9 +573,7 @@ WM_CASES = [
 def test_fused_message_matrix_core_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff_kind, shuffle, eps, impl, monkeypatch):
     """The wave / matrix-core kernels (xeq_message_{fwd,bwd}_wm, f32) against the fp64 oracle: every output of the
     forward pass and every gradient of the reverse pass, ragged molecules (3..29 atoms), shuffled edges, K = B + 1
-    from 9 to 32 (wq: up to 24), and stream lengths from one tile per stream to one wave for the whole batch."""
-    if impl == "wq" and B > 23:
-        pytest.skip("the wave / quad form takes num_basis <= 23")
+    from 9 to 32, and stream lengths from one tile per stream to one wave for the whole batch."""
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", impl)
     monkeypatch.setenv("XEQ_WM_EDGES_PER_STREAM", eps)
     got, want = _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, torch.float32, shuffle, n_mol=40)

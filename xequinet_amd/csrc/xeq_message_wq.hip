@@ -47,9 +47,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // bits, exact): six products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid of v_mfma_f32_32x32x16_bf16 (32 cycles each, f32
 // accumulate) leave out mid lo, lo mid, lo lo = 2^-24 of a product, the size of one f32 rounding; the remaining k (16 .. B - 1)
 // and the bias column stay exact-f32 steps.  K = 21: 6 x 32 + 3 x 64 = 384 pipe cycles instead of 704.
-constexpr int WQ_REC = 40;                 // dwords per record (160 B): [kh][hi | mid | lo][4] bf16 packs of k = 8 kh .. 8 kh + 7,
-                                           // [kh][4] f32 tail (q = 2 s + kh -> k = 16 + q, then the envelope for the bias), Y1[3] Y2[5]
-constexpr int WQ_TAIL = 24, WQ_Y = 32;     // dword offsets of the f32 tail and of Y inside a record
+// dwords per record: [kh][hi | mid | lo][4] bf16 packs of k = 8 kh .. 8 kh + 7 (24), [kh][TW] f32 tail (q = 2 s + kh -> k = 16 + q, then the
+// envelope for the bias; TW = 4 tail values per k half up to 23 basis functions (KS <= 4 exact-f32 steps), 8 up to 31 (KS = 8)), Y1[3] Y2[5]:
+// 40 dwords (160 B) or 48 (192 B)
+constexpr int WQ_TAIL = 24;                // dword offset of the f32 tail inside a record
+constexpr int wq_tailw(int ks) { return ks <= 4 ? 4 : 8; }
+constexpr int wq_recf(int ks) { return WQ_TAIL + 2 * wq_tailw(ks) + 8; }
+constexpr int wq_yoff(int ks) { return WQ_TAIL + 2 * wq_tailw(ks); }
+constexpr int wq_ks(int num_basis) { return ((num_basis > 16 ? num_basis - 16 : 0) + 2) / 2; }   // exact-f32 steps of the tail (+ the bias column), two per step
+constexpr int WQ_REC_MAX = 48;
 __device__ __forceinline__ uint32_t wq_bf16_rne(float x) {
   const uint32_t u = __float_as_uint(x);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
@@ -177,14 +183,15 @@ __global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __re
 __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
                              const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
                              const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
-                             float* __restrict__ drec) {
+                             float* __restrict__ drec, int recf, int tailw) {
+  const int yoff = WQ_TAIL + 2 * tailw;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t p = t / 6;
   if (p >= pcap || p >= 4 * (int64_t)qptr[N]) return;
   const int grp = (int)(t - 6 * p);   // 0-1: bf16 packs of k half kh = grp; 2-3: f32 tail of kh = grp - 2; 4-5: Y
   const int32_t e = peid[p];
-  float* __restrict__ out = rec + p * WQ_REC;
-  float* __restrict__ dout = drec ? drec + p * WQ_REC : nullptr;
+  float* __restrict__ out = rec + p * recf;
+  float* __restrict__ dout = drec ? drec + p * recf : nullptr;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   if (e < 0) {   // padding slot: an all-zero record (its filter is exactly 0)
     if (grp < 2) {
@@ -193,10 +200,14 @@ __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __res
         *reinterpret_cast<f32x4*>(out + 12 * grp + 4 * c) = zero;
         if (dout) *reinterpret_cast<f32x4*>(dout + 12 * grp + 4 * c) = zero;
       }
+    } else if (grp < 4) {
+      for (int c = 0; c < tailw; c += 4) {
+        *reinterpret_cast<f32x4*>(out + WQ_TAIL + tailw * (grp - 2) + c) = zero;
+        if (dout) *reinterpret_cast<f32x4*>(dout + WQ_TAIL + tailw * (grp - 2) + c) = zero;
+      }
     } else {
-      const int off = grp < 4 ? WQ_TAIL + 4 * (grp - 2) : WQ_Y + 4 * (grp - 4);
-      *reinterpret_cast<f32x4*>(out + off) = zero;
-      if (dout) *reinterpret_cast<f32x4*>(dout + off) = zero;
+      *reinterpret_cast<f32x4*>(out + yoff + 4 * (grp - 4)) = zero;
+      if (dout) *reinterpret_cast<f32x4*>(dout + yoff + 4 * (grp - 4)) = zero;
     }
     return;
   }
@@ -207,8 +218,8 @@ __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __res
     float y1[3], y2[5];
     sph_harm_l12<float>(g, y1, y2);
     const f32x4 v = grp == 4 ? f32x4{y1[0], y1[1], y1[2], y2[0]} : f32x4{y2[1], y2[2], y2[3], y2[4]};
-    *reinterpret_cast<f32x4*>(out + WQ_Y + 4 * (grp - 4)) = v;
-    if (dout) *reinterpret_cast<f32x4*>(dout + WQ_Y + 4 * (grp - 4)) = v;   // the reverse kernel reads Y next to the derivatives (one record
+    *reinterpret_cast<f32x4*>(out + yoff + 4 * (grp - 4)) = v;
+    if (dout) *reinterpret_cast<f32x4*>(dout + yoff + 4 * (grp - 4)) = v;   // the reverse kernel reads Y next to the derivatives (one record
     return;                                                                  // stream less per row load; measured: no change in traffic or
                                                                              // time -- the l > 0 units need the value record anyway, for the
                                                                              // gate_edge filter in dL/dY)
@@ -253,16 +264,18 @@ __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __res
     }
   } else {
     const int kh = grp - 2;
-    f32x4 v, dv;
+    for (int c0 = 0; c0 < tailw; c0 += 4) {   // tail value s of this k half: position q = 2 s + kh
+      f32x4 v, dv;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float val, dval;
-      value(wq_tail_k(2 * c + kh, B), val, dval);
-      v[c] = val;
-      dv[c] = dval;
+      for (int c = 0; c < 4; ++c) {
+        float val, dval;
+        value(wq_tail_k(2 * (c0 + c) + kh, B), val, dval);
+        v[c] = val;
+        dv[c] = dval;
+      }
+      *reinterpret_cast<f32x4*>(out + WQ_TAIL + tailw * kh + c0) = v;
+      if (dout) *reinterpret_cast<f32x4*>(dout + WQ_TAIL + tailw * kh + c0) = dv;
     }
-    *reinterpret_cast<f32x4*>(out + WQ_TAIL + 4 * kh) = v;
-    if (dout) *reinterpret_cast<f32x4*>(dout + WQ_TAIL + 4 * kh) = dv;
   }
 }
 
@@ -438,15 +451,20 @@ struct WqStreams {
 template <int KS>
 __device__ __forceinline__ void wq_load_rec(const float* __restrict__ rec, uint32_t ps, int kh, bool valid, WqR<KS>& R) {
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + 12 * kh);
+  const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * wq_recf(KS) + 12 * kh);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const f32x4 x = rp[c];
     R.b[c] = valid ? x : zero;
   }
-  const f32x4 tl = *reinterpret_cast<const f32x4*>(rec + (size_t)ps * WQ_REC + WQ_TAIL + 4 * kh);
+  const f32x4* __restrict__ tp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * wq_recf(KS) + WQ_TAIL + wq_tailw(KS) * kh);
 #pragma unroll
-  for (int s = 0; s < KS; ++s) R.f[s] = valid ? tl[s] : 0.f;
+  for (int c = 0; c < wq_tailw(KS) / 4; ++c) {
+    const f32x4 tl = tp[c];
+#pragma unroll
+    for (int s = 4 * c; s < 4 * c + 4; ++s)
+      if (s < KS) R.f[s] = valid ? tl[s - 4 * c] : 0.f;
+  }
 }
 template <int KS, int NREC, bool WITH_Y>
 __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int lane, int t, const float* __restrict__ rec,
@@ -466,7 +484,7 @@ __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int
   if constexpr (NREC > 1) wq_load_rec<KS>(drec, ps, kh, valid, w.R[1]);
   if constexpr (WITH_Y) {
     const float* __restrict__ ysrc = NREC > 1 ? drec : rec;   // (both records carry Y)
-    const f32x4* __restrict__ yp = reinterpret_cast<const f32x4*>(ysrc + (size_t)ps * WQ_REC + WQ_Y);
+    const f32x4* __restrict__ yp = reinterpret_cast<const f32x4*>(ysrc + (size_t)ps * wq_recf(KS) + wq_yoff(KS));
     w.ya = yp[0];
     w.yb = yp[1];
     if (a.mirror) {   // the mirror edge's vector is the negative of the slot's: d and Y_2 are the same bits, Y_1 changes sign
@@ -1362,7 +1380,7 @@ __global__ void k_wq_edge_grad(const float* __restrict__ vec, const int32_t* __r
 
 #endif
 static bool wq_supported(int num_basis, int node_dim, const int32_t mul[3]) {
-  return num_basis >= 1 && num_basis <= 23 && mul[0] == node_dim && mul[0] > 0 && mul[0] % 32 == 0 && mul[1] >= 0 &&
+  return num_basis >= 1 && num_basis <= 31 && mul[0] == node_dim && mul[0] > 0 && mul[0] % 32 == 0 && mul[1] >= 0 &&
          mul[1] % 32 == 0 && mul[2] >= 0 && mul[2] % 32 == 0;
 }
 // padded slots: at most deg + 3 per node that has an edge, four per node that has none; the capacity every buffer of a plan is sized for
@@ -1370,7 +1388,7 @@ static int64_t wq_pcap(int64_t n_nodes, int64_t n_edges) { return (n_edges + 4 *
 // 32-bit byte offsets: rows of h (n_nodes * H * 4) and records (pcap * 128)
 static bool wq_fits(int64_t n_nodes, int64_t n_edges, int node_dim, const int32_t mul[3]) {
   const int64_t H = node_dim + 2 * (int64_t)(mul[0] + mul[1] + mul[2]);
-  return n_nodes >= 0 && n_edges >= 0 && n_nodes * H * 4 < (1ll << 32) && wq_pcap(n_nodes, n_edges) * (int64_t)WQ_REC * 4 < (1ll << 32);
+  return n_nodes >= 0 && n_edges >= 0 && n_nodes * H * 4 < (1ll << 32) && wq_pcap(n_nodes, n_edges) * (int64_t)WQ_REC_MAX * 4 < (1ll << 32);
 }
 
 static int wq_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ranges, int num_basis, int node_dim,
@@ -1442,10 +1460,11 @@ using namespace xeq;
 // KS: exact-f32 steps of the filter's tail -- the basis functions from k = 16 on and the bias column, two per step
 #define XEQ_WQ_DISPATCH_KS(KERNEL, FLAG, ...)                                                                                \
   do {                                                                                                                       \
-    const int ks = ((num_basis > 16 ? num_basis - 16 : 0) + 2) / 2;                                                          \
+    const int ks = wq_ks(num_basis);                                                                                         \
     if (ks <= 1) hipLaunchKernelGGL((KERNEL<1, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);      \
     else if (ks <= 3) hipLaunchKernelGGL((KERNEL<3, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<4, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);              \
+    else if (ks <= 4) hipLaunchKernelGGL((KERNEL<4, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<8, FLAG>), grid, dim3(64 * WQ_WAVES), 0, (hipStream_t)stream, __VA_ARGS__);              \
   } while (0)
 #define XEQ_WQ_DISPATCH(KERNEL, flag, ...)                   \
   do {                                                       \
@@ -1466,7 +1485,8 @@ int64_t xeq_message_wq_pcap(int64_t n_nodes, int64_t n_edges) { return wq_pcap(n
 
 int xeq_message_wq_waves(void) { return WQ_WAVES; }
 
-int xeq_message_wq_record_floats(void) { return WQ_REC; }
+int xeq_message_wq_record_floats(void) { return wq_recf(4); }   /* up to 23 basis functions */
+int xeq_message_wq_record_floats_for(int num_basis) { return wq_recf(wq_ks(num_basis)); }
 
 int64_t xeq_message_wq_plan_workspace(int64_t n_nodes) {
   size_t temp = 0;
@@ -1511,16 +1531,17 @@ int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_
 int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
                       int rbf_kind, int cutoff_kind, int num_basis, double cutoff, const void* p0, const void* p1,
                       void* basis, void* dbasis, void* stream) {
-  XEQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 0 && num_basis >= 1 && num_basis <= 23 && cutoff > 0, "xeq_edge_basis_wq: bad sizes");
+  XEQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 0 && num_basis >= 1 && num_basis <= 31 && cutoff > 0, "xeq_edge_basis_wq: bad sizes");
   XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_edge_basis_wq: rbf kernel %d is not implemented", rbf_kind);
   XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
   if (n_edges == 0 && n_nodes == 0) return XEQ_OK;   // (no edge at all: the nodes' lone quads still need their zero records)
   const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * 6;   // six threads per record
-  XEQ_CHECK_ARG(pcap * WQ_REC < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
+  const int ks = wq_ks(num_basis);
+  XEQ_CHECK_ARG(pcap * wq_recf(ks) < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
   hipLaunchKernelGGL(k_wq_records, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
-                     peid, qptr, n_nodes, pcap, rs, (const float*)p0, (const float*)p1, (float*)basis, (float*)dbasis);
+                     peid, qptr, n_nodes, pcap, rs, (const float*)p0, (const float*)p1, (float*)basis, (float*)dbasis, wq_recf(ks), wq_tailw(ks));
   XEQ_CHECK_LAUNCH("xeq_edge_basis_wq");
   return XEQ_OK;
 }

@@ -550,9 +550,9 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   else TORCH_CHECK(false, "xeq::xpainn_eval: this configuration / size needs the generic message kernels: use the Python modules");
   if (impl == 0) {
     build_wq_plan(g, false, g.fwd);
-    g.fwd.basis = at::empty({g.fwd.pcap, xeq_message_wq_record_floats()}, fopt);
+    g.fwd.basis = at::empty({g.fwd.pcap, xeq_message_wq_record_floats_for(hy.B)}, fopt);
     // a reverse pass over the same plan (mirror walk) follows: its derivative records come out of the same launch (ops.message_forward)
-    if (g.mirror && (compute_forces || compute_virial)) g.fwd.dbasis = at::empty({g.fwd.pcap, xeq_message_wq_record_floats()}, fopt);
+    if (g.mirror && (compute_forces || compute_virial)) g.fwd.dbasis = at::empty({g.fwd.pcap, xeq_message_wq_record_floats_for(hy.B)}, fopt);
     XCALL(xeq_edge_basis_wq(vec.data_ptr(), N, E, (const int32_t*)g.fwd.qptr.data_ptr(), (const int32_t*)g.fwd.peid.data_ptr(),
                             hy.rbf_kind, hy.cutoff_kind, hy.B, hy.cutoff, p0.data_ptr(), OP(p1), g.fwd.basis.data_ptr(),
                             g.fwd.dbasis.defined() ? g.fwd.dbasis.data_ptr() : nullptr, st));
@@ -699,8 +699,8 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
     Tensor g_vec_total;
     if (impl == 0 && !g.mirror) {
       build_wq_plan(g, true, g.rev);
-      g.rev.basis = at::empty({g.rev.pcap, xeq_message_wq_record_floats()}, fopt);
-      g.rev.dbasis = at::empty({g.rev.pcap, xeq_message_wq_record_floats()}, fopt);
+      g.rev.basis = at::empty({g.rev.pcap, xeq_message_wq_record_floats_for(hy.B)}, fopt);
+      g.rev.dbasis = at::empty({g.rev.pcap, xeq_message_wq_record_floats_for(hy.B)}, fopt);
       XCALL(xeq_edge_basis_wq(vec.data_ptr(), N, E, (const int32_t*)g.rev.qptr.data_ptr(), (const int32_t*)g.rev.peid.data_ptr(),
                               hy.rbf_kind, hy.cutoff_kind, hy.B, hy.cutoff, p0.data_ptr(), OP(p1), g.rev.basis.data_ptr(),
                               g.rev.dbasis.data_ptr(), st));

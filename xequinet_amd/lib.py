@@ -117,6 +117,7 @@ _PROTOS = {
     "xeq_message_wq_pcap": [c_int64, c_int64],
     "xeq_message_wq_waves": [],
     "xeq_message_wq_record_floats": [],
+    "xeq_message_wq_record_floats_for": [c_int],
     "xeq_message_wq_plan_workspace": [c_int64],
     "xeq_message_wq_plan": [_P, _P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P],
     "xeq_edge_basis_wq": [_P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],

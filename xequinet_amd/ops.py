@@ -742,7 +742,7 @@ def edge_basis_wq(vec, plan, n_nodes, rbf_kind, cutoff_kind, num_basis, cutoff, 
     if _basis_cache_hit(cached, vec, key) and (cached[3] is not None or not deriv):   # records with derivatives serve both requests
         return cached[2], cached[3]
     E = vec.shape[0]
-    width = int(lib.load().xeq_message_wq_record_floats())
+    width = int(lib.load().xeq_message_wq_record_floats_for(int(num_basis)))
     basis = torch.empty((plan["pcap"], width), dtype=vec.dtype, device=vec.device)
     dbasis = torch.empty((plan["pcap"], width), dtype=vec.dtype, device=vec.device) if deriv else None
     call("xeq_edge_basis_wq", ptr(vec), n_nodes, E, ptr(plan["qptr"]), ptr(plan["peid"]), lib.RBF_KINDS[rbf_kind],
