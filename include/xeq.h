@@ -307,7 +307,7 @@ int xeq_tensor_product_path(int dtype, const void* x1, const void* x2, int64_t n
 /* ------------------------------------------------------------ fused message */
 
 /* GENERIC form (64-bit offsets, f32 / f64, up to 256 channels per kind): the fallback for sizes and layouts the
- * _wm and _sb forms below do not take.
+ * _wq and _sb forms below do not take.
  * XPainnMessage.forward lines nn/xpainn.py:140-159 in one pass over
  * destination-sorted edges (K5-K7, K11-K16 of SURVEY 2.2):
  *   filter = (rbf(d) W^T + b) * fcut(d)                       :140
@@ -387,7 +387,6 @@ int xeq_to_bt(const void* x, int64_t n_nodes, const int32_t mul[3], void* out, v
  * stream length of a wq walk plan (n_ranges = ceil(E / (2 x edges_per_stream))). */
 #define XEQ_FAMILY_WQ 0
 #define XEQ_FAMILY_SB 1
-#define XEQ_FAMILY_WM 2
 #define XEQ_FAMILY_GENERIC 3
 int xeq_message_auto_family(int dtype, int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]);
 int xeq_message_wq_edges_per_stream(int64_t n_nodes, int64_t n_edges);
@@ -414,50 +413,11 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
                        int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec,
                        int xhat_layout, void* stream);
 
-/* "Wave / matrix-core" form of the fused message (f32; the default whenever the channel layout allows it).
- * The filter (rbf_lin, nn/xpainn.py:117,140: [2C+F, B+1] x [B+1] per edge) runs on the matrix cores as exact-f32
- * MFMA with the channel on the lane and 16 consecutive edges in the 16 accumulator registers; each half-wave
- * is a STREAM over a contiguous range of CSR segments, so the aggregation (index_add, nn/xpainn.py:158-159) is a
- * running sum in registers that is stored once per node: deterministic, no atomics, no read-modify-write.
- * A wave owns (node range, 32 gate channels of one l).  Requires node_dim == mul[0], mul[l] % 32 == 0,
- * num_basis <= 31 (xeq_message_wm_supported; otherwise XEQ_ERR_UNSUPPORTED: use the _sb form).
- *   basis/dbasis[E, W], W = xeq_edge_basis_wm_width(B): per-edge records (value / d-by-dd), once per evaluation.
- *   stream_ptr[2 n_ranges + 1]: node boundaries of the streams (non-decreasing, first 0, last N; every node in
- *   exactly one stream); range w is processed by one wave per unit, stream 2w by its lanes 0-31 and stream 2w+1 by
- *   lanes 32-63.  xeq_message_wm_streams cuts them on equal edge counts from the CSR row pointer of the walk order
- *   (about 128 edges per stream: n_ranges = ceil(E / 256)).
- *   forward walks the edges sorted by center (c_rowptr[N+1]; c_perm[E] = edge id per slot of that order, NULL when
- *   edge_index is already center-sorted); the reverse pass walks them sorted by neighbor (n_rowptr, n_perm) and writes
- *   per-unit partials of dL/dd and dL/dY_lm into parts[xeq_message_wm_parts_floats(E, mul)], indexed by the SLOT of
- *   that order (16 consecutive rows of a tile are one 64-byte store); xeq_message_wm_edge_grad, given the same n_perm,
- *   sums them in fixed unit order into grad_vec[E,3] at the edge's own position.  center / nbr = edge_index rows 0 / 1.
- *   Nodes without edges keep s_in / x_in (forward) and get zero gradients (reverse). */
-int xeq_message_wm_supported(int num_basis, int node_dim, const int32_t mul[3]);   /* 1 / 0, not a status */
-/* 1 when the configuration is supported AND n_nodes / n_edges fit the kernels' 32-bit byte offsets
- * (n_nodes (F + 2C) 4 < 2^32, n_edges 288 < 2^32); a caller picks the _sb or the generic form otherwise */
-int xeq_message_wm_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]);
-int xeq_edge_basis_wm_width(int num_basis);
-int xeq_edge_basis_wm(const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis, double cutoff,
-                      const void* p0, const void* p1, void* basis, void* dbasis, void* stream);
-int xeq_message_wm_streams(const int32_t* rowptr, int64_t n_nodes, int64_t n_edges, int n_ranges, int32_t* stream_ptr,
-                           void* stream);
-int xeq_message_fwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* stream_ptr, const int32_t* c_rowptr,
-                       const int32_t* c_perm, const int64_t* center, const int64_t* nbr, const void* basis,
-                       const void* h, const void* xhat, const void* s_in, const void* x_in, const void* w_rbf,
-                       const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* s_out, void* x_out,
-                       int xhat_layout, void* stream);
-int xeq_message_bwd_wm(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* stream_ptr, const int32_t* n_rowptr,
-                       const int32_t* n_perm, const int64_t* center, const int64_t* nbr, const void* basis,
-                       const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,
-                       const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* grad_h,
-                       void* grad_xhat, void* parts, int xhat_layout, void* stream);
-int64_t xeq_message_wm_parts_floats(int64_t n_edges, const int32_t mul[3]);   /* a size, not a status */
-int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul[3], const void* parts, const int32_t* n_perm,
-                             void* grad_vec, void* stream);
-
-/* "Wave / quad" form of the fused message (f32; the default whenever the channel layout allows it, num_basis <= 23).
- * Same arithmetic mapping as the _wm form above (exact-f32 MFMA filter with the channel on the lane, two half-wave
- * streams per wave, running sums in registers stored once per node: nn/xpainn.py:140-159 and its reverse pass), on a
+/* "Wave / quad" form of the fused message (f32; the default whenever the channel layout allows it: node_dim == mul[0], mul[l] % 32 == 0,
+ * num_basis <= 31).  The filter (rbf_lin, nn/xpainn.py:117,140: [2C+F, B+1] x [B+1] per edge) runs on the matrix cores with the channel
+ * on the lane (the first sixteen basis functions as split-bf16 products, the rest and the bias column as exact-f32 steps); each half-wave
+ * is a STREAM over a contiguous range of CSR segments, so the aggregation (index_add, nn/xpainn.py:158-159) is a running sum in registers
+ * that is stored once per node: deterministic, no atomics, no read-modify-write (nn/xpainn.py:140-159 and its reverse pass), on a
  * PADDED walk order: every node's edge list is padded to a multiple of four slots (a "quad" = the four accumulator
  * registers 4g..4g+3 of a lane; padding slots carry an all-zero record), so a quad belongs to one node and the segment
  * logic (reset / residual / the node's only store) runs once per quad instead of once per row.
@@ -472,7 +432,7 @@ int xeq_message_wm_edge_grad(const void* vec, int64_t n_edges, const int32_t mul
  *     Depends on the graph only, not on the positions.
  *   xeq_edge_basis_wq: per-edge records IN PADDED WALK ORDER, basis / dbasis [P, xeq_message_wq_record_floats_for(num_basis)] floats
  *     ([12 even k | 12 odd k | Y1[3] Y2[5]], value and d/dd; dbasis may be NULL), once per evaluation and direction.
- *   xeq_message_fwd_wq / _bwd_wq: as the _wm entries.  A workgroup walks a chunk of steps; per step it stages the window's
+ *   xeq_message_fwd_wq / _bwd_wq: one launch per message block and direction.  A workgroup walks a chunk of steps; per step it stages the window's
  *     rows (the unit's columns of h and xhat, or of grad_x and grad_s) in LDS with 16-byte loads when they fit 48 KB --
  *     batches of molecules: a few molecules -- and the per-row gathers become LDS reads; a step whose window does not fit
  *     (periodic systems, large graphs) gathers from global memory. rowptr is the CSR of the walk order (nodes without edges keep

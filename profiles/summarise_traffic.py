@@ -40,7 +40,6 @@ print(open(out_csv).read()[:3000])
 
 # kernel symbol -> C-ABI entry point names used by bench.py's KERNEL_TIMER
 alias = {"k_message_fwd_sb": "xeq_message_fwd_sb", "k_message_bwd_sb": "xeq_message_bwd_sb",
-         "k_message_fwd_wm": "xeq_message_fwd_wm", "k_message_bwd_wm": "xeq_message_bwd_wm",
          "k_message_fwd_wq": "xeq_message_fwd_wq", "k_message_bwd_wq": "xeq_message_bwd_wq"}
 traffic = {}
 for k, n, f, wr in rows:

@@ -26,7 +26,7 @@ gs = torch.randn(N, F_, device=dev); gx = torch.randn(N, D, device=dev)
 cfg = ("bessel", "cosine", B, 5.0, F_, mul)
 def run(impl):
     os.environ["XEQ_MESSAGE_IMPL"] = impl
-    g._basis = g._basis_wm = None
+    g._basis = None
     for p in (g._wq or {}).values(): p["records"] = None
     hh, xx, vv = h.clone().requires_grad_(), xhat.clone().requires_grad_(), vec.clone().requires_grad_()
     so, xo = ops.FusedMessage.apply(hh, xx, vv, s, x, W, bias, p0, None, g, cfg)

@@ -493,7 +493,7 @@ def _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, dtype, shuffle, se
     hg, xg, vg, sg, xig = (dev(t).requires_grad_() for t in (h, xhat, vec, s, x))
     Wg, bg, p0g = (dev(t).requires_grad_() for t in (W, b, p0))
     p1g = None if p1 is None else dev(p1).requires_grad_()
-    graph = ops.EdgeGraph(_t(ei), N, ptr=_t(ptr) if with_ptr else None)  # graph boundaries enable the wm kernels
+    graph = ops.EdgeGraph(_t(ei), N, ptr=_t(ptr) if with_ptr else None)  # graph boundaries (the matrix-core kernels walk segments)
     mul = [0, 0, 0]
     for m_, l_, _ in orc.parse_irreps(irreps):
         mul[l_] = m_
@@ -567,15 +567,15 @@ WM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("impl", ["wq", "wm"])
+@pytest.mark.parametrize("impl", ["wq"])
 @pytest.mark.parametrize("eps", ["16", "128", "100000"])
 @pytest.mark.parametrize("irreps,node_dim,B,rbf_kind,cutoff_kind,shuffle", WM_CASES)
 def test_fused_message_matrix_core_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff_kind, shuffle, eps, impl, monkeypatch):
-    """The wave / matrix-core kernels (xeq_message_{fwd,bwd}_wm, f32) against the fp64 oracle: every output of the
+    """The matrix-core kernels (xeq_message_{fwd,bwd}_wq, f32) against the fp64 oracle: every output of the
     forward pass and every gradient of the reverse pass, ragged molecules (3..29 atoms), shuffled edges, K = B + 1
     from 9 to 32, and stream lengths from one tile per stream to one wave for the whole batch."""
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", impl)
-    monkeypatch.setenv("XEQ_WM_EDGES_PER_STREAM", eps)
+    monkeypatch.setenv("XEQ_WQ_EDGES_PER_STREAM", eps)
     got, want = _message_case(irreps, node_dim, B, rbf_kind, cutoff_kind, torch.float32, shuffle, n_mol=40)
     names = ["s_out", "x_out", "grad_h", "grad_xhat", "grad_vec", "grad_s", "grad_x"]
     for name, a, b in zip(names, got, want):
@@ -585,7 +585,7 @@ def test_fused_message_matrix_core_fwd_bwd(irreps, node_dim, B, rbf_kind, cutoff
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * scale, err_msg=name)
 
 
-@pytest.mark.parametrize("impl", ["wq", "wm"])
+@pytest.mark.parametrize("impl", ["wq"])
 def test_fused_message_matrix_core_isolated_nodes_and_empty_graph(impl, monkeypatch):
     """Nodes without edges keep their residual rows (forward) and get zero gradients (reverse); a batch without any
     edge at all runs through the same entry points."""
@@ -619,10 +619,10 @@ def test_fused_message_matrix_core_isolated_nodes_and_empty_graph(impl, monkeypa
         assert torch.isfinite(h.grad).all() and torch.isfinite(xhat.grad).all() and vec.grad.shape == (E, 3)
 
 
-@pytest.mark.parametrize("impl", ["wq", "wm"])
+@pytest.mark.parametrize("impl", ["wq"])
 def test_fused_message_matrix_core_matches_scalar_broadcast_and_is_reproducible(impl, monkeypatch):
-    """wq / wm against the sb kernels on the same f32 inputs (both are exact-f32 fmaf chains over the same terms; the
-    k-order of the filter sum differs), and bitwise reproducibility of wm (register sums in CSR order)."""
+    """wq against the sb kernels on the same f32 inputs (the same terms; the k-order of the filter sum differs and its first
+    sixteen k are split-bf16 products), and bitwise reproducibility (register sums in walk order)."""
     args = ("128x0e + 64x1o + 32x2e", 128, 20, "bessel", "cosine", torch.float32, False)
     monkeypatch.setenv("XEQ_MESSAGE_IMPL", "sb")
     ref, _ = _message_case(*args, n_mol=24)
@@ -637,12 +637,12 @@ def test_fused_message_matrix_core_matches_scalar_broadcast_and_is_reproducible(
 
 
 def test_fused_message_matrix_core_falls_back_or_refuses(monkeypatch):
-    """Channel layouts outside the wm form (not in multiples of 32) and f64 run on the sb kernels under the default
-    selection, and raise when wm is demanded."""
+    """Channel layouts outside the matrix-core form (not in multiples of 32) and f64 run on the sb kernels under the default
+    selection, and raise when wq is demanded."""
     monkeypatch.delenv("XEQ_MESSAGE_IMPL", raising=False)
     got, want = _message_case("8x0e+4x1o+2x2e", 12, 12, "bessel", "polynomial", torch.float32, True)
     np.testing.assert_allclose(got[0].detach().cpu().double().numpy(), want[0].detach().numpy(), rtol=2e-5, atol=2e-5)
-    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wq")
     with pytest.raises(RuntimeError, match="does not fit"):
         _message_case("8x0e+4x1o+2x2e", 12, 12, "bessel", "polynomial", torch.float32, True)
     with pytest.raises(RuntimeError, match="does not fit"):
@@ -845,7 +845,7 @@ def test_model_virial_pbc_and_molecules(dtype):
         assert "forces" not in only
 
 
-@pytest.mark.parametrize("impl", ["generic", "sb", "wm", "wq"])
+@pytest.mark.parametrize("impl", ["generic", "sb", "wq"])
 def test_model_message_kernel_families_agree(impl, monkeypatch):
     """The fused-message kernel families (generic, scalar-broadcast, wave / matrix-core) and the
     operator-level module path all reproduce the oracle on a molecule batch (fp32)."""
@@ -1041,7 +1041,7 @@ def test_reused_edge_graph_follows_new_positions():
 
 def test_auto_picks_a_kernel_family_that_fits(monkeypatch):
     """XEQ_MESSAGE_IMPL=auto looks at the sizes too: sb where it is the faster family (ops.prefers_sb), beyond the 32-bit byte offsets of the matrix-core kernels it takes
-    the scalar-broadcast form, beyond that one's 32-bit element offsets the generic form; f64 never takes wm."""
+    the scalar-broadcast form, beyond that one's 32-bit element offsets the generic form; f64 never takes the matrix-core kernels."""
     from xequinet_amd import ops
 
     monkeypatch.delenv("XEQ_MESSAGE_IMPL", raising=False)
@@ -1054,11 +1054,12 @@ def test_auto_picks_a_kernel_family_that_fits(monkeypatch):
     assert pick(torch.float32, 4_000_000, 1_000_000) == "generic"      # N * 576 elements >= 2^31
     assert pick(torch.float64, 18_609, 311_994) == "sb"
     assert ops.select_message_impl(torch.float32, 100, 1000, 20, 96, (96, 48, 24)) == "sb"   # multiplicities not in 32s
-    assert ops.select_message_impl(torch.float32, 10_000, 100_000, 30, 128, mul) == "wm"      # num_basis > 23
+    assert ops.select_message_impl(torch.float32, 10_000, 100_000, 30, 128, mul) == "wq"      # num_basis up to 31 since round 4
+    assert ops.select_message_impl(torch.float32, 10_000, 100_000, 32, 128, mul) == "sb"      # 32: the scalar-broadcast form
     assert pick(torch.float32, 1_536, 82_996) == "wq"                  # dense neighbourhoods (water box): wq too since the split-bf16 filter
     assert pick(torch.float32, 21, 360) == "sb"                        # one small molecule: launch-bound, sb needs no walk plan
     assert pick(torch.float32, 1_175, 19_984) == "wq"                  # 64 QM9-shaped molecules: wq from there on
-    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wm")
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wq")
     with pytest.raises(RuntimeError):
         ops.select_message_impl(torch.float64, 100, 1000, 20, 128, mul)
 

@@ -358,12 +358,13 @@ def test_launch_policy_is_stated_once_in_the_c_abi():
     L = lib.load()
     mul = (ctypes.c_int32 * 3)(128, 64, 32)
     fam = lambda dt, n, e, b=20: int(L.xeq_message_auto_family(dt, n, e, b, 128, mul))
-    WQ, SB, WM, GENERIC = 0, 1, 2, 3
+    WQ, SB, GENERIC = 0, 1, 3
     assert fam(lib.XEQ_F32, 21, 360) == SB                    # one small molecule: launch-bound, no walk plan
     assert fam(lib.XEQ_F32, 18609, 311994) == WQ              # QM9-1024
     assert fam(lib.XEQ_F32, 1536, 82996) == WQ                # dense periodic box (round 3: wq wins there too)
     assert fam(lib.XEQ_F64, 18609, 311994) == SB              # f64
-    assert fam(lib.XEQ_F32, 18609, 311994, 31) == WM          # num_basis beyond the wq form
+    assert fam(lib.XEQ_F32, 18609, 311994, 31) == WQ          # num_basis up to 31 (round 4: the wm family is gone)
+    assert fam(lib.XEQ_F32, 18609, 311994, 32) == SB
     assert fam(lib.XEQ_F32, 3_000_000, 150_000_000) == GENERIC   # beyond every 32-bit offset
     assert fam(lib.XEQ_F32, 2_500_000, 40_000_000) in (SB, GENERIC)
     eps = lambda n, e: int(L.xeq_message_wq_edges_per_stream(n, e))

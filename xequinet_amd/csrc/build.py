@@ -13,13 +13,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "libxeq_hip.so")
-SOURCES = ["xeq_graph.hip", "xeq_ops.hip", "xeq_message.hip", "xeq_message_sb.hip", "xeq_message_wm.hip", "xeq_message_wq.hip", "xeq_message_wq_bwd.hip", "xeq_node.hip", "xeq_mlp.hip", "xeq_linear.hip", "xeq_update.hip", "xeq_nodeblock.hip", "xeq_tp.hip", "xeq_train.hip"]
+SOURCES = ["xeq_graph.hip", "xeq_ops.hip", "xeq_message.hip", "xeq_message_sb.hip", "xeq_message_wq.hip", "xeq_message_wq_bwd.hip", "xeq_node.hip", "xeq_mlp.hip", "xeq_linear.hip", "xeq_update.hip", "xeq_nodeblock.hip", "xeq_tp.hip", "xeq_train.hip"]
 HEADERS = ["xeq_common.h", os.path.join("..", "..", "include", "xeq.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
-# per-source extras.  The matrix-core message kernels: LLVM's max-ILP machine scheduler instead of the default
-# (measured, scratch/bench_wm.py on QM9-1024: reverse launch 573 -> 544 us, forward 236 -> 239 us, same VGPR budgets)
-EXTRA_FLAGS = {"xeq_message_wm.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-               # wq: explicit fma chains only (its window / global instantiations must round alike)
+# per-source extras.  The matrix-core message kernels: LLVM's max-ILP machine scheduler instead of the default (measured in round 1 on
+# their predecessor: reverse launch 573 -> 544 us, same VGPR budgets);
+EXTRA_FLAGS = {# wq: explicit fma chains only (its window / global instantiations must round alike)
                "xeq_message_wq.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-ffp-contract=off"],
                # its reverse half (same text, XEQ_WQ_PART_BWD): the default scheduler orders the unfenced reverse tile better
                "xeq_message_wq_bwd.hip": ["-ffp-contract=off"]}

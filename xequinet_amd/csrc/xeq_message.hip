@@ -1,7 +1,7 @@
 // Fused XPaiNN message kernels, GENERIC form (SURVEY 8a rows a3-a5, a10-a13, and their reverse
 // pass for a16).  Reference dataflow: nn/xpainn.py:140-159.
 //
-// This is the fallback for configurations neither xeq_message_wm.hip (f32, multiplicities in multiples of 32) nor
+// This is the fallback for configurations neither xeq_message_wq.hip (f32, multiplicities in multiples of 32) nor
 // xeq_message_sb.hip (at most 256 channels) covers: any multiplicities, any node_dim, f32 and f64.
 //
 // Mapping ("channel on the lane"):

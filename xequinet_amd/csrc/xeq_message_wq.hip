@@ -1,12 +1,12 @@
 // Fused XPaiNN message kernels, "wave / quad" form (fp32; the default where the channel layout allows it).
 // Reference dataflow: nn/xpainn.py:140-159; reverse pass for nn/basic.py:143-159.
 //
-// Same arithmetic mapping as the wave / matrix-core form it replaces (xeq_message_wm.hip): the filter
-// phi_e = (W rho(d_e) + b) f(d_e) is an exact-f32 MFMA tile D[edge][channel] (v_mfma_f32_32x32x2_f32, K = B + 1),
+// Arithmetic mapping (kept from round 1's wave / matrix-core form, xeq_message_wm.hip, retired in round 4): the filter
+// phi_e = (W rho(d_e) + b) f(d_e) is a matrix-core tile D[edge][channel] (K = B + 1),
 // a wave owns (range of nodes, 32 gate channels of one l), its two half-waves are two independent streams over
 // contiguous CSR segments, and the sum over the edges of a node is a running sum in registers that is stored once.
 //
-// What changed is the WALK ORDER, which removes the per-row bookkeeping that bounded the older form (19 vector
+// The WALK ORDER removes the per-row bookkeeping that bounded that form (19 vector
 // instructions per MFMA, 244 VGPRs, a divergent first/last branch per row):
 //
 //   * every node's edge list is padded to a multiple of FOUR slots ("quads"; padding slots carry an all-zero record,

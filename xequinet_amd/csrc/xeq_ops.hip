@@ -374,13 +374,12 @@ void xeq_pack_epoch_bump(void) { g_pack_epoch.fetch_add(1); }
 /* ---- launch policy shared by every front (Python modules, registered operator): ONE statement of the rules ---------------- */
 int xeq_message_auto_family(int dtype, int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
   // tiny graphs are launch-bound and the scalar-broadcast kernels need no walk plan; everything else that fits takes the wave / quad
-  // matrix-core kernels (since the split-bf16 filter also the dense periodic boxes), then their predecessor wm (num_basis 24..31),
-  // then sb (f64, other channel layouts), then the generic 64-bit form
+  // matrix-core kernels (since the split-bf16 filter also the dense periodic boxes; num_basis <= 31), then sb (f64, other channel
+  // layouts), then the generic 64-bit form
   const bool f32 = dtype == XEQ_F32;
   const bool sb_fits = xeq_message_sb_fits(n_nodes, n_edges, num_basis, node_dim, mul) != 0;
   if (n_edges < 4096 && sb_fits) return XEQ_FAMILY_SB;
   if (f32 && xeq_message_wq_fits(n_nodes, n_edges, num_basis, node_dim, mul)) return XEQ_FAMILY_WQ;
-  if (f32 && xeq_message_wm_fits(n_nodes, n_edges, num_basis, node_dim, mul)) return XEQ_FAMILY_WM;
   if (sb_fits) return XEQ_FAMILY_SB;
   return XEQ_FAMILY_GENERIC;
 }

@@ -540,13 +540,13 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   }
   Graph g = build_graph(ei_c, N, center_sorted, symmetric);
 
-  // ---- which message kernels (ops.select_message_impl, without the wm / generic forms)
+  // ---- which message kernels (ops.select_message_impl, without the generic form)
   int impl;
   // the family rule is the C ABI's (xeq_message_auto_family: the Python modules ask the same function); this operator carries the
   // wq and sb sequences
   const int family = xeq_message_auto_family(dt, N, E, hy.B, F, mul);
   if (family == XEQ_FAMILY_WQ) impl = 0;
-  else if (family == XEQ_FAMILY_SB || (family == XEQ_FAMILY_WM && xeq_message_sb_fits(N, E, hy.B, F, mul))) impl = 1;   // (no wm sequence here)
+  else if (family == XEQ_FAMILY_SB) impl = 1;
   else TORCH_CHECK(false, "xeq::xpainn_eval: this configuration / size needs the generic message kernels: use the Python modules");
   if (impl == 0) {
     build_wq_plan(g, false, g.fwd);

@@ -43,7 +43,7 @@ def plan_chunks(ptr: Sequence[int], max_edges: int, g0: int = 0, g1: int = None)
     """Cut molecules [g0, g1) into contiguous ranges whose edge count cannot exceed ``max_edges``.
 
     The bound per molecule is n_g (n_g - 1) (every ordered pair inside the cutoff), so a range never overflows the
-    32-bit byte offsets of the matrix-core message kernels (xeq_message_wm_fits) whatever the geometry.  A single
+    32-bit byte offsets of the matrix-core message kernels (xeq_message_wq_fits) whatever the geometry.  A single
     molecule above the cap gets a range of its own (the kernels' own size check then decides)."""
     ptr = np.asarray(ptr, dtype=np.int64)
     g1 = len(ptr) - 1 if g1 is None else g1

@@ -101,17 +101,7 @@ _PROTOS = {
     "xeq_message_fwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, c_int, _P],
     "xeq_message_bwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P,
                            c_int, _P],
-    "xeq_message_wm_supported": [c_int, c_int, _I3],
-    "xeq_message_wm_fits": [c_int64, c_int64, c_int, c_int, _I3],
     "xeq_message_sb_fits": [c_int64, c_int64, c_int, c_int, _I3],
-    "xeq_message_wm_streams": [_P, c_int64, c_int64, c_int, _P, _P],
-    "xeq_edge_basis_wm_width": [c_int],
-    "xeq_edge_basis_wm": [_P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
-    "xeq_message_fwd_wm": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3,
-                           _P, _P, c_int, _P],
-    "xeq_message_bwd_wm": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
-                           _I3, _P, _P, _P, c_int, _P],
-    "xeq_message_wm_parts_floats": [c_int64, _I3],
     "xeq_message_wq_supported": [c_int, c_int, _I3],
     "xeq_message_wq_fits": [c_int64, c_int64, c_int, c_int, _I3],
     "xeq_message_wq_pcap": [c_int64, c_int64],
@@ -127,7 +117,6 @@ _PROTOS = {
     "xeq_message_bwd_wq": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                            _I3, _P, _P, _P, c_int, _P],
     "xeq_message_wq_edge_grad": [_P, c_int64, c_int64, _P, _P, _P, _I3, _P, _P, _P],
-    "xeq_message_wm_edge_grad": [_P, c_int64, _I3, _P, _P, _P, _P],
     "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
     "xeq_norm_bwd": [c_int, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P],
     "xeq_uv_reduce_fwd": [c_int, _P, c_int64, _I3, c_double, _P, c_int64, c_int, _P, _P],
@@ -161,7 +150,7 @@ _PROTOS = {
                            _P, _P, _P],
 }
 # entry points that return a size, not a status
-_RET_I64 = {"xeq_message_wm_parts_floats", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
+_RET_I64 = {"xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
             "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch", "xeq_tensor_product_wgrad_chunks"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 

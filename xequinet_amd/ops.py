@@ -116,9 +116,8 @@ class EdgeGraph:
                  symmetric: bool = False, capacity_form: bool = False) -> None:
         require_hip(edge_index)
         self.ptr = ptr          # graph boundaries [G+1] (keys.BATCH_PTR), when the caller knows them
-        self._wm = None
         self._wq = None
-        self._basis = self._basis_wm = None   # per-edge records of the current geometry (edge_basis / edge_basis_wm)
+        self._basis = None   # per-edge records of the current geometry (edge_basis)
         assert edge_index.dim() == 2 and edge_index.shape[0] == 2 and edge_index.dtype == torch.int64
         self.edge_index = edge_index = edge_index.contiguous()
         self.n_nodes = int(n_nodes)
@@ -152,21 +151,6 @@ class EdgeGraph:
             self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes, n_valid=self.c_rowptr[self.n_nodes:])
         else:
             self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes)
-
-    def wm_plan(self, reverse: bool, edges_per_stream: int = 128):
-        """Stream table of the wave / matrix-core message kernels (xeq_message_{fwd,bwd}_wm): contiguous ranges of
-        CSR segments (forward: over centers, reverse: over neighbors) of about `edges_per_stream` edges each."""
-        key = (bool(reverse), int(edges_per_stream))
-        if self._wm is None:
-            self._wm = {}
-        plan = self._wm.get(key)
-        if plan is None:
-            rowptr, perm = (self.n_rowptr, self.n_perm) if reverse else (self.c_rowptr, self.c_perm)
-            n_ranges = max(1, -(-self.n_edges // (2 * edges_per_stream)))
-            sp = torch.empty(2 * n_ranges + 1, dtype=torch.int32, device=rowptr.device)
-            call("xeq_message_wm_streams", ptr(rowptr), self.n_nodes, self.n_edges, n_ranges, ptr(sp), stream())
-            plan = self._wm[key] = {"n_ranges": n_ranges, "stream_ptr": sp, "rowptr": rowptr, "perm": perm}
-        return plan
 
     def wq_plan(self, reverse: bool, edges_per_stream: int = 128):
         """Walk plan of the wave / quad message kernels (xeq_message_wq_plan): every node's edge list padded to whole
@@ -203,13 +187,9 @@ class EdgeGraph:
     def refresh_plans(self) -> None:
         """Recompute the cached stream tables / walk plans in place after the CSR arrays were overwritten (HIP-graph
         replay: same sizes, new contents)."""
-        for plan in (self._wm or {}).values():
-            call("xeq_message_wm_streams", ptr(plan["rowptr"]), self.n_nodes, self.n_edges, plan["n_ranges"],
-                 ptr(plan["stream_ptr"]), stream())
         for plan in (self._wq or {}).values():
             self._build_wq_plan(plan)
 
-    refresh_wm_plans = refresh_plans   # earlier name
 
 
 _CELL_LIST_MIN_ATOMS = 512   # average atoms per graph from which the bin grid replaces the O(n_g^2) sweep
@@ -418,7 +398,7 @@ class EdgeVectors(Function):
         cell, cell_offsets, batch = _c(cell), _c(cell_offsets), _c(batch)
         call("xeq_edge_vectors_fwd", dtype_code(pos), ptr(pos_c), ptr(graph.edge_index), E, ptr(cell), ptr(cell_offsets),
              ptr(batch), ptr(vec), ptr(dist), stream())
-        graph._basis = graph._basis_wm = None   # records of an earlier geometry on this graph
+        graph._basis = None   # records of an earlier geometry on this graph
         for plan in (graph._wq or {}).values():
             plan["records"] = None
         ctx.graph = graph
@@ -626,7 +606,7 @@ def radial_basis(dist, rbf_kind: str, cutoff_kind: str, num_basis: int, cutoff: 
 
 
 # ------------------------------------------------------------------- fused message
-_MESSAGE_IMPLS = ("auto", "wq", "wm", "sb", "generic")
+_MESSAGE_IMPLS = ("auto", "wq", "sb", "generic")
 
 
 def _message_impl() -> str:
@@ -660,42 +640,24 @@ def prefers_sb(n_nodes: int, n_edges: int) -> bool:
 def select_message_impl(dtype, n_nodes: int, n_edges: int, num_basis: int, node_dim: int, mul) -> str:
     """Kernel family of the fused message for this configuration AND these sizes.  ``auto``: the scalar-broadcast form where it is
     the faster one (``prefers_sb``), else the wave / quad matrix-core
-    form (f32, multiplicities in multiples of 32, num_basis <= 23, 32-bit byte offsets: ~1.8 M atoms / ~28 M padded edge
-    slots with the default model), else its predecessor wm (num_basis <= 31), else the scalar-broadcast form (f32 / f64, at most 256 channels, 32-bit element offsets), else the generic
+    form (f32, multiplicities in multiples of 32, num_basis <= 31, 32-bit byte offsets: ~1.8 M atoms / ~28 M padded edge
+    slots with the default model), else the scalar-broadcast form (f32 / f64, at most 256 channels, 32-bit element offsets), else the generic
     form (64-bit offsets).  An explicit XEQ_MESSAGE_IMPL is taken as is: its kernels raise when they do not fit."""
     impl = _message_impl()
     if impl != "auto":
-        if impl == "wm" and not wm_supported(dtype, num_basis, node_dim, mul):
-            raise RuntimeError("XEQ_MESSAGE_IMPL=wm: this configuration does not fit the matrix-core kernels "
-                               "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 31)")
         if impl == "wq" and not (dtype == torch.float32 and lib.load().xeq_message_wq_supported(int(num_basis), int(node_dim), mul3(mul))):
             raise RuntimeError("XEQ_MESSAGE_IMPL=wq: this configuration does not fit the matrix-core kernels "
-                               "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 23)")
+                               "(needs f32, node_dim == mul[0], multiplicities in multiples of 32, num_basis <= 31)")
         return impl
     # the rule itself lives in the C ABI (xeq_message_auto_family), shared with the registered operator
     code = lib.load().xeq_message_auto_family(dtype_code_of(dtype), int(n_nodes), int(n_edges), int(num_basis), int(node_dim), mul3(mul))
-    return ("wq", "sb", "wm", "generic")[int(code)]
-
-
-def _wm_edges_per_stream(n_edges: int, n_nodes: int) -> int:
-    """Edges per half-wave stream of the wm kernels.  XEQ_WM_EDGES_PER_STREAM fixes it; otherwise 128 (8 tiles) for
-    large batches, shorter streams for small systems so that the launch still spreads over the chip (a stream is a
-    serial walk: ~1 us per edge tile), but never below the mean segment length (streams hold whole segments; more
-    streams than nodes would be empty waves).  Measured (scratch/eps_sweep.py): water-64 137 -> 62 us per reverse
-    launch, 76 k edges 219 -> 176 us, 312 k edges unchanged."""
-    import os
-
-    env = os.environ.get("XEQ_WM_EDGES_PER_STREAM")
-    if env:
-        return max(16, int(env))
-    per_node = n_edges / max(1, n_nodes)
-    return int(min(128, max(16, per_node, n_edges / 1500)))
+    return {0: "wq", 1: "sb", 3: "generic"}[int(code)]
 
 
 def _wq_edges_per_stream(n_edges: int, n_nodes: int) -> int:
     """Edges per half-wave stream of the wq kernels.  A step (what the four waves of a workgroup walk together: eight
     streams) should gather from few enough nodes for its window to fit LDS: 64 edges per stream is ~30 owner nodes and
-    a window of two to four QM9-size molecules.  Small systems get shorter streams, as for wm.  XEQ_WQ_EDGES_PER_STREAM
+    a window of two to four QM9-size molecules.  Small systems get shorter streams so that the launch still spreads over the chip.  XEQ_WQ_EDGES_PER_STREAM
     fixes it."""
     import os
 
@@ -705,32 +667,12 @@ def _wq_edges_per_stream(n_edges: int, n_nodes: int) -> int:
     return int(lib.load().xeq_message_wq_edges_per_stream(int(n_nodes), int(n_edges)))   # (the C ABI states the rule)
 
 
-def wm_supported(dtype, num_basis, node_dim, mul) -> bool:
-    return dtype == torch.float32 and bool(lib.load().xeq_message_wm_supported(int(num_basis), int(node_dim), mul3(mul)))
-
-
 def _basis_cache_hit(cached, vec, key):
     """A cached record set is valid only for the very tensor it was computed from.  ``vec`` is written by a raw
     HIP kernel into a fresh allocation, so its ``_version`` never moves and the caching allocator can hand the next
     evaluation's vec the same address: identity of the tensor object is the test (the cache holds a reference, which
     also keeps that address from being reused while the entry lives)."""
     return cached is not None and cached[0] is vec and cached[1] == key
-
-
-def edge_basis_wm(vec, graph: "EdgeGraph", rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1):
-    """Per-edge records of the wm kernels (xeq_edge_basis_wm), once per evaluation, cached on the graph."""
-    key = (rbf_kind, cutoff_kind, num_basis, float(cutoff), p0.data_ptr(), p0._version)
-    cached = getattr(graph, "_basis_wm", None)
-    if _basis_cache_hit(cached, vec, key):
-        return cached[2], cached[3]
-    width = lib.load().xeq_edge_basis_wm_width(num_basis)
-    E = vec.shape[0]
-    basis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
-    dbasis = torch.empty((E, width), dtype=vec.dtype, device=vec.device)
-    call("xeq_edge_basis_wm", ptr(vec), E, lib.RBF_KINDS[rbf_kind], lib.CUTOFF_KINDS[cutoff_kind], num_basis, float(cutoff),
-         ptr(p0), ptr(p1), ptr(basis), ptr(dbasis), stream())
-    graph._basis_wm = (vec, key, basis, dbasis)
-    return basis, dbasis
 
 
 def edge_basis_wq(vec, plan, n_nodes, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv: bool):
@@ -817,13 +759,6 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
                             ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream(),
                             label="xeq_message_fwd_wq_first" if xl & lib.XHAT_HIGHER_L_ZERO else None)   # the first-block form moves fewer bytes
         return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, None, None), impl
-    if impl == "wm":
-        basis, dbasis = edge_basis_wm(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
-        plan = graph.wm_plan(False, _wm_edges_per_stream(E, N))
-        KERNEL_TIMER.launch("xeq_message_fwd_wm", N, E, plan["n_ranges"], ptr(plan["stream_ptr"]), ptr(plan["rowptr"]),
-                            ptr(plan["perm"]), ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x),
-                            ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream())
-        return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, basis, dbasis), impl
     if impl == "sb":
         basis, dbasis = edge_basis(vec, graph, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1)
         KERNEL_TIMER.launch("xeq_message_fwd_sb", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm),
@@ -863,14 +798,6 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
                             label="xeq_message_bwd_wq_first" if (skip and xl & lib.XHAT_HIGHER_L_ZERO) else None)
         call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), ptr(graph.n_perm if mirror else None),
              mul3(mul), ptr(parts), ptr(g_vec), stream())
-    elif impl == "wm":
-        plan = graph.wm_plan(True, _wm_edges_per_stream(graph.n_edges, graph.n_nodes))
-        parts = torch.empty(lib.load().xeq_message_wm_parts_floats(graph.n_edges, mul3(mul)), dtype=h.dtype, device=h.device)
-        KERNEL_TIMER.launch("xeq_message_bwd_wm", graph.n_nodes, graph.n_edges, plan["n_ranges"], ptr(plan["stream_ptr"]),
-                            ptr(plan["rowptr"]), ptr(plan["perm"]), ptr(graph.edge_index[0]), ptr(graph.edge_index[1]), ptr(basis), ptr(dbasis),
-                            ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul),
-                            ptr(g_h), ptr(g_xhat), ptr(parts), xl, stream())
-        call("xeq_message_wm_edge_grad", ptr(vec), graph.n_edges, mul3(mul), ptr(parts), ptr(plan["perm"]), ptr(g_vec), stream())
     elif impl == "sb":
         KERNEL_TIMER.launch("xeq_message_bwd_sb", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),
                             ptr(graph.n_perm), ptr(graph.edge_index[0]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s),
