@@ -121,7 +121,7 @@ class XEmbedding(nn.Module):
             # x = 0), and so are the norms and scalar_mlp of the first message block: they are evaluated once per table row (cached per
             # weight version) and gathered by atomic number, here and in the first XPainnMessage (nn/fused.py::first_block_front).
             # The kernels give a row the same bits in any batch, so the results are those of the per-node launches.
-            z = atomic_numbers.long()
+            z = atomic_numbers if atomic_numbers.dtype in (torch.int32, torch.int64) else atomic_numbers.long()   # (index_select takes either)
             node_invariant = rows.index_select(0, z)
             data[ELEMENT_ROWS] = (z, rows, node_invariant)
         else:
