@@ -260,10 +260,11 @@ def test_node_block_backward_matches_f64_autograd(n, mode):
 
 
 def test_node_block_at_full_size_equals_itself_on_slices():
-    """86 016 nodes (the MD17 x 4096 batch: several rounds of workgroups per CU) against the same launches on slices of a few hundred
-    rows, BIT FOR BIT, forward and reverse: a node's result may not depend on how full the chip is.  (Round 4's 16-node form of these
-    kernels passed every small-size test and failed exactly this -- sporadic wrong rows once two workgroups shared a CU,
-    profiles/r04_nodeblock.txt item 9 -- so the property is pinned at a size where it can break.)"""
+    """86 016 nodes (the MD17 x 4096 batch: several rounds of workgroups per CU, two workgroups resident per CU) against the same
+    launches on slices of a few hundred rows, BIT FOR BIT, forward and reverse: a node's result may not depend on how full the chip is.
+    (The 16-node form of these kernels passed every small-size test and failed exactly this while it was compiled with packed-fp32
+    instructions -- sporadic wrong values in one 16-lane row once two waves shared a SIMD, profiles/r04_nodeblock.txt item 9 -- so
+    the property is pinned at a size where it can break.)"""
     from xequinet_amd.nn import nodeblock
 
     n = 86016

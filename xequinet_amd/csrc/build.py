@@ -18,7 +18,10 @@ HEADERS = ["xeq_common.h", os.path.join("..", "..", "include", "xeq.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 # per-source extras.  The matrix-core message kernels: LLVM's max-ILP machine scheduler instead of the default (measured in round 1 on
 # their predecessor: reverse launch 573 -> 544 us, same VGPR budgets);
-EXTRA_FLAGS = {# wq: explicit fma chains only (its window / global instantiations must round alike)
+EXTRA_FLAGS = {# node block: no packed-fp32 instructions.  With two waves of this kernel on a SIMD, v_pk_fma_f32 / v_pk_add_f32 results computed
+               # from matrix-core outputs came out wrong in one 16-lane row, sporadically (profiles/r04_nodeblock.txt item 9c: bisected to exactly this)
+               "xeq_nodeblock.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+               # wq: explicit fma chains only (its window / global instantiations must round alike)
                "xeq_message_wq.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-ffp-contract=off"],
                # its reverse half (same text, XEQ_WQ_PART_BWD): the default scheduler orders the unfenced reverse tile better
                "xeq_message_wq_bwd.hip": ["-ffp-contract=off"]}

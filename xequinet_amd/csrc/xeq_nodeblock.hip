@@ -10,15 +10,17 @@
 // launches that re-read [N, 480..1056] tensors between them) by one launch that reads (s, x) and writes what the message kernel and
 // the reverse pass read.
 //
-// Design (MI355X): ACTIVATION-STATIONARY.  A wave owns 32 nodes and keeps every activation of theirs in registers in the matrix
-// cores' accumulator layout (lane = node | channel half, register = channel: one 32-channel tile is 16 VGPRs), so that the result
-// of one product is the B operand of the next without any data movement between lanes (v_mfma_f32_32x32x16_bf16, D = W X with the
-// WEIGHT tile as the A operand: the k order inside a 16-wide step is permuted identically in the packed weights).  Every layer
-// norm, SiLU, invariant and residual is then plain per-lane arithmetic (a row reduction is an in-lane sum plus one exchange between
-// the two half-waves).  The weights are what streams: packed once per weight version in CONSUMPTION order (one linear array of
-// 3 KB tiles, xeq_node_block_pack), pulled by the four waves of a workgroup through a three-stage LDS ring (each wave fetches one
-// tile of a four-tile stage, one barrier per stage) and read by every wave as A fragments.  One workgroup = 4 waves = 128 nodes
-// reads the block's ~1.7 MB of packed weights once (the 32-row kernels read them once per 32 nodes).
+// Design (MI355X): ACTIVATION-STATIONARY.  A wave owns 16 nodes and keeps every activation of theirs in registers in the matrix
+// cores' accumulator layout (lane = node | channel quarter q, register = channel: one 32-channel tile is 8 VGPRs, register 4 g + e
+// <-> channel 16 g + 4 q + e), so that the result of one product is the B operand of the next without any data movement between
+// lanes (v_mfma_f32_16x16x32_bf16, D = W X with the WEIGHT tile -- 16 output rows x 32 k -- as the A operand: the k order inside a
+// 32-wide step is permuted identically in the packed weights).  Every layer norm, SiLU, invariant and residual is then plain
+// per-lane arithmetic (a row reduction is an in-lane sum plus two exchanges between the four lane quarters).  The weights are what
+// streams: packed once per weight version in CONSUMPTION order (one linear array of 3 KB tiles, xeq_node_block_pack), pulled by the
+// four waves of a workgroup through a double-buffered LDS ring (each wave fetches one tile of a four-tile stage, one barrier per
+// stage) and read by every wave as A fragments.  One workgroup = 4 waves = 64 nodes; 256 registers and 72 KB of LDS, so two
+// workgroups share a CU.  (The first form of this file gave a wave 32 nodes on v_mfma_f32_32x32x16_bf16, 512 registers, one wave per
+// SIMD: a launch was one 510 k-cycle chain per wave whatever the node count, profiles/r04_nodeblock.txt.)
 //
 // Arithmetic: every contraction runs on bf16 MFMAs over operands split three ways (x = hi + mid + lo, bf16 each, exact to 24 bits),
 // six products per k-step with f32 accumulation (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; what is left out is 2^-26 of a
@@ -34,7 +36,8 @@
 namespace xeq {
 namespace nb {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float tile_t __attribute__((ext_vector_type(8)));    // one 32-channel tile of 16 nodes: register 4 g + e <-> channel 16 g + 4 q + e
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -42,12 +45,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int F = 128, M0 = 128, M1 = 64, M2 = 32, C = M0 + M1 + M2, D = M0 + 3 * M1 + 5 * M2;
 constexpr int HM = F + 2 * C;    // scalar_mlp output (576)
 constexpr int AU = C + 2 * F;    // update_mlp output (480)
-constexpr int ROWS_WG = 128;     // 4 waves x 32 nodes
-constexpr int TILE_U4 = 192;     // one packed weight tile: 3 splits x 64 lanes x 16 B
+constexpr int WAVE_ROWS = 16;    // nodes of a wave
+constexpr int ROWS_WG = 64;      // 4 waves x 16 nodes
+constexpr int TILE_U4 = 192;     // one packed weight tile (16 output rows x 32 k): 3 splits x 64 lanes x 16 B
 #ifndef XEQ_NB_STAGE
 #define XEQ_NB_STAGE 4
 #endif
-constexpr int RING_STAGES = 3, STAGE_TILES = XEQ_NB_STAGE;   // tiles per stage: a multiple of 4 (each wave fetches STAGE_TILES / 4 tiles of a stage)
+constexpr int RING_STAGES = 2, STAGE_TILES = XEQ_NB_STAGE;   // tiles per stage: a multiple of 4 (each wave fetches STAGE_TILES / 4 tiles of a stage)
 constexpr int PF = STAGE_TILES / 4;
 constexpr int RING_BYTES = RING_STAGES * STAGE_TILES * TILE_U4 * 16;
 
@@ -79,16 +83,13 @@ __device__ unsigned long long g_nb_stamps[1024 * 4 * NB_STAMPS];
 #define NB_RSTAMP(i)
 #endif
 
-struct Frag {   // one k-step (16 channels) of an operand, split three ways
+struct Frag {   // one k-step (32 channels) of an operand, split three ways
   bf16x8 hi, mid, lo;
 };
 
-// k-step s (0, 1) of a 32-channel activation tile in accumulator layout: element j of this lane is register 8 s + j
-template <int S>
-__device__ __forceinline__ Frag split_k(const f32x16& t) {
-  f32x8 v;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = t[8 * S + j];
+// a 32-channel activation tile in accumulator layout as the B operand of one k-step: element j of this lane is register j
+__device__ __forceinline__ Frag split_t(const tile_t& t) {
+  const f32x8 v = t;
   Frag f;
   f.hi = __builtin_convertvector(v, bf16x8);
   const f32x8 r1 = v - __builtin_convertvector(f.hi, f32x8);
@@ -98,19 +99,35 @@ __device__ __forceinline__ Frag split_k(const f32x16& t) {
   return f;
 }
 
-// acc += W X over one k-step: small terms first
-__device__ __forceinline__ void mfma6(f32x16& acc, const Frag& w, const Frag& x) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.mid, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.mid, x.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.mid, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, acc, 0, 0, 0);
+// acc(rows 16 S .. 16 S + 15 of the tile) += W X over one k-step: small terms first
+template <int S>
+__device__ __forceinline__ f32x4 half_of(const tile_t& t) { return __builtin_shufflevector(t, t, 4 * S, 4 * S + 1, 4 * S + 2, 4 * S + 3); }
+template <int S>
+__device__ __forceinline__ void set_half(tile_t& t, const f32x4& v) {
+  t[4 * S] = v[0];
+  t[4 * S + 1] = v[1];
+  t[4 * S + 2] = v[2];
+  t[4 * S + 3] = v[3];
+}
+__device__ __forceinline__ f32x4 mfma6q(f32x4 a, const Frag& w, const Frag& x) {
+  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, x.hi, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.lo, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.mid, x.mid, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.mid, x.hi, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.mid, a, 0, 0, 0);
+  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, x.hi, a, 0, 0, 0);
+  return a;
+}
+template <int S>
+__device__ __forceinline__ void mfma6(tile_t& acc, const Frag& w, const Frag& x) {
+  set_half<S>(acc, mfma6q(half_of<S>(acc), w, x));
 }
 
-// The weight stream: tiles in consumption order, four per stage, three stages in LDS.  Stage j is fetched into registers while
-// stage j - 2 is consumed, written to LDS at the boundary j - 2 -> j - 1 (one barrier per boundary: it publishes that write and
-// tells every wave that stage j - 2's slot is free for the write of the boundary after it).
+// The weight stream: tiles in consumption order, four per stage, TWO stages in LDS.  A wave reads the fragments of tile t + 1 while
+// it multiplies tile t (two calls of lookahead: with one or two waves on a SIMD little else hides the LDS latency).  The synchronisation
+// point of stage j sits two tiles before the end of stage j - 1: there every wave has the last two tiles of stage j - 1 in registers
+// and waits for its LDS reads, so after the barrier (a) stage j, written behind the previous barrier, is published, and (b) stage
+// j - 1's slot is free: the stage j + 1 this wave fetched one stage ago is written into it, and the fetch of stage j + 2 is issued.
 struct WStream {
   const uint4* __restrict__ g;
   uint4* ring;
@@ -119,15 +136,12 @@ struct WStream {
 #ifdef XEQ_NB_STAMPS
   unsigned long long t_commit = 0, t_barrier = 0;   // cycles waiting for the fetched stage / at the stage barrier
 #endif
-  Frag cur, nxt;   // fragments of tiles t and t + 1, read from LDS two calls ahead of their use (one wave per SIMD: nothing else hides the LDS latency)
+  Frag cur, nxt;   // fragments of tiles t and t + 1
   __device__ __forceinline__ void issue(int stage) {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       int tile = stage * STAGE_TILES + 4 * i + wave;
       tile = tile < n_tiles ? tile : n_tiles - 1;
-#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 4   // experiment: always the same four tiles (vector-L1 hits)
-      tile = wave;
-#endif
       const uint4* p = g + (int64_t)tile * TILE_U4 + lane;
       pf[i][0] = p[0];
       pf[i][1] = p[64];
@@ -148,7 +162,7 @@ struct WStream {
     nxt.hi = __builtin_bit_cast(bf16x8, q[0]);
     nxt.mid = __builtin_bit_cast(bf16x8, q[64]);
     nxt.lo = __builtin_bit_cast(bf16x8, q[128]);
-    __builtin_amdgcn_sched_barrier(0);   // nothing crosses: the reads are issued in front of the products of the two tiles before
+    __builtin_amdgcn_sched_barrier(0);   // nothing crosses: the reads are issued in front of the products of the tile before
   }
   __device__ __forceinline__ void init(const uint4* g_, uint4* ring_, int n_tiles_, int lane_, int wave_) {
     g = g_;
@@ -168,94 +182,69 @@ struct WStream {
     cur = nxt;
     read(1);
   }
-  // the fragments of the next tile of the program.  At a stage boundary (the tile handed out was the last of its stage) the fetched
-  // stage is written to LDS, the barrier publishes it and frees the oldest slot, and the fetch of the stage after it is issued.
-  // Tiles t + 1 and t + 2 are on their way from LDS meanwhile (their stages were published one boundary earlier).
+  // the fragments of the next tile of the program
   __device__ __forceinline__ Frag next() {
     const Frag r = cur;
     cur = nxt;
     ++t;
-#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 1   // experiment: no LDS reads, no stage boundaries
-    return r;
-#endif
-#if defined(XEQ_NB_EXP) && XEQ_NB_EXP == 2   // experiment: LDS reads, no stage boundaries
-    read((t + 1) & 7);
-    return r;
-#endif
-    if ((t & (STAGE_TILES - 1)) == 0) {
-      const int j = t / STAGE_TILES;
+    read(t + 1);
+    if ((t & (STAGE_TILES - 1)) == STAGE_TILES - 2) {   // tiles t, t + 1 (the last two of their stage) are in registers or on their way
+      const int j = t / STAGE_TILES + 1;
 #ifdef XEQ_NB_STAMPS
       unsigned long long b0_, b1_, b2_;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b0_)::"memory");
-      commit(j + 1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b1_)::"memory");
       NB_LDS_BARRIER();
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b2_)::"memory");
-      t_commit += b1_ - b0_;
-      t_barrier += b2_ - b1_;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b1_)::"memory");
+      commit(j + 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b2_)::"memory");
+      t_barrier += b1_ - b0_;
+      t_commit += b2_ - b1_;
 #else
-      commit(j + 1);
       NB_LDS_BARRIER();
+      commit(j + 1);
 #endif
-#if !(defined(XEQ_NB_EXP) && XEQ_NB_EXP == 3)   // experiment 3: no fetch
       issue(j + 2);
-#endif
       __builtin_amdgcn_sched_barrier(0);   // the fetch stays HERE, a whole stage ahead of its commit (the scheduler otherwise sinks it to its use)
     }
-    read(t + 1);
     return r;
   }
 };
 
-// acc[ot] += W[ot-th row tile, this k tile] T for NOT output tiles and one 32-channel activation tile; program order (s, ot)
+// acc[ot] += W[ot-th row tile, this k tile] T for NOT output tiles and one 32-channel activation tile; program order (row half, ot)
 template <int NOT>
-__device__ __forceinline__ void accum_tile(WStream& w, f32x16 (&acc)[NOT], const f32x16& T) {
-  const Frag f0 = split_k<0>(T);
+__device__ __forceinline__ void accum_tile(WStream& w, tile_t (&acc)[NOT], const tile_t& T) {
+  const Frag f = split_t(T);
 #pragma unroll
-  for (int ot = 0; ot < NOT; ++ot) mfma6(acc[ot], w.next(), f0);
-  const Frag f1 = split_k<1>(T);
+  for (int ot = 0; ot < NOT; ++ot) mfma6<0>(acc[ot], w.next(), f);
 #pragma unroll
-  for (int ot = 0; ot < NOT; ++ot) mfma6(acc[ot], w.next(), f1);
+  for (int ot = 0; ot < NOT; ++ot) mfma6<1>(acc[ot], w.next(), f);
 }
 
-// one output tile over NK k-steps whose fragments are resident; program order (k-step)
+// one output tile over NK k-steps whose fragments are resident; program order (k-step, row half)
 template <int NK>
-__device__ __forceinline__ void out_tile(WStream& w, f32x16& acc, const Frag (&fx)[NK]) {
-#pragma unroll
-  for (int k = 0; k < NK; ++k) mfma6(acc, w.next(), fx[k]);
-}
-
-// two accumulators fed from two weight tiles against the same operand fragment, products interleaved: a dependent
-// v_mfma_f32_32x32x16_bf16 does not issue back to back (measured: 55 cycles per product in a single chain, 32 when two chains alternate)
-__device__ __forceinline__ void mfma6x2(f32x16& a0, f32x16& a1, const Frag& w0, const Frag& w1, const Frag& x) {
-  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.lo, x.hi, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.lo, x.hi, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, x.lo, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, x.lo, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.mid, x.mid, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.mid, x.mid, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.mid, x.hi, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.mid, x.hi, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, x.mid, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, x.mid, a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0.hi, x.hi, a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1.hi, x.hi, a1, 0, 0, 0);
-}
-// two output tiles over NK resident k-steps; program order (k-step, tile of the pair)
-template <int NK>
-__device__ __forceinline__ void out_pair(WStream& w, f32x16& a0, f32x16& a1, const Frag (&fx)[NK]) {
+__device__ __forceinline__ void out_tile(WStream& w, tile_t& acc, const Frag (&fx)[NK]) {
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const Frag w0 = w.next();
-    const Frag w1 = w.next();
-    mfma6x2(a0, a1, w0, w1, fx[k]);
+    mfma6<0>(acc, w.next(), fx[k]);
+    mfma6<1>(acc, w.next(), fx[k]);
+  }
+}
+// two output tiles over NK resident k-steps; program order (k-step, row half, tile of the pair)
+template <int NK>
+__device__ __forceinline__ void out_pair(WStream& w, tile_t& a0, tile_t& a1, const Frag (&fx)[NK]) {
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    mfma6<0>(a0, w.next(), fx[k]);
+    mfma6<0>(a1, w.next(), fx[k]);
+    mfma6<1>(a0, w.next(), fx[k]);
+    mfma6<1>(a1, w.next(), fx[k]);
   }
 }
 
-// A set of operand fragments (up to 8 k-steps = 128 channels of this wave's 32 nodes) parked in a wave-private LDS area: the products
-// that sweep many output tiles over the same operand read it from there, step by step, instead of holding 96 registers -- the loops
+// A set of operand fragments (up to 4 k-steps = 128 channels of this wave's 16 nodes) parked in a wave-private LDS area: the products
+// that sweep many output tiles over the same operand read it from there, step by step, instead of holding 48 registers -- the loops
 // over output tiles then stay rolled and small.  (LDS operations of one wave execute in order: no barrier between put and get.)
-constexpr int PARK_STEPS = 8, PARK_U4 = PARK_STEPS * TILE_U4;
+constexpr int PARK_STEPS = 4, PARK_U4 = PARK_STEPS * TILE_U4;
 constexpr int LDS_BYTES = RING_BYTES + 4 * PARK_U4 * 16;
 struct Park {
   uint4* fb;
@@ -271,55 +260,44 @@ struct Park {
     f.lo = __builtin_bit_cast(bf16x8, fb[(3 * k + 2) * 64]);
     return f;
   }
-  template <int T>   // both k-steps of 32-channel tile number T of the set
-  __device__ __forceinline__ void put_tile(const f32x16& v) const {
-    put(2 * T, split_k<0>(v));
-    put(2 * T + 1, split_k<1>(v));
-  }
 };
-// one output tile over NK parked k-steps; program order (k-step)
+// one output tile over NK parked k-steps; program order (k-step, row half)
 template <int NK>
-__device__ __forceinline__ void out_tile_p(WStream& w, f32x16& acc, const Park& pk) {
-  Frag b = pk.get(0);
+__device__ __forceinline__ void out_tile_p(WStream& w, tile_t& acc, const Park& pk) {
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const Frag bn = pk.get(k + 1 < NK ? k + 1 : k);
-    mfma6(acc, w.next(), b);
-    b = bn;
+    const Frag b = pk.get(k);   // (two waves share the SIMD: the other one covers this read; a second fragment in flight costs 12 registers)
+    mfma6<0>(acc, w.next(), b);
+    mfma6<1>(acc, w.next(), b);
   }
 }
-// two output tiles over NK parked k-steps, products interleaved; program order (k-step, tile of the pair)
+// two output tiles over NK parked k-steps; program order (k-step, row half, tile of the pair)
 template <int NK>
-__device__ __forceinline__ void out_pair_p(WStream& w, f32x16& a0, f32x16& a1, const Park& pk) {
-  Frag b = pk.get(0);
+__device__ __forceinline__ void out_pair_p(WStream& w, tile_t& a0, tile_t& a1, const Park& pk) {
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
-    const Frag bn = pk.get(k + 1 < NK ? k + 1 : k);
-    const Frag w0 = w.next();
-    const Frag w1 = w.next();
-    mfma6x2(a0, a1, w0, w1, b);
-    b = bn;
+    const Frag b = pk.get(k);
+    mfma6<0>(a0, w.next(), b);
+    mfma6<0>(a1, w.next(), b);
+    mfma6<1>(a0, w.next(), b);
+    mfma6<1>(a1, w.next(), b);
   }
 }
 
-__device__ __forceinline__ f32x16 zero16() {
-  f32x16 z;
+__device__ __forceinline__ tile_t zero16() {
+  tile_t z;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  for (int r = 0; r < 8; ++r) z[r] = 0.f;
   return z;
 }
 
 // 32 consecutive channels starting at c0 of a row-major row (or of a parameter vector) in accumulator layout:
-// register 4 g + e <-> channel c0 + 8 g + 4 h + e
-__device__ __forceinline__ f32x16 ld_tile(const float* __restrict__ row, int c0, int h) {
-  f32x16 t;
-#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 8 || XEQ_NB_EXP == 9)
-  for (int r = 0; r < 16; ++r) t[r] = 0.25f * (float)(c0 + r + h);
-  return t;
-#endif
+// register 4 g + e <-> channel c0 + 16 g + 4 h + e (h = lane >> 4: the lane's channel quarter)
+__device__ __forceinline__ tile_t ld_tile(const float* __restrict__ row, int c0, int h) {
+  tile_t t;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 v = *reinterpret_cast<const float4*>(row + c0 + 8 * g + 4 * h);
+  for (int g = 0; g < 2; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c0 + 16 * g + 4 * h);
     t[4 * g] = v.x;
     t[4 * g + 1] = v.y;
     t[4 * g + 2] = v.z;
@@ -327,27 +305,21 @@ __device__ __forceinline__ f32x16 ld_tile(const float* __restrict__ row, int c0,
   }
   return t;
 }
-__device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, const f32x16& t, bool ok) {
-#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 7 || XEQ_NB_EXP == 9)
-  if (t[0] != 12345.678f) return;
-#endif
+__device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, const tile_t& t, bool ok) {
   if (!ok) return;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-    *reinterpret_cast<float4*>(row + c0 + 8 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+  for (int g = 0; g < 2; ++g)
+    *reinterpret_cast<float4*>(row + c0 + 16 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
 }
 // Tensors that only these kernels read and write (the forward launch's hand-over to the reverse launch, scratch) use a layout in which
-// every wave access is 1 KB of consecutive bytes: [wave block of 32 nodes][tile][register quad][lane][4 floats].  (A row-major
-// tile access touches 32 rows with 32 bytes each: the texture addresser pays per row, and these kernels move ~10 KB per node.)
-__device__ __forceinline__ f32x16 ld_nat(const float* __restrict__ wb, int t, int lane) {
-  const float4* p = reinterpret_cast<const float4*>(wb + t * 1024) + lane;
-  f32x16 r;
-#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 8 || XEQ_NB_EXP == 9)
-  for (int q = 0; q < 16; ++q) r[q] = 0.25f * (float)(t + q + lane);
-  return r;
-#endif
+// every wave access is 1 KB of consecutive bytes: [wave block of 16 nodes][tile][register quad][lane][4 floats] (NAT_TILE floats per
+// tile and block).
+constexpr int NAT_TILE = 512;
+__device__ __forceinline__ tile_t ld_nat(const float* __restrict__ wb, int t, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(wb + t * NAT_TILE) + lane;
+  tile_t r;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+  for (int g = 0; g < 2; ++g) {
     const float4 v = p[64 * g];
     r[4 * g] = v.x;
     r[4 * g + 1] = v.y;
@@ -356,13 +328,10 @@ __device__ __forceinline__ f32x16 ld_nat(const float* __restrict__ wb, int t, in
   }
   return r;
 }
-__device__ __forceinline__ void st_nat(float* __restrict__ wb, int t, int lane, const f32x16& v) {
-#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 7 || XEQ_NB_EXP == 9)
-  if (v[0] != 12345.678f) return;
-#endif
-  float4* p = reinterpret_cast<float4*>(wb + t * 1024) + lane;
+__device__ __forceinline__ void st_nat(float* __restrict__ wb, int t, int lane, const tile_t& v) {
+  float4* p = reinterpret_cast<float4*>(wb + t * NAT_TILE) + lane;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) p[64 * g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  for (int g = 0; g < 2; ++g) p[64 * g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 // tile numbers: the U|V buffer (l, component m, 0 U / 1 V, channel tile c) and equivariant rows (l, m, c)
 constexpr int UV_TILES = 2 * D / 32, X_TILES = D / 32, A_TILES = AU / 32, P_TILES = C / 32, S_TILES = F / 32;
@@ -372,15 +341,10 @@ __device__ __forceinline__ constexpr int x_tile(int l, int m, int c) { return l 
 // e3nn mul_ir rows (channel-major, m-minor): the DL components of 32 channels of one l > 0 block; `blk` = the block's first float
 // of the row + DL * 32 * tile
 template <int DL>
-__device__ __forceinline__ void ld_xm(const float* __restrict__ blk, int h, f32x16 (&X)[DL]) {
-#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 8 || XEQ_NB_EXP == 9)
-  for (int m = 0; m < DL; ++m)
-    for (int r = 0; r < 16; ++r) X[m][r] = 0.125f * (float)(m + r + h);
-  return;
-#endif
+__device__ __forceinline__ void ld_xm(const float* __restrict__ blk, int h, tile_t (&X)[DL]) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float* p = blk + DL * (8 * g + 4 * h);
+  for (int g = 0; g < 2; ++g) {
+    const float* p = blk + DL * (16 * g + 4 * h);
     float flat[4 * DL];
 #pragma unroll
     for (int q = 0; q < DL; ++q) {
@@ -397,14 +361,11 @@ __device__ __forceinline__ void ld_xm(const float* __restrict__ blk, int h, f32x
   }
 }
 template <int DL>
-__device__ __forceinline__ void st_xm(float* __restrict__ blk, int h, const f32x16 (&X)[DL], bool ok) {
-#if defined(XEQ_NB_EXP) && (XEQ_NB_EXP == 7 || XEQ_NB_EXP == 9)
-  if (X[0][0] != 12345.678f) return;
-#endif
+__device__ __forceinline__ void st_xm(float* __restrict__ blk, int h, const tile_t (&X)[DL], bool ok) {
   if (!ok) return;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float* p = blk + DL * (8 * g + 4 * h);
+  for (int g = 0; g < 2; ++g) {
+    float* p = blk + DL * (16 * g + 4 * h);
     float flat[4 * DL];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -415,20 +376,37 @@ __device__ __forceinline__ void st_xm(float* __restrict__ blk, int h, const f32x
   }
 }
 
-__device__ __forceinline__ float sum16(const f32x16& t) {
-  return (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) + (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
-}
-__device__ __forceinline__ float sumsq16(const f32x16& t, float c) {
+__device__ __forceinline__ float sum16(const tile_t& t) { return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])); }
+__device__ __forceinline__ float sumsq16(const tile_t& t, float c) {
   float a = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r = 0; r < 8; ++r) {
     const float d = t[r] - c;
     a = __builtin_fmaf(d, d, a);
   }
   return a;
 }
-// the node's row lives in lanes n and n + 32
-__device__ __forceinline__ float row_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// this lane's share of the sum of squares of NQ * 16 consecutive floats of a row (16-byte pieces q, q + 4, ...: the four lanes of a
+// node cover the span), in a fixed order
+template <int NQ>
+__device__ __forceinline__ float sumsq_span(const float* __restrict__ p, int h) {
+  float a = 0.f;
+  const float4* p4 = reinterpret_cast<const float4*>(p) + h;
+#pragma unroll 11
+  for (int i = 0; i < NQ; ++i) {
+    const float4 v = p4[4 * i];
+    a = __builtin_fmaf(v.x, v.x, a);
+    a = __builtin_fmaf(v.y, v.y, a);
+    a = __builtin_fmaf(v.z, v.z, a);
+    a = __builtin_fmaf(v.w, v.w, a);
+  }
+  return a;
+}
+// the node's row lives in lanes n, n + 16, n + 32, n + 48
+__device__ __forceinline__ float row_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
 
 // exp: the library's expf (what the other node kernels evaluate; csrc/xeq_mlp.hip)
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + expf(-x)); }
@@ -439,12 +417,12 @@ __device__ __forceinline__ float silu_grad_f(float x) {  // aten silu_backward: 
 
 // ------------------------------------------------------------------------------------------------ packed weight programs
 // A program is the list of weight tiles in the order a kernel consumes them, described by segments over source matrices.
-// Tile (o0, k0) of a source holds value(o0 + r, k0 + 8 (j >> 2) + 4 h + (j & 3)) in element j of lane (r = lane & 31, h = lane >> 5):
-// the k order of an accumulator tile used as the B operand (cdna_hip_programming.md, accumulator as the next operand).
+// Tile (o0 + 16 s, k0) of a source holds value(o0 + 16 s + r, k0 + 16 (j >> 2) + 4 h + (j & 3)) in element j of lane (r = lane & 15,
+// h = lane >> 4): the k order of an accumulator tile used as the B operand (cdna_hip_programming.md, accumulator as the next operand).
 struct Seg {
   int src;                      // source matrix
-  int o0, n_ot, o_stride;       // output (row) tiles: o0 + i o_stride, in units of 32
-  int k0, n_kt, k_stride;       // k tiles of 32 channels (two k-steps each)
+  int o0, n_ot, o_stride;       // output (row) tiles: o0 + i o_stride, in units of 32 (two 16-row MFMA tiles each: s = 0, 1)
+  int k0, n_kt, k_stride;       // k tiles of 32 channels (one k-step each)
   int order;                    // 0: (kt, s, ot)   1: (ot, kt, s)
 };
 constexpr int MAX_SEGS = 56, MAX_SRCS = 8;
@@ -483,13 +461,13 @@ __global__ void __launch_bounds__(64) k_nb_pack(PackArgs a) {
     ot = tile / (2 * sg.n_kt);
   }
   const Src sr = a.src[sg.src];
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-  const int o = 32 * (sg.o0 + ot * sg.o_stride) + r;
-  const int kb = 32 * (sg.k0 + kt * sg.k_stride) + 16 * s;
+  const int lane = threadIdx.x, r = lane & 15, h = lane >> 4;
+  const int o = 32 * (sg.o0 + ot * sg.o_stride) + 16 * s + r;   // s: the row half of the 32-row output tile
+  const int kb = 32 * (sg.k0 + kt * sg.k_stride);
   uint32_t hi[8], mid[8], lo[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int k = kb + 8 * (j >> 2) + 4 * h + (j & 3);
+    const int k = kb + 16 * (j >> 2) + 4 * h + (j & 3);
     const float v = (sr.transposed ? sr.p[(int64_t)k * sr.ld + o] : sr.p[(int64_t)o * sr.ld + k]) * sr.scale;
     const __bf16 bh = (__bf16)v;
     const float r1 = v - (float)bh;
@@ -547,11 +525,11 @@ struct LinTestArgs {
   int n_tiles, n_ot, form;
   float* y;
 };
-__global__ void __launch_bounds__(256, 1) k_nb_linear_test(LinTestArgs a) {
+__global__ void __launch_bounds__(256, 2) k_nb_linear_test(LinTestArgs a) {
   extern __shared__ uint4 ring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = lane & 31, h = lane >> 5;
-  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * 32 + n;
+  const int n = lane & 15, h = lane >> 4;   // node of the wave, channel quarter
+  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * WAVE_ROWS + n;
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
   NB_STAMP(0);
@@ -560,27 +538,26 @@ __global__ void __launch_bounds__(256, 1) k_nb_linear_test(LinTestArgs a) {
   w.init(a.wp, ring, a.n_tiles, lane, wave);
   const float* xr = a.x + row * 128;
   float* yr = a.y + row * (32 * a.n_ot);
-  f32x16 X[4];
+  tile_t X[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) X[t] = ld_tile(xr, 32 * t, h);
   if (a.form == 0) {   // 4 output tiles, program (kt, s, ot)
-    f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
+    tile_t acc[4] = {zero16(), zero16(), zero16(), zero16()};
 #pragma unroll
     for (int t = 0; t < 4; ++t) accum_tile<4>(w, acc, X[t]);
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) st_tile(yr, 32 * ot, h, acc[ot], ok);
   } else {             // n_ot output tiles, program (ot, kt, s)
-    Frag fx[8];
+    Frag fx[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      fx[2 * t] = split_k<0>(X[t]);
-      fx[2 * t + 1] = split_k<1>(X[t]);
+      fx[t] = split_t(X[t]);
     }
     NB_STAMP(1);
     if (a.form == 2) {   // pairs of output tiles, program (pair; kt, s, member)
       for (int ot = 0; ot < a.n_ot; ot += 2) {
-        f32x16 a0 = zero16(), a1 = zero16();
-        out_pair<8>(w, a0, a1, fx);
+        tile_t a0 = zero16(), a1 = zero16();
+        out_pair<4>(w, a0, a1, fx);
 #ifdef XEQ_NB_TEST_NOSTORE
         if (a0[0] == 12345.678f) { st_tile(yr, 32 * ot, h, a0, ok); st_tile(yr, 32 * ot + 32, h, a1, ok); }
 #else
@@ -590,8 +567,8 @@ __global__ void __launch_bounds__(256, 1) k_nb_linear_test(LinTestArgs a) {
       }
     } else
     for (int ot = 0; ot < a.n_ot; ++ot) {
-      f32x16 acc = zero16();
-      out_tile<8>(w, acc, fx);
+      tile_t acc = zero16();
+      out_tile<4>(w, acc, fx);
 #ifdef XEQ_NB_TEST_NOSTORE
       if (acc[0] == 12345.678f) st_tile(yr, 32 * ot, h, acc, ok);
 #else
@@ -622,15 +599,16 @@ struct FwdArgs {
 };
 
 template <bool TAIL>
-__global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
+__global__ void __launch_bounds__(256, 2) k_node_block_fwd(FwdArgs a) {
   extern __shared__ uint4 ring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = lane & 31, h = lane >> 5;
-  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * 32 + n;
+  const int n = lane & 15, h = lane >> 4;   // node of the wave, channel quarter
+  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * WAVE_ROWS + n;
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
   const int64_t N = a.n;
   NB_STAMP(0);
+  NB_RSTAMP(17);
   WStream w;
   w.init(a.wp, ring, a.n_tiles, lane, wave);
   const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
@@ -638,20 +616,20 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   const float* __restrict__ srow = a.s + row * F;
   const float* __restrict__ xrow = a.x + row * D;
   const int64_t wblk = (int64_t)blockIdx.x * 4 + wave;   // this wave's block of 32 nodes in the internal layout
-  float* __restrict__ pw = a.p + wblk * (P_TILES * 1024);
-  float* __restrict__ uvw = a.uv + wblk * (UV_TILES * 1024);
-  float* __restrict__ prew = a.pre + wblk * (S_TILES * 1024);
-  float* __restrict__ ipw = a.ip + wblk * (S_TILES * 1024);
-  float* __restrict__ aw = a.a + wblk * (A_TILES * 1024);
+  float* __restrict__ pw = a.p + wblk * (P_TILES * NAT_TILE);
+  float* __restrict__ uvw = a.uv + wblk * (UV_TILES * NAT_TILE);
+  float* __restrict__ prew = a.pre + wblk * (S_TILES * NAT_TILE);
+  float* __restrict__ ipw = a.ip + wblk * (S_TILES * NAT_TILE);
+  float* __restrict__ aw = a.a + wblk * (A_TILES * NAT_TILE);
   const bool wx = a.x_out != nullptr;
   const float e1 = a.eps, e2 = a.eps * a.eps;
 
-  f32x16 HID[4] = {zero16(), zero16(), zero16(), zero16()};   // update_mlp hidden pre-activation, accumulated chunk by chunk
+  tile_t HID[4] = {zero16(), zero16(), zero16(), zero16()};   // update_mlp hidden pre-activation, accumulated chunk by chunk
   float mean, rstd, mean0, rr;
   {
-    f32x16 X0[4];
+    tile_t X0[4];
     {  // ---- LayerNorm(s) (nn.LayerNorm: biased variance, eps 1e-5) -> first K chunk of update_mlp[0]
-      f32x16 S[4];
+      tile_t S[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) S[t] = ld_tile(srow, 32 * t, h);
 #pragma unroll
@@ -661,10 +639,10 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
       rstd = 1.f / sqrtf(var + 1e-5f);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x16 wv = ld_tile(a.lnw, 32 * t, h), bv = ld_tile(a.lnb, 32 * t, h);
-        f32x16 sh;
+        const tile_t wv = ld_tile(a.lnw, 32 * t, h), bv = ld_tile(a.lnb, 32 * t, h);
+        tile_t sh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sh[r] = (S[t][r] - mean) * rstd * wv[r] + bv[r];
+        for (int r = 0; r < 8; ++r) sh[r] = (S[t][r] - mean) * rstd * wv[r] + bv[r];
         accum_tile<4>(w, HID, sh);
       }
     }
@@ -672,45 +650,36 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
     // ---- EquivariantLayerNorm statistics (nn/o3layer.py:145-171): 0e channels centred, one rms over all channels
     mean0 = row_sum((sum16(X0[0]) + sum16(X0[1])) + (sum16(X0[2]) + sum16(X0[3]))) * (1.f / M0);
     float q = (sumsq16(X0[0], mean0) + sumsq16(X0[1], mean0)) + (sumsq16(X0[2], mean0) + sumsq16(X0[3], mean0));
-    {
-      f32x16 Xa[3], Xb[3], Xc[5];
-      ld_xm<3>(xrow + M0, h, Xa);
-      ld_xm<3>(xrow + M0 + 3 * 32, h, Xb);
-      ld_xm<5>(xrow + M0 + 3 * M1, h, Xc);
-      q += (sumsq16(Xa[0], 0.f) + sumsq16(Xa[1], 0.f)) + sumsq16(Xa[2], 0.f);
-      q += (sumsq16(Xb[0], 0.f) + sumsq16(Xb[1], 0.f)) + sumsq16(Xb[2], 0.f);
-      q += ((sumsq16(Xc[0], 0.f) + sumsq16(Xc[1], 0.f)) + (sumsq16(Xc[2], 0.f) + sumsq16(Xc[3], 0.f))) + sumsq16(Xc[4], 0.f);
-    }
+    q += sumsq_span<(D - M0) / 16>(xrow + M0, h);   // the l > 0 features: plain squares, no layout needed
     rr = 1.f / sqrtf(row_sum(q) * (1.f / C) + 1e-5f);
     if (ok && h == 0) *reinterpret_cast<float4*>(a.stats + 4 * row) = make_float4(mean, rstd, mean0, rr);
     NB_STAMP(3);
     // ---- l = 0: normalised features -> parked fragments
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 wv = ld_tile(a.eqw, 32 * t, h), bv = ld_tile(a.eqb, 32 * t, h);
-      f32x16 xh;
+      const tile_t wv = ld_tile(a.eqw, 32 * t, h), bv = ld_tile(a.eqb, 32 * t, h);
+      tile_t xh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xh[r] = (X0[t][r] - mean0) * rr * wv[r] + bv[r];
-      pk.put(2 * t, split_k<0>(xh));
-      pk.put(2 * t + 1, split_k<1>(xh));
+      for (int r = 0; r < 8; ++r) xh[r] = (X0[t][r] - mean0) * rr * wv[r] + bv[r];
+      pk.put(t, split_t(xh));
     }
   }
   // ---- l = 0: U, V (o3.Linear with bias), v = |V|, p = U V per channel tile
   for (int c = 0; c < 4; ++c) {
-    f32x16 bu = zero16(), bv = zero16();
+    tile_t bu = zero16(), bv = zero16();
     if (a.b_uv) {
       bu = ld_tile(a.b_uv, 32 * c, h);
       bv = ld_tile(a.b_uv + F, 32 * c, h);
     }
-    f32x16 U = zero16(), V = zero16();
-    out_pair_p<8>(w, U, V, pk);
+    tile_t U = zero16(), V = zero16();
+    out_pair_p<4>(w, U, V, pk);
     U += bu;
     V += bv;
     st_nat(uvw, uv_tile(0, 0, 0, c), lane, U);
     st_nat(uvw, uv_tile(0, 0, 1, c), lane, V);
-    f32x16 v, p;
+    tile_t v, p;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 8; ++r) {
       v[r] = sqrtf(__builtin_fmaf(V[r], V[r], e2)) - e1;
       p[r] = U[r] * V[r];
     }
@@ -719,31 +688,29 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   }
   NB_STAMP(4);
   {  // ---- l = 1
-    f32x16 X1[2][3];
+    tile_t X1[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X1[t]);
-      const f32x16 wv = ld_tile(a.eqw, M0 + 32 * t, h);
+      const tile_t wv = ld_tile(a.eqw, M0 + 32 * t, h);
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) X1[t][m][r] = X1[t][m][r] * rr * wv[r];
+        for (int r = 0; r < 8; ++r) X1[t][m][r] = X1[t][m][r] * rr * wv[r];
     }
-    f32x16 VSQ[2] = {zero16(), zero16()}, PP[2] = {zero16(), zero16()};
+    tile_t VSQ[2] = {zero16(), zero16()}, PP[2] = {zero16(), zero16()};
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      pk.put(0, split_k<0>(X1[0][m]));
-      pk.put(1, split_k<1>(X1[0][m]));
-      pk.put(2, split_k<0>(X1[1][m]));
-      pk.put(3, split_k<1>(X1[1][m]));
+      pk.put(0, split_t(X1[0][m]));
+      pk.put(1, split_t(X1[1][m]));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        f32x16 U = zero16(), V = zero16();
-        out_pair_p<4>(w, U, V, pk);
+        tile_t U = zero16(), V = zero16();
+        out_pair_p<2>(w, U, V, pk);
         st_nat(uvw, uv_tile(1, m, 0, c), lane, U);
         st_nat(uvw, uv_tile(1, m, 1, c), lane, V);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 8; ++r) {
           VSQ[c][r] = __builtin_fmaf(V[r], V[r], VSQ[c][r]);
           PP[c][r] = __builtin_fmaf(U[r], V[r], PP[c][r]);
         }
@@ -752,40 +719,39 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       st_nat(pw, 4 + c, lane, PP[c]);
-      f32x16 v;
+      tile_t v;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = sqrtf(VSQ[c][r] + e2) - e1;
+      for (int r = 0; r < 8; ++r) v[r] = sqrtf(VSQ[c][r] + e2) - e1;
       accum_tile<4>(w, HID, v);
     }
   }
   NB_STAMP(5);
   {  // ---- l = 2
-    f32x16 X2[5];
+    tile_t X2[5];
     ld_xm<5>(xrow + M0 + 3 * M1, h, X2);
-    const f32x16 wv = ld_tile(a.eqw, M0 + M1, h);
+    const tile_t wv = ld_tile(a.eqw, M0 + M1, h);
 #pragma unroll
     for (int m = 0; m < 5; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) X2[m][r] = X2[m][r] * rr * wv[r];
-    f32x16 VSQ = zero16(), PP = zero16();
+      for (int r = 0; r < 8; ++r) X2[m][r] = X2[m][r] * rr * wv[r];
+    tile_t VSQ = zero16(), PP = zero16();
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      pk.put(0, split_k<0>(X2[m]));
-      pk.put(1, split_k<1>(X2[m]));
-      f32x16 U = zero16(), V = zero16();
-      out_pair_p<2>(w, U, V, pk);
+      pk.put(0, split_t(X2[m]));
+      tile_t U = zero16(), V = zero16();
+      out_pair_p<1>(w, U, V, pk);
       st_nat(uvw, uv_tile(2, m, 0, 0), lane, U);
       st_nat(uvw, uv_tile(2, m, 1, 0), lane, V);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         VSQ[r] = __builtin_fmaf(V[r], V[r], VSQ[r]);
         PP[r] = __builtin_fmaf(U[r], V[r], PP[r]);
       }
     }
     st_nat(pw, 6, lane, PP);
-    f32x16 v;
+    tile_t v;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = sqrtf(VSQ[r] + e2) - e1;
+    for (int r = 0; r < 8; ++r) v[r] = sqrtf(VSQ[r] + e2) - e1;
     accum_tile<4>(w, HID, v);
   }
   NB_STAMP(6);
@@ -794,11 +760,10 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   for (int t = 0; t < 4; ++t) {
     HID[t] += ld_tile(a.b3, 32 * t, h);
     st_nat(prew, t, lane, HID[t]);
-    f32x16 hv;
+    tile_t hv;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hv[r] = silu_f(HID[t][r]);
-    pk.put(2 * t, split_k<0>(hv));
-    pk.put(2 * t + 1, split_k<1>(hv));
+    for (int r = 0; r < 8; ++r) hv[r] = silu_f(HID[t][r]);
+    pk.put(t, split_t(hv));
   }
   NB_STAMP(7);
   float* __restrict__ xor_ = wx ? a.x_out + row * D : nullptr;
@@ -806,63 +771,61 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   // ---- a_vv tiles and the equivariant residual update x_out = x + U a_vv (nn/xpainn.py:218-219, 229); the epilogue's operands
   // (U of this lane's own stores, x, the bias) are requested in front of the tile's products
   for (int c = 0; c < 4; ++c) {
-    const f32x16 b4v = ld_tile(a.b4, 32 * c, h);
-    f32x16 U = zero16(), X0c = zero16();
+    const tile_t b4v = ld_tile(a.b4, 32 * c, h);
+    tile_t U = zero16(), X0c = zero16();
     if (wx) {
       U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane);
       X0c = ld_tile(xrow, 32 * c, h);
     }
-    f32x16 av = zero16();
-    out_tile_p<8>(w, av, pk);
+    tile_t av = zero16();
+    out_tile_p<4>(w, av, pk);
     av += b4v;
     st_nat(aw, c, lane, av);
     if (wx) {
-      f32x16 xn;
+      tile_t xn;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xn[r] = __builtin_fmaf(U[r], av[r], X0c[r]);
+      for (int r = 0; r < 8; ++r) xn[r] = __builtin_fmaf(U[r], av[r], X0c[r]);
       st_tile(xor_, 32 * c, h, xn, ok);
       if (TAIL) s0 += sum16(xn);
     }
   }
   for (int c = 0; c < 2; ++c) {
-    const f32x16 b4v = ld_tile(a.b4, M0 + 32 * c, h);
-    f32x16 X[3], U[3];
-    if (wx) {
-      ld_xm<3>(xrow + M0 + 3 * 32 * c, h, X);
-#pragma unroll
-      for (int m = 0; m < 3; ++m) U[m] = ld_nat(uvw, uv_tile(1, m, 0, c), lane);
-    }
-    f32x16 av = zero16();
-    out_tile_p<8>(w, av, pk);
+    const tile_t b4v = ld_tile(a.b4, M0 + 32 * c, h);
+    tile_t X[3];
+    if (wx) ld_xm<3>(xrow + M0 + 3 * 32 * c, h, X);
+    tile_t av = zero16();
+    out_tile_p<4>(w, av, pk);
     av += b4v;
     st_nat(aw, 4 + c, lane, av);
     if (wx) {
+      tile_t U[3];   // (this lane's own stores; fetched behind the products: two waves share the SIMD, the registers are worth more than the latency)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) U[m] = ld_nat(uvw, uv_tile(1, m, 0, c), lane);
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) X[m][r] = __builtin_fmaf(U[m][r], av[r], X[m][r]);
+        for (int r = 0; r < 8; ++r) X[m][r] = __builtin_fmaf(U[m][r], av[r], X[m][r]);
         if (TAIL) q2 += sumsq16(X[m], 0.f);
       }
       st_xm<3>(xor_ + M0 + 3 * 32 * c, h, X, ok);
     }
   }
   {
-    const f32x16 b4v = ld_tile(a.b4, M0 + M1, h);
-    f32x16 X[5], U[5];
-    if (wx) {
-      ld_xm<5>(xrow + M0 + 3 * M1, h, X);
-#pragma unroll
-      for (int m = 0; m < 5; ++m) U[m] = ld_nat(uvw, uv_tile(2, m, 0, 0), lane);
-    }
-    f32x16 av = zero16();
-    out_tile_p<8>(w, av, pk);
+    const tile_t b4v = ld_tile(a.b4, M0 + M1, h);
+    tile_t X[5];
+    if (wx) ld_xm<5>(xrow + M0 + 3 * M1, h, X);
+    tile_t av = zero16();
+    out_tile_p<4>(w, av, pk);
     av += b4v;
     st_nat(aw, 6, lane, av);
     if (wx) {
+      tile_t U[5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) U[m] = ld_nat(uvw, uv_tile(2, m, 0, 0), lane);
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) X[m][r] = __builtin_fmaf(U[m][r], av[r], X[m][r]);
+        for (int r = 0; r < 8; ++r) X[m][r] = __builtin_fmaf(U[m][r], av[r], X[m][r]);
         if (TAIL) q2 += sumsq16(X[m], 0.f);
       }
       st_xm<5>(xor_ + M0 + 3 * M1, h, X, ok);
@@ -870,30 +833,30 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   }
   NB_STAMP(8);
   // ---- dot_lin over the p tiles this lane stored (nn/xpainn.py:222-223)
-  f32x16 IP[4] = {zero16(), zero16(), zero16(), zero16()};
+  tile_t IP[4] = {zero16(), zero16(), zero16(), zero16()};
   {
-    f32x16 pt = ld_nat(pw, 0, lane);
+    tile_t pt = ld_nat(pw, 0, lane);
     for (int t = 0; t < 7; ++t) {
-      const f32x16 cur = pt;
+      const tile_t cur = pt;
       if (t + 1 < 7) pt = ld_nat(pw, t + 1, lane);
       accum_tile<4>(w, IP, cur);
     }
   }
   // ---- (a_sv, a_ss) per scalar tile and the scalar residual update s_out = s + a_sv dot_lin(p) + a_ss (nn/xpainn.py:221-228)
-  f32x16 SN[4];
+  tile_t SN[4];
   float* __restrict__ sor = a.s_out + row * F;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const f32x16 bsv = ld_tile(a.b4, C + 32 * c, h), bss = ld_tile(a.b4, C + F + 32 * c, h), S = ld_tile(srow, 32 * c, h);
+    const tile_t bsv = ld_tile(a.b4, C + 32 * c, h), bss = ld_tile(a.b4, C + F + 32 * c, h), S = ld_tile(srow, 32 * c, h);
     st_nat(ipw, c, lane, IP[c]);
-    f32x16 asv = zero16(), ass = zero16();
-    out_pair_p<8>(w, asv, ass, pk);
+    tile_t asv = zero16(), ass = zero16();
+    out_pair_p<4>(w, asv, ass, pk);
     asv += bsv;
     ass += bss;
     st_nat(aw, 7 + c, lane, asv);
     st_nat(aw, 11 + c, lane, ass);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) SN[c][r] = (S[r] + asv[r] * IP[c][r]) + ass[r];
+    for (int r = 0; r < 8; ++r) SN[c][r] = (S[r] + asv[r] * IP[c][r]) + ass[r];
     st_tile(sor, 32 * c, h, SN[c], ok);
   }
   NB_STAMP(9);
@@ -905,16 +868,16 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   const float rstd_n = 1.f / sqrtf(var_n + 1e-5f);
   const float mean0_n = row_sum(s0) * (1.f / M0);
   // the new 0e features (this lane's own stores) once more for the centred second moment, the l > 0 blocks for xhat
-  f32x16 XN0[4];
+  tile_t XN0[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) XN0[t] = ld_tile(xor_, 32 * t, h);
-  f32x16 HN[4] = {zero16(), zero16(), zero16(), zero16()};
+  tile_t HN[4] = {zero16(), zero16(), zero16(), zero16()};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const f32x16 wv = ld_tile(a.lnw2, 32 * t, h), bv = ld_tile(a.lnb2, 32 * t, h);
-    f32x16 sh;
+    const tile_t wv = ld_tile(a.lnw2, 32 * t, h), bv = ld_tile(a.lnb2, 32 * t, h);
+    tile_t sh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sh[r] = (SN[t][r] - mean_n) * rstd_n * wv[r] + bv[r];
+    for (int r = 0; r < 8; ++r) sh[r] = (SN[t][r] - mean_n) * rstd_n * wv[r] + bv[r];
     accum_tile<4>(w, HN, sh);
   }
   NB_STAMP(10);
@@ -924,10 +887,10 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
   // xhat of the next block, BT layout (block l at N base_l, row (node, m), channels contiguous)
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const f32x16 wv = ld_tile(a.eqw2, 32 * t, h), bv = ld_tile(a.eqb2, 32 * t, h);
-    f32x16 xh;
+    const tile_t wv = ld_tile(a.eqw2, 32 * t, h), bv = ld_tile(a.eqb2, 32 * t, h);
+    tile_t xh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xh[r] = (XN0[t][r] - mean0_n) * rr_n * wv[r] + bv[r];
+    for (int r = 0; r < 8; ++r) xh[r] = (XN0[t][r] - mean0_n) * rr_n * wv[r] + bv[r];
     st_tile(a.xhat2 + row * M0, 32 * t, h, xh, ok);
   }
   NB_STAMP(11);
@@ -935,37 +898,36 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     HN[t] += ld_tile(a.b1n, 32 * t, h);
-    st_nat(a.pre2 + wblk * (S_TILES * 1024), t, lane, HN[t]);
-    f32x16 hv;
+    st_nat(a.pre2 + wblk * (S_TILES * NAT_TILE), t, lane, HN[t]);
+    tile_t hv;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hv[r] = silu_f(HN[t][r]);
-    pk.put(2 * t, split_k<0>(hv));
-    pk.put(2 * t + 1, split_k<1>(hv));
+    for (int r = 0; r < 8; ++r) hv[r] = silu_f(HN[t][r]);
+    pk.put(t, split_t(hv));
   }
   NB_STAMP(12);
   // scalar_mlp[2], two output tiles at a time; the l > 0 blocks of xhat (from this lane's own x_out stores) ride along
   float* __restrict__ hrow = a.h2 + row * HM;
   {
-    f32x16 XC[5];
+    tile_t XC[5];
     ld_xm<5>(xor_ + M0 + 3 * M1, h, XC);
-    const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
+    const tile_t wv = ld_tile(a.eqw2, M0 + M1, h);
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) XC[m][r] = XC[m][r] * rr_n * wv[r];
+      for (int r = 0; r < 8; ++r) XC[m][r] = XC[m][r] * rr_n * wv[r];
       st_tile(a.xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h, XC[m], ok);
     }
   }
   for (int j = 0; j < HM / 64; ++j) {
-    const f32x16 b0 = ld_tile(a.b2n, 64 * j, h), b1 = ld_tile(a.b2n, 64 * j + 32, h);
-    f32x16 XA[3];
-    f32x16 wa = zero16();
+    const tile_t b0 = ld_tile(a.b2n, 64 * j, h), b1 = ld_tile(a.b2n, 64 * j + 32, h);
+    tile_t XA[3];
+    tile_t wa = zero16();
     if (j < 2) {
       ld_xm<3>(xor_ + M0 + 3 * 32 * j, h, XA);
       wa = ld_tile(a.eqw2, M0 + 32 * j, h);
     }
-    f32x16 a0 = zero16(), a1 = zero16();
-    out_pair_p<8>(w, a0, a1, pk);
+    tile_t a0 = zero16(), a1 = zero16();
+    out_pair_p<4>(w, a0, a1, pk);
     a0 += b0;
     a1 += b1;
     st_tile(hrow, 64 * j, h, a0, ok);
@@ -974,16 +936,21 @@ __global__ void __launch_bounds__(256, 1) k_node_block_fwd(FwdArgs a) {
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) XA[m][r] = XA[m][r] * rr_n * wa[r];
+        for (int r = 0; r < 8; ++r) XA[m][r] = XA[m][r] * rr_n * wa[r];
         st_tile(a.xhat2 + N * M0 + (row * 3 + m) * M1, 32 * j, h, XA[m], ok);
       }
     }
   }
   NB_STAMP(13);
+  NB_RSTAMP(18);
 #ifdef XEQ_NB_STAMPS
   if (lane == 0 && blockIdx.x < 1024) {
     g_nb_stamps[((int)blockIdx.x * 4 + wave) * NB_STAMPS + 14] = w.t_commit;
     g_nb_stamps[((int)blockIdx.x * 4 + wave) * NB_STAMPS + 15] = w.t_barrier;
+    unsigned hw_, xcc_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+    g_nb_stamps[((int)blockIdx.x * 4 + wave) * NB_STAMPS + 16] = ((unsigned long long)xcc_ << 32) | hw_;
   }
 #endif
 }
@@ -1027,14 +994,14 @@ struct BwdArgs {
 
 // LayerNorm reverse on four scalar tiles, in place: g <- rstd (dy - mean(dy) - yh mean(dy yh)) + res, dy = g w, yh = (s - mean) rstd
 // (two sweeps over the row's s and weight tiles: they are re-read rather than held)
-__device__ __forceinline__ void ln_bwd(f32x16 (&g)[4], const float* __restrict__ srow, const float* __restrict__ lnw, float mean, float rstd,
-                                       const f32x16 (&res)[4], int h) {
+__device__ __forceinline__ void ln_bwd(tile_t (&g)[4], const float* __restrict__ srow, const float* __restrict__ lnw, float mean, float rstd,
+                                       const tile_t (&res)[4], int h) {
   float a1 = 0.f, a2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const f32x16 wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
+    const tile_t wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 8; ++r) {
       const float dy = g[t][r] * wv[r];
       a1 += dy;
       a2 = __builtin_fmaf(dy, (sv[r] - mean) * rstd, a2);
@@ -1044,18 +1011,18 @@ __device__ __forceinline__ void ln_bwd(f32x16 (&g)[4], const float* __restrict__
   a2 = row_sum(a2) * (1.f / F);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const f32x16 wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
+    const tile_t wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g[t][r] = rstd * (g[t][r] * wv[r] - a1 - ((sv[r] - mean) * rstd) * a2) + res[t][r];
+    for (int r = 0; r < 8; ++r) g[t][r] = rstd * (g[t][r] * wv[r] - a1 - ((sv[r] - mean) * rstd) * a2) + res[t][r];
   }
 }
 
 template <bool TAIL, bool GX>
-__global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
+__global__ void __launch_bounds__(256, 2) k_node_block_bwd(BwdArgs a) {
   extern __shared__ uint4 ring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = lane & 31, h = lane >> 5;
-  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * 32 + n;
+  const int n = lane & 15, h = lane >> 4;   // node of the wave, channel quarter
+  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * WAVE_ROWS + n;
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
   const int64_t N = a.n;
@@ -1064,40 +1031,39 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
   const float e2 = a.eps * a.eps;
   const int64_t wblk = (int64_t)blockIdx.x * 4 + wave;   // this wave's block of 32 nodes in the internal layout
-  float* __restrict__ gxow = a.gxo + wblk * (X_TILES * 1024);   // total dL/dx_out (GX)
-  float* __restrict__ gww = a.gw + wblk * (X_TILES * 1024);
-  float* __restrict__ gpw = a.gp + wblk * (P_TILES * 1024);
-  float* __restrict__ gvw = a.gv + wblk * (P_TILES * 1024);
-  const float* __restrict__ uvw = a.uv + wblk * (UV_TILES * 1024);
-  const float* __restrict__ aw = a.a + wblk * (A_TILES * 1024);
-  const float* __restrict__ prew = a.pre + wblk * (S_TILES * 1024);
-  const float* __restrict__ ipw = a.ip + wblk * (S_TILES * 1024);
+  float* __restrict__ gxow = a.gxo + wblk * (X_TILES * NAT_TILE);   // total dL/dx_out (GX)
+  float* __restrict__ gww = a.gw + wblk * (X_TILES * NAT_TILE);
+  float* __restrict__ gpw = a.gp + wblk * (P_TILES * NAT_TILE);
+  float* __restrict__ gvw = a.gv + wblk * (P_TILES * NAT_TILE);
+  const float* __restrict__ uvw = a.uv + wblk * (UV_TILES * NAT_TILE);
+  const float* __restrict__ aw = a.a + wblk * (A_TILES * NAT_TILE);
+  const float* __restrict__ prew = a.pre + wblk * (S_TILES * NAT_TILE);
+  const float* __restrict__ ipw = a.ip + wblk * (S_TILES * NAT_TILE);
 
-  f32x16 GS[4];   // total dL/ds_out
+  tile_t GS[4];   // total dL/ds_out
   if (TAIL) {
     // ---- reverse of scalar_mlp (nn/xpainn.py:139): g_hidden' = (W2'^T g_h) silu'(pre'), g_shat' = W1'^T g_hidden'
-    f32x16 GH[4] = {zero16(), zero16(), zero16(), zero16()};
+    tile_t GH[4] = {zero16(), zero16(), zero16(), zero16()};
     const float* __restrict__ ghr = a.g_h + row * HM;
-    f32x16 gt = ld_tile(ghr, 0, h);
+    tile_t gt = ld_tile(ghr, 0, h);
     for (int kt = 0; kt < HM / 32; ++kt) {
-      const f32x16 cur = gt;
+      const tile_t cur = gt;
       if (kt + 1 < HM / 32) gt = ld_tile(ghr, 32 * (kt + 1), h);
       accum_tile<4>(w, GH, cur);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 pv = ld_nat(a.pre2 + wblk * (S_TILES * 1024), t, lane);
-      f32x16 gv;
+      const tile_t pv = ld_nat(a.pre2 + wblk * (S_TILES * NAT_TILE), t, lane);
+      tile_t gv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gv[r] = GH[t][r] * silu_grad_f(pv[r]);
-      pk.put(2 * t, split_k<0>(gv));
-      pk.put(2 * t + 1, split_k<1>(gv));
+      for (int r = 0; r < 8; ++r) gv[r] = GH[t][r] * silu_grad_f(pv[r]);
+      pk.put(t, split_t(gv));
     }
-    f32x16 gsh[4] = {zero16(), zero16(), zero16(), zero16()}, res[4];
+    tile_t gsh[4] = {zero16(), zero16(), zero16(), zero16()}, res[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       res[t] = ld_tile(a.g_s_in + row * F, 32 * t, h);
-      out_tile_p<8>(w, gsh[t], pk);
+      out_tile_p<4>(w, gsh[t], pk);
     }
     const float4 st2 = *reinterpret_cast<const float4*>(a.stats2 + 4 * row);
     ln_bwd(gsh, a.s_out + row * F, a.lnw2, st2.x, st2.y, res, h);
@@ -1110,9 +1076,9 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     float dotp = 0.f, sgw0 = 0.f, sxc0 = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_tile(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h);
+      const tile_t g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_tile(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         const float gw = g[r] * wv[r], xc = xv[r] - mean0;
         dotp = __builtin_fmaf(gw, xc, dotp);
         sgw0 += gw;
@@ -1121,63 +1087,63 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      f32x16 X[3];
+      tile_t X[3];
       ld_xm<3>(xo + M0 + 3 * 32 * t, h, X);
-      const f32x16 wv = ld_tile(a.eqw2, M0 + 32 * t, h);
+      const tile_t wv = ld_tile(a.eqw2, M0 + 32 * t, h);
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        const f32x16 g = ld_tile(a.g_xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h);
+        const tile_t g = ld_tile(a.g_xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dotp = __builtin_fmaf(g[r] * wv[r], X[m][r], dotp);
+        for (int r = 0; r < 8; ++r) dotp = __builtin_fmaf(g[r] * wv[r], X[m][r], dotp);
       }
     }
     {
-      f32x16 X[5];
+      tile_t X[5];
       ld_xm<5>(xo + M0 + 3 * M1, h, X);
-      const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
+      const tile_t wv = ld_tile(a.eqw2, M0 + M1, h);
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
-        const f32x16 g = ld_tile(a.g_xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h);
+        const tile_t g = ld_tile(a.g_xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dotp = __builtin_fmaf(g[r] * wv[r], X[m][r], dotp);
+        for (int r = 0; r < 8; ++r) dotp = __builtin_fmaf(g[r] * wv[r], X[m][r], dotp);
       }
     }
     const float coef = row_sum(dotp) * r2 * r2 * r2 * (1.f / C);
     const float gmean = (r2 * row_sum(sgw0) - coef * row_sum(sxc0)) * (1.f / M0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_tile(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h),
+      const tile_t g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_tile(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h),
                    rv = ld_tile(gxi, 32 * t, h);
-      f32x16 o;
+      tile_t o;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = ((r2 * (g[r] * wv[r]) - coef * (xv[r] - mean0)) - gmean) + rv[r];
+      for (int r = 0; r < 8; ++r) o[r] = ((r2 * (g[r] * wv[r]) - coef * (xv[r] - mean0)) - gmean) + rv[r];
       st_nat(gxow, x_tile(0, 0, t), lane, o);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      f32x16 X[3], R[3];
+      tile_t X[3], R[3];
       ld_xm<3>(xo + M0 + 3 * 32 * t, h, X);
       ld_xm<3>(gxi + M0 + 3 * 32 * t, h, R);
-      const f32x16 wv = ld_tile(a.eqw2, M0 + 32 * t, h);
+      const tile_t wv = ld_tile(a.eqw2, M0 + 32 * t, h);
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        const f32x16 g = ld_tile(a.g_xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h);
+        const tile_t g = ld_tile(a.g_xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) X[m][r] = (r2 * (g[r] * wv[r]) - coef * X[m][r]) + R[m][r];
+        for (int r = 0; r < 8; ++r) X[m][r] = (r2 * (g[r] * wv[r]) - coef * X[m][r]) + R[m][r];
       }
 #pragma unroll
       for (int m = 0; m < 3; ++m) st_nat(gxow, x_tile(1, m, t), lane, X[m]);
     }
     {
-      f32x16 X[5], R[5];
+      tile_t X[5], R[5];
       ld_xm<5>(xo + M0 + 3 * M1, h, X);
       ld_xm<5>(gxi + M0 + 3 * M1, h, R);
-      const f32x16 wv = ld_tile(a.eqw2, M0 + M1, h);
+      const tile_t wv = ld_tile(a.eqw2, M0 + M1, h);
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
-        const f32x16 g = ld_tile(a.g_xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h);
+        const tile_t g = ld_tile(a.g_xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) X[m][r] = (r2 * (g[r] * wv[r]) - coef * X[m][r]) + R[m][r];
+        for (int r = 0; r < 8; ++r) X[m][r] = (r2 * (g[r] * wv[r]) - coef * X[m][r]) + R[m][r];
       }
 #pragma unroll
       for (int m = 0; m < 5; ++m) st_nat(gxow, x_tile(2, m, 0), lane, X[m]);
@@ -1191,12 +1157,12 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
       for (int t = 0; t < 4; ++t) st_nat(gxow, x_tile(0, 0, t), lane, ld_tile(gxi, 32 * t, h));
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        f32x16 R[3];
+        tile_t R[3];
         ld_xm<3>(gxi + M0 + 3 * 32 * t, h, R);
 #pragma unroll
         for (int m = 0; m < 3; ++m) st_nat(gxow, x_tile(1, m, t), lane, R[m]);
       }
-      f32x16 R[5];
+      tile_t R[5];
       ld_xm<5>(gxi + M0 + 3 * M1, h, R);
 #pragma unroll
       for (int m = 0; m < 5; ++m) st_nat(gxow, x_tile(2, m, 0), lane, R[m]);
@@ -1204,44 +1170,44 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   }
 
   // ---- reverse of the output stage (nn/xpainn.py:218-229) into the reverse of update_mlp[2]: g_hidden += W4^T[:, chunk] g_a[chunk]
-  f32x16 GHID[4] = {zero16(), zero16(), zero16(), zero16()};
+  tile_t GHID[4] = {zero16(), zero16(), zero16(), zero16()};
   if (GX) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {   // g_a_vv = sum_m g_x_out U
-      const f32x16 U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane), G = ld_nat(gxow, x_tile(0, 0, c), lane);
-      f32x16 ga;
+      const tile_t U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane), G = ld_nat(gxow, x_tile(0, 0, c), lane);
+      tile_t ga;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ga[r] = G[r] * U[r];
+      for (int r = 0; r < 8; ++r) ga[r] = G[r] * U[r];
       accum_tile<4>(w, GHID, ga);
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      f32x16 ga = zero16();
+      tile_t ga = zero16();
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        const f32x16 U = ld_nat(uvw, uv_tile(1, m, 0, c), lane), G = ld_nat(gxow, x_tile(1, m, c), lane);
+        const tile_t U = ld_nat(uvw, uv_tile(1, m, 0, c), lane), G = ld_nat(gxow, x_tile(1, m, c), lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ga[r] = __builtin_fmaf(G[r], U[r], ga[r]);
+        for (int r = 0; r < 8; ++r) ga[r] = __builtin_fmaf(G[r], U[r], ga[r]);
       }
       accum_tile<4>(w, GHID, ga);
     }
     {
-      f32x16 ga = zero16();
+      tile_t ga = zero16();
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
-        const f32x16 U = ld_nat(uvw, uv_tile(2, m, 0, 0), lane), G = ld_nat(gxow, x_tile(2, m, 0), lane);
+        const tile_t U = ld_nat(uvw, uv_tile(2, m, 0, 0), lane), G = ld_nat(gxow, x_tile(2, m, 0), lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ga[r] = __builtin_fmaf(G[r], U[r], ga[r]);
+        for (int r = 0; r < 8; ++r) ga[r] = __builtin_fmaf(G[r], U[r], ga[r]);
       }
       accum_tile<4>(w, GHID, ga);
     }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {   // g_a_sv = g_s_out ip
-    const f32x16 ipv = ld_nat(ipw, c, lane);
-    f32x16 ga;
+    const tile_t ipv = ld_nat(ipw, c, lane);
+    tile_t ga;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ga[r] = GS[c][r] * ipv[r];
+    for (int r = 0; r < 8; ++r) ga[r] = GS[c][r] * ipv[r];
     accum_tile<4>(w, GHID, ga);
   }
 #pragma unroll
@@ -1250,40 +1216,38 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   {  // ---- g_hidden silu'(pre) -> fragments; g_shat = W3^T[:F] g_hidden -> LayerNorm reverse -> g_s; g_v = W3^T[F:] g_hidden
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 pv = ld_nat(prew, t, lane);
-      f32x16 gv;
+      const tile_t pv = ld_nat(prew, t, lane);
+      tile_t gv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gv[r] = GHID[t][r] * silu_grad_f(pv[r]);
-      pk.put(2 * t, split_k<0>(gv));
-      pk.put(2 * t + 1, split_k<1>(gv));
+      for (int r = 0; r < 8; ++r) gv[r] = GHID[t][r] * silu_grad_f(pv[r]);
+      pk.put(t, split_t(gv));
     }
     {
-      f32x16 gsh[4] = {zero16(), zero16(), zero16(), zero16()};
+      tile_t gsh[4] = {zero16(), zero16(), zero16(), zero16()};
 #pragma unroll
-      for (int t = 0; t < 4; ++t) out_tile_p<8>(w, gsh[t], pk);
+      for (int t = 0; t < 4; ++t) out_tile_p<4>(w, gsh[t], pk);
       ln_bwd(gsh, a.s + row * F, a.lnw, st.x, st.y, GS, h);
 #pragma unroll
       for (int t = 0; t < 4; ++t) st_tile(a.g_s + row * F, 32 * t, h, gsh[t], ok);
     }
     for (int t = 0; t < 7; ++t) {   // parked in scratch for the per-block sweeps
-      f32x16 acc = zero16();
-      out_tile_p<8>(w, acc, pk);
+      tile_t acc = zero16();
+      out_tile_p<4>(w, acc, pk);
       st_nat(gvw, t, lane, acc);
     }
   }
   {  // ---- g_ip = g_s_out a_sv -> fragments; g_p = dot_lin^T g_ip, seven channel tiles
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 asv = ld_nat(aw, 7 + t, lane);
-      f32x16 gi;
+      const tile_t asv = ld_nat(aw, 7 + t, lane);
+      tile_t gi;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gi[r] = GS[t][r] * asv[r];
-      pk.put(2 * t, split_k<0>(gi));
-      pk.put(2 * t + 1, split_k<1>(gi));
+      for (int r = 0; r < 8; ++r) gi[r] = GS[t][r] * asv[r];
+      pk.put(t, split_t(gi));
     }
     for (int t = 0; t < 7; ++t) {
-      f32x16 acc = zero16();
-      out_tile_p<8>(w, acc, pk);
+      tile_t acc = zero16();
+      out_tile_p<4>(w, acc, pk);
       st_nat(gpw, t, lane, acc);
     }
   }
@@ -1293,31 +1257,31 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   const float* __restrict__ xrow = a.x + row * D;
   float dotp = 0.f, sgw0 = 0.f, sxc0 = 0.f;
   {
-    f32x16 GXH[4] = {zero16(), zero16(), zero16(), zero16()};
+    tile_t GXH[4] = {zero16(), zero16(), zero16(), zero16()};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const f32x16 U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane), V = ld_nat(uvw, uv_tile(0, 0, 1, c), lane), gp = ld_nat(gpw, c, lane),
+      const tile_t U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane), V = ld_nat(uvw, uv_tile(0, 0, 1, c), lane), gp = ld_nat(gpw, c, lane),
                    gv = ld_nat(gvw, c, lane);
-      f32x16 gU, gV;
+      tile_t gU, gV;
       if (GX) {
-        const f32x16 G = ld_nat(gxow, x_tile(0, 0, c), lane), av = ld_nat(aw, c, lane);
+        const tile_t G = ld_nat(gxow, x_tile(0, 0, c), lane), av = ld_nat(aw, c, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gU[r] = __builtin_fmaf(G[r], av[r], gp[r] * V[r]);
+        for (int r = 0; r < 8; ++r) gU[r] = __builtin_fmaf(G[r], av[r], gp[r] * V[r]);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gU[r] = gp[r] * V[r];
+        for (int r = 0; r < 8; ++r) gU[r] = gp[r] * V[r];
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gV[r] = __builtin_fmaf(gp[r], U[r], gv[r] / sqrtf(__builtin_fmaf(V[r], V[r], e2)) * V[r]);
+      for (int r = 0; r < 8; ++r) gV[r] = __builtin_fmaf(gp[r], U[r], gv[r] / sqrtf(__builtin_fmaf(V[r], V[r], e2)) * V[r]);
       accum_tile<4>(w, GXH, gU);
       accum_tile<4>(w, GXH, gV);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x16 wv = ld_tile(a.eqw, 32 * t, h), xv = ld_tile(xrow, 32 * t, h);
-      f32x16 gw;
+      const tile_t wv = ld_tile(a.eqw, 32 * t, h), xv = ld_tile(xrow, 32 * t, h);
+      tile_t gw;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         gw[r] = GXH[t][r] * wv[r];
         const float xc = xv[r] - mean0;
         dotp = __builtin_fmaf(gw[r], xc, dotp);
@@ -1328,7 +1292,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     }
   }
   {
-    f32x16 GXH[3][2];
+    tile_t GXH[3][2];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       GXH[m][0] = zero16();
@@ -1336,30 +1300,30 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const f32x16 gp = ld_nat(gpw, 4 + c, lane), gv = ld_nat(gvw, 4 + c, lane);
-      f32x16 U[3], V[3], G[3];
-      f32x16 vv = zero16();
+      const tile_t gp = ld_nat(gpw, 4 + c, lane), gv = ld_nat(gvw, 4 + c, lane);
+      tile_t U[3], V[3], G[3];
+      tile_t vv = zero16();
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
         U[m] = ld_nat(uvw, uv_tile(1, m, 0, c), lane);
         V[m] = ld_nat(uvw, uv_tile(1, m, 1, c), lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) vv[r] = __builtin_fmaf(V[m][r], V[m][r], vv[r]);
+        for (int r = 0; r < 8; ++r) vv[r] = __builtin_fmaf(V[m][r], V[m][r], vv[r]);
       }
-      f32x16 av = zero16();
+      tile_t av = zero16();
       if (GX) {
 #pragma unroll
         for (int m = 0; m < 3; ++m) G[m] = ld_nat(gxow, x_tile(1, m, c), lane);
         av = ld_nat(aw, 4 + c, lane);
       }
-      f32x16 gvn;
+      tile_t gvn;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gvn[r] = gv[r] / sqrtf(vv[r] + e2);
+      for (int r = 0; r < 8; ++r) gvn[r] = gv[r] / sqrtf(vv[r] + e2);
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        f32x16 gU, gV;
+        tile_t gU, gV;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 8; ++r) {
           gU[r] = GX ? __builtin_fmaf(G[m][r], av[r], gp[r] * V[m][r]) : gp[r] * V[m][r];
           gV[r] = __builtin_fmaf(gp[r], U[m][r], gvn[r] * V[m][r]);
         }
@@ -1369,13 +1333,13 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      f32x16 X[3], GW[3];
+      tile_t X[3], GW[3];
       ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
-      const f32x16 wv = ld_tile(a.eqw, M0 + 32 * t, h);
+      const tile_t wv = ld_tile(a.eqw, M0 + 32 * t, h);
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 8; ++r) {
           GW[m][r] = GXH[m][t][r] * wv[r];
           dotp = __builtin_fmaf(GW[m][r], X[m][r], dotp);
         }
@@ -1384,46 +1348,46 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
     }
   }
   {
-    f32x16 GXH[5][1];
+    tile_t GXH[5][1];
 #pragma unroll
     for (int m = 0; m < 5; ++m) GXH[m][0] = zero16();
-    const f32x16 gp = ld_nat(gpw, 6, lane), gv = ld_nat(gvw, 6, lane);
-    f32x16 G[5];
-    f32x16 av = zero16();
+    const tile_t gp = ld_nat(gpw, 6, lane), gv = ld_nat(gvw, 6, lane);
+    tile_t G[5];
+    tile_t av = zero16();
     if (GX) {
 #pragma unroll
       for (int m = 0; m < 5; ++m) G[m] = ld_nat(gxow, x_tile(2, m, 0), lane);
       av = ld_nat(aw, 6, lane);
     }
-    f32x16 vv = zero16();
+    tile_t vv = zero16();
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      const f32x16 V = ld_nat(uvw, uv_tile(2, m, 1, 0), lane);
+      const tile_t V = ld_nat(uvw, uv_tile(2, m, 1, 0), lane);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) vv[r] = __builtin_fmaf(V[r], V[r], vv[r]);
+      for (int r = 0; r < 8; ++r) vv[r] = __builtin_fmaf(V[r], V[r], vv[r]);
     }
-    f32x16 gvn;
+    tile_t gvn;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gvn[r] = gv[r] / sqrtf(vv[r] + e2);
+    for (int r = 0; r < 8; ++r) gvn[r] = gv[r] / sqrtf(vv[r] + e2);
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      const f32x16 U = ld_nat(uvw, uv_tile(2, m, 0, 0), lane), V = ld_nat(uvw, uv_tile(2, m, 1, 0), lane);
-      f32x16 gU, gV;
+      const tile_t U = ld_nat(uvw, uv_tile(2, m, 0, 0), lane), V = ld_nat(uvw, uv_tile(2, m, 1, 0), lane);
+      tile_t gU, gV;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         gU[r] = GX ? __builtin_fmaf(G[m][r], av[r], gp[r] * V[r]) : gp[r] * V[r];
         gV[r] = __builtin_fmaf(gp[r], U[r], gvn[r] * V[r]);
       }
       accum_tile<1>(w, GXH[m], gU);
       accum_tile<1>(w, GXH[m], gV);
     }
-    f32x16 X[5], GW[5];
+    tile_t X[5], GW[5];
     ld_xm<5>(xrow + M0 + 3 * M1, h, X);
-    const f32x16 wv = ld_tile(a.eqw, M0 + M1, h);
+    const tile_t wv = ld_tile(a.eqw, M0 + M1, h);
 #pragma unroll
     for (int m = 0; m < 5; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         GW[m][r] = GXH[m][0][r] * wv[r];
         dotp = __builtin_fmaf(GW[m][r], X[m][r], dotp);
       }
@@ -1436,16 +1400,16 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
   float* __restrict__ gxr = a.g_x + row * D;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const f32x16 gw = ld_nat(gww, x_tile(0, 0, t), lane), xv = ld_tile(xrow, 32 * t, h);
-    f32x16 o;
+    const tile_t gw = ld_nat(gww, x_tile(0, 0, t), lane), xv = ld_tile(xrow, 32 * t, h);
+    tile_t o;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = (rr * gw[r] - coef * (xv[r] - mean0)) - gmean;
+    for (int r = 0; r < 8; ++r) o[r] = (rr * gw[r] - coef * (xv[r] - mean0)) - gmean;
     if (GX) o += ld_nat(gxow, x_tile(0, 0, t), lane);
     st_tile(gxr, 32 * t, h, o, ok);
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    f32x16 X[3], GW[3], R[3];
+    tile_t X[3], GW[3], R[3];
     ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -1455,11 +1419,11 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) X[m][r] = (rr * GW[m][r] - coef * X[m][r]) + (GX ? R[m][r] : 0.f);
+      for (int r = 0; r < 8; ++r) X[m][r] = (rr * GW[m][r] - coef * X[m][r]) + (GX ? R[m][r] : 0.f);
     st_xm<3>(gxr + M0 + 3 * 32 * t, h, X, ok);
   }
   {
-    f32x16 X[5], GW[5], R[5];
+    tile_t X[5], GW[5], R[5];
     ld_xm<5>(xrow + M0 + 3 * M1, h, X);
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
@@ -1469,7 +1433,7 @@ __global__ void __launch_bounds__(256, 1) k_node_block_bwd(BwdArgs a) {
 #pragma unroll
     for (int m = 0; m < 5; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) X[m][r] = (rr * GW[m][r] - coef * X[m][r]) + (GX ? R[m][r] : 0.f);
+      for (int r = 0; r < 8; ++r) X[m][r] = (rr * GW[m][r] - coef * X[m][r]) + (GX ? R[m][r] : 0.f);
     st_xm<5>(gxr + M0 + 3 * M1, h, X, ok);
   }
 }

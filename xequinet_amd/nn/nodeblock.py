@@ -170,9 +170,7 @@ def node_block_bwd(saved: dict, s: torch.Tensor, x: torch.Tensor, update, messag
 
 
 def native_to_rows(buf: torch.Tensor, n: int, width: int) -> torch.Tensor:
-    """An internal tensor of the node-block kernels ([block of 32 nodes][tile][quad][lane][4], include/xeq.h) as plain rows [n, width]
-    in tile order (tests / debugging)."""
     k = width // 32
-    wb = buf.numel() // (k * 1024)
-    t = buf.reshape(wb, k, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(wb * 32, width)
+    wb = buf.numel() // (k * 512)
+    t = buf.reshape(wb, k, 2, 4, 16, 4).permute(0, 4, 1, 2, 3, 5).reshape(wb * 16, width)
     return t[:n]
