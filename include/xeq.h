@@ -578,8 +578,8 @@ void xeq_pack_epoch_bump(void);
 int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream);
 
 /* ---- the per-node chain between two message aggregations as ONE launch per direction (round 4; csrc/xeq_nodeblock.hip) -------------
- * f32, the default layout (node_dim 128, 128x0e + 64x1o + 32x2e: xeq_node_block_supported).  A wave owns 32 nodes and keeps their
- * activations in the matrix cores' accumulator layout; every contraction runs on bf16 MFMAs over three-way split operands
+ * f32, the default layout (node_dim 128, 128x0e + 64x1o + 32x2e: xeq_node_block_supported).  A wave owns 16 nodes and keeps their
+ * activations in the matrix cores' accumulator layout; every contraction runs on bf16 MFMAs (16x16x32) over three-way split operands
  * (six products per k-step, f32 accumulation); the weights stream through LDS from a copy packed in consumption order.
  *
  * xeq_node_block_fwd = XPainnUpdate.forward (nn/xpainn.py:206-231: both norms, o3.Linear U / V, Invariant, EquivariantDot, update_mlp,
@@ -588,8 +588,8 @@ int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int3
  * (+ xeq_norm_fwd + xeq_mlp2_fwd of the next block).  What other kernels read keeps their layouts: s_out [n, F], x_out [n, D] (NULL: no
  * consumer), stats [n, 4], and for the next block stats_next [n, 4], xhat_next (BT), h_next [n, F + 2 C].  What only the reverse launch
  * reads is INTERNAL: uv (U|V), pre (update_mlp hidden pre-activation), a (update_mlp output), ip (dot_lin output), pre_next and the
- * scratch p -- xeq_node_block_rows(n) rows each (whole workgroups of 128 nodes) in the wave-native layout [block of 32 nodes][tile of
- * 32 channels][register quad][lane][4 floats], in which every wave access is 1 KB of consecutive bytes (tile numbering:
+ * scratch p -- xeq_node_block_rows(n) rows each (whole workgroups of 64 nodes) in the wave-native layout [block of 16 nodes][tile of
+ * 32 channels][register quad g][lane = 16 q + node][4 floats] (channel 16 g + 4 q + e of the tile), in which every wave access is 1 KB of consecutive bytes (tile numbering:
  * csrc/xeq_nodeblock.hip, uv_tile / x_tile; nn/nodeblock.py::native_to_rows turns one into rows).
  * packed: xeq_node_block_pack_fwd(update_mlp[0].weight [F, F + C], [W_U | W_V] / sqrt(mul_l) as [mul_l, 2 mul_l] for l = 0, 1, 2,
  * dot_lin.weight [F, C], update_mlp[2].weight [C + 2 F, F], next scalar_mlp[0].weight [F, F] and [2].weight [F + 2 C, F] (both
@@ -597,7 +597,7 @@ int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int3
  * b_uv = [update_U.bias | update_V.bias] ([2 F]) or NULL; p_scratch: [n, C] floats (EquivariantDot(U, V), read back by dot_lin). */
 int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]);
 /* launch policy (host only): 1 when an evaluation of n nodes should take the fused launches (n >= XEQ_NODE_BLOCK_MIN_NODES, default
- * 12 288; XEQ_NODE_BLOCK=0: never).  Below that the chain of small kernels is faster (a fused launch is one serial chain per wave). */
+ * 6 144; XEQ_NODE_BLOCK=0: never).  Below that the chain of small kernels is faster (a fused launch is one serial chain per wave). */
 int xeq_node_block_auto(int64_t n);
 int64_t xeq_node_block_rows(int64_t n);
 int64_t xeq_node_block_fwd_tiles(int with_tail);

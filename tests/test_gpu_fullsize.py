@@ -89,18 +89,26 @@ def test_full_size_against_oracle(name, n_mol, n_atoms, n_edges, chunked):
                   compared_edges=int(e_sub)), oracle, ref_in)
 
 
-def test_chunked_equals_unchunked():
+@pytest.mark.parametrize("node_block,n_mol,max_edges", [("by size", 1024, 200_000), ("always", 512, 40_000), ("never", 512, 40_000)])
+def test_chunked_equals_unchunked(node_block, n_mol, max_edges, monkeypatch):
     """runtime.evaluate_in_chunks (what a rank does with a shard above the kernels' 32-bit bound) against ONE evaluation
     of the same batch: identical edge count, and identical BITS.  Every kernel of the f32 path is this library's own since
     round 3 (dot_lin, the embedding and the energy head were library GEMMs, which pick another kernel -- another summation
     order -- for another row count: 1.2e-3 between two batchings of an ill-conditioned molecule then) and gives a node /
-    graph the same sums in the same order in any batch."""
+    graph the same sums in the same order in any batch.  As for shards (test_sharded_equals_unsharded): the fused node-block
+    launches and the chain they replace round differently, so the bits agree while every chunk sits on the batch's side of
+    xeq_node_block_auto's threshold ("by size": 1024 molecules in two chunks of ~9 300 atoms, like the multi-million-edge chunks of real use) or
+    with the choice pinned for the job."""
+    if node_block == "always":
+        monkeypatch.setenv("XEQ_NODE_BLOCK_MIN_NODES", "0")
+    elif node_block == "never":
+        monkeypatch.setenv("XEQ_NODE_BLOCK", "0")
     model, _ = _build(torch.float32)
-    pos, z, ptr = syn.synth_qm9_batch(512, seed=99)
+    pos, z, ptr = syn.synth_qm9_batch(n_mol, seed=99)
     E, F, e1, _ = _hip_eval(model, pos, z, ptr)
-    Ec, Fc, e2, _ = _hip_eval(model, pos, z, ptr, chunked=40_000)
+    Ec, Fc, e2, _ = _hip_eval(model, pos, z, ptr, chunked=max_edges)
     assert e1 == e2
-    parity_record.add(dict(config="qm9_512 chunked (5+ chunks) vs one evaluation", max_abs_dE=float(np.abs(E - Ec).max()),
+    parity_record.add(dict(config=f"qm9_{n_mol} chunked (max {max_edges} edges, node block {node_block}) vs one evaluation", max_abs_dE=float(np.abs(E - Ec).max()),
                            max_abs_dF=float(np.abs(F - Fc).max()), bitwise=bool(np.array_equal(E, Ec) and np.array_equal(F, Fc))))
     assert np.array_equal(Ec, E) and np.array_equal(Fc, F), (np.abs(E - Ec).max(), np.abs(F - Fc).max())
 
@@ -362,3 +370,19 @@ def test_qm9_1024_with_the_reference_initialisation():
     assert np.all(dE <= E_RTOL * np.abs(Eref) + E_ATOL)
     assert np.quantile(dF, 0.999) <= F32_PLAIN_FORCE_TOL, float(np.quantile(dF, 0.999))
     assert dF.max() <= b_max, (float(dF.max()), b_max)
+
+
+@pytest.mark.parametrize("name,repeats", [("qm9_1024", 5), ("md17_4096", 3)])
+def test_full_size_evaluations_repeat_bit_for_bit(name, repeats):
+    """A whole evaluation run again gives the same bits, at sizes that put two or more waves of every kernel on a SIMD and several
+    rounds of workgroups on a CU: every sum has a fixed order (no atomics), so anything else is a hazard.  (This is the check that
+    shows a sporadic error at once; round 4's packed-fp32 finding, profiles/r04_nodeblock.txt item 9, was of this kind.)"""
+    model, _ = _build(torch.float32)
+    pos, z, ptr, _ = syn.make_workload(name, seed=1234)
+    first = None
+    for _ in range(repeats):
+        E, F, _, _ = _hip_eval(model, pos, z, ptr)
+        if first is None:
+            first = (E, F)
+        else:
+            assert np.array_equal(E, first[0]) and np.array_equal(F, first[1]), (name, np.abs(F - first[1]).max())

@@ -1465,19 +1465,19 @@ using namespace xeq::nb;
 extern "C" {
 
 /* Launch policy, stated once for both fronts (nn/xpainn.py, csrc/xeq_torch.cpp): whether a force evaluation of n nodes takes the fused
- * node-block launches.  One wave owns 32 nodes and walks the whole chain alone on its SIMD (512 registers: nothing shares the SIMD to
- * hide its stalls), so a launch takes about as long for 1 500 nodes as for 18 000 (~0.2 ms): below XEQ_NODE_BLOCK_MIN_NODES (default
- * 12 288) the chain of small kernels, which spreads a few tiles over many workgroups, is the faster path (profiles/r04_nodeblock.txt).
- * XEQ_NODE_BLOCK=0 switches the fused launches off. */
+ * node-block launches.  A wave owns 16 nodes and walks the whole chain of its block, so a launch takes about as long for 1 500 nodes as
+ * for 9 000 (~0.1 ms: one workgroup's serial chain): below XEQ_NODE_BLOCK_MIN_NODES (default 6 144) the chain of small kernels, which
+ * spreads a few tiles over many workgroups, is the faster path (whole steps, QM9-shape batches: 4 587 atoms 1.22 against 1.18 ms,
+ * 9 133 atoms 1.57 against 1.69 ms; profiles/r04_nodeblock.txt).  XEQ_NODE_BLOCK=0 switches the fused launches off. */
 int xeq_node_block_auto(int64_t n) {
   const char* off = getenv("XEQ_NODE_BLOCK");
   if (off && off[0] == '0') return 0;
-  int64_t min_nodes = 12288;
+  int64_t min_nodes = 6144;
   if (const char* v = getenv("XEQ_NODE_BLOCK_MIN_NODES")) min_nodes = atoll(v);
   return n >= min_nodes;
 }
 
-/* rows of the kernels' internal tensors (uv, p, pre, a, ip, pre_next; gxo, gp, gv, gw): whole workgroups of 128 nodes */
+/* rows of the kernels' internal tensors (uv, p, pre, a, ip, pre_next; gxo, gp, gv, gw): whole workgroups of 64 nodes */
 int64_t xeq_node_block_rows(int64_t n) { return (n + ROWS_WG - 1) / ROWS_WG * ROWS_WG; }
 
 int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]) { return dtype == XEQ_F32 && mul && shape_ok(node_dim, mul); }
