@@ -27,6 +27,10 @@
 // product with round-to-nearest splits, below one f32 rounding): 192 instead of 512 matrix-pipe cycles per 32 x 32 x 16 tile of the
 // exact-f32 MFMA.  A row's sums do not depend on the rows it shares a wave with, so sharded / chunked / padded batches agree bit for
 // bit as before.
+//
+// Build: WITHOUT packed-fp32 instructions (csrc/build.py: -target-feature -packed-fp32-ops).  With two waves of these kernels on a SIMD,
+// v_pk_fma_f32 / v_pk_add_f32 on matrix-core results gave sporadic wrong values in one 16-lane row (profiles/r04_nodeblock.txt item 9c);
+// tests/test_gpu_nodeblock.py::test_node_block_at_full_size_equals_itself_on_slices is the check that shows it.
 #include <stdlib.h>
 
 #include <vector>
