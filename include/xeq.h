@@ -413,6 +413,23 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
                        int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat, void* grad_vec,
                        int xhat_layout, void* stream);
 
+/* The reverse pass in the form a TRAINING pass differentiates a second time (force loss: nn/basic.py:143-159 with create_graph=training,
+ * utils/trainer.py:295-308; host side ops.DiffMessage).  The message nn/xpainn.py:140-159 is multilinear in (dL/dout, h, xhat | Y, the
+ * record head f rho_k | f, the rbf_lin rows), so each second-order term is xeq_message_fwd_sb or this entry with ONE operand replaced by
+ * its tangent.  Records as xeq_edge_basis writes them (here formed by the caller, differentiably).  Walk and operands of xeq_message_bwd_sb;
+ * instead of dL/dvec it writes
+ *   q[E, 2C+F]  = h[nbr(e), c] P[e, c]   (P = <dL/dx_out[center], xhat[nbr]>, <dL/dx_out[center], Y_e>, dL/ds_out[center]) -- the caller gets
+ *                 dL/d(record head) = q [W | b] and dL/d[W | b] = q^T (record head) from two library GEMMs;
+ *   gy[E, 8]    = dL/dY_1[3], dL/dY_2[5] of the edge.
+ * flags: bit 0 the xhat layout, XEQ_SB_Y0_ZERO (also accepted by xeq_message_fwd_sb's xhat_layout): the l = 0 harmonic counts as 0 -- the
+ * record holds a tangent of the harmonics; XEQ_SB_Q_ACCUMULATE: q += instead of q =.  f32 / f64. */
+#define XEQ_SB_Y0_ZERO 8
+#define XEQ_SB_Q_ACCUMULATE 16
+int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                        const int64_t* center, const void* basis, const void* h, const void* xhat, const void* grad_s,
+                        const void* grad_x, const void* w_rbf, const void* b_rbf, int num_basis, int node_dim,
+                        const int32_t mul[3], void* grad_h, void* grad_xhat, void* q, void* gy, int flags, void* stream);
+
 /* "Wave / quad" form of the fused message (f32; the default whenever the channel layout allows it: node_dim == mul[0], mul[l] % 32 == 0,
  * num_basis <= 31).  The filter (rbf_lin, nn/xpainn.py:117,140: [2C+F, B+1] x [B+1] per edge) runs on the matrix cores with the channel
  * on the lane (the first sixteen basis functions as split-bf16 products, the rest and the bias column as exact-f32 steps); each half-wave

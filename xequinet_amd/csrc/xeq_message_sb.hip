@@ -78,6 +78,8 @@ struct SbArgs {
   Irreps ir;
   int xl;     // layout of xhat / grad_xhat
   int chunk;  // consecutive nodes per XCD label
+  int y0_zero;  // the l = 0 harmonic is 0 instead of 1: the record stands for a TANGENT of the harmonics (training pass, second order)
+  int q_accum;  // k_message_bwd_sbq: add to the per-edge products instead of storing them
 };
 
 template <typename T, int MAXB>
@@ -139,10 +141,10 @@ __device__ __forceinline__ ChanMap chan_map(const SbArgs& a) {
 }
 // Y_lm of this lane's l from the scalar record tail [f, Y1(3), Y2(5)]: y[m], m < 5
 template <typename T>
-__device__ __forceinline__ void lane_y(const T* __restrict__ tail, int l, T (&y)[5]) {
+__device__ __forceinline__ void lane_y(const T* __restrict__ tail, int l, T (&y)[5], T y00 = T(1)) {
   const T y10 = tail[1], y11 = tail[2], y12 = tail[3];
   const T y20 = tail[4], y21 = tail[5], y22 = tail[6], y23 = tail[7], y24 = tail[8];
-  y[0] = l == 0 ? T(1) : (l == 1 ? y10 : y20);
+  y[0] = l == 0 ? y00 : (l == 1 ? y10 : y20);
   y[1] = l == 1 ? y11 : y21;
   y[2] = l == 1 ? y12 : y22;
   y[3] = y23;
@@ -172,6 +174,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
   load_w<T, MAXB>(w_rbf, b_rbf, 2 * C + cm.ts, B, cm.has_s, wm, bm);
 
   const int lane = threadIdx.x & 63;
+  const T y00 = a.y0_zero ? T(0) : T(1);
   XcdWalk walk(a.n_nodes, a.chunk);
   for (int64_t c = walk.next(); c >= 0; c = walk.next()) {
     const int32_t e0 = a.rowptr[c], e1 = a.rowptr[c + 1];
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
             acc_s += hm[u] * pm;
             const T gs = hs[u] * ps, ge = he[u] * pe;
             T y[5];
-            lane_y<T>(rec + BP, cm.l, y);
+            lane_y<T>(rec + BP, cm.l, y, y00);
 #pragma unroll
             for (int m = 0; m < 5; ++m) acc_x[m] += xv[u][m] * gs + y[m] * ge;
           }
@@ -411,6 +414,143 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
   }
 }
 
+// The reverse pass in the form a TRAINING pass differentiates again (nn/training.py, ops.DiffMessage): the message is multilinear in
+// (dL/dout, h, xhat | Y, record head, rbf_lin rows), so every second-order term is this kernel or the forward kernel with one operand
+// replaced by its tangent.  Same walk as k_message_bwd_sb; instead of folding the per-edge sums into dL/dvec it hands out
+//   q[e, c]  = h[nbr(e), c] * P[e, c]   (P: the contraction of dL/dx_out with xhat / Y, or dL/ds_out)  -- the caller forms
+//              dL/drecord_head = q W' and dL/dW' = record_head^T q with two library GEMMs, q never outlives the call;
+//   gy[e, 8] = dL/dY_1, dL/dY_2 of the edge.
+template <typename T, int MAXB, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_message_bwd_sbq(SbArgs a, const T* __restrict__ eb,
+                                                        const T* __restrict__ h, const T* __restrict__ xhat,
+                                                        const T* __restrict__ grad_s, const T* __restrict__ grad_x,
+                                                        const T* __restrict__ w_rbf, const T* __restrict__ b_rbf,
+                                                        T* __restrict__ grad_h, T* __restrict__ grad_xhat,
+                                                        T* __restrict__ q_out, T* __restrict__ gy_out) {
+  __shared__ T red[SB_RED][4][8];
+  __shared__ int32_t red_eid[SB_RED];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int B = a.B, C = a.C, F = a.F, D = a.D, H = a.H;
+  const int BP = eb_bp(B), EW = BP + 12;
+  const ChanMap cm = chan_map(a);
+  const bool is1 = cm.has_u && cm.l == 1, is2 = cm.has_u && cm.l == 2;
+  const bool wave_has1 = __ballot(is1) != 0ull, wave_has2 = __ballot(is2) != 0ull;
+  const XAddr xa = xaddr(a.ir, a.n_nodes, cm.tu, a.xl);
+  const T y00 = a.y0_zero ? T(0) : T(1);
+  int gcomp[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) gcomp[m] = cm.off + min(m, cm.nm - 1);
+  T ws[MAXB], we[MAXB], wm[MAXB], bs, be, bm;
+  load_w<T, MAXB>(w_rbf, b_rbf, cm.tu, B, cm.has_u, ws, bs);
+  load_w<T, MAXB>(w_rbf, b_rbf, C + cm.tu, B, cm.has_u, we, be);
+  load_w<T, MAXB>(w_rbf, b_rbf, 2 * C + cm.ts, B, cm.has_s, wm, bm);
+
+  XcdWalk walk(a.n_nodes, a.chunk);
+  for (int64_t n = walk.next(); n >= 0; n = walk.next()) {
+    const int32_t e0 = a.rowptr[n], e1 = a.rowptr[n + 1];
+    const T hs = cm.has_u ? h[n * H + cm.tu] : T(0), he = cm.has_u ? h[n * H + C + cm.tu] : T(0);
+    const T hm = cm.has_s ? h[n * H + 2 * C + cm.ts] : T(0);
+    T xh[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) xh[m] = (cm.has_u && m < cm.nm) ? xhat[xa.off + n * xa.node + m * xa.comp] : T(0);
+    T acc_hs = T(0), acc_he = T(0), acc_hm = T(0), acc_xh[5] = {T(0), T(0), T(0), T(0), T(0)};
+    for (int32_t pb = e0; pb < e1; pb += SB_RED) {
+      const int32_t pe_ = min(pb + SB_RED, e1);
+      const int cnt = pe_ - pb;
+      const int32_t slot_v = pb + min(lane, cnt - 1);
+      const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
+      const int32_t ctr_v = (int32_t)a.other[eid_v];
+      for (int32_t p = pb; p < pe_; ++p) {
+        const int j = p - pb;
+        const int32_t eid = __builtin_amdgcn_readlane(eid_v, j);
+        const uint32_t cidx = (uint32_t)__builtin_amdgcn_readlane(ctr_v, j);
+        T gx[5];
+        const T dgm = grad_s[cidx * (uint32_t)F + cm.ts];
+        const T* gr = grad_x + cidx * (uint32_t)D;
+        gx[0] = gr[gcomp[0]];
+        if (cm.wnm >= 3) {  // wave-uniform
+          gx[1] = gr[gcomp[1]];
+          gx[2] = gr[gcomp[2]];
+        } else {
+          gx[1] = gx[2] = T(0);
+        }
+        if (cm.wnm >= 5) {
+          gx[3] = gr[gcomp[3]];
+          gx[4] = gr[gcomp[4]];
+        } else {
+          gx[3] = gx[4] = T(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+          if (m >= cm.nm) gx[m] = T(0);
+        const T* rec = eb + (uint32_t)eid * (uint32_t)EW;
+        const T fe = rec[BP];
+        const T ps = filt(ws, bs, rec, fe), pe = filt(we, be, rec, fe), pm = filt(wm, bm, rec, fe);
+        T y[5];
+        lane_y<T>(rec + BP, cm.l, y, y00);
+        T dgs = T(0), dge = T(0);
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+          dgs += xh[m] * gx[m];
+          dge += y[m] * gx[m];
+        }
+        const T dg_m = cm.has_s ? dgm : T(0);
+        acc_hs += ps * dgs;
+        acc_he += pe * dge;
+        acc_hm += pm * dg_m;
+        const T gate = hs * ps;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc_xh[m] += gate * gx[m];
+        T* qr = q_out + (int64_t)eid * H;
+        if (a.q_accum) {
+          if (cm.has_u) {
+            qr[cm.tu] += hs * dgs;
+            qr[C + cm.tu] += he * dge;
+          }
+          if (cm.has_s) qr[2 * C + cm.ts] += hm * dg_m;
+        } else {
+          if (cm.has_u) {
+            qr[cm.tu] = hs * dgs;
+            qr[C + cm.tu] = he * dge;
+          }
+          if (cm.has_s) qr[2 * C + cm.ts] = hm * dg_m;
+        }
+        const T gy = he * pe;
+        T r1[3] = {T(0), T(0), T(0)}, r2[5] = {T(0), T(0), T(0), T(0), T(0)};
+        if (wave_has1) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) r1[m] = wave_total(is1 ? gy * gx[m] : T(0));
+        }
+        if (wave_has2) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) r2[m] = wave_total(is2 ? gy * gx[m] : T(0));
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) red[j][wave][m] = r1[m];
+#pragma unroll
+          for (int m = 0; m < 5; ++m) red[j][wave][3 + m] = r2[m];
+          if (wave == 0) red_eid[j] = eid;
+        }
+      }
+      __syncthreads();
+      for (int i = t; i < cnt * 8; i += 256) {  // a lane per (edge, harmonic): the four waves' sums in wave order
+        const int j = i >> 3, m = i & 7;
+        gy_out[(int64_t)red_eid[j] * 8 + m] = ((red[j][0][m] + red[j][1][m]) + red[j][2][m]) + red[j][3][m];
+      }
+      __syncthreads();
+    }
+    if (cm.has_u) {
+      grad_h[n * H + cm.tu] = acc_hs;
+      grad_h[n * H + C + cm.tu] = acc_he;
+#pragma unroll
+      for (int m = 0; m < 5; ++m)
+        if (m < cm.nm) grad_xhat[xa.off + n * xa.node + m * xa.comp] = acc_xh[m];
+    }
+    if (cm.has_s) grad_h[n * H + 2 * C + cm.ts] = acc_hm;
+  }
+}
+
 // what the scalar-broadcast kernels cover: at most 256 channels per kind (one thread each) and 32-bit row offsets
 static bool sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
   if (num_basis < 1 || num_basis > 32 || mul[0] < 0 || mul[1] < 0 || mul[2] < 0) return false;
@@ -504,6 +644,7 @@ int xeq_message_fwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.perm = perm;
   a.other = nbr;
   a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
+  a.y0_zero = (xhat_layout & XEQ_SB_Y0_ZERO) ? 1 : 0;
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
   XEQ_SB_DISPATCH(k_message_fwd_sb, 2, 2, a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)s_in, (const T*)x_in,
                   (const T*)w_rbf, (const T*)b_rbf, (T*)s_out, (T*)x_out);
@@ -529,6 +670,48 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
                   (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat,
                   (T*)grad_vec);
   XEQ_CHECK_LAUNCH("xeq_message_bwd_sb");
+  return XEQ_OK;
+}
+
+#define XEQ_SBQ_DISPATCH(...)                                                                                            \
+  do {                                                                                                                   \
+    if (dtype == XEQ_F32) {                                                                                              \
+      using T = float;                                                                                                   \
+      if (num_basis <= 8) hipLaunchKernelGGL((k_message_bwd_sbq<T, 8, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);        \
+      else if (num_basis <= 16) hipLaunchKernelGGL((k_message_bwd_sbq<T, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (num_basis <= 20) hipLaunchKernelGGL((k_message_bwd_sbq<T, 20, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((k_message_bwd_sbq<T, 32, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+    } else if (dtype == XEQ_F64) {                                                                                       \
+      using T = double;                                                                                                  \
+      if (num_basis <= 8) hipLaunchKernelGGL((k_message_bwd_sbq<T, 8, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);        \
+      else if (num_basis <= 16) hipLaunchKernelGGL((k_message_bwd_sbq<T, 16, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (num_basis <= 20) hipLaunchKernelGGL((k_message_bwd_sbq<T, 20, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((k_message_bwd_sbq<T, 32, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+    } else {                                                                                                             \
+      xeq::set_error("unsupported dtype %d", dtype);                                                                     \
+      return XEQ_ERR_INVALID_ARGUMENT;                                                                                   \
+    }                                                                                                                    \
+  } while (0)
+
+int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                        const int64_t* center, const void* basis, const void* h, const void* xhat, const void* grad_s,
+                        const void* grad_x, const void* w_rbf, const void* b_rbf, int num_basis, int node_dim,
+                        const int32_t mul[3], void* grad_h, void* grad_xhat, void* q, void* gy, int flags, void* stream) {
+  SbArgs a{};
+  int rcode = sb_check("xeq_message_bwd_sbq", n_nodes, n_edges, num_basis, node_dim, mul, a);
+  if (rcode != XEQ_OK) return rcode;
+  XEQ_CHECK_ARG(n_edges * (int64_t)a.H < (1ll << 40), "xeq_message_bwd_sbq: q too large");
+  if (n_nodes == 0) return XEQ_OK;
+  a.rowptr = n_rowptr;
+  a.perm = n_perm;
+  a.other = center;
+  a.xl = flags & 1;
+  a.y0_zero = (flags & XEQ_SB_Y0_ZERO) ? 1 : 0;
+  a.q_accum = (flags & XEQ_SB_Q_ACCUMULATE) ? 1 : 0;
+  dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
+  XEQ_SBQ_DISPATCH(a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf,
+                   (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat, (T*)q, (T*)gy);
+  XEQ_CHECK_LAUNCH("xeq_message_bwd_sbq");
   return XEQ_OK;
 }
 

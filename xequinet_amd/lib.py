@@ -18,6 +18,8 @@ LIB_PATH = os.environ.get("XEQ_LIB_PATH") or os.path.join(_HERE, "libxeq_hip.so"
 XEQ_F32, XEQ_F64 = 0, 1
 COPY_MANY_MAX = 16       # XEQ_COPY_MANY_MAX of include/xeq.h
 XHAT_HIGHER_L_ZERO = 2   # XEQ_XHAT_HIGHER_L_ZERO of include/xeq.h: hint bit on the xhat_layout argument of the wq message kernels
+SB_Y0_ZERO = 8           # XEQ_SB_Y0_ZERO / XEQ_SB_Q_ACCUMULATE: the training-pass forms of the sb message kernels (ops.DiffMessage)
+SB_Q_ACCUMULATE = 16
 WQ_MIRROR_WALK = 4       # XEQ_WQ_MIRROR_WALK: the reverse wq kernel walks the forward plan of a symmetric list
 RBF_KINDS = {"bessel": 0, "gaussian": 1}
 CUTOFF_KINDS = {"cosine": 0, "polynomial": 1}
@@ -99,6 +101,7 @@ _PROTOS = {
     "xeq_edge_basis_width": [c_int],
     "xeq_edge_basis": [c_int, _P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
     "xeq_message_fwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, c_int, _P],
+    "xeq_message_bwd_sbq": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P, _P, c_int, _P],
     "xeq_message_bwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P,
                            c_int, _P],
     "xeq_message_sb_fits": [c_int64, c_int64, c_int, c_int, _I3],

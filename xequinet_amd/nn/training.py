@@ -23,6 +23,9 @@ from .. import keys, lib
 
 TRAIN_PASS = "_xeq_train_pass"      # data-dict flag set by BaseModel.forward: every block of this pass takes the training form
 _RSH = "_xeq_train_rsh"             # per-l list of Y_l [E, 2l+1] written by the embedding
+_REC = "_xeq_train_records"         # per-edge records [E, roundup(B, 4) + 12] of the kernel message (ops.training_records), or absent
+# False: the message block of this pass stays on ATen tensor operations (the cross-check of the kernel form, tests/test_gpu_training.py)
+NATIVE_MESSAGE = True
 # data-dict flag set by BaseModel.forward for a training pass whose loss reads energies only (no forces, no virial): the blocks stay on
 # the fused HIP kernels and hand their parameters to the block functions, which return the parameter gradients (nn/fused.py)
 PARAM_GRADS = "_xeq_param_grads"
@@ -150,6 +153,15 @@ def embedding(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     data[keys.RADIAL_BASIS_FUNCTION] = radial_basis(module.rbf, dist)
     data[keys.ENVELOPE_FUNCTION] = envelope(module.cutoff_fn, dist)
     data[_RSH] = spherical_harmonics(vectors, module.node_irreps.lmax)
+    if NATIVE_MESSAGE and s.is_cuda and module.node_irreps.lmax <= 2 and data[keys.RADIAL_BASIS_FUNCTION].shape[1] <= 32:
+        # the three message blocks share the geometry: one record per edge, differentiable in the vectors and the basis parameters
+        from .. import ops
+
+        rsh, env = data[_RSH], data[keys.ENVELOPE_FUNCTION]
+        E = env.shape[0]
+        y1 = rsh[1] if len(rsh) > 1 else env.new_zeros((E, 3))
+        y2 = rsh[2] if len(rsh) > 2 else env.new_zeros((E, 5))
+        data[_REC] = ops.training_records(data[keys.RADIAL_BASIS_FUNCTION] * env, env, y1, y2)
     data[keys.NODE_EQUIVARIANT] = torch.zeros((s.shape[0], module.node_irreps.dim), dtype=s.dtype, device=s.device)
     return data
 
@@ -191,6 +203,20 @@ def message(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     center, neighbor = ei[keys.CENTER_IDX].long(), ei[keys.NEIGHBOR_IDX].long()
     s, x = _norms(module, s0, x0)
     scalar_out = module.scalar_mlp(s)
+    rec = data.get(_REC)
+    if rec is not None:
+        # the edge side on the kernels: the aggregation, its reverse pass and the reverse of that (ops.DiffMessage); nothing of size
+        # [E, 576] outlives a launch pair
+        from .. import ops
+        from .basic import edge_graph
+
+        graph = edge_graph(data)
+        cfg = (int(module.rbf_lin.weight.shape[1]), int(module.node_dim), tuple(irreps.mul3()))
+        if ops.diff_message_supported(scalar_out, graph, cfg):
+            d_s, d_x = ops.DiffMessage.apply(scalar_out, x, rec, module.rbf_lin.weight, module.rbf_lin.bias, graph, cfg)
+            data[keys.NODE_INVARIANT] = s0 + d_s
+            data[keys.NODE_EQUIVARIANT] = x0 + d_x
+            return data
     filt = module.rbf_lin(data[keys.RADIAL_BASIS_FUNCTION]) * data[keys.ENVELOPE_FUNCTION]
     filt = scalar_out.index_select(0, neighbor) * filt
     gate_state, gate_edge, msg_s = torch.split(filt, [C, C, module.node_dim], dim=-1)

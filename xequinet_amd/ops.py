@@ -880,3 +880,170 @@ class FusedMessage(Function):
             d_p0 = d_p0.view(ctx.p_shapes[0])
             d_p1 = None if d_p1 is None else d_p1.view(ctx.p_shapes[1])
         return g_h, g_xhat, g_vec, g_s, g_x, d_w, d_b, d_p0, d_p1, None, None
+
+
+# ---- the message block of a TRAINING pass with forces in the loss: differentiable twice ---------------------------------------------
+def training_records(rbf_env: torch.Tensor, env: torch.Tensor, y1: torch.Tensor, y2: torch.Tensor) -> torch.Tensor:
+    """Per-edge records in xeq_edge_basis's layout -- [f rho_k (B) | 0 to a multiple of 4 | f | Y_1 (3) | Y_2 (5) | 0 0 0] -- formed from
+    differentiable tensors (nn/training.py: radial basis x envelope [E, B], envelope [E, 1], harmonics), so autograd carries both orders
+    of the geometry and of the trainable basis parameters through them."""
+    E, B = rbf_env.shape
+    bp = (B + 3) & ~3
+    z = rbf_env.new_zeros
+    return torch.cat([rbf_env, z((E, bp - B)), env.reshape(E, 1), y1, y2, z((E, 3))], dim=1).contiguous()
+
+
+def _diff_sizes(cfg):
+    num_basis, node_dim, mul = cfg
+    C, D = sum(mul), mul[0] + 3 * mul[1] + 5 * mul[2]
+    return num_basis, node_dim, mul, C, D, node_dim + 2 * C, (num_basis + 3) & ~3
+
+
+def _diff_fwd(h, xhat, rec, w, b, graph: "EdgeGraph", cfg, y0_zero: bool = False):
+    B, F, mul, C, D, H, bp = _diff_sizes(cfg)
+    N, E = graph.n_nodes, graph.n_edges
+    zs, zx = h.new_zeros((N, F)), h.new_zeros((N, D))
+    ds, dx = torch.empty_like(zs), torch.empty_like(zx)
+    KERNEL_TIMER.launch("xeq_message_fwd_sb", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm), ptr(graph.edge_index[1]),
+                        ptr(rec), ptr(h), ptr(xhat), ptr(zs), ptr(zx), ptr(w), ptr(b), B, F, mul3(mul), ptr(ds), ptr(dx),
+                        lib.SB_Y0_ZERO if y0_zero else 0, stream())
+    return ds, dx
+
+
+def _diff_bwd(h, xhat, rec, w, b, g_s, g_x, graph: "EdgeGraph", cfg, q=None, y0_zero: bool = False):
+    """(grad_h, grad_xhat, q, gy) of xeq_message_bwd_sbq; ``q`` given: the per-edge products are added to it."""
+    B, F, mul, C, D, H, bp = _diff_sizes(cfg)
+    N, E = graph.n_nodes, graph.n_edges
+    g_h, g_xh = torch.empty_like(h), torch.empty_like(xhat)
+    flags = (lib.SB_Y0_ZERO if y0_zero else 0) | (lib.SB_Q_ACCUMULATE if q is not None else 0)
+    if q is None:
+        q = torch.empty((E, H), dtype=h.dtype, device=h.device)
+    gy = torch.zeros((E, 8), dtype=h.dtype, device=h.device)
+    KERNEL_TIMER.launch("xeq_message_bwd_sbq", dtype_code(h), N, E, ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(graph.edge_index[0]),
+                        ptr(rec), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w), ptr(b), B, F, mul3(mul), ptr(g_h), ptr(g_xh),
+                        ptr(q), ptr(gy), flags, stream())
+    return g_h, g_xh, q, gy
+
+
+def diff_message_supported(h: torch.Tensor, graph: "EdgeGraph", cfg) -> bool:
+    B, F, mul, C, D, H, bp = _diff_sizes(cfg)
+    return bool(h.is_cuda and h.dtype in (torch.float32, torch.float64)
+                and lib.load().xeq_message_sb_fits(graph.n_nodes, graph.n_edges, B, F, mul3(mul)))
+
+
+class DiffMessage(Function):
+    """nn/xpainn.py:140-159 without the residual: (sum_e msg_s, sum_e msg_x) from h = scalar_mlp(s), xhat, the per-edge records
+    (``training_records``) and rbf_lin's weight [2C+F, B] / bias.  First derivatives w.r.t. all five; the reverse pass is itself a
+    differentiable node (``DiffMessageGrad``), so a loss on forces (nn/basic.py:143-159, create_graph=training) stays on the kernels."""
+
+    @staticmethod
+    def forward(ctx, h, xhat, rec, w, b, graph, cfg):
+        require_hip(h, xhat, rec, w, b)
+        h, xhat, rec, w, b = (t.contiguous() for t in (h, xhat, rec, w, b))
+        ds, dx = _diff_fwd(h, xhat, rec, w, b, graph, cfg)
+        ctx.save_for_backward(h, xhat, rec, w, b)
+        ctx.graph, ctx.cfg = graph, cfg
+        return ds, dx
+
+    @staticmethod
+    def backward(ctx, g_s, g_x):
+        h, xhat, rec, w, b = ctx.saved_tensors
+        B, F, mul, C, D, H, bp = _diff_sizes(ctx.cfg)
+        N = ctx.graph.n_nodes
+        g_s = h.new_zeros((N, F)) if g_s is None else g_s
+        g_x = h.new_zeros((N, D)) if g_x is None else g_x
+        want = (ctx.needs_input_grad[2], ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        g_h, g_xh, g_rec, g_w, g_b = DiffMessageGrad.apply(h, xhat, rec, w, b, g_s, g_x, ctx.graph, ctx.cfg, want)
+        return g_h, g_xh, g_rec, g_w, g_b, None, None
+
+
+def _rec_from_q(q, gy, w, b, bp):
+    """dL/drecord [E, bp + 12] from the per-edge products: head = q [W | b], harmonics from the kernel."""
+    B = w.shape[1]
+    head = q @ torch.cat([w, b.unsqueeze(1)], dim=1)       # [E, B + 1]
+    z = q.new_zeros
+    return torch.cat([head[:, :B], z((q.shape[0], bp - B)), head[:, B:], gy, z((q.shape[0], 3))], dim=1)
+
+
+def _wb_from_q(q, rec, B, bp):
+    """dL/dW [H, B], dL/db [H] = q^T (record head)."""
+    head = torch.cat([rec[:, :B], rec[:, bp : bp + 1]], dim=1)
+    g = q.t() @ head
+    return g[:, :B].contiguous(), g[:, B].contiguous()
+
+
+class DiffMessageGrad(Function):
+    """The reverse pass of ``DiffMessage`` as a differentiable node: (h, xhat, rec, w, b, g_s, g_x) -> (dh, dxhat, drec, dw, db).
+    The message is multilinear in its operands, so this node's own reverse pass is three pairs of the same two kernels with one operand
+    replaced by the incoming cotangent (include/xeq.h, xeq_message_bwd_sbq).  Cotangents of dw / db (a third order) are refused."""
+
+    @staticmethod
+    def forward(ctx, h, xhat, rec, w, b, g_s, g_x, graph, cfg, want):
+        B, F, mul, C, D, H, bp = _diff_sizes(cfg)
+        g_s, g_x = g_s.contiguous(), g_x.contiguous()
+        g_h, g_xh, q, gy = _diff_bwd(h, xhat, rec, w, b, g_s, g_x, graph, cfg)
+        g_rec = _rec_from_q(q, gy, w, b, bp) if want[0] else None
+        g_w, g_b = _wb_from_q(q, rec, B, bp) if want[1] else (None, None)
+        ctx.save_for_backward(h, xhat, rec, w, b, g_s, g_x)
+        ctx.graph, ctx.cfg = graph, cfg
+        ctx.set_materialize_grads(False)
+        return g_h, g_xh, g_rec, g_w, g_b
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, u_h, u_xh, u_rec, u_w, u_b):
+        if u_w is not None or u_b is not None:
+            raise NotImplementedError("DiffMessageGrad: derivatives of the filter's parameter gradients are not implemented")
+        h, xhat, rec, w, b, g_s, g_x = ctx.saved_tensors
+        graph, cfg = ctx.graph, ctx.cfg
+        B, F, mul, C, D, H, bp = _diff_sizes(cfg)
+        N, E = graph.n_nodes, graph.n_edges
+        need = ctx.needs_input_grad
+        zeros = lambda *shape: h.new_zeros(shape)
+        d_h = d_xh = d_gs = d_gx = None
+        gy_sum = None
+        q_ab = None        # products of the passes whose record head is the true one: they meet [W | b] and the true head
+        d_w = d_b = None
+
+        def add(acc, t):
+            return t if acc is None else acc + t
+
+        if u_h is not None:                      # A: h <- u_h
+            u_h = u_h.contiguous()
+            s_, x_ = _diff_fwd(u_h, xhat, rec, w, b, graph, cfg)
+            d_gs, d_gx = add(d_gs, s_), add(d_gx, x_)
+            _, gxh, q_ab, gy = _diff_bwd(u_h, xhat, rec, w, b, g_s, g_x, graph, cfg)
+            d_xh, gy_sum = add(d_xh, gxh), add(gy_sum, gy)
+        u_y = None if u_rec is None else u_rec[:, bp + 1 : bp + 9]
+        if u_xh is not None or u_rec is not None:  # B: (xhat, Y) <- (u_xhat, u_Y); dL/ds_out plays no part
+            ux = zeros(*xhat.shape) if u_xh is None else u_xh.contiguous()
+            rec_b = rec if u_rec is None else None
+            if u_rec is None:
+                rec_b = torch.cat([rec[:, : bp + 1], zeros(E, 11)], dim=1)
+            else:
+                rec_b = torch.cat([rec[:, : bp + 1], u_y, zeros(E, 3)], dim=1)
+            _, x_ = _diff_fwd(h, ux, rec_b, w, b, graph, cfg, y0_zero=True)
+            d_gx = add(d_gx, x_)
+            gh, _, q_ab, _ = _diff_bwd(h, ux, rec_b, w, b, zeros(N, F), g_x, graph, cfg, q=q_ab, y0_zero=True)
+            d_h = add(d_h, gh)
+        if u_rec is not None:                    # C: record head <- its cotangent
+            rec_c = torch.cat([u_rec[:, : bp + 1], rec[:, bp + 1 :]], dim=1)
+            if bp > B:
+                rec_c[:, B:bp] = 0
+            s_, x_ = _diff_fwd(h, xhat, rec_c, w, b, graph, cfg)
+            d_gs, d_gx = add(d_gs, s_), add(d_gx, x_)
+            gh, gxh, q_c, gy = _diff_bwd(h, xhat, rec_c, w, b, g_s, g_x, graph, cfg)
+            d_h, d_xh, gy_sum = add(d_h, gh), add(d_xh, gxh), add(gy_sum, gy)
+            if need[3] or need[4]:
+                d_w, d_b = _wb_from_q(q_c, rec_c, B, bp)
+            del q_c
+        d_rec = None
+        if q_ab is not None:
+            if need[2]:
+                d_rec = _rec_from_q(q_ab, gy_sum if gy_sum is not None else zeros(E, 8), w, b, bp)
+            if need[3] or need[4]:
+                gw, gb = _wb_from_q(q_ab, rec, B, bp)
+                d_w, d_b = add(d_w, gw), add(d_b, gb)
+        elif gy_sum is not None and need[2]:
+            d_rec = torch.cat([zeros(E, bp + 1), gy_sum, zeros(E, 3)], dim=1)
+        return d_h, d_xh, d_rec, d_w, d_b, d_gs, d_gx, None, None, None
