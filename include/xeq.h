@@ -382,6 +382,29 @@ int xeq_norm_param_grad(const void* s, const void* x, const void* stats, const v
  * xhat_layout / grad_x_layout arguments): the gradient kernel's gathers of dL/dx_out rows are contiguous over the channels there. */
 int xeq_to_bt(const void* x, int64_t n_nodes, const int32_t mul[3], void* out, void* stream);
 
+/* Node-side functions of a training pass that is differentiated TWICE (forces in the loss: nn/basic.py:143-159 with create_graph=training,
+ * utils/trainer.py:295-308; host side ops.NormFn / UvFn / UpdateOutFn, csrc/xeq_train_node.hip).  f32 / f64.  Every entry has a forward
+ * form (reverse = 0) and a reverse form (reverse = 1); with the *_tan pointers given, the same body runs on dual numbers (value, tangent)
+ * and the outputs are the TANGENTS -- that is the second order: for the cotangent u of a first-order input gradient, the forward form at
+ * tangent u gives d<u, xbar>/dg, the reverse form at tangent u gives d<u, xbar>/dx and d<u, xbar>/dtheta.
+ *
+ * xeq_train_norm: (s[N, F], x[N, D]) -> (LayerNorm(s), EquivariantLayerNorm(x))  (nn/xpainn.py:130-131, :213-214; nn/o3layer.py:145-171:
+ *   the l = 0 block is centred, one rms over all C channels, weight per channel, bias on the l = 0 block).  xhat_layout 0: the e3nn row,
+ *   1: BT (per l a row-major [N (2l+1), mul_l] matrix, one after the other) -- of out_x (forward) and of g_x (reverse).
+ *   reverse: out_s / out_x = dL/ds, dL/dx (e3nn rows); rows[N, 2F + C + mul0] = per-node [d ln_w | d ln_b | d eq_w | d eq_b] (the caller sums).
+ * xeq_train_uv: uv[l] = [N (2l+1), 2 mul_l] row-major (U | V of update_U / update_V in BT rows) -> out[N, 2C] = [Invariant(V) | sum_m U V]
+ *   (nn/o3layer.py:40-44, :61-68; eps of the Invariant).  reverse: g = dL/dout, d_uv[l] = dL/duv[l].
+ * xeq_train_out: (uv, a[N, C + 2F] = [a_vv | a_sv | a_ss], inner[N, F]) -> out0[N, F] = a_sv inner + a_ss, out1[N, D] = U a_vv (e3nn row)
+ *   (nn/xpainn.py:226-230 without the residual).  reverse: g_s, g_x = dL/dout0, dL/dout1; out0 = dL/da, out1 = dL/dinner, d_uv. */
+int xeq_train_norm(int dtype, int reverse, int64_t n, const void* s, const void* s_tan, const void* x, const void* x_tan, const void* ln_w,
+                   const void* ln_b, const void* eq_w, const void* eq_b, const void* g_s, const void* g_x, int node_dim,
+                   const int32_t mul[3], double eps_ln, double eps_eq, int xhat_layout, void* out_s, void* out_x, void* rows, void* stream);
+int xeq_train_uv(int dtype, int reverse, int64_t n, const void* const uv[3], const void* const uv_tan[3], const void* g, const int32_t mul[3],
+                 double eps, void* out, void* const d_uv[3], void* stream);
+int xeq_train_out(int dtype, int reverse, int64_t n, const void* const uv[3], const void* const uv_tan[3], const void* a, const void* a_tan,
+                  const void* inner, const void* inner_tan, const void* g_s, const void* g_x, int node_dim, const int32_t mul[3],
+                  void* out0, void* out1, void* const d_uv[3], void* stream);
+
 /* Launch policy, stated ONCE for every front (the Python modules' ops.select_message_impl / ops._wq_edges_per_stream and the
  * registered operator xeq::xpainn_eval call these): the kernel family `auto` takes for a configuration and these sizes, and the
  * stream length of a wq walk plan (n_ranges = ceil(E / (2 x edges_per_stream))). */
@@ -429,6 +452,11 @@ int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32
                         const int64_t* center, const void* basis, const void* h, const void* xhat, const void* grad_s,
                         const void* grad_x, const void* w_rbf, const void* b_rbf, int num_basis, int node_dim,
                         const int32_t mul[3], void* grad_h, void* grad_xhat, void* q, void* gy, int flags, void* stream);
+/* dL/d[W | b] from those products: parts[n_chunks][2C+F][roundup(B, 4) + 1] with out[c, k] = sum_e q[e, c] basis[e, k] over the chunk's
+ * edges (columns [0, B): dL/dW[c, k]; column roundup(B, 4): dL/db[c]); the caller adds the chunks in order.  At most 768 filter rows. */
+int xeq_message_q_wgrad_chunks(int64_t n_edges);
+int xeq_message_q_wgrad(int dtype, const void* q, const void* basis, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3],
+                        int n_chunks, void* parts, void* stream);
 
 /* "Wave / quad" form of the fused message (f32; the default whenever the channel layout allows it: node_dim == mul[0], mul[l] % 32 == 0,
  * num_basis <= 31).  The filter (rbf_lin, nn/xpainn.py:117,140: [2C+F, B+1] x [B+1] per edge) runs on the matrix cores with the channel

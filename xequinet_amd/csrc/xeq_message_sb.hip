@@ -551,6 +551,69 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
   }
 }
 
+// dL/d[W | b] of the training-pass message: out[c, k] = sum_e q[e, c] rec[e, k], k <= roundup(B, 4) (the record head and the envelope
+// column behind it), a [H x E] x [E x K] product with K <= 33 -- the library's kernels for this shape run at a third of the read rate.
+// A workgroup owns TNQ_EDGES consecutive edges, thread t the channels t, t + 256, t + 512; the record columns are workgroup-uniform
+// (scalar loads), q rows are read once, coalesced.  parts[chunk][H][K], summed by the caller in chunk order.
+constexpr int TNQ_EDGES = 256;
+constexpr int TNQ_STAGE = 128;   // record rows staged in LDS at a time (scalar loads of eight rows ahead spilled 396 SGPRs: 740 us)
+template <typename T, int MAXK>
+__global__ void __launch_bounds__(256) k_q_wgrad(const T* __restrict__ q, const T* __restrict__ rec, int64_t E, int H, int EW, int K,
+                                                 T* __restrict__ parts) {
+  constexpr int KP = (MAXK + 3) & ~3;
+  __shared__ T srec[TNQ_STAGE][KP];
+  const int t = threadIdx.x;
+  const int64_t e0 = (int64_t)blockIdx.x * TNQ_EDGES, e1 = min(e0 + TNQ_EDGES, E);
+  T acc[3][MAXK];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) acc[i][k] = T(0);
+  const int c0 = t, c1 = t + 256, c2 = t + 512;
+  constexpr int U = 4;   // q rows in flight
+  for (int64_t sb = e0; sb < e1; sb += TNQ_STAGE) {
+    const int cnt = (int)min((int64_t)TNQ_STAGE, e1 - sb);
+    __syncthreads();
+    for (int i = t; i < cnt * KP; i += 256) {
+      const int e = i / KP, k = i - e * KP;
+      srec[e][k] = k < K ? rec[(sb + e) * EW + k] : T(0);
+    }
+    __syncthreads();
+    for (int eb = 0; eb < cnt; eb += U) {
+      T qv[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool live = eb + u < cnt;
+        const T* qr = q + (sb + min(eb + u, cnt - 1)) * H;
+        qv[u][0] = (live && c0 < H) ? qr[c0] : T(0);
+        qv[u][1] = (live && c1 < H) ? qr[c1] : T(0);
+        qv[u][2] = (live && c2 < H) ? qr[c2] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const T* r = srec[min(eb + u, cnt - 1)];   // uniform: LDS broadcast reads
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+          const T rv = r[k];
+          acc[0][k] += qv[u][0] * rv;
+          acc[1][k] += qv[u][1] * rv;
+          acc[2][k] += qv[u][2] * rv;
+        }
+      }
+    }
+  }
+  T* out = parts + (int64_t)blockIdx.x * H * K;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = t + 256 * i;
+    if (c < H) {
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k)
+        if (k < K) out[(int64_t)c * K + k] = acc[i][k];
+    }
+  }
+}
+
 // what the scalar-broadcast kernels cover: at most 256 channels per kind (one thread each) and 32-bit row offsets
 static bool sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
   if (num_basis < 1 || num_basis > 32 || mul[0] < 0 || mul[1] < 0 || mul[2] < 0) return false;
@@ -712,6 +775,27 @@ int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32
   XEQ_SBQ_DISPATCH(a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf,
                    (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat, (T*)q, (T*)gy);
   XEQ_CHECK_LAUNCH("xeq_message_bwd_sbq");
+  return XEQ_OK;
+}
+
+int xeq_message_q_wgrad_chunks(int64_t n_edges) { return (int)((n_edges + TNQ_EDGES - 1) / TNQ_EDGES); }
+
+int xeq_message_q_wgrad(int dtype, const void* q, const void* basis, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3],
+                        int n_chunks, void* parts, void* stream) {
+  XEQ_CHECK_ARG(n_edges >= 0 && num_basis >= 1 && num_basis <= 32, "xeq_message_q_wgrad: bad sizes");
+  const int H = node_dim + 2 * (mul[0] + mul[1] + mul[2]), BP = eb_bp(num_basis), EW = BP + 12, K = BP + 1;
+  XEQ_CHECK_ARG(H >= 1 && H <= 768, "xeq_message_q_wgrad: %d filter rows exceed the 768 of the thread mapping", H);
+  XEQ_CHECK_ARG(n_chunks == xeq_message_q_wgrad_chunks(n_edges), "xeq_message_q_wgrad: n_chunks %d, expected %d", n_chunks,
+                xeq_message_q_wgrad_chunks(n_edges));
+  if (n_edges == 0) return XEQ_OK;
+  dim3 grid((unsigned)n_chunks);
+  XEQ_DISPATCH_FLOAT(dtype, {
+    if (K <= 9) hipLaunchKernelGGL((k_q_wgrad<T, 9>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q, (const T*)basis, n_edges, H, EW, K, (T*)parts);
+    else if (K <= 17) hipLaunchKernelGGL((k_q_wgrad<T, 17>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q, (const T*)basis, n_edges, H, EW, K, (T*)parts);
+    else if (K <= 21) hipLaunchKernelGGL((k_q_wgrad<T, 21>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q, (const T*)basis, n_edges, H, EW, K, (T*)parts);
+    else hipLaunchKernelGGL((k_q_wgrad<T, 33>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q, (const T*)basis, n_edges, H, EW, K, (T*)parts);
+  });
+  XEQ_CHECK_LAUNCH("xeq_message_q_wgrad");
   return XEQ_OK;
 }
 

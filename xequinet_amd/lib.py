@@ -102,6 +102,11 @@ _PROTOS = {
     "xeq_edge_basis": [c_int, _P, c_int64, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
     "xeq_message_fwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, c_int, _P],
     "xeq_message_bwd_sbq": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P, _P, c_int, _P],
+    "xeq_message_q_wgrad": [c_int, _P, _P, c_int64, c_int, c_int, _I3, c_int, _P, _P],
+    "xeq_message_q_wgrad_chunks": [c_int64],
+    "xeq_train_norm": [c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _I3, c_double, c_double, c_int, _P, _P, _P, _P],
+    "xeq_train_uv": [c_int, c_int, c_int64, _P, _P, _P, _I3, c_double, _P, _P, _P],
+    "xeq_train_out": [c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _I3, _P, _P, _P, _P],
     "xeq_message_bwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P,
                            c_int, _P],
     "xeq_message_sb_fits": [c_int64, c_int64, c_int, c_int, _I3],
@@ -213,6 +218,13 @@ def require_hip(*tensors: torch.Tensor) -> None:
                 "xequinet_amd ops run on MI355X (HIP) tensors only and have no CPU fallback; "
                 f"got a tensor on {t.device}"
             )
+
+
+def ptr3(ts):
+    """Three device pointers as one argument (``const void* const [3]``); None for an absent list."""
+    if ts is None:
+        return None
+    return (c_void_p * 3)(*[None if t is None else t.data_ptr() for t in ts])
 
 
 def ptr(t: Optional[torch.Tensor]):

@@ -26,6 +26,8 @@ _RSH = "_xeq_train_rsh"             # per-l list of Y_l [E, 2l+1] written by the
 _REC = "_xeq_train_records"         # per-edge records [E, roundup(B, 4) + 12] of the kernel message (ops.training_records), or absent
 # False: the message block of this pass stays on ATen tensor operations (the cross-check of the kernel form, tests/test_gpu_training.py)
 NATIVE_MESSAGE = True
+# False: norms, invariants and the update block's products stay on ATen tensor operations too (csrc/xeq_train_node.hip otherwise)
+NATIVE_NODE = True
 # data-dict flag set by BaseModel.forward for a training pass whose loss reads energies only (no forces, no virial): the blocks stay on
 # the fused HIP kernels and hand their parameters to the block functions, which return the parameter gradients (nn/fused.py)
 PARAM_GRADS = "_xeq_param_grads"
@@ -188,9 +190,36 @@ def equivariant_layer_norm(norm, x: torch.Tensor) -> torch.Tensor:
     return _flat(out)
 
 
-def _norms(module, s: torch.Tensor, x: torch.Tensor):
+def _native_node(module, s: torch.Tensor):
+    """(node_dim, mul) when the block's norms / products can take the kernels of csrc/xeq_train_node.hip: a device tensor, an affine
+    LayerNorm + EquivariantLayerNorm pair, irreps of one block per l <= 2 in ascending order whose l = 0 block is even."""
+    if not (NATIVE_NODE and s.is_cuda and s.dtype in (torch.float32, torch.float64)):
+        return None
+    ln, eq = module.norm, getattr(module, "o3norm", None)
+    if not isinstance(ln, torch.nn.LayerNorm) or ln.weight is None or ln.bias is None or eq is None or not hasattr(eq, "affine_weight"):
+        return None
+    irreps = eq.irreps
+    try:
+        mul = tuple(irreps.mul3())
+    except NotImplementedError:
+        return None
+    if any(ir.l == 0 and ir.p != 1 for _, ir in irreps) or eq.affine_bias.numel() != mul[0] or eq.affine_weight.numel() != sum(mul):
+        return None
+    return int(s.shape[1]), mul
+
+
+def _norms(module, s: torch.Tensor, x: torch.Tensor, bt: bool = False):
+    """(LayerNorm(s), EquivariantLayerNorm(x)); ``bt`` asks for xhat in the BT layout (a flat buffer) and is honoured by the kernel form
+    only -- the caller checks ``_native_node`` first."""
     if isinstance(module.norm, torch.nn.Identity):
         return s, x
+    nat = _native_node(module, s)
+    if nat is not None:
+        from .training_ops import NormFn
+
+        F, mul = nat
+        return NormFn.apply(s, x, module.norm.weight, module.norm.bias, module.o3norm.affine_weight, module.o3norm.affine_bias,
+                            (F, mul, float(module.norm.eps), float(module.o3norm.eps), 1 if bt else 0))
     return module.norm(s), equivariant_layer_norm(module.o3norm, x)
 
 
@@ -248,10 +277,53 @@ def o3_linear(lin, x: torch.Tensor) -> List[torch.Tensor]:
     return out
 
 
+def _uv_weights_ok(module, mul) -> bool:
+    want_w = sum(m * m for m in mul)
+    for lin in (module.update_U, module.update_V):
+        if lin.weight.numel() != want_w or lin.bias.numel() not in (0, mul[0]):
+            return False
+    return module.update_U.bias.numel() == module.update_V.bias.numel()
+
+
+def _update_on_kernels(module, data, s0, x0, mul):
+    """``update`` with the norms, the Invariant / channel dot and the products on csrc/xeq_train_node.hip (training_ops) and the
+    o3.Linear pair as one library GEMM per l on BT rows: [N (2l+1), mul_l] x [mul_l, 2 mul_l] = (U | V)."""
+    from .training_ops import UpdateOutFn, UvFn
+
+    N, C, F = s0.shape[0], module.node_num_irreps, module.node_dim
+    s, x_bt = _norms(module, s0, x0, bt=True)
+    uv, woff, base = [], 0, 0
+    lu, lv = module.update_U, module.update_V
+    for l in range(3):
+        m = mul[l]
+        if m == 0:
+            uv.append(s0.new_zeros(0))
+            continue
+        rows = N * (2 * l + 1)
+        xl = x_bt[N * base : N * base + rows * m].view(rows, m)
+        base += (2 * l + 1) * m
+        w = torch.cat([lu.weight[woff : woff + m * m].view(m, m), lv.weight[woff : woff + m * m].view(m, m)], dim=1) * (1.0 / math.sqrt(m))
+        woff += m * m
+        if l == 0 and lu.bias.numel() > 0:
+            uv.append(torch.addmm(torch.cat([lu.bias, lv.bias]), xl, w))
+        else:
+            uv.append(xl @ w)
+    vd = UvFn.apply(uv[0], uv[1], uv[2], (mul, float(module.invariant.eps)))
+    a = module.update_mlp(torch.cat([s, vd[:, :C]], dim=-1))
+    inner = module.dot_lin(vd[:, C:])
+    d_s, d_x = UpdateOutFn.apply(uv[0], uv[1], uv[2], a, inner, (int(F), mul))
+    data[keys.NODE_INVARIANT] = s0 + d_s
+    data[keys.NODE_EQUIVARIANT] = x0 + d_x
+    return data
+
+
 def update(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     s0, x0 = data[keys.NODE_INVARIANT], data[keys.NODE_EQUIVARIANT]
     lib.require_hip(s0)
     C, F = module.node_num_irreps, module.node_dim
+    nat = _native_node(module, s0)
+    if nat is not None and not isinstance(module.norm, torch.nn.Identity) and _uv_weights_ok(module, nat[1]):
+        return _update_on_kernels(module, data, s0, x0, nat[1])
     s, x = _norms(module, s0, x0)
     U, V = o3_linear(module.update_U, x), o3_linear(module.update_V, x)
     eps = module.invariant.eps

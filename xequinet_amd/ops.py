@@ -965,11 +965,17 @@ def _rec_from_q(q, gy, w, b, bp):
     return torch.cat([head[:, :B], z((q.shape[0], bp - B)), head[:, B:], gy, z((q.shape[0], 3))], dim=1)
 
 
-def _wb_from_q(q, rec, B, bp):
-    """dL/dW [H, B], dL/db [H] = q^T (record head)."""
-    head = torch.cat([rec[:, :B], rec[:, bp : bp + 1]], dim=1)
-    g = q.t() @ head
-    return g[:, :B].contiguous(), g[:, B].contiguous()
+def _wb_from_q(q, rec, cfg):
+    """dL/dW [H, B], dL/db [H] = q^T (record head | envelope column): xeq_message_q_wgrad and the sum over its chunks."""
+    B, F, mul, C, D, H, bp = _diff_sizes(cfg)
+    E = q.shape[0]
+    n_chunks = int(lib.load().xeq_message_q_wgrad_chunks(E))
+    parts = torch.empty((max(n_chunks, 1), H, bp + 1), dtype=q.dtype, device=q.device)
+    if n_chunks == 0:
+        parts.zero_()
+    KERNEL_TIMER.launch("xeq_message_q_wgrad", dtype_code(q), ptr(q), ptr(rec), E, B, F, mul3(mul), n_chunks, ptr(parts), stream())
+    g = parts.sum(0)
+    return g[:, :B].contiguous(), g[:, bp].contiguous()
 
 
 class DiffMessageGrad(Function):
@@ -983,7 +989,7 @@ class DiffMessageGrad(Function):
         g_s, g_x = g_s.contiguous(), g_x.contiguous()
         g_h, g_xh, q, gy = _diff_bwd(h, xhat, rec, w, b, g_s, g_x, graph, cfg)
         g_rec = _rec_from_q(q, gy, w, b, bp) if want[0] else None
-        g_w, g_b = _wb_from_q(q, rec, B, bp) if want[1] else (None, None)
+        g_w, g_b = _wb_from_q(q, rec, cfg) if want[1] else (None, None)
         ctx.save_for_backward(h, xhat, rec, w, b, g_s, g_x)
         ctx.graph, ctx.cfg = graph, cfg
         ctx.set_materialize_grads(False)
@@ -1035,14 +1041,14 @@ class DiffMessageGrad(Function):
             gh, gxh, q_c, gy = _diff_bwd(h, xhat, rec_c, w, b, g_s, g_x, graph, cfg)
             d_h, d_xh, gy_sum = add(d_h, gh), add(d_xh, gxh), add(gy_sum, gy)
             if need[3] or need[4]:
-                d_w, d_b = _wb_from_q(q_c, rec_c, B, bp)
+                d_w, d_b = _wb_from_q(q_c, rec_c, cfg)
             del q_c
         d_rec = None
         if q_ab is not None:
             if need[2]:
                 d_rec = _rec_from_q(q_ab, gy_sum if gy_sum is not None else zeros(E, 8), w, b, bp)
             if need[3] or need[4]:
-                gw, gb = _wb_from_q(q_ab, rec, B, bp)
+                gw, gb = _wb_from_q(q_ab, rec, cfg)
                 d_w, d_b = add(d_w, gw), add(d_b, gb)
         elif gy_sum is not None and need[2]:
             d_rec = torch.cat([zeros(E, bp + 1), gy_sum, zeros(E, 3)], dim=1)
