@@ -445,9 +445,10 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
  *                 dL/d(record head) = q [W | b] and dL/d[W | b] = q^T (record head) from two library GEMMs;
  *   gy[E, 8]    = dL/dY_1[3], dL/dY_2[5] of the edge.
  * flags: bit 0 the xhat layout, XEQ_SB_Y0_ZERO (also accepted by xeq_message_fwd_sb's xhat_layout): the l = 0 harmonic counts as 0 -- the
- * record holds a tangent of the harmonics; XEQ_SB_Q_ACCUMULATE: q += instead of q =.  f32 / f64. */
+ * record holds a tangent of the harmonics; XEQ_SB_Q_ACCUMULATE: q += instead of q =; XEQ_SB_NO_GY.  f32 / f64. */
 #define XEQ_SB_Y0_ZERO 8
 #define XEQ_SB_Q_ACCUMULATE 16
+#define XEQ_SB_NO_GY 32   /* gy is not wanted (and not written) */
 int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
                         const int64_t* center, const void* basis, const void* h, const void* xhat, const void* grad_s,
                         const void* grad_x, const void* w_rbf, const void* b_rbf, int num_basis, int node_dim,

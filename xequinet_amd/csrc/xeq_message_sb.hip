@@ -80,6 +80,7 @@ struct SbArgs {
   int chunk;  // consecutive nodes per XCD label
   int y0_zero;  // the l = 0 harmonic is 0 instead of 1: the record stands for a TANGENT of the harmonics (training pass, second order)
   int q_accum;  // k_message_bwd_sbq: add to the per-edge products instead of storing them
+  int want_gy;  // k_message_bwd_sbq: form dL/dY_1, dL/dY_2 per edge (eight wave reductions per edge otherwise saved)
 };
 
 template <typename T, int MAXB>
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 //   q[e, c]  = h[nbr(e), c] * P[e, c]   (P: the contraction of dL/dx_out with xhat / Y, or dL/ds_out)  -- the caller forms
 //              dL/drecord_head = q W' and dL/dW' = record_head^T q with two library GEMMs, q never outlives the call;
 //   gy[e, 8] = dL/dY_1, dL/dY_2 of the edge.
-template <typename T, int MAXB, int WPE>
+template <typename T, int MAXB, int U, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_message_bwd_sbq(SbArgs a, const T* __restrict__ eb,
                                                         const T* __restrict__ h, const T* __restrict__ xhat,
                                                         const T* __restrict__ grad_s, const T* __restrict__ grad_x,
@@ -460,79 +461,96 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
       const int32_t slot_v = pb + min(lane, cnt - 1);
       const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
       const int32_t ctr_v = (int32_t)a.other[eid_v];
-      for (int32_t p = pb; p < pe_; ++p) {
-        const int j = p - pb;
-        const int32_t eid = __builtin_amdgcn_readlane(eid_v, j);
-        const uint32_t cidx = (uint32_t)__builtin_amdgcn_readlane(ctr_v, j);
-        T gx[5];
-        const T dgm = grad_s[cidx * (uint32_t)F + cm.ts];
-        const T* gr = grad_x + cidx * (uint32_t)D;
-        gx[0] = gr[gcomp[0]];
-        if (cm.wnm >= 3) {  // wave-uniform
-          gx[1] = gr[gcomp[1]];
-          gx[2] = gr[gcomp[2]];
-        } else {
-          gx[1] = gx[2] = T(0);
-        }
-        if (cm.wnm >= 5) {
-          gx[3] = gr[gcomp[3]];
-          gx[4] = gr[gcomp[4]];
-        } else {
-          gx[3] = gx[4] = T(0);
-        }
+      for (int32_t p = pb; p < pe_; p += U) {
+        int32_t eid[U];
+        uint32_t cidx[U];
 #pragma unroll
-        for (int m = 0; m < 5; ++m)
-          if (m >= cm.nm) gx[m] = T(0);
-        const T* rec = eb + (uint32_t)eid * (uint32_t)EW;
-        const T fe = rec[BP];
-        const T ps = filt(ws, bs, rec, fe), pe = filt(we, be, rec, fe), pm = filt(wm, bm, rec, fe);
-        T y[5];
-        lane_y<T>(rec + BP, cm.l, y, y00);
-        T dgs = T(0), dge = T(0);
-#pragma unroll
-        for (int m = 0; m < 5; ++m) {
-          dgs += xh[m] * gx[m];
-          dge += y[m] * gx[m];
+        for (int u = 0; u < U; ++u) {
+          const int j = min(p + u, pe_ - 1) - pb;
+          eid[u] = __builtin_amdgcn_readlane(eid_v, j);
+          cidx[u] = (uint32_t)__builtin_amdgcn_readlane(ctr_v, j);
         }
-        const T dg_m = cm.has_s ? dgm : T(0);
-        acc_hs += ps * dgs;
-        acc_he += pe * dge;
-        acc_hm += pm * dg_m;
-        const T gate = hs * ps;
+        T gx[U][5], dgm[U];
 #pragma unroll
-        for (int m = 0; m < 5; ++m) acc_xh[m] += gate * gx[m];
-        T* qr = q_out + (int64_t)eid * H;
-        if (a.q_accum) {
-          if (cm.has_u) {
-            qr[cm.tu] += hs * dgs;
-            qr[C + cm.tu] += he * dge;
+        for (int u = 0; u < U; ++u) {
+          dgm[u] = grad_s[cidx[u] * (uint32_t)F + cm.ts];
+          const T* gr = grad_x + cidx[u] * (uint32_t)D;
+          gx[u][0] = gr[gcomp[0]];
+          if (cm.wnm >= 3) {  // wave-uniform
+            gx[u][1] = gr[gcomp[1]];
+            gx[u][2] = gr[gcomp[2]];
+          } else {
+            gx[u][1] = gx[u][2] = T(0);
           }
-          if (cm.has_s) qr[2 * C + cm.ts] += hm * dg_m;
-        } else {
-          if (cm.has_u) {
-            qr[cm.tu] = hs * dgs;
-            qr[C + cm.tu] = he * dge;
+          if (cm.wnm >= 5) {
+            gx[u][3] = gr[gcomp[3]];
+            gx[u][4] = gr[gcomp[4]];
+          } else {
+            gx[u][3] = gx[u][4] = T(0);
           }
-          if (cm.has_s) qr[2 * C + cm.ts] = hm * dg_m;
+#pragma unroll
+          for (int m = 0; m < 5; ++m)
+            if (m >= cm.nm) gx[u][m] = T(0);
         }
-        const T gy = he * pe;
-        T r1[3] = {T(0), T(0), T(0)}, r2[5] = {T(0), T(0), T(0), T(0), T(0)};
-        if (wave_has1) {
 #pragma unroll
-          for (int m = 0; m < 3; ++m) r1[m] = wave_total(is1 ? gy * gx[m] : T(0));
-        }
-        if (wave_has2) {
+        for (int u = 0; u < U; ++u) {
+          if (p + u < pe_) {  // uniform
+            const int j = p + u - pb;
+            const T* rec = eb + (uint32_t)eid[u] * (uint32_t)EW;
+            const T fe = rec[BP];
+            const T ps = filt(ws, bs, rec, fe), pe = filt(we, be, rec, fe), pm = filt(wm, bm, rec, fe);
+            T y[5];
+            lane_y<T>(rec + BP, cm.l, y, y00);
+            T dgs = T(0), dge = T(0);
 #pragma unroll
-          for (int m = 0; m < 5; ++m) r2[m] = wave_total(is2 ? gy * gx[m] : T(0));
-        }
-        if (lane == 0) {
+            for (int m = 0; m < 5; ++m) {
+              dgs += xh[m] * gx[u][m];
+              dge += y[m] * gx[u][m];
+            }
+            const T dg_m = cm.has_s ? dgm[u] : T(0);
+            acc_hs += ps * dgs;
+            acc_he += pe * dge;
+            acc_hm += pm * dg_m;
+            const T gate = hs * ps;
 #pragma unroll
-          for (int m = 0; m < 3; ++m) red[j][wave][m] = r1[m];
+            for (int m = 0; m < 5; ++m) acc_xh[m] += gate * gx[u][m];
+            T* qr = q_out + (int64_t)eid[u] * H;
+            if (a.q_accum) {
+              if (cm.has_u) {
+                qr[cm.tu] += hs * dgs;
+                qr[C + cm.tu] += he * dge;
+              }
+              if (cm.has_s) qr[2 * C + cm.ts] += hm * dg_m;
+            } else {
+              if (cm.has_u) {
+                qr[cm.tu] = hs * dgs;
+                qr[C + cm.tu] = he * dge;
+              }
+              if (cm.has_s) qr[2 * C + cm.ts] = hm * dg_m;
+            }
+            if (a.want_gy) {  // uniform
+              const T gy = he * pe;
+              T r1[3] = {T(0), T(0), T(0)}, r2[5] = {T(0), T(0), T(0), T(0), T(0)};
+              if (wave_has1) {
 #pragma unroll
-          for (int m = 0; m < 5; ++m) red[j][wave][3 + m] = r2[m];
-          if (wave == 0) red_eid[j] = eid;
+                for (int m = 0; m < 3; ++m) r1[m] = wave_total(is1 ? gy * gx[u][m] : T(0));
+              }
+              if (wave_has2) {
+#pragma unroll
+                for (int m = 0; m < 5; ++m) r2[m] = wave_total(is2 ? gy * gx[u][m] : T(0));
+              }
+              if (lane == 0) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) red[j][wave][m] = r1[m];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) red[j][wave][3 + m] = r2[m];
+                if (wave == 0) red_eid[j] = eid[u];
+              }
+            }
+          }
         }
       }
+      if (!a.want_gy) continue;   // uniform: no harmonics' gradient wanted, nothing was put in LDS
       __syncthreads();
       for (int i = t; i < cnt * 8; i += 256) {  // a lane per (edge, harmonic): the four waves' sums in wave order
         const int j = i >> 3, m = i & 7;
@@ -740,16 +758,16 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   do {                                                                                                                   \
     if (dtype == XEQ_F32) {                                                                                              \
       using T = float;                                                                                                   \
-      if (num_basis <= 8) hipLaunchKernelGGL((k_message_bwd_sbq<T, 8, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);        \
-      else if (num_basis <= 16) hipLaunchKernelGGL((k_message_bwd_sbq<T, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else if (num_basis <= 20) hipLaunchKernelGGL((k_message_bwd_sbq<T, 20, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((k_message_bwd_sbq<T, 32, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+      if (num_basis <= 8) hipLaunchKernelGGL((k_message_bwd_sbq<T, 8, 2, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);        \
+      else if (num_basis <= 16) hipLaunchKernelGGL((k_message_bwd_sbq<T, 16, 2, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (num_basis <= 20) hipLaunchKernelGGL((k_message_bwd_sbq<T, 20, 2, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((k_message_bwd_sbq<T, 32, 2, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
     } else if (dtype == XEQ_F64) {                                                                                       \
       using T = double;                                                                                                  \
-      if (num_basis <= 8) hipLaunchKernelGGL((k_message_bwd_sbq<T, 8, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);        \
-      else if (num_basis <= 16) hipLaunchKernelGGL((k_message_bwd_sbq<T, 16, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else if (num_basis <= 20) hipLaunchKernelGGL((k_message_bwd_sbq<T, 20, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((k_message_bwd_sbq<T, 32, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+      if (num_basis <= 8) hipLaunchKernelGGL((k_message_bwd_sbq<T, 8, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);        \
+      else if (num_basis <= 16) hipLaunchKernelGGL((k_message_bwd_sbq<T, 16, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else if (num_basis <= 20) hipLaunchKernelGGL((k_message_bwd_sbq<T, 20, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((k_message_bwd_sbq<T, 32, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
     } else {                                                                                                             \
       xeq::set_error("unsupported dtype %d", dtype);                                                                     \
       return XEQ_ERR_INVALID_ARGUMENT;                                                                                   \
@@ -771,6 +789,7 @@ int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32
   a.xl = flags & 1;
   a.y0_zero = (flags & XEQ_SB_Y0_ZERO) ? 1 : 0;
   a.q_accum = (flags & XEQ_SB_Q_ACCUMULATE) ? 1 : 0;
+  a.want_gy = (flags & XEQ_SB_NO_GY) ? 0 : 1;
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
   XEQ_SBQ_DISPATCH(a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf,
                    (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat, (T*)q, (T*)gy);

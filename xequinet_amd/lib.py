@@ -20,6 +20,7 @@ COPY_MANY_MAX = 16       # XEQ_COPY_MANY_MAX of include/xeq.h
 XHAT_HIGHER_L_ZERO = 2   # XEQ_XHAT_HIGHER_L_ZERO of include/xeq.h: hint bit on the xhat_layout argument of the wq message kernels
 SB_Y0_ZERO = 8           # XEQ_SB_Y0_ZERO / XEQ_SB_Q_ACCUMULATE: the training-pass forms of the sb message kernels (ops.DiffMessage)
 SB_Q_ACCUMULATE = 16
+SB_NO_GY = 32
 WQ_MIRROR_WALK = 4       # XEQ_WQ_MIRROR_WALK: the reverse wq kernel walks the forward plan of a symmetric list
 RBF_KINDS = {"bessel": 0, "gaussian": 1}
 CUTOFF_KINDS = {"cosine": 0, "polynomial": 1}

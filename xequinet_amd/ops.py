@@ -910,15 +910,15 @@ def _diff_fwd(h, xhat, rec, w, b, graph: "EdgeGraph", cfg, y0_zero: bool = False
     return ds, dx
 
 
-def _diff_bwd(h, xhat, rec, w, b, g_s, g_x, graph: "EdgeGraph", cfg, q=None, y0_zero: bool = False):
+def _diff_bwd(h, xhat, rec, w, b, g_s, g_x, graph: "EdgeGraph", cfg, q=None, y0_zero: bool = False, want_gy: bool = True):
     """(grad_h, grad_xhat, q, gy) of xeq_message_bwd_sbq; ``q`` given: the per-edge products are added to it."""
     B, F, mul, C, D, H, bp = _diff_sizes(cfg)
     N, E = graph.n_nodes, graph.n_edges
     g_h, g_xh = torch.empty_like(h), torch.empty_like(xhat)
-    flags = (lib.SB_Y0_ZERO if y0_zero else 0) | (lib.SB_Q_ACCUMULATE if q is not None else 0)
+    flags = (lib.SB_Y0_ZERO if y0_zero else 0) | (lib.SB_Q_ACCUMULATE if q is not None else 0) | (0 if want_gy else lib.SB_NO_GY)
     if q is None:
         q = torch.empty((E, H), dtype=h.dtype, device=h.device)
-    gy = torch.zeros((E, 8), dtype=h.dtype, device=h.device)
+    gy = torch.zeros((E, 8), dtype=h.dtype, device=h.device) if want_gy else None
     KERNEL_TIMER.launch("xeq_message_bwd_sbq", dtype_code(h), N, E, ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(graph.edge_index[0]),
                         ptr(rec), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w), ptr(b), B, F, mul3(mul), ptr(g_h), ptr(g_xh),
                         ptr(q), ptr(gy), flags, stream())
@@ -1030,7 +1030,7 @@ class DiffMessageGrad(Function):
                 rec_b = torch.cat([rec[:, : bp + 1], u_y, zeros(E, 3)], dim=1)
             _, x_ = _diff_fwd(h, ux, rec_b, w, b, graph, cfg, y0_zero=True)
             d_gx = add(d_gx, x_)
-            gh, _, q_ab, _ = _diff_bwd(h, ux, rec_b, w, b, zeros(N, F), g_x, graph, cfg, q=q_ab, y0_zero=True)
+            gh, _, q_ab, _ = _diff_bwd(h, ux, rec_b, w, b, zeros(N, F), g_x, graph, cfg, q=q_ab, y0_zero=True, want_gy=False)
             d_h = add(d_h, gh)
         if u_rec is not None:                    # C: record head <- its cotangent
             rec_c = torch.cat([u_rec[:, : bp + 1], rec[:, bp + 1 :]], dim=1)
