@@ -59,6 +59,24 @@ def test_c_abi_argument_errors_are_reported_without_a_gpu():
     rc = handle.xeq_csr_by_key_bounded(None, 10, 5, None, None, 0, None, None, None)           # no device-side count
     assert rc == 1 and b"bad sizes" in handle.xeq_last_error()
     assert handle.xeq_message_wq_pcap(100, 1000) == 1400                                        # E + 4 N: a quad for every node without an edge
+    # round-4 entries: the twice-differentiable training pass
+    rc = handle.xeq_message_bwd_sbq(0, 10, 10, None, None, None, None, None, None, None, None, None, None, 40, 128, mul, None, None, None, None, 0, None)
+    assert rc == 1 and b"num_basis" in handle.xeq_last_error()
+    assert handle.xeq_message_q_wgrad_chunks(311994) == 1219 and handle.xeq_message_q_wgrad_chunks(0) == 0
+    rc = handle.xeq_message_q_wgrad(0, None, None, 1000, 20, 128, mul, 3, None, None)           # wrong chunk count
+    assert rc == 1 and b"n_chunks" in handle.xeq_last_error()
+    rc = handle.xeq_message_q_wgrad(0, None, None, 1000, 20, 512, mul, 4, None, None)           # 960 filter rows
+    assert rc == 1 and b"768" in handle.xeq_last_error()
+    rc = handle.xeq_train_norm(0, 0, 10, None, None, None, None, None, None, None, None, None, None, 128, mul, 1e-5, 1e-5, 2, None, None, None, None)
+    assert rc == 1 and b"layout" in handle.xeq_last_error()
+    rc = handle.xeq_train_norm(0, 1, 10, None, None, None, None, None, None, None, None, None, None, 128, mul, 1e-5, 1e-5, 0, None, None, None, None)
+    assert rc == 1 and b"reverse form" in handle.xeq_last_error()
+    rc = handle.xeq_train_uv(0, 1, 10, None, None, None, mul, 1e-5, None, None, None)
+    assert rc == 1 and b"reverse form" in handle.xeq_last_error()
+    rc = handle.xeq_train_out(7, 0, 10, None, None, None, None, None, None, None, None, 128, mul, None, None, None, None)   # bad dtype code
+    assert rc == 1
+    rc = handle.xeq_train_out(0, 0, 10, None, None, None, None, None, None, None, None, 128, lib.mul3((0, 0, 0)), None, None, None, None)
+    assert rc == 1 and b"no channels" in handle.xeq_last_error()
 
 
 def test_irreps_mirror():
