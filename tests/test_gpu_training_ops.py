@@ -140,8 +140,8 @@ def test_message_kernels_first_and_second_order(sorted_edges):
     assert torch.allclose(dx, want_x, rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("periodic", [False, True])
-def test_force_loss_gradients_kernel_form_equals_tensor_form(periodic, monkeypatch):
+@pytest.mark.parametrize("periodic,linear", [(False, False), (True, False), (False, True)])
+def test_force_loss_gradients_kernel_form_equals_tensor_form(periodic, linear, monkeypatch):
     """The whole model, energy + forces (+ virial) in the loss: every parameter gradient from the kernel forms of the training pass
     equals the one from the tensor form of the same arithmetic; the kernel forms did run."""
     weights = {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 10.0}
@@ -156,6 +156,7 @@ def test_force_loss_gradients_kernel_form_equals_tensor_form(periodic, monkeypat
     for native in (True, False):
         monkeypatch.setattr(tr, "NATIVE_MESSAGE", native)
         monkeypatch.setattr(tr, "NATIVE_NODE", native)
+        monkeypatch.setattr(tr, "NATIVE_LINEAR", native and linear)     # linear layers as LinearFn / WGradFn (off by default: host-bound)
         model = _model(torch.float64, **SMALL).train()
         ops.KERNEL_TIMER.reset(True)
         loss, _ = train.weighted_loss(model(dict(dev), True, periodic), tgt, weights)
@@ -169,3 +170,24 @@ def test_force_loss_gradients_kernel_form_equals_tensor_form(periodic, monkeypat
     for name, g in grads[False].items():
         err = (grads[True][name] - g).abs().max().item()
         assert err <= 1e-9 * max(1e-6, g.abs().max().item()), f"{name}: {err:.2e} of {g.abs().max().item():.2e}"
+
+
+def test_linear_function_pair_is_closed_under_differentiation():
+    """LinearFn / WGradFn: values and two orders of derivatives equal the library's, in fp64 (library products inside) and in fp32 (the
+    row reductions on xeq_wgrad; tolerance 2e-5 of the largest entry: different summation orders of 300 fp32 rows)."""
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        x = _rand(300, 64, seed=1).detach().to(dtype).requires_grad_()
+        W = _rand(96, 64, seed=2).detach().to(dtype).requires_grad_()
+        b = _rand(96, seed=3).detach().to(dtype).requires_grad_()
+        t = _rand(300, 96, seed=4).detach().to(dtype)
+        outs = []
+        for fn in (lambda: tops.LinearFn.apply(x, W, b), lambda: torch.nn.functional.linear(x, W, b)):
+            y = torch.tanh(fn())
+            (gx,) = torch.autograd.grad((y * t).sum(), x, create_graph=True)
+            second = torch.autograd.grad((gx * gx).sum(), (x, W, b), allow_unused=True)
+            outs.append((y, gx, *second))
+        for got, want in zip(*outs):
+            if want is None:
+                assert got is None or float(got.abs().max()) == 0.0
+            else:
+                assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))

@@ -28,6 +28,10 @@ _REC = "_xeq_train_records"         # per-edge records [E, roundup(B, 4) + 12] o
 NATIVE_MESSAGE = True
 # False: norms, invariants and the update block's products stay on ATen tensor operations too (csrc/xeq_train_node.hip otherwise)
 NATIVE_NODE = True
+# True: the linear layers as training_ops.LinearFn, i.e. every reduction over the N rows (weight gradients of both orders) on xeq_wgrad
+# instead of the library.  Measured on the QM9-1024 energy+force step: kernel time 40.4 -> 37.0 ms, but ~100 more Python autograd nodes
+# per step make the HOST the bound (wall 39 -> 44 ms); off until that step is captured as a graph (profiles/r04_train_step.txt)
+NATIVE_LINEAR = False
 # data-dict flag set by BaseModel.forward for a training pass whose loss reads energies only (no forces, no virial): the blocks stay on
 # the fused HIP kernels and hand their parameters to the block functions, which return the parameter gradients (nn/fused.py)
 PARAM_GRADS = "_xeq_param_grads"
@@ -190,6 +194,16 @@ def equivariant_layer_norm(norm, x: torch.Tensor) -> torch.Tensor:
     return _flat(out)
 
 
+def _mlp(seq, x: torch.Tensor) -> torch.Tensor:
+    """scalar_mlp / update_mlp / dot_lin / out_mlp: the module itself, or (NATIVE_LINEAR) with the weight-gradient products on
+    ``xeq_wgrad`` (training_ops.LinearFn)."""
+    if NATIVE_LINEAR and x.is_cuda and (isinstance(seq, torch.nn.Linear) or isinstance(seq, torch.nn.Sequential)):
+        from .training_ops import mlp
+
+        return mlp(seq, x)
+    return seq(x)
+
+
 def _native_node(module, s: torch.Tensor):
     """(node_dim, mul) when the block's norms / products can take the kernels of csrc/xeq_train_node.hip: a device tensor, an affine
     LayerNorm + EquivariantLayerNorm pair, irreps of one block per l <= 2 in ascending order whose l = 0 block is even."""
@@ -231,7 +245,7 @@ def message(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     ei = data[keys.EDGE_INDEX]
     center, neighbor = ei[keys.CENTER_IDX].long(), ei[keys.NEIGHBOR_IDX].long()
     s, x = _norms(module, s0, x0)
-    scalar_out = module.scalar_mlp(s)
+    scalar_out = _mlp(module.scalar_mlp, s)
     rec = data.get(_REC)
     if rec is not None:
         # the edge side on the kernels: the aggregation, its reverse pass and the reverse of that (ops.DiffMessage); nothing of size
@@ -288,7 +302,7 @@ def _uv_weights_ok(module, mul) -> bool:
 def _update_on_kernels(module, data, s0, x0, mul):
     """``update`` with the norms, the Invariant / channel dot and the products on csrc/xeq_train_node.hip (training_ops) and the
     o3.Linear pair as one library GEMM per l on BT rows: [N (2l+1), mul_l] x [mul_l, 2 mul_l] = (U | V)."""
-    from .training_ops import UpdateOutFn, UvFn
+    from .training_ops import LinearFn, UpdateOutFn, UvFn
 
     N, C, F = s0.shape[0], module.node_num_irreps, module.node_dim
     s, x_bt = _norms(module, s0, x0, bt=True)
@@ -304,13 +318,14 @@ def _update_on_kernels(module, data, s0, x0, mul):
         base += (2 * l + 1) * m
         w = torch.cat([lu.weight[woff : woff + m * m].view(m, m), lv.weight[woff : woff + m * m].view(m, m)], dim=1) * (1.0 / math.sqrt(m))
         woff += m * m
-        if l == 0 and lu.bias.numel() > 0:
-            uv.append(torch.addmm(torch.cat([lu.bias, lv.bias]), xl, w))
+        bias = torch.cat([lu.bias, lv.bias]) if l == 0 and lu.bias.numel() > 0 else None
+        if NATIVE_LINEAR:
+            uv.append(LinearFn.apply(xl, w.t(), bias))
         else:
-            uv.append(xl @ w)
+            uv.append(xl @ w if bias is None else torch.addmm(bias, xl, w))
     vd = UvFn.apply(uv[0], uv[1], uv[2], (mul, float(module.invariant.eps)))
-    a = module.update_mlp(torch.cat([s, vd[:, :C]], dim=-1))
-    inner = module.dot_lin(vd[:, C:])
+    a = _mlp(module.update_mlp, torch.cat([s, vd[:, :C]], dim=-1))
+    inner = _mlp(module.dot_lin, vd[:, C:])
     d_s, d_x = UpdateOutFn.apply(uv[0], uv[1], uv[2], a, inner, (int(F), mul))
     data[keys.NODE_INVARIANT] = s0 + d_s
     data[keys.NODE_EQUIVARIANT] = x0 + d_x
@@ -343,7 +358,7 @@ def update(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 # ---- energy head (nn/output.py:114-128) --------------------------------------------------------------------------------------------
 def energy_out(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     lib.require_hip(data[keys.NODE_INVARIANT])
-    atom = module.out_mlp(data[keys.NODE_INVARIANT]).reshape(-1)
+    atom = _mlp(module.out_mlp, data[keys.NODE_INVARIANT]).reshape(-1)
     if keys.ATOMIC_ENERGIES in data:
         atom = data[keys.ATOMIC_ENERGIES] + atom
     n_graphs = data[keys.BATCH_PTR].numel() - 1

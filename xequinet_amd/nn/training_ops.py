@@ -204,3 +204,51 @@ class UpdateOutGrad(Function):
         d_gs, d_gx = _out_call(0, uv, u, a, u_a, inner, u_in, None, None, ctx.meta)
         d_uv, d_a, d_in = _out_call(1, uv, u, a, u_a, inner, u_in, g_s, g_x, ctx.meta)
         return (*d_uv, d_a, d_in, d_gs, d_gx, None)
+
+
+# ---- linear layers: the weight-gradient products on the row-chunk kernel ----------------------------------------------------------------
+class LinearFn(Function):
+    """y = x W^T (+ b) on rows (nn.Linear, and the o3.Linear blocks on BT rows).  Its reverse pass is written with ``LinearFn`` and
+    ``WGradFn`` themselves (dL/dx = g W, dL/dW = g^T x), so every order of derivative stays on these two products -- and every
+    reduction over the N rows, which the library's GEMMs run at a tenth of their rate for these shapes ([576 x N] x [N x 128] ...), goes
+    to ``xeq_wgrad`` (fp32; nn/fused.py ``_wgrad``).  The row-parallel products stay library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        d_x = LinearFn.apply(g, W.t(), None) if ctx.needs_input_grad[0] else None
+        d_W = WGradFn.apply(g, x) if ctx.needs_input_grad[1] else None
+        d_b = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return d_x, d_W, d_b
+
+
+class WGradFn(Function):
+    """a^T b over the rows: a [N, M], b [N, K] -> [M, K]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        from .fused import _wgrad
+
+        ctx.save_for_backward(a, b)
+        return _wgrad(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, U):
+        a, b = ctx.saved_tensors
+        d_a = LinearFn.apply(b, U, None) if ctx.needs_input_grad[0] else None          # b U^T
+        d_b = LinearFn.apply(a, U.t(), None) if ctx.needs_input_grad[1] else None      # a U
+        return d_a, d_b
+
+
+def mlp(seq: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """An nn.Sequential of nn.Linear and activations (or one nn.Linear) with the linear layers as ``LinearFn``."""
+    mods = [seq] if isinstance(seq, torch.nn.Linear) else list(seq)
+    for m in mods:
+        x = LinearFn.apply(x, m.weight, m.bias) if isinstance(m, torch.nn.Linear) else m(x)
+    return x

@@ -1014,25 +1014,7 @@ class DiffMessageGrad(Function):
         def add(acc, t):
             return t if acc is None else acc + t
 
-        if u_h is not None:                      # A: h <- u_h
-            u_h = u_h.contiguous()
-            s_, x_ = _diff_fwd(u_h, xhat, rec, w, b, graph, cfg)
-            d_gs, d_gx = add(d_gs, s_), add(d_gx, x_)
-            _, gxh, q_ab, gy = _diff_bwd(u_h, xhat, rec, w, b, g_s, g_x, graph, cfg)
-            d_xh, gy_sum = add(d_xh, gxh), add(gy_sum, gy)
-        u_y = None if u_rec is None else u_rec[:, bp + 1 : bp + 9]
-        if u_xh is not None or u_rec is not None:  # B: (xhat, Y) <- (u_xhat, u_Y); dL/ds_out plays no part
-            ux = zeros(*xhat.shape) if u_xh is None else u_xh.contiguous()
-            rec_b = rec if u_rec is None else None
-            if u_rec is None:
-                rec_b = torch.cat([rec[:, : bp + 1], zeros(E, 11)], dim=1)
-            else:
-                rec_b = torch.cat([rec[:, : bp + 1], u_y, zeros(E, 3)], dim=1)
-            _, x_ = _diff_fwd(h, ux, rec_b, w, b, graph, cfg, y0_zero=True)
-            d_gx = add(d_gx, x_)
-            gh, _, q_ab, _ = _diff_bwd(h, ux, rec_b, w, b, zeros(N, F), g_x, graph, cfg, q=q_ab, y0_zero=True, want_gy=False)
-            d_h = add(d_h, gh)
-        if u_rec is not None:                    # C: record head <- its cotangent
+        if u_rec is not None:                    # C: record head <- its cotangent (first: its products are dropped before the others exist)
             rec_c = torch.cat([u_rec[:, : bp + 1], rec[:, bp + 1 :]], dim=1)
             if bp > B:
                 rec_c[:, B:bp] = 0
@@ -1043,6 +1025,23 @@ class DiffMessageGrad(Function):
             if need[3] or need[4]:
                 d_w, d_b = _wb_from_q(q_c, rec_c, cfg)
             del q_c
+        if u_h is not None:                      # A: h <- u_h
+            u_h = u_h.contiguous()
+            s_, x_ = _diff_fwd(u_h, xhat, rec, w, b, graph, cfg)
+            d_gs, d_gx = add(d_gs, s_), add(d_gx, x_)
+            _, gxh, q_ab, gy = _diff_bwd(u_h, xhat, rec, w, b, g_s, g_x, graph, cfg)
+            d_xh, gy_sum = add(d_xh, gxh), add(gy_sum, gy)
+        u_y = None if u_rec is None else u_rec[:, bp + 1 : bp + 9]
+        if u_xh is not None or u_rec is not None:  # B: (xhat, Y) <- (u_xhat, u_Y); dL/ds_out plays no part
+            ux = zeros(*xhat.shape) if u_xh is None else u_xh.contiguous()
+            if u_rec is None:
+                rec_b = torch.cat([rec[:, : bp + 1], zeros(E, 11)], dim=1)
+            else:
+                rec_b = torch.cat([rec[:, : bp + 1], u_y, zeros(E, 3)], dim=1)
+            _, x_ = _diff_fwd(h, ux, rec_b, w, b, graph, cfg, y0_zero=True)
+            d_gx = add(d_gx, x_)
+            gh, _, q_ab, _ = _diff_bwd(h, ux, rec_b, w, b, zeros(N, F), g_x, graph, cfg, q=q_ab, y0_zero=True, want_gy=False)
+            d_h = add(d_h, gh)
         d_rec = None
         if q_ab is not None:
             if need[2]:
