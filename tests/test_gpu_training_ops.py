@@ -190,4 +190,39 @@ def test_linear_function_pair_is_closed_under_differentiation():
             if want is None:
                 assert got is None or float(got.abs().max()) == 0.0
             else:
-                assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+                assert float((got - want).detach().abs().max()) <= tol * max(1.0, float(want.detach().abs().max()))
+
+
+def test_force_loss_kernel_form_without_l2_channels_and_with_an_isolated_atom(monkeypatch):
+    """Irreps that stop at l = 1 (no Y_2 rows, an empty uv_2) and an atom without neighbours (a row of the walk without edges): the kernel
+    form of the force-loss pass against the tensor form."""
+    from oracle import xpainn_oracle as orc
+    from xequinet_amd.data import synthetic as syn
+
+    cfg = dict(node_dim=64, node_irreps="64x0e + 32x1o", action_blocks=2, hidden_dim=32)
+    pos, z, ptr = syn.synth_qm9_batch(4, seed=3)
+    pos = pos.copy()
+    pos[0] += 100.0                                              # out of every cutoff sphere
+    ei = orc.radius_graph_canonical(pos, ptr, 5.0)
+    assert not (ei == 0).any()
+    batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    dev = {"pos": torch.tensor(pos, dtype=torch.float64, device=DEV), "atomic_numbers": torch.tensor(z.astype(np.int64), device=DEV),
+           "edge_index": torch.tensor(ei, device=DEV), "batch": torch.tensor(batch, device=DEV), "ptr": torch.tensor(ptr, device=DEV)}
+    g = torch.Generator().manual_seed(2)
+    tgt = {keys.TOTAL_ENERGY: torch.randn(4, generator=g, dtype=torch.float64).to(DEV),
+           keys.FORCES: torch.randn(len(pos), 3, generator=g, dtype=torch.float64).to(DEV), keys.BATCH_PTR: dev["ptr"]}
+    weights = {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 5.0}
+    grads = {}
+    for native in (True, False):
+        monkeypatch.setattr(tr, "NATIVE_MESSAGE", native)
+        monkeypatch.setattr(tr, "NATIVE_NODE", native)
+        model = _model(torch.float64, **cfg).train()
+        result = model(dict(dev), True, False)
+        loss, _ = train.weighted_loss(result, tgt, weights)
+        loss.backward()
+        assert float(result[keys.FORCES][0].abs().max()) == 0.0          # the isolated atom feels nothing
+        grads[native] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) >= 40
+    for name, want in grads[False].items():
+        err = (grads[True][name] - want).abs().max().item()
+        assert err <= 1e-9 * max(1e-6, want.abs().max().item()), f"{name}: {err:.2e} of {want.abs().max().item():.2e}"
