@@ -244,6 +244,11 @@ def message(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     irreps, C = module.node_irreps, module.node_num_irreps
     ei = data[keys.EDGE_INDEX]
     center, neighbor = ei[keys.CENTER_IDX].long(), ei[keys.NEIGHBOR_IDX].long()
+    if getattr(data.get(keys.EDGE_GRAPH), "edge_count_on_device", False):
+        # a capacity-sized edge list (train.GraphedTrainStep): the slots behind the true count hold stale pairs, which this form would
+        # walk as edges (its tensors have one row per SLOT); only the native energy-loss pass stops at the device-side count
+        raise NotImplementedError("the twice-differentiable training pass does not take a capacity-sized edge list "
+                                  "(GraphedTrainStep captures the native energy-loss pass only: keep model.native_training = True)")
     s, x = _norms(module, s0, x0)
     scalar_out = _mlp(module.scalar_mlp, s)
     rec = data.get(_REC)
