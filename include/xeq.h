@@ -455,6 +455,10 @@ int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32
                         const int32_t mul[3], void* grad_h, void* grad_xhat, void* q, void* gy, int flags, void* stream);
 /* dL/d[W | b] from those products: parts[n_chunks][2C+F][roundup(B, 4) + 1] with out[c, k] = sum_e q[e, c] basis[e, k] over the chunk's
  * edges (columns [0, B): dL/dW[c, k]; column roundup(B, 4): dL/db[c]); the caller adds the chunks in order.  At most 768 filter rows. */
+/* Rows [*n_valid, n_rows) of a row-major buffer of 4-byte words := 0 (n_valid: device pointer).  For q and a capacity-sized edge list whose
+ * true count never reached the host (train.GraphedTrainStep): xeq_message_bwd_sbq writes the rows of walked edges only, the two products
+ * above read every row. */
+int xeq_zero_rows_from(void* buf, int64_t row_words, int64_t n_rows, const int32_t* n_valid, void* stream);
 int xeq_message_q_wgrad_chunks(int64_t n_edges);
 int xeq_message_q_wgrad(int dtype, const void* q, const void* basis, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3],
                         int n_chunks, void* parts, void* stream);

@@ -23,6 +23,19 @@ g = torch.Generator().manual_seed(0)
 tgt = {keys.TOTAL_ENERGY: torch.randn(n_mol, generator=g).to(dev), keys.FORCES: torch.randn(len(pos), 3, generator=g).to(dev), keys.BATCH_PTR: data["ptr"]}
 w = {keys.TOTAL_ENERGY: 1.0} if mode.startswith("energy") else {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 10.0}
 model.native_training = mode != "energy-aten"
+if mode == "forces-graph":   # energy + forces, the twice-differentiable pass inside ONE captured graph
+    from xequinet_amd import runtime
+    from xequinet_amd.nn import training as tr
+    tr.NATIVE_LINEAR = len(sys.argv) > 3 and sys.argv[3] == "linear"
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+    gstep = train.GraphedTrainStep(model, opt, (len(pos) + 64, n_mol, runtime.pair_capacity(ptr)), forces_weight=10.0)
+    p_d, z_d, ptr_d, b_d = data["pos"].detach(), data["atomic_numbers"], data["ptr"], data["batch"]
+    for _ in range(3): l = gstep(p_d, z_d, ptr_d, tgt[keys.TOTAL_ENERGY], batch=b_d, target_forces=tgt[keys.FORCES])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): l = gstep(p_d, z_d, ptr_d, tgt[keys.TOTAL_ENERGY], batch=b_d, target_forces=tgt[keys.FORCES])
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+    print(f"train step (energy + forces, ONE captured graph incl. the neighbour list, linear layers {'LinearFn' if tr.NATIVE_LINEAR else 'torch.nn'}) n_mol={n_mol} N={len(pos)} E={E}: {dt*1e3:.2f} ms/step, {E/dt/1e6:.1f} M edges/s, peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss {l.item():.4f}")
+    sys.exit(0)
 if mode == "energy-graph":   # the whole step (neighbour list included) as ONE captured HIP graph: train.GraphedTrainStep
     from xequinet_amd import runtime
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)

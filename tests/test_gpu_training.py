@@ -224,6 +224,49 @@ def test_training_step_as_one_graph_follows_the_host_launched_steps():
         assert (p - q).abs().max().item() <= 2e-4 * scale, n
 
 
+def test_force_loss_training_step_as_one_graph_follows_the_host_launched_steps():
+    """The same with forces in the loss: the twice-differentiable pass (kernel forms of nn/training.py) inside the capture, over the
+    capacity-sized edge list -- padding atoms, empty graph slots and the edge slots behind the true count (stale pairs of earlier
+    batches) must not reach the gradients.  In fp64, every replay against a host-launched evaluation on the exact edge list at EQUAL
+    weights (the twin takes the captured model's weights before each step): 1e-8 of the largest entry of each gradient.  fp32 cannot
+    make this comparison: the force-loss gradient of a random-weight model is ill-conditioned (fp32 against fp64 on the exact list:
+    0.5 % - 25 % depending on the batch, scratch/dbg_f32_vs_f64.py), and a library GEMM that changes its kernel with the row count
+    (257 rows against 256) moves fp32 gradients by as much."""
+    from xequinet_amd import runtime
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+
+    torch.manual_seed(0)
+    dt = torch.float64
+    batches = []
+    for k, n_mol in enumerate((20, 14, 24)):
+        host, dev = _batch(n_mol, 40 + k, dt)
+        batches.append((host, dev, _targets(host, 70 + k, False)))
+    cap = (max(b[0]["pos"].shape[0] for b in batches) + 8, max(b[0]["ptr"].numel() - 1 for b in batches),
+           max(runtime.pair_capacity(b[0]["ptr"].numpy()) for b in batches))
+    fast, slow = _model(dt, **SMALL).train(), _model(dt, **SMALL).train()
+    opt_f = torch.optim.Adam(fast.parameters(), lr=1e-4, capturable=True)
+    step = train.GraphedTrainStep(fast, opt_f, cap, energy_weight=1.0, forces_weight=5.0)
+    weights = {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 5.0}
+    for host, dev, tgt in batches + batches[:1]:
+        slow.load_state_dict(fast.state_dict())
+        before = {n: p.detach().clone() for n, p in fast.named_parameters()}
+        e_t, f_t = tgt[keys.TOTAL_ENERGY].to(DEV), tgt[keys.FORCES].to(DEV)
+        loss_f = step(dev["pos"], dev["atomic_numbers"], dev["ptr"], e_t, batch=dev["batch"], target_forces=f_t).item()
+        b = NeighborTransform(5.0)(XequiBatch(dev["pos"], dev["atomic_numbers"], dev["ptr"]))
+        assert b.to_dict()["edge_index"].shape[1] < cap[2]                  # slots behind the list in the captured step
+        slow.zero_grad(set_to_none=True)
+        loss_s, _ = train.weighted_loss(slow(b.to_dict(), True, False), {keys.TOTAL_ENERGY: e_t, keys.FORCES: f_t, keys.BATCH_PTR: dev["ptr"]}, weights)
+        loss_s.backward()
+        assert abs(loss_f - loss_s.item()) <= 1e-10 * max(1.0, abs(loss_s.item())), (loss_f, loss_s.item())
+        for (n, p), (_, q) in zip(fast.named_parameters(), slow.named_parameters()):
+            if q.grad is None:
+                continue
+            scale = max(1e-6, q.grad.abs().max().item())
+            assert (p.grad - q.grad).abs().max().item() <= 1e-8 * scale, n              # the replay's gradients live in the graph's pool
+            assert not torch.equal(p.detach(), before[n]) or float(q.grad.abs().max()) == 0.0, n      # and the update was applied
+    assert step.captures == 1
+
+
 def test_evaluations_between_graphed_training_steps_see_the_current_weights():
     """Replays of train.GraphedTrainStep update the weights in place without bumping their version counters; the packed weight
     copies (MLP, U|V, linear, node-block programs; Python and C++ caches) key on those counters.  The step now bumps the pack

@@ -632,6 +632,18 @@ __global__ void __launch_bounds__(256) k_q_wgrad(const T* __restrict__ q, const 
   }
 }
 
+// rows [*n_valid, n_rows) of a row-major buffer of 4-byte words := 0: the per-edge products of the slots behind the true edge count of a
+// capacity-sized list (a training step captured as one graph), which the walk never writes and the products over ALL rows would read
+__global__ void __launch_bounds__(256) k_zero_rows_from(uint32_t* __restrict__ buf, int64_t row_words, int64_t n_rows,
+                                                        const int32_t* __restrict__ n_valid) {
+  int64_t first = *n_valid;
+  if (first < 0) first = 0;
+  for (int64_t r = first + blockIdx.x; r < n_rows; r += gridDim.x) {
+    uint32_t* row = buf + r * row_words;
+    for (int64_t i = threadIdx.x; i < row_words; i += 256) row[i] = 0u;
+  }
+}
+
 // what the scalar-broadcast kernels cover: at most 256 channels per kind (one thread each) and 32-bit row offsets
 static bool sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
   if (num_basis < 1 || num_basis > 32 || mul[0] < 0 || mul[1] < 0 || mul[2] < 0) return false;
@@ -815,6 +827,15 @@ int xeq_message_q_wgrad(int dtype, const void* q, const void* basis, int64_t n_e
     else hipLaunchKernelGGL((k_q_wgrad<T, 33>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q, (const T*)basis, n_edges, H, EW, K, (T*)parts);
   });
   XEQ_CHECK_LAUNCH("xeq_message_q_wgrad");
+  return XEQ_OK;
+}
+
+int xeq_zero_rows_from(void* buf, int64_t row_words, int64_t n_rows, const int32_t* n_valid, void* stream) {
+  XEQ_CHECK_ARG(row_words >= 0 && n_rows >= 0 && n_valid != nullptr, "xeq_zero_rows_from: bad sizes");
+  if (n_rows == 0 || row_words == 0) return XEQ_OK;
+  hipLaunchKernelGGL(k_zero_rows_from, dim3((unsigned)(n_rows < 2048 ? n_rows : 2048)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)buf,
+                     row_words, n_rows, n_valid);
+  XEQ_CHECK_LAUNCH("xeq_zero_rows_from");
   return XEQ_OK;
 }
 

@@ -244,11 +244,6 @@ def message(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     irreps, C = module.node_irreps, module.node_num_irreps
     ei = data[keys.EDGE_INDEX]
     center, neighbor = ei[keys.CENTER_IDX].long(), ei[keys.NEIGHBOR_IDX].long()
-    if getattr(data.get(keys.EDGE_GRAPH), "edge_count_on_device", False):
-        # a capacity-sized edge list (train.GraphedTrainStep): the slots behind the true count hold stale pairs, which this form would
-        # walk as edges (its tensors have one row per SLOT); only the native energy-loss pass stops at the device-side count
-        raise NotImplementedError("the twice-differentiable training pass does not take a capacity-sized edge list "
-                                  "(GraphedTrainStep captures the native energy-loss pass only: keep model.native_training = True)")
     s, x = _norms(module, s0, x0)
     scalar_out = _mlp(module.scalar_mlp, s)
     rec = data.get(_REC)
@@ -265,6 +260,10 @@ def message(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
             data[keys.NODE_INVARIANT] = s0 + d_s
             data[keys.NODE_EQUIVARIANT] = x0 + d_x
             return data
+    if getattr(data.get(keys.EDGE_GRAPH), "edge_count_on_device", False):
+        # a capacity-sized edge list (train.GraphedTrainStep): the slots behind the true count hold stale pairs, which the tensor form
+        # below would walk as edges (one row per SLOT); the kernel form above walks the row pointer and stops at the true count
+        raise NotImplementedError("the tensor form of the training pass does not take a capacity-sized edge list")
     filt = module.rbf_lin(data[keys.RADIAL_BASIS_FUNCTION]) * data[keys.ENVELOPE_FUNCTION]
     filt = scalar_out.index_select(0, neighbor) * filt
     gate_state, gate_edge, msg_s = torch.split(filt, [C, C, module.node_dim], dim=-1)

@@ -922,6 +922,9 @@ def _diff_bwd(h, xhat, rec, w, b, g_s, g_x, graph: "EdgeGraph", cfg, q=None, y0_
     KERNEL_TIMER.launch("xeq_message_bwd_sbq", dtype_code(h), N, E, ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(graph.edge_index[0]),
                         ptr(rec), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w), ptr(b), B, F, mul3(mul), ptr(g_h), ptr(g_xh),
                         ptr(q), ptr(gy), flags, stream())
+    if getattr(graph, "edge_count_on_device", False) and not flags & lib.SB_Q_ACCUMULATE:
+        # capacity-sized list: the slots behind the true count were not walked, and the products over all rows of q must read zeros there
+        call("xeq_zero_rows_from", ptr(q), H * (q.element_size() // 4), E, ptr(graph.c_rowptr[N:]), stream())
     return g_h, g_xh, q, gy
 
 

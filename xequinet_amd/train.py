@@ -79,8 +79,9 @@ class GraphedTrainStep:
     QM9-1024 step where the GPU needs 8.5); a captured step is one launch.  The arrays have a capacity as in ``runtime.GraphedStep``
     (atoms, graphs, edges <= sum n_g (n_g - 1)); a batch is padded in one launch, the padding atoms sit in one trailing graph whose
     energy is masked out of the loss, so they receive no gradient.  The loss is the reference's weighted l2 / l1 loss on ``energy`` or
-    ``energy_per_atom`` (utils/loss.py:47-110, utils/trainer.py:295-302); forces in the loss need the differentiable pass and are not
-    captured here.
+    ``energy_per_atom`` (utils/loss.py:47-110, utils/trainer.py:295-302), times ``energy_weight``; with ``forces_weight`` the same loss on
+    the forces is added (``target_forces`` per call) and the capture holds the twice-differentiable pass (nn/training.py) instead of the
+    native energy-loss pass.
 
     The optimizer must keep its state on the device (``torch.optim.Adam(..., capturable=True)``).  Python-float hyper-parameters
     (``lr``, betas, ``weight_decay``) are baked into the graph at capture: a scheduler or warm-up that rewrites
@@ -91,7 +92,8 @@ class GraphedTrainStep:
     replayed step is the first update."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, capacity, prop: str = keys.TOTAL_ENERGY,
-                 loss_fn: str = "l2", cutoff: Optional[float] = None, warmup: int = 3) -> None:
+                 loss_fn: str = "l2", cutoff: Optional[float] = None, warmup: int = 3, energy_weight: float = 1.0,
+                 forces_weight: Optional[float] = None) -> None:
         from . import runtime
 
         if prop not in (keys.TOTAL_ENERGY, keys.ENERGY_PER_ATOM):
@@ -107,6 +109,12 @@ class GraphedTrainStep:
         dev, dt = g.pos.device, g.pos.dtype
         self.target = torch.zeros(g.n_graphs, dtype=dt, device=dev)
         self.mask = torch.zeros(g.n_graphs, dtype=dt, device=dev)         # 1 for the batch's graphs, 0 for the padding graph / unused slots
+        # forces in the loss (round 4): the twice-differentiable pass (nn/training.py) inside the same capture.  Its kernels walk the row
+        # pointer, so the capacity-sized edge list is safe there (ops._diff_bwd zeroes the per-edge products behind the true count);
+        # the padding atoms have no neighbour, feel no force and carry weight 0
+        self.energy_weight, self.forces_weight = float(energy_weight), None if forces_weight is None else float(forces_weight)
+        self.target_forces = torch.zeros((g.n_atoms, 3), dtype=dt, device=dev) if forces_weight is not None else None
+        self.atom_mask = torch.zeros((g.n_atoms, 1), dtype=dt, device=dev) if forces_weight is not None else None
         self.warmup = warmup
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.loss: Optional[torch.Tensor] = None
@@ -132,12 +140,20 @@ class GraphedTrainStep:
         eg.edge_count_on_device = True
         data = {keys.POSITIONS: g.pos.detach(), keys.ATOMIC_NUMBERS: g.z, keys.EDGE_INDEX: g.edge_index, keys.BATCH: g.batch,
                 keys.BATCH_PTR: g.ptr, keys.EDGE_GRAPH: eg}
-        energy = self.model(data, False, False)[keys.TOTAL_ENERGY]
+        with_forces = self.forces_weight is not None
+        result = self.model(data, with_forces, False)
+        energy = result[keys.TOTAL_ENERGY]
         diff = energy - self.target
         if self.prop == keys.ENERGY_PER_ATOM:
             diff = diff / (g.ptr[1:] - g.ptr[:-1]).clamp(min=1).to(diff.dtype)
         per_graph = diff * diff if self.loss_fn in ("l2", "mse") else diff.abs()
         loss = (per_graph * self.mask).sum() / self.mask.sum()            # the mean over the batch's own graphs
+        if with_forces:                                                   # the mean over the 3 n components of the batch's own atoms
+            df = result[keys.FORCES] - self.target_forces
+            per_atom = df * df if self.loss_fn in ("l2", "mse") else df.abs()
+            loss = self.energy_weight * loss + self.forces_weight * (per_atom * self.atom_mask).sum() / (3.0 * self.atom_mask.sum())
+        elif self.energy_weight != 1.0:
+            loss = self.energy_weight * loss
         loss.backward()
         self.optimizer.step()
         return loss.detach()
@@ -178,7 +194,7 @@ class GraphedTrainStep:
         # the capture itself ran no kernel; the replay below is the first update
 
     def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, target_energy: torch.Tensor,
-                 batch: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 batch: Optional[torch.Tensor] = None, target_forces: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One step on this batch; returns the loss (a device scalar owned by the graph, overwritten by the next call)."""
         g = self._gs
         n_graphs = int(ptr.numel() - 1)
@@ -187,6 +203,14 @@ class GraphedTrainStep:
         self.target[:n_graphs] = target_energy.to(self.target.dtype)
         self.mask.zero_()
         self.mask[:n_graphs] = 1.0
+        if self.forces_weight is not None:
+            if target_forces is None:
+                raise ValueError("GraphedTrainStep(forces_weight=...) needs target_forces")
+            n = int(pos.shape[0])
+            self.target_forces.zero_()
+            self.target_forces[:n] = target_forces.to(self.target_forces.dtype)
+            self.atom_mask.zero_()
+            self.atom_mask[:n] = 1.0
         if self.graph is None:
             self._capture()
         self.graph.replay()
