@@ -254,8 +254,11 @@ def message(module, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         from .basic import edge_graph
 
         graph = edge_graph(data)
-        cfg = (int(module.rbf_lin.weight.shape[1]), int(module.node_dim), tuple(irreps.mul3()))
-        if ops.diff_message_supported(scalar_out, graph, cfg):
+        try:
+            cfg = (int(module.rbf_lin.weight.shape[1]), int(module.node_dim), tuple(irreps.mul3()))
+        except NotImplementedError:     # irreps the kernels do not take (several blocks per l, ...): the tensor form below
+            cfg = None
+        if cfg is not None and ops.diff_message_supported(scalar_out, graph, cfg):
             d_s, d_x = ops.DiffMessage.apply(scalar_out, x, rec, module.rbf_lin.weight, module.rbf_lin.bias, graph, cfg)
             data[keys.NODE_INVARIANT] = s0 + d_s
             data[keys.NODE_EQUIVARIANT] = x0 + d_x
