@@ -220,9 +220,34 @@ def test_force_loss_kernel_form_without_l2_channels_and_with_an_isolated_atom(mo
         result = model(dict(dev), True, False)
         loss, _ = train.weighted_loss(result, tgt, weights)
         loss.backward()
-        assert float(result[keys.FORCES][0].abs().max()) == 0.0          # the isolated atom feels nothing
+        assert float(result[keys.FORCES][0].detach().abs().max()) == 0.0          # the isolated atom feels nothing
         grads[native] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     assert grads[True].keys() == grads[False].keys() and len(grads[True]) >= 40
     for name, want in grads[False].items():
         err = (grads[True][name] - want).abs().max().item()
         assert err <= 1e-9 * max(1e-6, want.abs().max().item()), f"{name}: {err:.2e} of {want.abs().max().item():.2e}"
+
+
+@pytest.mark.parametrize("B", [5, 12, 20, 31])
+def test_message_kernels_every_basis_width_in_both_precisions(B):
+    """The four record widths the sb-family kernels are instantiated for (num_basis <= 8 / 16 / 20 / 32), fp32 against fp64: values,
+    first-order gradients and the second-order gradients of a quadratic in the first-order ones (2e-5 of the largest entry)."""
+    n = 40
+    H = F + 2 * C
+    g = torch.Generator().manual_seed(B)
+    pairs = [(i, j) for i in range(n) for j in range(n) if i != j and (3 * i + j) % 5 < 2]
+    ei = torch.tensor(pairs, dtype=torch.int64).t().contiguous().to(DEV)
+    graph = ops.EdgeGraph(ei, n)
+    E, bp = ei.shape[1], (B + 3) & ~3
+    base = [torch.randn(n, H, generator=g, dtype=torch.float64), torch.randn(n, D, generator=g, dtype=torch.float64),
+            torch.randn(E, bp + 12, generator=g, dtype=torch.float64), torch.randn(H, B, generator=g, dtype=torch.float64) / B ** 0.5,
+            torch.randn(H, generator=g, dtype=torch.float64)]
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        h, xhat, rec, w, b = (t.to(dt).to(DEV).requires_grad_() for t in base)
+        ds, dx = ops.DiffMessage.apply(h, xhat, rec, w, b, graph, (B, F, MUL))
+        first = torch.autograd.grad((ds * ds).sum() + (dx * dx).sum(), (h, xhat, rec), create_graph=True)
+        second = torch.autograd.grad(sum((t * t).sum() for t in first), (h, xhat, rec, w, b))
+        res[dt] = [t.detach().double() for t in (ds, dx, *first, *second)]
+    for got, want in zip(res[torch.float32], res[torch.float64]):
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
