@@ -34,7 +34,7 @@ if mode == "forces-graph":   # energy + forces, the twice-differentiable pass in
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): l = gstep(p_d, z_d, ptr_d, tgt[keys.TOTAL_ENERGY], batch=b_d, target_forces=tgt[keys.FORCES])
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
-    print(f"train step (energy + forces, ONE captured graph incl. the neighbour list, linear layers {'LinearFn' if tr.NATIVE_LINEAR else 'torch.nn'}) n_mol={n_mol} N={len(pos)} E={E}: {dt*1e3:.2f} ms/step, {E/dt/1e6:.1f} M edges/s, peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss {l.item():.4f}")
+    print(f"train step (energy + forces, ONE captured graph incl. the neighbour list, linear layers LinearFn inside the capture) n_mol={n_mol} N={len(pos)} E={E}: {dt*1e3:.2f} ms/step, {E/dt/1e6:.1f} M edges/s, peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, loss {l.item():.4f}")
     sys.exit(0)
 if mode == "energy-graph":   # the whole step (neighbour list included) as ONE captured HIP graph: train.GraphedTrainStep
     from xequinet_amd import runtime
