@@ -420,7 +420,8 @@ int xeq_message_wq_edges_per_stream(int64_t n_nodes, int64_t n_edges);
  * blocks and both directions; the message kernels fetch them with scalar loads (the edge index is
  * workgroup-uniform) and need no LDS and no barriers in the forward pass.
  * basis[E, W] / dbasis[E, W], W = xeq_edge_basis_width(B); dbasis may be NULL when only the forward
- * pass is needed.  Same semantics as xeq_message_fwd / xeq_message_bwd otherwise. */
+ * pass is needed.  Same semantics as xeq_message_fwd / xeq_message_bwd otherwise; s_in / x_in of xeq_message_fwd_sb may be NULL
+ * (the aggregate without the residual: what the training pass's ops.DiffMessage asks for). */
 int xeq_edge_basis_width(int num_basis);
 /* 1 / 0: at most 256 channels per kind, num_basis <= 32, 32-bit element offsets (n_nodes max(H, D) < 2^31) */
 int xeq_message_sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]);

@@ -235,11 +235,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
         }
       }
     }
-    if (cm.has_s) s_out[c * F + cm.ts] = s_in[c * F + cm.ts] + acc_s;
+    if (cm.has_s) s_out[c * F + cm.ts] = (s_in ? s_in[c * F + cm.ts] : T(0)) + acc_s;   // s_in / x_in NULL: the aggregate alone (ops.DiffMessage)
     if (cm.has_u) {
 #pragma unroll
       for (int m = 0; m < 5; ++m)
-        if (m < cm.nm) x_out[c * D + cm.off + m] = x_in[c * D + cm.off + m] + acc_x[m];
+        if (m < cm.nm) x_out[c * D + cm.off + m] = (x_in ? x_in[c * D + cm.off + m] : T(0)) + acc_x[m];
     }
   }
 }

@@ -902,10 +902,9 @@ def _diff_sizes(cfg):
 def _diff_fwd(h, xhat, rec, w, b, graph: "EdgeGraph", cfg, y0_zero: bool = False):
     B, F, mul, C, D, H, bp = _diff_sizes(cfg)
     N, E = graph.n_nodes, graph.n_edges
-    zs, zx = h.new_zeros((N, F)), h.new_zeros((N, D))
-    ds, dx = torch.empty_like(zs), torch.empty_like(zx)
+    ds, dx = torch.empty((N, F), dtype=h.dtype, device=h.device), torch.empty((N, D), dtype=h.dtype, device=h.device)
     KERNEL_TIMER.launch("xeq_message_fwd_sb", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm), ptr(graph.edge_index[1]),
-                        ptr(rec), ptr(h), ptr(xhat), ptr(zs), ptr(zx), ptr(w), ptr(b), B, F, mul3(mul), ptr(ds), ptr(dx),
+                        ptr(rec), ptr(h), ptr(xhat), None, None, ptr(w), ptr(b), B, F, mul3(mul), ptr(ds), ptr(dx),
                         lib.SB_Y0_ZERO if y0_zero else 0, stream())
     return ds, dx
 
@@ -918,7 +917,8 @@ def _diff_bwd(h, xhat, rec, w, b, g_s, g_x, graph: "EdgeGraph", cfg, q=None, y0_
     flags = (lib.SB_Y0_ZERO if y0_zero else 0) | (lib.SB_Q_ACCUMULATE if q is not None else 0) | (0 if want_gy else lib.SB_NO_GY)
     if q is None:
         q = torch.empty((E, H), dtype=h.dtype, device=h.device)
-    gy = torch.zeros((E, 8), dtype=h.dtype, device=h.device) if want_gy else None
+    # every edge of an exact list is walked and writes its row; only the slots behind the count of a capacity-sized list need zeros
+    gy = None if not want_gy else (torch.zeros if getattr(graph, "edge_count_on_device", False) else torch.empty)((E, 8), dtype=h.dtype, device=h.device)
     KERNEL_TIMER.launch("xeq_message_bwd_sbq", dtype_code(h), N, E, ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(graph.edge_index[0]),
                         ptr(rec), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x), ptr(w), ptr(b), B, F, mul3(mul), ptr(g_h), ptr(g_xh),
                         ptr(q), ptr(gy), flags, stream())
