@@ -899,12 +899,13 @@ def _diff_sizes(cfg):
     return num_basis, node_dim, mul, C, D, node_dim + 2 * C, (num_basis + 3) & ~3
 
 
-def _diff_fwd(h, xhat, rec, w, b, graph: "EdgeGraph", cfg, y0_zero: bool = False):
+def _diff_fwd(h, xhat, rec, w, b, graph: "EdgeGraph", cfg, y0_zero: bool = False, s_in=None, x_in=None):
+    """(s_in + sum_e msg_s, x_in + sum_e msg_x); s_in / x_in None: the aggregates alone."""
     B, F, mul, C, D, H, bp = _diff_sizes(cfg)
     N, E = graph.n_nodes, graph.n_edges
     ds, dx = torch.empty((N, F), dtype=h.dtype, device=h.device), torch.empty((N, D), dtype=h.dtype, device=h.device)
     KERNEL_TIMER.launch("xeq_message_fwd_sb", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm), ptr(graph.edge_index[1]),
-                        ptr(rec), ptr(h), ptr(xhat), None, None, ptr(w), ptr(b), B, F, mul3(mul), ptr(ds), ptr(dx),
+                        ptr(rec), ptr(h), ptr(xhat), ptr(s_in), ptr(x_in), ptr(w), ptr(b), B, F, mul3(mul), ptr(ds), ptr(dx),
                         lib.SB_Y0_ZERO if y0_zero else 0, stream())
     return ds, dx
 
@@ -1021,8 +1022,7 @@ class DiffMessageGrad(Function):
             rec_c = torch.cat([u_rec[:, : bp + 1], rec[:, bp + 1 :]], dim=1)
             if bp > B:
                 rec_c[:, B:bp] = 0
-            s_, x_ = _diff_fwd(h, xhat, rec_c, w, b, graph, cfg)
-            d_gs, d_gx = add(d_gs, s_), add(d_gx, x_)
+            d_gs, d_gx = _diff_fwd(h, xhat, rec_c, w, b, graph, cfg)
             gh, gxh, q_c, gy = _diff_bwd(h, xhat, rec_c, w, b, g_s, g_x, graph, cfg)
             d_h, d_xh, gy_sum = add(d_h, gh), add(d_xh, gxh), add(gy_sum, gy)
             if need[3] or need[4]:
@@ -1030,8 +1030,7 @@ class DiffMessageGrad(Function):
             del q_c
         if u_h is not None:                      # A: h <- u_h
             u_h = u_h.contiguous()
-            s_, x_ = _diff_fwd(u_h, xhat, rec, w, b, graph, cfg)
-            d_gs, d_gx = add(d_gs, s_), add(d_gx, x_)
+            d_gs, d_gx = _diff_fwd(u_h, xhat, rec, w, b, graph, cfg, s_in=d_gs, x_in=d_gx)     # the kernel adds to the sums so far
             _, gxh, q_ab, gy = _diff_bwd(u_h, xhat, rec, w, b, g_s, g_x, graph, cfg)
             d_xh, gy_sum = add(d_xh, gxh), add(gy_sum, gy)
         u_y = None if u_rec is None else u_rec[:, bp + 1 : bp + 9]
@@ -1041,8 +1040,7 @@ class DiffMessageGrad(Function):
                 rec_b = torch.cat([rec[:, : bp + 1], zeros(E, 11)], dim=1)
             else:
                 rec_b = torch.cat([rec[:, : bp + 1], u_y, zeros(E, 3)], dim=1)
-            _, x_ = _diff_fwd(h, ux, rec_b, w, b, graph, cfg, y0_zero=True)
-            d_gx = add(d_gx, x_)
+            _, d_gx = _diff_fwd(h, ux, rec_b, w, b, graph, cfg, y0_zero=True, x_in=d_gx)      # (its scalar aggregate is not a term)
             gh, _, q_ab, _ = _diff_bwd(h, ux, rec_b, w, b, zeros(N, F), g_x, graph, cfg, q=q_ab, y0_zero=True, want_gy=False)
             d_h = add(d_h, gh)
         d_rec = None
