@@ -23,10 +23,12 @@ g = torch.Generator().manual_seed(0)
 tgt = {keys.TOTAL_ENERGY: torch.randn(n_mol, generator=g).to(dev), keys.FORCES: torch.randn(len(pos), 3, generator=g).to(dev), keys.BATCH_PTR: data["ptr"]}
 w = {keys.TOTAL_ENERGY: 1.0} if mode.startswith("energy") else {keys.TOTAL_ENERGY: 1.0, keys.FORCES: 10.0}
 model.native_training = mode != "energy-aten"
+if os.environ.get("XEQ_NATIVE_LINEAR"):
+    from xequinet_amd.nn import training as _tr
+    _tr.NATIVE_LINEAR = os.environ["XEQ_NATIVE_LINEAR"] == "1"
 if mode == "forces-graph":   # energy + forces, the twice-differentiable pass inside ONE captured graph
     from xequinet_amd import runtime
     from xequinet_amd.nn import training as tr
-    tr.NATIVE_LINEAR = len(sys.argv) > 3 and sys.argv[3] == "linear"
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
     gstep = train.GraphedTrainStep(model, opt, (len(pos) + 64, n_mol, runtime.pair_capacity(ptr)), forces_weight=10.0)
     p_d, z_d, ptr_d, b_d = data["pos"].detach(), data["atomic_numbers"], data["ptr"], data["batch"]
@@ -51,7 +53,7 @@ def step():
     d = {k: v for k, v in data.items() if not k.startswith("_")}
     d["pos"] = d["pos"].detach().clone()
     return train.train_step(model, d, tgt, opt, w)[0]
-for _ in range(3): step()
+for _ in range(int(os.environ.get("XEQ_WARMUP", "15"))): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 10
 for _ in range(K): l = step()

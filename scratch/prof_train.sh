@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 MODE=${1:-forces}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o p -- python3 $R/scratch/bench_train.py 1024 $MODE > $R/gpurun_out/prof_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o p -- python3 $R/scratch/bench_train.py ${NMOL:-1024} $MODE > $R/gpurun_out/prof_train.log 2>&1
 cd $R
 f=$(find /tmp/prof_train -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'PY'

@@ -156,7 +156,7 @@ def test_force_loss_gradients_kernel_form_equals_tensor_form(periodic, linear, m
     for native in (True, False):
         monkeypatch.setattr(tr, "NATIVE_MESSAGE", native)
         monkeypatch.setattr(tr, "NATIVE_NODE", native)
-        monkeypatch.setattr(tr, "NATIVE_LINEAR", native and linear)     # linear layers as LinearFn / WGradFn (off by default: host-bound)
+        monkeypatch.setattr(tr, "NATIVE_LINEAR", native and linear)     # linear layers as xeq::linear (LinearFn / WGradFn nodes) or torch.nn
         model = _model(torch.float64, **SMALL).train()
         ops.KERNEL_TIMER.reset(True)
         loss, _ = train.weighted_loss(model(dict(dev), True, periodic), tgt, weights)

@@ -935,6 +935,61 @@ std::tuple<Tensor, Tensor, Tensor> radius_graph_pbc(const Tensor& pos_in, const 
   return {ei, cell_offsets, rowptr};
 }
 
+// ---------------------------------------------------------------------------------------------- linear layers of the training pass
+// y = x W^T (+ b) as an autograd node whose reverse pass is written with itself and with XeqWGradFn (dL/dx = g W, dL/dW = g^T x), so
+// every order of derivative stays on these two products, and every reduction over the N rows -- which the library's GEMMs run at a
+// tenth of their rate for [576 x N] x [N x 128] and the like -- goes to xeq_wgrad (fp32).  Python twin: nn/training_ops.py LinearFn /
+// WGradFn (same arithmetic; a C++ node costs the host a fifth of a Python one, which is what decides a host-launched training step).
+struct XeqWGradFn;
+Tensor xeq_wgrad_apply(const Tensor& a, const Tensor& b);
+
+struct XeqLinearFn : public torch::autograd::Function<XeqLinearFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& W, const std::optional<Tensor>& b) {
+    ctx->save_for_backward({x, W});
+    const bool has_bias = b.has_value() && b->defined();
+    ctx->saved_data["has_bias"] = has_bias;
+    return has_bias ? at::addmm(*b, x, W.t()) : at::mm(x, W.t());
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &x = saved[0], &W = saved[1], &go = g[0];
+    Tensor dx, dW, db;
+    if (ctx->needs_input_grad(0)) dx = XeqLinearFn::apply(go, W.t(), std::optional<Tensor>());
+    if (ctx->needs_input_grad(1)) dW = xeq_wgrad_apply(go, x);
+    if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) db = go.sum(0);
+    return {dx, dW, db};
+  }
+};
+
+struct XeqWGradFn : public torch::autograd::Function<XeqWGradFn> {   // a^T b over the rows: a [N, M], b [N, K] -> [M, K]
+  static Tensor forward(AutogradContext* ctx, const Tensor& a, const Tensor& b) {
+    ctx->save_for_backward({a, b});
+    if (!(a.is_cuda() && a.scalar_type() == at::kFloat && b.scalar_type() == at::kFloat && a.dim() == 2 && b.dim() == 2 && a.size(0) == b.size(0)))
+      return at::mm(a.t(), b);
+    const Tensor ac = a.stride(1) == 1 ? a : a.contiguous(), bc = b.stride(1) == 1 ? b : b.contiguous();
+    const int64_t n = ac.size(0);
+    const int M = (int)ac.size(1), K = (int)bc.size(1);
+    const int chunks = xeq_wgrad_chunks(n, M, K);
+    Tensor parts = at::empty({chunks, (int64_t)M * K}, ac.options());
+    XCALL(xeq_wgrad(ac.data_ptr(), ac.stride(0), bc.data_ptr(), bc.stride(0), n, M, K, 0, chunks, parts.data_ptr(), cur_stream()));
+    return (chunks > 1 ? parts.sum(0) : parts[0]).view({M, K});
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list g) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &a = saved[0], &b = saved[1], &U = g[0];
+    Tensor da, db;
+    if (ctx->needs_input_grad(0)) da = XeqLinearFn::apply(b, U, std::optional<Tensor>());       // b U^T
+    if (ctx->needs_input_grad(1)) db = XeqLinearFn::apply(a, U.t(), std::optional<Tensor>());   // a U
+    return {da, db};
+  }
+};
+Tensor xeq_wgrad_apply(const Tensor& a, const Tensor& b) { return XeqWGradFn::apply(a, b); }
+
+Tensor linear_op(const Tensor& x, const Tensor& W, const std::optional<Tensor>& b) {
+  TORCH_CHECK(x.dim() == 2 && W.dim() == 2 && x.size(1) == W.size(1), "xeq::linear: x [N, K], W [M, K]");
+  return XeqLinearFn::apply(x, W, b);
+}
+
 }  // namespace
 
 TORCH_LIBRARY(xeq, m) {
@@ -944,6 +999,7 @@ TORCH_LIBRARY(xeq, m) {
       "bool compute_virial) -> Tensor[]");
   m.def("radius_graph(Tensor pos, Tensor ptr, float cutoff) -> (Tensor, Tensor)");
   m.def("radius_graph_pbc(Tensor pos, Tensor cell, Tensor pbc, float cutoff) -> (Tensor, Tensor, Tensor)");
+  m.def("linear(Tensor x, Tensor W, Tensor? b) -> Tensor", linear_op);   // differentiable to every order (XeqLinearFn / XeqWGradFn)
 }
 
 TORCH_LIBRARY_IMPL(xeq, Autograd, m) { m.impl("xpainn_eval", xpainn_eval); }

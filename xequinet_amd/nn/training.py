@@ -28,10 +28,16 @@ _REC = "_xeq_train_records"         # per-edge records [E, roundup(B, 4) + 12] o
 NATIVE_MESSAGE = True
 # False: norms, invariants and the update block's products stay on ATen tensor operations too (csrc/xeq_train_node.hip otherwise)
 NATIVE_NODE = True
-# True: the linear layers as training_ops.LinearFn, i.e. every reduction over the N rows (weight gradients of both orders) on xeq_wgrad
-# instead of the library.  Measured on the QM9-1024 energy+force step: kernel time 40.4 -> 37.0 ms, but ~100 more Python autograd nodes
-# per step make the HOST the bound (wall 39 -> 44 ms); off until that step is captured as a graph (profiles/r04_train_step.txt)
-NATIVE_LINEAR = False
+# True: the linear layers as training_ops.linear (xeq::linear: C++ autograd nodes closed under differentiation), i.e. every reduction over
+# the N rows (weight gradients of both orders) on xeq_wgrad instead of the library.  QM9-1024 energy+force step 38.6 -> 34.4 ms.  (A first
+# measurement after three warm-up steps had it 5 ms SLOWER: the variant's new buffer sizes were still growing the caching allocator;
+# profiles/r04_train_step.txt)
+NATIVE_LINEAR = True
+# set by edge_data at the start of every training pass: forces or the virial enter the result, i.e. the pass will be differentiated twice.
+# Only then do the linear layers take the xeq::linear form: an energy-only pass on this module (model.native_training = False) has ~12 ms of
+# GPU work per QM9-1024 step, too little to hide the nodes' host cost behind (12.7 ms with torch.nn's layers, 18-22 ms with these).  A
+# choice between two correct forms, so a plain module variable is enough.
+_SECOND_ORDER_PASS = False
 # data-dict flag set by BaseModel.forward for a training pass whose loss reads energies only (no forces, no virial): the blocks stay on
 # the fused HIP kernels and hand their parameters to the block functions, which return the parameter gradients (nn/fused.py)
 PARAM_GRADS = "_xeq_param_grads"
@@ -79,6 +85,8 @@ def _flat(parts: List[torch.Tensor]) -> torch.Tensor:
 
 # ---- edge geometry (nn/basic.py:60-140) ---------------------------------------------------------------------------------
 def edge_data(data: Dict[str, torch.Tensor], compute_forces: bool, compute_virial: bool) -> Dict[str, torch.Tensor]:
+    global _SECOND_ORDER_PASS
+    _SECOND_ORDER_PASS = bool(compute_forces or compute_virial)
     pos = data[keys.POSITIONS]
     lib.require_hip(pos)
     ei = data[keys.EDGE_INDEX]
@@ -197,7 +205,7 @@ def equivariant_layer_norm(norm, x: torch.Tensor) -> torch.Tensor:
 def _mlp(seq, x: torch.Tensor) -> torch.Tensor:
     """scalar_mlp / update_mlp / dot_lin / out_mlp: the module itself, or (NATIVE_LINEAR) with the weight-gradient products on
     ``xeq_wgrad`` (training_ops.LinearFn)."""
-    if NATIVE_LINEAR and x.is_cuda and (isinstance(seq, torch.nn.Linear) or isinstance(seq, torch.nn.Sequential)):
+    if NATIVE_LINEAR and _SECOND_ORDER_PASS and x.is_cuda and (isinstance(seq, torch.nn.Linear) or isinstance(seq, torch.nn.Sequential)):
         from .training_ops import mlp
 
         return mlp(seq, x)
@@ -309,7 +317,7 @@ def _uv_weights_ok(module, mul) -> bool:
 def _update_on_kernels(module, data, s0, x0, mul):
     """``update`` with the norms, the Invariant / channel dot and the products on csrc/xeq_train_node.hip (training_ops) and the
     o3.Linear pair as one library GEMM per l on BT rows: [N (2l+1), mul_l] x [mul_l, 2 mul_l] = (U | V)."""
-    from .training_ops import LinearFn, UpdateOutFn, UvFn
+    from .training_ops import UpdateOutFn, UvFn, linear
 
     N, C, F = s0.shape[0], module.node_num_irreps, module.node_dim
     s, x_bt = _norms(module, s0, x0, bt=True)
@@ -326,8 +334,8 @@ def _update_on_kernels(module, data, s0, x0, mul):
         w = torch.cat([lu.weight[woff : woff + m * m].view(m, m), lv.weight[woff : woff + m * m].view(m, m)], dim=1) * (1.0 / math.sqrt(m))
         woff += m * m
         bias = torch.cat([lu.bias, lv.bias]) if l == 0 and lu.bias.numel() > 0 else None
-        if NATIVE_LINEAR:
-            uv.append(LinearFn.apply(xl, w.t(), bias))
+        if NATIVE_LINEAR and _SECOND_ORDER_PASS:
+            uv.append(linear(xl, w.t(), bias))
         else:
             uv.append(xl @ w if bias is None else torch.addmm(bias, xl, w))
     vd = UvFn.apply(uv[0], uv[1], uv[2], (mul, float(module.invariant.eps)))

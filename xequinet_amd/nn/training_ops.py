@@ -246,9 +246,30 @@ class WGradFn(Function):
         return d_a, d_b
 
 
+_cpp_linear = None
+
+
+def linear(x: torch.Tensor, W: torch.Tensor, b) -> torch.Tensor:
+    """x W^T (+ b) through the LinearFn / WGradFn pair: the C++ nodes of csrc/xeq_torch.cpp (``xeq::linear``: the same two functions as
+    ``torch::autograd::Function``s -- a C++ node costs the host a fifth of a Python one, and a host-launched training step is decided
+    there) when the operator library is built, the Python pair above otherwise."""
+    global _cpp_linear
+    if _cpp_linear is None:
+        try:
+            from ..interface.scripted import load_torch_library
+
+            load_torch_library()
+            _cpp_linear = torch.ops.xeq.linear
+        except (ImportError, OSError, AttributeError, RuntimeError):
+            _cpp_linear = False
+    if _cpp_linear:
+        return _cpp_linear(x, W, b)
+    return LinearFn.apply(x, W, b)
+
+
 def mlp(seq: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
-    """An nn.Sequential of nn.Linear and activations (or one nn.Linear) with the linear layers as ``LinearFn``."""
+    """An nn.Sequential of nn.Linear and activations (or one nn.Linear) with the linear layers as ``linear``."""
     mods = [seq] if isinstance(seq, torch.nn.Linear) else list(seq)
     for m in mods:
-        x = LinearFn.apply(x, m.weight, m.bias) if isinstance(m, torch.nn.Linear) else m(x)
+        x = linear(x, m.weight, m.bias) if isinstance(m, torch.nn.Linear) else m(x)
     return x

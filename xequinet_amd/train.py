@@ -141,18 +141,7 @@ class GraphedTrainStep:
         data = {keys.POSITIONS: g.pos.detach(), keys.ATOMIC_NUMBERS: g.z, keys.EDGE_INDEX: g.edge_index, keys.BATCH: g.batch,
                 keys.BATCH_PTR: g.ptr, keys.EDGE_GRAPH: eg}
         with_forces = self.forces_weight is not None
-        if with_forces:
-            # inside a capture the host's launch rate does not count, so the linear layers take the form whose row reductions run on
-            # xeq_wgrad (nn/training.py NATIVE_LINEAR: 3.4 ms less kernel time per QM9-1024 step, too many autograd nodes for a host-launched one)
-            from .nn import training as _tr
-
-            keep, _tr.NATIVE_LINEAR = _tr.NATIVE_LINEAR, True
-            try:
-                result = self.model(data, True, False)
-            finally:
-                _tr.NATIVE_LINEAR = keep
-        else:
-            result = self.model(data, False, False)
+        result = self.model(data, with_forces, False)
         energy = result[keys.TOTAL_ENERGY]
         diff = energy - self.target
         if self.prop == keys.ENERGY_PER_ATOM:
