@@ -180,17 +180,20 @@ def test_linear_function_pair_is_closed_under_differentiation():
         W = _rand(96, 64, seed=2).detach().to(dtype).requires_grad_()
         b = _rand(96, seed=3).detach().to(dtype).requires_grad_()
         t = _rand(300, 96, seed=4).detach().to(dtype)
-        outs = []
-        for fn in (lambda: tops.LinearFn.apply(x, W, b), lambda: torch.nn.functional.linear(x, W, b)):
+        tops.linear(x, W, b)                                   # loads the operator library
+        forms = [lambda: tops.LinearFn.apply(x, W, b), lambda: torch.ops.xeq.linear(x, W, b), lambda: torch.nn.functional.linear(x, W, b)]
+        results = []
+        for fn in forms:
             y = torch.tanh(fn())
             (gx,) = torch.autograd.grad((y * t).sum(), x, create_graph=True)
             second = torch.autograd.grad((gx * gx).sum(), (x, W, b), allow_unused=True)
-            outs.append((y, gx, *second))
-        for got, want in zip(*outs):
-            if want is None:
-                assert got is None or float(got.abs().max()) == 0.0
-            else:
-                assert float((got - want).detach().abs().max()) <= tol * max(1.0, float(want.detach().abs().max()))
+            results.append((y, gx, *second))
+        for outs in (results[0], results[1]):                  # the Python pair and the C++ pair against the library's layer
+            for got, want in zip(outs, results[2]):
+                if want is None:
+                    assert got is None or float(got.abs().max()) == 0.0
+                else:
+                    assert float((got - want).detach().abs().max()) <= tol * max(1.0, float(want.detach().abs().max()))
 
 
 def test_force_loss_kernel_form_without_l2_channels_and_with_an_isolated_atom(monkeypatch):

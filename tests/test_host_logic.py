@@ -394,3 +394,19 @@ def test_launch_policy_is_stated_once_in_the_c_abi():
     assert "xeq_message_auto_family" in src and "xeq_message_wq_edges_per_stream" in src
     cpp = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xequinet_amd", "csrc", "xeq_torch.cpp")).read()
     assert "xeq_message_auto_family" in cpp and "xeq_message_wq_edges_per_stream" in cpp and "E < 4096" not in cpp
+
+
+def test_linear_operator_is_differentiable_to_second_order_on_the_host():
+    """``xeq::linear`` (csrc/xeq_torch.cpp): the node pair y = x W^T + b / a^T b is closed under differentiation; on host tensors the
+    row reduction falls to the library product, the graph structure is the one the GPU pass runs."""
+    import torch
+    from torch.autograd import gradcheck, gradgradcheck
+
+    from xequinet_amd.interface import scripted
+
+    scripted.load_torch_library()
+    g = torch.Generator().manual_seed(0)
+    x, W, b = (torch.randn(*shape, generator=g, dtype=torch.float64).requires_grad_() for shape in ((7, 5), (3, 5), (3,)))
+    assert gradcheck(torch.ops.xeq.linear, (x, W, b)) and gradgradcheck(torch.ops.xeq.linear, (x, W, b))
+    assert gradcheck(lambda a, c: torch.ops.xeq.linear(a, c, None), (x, W)) and gradgradcheck(lambda a, c: torch.ops.xeq.linear(a, c, None), (x, W))
+    assert torch.allclose(torch.ops.xeq.linear(x, W, b), torch.nn.functional.linear(x, W, b), rtol=0, atol=1e-14)
