@@ -10,7 +10,7 @@ python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-steps = 18.0   # 3 warm-up + 10 timed + 5 with the launch timer
+steps = 30.0   # 15 warm-up + 10 timed + 5 with the launch timer (scratch/bench_train.py)
 with open("gpurun_out/train_kernel_stats.csv", "w", newline="") as fh:
     w = csv.writer(fh)
     w.writerow(["kernel", "calls_per_step", "us_per_step", "average_us", "percent"])
