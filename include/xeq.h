@@ -456,6 +456,19 @@ int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32
                         const int32_t mul[3], void* grad_h, void* grad_xhat, void* q, void* gy, int flags, void* stream);
 /* dL/d[W | b] from those products: parts[n_chunks][2C+F][roundup(B, 4) + 1] with out[c, k] = sum_e q[e, c] basis[e, k] over the chunk's
  * edges (columns [0, B): dL/dW[c, k]; column roundup(B, 4): dL/db[c]); the caller adds the chunks in order.  At most 768 filter rows. */
+/* Two of the three second-order passes in one walk each: pass A (h <- u_h) and pass B ((xhat, Y) <- (u_xhat, u_Y); the l = 0 harmonic counts as
+ * 0, the scalar message has no term) use the TRUE record head, i.e. the same filter values and the same gathered rows; the pair kernels
+ * evaluate the filter once per edge.  basis_u: records whose harmonics are u_Y (only their tail is read).
+ *   xeq_message_fwd_sb_pair:  s_out = s_in + A's scalar aggregate, x_out = x_in + A's + B's equivariant aggregates (s_in / x_in may be NULL);
+ *   xeq_message_bwd_sbq_pair: grad_h = B's dL/dh, grad_xhat = A's dL/dxhat, q = q_A + q_B, gy = A's dL/dY. */
+int xeq_message_fwd_sb_pair(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* perm, const int64_t* nbr,
+                            const void* basis, const void* basis_u, const void* h, const void* u_h, const void* xhat, const void* u_xhat,
+                            const void* s_in, const void* x_in, const void* w_rbf, const void* b_rbf, int num_basis, int node_dim,
+                            const int32_t mul[3], void* s_out, void* x_out, int xhat_layout, void* stream);
+int xeq_message_bwd_sbq_pair(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                             const int64_t* center, const void* basis, const void* basis_u, const void* h, const void* u_h, const void* xhat,
+                             const void* u_xhat, const void* grad_s, const void* grad_x, const void* w_rbf, const void* b_rbf, int num_basis,
+                             int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat, void* q, void* gy, int flags, void* stream);
 /* Rows [*n_valid, n_rows) of a row-major buffer of 4-byte words := 0 (n_valid: device pointer).  For q and a capacity-sized edge list whose
  * true count never reached the host (train.GraphedTrainStep): xeq_message_bwd_sbq writes the rows of walked edges only, the two products
  * above read every row. */

@@ -67,6 +67,10 @@ def test_c_abi_argument_errors_are_reported_without_a_gpu():
     assert rc == 1 and b"n_chunks" in handle.xeq_last_error()
     rc = handle.xeq_message_q_wgrad(0, None, None, 1000, 20, 512, mul, 4, None, None)           # 960 filter rows
     assert rc == 1 and b"768" in handle.xeq_last_error()
+    rc = handle.xeq_message_fwd_sb_pair(0, 10, 10, None, None, None, None, None, None, None, None, None, None, None, None, None, 20, 128, mul, None, None, 0, None)
+    assert rc == 1 and b"cotangent operands" in handle.xeq_last_error()
+    rc = handle.xeq_message_bwd_sbq_pair(0, 10, 10, None, None, None, None, None, None, None, None, None, None, None, None, None, 20, 300, mul, None, None, None, None, 0, None)
+    assert rc == 1 and b"256-channel" in handle.xeq_last_error()
     rc = handle.xeq_train_norm(0, 0, 10, None, None, None, None, None, None, None, None, None, None, 128, mul, 1e-5, 1e-5, 2, None, None, None, None)
     assert rc == 1 and b"layout" in handle.xeq_last_error()
     rc = handle.xeq_train_norm(0, 1, 10, None, None, None, None, None, None, None, None, None, None, 128, mul, 1e-5, 1e-5, 0, None, None, None, None)

@@ -644,6 +644,217 @@ __global__ void __launch_bounds__(256) k_zero_rows_from(uint32_t* __restrict__ b
   }
 }
 
+// ---- the two second-order passes that share their filter, in one walk each (training pass, ops.DiffMessageGrad.backward) -------------
+// Pass A replaces h by its cotangent u_h; pass B replaces (xhat, Y) by (u_xhat, u_Y) with the constant l = 0 harmonic counted as 0 and no
+// scalar-message term.  Both use the TRUE record head, i.e. the same filter values and the same gathered rows of dL/dout: a "pair"
+// kernel evaluates the filter once per edge and forms both passes' terms (h2 = u_h, xhat2 = u_xhat, eb2 = records whose harmonics are
+// u_Y; only their tail is read).  Forward pair: s_out = s_in + A's scalar aggregate, x_out = x_in + A's + B's equivariant aggregates.
+template <typename T, int MAXB, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_message_fwd_sb2(
+    SbArgs a, const T* __restrict__ eb, const T* __restrict__ eb2, const T* __restrict__ h, const T* __restrict__ h2,
+    const T* __restrict__ xhat, const T* __restrict__ xhat2, const T* __restrict__ s_in, const T* __restrict__ x_in,
+    const T* __restrict__ w_rbf, const T* __restrict__ b_rbf, T* __restrict__ s_out, T* __restrict__ x_out) {
+  const int B = a.B, C = a.C, F = a.F, D = a.D, H = a.H;
+  const int BP = eb_bp(B), EW = BP + 12;
+  const ChanMap cm = chan_map(a);
+  const XAddr xa = xaddr(a.ir, a.n_nodes, cm.tu, a.xl);
+  int xcomp[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) xcomp[m] = min(m, cm.nm - 1) * xa.comp;
+  T ws[MAXB], we[MAXB], wm[MAXB], bs, be, bm;
+  load_w<T, MAXB>(w_rbf, b_rbf, cm.tu, B, cm.has_u, ws, bs);
+  load_w<T, MAXB>(w_rbf, b_rbf, C + cm.tu, B, cm.has_u, we, be);
+  load_w<T, MAXB>(w_rbf, b_rbf, 2 * C + cm.ts, B, cm.has_s, wm, bm);
+  const int lane = threadIdx.x & 63;
+  XcdWalk walk(a.n_nodes, a.chunk);
+  for (int64_t c = walk.next(); c >= 0; c = walk.next()) {
+    const int32_t e0 = a.rowptr[c], e1 = a.rowptr[c + 1];
+    T acc_s = T(0), acc_x[5] = {T(0), T(0), T(0), T(0), T(0)};
+    for (int32_t pb = e0; pb < e1; pb += 64) {
+      const int cnt = min(64, e1 - pb);
+      const int32_t slot_v = pb + min(lane, cnt - 1);
+      const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
+      const int32_t nbr_v = (int32_t)a.other[eid_v];
+      for (int j = 0; j < cnt; ++j) {
+        const uint32_t noff = (uint32_t)__builtin_amdgcn_readlane(nbr_v, j);
+        const uint32_t eoff = (uint32_t)__builtin_amdgcn_readlane(eid_v, j) * (uint32_t)EW;
+        const T* hn = h + noff * (uint32_t)H;
+        const T* gn = h2 + noff * (uint32_t)H;
+        const T hs = hn[cm.tu], he = hn[C + cm.tu];
+        const T hs2 = gn[cm.tu], he2 = gn[C + cm.tu], hm2 = gn[2 * C + cm.ts];
+        const T* xn = xhat + xa.off + (int64_t)noff * xa.node;
+        const T* x2 = xhat2 + xa.off + (int64_t)noff * xa.node;
+        T xv[5], xw[5];
+        xv[0] = xn[0];
+        xw[0] = x2[0];
+        if (cm.wnm >= 3) {  // wave-uniform
+          xv[1] = xn[xcomp[1]];
+          xv[2] = xn[xcomp[2]];
+          xw[1] = x2[xcomp[1]];
+          xw[2] = x2[xcomp[2]];
+        } else {
+          xv[1] = xv[2] = xw[1] = xw[2] = T(0);
+        }
+        if (cm.wnm >= 5) {
+          xv[3] = xn[xcomp[3]];
+          xv[4] = xn[xcomp[4]];
+          xw[3] = x2[xcomp[3]];
+          xw[4] = x2[xcomp[4]];
+        } else {
+          xv[3] = xv[4] = xw[3] = xw[4] = T(0);
+        }
+        const T* rec = eb + eoff;
+        const T* rec2 = eb2 + eoff;
+        const T fe = rec[BP];
+        const T ps = filt(ws, bs, rec, fe), pe = filt(we, be, rec, fe), pm = filt(wm, bm, rec, fe);
+        acc_s += hm2 * pm;
+        const T gsa = hs2 * ps, gea = he2 * pe, gsb = hs * ps, geb = he * pe;
+        T y[5], y2[5];
+        lane_y<T>(rec + BP, cm.l, y, T(1));
+        lane_y<T>(rec2 + BP, cm.l, y2, T(0));
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc_x[m] += xv[m] * gsa + y[m] * gea + xw[m] * gsb + y2[m] * geb;
+      }
+    }
+    if (cm.has_s) s_out[c * F + cm.ts] = (s_in ? s_in[c * F + cm.ts] : T(0)) + acc_s;
+    if (cm.has_u) {
+#pragma unroll
+      for (int m = 0; m < 5; ++m)
+        if (m < cm.nm) x_out[c * D + cm.off + m] = (x_in ? x_in[c * D + cm.off + m] : T(0)) + acc_x[m];
+    }
+  }
+}
+
+// Reverse pair: grad_h = pass B's dL/dh, grad_xhat = pass A's dL/dxhat, q = q_A + q_B, gy = pass A's dL/dY.
+template <typename T, int MAXB, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_message_bwd_sbq2(
+    SbArgs a, const T* __restrict__ eb, const T* __restrict__ eb2, const T* __restrict__ h, const T* __restrict__ h2,
+    const T* __restrict__ xhat, const T* __restrict__ xhat2, const T* __restrict__ grad_s, const T* __restrict__ grad_x,
+    const T* __restrict__ w_rbf, const T* __restrict__ b_rbf, T* __restrict__ grad_h, T* __restrict__ grad_xhat,
+    T* __restrict__ q_out, T* __restrict__ gy_out) {
+  __shared__ T red[SB_RED][4][8];
+  __shared__ int32_t red_eid[SB_RED];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int B = a.B, C = a.C, F = a.F, D = a.D, H = a.H;
+  const int BP = eb_bp(B), EW = BP + 12;
+  const ChanMap cm = chan_map(a);
+  const bool is1 = cm.has_u && cm.l == 1, is2 = cm.has_u && cm.l == 2;
+  const bool wave_has1 = __ballot(is1) != 0ull, wave_has2 = __ballot(is2) != 0ull;
+  const XAddr xa = xaddr(a.ir, a.n_nodes, cm.tu, a.xl);
+  int gcomp[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) gcomp[m] = cm.off + min(m, cm.nm - 1);
+  T ws[MAXB], we[MAXB], wm[MAXB], bs, be, bm;
+  load_w<T, MAXB>(w_rbf, b_rbf, cm.tu, B, cm.has_u, ws, bs);
+  load_w<T, MAXB>(w_rbf, b_rbf, C + cm.tu, B, cm.has_u, we, be);
+  load_w<T, MAXB>(w_rbf, b_rbf, 2 * C + cm.ts, B, cm.has_s, wm, bm);
+  XcdWalk walk(a.n_nodes, a.chunk);
+  for (int64_t n = walk.next(); n >= 0; n = walk.next()) {
+    const int32_t e0 = a.rowptr[n], e1 = a.rowptr[n + 1];
+    const T hs = cm.has_u ? h[n * H + cm.tu] : T(0), he = cm.has_u ? h[n * H + C + cm.tu] : T(0);
+    const T hs2 = cm.has_u ? h2[n * H + cm.tu] : T(0), he2 = cm.has_u ? h2[n * H + C + cm.tu] : T(0);
+    const T hm2 = cm.has_s ? h2[n * H + 2 * C + cm.ts] : T(0);
+    T xh[5], xw[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const bool own = cm.has_u && m < cm.nm;
+      xh[m] = own ? xhat[xa.off + n * xa.node + m * xa.comp] : T(0);
+      xw[m] = own ? xhat2[xa.off + n * xa.node + m * xa.comp] : T(0);
+    }
+    T acc_hs = T(0), acc_he = T(0), acc_xh[5] = {T(0), T(0), T(0), T(0), T(0)};
+    for (int32_t pb = e0; pb < e1; pb += SB_RED) {
+      const int32_t pe_ = min(pb + SB_RED, e1);
+      const int cnt = pe_ - pb;
+      const int32_t slot_v = pb + min(lane, cnt - 1);
+      const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
+      const int32_t ctr_v = (int32_t)a.other[eid_v];
+      for (int32_t p = pb; p < pe_; ++p) {
+        const int j = p - pb;
+        const int32_t eid = __builtin_amdgcn_readlane(eid_v, j);
+        const uint32_t cidx = (uint32_t)__builtin_amdgcn_readlane(ctr_v, j);
+        T gx[5];
+        const T dgm = grad_s[cidx * (uint32_t)F + cm.ts];
+        const T* gr = grad_x + cidx * (uint32_t)D;
+        gx[0] = gr[gcomp[0]];
+        if (cm.wnm >= 3) {  // wave-uniform
+          gx[1] = gr[gcomp[1]];
+          gx[2] = gr[gcomp[2]];
+        } else {
+          gx[1] = gx[2] = T(0);
+        }
+        if (cm.wnm >= 5) {
+          gx[3] = gr[gcomp[3]];
+          gx[4] = gr[gcomp[4]];
+        } else {
+          gx[3] = gx[4] = T(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+          if (m >= cm.nm) gx[m] = T(0);
+        const T* rec = eb + (uint32_t)eid * (uint32_t)EW;
+        const T* rec2 = eb2 + (uint32_t)eid * (uint32_t)EW;
+        const T fe = rec[BP];
+        const T ps = filt(ws, bs, rec, fe), pe = filt(we, be, rec, fe), pm = filt(wm, bm, rec, fe);
+        T y[5], y2[5];
+        lane_y<T>(rec + BP, cm.l, y, T(1));
+        lane_y<T>(rec2 + BP, cm.l, y2, T(0));
+        T dgs = T(0), dge = T(0), dgs2 = T(0), dge2 = T(0);
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+          dgs += xh[m] * gx[m];     // pass A: the true xhat / Y against dL/dx_out
+          dge += y[m] * gx[m];
+          dgs2 += xw[m] * gx[m];    // pass B: their cotangents
+          dge2 += y2[m] * gx[m];
+        }
+        const T dg_m = cm.has_s ? dgm : T(0);
+        acc_hs += ps * dgs2;        // dL/dh: pass B (its scalar-message row has no term)
+        acc_he += pe * dge2;
+        const T gate = hs2 * ps;    // dL/dxhat: pass A
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc_xh[m] += gate * gx[m];
+        T* qr = q_out + (int64_t)eid * H;
+        if (cm.has_u) {
+          qr[cm.tu] = hs2 * dgs + hs * dgs2;
+          qr[C + cm.tu] = he2 * dge + he * dge2;
+        }
+        if (cm.has_s) qr[2 * C + cm.ts] = hm2 * dg_m;
+        (void)pm;
+        const T gy = he2 * pe;      // dL/dY: pass A
+        T r1[3] = {T(0), T(0), T(0)}, r2[5] = {T(0), T(0), T(0), T(0), T(0)};
+        if (wave_has1) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) r1[m] = wave_total(is1 ? gy * gx[m] : T(0));
+        }
+        if (wave_has2) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) r2[m] = wave_total(is2 ? gy * gx[m] : T(0));
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) red[j][wave][m] = r1[m];
+#pragma unroll
+          for (int m = 0; m < 5; ++m) red[j][wave][3 + m] = r2[m];
+          if (wave == 0) red_eid[j] = eid;
+        }
+      }
+      __syncthreads();
+      for (int i = t; i < cnt * 8; i += 256) {
+        const int j = i >> 3, m = i & 7;
+        gy_out[(int64_t)red_eid[j] * 8 + m] = ((red[j][0][m] + red[j][1][m]) + red[j][2][m]) + red[j][3][m];
+      }
+      __syncthreads();
+    }
+    if (cm.has_u) {
+      grad_h[n * H + cm.tu] = acc_hs;
+      grad_h[n * H + C + cm.tu] = acc_he;
+#pragma unroll
+      for (int m = 0; m < 5; ++m)
+        if (m < cm.nm) grad_xhat[xa.off + n * xa.node + m * xa.comp] = acc_xh[m];
+    }
+    if (cm.has_s) grad_h[n * H + 2 * C + cm.ts] = T(0);
+  }
+}
+
 // what the scalar-broadcast kernels cover: at most 256 channels per kind (one thread each) and 32-bit row offsets
 static bool sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int node_dim, const int32_t mul[3]) {
   if (num_basis < 1 || num_basis > 32 || mul[0] < 0 || mul[1] < 0 || mul[2] < 0) return false;
@@ -836,6 +1047,66 @@ int xeq_zero_rows_from(void* buf, int64_t row_words, int64_t n_rows, const int32
   hipLaunchKernelGGL(k_zero_rows_from, dim3((unsigned)(n_rows < 2048 ? n_rows : 2048)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)buf,
                      row_words, n_rows, n_valid);
   XEQ_CHECK_LAUNCH("xeq_zero_rows_from");
+  return XEQ_OK;
+}
+
+#define XEQ_SB2_DISPATCH(KERNEL, ...)                                                                                        \
+  do {                                                                                                                       \
+    if (dtype == XEQ_F32) {                                                                                                  \
+      using T = float;                                                                                                       \
+      if (num_basis <= 8) hipLaunchKernelGGL((KERNEL<T, 8, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);         \
+      else if (num_basis <= 16) hipLaunchKernelGGL((KERNEL<T, 16, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+      else if (num_basis <= 20) hipLaunchKernelGGL((KERNEL<T, 20, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+      else hipLaunchKernelGGL((KERNEL<T, 32, 3>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                      \
+    } else if (dtype == XEQ_F64) {                                                                                           \
+      using T = double;                                                                                                      \
+      if (num_basis <= 8) hipLaunchKernelGGL((KERNEL<T, 8, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);         \
+      else if (num_basis <= 16) hipLaunchKernelGGL((KERNEL<T, 16, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+      else if (num_basis <= 20) hipLaunchKernelGGL((KERNEL<T, 20, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+      else hipLaunchKernelGGL((KERNEL<T, 32, 1>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                      \
+    } else {                                                                                                                 \
+      xeq::set_error("unsupported dtype %d", dtype);                                                                         \
+      return XEQ_ERR_INVALID_ARGUMENT;                                                                                       \
+    }                                                                                                                        \
+  } while (0)
+
+int xeq_message_fwd_sb_pair(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* rowptr, const int32_t* perm, const int64_t* nbr,
+                            const void* basis, const void* basis_u, const void* h, const void* u_h, const void* xhat, const void* u_xhat,
+                            const void* s_in, const void* x_in, const void* w_rbf, const void* b_rbf, int num_basis, int node_dim,
+                            const int32_t mul[3], void* s_out, void* x_out, int xhat_layout, void* stream) {
+  SbArgs a{};
+  int rcode = sb_check("xeq_message_fwd_sb_pair", n_nodes, n_edges, num_basis, node_dim, mul, a);
+  if (rcode != XEQ_OK) return rcode;
+  XEQ_CHECK_ARG(n_nodes == 0 || (basis_u && u_h && u_xhat), "xeq_message_fwd_sb_pair: the cotangent operands are missing");
+  if (n_nodes == 0) return XEQ_OK;
+  a.rowptr = rowptr;
+  a.perm = perm;
+  a.other = nbr;
+  a.xl = xhat_layout & 1;
+  dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
+  XEQ_SB2_DISPATCH(k_message_fwd_sb2, a, (const T*)basis, (const T*)basis_u, (const T*)h, (const T*)u_h, (const T*)xhat, (const T*)u_xhat,
+                   (const T*)s_in, (const T*)x_in, (const T*)w_rbf, (const T*)b_rbf, (T*)s_out, (T*)x_out);
+  XEQ_CHECK_LAUNCH("xeq_message_fwd_sb_pair");
+  return XEQ_OK;
+}
+
+int xeq_message_bwd_sbq_pair(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,
+                             const int64_t* center, const void* basis, const void* basis_u, const void* h, const void* u_h, const void* xhat,
+                             const void* u_xhat, const void* grad_s, const void* grad_x, const void* w_rbf, const void* b_rbf, int num_basis,
+                             int node_dim, const int32_t mul[3], void* grad_h, void* grad_xhat, void* q, void* gy, int flags, void* stream) {
+  SbArgs a{};
+  int rcode = sb_check("xeq_message_bwd_sbq_pair", n_nodes, n_edges, num_basis, node_dim, mul, a);
+  if (rcode != XEQ_OK) return rcode;
+  XEQ_CHECK_ARG(n_nodes == 0 || (basis_u && u_h && u_xhat && q && gy), "xeq_message_bwd_sbq_pair: operands missing");
+  if (n_nodes == 0) return XEQ_OK;
+  a.rowptr = n_rowptr;
+  a.perm = n_perm;
+  a.other = center;
+  a.xl = flags & 1;
+  dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
+  XEQ_SB2_DISPATCH(k_message_bwd_sbq2, a, (const T*)basis, (const T*)basis_u, (const T*)h, (const T*)u_h, (const T*)xhat, (const T*)u_xhat,
+                   (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat, (T*)q, (T*)gy);
+  XEQ_CHECK_LAUNCH("xeq_message_bwd_sbq_pair");
   return XEQ_OK;
 }
 

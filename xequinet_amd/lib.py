@@ -109,6 +109,8 @@ _PROTOS = {
     "xeq_train_uv": [c_int, c_int, c_int64, _P, _P, _P, _I3, c_double, _P, _P, _P],
     "xeq_train_out": [c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _I3, _P, _P, _P, _P],
     "xeq_zero_rows_from": [_P, c_int64, c_int64, _P, _P],
+    "xeq_message_fwd_sb_pair": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, c_int, _P],
+    "xeq_message_bwd_sbq_pair": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P, _P, c_int, _P],
     "xeq_message_bwd_sb": [c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3, _P, _P, _P,
                            c_int, _P],
     "xeq_message_sb_fits": [c_int64, c_int64, c_int, c_int, _I3],

@@ -929,6 +929,34 @@ def _diff_bwd(h, xhat, rec, w, b, g_s, g_x, graph: "EdgeGraph", cfg, q=None, y0_
     return g_h, g_xh, q, gy
 
 
+def _diff_fwd_pair(h, u_h, xhat, u_xh, rec, rec_u, w, b, graph: "EdgeGraph", cfg, s_in=None, x_in=None):
+    """Passes A (h <- u_h) and B ((xhat, Y) <- (u_xh, harmonics of rec_u)) of the second order in one walk (xeq_message_fwd_sb_pair):
+    (s_in + A's scalar aggregate, x_in + both equivariant aggregates)."""
+    B, F, mul, C, D, H, bp = _diff_sizes(cfg)
+    N, E = graph.n_nodes, graph.n_edges
+    ds, dx = torch.empty((N, F), dtype=h.dtype, device=h.device), torch.empty((N, D), dtype=h.dtype, device=h.device)
+    KERNEL_TIMER.launch("xeq_message_fwd_sb_pair", dtype_code(h), N, E, ptr(graph.c_rowptr), ptr(graph.c_perm), ptr(graph.edge_index[1]),
+                        ptr(rec), ptr(rec_u), ptr(h), ptr(u_h), ptr(xhat), ptr(u_xh), ptr(s_in), ptr(x_in), ptr(w), ptr(b), B, F, mul3(mul),
+                        ptr(ds), ptr(dx), 0, stream())
+    return ds, dx
+
+
+def _diff_bwd_pair(h, u_h, xhat, u_xh, rec, rec_u, w, b, g_s, g_x, graph: "EdgeGraph", cfg):
+    """The same two passes' reverse walk (xeq_message_bwd_sbq_pair): (B's dL/dh, A's dL/dxhat, q_A + q_B, A's dL/dY)."""
+    B, F, mul, C, D, H, bp = _diff_sizes(cfg)
+    N, E = graph.n_nodes, graph.n_edges
+    capacity = getattr(graph, "edge_count_on_device", False)
+    g_h, g_xh = torch.empty_like(h), torch.empty_like(xhat)
+    q = torch.empty((E, H), dtype=h.dtype, device=h.device)
+    gy = (torch.zeros if capacity else torch.empty)((E, 8), dtype=h.dtype, device=h.device)
+    KERNEL_TIMER.launch("xeq_message_bwd_sbq_pair", dtype_code(h), N, E, ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(graph.edge_index[0]),
+                        ptr(rec), ptr(rec_u), ptr(h), ptr(u_h), ptr(xhat), ptr(u_xh), ptr(g_s), ptr(g_x), ptr(w), ptr(b), B, F, mul3(mul),
+                        ptr(g_h), ptr(g_xh), ptr(q), ptr(gy), 0, stream())
+    if capacity:
+        call("xeq_zero_rows_from", ptr(q), H * (q.element_size() // 4), E, ptr(graph.c_rowptr[N:]), stream())
+    return g_h, g_xh, q, gy
+
+
 def diff_message_supported(h: torch.Tensor, graph: "EdgeGraph", cfg) -> bool:
     B, F, mul, C, D, H, bp = _diff_sizes(cfg)
     return bool(h.is_cuda and h.dtype in (torch.float32, torch.float64)
@@ -1028,20 +1056,24 @@ class DiffMessageGrad(Function):
             if need[3] or need[4]:
                 d_w, d_b = _wb_from_q(q_c, rec_c, cfg)
             del q_c
-        if u_h is not None:                      # A: h <- u_h
+        u_y = None if u_rec is None else u_rec[:, bp + 1 : bp + 9]
+        has_b = u_xh is not None or u_rec is not None
+        if has_b:       # the operands of pass B: (xhat, Y) <- (u_xhat, u_Y)
+            ux = zeros(*xhat.shape) if u_xh is None else u_xh.contiguous()
+            rec_b = torch.cat([rec[:, : bp + 1], zeros(E, 8) if u_y is None else u_y, zeros(E, 3)], dim=1)
+        if u_h is not None and has_b:            # A (h <- u_h) and B share the filter and the gathered rows: one walk each way for both
+            u_h = u_h.contiguous()
+            d_gs, d_gx = _diff_fwd_pair(h, u_h, xhat, ux, rec, rec_b, w, b, graph, cfg, s_in=d_gs, x_in=d_gx)
+            gh, gxh, q_ab, gy = _diff_bwd_pair(h, u_h, xhat, ux, rec, rec_b, w, b, g_s, g_x, graph, cfg)
+            d_h, d_xh, gy_sum = add(d_h, gh), add(d_xh, gxh), add(gy_sum, gy)
+        elif u_h is not None:                    # A alone
             u_h = u_h.contiguous()
             d_gs, d_gx = _diff_fwd(u_h, xhat, rec, w, b, graph, cfg, s_in=d_gs, x_in=d_gx)     # the kernel adds to the sums so far
             _, gxh, q_ab, gy = _diff_bwd(u_h, xhat, rec, w, b, g_s, g_x, graph, cfg)
             d_xh, gy_sum = add(d_xh, gxh), add(gy_sum, gy)
-        u_y = None if u_rec is None else u_rec[:, bp + 1 : bp + 9]
-        if u_xh is not None or u_rec is not None:  # B: (xhat, Y) <- (u_xhat, u_Y); dL/ds_out plays no part
-            ux = zeros(*xhat.shape) if u_xh is None else u_xh.contiguous()
-            if u_rec is None:
-                rec_b = torch.cat([rec[:, : bp + 1], zeros(E, 11)], dim=1)
-            else:
-                rec_b = torch.cat([rec[:, : bp + 1], u_y, zeros(E, 3)], dim=1)
+        elif has_b:                              # B alone (the first block: its h does not depend on the positions); dL/ds_out plays no part
             _, d_gx = _diff_fwd(h, ux, rec_b, w, b, graph, cfg, y0_zero=True, x_in=d_gx)      # (its scalar aggregate is not a term)
-            gh, _, q_ab, _ = _diff_bwd(h, ux, rec_b, w, b, zeros(N, F), g_x, graph, cfg, q=q_ab, y0_zero=True, want_gy=False)
+            gh, _, q_ab, _ = _diff_bwd(h, ux, rec_b, w, b, zeros(N, F), g_x, graph, cfg, y0_zero=True, want_gy=False)
             d_h = add(d_h, gh)
         d_rec = None
         if q_ab is not None:
