@@ -254,3 +254,25 @@ def test_message_kernels_every_basis_width_in_both_precisions(B):
         res[dt] = [t.detach().double() for t in (ds, dx, *first, *second)]
     for got, want in zip(res[torch.float32], res[torch.float64]):
         assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_geometry_only_pass_skips_the_filter_gradients_and_nothing_else():
+    """``ops.geometry_only_backward``: inside it (the force evaluation's own reverse pass, nn/basic.py:143-159) DiffMessage leaves out
+    dL/d[W | b]; every other gradient is the same, and a reverse pass outside it -- also one running while another is inside -- gets all."""
+    n, B = 6, 5
+    H = F + 2 * C
+    pairs = [(i, j) for i in range(n) for j in range(n) if i != j]
+    graph = ops.EdgeGraph(torch.tensor(pairs, dtype=torch.int64).t().contiguous().to(DEV), n)
+    E, bp = len(pairs), (B + 3) & ~3
+    h, xhat, rec, w, b = _rand(n, H, seed=1), _rand(n, D, seed=2), _rand(E, bp + 12, seed=3), _rand(H, B, seed=4), _rand(H, seed=5)
+    ds, dx = ops.DiffMessage.apply(h, xhat, rec, w, b, graph, (B, F, MUL))
+    e = (ds * ds).sum() + (dx * dx).sum()
+    full = torch.autograd.grad(e, (h, xhat, rec, w, b), retain_graph=True)
+    with ops.geometry_only_backward(e):
+        part = torch.autograd.grad(e, (h, xhat, rec, w, b), retain_graph=True, allow_unused=True)
+    assert part[3] is None and part[4] is None
+    for got, want in zip(part[:3], full[:3]):
+        assert torch.equal(got, want)
+    assert not ops._GEOMETRY_ONLY_TASKS                         # the task ids are forgotten on exit
+    again = torch.autograd.grad(e, (w, b))
+    assert torch.equal(again[0], full[3]) and torch.equal(again[1], full[4])

@@ -91,16 +91,18 @@ def compute_edge_data(
 def compute_forces_only(energy: torch.Tensor, pos: torch.Tensor, training: bool = True) -> torch.Tensor:
     """nn/basic.py:143-159"""
     grad_outputs: Optional[List[Optional[torch.Tensor]]] = [torch.ones_like(energy)]
-    pos_grad = torch.autograd.grad(outputs=[energy], inputs=[pos], grad_outputs=grad_outputs, retain_graph=training,
-                                   create_graph=training, allow_unused=True)[0]
+    with ops.geometry_only_backward(energy):     # this reverse pass is asked for dE/dpos alone (ops.DiffMessage skips its parameter gradients)
+        pos_grad = torch.autograd.grad(outputs=[energy], inputs=[pos], grad_outputs=grad_outputs, retain_graph=training,
+                                       create_graph=training, allow_unused=True)[0]
     if pos_grad is None:
         pos_grad = torch.zeros_like(pos)
     return -1.0 * pos_grad
 
 
 def _grad(energy, inputs, training):
-    grads = torch.autograd.grad(outputs=[energy], inputs=inputs, grad_outputs=[torch.ones_like(energy)], retain_graph=training,
-                                create_graph=training, allow_unused=True)
+    with ops.geometry_only_backward(energy):
+        grads = torch.autograd.grad(outputs=[energy], inputs=inputs, grad_outputs=[torch.ones_like(energy)], retain_graph=training,
+                                    create_graph=training, allow_unused=True)
     return [torch.zeros_like(x) if g is None else g for g, x in zip(grads, inputs)]
 
 

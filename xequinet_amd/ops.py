@@ -963,6 +963,45 @@ def diff_message_supported(h: torch.Tensor, graph: "EdgeGraph", cfg) -> bool:
                 and lib.load().xeq_message_sb_fits(graph.n_nodes, graph.n_edges, B, F, mul3(mul)))
 
 
+_GEOMETRY_ONLY_TASKS = set()     # ids of autograd graph tasks that were started for gradients w.r.t. the geometry only
+
+
+class geometry_only_backward:
+    """``with geometry_only_backward(energy): autograd.grad(energy, [pos, strain], ...)`` -- the force / virial evaluation of nn/basic.py:
+    143-199.  That reverse pass wants no parameter gradient, but a Python ``Function`` cannot see it (``needs_input_grad`` says "the parameter
+    requires grad", not "this pass wants it"), and ``DiffMessage.backward`` would form dL/d[W | b] three times per evaluation for the engine
+    to drop (0.9 ms of a QM9-1024 training step).  The pass is identified by its GRAPH TASK: a pre-hook on the root node notes the task's id
+    when the engine starts it, ``DiffMessage.backward`` looks its own task up -- exact under concurrent backward passes of other threads
+    (the engine runs all of them on one device thread; a process-wide flag would leak into theirs).  Without the private id call
+    (``torch._C._current_graph_task_id``) nothing is skipped."""
+
+    def __init__(self, root: torch.Tensor) -> None:
+        self.node = root.grad_fn if torch.is_tensor(root) else None
+        self.ids, self.handle = [], None
+
+    def _note(self, _grads):
+        tid = torch._C._current_graph_task_id()
+        if tid >= 0:
+            self.ids.append(tid)
+            _GEOMETRY_ONLY_TASKS.add(tid)
+
+    def __enter__(self):
+        if self.node is not None and hasattr(torch._C, "_current_graph_task_id"):
+            self.handle = self.node.register_prehook(self._note)
+        return self
+
+    def __exit__(self, *exc):
+        if self.handle is not None:
+            self.handle.remove()
+        for tid in self.ids:
+            _GEOMETRY_ONLY_TASKS.discard(tid)
+        return False
+
+
+def _in_geometry_only_task() -> bool:
+    return bool(_GEOMETRY_ONLY_TASKS) and torch._C._current_graph_task_id() in _GEOMETRY_ONLY_TASKS
+
+
 class DiffMessage(Function):
     """nn/xpainn.py:140-159 without the residual: (sum_e msg_s, sum_e msg_x) from h = scalar_mlp(s), xhat, the per-edge records
     (``training_records``) and rbf_lin's weight [2C+F, B] / bias.  First derivatives w.r.t. all five; the reverse pass is itself a
@@ -984,7 +1023,7 @@ class DiffMessage(Function):
         N = ctx.graph.n_nodes
         g_s = h.new_zeros((N, F)) if g_s is None else g_s
         g_x = h.new_zeros((N, D)) if g_x is None else g_x
-        want = (ctx.needs_input_grad[2], ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        want = (ctx.needs_input_grad[2], (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) and not _in_geometry_only_task())
         g_h, g_xh, g_rec, g_w, g_b = DiffMessageGrad.apply(h, xhat, rec, w, b, g_s, g_x, ctx.graph, ctx.cfg, want)
         return g_h, g_xh, g_rec, g_w, g_b, None, None
 
