@@ -62,10 +62,10 @@ def test_c_abi_argument_errors_are_reported_without_a_gpu():
     # round-4 entries: the twice-differentiable training pass
     rc = handle.xeq_message_bwd_sbq(0, 10, 10, None, None, None, None, None, None, None, None, None, None, 40, 128, mul, None, None, None, None, 0, None)
     assert rc == 1 and b"num_basis" in handle.xeq_last_error()
-    assert handle.xeq_message_q_wgrad_chunks(311994) == 1219 and handle.xeq_message_q_wgrad_chunks(0) == 0
-    rc = handle.xeq_message_q_wgrad(0, None, None, 1000, 20, 128, mul, 3, None, None)           # wrong chunk count
+    assert handle.xeq_message_q_wgrad_chunks(311994) == 610 and handle.xeq_message_q_wgrad_chunks(0) == 0
+    rc = handle.xeq_message_q_wgrad(0, None, None, 1000, 20, 128, mul, 3, None, None)           # wrong chunk count (2)
     assert rc == 1 and b"n_chunks" in handle.xeq_last_error()
-    rc = handle.xeq_message_q_wgrad(0, None, None, 1000, 20, 512, mul, 4, None, None)           # 960 filter rows
+    rc = handle.xeq_message_q_wgrad(0, None, None, 1000, 20, 512, mul, 2, None, None)           # 960 filter rows
     assert rc == 1 and b"768" in handle.xeq_last_error()
     rc = handle.xeq_message_fwd_sb_pair(0, 10, 10, None, None, None, None, None, None, None, None, None, None, None, None, None, 20, 128, mul, None, None, 0, None)
     assert rc == 1 and b"cotangent operands" in handle.xeq_last_error()

@@ -63,17 +63,22 @@ class NormFn(Function):
         s, x, ln_w, ln_b, eq_w, eq_b = ctx.saved_tensors
         g_s = _z(s, g_s)
         g_x = torch.zeros(x.numel() if ctx.meta[4] else x.shape, dtype=x.dtype, device=x.device) if g_x is None else g_x.contiguous()
-        return (*NormGrad.apply(s, x, ln_w, ln_b, eq_w, eq_b, g_s, g_x, ctx.meta), None)
+        from ..ops import _in_geometry_only_task
+
+        # the force evaluation's own reverse pass (ops.geometry_only_backward) wants no parameter gradient: the sum over the nodes is left out
+        return (*NormGrad.apply(s, x, ln_w, ln_b, eq_w, eq_b, g_s, g_x, ctx.meta, not _in_geometry_only_task()), None)
 
 
 class NormGrad(Function):
     @staticmethod
-    def forward(ctx, s, x, ln_w, ln_b, eq_w, eq_b, g_s, g_x, meta):
+    def forward(ctx, s, x, ln_w, ln_b, eq_w, eq_b, g_s, g_x, meta, want_params=True):
         F, mul = meta[0], meta[1]
         d_s, d_x, rows = _norm_call(1, s, None, x, None, ln_w, ln_b, eq_w, eq_b, g_s, g_x, meta)
         ctx.save_for_backward(s, x, ln_w, ln_b, eq_w, eq_b, g_s, g_x)
         ctx.meta = meta
         ctx.set_materialize_grads(False)
+        if not want_params:
+            return d_s, d_x, None, None, None, None
         return (d_s, d_x, *_norm_rows(rows, F, sum(mul), mul[0]))
 
     @staticmethod
@@ -82,13 +87,13 @@ class NormGrad(Function):
         _no_param_cotangent(u_lw, u_lb, u_ew, u_eb)
         s, x, ln_w, ln_b, eq_w, eq_b, g_s, g_x = ctx.saved_tensors
         if u_s is None and u_x is None:
-            return (None,) * 9
+            return (None,) * 10
         F, mul = ctx.meta[0], ctx.meta[1]
         u_s, u_x = _z(s, u_s), _z(x, u_x)
         d_gs, d_gx, _ = _norm_call(0, s, u_s, x, u_x, ln_w, ln_b, eq_w, eq_b, None, None, ctx.meta)
         d_s, d_x, rows = _norm_call(1, s, u_s, x, u_x, ln_w, ln_b, eq_w, eq_b, g_s, g_x, ctx.meta)
         d_lw, _, d_ew, _ = _norm_rows(rows, F, sum(mul), mul[0])
-        return d_s, d_x, d_lw, None, d_ew, None, d_gs, d_gx, None
+        return d_s, d_x, d_lw, None, d_ew, None, d_gs, d_gx, None, None
 
 
 # ---- Invariant(V) and the channel-wise U . V ------------------------------------------------------------------------------------------
