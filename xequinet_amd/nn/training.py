@@ -17,7 +17,6 @@ import math
 from typing import Dict, List
 
 import torch
-import torch.nn.functional as F_
 
 from .. import keys, lib
 
