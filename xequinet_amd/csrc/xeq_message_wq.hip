@@ -185,10 +185,16 @@ __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __res
                              const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
                              float* __restrict__ drec, int recf, int tailw) {
   const int yoff = WQ_TAIL + 2 * tailw;
+  // thread -> (slot, piece): the three KINDS of piece (bf16 packs: eight basis functions; f32 tail: four; harmonics) sit in three
+  // consecutive thirds of the grid, so a wave runs ONE kind -- with the six pieces of a slot on six neighbouring lanes every wave ran
+  // all three branches one after the other at a third of its lanes (48 us per QM9-1024 step; the same values, bit for bit, in ~half)
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p = t / 6;
-  if (p >= pcap || p >= 4 * (int64_t)qptr[N]) return;
-  const int grp = (int)(t - 6 * p);   // 0-1: bf16 packs of k half kh = grp; 2-3: f32 tail of kh = grp - 2; 4-5: Y
+  const int64_t pc2 = 2 * ((pcap + 31) & ~(int64_t)31);            // threads per kind, whole waves
+  const int kind = (int)(t / pc2);
+  const int64_t r = t - kind * pc2;
+  const int64_t p = r >> 1;
+  if (kind > 2 || p >= pcap || p >= 4 * (int64_t)qptr[N]) return;
+  const int grp = 2 * kind + (int)(r & 1);   // 0-1: bf16 packs of k half kh = grp; 2-3: f32 tail of kh = grp - 2; 4-5: Y
   const int32_t e = peid[p];
   float* __restrict__ out = rec + p * recf;
   float* __restrict__ dout = drec ? drec + p * recf : nullptr;
@@ -1536,7 +1542,7 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
   if (n_edges == 0 && n_nodes == 0) return XEQ_OK;   // (no edge at all: the nodes' lone quads still need their zero records)
-  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = pcap * 6;   // six threads per record
+  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = 6 * ((pcap + 31) & ~(int64_t)31);   // six threads per record, three kinds in whole waves
   const int ks = wq_ks(num_basis);
   XEQ_CHECK_ARG(pcap * wq_recf(ks) < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
