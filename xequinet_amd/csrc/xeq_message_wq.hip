@@ -180,24 +180,13 @@ __global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __re
 // records in padded walk order (layout: WQ_REC above); val(k) = f rho_k, the bias column's multiplier is f; derivative record
 // likewise.  Six threads per slot: two (one per k half) evaluate eight basis functions each and store their three bf16 packs,
 // two the f32 tail, two the harmonics.
-__global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
-                             const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
-                             const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
-                             float* __restrict__ drec, int recf, int tailw) {
+// one piece (grp: 0-1 bf16 packs of k half grp; 2-3 f32 tail of k half grp - 2; 4-5 harmonics) of the record of padded slot p, written
+// through out / dout (the slot's record in the workgroup's LDS staging rows)
+__device__ __forceinline__ void wq_record_piece(const float* __restrict__ vec, const int32_t* __restrict__ peid, int64_t p, int grp,
+                                                const RadialSpec& rs, const float* __restrict__ p0, const float* __restrict__ p1,
+                                                float* __restrict__ out, float* __restrict__ dout, int tailw) {
   const int yoff = WQ_TAIL + 2 * tailw;
-  // thread -> (slot, piece): the three KINDS of piece (bf16 packs: eight basis functions; f32 tail: four; harmonics) sit in three
-  // consecutive thirds of the grid, so a wave runs ONE kind -- with the six pieces of a slot on six neighbouring lanes every wave ran
-  // all three branches one after the other at a third of its lanes (48 us per QM9-1024 step; the same values, bit for bit, in ~half)
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t pc2 = 2 * ((pcap + 31) & ~(int64_t)31);            // threads per kind, whole waves
-  const int kind = (int)(t / pc2);
-  const int64_t r = t - kind * pc2;
-  const int64_t p = r >> 1;
-  if (kind > 2 || p >= pcap || p >= 4 * (int64_t)qptr[N]) return;
-  const int grp = 2 * kind + (int)(r & 1);   // 0-1: bf16 packs of k half kh = grp; 2-3: f32 tail of kh = grp - 2; 4-5: Y
   const int32_t e = peid[p];
-  float* __restrict__ out = rec + p * recf;
-  float* __restrict__ dout = drec ? drec + p * recf : nullptr;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   if (e < 0) {   // padding slot: an all-zero record (its filter is exactly 0)
     if (grp < 2) {
@@ -282,6 +271,37 @@ __global__ void k_wq_records(const float* __restrict__ vec, const int32_t* __res
       *reinterpret_cast<f32x4*>(out + WQ_TAIL + tailw * kh + c0) = v;
       if (dout) *reinterpret_cast<f32x4*>(dout + WQ_TAIL + tailw * kh + c0) = dv;
     }
+  }
+}
+
+
+// A workgroup writes the records of WQ_REC_SLOTS consecutive padded slots: waves 0 / 1 / 2 compute the bf16 packs / the f32 tails / the
+// harmonics of all of them (one KIND of piece per wave: with the six pieces of a slot on six neighbouring lanes every wave ran all three
+// branches one after the other at a third of its lanes) into LDS rows, then all 256 threads store the rows with whole 16-byte lanes
+// (the pieces are 16-48 bytes at a stride of 160: stored directly they kept the kernel at 2.6 TB/s of writes).  48.5 -> 42 us with the
+// wave-uniform kinds alone; the same values bit for bit.
+constexpr int WQ_REC_SLOTS = 32;
+__global__ void __launch_bounds__(256) k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
+                             const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
+                             const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
+                             float* __restrict__ drec, int recf, int tailw) {
+  __shared__ __attribute__((aligned(16))) float stage[2][WQ_REC_SLOTS * 48];
+  const int64_t limit = min(pcap, 4 * (int64_t)qptr[N]);
+  const int64_t first = (int64_t)blockIdx.x * WQ_REC_SLOTS;
+  if (first >= limit) return;                                   // uniform
+  const int t = threadIdx.x, kind = t >> 6, r = t & 63, slot = r >> 1;
+  const int64_t p = first + slot;
+  if (kind < 3 && p < limit)
+    wq_record_piece(vec, peid, p, 2 * kind + (r & 1), rs, p0, p1, stage[0] + slot * recf, drec ? stage[1] + slot * recf : nullptr, tailw);
+  __syncthreads();
+  const int n4 = (int)min((int64_t)WQ_REC_SLOTS, limit - first) * recf / 4;
+  const f32x4* s0 = reinterpret_cast<const f32x4*>(stage[0]);
+  const f32x4* s1 = reinterpret_cast<const f32x4*>(stage[1]);
+  f32x4* g0 = reinterpret_cast<f32x4*>(rec + first * recf);
+  f32x4* g1 = drec ? reinterpret_cast<f32x4*>(drec + first * recf) : nullptr;
+  for (int i = t; i < n4; i += 256) {
+    g0[i] = s0[i];
+    if (g1) g1[i] = s1[i];
   }
 }
 
@@ -1542,7 +1562,7 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
   if (n_edges == 0 && n_nodes == 0) return XEQ_OK;   // (no edge at all: the nodes' lone quads still need their zero records)
-  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = 6 * ((pcap + 31) & ~(int64_t)31);   // six threads per record, three kinds in whole waves
+  const int64_t pcap = wq_pcap(n_nodes, n_edges), total = (pcap + WQ_REC_SLOTS - 1) / WQ_REC_SLOTS * 256;   // a workgroup per WQ_REC_SLOTS records
   const int ks = wq_ks(num_basis);
   XEQ_CHECK_ARG(pcap * wq_recf(ks) < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
