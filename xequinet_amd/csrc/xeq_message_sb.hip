@@ -572,7 +572,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 // dL/d[W | b] of the training-pass message: out[c, k] = sum_e q[e, c] rec[e, k], k <= roundup(B, 4) (the record head and the envelope
 // column behind it), a [H x E] x [E x K] product with K <= 33 -- the library's kernels for this shape run at a third of the read rate.
 // A workgroup owns TNQ_EDGES consecutive edges, thread t the channels t, t + 256, t + 512; the record columns are workgroup-uniform
-// (scalar loads), q rows are read once, coalesced.  parts[chunk][H][K], summed by the caller in chunk order.
+// (staged in LDS TNQ_STAGE rows at a time, read back as broadcasts), q rows are read once, coalesced, four rows in flight.
+// parts[chunk][H][K], summed by the caller in chunk order.
 constexpr int TNQ_EDGES = 512;   // (256: the same kernel time, twice the partial blocks for the caller to add)
 constexpr int TNQ_STAGE = 128;   // record rows staged in LDS at a time (scalar loads of eight rows ahead spilled 396 SGPRs: 740 us)
 template <typename T, int MAXK>
