@@ -68,7 +68,7 @@ VARIANT = dict(node_dim=64, node_irreps="64x0e + 32x1o + 32x2e", action_blocks=2
 
 
 @pytest.mark.parametrize("case", ["energy", "variant energy", "periodic energy", "energy (differentiable form)", "energy+forces",
-                                  "periodic energy+forces+virial", "variant energy+forces"])
+                                  "periodic energy+forces+virial", "variant energy+forces", "energy+forces, 40 molecules"])
 def test_parameter_gradients_match_the_oracle(case):
     """An energy-only loss takes the NATIVE training pass (fused kernels + xeq_message_param_grad, nn/fused.py); forces / virial in
     the loss need second order and take the differentiable form (nn/training.py)."""
@@ -81,7 +81,7 @@ def test_parameter_gradients_match_the_oracle(case):
         weights[keys.VIRIAL] = 0.5
     model = _model(torch.float64, **cfg).train()
     model.native_training = "differentiable" not in case
-    host, dev = _batch(6, 5, torch.float64, periodic)
+    host, dev = _batch(40 if "40 molecules" in case else 6, 5, torch.float64, periodic)     # 40 molecules: ~720 atoms, 12 k edges
     tgt = _targets(host, 7, keys.VIRIAL in weights)
     data = dict(dev)
     result = model(data, keys.FORCES in weights, keys.VIRIAL in weights)
