@@ -42,6 +42,10 @@ enum {
 
 int xeq_version(void);
 const char* xeq_last_error(void);
+/* Kernel launches this library has enqueued so far in the process (all threads, every entry point, whichever front called it).
+ * Test infrastructure: tests/test_gpu_parity.py::_aten_only proves with it that the ATen-only evaluation of the reference's op
+ * sequence -- a member of the fp32 error envelope -- launched no kernel of this library. */
+int64_t xeq_launch_count(void);
 
 /* ------------------------------------------------------------------ graph */
 

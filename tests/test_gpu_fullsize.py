@@ -8,7 +8,7 @@ than the reference's own arithmetic at the reference's own precision).  Molecule
 molecule's oracle result does not depend on which other molecules the oracle sees.
 
 Every comparison appends its achieved maxima to PARITY; tests/conftest.py writes them to
-``gpurun_out/parity_r04.json`` at the end of the session (copied to ``profiles/``).
+``gpurun_out/parity_r05.json`` at the end of the session (copied to ``profiles/``).
 """
 import numpy as np
 import pytest
@@ -57,12 +57,12 @@ def _oracle_subset(oracle, pos, z, ptr, mols):
 
 def _compare(name, E, F, Eref, Fref, extra, oracle, ref_in):
     dE, dF = np.abs(E - Eref), np.abs(F - Fref)
-    b_max, b_p99, e32_max, e32_p99 = f32_force_bounds(oracle, ref_in, Fref)
+    bounds = f32_force_bounds(oracle, ref_in, Fref)
+    b_max, b_p99, e32_max, e32_p99 = bounds
     rec = dict(config=name, max_abs_dE=float(dE.max()), max_dE_over_bound=float((dE / (E_RTOL * np.abs(Eref) + E_ATOL)).max()),
                max_abs_dF=float(dF.max()), max_abs_F=float(np.abs(Fref).max()), max_abs_E=float(np.abs(Eref).max()),
                p99_abs_dF=float(np.quantile(dF, 0.99)), p999_abs_dF=float(np.quantile(dF, 0.999)),
-               bound_dE=f"{E_RTOL}*|E|+{E_ATOL}", bound_dF_max=b_max, bound_dF_p99=b_p99,
-               oracle32_max_abs_dF=e32_max, oracle32_p99_abs_dF=e32_p99,
+               bound_dE=f"{E_RTOL}*|E|+{E_ATOL}", **bounds.record(),
                dtype="f32 HIP vs f64 oracle", **extra)
     parity_record.add(rec)
     assert np.all(dE <= E_RTOL * np.abs(Eref) + E_ATOL), rec
@@ -361,15 +361,51 @@ def test_qm9_1024_with_the_reference_initialisation():
     mols = np.sort(np.random.default_rng(11).choice(len(ptr) - 1, size=N_SAMPLE, replace=False))
     idx, Eref, Fref, _, ref_in = _oracle_subset(oracle, pos, z, ptr, mols)
     dE, dF = np.abs(E[mols] - Eref), np.abs(F[idx] - Fref)
-    b_max, _, e32_max, e32_p99 = f32_force_bounds(oracle, ref_in, Fref)
+    bounds = f32_force_bounds(oracle, ref_in, Fref)
+    b_max = bounds[0]
     parity_record.add(dict(config="qm9_1024, reference initialisation", max_abs_dE=float(dE.max()), max_abs_dF=float(dF.max()),
                            p99_abs_dF=float(np.quantile(dF, 0.99)), p999_abs_dF=float(np.quantile(dF, 0.999)), rms_dF=float(np.sqrt((dF ** 2).mean())),
-                           max_abs_F=float(np.abs(Fref).max()), bound_dF_p999=F32_PLAIN_FORCE_TOL, bound_dF_max=b_max,
-                           oracle32_max_abs_dF=e32_max, oracle32_p99_abs_dF=e32_p99, compared_graphs=int(len(mols)),
+                           max_abs_F=float(np.abs(Fref).max()), bound_dF_p999=F32_PLAIN_FORCE_TOL, **bounds.record(), compared_graphs=int(len(mols)),
                            compared_atoms=int(len(idx)), dtype="f32 HIP vs f64 oracle"))
     assert np.all(dE <= E_RTOL * np.abs(Eref) + E_ATOL)
     assert np.quantile(dF, 0.999) <= F32_PLAIN_FORCE_TOL, float(np.quantile(dF, 0.999))
     assert dF.max() <= b_max, (float(dF.max()), b_max)
+
+
+def test_qm9_1024_well_conditioned_model_meets_the_plain_tolerance():
+    """BASELINE.md section 2's plain figure, max |dF| <= 1e-4 in fp32, with NO envelope, at full size.
+
+    The fp32 tail of the other checks sits at one spot of the reference's function (profiles/r04_fp32_tail.txt): ``Invariant``'s
+    sqrt(sum_m V^2 + eps^2) - eps with eps = 1e-5 (nn/o3layer.py:39-44) on the 0e channels of V = update_V(xhat) (nn/xpainn.py:213-216),
+    where V is a SCALAR that crosses zero: among 128 channels x 18 609 atoms x 3 blocks a few hundred land within 1e-4 of zero, and
+    there the derivative V / sqrt(V^2 + eps^2) is decided by the low bits of V in any fp32 evaluation.  This model has the same
+    architecture and random weights everywhere else, but the 0e block of every ``update_V`` is bounded away from zero BY CONSTRUCTION
+    (weights scaled by 0.02, biases of magnitude 1 .. 1.5 with random signs: |V_0e| >= ~0.8), so the function itself is well
+    conditioned and the stated tolerance is a property of the implementation: asserted on every force component of the compared
+    molecules."""
+    model, oracle = _build(torch.float32)
+    g = torch.Generator().manual_seed(5)
+    sd = model.state_dict()
+    for name in sd:
+        if name.endswith("update_V.weight"):
+            sd[name][: 128 * 128] *= 0.02                        # flat o3.Linear weight: the l = 0 block comes first (SURVEY A8)
+        elif name.endswith("update_V.bias"):
+            sign = torch.where(torch.rand(128, generator=g) < 0.5, -1.0, 1.0)
+            sd[name].copy_((sign * (1.0 + 0.5 * torch.rand(128, generator=g))).to(sd[name]))
+    model.load_state_dict(sd)
+    oracle = orc.XPaiNNOracle({k: v.detach().double().cpu().clone() for k, v in model.state_dict().items()})
+    pos, z, ptr, _ = syn.make_workload("qm9_1024", seed=1234)
+    E, F, n_edges, _ = _hip_eval(model, pos, z, ptr)
+    assert n_edges == 311994
+    mols = np.sort(np.random.default_rng(13).choice(len(ptr) - 1, size=N_SAMPLE, replace=False))
+    idx, Eref, Fref, _, ref_in = _oracle_subset(oracle, pos, z, ptr, mols)
+    dE, dF = np.abs(E[mols] - Eref), np.abs(F[idx] - Fref)
+    parity_record.add(dict(config="qm9_1024, well-conditioned model (0e block of update_V bounded away from 0), plain tolerance", max_abs_dE=float(dE.max()),
+                           max_abs_dF=float(dF.max()), p99_abs_dF=float(np.quantile(dF, 0.99)), rms_dF=float(np.sqrt((dF ** 2).mean())),
+                           max_abs_F=float(np.abs(Fref).max()), bound_dF_max=F32_PLAIN_FORCE_TOL, compared_graphs=int(len(mols)),
+                           compared_atoms=int(len(idx)), dtype="f32 HIP vs f64 oracle, no envelope"))
+    assert np.all(dE <= E_RTOL * np.abs(Eref) + E_ATOL)
+    assert dF.max() <= F32_PLAIN_FORCE_TOL, float(dF.max())
 
 
 @pytest.mark.parametrize("name,repeats", [("qm9_1024", 5), ("md17_4096", 3)])

@@ -414,3 +414,22 @@ def test_linear_operator_is_differentiable_to_second_order_on_the_host():
     assert gradcheck(torch.ops.xeq.linear, (x, W, b)) and gradgradcheck(torch.ops.xeq.linear, (x, W, b))
     assert gradcheck(lambda a, c: torch.ops.xeq.linear(a, c, None), (x, W)) and gradgradcheck(lambda a, c: torch.ops.xeq.linear(a, c, None), (x, W))
     assert torch.allclose(torch.ops.xeq.linear(x, W, b), torch.nn.functional.linear(x, W, b), rtol=0, atol=1e-14)
+
+
+def test_matrix_core_objects_hold_no_packed_fp32_instructions():
+    """Every object with v_mfma in it is built with -packed-fp32-ops off (csrc/build.py: MFMA_SOURCES; the sporadic wrong rows of
+    round 4, profiles/r04_nodeblock.txt item 9c): the disassembly of the built objects holds no v_pk_{fma,add,mul}_f32 there, and
+    no object outside that list holds a matrix-core instruction."""
+    from xequinet_amd.csrc import build
+
+    build.build(verbose=False)
+    build.check_no_packed()
+    for src in build.MFMA_SOURCES:
+        pk, mfma = build.packed_fp32_counts(src)
+        assert pk == 0 and mfma > 0, (src, pk, mfma)
+
+
+def test_launch_counter_is_exported_and_starts_without_a_gpu():
+    from xequinet_amd import lib
+
+    assert lib.launch_count() >= 0

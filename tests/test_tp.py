@@ -214,3 +214,19 @@ def test_all_paths_in_one_launch_equal_one_launch_per_path(which):
     assert mod._fused_table("fwd", x) is not None
     for name, a, b in zip(("out", "grad_x1", "grad_x2", "grad_w"), got[True], got[False]):
         assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(b.abs().max())), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["selfmix", "head"])
+def test_zero_rows_give_zero_weight_gradients(which):
+    """n == 0 (an empty shard): the fused weight-gradient entry returns without writing; shared weights get exact zeros,
+    per-sample weights an empty gradient of their own shape (uninitialised memory / a shape error before)."""
+    mod = _reference_products(70)[0 if which == "selfmix" else 1].double().cuda()
+    x = torch.zeros(0, mod.irreps_in1.dim, dtype=torch.float64, device="cuda", requires_grad=True)
+    y = torch.zeros(0, mod.irreps_in2.dim, dtype=torch.float64, device="cuda", requires_grad=True)
+    w = None if mod.internal_weights else torch.zeros(0, mod.weight_numel, dtype=torch.float64, device="cuda", requires_grad=True)
+    o = mod(x, y) if w is None else mod(x, y, w)
+    gw, = torch.autograd.grad(o.sum(), [w] if w is not None else [mod.weight], allow_unused=True)
+    want = w if w is not None else mod.weight
+    assert gw is None or (gw.shape == want.shape and float(gw.abs().sum()) == 0.0)
+

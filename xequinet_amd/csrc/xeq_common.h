@@ -14,6 +14,7 @@
 namespace xeq {
 
 void set_error(const char* fmt, ...);
+void note_launch();   // counts kernel launches of this library (xeq_launch_count: lets a test prove that a code path launched none)
 
 #define XEQ_CHECK_ARG(cond, ...)        \
   do {                                  \
@@ -25,6 +26,7 @@ void set_error(const char* fmt, ...);
 
 #define XEQ_CHECK_LAUNCH(name)                                                   \
   do {                                                                           \
+    xeq::note_launch();                                                          \
     hipError_t e_ = hipGetLastError();                                           \
     if (e_ != hipSuccess) {                                                      \
       xeq::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <cmath>
 
 #include <hipcub/hipcub.hpp>
@@ -17,6 +18,9 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+static std::atomic<int64_t> g_launches{0};
+void note_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 
 // ---------------------------------------------------------------- CSR helpers
 __global__ void k_csr_rowptr(const int64_t* __restrict__ keys, int64_t n_keys, int64_t n_rows,
@@ -714,6 +718,7 @@ extern "C" {
 
 int xeq_version(void) { return 100; }
 const char* xeq_last_error(void) { return xeq::g_err; }
+int64_t xeq_launch_count(void) { return xeq::g_launches.load(std::memory_order_relaxed); }
 
 int xeq_csr_rowptr(const int64_t* keys, int64_t n_keys, int64_t n_rows, int32_t* rowptr, void* stream) {
   XEQ_CHECK_ARG(n_keys >= 0 && n_rows >= 0 && n_keys < (1ll << 31), "xeq_csr_rowptr: bad sizes");

@@ -30,6 +30,7 @@ _I3 = ctypes.POINTER(c_int32)
 
 # name -> argtypes, exactly the prototypes of include/xeq.h
 _PROTOS = {
+    "xeq_launch_count": [],
     "xeq_csr_rowptr": [_P, c_int64, c_int64, _P, _P],
     "xeq_csr_by_key_workspace": [c_int64, c_int64],
     "xeq_csr_by_key": [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P],
@@ -162,7 +163,7 @@ _PROTOS = {
                            _P, _P, _P],
 }
 # entry points that return a size, not a status
-_RET_I64 = {"xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
+_RET_I64 = {"xeq_launch_count", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
             "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch", "xeq_tensor_product_wgrad_chunks"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
@@ -198,6 +199,11 @@ def pack_epoch() -> int:
 def bump_pack_epoch() -> None:
     """Parameters changed behind autograd's back (a replayed captured optimizer step): every pack cache misses from here on."""
     load().xeq_pack_epoch_bump()
+
+
+def launch_count() -> int:
+    """Kernel launches libxeq_hip.so has enqueued in this process (include/xeq.h: xeq_launch_count)."""
+    return int(load().xeq_launch_count())
 
 
 def call(name: str, *args) -> None:

@@ -160,8 +160,10 @@ def node_block_bwd(saved: dict, s: torch.Tensor, x: torch.Tensor, update, messag
     rows = int(lib.load().xeq_node_block_rows(n))
     gxo = torch.empty((rows, D), **f32) if (tail or g_x_in is not None) else None
     gp, gv, gw = torch.empty((rows, C), **f32), torch.empty((rows, C), **f32), torch.empty((rows, D), **f32)
-    cont = lambda t: None if t is None else t.contiguous()
-    call("xeq_node_block_bwd", n, ptr(cont(g_h)), ptr(cont(g_xhat)), ptr(cont(g_s_in)), ptr(cont(g_x_in)), ptr(saved["s_out"] if tail else None),
+    # contiguous copies stay bound to names until the launch is enqueued: a temporary freed after its pointer was taken could be
+    # handed by the caching allocator to the next copy
+    g_h, g_xhat, g_s_in, g_x_in = (None if t is None else t.contiguous() for t in (g_h, g_xhat, g_s_in, g_x_in))
+    call("xeq_node_block_bwd", n, ptr(g_h), ptr(g_xhat), ptr(g_s_in), ptr(g_x_in), ptr(saved["s_out"] if tail else None),
          ptr(saved["x_out"] if tail else None), ptr(saved.get("stats2")), ptr(saved.get("pre2")),
          ptr(message.norm.weight if tail else None), ptr(message.o3norm.affine_weight if tail else None), ptr(saved["uv"]), ptr(saved["a"]),
          ptr(saved["ip"]), ptr(saved["pre"]), ptr(s), ptr(x), ptr(saved["stats"]), ptr(update.norm.weight), ptr(update.o3norm.affine_weight),

@@ -267,8 +267,9 @@ class GraphedStep:
         self._param_state = None
 
     def overflowed(self) -> bool:
-        """Whether the last step's neighbour list outgrew the edge capacity (reads the device-side count: a synchronisation).  The
-        kernels cut such a list at the capacity -- nothing is written out of bounds -- but its results are those of the cut list."""
+        """Whether the last step's neighbour list outgrew the edge capacity (reads the device-side count: a synchronisation).  Such a
+        list is replaced by an EMPTY one that reports its true count (xeq_rowptr_guard) -- nothing is written out of bounds -- and the
+        step's results are those of the edge-less batch: re-run it on a larger capacity."""
         return bool(self.outputs) and int(self.outputs["n_edges"].item()) > self.n_edges
 
     # -- the step on the static buffers (what is captured)

@@ -135,7 +135,9 @@ class GraphedTrainStep:
         from . import ops
 
         g = self._gs
-        rowptr, self._count = ops.radius_graph_capacity(g.pos, g.ptr, g.cutoff, g.edge_index)   # (cut at the capacity: no walk leaves a buffer)
+        # a list that outgrows the capacity comes back EMPTY with its true count (xeq_rowptr_guard): no walk leaves a buffer, and the
+        # loss of such a replay is multiplied by 0 below, so the wrong forward pass of the edge-less batch feeds no gradient
+        rowptr, self._count = ops.radius_graph_capacity(g.pos, g.ptr, g.cutoff, g.edge_index)
         eg = ops.EdgeGraph(g.edge_index, g.n_atoms, center_sorted=True, ptr=g.ptr, c_rowptr=rowptr, symmetric=True)
         eg.edge_count_on_device = True
         data = {keys.POSITIONS: g.pos.detach(), keys.ATOMIC_NUMBERS: g.z, keys.EDGE_INDEX: g.edge_index, keys.BATCH: g.batch,
@@ -154,6 +156,7 @@ class GraphedTrainStep:
             loss = self.energy_weight * loss + self.forces_weight * (per_atom * self.atom_mask).sum() / (3.0 * self.atom_mask.sum())
         elif self.energy_weight != 1.0:
             loss = self.energy_weight * loss
+        loss = loss * (self._count.reshape(-1)[0] <= g.n_edges).to(loss.dtype)   # device-side: an overflowed replay has zero gradients
         loss.backward()
         self.optimizer.step()
         return loss.detach()
@@ -194,9 +197,14 @@ class GraphedTrainStep:
         # the capture itself ran no kernel; the replay below is the first update
 
     def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, target_energy: torch.Tensor,
-                 batch: Optional[torch.Tensor] = None, target_forces: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """One step on this batch; returns the loss (a device scalar owned by the graph, overwritten by the next call)."""
+                 batch: Optional[torch.Tensor] = None, target_forces: Optional[torch.Tensor] = None, ptr_host=None) -> torch.Tensor:
+        """One step on this batch; returns the loss (a device scalar owned by the graph, overwritten by the next call).
+        ``ptr_host`` (optional, as ``runtime.GraphedStep.__call__``): checks the edge capacity against the batch on the host BEFORE the
+        update.  Without it an overflowing batch is caught on the device: its loss and gradients are exactly zero (the optimizer's
+        moments still decay), and ``overflowed()`` reports it afterwards."""
         g = self._gs
+        if ptr_host is not None and runtime.pair_capacity(ptr_host) > g.n_edges:
+            raise ValueError(f"GraphedTrainStep: the batch may hold {runtime.pair_capacity(ptr_host)} edges, the capacity is {g.n_edges}")
         n_graphs = int(ptr.numel() - 1)
         g._load(pos, atomic_numbers, ptr, batch)
         self.target.zero_()
@@ -220,5 +228,7 @@ class GraphedTrainStep:
         return self.loss
 
     def overflowed(self) -> bool:
-        """Whether the last step's neighbour list outgrew the edge capacity (a synchronisation; the list is cut, never overrun)."""
+        """Whether the last step's neighbour list outgrew the edge capacity (a synchronisation).  Such a list is replaced by an EMPTY
+        one (xeq_rowptr_guard) and the step's loss multiplied by zero: nothing is overrun and no gradient of the wrong forward pass
+        reaches the weights."""
         return self._count is not None and int(self._count.item()) > self._gs.n_edges
