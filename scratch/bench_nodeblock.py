@@ -8,9 +8,9 @@ dev = torch.device("cuda:0")
 upd, msg = _modules(1)
 upd, msg = upd.to(dev), msg.to(dev)
 import sys as _s
-for n in ((18609,) if 'quick' in _s.argv else (18609, 147410, 1536, 4096)):
+for n in ((1536,) if 'small' in _s.argv else (18609,) if 'quick' in _s.argv else (18609, 147410, 1536, 4096)):
     s = torch.randn(n, F, device=dev); x = torch.randn(n, D, device=dev)
-    for tail in ((True,) if 'quick' in _s.argv else (True, False)):
+    for tail in ((True,) if ('quick' in _s.argv or 'small' in _s.argv) else (True, False)):
         for _ in range(3):
             nodeblock.node_block_fwd(s, x, upd, msg if tail else None)
         torch.cuda.synchronize()
