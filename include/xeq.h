@@ -239,6 +239,14 @@ int xeq_segment_sum(int dtype, const void* src, const int64_t* ptr, int64_t n_se
 int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n, int64_t width, void* out,
                     int64_t n_out, void* stream);
 
+/* The model's first message block behind XEmbedding in ONE gather (round 5): there a node's scalar features, the LayerNorm /
+ * scalar_mlp output h and the 0e block of the equivariant norm are functions of the node's ELEMENT alone (nn/xpainn.py:62, 76-81,
+ * 128-139: s = Linear(table[Z]), x = 0), so they are evaluated once per table row (rows_s [Zmax + 1, node_dim], rows_h [., hidden_dim],
+ * rows_x0 [., node_dim]) and gathered by atomic number: s_out [n, node_dim], h_out [n, hidden_dim], xhat_out [n * irreps_dim] in BT
+ * layout with every l > 0 block zero.  z: int32 or int64 atomic numbers.  Replaces three ATen gathers and a fill. */
+int xeq_first_block_front(const void* z, int z_is_int64, int64_t n, const void* rows_s, const void* rows_h, const void* rows_x0,
+                          int node_dim, int hidden_dim, int64_t irreps_dim, void* s_out, void* h_out, void* xhat_out, void* stream);
+
 /* Up to XEQ_COPY_MANY_MAX device-to-device copies in ONE launch: dst[i][0 .. bytes[i]) = src[i][...] (whole aligned 4-byte
  * words, buffers must not overlap).  src / dst / bytes are HOST arrays.  HIP-graph replay (runtime.GraphedModel) refreshes
  * the captured inputs of an evaluation with it -- the per-step tensor hand-over the reference does with `data.to(device)`
@@ -256,6 +264,18 @@ int xeq_linear_fwd(const void* x, int64_t ldx, int64_t n, int k_in, const int32_
                    int has_bias, int act, void* pre, void* y, int64_t ldy, void* stream);
 int xeq_head_dot(const void* hidden, int64_t n, int hidden_dim, const void* w2, const void* b2, void* out, void* stream);
 int xeq_head_bwd_hidden(const void* pre, int64_t n, int hidden_dim, const void* w2, const void* g_atomic, void* g_hidden, void* stream);
+/* The whole energy head of a force evaluation in ONE launch (round 5; nn/output.py:104-128 with the reverse pass of
+ * nn/basic.py:143-159): atomic[n] = <SiLU(W1 s_n + b1), w2> + b2 and, when `jac` is given, the head's reverse pass as a saved row
+ * jac[n, :] = d atomic_n / d s_n = W1^T (w2 . SiLU'(W1 s_n + b1)) -- the output is one number per node, so the reverse pass of
+ * whatever reaches the head is g_s[n, :] = (g_atomic[n] + g_total[batch[n]]) jac[n, :] (xeq_head_bwd; either gradient may be NULL,
+ * strides in elements, 0 = a broadcast scalar; batch NULL: one graph).  w1_packed = xeq_mlp_pack(W1, b1, hidden, node_dim, 0),
+ * w1t_packed = xeq_mlp_pack(W1, NULL, node_dim, hidden, 1).  Widths: multiples of 32, <= 256.  Replaces xeq_linear_fwd + xeq_head_dot
+ * (+ xeq_segment_sum's reverse gather) + xeq_head_bwd_hidden + xeq_linear_fwd of the round-3 head: seven launches -> three. */
+int xeq_head_supported(int dtype, int node_dim, int hidden_dim);   /* 1 / 0, not a status */
+int xeq_head_fwd(const void* s, int64_t lds, int64_t n, int node_dim, int hidden_dim, const void* w1_packed, const void* w1t_packed,
+                 const void* w2, const void* b2, void* atomic, void* jac, void* stream);
+int xeq_head_bwd(const void* jac, int64_t n, int node_dim, const void* g_atomic, int64_t ga_stride, const void* g_total, int64_t gt_stride,
+                 const int64_t* batch, void* g_s, void* stream);
 
 /* Weight gradient of a linear layer for a TRAINING pass (what autograd forms as grad_output^T @ input for nn.Linear, utils/trainer.py:
  * 295-302; the o3.Linear blocks likewise): parts[c][M][K] = sum over the rows of chunk c of a[row, 0..M)^T b[row, 0..K), f32, rows
@@ -549,6 +569,14 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
                        void* grad_xhat, void* parts, int xhat_layout, void* stream);
 int xeq_message_wq_edge_grad(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
                              const int32_t* mirror, const int32_t mul[3], const void* parts, void* grad_vec, void* stream);
+/* The same for the partials of SEVERAL message blocks of one evaluation (all walked on the same plan): parts[0 .. n_sets) are summed
+ * per quantity in that order before the chain rule runs once (it is linear in dL/dd, dL/dY_lm): the three blocks' contributions to
+ * dL/dvec -- which autograd otherwise adds up with elementwise launches behind three edge-gradient launches, nn/basic.py:143-159 over
+ * nn/xpainn.py:140-159 -- in ONE launch.  n_sets <= XEQ_WQ_MAX_PART_SETS; `parts` is a HOST array of device pointers. */
+#define XEQ_WQ_MAX_PART_SETS 8
+int xeq_message_wq_edge_grad_sum(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
+                                 const int32_t* mirror, const int32_t mul[3], int n_sets, const void* const* parts, void* grad_vec,
+                                 void* stream);
 
 /* ------------------------------------------------- node-side fused elementwise stages
  * Internal "BT" layout of equivariant intermediates (xhat_layout = 1 above): block-major over
@@ -644,6 +672,11 @@ void xeq_pack_epoch_bump(void);
  * all zeros (an EMPTY list) when it does not -- a cut list would not be symmetric and the symmetric shortcuts downstream index by the
  * reverse edge (replaces the unguarded row pointer of round 3: a list that outgrew its arrays now leads no kernel past a buffer). */
 int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream);
+/* Degrees -> guarded row pointer in ONE launch (round 5): rowptr[0 .. n] = exclusive prefix sums of deg[0 .. n) with
+ * xeq_rowptr_guard's rule (a list beyond `capacity` becomes EMPTY; capacity < 0: no guard), count[0] (optional) = the true total.
+ * One workgroup; n_nodes <= xeq_rowptr_from_degrees_max() (XEQ_ERR_UNSUPPORTED above: xeq_exclusive_scan_i32_ws + xeq_rowptr_guard). */
+int xeq_rowptr_from_degrees(const int32_t* deg, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream);
+int64_t xeq_rowptr_from_degrees_max(void);   /* a size, not a status */
 
 /* ---- the per-node chain between two message aggregations as ONE launch per direction (round 4; csrc/xeq_nodeblock.hip) -------------
  * f32, the default layout (node_dim 128, 128x0e + 64x1o + 32x2e: xeq_node_block_supported).  A wave owns 16 nodes and keeps their

@@ -13,7 +13,7 @@ torch.cuda.synchronize()
 h = lib.load(); h.xeq_node_block_debug_stamps.argtypes = [ctypes.c_void_p]
 buf = np.zeros(1024 * 4 * 24, dtype=np.uint64)
 h.xeq_node_block_debug_stamps(buf.ctypes.data)
-st = buf.reshape(1024, 4, 24)[: (n + 127) // 128].astype(np.int64)
+st = buf.reshape(1024, 4, 24)[: (n + 63) // 64].astype(np.int64)
 names = ["init", "LN+L1c0", "eq stats", "l=0", "l=1", "l=2", "hidden", "a_vv+dx", "scalar", "tailLN+sL1", "eqln2", "hid2", "sL2"]
 d = np.diff(st[:, :, :14], axis=2)
 print("workgroups", st.shape[0], "total cycles median", np.median(st[:, :, 13] - st[:, :, 0]))

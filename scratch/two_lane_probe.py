@@ -57,6 +57,12 @@ a = (t(pos, torch.float32), t(z), t(ptr))
 o = full(*a)
 E0, F0 = o["energy"].clone(), o["forces"].clone()
 print(f"one lane (GraphedStep): {time_it(lambda: full(*a)):.3f} ms   XEQ_NODE_BLOCK_MIN_NODES={os.environ.get('XEQ_NODE_BLOCK_MIN_NODES')}")
+for L in (2, 4):     # one shard of L alone: what a lane costs when nothing runs beside it
+    g0, g1 = xdist.shard_by_edges(ptr, L)[0]
+    p_, zz_, pp_ = xdist.take_shard(pos, z, ptr, g0, g1)
+    st_ = runtime.GraphedStep(model, (len(p_) + 64, g1 - g0, int(runtime.pair_capacity(pp_))))
+    a_ = (t(p_, torch.float32), t(zz_), t(pp_))
+    print(f"shard 1/{L} alone ({len(p_)} atoms): {time_it(lambda: st_(*a_)):.3f} ms")
 for L in [int(x) for x in sys.argv[1:]] or [2, 3]:
     ms, E, F = lanes_run(L)
     print(f"{L} lanes in one graph: {ms:.3f} ms   max |dE| {float((E - E0).abs().max()):.2e}  max |dF| {float((F - F0).abs().max()):.2e}")

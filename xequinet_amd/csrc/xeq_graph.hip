@@ -613,6 +613,25 @@ __global__ void k_sort_segment_plain(const int64_t* __restrict__ tmp_keys, const
   }
 }
 
+// degrees -> guarded row pointer in ONE launch (xeq_rowptr_from_degrees): the scan, the total and the capacity guard of
+// xeq_rowptr_guard by one workgroup
+__global__ void __launch_bounds__(SCAN_WG_THREADS) k_rowptr_from_degrees(const int32_t* __restrict__ deg, int64_t n, int64_t cap,
+                                                                        int32_t* __restrict__ rowptr, int32_t* __restrict__ count) {
+  __shared__ int32_t lds[SCAN_WG_THREADS / 64 + 1];
+  int64_t i0, i1;
+  int32_t base;
+  const int32_t total = wg_scan_bases([&](int64_t i) { return deg[i]; }, n, i0, i1, base, lds);
+  const bool ok = cap < 0 || (int64_t)total <= cap;
+  for (int64_t i = i0; i < i1; ++i) {
+    rowptr[i] = ok ? base : 0;
+    base += deg[i];
+  }
+  if (threadIdx.x == 0) {
+    rowptr[n] = ok ? total : 0;
+    if (count) count[0] = total;
+  }
+}
+
 __global__ void k_rowptr_guard(const int32_t* __restrict__ raw, int64_t n, int32_t cap, int32_t* __restrict__ rowptr, int32_t* __restrict__ count) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
@@ -891,6 +910,21 @@ int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int3
   XEQ_CHECK_LAUNCH("xeq_rowptr_guard");
   return XEQ_OK;
 }
+
+/* rowptr[0 .. n] = exclusive prefix sums of deg[0 .. n) with xeq_rowptr_guard's rule applied (capacity < 0: no guard), count[0]
+ * (optional) = the true total: ONE launch by one workgroup for n <= 65 536 (the scan + guard pair is three); XEQ_ERR_UNSUPPORTED
+ * above, where the caller keeps the grid-wide scan. */
+int xeq_rowptr_from_degrees(const int32_t* deg, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream) {
+  XEQ_CHECK_ARG(deg && rowptr && n_nodes >= 0 && capacity < ((int64_t)1 << 31), "xeq_rowptr_from_degrees: bad arguments");
+  if (n_nodes > SCAN_WG_MAX_ITEMS) {
+    xeq::set_error("xeq_rowptr_from_degrees: %lld nodes (the one-workgroup form takes <= %lld)", (long long)n_nodes, (long long)SCAN_WG_MAX_ITEMS);
+    return XEQ_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(xeq::k_rowptr_from_degrees, dim3(1), dim3(SCAN_WG_THREADS), 0, (hipStream_t)stream, deg, n_nodes, capacity, rowptr, count);
+  XEQ_CHECK_LAUNCH("xeq_rowptr_from_degrees");
+  return XEQ_OK;
+}
+int64_t xeq_rowptr_from_degrees_max(void) { return SCAN_WG_MAX_ITEMS; }
 
 int xeq_pbc_image_counts(int dtype, const void* cell_host, int64_t n_graphs, const int32_t pbc[3], double cutoff, int32_t reps[3]) {
   XEQ_CHECK_ARG(n_graphs >= 1 && cell_host != nullptr && cutoff > 0, "xeq_pbc_image_counts: bad arguments");

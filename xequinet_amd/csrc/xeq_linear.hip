@@ -136,6 +136,140 @@ __global__ void k_head_bwd_hidden(const float* __restrict__ pre, int64_t n, int 
       make_float4(ga * w.x * dsilu(p.x), ga * w.y * dsilu(p.y), ga * w.z * dsilu(p.z), ga * w.w * dsilu(p.w));
 }
 
+// ---- the whole energy head of a force evaluation in one launch (round 5) -------------------------------------------------------------
+// EnergyOut's MLP (nn/output.py:104-118) on 32 rows per workgroup: pre = W1 s + b1 (exact-f32 tiles as k_linear), hidden = SiLU(pre),
+// atomic = <hidden, w2> + b2, and -- because the head's output is ONE number per node -- its whole reverse pass as a saved row
+// J[n, :] = d atomic_n / d s_n = W1^T (w2 . SiLU'(pre)): the reverse pass of a force evaluation (nn/basic.py:143-159) is then
+// g_s[n, :] = g[n] J[n, :] (k_head_bwd).  Replaces k_linear + k_head_dot (forward) and k_head_bwd_hidden + k_linear (reverse).
+// A row's sums run in one fixed order whatever the batch.
+struct HeadArgs {
+  const float* S;       // [n, lds]
+  int64_t lds, n;
+  int F, H;             // node_dim, hidden width (multiples of 32, <= 256)
+  const float* W1p;     // xeq_mlp_pack(W1 [H, F], b1): [H / 32][F / 8 + 1][64][4]
+  const float* W1tp;    // xeq_mlp_pack(W1, transposed): the product g_hidden [., H] x W1 [H, F]: [F / 32][H / 8 + 1][64][4] (no bias)
+  const float* w2;      // [H]
+  const float* b2;      // [1] or NULL
+  float* atomic;        // [n]
+  float* J;             // [n, F] or NULL (energies only)
+};
+
+__global__ void __launch_bounds__(256) k_head_fused(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float head_lds[];
+  const int XLD = a.F + 4, HLD = a.H + 4;
+  float* Xs = head_lds;                   // [32][F + 4] staged rows
+  float* Es = Xs + LIN_ROWS * XLD;        // [32][H + 4] hidden . w2
+  float* Gs = Es + LIN_ROWS * HLD;        // [32][H + 4] w2 . SiLU'(pre)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, kh = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * LIN_ROWS;
+  const int rows_here = (int)min((int64_t)LIN_ROWS, a.n - row0);
+  const int k4 = a.F >> 2;
+  for (int idx = tid; idx < LIN_ROWS * k4; idx += 256) {
+    const int r = idx / k4, c4 = idx - r * k4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows_here) v = *reinterpret_cast<const float4*>(a.S + (row0 + r) * a.lds + 4 * c4);
+    *reinterpret_cast<float4*>(&Xs[r * XLD + 4 * c4]) = v;
+  }
+  __syncthreads();
+  const float one_k0 = kh == 0 ? 1.f : 0.f;
+  {  // hidden layer: output tile t (32 hidden columns) per wave
+    const int G = a.F >> 3, nt = a.H >> 5;
+    const float* xs = &Xs[i * XLD + 4 * kh];
+    for (int t = wave; t < nt; t += 4) {
+      const float4* wp = reinterpret_cast<const float4*>(a.W1p) + (int64_t)t * (G + 1) * 64 + lane;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      float4 w0 = wp[0], w1 = wp[(1 < G ? 1 : G - 1) * 64], w2r = wp[(2 < G ? 2 : G - 1) * 64], w3 = wp[(3 < G ? 3 : G - 1) * 64];
+      for (int q = 0; q < G; ++q) {
+        const float4 wn = wp[(q + 4 < G ? q + 4 : G - 1) * 64];
+        const float4 xv = *reinterpret_cast<const float4*>(xs + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, xv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, xv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, xv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, xv.w, acc, 0, 0, 0);
+        w0 = w1;
+        w1 = w2r;
+        w2r = w3;
+        w3 = wn;
+      }
+      const float bias_a = reinterpret_cast<const float*>(wp + (int64_t)G * 64)[0];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, one_k0, acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = 32 * t + 8 * g + 4 * kh;
+        const float4 wv = *reinterpret_cast<const float4*>(a.w2 + col);
+        float e[4], gh[4];
+        const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = acc[4 * g + c];
+          const float sig = 1.f / (1.f + expf(-x));
+          e[c] = (x * sig) * wq[c];                               // SiLU(pre) w2
+          gh[c] = wq[c] * (sig * (1.f + x * (1.f - sig)));        // w2 SiLU'(pre)  (aten silu_backward's form)
+        }
+        *reinterpret_cast<float4*>(&Es[i * HLD + col]) = make_float4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<float4*>(&Gs[i * HLD + col]) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+      }
+    }
+  }
+  __syncthreads();
+  {  // atomic energies: eight threads per row, columns sub, sub + 8, ... then a butterfly: one fixed order per row
+    const int r = tid >> 3, sub = tid & 7;
+    float acc = 0.f;
+    for (int c = sub; c < a.H; c += 8) acc += Es[r * HLD + c];
+    acc += __shfl_xor(acc, 4, 8);
+    acc += __shfl_xor(acc, 2, 8);
+    acc += __shfl_xor(acc, 1, 8);
+    if (sub == 0 && r < rows_here) a.atomic[row0 + r] = acc + (a.b2 ? a.b2[0] : 0.f);
+  }
+  if (a.J) {  // J = (w2 . SiLU'(pre)) W1: output tile t (32 input columns) per wave, K = H
+    const int G = a.H >> 3, nt = a.F >> 5;
+    const float* gs = &Gs[i * HLD + 4 * kh];
+    for (int t = wave; t < nt; t += 4) {
+      const float4* wp = reinterpret_cast<const float4*>(a.W1tp) + (int64_t)t * (G + 1) * 64 + lane;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      float4 w0 = wp[0], w1 = wp[(1 < G ? 1 : G - 1) * 64], w2r = wp[(2 < G ? 2 : G - 1) * 64], w3 = wp[(3 < G ? 3 : G - 1) * 64];
+      for (int q = 0; q < G; ++q) {
+        const float4 wn = wp[(q + 4 < G ? q + 4 : G - 1) * 64];
+        const float4 xv = *reinterpret_cast<const float4*>(gs + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, xv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, xv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, xv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, xv.w, acc, 0, 0, 0);
+        w0 = w1;
+        w1 = w2r;
+        w2r = w3;
+        w3 = wn;
+      }
+      if (i < rows_here) {
+        const int64_t row = row0 + i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(a.J + row * a.F + 32 * t + 8 * g + 4 * kh) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+      }
+    }
+  }
+}
+
+// reverse of the head for whatever arrives at its two outputs: g_s[n, :] = (g_atomic[n] + g_total[graph(n)]) J[n, :]  (either may be NULL;
+// strides in elements: 0 = one broadcast value, what autograd hands over for the sum of the energies)
+__global__ void k_head_bwd(const float* __restrict__ J, int64_t n, int F, const float* __restrict__ g_atomic, int64_t ga_stride,
+                           const float* __restrict__ g_total, int64_t gt_stride, const int64_t* __restrict__ batch, float* __restrict__ g_s) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4
+  const int f4 = F >> 2;
+  if (t >= n * f4) return;
+  const int64_t node = t / f4;
+  float g = g_atomic ? g_atomic[node * ga_stride] : 0.f;
+  if (g_total) g += g_total[(batch ? batch[node] : 0) * gt_stride];
+  const float4 j = reinterpret_cast<const float4*>(J)[t];
+  reinterpret_cast<float4*>(g_s)[t] = make_float4(g * j.x, g * j.y, g * j.z, g * j.w);
+}
+
 // ---- weight gradients of a training pass: dW[M, K] = A[n, M]^T B[n, K] over the n node rows ----------------------------------------
 // (A = dL/dy rows, B = the layer's input rows: nn.Linear's weight gradient; the o3.Linear blocks likewise on the BT views.)  The
 // reduction runs over the LONG dimension (n = 18 k rows against M, K <= 576; the library takes 60-130 us per product here,
@@ -254,6 +388,34 @@ int xeq_head_bwd_hidden(const void* pre, int64_t n, int hidden_dim, const void* 
   hipLaunchKernelGGL(k_head_bwd_hidden, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)pre, n,
                      hidden_dim, (const float*)w2, (const float*)g_atomic, (float*)g_hidden);
   XEQ_CHECK_LAUNCH("xeq_head_bwd_hidden");
+  return XEQ_OK;
+}
+
+int xeq_head_supported(int dtype, int node_dim, int hidden_dim) {
+  return dtype == XEQ_F32 && xeq_linear_supported(dtype, node_dim, hidden_dim) && xeq_linear_supported(dtype, hidden_dim, node_dim) ? 1 : 0;
+}
+
+int xeq_head_fwd(const void* s, int64_t lds, int64_t n, int node_dim, int hidden_dim, const void* w1_packed, const void* w1t_packed,
+                 const void* w2, const void* b2, void* atomic, void* jac, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && xeq_head_supported(XEQ_F32, node_dim, hidden_dim), "xeq_head_fwd: node_dim %d, hidden %d (multiples of 32, <= 256)", node_dim, hidden_dim);
+  XEQ_CHECK_ARG(s && w1_packed && w2 && atomic && (w1t_packed || !jac) && lds >= node_dim && lds % 4 == 0, "xeq_head_fwd: bad arguments");
+  if (n == 0) return XEQ_OK;
+  HeadArgs a{(const float*)s, lds, n, node_dim, hidden_dim, (const float*)w1_packed, (const float*)w1t_packed, (const float*)w2, (const float*)b2,
+             (float*)atomic, (float*)jac};
+  const size_t shmem = sizeof(float) * (size_t)LIN_ROWS * ((node_dim + 4) + 2 * (hidden_dim + 4));
+  hipLaunchKernelGGL(k_head_fused, dim3((unsigned)((n + LIN_ROWS - 1) / LIN_ROWS)), dim3(256), shmem, (hipStream_t)stream, a);
+  XEQ_CHECK_LAUNCH("xeq_head_fwd");
+  return XEQ_OK;
+}
+
+int xeq_head_bwd(const void* jac, int64_t n, int node_dim, const void* g_atomic, int64_t ga_stride, const void* g_total, int64_t gt_stride,
+                 const int64_t* batch, void* g_s, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && node_dim >= 4 && node_dim % 4 == 0 && jac && g_s && (g_atomic || g_total), "xeq_head_bwd: bad arguments");
+  if (n == 0) return XEQ_OK;
+  const int64_t total = n * (node_dim / 4);
+  hipLaunchKernelGGL(k_head_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)jac, n, node_dim,
+                     (const float*)g_atomic, ga_stride, (const float*)g_total, gt_stride, batch, (float*)g_s);
+  XEQ_CHECK_LAUNCH("xeq_head_bwd");
   return XEQ_OK;
 }
 

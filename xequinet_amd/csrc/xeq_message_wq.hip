@@ -91,6 +91,20 @@ struct QuadCount {
     return deg > 0 ? (deg + 3) >> 2 : 1;
   }
 };
+#ifndef XEQ_WQ_PART_BWD
+// qptr[0 .. n] = exclusive prefix sums of the quads per node, by one workgroup (xeq_common.h: wg_scan_bases)
+__global__ void __launch_bounds__(SCAN_WG_THREADS) k_wq_quad_scan(const QuadCount op, int32_t* __restrict__ qptr) {
+  __shared__ int32_t lds[SCAN_WG_THREADS / 64 + 1];
+  int64_t i0, i1;
+  int32_t base;
+  const int32_t total = wg_scan_bases(op, op.n, i0, i1, base, lds);
+  for (int64_t i = i0; i < i1; ++i) {
+    qptr[i] = base;
+    base += op(i);
+  }
+  if (threadIdx.x == 0) qptr[op.n] = total;
+}
+#endif
 
 // one thread per slot of the walk order: its padded position, the pads behind a segment's last slot, the quad records
 __global__ void k_wq_fill(int64_t E, int64_t n_nodes, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
@@ -1404,6 +1418,44 @@ __global__ void k_wq_edge_grad(const float* __restrict__ vec, const int32_t* __r
   grad_vec[3 * (int64_t)e + 2] = out[2];
 }
 
+// The same for ALL message blocks of an evaluation at once (round 5): the chain rule A1-A3 is linear in (dL/dd, dL/dY_1, dL/dY_2), so
+// the blocks' partials are added first -- per quantity in the order the parts are listed, then over the units -- and the chain rule
+// runs once: one launch per evaluation instead of one per block plus the sums of their [E, 3] results (three k_wq_edge_grad and two
+// elementwise adds per force evaluation before).
+struct WqPartList {
+  const float* p[XEQ_WQ_MAX_PART_SETS];
+  int n;
+};
+__global__ void k_wq_edge_grad_sum(const float* __restrict__ vec, const int32_t* __restrict__ peid, const int32_t* __restrict__ mirror,
+                                   const int32_t* __restrict__ qptr, int64_t N, int64_t P, int nu, int nu1, int nu2, const WqPartList pl,
+                                   float* __restrict__ grad_vec) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P || p >= 4 * (int64_t)qptr[N]) return;
+  int32_t e = peid[p];
+  if (e < 0) return;
+  if (mirror) e = mirror[e];
+  if (e < 0) return;
+  float gd = 0.f, q1[3] = {0.f, 0.f, 0.f}, q2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < pl.n; ++s) {
+    const float* pd = pl.p[s];
+    const float* y1 = pd + (int64_t)nu * P;
+    const float* y2 = y1 + (int64_t)nu1 * 3 * P;
+    for (int u = 0; u < nu; ++u) gd += pd[(int64_t)u * P + p];
+    for (int u = 0; u < nu1; ++u)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) q1[m] += y1[((int64_t)u * 3 + m) * P + p];
+    for (int u = 0; u < nu2; ++u)
+#pragma unroll
+      for (int m = 0; m < 5; ++m) q2[m] += y2[((int64_t)u * 5 + m) * P + p];
+  }
+  const EdgeGeom<float> g = edge_geom<float>(vec[3 * (int64_t)e], vec[3 * (int64_t)e + 1], vec[3 * (int64_t)e + 2]);
+  float out[3];
+  edge_grad<float>(g, gd, q1, q2, out);
+  grad_vec[3 * (int64_t)e] = out[0];
+  grad_vec[3 * (int64_t)e + 1] = out[1];
+  grad_vec[3 * (int64_t)e + 2] = out[2];
+}
+
 #endif
 static bool wq_supported(int num_basis, int node_dim, const int32_t mul[3]) {
   return num_basis >= 1 && num_basis <= 31 && mul[0] == node_dim && mul[0] > 0 && mul[0] % 32 == 0 && mul[1] >= 0 &&
@@ -1531,12 +1583,17 @@ int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_
   const int64_t need = xeq_message_wq_plan_workspace(n_nodes);
   XEQ_CHECK_ARG(need >= 0 && workspace_bytes >= need, "xeq_message_wq_plan: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
   QuadCount op{rowptr, n_nodes};
-  hipcub::CountingInputIterator<int64_t> cnt(0);
-  hipcub::TransformInputIterator<int32_t, QuadCount, hipcub::CountingInputIterator<int64_t>> it(cnt, op);
-  size_t temp = (size_t)workspace_bytes;
-  if (hipcub::DeviceScan::ExclusiveSum(workspace, temp, it, qptr, (int)(n_nodes + 1), (hipStream_t)stream) != hipSuccess) {
-    xeq::set_error("xeq_message_wq_plan: scan failed");
-    return XEQ_ERR_LAUNCH;
+  if (n_nodes <= SCAN_WG_MAX_ITEMS) {   // one workgroup, one launch (the grid-wide scan is two)
+    hipLaunchKernelGGL(k_wq_quad_scan, dim3(1), dim3(SCAN_WG_THREADS), 0, (hipStream_t)stream, op, qptr);
+    XEQ_CHECK_LAUNCH("xeq_message_wq_plan (quad scan)");
+  } else {
+    hipcub::CountingInputIterator<int64_t> cnt(0);
+    hipcub::TransformInputIterator<int32_t, QuadCount, hipcub::CountingInputIterator<int64_t>> it(cnt, op);
+    size_t temp = (size_t)workspace_bytes;
+    if (hipcub::DeviceScan::ExclusiveSum(workspace, temp, it, qptr, (int)(n_nodes + 1), (hipStream_t)stream) != hipSuccess) {
+      xeq::set_error("xeq_message_wq_plan: scan failed");
+      return XEQ_ERR_LAUNCH;
+    }
   }
   if (n_edges + n_nodes > 0) {
     hipLaunchKernelGGL(k_wq_fill, dim3((unsigned)((n_edges + n_nodes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_edges, n_nodes,
@@ -1673,6 +1730,24 @@ int xeq_message_wq_edge_grad(const void* vec, int64_t n_nodes, int64_t n_edges, 
   hipLaunchKernelGGL(k_wq_edge_grad, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
                      peid, mirror, qptr, n_nodes, P, nunits, nu1, nu2, pd, y1, y2, (float*)grad_vec);
   XEQ_CHECK_LAUNCH("xeq_message_wq_edge_grad");
+  return XEQ_OK;
+}
+
+int xeq_message_wq_edge_grad_sum(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,
+                                 const int32_t* mirror, const int32_t mul[3], int n_sets, const void* const* parts, void* grad_vec,
+                                 void* stream) {
+  XEQ_CHECK_ARG(n_edges >= 0 && mul[0] % 32 == 0 && mul[1] % 32 == 0 && mul[2] % 32 == 0, "xeq_message_wq_edge_grad_sum: bad sizes");
+  XEQ_CHECK_ARG(n_sets >= 1 && n_sets <= XEQ_WQ_MAX_PART_SETS && parts, "xeq_message_wq_edge_grad_sum: 1 .. %d sets of partials", XEQ_WQ_MAX_PART_SETS);
+  if (n_edges == 0) return XEQ_OK;
+  const int64_t P = wq_pcap(n_nodes, n_edges);
+  const int nu1 = mul[1] / 32, nu2 = mul[2] / 32, nunits = mul[0] / 32 + nu1 + nu2;
+  WqPartList pl;
+  pl.n = n_sets;
+  for (int s = 0; s < XEQ_WQ_MAX_PART_SETS; ++s) pl.p[s] = s < n_sets ? (const float*)parts[s] : nullptr;
+  for (int s = 0; s < n_sets; ++s) XEQ_CHECK_ARG(pl.p[s], "xeq_message_wq_edge_grad_sum: parts[%d] is NULL", s);
+  hipLaunchKernelGGL(k_wq_edge_grad_sum, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
+                     peid, mirror, qptr, n_nodes, P, nunits, nu1, nu2, pl, (float*)grad_vec);
+  XEQ_CHECK_LAUNCH("xeq_message_wq_edge_grad_sum");
   return XEQ_OK;
 }
 

@@ -672,8 +672,16 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   // (nn/fused.py::EnergyHead is the Python twin: the same kernels where they take the layer, the library GEMMs elsewhere)
   const LinPack* head_pk = dt == XEQ_F32 && t[0].size(0) % 4 == 0 && t[2].size(0) == 1 ? lin_pack(t[0], t[1]) : nullptr;
   const bool head_native = head_pk != nullptr && head_pk->bwd.defined();
-  Tensor pre_o, atomic;
-  if (head_native) {
+  Tensor pre_o, atomic, jac;
+  // round 5: the head with its whole reverse pass saved as one row per node, in ONE launch (nn/fused.py::EnergyReadout is the twin)
+  const bool head_fused = head_native && s.stride(1) == 1 && s.stride(0) % 4 == 0 && t[1].defined() && t[1].numel() > 0 &&
+                          xeq_head_supported(XEQ_F32, F, (int)t[0].size(0));
+  if (head_fused) {
+    atomic = at::empty({N}, fopt);
+    if (compute_forces || compute_virial) jac = at::empty({N, (int64_t)F}, fopt);
+    XCALL(xeq_head_fwd(s.data_ptr(), s.stride(0), N, F, (int)t[0].size(0), head_pk->fwd.data_ptr(), head_pk->bwd.data_ptr(), t[2].data_ptr(),
+                       t[3].data_ptr(), atomic.data_ptr(), jac.defined() ? jac.data_ptr() : nullptr, st));
+  } else if (head_native) {
     const Tensor hidden = linear_fwd(s, t[0], t[1], 1, nullptr, &pre_o);
     atomic = at::empty({N}, fopt);
     XCALL(xeq_head_dot(hidden.data_ptr(), N, (int)t[0].size(0), t[2].data_ptr(), t[3].data_ptr(), atomic.data_ptr(), st));
@@ -688,7 +696,9 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   if (compute_forces || compute_virial) {
     // ---- explicit reverse pass: dE/ds of the head, then the blocks backwards, then the edge geometry (nn/basic.py:143-199)
     Tensor g_s;   // dE_i/d atomic_i = 1
-    if (head_native) {
+    if (head_fused) {
+      g_s = jac;    // d atomic_i / d s_i, saved by the forward launch
+    } else if (head_native) {
       Tensor g_hidden = at::empty_like(pre_o);
       XCALL(xeq_head_bwd_hidden(pre_o.data_ptr(), N, (int)pre_o.size(1), t[2].data_ptr(), nullptr, g_hidden.data_ptr(), st));
       g_s = linear_bwd(g_hidden, t[0], t[1]);
@@ -697,6 +707,10 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
     }
     Tensor g_x;   // undefined = zero: the head reads the scalars only, the last block's equivariant output has no consumer
     Tensor g_vec_total;
+    // round 5: the wq blocks' partials are added up and the chain rule to dL/dvec runs ONCE behind the last block of the reverse pass
+    // (xeq_message_wq_edge_grad_sum; ops.EdgeGradDeferral is the Python twin, same order: last block first)
+    const bool defer_edge_grad = impl == 0 && hy.blocks <= XEQ_WQ_MAX_PART_SETS;
+    std::vector<Tensor> part_sets;
     if (impl == 0 && !g.mirror) {
       build_wq_plan(g, true, g.rev);
       g.rev.basis = at::empty({g.rev.pcap, xeq_message_wq_record_floats_for(hy.B)}, fopt);
@@ -785,16 +799,31 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                                    w.basis.data_ptr(), w.dbasis.data_ptr(), m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(),
                                    g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B, F, mul, node_grads ? g_h.data_ptr() : nullptr,
                                    node_grads ? g_xhat.data_ptr() : nullptr, parts.data_ptr(), xl_bwd, st));
-          XCALL(xeq_message_wq_edge_grad(vec.data_ptr(), N, E, (const int32_t*)w.qptr.data_ptr(), (const int32_t*)w.peid.data_ptr(),
-                                         g.mirror ? (const int32_t*)g.n_perm.data_ptr() : nullptr, mul, parts.data_ptr(),
-                                         g_vec.data_ptr(), st));
+          if (defer_edge_grad) {
+            part_sets.push_back(parts);
+            if (b == 0) {
+              std::vector<const void*> pp;
+              for (const Tensor& ps : part_sets) pp.push_back(ps.data_ptr());
+              XCALL(xeq_message_wq_edge_grad_sum(vec.data_ptr(), N, E, (const int32_t*)w.qptr.data_ptr(), (const int32_t*)w.peid.data_ptr(),
+                                                 g.mirror ? (const int32_t*)g.n_perm.data_ptr() : nullptr, mul, (int)pp.size(), pp.data(),
+                                                 g_vec.data_ptr(), st));
+            }
+          } else {
+            XCALL(xeq_message_wq_edge_grad(vec.data_ptr(), N, E, (const int32_t*)w.qptr.data_ptr(), (const int32_t*)w.peid.data_ptr(),
+                                           g.mirror ? (const int32_t*)g.n_perm.data_ptr() : nullptr, mul, parts.data_ptr(),
+                                           g_vec.data_ptr(), st));
+          }
         } else {
           XCALL(xeq_message_bwd_sb(dt, N, E, (const int32_t*)g.n_rowptr.data_ptr(), (const int32_t*)g.n_perm.data_ptr(),
                                    (const int64_t*)g.ei.select(0, 0).data_ptr(), g.sb_basis.data_ptr(), g.sb_dbasis.data_ptr(),
                                    m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(), g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
                                    hy.B, F, mul, g_h.data_ptr(), g_xhat.data_ptr(), g_vec.data_ptr(), 1, st));
         }
-        g_vec_total = g_vec_total.defined() ? g_vec_total + g_vec : g_vec;
+        if (m.impl == 0 && defer_edge_grad) {
+          if (b == 0) g_vec_total = g_vec;
+        } else {
+          g_vec_total = g_vec_total.defined() ? g_vec_total + g_vec : g_vec;
+        }
         if (b == 0) break;   // the first block's node features (embedding, zeros) do not depend on the positions
         if (nb_ok) {         // the front half of this block is reversed by the node block of update b - 1; g_s, g_x: the residual path
           pend_gh = g_h;

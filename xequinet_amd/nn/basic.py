@@ -69,7 +69,12 @@ def compute_edge_data(
     has_cell = keys.CELL in data
     if compute_forces:
         pos.requires_grad_()
-    strain = torch.zeros((n_graphs, 3, 3), dtype=pos.dtype, device=pos.device)
+    if compute_virial:
+        strain = torch.zeros((n_graphs, 3, 3), dtype=pos.dtype, device=pos.device)
+    else:   # nobody differentiates with respect to it: a cached read-only zero tensor instead of a fill launch per evaluation
+        from .fused import constant_vector
+
+        strain = constant_vector(n_graphs * 9, 0.0, pos.dtype, pos.device).view(n_graphs, 3, 3)
     if compute_virial:
         # nn/basic.py:99-107 scales positions and cell by (1 + sym(strain)); every edge vector then scales the same
         # way, so the strain enters the edge-vector op (values at strain = 0 unchanged, gradient in its backward)
@@ -88,33 +93,41 @@ def compute_edge_data(
     return data
 
 
-def compute_forces_only(energy: torch.Tensor, pos: torch.Tensor, training: bool = True) -> torch.Tensor:
-    """nn/basic.py:143-159"""
-    grad_outputs: Optional[List[Optional[torch.Tensor]]] = [torch.ones_like(energy)]
-    with ops.geometry_only_backward(energy):     # this reverse pass is asked for dE/dpos alone (ops.DiffMessage skips its parameter gradients)
-        pos_grad = torch.autograd.grad(outputs=[energy], inputs=[pos], grad_outputs=grad_outputs, retain_graph=training,
-                                       create_graph=training, allow_unused=True)[0]
-    if pos_grad is None:
-        pos_grad = torch.zeros_like(pos)
-    return -1.0 * pos_grad
+def _seed(energy: torch.Tensor, training: bool):
+    """(grad_outputs, sign) of a force / virial evaluation.  The reference seeds the reverse pass with ones and negates the result
+    (nn/basic.py:150-159).  Outside a training pass the seed is MINUS ones -- a cached constant, no fill launch -- and the reverse pass,
+    linear in its seed, returns -dE/dx with the very bits of the negated +1 result (IEEE rounding is symmetric in the sign): one fill
+    and one negation launch less per evaluation.  A training pass (create_graph) keeps the reference's form."""
+    if training or not energy.is_cuda or energy.dim() != 1:
+        return [torch.ones_like(energy)], -1.0
+    from .fused import constant_vector
+
+    return [constant_vector(energy.shape[0], -1.0, energy.dtype, energy.device)], None
 
 
 def _grad(energy, inputs, training):
-    with ops.geometry_only_backward(energy):
-        grads = torch.autograd.grad(outputs=[energy], inputs=inputs, grad_outputs=[torch.ones_like(energy)], retain_graph=training,
+    seed, sign = _seed(energy, training)
+    with ops.geometry_only_backward(energy):     # this reverse pass is asked for dE/dpos alone (ops.DiffMessage skips its parameter gradients)
+        grads = torch.autograd.grad(outputs=[energy], inputs=inputs, grad_outputs=seed, retain_graph=training,
                                     create_graph=training, allow_unused=True)
-    return [torch.zeros_like(x) if g is None else g for g, x in zip(grads, inputs)]
+    grads = [torch.zeros_like(x) if g is None else g for g, x in zip(grads, inputs)]
+    return grads if sign is None else [sign * g for g in grads]
+
+
+def compute_forces_only(energy: torch.Tensor, pos: torch.Tensor, training: bool = True) -> torch.Tensor:
+    """nn/basic.py:143-159"""
+    return _grad(energy, [pos], training)[0]
 
 
 def compute_virial_only(energy: torch.Tensor, strain: torch.Tensor, training: bool = True) -> torch.Tensor:
     """nn/basic.py:162-178"""
-    return -1.0 * _grad(energy, [strain], training)[0]
+    return _grad(energy, [strain], training)[0]
 
 
 def compute_forces_and_virial(energy: torch.Tensor, pos: torch.Tensor, strain: torch.Tensor, training: bool = True):
     """nn/basic.py:181-199"""
-    pos_grad, strain_grad = _grad(energy, [pos, strain], training)
-    return -1.0 * pos_grad, -1.0 * strain_grad
+    forces, virial = _grad(energy, [pos, strain], training)
+    return forces, virial
 
 
 def compute_properties(

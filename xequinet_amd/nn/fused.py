@@ -304,6 +304,72 @@ class EnergyHead(Function):
         return (g_s, None, *_wgrad(g_pre, s, with_bias=True), torch.mv(hidden.t(), g_out).view(1, -1), g_out.sum().view(1))
 
 
+_SEEDS = {}
+
+
+def constant_vector(n: int, value: float, dtype, device) -> torch.Tensor:
+    """A read-only [n] tensor of one value, cached per (n, value, dtype, device): the seed of a force evaluation's reverse pass
+    (nn/basic.py:150: ``grad_outputs = [ones_like(energy)]``) without a fill launch per evaluation.  Not cached while a HIP graph is being
+    captured (the tensor would live in that graph's pool); the warm-up steps in front of a capture fill the cache."""
+    key = (int(n), float(value), dtype, str(device))
+    t = _SEEDS.get(key)
+    if t is None:
+        t = torch.full((int(n),), float(value), dtype=dtype, device=device)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if len(_SEEDS) > 256:
+                _SEEDS.clear()
+            _SEEDS[key] = t
+    return t
+
+
+class EnergyReadout(Function):
+    """EnergyOut.forward of an evaluation that wants no parameter gradients (nn/output.py:104-128): (atomic energies [n], total energies
+    [G]) in two launches -- the head's MLP with its whole reverse pass saved as a row per node (xeq_head_fwd) and the per-graph sum
+    (xeq_segment_sum) -- and its reverse pass in one (xeq_head_bwd: g_s[n] = (g_atomic[n] + g_total[graph(n)]) J[n]).  Round 3's head took
+    seven launches per force evaluation."""
+
+    @staticmethod
+    def supported(seq: torch.nn.Sequential, s: torch.Tensor) -> bool:
+        lin1, act, lin2 = seq[0], seq[1], seq[2]
+        return (isinstance(act, torch.nn.SiLU) and s.is_cuda and s.dtype == torch.float32 and lin1.bias is not None and lin2.weight.shape[0] == 1
+                and bool(lib.load().xeq_head_supported(lib.XEQ_F32, lin1.weight.shape[1], lin1.weight.shape[0])))
+
+    @staticmethod
+    def forward(ctx, s, seq, batch, ptr_):
+        lin1, lin2 = seq[0], seq[2]
+        s = s.contiguous()
+        n, F = s.shape
+        H = lin1.weight.shape[0]
+        want_bwd = ctx.needs_input_grad[0]
+        atomic = torch.empty(n, dtype=s.dtype, device=s.device)
+        jac = torch.empty((n, F), dtype=s.dtype, device=s.device) if want_bwd else None
+        w2 = lin2.weight.detach().reshape(-1).contiguous()
+        call("xeq_head_fwd", ptr(s), s.stride(0), n, F, H, ptr(_linear_pack(lin1, lin1.weight, lin1.bias, False)),
+             ptr(_linear_pack(lin1, lin1.weight, None, True) if want_bwd else None), ptr(w2), ptr(lin2.bias), ptr(atomic), ptr(jac), stream())
+        ptr64 = ptr_.to(torch.int64).contiguous()
+        total = torch.empty(ptr64.numel() - 1, dtype=s.dtype, device=s.device)
+        call("xeq_segment_sum", dtype_code(s), ptr(atomic), ptr(ptr64), ptr64.numel() - 1, 1, ptr(total), stream())
+        ctx.save_for_backward(*((jac, batch) if want_bwd else ()))
+        ctx.set_materialize_grads(False)
+        return atomic, total
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_atomic, g_total):
+        if not ctx.saved_tensors or (g_atomic is None and g_total is None):
+            return None, None, None, None
+        jac, batch = ctx.saved_tensors
+        n, F = jac.shape
+        if g_atomic is not None and g_atomic.stride(0) not in (0, 1):
+            g_atomic = g_atomic.contiguous()
+        if g_total is not None and g_total.stride(0) not in (0, 1):
+            g_total = g_total.contiguous()
+        g_s = torch.empty_like(jac)
+        call("xeq_head_bwd", ptr(jac), n, F, ptr(g_atomic), 0 if g_atomic is None else g_atomic.stride(0), ptr(g_total),
+             0 if g_total is None else g_total.stride(0), ptr(batch), ptr(g_s), stream())
+        return g_s, None, None, None
+
+
 class EmbeddingLinear(Function):
     """Table rows of the atomic numbers through Linear(embed_dim, node_dim) (nn/xpainn.py:62) as XEmbedding._embed launches it, with
     the Linear's parameter gradients for a training pass (the table is a buffer, the atomic numbers are integers)."""
@@ -325,14 +391,14 @@ class EmbeddingLinear(Function):
 
 
 def first_block_front(module, z: torch.Tensor, rows: torch.Tensor, n: int):
-    """(h, xhat) of the model's FIRST message block from the element table: behind XEmbedding s = rows[Z] and x = 0, so LayerNorm,
+    """(s, h, xhat) of the model's FIRST message block from the element table: behind XEmbedding s = rows[Z] and x = 0, so LayerNorm,
     EquivariantLayerNorm and scalar_mlp (nn/xpainn.py:128-139) are functions of the element alone.  They run on the table rows (once per
-    weight version: the same xeq_norm_fwd / xeq_mlp2_fwd launches, which give a row the same bits in any batch) and are gathered by atomic
-    number: two row gathers and one fill per evaluation instead of two node-sized launches.  xhat is in BT layout; its l > 0 blocks are the
-    equivariant norm of zero: zero.  None when the block is not the layout the table form covers."""
+    weight version: the same xeq_norm_fwd / xeq_mlp2_fwd launches, which give a row the same bits in any batch) and all three are
+    gathered by atomic number in ONE launch (xeq_first_block_front; round 4: three ATen gathers and a fill).  xhat is in BT layout; its
+    l > 0 blocks are the equivariant norm of zero: zero.  None when the block is not the layout the table form covers."""
     F, mul = module.node_dim, module._mul
     D = sum(m * (2 * l + 1) for l, m in enumerate(mul))
-    if rows.dtype != torch.float32 or mul[0] != F or isinstance(module.norm, torch.nn.Identity):
+    if rows.dtype != torch.float32 or mul[0] != F or isinstance(module.norm, torch.nn.Identity) or z.dtype not in (torch.int32, torch.int64):
         return None
     mlp = module.scalar_mlp
     key = (rows.data_ptr(), rows._version, module.norm.weight._version, module.norm.bias._version, module.o3norm.affine_weight._version,
@@ -344,12 +410,16 @@ def first_block_front(module, z: torch.Tensor, rows: torch.Tensor, n: int):
             zt = rows.shape[0]
             shat, xhat_t, _, _ = _norm_fwd(rows, torch.zeros((zt, D), dtype=rows.dtype, device=rows.device), module.norm, module.o3norm, F, mul)
             _, h_t = _mlp_fwd(mlp, shat)
-            cache = module._element_front = (key, h_t, xhat_t[: zt * F].view(zt, F).contiguous())
+            cache = module._element_front = (key, h_t.contiguous(), xhat_t[: zt * F].view(zt, F).contiguous())
     _, h_t, xhat0_t = cache
-    h = h_t.index_select(0, z)
-    xhat = torch.zeros(n * D, dtype=rows.dtype, device=rows.device)
-    torch.index_select(xhat0_t, 0, z, out=xhat[: n * F].view(n, F))
-    return h, xhat
+    H = h_t.shape[1]
+    z = z.contiguous()
+    s = torch.empty((n, F), dtype=rows.dtype, device=rows.device)
+    h = torch.empty((n, H), dtype=rows.dtype, device=rows.device)
+    xhat = torch.empty(n * D, dtype=rows.dtype, device=rows.device)
+    call("xeq_first_block_front", ptr(z), int(z.dtype == torch.int64), n, ptr(rows), ptr(h_t), ptr(xhat0_t), F, H, D, ptr(s), ptr(h), ptr(xhat),
+         stream())
+    return s, h, xhat
 
 
 class MessageBlock(Function):
@@ -374,6 +444,7 @@ class MessageBlock(Function):
         ctx.train = len(params) > 0
         ctx.save_for_backward(*[t for t in saved if t is not None], *((shat,) if ctx.train else ()), s, x, stats, pre)
         ctx.module, ctx.do_norm, ctx.graph, ctx.cfg, ctx.impl = module, do_norm, graph, cfg, impl
+        ctx.deferral = ops.register_edge_grad(graph, impl, ctx.needs_input_grad[2])
         return s_out, x_out
 
     @staticmethod
@@ -388,7 +459,7 @@ class MessageBlock(Function):
         msg_saved = tuple(None if is_none else next(it) for is_none in ctx.none_mask)
         node_grads = ctx.train or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         g_h, g_xhat, g_vec, g_s_res, g_x_res = ops.message_backward(msg_saved, ctx.graph, ctx.cfg, ctx.impl, g_s_out, g_x_out,
-                                                                    node_grads=node_grads)
+                                                                    node_grads=node_grads, deferral=ctx.deferral)
         if not node_grads:
             # first block of a force evaluation: its node features are the embedding of the atomic numbers and zeros, neither
             # depends on the positions; only dL/dvec leaves this block (no MLP / norm reverse launches)

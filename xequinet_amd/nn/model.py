@@ -46,6 +46,12 @@ class BaseModel(nn.Module):
             data = training.edge_data(data, compute_forces=compute_forces, compute_virial=compute_virial)
         else:
             data = compute_edge_data(data=data, compute_forces=compute_forces, compute_virial=compute_virial)
+            # one edge-gradient launch for all message blocks of this evaluation (ops.EdgeGradDeferral): a fresh collector per call
+            from .. import keys, ops
+
+            g = data.get(keys.EDGE_GRAPH)
+            if g is not None:
+                g.edge_grad_deferral = ops.EdgeGradDeferral() if (compute_forces or compute_virial) and not native else None
         for mod in self.mods.values():
             data = mod(data)
         result = compute_properties(
@@ -107,6 +113,8 @@ class XPaiNN(BaseModel):
             self.mods[f"update_{i}"] = XPainnUpdate(
                 node_dim=node_dim, node_irreps=node_irreps, activation=activation, layer_norm=layer_norm,
             )
+        if action_blocks > 0:                # the embedding gathers the first message block's front half with the node scalars
+            self.mods["embedding"]._next_message = [self.mods["message_0"]]
         for i in range(action_blocks - 1):   # an update block launches the front half of the message block behind it (nn/fused.py::NodeBlock)
             self.mods[f"update_{i}"]._next_message = [self.mods[f"message_{i + 1}"]]
         if output_modes is None:

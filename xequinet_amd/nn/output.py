@@ -52,8 +52,16 @@ class EnergyOut(OutputModule):
             return training.energy_out(self, data)
         batch = data[keys.BATCH]
         node_scalar = data[keys.NODE_INVARIANT]
-        from .fused import EnergyHead
+        from .fused import EnergyHead, EnergyReadout
 
+        ptr_ = data.get(keys.BATCH_PTR)
+        if (ptr_ is not None and keys.ATOMIC_ENERGIES not in data and not data.get(training.PARAM_GRADS, False)
+                and EnergyReadout.supported(self.out_mlp, node_scalar)):
+            # the head, the per-graph sum and (saved as one row per node) the head's whole reverse pass: two launches (nn/fused.py)
+            atomic_energies, total_energy = EnergyReadout.apply(node_scalar, self.out_mlp, batch.to(torch.int64).contiguous(), ptr_)
+            data[keys.ATOMIC_ENERGIES] = atomic_energies
+            data[keys.TOTAL_ENERGY] = total_energy
+            return data
         if EnergyHead.supported(self.out_mlp, node_scalar):    # matrix-core kernels, explicit reverse pass (nn/fused.py)
             params = EnergyHead.params(self.out_mlp) if data.get(training.PARAM_GRADS, False) else ()
             atom_eng_out = EnergyHead.apply(node_scalar, self.out_mlp, *params)

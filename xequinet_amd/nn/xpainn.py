@@ -34,6 +34,7 @@ ZERO_EQUIVARIANT = "_xeq_zero_equivariant"
 # front half of the message block behind it: (s, x, h, xhat) -- the block's outputs and the next block's scalar_mlp output and
 # normalised equivariant features (BT layout).  The message block consumes it when (s, x) are the tensors it is handed.
 PRESTAGE = "_xeq_message_prestage"
+FIRST_FRONT = "_xeq_first_front"     # (s, h, xhat) of the first message block gathered by XEmbedding.forward in one launch
 ELEMENT_ROWS = "_xeq_element_rows"   # (atomic numbers, embedding of every table row, the gathered node features): see XEmbedding.forward
 
 
@@ -68,6 +69,9 @@ class XEmbedding(nn.Module):
         self.rbf = resolve_rbf(rbf_kernel, num_basis, cutoff)
         self.cutoff_fn = resolve_cutoff(cutoff_fn, cutoff)
         self.materialize_edge_basis = materialize_edge_basis
+        # set by the model: [the message block behind the embedding] (a plain list: not a registered sub-module); its norms and scalar_mlp
+        # are then gathered from the element table together with the node scalars (nn/fused.py::first_block_front)
+        self._next_message = []
 
     def _embed(self, atomic_numbers: torch.Tensor, param_grads: bool = False) -> torch.Tensor:
         """nn/xpainn.py:62: table rows of the atomic numbers through Linear(embed_dim, node_dim) -- one matrix-core launch that
@@ -122,8 +126,18 @@ class XEmbedding(nn.Module):
             # weight version) and gathered by atomic number, here and in the first XPainnMessage (nn/fused.py::first_block_front).
             # The kernels give a row the same bits in any batch, so the results are those of the per-node launches.
             z = atomic_numbers if atomic_numbers.dtype in (torch.int32, torch.int64) else atomic_numbers.long()   # (index_select takes either)
-            node_invariant = rows.index_select(0, z)
-            data[ELEMENT_ROWS] = (z, rows, node_invariant)
+            nxt = self._next_message[0] if self._next_message else None
+            front = None
+            if nxt is not None and nxt.fused and rows.shape[1] == nxt.node_dim and nxt._mul == tuple(self.node_irreps.mul3()):
+                from .fused import first_block_front
+
+                front = first_block_front(nxt, z, rows, z.shape[0])   # s, h, xhat of the first block in ONE gather launch
+            if front is not None:
+                node_invariant = front[0]
+                data[FIRST_FRONT] = front
+            else:
+                node_invariant = rows.index_select(0, z)
+                data[ELEMENT_ROWS] = (z, rows, node_invariant)
         else:
             node_invariant = self._embed(atomic_numbers, bool(data.get(training.PARAM_GRADS, False)))
         data[keys.NODE_INVARIANT] = node_invariant
@@ -144,6 +158,9 @@ class XEmbedding(nn.Module):
             )
         data[keys.NODE_EQUIVARIANT] = node_equivariant
         data[EQUIVARIANT_IS_ZERO] = True
+        front = data.pop(FIRST_FRONT, None)
+        if front is not None:   # the first message block finds its norms and scalar_mlp done (the hand-over an update block uses)
+            data[PRESTAGE] = (node_invariant, node_equivariant, front[1], front[2], ops.lib.XHAT_HIGHER_L_ZERO)
         return data
 
 

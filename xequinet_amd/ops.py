@@ -8,6 +8,7 @@ the blocks in nn/training.py and does not come through these ops).
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -58,8 +59,22 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _SCAN_BYTES = {}
 
 
+_SCAN_ONE_LAUNCH_MAX = None
+
+
+def _scan_one_launch_max() -> int:
+    global _SCAN_ONE_LAUNCH_MAX
+    if _SCAN_ONE_LAUNCH_MAX is None:
+        _SCAN_ONE_LAUNCH_MAX = int(lib.load().xeq_rowptr_from_degrees_max())
+    return _SCAN_ONE_LAUNCH_MAX
+
+
 def _exclusive_scan(deg: torch.Tensor, n: int, rowptr: torch.Tensor) -> None:
-    """rowptr[0..n] = exclusive prefix sum of deg[0..n) (rowptr[n] = total), grid-wide (xeq_exclusive_scan_i32_ws)."""
+    """rowptr[0..n] = exclusive prefix sum of deg[0..n) (rowptr[n] = total): one launch of one workgroup up to 65 536 entries, the
+    grid-wide scan (xeq_exclusive_scan_i32_ws) above."""
+    if n <= _scan_one_launch_max():      # one workgroup, one launch (csrc/xeq_graph.hip: k_rowptr_from_degrees); the library's scan is two
+        call("xeq_rowptr_from_degrees", ptr(deg), n, -1, ptr(rowptr), None, stream())
+        return
     nbytes = _SCAN_BYTES.get(n)
     if nbytes is None:      # a pure function of n: asked once per size (the neighbour lists sit in front of every evaluation)
         nbytes = _SCAN_BYTES[n] = lib.load().xeq_exclusive_scan_i32_workspace(n)
@@ -275,10 +290,13 @@ def radius_graph_capacity(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float, 
     rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     dt = dtype_code(pos)
     call("xeq_radius_graph_count", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(deg), stream())
-    raw = torch.empty(N + 1, dtype=torch.int32, device=dev)
-    _exclusive_scan(deg, N, raw)
     count = torch.empty(1, dtype=torch.int32, device=dev)
-    call("xeq_rowptr_guard", ptr(raw), N, cap, ptr(rowptr), ptr(count), stream())
+    if N <= _scan_one_launch_max():     # scan, total and capacity guard by one workgroup in one launch (three before)
+        call("xeq_rowptr_from_degrees", ptr(deg), N, cap, ptr(rowptr), ptr(count), stream())
+    else:
+        raw = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        _exclusive_scan(deg, N, raw)
+        call("xeq_rowptr_guard", ptr(raw), N, cap, ptr(rowptr), ptr(count), stream())
     call("xeq_radius_graph_fill", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(rowptr), cap, ptr(edge_index), stream())
     return rowptr, count
 
@@ -773,9 +791,43 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
     return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, None, None), impl
 
 
-def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_grads: bool = True):
+class EdgeGradDeferral:
+    """dL/dvec of ALL message blocks of one evaluation in one launch (round 5).  Every wq block of a force evaluation leaves per-unit
+    partials of dL/dd and dL/dY_lm by padded slot; the chain rule to dL/dvec is linear in them, so the blocks' partials are added first
+    and the chain rule runs once (xeq_message_wq_edge_grad_sum) when the LAST block of the reverse pass -- the model's first -- has
+    run: that block returns the total as its dL/dvec, the others return None (autograd's sum then has one term).  Before: three
+    edge-gradient launches and two elementwise adds per evaluation.
+
+    The model creates one per forward call and hangs it on the evaluation's EdgeGraph (nn/model.py); blocks register in their forward
+    when their edge vectors ask for a gradient.  Operator-level callers (no model) have none and keep one launch per block."""
+
+    def __init__(self) -> None:
+        self.registered = 0
+        self.sets = []
+
+    def register(self) -> bool:
+        if self.registered >= lib.WQ_MAX_PART_SETS:
+            return False
+        self.registered += 1
+        return True
+
+    def add(self, parts, vec, graph, plan, mirror: bool, mul):
+        """One block's partials; -> dL/dvec [E, 3] from the last registered block, None from the others."""
+        self.sets.append(parts)
+        if len(self.sets) < self.registered:
+            return None
+        sets, self.sets = self.sets, []          # (a second reverse pass over a retained graph collects afresh)
+        g_vec = torch.empty_like(vec)
+        arr = (ctypes.c_void_p * len(sets))(*[t.data_ptr() for t in sets])
+        call("xeq_message_wq_edge_grad_sum", ptr(vec), graph.n_nodes, graph.n_edges, ptr(plan["qptr"]), ptr(plan["peid"]),
+             ptr(graph.n_perm if mirror else None), mul3(mul), len(sets), arr, ptr(g_vec), stream())
+        return g_vec
+
+
+def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_grads: bool = True, deferral: Optional[EdgeGradDeferral] = None):
     """Reverse pass of the fused message: (grad_h, grad_xhat, grad_vec, grad_s, grad_x).  node_grads=False: only grad_vec is
-    wanted (the first block of a force evaluation); the wq kernel then stores no node gradients and None is returned for them."""
+    wanted (the first block of a force evaluation); the wq kernel then stores no node gradients and None is returned for them.
+    ``deferral`` (wq only): grad_vec is None unless this is the last block the deferral waits for (EdgeGradDeferral)."""
     h, xhat, vec, w_rbf, b_rbf, p0, p1, basis, dbasis = saved
     rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul = cfg[:6]
     xl = int(cfg[6]) if len(cfg) > 6 else 0
@@ -784,7 +836,7 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
     g_x = torch.zeros((graph.n_nodes, D), dtype=h.dtype, device=h.device) if g_x is None else g_x.contiguous()
     skip = impl == "wq" and not node_grads
     g_h, g_xhat = (None, None) if skip else (torch.empty_like(h), torch.empty_like(xhat))
-    g_vec = torch.empty_like(vec)  # written at the edge's own position by every kernel family
+    g_vec = None if (impl == "wq" and deferral is not None) else torch.empty_like(vec)  # written at the edge's own position by every kernel family
     if impl == "wq":
         N, E = graph.n_nodes, graph.n_edges
         mirror = getattr(graph, "mirror_walk", False)      # symmetric list: the forward plan and its records serve both directions
@@ -796,8 +848,11 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
                             ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x),
                             ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl_bwd, stream(),
                             label="xeq_message_bwd_wq_first" if (skip and xl & lib.XHAT_HIGHER_L_ZERO) else None)
-        call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), ptr(graph.n_perm if mirror else None),
-             mul3(mul), ptr(parts), ptr(g_vec), stream())
+        if deferral is not None:
+            g_vec = deferral.add(parts, vec, graph, plan, mirror, mul)
+        else:
+            call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), ptr(graph.n_perm if mirror else None),
+                 mul3(mul), ptr(parts), ptr(g_vec), stream())
     elif impl == "sb":
         KERNEL_TIMER.launch("xeq_message_bwd_sb", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),
                             ptr(graph.n_perm), ptr(graph.edge_index[0]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s),
@@ -854,6 +909,14 @@ def message_param_grad(saved, graph: EdgeGraph, cfg, g_s, g_x):
     return d_w, d_b, d_p0, d_p1
 
 
+def register_edge_grad(graph: EdgeGraph, impl: str, vec_needs_grad: bool) -> Optional[EdgeGradDeferral]:
+    """The evaluation's EdgeGradDeferral for a block that runs the wq kernels and owes a dL/dvec, registered; else None."""
+    d = getattr(graph, "edge_grad_deferral", None)
+    if d is None or impl != "wq" or not vec_needs_grad or not d.register():
+        return None
+    return d
+
+
 class FusedMessage(Function):
     """nn/xpainn.py:140-159 in one kernel; see xeq_message_fwd / xeq_message_bwd."""
 
@@ -864,6 +927,7 @@ class FusedMessage(Function):
         ctx.p_shapes = (p0.shape, None if p1 is None else p1.shape)
         ctx.save_for_backward(*saved)
         ctx.graph, ctx.cfg, ctx.impl = graph, cfg, impl
+        ctx.deferral = register_edge_grad(graph, impl, ctx.needs_input_grad[2])
         return s_out, x_out
 
     @staticmethod
@@ -873,7 +937,8 @@ class FusedMessage(Function):
         # no node input asks for a gradient: the model's first block in a force evaluation (its node features do not depend on the
         # positions, nn/xpainn.py first-block table) -- only dL/dvec is formed
         node_grads = any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
-        g_h, g_xhat, g_vec, g_s, g_x = message_backward(saved, ctx.graph, ctx.cfg, ctx.impl, g_s, g_x, node_grads=node_grads)
+        g_h, g_xhat, g_vec, g_s, g_x = message_backward(saved, ctx.graph, ctx.cfg, ctx.impl, g_s, g_x, node_grads=node_grads,
+                                                        deferral=ctx.deferral)
         d_w = d_b = d_p0 = d_p1 = None
         if any(ctx.needs_input_grad[5:9]):   # first order only: a loss on forces differentiates the reverse pass itself (nn/training.py)
             d_w, d_b, d_p0, d_p1 = message_param_grad(saved, ctx.graph, ctx.cfg, g_s, g_x)
