@@ -293,6 +293,10 @@ int xeq_wgrad(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t n,
 int xeq_load_padded_batch(int dtype, const void* pos, const int32_t* z, const int64_t* ptr, const int64_t* batch, int64_t n,
                           int64_t g, int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out, int32_t* z_out,
                           int64_t* ptr_out, int64_t* batch_out, void* stream);
+/* the same reading int64 atomic numbers (a torch.long tensor as it is: no conversion launch in front of every step) */
+int xeq_load_padded_batch_z64(int dtype, const void* pos, const int64_t* z, const int64_t* ptr, const int64_t* batch, int64_t n, int64_t g,
+                              int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out, int32_t* z_out,
+                              int64_t* ptr_out, int64_t* batch_out, void* stream);
 
 #define XEQ_COPY_MANY_MAX 16
 int xeq_copy_many(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);
@@ -673,9 +677,11 @@ void xeq_pack_epoch_bump(void);
  * reverse edge (replaces the unguarded row pointer of round 3: a list that outgrew its arrays now leads no kernel past a buffer). */
 int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream);
 /* Degrees -> guarded row pointer in ONE launch (round 5): rowptr[0 .. n] = exclusive prefix sums of deg[0 .. n) with
- * xeq_rowptr_guard's rule (a list beyond `capacity` becomes EMPTY; capacity < 0: no guard), count[0] (optional) = the true total.
+ * xeq_rowptr_guard's rule (a list beyond `capacity` becomes EMPTY; capacity < 0: no guard), count[0] (optional) = the true total,
+ * running_total[0] (optional, int64) += the true total: a device-side counter of the edges a replayed step has processed.
  * One workgroup; n_nodes <= xeq_rowptr_from_degrees_max() (XEQ_ERR_UNSUPPORTED above: xeq_exclusive_scan_i32_ws + xeq_rowptr_guard). */
-int xeq_rowptr_from_degrees(const int32_t* deg, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream);
+int xeq_rowptr_from_degrees(const int32_t* deg, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, int64_t* running_total,
+                            void* stream);
 int64_t xeq_rowptr_from_degrees_max(void);   /* a size, not a status */
 
 /* ---- the per-node chain between two message aggregations as ONE launch per direction (round 4; csrc/xeq_nodeblock.hip) -------------

@@ -616,19 +616,17 @@ __global__ void k_sort_segment_plain(const int64_t* __restrict__ tmp_keys, const
 // degrees -> guarded row pointer in ONE launch (xeq_rowptr_from_degrees): the scan, the total and the capacity guard of
 // xeq_rowptr_guard by one workgroup
 __global__ void __launch_bounds__(SCAN_WG_THREADS) k_rowptr_from_degrees(const int32_t* __restrict__ deg, int64_t n, int64_t cap,
-                                                                        int32_t* __restrict__ rowptr, int32_t* __restrict__ count) {
-  __shared__ int32_t lds[SCAN_WG_THREADS / 64 + 1];
-  int64_t i0, i1;
-  int32_t base;
-  const int32_t total = wg_scan_bases([&](int64_t i) { return deg[i]; }, n, i0, i1, base, lds);
+                                                                        int32_t* __restrict__ rowptr, int32_t* __restrict__ count,
+                                                                        int64_t* __restrict__ running_total) {
+  extern __shared__ int32_t scan_lds[];
+  const int32_t total = wg_scan_lds([&](int64_t i) { return deg[i]; }, n, scan_lds);
   const bool ok = cap < 0 || (int64_t)total <= cap;
-  for (int64_t i = i0; i < i1; ++i) {
-    rowptr[i] = ok ? base : 0;
-    base += deg[i];
-  }
+#pragma unroll 4
+  for (int64_t i = threadIdx.x; i < n; i += SCAN_WG_THREADS) rowptr[i] = ok ? scan_lds[i] : 0;
   if (threadIdx.x == 0) {
     rowptr[n] = ok ? total : 0;
     if (count) count[0] = total;
+    if (running_total) running_total[0] += total;   // one thread of one workgroup: a plain read-modify-write
   }
 }
 
@@ -912,15 +910,21 @@ int xeq_rowptr_guard(const int32_t* raw, int64_t n_nodes, int64_t capacity, int3
 }
 
 /* rowptr[0 .. n] = exclusive prefix sums of deg[0 .. n) with xeq_rowptr_guard's rule applied (capacity < 0: no guard), count[0]
- * (optional) = the true total: ONE launch by one workgroup for n <= 65 536 (the scan + guard pair is three); XEQ_ERR_UNSUPPORTED
+ * (optional) = the true total, running_total[0] (optional, int64) += the true total (a benchmark's device-side edge counter, kept
+ * inside the captured step): ONE launch by one workgroup for n <= 36 864 (the scan + guard pair is three); XEQ_ERR_UNSUPPORTED
  * above, where the caller keeps the grid-wide scan. */
-int xeq_rowptr_from_degrees(const int32_t* deg, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, void* stream) {
-  XEQ_CHECK_ARG(deg && rowptr && n_nodes >= 0 && capacity < ((int64_t)1 << 31), "xeq_rowptr_from_degrees: bad arguments");
+int xeq_rowptr_from_degrees(const int32_t* deg, int64_t n_nodes, int64_t capacity, int32_t* rowptr, int32_t* count, int64_t* running_total,
+                            void* stream) {
+  XEQ_CHECK_ARG((deg || n_nodes == 0) && rowptr && n_nodes >= 0 && capacity < ((int64_t)1 << 31), "xeq_rowptr_from_degrees: bad arguments");
   if (n_nodes > SCAN_WG_MAX_ITEMS) {
     xeq::set_error("xeq_rowptr_from_degrees: %lld nodes (the one-workgroup form takes <= %lld)", (long long)n_nodes, (long long)SCAN_WG_MAX_ITEMS);
     return XEQ_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(xeq::k_rowptr_from_degrees, dim3(1), dim3(SCAN_WG_THREADS), 0, (hipStream_t)stream, deg, n_nodes, capacity, rowptr, count);
+  static const bool attr_ok = hipFuncSetAttribute((const void*)xeq::k_rowptr_from_degrees, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)wg_scan_lds_bytes(SCAN_WG_MAX_ITEMS)) == hipSuccess;
+  XEQ_CHECK_ARG(attr_ok, "xeq_rowptr_from_degrees: cannot reserve %zu bytes of LDS", wg_scan_lds_bytes(SCAN_WG_MAX_ITEMS));
+  hipLaunchKernelGGL(xeq::k_rowptr_from_degrees, dim3(1), dim3(SCAN_WG_THREADS), wg_scan_lds_bytes(n_nodes), (hipStream_t)stream, deg, n_nodes,
+                     capacity, rowptr, count, running_total);
   XEQ_CHECK_LAUNCH("xeq_rowptr_from_degrees");
   return XEQ_OK;
 }

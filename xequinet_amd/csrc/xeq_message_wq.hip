@@ -92,16 +92,12 @@ struct QuadCount {
   }
 };
 #ifndef XEQ_WQ_PART_BWD
-// qptr[0 .. n] = exclusive prefix sums of the quads per node, by one workgroup (xeq_common.h: wg_scan_bases)
+// qptr[0 .. n] = exclusive prefix sums of the quads per node, by one workgroup (xeq_common.h: wg_scan_lds)
 __global__ void __launch_bounds__(SCAN_WG_THREADS) k_wq_quad_scan(const QuadCount op, int32_t* __restrict__ qptr) {
-  __shared__ int32_t lds[SCAN_WG_THREADS / 64 + 1];
-  int64_t i0, i1;
-  int32_t base;
-  const int32_t total = wg_scan_bases(op, op.n, i0, i1, base, lds);
-  for (int64_t i = i0; i < i1; ++i) {
-    qptr[i] = base;
-    base += op(i);
-  }
+  extern __shared__ int32_t scan_lds[];
+  const int32_t total = wg_scan_lds(op, op.n, scan_lds);
+#pragma unroll 4
+  for (int64_t i = threadIdx.x; i < op.n; i += SCAN_WG_THREADS) qptr[i] = scan_lds[i];
   if (threadIdx.x == 0) qptr[op.n] = total;
 }
 #endif
@@ -1584,7 +1580,10 @@ int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_
   XEQ_CHECK_ARG(need >= 0 && workspace_bytes >= need, "xeq_message_wq_plan: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
   QuadCount op{rowptr, n_nodes};
   if (n_nodes <= SCAN_WG_MAX_ITEMS) {   // one workgroup, one launch (the grid-wide scan is two)
-    hipLaunchKernelGGL(k_wq_quad_scan, dim3(1), dim3(SCAN_WG_THREADS), 0, (hipStream_t)stream, op, qptr);
+    static const bool attr_ok = hipFuncSetAttribute((const void*)k_wq_quad_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)wg_scan_lds_bytes(SCAN_WG_MAX_ITEMS)) == hipSuccess;
+    XEQ_CHECK_ARG(attr_ok, "xeq_message_wq_plan: cannot reserve LDS for the quad scan");
+    hipLaunchKernelGGL(k_wq_quad_scan, dim3(1), dim3(SCAN_WG_THREADS), wg_scan_lds_bytes(n_nodes), (hipStream_t)stream, op, qptr);
     XEQ_CHECK_LAUNCH("xeq_message_wq_plan (quad scan)");
   } else {
     hipcub::CountingInputIterator<int64_t> cnt(0);

@@ -571,8 +571,8 @@ int xeq_copy_many(int n, const void* const* src, void* const* dst, const int64_t
 
 // ---- a batch into capacity-sized arrays, padded (xeq_load_padded_batch, include/xeq.h) ----
 namespace xeq {
-template <typename T>
-__global__ void k_load_padded_batch(const T* __restrict__ pos, const int32_t* __restrict__ z, const int64_t* __restrict__ ptr,
+template <typename T, typename Z>
+__global__ void k_load_padded_batch(const T* __restrict__ pos, const Z* __restrict__ z, const int64_t* __restrict__ ptr,
                                     const int64_t* __restrict__ batch, int64_t n, int64_t g, int64_t N, int64_t G, T pad0, T spacing,
                                     T* __restrict__ pos_out, int32_t* __restrict__ z_out, int64_t* __restrict__ ptr_out,
                                     int64_t* __restrict__ batch_out) {
@@ -582,25 +582,41 @@ __global__ void k_load_padded_batch(const T* __restrict__ pos, const int32_t* __
     pos_out[3 * i] = real ? pos[3 * i] : pad0 + spacing * (T)(i - n);
     pos_out[3 * i + 1] = real ? pos[3 * i + 1] : T(0);
     pos_out[3 * i + 2] = real ? pos[3 * i + 2] : T(0);
-    z_out[i] = real ? z[i] : 0;
+    z_out[i] = real ? (int32_t)z[i] : 0;
     batch_out[i] = real ? batch[i] : G - 1;
   }
   if (i <= G) ptr_out[i] = i <= g ? ptr[i] : (i < G ? n : N);   // graphs g .. G - 2 are empty, graph G - 1 holds the padding atoms
 }
 }  // namespace xeq
 
-extern "C" int xeq_load_padded_batch(int dtype, const void* pos, const int32_t* z, const int64_t* ptr, const int64_t* batch, int64_t n,
-                                     int64_t g, int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out,
-                                     int32_t* z_out, int64_t* ptr_out, int64_t* batch_out, void* stream) {
+static int load_padded_batch(int dtype, const void* pos, const void* z, int z_is_int64, const int64_t* ptr, const int64_t* batch, int64_t n,
+                             int64_t g, int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out,
+                             int32_t* z_out, int64_t* ptr_out, int64_t* batch_out, void* stream) {
   XEQ_CHECK_ARG(n >= 0 && g >= 0 && n <= n_cap && g < g_cap, "xeq_load_padded_batch: %lld atoms / %lld graphs into a capacity of %lld / %lld (one graph is the padding's)",
                 (long long)n, (long long)g, (long long)n_cap, (long long)(g_cap - 1));
   const int64_t threads = (n_cap > g_cap + 1 ? n_cap : g_cap + 1);
   XEQ_DISPATCH_FLOAT(dtype, {
-    hipLaunchKernelGGL((xeq::k_load_padded_batch<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const T*)pos, z, ptr, batch, n, g, n_cap, g_cap, (T)pad0, (T)spacing, (T*)pos_out, z_out, ptr_out, batch_out);
+    if (z_is_int64)
+      hipLaunchKernelGGL((xeq::k_load_padded_batch<T, int64_t>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)pos, (const int64_t*)z, ptr, batch, n, g, n_cap, g_cap, (T)pad0, (T)spacing, (T*)pos_out, z_out, ptr_out, batch_out);
+    else
+      hipLaunchKernelGGL((xeq::k_load_padded_batch<T, int32_t>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)pos, (const int32_t*)z, ptr, batch, n, g, n_cap, g_cap, (T)pad0, (T)spacing, (T*)pos_out, z_out, ptr_out, batch_out);
   });
   XEQ_CHECK_LAUNCH("xeq_load_padded_batch");
   return XEQ_OK;
+}
+
+extern "C" int xeq_load_padded_batch(int dtype, const void* pos, const int32_t* z, const int64_t* ptr, const int64_t* batch, int64_t n,
+                                     int64_t g, int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out,
+                                     int32_t* z_out, int64_t* ptr_out, int64_t* batch_out, void* stream) {
+  return load_padded_batch(dtype, pos, z, 0, ptr, batch, n, g, n_cap, g_cap, pad0, spacing, pos_out, z_out, ptr_out, batch_out, stream);
+}
+/* the same with int64 atomic numbers (what a torch.long tensor holds): no conversion launch in front of every step */
+extern "C" int xeq_load_padded_batch_z64(int dtype, const void* pos, const int64_t* z, const int64_t* ptr, const int64_t* batch, int64_t n,
+                                         int64_t g, int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out,
+                                         int32_t* z_out, int64_t* ptr_out, int64_t* batch_out, void* stream) {
+  return load_padded_batch(dtype, pos, z, 1, ptr, batch, n, g, n_cap, g_cap, pad0, spacing, pos_out, z_out, ptr_out, batch_out, stream);
 }
 
 // ---- the first message block's front half gathered from the element table (xeq_first_block_front, include/xeq.h) ----

@@ -390,12 +390,14 @@ class EmbeddingLinear(Function):
         return None, None, None, d_w, (d_b if ctx.has_bias else None)
 
 
-def first_block_front(module, z: torch.Tensor, rows: torch.Tensor, n: int):
+def first_block_front(module, z: torch.Tensor, rows: torch.Tensor, n: int, higher_l_unread: bool = False):
     """(s, h, xhat) of the model's FIRST message block from the element table: behind XEmbedding s = rows[Z] and x = 0, so LayerNorm,
     EquivariantLayerNorm and scalar_mlp (nn/xpainn.py:128-139) are functions of the element alone.  They run on the table rows (once per
     weight version: the same xeq_norm_fwd / xeq_mlp2_fwd launches, which give a row the same bits in any batch) and all three are
     gathered by atomic number in ONE launch (xeq_first_block_front; round 4: three ATen gathers and a fill).  xhat is in BT layout; its
-    l > 0 blocks are the equivariant norm of zero: zero.  None when the block is not the layout the table form covers."""
+    l > 0 blocks are the equivariant norm of zero: zero -- and are not even written when the caller knows that nobody reads them
+    (``higher_l_unread``: the wq message kernels under XEQ_XHAT_HIGHER_L_ZERO drop every term with a factor xhat_{l>0}; 27 MB of zeros
+    per QM9-1024 evaluation).  None when the block is not the layout the table form covers."""
     F, mul = module.node_dim, module._mul
     D = sum(m * (2 * l + 1) for l, m in enumerate(mul))
     if rows.dtype != torch.float32 or mul[0] != F or isinstance(module.norm, torch.nn.Identity) or z.dtype not in (torch.int32, torch.int64):
@@ -417,8 +419,8 @@ def first_block_front(module, z: torch.Tensor, rows: torch.Tensor, n: int):
     s = torch.empty((n, F), dtype=rows.dtype, device=rows.device)
     h = torch.empty((n, H), dtype=rows.dtype, device=rows.device)
     xhat = torch.empty(n * D, dtype=rows.dtype, device=rows.device)
-    call("xeq_first_block_front", ptr(z), int(z.dtype == torch.int64), n, ptr(rows), ptr(h_t), ptr(xhat0_t), F, H, D, ptr(s), ptr(h), ptr(xhat),
-         stream())
+    call("xeq_first_block_front", ptr(z), int(z.dtype == torch.int64), n, ptr(rows), ptr(h_t), ptr(xhat0_t), F, H, F if higher_l_unread else D,
+         ptr(s), ptr(h), ptr(xhat), stream())
     return s, h, xhat
 
 

@@ -131,7 +131,11 @@ class XEmbedding(nn.Module):
             if nxt is not None and nxt.fused and rows.shape[1] == nxt.node_dim and nxt._mul == tuple(self.node_irreps.mul3()):
                 from .fused import first_block_front
 
-                front = first_block_front(nxt, z, rows, z.shape[0])   # s, h, xhat of the first block in ONE gather launch
+                # s, h, xhat of the first block in ONE gather launch; the wq kernels never read xhat's l > 0 blocks behind the embedding
+                g = data.get(keys.EDGE_GRAPH)
+                unread = (g is not None and not rows.requires_grad and
+                          ops.select_message_impl(rows.dtype, g.n_nodes, g.n_edges, nxt.num_basis, nxt.node_dim, nxt._mul) == "wq")
+                front = first_block_front(nxt, z, rows, z.shape[0], higher_l_unread=unread)
             if front is not None:
                 node_invariant = front[0]
                 data[FIRST_FRONT] = front

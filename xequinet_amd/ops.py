@@ -70,10 +70,10 @@ def _scan_one_launch_max() -> int:
 
 
 def _exclusive_scan(deg: torch.Tensor, n: int, rowptr: torch.Tensor) -> None:
-    """rowptr[0..n] = exclusive prefix sum of deg[0..n) (rowptr[n] = total): one launch of one workgroup up to 65 536 entries, the
+    """rowptr[0..n] = exclusive prefix sum of deg[0..n) (rowptr[n] = total): one launch of one workgroup up to 36 864 entries, the
     grid-wide scan (xeq_exclusive_scan_i32_ws) above."""
     if n <= _scan_one_launch_max():      # one workgroup, one launch (csrc/xeq_graph.hip: k_rowptr_from_degrees); the library's scan is two
-        call("xeq_rowptr_from_degrees", ptr(deg), n, -1, ptr(rowptr), None, stream())
+        call("xeq_rowptr_from_degrees", ptr(deg), n, -1, ptr(rowptr), None, None, stream())
         return
     nbytes = _SCAN_BYTES.get(n)
     if nbytes is None:      # a pure function of n: asked once per size (the neighbour lists sit in front of every evaluation)
@@ -272,13 +272,14 @@ def radius_graph_raw(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float) -> Tu
     return edge_index, rowptr
 
 
-def radius_graph_capacity(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float, edge_index: torch.Tensor):
+def radius_graph_capacity(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float, edge_index: torch.Tensor, running_total: Optional[torch.Tensor] = None):
     """Non-PBC neighbour list into a caller-owned ``edge_index`` [2, capacity] WITHOUT reading the edge count back: returns
     (row pointer [N + 1], count [1]) on the device.  ``count`` is the true edge count; a list that outgrew the capacity is replaced
     by an EMPTY one (row pointer all zeros: no kernel walks past a buffer, and the symmetric shortcuts downstream never see a cut,
     asymmetric list) -- ``count > capacity`` tells the caller, who reads it next to the results.  Slots behind the count keep their old contents, which must
     be valid node ids (zero-initialise the buffer once).  Every kernel downstream bounds its walk by the row pointer, so the
-    whole evaluation can sit in one captured HIP graph (runtime.GraphedStep).  The pair sweep only (graphs of many atoms go
+    whole evaluation can sit in one captured HIP graph (runtime.GraphedStep).  ``running_total`` (int64 [1], optional) += the true count,
+    inside the same launch.  The pair sweep only (graphs of many atoms go
     through the cell list, whose bin count is a host value)."""
     require_hip(pos, ptr_, edge_index)
     pos = pos.detach().contiguous()
@@ -292,11 +293,13 @@ def radius_graph_capacity(pos: torch.Tensor, ptr_: torch.Tensor, cutoff: float, 
     call("xeq_radius_graph_count", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(deg), stream())
     count = torch.empty(1, dtype=torch.int32, device=dev)
     if N <= _scan_one_launch_max():     # scan, total and capacity guard by one workgroup in one launch (three before)
-        call("xeq_rowptr_from_degrees", ptr(deg), N, cap, ptr(rowptr), ptr(count), stream())
+        call("xeq_rowptr_from_degrees", ptr(deg), N, cap, ptr(rowptr), ptr(count), ptr(running_total), stream())
     else:
         raw = torch.empty(N + 1, dtype=torch.int32, device=dev)
         _exclusive_scan(deg, N, raw)
         call("xeq_rowptr_guard", ptr(raw), N, cap, ptr(rowptr), ptr(count), stream())
+        if running_total is not None:
+            running_total.add_(count)
     call("xeq_radius_graph_fill", dt, ptr(pos), ptr(ptr_), G, N, float(cutoff), ptr(rowptr), cap, ptr(edge_index), stream())
     return rowptr, count
 

@@ -265,6 +265,9 @@ class GraphedStep:
         self.warmup = warmup
         self.captures = 0
         self._param_state = None
+        # edges of every step run so far (true counts), accumulated on the device inside the step's own launches: what a benchmark
+        # reads once behind its timed region (zero it in front)
+        self.edge_total = torch.zeros(1, dtype=torch.int64, device=self.pos.device)
 
     def overflowed(self) -> bool:
         """Whether the last step's neighbour list outgrew the edge capacity (reads the device-side count: a synchronisation).  Such a
@@ -274,7 +277,7 @@ class GraphedStep:
 
     # -- the step on the static buffers (what is captured)
     def _step(self) -> Dict[str, torch.Tensor]:
-        rowptr, count = ops.radius_graph_capacity(self.pos, self.ptr, self.cutoff, self.edge_index)
+        rowptr, count = ops.radius_graph_capacity(self.pos, self.ptr, self.cutoff, self.edge_index, running_total=self.edge_total)
         eg = ops.EdgeGraph(self.edge_index, self.n_atoms, center_sorted=True, ptr=self.ptr, c_rowptr=rowptr, symmetric=True)
         data = {keys.POSITIONS: self.pos.detach(), keys.ATOMIC_NUMBERS: self.z, keys.EDGE_INDEX: self.edge_index, keys.BATCH: self.batch,
                 keys.BATCH_PTR: self.ptr, keys.EDGE_GRAPH: eg}
@@ -296,8 +299,10 @@ class GraphedStep:
             counts = ptr[1:] - ptr[:-1]
             batch = torch.repeat_interleave(torch.arange(g, device=ptr.device), counts, output_size=n)
         pos_c = pos.detach().to(self.pos.dtype).contiguous()
-        z_c, ptr_c, batch_c = atomic_numbers.to(torch.int32).contiguous(), ptr.to(torch.int64).contiguous(), batch.to(torch.int64).contiguous()
-        call("xeq_load_padded_batch", dtype_code(pos_c), p_(pos_c), p_(z_c), p_(ptr_c), p_(batch_c), n, g, self.n_atoms, self.n_graphs,
+        z64 = atomic_numbers.dtype == torch.int64     # (a torch.long tensor is read as it is: no conversion launch per step)
+        z_c = atomic_numbers.contiguous() if z64 else atomic_numbers.to(torch.int32).contiguous()
+        ptr_c, batch_c = ptr.to(torch.int64).contiguous(), batch.to(torch.int64).contiguous()
+        call("xeq_load_padded_batch_z64" if z64 else "xeq_load_padded_batch", dtype_code(pos_c), p_(pos_c), p_(z_c), p_(ptr_c), p_(batch_c), n, g, self.n_atoms, self.n_graphs,
              1.0e4, self.PAD_SPACING, p_(self.pos), p_(self.z), p_(self.ptr), p_(self.batch), stream())
 
     def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor] = None,
