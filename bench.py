@@ -141,6 +141,9 @@ def main():
                     help="round 2's launch mode: the model part as a captured graph per (atoms, edges) signature, the neighbour list "
                          "launched from the host with its edge count read back (default since round 3 for open-boundary workloads: "
                          "neighbour list + model as ONE graph over capacity-sized arrays, runtime.GraphedStep)")
+    ap.add_argument("--lanes", type=int, default=-1, metavar="L",
+                    help="whole-step graph of an open-boundary batch: evaluate the batch as L contiguous molecule ranges in parallel branches of "
+                         "the one captured graph (runtime.GraphedLanes; results bit for bit those of L = 1).  Default: runtime.auto_lanes(atoms)")
     ap.add_argument("--vary-batch", type=int, default=0, metavar="K",
                     help="feed K different draws of the workload in turn (different atom and edge counts every step) through the "
                          "one captured graph")
@@ -214,6 +217,7 @@ def main():
         return batch.edge_index.shape[1], out
 
     n_chunks = 1
+    n_lanes = 1
     if sharded:
         max_edges = args.max_chunk_edges or runtime.WM_MAX_EDGES_PER_CHUNK
         n_chunks = len(xdist.plan_chunks(ptr, max_edges))
@@ -240,14 +244,19 @@ def main():
             b_k = XequiBatch(torch.tensor(p_k, dtype=dtype, device=dev), torch.tensor(z_k, device=dev), torch.tensor(ptr_k, device=dev))
             draws.append((b_k.pos, b_k.atomic_numbers, b_k.ptr, ptr_k, b_k.batch))
         cap = (max(d[0].shape[0] for d in draws) + 64, len(ptr) - 1, max(runtime.pair_capacity(d[3]) for d in draws))
-        gstep = runtime.GraphedStep(model, cap, compute_forces=True)
-        edge_total = gstep.edge_total                  # the step's own device-side counter (added to inside the neighbour-list launch)
+        n_lanes = args.lanes if args.lanes >= 1 else runtime.auto_lanes(cap[0])
+        if n_lanes > 1:
+            gstep = runtime.GraphedLanes(model, cap, lanes=n_lanes, compute_forces=True)
+        else:
+            gstep = runtime.GraphedStep(model, cap, compute_forces=True)
         turn = [0]
 
         def step():
-            p_k, z_k, ptr_k, _, b_k = draws[turn[0] % len(draws)]
+            p_k, z_k, ptr_k, ph_k, b_k = draws[turn[0] % len(draws)]
             turn[0] += 1
-            out = gstep(p_k, z_k, ptr_k, batch=b_k)    # every replay adds its true edge count to edge_total; read once behind the timed region
+            # every replay adds its true edge count to the step's device-side counter (inside the neighbour-list launch); read once
+            # behind the timed region
+            out = gstep(p_k, z_k, ptr_k, b_k, ph_k) if n_lanes > 1 else gstep(p_k, z_k, ptr_k, batch=b_k)
             return None, out
     elif cell is not None and len(ptr) == 2 and not args.replay_model_only:
         # ONE periodic system: search + model as one captured graph over capacity-sized edge arrays (runtime.GraphedStepPBC); the
@@ -280,7 +289,8 @@ def main():
             n_edges, out = step()
         torch.cuda.synchronize()
         if whole_step:
-            n_edges = int(out["n_edges"].item())
+            n_edges = (sum(int(st.outputs["n_edges"].item()) for st in gstep.steps) if (cell is None and n_lanes > 1)
+                       else int(out["n_edges"].item()))
     except RuntimeError as err:      # a failed capture must not cost the measurement: fall back to host launches
         if args.eager:
             raise
@@ -301,7 +311,11 @@ def main():
     xdist.barrier()
     torch.cuda.synchronize()
     if whole_step:
-        edge_total.zero_()
+        if cell is None:
+            for st in (gstep.steps if n_lanes > 1 else [gstep]):
+                st.edge_total.zero_()
+        else:
+            edge_total.zero_()
         turn[0] = 0
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -313,7 +327,7 @@ def main():
     xdist.barrier()
     elapsed = time.perf_counter() - t0
     if whole_step:
-        edges_done = int(edge_total.item())   # the device-side counts of the K timed steps
+        edges_done = int((gstep.edge_total if cell is None else edge_total).item())   # the device-side counts of the K timed steps
         if cell is not None:
             assert not gpbc.overflowed(), "the periodic list outgrew its capacity inside the timed region"
     eager_ms = native_ms = None
@@ -452,7 +466,7 @@ def main():
                        "library_gemm_selection": ("no library GEMM on the f32 path since round 3 (every contraction is an xeq kernel)" if dtype == torch.float32 else
                                                   "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)"),
                        "launch": ("host launch per kernel" if args.eager else
-                                  (f"neighbour list + model as ONE captured HIP graph over capacity-sized arrays, edge count on the device (runtime.GraphedStep; {max(1, args.vary_batch)} different draw(s) of the workload in turn)"
+                                  (f"neighbour list + model as ONE captured HIP graph over capacity-sized arrays, edge count on the device (runtime.{'GraphedLanes: ' + str(n_lanes) + ' contiguous molecule ranges as parallel branches of the graph, results bit for bit those of one range' if n_lanes > 1 else 'GraphedStep'}; {max(1, args.vary_batch)} different draw(s) of the workload in turn)"
                                    if cell is None else "periodic neighbour search + model as ONE captured HIP graph over capacity-sized edge arrays, edge count on the device (runtime.GraphedStepPBC)")
                                   if whole_step else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host"),
                        "ms_per_step_eager": "the same step with every kernel launched from the host through the Python modules, measured on rank 0 right after the timed region",

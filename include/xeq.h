@@ -297,6 +297,11 @@ int xeq_load_padded_batch(int dtype, const void* pos, const int32_t* z, const in
 int xeq_load_padded_batch_z64(int dtype, const void* pos, const int64_t* z, const int64_t* ptr, const int64_t* batch, int64_t n, int64_t g,
                               int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out, int32_t* z_out,
                               int64_t* ptr_out, int64_t* batch_out, void* stream);
+/* a contiguous range of molecules of a larger batch (a shard of it: runtime.GraphedLanes): pos, z, batch point at the range's first
+ * atom, ptr at its first graph; the range is renumbered from zero (ptr values - atom_offset, batch values - graph_offset) */
+int xeq_load_padded_shard(int dtype, const void* pos, const void* z, int z_is_int64, const int64_t* ptr, const int64_t* batch, int64_t n,
+                          int64_t g, int64_t atom_offset, int64_t graph_offset, int64_t n_cap, int64_t g_cap, double pad0, double spacing,
+                          void* pos_out, int32_t* z_out, int64_t* ptr_out, int64_t* batch_out, void* stream);
 
 #define XEQ_COPY_MANY_MAX 16
 int xeq_copy_many(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);

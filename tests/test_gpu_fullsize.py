@@ -422,3 +422,30 @@ def test_full_size_evaluations_repeat_bit_for_bit(name, repeats):
             first = (E, F)
         else:
             assert np.array_equal(E, first[0]) and np.array_equal(F, first[1]), (name, np.abs(F - first[1]).max())
+
+
+def test_two_lanes_in_one_graph_equal_the_unsplit_step_bit_for_bit():
+    """runtime.GraphedLanes: the QM9-1024 batch as two contiguous molecule ranges in parallel branches of one captured graph gives the
+    energies and forces of the one-range step (runtime.GraphedStep) bit for bit, for two different batches through the same capture,
+    and counts the same edges on the device."""
+    from xequinet_amd import runtime
+
+    model, _ = _build(torch.float32)
+    cap = None
+    draws = []
+    for seed in (1234, 77):
+        pos, z, ptr, _ = syn.make_workload("qm9_1024", seed=seed)
+        batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+        draws.append((pos, z, ptr, batch))
+    cap = (max(len(d[0]) for d in draws) + 64, 1024, max(runtime.pair_capacity(d[2]) for d in draws))
+    one = runtime.GraphedStep(model, cap)
+    two = runtime.GraphedLanes(model, cap, lanes=2)
+    for pos, z, ptr, batch in draws:
+        args = (_t(pos, torch.float32), _t(z), _t(ptr), _t(batch))
+        a = one(*args[:3], batch=args[3])
+        Ea, Fa, na = a["energy"].clone(), a["forces"].clone(), int(a["n_edges"])
+        b = two(*args, ptr)
+        assert torch.equal(b["energy"], Ea) and torch.equal(b["forces"], Fa)
+        assert sum(int(st.outputs["n_edges"]) for st in two.steps) == na
+    assert two.captures == 1 and not two.overflowed()
+    assert int(two.edge_total) == int(one.edge_total)

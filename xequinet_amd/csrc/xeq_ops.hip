@@ -575,7 +575,7 @@ template <typename T, typename Z>
 __global__ void k_load_padded_batch(const T* __restrict__ pos, const Z* __restrict__ z, const int64_t* __restrict__ ptr,
                                     const int64_t* __restrict__ batch, int64_t n, int64_t g, int64_t N, int64_t G, T pad0, T spacing,
                                     T* __restrict__ pos_out, int32_t* __restrict__ z_out, int64_t* __restrict__ ptr_out,
-                                    int64_t* __restrict__ batch_out) {
+                                    int64_t* __restrict__ batch_out, int64_t atom0, int64_t graph0) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) {
     const bool real = i < n;
@@ -583,25 +583,27 @@ __global__ void k_load_padded_batch(const T* __restrict__ pos, const Z* __restri
     pos_out[3 * i + 1] = real ? pos[3 * i + 1] : T(0);
     pos_out[3 * i + 2] = real ? pos[3 * i + 2] : T(0);
     z_out[i] = real ? (int32_t)z[i] : 0;
-    batch_out[i] = real ? batch[i] : G - 1;
+    batch_out[i] = real ? batch[i] - graph0 : G - 1;
   }
-  if (i <= G) ptr_out[i] = i <= g ? ptr[i] : (i < G ? n : N);   // graphs g .. G - 2 are empty, graph G - 1 holds the padding atoms
+  if (i <= G) ptr_out[i] = i <= g ? ptr[i] - atom0 : (i < G ? n : N);   // graphs g .. G - 2 are empty, graph G - 1 holds the padding atoms
 }
 }  // namespace xeq
 
 static int load_padded_batch(int dtype, const void* pos, const void* z, int z_is_int64, const int64_t* ptr, const int64_t* batch, int64_t n,
                              int64_t g, int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out,
-                             int32_t* z_out, int64_t* ptr_out, int64_t* batch_out, void* stream) {
+                             int32_t* z_out, int64_t* ptr_out, int64_t* batch_out, void* stream, int64_t atom0 = 0, int64_t graph0 = 0) {
   XEQ_CHECK_ARG(n >= 0 && g >= 0 && n <= n_cap && g < g_cap, "xeq_load_padded_batch: %lld atoms / %lld graphs into a capacity of %lld / %lld (one graph is the padding's)",
                 (long long)n, (long long)g, (long long)n_cap, (long long)(g_cap - 1));
   const int64_t threads = (n_cap > g_cap + 1 ? n_cap : g_cap + 1);
   XEQ_DISPATCH_FLOAT(dtype, {
     if (z_is_int64)
       hipLaunchKernelGGL((xeq::k_load_padded_batch<T, int64_t>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                         (const T*)pos, (const int64_t*)z, ptr, batch, n, g, n_cap, g_cap, (T)pad0, (T)spacing, (T*)pos_out, z_out, ptr_out, batch_out);
+                         (const T*)pos, (const int64_t*)z, ptr, batch, n, g, n_cap, g_cap, (T)pad0, (T)spacing, (T*)pos_out, z_out, ptr_out, batch_out,
+                         atom0, graph0);
     else
       hipLaunchKernelGGL((xeq::k_load_padded_batch<T, int32_t>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                         (const T*)pos, (const int32_t*)z, ptr, batch, n, g, n_cap, g_cap, (T)pad0, (T)spacing, (T*)pos_out, z_out, ptr_out, batch_out);
+                         (const T*)pos, (const int32_t*)z, ptr, batch, n, g, n_cap, g_cap, (T)pad0, (T)spacing, (T*)pos_out, z_out, ptr_out, batch_out,
+                         atom0, graph0);
   });
   XEQ_CHECK_LAUNCH("xeq_load_padded_batch");
   return XEQ_OK;
@@ -663,4 +665,11 @@ extern "C" int xeq_first_block_front(const void* z, int z_is_int64, int64_t n, c
   XEQ_CHECK_LAUNCH("xeq_first_block_front");
   return XEQ_OK;
 }
-
+/* a contiguous range of molecules of a larger batch (a shard / lane): pos, z, batch point at the range's first atom, ptr at its first
+ * graph; the range's own numbering starts at zero (ptr values - atom_offset, batch values - graph_offset) */
+extern "C" int xeq_load_padded_shard(int dtype, const void* pos, const void* z, int z_is_int64, const int64_t* ptr, const int64_t* batch,
+                                     int64_t n, int64_t g, int64_t atom_offset, int64_t graph_offset, int64_t n_cap, int64_t g_cap, double pad0,
+                                     double spacing, void* pos_out, int32_t* z_out, int64_t* ptr_out, int64_t* batch_out, void* stream) {
+  return load_padded_batch(dtype, pos, z, z_is_int64, ptr, batch, n, g, n_cap, g_cap, pad0, spacing, pos_out, z_out, ptr_out, batch_out, stream,
+                           atom_offset, graph_offset);
+}

@@ -288,6 +288,24 @@ class GraphedStep:
         res["n_edges"] = count                              # device-side TRUE edge count (the row pointer itself is cut at the capacity)
         return res
 
+    def _load_shard(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: torch.Tensor, a: int, b: int, g0: int,
+                    g1: int) -> None:
+        """Molecules g0 .. g1 - 1 (atoms a .. b - 1) of a larger resident batch into the static buffers, renumbered from zero: one launch
+        (xeq_load_padded_shard), no slicing or subtraction launches in front."""
+        from .lib import call, dtype_code
+        from ctypes import c_void_p
+
+        n, g = b - a, g1 - g0
+        if n > self.n_atoms or g > self.n_graphs - 1:
+            raise ValueError(f"GraphedStep: shard of {n} atoms / {g} graphs exceeds the capacity {self.n_atoms} / {self.n_graphs - 1}")
+        assert pos.dtype == self.pos.dtype and pos.is_contiguous() and ptr.dtype == torch.int64 and batch.dtype == torch.int64
+        z64 = atomic_numbers.dtype == torch.int64
+        assert z64 or atomic_numbers.dtype == torch.int32
+        at = lambda t, off: c_void_p(t.data_ptr() + off * t.element_size() * (t.stride(0) if t.dim() > 0 else 1))
+        call("xeq_load_padded_shard", dtype_code(pos), at(pos, a), at(atomic_numbers, a), int(z64), at(ptr, g0), at(batch, a), n, g, a, g0,
+             self.n_atoms, self.n_graphs, 1.0e4, self.PAD_SPACING, c_void_p(self.pos.data_ptr()), c_void_p(self.z.data_ptr()),
+             c_void_p(self.ptr.data_ptr()), c_void_p(self.batch.data_ptr()), c_void_p(torch.cuda.current_stream().cuda_stream))
+
     def _load(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor]) -> None:
         """The batch into the static buffers, padded to the capacity: one launch (xeq_load_padded_batch), no read-back."""
         from .lib import call, dtype_code, ptr as p_, stream
@@ -334,6 +352,145 @@ class GraphedStep:
             out[keys.ATOMIC_ENERGIES] = self.outputs[keys.ATOMIC_ENERGIES][:n]
         if keys.FORCES in self.outputs:
             out[keys.FORCES] = self.outputs[keys.FORCES][:n]
+        return out
+
+
+def auto_lanes(n_atoms: int) -> int:
+    """Lanes of a whole-step graph for an open-boundary batch of this many atoms (GraphedLanes): 2 where the big kernels of a step
+    leave the chip half empty AND each half still takes the fused node block (measured, profiles/r05_lanes.txt); 1 elsewhere."""
+    import os
+
+    env = os.environ.get("XEQ_LANES")
+    if env:
+        return max(1, int(env))
+    lo, hi = AUTO_LANES_RANGE
+    return 2 if lo <= n_atoms < hi and bool(ops.lib.load().xeq_node_block_auto(n_atoms // 2 - 64)) else 1
+
+
+AUTO_LANES_RANGE = (12288, 49152)
+
+
+class GraphedLanes:
+    """One batch of independent molecules as ``lanes`` contiguous molecule ranges whose whole steps (``GraphedStep``: neighbour list +
+    model + forces) run CONCURRENTLY as parallel branches of ONE captured HIP graph.
+
+    Why: at 1 024 QM9-size molecules every big kernel of the step is a chain per wave with one or two waves per SIMD -- the node
+    block runs 1.14 waves per SIMD, the message kernels wait on their gathers 40 % of the time -- so the chip's matrix pipes are busy
+    ~15 % and HBM ~30 % over a step.  Molecules do not interact (data/transform.py:58-64, nn/output.py:124), so two halves of the
+    batch are two independent steps; as two branches of one graph their kernels share the CUs (a node-block workgroup leaves half a
+    CU's registers and LDS free), and the small launches of one half disappear under the large ones of the other.  Results are those of
+    the unsplit step bit for bit (every kernel gives a row the same bits in any batch; both halves stay on one side of the
+    node-block threshold or the split is refused).  Measured on QM9-1024: profiles/r05_lanes.txt.
+
+    ``capacity`` as GraphedStep.  ``ptr_host`` is needed per call (the cut is balanced on the host by estimated edges,
+    dist.shard_by_edges, cached per ``ptr_host`` object).  Outputs come back in the batch's own order through one copy launch."""
+
+    def __init__(self, model: torch.nn.Module, capacity, lanes: int = 2, cutoff: Optional[float] = None, compute_forces: bool = True,
+                 warmup: int = 2, slack: float = 0.15) -> None:
+        from . import lib
+
+        assert 2 <= lanes <= lib.COPY_MANY_MAX // 3
+        n_atoms, n_graphs, n_edges = (int(c) for c in capacity)
+        self.model, self.lanes, self.compute_forces, self.warmup = model, lanes, compute_forces, warmup
+        self.n_atoms, self.n_graphs, self.n_edges = n_atoms, n_graphs, n_edges
+        grow = lambda v: int(v / lanes * (1.0 + slack)) + 64
+        self.steps = [GraphedStep(model, (grow(n_atoms), grow(n_graphs), grow(n_edges)), cutoff=cutoff, compute_forces=compute_forces, warmup=0)
+                      for _ in range(lanes)]
+        p = self.steps[0].pos
+        self.energy = torch.zeros(n_graphs, dtype=p.dtype, device=p.device)
+        self.atomic = torch.zeros(n_atoms, dtype=p.dtype, device=p.device)
+        self.forces = torch.zeros((n_atoms, 3), dtype=p.dtype, device=p.device) if compute_forces else None
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.lane_outputs = None
+        self.captures = 0
+        self._param_state = None
+        self._cuts = (None, None)
+        self._streams = [torch.cuda.Stream(device=p.device) for _ in range(lanes - 1)]
+
+    @property
+    def edge_total(self) -> torch.Tensor:
+        """Edges of every step run so far, all lanes (a device scalar; a synchronisation-free sum of the lanes' counters)."""
+        return torch.stack([st.edge_total for st in self.steps]).sum(0)
+
+    def zero_edge_total(self) -> None:
+        for st in self.steps:
+            st.edge_total.zero_()
+
+    def overflowed(self) -> bool:
+        return any(st.outputs and int(st.outputs["n_edges"].item()) > st.n_edges for st in self.steps)
+
+    def _plan(self, ptr_host):
+        import numpy as np
+        from .dist import shard_by_edges
+
+        if self._cuts[0] is not ptr_host:
+            ph = np.asarray(ptr_host, dtype=np.int64)
+            cuts = shard_by_edges(ph, self.lanes)
+            plan = [(int(ph[g0]), int(ph[g1]), int(g0), int(g1)) for g0, g1 in cuts]
+            for (a, b, g0, g1), st in zip(plan, self.steps):
+                if b - a > st.n_atoms or g1 - g0 > st.n_graphs - 1 or pair_capacity(ph[g0 : g1 + 1] - ph[g0]) > st.n_edges:
+                    raise ValueError(f"GraphedLanes: lane of {b - a} atoms / {g1 - g0} graphs / {pair_capacity(ph[g0:g1 + 1] - ph[g0])} possible edges "
+                                     f"exceeds the lane capacity {st.n_atoms} / {st.n_graphs - 1} / {st.n_edges}")
+            self._cuts = (ptr_host, plan)
+        return self._cuts[1]
+
+    def _capture(self) -> None:
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                for st in self.steps:
+                    st._step()
+        main.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        outs = [None] * self.lanes
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            cur = torch.cuda.current_stream()
+            for i in range(1, self.lanes):                      # fork: every lane but the first on its own stream
+                self._streams[i - 1].wait_stream(cur)
+                with torch.cuda.stream(self._streams[i - 1]):
+                    outs[i] = self.steps[i]._step()
+            outs[0] = self.steps[0]._step()
+            for i in range(1, self.lanes):                      # join
+                cur.wait_stream(self._streams[i - 1])
+        for st, o in zip(self.steps, outs):
+            st.outputs = o
+        self.lane_outputs = outs
+        self.captures += 1
+
+    def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: torch.Tensor, ptr_host) -> Dict[str, torch.Tensor]:
+        """-> {energy [G], atomic_energies [n], forces [n, 3]}: this object's output buffers, overwritten by the next call."""
+        n, g = int(pos.shape[0]), int(ptr.numel() - 1)
+        if n > self.n_atoms or g > self.n_graphs:
+            raise ValueError(f"GraphedLanes: batch of {n} atoms / {g} graphs exceeds the capacity {self.n_atoms} / {self.n_graphs}")
+        plan = self._plan(ptr_host)
+        sides = {bool(ops.lib.load().xeq_node_block_auto(b - a)) for a, b, _, _ in plan}
+        if len(sides) > 1:
+            raise ValueError("GraphedLanes: the lanes fall on both sides of the node-block threshold (their bits would differ from the unsplit step's)")
+        pos_c = pos.detach().contiguous()
+        ptr_c, batch_c = ptr.to(torch.int64).contiguous(), batch.to(torch.int64).contiguous()
+        z_c = atomic_numbers.contiguous() if atomic_numbers.dtype in (torch.int32, torch.int64) else atomic_numbers.to(torch.int32).contiguous()
+        for (a, b, g0, g1), st in zip(plan, self.steps):
+            st._load_shard(pos_c, z_c, ptr_c, batch_c, a, b, g0, g1)
+        state = _params_state(self)
+        if self.graph is not None and state != self._param_state:
+            self.graph = None
+        self._param_state = state
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        pairs = []
+        for (a, b, g0, g1), o in zip(plan, self.lane_outputs):
+            pairs.append((self.energy[g0:g1], o[keys.TOTAL_ENERGY][: g1 - g0]))
+            if keys.ATOMIC_ENERGIES in o:
+                pairs.append((self.atomic[a:b], o[keys.ATOMIC_ENERGIES][: b - a]))
+            if self.forces is not None and keys.FORCES in o:
+                pairs.append((self.forces[a:b], o[keys.FORCES][: b - a]))
+        ops.copy_many(pairs)                                     # ONE launch: the lanes' results into the batch's own order
+        out = {keys.TOTAL_ENERGY: self.energy[:g], keys.ATOMIC_ENERGIES: self.atomic[:n]}
+        if self.forces is not None:
+            out[keys.FORCES] = self.forces[:n]
         return out
 
 
