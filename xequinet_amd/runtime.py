@@ -356,18 +356,14 @@ class GraphedStep:
 
 
 def auto_lanes(n_atoms: int) -> int:
-    """Lanes of a whole-step graph for an open-boundary batch of this many atoms (GraphedLanes): 2 where the big kernels of a step
-    leave the chip half empty AND each half still takes the fused node block (measured, profiles/r05_lanes.txt); 1 elsewhere."""
+    """Lanes of a whole-step graph for an open-boundary batch of this many atoms (GraphedLanes).  1: measured on QM9-1024, MD17 x 4096
+    and QM9 x 8192 (profiles/r05_lanes.txt), two lanes gained 5 % while a step still carried 34 small launches (round 4: they vanished
+    under the other lane's large kernels) and LOSE 3-9 % since those launches are gone -- a half-size node block or message kernel is
+    a chain per wave that takes 60-70 % of the full-size launch, and two of them share the CUs' registers.  XEQ_LANES overrides."""
     import os
 
     env = os.environ.get("XEQ_LANES")
-    if env:
-        return max(1, int(env))
-    lo, hi = AUTO_LANES_RANGE
-    return 2 if lo <= n_atoms < hi and bool(ops.lib.load().xeq_node_block_auto(n_atoms // 2 - 64)) else 1
-
-
-AUTO_LANES_RANGE = (12288, 49152)
+    return max(1, int(env)) if env else 1
 
 
 class GraphedLanes:
