@@ -174,17 +174,21 @@ __global__ void __launch_bounds__(256) k_head_fused(HeadArgs a) {
   }
   __syncthreads();
   const float one_k0 = kh == 0 ? 1.f : 0.f;
-  {  // hidden layer: output tile t (32 hidden columns) per wave
-    const int G = a.F >> 3, nt = a.H >> 5;
+  {  // hidden layer: a wave takes (output tile t of 32 hidden columns, half kp of the k range) when the tiles leave waves idle (the
+     // default head: two tiles, four waves), so the serial chain of a wave is half as long; the two partial sums meet in LDS, in one order
+    const int G = a.F >> 3, nt = a.H >> 5, ksplit = (nt <= 2 && (G & 1) == 0) ? 2 : 1;
     const float* xs = &Xs[i * XLD + 4 * kh];
-    for (int t = wave; t < nt; t += 4) {
+    for (int item = wave; item < nt * ksplit; item += 4) {
+      const int t = item % nt, kp = item / nt;
+      const int q0 = kp * (G / ksplit), q1 = q0 + G / ksplit;
       const float4* wp = reinterpret_cast<const float4*>(a.W1p) + (int64_t)t * (G + 1) * 64 + lane;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      float4 w0 = wp[0], w1 = wp[(1 < G ? 1 : G - 1) * 64], w2r = wp[(2 < G ? 2 : G - 1) * 64], w3 = wp[(3 < G ? 3 : G - 1) * 64];
-      for (int q = 0; q < G; ++q) {
-        const float4 wn = wp[(q + 4 < G ? q + 4 : G - 1) * 64];
+      auto wq = [&](int q) { return wp[(q < q1 ? q : q1 - 1) * 64]; };
+      float4 w0 = wq(q0), w1 = wq(q0 + 1), w2r = wq(q0 + 2), w3 = wq(q0 + 3);
+      for (int q = q0; q < q1; ++q) {
+        const float4 wn = wq(q + 4);
         const float4 xv = *reinterpret_cast<const float4*>(xs + 8 * q);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, xv.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, xv.y, acc, 0, 0, 0);
@@ -195,24 +199,37 @@ __global__ void __launch_bounds__(256) k_head_fused(HeadArgs a) {
         w2r = w3;
         w3 = wn;
       }
-      const float bias_a = reinterpret_cast<const float*>(wp + (int64_t)G * 64)[0];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, one_k0, acc, 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = 32 * t + 8 * g + 4 * kh;
-        const float4 wv = *reinterpret_cast<const float4*>(a.w2 + col);
-        float e[4], gh[4];
-        const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float x = acc[4 * g + c];
-          const float sig = 1.f / (1.f + expf(-x));
-          e[c] = (x * sig) * wq[c];                               // SiLU(pre) w2
-          gh[c] = wq[c] * (sig * (1.f + x * (1.f - sig)));        // w2 SiLU'(pre)  (aten silu_backward's form)
-        }
-        *reinterpret_cast<float4*>(&Es[i * HLD + col]) = make_float4(e[0], e[1], e[2], e[3]);
-        *reinterpret_cast<float4*>(&Gs[i * HLD + col]) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+      if (kp == 0) {   // the bias rides with the first half
+        const float bias_a = reinterpret_cast<const float*>(wp + (int64_t)G * 64)[0];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a, one_k0, acc, 0, 0, 0);
       }
+      float* dst = kp == 0 ? Es : Gs;   // partial pre-activations
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(&dst[i * HLD + 32 * t + 8 * g + 4 * kh]) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    }
+    __syncthreads();
+    // pre = half 0 (+ half 1); e = SiLU(pre) w2 -> Es, w2 SiLU'(pre) -> Gs, in place: a thread per four columns
+    const int h4 = a.H >> 2;
+    for (int idx = tid; idx < LIN_ROWS * h4; idx += 256) {
+      const int r = idx / h4, col = 4 * (idx - r * h4);
+      float4 p = *reinterpret_cast<const float4*>(&Es[r * HLD + col]);
+      if (ksplit == 2) {
+        const float4 p1 = *reinterpret_cast<const float4*>(&Gs[r * HLD + col]);
+        p = make_float4(p.x + p1.x, p.y + p1.y, p.z + p1.z, p.w + p1.w);
+      }
+      const float4 wv = *reinterpret_cast<const float4*>(a.w2 + col);
+      const float xq[4] = {p.x, p.y, p.z, p.w}, wq4[4] = {wv.x, wv.y, wv.z, wv.w};
+      float e[4], gh[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float x = xq[c];
+        const float sig = 1.f / (1.f + expf(-x));
+        e[c] = (x * sig) * wq4[c];                               // SiLU(pre) w2
+        gh[c] = wq4[c] * (sig * (1.f + x * (1.f - sig)));        // w2 SiLU'(pre)  (aten silu_backward's form)
+      }
+      *reinterpret_cast<float4*>(&Es[r * HLD + col]) = make_float4(e[0], e[1], e[2], e[3]);
+      *reinterpret_cast<float4*>(&Gs[r * HLD + col]) = make_float4(gh[0], gh[1], gh[2], gh[3]);
     }
   }
   __syncthreads();
