@@ -118,6 +118,60 @@ def _load_sharded_batch(name, seed):
     return pos, z, ptr
 
 
+def run_train(args, rank, world, dev, dtype, xdist):
+    """bench.py --train [--forces]: K optimisation steps of the reference's inner loop (utils/trainer.py:290-308) on this rank's own batch
+    of the workload, barrier + synchronize on both sides, MAX over ranks; with --gpus > 1 the model is DistributedDataParallel
+    (run/train.py:185-190), so every timed step carries the bucketed gradient all-reduce over RCCL."""
+    from xequinet_amd import keys, train
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+    from xequinet_amd.data import synthetic as syn
+    from xequinet_amd.nn import resolve_model
+
+    pos, z, ptr, cell = syn.make_workload(args.workload, seed=1234 + rank)
+    assert cell is None, "--train takes the open-boundary workloads"
+    torch.manual_seed(0)                                        # the same initial weights on every rank
+    model = resolve_model("xpainn").to(dtype).to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    ddp = train.wrap_ddp(model, local_rank=dev.index)
+    opt = torch.optim.Adam(ddp.parameters(), lr=1e-4)
+    b = NeighborTransform(5.0)(XequiBatch(torch.tensor(pos, dtype=dtype, device=dev), torch.tensor(z, device=dev), torch.tensor(ptr, device=dev)))
+    data = b.to_dict()
+    n_edges = int(data["edge_index"].shape[1])
+    g = torch.Generator().manual_seed(rank)
+    target = {keys.TOTAL_ENERGY: torch.randn(len(ptr) - 1, generator=g).to(dtype).to(dev), keys.BATCH_PTR: data["ptr"]}
+    weights = {keys.TOTAL_ENERGY: 1.0}
+    if args.forces:
+        target[keys.FORCES] = torch.randn(len(pos), 3, generator=g).to(dtype).to(dev)
+        weights[keys.FORCES] = 10.0
+
+    def step():
+        d = {k: v for k, v in data.items() if not k.startswith("_")}
+        d["pos"] = d["pos"].detach().clone()
+        return train.train_step(ddp, d, target, opt, weights)[0]
+
+    for _ in range(max(args.warmup, 15 if args.forces else 5)):     # (the caching allocator of a new step shape settles in ~15 steps)
+        step()
+    xdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    xdist.barrier()
+    elapsed, edges_all = xdist.reduce_timing(time.perf_counter() - t0, float(n_edges), device=dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training step: edges/sec, " + ("energy + forces loss (twice-differentiated pass)" if args.forces else "energy loss (native pass)"),
+            "value": edges_all * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: one optimisation step (forward, l2 loss, backward, Adam) per step on {len(pos)} atoms / {n_edges} edges per rank",
+                       "parallelism": f"DistributedDataParallel x{world}: one gradient bucket of {n_params * 4 / 1e6:.2f} MB all-reduced per step" if world > 1 else "one rank, no collective",
+                       "loss": float(loss), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     from xequinet_amd.data import synthetic as syn
 
@@ -144,6 +198,12 @@ def main():
     ap.add_argument("--lanes", type=int, default=-1, metavar="L",
                     help="whole-step graph of an open-boundary batch: evaluate the batch as L contiguous molecule ranges in parallel branches of "
                          "the one captured graph (runtime.GraphedLanes; results bit for bit those of L = 1).  Default: runtime.auto_lanes(atoms)")
+    ap.add_argument("--train", action="store_true",
+                    help="time ONE OPTIMISATION STEP per step instead of an inference step (SURVEY 8f-4; utils/trainer.py:290-308): forward in train "
+                         "mode, weighted l2 loss, backward, Adam, the model wrapped in DistributedDataParallel when --gpus > 1 so that the timed "
+                         "step includes the gradient all-reduce (RCCL; 865 k fp32 gradients, one bucket).  Prints its own JSON line "
+                         "(metric 'training step'); the headline metric is the default mode's")
+    ap.add_argument("--forces", action="store_true", help="with --train: forces in the loss (weight 10), i.e. the twice-differentiated pass")
     ap.add_argument("--vary-batch", type=int, default=0, metavar="K",
                     help="feed K different draws of the workload in turn (different atom and edge counts every step) through the "
                          "one captured graph")
@@ -180,6 +240,9 @@ def main():
     model = resolve_model("xpainn").eval().requires_grad_(False)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(dtype).to(dev)
+
+    if args.train:
+        return run_train(args, rank, world, dev, dtype, xdist)
 
     sharded = args.workload in SHARDED
     if sharded:

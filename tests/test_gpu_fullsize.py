@@ -449,3 +449,25 @@ def test_two_lanes_in_one_graph_equal_the_unsplit_step_bit_for_bit():
         assert sum(int(st.outputs["n_edges"]) for st in two.steps) == na
     assert two.captures == 1 and not two.overflowed()
     assert int(two.edge_total) == int(one.edge_total)
+
+
+@pytest.mark.parametrize("forces", [False, True])
+def test_bench_train_mode_times_a_ddp_step_over_two_ranks_on_one_card(forces):
+    """`bench.py --train [--forces] --gpus 2`: one optimisation step per timed step, the model in DistributedDataParallel, so the step
+    carries the gradient all-reduce (gloo here, every rank on device 0; RCCL on a multi-GPU node).  One JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(XEQ_BENCH_BACKEND="gloo", XEQ_BENCH_DEVICE="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--train", "--workload", "qm9_64", "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd + (["--forces"] if forces else []), capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["metric"].startswith("training step") and line["value"] > 0 and line["ms_per_step"] > 0
+    assert "DistributedDataParallel x2" in line["config"]["parallelism"] and np.isfinite(line["config"]["loss"])
