@@ -50,7 +50,8 @@ constexpr int F = 128, M0 = 128, M1 = 64, M2 = 32, C = M0 + M1 + M2, D = M0 + 3 
 constexpr int HM = F + 2 * C;    // scalar_mlp output (576)
 constexpr int AU = C + 2 * F;    // update_mlp output (480)
 constexpr int WAVE_ROWS = 16;    // nodes of a wave
-constexpr int ROWS_WG = 64;      // 4 waves x 16 nodes
+constexpr int ROWS_WG = 64;      // 4 waves x 16 nodes: the default workgroup (two per CU)
+constexpr int MAX_WAVES = 8;     // waves of a workgroup: 4 .. 8 (xeq::nb::waves_for), every wave a block of 16 nodes; the first four move the weights
 constexpr int TILE_U4 = 192;     // one packed weight tile (16 output rows x 32 k): 3 splits x 64 lanes x 16 B
 #ifndef XEQ_NB_STAGE
 #define XEQ_NB_STAGE 4
@@ -168,6 +169,11 @@ struct WStream {
     nxt.lo = __builtin_bit_cast(bf16x8, q[128]);
     __builtin_amdgcn_sched_barrier(0);   // nothing crosses: the reads are issued in front of the products of the tile before
   }
+  // wave_: the wave's FETCH ROLE, 0 .. 3.  In a workgroup of more than four waves (xeq::nb::waves_for) waves 4 .. 7 take the roles of waves
+  // 0 .. 3 once more: they fetch the same tile and write the same bytes into the same ring slot -- a benign duplicate (L2 / L1 hits, equal
+  // values) that keeps the stream free of branches and of any address arithmetic the four-wave form does not have.  (A branch around the
+  // fetch spilled 130-180 more dwords; a separate unread slot cost one more address register, and the register allocator answered by
+  // spilling the IN-FLIGHT fetch registers -- a wait for the load right behind its issue: 108 -> 150 us per launch at 8 192 nodes.)
   __device__ __forceinline__ void init(const uint4* g_, uint4* ring_, int n_tiles_, int lane_, int wave_) {
     g = g_;
     ring = ring_;
@@ -249,7 +255,8 @@ __device__ __forceinline__ void out_pair(WStream& w, tile_t& a0, tile_t& a1, con
 // that sweep many output tiles over the same operand read it from there, step by step, instead of holding 48 registers -- the loops
 // over output tiles then stay rolled and small.  (LDS operations of one wave execute in order: no barrier between put and get.)
 constexpr int PARK_STEPS = 4, PARK_U4 = PARK_STEPS * TILE_U4;
-constexpr int LDS_BYTES = RING_BYTES + 4 * PARK_U4 * 16;
+constexpr int LDS_BYTES = RING_BYTES + 4 * PARK_U4 * 16;           // the default workgroup of four waves: 72 KB, two per CU
+constexpr int lds_bytes(int waves) { return RING_BYTES + waves * PARK_U4 * 16; }
 struct Park {
   uint4* fb;
   __device__ __forceinline__ void put(int k, const Frag& f) const {
@@ -603,23 +610,24 @@ struct FwdArgs {
 };
 
 template <bool TAIL>
-__global__ void __launch_bounds__(256, 2) k_node_block_fwd(FwdArgs a) {
+__global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a) {
   extern __shared__ uint4 ring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, h = lane >> 4;   // node of the wave, channel quarter
-  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * WAVE_ROWS + n;
+  const int n_waves = (int)(blockDim.x >> 6);   // 4 .. 8, chosen by the host (xeq::nb::waves_for)
+  const int64_t node = ((int64_t)blockIdx.x * n_waves + wave) * WAVE_ROWS + n;
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
   const int64_t N = a.n;
   NB_STAMP(0);
   NB_RSTAMP(17);
   WStream w;
-  w.init(a.wp, ring, a.n_tiles, lane, wave);
+  w.init(a.wp, ring, a.n_tiles, lane, wave & 3);
   const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
   NB_STAMP(1);
   const float* __restrict__ srow = a.s + row * F;
   const float* __restrict__ xrow = a.x + row * D;
-  const int64_t wblk = (int64_t)blockIdx.x * 4 + wave;   // this wave's block of 32 nodes in the internal layout
+  const int64_t wblk = (int64_t)blockIdx.x * n_waves + wave;   // this wave's block of 16 nodes in the internal layout (= node / 16)
   float* __restrict__ pw = a.p + wblk * (P_TILES * NAT_TILE);
   float* __restrict__ uvw = a.uv + wblk * (UV_TILES * NAT_TILE);
   float* __restrict__ prew = a.pre + wblk * (S_TILES * NAT_TILE);
@@ -1022,19 +1030,20 @@ __device__ __forceinline__ void ln_bwd(tile_t (&g)[4], const float* __restrict__
 }
 
 template <bool TAIL, bool GX>
-__global__ void __launch_bounds__(256, 2) k_node_block_bwd(BwdArgs a) {
+__global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a) {
   extern __shared__ uint4 ring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, h = lane >> 4;   // node of the wave, channel quarter
-  const int64_t node = (int64_t)blockIdx.x * ROWS_WG + wave * WAVE_ROWS + n;
+  const int n_waves = (int)(blockDim.x >> 6);   // 4 .. 8, chosen by the host (xeq::nb::waves_for)
+  const int64_t node = ((int64_t)blockIdx.x * n_waves + wave) * WAVE_ROWS + n;
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
   const int64_t N = a.n;
   WStream w;
-  w.init(a.wp, ring, a.n_tiles, lane, wave);
+  w.init(a.wp, ring, a.n_tiles, lane, wave & 3);
   const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
   const float e2 = a.eps * a.eps;
-  const int64_t wblk = (int64_t)blockIdx.x * 4 + wave;   // this wave's block of 32 nodes in the internal layout
+  const int64_t wblk = (int64_t)blockIdx.x * n_waves + wave;   // this wave's block of 16 nodes in the internal layout (= node / 16)
   float* __restrict__ gxow = a.gxo + wblk * (X_TILES * NAT_TILE);   // total dL/dx_out (GX)
   float* __restrict__ gww = a.gw + wblk * (X_TILES * NAT_TILE);
   float* __restrict__ gpw = a.gp + wblk * (P_TILES * NAT_TILE);
@@ -1450,12 +1459,31 @@ static hipError_t raise_lds() {
                          reinterpret_cast<const void*>(&k_node_block_bwd<false, false>)};
     hipError_t e = hipSuccess;
     for (const void* f : fns) {
-      const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(MAX_WAVES));
       if (r != hipSuccess) e = r;
     }
     return e;
   }();
   return err;
+}
+
+// Waves per workgroup for a launch over n nodes.  A wave is one serial chain (~130 us alone on its SIMD, ~170 us when two share one),
+// and a launch ends with its slowest CU: with workgroups of four waves, 18 609 nodes are 291 workgroups on 256 CUs -- 35 CUs run two
+// workgroups (every SIMD of theirs two waves, 167 us) while 221 CUs are done after 131 us (scratch/bench_nodeblock_sizes.py: 16 384 nodes
+// 131 us, 17 408 nodes 168 us).  Between one and two workgroups of four per CU the waves are therefore dealt out EVENLY: one workgroup
+// per CU of 5 .. 8 waves (the extra waves only read the weight ring), so that no CU carries twice the load of another.  Up to one
+// four-wave workgroup per CU, and from two per CU on (several rounds), workgroups of four as before.  Results do not depend on the
+// choice: a wave's 16 nodes see the same weights in the same order in any workgroup.
+static int waves_for(int64_t n) {
+  static const int forced = [] {
+    const char* v = getenv("XEQ_NODE_BLOCK_WAVES");
+    return v ? atoi(v) : 0;
+  }();
+  if (forced >= 4 && forced <= MAX_WAVES) return forced;
+  const int64_t blocks16 = (n + WAVE_ROWS - 1) / WAVE_ROWS;   // waves needed
+  const int64_t cus = 256;
+  if (blocks16 <= 4 * cus || blocks16 > MAX_WAVES * cus) return 4;
+  return (int)((blocks16 + cus - 1) / cus);
 }
 
 static bool shape_ok(int node_dim, const int32_t mul[3]) { return node_dim == F && mul[0] == M0 && mul[1] == M1 && mul[2] == M2; }
@@ -1481,8 +1509,9 @@ int xeq_node_block_auto(int64_t n) {
   return n >= min_nodes;
 }
 
-/* rows of the kernels' internal tensors (uv, p, pre, a, ip, pre_next; gxo, gp, gv, gw): whole workgroups of 64 nodes */
-int64_t xeq_node_block_rows(int64_t n) { return (n + ROWS_WG - 1) / ROWS_WG * ROWS_WG; }
+/* rows of the kernels' internal tensors (uv, p, pre, a, ip, pre_next; gxo, gp, gv, gw): whole wave blocks of 16 nodes plus one workgroup's worth
+ * of slack (the last workgroup's idle waves store their padding rows) */
+int64_t xeq_node_block_rows(int64_t n) { return ((n + WAVE_ROWS - 1) / WAVE_ROWS + MAX_WAVES) * WAVE_ROWS; }
 
 int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]) { return dtype == XEQ_F32 && mul && shape_ok(node_dim, mul); }
 
@@ -1543,10 +1572,11 @@ int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* l
   fa.p = p_scratch; fa.uv = uv_bt; fa.stats = stats; fa.pre = pre; fa.a = a; fa.ip = ip; fa.s_out = s_out; fa.x_out = x_out;
   fa.lnw2 = ln_w_next; fa.lnb2 = ln_b_next; fa.eqw2 = eq_w_next; fa.eqb2 = eq_b_next; fa.b1n = b1_next; fa.b2n = b2_next;
   fa.stats2 = stats_next; fa.xhat2 = xhat_next; fa.pre2 = pre_next; fa.h2 = h_next;
-  const dim3 grid((unsigned)((n + ROWS_WG - 1) / ROWS_WG));
+  const int nw = waves_for(n);
+  const dim3 grid((unsigned)((n + nw * WAVE_ROWS - 1) / (nw * WAVE_ROWS)));
   XEQ_CHECK_ARG(raise_lds() == hipSuccess, "xeq_node_block_fwd: cannot raise the dynamic LDS limit");
-  if (tail) hipLaunchKernelGGL(k_node_block_fwd<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, fa);
-  else hipLaunchKernelGGL(k_node_block_fwd<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, fa);
+  if (tail) hipLaunchKernelGGL(k_node_block_fwd<true>, grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, fa);
+  else hipLaunchKernelGGL(k_node_block_fwd<false>, grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, fa);
   XEQ_CHECK_LAUNCH("xeq_node_block_fwd");
   return XEQ_OK;
 }
@@ -1594,11 +1624,12 @@ int xeq_node_block_bwd(int64_t n, const float* g_h, const float* g_xhat_next, co
   b.stats2 = stats_next; b.pre2 = pre_next; b.lnw2 = ln_w_next; b.eqw2 = eq_w_next; b.uv = uv_bt; b.a = a; b.ip = ip; b.pre = pre;
   b.s = s; b.x = x; b.stats = stats; b.lnw = ln_w; b.eqw = eq_w; b.eps = (float)eps; b.wp = (const uint4*)packed;
   b.n_tiles = (int)xeq_node_block_bwd_tiles(tail, gx); b.gxo = gxo; b.gp = gp; b.gv = gv; b.gw = gw; b.g_s = g_s; b.g_x = g_x;
-  const dim3 grid((unsigned)((n + ROWS_WG - 1) / ROWS_WG));
+  const int nw = waves_for(n);
+  const dim3 grid((unsigned)((n + nw * WAVE_ROWS - 1) / (nw * WAVE_ROWS)));
   XEQ_CHECK_ARG(raise_lds() == hipSuccess, "xeq_node_block_bwd: cannot raise the dynamic LDS limit");
-  if (tail) hipLaunchKernelGGL((k_node_block_bwd<true, true>), grid, dim3(256), LDS_BYTES, (hipStream_t)stream, b);
-  else if (gx) hipLaunchKernelGGL((k_node_block_bwd<false, true>), grid, dim3(256), LDS_BYTES, (hipStream_t)stream, b);
-  else hipLaunchKernelGGL((k_node_block_bwd<false, false>), grid, dim3(256), LDS_BYTES, (hipStream_t)stream, b);
+  if (tail) hipLaunchKernelGGL((k_node_block_bwd<true, true>), grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, b);
+  else if (gx) hipLaunchKernelGGL((k_node_block_bwd<false, true>), grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, b);
+  else hipLaunchKernelGGL((k_node_block_bwd<false, false>), grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, b);
   XEQ_CHECK_LAUNCH("xeq_node_block_bwd");
   return XEQ_OK;
 }
