@@ -74,9 +74,10 @@ if os.environ.get("XEQ_WQ_ROLE_TIME"):   # workgroup timeline of the reverse ker
     from xequinet_amd import lib as _lib
     L = _lib.load()
     wg = (ctypes.c_ulonglong * (8192 * 4))()
-    L.xeq_wq_debug_wg(wg)
+    dbg = getattr(L, "xeq_wq_debug_wg" if os.environ["XEQ_WQ_ROLE_TIME"] == "fwd" else "xeq_wq_debug_wg_bwd")   # (each half of the file has its own array)
+    dbg(wg)
     run("wq"); torch.cuda.synchronize()
-    L.xeq_wq_debug_wg(wg)
+    dbg(wg)
     recs = [(wg[4*b] & 0xffffffff, wg[4*b] >> 32, wg[4*b+1] & 0xf, wg[4*b+2], wg[4*b+3]) for b in range(8192) if wg[4*b+3]]
     t0 = min(r[3] for r in recs); t1 = max(r[4] for r in recs)
     percu = collections.defaultdict(list)
