@@ -243,8 +243,9 @@ int xeq_scatter_add(int dtype, const void* src, const int64_t* index, int64_t n,
  * scalar_mlp output h and the 0e block of the equivariant norm are functions of the node's ELEMENT alone (nn/xpainn.py:62, 76-81,
  * 128-139: s = Linear(table[Z]), x = 0), so they are evaluated once per table row (rows_s [Zmax + 1, node_dim], rows_h [., hidden_dim],
  * rows_x0 [., node_dim]) and gathered by atomic number: s_out [n, node_dim], h_out [n, hidden_dim], xhat_out [n * irreps_dim] in BT
- * layout with every l > 0 block zero.  z: int32 or int64 atomic numbers.  Replaces three ATen gathers and a fill. */
-int xeq_first_block_front(const void* z, int z_is_int64, int64_t n, const void* rows_s, const void* rows_h, const void* rows_x0,
+ * layout with every l > 0 block zero.  z: int32 or int64 atomic numbers; one outside [0, n_rows) reads row 0.  Replaces three ATen
+ * gathers and a fill. */
+int xeq_first_block_front(const void* z, int z_is_int64, int64_t n, int64_t n_rows, const void* rows_s, const void* rows_h, const void* rows_x0,
                           int node_dim, int hidden_dim, int64_t irreps_dim, void* s_out, void* h_out, void* xhat_out, void* stream);
 
 /* Up to XEQ_COPY_MANY_MAX device-to-device copies in ONE launch: dst[i][0 .. bytes[i]) = src[i][...] (whole aligned 4-byte

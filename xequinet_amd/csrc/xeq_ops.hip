@@ -624,43 +624,45 @@ extern "C" int xeq_load_padded_batch_z64(int dtype, const void* pos, const int64
 // ---- the first message block's front half gathered from the element table (xeq_first_block_front, include/xeq.h) ----
 namespace xeq {
 template <typename Z>
-__global__ void k_first_block_front(const Z* __restrict__ z, int64_t n, const float* __restrict__ rows_s, const float* __restrict__ rows_h,
+__global__ void k_first_block_front(const Z* __restrict__ z, int64_t n, int64_t n_rows, const float* __restrict__ rows_s, const float* __restrict__ rows_h,
                                     const float* __restrict__ rows_x0, int F, int H, int64_t D, float* __restrict__ s_out,
                                     float* __restrict__ h_out, float* __restrict__ xhat_out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of the three outputs laid end to end
   const int64_t f4 = F >> 2, h4 = H >> 2, d4 = D >> 2;
   const int64_t n_s = n * f4, n_h = n * h4, n_x = n * d4;
+  // (an atomic number outside the table reads row 0 -- the table's all-zero padding row -- instead of faulting; the reference's lookup raises)
+  auto row_of = [&](int64_t i) { const int64_t r = (int64_t)z[i]; return r >= 0 && r < n_rows ? r : 0; };
   if (t < n_s) {
     const int64_t i = t / f4, c = t - i * f4;
-    reinterpret_cast<float4*>(s_out)[t] = reinterpret_cast<const float4*>(rows_s)[(int64_t)z[i] * f4 + c];
+    reinterpret_cast<float4*>(s_out)[t] = reinterpret_cast<const float4*>(rows_s)[row_of(i) * f4 + c];
   } else if (t < n_s + n_h) {
     const int64_t u = t - n_s, i = u / h4, c = u - i * h4;
-    reinterpret_cast<float4*>(h_out)[u] = reinterpret_cast<const float4*>(rows_h)[(int64_t)z[i] * h4 + c];
+    reinterpret_cast<float4*>(h_out)[u] = reinterpret_cast<const float4*>(rows_h)[row_of(i) * h4 + c];
   } else if (t < n_s + n_h + n_x) {
     const int64_t u = t - n_s - n_h;   // BT layout: the 0e block [n, F] first, every l > 0 block behind it is the norm of zero: zero
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (u < n_s) {
       const int64_t i = u / f4, c = u - i * f4;
-      v = reinterpret_cast<const float4*>(rows_x0)[(int64_t)z[i] * f4 + c];
+      v = reinterpret_cast<const float4*>(rows_x0)[row_of(i) * f4 + c];
     }
     reinterpret_cast<float4*>(xhat_out)[u] = v;
   }
 }
 }  // namespace xeq
 
-extern "C" int xeq_first_block_front(const void* z, int z_is_int64, int64_t n, const void* rows_s, const void* rows_h, const void* rows_x0,
+extern "C" int xeq_first_block_front(const void* z, int z_is_int64, int64_t n, int64_t n_rows, const void* rows_s, const void* rows_h, const void* rows_x0,
                                      int node_dim, int hidden_dim, int64_t irreps_dim, void* s_out, void* h_out, void* xhat_out, void* stream) {
   XEQ_CHECK_ARG(n >= 0 && node_dim > 0 && node_dim % 4 == 0 && hidden_dim % 4 == 0 && irreps_dim % 4 == 0 && irreps_dim >= node_dim,
                 "xeq_first_block_front: widths must be multiples of four floats");
-  XEQ_CHECK_ARG(z && rows_s && rows_h && rows_x0 && s_out && h_out && xhat_out, "xeq_first_block_front: NULL argument");
+  XEQ_CHECK_ARG(z && rows_s && rows_h && rows_x0 && s_out && h_out && xhat_out && n_rows >= 1, "xeq_first_block_front: NULL argument / empty table");
   if (n == 0) return XEQ_OK;
   const int64_t total = n * ((node_dim + hidden_dim + irreps_dim) / 4);
   const dim3 grid((unsigned)((total + 255) / 256));
   if (z_is_int64)
-    hipLaunchKernelGGL((xeq::k_first_block_front<int64_t>), grid, dim3(256), 0, (hipStream_t)stream, (const int64_t*)z, n, (const float*)rows_s,
+    hipLaunchKernelGGL((xeq::k_first_block_front<int64_t>), grid, dim3(256), 0, (hipStream_t)stream, (const int64_t*)z, n, n_rows, (const float*)rows_s,
                        (const float*)rows_h, (const float*)rows_x0, node_dim, hidden_dim, irreps_dim, (float*)s_out, (float*)h_out, (float*)xhat_out);
   else
-    hipLaunchKernelGGL((xeq::k_first_block_front<int32_t>), grid, dim3(256), 0, (hipStream_t)stream, (const int32_t*)z, n, (const float*)rows_s,
+    hipLaunchKernelGGL((xeq::k_first_block_front<int32_t>), grid, dim3(256), 0, (hipStream_t)stream, (const int32_t*)z, n, n_rows, (const float*)rows_s,
                        (const float*)rows_h, (const float*)rows_x0, node_dim, hidden_dim, irreps_dim, (float*)s_out, (float*)h_out, (float*)xhat_out);
   XEQ_CHECK_LAUNCH("xeq_first_block_front");
   return XEQ_OK;

@@ -74,7 +74,7 @@ _PROTOS = {
     "xeq_head_supported": [c_int, c_int, c_int],
     "xeq_head_fwd": [_P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P],
     "xeq_head_bwd": [_P, c_int64, c_int, _P, c_int64, _P, c_int64, _P, _P, _P],
-    "xeq_first_block_front": [_P, c_int, c_int64, _P, _P, _P, c_int, c_int, c_int64, _P, _P, _P, _P],
+    "xeq_first_block_front": [_P, c_int, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_int64, _P, _P, _P, _P],
     "xeq_rowptr_from_degrees": [_P, c_int64, c_int64, _P, _P, _P, _P],
     "xeq_rowptr_from_degrees_max": [],
     "xeq_wgrad_chunks": [c_int64, c_int, c_int],

@@ -316,6 +316,8 @@ def constant_vector(n: int, value: float, dtype, device) -> torch.Tensor:
     if t is None:
         t = torch.full((int(n),), float(value), dtype=dtype, device=device)
         if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if t.is_cuda:
+                torch.cuda.current_stream().synchronize()   # once per key: the constant is complete before ANY stream may read it
             if len(_SEEDS) > 256:
                 _SEEDS.clear()
             _SEEDS[key] = t
@@ -419,8 +421,8 @@ def first_block_front(module, z: torch.Tensor, rows: torch.Tensor, n: int, highe
     s = torch.empty((n, F), dtype=rows.dtype, device=rows.device)
     h = torch.empty((n, H), dtype=rows.dtype, device=rows.device)
     xhat = torch.empty(n * D, dtype=rows.dtype, device=rows.device)
-    call("xeq_first_block_front", ptr(z), int(z.dtype == torch.int64), n, ptr(rows), ptr(h_t), ptr(xhat0_t), F, H, F if higher_l_unread else D,
-         ptr(s), ptr(h), ptr(xhat), stream())
+    call("xeq_first_block_front", ptr(z), int(z.dtype == torch.int64), n, rows.shape[0], ptr(rows), ptr(h_t), ptr(xhat0_t), F, H,
+         F if higher_l_unread else D, ptr(s), ptr(h), ptr(xhat), stream())
     return s, h, xhat
 
 
