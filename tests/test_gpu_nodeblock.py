@@ -290,3 +290,36 @@ def test_node_block_at_full_size_equals_itself_on_slices():
             gs2, gx2 = nodeblock.node_block_bwd(part, sp, xp, upd, msg, g_s_in[a:b].contiguous(), g_x_in[a:b].contiguous(), g_h[a:b].contiguous(),
                                                 _mulir_to_bt(g_xh[a:b].contiguous()))
             assert torch.equal(g_s[a:b], gs2) and torch.equal(g_x[a:b], gx2), (rep, a)
+
+
+@pytest.mark.parametrize("n", [18609, 24000, 32768])
+def test_node_block_results_do_not_depend_on_the_waves_per_workgroup(n, monkeypatch):
+    """Between one and two four-wave workgroups per CU a launch takes one workgroup of 5 .. 8 waves per CU (xeq::nb::waves_for, round 5:
+    no CU with twice the load of another).  A wave's 16 nodes see the same weights in the same order in any workgroup: forward and
+    reverse results with the automatic choice equal those of four-wave and of eight-wave workgroups BIT FOR BIT, and repeat."""
+    from xequinet_amd.nn import nodeblock
+
+    upd, msg = _modules(3)
+    upd, msg = upd.to(_dev()), msg.to(_dev())
+    torch.manual_seed(2)
+    s = torch.randn(n, F, device=_dev())
+    x = torch.randn(n, D, device=_dev())
+    g_s_in, g_x_in = torch.randn(n, F, device=_dev()), torch.randn(n, D, device=_dev())
+    g_h, g_xh = torch.randn(n, F + 2 * C, device=_dev()), _mulir_to_bt(torch.randn(n, D, device=_dev()))
+
+    def run():
+        full = nodeblock.node_block_fwd(s, x, upd, msg, want_x=True)
+        g = nodeblock.node_block_bwd(full, s, x, upd, msg, g_s_in, g_x_in, g_h, g_xh)
+        return [full[k].clone() for k in ("s_out", "x_out", "h2", "xhat2")] + [t.clone() for t in g]
+
+    monkeypatch.delenv("XEQ_NODE_BLOCK_WAVES", raising=False)
+    auto = run()
+    again = run()
+    outs = {}
+    for w in ("4", "8"):
+        monkeypatch.setenv("XEQ_NODE_BLOCK_WAVES", w)
+        outs[w] = run()
+    monkeypatch.delenv("XEQ_NODE_BLOCK_WAVES")
+    for other in (again, outs["4"], outs["8"]):
+        for a, b in zip(auto, other):
+            assert torch.equal(a, b)

@@ -1475,10 +1475,8 @@ static hipError_t raise_lds() {
 // four-wave workgroup per CU, and from two per CU on (several rounds), workgroups of four as before.  Results do not depend on the
 // choice: a wave's 16 nodes see the same weights in the same order in any workgroup.
 static int waves_for(int64_t n) {
-  static const int forced = [] {
-    const char* v = getenv("XEQ_NODE_BLOCK_WAVES");
-    return v ? atoi(v) : 0;
-  }();
+  const char* v = getenv("XEQ_NODE_BLOCK_WAVES");   // development / tests: a fixed workgroup size (read per call: a test flips it)
+  const int forced = v ? atoi(v) : 0;
   if (forced >= 4 && forced <= MAX_WAVES) return forced;
   const int64_t blocks16 = (n + WAVE_ROWS - 1) / WAVE_ROWS;   // waves needed
   const int64_t cus = 256;
