@@ -572,6 +572,14 @@ int64_t xeq_message_wq_parts_floats(int64_t n_nodes, int64_t n_edges, const int3
  * reverse plan and its records are never built.  xeq_message_wq_edge_grad then takes `mirror` = the reverse-edge map
  * (xeq_reverse_edge_map: position of edge (j, i) for edge (i, j)) to write each slot's gradient to the mirror edge; NULL otherwise. */
 #define XEQ_WQ_MIRROR_WALK 4
+/* xeq_message_fwd_wq / _bwd_wq: xhat_layout | XEQ_WQ_PACKED_WEIGHTS says that `w_rbf` points at the output of
+ * xeq_message_wq_pack_weights (the units' rbf_lin rows -- bf16 splits of the first sixteen basis columns, the exact-f32 tail and the
+ * bias -- in the kernels' LDS layout, xeq_message_wq_packed_weight_floats floats, once per weight version) and `b_rbf` is ignored: the
+ * workgroups then stage their unit's weights with coalesced 16-byte loads instead of one row per lane (~11 us per launch). */
+#define XEQ_WQ_PACKED_WEIGHTS 64
+int64_t xeq_message_wq_packed_weight_floats(int num_basis, int node_dim, const int32_t mul[3]);   /* a size (-1: unsupported), not a status */
+int xeq_message_wq_pack_weights(const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* packed,
+                                void* stream);
 int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* n_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis,
                        const void* dbasis, const void* h, const void* xhat, const void* grad_s, const void* grad_x,

@@ -334,6 +334,7 @@ struct WqArgs {
   Irreps ir;
   int xl;                  // layout of xhat / grad_xhat
   int mirror;              // reverse pass over the FORWARD plan of a symmetric list: every slot stands for its mirror edge (Y_1 negated)
+  int packed_w;            // w_rbf points at xeq_message_wq_pack_weights' output (XEQ_WQ_PACKED_WEIGHTS): staging is a coalesced copy
   int nu[3];               // 32-channel units per l
 };
 
@@ -409,6 +410,12 @@ template <int KS>
 __device__ __forceinline__ void wq_stage_weights(const WqArgs& a, const WqUnit& un, const float* __restrict__ w,
                                                  const float* __restrict__ b, float* wl) {
   const int nkind = un.l == 0 ? 3 : 2, B = a.B;
+  if (a.packed_w) {   // the unit's block of the packed copy, already in this layout: 16-byte coalesced loads (round 5)
+    const int unit_index = (un.l == 0 ? 0 : (un.l == 1 ? a.nu[0] : a.nu[0] + a.nu[1])) + un.cb;
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(w + (size_t)unit_index * (3 * WQ_WK<KS>));
+    for (int idx = threadIdx.x; idx < nkind * WQ_WK<KS> / 4; idx += blockDim.x) reinterpret_cast<f32x4*>(wl)[idx] = src[idx];
+    return;
+  }
   auto row_of = [&](int kind, int ln) { return (kind == 0 ? un.u0 : (kind == 1 ? a.C + un.u0 : 2 * a.C + 32 * un.cb)) + (ln & 31); };
   for (int idx = threadIdx.x; idx < nkind * 3 * 64; idx += blockDim.x) {   // one 16-byte pack per thread and trip
     const int kind = idx / 192, rem = idx - 192 * kind, split = rem >> 6, ln = rem & 63;
@@ -910,6 +917,19 @@ __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_en
     atomicAdd(&g_wq_stamps[15], 1ull);
   }
 #endif
+}
+
+// The units' rbf_lin rows in the kernels' LDS layout, once per weight version (xeq_message_wq_pack_weights): a workgroup per unit runs
+// the very staging code of the kernels into global memory.  Why: that staging reads w[row B + k] with one ROW PER LANE -- 64 cache
+// lines per wave instruction, 24 such instructions per workgroup -- and sits between every two workgroups of a CU slot: ~11 us of a
+// 160-280 us launch (timing-only variant with a coalesced copy: forward 181 -> 170 us, reverse 296 -> 285 us).
+template <int KS>
+__global__ void __launch_bounds__(256) k_wq_pack_weights(WqArgs a, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out) {
+  const WqUnit un = wq_unit(a, (int)blockIdx.x);
+  float* dst = out + (size_t)blockIdx.x * (3 * WQ_WK<KS>);
+  if (un.l != 0)   // (two kinds only: the third block of the unit's slot reads as zeros)
+    for (int idx = threadIdx.x; idx < WQ_WK<KS>; idx += blockDim.x) dst[2 * WQ_WK<KS> + idx] = 0.f;
+  wq_stage_weights<KS>(a, un, w, b, dst);
 }
 
 // XZ: xhat is zero on every l > 0 column (the model's first message block: XEmbedding hands over x = 0, and the
@@ -1628,6 +1648,33 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   return XEQ_OK;
 }
 
+static int wq_ks_template(int num_basis) {   // the KS the dispatch macros instantiate for this basis width
+  const int ks = wq_ks(num_basis);
+  return ks <= 1 ? 1 : (ks <= 3 ? 3 : (ks <= 4 ? 4 : 8));
+}
+int64_t xeq_message_wq_packed_weight_floats(int num_basis, int node_dim, const int32_t mul[3]) {
+  if (!wq_supported(num_basis, node_dim, mul)) return -1;
+  const int64_t per_unit = 3 * (int64_t)(3 * 64 * 4 + wq_ks_template(num_basis) * 64);
+  return per_unit * (mul[0] / 32 + mul[1] / 32 + mul[2] / 32);
+}
+int xeq_message_wq_pack_weights(const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* packed,
+                                void* stream) {
+  WqArgs a{};
+  int rcode = wq_check("xeq_message_wq_pack_weights", 0, 0, 1, num_basis, node_dim, mul, a);
+  if (rcode != XEQ_OK) return rcode;
+  XEQ_CHECK_ARG(w_rbf && b_rbf && packed, "xeq_message_wq_pack_weights: NULL argument");
+  const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
+  const dim3 grid((unsigned)nunits);
+  switch (wq_ks_template(num_basis)) {
+    case 1: hipLaunchKernelGGL(k_wq_pack_weights<1>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)w_rbf, (const float*)b_rbf, (float*)packed); break;
+    case 3: hipLaunchKernelGGL(k_wq_pack_weights<3>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)w_rbf, (const float*)b_rbf, (float*)packed); break;
+    case 4: hipLaunchKernelGGL(k_wq_pack_weights<4>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)w_rbf, (const float*)b_rbf, (float*)packed); break;
+    default: hipLaunchKernelGGL(k_wq_pack_weights<8>, grid, dim3(256), 0, (hipStream_t)stream, a, (const float*)w_rbf, (const float*)b_rbf, (float*)packed); break;
+  }
+  XEQ_CHECK_LAUNCH("xeq_message_wq_pack_weights");
+  return XEQ_OK;
+}
+
 int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int32_t* sq, const int32_t* sn, const int32_t* win,
                        const int32_t* c_rowptr, const int32_t* pgath, const int32_t* qinfo, const void* basis, const void* h,
                        const void* xhat, const void* s_in, const void* x_in, const void* w_rbf, const void* b_rbf,
@@ -1643,6 +1690,7 @@ int xeq_message_fwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   a.pgath = pgath;
   a.qinfo = (const uint32_t*)qinfo;
   a.xl = xhat_layout & 1;
+  a.packed_w = (xhat_layout & XEQ_WQ_PACKED_WEIGHTS) ? 1 : 0;
   const bool x_zero = (xhat_layout & XEQ_XHAT_HIGHER_L_ZERO) != 0;
   a.win = win;
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
@@ -1677,6 +1725,7 @@ int xeq_message_bwd_wq(int64_t n_nodes, int64_t n_edges, int n_ranges, const int
   a.qinfo = (const uint32_t*)qinfo;
   a.xl = xhat_layout & 1;
   a.mirror = (xhat_layout & XEQ_WQ_MIRROR_WALK) ? 1 : 0;
+  a.packed_w = (xhat_layout & XEQ_WQ_PACKED_WEIGHTS) ? 1 : 0;
   const bool first = (xhat_layout & XEQ_XHAT_HIGHER_L_ZERO) != 0 && grad_h == nullptr;
   const int nunits = a.nu[0] + a.nu[1] + a.nu[2];
   WqParts pr;

@@ -123,6 +123,32 @@ const MlpPacks* mlp_packs(const Tensor& w1, const Tensor& b1, const Tensor& w2, 
   }
   return &e;
 }
+// rbf_lin's rows in the wq message kernels' LDS layout (xeq_message_wq_pack_weights; ops.wq_packed_weights is the Python twin), cached
+// per weight version like the packs above: the kernels then stage a unit's weights with coalesced loads (XEQ_WQ_PACKED_WEIGHTS)
+struct WqWeightPack {
+  int64_t key[4];
+  Owners owners;
+  Tensor packed;
+};
+const Tensor* wq_weight_pack(const Tensor& w, const Tensor& b, int num_basis, int node_dim, const int32_t mul[3]) {
+  const int64_t n = xeq_message_wq_packed_weight_floats(num_basis, node_dim, mul);
+  if (n <= 0 || w.scalar_type() != at::kFloat || !b.defined() || b.numel() == 0) return nullptr;
+  static std::mutex mu;
+  static std::unordered_map<const void*, WqWeightPack> cache;
+  const int64_t key[4] = {(int64_t)w._version() + ((int64_t)xeq_pack_epoch() << 32), (int64_t)(intptr_t)w.data_ptr(), (int64_t)b._version(), (int64_t)(intptr_t)b.data_ptr()};
+  std::lock_guard<std::mutex> lock(mu);
+  WqWeightPack& e = cache[w.data_ptr()];
+  bool same = e.packed.defined() && e.owners.same({&w, &b});
+  for (int i = 0; i < 4 && same; ++i) same = e.key[i] == key[i];
+  if (!same) {
+    const Tensor wc = w.detach().contiguous(), bc = b.detach().contiguous();
+    e.packed = at::empty({n}, w.options());
+    XCALL(xeq_message_wq_pack_weights(wc.data_ptr(), bc.data_ptr(), num_basis, node_dim, mul, e.packed.data_ptr(), cur_stream()));
+    e.owners.set({&w, &b});
+    for (int i = 0; i < 4; ++i) e.key[i] = key[i];
+  }
+  return &e.packed;
+}
 // x: [n, k1] rows with stride ldx (a column slice of a wider buffer is fine)
 void mlp_fwd(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, Tensor& pre, Tensor& y) {
   const MlpPacks* pk = (x.stride(1) == 1 && x.stride(0) % 4 == 0) ? mlp_packs(w1, b1, w2, b2) : nullptr;
@@ -564,6 +590,12 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                          g.sb_basis.data_ptr(), g.sb_dbasis.data_ptr(), st));
   }
 
+  // the wq kernels take rbf_lin's rows from the packed copy (one per weight version)
+  auto wq_w = [&](const Tensor* q) {
+    const Tensor* pk = wq_weight_pack(q[4], q[5], hy.B, F, mul);
+    TORCH_CHECK(pk != nullptr, "xeq::xpainn_eval: rbf_lin weights cannot be packed for the wq kernels");
+    return pk;
+  };
   // fused node blocks: f32, the default layout, layer norms on (nn/nodeblock.py::supported)
   const bool nb_ok = dt == XEQ_F32 && hy.layer_norm && xeq_node_block_supported(XEQ_F32, F, mul) && xeq_node_block_auto(N);
   for (int b = 0; b < hy.blocks; ++b) {
@@ -584,8 +616,8 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         XCALL(xeq_message_fwd_wq(N, E, g.fwd.n_ranges, (const int32_t*)g.fwd.sq.data_ptr(), (const int32_t*)g.fwd.sn.data_ptr(),
                                  (const int32_t*)g.fwd.win.data_ptr(), (const int32_t*)g.fwd.rowptr.data_ptr(),
                                  (const int32_t*)g.fwd.pgath.data_ptr(), (const int32_t*)g.fwd.qinfo.data_ptr(), g.fwd.basis.data_ptr(),
-                                 m.h.data_ptr(), m.xhat.data_ptr(), s.data_ptr(), x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B,
-                                 F, mul, s_out.data_ptr(), x_out.data_ptr(), b == 0 ? (1 | XEQ_XHAT_HIGHER_L_ZERO) : 1, st));   // block 0: x = 0
+                                 m.h.data_ptr(), m.xhat.data_ptr(), s.data_ptr(), x.data_ptr(), wq_w(q)->data_ptr(), nullptr, hy.B,
+                                 F, mul, s_out.data_ptr(), x_out.data_ptr(), (b == 0 ? (1 | XEQ_XHAT_HIGHER_L_ZERO) : 1) | XEQ_WQ_PACKED_WEIGHTS, st));   // block 0: x = 0
       } else {
         XCALL(xeq_message_fwd_sb(dt, N, E, (const int32_t*)g.c_rowptr.data_ptr(),
                                  g.c_perm.defined() ? (const int32_t*)g.c_perm.data_ptr() : nullptr,
@@ -797,8 +829,8 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
                                    (const int32_t*)w.win.data_ptr(), (const int32_t*)w.rowptr.data_ptr(),
                                    (const int32_t*)w.pgath.data_ptr(), (const int32_t*)w.qinfo.data_ptr(),
                                    w.basis.data_ptr(), w.dbasis.data_ptr(), m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(),
-                                   g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(), hy.B, F, mul, node_grads ? g_h.data_ptr() : nullptr,
-                                   node_grads ? g_xhat.data_ptr() : nullptr, parts.data_ptr(), xl_bwd, st));
+                                   g_x.data_ptr(), wq_w(q)->data_ptr(), nullptr, hy.B, F, mul, node_grads ? g_h.data_ptr() : nullptr,
+                                   node_grads ? g_xhat.data_ptr() : nullptr, parts.data_ptr(), xl_bwd | XEQ_WQ_PACKED_WEIGHTS, st));
           if (defer_edge_grad) {
             part_sets.push_back(parts);
             if (b == 0) {

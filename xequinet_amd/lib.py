@@ -22,6 +22,7 @@ SB_Y0_ZERO = 8           # XEQ_SB_Y0_ZERO / XEQ_SB_Q_ACCUMULATE: the training-pa
 SB_Q_ACCUMULATE = 16
 SB_NO_GY = 32
 WQ_MIRROR_WALK = 4       # XEQ_WQ_MIRROR_WALK: the reverse wq kernel walks the forward plan of a symmetric list
+WQ_PACKED_WEIGHTS = 64   # XEQ_WQ_PACKED_WEIGHTS: w_rbf of the wq message kernels is the packed copy (xeq_message_wq_pack_weights)
 WQ_MAX_PART_SETS = 8     # XEQ_WQ_MAX_PART_SETS: sets of per-block partials one xeq_message_wq_edge_grad_sum launch adds up
 RBF_KINDS = {"bessel": 0, "gaussian": 1}
 CUTOFF_KINDS = {"cosine": 0, "polynomial": 1}
@@ -138,6 +139,8 @@ _PROTOS = {
     "xeq_message_wq_parts_floats": [c_int64, c_int64, _I3],
     "xeq_message_bwd_wq": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                            _I3, _P, _P, _P, c_int, _P],
+    "xeq_message_wq_packed_weight_floats": [c_int, c_int, _I3],
+    "xeq_message_wq_pack_weights": [_P, _P, c_int, c_int, _I3, _P, _P],
     "xeq_message_wq_edge_grad": [_P, c_int64, c_int64, _P, _P, _P, _I3, _P, _P, _P],
     "xeq_message_wq_edge_grad_sum": [_P, c_int64, c_int64, _P, _P, _P, _I3, c_int, ctypes.POINTER(c_void_p), _P, _P],
     "xeq_norm_fwd": [c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int, _I3, c_int, _P, c_int64, _P, _P, _P],
@@ -173,7 +176,7 @@ _PROTOS = {
                            _P, _P, _P],
 }
 # entry points that return a size, not a status
-_RET_I64 = {"xeq_launch_count", "xeq_rowptr_from_degrees_max", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
+_RET_I64 = {"xeq_launch_count", "xeq_message_wq_packed_weight_floats", "xeq_rowptr_from_degrees_max", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
             "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch", "xeq_tensor_product_wgrad_chunks"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 

@@ -754,6 +754,28 @@ def copy_many(pairs) -> None:
         call("xeq_copy_many", n, srcs, dsts, sizes, stream())
 
 
+_WQ_WEIGHT_PACKS = {}
+
+
+def wq_packed_weights(w_rbf: torch.Tensor, b_rbf: torch.Tensor, num_basis: int, node_dim: int, mul) -> torch.Tensor:
+    """rbf_lin's rows in the wq kernels' LDS layout, per unit (xeq_message_wq_pack_weights), cached per weight version and pack epoch.
+    The kernels' own staging reads W with one row per lane -- 64 cache lines per wave instruction -- between every two workgroups of
+    a CU slot; from this copy it is a coalesced 16-byte copy (~11 us per launch).  The cache holds the weight tensors themselves, so an
+    entry's address cannot be reused by another tensor while the entry lives (at most 32 entries)."""
+    key = (w_rbf.data_ptr(), w_rbf._version, b_rbf.data_ptr(), b_rbf._version, int(num_basis), int(node_dim), tuple(int(m) for m in mul),
+           lib.pack_epoch())
+    hit = _WQ_WEIGHT_PACKS.get(key)
+    if hit is not None:
+        return hit[0]
+    n = int(lib.load().xeq_message_wq_packed_weight_floats(int(num_basis), int(node_dim), mul3(mul)))
+    packed = torch.empty(n, dtype=torch.float32, device=w_rbf.device)
+    call("xeq_message_wq_pack_weights", ptr(w_rbf), ptr(b_rbf), int(num_basis), int(node_dim), mul3(mul), ptr(packed), stream())
+    if len(_WQ_WEIGHT_PACKS) >= 32:
+        _WQ_WEIGHT_PACKS.pop(next(iter(_WQ_WEIGHT_PACKS)))
+    _WQ_WEIGHT_PACKS[key] = (packed, w_rbf, b_rbf)
+    return packed
+
+
 def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, cfg, want_backward: bool = False):
     """Launch the fused message kernel.  cfg = (rbf_kind, cutoff_kind, num_basis, cutoff, node_dim, mul[, xhat_layout]).
     Returns (s_out, x_out, saved, impl): `saved` is what message_backward needs.  ``want_backward``: a reverse pass will follow
@@ -775,9 +797,10 @@ def message_forward(h, xhat, vec, s, x, w_rbf, b_rbf, p0, p1, graph: EdgeGraph, 
         plan = graph.wq_plan(False, _wq_edges_per_stream(E, N))
         basis, _ = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1,
                                  deriv=bool(want_backward and getattr(graph, "mirror_walk", False)))
+        wp = wq_packed_weights(w_rbf, b_rbf, num_basis, node_dim, mul)
         KERNEL_TIMER.launch("xeq_message_fwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), ptr(plan["rowptr"]),
-                            ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(w_rbf),
-                            ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl, stream(),
+                            ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(h), ptr(xhat), ptr(s), ptr(x), ptr(wp),
+                            None, num_basis, node_dim, mul3(mul), ptr(s_out), ptr(x_out), xl | lib.WQ_PACKED_WEIGHTS, stream(),
                             label="xeq_message_fwd_wq_first" if xl & lib.XHAT_HIGHER_L_ZERO else None)   # the first-block form moves fewer bytes
         return s_out, x_out, (h, xhat, vec, w_rbf, b_rbf, p0, p1, None, None), impl
     if impl == "sb":
@@ -845,11 +868,12 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
         mirror = getattr(graph, "mirror_walk", False)      # symmetric list: the forward plan and its records serve both directions
         plan = graph.wq_plan(not mirror, _wq_edges_per_stream(E, N))
         basis, dbasis = edge_basis_wq(vec, plan, N, rbf_kind, cutoff_kind, num_basis, cutoff, p0, p1, deriv=True)
-        xl_bwd = xl | (lib.WQ_MIRROR_WALK if mirror else 0)
+        xl_bwd = xl | (lib.WQ_MIRROR_WALK if mirror else 0) | lib.WQ_PACKED_WEIGHTS
+        wp = wq_packed_weights(w_rbf, b_rbf, num_basis, node_dim, mul)
         parts = torch.empty(max(1, lib.load().xeq_message_wq_parts_floats(N, E, mul3(mul))), dtype=h.dtype, device=h.device)
         KERNEL_TIMER.launch("xeq_message_bwd_wq", N, E, plan["n_ranges"], ptr(plan["sq"]), ptr(plan["sn"]), ptr(plan["win"]), ptr(plan["rowptr"]),
                             ptr(plan["pgath"]), ptr(plan["qinfo"]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x),
-                            ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl_bwd, stream(),
+                            ptr(wp), None, num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat), ptr(parts), xl_bwd, stream(),
                             label="xeq_message_bwd_wq_first" if (skip and xl & lib.XHAT_HIGHER_L_ZERO) else None)
         if deferral is not None:
             g_vec = deferral.add(parts, vec, graph, plan, mirror, mul)
