@@ -390,7 +390,7 @@ def test_launch_policy_is_stated_once_in_the_c_abi():
     assert fam(lib.XEQ_F32, 3_000_000, 150_000_000) == GENERIC   # beyond every 32-bit offset
     assert fam(lib.XEQ_F32, 2_500_000, 40_000_000) in (SB, GENERIC)
     eps = lambda n, e: int(L.xeq_message_wq_edges_per_stream(n, e))
-    assert eps(18609, 311994) == 64 and eps(192, 10390) == 54 and eps(21, 360) == 17 and eps(10, 20) == 16
+    assert eps(18609, 311994) == 80 and eps(192, 10390) == 54 and eps(21, 360) == 17 and eps(10, 20) == 16
     import inspect
 
     from xequinet_amd import ops

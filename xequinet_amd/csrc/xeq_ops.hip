@@ -386,12 +386,15 @@ int xeq_message_auto_family(int dtype, int64_t n_nodes, int64_t n_edges, int num
 
 int xeq_message_wq_edges_per_stream(int64_t n_nodes, int64_t n_edges) {
   // a step (eight half-wave streams) should gather from few enough nodes for its window to fit LDS: 64 edges per stream is ~30 owner
-  // nodes; small systems get shorter streams so that the launch still spreads over the chip, never below the mean segment length
+  // nodes; small systems get shorter streams so that the launch still spreads over the chip, never below the mean segment length.
+  // The cap was 64 up to round 4; since the workgroups stage their unit's weights from the packed copy (round 5) longer steps pay:
+  // QM9-1024 2.287 / 2.261 / 2.270 / 2.265 ms at 64 / 72 / 80 / 88, MD17 x 4096 9.20 / 9.07 / 8.92 / 8.99 ms, QM9 x 8192 14.96 / 14.90 /
+  // 14.76 / 14.61 ms (one box): 80.
   const double per_node = (double)n_edges / (double)(n_nodes > 0 ? n_nodes : 1);
   double v = per_node > 16.0 ? per_node : 16.0;
   const double spread = (double)n_edges / 1500.0;
   if (spread > v) v = spread;
-  if (v > 64.0) v = 64.0;
+  if (v > 80.0) v = 80.0;
   return (int)v;
 }
 
