@@ -198,6 +198,12 @@ def main():
     ap.add_argument("--lanes", type=int, default=-1, metavar="L",
                     help="whole-step graph of an open-boundary batch: evaluate the batch as L contiguous molecule ranges in parallel branches of "
                          "the one captured graph (runtime.GraphedLanes; results bit for bit those of L = 1).  Default: runtime.auto_lanes(atoms)")
+    ap.add_argument("--in-flight", type=int, default=2, metavar="D",
+                    help="whole-step graph of an open-boundary batch: D steps in flight (runtime.GraphedStepsInFlight: D contexts with their own "
+                         "buffers and captured graphs, each replayed on its own stream, in turn; every step's results are bit for bit those of "
+                         "D = 1).  The K timed steps are still K whole steps, all finished before the clock stops; what overlaps is the "
+                         "front / the tails of one step with the body of the next.  D = 1: one step at a time (also reported by the default "
+                         "run as ms_per_step_one_in_flight)")
     ap.add_argument("--train", action="store_true",
                     help="time ONE OPTIMISATION STEP per step instead of an inference step (SURVEY 8f-4; utils/trainer.py:290-308): forward in train "
                          "mode, weighted l2 loss, backward, Adam, the model wrapped in DistributedDataParallel when --gpus > 1 so that the timed "
@@ -281,6 +287,7 @@ def main():
 
     n_chunks = 1
     n_lanes = 1
+    n_flight = 1
     if sharded:
         max_edges = args.max_chunk_edges or runtime.WM_MAX_EDGES_PER_CHUNK
         n_chunks = len(xdist.plan_chunks(ptr, max_edges))
@@ -308,17 +315,24 @@ def main():
             draws.append((b_k.pos, b_k.atomic_numbers, b_k.ptr, ptr_k, b_k.batch))
         cap = (max(d[0].shape[0] for d in draws) + 64, len(ptr) - 1, max(runtime.pair_capacity(d[3]) for d in draws))
         n_lanes = args.lanes if args.lanes >= 1 else runtime.auto_lanes(cap[0])
+        n_flight = max(1, args.in_flight) if n_lanes == 1 else 1
         if n_lanes > 1:
             gstep = runtime.GraphedLanes(model, cap, lanes=n_lanes, compute_forces=True)
+        elif n_flight > 1:
+            gstep = runtime.GraphedStepsInFlight(model, cap, depth=n_flight, compute_forces=True)
         else:
             gstep = runtime.GraphedStep(model, cap, compute_forces=True)
         turn = [0]
+        ticket = [None]
 
         def step():
             p_k, z_k, ptr_k, ph_k, b_k = draws[turn[0] % len(draws)]
             turn[0] += 1
             # every replay adds its true edge count to the step's device-side counter (inside the neighbour-list launch); read once
             # behind the timed region
+            if n_flight > 1:                               # enqueue and go on: the step's results are fetched (and waited for) by ticket
+                ticket[0] = gstep.submit(p_k, z_k, ptr_k, batch=b_k)
+                return None, None
             out = gstep(p_k, z_k, ptr_k, b_k, ph_k) if n_lanes > 1 else gstep(p_k, z_k, ptr_k, batch=b_k)
             return None, out
     elif cell is not None and len(ptr) == 2 and not args.replay_model_only:
@@ -351,6 +365,8 @@ def main():
         for _ in range(args.warmup):
             n_edges, out = step()
         torch.cuda.synchronize()
+        if n_flight > 1:
+            out = gstep.result(ticket[0])
         if whole_step:
             n_edges = (sum(int(st.outputs["n_edges"].item()) for st in gstep.steps) if (cell is None and n_lanes > 1)
                        else int(out["n_edges"].item()))
@@ -375,7 +391,7 @@ def main():
     torch.cuda.synchronize()
     if whole_step:
         if cell is None:
-            for st in (gstep.steps if n_lanes > 1 else [gstep]):
+            for st in (gstep.steps if (n_lanes > 1 or n_flight > 1) else [gstep]):
                 st.edge_total.zero_()
         else:
             edge_total.zero_()
@@ -386,11 +402,25 @@ def main():
     for _ in range(args.steps):
         n_step, out = step()
         edges_done += n_step if n_step is not None else 0
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()                              # every step in flight has finished here
     xdist.barrier()
     elapsed = time.perf_counter() - t0
+    one_ms = None
+    if n_flight > 1:
+        out = gstep.result(ticket[0])
+        edges_timed = int(gstep.edge_total.item())
+        one = gstep.steps[0]                               # the same step, ONE at a time (its latency): context 0 replayed on this stream
+        p_k, z_k, ptr_k, _, b_k = draws[0]
+        for _ in range(3):
+            one(p_k, z_k, ptr_k, batch=b_k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one(p_k, z_k, ptr_k, batch=b_k)
+        torch.cuda.synchronize()
+        one_ms = (time.perf_counter() - t1) / args.steps * 1e3
     if whole_step:
-        edges_done = int((gstep.edge_total if cell is None else edge_total).item())   # the device-side counts of the K timed steps
+        edges_done = edges_timed if n_flight > 1 else int((gstep.edge_total if cell is None else edge_total).item())   # the device-side counts of the K timed steps
         if cell is not None:
             assert not gpbc.overflowed(), "the periodic list outgrew its capacity inside the timed region"
     eager_ms = native_ms = None
@@ -518,7 +548,7 @@ def main():
         line = {
             "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_eager": eager_ms if eager_ms is not None else ms_per_step,
-            "ms_per_step_native_op": native_ms,
+            "ms_per_step_native_op": native_ms, "ms_per_step_one_in_flight": one_ms if one_ms is not None else ms_per_step,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {syn.WORKLOADS[args.workload]} ({what}), 5 A cutoff, default XPaiNN (865141 params, "
@@ -529,10 +559,11 @@ def main():
                        "library_gemm_selection": ("no library GEMM on the f32 path since round 3 (every contraction is an xeq kernel)" if dtype == torch.float32 else
                                                   "default heuristics" if args.no_gemm_autotune else "timed once per shape in warm-up (TunableOp)"),
                        "launch": ("host launch per kernel" if args.eager else
-                                  (f"neighbour list + model as ONE captured HIP graph over capacity-sized arrays, edge count on the device (runtime.{'GraphedLanes: ' + str(n_lanes) + ' contiguous molecule ranges as parallel branches of the graph, results bit for bit those of one range' if n_lanes > 1 else 'GraphedStep'}; {max(1, args.vary_batch)} different draw(s) of the workload in turn)"
+                                  (f"neighbour list + model as ONE captured HIP graph over capacity-sized arrays, edge count on the device (runtime.{'GraphedLanes: ' + str(n_lanes) + ' contiguous molecule ranges as parallel branches of the graph, results bit for bit those of one range' if n_lanes > 1 else ('GraphedStepsInFlight: ' + str(n_flight) + ' steps in flight, each on its own stream with its own buffers, all K finished inside the timed region; results bit for bit those of one at a time, whose time is ms_per_step_one_in_flight') if n_flight > 1 else 'GraphedStep'}; {max(1, args.vary_batch)} different draw(s) of the workload in turn)"
                                    if cell is None else "periodic neighbour search + model as ONE captured HIP graph over capacity-sized edge arrays, edge count on the device (runtime.GraphedStepPBC)")
                                   if whole_step else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host"),
                        "ms_per_step_eager": "the same step with every kernel launched from the host through the Python modules, measured on rank 0 right after the timed region",
+                       "in_flight": n_flight,
                        "ms_per_step_native_op": "the same step as ONE registered operator (xeq::xpainn_eval: kernels enqueued from C++, no capture): what a stream of batches with ever-new edge counts pays"},
             "roofline": roofline,
         }

@@ -451,6 +451,42 @@ def test_two_lanes_in_one_graph_equal_the_unsplit_step_bit_for_bit():
     assert int(two.edge_total) == int(one.edge_total)
 
 
+def test_steps_in_flight_equal_one_at_a_time_bit_for_bit():
+    """runtime.GraphedStepsInFlight: a stream of DIFFERENT batches with two (and three) steps in flight -- each on its own stream with
+    its own buffers -- gives every batch the energies / forces / edge count of a lone runtime.GraphedStep bit for bit, in submit order;
+    a ticket whose buffers were reused is refused; the device-side edge total is the sum over all submits."""
+    from xequinet_amd import runtime
+
+    model, _ = _build(torch.float32)
+    draws = []
+    for seed in (1234, 77, 5, 901, 42):
+        pos, z, ptr, _ = syn.make_workload("qm9_256", seed=seed)
+        draws.append((_t(pos, torch.float32), _t(z), _t(ptr)))
+    cap = (max(d[0].shape[0] for d in draws) + 64, 256, max(runtime.pair_capacity(d[2].cpu().numpy()) for d in draws))
+    one = runtime.GraphedStep(model, cap)
+    want = []
+    for d in draws:
+        o = one(*d)
+        want.append((o["energy"].clone(), o["forces"].clone(), int(o["n_edges"])))
+    for depth in (2, 3):
+        fl = runtime.GraphedStepsInFlight(model, cap, depth=depth)
+        order = [0, 1, 2, 3, 4, 2, 0, 4, 1, 3, 3]
+        tickets = []
+        for k, i in enumerate(order):
+            tickets.append(fl.submit(*draws[i]))
+            if k >= depth - 1:                               # the oldest step still in flight: fetch it while the newer ones run
+                t = tickets[k - depth + 1]
+                o = fl.result(t)
+                E, F, n = want[order[t]]
+                assert torch.equal(o["energy"], E) and torch.equal(o["forces"], F) and int(o["n_edges"]) == n
+        with pytest.raises(ValueError, match="reused"):
+            fl.result(tickets[0])
+        assert int(fl.edge_total) == sum(want[i][2] for i in order)
+        assert all(st.captures == 1 for st in fl.steps) and not fl.overflowed()
+        o = fl(*draws[1])                                     # the call form: submit + result
+        assert torch.equal(o["forces"], want[1][1])
+
+
 @pytest.mark.parametrize("forces", [False, True])
 def test_bench_train_mode_times_a_ddp_step_over_two_ranks_on_one_card(forces):
     """`bench.py --train [--forces] --gpus 2`: one optimisation step per timed step, the model in DistributedDataParallel, so the step

@@ -338,8 +338,10 @@ class GraphedStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                counted = self.edge_total.clone()
                 for _ in range(self.warmup):
                     self._step()
+                self.edge_total.copy_(counted)                  # the warm-up runs are not steps: they leave the edge counter alone
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -435,9 +437,12 @@ class GraphedLanes:
         side = torch.cuda.Stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            counted = [st.edge_total.clone() for st in self.steps]
             for _ in range(self.warmup):
                 for st in self.steps:
                     st._step()
+            for st, c in zip(self.steps, counted):
+                st.edge_total.copy_(c)                          # the warm-up runs are not steps
         main.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         outs = [None] * self.lanes
@@ -488,6 +493,90 @@ class GraphedLanes:
         if self.forces is not None:
             out[keys.FORCES] = self.forces[:n]
         return out
+
+
+class GraphedStepsInFlight:
+    """A STREAM of batches with ``depth`` of them in flight: ``depth`` independent ``GraphedStep`` contexts (their own static buffers
+    and captured graphs), each replayed on its own HIP stream, taken in turn.
+
+    Why: one whole step is a chain of 29 launches whose front (load, count / scan / fill of the neighbour list, reverse map, walk plan,
+    records: ~110 us of launches that fill a fraction of the chip) and whose tails (the last workgroups of every big launch) leave
+    CUs idle; nothing in step k+1 depends on step k (batches are independent: run/inference.py:39-75 walks a DataLoader), so the next
+    batch's step is issued on another stream while this one runs and its kernels fill those holes.  Measured on QM9-1024
+    (profiles/r05_in_flight.txt): 2.28 -> 2.03 ms per step with two in flight, nothing more from three.  A step's LATENCY does not
+    shorten (it grows by what the other step's kernels take from it); the gain is throughput of a stream of batches.
+
+    Every context's results are the bits of a lone ``GraphedStep`` (same kernels on the same static shapes; no kernel's result
+    depends on what runs beside it).
+
+        t = steps.submit(pos, z, ptr[, batch])     # enqueue; returns a ticket at once, nothing waits
+        out = steps.result(t)                      # the CALLER's stream waits for that step; views valid until ``depth`` submits later
+    """
+
+    def __init__(self, model: torch.nn.Module, capacity, depth: int = 2, **kw) -> None:
+        assert depth >= 1
+        self.depth = int(depth)
+        self.steps = [GraphedStep(model, capacity, **kw) for _ in range(self.depth)]
+        dev = self.steps[0].pos.device
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)]
+        self._done = [torch.cuda.Event() for _ in range(self.depth)]
+        self._out = [None] * self.depth
+        self._serial = [-1] * self.depth
+        self.submitted = 0
+
+    @property
+    def edge_total(self) -> torch.Tensor:
+        """Edges of every step submitted so far (a device scalar on the caller's stream; waits for the steps in flight)."""
+        self.drain()
+        return torch.stack([st.edge_total for st in self.steps]).sum(0)
+
+    def zero_edge_total(self) -> None:
+        self.drain()
+        cur = torch.cuda.current_stream()
+        for st, s in zip(self.steps, self._streams):
+            st.edge_total.zero_()
+            s.wait_stream(cur)
+
+    def submit(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor] = None,
+               ptr_host=None) -> int:
+        """Enqueue one step on the next context's stream (behind whatever the caller's stream has enqueued so far: the inputs may
+        have been produced there).  The context's previous step -- ``depth`` submits ago -- is ahead of it on the same stream, so
+        its static buffers are free by the time they are overwritten."""
+        i = self.submitted % self.depth
+        s = self._streams[i]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._out[i] = self.steps[i](pos, atomic_numbers, ptr, batch, ptr_host)
+            self._done[i].record(s)
+        for t in (pos, atomic_numbers, ptr, batch):
+            if t is not None and t.is_cuda:
+                t.record_stream(s)                           # the caching allocator must not hand the inputs out while the side stream reads them
+        self._serial[i] = self.submitted
+        self.submitted += 1
+        return self._serial[i]
+
+    def result(self, ticket: int) -> Dict[str, torch.Tensor]:
+        """The outputs of submit number ``ticket``, ordered into the caller's stream (no host synchronisation)."""
+        i = ticket % self.depth
+        if self._serial[i] != ticket:
+            raise ValueError(f"GraphedStepsInFlight: the buffers of step {ticket} were reused by step {self._serial[i]} (depth {self.depth})")
+        torch.cuda.current_stream().wait_event(self._done[i])
+        return self._out[i]
+
+    def drain(self) -> None:
+        """The caller's stream waits for every step in flight."""
+        cur = torch.cuda.current_stream()
+        for i in range(self.depth):
+            if self._serial[i] >= 0:
+                cur.wait_event(self._done[i])
+
+    def __call__(self, pos, atomic_numbers, ptr, batch=None, ptr_host=None) -> Dict[str, torch.Tensor]:
+        """One step, waited for (the GraphedStep call form; nothing overlaps this way)."""
+        return self.result(self.submit(pos, atomic_numbers, ptr, batch, ptr_host))
+
+    def overflowed(self) -> bool:
+        self.drain()
+        return any(st.overflowed() for st in self.steps)
 
 
 class GraphedStepPBC:
