@@ -409,7 +409,7 @@ def main():
     if n_flight > 1:
         out = gstep.result(ticket[0])
         edges_timed = int(gstep.edge_total.item())
-        one = gstep.steps[0]                               # the same step, ONE at a time (its latency): context 0 replayed on this stream
+        one = runtime.GraphedStep(model, cap, compute_forces=True)   # the same step, ONE at a time (its latency): a lone step's own capture
         p_k, z_k, ptr_k, _, b_k = draws[0]
         for _ in range(3):
             one(p_k, z_k, ptr_k, batch=b_k)

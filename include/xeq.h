@@ -720,6 +720,10 @@ int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]);
 /* launch policy (host only): 1 when an evaluation of n nodes should take the fused launches (n >= XEQ_NODE_BLOCK_MIN_NODES, default
  * 6 144; XEQ_NODE_BLOCK=0: never).  Below that the chain of small kernels is faster (a fused launch is one serial chain per wave). */
 int xeq_node_block_auto(int64_t n);
+/* waves per workgroup of the node-block launches that follow (host only, process-wide): 0 = by node count (one workgroup per CU of 5 .. 8
+ * waves between 4 097 and 8 192 wave-blocks of 16 nodes, four otherwise: a lone launch ends with its slowest CU), 4 .. 8 = fixed.  Results
+ * do not depend on it.  -> the former setting; -1: out of range, nothing changed. */
+int xeq_node_block_set_waves(int waves);
 int64_t xeq_node_block_rows(int64_t n);
 int64_t xeq_node_block_fwd_tiles(int with_tail);
 int xeq_node_block_pack_fwd(const float* w3, const float* uv0, const float* uv1, const float* uv2, const float* dot, const float* w4,

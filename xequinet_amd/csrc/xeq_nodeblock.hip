@@ -32,6 +32,7 @@
 // v_pk_fma_f32 / v_pk_add_f32 on matrix-core results gave sporadic wrong values in one 16-lane row (profiles/r04_nodeblock.txt item 9c);
 // tests/test_gpu_nodeblock.py::test_node_block_at_full_size_equals_itself_on_slices is the check that shows it.
 #include <stdlib.h>
+#include <atomic>
 
 #include <vector>
 
@@ -1474,9 +1475,12 @@ static hipError_t raise_lds() {
 // per CU of 5 .. 8 waves (the extra waves only read the weight ring), so that no CU carries twice the load of another.  Up to one
 // four-wave workgroup per CU, and from two per CU on (several rounds), workgroups of four as before.  Results do not depend on the
 // choice: a wave's 16 nodes see the same weights in the same order in any workgroup.
+static std::atomic<int> g_waves_override{0};   // xeq_node_block_set_waves
 static int waves_for(int64_t n) {
   const char* v = getenv("XEQ_NODE_BLOCK_WAVES");   // development / tests: a fixed workgroup size (read per call: a test flips it)
-  const int forced = v ? atoi(v) : 0;
+  int forced = v ? atoi(v) : 0;
+  if (forced >= 4 && forced <= MAX_WAVES) return forced;
+  forced = g_waves_override.load(std::memory_order_relaxed);
   if (forced >= 4 && forced <= MAX_WAVES) return forced;
   const int64_t blocks16 = (n + WAVE_ROWS - 1) / WAVE_ROWS;   // waves needed
   const int64_t cus = 256;
@@ -1493,6 +1497,14 @@ using namespace xeq;
 using namespace xeq::nb;
 
 extern "C" {
+
+/* Waves per workgroup of the launches that follow, process-wide (0: the rule of waves_for above; 4 .. 8: fixed).  -> the former value, -1
+ * for a value out of range.  Results do not depend on it.  runtime.GraphedStepsInFlight asks for four: with a second step's kernels on
+ * the chip the CUs that finish early are not idle, and two four-wave workgroups share a CU where one of five to eight fills it. */
+int xeq_node_block_set_waves(int waves) {
+  if (waves != 0 && (waves < 4 || waves > MAX_WAVES)) return -1;
+  return g_waves_override.exchange(waves, std::memory_order_relaxed);
+}
 
 /* Launch policy, stated once for both fronts (nn/xpainn.py, csrc/xeq_torch.cpp): whether a force evaluation of n nodes takes the fused
  * node-block launches.  A wave owns 16 nodes and walks the whole chain of its block, so a launch takes about as long for 1 500 nodes as

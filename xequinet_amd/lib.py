@@ -166,6 +166,7 @@ _PROTOS = {
     "xeq_node_block_fwd_tiles": [c_int],
     "xeq_node_block_rows": [c_int64],
     "xeq_node_block_auto": [c_int64],
+    "xeq_node_block_set_waves": [c_int],
     "xeq_node_block_pack_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "xeq_node_block_fwd": [c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                            _P, _P, _P, _P, _P],

@@ -513,6 +513,8 @@ class GraphedStepsInFlight:
         out = steps.result(t)                      # the CALLER's stream waits for that step; views valid until ``depth`` submits later
     """
 
+    NODE_BLOCK_WAVES = 4
+
     def __init__(self, model: torch.nn.Module, capacity, depth: int = 2, **kw) -> None:
         assert depth >= 1
         self.depth = int(depth)
@@ -545,9 +547,17 @@ class GraphedStepsInFlight:
         i = self.submitted % self.depth
         s = self._streams[i]
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self._out[i] = self.steps[i](pos, atomic_numbers, ptr, batch, ptr_host)
-            self._done[i].record(s)
+        L = ops.lib.load()
+        # workgroups of four waves for the node-block launches captured here (the setting is read at launch, i.e. at capture): next to
+        # another step's kernels a CU that finishes early is not idle (profiles/r05_in_flight.txt: 2.00 -> 1.89 ms)
+        former = L.xeq_node_block_set_waves(self.NODE_BLOCK_WAVES) if self.depth > 1 else None
+        try:
+            with torch.cuda.stream(s):
+                self._out[i] = self.steps[i](pos, atomic_numbers, ptr, batch, ptr_host)
+                self._done[i].record(s)
+        finally:
+            if former is not None:
+                L.xeq_node_block_set_waves(former)
         for t in (pos, atomic_numbers, ptr, batch):
             if t is not None and t.is_cuda:
                 t.record_stream(s)                           # the caching allocator must not hand the inputs out while the side stream reads them
