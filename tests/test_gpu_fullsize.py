@@ -485,6 +485,13 @@ def test_steps_in_flight_equal_one_at_a_time_bit_for_bit():
         assert all(st.captures == 1 for st in fl.steps) and not fl.overflowed()
         o = fl(*draws[1])                                     # the call form: submit + result
         assert torch.equal(o["forces"], want[1][1])
+    # the loop over a stream of batches (run/inference.py:39-75): results in order, own copies
+    got = list(runtime.evaluate_batches(model, (draws[i] for i in (3, 0, 4, 1, 2)), cap))
+    assert len(got) == 5
+    for o, i in zip(got, (3, 0, 4, 1, 2)):
+        n, g = draws[i][0].shape[0], draws[i][2].numel() - 1
+        assert o["energy"].shape == (g,) and o["forces"].shape == (n, 3)
+        assert torch.equal(o["energy"], want[i][0]) and torch.equal(o["forces"], want[i][1]) and int(o["n_edges"]) == want[i][2]
 
 
 @pytest.mark.parametrize("forces", [False, True])

@@ -589,6 +589,28 @@ class GraphedStepsInFlight:
         return any(st.overflowed() for st in self.steps)
 
 
+def evaluate_batches(model: torch.nn.Module, batches, capacity, depth: int = 2, compute_forces: bool = True):
+    """The loop of run/inference.py:39-75 over an iterable of open-boundary batches ``(pos, atomic_numbers, ptr[, batch])`` already on the
+    device, with ``depth`` steps in flight (``GraphedStepsInFlight``): yields one dict per batch, in order -- energy [G], atomic_energies [n],
+    forces [n, 3] (own copies), n_edges (device scalar) -- each while the next ``depth - 1`` batches are already running.
+    ``capacity = (atoms, graphs, edges)`` must bound every batch (``pair_capacity(ptr_host)`` bounds a batch's edges)."""
+    from collections import deque
+
+    fl = GraphedStepsInFlight(model, capacity, depth=depth, compute_forces=compute_forces)
+    pending = deque()
+
+    def fetch():
+        out = fl.result(pending.popleft())
+        return {k: v.clone() for k, v in out.items()}           # (on the caller's stream, behind the step's event)
+
+    for b in batches:
+        pending.append(fl.submit(*b))
+        if len(pending) == fl.depth:
+            yield fetch()
+    while pending:
+        yield fetch()
+
+
 class GraphedStepPBC:
     """Neighbour search + model of ONE periodic (or open) system as one captured HIP graph: what an MD engine that hands over
     positions and a box per step runs (the GROMACS-style model, interface/jit_model.py:183-216: ``single_radius_graph`` inside
