@@ -46,6 +46,10 @@ const char* xeq_last_error(void);
  * Test infrastructure: tests/test_gpu_parity.py::_aten_only proves with it that the ATen-only evaluation of the reference's op
  * sequence -- a member of the fp32 error envelope -- launched no kernel of this library. */
 int64_t xeq_launch_count(void);
+/* The entry-point names of launches number first .. xeq_launch_count() - 1, one per line, into buf (NUL-terminated).  -> the bytes needed
+ * (call with buf = NULL to size it); -1 when `first` is out of range or older than the last 8 192 launches.  Test infrastructure:
+ * tests/test_gpu_interface.py compares the launch SEQUENCES of the two fronts (Python modules, xeq::xpainn_eval) with it. */
+int64_t xeq_launch_names(int64_t first, char* buf, int64_t cap);
 
 /* ------------------------------------------------------------------ graph */
 

@@ -254,8 +254,11 @@ def test_replay_with_timed_gemm_selection_meets_the_fp32_parity_bar():
 
 
 # ------------------------------------------------------------------ TorchScript front ends (registered xeq:: operators)
-def _native_vs_python(dtype, periodic):
-    """xeq::xpainn_eval (C++: csrc/xeq_torch.cpp) against the Python modules (nn/fused.py): same kernels, same order."""
+def _native_vs_python(dtype, periodic, n_mol=24, trace=False):
+    """xeq::xpainn_eval (C++: csrc/xeq_torch.cpp) against the Python modules (nn/fused.py): same kernels, same order.
+    ``trace``: additionally the two fronts' launch sequences (entry-point names, include/xeq.h: xeq_launch_names) of one evaluation each,
+    both building the sorted views and walk plans themselves (a fresh EdgeGraph with the list builder's promises for the Python front)."""
+    from xequinet_amd import keys, lib, ops
     from xequinet_amd.data import NeighborTransform, XequiBatch
     from xequinet_amd.interface.scripted import XPaiNNNative
 
@@ -269,15 +272,32 @@ def _native_vs_python(dtype, periodic):
                 "cell_offsets": P._t(f["cell_offsets"], dtype)}
         cs, sym = True, False
     else:
-        pos, z, ptr = syn.synth_qm9_batch(24, seed=13)
+        pos, z, ptr = syn.synth_qm9_batch(n_mol, seed=13)
         b = NeighborTransform(5.0)(XequiBatch(P._t(pos, dtype), P._t(z), P._t(ptr)))
         data = b.to_dict()
         cs, sym = True, True
-    with torch.enable_grad():
-        want = model(dict(data), compute_forces=True, compute_virial=periodic)
-    got = native(data["pos"].detach(), data["atomic_numbers"], data["edge_index"], data["ptr"], data.get("cell"),
-                 data.get("cell_offsets"), cs, sym, True, periodic)
-    return got, want
+
+    def py():
+        d = dict(data)
+        if trace:
+            d[keys.EDGE_GRAPH] = ops.EdgeGraph(data["edge_index"], data["pos"].shape[0], center_sorted=cs, ptr=data["ptr"], symmetric=sym)
+        with torch.enable_grad():
+            return model(d, compute_forces=True, compute_virial=periodic)
+
+    def cc():
+        return native(data["pos"].detach(), data["atomic_numbers"], data["edge_index"], data["ptr"], data.get("cell"),
+                      data.get("cell_offsets"), cs, sym, True, periodic)
+
+    if not trace:
+        want = py()
+        return cc(), want
+    py(), cc()                                               # packed weights, element tables, cached constants: not part of a steady evaluation
+    c0 = lib.launch_count()
+    want = py()
+    seq_py = lib.launch_names(c0)
+    c0 = lib.launch_count()
+    got = cc()
+    return got, want, seq_py, lib.launch_names(c0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
@@ -289,6 +309,19 @@ def test_native_operator_equals_python_modules_bitwise(dtype, periodic):
     assert torch.equal(got[2], want["forces"].detach()), (got[2] - want["forces"]).abs().max()
     if periodic:
         assert torch.equal(got[3], want["virial"].detach()), (got[3] - want["virial"]).abs().max()
+
+
+@pytest.mark.parametrize("n_mol", [24, 400])
+def test_both_fronts_issue_the_same_launch_sequence(n_mol):
+    """One kernel sequence, two fronts: the entry points of libxeq_hip.so that one f32 open-boundary force evaluation launches -- through the
+    Python modules and through xeq::xpainn_eval -- are the same names in the same order (24 molecules: the chain of small node kernels;
+    400 molecules, 7 187 atoms: the fused node blocks), and the results are bit for bit equal at both sizes.  The second holds because
+    both fronts seed the reverse pass with MINUS one: the node block's bf16 matrix products are not symmetric in the sign
+    (profiles/r05_mfma_sign.txt), a +1 seed negated afterwards differs in the last bits."""
+    got, want, seq_py, seq_cc = _native_vs_python(torch.float32, False, n_mol=n_mol, trace=True)
+    assert seq_py == seq_cc, "\n".join(f"{a:36s} {b}" for a, b in zip(seq_py + ["-"] * len(seq_cc), seq_cc + ["-"] * len(seq_py)) if a != b)
+    assert ("xeq_node_block_fwd" in seq_py) == (n_mol >= 400) and "xeq_first_block_front" in seq_py and "xeq_head_bwd" in seq_py
+    assert torch.equal(got[0], want["energy"].detach()) and torch.equal(got[2], want["forces"].detach())
 
 
 def test_compile_model_scripts_saves_reloads_and_reproduces(tmp_path):

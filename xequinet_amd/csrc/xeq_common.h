@@ -14,7 +14,7 @@
 namespace xeq {
 
 void set_error(const char* fmt, ...);
-void note_launch();   // counts kernel launches of this library (xeq_launch_count: lets a test prove that a code path launched none)
+void note_launch(const char* name);   // counts and names the kernel launches of this library (xeq_launch_count / xeq_launch_names; name: a string literal)
 
 #define XEQ_CHECK_ARG(cond, ...)        \
   do {                                  \
@@ -26,7 +26,7 @@ void note_launch();   // counts kernel launches of this library (xeq_launch_coun
 
 #define XEQ_CHECK_LAUNCH(name)                                                   \
   do {                                                                           \
-    xeq::note_launch();                                                          \
+    xeq::note_launch(name);                                                      \
     hipError_t e_ = hipGetLastError();                                           \
     if (e_ != hipSuccess) {                                                      \
       xeq::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \

@@ -20,7 +20,9 @@ void set_error(const char* fmt, ...) {
 }
 
 static std::atomic<int64_t> g_launches{0};
-void note_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+constexpr int64_t LAUNCH_RING = 8192;            // names of the last launches (pointers to string literals), for xeq_launch_names
+static const char* g_launch_ring[LAUNCH_RING];
+void note_launch(const char* name) { g_launch_ring[g_launches.fetch_add(1, std::memory_order_relaxed) & (LAUNCH_RING - 1)] = name; }
 
 // ---------------------------------------------------------------- CSR helpers
 __global__ void k_csr_rowptr(const int64_t* __restrict__ keys, int64_t n_keys, int64_t n_rows,
@@ -736,6 +738,26 @@ extern "C" {
 int xeq_version(void) { return 100; }
 const char* xeq_last_error(void) { return xeq::g_err; }
 int64_t xeq_launch_count(void) { return xeq::g_launches.load(std::memory_order_relaxed); }
+int64_t xeq_launch_names(int64_t first, char* buf, int64_t cap) {
+  const int64_t last = xeq::g_launches.load(std::memory_order_relaxed);
+  if (first < 0 || first > last || last - first > xeq::LAUNCH_RING) return -1;
+  int64_t need = 1;
+  for (int64_t i = first; i < last; ++i) {
+    const char* s = xeq::g_launch_ring[i & (xeq::LAUNCH_RING - 1)];
+    need += (int64_t)strlen(s ? s : "?") + 1;
+  }
+  if (buf == nullptr || cap < need) return need;
+  char* p = buf;
+  for (int64_t i = first; i < last; ++i) {
+    const char* s = xeq::g_launch_ring[i & (xeq::LAUNCH_RING - 1)];
+    const size_t n = strlen(s ? s : "?");
+    memcpy(p, s ? s : "?", n);
+    p += n;
+    *p++ = '\n';
+  }
+  *p = 0;
+  return need;
+}
 
 int xeq_csr_rowptr(const int64_t* keys, int64_t n_keys, int64_t n_rows, int32_t* rowptr, void* stream) {
   XEQ_CHECK_ARG(n_keys >= 0 && n_rows >= 0 && n_keys < (1ll << 31), "xeq_csr_rowptr: bad sizes");

@@ -21,6 +21,7 @@
 //                         interface/jit_model.py:183-195).
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
@@ -516,6 +517,28 @@ void norm_bwd(const Hyper& hy, const Tensor& s, const Tensor& x, const Tensor& l
 }
 
 // what one block keeps for the reverse pass
+// The seed of an inference reverse pass behind the fused head: MINUS one (a [1] f32 constant, cached per device; nn/basic.py::_seed and
+// nn/fused.py::constant_vector are the Python twins).  The reverse pass then returns -dE/dx = the forces without a negation launch -- and
+// with the bits of the Python front: the bf16 matrix instructions are not symmetric in the sign (profiles/r05_mfma_sign.txt), so a pass
+// seeded with +1 and negated afterwards differs in the last bit wherever a cotangent runs through the fused node block.  Not cached while
+// a HIP graph is being captured (the tensor would live in that graph's pool).
+Tensor minus_one(const at::TensorOptions& fopt) {
+  static std::mutex mu;
+  static std::unordered_map<int, Tensor> cache;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing((hipStream_t)cur_stream(), &capturing);
+  std::lock_guard<std::mutex> lock(mu);
+  const int dev = (int)fopt.device().index();
+  auto it = cache.find(dev);
+  if (it != cache.end()) return it->second;
+  Tensor t = at::full({1}, -1.0, fopt.dtype(at::kFloat));
+  if (capturing == hipStreamCaptureStatusNone) {
+    (void)hipStreamSynchronize((hipStream_t)cur_stream());   // once: complete before any other stream may read it
+    cache[dev] = t;
+  }
+  return t;
+}
+
 struct MsgSaved {
   Tensor s, x, stats, pre, h, xhat;
   int impl = 0;   // 0 wq, 1 sb
@@ -560,7 +583,10 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   const Tensor ei_c = edge_index.contiguous();
   const int64_t E = ei_c.size(1);
 
-  // ---- edge geometry (nn/basic.py:110-131)
+  // ---- sorted views of the edge list (ops.EdgeGraph), then the edge geometry (nn/basic.py:110-131): the order of the Python front
+  // (nn/basic.py::compute_edge_data builds the graph first), so that both fronts issue ONE launch sequence
+  // (tests/test_gpu_interface.py::test_both_fronts_issue_the_same_launch_sequence)
+  Graph g = build_graph(ei_c, N, center_sorted, symmetric);
   Tensor cell, cell_offsets, batch;
   const bool has_cell = cell_o.has_value() && cell_o->defined();
   if (has_cell) {
@@ -616,9 +642,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   const Tensor& p0 = prm[3];
   const Tensor& p1 = prm[4];
 
-  // ---- the first block's norms and scalar MLP go out BEFORE the graph / walk-plan kernels: they depend on the embedding only,
-  // and their ~70 us of GPU work let the host run ahead through the two dozen short plan launches that follow (enqueued behind
-  // the caller's read-back of the edge count, those would otherwise find the queue empty)
+  // ---- the first block's norms and scalar MLP where the table form above does not cover the layout (per-node launches)
   if (hy.blocks > 0 && !front_done) {
     const Tensor* q = &prm[P_BLOCK0];
     MsgSaved& m = msv[0];
@@ -629,8 +653,6 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
     m.xhat = no.xhat;
     mlp_fwd(no.shat, q[0], q[1], q[2], q[3], m.pre, m.h);
   }
-  Graph g = build_graph(ei_c, N, center_sorted, symmetric);
-
   if (impl == 0) {
     build_wq_plan(g, false, g.fwd);
     g.fwd.basis = at::empty({g.fwd.pcap, xeq_message_wq_record_floats_for(hy.B)}, fopt);
@@ -785,8 +807,12 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   if (compute_forces || compute_virial) {
     // ---- explicit reverse pass: dE/ds of the head, then the blocks backwards, then the edge geometry (nn/basic.py:143-199)
     Tensor g_s;   // dE_i/d atomic_i = 1
+    const bool neg_seed = head_fused;   // the reverse pass runs on MINUS the gradient: forces (and the virial) come out without a negation
     if (head_fused) {
-      g_s = jac;    // d atomic_i / d s_i, saved by the forward launch
+      // (seed) x d atomic_i / d s_i, the row saved by the forward launch (nn/fused.py::EnergyReadout.backward)
+      const Tensor seed = minus_one(fopt);
+      g_s = at::empty_like(jac);
+      XCALL(xeq_head_bwd(jac.data_ptr(), N, F, nullptr, 0, seed.data_ptr(), 0, nullptr, g_s.data_ptr(), st));
     } else if (head_native) {
       Tensor g_hidden = at::empty_like(pre_o);
       XCALL(xeq_head_bwd_hidden(pre_o.data_ptr(), N, (int)pre_o.size(1), t[2].data_ptr(), nullptr, g_hidden.data_ptr(), st));
@@ -933,7 +959,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       XCALL(xeq_edge_vectors_bwd(dt, g_vec_total.data_ptr(), N, (const int32_t*)g.c_rowptr.data_ptr(),
                                  g.c_perm.defined() ? (const int32_t*)g.c_perm.data_ptr() : nullptr,
                                  (const int32_t*)g.n_rowptr.data_ptr(), (const int32_t*)g.n_perm.data_ptr(), grad_pos.data_ptr(), st));
-      forces = grad_pos.neg();
+      forces = neg_seed ? grad_pos : grad_pos.neg();
     }
     if (compute_virial) {   // sym(sum_e vec_e (x) dE/dvec_e) per graph, edges walked center-sorted (ops.EdgeVectors.backward)
       Tensor outer = (vec.unsqueeze(2) * g_vec_total.unsqueeze(1)).reshape({-1, 9});
@@ -943,7 +969,8 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       Tensor msum = at::empty({G, 9}, fopt);
       XCALL(xeq_segment_sum(dt, outer.data_ptr(), (const int64_t*)eptr.data_ptr(), G, 9, msum.data_ptr(), st));
       msum = msum.view({G, 3, 3});
-      virial = (0.5 * (msum + msum.transpose(1, 2))).neg();
+      virial = 0.5 * (msum + msum.transpose(1, 2));
+      if (!neg_seed) virial = virial.neg();
     }
   }
   if (!forces.defined()) forces = at::empty({0, 3}, fopt);

@@ -33,6 +33,7 @@ _I3 = ctypes.POINTER(c_int32)
 # name -> argtypes, exactly the prototypes of include/xeq.h
 _PROTOS = {
     "xeq_launch_count": [],
+    "xeq_launch_names": [c_int64, c_char_p, c_int64],
     "xeq_csr_rowptr": [_P, c_int64, c_int64, _P, _P],
     "xeq_csr_by_key_workspace": [c_int64, c_int64],
     "xeq_csr_by_key": [_P, c_int64, c_int64, _P, c_int64, _P, _P, _P],
@@ -177,7 +178,7 @@ _PROTOS = {
                            _P, _P, _P],
 }
 # entry points that return a size, not a status
-_RET_I64 = {"xeq_launch_count", "xeq_message_wq_packed_weight_floats", "xeq_rowptr_from_degrees_max", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
+_RET_I64 = {"xeq_launch_count", "xeq_launch_names", "xeq_message_wq_packed_weight_floats", "xeq_rowptr_from_degrees_max", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
             "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch", "xeq_tensor_product_wgrad_chunks"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
@@ -218,6 +219,17 @@ def bump_pack_epoch() -> None:
 def launch_count() -> int:
     """Kernel launches libxeq_hip.so has enqueued in this process (include/xeq.h: xeq_launch_count)."""
     return int(load().xeq_launch_count())
+
+
+def launch_names(first: int) -> list:
+    """Entry-point names of the launches numbered ``first`` .. launch_count() - 1, in order (include/xeq.h: xeq_launch_names)."""
+    L = load()
+    need = int(L.xeq_launch_names(int(first), None, 0))
+    if need < 0:
+        raise ValueError("launch_names: the range is out of the library's ring of names")
+    buf = ctypes.create_string_buffer(need)
+    L.xeq_launch_names(int(first), buf, need)
+    return [n for n in buf.value.decode().split("\n") if n]
 
 
 def call(name: str, *args) -> None:

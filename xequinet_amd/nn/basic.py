@@ -96,8 +96,12 @@ def compute_edge_data(
 def _seed(energy: torch.Tensor, training: bool):
     """(grad_outputs, sign) of a force / virial evaluation.  The reference seeds the reverse pass with ones and negates the result
     (nn/basic.py:150-159).  Outside a training pass the seed is MINUS ones -- a cached constant, no fill launch -- and the reverse pass,
-    linear in its seed, returns -dE/dx with the very bits of the negated +1 result (IEEE rounding is symmetric in the sign): one fill
-    and one negation launch less per evaluation.  A training pass (create_graph) keeps the reference's form."""
+    linear in its seed, returns -dE/dx: one fill and one negation launch less per evaluation.  The bits are those of the negated +1
+    result wherever the cotangents run through IEEE operations and the exact-f32 matrix instruction (symmetric in the sign: the message
+    kernels, the small-system chain, every f64 kernel); the fused node block puts them through bf16 matrix products, which are NOT
+    symmetric (profiles/r05_mfma_sign.txt: 1-2 results in 10 000 differ in the last bit), so there the forces differ from the
+    reference's form in the last bits (<= 1e-6 on forces of order one) -- both fronts seed alike (csrc/xeq_torch.cpp::minus_one) and stay
+    bit-identical to each other.  A training pass (create_graph) keeps the reference's form."""
     if training or not energy.is_cuda or energy.dim() != 1:
         return [torch.ones_like(energy)], -1.0
     from .fused import constant_vector
