@@ -186,6 +186,16 @@ int xeq_radius_graph_pbc_fill_cl(int dtype, const void* pos_wrap, const int64_t*
  * rev[e] = -1 where the reverse edge is missing (the list was not symmetric). */
 int xeq_reverse_edge_map(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, const int32_t* c_rowptr,
                          int32_t* rev, void* stream);
+/* The same for a PERIODIC list of the builders below (xeq_radius_graph_pbc_*: center-sorted, a center's edges ascending in (neighbor,
+ * image)): rev[e] = position of (j <- i, -offset) for e = (i <- j, offset), -1 where the list holds no such edge.  Such a list is
+ * symmetric up to a rounding at the cutoff -- the reference forms |pos_i - (pos_j + image)| (data/radius_graph.py:117-121), and the two
+ * directions round differently -- so a -1 can occur for an edge within an ulp of the cutoff, where the envelope is ~1e-14 (and its
+ * slope ~1e-7 of the scale): the consumers of a mirror map (XEQ_WQ_MIRROR_WALK, xeq_message_wq_edge_grad*, xeq_edge_vectors_bwd) skip
+ * such an entry, the edge then misses its vanishing reverse contribution.  n_edges may be a capacity (the list ends at c_rowptr[N]).
+ * With it a periodic system's reverse pass walks the forward plan like an open one's: no sort by neighbor, no second plan, no second
+ * set of records (round 5; ~0.1 ms of a 1 536-atom step). */
+int xeq_reverse_edge_map_pbc(int dtype, const int64_t* edge_index, const void* cell_offsets, int64_t n_edges, int64_t n_nodes,
+                             const int32_t* c_rowptr, int32_t* rev, void* stream);
 
 /* compute_edge_data (nn/basic.py:110-131): vec = pos[c] - pos[n] - cell_offsets @ cell[batch[n]],
  * dist = |vec|.  cell/cell_offsets/batch may be NULL (non-PBC).  batch == NULL with a

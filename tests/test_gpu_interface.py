@@ -254,7 +254,7 @@ def test_replay_with_timed_gemm_selection_meets_the_fp32_parity_bar():
 
 
 # ------------------------------------------------------------------ TorchScript front ends (registered xeq:: operators)
-def _native_vs_python(dtype, periodic, n_mol=24, trace=False):
+def _native_vs_python(dtype, periodic, n_mol=24, trace=False, own_list=False):
     """xeq::xpainn_eval (C++: csrc/xeq_torch.cpp) against the Python modules (nn/fused.py): same kernels, same order.
     ``trace``: additionally the two fronts' launch sequences (entry-point names, include/xeq.h: xeq_launch_names) of one evaluation each,
     both building the sorted views and walk plans themselves (a fresh EdgeGraph with the list builder's promises for the Python front)."""
@@ -271,6 +271,12 @@ def _native_vs_python(dtype, periodic, n_mol=24, trace=False):
                 "ptr": P._t(ptr), "batch": P._t(np.zeros(len(z), dtype=np.int64)), "cell": P._t(f["cell"], dtype),
                 "cell_offsets": P._t(f["cell_offsets"], dtype)}
         cs, sym = True, False
+        if own_list:   # the list of this package's own periodic search: the same edges, with the builder's promise (every edge with its mirror)
+            b = NeighborTransform(5.0)(XequiBatch(data["pos"], data["atomic_numbers"], data["ptr"], pbc=P._t(np.array([[True, True, True]])),
+                                                  cell=data["cell"]))
+            assert torch.equal(b.edge_index, data["edge_index"]) and torch.equal(b.cell_offsets, data["cell_offsets"])
+            data, sym = b.to_dict(), True
+            assert data[keys.EDGE_GRAPH].mirror_walk
     else:
         pos, z, ptr = syn.synth_qm9_batch(n_mol, seed=13)
         b = NeighborTransform(5.0)(XequiBatch(P._t(pos, dtype), P._t(z), P._t(ptr)))
@@ -280,7 +286,8 @@ def _native_vs_python(dtype, periodic, n_mol=24, trace=False):
     def py():
         d = dict(data)
         if trace:
-            d[keys.EDGE_GRAPH] = ops.EdgeGraph(data["edge_index"], data["pos"].shape[0], center_sorted=cs, ptr=data["ptr"], symmetric=sym)
+            d[keys.EDGE_GRAPH] = ops.EdgeGraph(data["edge_index"], data["pos"].shape[0], center_sorted=cs, ptr=data["ptr"], symmetric=sym,
+                                               cell_offsets=data.get("cell_offsets") if sym else None)
         with torch.enable_grad():
             return model(d, compute_forces=True, compute_virial=periodic)
 
@@ -309,6 +316,17 @@ def test_native_operator_equals_python_modules_bitwise(dtype, periodic):
     assert torch.equal(got[2], want["forces"].detach()), (got[2] - want["forces"]).abs().max()
     if periodic:
         assert torch.equal(got[3], want["virial"].detach()), (got[3] - want["virial"]).abs().max()
+
+
+def test_both_fronts_on_this_package_s_periodic_list():
+    """A periodic box whose list comes from this package's own search: both fronts take the mirror map (xeq_reverse_edge_map_pbc: no sort
+    by neighbor, the reverse pass walks the forward plan) -- the same launches in the same order, results bit for bit, no sort launch."""
+    got, want, seq_py, seq_cc = _native_vs_python(torch.float32, True, trace=True, own_list=True)
+    assert seq_py == seq_cc, "\n".join(f"{a:36s} {b}" for a, b in zip(seq_py + ["-"] * len(seq_cc), seq_cc + ["-"] * len(seq_py)) if a != b)
+    assert "xeq_reverse_edge_map_pbc" in seq_py and not any(n.startswith("xeq_csr_by_key") for n in seq_py)
+    assert sum(n.startswith("xeq_message_wq_plan") for n in seq_py) == 4          # ONE walk plan (four launches), not two
+    assert torch.equal(got[0], want["energy"].detach()) and torch.equal(got[2], want["forces"].detach())
+    assert torch.equal(got[3], want["virial"].detach())
 
 
 @pytest.mark.parametrize("n_mol", [24, 400])

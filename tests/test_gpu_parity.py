@@ -725,6 +725,85 @@ def test_edge_graph_reverse_edge_map_equals_stable_sort(monkeypatch):
     assert rev.tolist() == [2, -1, 0, -1]
 
 
+@pytest.mark.parametrize("name", ["radius_graph_pbc_slab30.npz", "radius_graph_pbc_triclinic40.npz", "radius_graph_pbc_two_graphs_unwrapped.npz",
+                                  "radius_graph_pbc_water192.npz"])
+def test_periodic_mirror_map_on_the_reference_lists(name):
+    """xeq_reverse_edge_map_pbc on the REFERENCE's own periodic lists (tests/golden: slab, triclinic cell with several images per pair,
+    two graphs with unwrapped positions, a water box): every edge (i, j, o) finds its mirror (j, i, -o), the map is an involution --
+    and, as the open-boundary map, it is then the permutation of the stable sort by neighbor up to the order inside a (neighbor, center)
+    run; with one edge taken out, its mirror reports -1 and nothing else changes."""
+    from xequinet_amd import ops
+    from xequinet_amd.lib import call, dtype_code, ptr, stream
+
+    f = _load(name)
+    ei, off = _t(f["edge_index"]), _t(f["cell_offsets"], torch.float32)
+    N, E = len(f["pos"]), ei.shape[1]
+    assert bool((ei[0][1:] >= ei[0][:-1]).all())
+    g = ops.EdgeGraph(ei, N, center_sorted=True, symmetric=True, cell_offsets=off)
+    rev = g.mirror_map.long()
+    assert g.mirror_walk and int(rev.min()) >= 0
+    assert torch.equal(rev[rev], torch.arange(E, device=DEV))
+    assert torch.equal(ei[0][rev], ei[1]) and torch.equal(ei[1][rev], ei[0]) and torch.equal(off[rev], -off)
+    # the sorted view proper is built on demand and holds the same edges per neighbor
+    assert g._n_view is None
+    n_rowptr, n_perm = g.n_rowptr, g.n_perm
+    assert torch.equal(n_rowptr, g.c_rowptr)                                          # symmetric: as many edges towards a node as from it
+    assert torch.equal(torch.sort(n_perm.long())[0], torch.arange(E, device=DEV))
+    # one edge out: the list is center-sorted still, the mate of the missing edge has no mirror, every other entry follows the shift
+    k = E // 3
+    keep = torch.ones(E, dtype=torch.bool, device=DEV)
+    keep[k] = False
+    ei2, off2 = ei[:, keep].contiguous(), off[keep].contiguous()
+    g2 = ops.EdgeGraph(ei2, N, center_sorted=True, symmetric=True, cell_offsets=off2)
+    rev2 = g2.mirror_map.long()
+    mate = int(rev[k]) - (1 if int(rev[k]) > k else 0)
+    assert int(rev2[mate]) == -1 and int((rev2 < 0).sum()) == 1
+    ok = rev2 >= 0
+    assert torch.equal(ei2[0][rev2[ok]], ei2[1][ok]) and torch.equal(off2[rev2[ok]], -off2[ok])
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_periodic_model_with_the_mirror_map_equals_the_sorted_reverse_walk(drop, monkeypatch):
+    """A periodic force evaluation whose reverse pass walks the forward plan through the mirror map (the default for this package's own
+    periodic lists) against the same evaluation with the stable sort by neighbor, a second walk plan and a second set of records
+    (XEQ_PBC_MIRROR=0): energies bit for bit (the forward pass is the same), forces and virial to rounding (other summation orders).
+    ``drop``: with one edge taken out of the list the mirror walk misses one edge's reverse contribution by construction (a periodic list
+    is symmetric up to a rounding at the cutoff, where that contribution vanishes; here the dropped edge is an ordinary one, so only
+    finiteness and the size of the change are checked) -- nothing is read or written out of bounds."""
+    from xequinet_amd import keys, ops
+
+    f = _load("radius_graph_pbc_water192.npz")
+    _, z, ptr, _ = syn.synth_water_box(4, seed=5)
+    ei, off = _t(f["edge_index"]), _t(f["cell_offsets"], torch.float32)
+    if drop:
+        keep = torch.ones(ei.shape[1], dtype=torch.bool, device=DEV)
+        keep[1234] = False
+        ei, off = ei[:, keep].contiguous(), off[keep].contiguous()
+    model, _ = _build(torch.float32)
+    base = {"pos": _t(f["pos"], torch.float32), "atomic_numbers": _t(z.astype(np.int32)), "edge_index": ei, "ptr": _t(ptr),
+            "batch": _t(np.zeros(len(z), dtype=np.int64)), "cell": _t(f["cell"], torch.float32), "cell_offsets": off}
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("XEQ_PBC_MIRROR", flag)
+        d = dict(base)
+        d[keys.EDGE_GRAPH] = g = ops.EdgeGraph(ei, len(z), center_sorted=True, ptr=base["ptr"], symmetric=True, cell_offsets=off)
+        assert g.mirror_walk == (flag == "1") and (g.mirror_map is not None) == (flag == "1")
+        with torch.enable_grad():
+            outs.append(model(d, compute_forces=True, compute_virial=True))
+    a, b = outs
+    assert torch.equal(a["energy"], b["energy"])
+    assert bool(torch.isfinite(a["forces"]).all()) and bool(torch.isfinite(a["virial"]).all())
+    scale = float(b["forces"].abs().max())
+    if not drop:
+        assert float((a["forces"] - b["forces"]).abs().max()) <= 2e-6 * scale
+        assert float((a["virial"] - b["virial"]).abs().max()) <= 2e-6 * float(b["virial"].abs().max())
+    else:
+        # one ORDINARY edge's reverse contribution is missing (three blocks reach across the whole 192-atom box): a small, bounded
+        # change -- one edge of ~54 per atom -- not a fault
+        diff = (a["forces"] - b["forces"]).abs().amax(1)
+        assert float(diff.median()) <= 1e-4 * scale and float(diff.max()) <= 2e-2 * scale
+
+
 # -------------------------------------------------------------------- whole model
 def _build(dtype, **kw):
     from xequinet_amd.nn import resolve_model

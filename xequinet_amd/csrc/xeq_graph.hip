@@ -125,6 +125,35 @@ __global__ void k_reverse_edge_map(const int64_t* __restrict__ center, const int
   rev[e] = (lo < c_rowptr[j + 1] && nbr[lo] == i) ? lo : -1;
 }
 
+// The same map for a PERIODIC list of this library's builders: center-sorted, a center's edges ascending in (neighbor, image index), and
+// (i <- j, offset o) present iff (j <- i, -o) is -- up to a rounding at the cutoff (the distance of the two is formed from differently
+// rounded sums, data/radius_graph.py:117-121, so one of a pair may fall on the other side of `<` when it sits within an ulp of the
+// cutoff; there the envelope is ~1e-14).  Binary search for the first slot of row j whose neighbor is i, then the run of that neighbor
+// for the slot with the negated offset (offsets are whole numbers held in floating point: exact).  rev[e] = -1: no such edge.
+template <typename T>
+__global__ void k_reverse_edge_map_pbc(const int64_t* __restrict__ center, const int64_t* __restrict__ nbr, const T* __restrict__ off,
+                                       const int32_t* __restrict__ c_rowptr, int64_t E, int64_t N, int32_t* __restrict__ rev) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t count = c_rowptr[N] < E ? (int64_t)c_rowptr[N] : E;   // E may be a capacity (a list cut at it keeps its true count in c_rowptr[N])
+  if (e >= count) return;
+  const int64_t i = center[e], j = nbr[e];
+  const T o0 = -off[3 * e], o1 = -off[3 * e + 1], o2 = -off[3 * e + 2];
+  const int32_t end = c_rowptr[j + 1] < count ? c_rowptr[j + 1] : (int32_t)count;
+  int32_t lo = c_rowptr[j], hi = end;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (nbr[mid] < i) lo = mid + 1;
+    else hi = mid;
+  }
+  int32_t r = -1;
+  for (int32_t q = lo; q < end && nbr[q] == i; ++q)
+    if (off[3 * (int64_t)q] == o0 && off[3 * (int64_t)q + 1] == o1 && off[3 * (int64_t)q + 2] == o2) {
+      r = q;
+      break;
+    }
+  rev[e] = r;
+}
+
 // ---------------------------------------------------------- non-PBC radius graph
 // One thread per center; all lanes of a wave walk (mostly) the same molecule, so the
 // position loads broadcast.  d^2 is evaluated without fma contraction so that the
@@ -885,6 +914,19 @@ int xeq_reverse_edge_map(const int64_t* edge_index, int64_t n_edges, int64_t n_n
   hipLaunchKernelGGL(k_reverse_edge_map, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      edge_index, edge_index + n_edges, c_rowptr, n_edges, n_nodes, rev);
   XEQ_CHECK_LAUNCH("xeq_reverse_edge_map");
+  return XEQ_OK;
+}
+
+int xeq_reverse_edge_map_pbc(int dtype, const int64_t* edge_index, const void* cell_offsets, int64_t n_edges, int64_t n_nodes,
+                             const int32_t* c_rowptr, int32_t* rev, void* stream) {
+  XEQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 0, "xeq_reverse_edge_map_pbc: negative size");
+  if (n_edges == 0) return XEQ_OK;
+  XEQ_CHECK_ARG(edge_index && cell_offsets && c_rowptr && rev, "xeq_reverse_edge_map_pbc: NULL argument");
+  XEQ_DISPATCH_FLOAT(dtype, {
+    hipLaunchKernelGGL((k_reverse_edge_map_pbc<T>), dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, edge_index,
+                       edge_index + n_edges, (const T*)cell_offsets, c_rowptr, n_edges, n_nodes, rev);
+  });
+  XEQ_CHECK_LAUNCH("xeq_reverse_edge_map_pbc");
   return XEQ_OK;
 }
 

@@ -1416,8 +1416,14 @@ __global__ void k_wq_edge_grad(const float* __restrict__ vec, const int32_t* __r
   if (p >= P || p >= 4 * (int64_t)qptr[N]) return;
   int32_t e = peid[p];
   if (e < 0) return;
-  if (mirror) e = mirror[e];   // mirror walk: the slot's partials belong to the reverse edge
-  if (e < 0) return;           // (a list wrongly promised as symmetric: xeq_reverse_edge_map wrote -1 for the missing reverse edge)
+  if (mirror) {                // mirror walk: the slot's partials belong to the reverse edge
+    const int32_t m = mirror[e];
+    if (m < 0) {               // no reverse edge in the list (a periodic list one rounding off symmetric): nobody stands for edge e either
+      grad_vec[3 * (int64_t)e] = grad_vec[3 * (int64_t)e + 1] = grad_vec[3 * (int64_t)e + 2] = 0.f;
+      return;
+    }
+    e = m;
+  }
   float gd = 0.f, q1[3] = {0.f, 0.f, 0.f}, q2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int u = 0; u < nu; ++u) gd += pd[(int64_t)u * P + p];
   for (int u = 0; u < nu1; ++u)
@@ -1449,8 +1455,14 @@ __global__ void k_wq_edge_grad_sum(const float* __restrict__ vec, const int32_t*
   if (p >= P || p >= 4 * (int64_t)qptr[N]) return;
   int32_t e = peid[p];
   if (e < 0) return;
-  if (mirror) e = mirror[e];
-  if (e < 0) return;
+  if (mirror) {
+    const int32_t m = mirror[e];
+    if (m < 0) {   // no mirror edge in the list (a periodic list one rounding off symmetric): then nobody stands for edge e either
+      grad_vec[3 * (int64_t)e] = grad_vec[3 * (int64_t)e + 1] = grad_vec[3 * (int64_t)e + 2] = 0.f;
+      return;
+    }
+    e = m;
+  }
   float gd = 0.f, q1[3] = {0.f, 0.f, 0.f}, q2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < pl.n; ++s) {
     const float* pd = pl.p[s];

@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256) k_edge_vectors_bwd(const T* __restrict__ 
     }
     for (int32_t p = n_rowptr[i] + l, p1 = n_rowptr[i + 1]; p < p1; p += 16) {
       const int64_t e = n_perm ? n_perm[p] : p;
+      if (e < 0) continue;   // a mirror map's missing entry (xeq_reverse_edge_map_pbc)
       a0 -= g[3 * e];
       a1 -= g[3 * e + 1];
       a2 -= g[3 * e + 2];

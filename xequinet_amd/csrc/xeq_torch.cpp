@@ -337,9 +337,14 @@ struct WqPlan {
 struct Graph {
   int64_t N = 0, E = 0;
   bool mirror = false;   // symmetric center-sorted list: the reverse wq kernel walks the forward plan (XEQ_WQ_MIRROR_WALK), ops.EdgeGraph.mirror_walk
-  Tensor ei, c_rowptr, c_perm, n_rowptr, n_perm;   // c_perm undefined: edges already center-sorted
+  Tensor ei, c_rowptr, c_perm, n_rowptr, n_perm;   // c_perm undefined: edges already center-sorted.  n_*: the neighbor-sorted view (sorted_view)
+  Tensor mirror_map;     // position of every edge's mirror edge (-1: none), for a list with `mirror`; an open list's is a permutation (= n_perm)
   WqPlan fwd, rev;
   Tensor sb_basis, sb_dbasis;
+  void sorted_view();    // builds n_rowptr / n_perm by a stable sort when nobody has yet (a periodic mirror map is not a permutation)
+  // the edges by neighbor for a kernel that only sums over them (xeq_edge_vectors_bwd): the mirror map over the center rows, else the sorted view
+  const Tensor& rev_rowptr() { if (!mirror_map.defined()) sorted_view(); return mirror_map.defined() ? c_rowptr : n_rowptr; }
+  const Tensor& rev_perm() { if (!mirror_map.defined()) sorted_view(); return mirror_map.defined() ? mirror_map : n_perm; }
 };
 
 Tensor i32(int64_t n, const Tensor& like) { return at::empty({std::max<int64_t>(n, 1)}, like.options().dtype(at::kInt)); }
@@ -354,7 +359,14 @@ void csr_by_key(const Tensor& keys, int64_t n_rows, Tensor& rowptr, Tensor& perm
                        (int32_t*)perm.data_ptr(), cur_stream()));
 }
 
-Graph build_graph(const Tensor& edge_index, int64_t n_nodes, bool center_sorted, bool symmetric) {
+void Graph::sorted_view() {
+  if (!n_perm.defined()) csr_by_key(ei.select(0, 1), N, n_rowptr, n_perm);
+}
+
+// ops.EdgeGraph's twin.  symmetric && center_sorted: the promise of this package's list builders -- open boundaries: neighbours ascending
+// and unique per center, (i, j) present iff (j, i) is; with cell_offsets (a periodic list): a center's edges ascending in (neighbor, image),
+// (i, j, o) present iff (j, i, -o) is up to a rounding at the cutoff (include/xeq.h, xeq_reverse_edge_map_pbc).
+Graph build_graph(const Tensor& edge_index, int64_t n_nodes, bool center_sorted, bool symmetric, const Tensor* cell_offsets) {
   Graph g;
   g.N = n_nodes;
   g.ei = edge_index.contiguous();
@@ -366,19 +378,27 @@ Graph build_graph(const Tensor& edge_index, int64_t n_nodes, bool center_sorted,
   } else {
     csr_by_key(center, n_nodes, g.c_rowptr, g.c_perm);
   }
-  g.mirror = symmetric && center_sorted;
-  if (symmetric && center_sorted) {
+  const char* env = std::getenv("XEQ_PBC_MIRROR");
+  const bool periodic = cell_offsets != nullptr && cell_offsets->defined();
+  g.mirror = symmetric && center_sorted && (!periodic || !(env && env[0] == '0' && env[1] == 0));
+  if (g.mirror && !periodic) {
     g.n_rowptr = g.c_rowptr;
     g.n_perm = i32(g.E, g.ei);
     XCALL(xeq_reverse_edge_map((const int64_t*)g.ei.data_ptr(), g.E, n_nodes, (const int32_t*)g.c_rowptr.data_ptr(),
                                (int32_t*)g.n_perm.data_ptr(), cur_stream()));
+    g.mirror_map = g.n_perm;
+  } else if (g.mirror) {
+    g.mirror_map = i32(g.E, g.ei);
+    XCALL(xeq_reverse_edge_map_pbc(dcode(*cell_offsets), (const int64_t*)g.ei.data_ptr(), cell_offsets->data_ptr(), g.E, n_nodes,
+                                   (const int32_t*)g.c_rowptr.data_ptr(), (int32_t*)g.mirror_map.data_ptr(), cur_stream()));
   } else {
-    csr_by_key(nbr, n_nodes, g.n_rowptr, g.n_perm);
+    g.sorted_view();
   }
   return g;
 }
 
-void build_wq_plan(const Graph& g, bool reverse, WqPlan& p) {
+void build_wq_plan(Graph& g, bool reverse, WqPlan& p) {
+  if (reverse) g.sorted_view();
   const int eps = xeq_message_wq_edges_per_stream(g.N, g.E);   // (the C ABI states the rule; ops._wq_edges_per_stream asks it too)
   p.n_ranges = (int)std::max<int64_t>(1, (g.E + 2 * eps - 1) / (2 * eps));
   p.pcap = xeq_message_wq_pcap(g.N, g.E);
@@ -586,13 +606,15 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
   // ---- sorted views of the edge list (ops.EdgeGraph), then the edge geometry (nn/basic.py:110-131): the order of the Python front
   // (nn/basic.py::compute_edge_data builds the graph first), so that both fronts issue ONE launch sequence
   // (tests/test_gpu_interface.py::test_both_fronts_issue_the_same_launch_sequence)
-  Graph g = build_graph(ei_c, N, center_sorted, symmetric);
   Tensor cell, cell_offsets, batch;
   const bool has_cell = cell_o.has_value() && cell_o->defined();
   if (has_cell) {
     TORCH_CHECK(cell_offsets_o.has_value() && cell_offsets_o->defined(), "cell without cell_offsets");
     cell = cell_o->to(pos.scalar_type()).contiguous();
     cell_offsets = cell_offsets_o->to(pos.scalar_type()).contiguous();
+  }
+  Graph g = build_graph(ei_c, N, center_sorted, symmetric, has_cell ? &cell_offsets : nullptr);
+  if (has_cell) {
     if (G > 1) {
       const Tensor counts = ptr64.slice(0, 1) - ptr64.slice(0, 0, G);
       batch = at::repeat_interleave(at::arange(G, ptr64.options()), counts, 0, N);
@@ -920,15 +942,16 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
               std::vector<const void*> pp;
               for (const Tensor& ps : part_sets) pp.push_back(ps.data_ptr());
               XCALL(xeq_message_wq_edge_grad_sum(vec.data_ptr(), N, E, (const int32_t*)w.qptr.data_ptr(), (const int32_t*)w.peid.data_ptr(),
-                                                 g.mirror ? (const int32_t*)g.n_perm.data_ptr() : nullptr, mul, (int)pp.size(), pp.data(),
+                                                 g.mirror ? (const int32_t*)g.mirror_map.data_ptr() : nullptr, mul, (int)pp.size(), pp.data(),
                                                  g_vec.data_ptr(), st));
             }
           } else {
             XCALL(xeq_message_wq_edge_grad(vec.data_ptr(), N, E, (const int32_t*)w.qptr.data_ptr(), (const int32_t*)w.peid.data_ptr(),
-                                           g.mirror ? (const int32_t*)g.n_perm.data_ptr() : nullptr, mul, parts.data_ptr(),
+                                           g.mirror ? (const int32_t*)g.mirror_map.data_ptr() : nullptr, mul, parts.data_ptr(),
                                            g_vec.data_ptr(), st));
           }
         } else {
+          g.sorted_view();
           XCALL(xeq_message_bwd_sb(dt, N, E, (const int32_t*)g.n_rowptr.data_ptr(), (const int32_t*)g.n_perm.data_ptr(),
                                    (const int64_t*)g.ei.select(0, 0).data_ptr(), g.sb_basis.data_ptr(), g.sb_dbasis.data_ptr(),
                                    m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(), g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
@@ -958,7 +981,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
       Tensor grad_pos = at::empty({N, 3}, fopt);
       XCALL(xeq_edge_vectors_bwd(dt, g_vec_total.data_ptr(), N, (const int32_t*)g.c_rowptr.data_ptr(),
                                  g.c_perm.defined() ? (const int32_t*)g.c_perm.data_ptr() : nullptr,
-                                 (const int32_t*)g.n_rowptr.data_ptr(), (const int32_t*)g.n_perm.data_ptr(), grad_pos.data_ptr(), st));
+                                 (const int32_t*)g.rev_rowptr().data_ptr(), (const int32_t*)g.rev_perm().data_ptr(), grad_pos.data_ptr(), st));
       forces = neg_seed ? grad_pos : grad_pos.neg();
     }
     if (compute_virial) {   // sym(sum_e vec_e (x) dE/dvec_e) per graph, edges walked center-sorted (ops.EdgeVectors.backward)

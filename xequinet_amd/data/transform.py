@@ -46,6 +46,8 @@ class NeighborTransform:
             return data
         else:
             raise ValueError("PBC and cell must be both defined or both undefined.")
-        # center-sorted edges: hand the CSR views to the model
-        setattr(data, keys.EDGE_GRAPH, ops.EdgeGraph(data.edge_index, data.pos.shape[0], center_sorted=True, ptr=ptr))
+        # center-sorted edges in (neighbor, image) order, every edge with its mirror image (up to a rounding at the cutoff): hand the CSR
+        # view and the mirror map to the model (ops.EdgeGraph: no sort by neighbor, the reverse pass walks the forward plan)
+        setattr(data, keys.EDGE_GRAPH, ops.EdgeGraph(data.edge_index, data.pos.shape[0], center_sorted=True, ptr=ptr, symmetric=True,
+                                                     cell_offsets=data.cell_offsets))
         return data

@@ -123,7 +123,7 @@ class XequiCalculator(_AseCalculator):
                 from .scripted import XPaiNNNative
                 self._native = XPaiNNNative(self.model)
             graph = data.get(keys.EDGE_GRAPH)
-            symmetric = graph is not None and keys.CELL not in data      # the open-boundary lists of NeighborTransform
+            symmetric = graph is not None and graph.mirror_walk          # the lists of NeighborTransform (open and periodic): every edge with its mirror
             out = self._native(data[keys.POSITIONS], data[keys.ATOMIC_NUMBERS], data[keys.EDGE_INDEX], data[keys.BATCH_PTR],
                                data.get(keys.CELL), data.get(keys.CELL_OFFSETS), True, symmetric, compute_forces, compute_virial)
             result = {keys.TOTAL_ENERGY: out[0], keys.ATOMIC_ENERGIES: out[1]}

@@ -61,8 +61,11 @@ class XPaiNNLMP(XPaiNN):
             ptr = data.get(keys.BATCH_PTR)
             if ptr is None:
                 ptr = torch.tensor([0, pos.shape[0]], dtype=torch.long, device=pos.device)
+            # a list of this package's own search comes with its EdgeGraph and that one's promises (center-sorted; every edge with its
+            # mirror); the engine's list (LAMMPS) promises nothing
+            graph = data.get(keys.EDGE_GRAPH)
             out = self._native(pos, data[keys.ATOMIC_NUMBERS], data[keys.EDGE_INDEX], ptr, data.get(keys.CELL), data.get(keys.CELL_OFFSETS),
-                               False, False, compute_forces, compute_virial)
+                               graph is not None and graph.c_perm is None, graph is not None and graph.mirror_walk, compute_forces, compute_virial)
             result = {keys.TOTAL_ENERGY: out[0], keys.ATOMIC_ENERGIES: out[1]}
             if compute_forces:
                 result[keys.FORCES] = out[2]
@@ -176,7 +179,8 @@ class XPaiNNGMX(XPaiNN):
             keys.EDGE_INDEX: edge_index,
             keys.CELL_OFFSETS: cell_offsets,
             # the search's list is center-sorted and comes with its row pointer: no sortedness check, no second pass over it
-            keys.EDGE_GRAPH: ops.EdgeGraph(edge_index, positions.shape[0], center_sorted=True, c_rowptr=rowptr),
+            keys.EDGE_GRAPH: ops.EdgeGraph(edge_index, positions.shape[0], center_sorted=True, c_rowptr=rowptr, symmetric=True,
+                                           cell_offsets=cell_offsets),
         }
         if self.net_charge is not None:
             data[keys.TOTAL_CHARGE] = torch.tensor([self.net_charge], device=positions.device)

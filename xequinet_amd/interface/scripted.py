@@ -193,7 +193,8 @@ class XPaiNNGMXScript(nn.Module):
             cell = box * self.pos_unit_factor
             with torch.no_grad():
                 edge_index, cell_offsets, _ = torch.ops.xeq.radius_graph_pbc(pos, cell, pbc, self.cutoff_radius)
-            out = self.core(pos, atomic_numbers, edge_index, ptr, cell.unsqueeze(0), cell_offsets, True, False, False, False)
+            # (this package's own periodic search: center-sorted, every edge with its mirror image -- the operator's mirror map)
+            out = self.core(pos, atomic_numbers, edge_index, ptr, cell.unsqueeze(0), cell_offsets, True, True, False, False)
         else:
             with torch.no_grad():
                 edge_index, _ = torch.ops.xeq.radius_graph(pos, ptr, self.cutoff_radius)

@@ -42,6 +42,7 @@ _PROTOS = {
     "xeq_exclusive_scan_i32_workspace": [c_int64],
     "xeq_exclusive_scan_i32_ws": [_P, c_int64, _P, _P, c_int64, _P],
     "xeq_reverse_edge_map": [_P, c_int64, c_int64, _P, _P, _P],
+    "xeq_reverse_edge_map_pbc": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P],
     "xeq_radius_graph_count": [c_int, _P, _P, c_int64, c_int64, c_double, _P, _P],
     "xeq_radius_graph_fill": [c_int, _P, _P, c_int64, c_int64, c_double, _P, c_int64, _P, _P],
     "xeq_radius_graph_bin_ids": [c_int, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P],

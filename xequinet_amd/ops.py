@@ -124,11 +124,17 @@ class EdgeGraph:
     neighbours ascending and unique per center, (i, j) present iff (j, i) is.  Then the neighbour-sorted order is
     the reverse-edge map (``xeq_reverse_edge_map``, one binary search per edge) and needs no sort; the result is
     the same permutation the stable sort gives.
+    ``symmetric=True`` WITH ``cell_offsets`` is the promise of this package's PERIODIC builders (radius_graph_pbc*, runtime.GraphedStepPBC):
+    center-sorted, a center's edges ascending in (neighbor, image), and (i, j, o) present iff (j, i, -o) is -- up to a rounding at the
+    cutoff (include/xeq.h, xeq_reverse_edge_map_pbc).  Then ``mirror_map`` (position of the mirror edge, -1 where the list holds none)
+    lets the wq reverse kernel walk the forward plan as for an open system: no sort, no second plan, no second set of records.  It is
+    not a permutation, so the neighbor-sorted view proper (``n_rowptr`` / ``n_perm``) is built only when somebody asks for it (the sb /
+    generic kernel families, the training kernels).  XEQ_PBC_MIRROR=0 switches the periodic mirror map off.
     """
 
     def __init__(self, edge_index: torch.Tensor, n_nodes: int, center_sorted: Optional[bool] = None,
                  ptr: Optional[torch.Tensor] = None, c_rowptr: Optional[torch.Tensor] = None,
-                 symmetric: bool = False, capacity_form: bool = False) -> None:
+                 symmetric: bool = False, capacity_form: bool = False, cell_offsets: Optional[torch.Tensor] = None) -> None:
         require_hip(edge_index)
         self.ptr = ptr          # graph boundaries [G+1] (keys.BATCH_PTR), when the caller knows them
         self._wq = None
@@ -149,23 +155,61 @@ class EdgeGraph:
                 self.c_rowptr = csr_rowptr(center, self.n_nodes)
         else:
             self.c_rowptr, self.c_perm = csr_by_key(center, self.n_nodes)
-        # symmetric, center-sorted list: the reverse wq kernel walks the FORWARD plan (every slot stands for its mirror edge), n_perm
-        # is the mirror map (include/xeq.h, XEQ_WQ_MIRROR_WALK)
-        self.mirror_walk = bool(symmetric and center_sorted)
+        import os
+
+        periodic_mirror = bool(symmetric and center_sorted and cell_offsets is not None and os.environ.get("XEQ_PBC_MIRROR", "1") != "0")
+        exact_mirror = bool(symmetric and center_sorted and cell_offsets is None)
+        # symmetric, center-sorted list: the reverse wq kernel walks the FORWARD plan (every slot stands for its mirror edge) and
+        # mirror_map tells where a slot's edge gradient goes (include/xeq.h, XEQ_WQ_MIRROR_WALK)
+        self.mirror_walk = exact_mirror or periodic_mirror
+        self.mirror_map: Optional[torch.Tensor] = None
         # set by callers whose edge_index is a capacity-sized buffer (runtime.GraphedStep*, train.GraphedTrainStep): the true edge count
         # is c_rowptr[N] on the device; kernels that walk edges by index rather than by row pointer are handed that pointer
         self.edge_count_on_device = False
-        if symmetric and center_sorted:
-            self.n_rowptr = self.c_rowptr
-            self.n_perm = torch.empty(E, dtype=torch.int32, device=edge_index.device)
-            call("xeq_reverse_edge_map", lib.ptr(edge_index), E, self.n_nodes, lib.ptr(self.c_rowptr), lib.ptr(self.n_perm), stream())
-        elif capacity_form:
-            # edge_index is a capacity-sized buffer, the edge count sits in c_rowptr[N] on the device (radius_graph_pbc_capacity):
-            # the neighbor-sorted view skips the slots behind it
+        self._capacity_form = bool(capacity_form)
+        self._n_view = None                      # (n_rowptr, n_perm), built on demand
+        if capacity_form:
             assert center_sorted and c_rowptr is not None
-            self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes, n_valid=self.c_rowptr[self.n_nodes:])
+        if exact_mirror:
+            rev = torch.empty(E, dtype=torch.int32, device=edge_index.device)
+            call("xeq_reverse_edge_map", lib.ptr(edge_index), E, self.n_nodes, lib.ptr(self.c_rowptr), lib.ptr(rev), stream())
+            self.mirror_map = rev
+            self._n_view = (self.c_rowptr, rev)   # a permutation: the stable sort by neighbor gives the same one
+        elif periodic_mirror:
+            off = cell_offsets.contiguous()
+            assert off.shape == (E, 3) and off.is_floating_point()
+            rev = torch.empty(E, dtype=torch.int32, device=edge_index.device)
+            call("xeq_reverse_edge_map_pbc", dtype_code(off), lib.ptr(edge_index), lib.ptr(off), E, self.n_nodes, lib.ptr(self.c_rowptr),
+                 lib.ptr(rev), stream())
+            self.mirror_map = rev
         else:
-            self.n_rowptr, self.n_perm = csr_by_key(nbr, self.n_nodes)
+            self._sorted_neighbor_view()
+
+    def _sorted_neighbor_view(self):
+        if self._n_view is None:
+            nbr = self.edge_index[1]
+            if self._capacity_form:
+                # edge_index is a capacity-sized buffer, the edge count sits in c_rowptr[N] on the device (radius_graph_pbc_capacity):
+                # the neighbor-sorted view skips the slots behind it
+                self._n_view = csr_by_key(nbr, self.n_nodes, n_valid=self.c_rowptr[self.n_nodes:])
+            else:
+                self._n_view = csr_by_key(nbr, self.n_nodes)
+        return self._n_view
+
+    @property
+    def n_rowptr(self) -> torch.Tensor:
+        return self._sorted_neighbor_view()[0]
+
+    @property
+    def n_perm(self) -> torch.Tensor:
+        return self._sorted_neighbor_view()[1]
+
+    def reverse_view(self):
+        """(row pointer, edge per slot) of the edges by NEIGHBOR for kernels that only sum over them (xeq_edge_vectors_bwd): the mirror map
+        over the center rows where there is one (a missing mirror, -1, is skipped), else the sorted view."""
+        if self.mirror_map is not None:
+            return self.c_rowptr, self.mirror_map
+        return self._sorted_neighbor_view()
 
     def wq_plan(self, reverse: bool, edges_per_stream: int = 128):
         """Walk plan of the wave / quad message kernels (xeq_message_wq_plan): every node's edge list padded to whole
@@ -443,8 +487,9 @@ class EdgeVectors(Function):
         grad_pos = None
         if ctx.needs_input_grad[0]:
             grad_pos = torch.empty((graph.n_nodes, 3), dtype=vec.dtype, device=vec.device)
+            n_rowptr, n_perm = graph.reverse_view()
             call("xeq_edge_vectors_bwd", dtype_code(vec), ptr(g), graph.n_nodes, ptr(graph.c_rowptr), ptr(graph.c_perm),
-                 ptr(graph.n_rowptr), ptr(graph.n_perm), ptr(grad_pos), stream())
+                 ptr(n_rowptr), ptr(n_perm), ptr(grad_pos), stream())
         grad_strain = None
         if ctx.n_graphs is not None and ctx.needs_input_grad[5]:
             outer = (vec.unsqueeze(2) * g.unsqueeze(1)).reshape(-1, 9)            # vec_e (x) dE/dvec_e
@@ -846,7 +891,7 @@ class EdgeGradDeferral:
         g_vec = torch.empty_like(vec)
         arr = (ctypes.c_void_p * len(sets))(*[t.data_ptr() for t in sets])
         call("xeq_message_wq_edge_grad_sum", ptr(vec), graph.n_nodes, graph.n_edges, ptr(plan["qptr"]), ptr(plan["peid"]),
-             ptr(graph.n_perm if mirror else None), mul3(mul), len(sets), arr, ptr(g_vec), stream())
+             ptr(graph.mirror_map if mirror else None), mul3(mul), len(sets), arr, ptr(g_vec), stream())
         return g_vec
 
 
@@ -878,7 +923,7 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
         if deferral is not None:
             g_vec = deferral.add(parts, vec, graph, plan, mirror, mul)
         else:
-            call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), ptr(graph.n_perm if mirror else None),
+            call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), ptr(graph.mirror_map if mirror else None),
                  mul3(mul), ptr(parts), ptr(g_vec), stream())
     elif impl == "sb":
         KERNEL_TIMER.launch("xeq_message_bwd_sb", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),

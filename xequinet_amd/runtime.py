@@ -107,8 +107,10 @@ class GraphedModel:
             c.inputs[keys.BATCH] = torch.repeat_interleave(torch.arange(counts.numel(), device=ptr.device), counts,
                                                            output_size=c.inputs[keys.POSITIONS].shape[0])
         # a private EdgeGraph over the captured edge_index; its CSR arrays are refreshed in place before every replay
+        periodic_mirror = eg.mirror_map is not None and eg._n_view is None
         c.edge_graph = ops.EdgeGraph(c.inputs[keys.EDGE_INDEX], eg.n_nodes, center_sorted=eg.c_perm is None,
-                                     ptr=c.inputs[keys.BATCH_PTR], symmetric=eg.mirror_walk)
+                                     ptr=c.inputs[keys.BATCH_PTR], symmetric=eg.mirror_walk,
+                                     cell_offsets=c.inputs[keys.CELL_OFFSETS] if periodic_mirror else None)
         static = dict(c.inputs)
         static[keys.EDGE_GRAPH] = c.edge_graph
         # library GEMM selection is timed during the warm-up only: TunableOp is a process-wide switch, so the state the
@@ -136,7 +138,11 @@ class GraphedModel:
         """The new inputs and CSR arrays go into the captured buffers in one launch (ops.copy_many)."""
         pairs = [(t, data[k]) for k, t in c.inputs.items() if k in data]
         s = c.edge_graph
-        pairs += [(s.c_rowptr, eg.c_rowptr), (s.n_rowptr, eg.n_rowptr), (s.n_perm, eg.n_perm)]
+        pairs.append((s.c_rowptr, eg.c_rowptr))
+        if s.mirror_map is not None:
+            pairs.append((s.mirror_map, eg.mirror_map))
+        if s._n_view is not None and s._n_view[1] is not s.mirror_map:   # the sorted view proper, where the captured step asked for it
+            pairs += [(s.n_rowptr, eg.n_rowptr), (s.n_perm, eg.n_perm)]
         if s.c_perm is not None:
             pairs.append((s.c_perm, eg.c_perm))
         ops.copy_many(pairs)
@@ -185,7 +191,13 @@ class GraphedModel:
                 return False
         if c.derived_batch and keys.BATCH_PTR in data and not torch.equal(data[keys.BATCH_PTR], c.inputs[keys.BATCH_PTR]):
             return False
-        return bool(torch.equal(ei, ref))
+        if not torch.equal(ei, ref):
+            return False
+        # a periodic list's mirror map pairs edges by their image offsets as well: the same pairs under other offsets are another map
+        if (c.edge_graph.mirror_map is not None and keys.CELL_OFFSETS in data
+                and not torch.equal(data[keys.CELL_OFFSETS], c.inputs[keys.CELL_OFFSETS])):
+            return False
+        return True
 
 
 # ----------------------------------------------------------------------------------------------- whole step as one graph
@@ -670,7 +682,8 @@ class GraphedStepPBC:
         tab = split_cell_tables(self._tab_flat, 1, n_cells, False)
         rowptr, count = ops.radius_graph_pbc_capacity(self.pos, self.ptr, tab["pbc_offsets"], tab["cell_offsets"], self.shift, self.cutoff,
                                                       (tab["recip"], tab["thr"], self._reps), self.edge_index, self.cell_offsets)
-        eg = ops.EdgeGraph(self.edge_index, self.n_atoms, center_sorted=True, ptr=self.ptr, c_rowptr=rowptr, capacity_form=True)
+        eg = ops.EdgeGraph(self.edge_index, self.n_atoms, center_sorted=True, ptr=self.ptr, c_rowptr=rowptr, capacity_form=True, symmetric=True,
+                           cell_offsets=self.cell_offsets)
         data = {keys.POSITIONS: self.pos.detach(), keys.ATOMIC_NUMBERS: self.z, keys.CELL: self.cell, keys.EDGE_INDEX: self.edge_index,
                 keys.CELL_OFFSETS: self.cell_offsets, keys.BATCH: self.batch, keys.BATCH_PTR: self.ptr, keys.EDGE_GRAPH: eg}
         _offer_zero_start(self, data)
