@@ -301,7 +301,18 @@ def main():
         def step_eager():                              # noqa: F811  (the chunked form of the same step)
             return step_chunked(None)
 
-        step = step_eager if graphed is None else (lambda: step_chunked(graphed))
+        gchunks = None
+        if graphed is not None and not args.replay_model_only:
+            # default since round 5: every chunk a whole captured step over capacity-sized arrays (no edge count read back, no list built
+            # from the host), --in-flight of them side by side (runtime.GraphedChunks); results bit for bit those of the forms above
+            gchunks = runtime.GraphedChunks(model, ptr, max_edges=max_edges, depth=max(1, args.in_flight), compute_forces=True)
+            batch_d = collated.batch
+            n_flight = gchunks.depth
+
+            def step():
+                return None, gchunks(pos_d, z_d, ptr_d, batch_d)
+        else:
+            step = step_eager if graphed is None else (lambda: step_chunked(graphed))
     elif args.eager:
         step = step_eager
     elif cell is None and not args.replay_model_only:
@@ -358,6 +369,7 @@ def main():
             return batch.edge_index.shape[1], graphed(batch.to_dict())
 
     whole_step = not sharded and not args.eager and (cell is None or len(ptr) == 2) and not args.replay_model_only
+    chunk_graphs = sharded and not args.eager and not args.replay_model_only
     try:
         # set-up, not a timed or counted step: the first evaluation times the library GEMM candidates (TunableOp) and
         # captures the HIP graph; the W warm-up steps and the K timed steps that follow are all plain steps
@@ -365,7 +377,9 @@ def main():
         for _ in range(args.warmup):
             n_edges, out = step()
         torch.cuda.synchronize()
-        if n_flight > 1:
+        if chunk_graphs:
+            n_edges = int(gchunks.edge_total.item()) // (args.warmup + 1)
+        elif n_flight > 1:
             out = gstep.result(ticket[0])
         if whole_step:
             n_edges = (sum(int(st.outputs["n_edges"].item()) for st in gstep.steps) if (cell is None and n_lanes > 1)
@@ -374,7 +388,7 @@ def main():
         if args.eager:
             raise
         print(f"[bench] HIP-graph capture failed on rank {rank} ({err}); continuing with host launches", file=sys.stderr, flush=True)
-        args.eager, step = True, step_eager
+        args.eager, step, chunk_graphs, whole_step, n_flight = True, step_eager, False, False, 1
         for _ in range(args.warmup + 1):
             n_edges, out = step()
         torch.cuda.synchronize()
@@ -382,13 +396,16 @@ def main():
         flag = torch.tensor([1 if args.eager else 0], device=dev)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
         if bool(flag.item()) and not args.eager:
-            args.eager, step = True, step_eager
+            args.eager, step, chunk_graphs, whole_step, n_flight = True, step_eager, False, False, 1
     n_atoms = pos_d.shape[0]
 
     # ---- timed region: exactly K steps between barrier + synchronize
     ops.KERNEL_TIMER.reset(enabled=args.eager)
     xdist.barrier()
     torch.cuda.synchronize()
+    if chunk_graphs:
+        gchunks.zero_edge_total()
+        torch.cuda.synchronize()
     if whole_step:
         if cell is None:
             for st in (gstep.steps if (n_lanes > 1 or n_flight > 1) else [gstep]):
@@ -406,7 +423,21 @@ def main():
     xdist.barrier()
     elapsed = time.perf_counter() - t0
     one_ms = None
-    if n_flight > 1:
+    if chunk_graphs:
+        edges_done = int(gchunks.edge_total.item())
+        assert not gchunks.overflowed(), "a chunk's neighbour list outgrew its capacity"
+        if gchunks.depth > 1:                              # the same chunks one at a time
+            one = runtime.GraphedChunks(model, ptr, max_edges=max_edges, depth=1, compute_forces=True)
+            for _ in range(2):
+                one(pos_d, z_d, ptr_d, batch_d)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one(pos_d, z_d, ptr_d, batch_d)
+            torch.cuda.synchronize()
+            one_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            del one
+    elif n_flight > 1:
         out = gstep.result(ticket[0])
         edges_timed = int(gstep.edge_total.item())
         one = runtime.GraphedStep(model, cap, compute_forces=True)   # the same step, ONE at a time (its latency): a lone step's own capture
@@ -561,7 +592,9 @@ def main():
                        "launch": ("host launch per kernel" if args.eager else
                                   (f"neighbour list + model as ONE captured HIP graph over capacity-sized arrays, edge count on the device (runtime.{'GraphedLanes: ' + str(n_lanes) + ' contiguous molecule ranges as parallel branches of the graph, results bit for bit those of one range' if n_lanes > 1 else ('GraphedStepsInFlight: ' + str(n_flight) + ' steps in flight, each on its own stream with its own buffers, all K finished inside the timed region; results bit for bit those of one at a time, whose time is ms_per_step_one_in_flight') if n_flight > 1 else 'GraphedStep'}; {max(1, args.vary_batch)} different draw(s) of the workload in turn)"
                                    if cell is None else "periodic neighbour search + model as ONE captured HIP graph over capacity-sized edge arrays, edge count on the device (runtime.GraphedStepPBC)")
-                                  if whole_step else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host"),
+                                  if whole_step else
+                                  (f"every chunk a whole captured step (neighbour list + model + forces over capacity-sized arrays, edge count on the device), {n_flight} chunk(s) in flight on their own streams (runtime.GraphedChunks); results bit for bit those of one chunk at a time, whose time is ms_per_step_one_in_flight"
+                                   if chunk_graphs else "model part (forward + force backward) as one captured HIP graph per step (per chunk); neighbour list launched from the host")),
                        "ms_per_step_eager": "the same step with every kernel launched from the host through the Python modules, measured on rank 0 right after the timed region",
                        "in_flight": n_flight,
                        "ms_per_step_native_op": "the same step as ONE registered operator (xeq::xpainn_eval: kernels enqueued from C++, no capture): what a stream of batches with ever-new edge counts pays"},

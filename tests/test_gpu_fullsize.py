@@ -89,6 +89,30 @@ def test_full_size_against_oracle(name, n_mol, n_atoms, n_edges, chunked):
                   compared_edges=int(e_sub)), oracle, ref_in)
 
 
+@pytest.mark.parametrize("depth", [1, 2])
+def test_graphed_chunks_equal_one_evaluation_bit_for_bit(depth, monkeypatch):
+    """runtime.GraphedChunks: a 1536-molecule batch as three chunks of ~9 200 atoms, every chunk a whole captured step (its neighbour
+    list inside, nothing read back), one at a time and two in flight: energies, forces and the device-side edge count are those of ONE
+    evaluation of the batch, bit for bit, call after call; chunks on both sides of the node-block threshold are refused."""
+    from xequinet_amd import runtime
+
+    model, _ = _build(torch.float32)
+    pos, z, ptr = syn.synth_qm9_batch(1536, seed=99)
+    E, F, e1, _ = _hip_eval(model, pos, z, ptr)
+    batch = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    gc = runtime.GraphedChunks(model, ptr, max_edges=200_000, depth=depth)
+    assert gc.n_chunks == 3 and gc.depth == depth
+    args = (_t(pos, torch.float32), _t(z), _t(ptr), _t(batch))
+    for rep in range(3):
+        out = gc(*args)
+        assert np.array_equal(out["energy"].cpu().double().numpy(), E) and np.array_equal(out["forces"].cpu().double().numpy(), F)
+    assert int(gc.edge_total) == 3 * e1 and not gc.overflowed()
+    assert all(st.captures == 1 for st in gc.steps)
+    monkeypatch.setenv("XEQ_NODE_BLOCK_MIN_NODES", "9200")       # chunks of 9 220 / 9 123 / 9 257 atoms: one would take the chain of small kernels
+    with pytest.raises(ValueError, match="threshold"):
+        runtime.GraphedChunks(model, ptr, max_edges=200_000)
+
+
 @pytest.mark.parametrize("node_block,n_mol,max_edges", [("by size", 1024, 200_000), ("always", 512, 40_000), ("never", 512, 40_000)])
 def test_chunked_equals_unchunked(node_block, n_mol, max_edges, monkeypatch):
     """runtime.evaluate_in_chunks (what a rank does with a shard above the kernels' 32-bit bound) against ONE evaluation

@@ -335,13 +335,8 @@ class GraphedStep:
         call("xeq_load_padded_batch_z64" if z64 else "xeq_load_padded_batch", dtype_code(pos_c), p_(pos_c), p_(z_c), p_(ptr_c), p_(batch_c), n, g, self.n_atoms, self.n_graphs,
              1.0e4, self.PAD_SPACING, p_(self.pos), p_(self.z), p_(self.ptr), p_(self.batch), stream())
 
-    def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor] = None,
-                 ptr_host=None) -> Dict[str, torch.Tensor]:
-        """-> {energy [G], atomic_energies [n], forces [n, 3], n_edges [1] (device)}: views of the graph's output buffers,
-        overwritten by the next call.  ``ptr_host`` (optional): checks the edge capacity against the batch on the host."""
-        if ptr_host is not None and pair_capacity(ptr_host) > self.n_edges:
-            raise ValueError(f"GraphedStep: the batch may hold {pair_capacity(ptr_host)} edges, the capacity is {self.n_edges}")
-        self._load(pos, atomic_numbers, ptr, batch)
+    def _replay(self) -> None:
+        """The step on whatever the static buffers hold: captured on first use (and again when the weights moved), replayed after."""
         state = _params_state(self)
         if self.graph is not None and state != self._param_state:   # weights moved since the capture: its packed copies are stale
             self.graph = None
@@ -360,6 +355,15 @@ class GraphedStep:
                 self.outputs = self._step()
             self.captures += 1
         self.graph.replay()
+
+    def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: Optional[torch.Tensor] = None,
+                 ptr_host=None) -> Dict[str, torch.Tensor]:
+        """-> {energy [G], atomic_energies [n], forces [n, 3], n_edges [1] (device)}: views of the graph's output buffers,
+        overwritten by the next call.  ``ptr_host`` (optional): checks the edge capacity against the batch on the host."""
+        if ptr_host is not None and pair_capacity(ptr_host) > self.n_edges:
+            raise ValueError(f"GraphedStep: the batch may hold {pair_capacity(ptr_host)} edges, the capacity is {self.n_edges}")
+        self._load(pos, atomic_numbers, ptr, batch)
+        self._replay()
         n, g = int(pos.shape[0]), int(ptr.numel() - 1)
         out = {keys.TOTAL_ENERGY: self.outputs[keys.TOTAL_ENERGY][:g], "n_edges": self.outputs["n_edges"]}
         if keys.ATOMIC_ENERGIES in self.outputs:
@@ -599,6 +603,102 @@ class GraphedStepsInFlight:
     def overflowed(self) -> bool:
         self.drain()
         return any(st.overflowed() for st in self.steps)
+
+
+class GraphedChunks:
+    """ONE batch of independent open-boundary molecules of any size as contiguous molecule ranges ("chunks": at most ``max_edges``
+    possible edges each, dist.plan_chunks -- the message kernels address with 32-bit offsets), every chunk a whole captured step
+    (``GraphedStep``: neighbour list, walk plan, model, forces over capacity-sized arrays, edge count on the device) and ``depth`` of
+    them in flight on their own streams.
+
+    ``evaluate_in_chunks`` builds every chunk's list from the host, reads its edge count back to size the edge arrays and replays a
+    model-only graph per (atoms, edges) signature; here nothing reaches the host inside an evaluation: a chunk is one shard-load launch
+    (xeq_load_padded_shard), one graph replay and one copy launch that puts its results at the chunk's place in the batch's arrays, and
+    the next chunk runs beside it (the same overlap as ``GraphedStepsInFlight``).  Molecules do not interact, so the results are those
+    of one evaluation of the whole batch bit for bit (every kernel gives a row the same bits in any batch; chunks on both sides of the
+    node-block threshold are refused).
+
+    ``ptr_host``: the batch's graph pointer on the host (sizes the chunks once; a batch with another pointer needs another object)."""
+
+    def __init__(self, model: torch.nn.Module, ptr_host, max_edges: int = None, depth: int = 2, compute_forces: bool = True) -> None:
+        import numpy as np
+
+        from .dist import plan_chunks
+
+        ph = np.asarray(ptr_host, dtype=np.int64)
+        self.ptr_host = ph
+        cuts = plan_chunks(ph, int(WM_MAX_EDGES_PER_CHUNK if max_edges is None else max_edges))
+        self.plan = [(int(ph[g0]), int(ph[g1]), int(g0), int(g1)) for g0, g1 in cuts]
+        cap = (max(b - a for a, b, _, _ in self.plan) + 64, max(g1 - g0 for _, _, g0, g1 in self.plan),
+               max(pair_capacity(ph[g0 : g1 + 1] - ph[g0]) for _, _, g0, g1 in self.plan))
+        sides = {bool(ops.lib.load().xeq_node_block_auto(b - a)) for a, b, _, _ in self.plan}
+        if len(sides) > 1:
+            raise ValueError("GraphedChunks: the chunks fall on both sides of the node-block threshold (their bits would differ from one evaluation's)")
+        self.depth = max(1, min(int(depth), len(self.plan)))
+        self.steps = [GraphedStep(model, cap, compute_forces=compute_forces) for _ in range(self.depth)]
+        p = self.steps[0].pos
+        n, g = int(ph[-1]), len(ph) - 1
+        self.energy = torch.zeros(g, dtype=p.dtype, device=p.device)
+        self.atomic = torch.zeros(n, dtype=p.dtype, device=p.device)
+        self.forces = torch.zeros((n, 3), dtype=p.dtype, device=p.device) if compute_forces else None
+        self._streams = [torch.cuda.Stream(device=p.device) for _ in range(self.depth)]
+        self._done = [torch.cuda.Event() for _ in range(self.depth)]
+
+    @property
+    def n_chunks(self) -> int:
+        return len(self.plan)
+
+    @property
+    def edge_total(self) -> torch.Tensor:
+        """Edges of every chunk evaluated so far (a device scalar)."""
+        return torch.stack([st.edge_total for st in self.steps]).sum(0)
+
+    def zero_edge_total(self) -> None:
+        for st in self.steps:
+            st.edge_total.zero_()
+
+    def overflowed(self) -> bool:
+        return any(st.overflowed() for st in self.steps)
+
+    def __call__(self, pos: torch.Tensor, atomic_numbers: torch.Tensor, ptr: torch.Tensor, batch: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """-> {energy [G], atomic_energies [N], forces [N, 3]}: this object's result arrays (overwritten by the next call), ordered into the
+        caller's stream.  ``batch``: the per-atom graph index (int64)."""
+        assert int(pos.shape[0]) == int(self.ptr_host[-1]) and int(ptr.numel()) == len(self.ptr_host), "GraphedChunks: another batch than the planned one"
+        pos_c = pos.detach().contiguous()
+        ptr_c, batch_c = ptr.to(torch.int64).contiguous(), batch.to(torch.int64).contiguous()
+        z_c = atomic_numbers.contiguous() if atomic_numbers.dtype in (torch.int32, torch.int64) else atomic_numbers.to(torch.int32).contiguous()
+        cur = torch.cuda.current_stream()
+        L = ops.lib.load()
+        former = L.xeq_node_block_set_waves(GraphedStepsInFlight.NODE_BLOCK_WAVES) if self.depth > 1 else None
+        try:
+            for k, (a, b, g0, g1) in enumerate(self.plan):
+                i = k % self.depth
+                st, s = self.steps[i], self._streams[i]
+                if k < self.depth:
+                    s.wait_stream(cur)                               # the inputs (and the result arrays' last readers) are on the caller's stream
+                with torch.cuda.stream(s):
+                    st._load_shard(pos_c, z_c, ptr_c, batch_c, a, b, g0, g1)
+                    st._replay()
+                    o = st.outputs
+                    pairs = [(self.energy[g0:g1], o[keys.TOTAL_ENERGY][: g1 - g0])]
+                    if keys.ATOMIC_ENERGIES in o:
+                        pairs.append((self.atomic[a:b], o[keys.ATOMIC_ENERGIES][: b - a]))
+                    if self.forces is not None and keys.FORCES in o:
+                        pairs.append((self.forces[a:b], o[keys.FORCES][: b - a]))
+                    ops.copy_many(pairs)                             # the chunk's results to their place, behind its replay on its stream
+                    self._done[i].record(s)
+        finally:
+            if former is not None:
+                L.xeq_node_block_set_waves(former)
+        for t in (pos_c, z_c, ptr_c, batch_c):
+            for s in self._streams:
+                t.record_stream(s)
+        for i in range(self.depth):
+            cur.wait_event(self._done[i])
+        out = {keys.TOTAL_ENERGY: self.energy, keys.ATOMIC_ENERGIES: self.atomic}
+        if self.forces is not None:
+            out[keys.FORCES] = self.forces
+        return out
 
 
 def evaluate_batches(model: torch.nn.Module, batches, capacity, depth: int = 2, compute_forces: bool = True):
