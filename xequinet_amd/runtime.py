@@ -600,6 +600,15 @@ class GraphedStepsInFlight:
         """One step, waited for (the GraphedStep call form; nothing overlaps this way)."""
         return self.result(self.submit(pos, atomic_numbers, ptr, batch, ptr_host))
 
+    def __del__(self):
+        # the contexts' buffers were allocated on the creator's stream and are used on the side streams: nothing of theirs may still be
+        # running when the allocator takes the memory back
+        try:
+            for s in self._streams:
+                s.synchronize()
+        except Exception:
+            pass
+
     def overflowed(self) -> bool:
         self.drain()
         return any(st.overflowed() for st in self.steps)
@@ -699,6 +708,13 @@ class GraphedChunks:
         if self.forces is not None:
             out[keys.FORCES] = self.forces
         return out
+
+    def __del__(self):
+        try:    # (as GraphedStepsInFlight: the side streams are idle before the buffers go back to the allocator)
+            for s in self._streams:
+                s.synchronize()
+        except Exception:
+            pass
 
 
 def evaluate_batches(model: torch.nn.Module, batches, capacity, depth: int = 2, compute_forces: bool = True):
