@@ -31,7 +31,11 @@ extern "C" {
 #endif
 
 enum { XEQ_F32 = 0, XEQ_F64 = 1 };
-enum { XEQ_RBF_BESSEL = 0, XEQ_RBF_GAUSSIAN = 1 };
+/* radial bases of nn/rbf.py: SphericalBesselj0 (p0 = freq), GaussianSmearing (p0 = mean, p1 = std), ExponentialBernstein (p0 =
+ * softplus(_alpha) repeated num_basis times, p1 = the log binomials `logc`; nn/rbf.py:161-191), ExponentialNorm (p0 = beta, p1 = mu;
+ * nn/rbf.py:194-207).  The last two: inference entry points (xeq_radial_fwd, xeq_edge_basis, xeq_edge_basis_wq, xeq_message_fwd / _bwd);
+ * the parameter-gradient kernels of the native training pass take the first two only. */
+enum { XEQ_RBF_BESSEL = 0, XEQ_RBF_GAUSSIAN = 1, XEQ_RBF_EXPBERN = 2, XEQ_RBF_EXPNORM = 3 };
 enum { XEQ_CUTOFF_COSINE = 0, XEQ_CUTOFF_POLYNOMIAL = 1 };
 enum {
   XEQ_OK = 0,

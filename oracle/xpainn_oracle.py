@@ -226,6 +226,18 @@ def gaussian_rbf(dist: Tensor, mean: Tensor, std: Tensor, eps: float = 1e-5) -> 
     return coeff * torch.exp(-0.5 * ((dist - mean) / std) ** 2)
 
 
+def exp_bernstein_rbf(dist: Tensor, alpha_raw: Tensor, logc: Tensor, n: Tensor, v: Tensor) -> Tensor:
+    """``ExponentialBernstein.forward`` (nn/rbf.py:186-191). dist [E,1]; alpha_raw: the stored ``_alpha`` (softplus inside);
+    logc / n / v: the module's buffers (log binomials, B - 1 - k, k)."""
+    x = -F.softplus(alpha_raw) * dist
+    return torch.exp(logc + n * x + v * torch.log(-torch.expm1(x)))
+
+
+def exp_norm_rbf(dist: Tensor, beta: Tensor, mu: Tensor) -> Tensor:
+    """``ExponentialNorm.forward`` (nn/rbf.py:204-207)."""
+    return torch.exp(-beta * torch.square(torch.exp(-dist) - mu))
+
+
 def compute_edge_data(data: Dict[str, Tensor], compute_forces: bool = True, compute_virial: bool = False) -> Dict[str, Tensor]:
     """``compute_edge_data`` (nn/basic.py:60-140) incl. the virial/strain branch (:93-107)."""
     pos = data[POSITIONS]
@@ -320,6 +332,10 @@ class XPaiNNOracle:
             data["rbf"] = bessel_rbf(dist, sd[p + "rbf.freq"], self.cutoff)
         elif self.rbf_kernel == "gaussian":
             data["rbf"] = gaussian_rbf(dist, sd[p + "rbf.mean"], sd[p + "rbf.std"])
+        elif self.rbf_kernel == "expbern":
+            data["rbf"] = exp_bernstein_rbf(dist, sd[p + "rbf._alpha"], sd[p + "rbf.logc"], sd[p + "rbf.n"], sd[p + "rbf.v"])
+        elif self.rbf_kernel == "expnorm":
+            data["rbf"] = exp_norm_rbf(dist, sd[p + "rbf.beta"], sd[p + "rbf.mu"])
         else:
             raise NotImplementedError(self.rbf_kernel)
         if self.cutoff_fn == "cosine":

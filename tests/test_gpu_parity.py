@@ -438,6 +438,40 @@ def test_equivariant_layer_norm_fwd_bwd(irreps, dtype, tol):
     np.testing.assert_allclose(xg.grad.cpu().double().numpy(), xr.grad.numpy(), rtol=tol, atol=tol * scale)
 
 
+def test_exponential_radial_bases_against_the_reference():
+    """nn/rbf.py:161-207 through xeq_radial_fwd: ExponentialBernstein as resolve_rbf builds it (the cutoff handed over as alpha) and with
+    the class default, ExponentialNorm -- against the reference's own values (tests/golden/rbf_exp_*.npz); the modules carry the
+    reference's parameter and buffer names."""
+    from xequinet_amd.nn import rbf as prbf
+
+    for tag, dtype, tol in (("f32", torch.float32, 2e-5), ("f64", torch.float64, 1e-11)):
+        f = _load(f"rbf_exp_{tag}.npz")
+        d = _t(f["dist"], dtype)
+        torch.set_default_dtype(dtype)
+        try:
+            mods = {"expbern20_a5": prbf.resolve_rbf("expbern", 20, 5.0), "expbern20_a05": prbf.ExponentialBernstein(20),
+                    "expnorm20_rc5": prbf.resolve_rbf("expnorm", 20, 5.0)}
+            assert set(mods["expbern20_a5"].state_dict()) == {"_alpha", "logc", "n", "v"} and set(mods["expnorm20_rc5"].state_dict()) == {"beta", "mu"}
+            for name, m in mods.items():
+                for pname, p in m.named_parameters():
+                    np.testing.assert_allclose(p.detach().numpy(), f[f"{name}_param_{pname}"], rtol=1e-6 if dtype == torch.float32 else 1e-14)
+                np.testing.assert_allclose(m.to(DEV)(d).cpu().numpy(), f[name], rtol=tol, atol=tol * 1e-3, err_msg=name)
+        finally:
+            torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("kernel", ["expbern", "expnorm"])
+@pytest.mark.parametrize("dtype,n_mol", [(torch.float64, 7), (torch.float32, 7), (torch.float32, 40)])
+def test_model_with_exponential_radial_bases(kernel, dtype, n_mol):
+    """The default XPaiNN with rbf_kernel = "expbern" / "expnorm" (nn/rbf.py:14-17): energies and forces against the fp64 oracle -- the
+    sb kernels (7 molecules, both precisions), the matrix-core wq kernels (40 molecules, f32); the basis and its distance derivative are
+    evaluated inside the record kernels (csrc/xeq_common.h::radial)."""
+    model, oracle = _build(dtype, rbf_kernel=kernel)
+    pos, z, ptr = syn.synth_qm9_batch(n_mol, seed=5)
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
+    _check_model(model, oracle, pos, z, ptr, ei, dtype)
+
+
 def test_radial_and_scatter_ops():
     from xequinet_amd.nn import rbf as prbf
     from xequinet_amd.scatter import scatter, scatter_sum

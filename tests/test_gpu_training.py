@@ -68,12 +68,15 @@ VARIANT = dict(node_dim=64, node_irreps="64x0e + 32x1o + 32x2e", action_blocks=2
 
 
 @pytest.mark.parametrize("case", ["energy", "variant energy", "periodic energy", "energy (differentiable form)", "energy+forces",
-                                  "periodic energy+forces+virial", "variant energy+forces", "energy+forces, 40 molecules"])
+                                  "periodic energy+forces+virial", "variant energy+forces", "energy+forces, 40 molecules",
+                                  "expbern energy", "expbern energy+forces", "expnorm energy", "expnorm energy+forces"])
 def test_parameter_gradients_match_the_oracle(case):
     """An energy-only loss takes the NATIVE training pass (fused kernels + xeq_message_param_grad, nn/fused.py); forces / virial in
     the loss need second order and take the differentiable form (nn/training.py)."""
     periodic = case.startswith("periodic")
     cfg = VARIANT if case.startswith("variant") else SMALL   # variant: gaussian basis (trainable mean / std), polynomial envelope, no layer norm, tanh
+    if case.startswith("exp"):   # the exponential bases (nn/rbf.py:161-207; trainable _alpha / beta, mu): every training pass takes the differentiable form
+        cfg = dict(SMALL, rbf_kernel=case.split()[0])
     weights = {keys.TOTAL_ENERGY: 1.0}
     if "forces" in case:
         weights[keys.FORCES] = 10.0
@@ -86,7 +89,8 @@ def test_parameter_gradients_match_the_oracle(case):
     data = dict(dev)
     result = model(data, keys.FORCES in weights, keys.VIRIAL in weights)
     from xequinet_amd.nn import training as tr
-    assert bool(data[tr.PARAM_GRADS]) == (model.native_training and keys.FORCES not in weights and keys.VIRIAL not in weights)
+    assert bool(data[tr.PARAM_GRADS]) == (model.native_training and keys.FORCES not in weights and keys.VIRIAL not in weights
+                                          and not case.startswith("exp"))
     loss, _ = train.weighted_loss(result, {k: v.to(DEV) for k, v in tgt.items()}, weights)
     loss.backward()
 

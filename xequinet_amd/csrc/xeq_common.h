@@ -98,7 +98,7 @@ __host__ __device__ inline XAddr xaddr(const Irreps& ir, int64_t N, int u, int l
 
 // radial-basis / envelope selection (mirrors resolve_rbf / resolve_cutoff, nn/rbf.py:9-32)
 struct RadialSpec {
-  int rbf_kind;     // XEQ_RBF_BESSEL | XEQ_RBF_GAUSSIAN
+  int rbf_kind;     // XEQ_RBF_BESSEL | XEQ_RBF_GAUSSIAN | XEQ_RBF_EXPBERN | XEQ_RBF_EXPNORM
   int cutoff_kind;  // XEQ_CUTOFF_COSINE | XEQ_CUTOFF_POLYNOMIAL
   int num_basis;
   double cutoff;
@@ -114,6 +114,12 @@ template <typename T> __device__ __forceinline__ T exp_(T x);
 template <> __device__ __forceinline__ float exp_<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ double exp_<double>(double x) { return exp(x); }
 template <typename T> __device__ __forceinline__ T abs_(T x) { return x < T(0) ? -x : x; }
+template <typename T> __device__ __forceinline__ T expm1_(T x);
+template <> __device__ __forceinline__ float expm1_<float>(float x) { return expm1f(x); }
+template <> __device__ __forceinline__ double expm1_<double>(double x) { return expm1(x); }
+template <typename T> __device__ __forceinline__ T log_(T x);
+template <> __device__ __forceinline__ float log_<float>(float x) { return logf(x); }
+template <> __device__ __forceinline__ double log_<double>(double x) { return log(x); }
 
 // envelope f(d) and f'(d)
 template <typename T>
@@ -138,10 +144,25 @@ __device__ __forceinline__ void envelope(int kind, T d, T rc, T& f, T& df) {
   }
 }
 
-// radial basis rho_k(d) and rho_k'(d); p0/p1 = freq/- (bessel) or mean/std (gaussian)
+// radial basis rho_k(d) and rho_k'(d); p0/p1 = freq/- (bessel), mean/std (gaussian), softplus(_alpha)/log binomial (exponential
+// Bernstein: k and the basis size B select the polynomial), beta/mu (exponential norm)
 template <typename T>
-__device__ __forceinline__ void radial(int kind, T d, T rc, T p0, T p1, T& rho, T& drho) {
-  if (kind == XEQ_RBF_BESSEL) {
+__device__ __forceinline__ void radial(int kind, T d, T rc, T p0, T p1, T& rho, T& drho, int k = 0, int B = 0) {
+  if (kind == XEQ_RBF_EXPBERN) {
+    // nn/rbf.py:186-191: x = -alpha d, rho_k = exp(logc_k + n_k x + v_k log(-expm1(x))), v_k = k, n_k = B - 1 - k
+    const T x = -p0 * d;
+    const T om = -expm1_<T>(x);           // 1 - e^x
+    const T L = log_<T>(om);
+    const T n = T(B - 1 - k), v = T(k);
+    rho = exp_<T>(p1 + n * x + v * L);
+    drho = rho * p0 * (v * (T(1) - om) / om - n);   // d/dd [n x + v log(1 - e^x)], x = -alpha d
+  } else if (kind == XEQ_RBF_EXPNORM) {
+    // nn/rbf.py:204-207: rho_k = exp(-beta_k (exp(-d) - mu_k)^2)
+    const T e = exp_<T>(-d);
+    const T t = e - p1;
+    rho = exp_<T>(-p0 * t * t);
+    drho = rho * T(2) * p0 * t * e;
+  } else if (kind == XEQ_RBF_BESSEL) {
     const T eps = T(1e-5);
     T coeff = sqrt_<T>(T(2) / rc);
     T s, c;

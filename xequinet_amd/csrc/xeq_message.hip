@@ -78,7 +78,7 @@ __device__ __forceinline__ void stage_chunk(const MsgArgs& a, const T* __restric
     int j = idx / B, k = idx - j * B;
     T d = sh_g[j][3], f = sh_y[j][9], df = sh_y[j][10];
     T rho, drho;
-    radial<T>(a.rs.rbf_kind, d, rc, p0[k], p1 ? p1[k] : T(0), rho, drho);
+    radial<T>(a.rs.rbf_kind, d, rc, p0[k], p1 ? p1[k] : T(0), rho, drho, k, B);
     sh_rf[j][k] = f * rho;
     if (BWD) sh_drf[j][k] = df * rho + f * drho;
   }
@@ -424,8 +424,8 @@ static int check_msg(const char* who, int64_t n_nodes, int64_t n_edges, int num_
   XEQ_CHECK_ARG(n_nodes >= 0 && n_edges >= 0 && n_edges < (1ll << 31) && n_nodes < (1ll << 31), "%s: bad sizes", who);
   XEQ_CHECK_ARG(num_basis >= 1 && num_basis <= 32, "%s: num_basis %d outside the supported range 1..32", who, num_basis);
   XEQ_CHECK_ARG(cutoff > 0, "%s: cutoff must be positive", who);
-  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "%s: rbf kernel %d is not implemented", who, rbf_kind);
-  XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "%s: gaussian rbf needs std", who);
+  XEQ_CHECK_ARG(rbf_kind >= XEQ_RBF_BESSEL && rbf_kind <= XEQ_RBF_EXPNORM, "%s: rbf kernel %d is not implemented", who, rbf_kind);
+  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || p1 != nullptr, "%s: this radial basis needs its second parameter array (std / logc / mu)", who);
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "%s: cutoff function %d is not implemented", who, cutoff_kind);
   for (int l = 0; l < 3; ++l) {
     XEQ_CHECK_ARG(mul[l] >= 0, "%s: negative multiplicity", who);
@@ -524,6 +524,7 @@ int xeq_message_param_grad(int dtype, int64_t n_nodes, int64_t n_edges, const in
                            void* stream) {
   MsgArgs a{};
   int rcode = check_msg("xeq_message_param_grad", n_nodes, n_edges, num_basis, cutoff, rbf_kind, cutoff_kind, node_dim, mul, p1, a);
+  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_message_param_grad: the parameter gradients of rbf kernel %d are not built (the differentiable tensor form takes that basis)", rbf_kind);
   if (rcode != XEQ_OK) return rcode;
   XEQ_CHECK_ARG(n_parts == xeq_message_param_grad_parts(n_nodes), "xeq_message_param_grad: parts must hold xeq_message_param_grad_parts(n_nodes) = %d blocks, got %d",
                 xeq_message_param_grad_parts(n_nodes), n_parts);

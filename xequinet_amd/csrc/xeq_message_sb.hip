@@ -41,7 +41,7 @@ __global__ void k_edge_basis(const T* __restrict__ vec, int64_t E, RadialSpec rs
   envelope<T>(rs.cutoff_kind, g.d, rc, f, df);
   if (k < B) {
     T rho, drho;
-    radial<T>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : T(0), rho, drho);
+    radial<T>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : T(0), rho, drho, k, B);
     eb[e * EW + k] = f * rho;
     if (ed) ed[e * EW + k] = df * rho + f * drho;
   } else {
@@ -923,8 +923,8 @@ int xeq_message_sb_fits(int64_t n_nodes, int64_t n_edges, int num_basis, int nod
 int xeq_edge_basis(int dtype, const void* vec, int64_t n_edges, int rbf_kind, int cutoff_kind, int num_basis,
                    double cutoff, const void* p0, const void* p1, void* basis, void* dbasis, void* stream) {
   XEQ_CHECK_ARG(n_edges >= 0 && num_basis >= 1 && num_basis <= 32 && cutoff > 0, "xeq_edge_basis: bad sizes");
-  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_edge_basis: rbf kernel %d is not implemented", rbf_kind);
-  XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis: gaussian rbf needs std");
+  XEQ_CHECK_ARG(rbf_kind >= XEQ_RBF_BESSEL && rbf_kind <= XEQ_RBF_EXPNORM, "xeq_edge_basis: rbf kernel %d is not implemented", rbf_kind);
+  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || p1 != nullptr, "xeq_edge_basis: this radial basis needs its second parameter array (std / logc / mu)");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis: cutoff function %d is not implemented", cutoff_kind);
   if (n_edges == 0) return XEQ_OK;
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};

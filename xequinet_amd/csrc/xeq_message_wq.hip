@@ -235,7 +235,7 @@ __device__ __forceinline__ void wq_record_piece(const float* __restrict__ vec, c
     val = dval = 0.f;
     if (k >= 0 && k < B) {
       float rho, drho;
-      radial<float>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : 0.f, rho, drho);
+      radial<float>(rs.rbf_kind, g.d, rc, p0[k], p1 ? p1[k] : 0.f, rho, drho, k, B);
       val = f * rho;
       dval = df * rho + f * drho;
     } else if (k == -1) {
@@ -1646,8 +1646,8 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
                       int rbf_kind, int cutoff_kind, int num_basis, double cutoff, const void* p0, const void* p1,
                       void* basis, void* dbasis, void* stream) {
   XEQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 0 && num_basis >= 1 && num_basis <= 31 && cutoff > 0, "xeq_edge_basis_wq: bad sizes");
-  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_edge_basis_wq: rbf kernel %d is not implemented", rbf_kind);
-  XEQ_CHECK_ARG(rbf_kind != XEQ_RBF_GAUSSIAN || p1 != nullptr, "xeq_edge_basis_wq: gaussian rbf needs std");
+  XEQ_CHECK_ARG(rbf_kind >= XEQ_RBF_BESSEL && rbf_kind <= XEQ_RBF_EXPNORM, "xeq_edge_basis_wq: rbf kernel %d is not implemented", rbf_kind);
+  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || p1 != nullptr, "xeq_edge_basis_wq: this radial basis needs its second parameter array (std / logc / mu)");
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_edge_basis_wq: cutoff function %d is not implemented", cutoff_kind);
   if (n_edges == 0 && n_nodes == 0) return XEQ_OK;   // (no edge at all: the nodes' lone quads still need their zero records)
   const int64_t pcap = wq_pcap(n_nodes, n_edges), total = (pcap + WQ_REC_SLOTS - 1) / WQ_REC_SLOTS * 256;   // a workgroup per WQ_REC_SLOTS records

@@ -160,7 +160,7 @@ __global__ void k_radial_fwd(const T* __restrict__ dist, int64_t n, RadialSpec r
     }
   } else if (rbf) {
     T rho, drho;
-    radial<T>(rs.rbf_kind, d, rc, p0[k], p1 ? p1[k] : T(0), rho, drho);
+    radial<T>(rs.rbf_kind, d, rc, p0[k], p1 ? p1[k] : T(0), rho, drho, k, B);
     rbf[e * B + k] = rho;
   }
 }
@@ -457,9 +457,10 @@ int xeq_sph_harm_bwd(int dtype, const void* vec, const void* grad_out, int64_t n
 int xeq_radial_fwd(int dtype, const void* dist, int64_t n, int rbf_kind, int cutoff_kind, int num_basis,
                    double cutoff, const void* p0, const void* p1, void* rbf_out, void* fcut_out, void* stream) {
   XEQ_CHECK_ARG(num_basis > 0 && cutoff > 0, "xeq_radial_fwd: bad num_basis/cutoff");
-  XEQ_CHECK_ARG(rbf_kind == XEQ_RBF_BESSEL || rbf_kind == XEQ_RBF_GAUSSIAN, "xeq_radial_fwd: rbf kernel %d is not implemented", rbf_kind);
+  XEQ_CHECK_ARG(rbf_kind >= XEQ_RBF_BESSEL && rbf_kind <= XEQ_RBF_EXPNORM, "xeq_radial_fwd: rbf kernel %d is not implemented", rbf_kind);
   XEQ_CHECK_ARG(cutoff_kind == XEQ_CUTOFF_COSINE || cutoff_kind == XEQ_CUTOFF_POLYNOMIAL, "xeq_radial_fwd: cutoff function %d is not implemented", cutoff_kind);
   XEQ_CHECK_ARG(rbf_out == nullptr || p0 != nullptr, "xeq_radial_fwd: rbf parameters missing");
+  XEQ_CHECK_ARG(rbf_out == nullptr || rbf_kind == XEQ_RBF_BESSEL || p1 != nullptr, "xeq_radial_fwd: this radial basis needs its second parameter array (std / logc / mu)");
   if (n <= 0) return XEQ_OK;
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
   int64_t total = n * (num_basis + 1);

@@ -24,7 +24,7 @@ SB_NO_GY = 32
 WQ_MIRROR_WALK = 4       # XEQ_WQ_MIRROR_WALK: the reverse wq kernel walks the forward plan of a symmetric list
 WQ_PACKED_WEIGHTS = 64   # XEQ_WQ_PACKED_WEIGHTS: w_rbf of the wq message kernels is the packed copy (xeq_message_wq_pack_weights)
 WQ_MAX_PART_SETS = 8     # XEQ_WQ_MAX_PART_SETS: sets of per-block partials one xeq_message_wq_edge_grad_sum launch adds up
-RBF_KINDS = {"bessel": 0, "gaussian": 1}
+RBF_KINDS = {"bessel": 0, "gaussian": 1, "expbern": 2, "expnorm": 3}
 CUTOFF_KINDS = {"cosine": 0, "polynomial": 1}
 
 _P = c_void_p

@@ -44,7 +44,9 @@ PARAM_GRADS = "_xeq_param_grads"
 
 def native_pass_supported(model: torch.nn.Module) -> bool:
     """Every block of the model has the fused form with parameter gradients (the blocks of this package with ``fused`` on)."""
-    return all(getattr(m, "fused", True) for m in model.modules())
+    # (the parameter-gradient kernels of the radial filter take the Bessel and Gaussian bases: xeq_message_param_grad)
+    return (all(getattr(m, "fused", True) for m in model.modules())
+            and all(getattr(m, "kind", "bessel") in ("bessel", "gaussian") for m in model.modules() if hasattr(m, "params") and hasattr(m, "num_basis")))
 
 
 def wants_training_pass(module: torch.nn.Module) -> bool:
@@ -123,6 +125,11 @@ def radial_basis(rbf: torch.nn.Module, dist: torch.Tensor) -> torch.Tensor:
     if rbf.kind == "gaussian":      # nn/rbf.py:128-131
         std = rbf.std.abs() + rbf.eps
         return torch.exp(-0.5 * ((dist - rbf.mean) / std) ** 2) / (std * math.sqrt(2 * math.pi))
+    if rbf.kind == "expbern":       # nn/rbf.py:186-191
+        x = -torch.nn.functional.softplus(rbf._alpha) * dist
+        return torch.exp(rbf.logc + rbf.n * x + rbf.v * torch.log(-torch.expm1(x)))
+    if rbf.kind == "expnorm":       # nn/rbf.py:204-207
+        return torch.exp(-rbf.beta * torch.square(torch.exp(-dist) - rbf.mu))
     raise NotImplementedError(f"radial basis {rbf.kind}")
 
 
