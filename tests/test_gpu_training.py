@@ -228,6 +228,52 @@ def test_training_step_as_one_graph_follows_the_host_launched_steps():
         assert (p - q).abs().max().item() <= 2e-4 * scale, n
 
 
+def test_captured_step_with_gradient_clipping_and_ema_follows_the_reference_loop():
+    """utils/trainer.py:303-311 inside the capture: clip_grad_norm_ between the reverse pass and Adam, and the exponential moving average
+    of the parameters behind it.  Against the host-launched loop in the reference's own form -- ``train_step(..., grad_clip=..)`` and a
+    ``torch.optim.swa_utils.AveragedModel`` with avg_fn = decay avg + (1 - decay) p, whose first update is a copy -- over four steps
+    on three different batches in fp64: losses, parameters and averaged parameters agree to 1e-9; the clip bites (the gradient norm of a
+    random-weight model is far above the threshold), and the average differs from the parameters."""
+    from torch.optim.swa_utils import AveragedModel
+
+    from xequinet_amd import runtime
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+
+    torch.manual_seed(0)
+    dt, decay, clip = torch.float64, 0.9, 0.05
+    batches = []
+    for k, n_mol in enumerate((12, 9, 14)):
+        host, dev = _batch(n_mol, 70 + k, dt)
+        batches.append((host, dev, _targets(host, 80 + k, False)))
+    cap = (max(b[0]["pos"].shape[0] for b in batches) + 8, max(b[0]["ptr"].numel() - 1 for b in batches),
+           max(runtime.pair_capacity(b[0]["ptr"].numpy()) for b in batches))
+    fast, slow = _model(dt, **SMALL).train(), _model(dt, **SMALL).train()
+    slow.load_state_dict(fast.state_dict())
+    opt_f = torch.optim.Adam(fast.parameters(), lr=1e-3, capturable=True)
+    opt_s = torch.optim.Adam(slow.parameters(), lr=1e-3, capturable=True)
+    ema_ref = AveragedModel(slow, device=DEV, avg_fn=lambda avg, p, num: decay * avg + (1 - decay) * p)     # trainer.py:218-227
+    step = train.GraphedTrainStep(fast, opt_f, cap, grad_clip=clip, ema_decay=decay)
+    for host, dev, tgt in batches + batches[:1]:
+        loss_f = step(dev["pos"], dev["atomic_numbers"], dev["ptr"], tgt[keys.TOTAL_ENERGY].to(DEV), batch=dev["batch"]).item()
+        b = NeighborTransform(5.0)(XequiBatch(dev["pos"], dev["atomic_numbers"], dev["ptr"]))
+        t = {keys.TOTAL_ENERGY: tgt[keys.TOTAL_ENERGY].to(DEV), keys.BATCH_PTR: dev["ptr"]}
+        loss_s = train.train_step(slow, b.to_dict(), t, opt_s, {keys.TOTAL_ENERGY: 1.0}, grad_clip=clip, ema_model=ema_ref)[0].item()
+        assert abs(loss_f - loss_s) <= 1e-9 * max(1.0, abs(loss_s)), (loss_f, loss_s)
+        gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in slow.parameters() if p.grad is not None)).item()
+        assert gnorm <= clip * (1 + 1e-6)                                   # what train_step left behind is the clipped gradient
+    assert step.captures == 1
+    moved = 0.0
+    for (n, p), q, a, (_, r) in zip(fast.named_parameters(), slow.parameters(), step.ema_parameters, ema_ref.module.named_parameters()):
+        scale = max(1e-3, q.abs().max().item())
+        assert (p - q).abs().max().item() <= 1e-9 * scale, n
+        assert (a - r).abs().max().item() <= 1e-9 * scale, "ema of " + n
+        moved = max(moved, (a - p).abs().max().item())
+    assert moved > 1e-5
+    twin = _model(dt, **SMALL)
+    step.copy_ema_to(twin)
+    assert all(torch.equal(a, b) for a, b in zip(twin.parameters(), step.ema_parameters))
+
+
 def test_force_loss_training_step_as_one_graph_follows_the_host_launched_steps():
     """The same with forces in the loss: the twice-differentiable pass (kernel forms of nn/training.py) inside the capture, over the
     capacity-sized edge list -- padding atoms, empty graph slots and the edge slots behind the true count (stale pairs of earlier

@@ -55,9 +55,10 @@ def wrap_ddp(model: torch.nn.Module, local_rank: Optional[int] = None, find_unus
 
 def train_step(model: torch.nn.Module, data: Dict[str, torch.Tensor], target: Dict[str, torch.Tensor],
                optimizer: torch.optim.Optimizer, weights: Dict[str, float], loss_fn: str = "l2",
-               grad_clip: Optional[float] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-    """utils/trainer.py:290-308 for one batch.  ``model`` is the (DDP-wrapped) BaseModel; forces / virial are evaluated
-    iff they carry a loss weight (trainer.py:173-177).  Returns the detached loss and the model's result."""
+               grad_clip: Optional[float] = None, ema_model=None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """utils/trainer.py:290-311 for one batch.  ``model`` is the (DDP-wrapped) BaseModel; forces / virial are evaluated
+    iff they carry a loss weight (trainer.py:173-177).  ``ema_model``: a ``torch.optim.swa_utils.AveragedModel`` as the reference builds it
+    (trainer.py:218-227), updated behind the optimizer step (:309-311).  Returns the detached loss and the model's result."""
     model.train()
     compute_forces = keys.FORCES in weights
     compute_virial = keys.VIRIAL in weights
@@ -68,6 +69,8 @@ def train_step(model: torch.nn.Module, data: Dict[str, torch.Tensor], target: Di
     if grad_clip is not None:
         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
     optimizer.step()
+    if ema_model is not None:
+        ema_model.update_parameters(model)
     return loss.detach(), {k: v.detach() for k, v in result.items()}
 
 
@@ -86,14 +89,21 @@ class GraphedTrainStep:
     The optimizer must keep its state on the device (``torch.optim.Adam(..., capturable=True)``).  Python-float hyper-parameters
     (``lr``, betas, ``weight_decay``) are baked into the graph at capture: a scheduler or warm-up that rewrites
     ``param_groups[...]['lr']`` has no effect on replays unless ``lr`` is a device tensor (``Adam(lr=torch.tensor(...),
-    capturable=True)``, updated in place) -- ``set_lr`` does that update and re-captures when ``lr`` is a plain float.  Gradient
-    clipping and EMA (utils/trainer.py:303-308 of the reference) are NOT part of the captured step.  The warm-up iterations in front of
-    the capture are real steps on the first batch; model and optimizer are put back to their state before them, so the first
-    replayed step is the first update."""
+    capturable=True)``, updated in place) -- ``set_lr`` does that update and re-captures when ``lr`` is a plain float.
+
+    ``grad_clip`` / ``ema_decay`` (round 5) put the rest of the reference's inner loop into the capture: ``clip_grad_norm_`` between the
+    reverse pass and the optimizer (utils/trainer.py:303-307; its device-side form: the total norm never reaches the host) and the
+    exponential moving average of the parameters behind it (trainer.py:218-227, 309-311: ``AveragedModel`` with avg = decay avg +
+    (1 - decay) p, the first update a copy) -- kept in ``ema_parameters`` (one tensor per model parameter, in order; ``copy_ema_to``
+    writes them into a model for validation, trainer.py:354-355), as multi-tensor launches, with the "first update copies" rule as a
+    device-side weight that is 0 once and ``decay`` from then on.
+
+    The warm-up iterations in front of the capture are real steps on the first batch; model, optimizer and average are put back to
+    their state before them, so the first replayed step is the first update."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, capacity, prop: str = keys.TOTAL_ENERGY,
                  loss_fn: str = "l2", cutoff: Optional[float] = None, warmup: int = 3, energy_weight: float = 1.0,
-                 forces_weight: Optional[float] = None) -> None:
+                 forces_weight: Optional[float] = None, grad_clip: Optional[float] = None, ema_decay: Optional[float] = None) -> None:
         from . import runtime
 
         if prop not in (keys.TOTAL_ENERGY, keys.ENERGY_PER_ATOM):
@@ -120,6 +130,13 @@ class GraphedTrainStep:
         self.loss: Optional[torch.Tensor] = None
         self.captures = 0
         self._count = None
+        self.grad_clip = None if grad_clip is None else float(grad_clip)
+        self.ema_decay = None if ema_decay is None else float(ema_decay)
+        self.ema_parameters = None
+        if self.ema_decay is not None:
+            self._params = [p for p in model.parameters()]
+            self.ema_parameters = [p.detach().clone() for p in self._params]
+            self._ema_w = torch.zeros((), dtype=dt, device=dev)            # weight of the old average: 0 at the first update (a copy), decay after
 
     def set_lr(self, lr: float) -> None:
         """A new learning rate for the next steps: written into a tensor-valued ``lr`` in place (the captured graph reads it), a
@@ -158,8 +175,24 @@ class GraphedTrainStep:
             loss = self.energy_weight * loss
         loss = loss * (self._count.reshape(-1)[0] <= g.n_edges).to(loss.dtype)   # device-side: an overflowed replay has zero gradients
         loss.backward()
+        if self.grad_clip is not None:      # utils/trainer.py:303-307; no error_if_nonfinite: nothing of the norm is read on the host
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
         self.optimizer.step()
+        if self.ema_decay is not None:      # trainer.py:309-311: avg <- w avg + (1 - w) p, w = 0 the first time, decay afterwards
+            with torch.no_grad():
+                torch._foreach_mul_(self.ema_parameters, self._ema_w)
+                torch._foreach_add_(self.ema_parameters, torch._foreach_mul([p.detach() for p in self._params], 1.0 - self._ema_w))
+                self._ema_w.fill_(self.ema_decay)
         return loss.detach()
+
+    def copy_ema_to(self, model: torch.nn.Module) -> None:
+        """The averaged parameters into ``model`` (same architecture): what the reference validates with (utils/trainer.py:354-355)."""
+        if self.ema_parameters is None:
+            raise ValueError("GraphedTrainStep was built without ema_decay")
+        with torch.no_grad():
+            for q, a in zip(model.parameters(), self.ema_parameters):
+                q.copy_(a)
+        lib.bump_pack_epoch()
 
     def _capture(self) -> None:
         import copy
@@ -168,6 +201,7 @@ class GraphedTrainStep:
         self.model.train()
         model_state = copy.deepcopy(self.model.state_dict())
         opt_saved = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.optimizer.state.items()}
+        ema_saved = None if self.ema_parameters is None else ([a.clone() for a in self.ema_parameters], self._ema_w.clone())
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -188,6 +222,10 @@ class GraphedTrainStep:
                             v.copy_(opt_saved[p][k])
                         else:
                             v.zero_()
+            if ema_saved is not None:
+                for a, b in zip(self.ema_parameters, ema_saved[0]):
+                    a.copy_(b)
+                self._ema_w.copy_(ema_saved[1])
         gc.collect()
         self.graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
