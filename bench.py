@@ -291,6 +291,10 @@ def main():
     if sharded:
         max_edges = args.max_chunk_edges or runtime.WM_MAX_EDGES_PER_CHUNK
         n_chunks = len(xdist.plan_chunks(ptr, max_edges))
+    # a shard that is ONE chunk (the 65k batch over 8 ranks) is a batch like any other: it takes the whole-step path below, two steps
+    # in flight; the chunk walkers are for shards beyond one step's buffers
+    chunked = sharded and (n_chunks > 1 or args.eager or args.replay_model_only)
+    if chunked:
         graphed = None if args.eager else runtime.GraphedModel(model, compute_forces=True, compute_virial=False, tune_gemms=False,
                                                                max_graphs=max(8, 2 * n_chunks))
 
@@ -368,8 +372,8 @@ def main():
             batch = transform(new_batch())
             return batch.edge_index.shape[1], graphed(batch.to_dict())
 
-    whole_step = not sharded and not args.eager and (cell is None or len(ptr) == 2) and not args.replay_model_only
-    chunk_graphs = sharded and not args.eager and not args.replay_model_only
+    whole_step = not chunked and not args.eager and (cell is None or len(ptr) == 2) and not args.replay_model_only
+    chunk_graphs = chunked and not args.eager and not args.replay_model_only
     try:
         # set-up, not a timed or counted step: the first evaluation times the library GEMM candidates (TunableOp) and
         # captures the HIP graph; the W warm-up steps and the K timed steps that follow are all plain steps
@@ -473,7 +477,7 @@ def main():
             step_eager()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - te) / cal * 1e3
-        if not sharded and cell is None and dtype == torch.float32:
+        if not chunked and cell is None and dtype == torch.float32:
             # the same step through ONE registered operator (xeq::xpainn_eval, csrc/xeq_torch.cpp): every kernel enqueued
             # from C++, nothing captured -- what a stream of batches with ever-new topologies pays
             try:
