@@ -165,9 +165,16 @@ class XPaiNNGMX(XPaiNN):
                     ei0, _ = single_radius_graph(pos=positions, cell=cell, pbc=pbc, cutoff=self.cutoff_radius)
                 self._step_graph = GraphedStepPBC(_Core(self), positions.shape[0], int(1.25 * ei0.shape[1]) + 1024,
                                                   cutoff=self.cutoff_radius, compute_forces=True)
-            out = self._step_graph(positions.detach(), atomic_numbers, cell, pbc)
-            energy = _EnergyOfPositions.apply(positions, out[keys.TOTAL_ENERGY].clone(), out[keys.FORCES].clone())
-            return energy * self.energy_unit_factor
+            # the capacity check reads the edge count on the host (a synchronisation): everything that follows the replay is enqueued
+            # FIRST, so that the wait covers it instead of standing in front of it; a list that outgrew the capacity (rare: the step
+            # graph then grows and re-captures) repeats the step
+            sg = self._step_graph
+            out = sg(positions.detach(), atomic_numbers, cell, pbc, check=False)
+            energy = _EnergyOfPositions.apply(positions, out[keys.TOTAL_ENERGY].clone(), out[keys.FORCES].clone()) * self.energy_unit_factor
+            if sg.overflowed():
+                out = sg(positions.detach(), atomic_numbers, cell, pbc)
+                energy = _EnergyOfPositions.apply(positions, out[keys.TOTAL_ENERGY].clone(), out[keys.FORCES].clone()) * self.energy_unit_factor
+            return energy
         with torch.no_grad():
             edge_index, cell_offsets, rowptr = single_radius_graph(pos=positions, cell=cell, pbc=pbc, cutoff=self.cutoff_radius,
                                                                    return_rowptr=True)
