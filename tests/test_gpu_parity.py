@@ -838,6 +838,34 @@ def test_periodic_model_with_the_mirror_map_equals_the_sorted_reverse_walk(drop,
         assert float(diff.median()) <= 1e-4 * scale and float(diff.max()) <= 2e-2 * scale
 
 
+def test_two_periodic_graphs_through_the_list_builder_take_the_mirror_walk(monkeypatch):
+    """A batch of TWO periodic boxes with unwrapped positions (the reference's own fixture) through NeighborTransform -- the list this
+    package builds, with the mirror map over both graphs -- and the wq kernels: energies, forces and virial equal the evaluation of the
+    same list without the promise (stable sort by neighbor, reverse plan) to rounding, and the reference's list is reproduced."""
+    from xequinet_amd import keys
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wq")
+    f = _load("radius_graph_pbc_two_graphs_unwrapped.npz")
+    n = f["n_per_graph"].astype(np.int64)
+    ptr = np.concatenate([[0], np.cumsum(n)])
+    z = np.random.default_rng(2).choice([1, 6, 7, 8], size=int(n.sum())).astype(np.int32)
+    model, _ = _build(torch.float32)
+    b = NeighborTransform(float(f["cutoff"]))(XequiBatch(_t(f["pos"], torch.float32), _t(z), _t(ptr), pbc=_t(f["pbc"].reshape(1, 3).repeat(2, 0)),
+                                                        cell=_t(f["cell"], torch.float32)))
+    assert np.array_equal(b.edge_index.cpu().numpy(), f["edge_index"]) and np.array_equal(b.cell_offsets.cpu().numpy(), f["cell_offsets"].astype(np.float32))
+    data = b.to_dict()
+    g = data[keys.EDGE_GRAPH]
+    assert g.mirror_walk and int(g.mirror_map.min()) >= 0
+    plain = {k: v for k, v in data.items() if k != keys.EDGE_GRAPH}
+    with torch.enable_grad():
+        a = model(dict(data), compute_forces=True, compute_virial=True)
+        c = model(plain, compute_forces=True, compute_virial=True)
+    assert torch.equal(a["energy"], c["energy"])
+    assert float((a["forces"] - c["forces"]).abs().max()) <= 2e-6 * float(c["forces"].abs().max())
+    assert float((a["virial"] - c["virial"]).abs().max()) <= 2e-6 * float(c["virial"].abs().max())
+
+
 # -------------------------------------------------------------------- whole model
 def _build(dtype, **kw):
     from xequinet_amd.nn import resolve_model
