@@ -95,7 +95,8 @@ class ForceBounds(tuple):
     def record(self):
         return dict(oracle32_max_abs_dF=self[2], oracle32_p99_abs_dF=self[3], bound_dF_max=self[0], bound_dF_p99=self[1],
                     cpu_oracle32_max_abs_dF=self.cpu[0], cpu_oracle32_p99_abs_dF=self.cpu[1],
-                    aten_gpu32_max_abs_dF=self.aten_gpu[0], aten_gpu32_p99_abs_dF=self.aten_gpu[1])
+                    aten_gpu32_max_abs_dF=self.aten_gpu[0], aten_gpu32_p99_abs_dF=self.aten_gpu[1],
+                    envelope_members_cpu=getattr(self, "members", (None, None))[0], envelope_members_aten_gpu=getattr(self, "members", (None, None))[1])
 
 
 def f32_force_bounds(oracle, ref_in, Fref):
@@ -126,15 +127,21 @@ def f32_force_bounds(oracle, ref_in, Fref):
     rng = np.random.default_rng(20261004)
     err_cpu = err_gpu = None
     n_members = F32_ORACLE_ORDERS * (4 if n_e < 30000 else 1)   # small systems: one ill-conditioned atom is the whole tail (see above)
-    for member in range(n_members):
+    # large systems: the CPU oracle is what the suite's wall time is, so it keeps four orders there -- the GPU member costs a tenth of
+    # a second and takes sixteen orders at every size (its maximum over four draws moved between 7.0e-4 and 1.2e-3 from run to run on
+    # QM9-1024 -- its index_add is an atomic scatter -- against this package's 9.8e-4, which repeats bit for bit: a bound of 1.5 x the
+    # largest of FOUR draws is one unlucky run away; profiles/parity_r05.json)
+    n_gpu_members = max(n_members, 4 * F32_ORACLE_ORDERS)
+    for member in range(n_gpu_members):
         perm = (torch.arange(n_e) if member == 0 else torch.arange(n_e - 1, -1, -1) if member == 1
                 else torch.as_tensor(rng.permutation(n_e)))
         run = dict(in32)
         run["edge_index"] = ei[:, perm]
         if "cell_offsets" in run:
             run["cell_offsets"] = run["cell_offsets"][perm]
-        e = np.abs(twin(run, compute_forces=True)["forces"].double().numpy() - Fref)
-        err_cpu = e if err_cpu is None else np.maximum(err_cpu, e)
+        if member < n_members:
+            e = np.abs(twin(run, compute_forces=True)["forces"].double().numpy() - Fref)
+            err_cpu = e if err_cpu is None else np.maximum(err_cpu, e)
         # ... and the same member through ATen's fp32 kernels on the GPU (autograd's reverse pass, atomic index_add): the reference's
         # arithmetic as a GPU runs it.  The tail is the conditioning of the random-weight network on a few molecules
         # (profiles/r04_fp32_tail.txt), where ANY fp32 evaluation order draws errors 10-50 x apart, so the envelope holds GPU members too
@@ -148,6 +155,7 @@ def f32_force_bounds(oracle, ref_in, Fref):
     out = ForceBounds((max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR_MAX * e_max), max(F32_FORCE_FLOOR, F32_ORACLE_FACTOR * e_p99), e_max, e_p99))
     out.cpu = (float(err_cpu.max()), float(np.quantile(err_cpu, 0.99)))
     out.aten_gpu = (float(err_gpu.max()), float(np.quantile(err_gpu, 0.99)))
+    out.members = (n_members, n_gpu_members)
     _F32_BOUNDS_CACHE[key] = out
     return out
 
