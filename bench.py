@@ -177,8 +177,8 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)    # (0.2 s of timed region at 2 ms per step: the fill and drain of two steps in flight are 1 % of it)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="qm9_1024", choices=list(syn.WORKLOADS))
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
