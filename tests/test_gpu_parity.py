@@ -874,6 +874,40 @@ def test_two_periodic_graphs_through_the_list_builder_take_the_mirror_walk(monke
     assert float((a["virial"] - c["virial"]).abs().max()) <= 2e-6 * float(c["virial"].abs().max())
 
 
+def test_periodic_own_list_in_fp64_builds_the_sorted_view_on_demand():
+    """fp64 has no wq kernels: on this package's own periodic list (mirror map present) the sb / generic reverse kernels ask for the
+    neighbor-sorted view, which EdgeGraph then builds by the stable sort -- eagerly and inside the captured periodic step
+    (runtime.GraphedStepPBC, capacity form).  Energies and forces against the fp64 oracle at 1e-9, the captured step bit for bit the
+    eager one."""
+    from xequinet_amd import keys, runtime
+    from xequinet_amd.data import NeighborTransform, XequiBatch
+
+    dt = torch.float64
+    model, oracle = _build(dt)
+    f = _load("radius_graph_pbc_water192.npz")
+    _, z, ptr, _ = syn.synth_water_box(4, seed=5)
+    pbc = _t(np.array([[True, True, True]]))
+    b = NeighborTransform(5.0)(XequiBatch(_t(f["pos"], dt), _t(z.astype(np.int32)), _t(ptr), pbc=pbc, cell=_t(f["cell"], dt)))
+    data = b.to_dict()
+    g = data[keys.EDGE_GRAPH]
+    assert g.mirror_walk and g._n_view is None
+    with torch.enable_grad():
+        got = model(dict(data), compute_forces=True, compute_virial=False)
+    assert g._n_view is not None                      # somebody asked: the sorted view exists now
+    batch = np.zeros(len(z), dtype=np.int64)
+    want = oracle({"pos": torch.tensor(f["pos"].astype(np.float64)), "atomic_numbers": torch.tensor(z.astype(np.int64)),
+                   "edge_index": torch.tensor(f["edge_index"]), "batch": torch.tensor(batch), "ptr": torch.tensor(ptr),
+                   "cell": torch.tensor(f["cell"].astype(np.float64)), "cell_offsets": torch.tensor(f["cell_offsets"].astype(np.float64))},
+                  compute_forces=True)
+    assert float((got["energy"].detach().cpu() - want["energy"]).abs().max()) <= 1e-9 * max(1.0, float(want["energy"].abs().max()))
+    assert float((got["forces"].detach().cpu() - want["forces"]).abs().max()) <= 1e-9 * max(1.0, float(want["forces"].abs().max()))
+    step = runtime.GraphedStepPBC(model, len(z), int(1.25 * f["edge_index"].shape[1]) + 64)
+    for _ in range(2):
+        out = step(_t(f["pos"], dt), _t(z.astype(np.int32)), _t(f["cell"], dt)[0], [True, True, True])
+    assert int(out["n_edges"]) == f["edge_index"].shape[1]
+    assert torch.equal(out["energy"], got["energy"].detach()) and torch.equal(out["forces"], got["forces"].detach())
+
+
 # -------------------------------------------------------------------- whole model
 def _build(dtype, **kw):
     from xequinet_amd.nn import resolve_model
