@@ -210,10 +210,13 @@ def main():
                          "step includes the gradient all-reduce (RCCL; 865 k fp32 gradients, one bucket).  Prints its own JSON line "
                          "(metric 'training step'); the headline metric is the default mode's")
     ap.add_argument("--forces", action="store_true", help="with --train: forces in the loss (weight 10), i.e. the twice-differentiated pass")
-    ap.add_argument("--vary-batch", type=int, default=0, metavar="K",
+    ap.add_argument("--vary-batch", type=int, default=-1, metavar="K",
                     help="feed K different draws of the workload in turn (different atom and edge counts every step) through the "
-                         "one captured graph")
+                         "one captured graph.  Default: as many draws as steps in flight (two contexts evaluate two different "
+                         "batches: a stream of batches, not one batch twice), one draw with --in-flight 1")
     args = ap.parse_args()
+    if args.vary_batch < 0:
+        args.vary_batch = max(1, args.in_flight)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything in this process touches the GPU
@@ -454,11 +457,14 @@ def main():
             one(p_k, z_k, ptr_k, batch=b_k)
         torch.cuda.synchronize()
         one_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        out = one(p_k, z_k, ptr_k, batch=b_k)             # draw 0 again: what the host-launched and native-operator runs below are checked against
+        out_is_draw0 = True
     if whole_step:
         edges_done = edges_timed if n_flight > 1 else int((gstep.edge_total if cell is None else edge_total).item())   # the device-side counts of the K timed steps
         if cell is not None:
             assert not gpbc.overflowed(), "the periodic list outgrew its capacity inside the timed region"
     eager_ms = native_ms = None
+    out_is_draw0 = locals().get("out_is_draw0", False) or max(1, args.vary_batch) == 1
     if args.eager:
         kernel_ms = ops.KERNEL_TIMER.summary()       # HIP events recorded on the launch stream, in the timed region
         kernel_timing = "HIP events around every launch of the timed region, on the launch stream"
@@ -497,7 +503,7 @@ def main():
                 torch.cuda.synchronize()
                 native_ms = (time.perf_counter() - tn) / cal * 1e3
                 if whole_step:   # the captured step works on the padded batch (another row count for the remaining library GEMMs)
-                    if max(1, args.vary_batch) == 1:
+                    if out_is_draw0:
                         assert float((got[2] - out_keep["forces"]).abs().max()) <= 2e-3, "native operator and graph replay disagree"
                 else:
                     assert torch.equal(got[2], out_keep["forces"]), "native operator and graph replay disagree"
@@ -555,7 +561,12 @@ def main():
             hbm_line = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
             head = ({"bound": "mfma", "achieved": tfl, "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F32_MATRIX_PEAK_TFLOPS}
                     if mfma_bound else dict(bound="hbm", **hbm_line))
+            traffic_source = (None if traffic is None else
+                              "profiles/traffic.json: HBM bytes per launch from the separate FETCH_SIZE / WRITE_SIZE rocprofv3 --pmc passes of "
+                              "profiles/collect_traffic.sh on this workload (FETCH doubled per MI355X_MICROARCH.md), recorded when the "
+                              "profiles were taken -- NOT measured inside this run")
             roofline = {**head, "kernel": dom, "mfma_dtype": "f32 (exact, v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s dense)",
+                        "traffic_source": traffic_source,
                         "arithmetic_intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
                         "traffic": traffic, "avg_launch_ms": avg_ms, "timing": kernel_timing,
                         "algorithmic_bytes_per_launch": alg, "algorithmic_flops_per_launch": flops, "hbm": hbm_line,
@@ -584,6 +595,9 @@ def main():
             "metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_eager": eager_ms if eager_ms is not None else ms_per_step,
             "ms_per_step_native_op": native_ms, "ms_per_step_one_in_flight": one_ms if one_ms is not None else ms_per_step,
+            # the headline `value` is THROUGHPUT (edges/s of K whole steps between the two barriers) and, since round 5, is taken with
+            # `in_flight` steps overlapped; the one-step-at-a-time figure (rounds 1-4's definition, a step's latency) stays next to it
+            "value_one_in_flight": (edges_total / args.steps) / ((one_ms if one_ms is not None else ms_per_step) * 1e-3) if world == 1 else None,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {syn.WORKLOADS[args.workload]} ({what}), 5 A cutoff, default XPaiNN (865141 params, "

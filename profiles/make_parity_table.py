@@ -1,8 +1,8 @@
 """DESIGN.md section 2's full-size parity table, generated FROM THE RECORD the GPU tests write (tests/conftest.py ->
-gpurun_out/parity_r05.json, copied to profiles/parity_r05.json as the last action of the round):
+gpurun_out/parity_r06.json, copied to profiles/parity_r06.json as the last action of the round):
 
-    python profiles/make_parity_table.py [profiles/parity_r05.json]            # prints the markdown table
-    python profiles/make_parity_table.py profiles/parity_r05.json --write     # ... and replaces the block between the markers in DESIGN.md
+    python profiles/make_parity_table.py [profiles/parity_r06.json]            # prints the markdown table
+    python profiles/make_parity_table.py profiles/parity_r06.json --write     # ... and replaces the block between the markers in DESIGN.md
 
 Per configuration: the HIP path's error against the fp64 oracle (max, p99), the two envelopes apart -- the CPU oracle evaluated in fp32
 and the ATen-only GPU evaluation of the reference's op sequence (tests/test_gpu_parity.py::_aten_only: no kernel of this package runs,
@@ -48,7 +48,7 @@ def table(path):
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    path = args[0] if args else os.path.join(ROOT, "profiles", "parity_r05.json")
+    path = args[0] if args else os.path.join(ROOT, "profiles", "parity_r06.json")
     t = table(path)
     print(t)
     if "--write" in sys.argv:

@@ -38,5 +38,5 @@ def pytest_sessionfinish(session, exitstatus):
         return
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_r05.json"), "w") as f:
+    with open(os.path.join(out, "parity_r06.json"), "w") as f:
         json.dump({"exitstatus": int(exitstatus), "records": parity_record.RECORDS}, f, indent=1)

@@ -8,7 +8,7 @@ than the reference's own arithmetic at the reference's own precision).  Molecule
 molecule's oracle result does not depend on which other molecules the oracle sees.
 
 Every comparison appends its achieved maxima to PARITY; tests/conftest.py writes them to
-``gpurun_out/parity_r05.json`` at the end of the session (copied to ``profiles/``).
+``gpurun_out/parity_r06.json`` at the end of the session (copied to ``profiles/``).
 """
 import numpy as np
 import pytest
@@ -24,7 +24,12 @@ pytestmark = pytest.mark.gpu
 
 E_RTOL, E_ATOL = 1e-5, 1e-4
 F32_PLAIN_FORCE_TOL = 1e-4     # max-abs force tolerance in fp32 (model units), no envelope
-N_SAMPLE = 160   # molecules / frames the oracle evaluates: the error distribution is heavy-tailed, 64 draws leave the maximum to chance
+N_SAMPLE = 160   # molecules / frames of the property checks further down (sharding, replay, other initialisations)
+# test_full_size_against_oracle (round-5 review, item 3): the fp64 oracle evaluates EVERY molecule of the headline configuration and
+# 1 024 molecules / frames of the larger ones, in chunks of ORACLE_CHUNK molecules (molecules do not interact); the error distribution
+# is heavy-tailed, the maximum over a 16 % sample is not the maximum
+N_COMPARE = {"qm9_1024": 1024, "md17_4096": 1024, "qm9_8192": 1024, "qm9_8192_chunked": 1024}
+ORACLE_CHUNK = 256
 # forces (model units): tests/test_gpu_parity.py::f32_force_bounds
 
 
@@ -69,6 +74,36 @@ def _compare(name, E, F, Eref, Fref, extra, oracle, ref_in):
     assert dF.max() <= b_max and np.quantile(dF, 0.99) <= b_p99, rec
 
 
+def _compare_chunked(name, E, F, pos, z, ptr, mols, oracle, extra):
+    """The comparison of ``_compare`` over MANY molecules: the fp64 oracle and the fp32 envelope (two CPU-oracle edge orders and sixteen
+    ATen-only GPU orders per chunk) walk the molecules in chunks, the per-atom errors and envelopes are gathered, and ONE maximum and
+    ONE 99th percentile are asserted over all of them -- the HIP maximum over the whole compared set against the envelope of the whole
+    compared set."""
+    from tests.test_gpu_parity import bounds_from_envelopes
+
+    dE_all, Eref_all, dF_all, Fref_all, ecpu, egpu, atoms, edges, members = [], [], [], [], [], [], 0, 0, None
+    for c0 in range(0, len(mols), ORACLE_CHUNK):
+        part = mols[c0 : c0 + ORACLE_CHUNK]
+        idx, Eref, Fref, e_sub, ref_in = _oracle_subset(oracle, pos, z, ptr, part)
+        b = f32_force_bounds(oracle, ref_in, Fref, cpu_members=2)
+        dE_all.append(np.abs(E[part] - Eref)); Eref_all.append(Eref)
+        dF_all.append(np.abs(F[idx] - Fref)); Fref_all.append(Fref)
+        ecpu.append(b.err_cpu); egpu.append(b.err_gpu)
+        atoms += len(idx); edges += e_sub; members = b.members
+    dE, Eref, dF, Fref = (np.concatenate(a) for a in (dE_all, Eref_all, dF_all, Fref_all))
+    bounds = bounds_from_envelopes(np.concatenate(ecpu), np.concatenate(egpu), members)
+    b_max, b_p99, e32_max, e32_p99 = bounds
+    rec = dict(config=name, max_abs_dE=float(dE.max()), max_dE_over_bound=float((dE / (E_RTOL * np.abs(Eref) + E_ATOL)).max()),
+               max_abs_dF=float(dF.max()), max_abs_F=float(np.abs(Fref).max()), max_abs_E=float(np.abs(Eref).max()),
+               p99_abs_dF=float(np.quantile(dF, 0.99)), p999_abs_dF=float(np.quantile(dF, 0.999)),
+               frac_atoms_within_plain_1e-4=float((dF.max(axis=1) <= F32_PLAIN_FORCE_TOL).mean()),
+               bound_dE=f"{E_RTOL}*|E|+{E_ATOL}", **bounds.record(), dtype="f32 HIP vs f64 oracle", compared_atoms=int(atoms),
+               compared_edges=int(edges), oracle_chunk_molecules=ORACLE_CHUNK, **extra)
+    parity_record.add(rec)
+    assert np.all(dE <= E_RTOL * np.abs(Eref) + E_ATOL), rec
+    assert dF.max() <= b_max and np.quantile(dF, 0.99) <= b_p99, rec
+
+
 @pytest.mark.parametrize("name,n_mol,n_atoms,n_edges,chunked", [
     ("qm9_1024", 1024, 18609, 311994, False),
     ("md17_4096", 4096, 86016, None, False),
@@ -82,11 +117,10 @@ def test_full_size_against_oracle(name, n_mol, n_atoms, n_edges, chunked):
     E, F, e_hip, _ = _hip_eval(model, pos, z, ptr, chunked=chunked)
     assert n_edges is None or e_hip == n_edges
     assert E.shape == (n_mol,) and F.shape == (len(pos), 3) and np.isfinite(E).all() and np.isfinite(F).all()
-    mols = np.sort(np.random.default_rng(7).choice(n_mol, size=N_SAMPLE, replace=False))
-    idx, Eref, Fref, e_sub, ref_in = _oracle_subset(oracle, pos, z, ptr, mols)
-    _compare(name, E[mols], F[idx], Eref, Fref,
-             dict(atoms=int(len(pos)), edges=int(e_hip), graphs=int(n_mol), compared_graphs=int(len(mols)), compared_atoms=int(len(idx)),
-                  compared_edges=int(e_sub)), oracle, ref_in)
+    n_cmp = min(n_mol, N_COMPARE[name])
+    mols = np.arange(n_mol) if n_cmp == n_mol else np.sort(np.random.default_rng(7).choice(n_mol, size=n_cmp, replace=False))
+    _compare_chunked(name, E, F, pos, z, ptr, mols, oracle,
+                     dict(atoms=int(len(pos)), edges=int(e_hip), graphs=int(n_mol), compared_graphs=int(len(mols))))
 
 
 @pytest.mark.parametrize("depth", [1, 2])

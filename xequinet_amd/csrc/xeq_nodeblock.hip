@@ -327,6 +327,14 @@ __device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, 
 // every wave access is 1 KB of consecutive bytes: [wave block of 16 nodes][tile][register quad][lane][4 floats] (NAT_TILE floats per
 // tile and block).
 constexpr int NAT_TILE = 512;
+// development (timing only, wrong results): -DXEQ_NB_EXP_NOSAVE drops the forward launch's stores that only the reverse launch reads;
+// -DXEQ_NB_EXP_SAVED0 lets every wave of the reverse launch read wave block 0's saved activations (cache-resident: what the
+// launch would cost if recomputing them were free); -DXEQ_NB_EXP_SCRATCH0 folds the reverse launch's scratch onto 256 wave blocks
+#ifdef XEQ_NB_EXP_NOSAVE
+#define NB_SAVE(stmt) do { } while (0)
+#else
+#define NB_SAVE(stmt) do { stmt; } while (0)
+#endif
 __device__ __forceinline__ tile_t ld_nat(const float* __restrict__ wb, int t, int lane) {
   const float4* p = reinterpret_cast<const float4*>(wb + t * NAT_TILE) + lane;
   tile_t r;
@@ -689,7 +697,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
     U += bu;
     V += bv;
     st_nat(uvw, uv_tile(0, 0, 0, c), lane, U);
-    st_nat(uvw, uv_tile(0, 0, 1, c), lane, V);
+    NB_SAVE(st_nat(uvw, uv_tile(0, 0, 1, c), lane, V));
     tile_t v, p;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -721,7 +729,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
         tile_t U = zero16(), V = zero16();
         out_pair_p<2>(w, U, V, pk);
         st_nat(uvw, uv_tile(1, m, 0, c), lane, U);
-        st_nat(uvw, uv_tile(1, m, 1, c), lane, V);
+        NB_SAVE(st_nat(uvw, uv_tile(1, m, 1, c), lane, V));
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           VSQ[c][r] = __builtin_fmaf(V[r], V[r], VSQ[c][r]);
@@ -754,7 +762,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
       tile_t U = zero16(), V = zero16();
       out_pair_p<1>(w, U, V, pk);
       st_nat(uvw, uv_tile(2, m, 0, 0), lane, U);
-      st_nat(uvw, uv_tile(2, m, 1, 0), lane, V);
+      NB_SAVE(st_nat(uvw, uv_tile(2, m, 1, 0), lane, V));
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         VSQ[r] = __builtin_fmaf(V[r], V[r], VSQ[r]);
@@ -772,7 +780,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     HID[t] += ld_tile(a.b3, 32 * t, h);
-    st_nat(prew, t, lane, HID[t]);
+    NB_SAVE(st_nat(prew, t, lane, HID[t]));
     tile_t hv;
 #pragma unroll
     for (int r = 0; r < 8; ++r) hv[r] = silu_f(HID[t][r]);
@@ -793,7 +801,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
     tile_t av = zero16();
     out_tile_p<4>(w, av, pk);
     av += b4v;
-    st_nat(aw, c, lane, av);
+    NB_SAVE(st_nat(aw, c, lane, av));
     if (wx) {
       tile_t xn;
 #pragma unroll
@@ -809,7 +817,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
     tile_t av = zero16();
     out_tile_p<4>(w, av, pk);
     av += b4v;
-    st_nat(aw, 4 + c, lane, av);
+    NB_SAVE(st_nat(aw, 4 + c, lane, av));
     if (wx) {
       tile_t U[3];   // (this lane's own stores; fetched behind the products: two waves share the SIMD, the registers are worth more than the latency)
 #pragma unroll
@@ -830,7 +838,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
     tile_t av = zero16();
     out_tile_p<4>(w, av, pk);
     av += b4v;
-    st_nat(aw, 6, lane, av);
+    NB_SAVE(st_nat(aw, 6, lane, av));
     if (wx) {
       tile_t U[5];
 #pragma unroll
@@ -861,13 +869,13 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const tile_t bsv = ld_tile(a.b4, C + 32 * c, h), bss = ld_tile(a.b4, C + F + 32 * c, h), S = ld_tile(srow, 32 * c, h);
-    st_nat(ipw, c, lane, IP[c]);
+    NB_SAVE(st_nat(ipw, c, lane, IP[c]));
     tile_t asv = zero16(), ass = zero16();
     out_pair_p<4>(w, asv, ass, pk);
     asv += bsv;
     ass += bss;
-    st_nat(aw, 7 + c, lane, asv);
-    st_nat(aw, 11 + c, lane, ass);
+    NB_SAVE(st_nat(aw, 7 + c, lane, asv));
+    NB_SAVE(st_nat(aw, 11 + c, lane, ass));
 #pragma unroll
     for (int r = 0; r < 8; ++r) SN[c][r] = (S[r] + asv[r] * IP[c][r]) + ass[r];
     st_tile(sor, 32 * c, h, SN[c], ok);
@@ -911,7 +919,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     HN[t] += ld_tile(a.b1n, 32 * t, h);
-    st_nat(a.pre2 + wblk * (S_TILES * NAT_TILE), t, lane, HN[t]);
+    NB_SAVE(st_nat(a.pre2 + wblk * (S_TILES * NAT_TILE), t, lane, HN[t]));
     tile_t hv;
 #pragma unroll
     for (int r = 0; r < 8; ++r) hv[r] = silu_f(HN[t][r]);
@@ -1045,14 +1053,24 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
   const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
   const float e2 = a.eps * a.eps;
   const int64_t wblk = (int64_t)blockIdx.x * n_waves + wave;   // this wave's block of 16 nodes in the internal layout (= node / 16)
-  float* __restrict__ gxow = a.gxo + wblk * (X_TILES * NAT_TILE);   // total dL/dx_out (GX)
-  float* __restrict__ gww = a.gw + wblk * (X_TILES * NAT_TILE);
-  float* __restrict__ gpw = a.gp + wblk * (P_TILES * NAT_TILE);
-  float* __restrict__ gvw = a.gv + wblk * (P_TILES * NAT_TILE);
-  const float* __restrict__ uvw = a.uv + wblk * (UV_TILES * NAT_TILE);
-  const float* __restrict__ aw = a.a + wblk * (A_TILES * NAT_TILE);
-  const float* __restrict__ prew = a.pre + wblk * (S_TILES * NAT_TILE);
-  const float* __restrict__ ipw = a.ip + wblk * (S_TILES * NAT_TILE);
+#ifdef XEQ_NB_EXP_SCRATCH0
+  const int64_t cblk = wblk & 255;
+#else
+  const int64_t cblk = wblk;
+#endif
+  float* __restrict__ gxow = a.gxo + cblk * (X_TILES * NAT_TILE);   // total dL/dx_out (GX)
+  float* __restrict__ gww = a.gw + cblk * (X_TILES * NAT_TILE);
+  float* __restrict__ gpw = a.gp + cblk * (P_TILES * NAT_TILE);
+  float* __restrict__ gvw = a.gv + cblk * (P_TILES * NAT_TILE);
+#ifdef XEQ_NB_EXP_SAVED0
+  const int64_t sblk = 0;
+#else
+  const int64_t sblk = wblk;
+#endif
+  const float* __restrict__ uvw = a.uv + sblk * (UV_TILES * NAT_TILE);
+  const float* __restrict__ aw = a.a + sblk * (A_TILES * NAT_TILE);
+  const float* __restrict__ prew = a.pre + sblk * (S_TILES * NAT_TILE);
+  const float* __restrict__ ipw = a.ip + sblk * (S_TILES * NAT_TILE);
 
   tile_t GS[4];   // total dL/ds_out
   if (TAIL) {
@@ -1067,7 +1085,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const tile_t pv = ld_nat(a.pre2 + wblk * (S_TILES * NAT_TILE), t, lane);
+      const tile_t pv = ld_nat(a.pre2 + sblk * (S_TILES * NAT_TILE), t, lane);
       tile_t gv;
 #pragma unroll
       for (int r = 0; r < 8; ++r) gv[r] = GH[t][r] * silu_grad_f(pv[r]);

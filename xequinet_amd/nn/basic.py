@@ -150,6 +150,15 @@ def compute_properties(
         results[keys.VIRIAL] = compute_virial_only(energy=data[keys.TOTAL_ENERGY], strain=data[keys.STRAIN], training=training)
     elif compute_forces:
         results[keys.FORCES] = compute_forces_only(energy=data[keys.TOTAL_ENERGY], pos=data[keys.POSITIONS], training=training)
+    # ops.EdgeGradDeferral finishes by count: if a registered message block's reverse pass never ran, every block returned None
+    # and the forces above came back as zeros through `allow_unused`.  That must be an error, not a silent zero (round-5 advisor).
+    graph = data.get(keys.EDGE_GRAPH)
+    deferral = getattr(graph, "edge_grad_deferral", None) if graph is not None else None
+    if deferral is not None and (compute_forces or compute_virial):
+        if deferral.sets:
+            n_left, deferral.sets = len(deferral.sets), []
+            raise RuntimeError(f"edge-gradient deferral not drained: {n_left} of {deferral.registered} registered message blocks "
+                               "reached the reverse pass; dL/dvec was never emitted")
     if extra_properties is not None:
         results.update({k: data[k] for k in extra_properties})
     return results

@@ -133,7 +133,12 @@ class XEmbedding(nn.Module):
 
                 # s, h, xhat of the first block in ONE gather launch; the wq kernels never read xhat's l > 0 blocks behind the embedding
                 g = data.get(keys.EDGE_GRAPH)
-                unread = (g is not None and not rows.requires_grad and
+                # ... but the PARAMETER-gradient kernels do (xeq_message_param_grad reads the whole xhat): an eval-mode model whose
+                # rbf_lin / radial parameters still require grad gets the zero-filled tail (round-5 advisor, medium: uninitialised
+                # memory reached d_w / d_b of message_0.rbf_lin on loss.backward())
+                params_want_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in nxt.rbf_lin.parameters())
+                                                                or any(p.requires_grad for p in self.rbf.parameters()))
+                unread = (g is not None and not rows.requires_grad and not params_want_grad and
                           ops.select_message_impl(rows.dtype, g.n_nodes, g.n_edges, nxt.num_basis, nxt.node_dim, nxt._mul) == "wq")
                 front = first_block_front(nxt, z, rows, z.shape[0], higher_l_unread=unread)
             if front is not None:

@@ -162,6 +162,10 @@ class EdgeGraph:
         # symmetric, center-sorted list: the reverse wq kernel walks the FORWARD plan (every slot stands for its mirror edge) and
         # mirror_map tells where a slot's edge gradient goes (include/xeq.h, XEQ_WQ_MIRROR_WALK)
         self.mirror_walk = exact_mirror or periodic_mirror
+        # the KIND of list, fixed at construction (runtime.GraphedModel re-creates a list of the same kind for its capture; what has
+        # been built lazily since -- the sorted view -- says nothing about it)
+        self.periodic = cell_offsets is not None
+        self.cell_offsets = cell_offsets
         self.mirror_map: Optional[torch.Tensor] = None
         # set by callers whose edge_index is a capacity-sized buffer (runtime.GraphedStep*, train.GraphedTrainStep): the true edge count
         # is c_rowptr[N] on the device; kernels that walk edges by index rather than by row pointer are handed that pointer

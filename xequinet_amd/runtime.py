@@ -80,7 +80,7 @@ class GraphedModel:
     def _signature(self, data, eg: ops.EdgeGraph) -> tuple:
         pos = data[keys.POSITIONS]
         return (tuple(pos.shape), pos.dtype, pos.device.index, int(data[keys.EDGE_INDEX].shape[1]),
-                int(data[keys.BATCH_PTR].numel()), keys.CELL in data, eg.c_perm is None, eg.mirror_walk)
+                int(data[keys.BATCH_PTR].numel()), keys.CELL in data, eg.c_perm is None, eg.mirror_walk, eg.periodic)
 
     @staticmethod
     def _edge_graph(data) -> ops.EdgeGraph:
@@ -107,10 +107,17 @@ class GraphedModel:
             c.inputs[keys.BATCH] = torch.repeat_interleave(torch.arange(counts.numel(), device=ptr.device), counts,
                                                            output_size=c.inputs[keys.POSITIONS].shape[0])
         # a private EdgeGraph over the captured edge_index; its CSR arrays are refreshed in place before every replay
-        periodic_mirror = eg.mirror_map is not None and eg._n_view is None
+        # The list kind comes from the EdgeGraph's construction (`periodic`), never from what it has built lazily since: a periodic
+        # list whose sorted view exists (an fp64 evaluation, a second capture) must NOT be re-created as an open-boundary exact-mirror
+        # list -- the offset-blind reverse-edge map pairs every image of (i, j) with the first (j, i) slot (round-5 advisor, high).
+        periodic = eg.periodic or (eg.mirror_walk and keys.CELL_OFFSETS in c.inputs and keys.CELL in c.inputs)
+        if periodic and eg.mirror_walk and keys.CELL_OFFSETS not in c.inputs:
+            raise ValueError("GraphedModel: a periodic mirror-walk list needs data['cell_offsets'] to be captured")
         c.edge_graph = ops.EdgeGraph(c.inputs[keys.EDGE_INDEX], eg.n_nodes, center_sorted=eg.c_perm is None,
                                      ptr=c.inputs[keys.BATCH_PTR], symmetric=eg.mirror_walk,
-                                     cell_offsets=c.inputs[keys.CELL_OFFSETS] if periodic_mirror else None)
+                                     cell_offsets=c.inputs[keys.CELL_OFFSETS] if (periodic and eg.mirror_walk) else None)
+        if periodic and not eg.mirror_walk:
+            c.edge_graph.periodic = True
         static = dict(c.inputs)
         static[keys.EDGE_GRAPH] = c.edge_graph
         # library GEMM selection is timed during the warm-up only: TunableOp is a process-wide switch, so the state the

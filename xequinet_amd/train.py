@@ -240,6 +240,8 @@ class GraphedTrainStep:
         ``ptr_host`` (optional, as ``runtime.GraphedStep.__call__``): checks the edge capacity against the batch on the host BEFORE the
         update.  Without it an overflowing batch is caught on the device: its loss and gradients are exactly zero (the optimizer's
         moments still decay), and ``overflowed()`` reports it afterwards."""
+        from . import runtime
+
         g = self._gs
         if ptr_host is not None and runtime.pair_capacity(ptr_host) > g.n_edges:
             raise ValueError(f"GraphedTrainStep: the batch may hold {runtime.pair_capacity(ptr_host)} edges, the capacity is {g.n_edges}")
