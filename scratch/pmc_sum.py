@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
             k = r["Kernel_Name"]
             if "message" not in k and "probe" not in k and "mlp2" not in k and "node_block" not in k:
                 continue
-            k = k.split("<")[0].split("(")[0][-28:]
+            k = k.split("(")[0][-36:]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
         print(d.split("/")[-1], k, {c: f"{sum(v)/len(v):.4g}" for c, v in sorted(cs.items())}, "launches", len(next(iter(cs.values()))))

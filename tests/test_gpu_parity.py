@@ -930,7 +930,7 @@ def test_graphed_model_keeps_a_periodic_list_periodic_once_its_sorted_view_exist
     """Round-5 advisor (high): GraphedModel used to tell a periodic list from `mirror_map is not None and _n_view is None`; once anything
     had built the sorted view (an fp64 evaluation, a second capture) the capture re-created the list as an OPEN-boundary exact-mirror
     list, whose offset-blind reverse-edge map pairs every image of (i, j) with the first (j, i) slot.  A box below twice the cutoff
-    (24 atoms, L = 6.2 A: several images per pair and self-image edges) shows it: here the sorted view is built FIRST, then the list is
+    (24 atoms, L = 6.2 A: several images per pair) shows it: here the sorted view is built FIRST, then the list is
     captured; the replay must equal the eager evaluation bit for bit and the fp64 oracle within the fp32 bounds."""
     from xequinet_amd import keys
     from xequinet_amd.data import NeighborTransform, XequiBatch
@@ -947,7 +947,7 @@ def test_graphed_model_keeps_a_periodic_list_periodic_once_its_sorted_view_exist
     assert g.periodic and g.mirror_walk and g._n_view is None
     ei, off = b.edge_index.cpu().numpy(), b.cell_offsets.cpu().numpy()
     pairs = ei[0] * len(z) + ei[1]
-    assert len(np.unique(pairs)) < len(pairs) and np.any(ei[0] == ei[1])     # several images per pair, self-image edges
+    assert len(np.unique(pairs)) < len(pairs)                               # several images per pair: where the offset-blind map goes wrong
     with torch.enable_grad():
         eager = model(dict(data), compute_forces=True, compute_virial=False)
     g.n_rowptr                                                            # somebody asks for the sorted view ...

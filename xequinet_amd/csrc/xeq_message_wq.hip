@@ -50,11 +50,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // dwords per record: [kh][hi | mid | lo][4] bf16 packs of k = 8 kh .. 8 kh + 7 (24), [kh][TW] f32 tail (q = 2 s + kh -> k = 16 + q, then the
 // envelope for the bias; TW = 4 tail values per k half up to 23 basis functions (KS <= 4 exact-f32 steps), 8 up to 31 (KS = 8)), Y1[3] Y2[5]:
 // 40 dwords (160 B) or 48 (192 B)
-constexpr int WQ_TAIL = 24;                // dword offset of the f32 tail inside a record
+// Round 6: the tail of up to FIVE values (k = 16 .. 19 and the bias column: num_basis <= 20, the default) runs through the bf16 matrix
+// instruction as well.  A 16-slot k block holds the three splits of the five values, A = [hi_0..4 | mid_0..4 | lo_0..4 | 0], and is
+// multiplied against THREE weight arrangements B1 = [hi | hi | hi | 0], B2 = [mid | mid | 0 | 0], B3 = [lo | 0 | 0 | 0] (packed once per
+// weight version): A B1 + A B2 + A B3 = a_hi (b_hi + b_mid + b_lo) + a_mid (b_hi + b_mid) + a_lo b_hi, the same six products as the
+// first sixteen k (what is left out is 2^-24 of a product).  Three 32-cycle instructions replace three 64-cycle exact-f32 steps: 288
+// instead of 384 matrix-pipe cycles per filter tile; the record keeps its 160 bytes (the tail's eight floats become eight dwords of
+// bf16 pairs).  Wider tails (num_basis 21 .. 31) keep the exact-f32 steps.
+constexpr bool wq_bftail(int ks) { return ks <= 3; }
+constexpr int WQ_TAIL = 24;                // dword offset of the tail inside a record
 constexpr int wq_tailw(int ks) { return ks <= 4 ? 4 : 8; }
 constexpr int wq_recf(int ks) { return WQ_TAIL + 2 * wq_tailw(ks) + 8; }
 constexpr int wq_yoff(int ks) { return WQ_TAIL + 2 * wq_tailw(ks); }
-constexpr int wq_ks(int num_basis) { return ((num_basis > 16 ? num_basis - 16 : 0) + 2) / 2; }   // exact-f32 steps of the tail (+ the bias column), two per step
+// KS: 1 / 3 = a tail of up to 1 / 5 values (basis functions from k = 16 on, then the bias column) in the bf16 block (wq_bftail); from six
+// values on, the exact-f32 steps of the tail, two values per step (never below 4, so that the two forms do not share a KS)
+constexpr int wq_tail_values(int num_basis) { return (num_basis > 16 ? num_basis - 16 : 0) + 1; }
+constexpr int wq_ks(int num_basis) {
+  return wq_tail_values(num_basis) <= 1 ? 1 : (wq_tail_values(num_basis) <= 5 ? 3 : ((wq_tail_values(num_basis) + 1) / 2 < 4 ? 4 : (wq_tail_values(num_basis) + 1) / 2));
+}
 constexpr int WQ_REC_MAX = 48;
 __device__ __forceinline__ uint32_t wq_bf16_rne(float x) {
   const uint32_t u = __float_as_uint(x);
@@ -194,7 +207,7 @@ __global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __re
 // through out / dout (the slot's record in the workgroup's LDS staging rows)
 __device__ __forceinline__ void wq_record_piece(const float* __restrict__ vec, const int32_t* __restrict__ peid, int64_t p, int grp,
                                                 const RadialSpec& rs, const float* __restrict__ p0, const float* __restrict__ p1,
-                                                float* __restrict__ out, float* __restrict__ dout, int tailw) {
+                                                float* __restrict__ out, float* __restrict__ dout, int tailw, bool bftail) {
   const int yoff = WQ_TAIL + 2 * tailw;
   const int32_t e = peid[p];
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -267,6 +280,28 @@ __device__ __forceinline__ void wq_record_piece(const float* __restrict__ vec, c
         *reinterpret_cast<f32x4*>(dout + 12 * kh + 4 * sp) =
             f32x4{__uint_as_float(dw[sp][0]), __uint_as_float(dw[sp][1]), __uint_as_float(dw[sp][2]), __uint_as_float(dw[sp][3])};
     }
+  } else if (bftail) {   // slots 8 kh .. 8 kh + 7 of [hi_0..4 | mid_0..4 | lo_0..4 | 0]: the three bf16 parts of the five tail values
+    const int kh = grp - 2;
+    uint32_t a3[5][3], d3[5][3];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      float val, dval;
+      value(wq_tail_k(q, B), val, dval);
+      wq_split3(val, a3[q][0], a3[q][1], a3[q][2]);
+      wq_split3(dval, d3[q][0], d3[q][1], d3[q][2]);
+    }
+    uint32_t w[4] = {0u, 0u, 0u, 0u}, dw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int sl0 = jj, sl1 = 8 + jj;   // (both k halves unrolled, one selected: the slot arithmetic stays compile-time)
+      const uint32_t v0 = sl0 < 15 ? a3[sl0 % 5][sl0 / 5] : 0u, v1 = sl1 < 15 ? a3[sl1 % 5][sl1 / 5] : 0u;
+      const uint32_t e0 = sl0 < 15 ? d3[sl0 % 5][sl0 / 5] : 0u, e1 = sl1 < 15 ? d3[sl1 % 5][sl1 / 5] : 0u;
+      w[jj >> 1] |= (kh ? v1 : v0) << (16 * (jj & 1));
+      dw[jj >> 1] |= (kh ? e1 : e0) << (16 * (jj & 1));
+    }
+    *reinterpret_cast<f32x4*>(out + WQ_TAIL + 4 * kh) = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+    if (dout)
+      *reinterpret_cast<f32x4*>(dout + WQ_TAIL + 4 * kh) = f32x4{__uint_as_float(dw[0]), __uint_as_float(dw[1]), __uint_as_float(dw[2]), __uint_as_float(dw[3])};
   } else {
     const int kh = grp - 2;
     for (int c0 = 0; c0 < tailw; c0 += 4) {   // tail value s of this k half: position q = 2 s + kh
@@ -294,7 +329,7 @@ constexpr int WQ_REC_SLOTS = 32;
 __global__ void __launch_bounds__(256) k_wq_records(const float* __restrict__ vec, const int32_t* __restrict__ peid,
                              const int32_t* __restrict__ qptr, int64_t N, int64_t pcap, RadialSpec rs,
                              const float* __restrict__ p0, const float* __restrict__ p1, float* __restrict__ rec,
-                             float* __restrict__ drec, int recf, int tailw) {
+                             float* __restrict__ drec, int recf, int tailw, int bftail) {
   __shared__ __attribute__((aligned(16))) float stage[2][WQ_REC_SLOTS * 48];
   const int64_t limit = min(pcap, 4 * (int64_t)qptr[N]);
   const int64_t first = (int64_t)blockIdx.x * WQ_REC_SLOTS;
@@ -302,7 +337,7 @@ __global__ void __launch_bounds__(256) k_wq_records(const float* __restrict__ ve
   const int t = threadIdx.x, kind = t >> 6, r = t & 63, slot = r >> 1;
   const int64_t p = first + slot;
   if (kind < 3 && p < limit)
-    wq_record_piece(vec, peid, p, 2 * kind + (r & 1), rs, p0, p1, stage[0] + slot * recf, drec ? stage[1] + slot * recf : nullptr, tailw);
+    wq_record_piece(vec, peid, p, 2 * kind + (r & 1), rs, p0, p1, stage[0] + slot * recf, drec ? stage[1] + slot * recf : nullptr, tailw, bftail != 0);
   __syncthreads();
   const int n4 = (int)min((int64_t)WQ_REC_SLOTS, limit - first) * recf / 4;
   const f32x4* s0 = reinterpret_cast<const f32x4*>(stage[0]);
@@ -404,8 +439,9 @@ constexpr int WQ_WIN_FLOATS = XEQ_WQ_WIN_FLOATS;   // 48 KB per workgroup: two w
 // rbf_lin rows of the unit as the B operands, per kind (0: gate_state, 1: gate_edge, 2: scalar message) WQ_WK<KS> floats:
 //   [split][lane][4]   bf16 packs of W[row][8 kh + j], j = 0..7 (lane: j = lane & 31 -> channel row, kh = lane >> 5); 3 x 64 x 4
 //   [s][lane]          f32 tail: position q = 2 s + kh (wq_tail_k: k = 16 + q, then the bias, then zeros); KS x 64
+//   wq_bftail(KS): instead of the f32 tail [arrangement v][lane][4]: bf16 packs of slots 8 kh .. 8 kh + 7 of B1 / B2 / B3 (above); 3 x 64 x 4
 template <int KS>
-constexpr int WQ_WK = 3 * 64 * 4 + KS * 64;
+constexpr int WQ_WK = 3 * 64 * 4 + (wq_bftail(KS) ? 3 * 64 * 4 : KS * 64);
 template <int KS>
 __device__ __forceinline__ void wq_stage_weights(const WqArgs& a, const WqUnit& un, const float* __restrict__ w,
                                                  const float* __restrict__ b, float* wl) {
@@ -431,6 +467,26 @@ __device__ __forceinline__ void wq_stage_weights(const WqArgs& a, const WqUnit& 
     *reinterpret_cast<f32x4*>(wl + kind * WQ_WK<KS> + 4 * (64 * split + ln)) =
         f32x4{__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])};
   }
+  if constexpr (wq_bftail(KS)) {
+    for (int idx = threadIdx.x; idx < nkind * 3 * 64; idx += blockDim.x) {   // one 16-byte pack per thread and trip
+      const int kind = idx / 192, rem = idx - 192 * kind, v = rem >> 6, ln = rem & 63;
+      const int row = row_of(kind, ln), kh = ln >> 5;
+      uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int slot = 8 * kh + jj, part = slot / 5, q = slot - 5 * part;   // slot 15: padding
+        const int k = wq_tail_k(q, B);
+        uint32_t a3[3];
+        wq_split3(k >= 0 ? w[(int64_t)row * B + k] : (k == -1 ? b[row] : 0.f), a3[0], a3[1], a3[2]);
+        // arrangement v multiplies the record's part `part` (0 hi, 1 mid, 2 lo) by the weight's split v, where part + v <= 2
+        const uint32_t val = (slot < 15 && part + v <= 2) ? a3[v] : 0u;
+        pk[jj >> 1] |= val << (16 * (jj & 1));
+      }
+      *reinterpret_cast<f32x4*>(wl + kind * WQ_WK<KS> + 768 + 4 * (64 * v + ln)) =
+          f32x4{__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])};
+    }
+    return;
+  }
   for (int idx = threadIdx.x; idx < nkind * KS * 64; idx += blockDim.x) {
     const int kind = idx / (KS * 64), rem = idx - kind * (KS * 64), sstep = rem >> 6, ln = rem & 63;
     const int row = row_of(kind, ln), k = wq_tail_k(2 * sstep + (ln >> 5), B);
@@ -442,7 +498,7 @@ __device__ __forceinline__ void wq_stage_weights(const WqArgs& a, const WqUnit& 
 template <int KS>
 struct WqR {
   f32x4 b[3];
-  float f[KS];
+  float f[wq_bftail(KS) ? 4 : KS];   // wq_bftail: the four dwords of the lane's eight tail slots
 };
 // W: the kind's block of the staged weights, + 4 lane for the packs / + 768 + lane for the tail (wq_wptr)
 template <int KS>
@@ -454,6 +510,20 @@ __device__ __forceinline__ f32x16 wq_filter(const WqR<KS>& R, const float* W, in
   // small terms first
   d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, d, 0, 0, 0);
   d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, d, 0, 0, 0);
+  if constexpr (wq_bftail(KS)) {   // the tail block against its three weight arrangements, smallest first (a_hi b_lo | a (b_mid) | a (b_hi))
+    const f32x4 tv = {R.f[0], R.f[1], R.f[2], R.f[3]};
+    const bf16x8 at = __builtin_bit_cast(bf16x8, tv);
+    const f32x4* Wt = reinterpret_cast<const f32x4*>(W + 768) + lane;
+    const bf16x8 t1 = __builtin_bit_cast(bf16x8, Wt[0]), t2 = __builtin_bit_cast(bf16x8, Wt[64]), t3 = __builtin_bit_cast(bf16x8, Wt[128]);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, t3, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, t2, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, t1, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, d, 0, 0, 0);
+    return d;
+  }
   d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, d, 0, 0, 0);
   d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, d, 0, 0, 0);
   d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, d, 0, 0, 0);
@@ -491,22 +561,22 @@ struct WqRow {
 struct WqStreams {
   int q0, q1, q2, ntiles;
 };
+// Rows beyond the stream's end (`valid` false) read slot 0's record as it stands (round 6; they used to be zeroed, 38 selects per tile
+// and lane in the reverse kernel): their quad carries neither the FIRST nor the LAST flag and comes behind the stream's last real quad
+// -- whose LAST flag has stored the node's sums --, so whatever such a row adds to the running sums is never stored, and the per-edge
+// partials of the reverse pass are stored for slots inside the stream only (`keeper`).
 template <int KS>
 __device__ __forceinline__ void wq_load_rec(const float* __restrict__ rec, uint32_t ps, int kh, bool valid, WqR<KS>& R) {
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const f32x4* __restrict__ rp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * wq_recf(KS) + 12 * kh);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const f32x4 x = rp[c];
-    R.b[c] = valid ? x : zero;
-  }
+  for (int c = 0; c < 3; ++c) R.b[c] = rp[c];
   const f32x4* __restrict__ tp = reinterpret_cast<const f32x4*>(rec + (size_t)ps * wq_recf(KS) + WQ_TAIL + wq_tailw(KS) * kh);
 #pragma unroll
   for (int c = 0; c < wq_tailw(KS) / 4; ++c) {
     const f32x4 tl = tp[c];
 #pragma unroll
     for (int s = 4 * c; s < 4 * c + 4; ++s)
-      if (s < KS) R.f[s] = valid ? tl[s - 4 * c] : 0.f;
+      if (s < (wq_bftail(KS) ? 4 : KS)) R.f[s] = tl[s - 4 * c];
   }
 }
 template <int KS, int NREC, bool WITH_Y>
@@ -1655,7 +1725,7 @@ int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const i
   XEQ_CHECK_ARG(pcap * wq_recf(ks) < (1ll << 31) * 2, "xeq_edge_basis_wq: too many edges for 32-bit record offsets (shard the batch)");
   RadialSpec rs{rbf_kind, cutoff_kind, num_basis, cutoff};
   hipLaunchKernelGGL(k_wq_records, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)vec,
-                     peid, qptr, n_nodes, pcap, rs, (const float*)p0, (const float*)p1, (float*)basis, (float*)dbasis, wq_recf(ks), wq_tailw(ks));
+                     peid, qptr, n_nodes, pcap, rs, (const float*)p0, (const float*)p1, (float*)basis, (float*)dbasis, wq_recf(ks), wq_tailw(ks), wq_bftail(ks) ? 1 : 0);
   XEQ_CHECK_LAUNCH("xeq_edge_basis_wq");
   return XEQ_OK;
 }
@@ -1666,7 +1736,8 @@ static int wq_ks_template(int num_basis) {   // the KS the dispatch macros insta
 }
 int64_t xeq_message_wq_packed_weight_floats(int num_basis, int node_dim, const int32_t mul[3]) {
   if (!wq_supported(num_basis, node_dim, mul)) return -1;
-  const int64_t per_unit = 3 * (int64_t)(3 * 64 * 4 + wq_ks_template(num_basis) * 64);
+  const int kst = wq_ks_template(num_basis);
+  const int64_t per_unit = 3 * (int64_t)(3 * 64 * 4 + (wq_bftail(kst) ? 3 * 64 * 4 : kst * 64));
   return per_unit * (mul[0] / 32 + mul[1] / 32 + mul[2] / 32);
 }
 int xeq_message_wq_pack_weights(const void* w_rbf, const void* b_rbf, int num_basis, int node_dim, const int32_t mul[3], void* packed,

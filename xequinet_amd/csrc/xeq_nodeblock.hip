@@ -57,11 +57,24 @@ constexpr int TILE_U4 = 192;     // one packed weight tile (16 output rows x 32 
 #ifndef XEQ_NB_STAGE
 #define XEQ_NB_STAGE 4
 #endif
-constexpr int RING_STAGES = 2, STAGE_TILES = XEQ_NB_STAGE;   // tiles per stage: a multiple of 4 (each wave fetches STAGE_TILES / 4 tiles of a stage)
+#ifndef XEQ_NB_RING
+#define XEQ_NB_RING 2
+#endif
+constexpr int RING_STAGES = XEQ_NB_RING, STAGE_TILES = XEQ_NB_STAGE;   // tiles per stage: a multiple of 4 (each wave fetches STAGE_TILES / 4 tiles of a stage)
 constexpr int PF = STAGE_TILES / 4;
 constexpr int RING_BYTES = RING_STAGES * STAGE_TILES * TILE_U4 * 16;
 
 #define NB_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// The stage barrier of the weight stream.  Two ring stages: the slot written behind the barrier is the one whose last tiles this wave
+// has just requested, so its LDS reads are drained first.  Three stages (-DXEQ_NB_RING=3): the slot written behind the barrier held
+// the stage BEFORE the one in flight -- every wave that reaches the barrier has multiplied all of that stage's tiles (their reads were
+// waited for by the products), and the stage published by the barrier was written a whole stage ago by LDS operations older than reads
+// this wave has since consumed (a wave's LDS operations complete in order): no drain.
+#if XEQ_NB_RING >= 3
+#define NB_STAGE_BARRIER() asm volatile("s_barrier" ::: "memory")
+#else
+#define NB_STAGE_BARRIER() NB_LDS_BARRIER()
+#endif
 
 // Development aid (-DXEQ_NB_STAMPS): core-clock stamps at the phase boundaries of the forward / reverse kernels, per (workgroup, wave)
 // (cdna_hip_programming.md section 7, in-kernel stamps).  Read back through xeq_node_block_debug_stamps.
@@ -198,6 +211,19 @@ struct WStream {
     const Frag r = cur;
     cur = nxt;
     ++t;
+#ifdef XEQ_NB_SYNC_LATE
+    // development: the stage boundary ONE tile later and IN FRONT of the tile's read -- the youngest LDS read in flight is then a
+    // whole tile old when the drain waits for it (two ring stages)
+    if ((t & (STAGE_TILES - 1)) == STAGE_TILES - 1) {
+      const int j = t / STAGE_TILES + 1;
+      NB_LDS_BARRIER();
+      commit(j + 1);
+      issue(j + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    read(t + 1);
+    return r;
+#endif
     read(t + 1);
     if ((t & (STAGE_TILES - 1)) == STAGE_TILES - 2) {   // tiles t, t + 1 (the last two of their stage) are in registers or on their way
       const int j = t / STAGE_TILES + 1;
@@ -211,7 +237,7 @@ struct WStream {
       t_barrier += b1_ - b0_;
       t_commit += b2_ - b1_;
 #else
-      NB_LDS_BARRIER();
+      NB_STAGE_BARRIER();
       commit(j + 1);
 #endif
       issue(j + 2);
