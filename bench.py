@@ -215,8 +215,8 @@ def main():
                          "one captured graph.  Default: as many draws as steps in flight (two contexts evaluate two different "
                          "batches: a stream of batches, not one batch twice), one draw with --in-flight 1")
     args = ap.parse_args()
-    if args.vary_batch < 0:
-        args.vary_batch = max(1, args.in_flight)
+    if args.vary_batch < 0:   # (a sharded workload is ONE batch by definition: every step evaluates this rank's share of it)
+        args.vary_batch = 1 if args.workload in SHARDED else max(1, args.in_flight)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything in this process touches the GPU

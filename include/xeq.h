@@ -542,9 +542,11 @@ int xeq_message_q_wgrad(int dtype, const void* q, const void* basis, int64_t n_e
  *     neighbor; reverse: neighbor / center).  Outputs, sized for P = xeq_message_wq_pcap(N, E) padded slots:
  *     qptr[N+1] (first quad per node), pgath[P] (gathered node per padded slot), peid[P] (edge id, -1 for pads),
  *     qinfo[P/4] (owner | first << 30 | last << 31 per quad), sq / sn[2 n_ranges + 1] (quad / node boundaries of the
- *     streams, on segment starts at about equal quad counts), win[2 ceil(n_ranges / xeq_message_wq_waves())] (per STEP = that many consecutive
- *     ranges, walked together by the waves of a workgroup: first gathered node and row count of the window that
- *     holds every node the step gathers from).  workspace: xeq_message_wq_plan_workspace(N) bytes.
+ *     streams, on segment starts at about equal quad counts), win[xeq_message_wq_win_ints(n_ranges)] (per STEP = xeq_message_wq_waves()
+ *     consecutive ranges, walked together by the waves of a workgroup: first gathered node and row count of the window that
+ *     holds every node the step gathers from; since round 6 for two stream CLASSES -- the table's streams, walked by the l > 0
+ *     units, and for large batches streams of three table streams each, walked by the l = 0 units -- one table behind the
+ *     other).  workspace: xeq_message_wq_plan_workspace(N) bytes.
  *     Depends on the graph only, not on the positions.
  *   xeq_edge_basis_wq: per-edge records IN PADDED WALK ORDER, basis / dbasis [P, xeq_message_wq_record_floats_for(num_basis)] floats
  *     ([12 even k | 12 odd k | Y1[3] Y2[5]], value and d/dd; dbasis may be NULL), once per evaluation and direction.
@@ -562,6 +564,7 @@ int xeq_message_wq_waves(void);
 int xeq_message_wq_record_floats_for(int num_basis);   /* floats per padded slot of a record buffer: 40 up to 23 basis functions, 48 up to 31 */
 int xeq_message_wq_record_floats(void);   /* floats per padded slot of a record buffer (basis / dbasis of xeq_edge_basis_wq) */   /* ranges per step (= waves per workgroup): win holds 2 ceil(n_ranges / that) entries */
 int64_t xeq_message_wq_plan_workspace(int64_t n_nodes);                             /* bytes, -1 on failure */
+int64_t xeq_message_wq_win_ints(int n_ranges);                                      /* ints of a plan's window table `win` (a size, not a status) */
 int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_t* owner, const int64_t* gather,
                         int64_t n_nodes, int64_t n_edges, int n_ranges, void* workspace, int64_t workspace_bytes,
                         int32_t* qptr, int32_t* pgath, int32_t* peid, int32_t* qinfo, int32_t* sq, int32_t* sn, int32_t* win,

@@ -52,11 +52,13 @@ if os.environ.get("XEQ_WQ_STAMPS"):
     import ctypes
     from xequinet_amd import lib
     L = lib.load()
-    buf = (ctypes.c_ulonglong * 32)()
+    buf = (ctypes.c_ulonglong * 32)(); buf2 = (ctypes.c_ulonglong * 32)()
     L.xeq_wq_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-    L.xeq_wq_debug_stamps(buf)            # clear
+    L.xeq_wq_debug_stamps_bwd.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]   # (each half of the source has its own counter array)
+    L.xeq_wq_debug_stamps(buf); L.xeq_wq_debug_stamps_bwd(buf2)            # clear
     run("wq"); torch.cuda.synchronize()
-    L.xeq_wq_debug_stamps(buf)
+    L.xeq_wq_debug_stamps(buf); L.xeq_wq_debug_stamps_bwd(buf2)
+    for i in range(16, 32): buf[i] = buf2[i]
     fn = ["step head", "window staging", "barrier after staging", "body prologue", "wait for record", "phase A issue", "phase B issue",
           "MFMA issue", "phase D rows+stores", "publish next table", "barrier after step"]
     bn = ["step head", "window staging", "barrier after staging", "body prologue", "wait for records", "tile top (gathers issued)",

@@ -96,7 +96,7 @@ def _compare_chunked(name, E, F, pos, z, ptr, mols, oracle, extra):
     rec = dict(config=name, max_abs_dE=float(dE.max()), max_dE_over_bound=float((dE / (E_RTOL * np.abs(Eref) + E_ATOL)).max()),
                max_abs_dF=float(dF.max()), max_abs_F=float(np.abs(Fref).max()), max_abs_E=float(np.abs(Eref).max()),
                p99_abs_dF=float(np.quantile(dF, 0.99)), p999_abs_dF=float(np.quantile(dF, 0.999)),
-               frac_atoms_within_plain_1e-4=float((dF.max(axis=1) <= F32_PLAIN_FORCE_TOL).mean()),
+               frac_atoms_within_plain_tol=float((dF.max(axis=1) <= F32_PLAIN_FORCE_TOL).mean()),
                bound_dE=f"{E_RTOL}*|E|+{E_ATOL}", **bounds.record(), dtype="f32 HIP vs f64 oracle", compared_atoms=int(atoms),
                compared_edges=int(edges), oracle_chunk_molecules=ORACLE_CHUNK, **extra)
     parity_record.add(rec)

@@ -176,11 +176,12 @@ __global__ void k_wq_streams(const int32_t* __restrict__ qptr, int64_t N, int n_
 // win[2 s], win[2 s + 1]: first gathered node and number of rows of the WINDOW of step s = the WQ_WAVES consecutive
 // ranges one workgroup walks together: every node its 2 WQ_WAVES streams gather from lies in [w0, w0 + rows).  One wave
 // per step.  For batches of molecules the window is the few molecules the step touches.
-__global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __restrict__ pgath, int n_ranges, int n_steps,
+// mult: the stream CLASS (wq_long_mult below): a stream of the class is `mult` consecutive streams of the table
+__global__ void k_wq_windows(const int32_t* __restrict__ sq, const int32_t* __restrict__ pgath, int n_ranges, int n_steps, int mult,
                              int32_t* __restrict__ win) {
   const int step = blockIdx.x, lane = threadIdx.x;
   if (step >= n_steps) return;
-  const int k0 = 2 * WQ_WAVES * step, k1 = min(k0 + 2 * WQ_WAVES, 2 * n_ranges);
+  const int k0 = min(2 * WQ_WAVES * mult * step, 2 * n_ranges), k1 = min(k0 + 2 * WQ_WAVES * mult, 2 * n_ranges);
   const int64_t p0 = 4 * (int64_t)sq[k0], p1 = 4 * (int64_t)sq[k1];
   int lo = 0x7fffffff, hi = -1;
   for (int64_t p = p0 + lane; p < p1; p += 64) {
@@ -360,9 +361,16 @@ struct WqArgs {
   const int32_t* rowptr;   // [N + 1] CSR of the walk order (isolated nodes)
   const int32_t* pgath;    // [P] gathered node per padded slot
   const uint32_t* qinfo;   // [Q] owner | WQ_FIRST | WQ_LAST per quad
-  const int32_t* win;      // [2 n_steps] window (first node, rows) of every step
-  int n_steps, steps_per_wg;   // steps_per_wg: steps of a LONG chunk
-  int regions, region_steps;   // the steps are cut in `regions` contiguous regions (one per XCD when the grid is XCD-mapped)
+  const int32_t* win;      // [2 n_steps(1)] window (first node, rows) of every step of the SHORT class, then [2 n_steps(mlong)] of the long class
+  // Stream classes (round 6).  The stream table (sq, sn) holds SHORT streams; the l = 0 units walk LONG streams, each `mlong` consecutive
+  // table streams (1: one class, as up to round 5).  Why: the l > 0 units gather 5-7 pieces of 128 bytes per window row, so their steps
+  // must stay short for the window to fit LDS (a step that does not fit gathers from global memory: the l = 2 unit's forward launch alone
+  // 90 us at 48 edges per stream, 148 us at 80), while the l = 0 units -- 2-4 pieces per row, more than half of the work -- run fastest on
+  // long streams (fewer range prologues, window stagings and barriers per edge).  The work of a workgroup is cut in UNITS of `mlong`
+  // short steps = one long step, so that the units of one chunk still walk the same records at about the same time.
+  int mlong;
+  int n_steps, steps_per_wg;   // in chunk UNITS (see above); steps_per_wg: units of a LONG chunk
+  int regions, region_steps;   // the units are cut in `regions` contiguous regions (one per XCD when the grid is XCD-mapped)
   int lvl_chunks[3], lvl_spw[3], lvl_start[3];   // per region: three runs of chunks, long to short (chunks, steps per chunk, first
                                                  // step): the grid ends on short workgroups (a region's last chunks start last)
   int F, C, D, H, B;
@@ -394,6 +402,31 @@ __device__ __forceinline__ WqUnit wq_unit(const WqArgs& a, int u) {
   a.ir.locate(w.u0, l_, off);
   w.xbase = off;
   return w;
+}
+
+// the stream class of a unit: multiplier, ranges and steps of the class, its window table
+struct WqClass {
+  int m, n_ranges, n_steps;
+  const int32_t* win;
+};
+__host__ __device__ __forceinline__ int wq_class_steps(int n_ranges, int m) { return ((n_ranges + m - 1) / m + WQ_WAVES - 1) / WQ_WAVES; }
+__device__ __forceinline__ WqClass wq_class(const WqArgs& a, int l) {
+  WqClass c;
+  c.m = (l == 0) ? a.mlong : 1;
+  c.n_ranges = (a.n_ranges + c.m - 1) / c.m;
+  c.n_steps = wq_class_steps(a.n_ranges, c.m);
+  c.win = (l == 0 && a.mlong > 1) ? a.win + 2 * wq_class_steps(a.n_ranges, 1) : a.win;
+  return c;
+}
+// One class for small or sparse walks, long streams of three for the l = 0 units of large batches (measured on QM9-1024, per-l builds,
+// us per launch at 48 / 64 / 80 / 112 / 160 edges per stream: forward l = 0 93 / 87 / 79 / 86 / 81, l = 1 65 / 64 / 76 / 89 / 131, l = 2
+// 90 / 109 / 148 / 147 / 157; reverse l = 0 171 / 157 / 145 / 163 / 134, l = 1 102 / 96 / 109 / 96 / 117, l = 2 122 / 113 / 136 / 157 / 190;
+// profiles/r06_stream_classes.txt).  XEQ_WQ_LONG_MULT overrides (development).
+static int wq_long_mult(int64_t n_edges, int n_ranges) {
+  const char* env = getenv("XEQ_WQ_LONG_MULT");
+  if (env && atoi(env) >= 1 && atoi(env) <= 8) return atoi(env);
+  const double eps = (double)n_edges / (2.0 * (double)(n_ranges > 0 ? n_ranges : 1));
+  return (n_edges >= 120000 && eps <= 56.0) ? 3 : 1;
 }
 
 // Work of a workgroup: (chunk of consecutive steps, unit).  A step is WQ_WAVES consecutive ranges, one per wave; the
@@ -663,11 +696,12 @@ __device__ __forceinline__ WqCols wq_cols(const WqArgs& a, const WqUnit& un, int
   w.x_base = xa.off;
   return w;
 }
-__device__ __forceinline__ WqStreams wq_streams(const WqArgs& a, int range) {
+__device__ __forceinline__ WqStreams wq_streams(const WqArgs& a, int range, int m = 1) {
   WqStreams s;
-  s.q0 = a.sq[2 * range];
-  s.q1 = a.sq[2 * range + 1];
-  s.q2 = a.sq[2 * range + 2];
+  const int last = 2 * a.n_ranges;   // (a class stream is m consecutive table streams; the last range of a class may be short)
+  s.q0 = a.sq[min(2 * range * m, last)];
+  s.q1 = a.sq[min((2 * range + 1) * m, last)];
+  s.q2 = a.sq[min((2 * range + 2) * m, last)];
   const int l0 = s.q1 - s.q0, l1 = s.q2 - s.q1;
   s.ntiles = ((l0 > l1 ? l0 : l1) + 3) >> 2;
   return s;
@@ -791,7 +825,7 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
         wq_st(x_out, (uint32_t)m * row_x + wc.b_xe + 4u * mm, wq_ld(x_in, (uint32_t)m * row_x + wc.b_xe + 4u * mm));
     }
   });
-  const WqStreams st = wq_streams(a, range);
+  const WqStreams st = wq_streams(a, range, un.l == 0 ? a.mlong : 1);
   if (st.ntiles == 0) return;
   const float* __restrict__ h_e = h + a.C;
   const float* __restrict__ h_m = h + (2 * a.C + 32 * un.cb - un.u0);
@@ -960,8 +994,11 @@ __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_en
 #ifdef XEQ_WQ_STAMPS
   last_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (int step = s_beg; step < s_end; ++step) {
-    const int w0 = a.win[2 * step], nrows = a.win[2 * step + 1];
+  // the workgroup's chunk [s_beg, s_end) counts UNITS of a.mlong short steps = one long step: the steps of this unit's class in it
+  const WqClass cl = wq_class(a, un.l);
+  const int c_beg = cl.m == a.mlong ? s_beg : s_beg * a.mlong, c_end = min(cl.m == a.mlong ? s_end : s_end * a.mlong, cl.n_steps);
+  for (int step = c_beg; step < c_end; ++step) {
+    const int w0 = cl.win[2 * step], nrows = cl.win[2 * step + 1];
 #ifdef XEQ_WQ_NO_WINDOW
     const bool use_win = false;
 #else
@@ -973,7 +1010,7 @@ __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_en
     __syncthreads();
     WQ_STAMP(2);   // barrier behind the staging
     const int range = step * WQ_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: the stream bounds become scalar loads)
-    if (range < a.n_ranges) {
+    if (range < cl.n_ranges) {
       if (use_win) wq_fwd_body<NM, KS, true, XZ>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, w0, st_, last_);
       else wq_fwd_body<NM, KS, false, XZ>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, 0, st_, last_);
     }
@@ -1142,7 +1179,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       for (int mm = 0; mm < NM; ++mm) wq_st(grad_xhat, (uint32_t)m * wc.xnode_b + wc.b_x + mm * wc.xcomp_b, 0.f);
     }
   });
-  const WqStreams st = wq_streams(a, range);
+  const WqStreams st = wq_streams(a, range, un.l == 0 ? a.mlong : 1);
   if (st.ntiles == 0) return;
   // gathered rows: grad_x, grad_s of the center (window mode: one LDS row of ROWB bytes holds both)
   const uint32_t stride0 = WIN ? (uint32_t)ROWB : 4u * (uint32_t)a.D, stride1 = WIN ? (uint32_t)ROWB : 4u * (uint32_t)a.F;
@@ -1164,6 +1201,39 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   wq_row<KS, 2, (NM > 1)>(a, st, lane, 0, rec, drec, row, (int)gbase);
   wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tbl, gbase);
   __builtin_amdgcn_wave_barrier();
+
+  // The owners' rows (h_state, h_edge, h_msg, xhat of the unit's columns) of a tile's four quads.  They come from GLOBAL memory (the
+  // owner of a quad is the node whose gradient the wave accumulates: not a row of the window), and up to round 5 they were requested
+  // inside the tile that multiplies them -- the l = 0 role in its quad loops, the l > 0 roles at the tile top: the phase stamps of
+  // round 6 show the first pass of a tile (which waits for them) at 29 % of a wave's cycles against 6 % for the second.  They are now
+  // requested ONE TILE AHEAD (l = 0, 1: 16 / 20 registers; the l = 2 role has no register to spare and keeps the tile-top request): as
+  // soon as the next tile's table is published its owners are known, and the loads fly under the loop's back edge, the wait for the
+  // next records and the first matrix chain.
+#ifdef XEQ_WQ_NO_OWNER_PREFETCH
+  constexpr bool OWN_AHEAD = false;
+#else
+  constexpr bool OWN_AHEAD = NM <= 3;
+#endif
+  struct Owners {
+    float hs[4], he[4], hm[HAS_S ? 4 : 1], x[4][NM];
+  };
+  auto load_owners = [&](const int* tb_) {
+    Owners o;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint32_t own = (uint32_t)tb_[T_QOWN + 4 * hh + g];
+      o.he[g] = wq_ld(h, own * row_h + wc.b_hs + he_off);
+      if constexpr (HAS_S) o.hm[g] = wq_ld(h, own * row_h + wc.b_hm);
+      if constexpr (!FIRST || HAS_S) {
+        o.hs[g] = wq_ld(h, own * row_h + wc.b_hs);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) o.x[g][m] = wq_ld(xhat, own * wc.xnode_b + wc.b_x + m * wc.xcomp_b);
+      }
+    }
+    return o;
+  };
+  Owners own_next;
+  if constexpr (OWN_AHEAD) own_next = load_owners(tbl);
 
   for (int t = 0; t < st.ntiles; ++t) {
     const int* tb = tbl + (t & 1) * T_SIZE;
@@ -1195,19 +1265,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
     // loaded them quad by quad inside the passes, behind scheduling fences between the quads: a load issued in a quad was waited
     // for in that quad -- twelve exposed global round trips per tile (step timeline of round 3, QM9-1024: a range of the l = 1 /
     // l = 2 units took 41 / 55 us against 28 us for l = 0, whose loads the scheduler hoists by itself; 34 / 43 us now).
-    float oq_hs[NM > 1 ? 4 : 1], oq_he[NM > 1 ? 4 : 1], oq_x[NM > 1 ? 4 : 1][NM];
-    if constexpr (NM > 1) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint32_t own = (uint32_t)tb[T_QOWN + 4 * hh + g];
-        oq_he[g] = wq_ld(h, own * row_h + wc.b_hs + he_off);
-        if constexpr (!FIRST) {
-          oq_hs[g] = wq_ld(h, own * row_h + wc.b_hs);
-#pragma unroll
-          for (int m = 0; m < NM; ++m) oq_x[g][m] = wq_ld(xhat, own * wc.xnode_b + wc.b_x + m * wc.xcomp_b);
-        }
-      }
-    }
+    const Owners oq = OWN_AHEAD ? own_next : load_owners(tb);   // (the tile-top request where the rows are not a tile ahead)
     WQ_STAMP(5);   // tile top: gathers issued
     // l > 0: the gathered rows are read one component at a time (four rows x one m), used and dropped: out of the LDS
     // window a re-read costs 2 cycles, while holding a quad's 4 x NM values (next to the filters, pd and the per-quad
@@ -1227,10 +1285,10 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         const int c = 4 * hh + g;
         const uint32_t own = (uint32_t)tb[T_QOWN + c];
         const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
-        const float o_hs = NM > 1 ? oq_hs[NM > 1 ? g : 0] : wq_ld(h, own * row_h + wc.b_hs);
+        const float o_hs = oq.hs[g];
         float o_x[NM];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) o_x[m] = NM > 1 ? oq_x[NM > 1 ? g : 0][m] : wq_ld(xhat, own * wc.xnode_b + wc.b_x + m * wc.xcomp_b);
+        for (int m = 0; m < NM; ++m) o_x[m] = oq.x[g][m];
         uint32_t g0[4];
         if constexpr (!HAS_S) wq_tread4<uint32_t>(tb, T_G0 + 16 * hh + 4 * g, g0);
         float u[NM], dgs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1281,7 +1339,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         const int p0 = 16 * hh + 4 * g, c = 4 * hh + g;
         const uint32_t own = (uint32_t)tb[T_QOWN + c];
         const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
-        const float o_he = NM > 1 ? oq_he[NM > 1 ? g : 0] : wq_ld(h, own * row_h + wc.b_hs + he_off);
+        const float o_he = oq.he[g];
         uint32_t g0[4];
         if constexpr (!HAS_S) wq_tread4<uint32_t>(tb, T_G0 + p0, g0);
         float dge[4], heq = 0.f;   // dge[r] = <Y[r], gx[r]>, one component at a time
@@ -1313,7 +1371,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int p0 = 16 * hh + 4 * g;
-          const float o_he = oq_he[NM > 1 ? g : 0];
+          const float o_he = oq.he[g];
           uint32_t g0[4];
           wq_tread4<uint32_t>(tb, T_G0 + p0, g0);
           float wy[4];
@@ -1360,7 +1418,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         const int c = 4 * hh + g;
         const uint32_t own = (uint32_t)tb[T_QOWN + c];
         const int keep = tb[T_QKEEP + c], last = tb[T_QLAST + c];
-        const float o_hm = wq_ld(h, own * row_h + wc.b_hm);
+        const float o_hm = oq.hm[HAS_S ? g : 0];
         float hmq = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1384,6 +1442,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
     WQ_STAMP(11);  // dL/dd channel sums
     wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tnext, gbase);
     __builtin_amdgcn_wave_barrier();
+    if constexpr (OWN_AHEAD) own_next = load_owners(tnext);   // the next tile's owners are known: their rows fly under the back edge
     WQ_STAMP(12);  // next table published
   }
 }
@@ -1400,8 +1459,10 @@ __device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int s_beg, int s_en
 #ifdef XEQ_WQ_STAMPS
   last_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (int step = s_beg; step < s_end; ++step) {
-    const int w0 = a.win[2 * step], nrows = a.win[2 * step + 1];
+  const WqClass cl = wq_class(a, un.l);   // (as in the forward role: the chunk counts units, the loop the steps of this unit's class)
+  const int c_beg = cl.m == a.mlong ? s_beg : s_beg * a.mlong, c_end = min(cl.m == a.mlong ? s_end : s_end * a.mlong, cl.n_steps);
+  for (int step = c_beg; step < c_end; ++step) {
+    const int w0 = cl.win[2 * step], nrows = cl.win[2 * step + 1];
 #ifdef XEQ_WQ_NO_WINDOW
     const bool use_win = false;
 #else
@@ -1413,7 +1474,7 @@ __device__ __forceinline__ void wq_bwd_role(const WqArgs& a, int s_beg, int s_en
     __syncthreads();
     WQ_STAMP(2);
     const int range = step * WQ_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: the stream bounds become scalar loads)
-    if (range < a.n_ranges) {
+    if (range < cl.n_ranges) {
       if (use_win) wq_bwd_body<NM, KS, true, FIRST>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, w0, st_, last_);
       else wq_bwd_body<NM, KS, false, FIRST>(a, range, unit, un, wc, rec, drec, h, xhat, grad_s, grad_x, wl, grad_h, grad_xhat, parts, tbl, win, 0, st_, last_);
     }
@@ -1596,7 +1657,8 @@ static int wq_check(const char* who, int64_t n_nodes, int64_t n_edges, int n_ran
 // pass, workgroup timeline); the short chunks fill that ragged end.  Regions keep the XCD mapping: block b runs on XCD b % 8 under
 // round-robin dispatch (speed only), so region b % 8 is one XCD's contiguous share of the walk and ITS last chunks are the short ones.
 static void wq_geometry(WqArgs& a, int nunits, unsigned& grid) {
-  a.n_steps = (a.n_ranges + WQ_WAVES - 1) / WQ_WAVES;
+  a.mlong = wq_long_mult(a.n_edges, a.n_ranges);
+  a.n_steps = wq_class_steps(a.n_ranges, a.mlong);   // chunk units: one long step = mlong short steps
   const int64_t want_chunks = (256 * 6 + nunits - 1) / nunits;
   a.steps_per_wg = (int)((a.n_steps + want_chunks - 1) / want_chunks);
   if (a.steps_per_wg < 1) a.steps_per_wg = 1;
@@ -1705,11 +1767,22 @@ int xeq_message_wq_plan(const int32_t* rowptr, const int32_t* perm, const int64_
   hipLaunchKernelGGL(k_wq_streams, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const int32_t*)qptr,
                      n_nodes, n_ranges, sq, sn);
   XEQ_CHECK_LAUNCH("xeq_message_wq_plan (streams)");
-  const int n_steps = (n_ranges + WQ_WAVES - 1) / WQ_WAVES;
+  const int n_steps = wq_class_steps(n_ranges, 1);
   hipLaunchKernelGGL(k_wq_windows, dim3((unsigned)n_steps), dim3(64), 0, (hipStream_t)stream, (const int32_t*)sq,
-                     (const int32_t*)pgath, n_ranges, n_steps, win);
+                     (const int32_t*)pgath, n_ranges, n_steps, 1, win);
   XEQ_CHECK_LAUNCH("xeq_message_wq_plan (windows)");
+  const int mlong = wq_long_mult(n_edges, n_ranges);
+  if (mlong > 1) {   // the long class of the l = 0 units (wq_long_mult): its window table behind the short class's
+    const int n_long = wq_class_steps(n_ranges, mlong);
+    hipLaunchKernelGGL(k_wq_windows, dim3((unsigned)n_long), dim3(64), 0, (hipStream_t)stream, (const int32_t*)sq,
+                       (const int32_t*)pgath, n_ranges, n_long, mlong, win + 2 * n_steps);
+    XEQ_CHECK_LAUNCH("xeq_message_wq_plan (windows, long class)");
+  }
   return XEQ_OK;
+}
+
+int64_t xeq_message_wq_win_ints(int n_ranges) {   /* ints of the plan's window table: both stream classes (include/xeq.h) */
+  return 2 * ((int64_t)wq_class_steps(n_ranges, 1) + (int64_t)wq_class_steps(n_ranges, 2) + 1);
 }
 
 int xeq_edge_basis_wq(const void* vec, int64_t n_nodes, int64_t n_edges, const int32_t* qptr, const int32_t* peid,

@@ -402,14 +402,13 @@ void build_wq_plan(Graph& g, bool reverse, WqPlan& p) {
   const int eps = xeq_message_wq_edges_per_stream(g.N, g.E);   // (the C ABI states the rule; ops._wq_edges_per_stream asks it too)
   p.n_ranges = (int)std::max<int64_t>(1, (g.E + 2 * eps - 1) / (2 * eps));
   p.pcap = xeq_message_wq_pcap(g.N, g.E);
-  const int waves = xeq_message_wq_waves();
   p.qptr = i32(g.N + 1, g.ei);
   p.pgath = i32(p.pcap, g.ei);
   p.peid = i32(p.pcap, g.ei);
   p.qinfo = i32(p.pcap / 4, g.ei);
   p.sq = i32(2 * p.n_ranges + 1, g.ei);
   p.sn = i32(2 * p.n_ranges + 1, g.ei);
-  p.win = i32(2 * ((p.n_ranges + waves - 1) / waves), g.ei);
+  p.win = i32(xeq_message_wq_win_ints(p.n_ranges), g.ei);
   const int64_t wbytes = xeq_message_wq_plan_workspace(g.N);
   TORCH_CHECK(wbytes >= 0, "xequinet_amd: wq plan workspace");
   p.work = at::empty({std::max<int64_t>(wbytes, 1)}, g.ei.options().dtype(at::kByte));

@@ -134,6 +134,7 @@ _PROTOS = {
     "xeq_message_wq_record_floats": [],
     "xeq_message_wq_record_floats_for": [c_int],
     "xeq_message_wq_plan_workspace": [c_int64],
+    "xeq_message_wq_win_ints": [c_int],
     "xeq_message_wq_plan": [_P, _P, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P],
     "xeq_edge_basis_wq": [_P, c_int64, c_int64, _P, _P, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P],
     "xeq_message_fwd_wq": [c_int64, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _I3,
@@ -179,7 +180,7 @@ _PROTOS = {
                            _P, _P, _P],
 }
 # entry points that return a size, not a status
-_RET_I64 = {"xeq_launch_count", "xeq_launch_names", "xeq_message_wq_packed_weight_floats", "xeq_rowptr_from_degrees_max", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace",
+_RET_I64 = {"xeq_launch_count", "xeq_launch_names", "xeq_message_wq_packed_weight_floats", "xeq_rowptr_from_degrees_max", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace", "xeq_message_wq_win_ints",
             "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch", "xeq_tensor_product_wgrad_chunks"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 

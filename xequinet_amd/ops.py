@@ -231,7 +231,7 @@ class EdgeGraph:
             i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
             plan = {"reverse": bool(reverse), "n_ranges": n_ranges, "pcap": pcap, "qptr": i32(N + 1), "pgath": i32(pcap),
                     "peid": i32(pcap), "qinfo": i32(pcap // 4), "sq": i32(2 * n_ranges + 1), "sn": i32(2 * n_ranges + 1),
-                    "win": i32(2 * (-(-n_ranges // int(L.xeq_message_wq_waves())))),
+                    "win": i32(int(L.xeq_message_wq_win_ints(n_ranges))),
                     "work": torch.empty(max(int(L.xeq_message_wq_plan_workspace(N)), 1), dtype=torch.uint8, device=dev),
                     "records": None}
             self._wq[key] = plan
