@@ -1367,6 +1367,42 @@ def test_exclusive_scan_grid_wide_matches_numpy(n):
     assert lib.load().xeq_exclusive_scan_i32_workspace(-1) == -1
 
 
+@pytest.mark.parametrize("mult,eps", [(3, 24), (2, 32), (4, 16)])
+def test_wq_stream_classes_change_no_bit(mult, eps, monkeypatch):
+    """Two stream classes (csrc/xeq_message_wq.hip::wq_long_mult; measured slower and switched off, XEQ_WQ_LONG_MULT brings them back):
+    the l = 0 units walk `mult` table streams at a time, the l > 0 units the table streams themselves.  A node's sums are running sums
+    over ITS edges in walk order whatever the cut of the walk into streams, so forward outputs, node gradients and dL/dvec are bit for
+    bit those of one class -- the same property the sharding tests rest on."""
+    from xequinet_amd import ops
+
+    monkeypatch.setenv("XEQ_MESSAGE_IMPL", "wq")
+    rng = np.random.default_rng(8)
+    pos, z, ptr = syn.synth_qm9_batch(96, seed=23)
+    ei = orc.radius_graph_canonical(pos.astype(np.float32), ptr, 5.0)
+    N, E = len(pos), ei.shape[1]
+    node_dim, mul, B = 128, (128, 64, 32), 20
+    C, D = sum(mul), mul[0] + 3 * mul[1] + 5 * mul[2]
+    H = node_dim + 2 * C
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    h, xhat, s, x = (f32(rng.normal(size=sh)) for sh in ((N, H), (N, D), (N, node_dim), (N, D)))
+    W, b = f32(rng.normal(size=(H, B)) / math.sqrt(B)), f32(rng.normal(size=(H,)))
+    p0 = f32(math.pi * np.arange(1, B + 1) / 5.0).view(1, -1)
+    vec = f32(pos[ei[0]] - pos[ei[1]])
+    gs, gx = f32(rng.normal(size=(N, node_dim))), f32(rng.normal(size=(N, D)))
+    cfg = ("bessel", "cosine", B, 5.0, node_dim, mul)
+    outs = []
+    for m_ in (1, mult):
+        monkeypatch.setenv("XEQ_WQ_LONG_MULT", str(m_))
+        monkeypatch.setenv("XEQ_WQ_EDGES_PER_STREAM", str(eps))
+        graph = ops.EdgeGraph(_t(ei), N, ptr=_t(ptr), symmetric=True)
+        s_out, x_out, saved, impl = ops.message_forward(h, xhat, vec, s, x, W, b, p0, None, graph, cfg, want_backward=True)
+        assert impl == "wq"
+        g = ops.message_backward(saved, graph, cfg, impl, gs, gx, node_grads=True)
+        outs.append((s_out, x_out, g[0], g[1], g[2]))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("irreps,node_dim,B", [("128x0e + 64x1o + 32x2e", 128, 20), ("32x0e + 64x2e", 32, 17), ("64x0e + 32x1o + 32x2e", 64, 8)])
 @pytest.mark.parametrize("layout", [0, 1])
 def test_wq_first_block_hint_changes_nothing(irreps, node_dim, B, layout, monkeypatch):

@@ -390,8 +390,7 @@ def test_launch_policy_is_stated_once_in_the_c_abi():
     assert fam(lib.XEQ_F32, 3_000_000, 150_000_000) == GENERIC   # beyond every 32-bit offset
     assert fam(lib.XEQ_F32, 2_500_000, 40_000_000) in (SB, GENERIC)
     eps = lambda n, e: int(L.xeq_message_wq_edges_per_stream(n, e))
-    # large batches: 48-edge table streams (walked three at a time by the l = 0 units, round 6); 80 below 120 000 edges
-    assert eps(18609, 311994) == 48 and eps(5000, 119000) == 79 and eps(1000, 100000) == 80 and eps(192, 10390) == 54
+    assert eps(18609, 311994) == 80 and eps(5000, 119000) == 79 and eps(1000, 100000) == 80 and eps(192, 10390) == 54
     assert eps(21, 360) == 17 and eps(10, 20) == 16
     assert int(L.xeq_message_wq_win_ints(100)) >= 2 * (25 + 9)   # both stream classes' window tables
     import inspect

@@ -418,15 +418,21 @@ __device__ __forceinline__ WqClass wq_class(const WqArgs& a, int l) {
   c.win = (l == 0 && a.mlong > 1) ? a.win + 2 * wq_class_steps(a.n_ranges, 1) : a.win;
   return c;
 }
-// One class for small or sparse walks, long streams of three for the l = 0 units of large batches (measured on QM9-1024, per-l builds,
+// Per-l builds (the other units exit) say the units want different stream lengths (QM9-1024,
 // us per launch at 48 / 64 / 80 / 112 / 160 edges per stream: forward l = 0 93 / 87 / 79 / 86 / 81, l = 1 65 / 64 / 76 / 89 / 131, l = 2
 // 90 / 109 / 148 / 147 / 157; reverse l = 0 171 / 157 / 145 / 163 / 134, l = 1 102 / 96 / 109 / 96 / 117, l = 2 122 / 113 / 136 / 157 / 190;
-// profiles/r06_stream_classes.txt).  XEQ_WQ_LONG_MULT overrides (development).
+// profiles/r06_small_experiments.txt item 6) -- but see below.
+// MEASURED AND SWITCHED OFF (round 6, profiles/r06_small_experiments.txt item 6): with all seven units in one launch the classes LOSE --
+// QM9-1024, whole step, one box: one class of 80 edges 1.731 ms | 48 x 3 1.775 | 48 x 2 1.790 | 64 x 2 1.747 | 40 x 3 1.796 | one class of
+// 48 1.838.  A unit alone on the chip is a latency measurement (290 workgroups, one or two per CU); seven units together are a throughput
+// measurement, and there every additional step (barrier, staging, range prologue) of the l > 0 units costs more than their window misses.
+// The mechanism stays behind XEQ_WQ_LONG_MULT (development; results do not depend on it, tests/test_gpu_parity.py) with one class as default.
 static int wq_long_mult(int64_t n_edges, int n_ranges) {
   const char* env = getenv("XEQ_WQ_LONG_MULT");
   if (env && atoi(env) >= 1 && atoi(env) <= 8) return atoi(env);
-  const double eps = (double)n_edges / (2.0 * (double)(n_ranges > 0 ? n_ranges : 1));
-  return (n_edges >= 120000 && eps <= 56.0) ? 3 : 1;
+  (void)n_edges;
+  (void)n_ranges;
+  return 1;
 }
 
 // Work of a workgroup: (chunk of consecutive steps, unit).  A step is WQ_WAVES consecutive ranges, one per wave; the

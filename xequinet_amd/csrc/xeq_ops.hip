@@ -395,10 +395,9 @@ int xeq_message_wq_edges_per_stream(int64_t n_nodes, int64_t n_edges) {
   double v = per_node > 16.0 ? per_node : 16.0;
   const double spread = (double)n_edges / 1500.0;
   if (spread > v) v = spread;
-  // Round 6: large batches get TABLE streams of 48 edges, which the l > 0 units walk as they are and the l = 0 units three at a time
-  // (two stream classes, csrc/xeq_message_wq.hip::wq_long_mult): per-l optimum instead of the one length of 80 that was a compromise
-  // between the l = 2 unit's window (best at 48) and the l = 0 units' per-step costs (best from 128 up).
-  if (v >= 80.0) return n_edges >= 120000 ? 48 : 80;
+  // (Round 6 tried 48-edge table streams walked three at a time by the l = 0 units -- two stream classes,
+  // csrc/xeq_message_wq.hip::wq_long_mult: slower with all units in one launch, 1.731 -> 1.775 ms; the one length of 80 stays.)
+  if (v > 80.0) v = 80.0;
   return (int)v;
 }
 
