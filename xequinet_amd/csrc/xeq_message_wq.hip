@@ -1240,6 +1240,14 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   };
   Owners own_next;
   if constexpr (OWN_AHEAD) own_next = load_owners(tbl);
+#ifdef XEQ_WQ_NO_ROW_EARLY
+  constexpr bool ROW_EARLY = false;
+#else
+#ifndef XEQ_WQ_ROW_EARLY_MAXNM
+#define XEQ_WQ_ROW_EARLY_MAXNM 0   // (measured: no change at 1 or 3 -- reverse launch 227-230 us either way -- so the registers stay free)
+#endif
+  constexpr bool ROW_EARLY = NM <= XEQ_WQ_ROW_EARLY_MAXNM;   // which roles request the next tile's records at the tile top (below)
+#endif
 
   for (int t = 0; t < st.ntiles; ++t) {
     const int* tb = tbl + (t & 1) * T_SIZE;
@@ -1272,6 +1280,12 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
     // for in that quad -- twelve exposed global round trips per tile (step timeline of round 3, QM9-1024: a range of the l = 1 /
     // l = 2 units took 41 / 55 us against 28 us for l = 0, whose loads the scheduler hoists by itself; 34 / 43 us now).
     const Owners oq = OWN_AHEAD ? own_next : load_owners(tb);   // (the tile-top request where the rows are not a tile ahead)
+    // development (-DXEQ_WQ_ROW_EARLY_MAXNM=1 / 3): the NEXT tile's records and indices requested here, a whole tile ahead of the table
+    // that is published from them, instead of behind the last matrix chain (the stamps show 8 % of a wave's cycles at the publish and
+    // 6 % at the next tile's top; 34 registers).  Measured on the whole step: no change (profiles/r06_small_experiments.txt item 7).
+#ifndef XEQ_WQ_NO_ROW_EARLY
+    if constexpr (ROW_EARLY) wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);
+#endif
     WQ_STAMP(5);   // tile top: gathers issued
     // l > 0: the gathered rows are read one component at a time (four rows x one m), used and dropped: out of the LDS
     // window a re-read costs 2 cycles, while holding a quad's 4 x NM values (next to the filters, pd and the per-quad
@@ -1403,7 +1417,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
       }
     }
     XEQ_WQ_RSB();
-    if constexpr (!HAS_S) wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // next tile's records
+    if constexpr (!HAS_S && !ROW_EARLY) wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // next tile's records
     WQ_STAMP(8);   // rows of pass E (+ dL/dY sums)
     if constexpr (HAS_S) {  // ---- pass M
       float gsv[16];          // the centers' grad_s rows: only this pass reads them; they land under its MFMAs
@@ -1415,9 +1429,11 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         for (int r = 0; r < 4; ++r) gsv[4 * g + r] = WIN ? wq_lds(win, g1[r] + lgs) : wq_ld(grad_s, g1[r] + wc.b_s);
       }
       const f32x16 dm = wq_filter<KS>(R, Wm, lane), qm = wq_filter<KS>(Rd, Wm, lane);
-      XEQ_WQ_RSB();
-      wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // last MFMAs issued: next tile's records
-      XEQ_WQ_RSB();
+      if constexpr (!ROW_EARLY) {
+        XEQ_WQ_RSB();
+        wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // last MFMAs issued: next tile's records
+        XEQ_WQ_RSB();
+      }
       WQ_STAMP(6);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
