@@ -649,30 +649,31 @@ __device__ __forceinline__ void wq_row(const WqArgs& a, const WqStreams& st, int
 template <int KS, int NREC, bool WITH_Y>
 __device__ __forceinline__ void wq_publish(int lane, const WqRow<KS, NREC, WITH_Y>& w, uint32_t stride0, uint32_t stride1,
                                            int* tbl, uint32_t gbase = 0u) {
-  if (lane < 32) {
-    const int i = lane, hr = (i >> 2) & 1, v = 4 * (i >> 3) + (i & 3), p = 16 * hr + v;
+  // EVERY lane writes, without a branch (round 6).  Lanes l and l + 32 hold the same row (wq_row: i = lane & 31) and the four lanes of
+  // a quad the same quad record, so the duplicates store equal values to equal addresses.  Why: behind `if (lane < 32)` / `if ((i & 3)
+  // == 0)` the compiler SANK the index loads of wq_row (pgath, qinfo: requested a tile ahead in the source) into the branches that
+  // alone use them -- two dependent global round trips per tile, each behind an s_waitcnt vmcnt(0) that also drained the record
+  // prefetch (the forward kernel's l = 0 waves: 19.5 % of their cycles waiting for the record and 3.7 % at the publish by the stamps).
+  const int i = lane & 31, hr = (i >> 2) & 1, v = 4 * (i >> 3) + (i & 3), p = 16 * hr + v;
 #ifdef XEQ_WQ_ABLATE_GATHER   // development: every gather reads node 0 (cache-resident): what the gathers cost
-    tbl[T_G0 + p] = 0;
-    tbl[T_G1 + p] = 0;
+  tbl[T_G0 + p] = 0;
+  tbl[T_G1 + p] = 0;
 #else
-    tbl[T_G0 + p] = (int)(((uint32_t)w.g - gbase) * stride0);   // window mode: gbase = first row of the window
-    tbl[T_G1 + p] = (int)(((uint32_t)w.g - gbase) * stride1);
+  tbl[T_G0 + p] = (int)(((uint32_t)w.g - gbase) * stride0);   // window mode: gbase = first row of the window
+  tbl[T_G1 + p] = (int)(((uint32_t)w.g - gbase) * stride1);
 #endif
-    if constexpr (WITH_Y) {
-      float* tf = reinterpret_cast<float*>(tbl);
+  if constexpr (WITH_Y) {
+    float* tf = reinterpret_cast<float*>(tbl);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        tf[T_Y + 32 * q + p] = w.ya[q];
-        tf[T_Y + 32 * (4 + q) + p] = w.yb[q];
-      }
-    }
-    if ((i & 3) == 0) {
-      const int c = 4 * hr + (i >> 3);
-      tbl[T_QOWN + c] = (int)(w.qi & WQ_OWNER);
-      tbl[T_QKEEP + c] = (w.qi & WQ_FIRST) ? 0 : 1;
-      tbl[T_QLAST + c] = (w.qi & WQ_LAST) ? 1 : 0;
+    for (int q = 0; q < 4; ++q) {
+      tf[T_Y + 32 * q + p] = w.ya[q];
+      tf[T_Y + 32 * (4 + q) + p] = w.yb[q];
     }
   }
+  const int c = 4 * hr + (i >> 3);
+  tbl[T_QOWN + c] = (int)(w.qi & WQ_OWNER);
+  tbl[T_QKEEP + c] = (w.qi & WQ_FIRST) ? 0 : 1;
+  tbl[T_QLAST + c] = (w.qi & WQ_LAST) ? 1 : 0;
 }
 template <typename T>
 __device__ __forceinline__ void wq_tread4(const int* tbl, int idx, T (&out)[4]) {
@@ -895,6 +896,8 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
       for (int m = 0; m < NM; ++m) res_x[g][m] = wq_ld(x_in, ob[g] + 4u * m);   // the owner's residual row, read per quad
       res_s[g] = HAS_S ? wq_ld(s_in, os[g]) : 0.f;
     }
+    XEQ_WQ_FSB();   // the residual rows are requested IN FRONT of the next tile's record: memory returns in order, and the rows are consumed
+                    // in this tile (waiting for them must not wait for the record prefetch behind them)
     wq_row<KS, 1, (NM > 1)>(a, st, lane, t + 1, rec, nullptr, row, (int)gbase);   // next tile's record flies under this tile
     XEQ_WQ_FSB();
     WQ_STAMP(5);   // phase A issued
@@ -969,13 +972,17 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
           }
           if constexpr (HAS_S) sq = __builtin_fmaf(hm[u], dm[v], sq);
         }
+        // A node's running sums START from its residual row (round 6; up to round 5 the residual was added at the store).  The residual
+        // rows are requested at the tile top; used only inside `if (last)` their loads were SUNK into that branch by the compiler -- a
+        // global round trip behind an s_waitcnt vmcnt(0) per finished node, which also drained the next tile's record prefetch.  Consumed
+        // here by a select they stay where they are requested.  (Order of a node's additions: ((res + q_0) + q_1) + ... in any batch.)
 #pragma unroll
-        for (int m = 0; m < NM; ++m) acc_x[m] = (keep[g] ? acc_x[m] : 0.f) + xq[m];
-        if constexpr (HAS_S) acc_s = (keep[g] ? acc_s : 0.f) + sq;
+        for (int m = 0; m < NM; ++m) acc_x[m] = (keep[g] ? acc_x[m] : res_x[g][m]) + xq[m];
+        if constexpr (HAS_S) acc_s = (keep[g] ? acc_s : res_s[g]) + sq;
         if (last[g]) {   // the node's only store
 #pragma unroll
-          for (int m = 0; m < NM; ++m) wq_st(x_out, ob[g] + 4u * m, res_x[g][m] + acc_x[m]);
-          if constexpr (HAS_S) wq_st(s_out, os[g], res_s[g] + acc_s);
+          for (int m = 0; m < NM; ++m) wq_st(x_out, ob[g] + 4u * m, acc_x[m]);
+          if constexpr (HAS_S) wq_st(s_out, os[g], acc_s);
         }
       }
       if constexpr (GR < 16) XEQ_WQ_FSB();
