@@ -866,9 +866,37 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
   //   B  the gathered rows of all 16 rows (LDS window, or global memory)
   //   C  the MFMA chains of the filter
   //   D  row arithmetic, quad by quad; the finished nodes' stores
+  // development (-DXEQ_WQ_DEFER_STORES): a finished node's sums stored at the TOP of the next tile, in front of that tile's requests (l = 0,
+  // 1), so that the wait for the record prefetch does not have to drain a store that may or may not have been issued.  The same idea pays
+  // in the reverse kernel (its per-edge partials); here it measured 278 -> 284 us per forward pair: off.
+#ifdef XEQ_WQ_DEFER_STORES
+  constexpr bool DEFER_ST = NM <= 3;
+#else
+  constexpr bool DEFER_ST = false;
+#endif
+  float pend_x[DEFER_ST ? 4 : 1][NM], pend_s[DEFER_ST ? 4 : 1];
+  uint32_t pend_ob[DEFER_ST ? 4 : 1], pend_os[DEFER_ST ? 4 : 1];
+  int pend_last[DEFER_ST ? 4 : 1];
+  if constexpr (DEFER_ST) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pend_last[g] = 0;
+  }
+  auto flush_nodes = [&]() {
+    if constexpr (DEFER_ST) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (pend_last[g]) {
+#pragma unroll
+          for (int m = 0; m < NM; ++m) wq_st(x_out, pend_ob[g] + 4u * m, pend_x[g][m]);
+          if constexpr (HAS_S) wq_st(s_out, pend_os[g], pend_s[g]);
+        }
+    }
+  };
+
   for (int t = 0; t < st.ntiles; ++t) {
     const int* tb = tbl + (t & 1) * T_SIZE;
     int* tnext = tbl + ((t + 1) & 1) * T_SIZE;
+    flush_nodes();   // the previous tile's finished nodes
     const WqR<KS> R = row.R[0];
     WQ_STAMP(4);   // waiting for the tile's record
     // ---- phase A
@@ -979,7 +1007,14 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
 #pragma unroll
         for (int m = 0; m < NM; ++m) acc_x[m] = (keep[g] ? acc_x[m] : res_x[g][m]) + xq[m];
         if constexpr (HAS_S) acc_s = (keep[g] ? acc_s : res_s[g]) + sq;
-        if (last[g]) {   // the node's only store
+        if constexpr (DEFER_ST) {   // the node's only store, at the next tile's top
+#pragma unroll
+          for (int m = 0; m < NM; ++m) pend_x[g][m] = acc_x[m];
+          pend_s[g] = acc_s;
+          pend_ob[g] = ob[g];
+          pend_os[g] = os[g];
+          pend_last[g] = last[g];
+        } else if (last[g]) {   // the node's only store
 #pragma unroll
           for (int m = 0; m < NM; ++m) wq_st(x_out, ob[g] + 4u * m, acc_x[m]);
           if constexpr (HAS_S) wq_st(s_out, os[g], acc_s);
@@ -992,6 +1027,7 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
     __builtin_amdgcn_wave_barrier();
     WQ_STAMP(9);   // next table published
   }
+  flush_nodes();   // the last tile's
 }
 
 
@@ -1256,9 +1292,45 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
   constexpr bool ROW_EARLY = NM <= XEQ_WQ_ROW_EARLY_MAXNM;   // which roles request the next tile's records at the tile top (below)
 #endif
 
+  // The per-edge partials of a tile (dL/dd and dL/dY_lm of its sixteen rows per half) are stored at the TOP of the next tile (round 6).
+  // A store inside `if (keeper)` is a memory operation that may or may not have been issued, so the compiler has to wait for the record
+  // prefetch -- issued in front of it -- with s_waitcnt vmcnt(0), which waits for the store as well: at the tile's end that was the next
+  // tile's first act.  Issued here they are a whole tile old when the next wait counts them.
+#ifdef XEQ_WQ_NO_DEFER_PARTS
+  constexpr bool DEFER = false;
+#else
+  constexpr bool DEFER = true;
+#endif
+  float pend_pd = 0.f, pend_y[NM > 1 ? NM : 1];
+  int64_t pend_slot = 0;
+  bool pend_keep = false;
+  float pend_hm[HAS_S ? 4 : 1];          // l = 0, general form: the scalar-message gradients of the tile's finished owners (pass M)
+  uint32_t pend_hm_off[HAS_S ? 4 : 1];
+  bool pend_hm_last[HAS_S ? 4 : 1];
+  if constexpr (HAS_S) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pend_hm_last[g] = false;
+  }
+  auto flush_parts = [&]() {
+    if constexpr (HAS_S && !FIRST) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (pend_hm_last[g]) wq_st(grad_h, pend_hm_off[g], pend_hm[g]);
+    }
+    if (pend_keep) {
+      parts.pd[(int64_t)unit * parts.P + pend_slot] = pend_pd;
+      if constexpr (NM > 1) {
+        float* dst = NM == 3 ? parts.y1 : parts.y2;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) dst[((int64_t)un.cb * NM + m) * parts.P + pend_slot] = pend_y[m];
+      }
+    }
+  };
+
   for (int t = 0; t < st.ntiles; ++t) {
     const int* tb = tbl + (t & 1) * T_SIZE;
     int* tnext = tbl + ((t + 1) & 1) * T_SIZE;
+    if constexpr (DEFER) flush_parts();   // the previous tile's partials
     const WqR<KS> R = row.R[0], Rd = row.R[1];
     WQ_STAMP(4);   // waiting for the tile's records
     // gathered gradient rows of one quad (the center's grad_x, NM components per channel)
@@ -1419,7 +1491,8 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
           const float tot = wq_red_cd(pq[m][0], pq[m][1], pq[m][2], pq[m][3], b2, b3);
-          if (keeper) dst[((int64_t)un.cb * NM + m) * parts.P + my_slot] = tot;
+          if constexpr (DEFER) pend_y[NM > 1 ? m : 0] = tot;
+          else if (keeper) dst[((int64_t)un.cb * NM + m) * parts.P + my_slot] = tot;
         }
       }
     }
@@ -1456,7 +1529,11 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
           pd[v] = __builtin_fmaf(o_hm * gsv[v], qm[v], pd[v]);
         }
         a_hm = (keep ? a_hm : 0.f) + hmq;
-        if (last && node_grads) wq_st(grad_h, own * row_h + wc.b_hm, a_hm);
+        if constexpr (DEFER && !FIRST) {   // (this pass's stores come BEHIND the next tile's record request: to the next tile's top with the partials)
+          pend_hm[g] = a_hm;
+          pend_hm_off[g] = own * row_h + wc.b_hm;
+          pend_hm_last[g] = last && node_grads;
+        } else if (last && node_grads) wq_st(grad_h, own * row_h + wc.b_hm, a_hm);
       }
     }
     XEQ_WQ_RSB();
@@ -1466,7 +1543,11 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
       for (int g = 0; g < 4; ++g) pq[g] = wq_red_ab(pd[4 * g], pd[4 * g + 1], pd[4 * g + 2], pd[4 * g + 3], b0, b1);
       const float tot = wq_red_cd(pq[0], pq[1], pq[2], pq[3], b2, b3);
-      if (keeper) parts.pd[(int64_t)unit * parts.P + my_slot] = tot;
+      if constexpr (DEFER) {
+        pend_pd = tot;
+        pend_slot = my_slot;
+        pend_keep = keeper;
+      } else if (keeper) parts.pd[(int64_t)unit * parts.P + my_slot] = tot;
     }
     WQ_STAMP(11);  // dL/dd channel sums
     wq_publish<KS, 2, (NM > 1)>(lane, row, stride0, stride1, tnext, gbase);
@@ -1474,6 +1555,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
     if constexpr (OWN_AHEAD) own_next = load_owners(tnext);   // the next tile's owners are known: their rows fly under the back edge
     WQ_STAMP(12);  // next table published
   }
+  if constexpr (DEFER) flush_parts();   // the last tile's
 }
 
 template <int NM, int KS, bool FIRST>

@@ -343,11 +343,34 @@ __device__ __forceinline__ tile_t ld_tile(const float* __restrict__ row, int c0,
   }
   return t;
 }
+// `ok`: the lane's node exists.  Lanes beyond the last node work on the LAST node's row (row = n - 1), so their results are that row's,
+// bit for bit, and -DXEQ_NB_UNCOND_STORES lets them store too (equal values to equal addresses): a store that is not behind a branch is
+// a memory operation the compiler can COUNT, so the waits behind it name the loads they wait for instead of draining everything.
+#ifdef XEQ_NB_UNCOND_STORES
+#define NB_STORE_OK(ok) true
+#else
+#define NB_STORE_OK(ok) (ok)
+#endif
 __device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, const tile_t& t, bool ok) {
-  if (!ok) return;
+  if (!NB_STORE_OK(ok)) return;
 #pragma unroll
   for (int g = 0; g < 2; ++g)
     *reinterpret_cast<float4*>(row + c0 + 16 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+}
+// a 32-channel tile of a PARAMETER vector (norm weights, biases).  -DXEQ_NB_EXP_NOPARAM (development, timing only, wrong results): no
+// memory access -- what the ~80 small parameter loads of a launch, each requested right in front of its use, cost
+__device__ __forceinline__ tile_t ld_par(const float* __restrict__ vec, int c0, int h) {
+#ifdef XEQ_NB_EXP_NOPARAM
+  extern __shared__ uint4 lds_any_[];   // (two 16-byte LDS reads of whatever the ring holds: the cost the values would have from LDS)
+  const float4 u = *reinterpret_cast<const float4*>(lds_any_ + ((c0 >> 5) & 7) * 64 + (threadIdx.x & 63));
+  const float4 v = *reinterpret_cast<const float4*>(lds_any_ + (((c0 >> 5) & 7) + 8) * 64 + (threadIdx.x & 63));
+  tile_t t;
+  t[0] = u.x; t[1] = u.y; t[2] = u.z; t[3] = u.w; t[4] = v.x; t[5] = v.y; t[6] = v.z; t[7] = v.w;
+  (void)vec; (void)h;
+  return t;
+#else
+  return ld_tile(vec, c0, h);
+#endif
 }
 // Tensors that only these kernels read and write (the forward launch's hand-over to the reverse launch, scratch) use a layout in which
 // every wave access is 1 KB of consecutive bytes: [wave block of 16 nodes][tile][register quad][lane][4 floats] (NAT_TILE floats per
@@ -408,7 +431,7 @@ __device__ __forceinline__ void ld_xm(const float* __restrict__ blk, int h, tile
 }
 template <int DL>
 __device__ __forceinline__ void st_xm(float* __restrict__ blk, int h, const tile_t (&X)[DL], bool ok) {
-  if (!ok) return;
+  if (!NB_STORE_OK(ok)) return;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     float* p = blk + DL * (16 * g + 4 * h);
@@ -686,7 +709,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
       rstd = 1.f / sqrtf(var + 1e-5f);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const tile_t wv = ld_tile(a.lnw, 32 * t, h), bv = ld_tile(a.lnb, 32 * t, h);
+        const tile_t wv = ld_par(a.lnw, 32 * t, h), bv = ld_par(a.lnb, 32 * t, h);
         tile_t sh;
 #pragma unroll
         for (int r = 0; r < 8; ++r) sh[r] = (S[t][r] - mean) * rstd * wv[r] + bv[r];
@@ -699,12 +722,12 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
     float q = (sumsq16(X0[0], mean0) + sumsq16(X0[1], mean0)) + (sumsq16(X0[2], mean0) + sumsq16(X0[3], mean0));
     q += sumsq_span<(D - M0) / 16>(xrow + M0, h);   // the l > 0 features: plain squares, no layout needed
     rr = 1.f / sqrtf(row_sum(q) * (1.f / C) + 1e-5f);
-    if (ok && h == 0) *reinterpret_cast<float4*>(a.stats + 4 * row) = make_float4(mean, rstd, mean0, rr);
+    if (NB_STORE_OK(ok && h == 0)) *reinterpret_cast<float4*>(a.stats + 4 * row) = make_float4(mean, rstd, mean0, rr);
     NB_STAMP(3);
     // ---- l = 0: normalised features -> parked fragments
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const tile_t wv = ld_tile(a.eqw, 32 * t, h), bv = ld_tile(a.eqb, 32 * t, h);
+      const tile_t wv = ld_par(a.eqw, 32 * t, h), bv = ld_par(a.eqb, 32 * t, h);
       tile_t xh;
 #pragma unroll
       for (int r = 0; r < 8; ++r) xh[r] = (X0[t][r] - mean0) * rr * wv[r] + bv[r];
@@ -715,8 +738,8 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   for (int c = 0; c < 4; ++c) {
     tile_t bu = zero16(), bv = zero16();
     if (a.b_uv) {
-      bu = ld_tile(a.b_uv, 32 * c, h);
-      bv = ld_tile(a.b_uv + F, 32 * c, h);
+      bu = ld_par(a.b_uv, 32 * c, h);
+      bv = ld_par(a.b_uv + F, 32 * c, h);
     }
     tile_t U = zero16(), V = zero16();
     out_pair_p<4>(w, U, V, pk);
@@ -739,7 +762,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X1[t]);
-      const tile_t wv = ld_tile(a.eqw, M0 + 32 * t, h);
+      const tile_t wv = ld_par(a.eqw, M0 + 32 * t, h);
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -776,7 +799,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   {  // ---- l = 2
     tile_t X2[5];
     ld_xm<5>(xrow + M0 + 3 * M1, h, X2);
-    const tile_t wv = ld_tile(a.eqw, M0 + M1, h);
+    const tile_t wv = ld_par(a.eqw, M0 + M1, h);
 #pragma unroll
     for (int m = 0; m < 5; ++m)
 #pragma unroll
@@ -805,7 +828,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   // ---- hidden layer of update_mlp: bias, SiLU -> parked fragments
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    HID[t] += ld_tile(a.b3, 32 * t, h);
+    HID[t] += ld_par(a.b3, 32 * t, h);
     NB_SAVE(st_nat(prew, t, lane, HID[t]));
     tile_t hv;
 #pragma unroll
@@ -818,7 +841,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   // ---- a_vv tiles and the equivariant residual update x_out = x + U a_vv (nn/xpainn.py:218-219, 229); the epilogue's operands
   // (U of this lane's own stores, x, the bias) are requested in front of the tile's products
   for (int c = 0; c < 4; ++c) {
-    const tile_t b4v = ld_tile(a.b4, 32 * c, h);
+    const tile_t b4v = ld_par(a.b4, 32 * c, h);
     tile_t U = zero16(), X0c = zero16();
     if (wx) {
       U = ld_nat(uvw, uv_tile(0, 0, 0, c), lane);
@@ -837,7 +860,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
     }
   }
   for (int c = 0; c < 2; ++c) {
-    const tile_t b4v = ld_tile(a.b4, M0 + 32 * c, h);
+    const tile_t b4v = ld_par(a.b4, M0 + 32 * c, h);
     tile_t X[3];
     if (wx) ld_xm<3>(xrow + M0 + 3 * 32 * c, h, X);
     tile_t av = zero16();
@@ -858,7 +881,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
     }
   }
   {
-    const tile_t b4v = ld_tile(a.b4, M0 + M1, h);
+    const tile_t b4v = ld_par(a.b4, M0 + M1, h);
     tile_t X[5];
     if (wx) ld_xm<5>(xrow + M0 + 3 * M1, h, X);
     tile_t av = zero16();
@@ -894,7 +917,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   float* __restrict__ sor = a.s_out + row * F;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const tile_t bsv = ld_tile(a.b4, C + 32 * c, h), bss = ld_tile(a.b4, C + F + 32 * c, h), S = ld_tile(srow, 32 * c, h);
+    const tile_t bsv = ld_par(a.b4, C + 32 * c, h), bss = ld_par(a.b4, C + F + 32 * c, h), S = ld_tile(srow, 32 * c, h);
     NB_SAVE(st_nat(ipw, c, lane, IP[c]));
     tile_t asv = zero16(), ass = zero16();
     out_pair_p<4>(w, asv, ass, pk);
@@ -921,7 +944,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   tile_t HN[4] = {zero16(), zero16(), zero16(), zero16()};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const tile_t wv = ld_tile(a.lnw2, 32 * t, h), bv = ld_tile(a.lnb2, 32 * t, h);
+    const tile_t wv = ld_par(a.lnw2, 32 * t, h), bv = ld_par(a.lnb2, 32 * t, h);
     tile_t sh;
 #pragma unroll
     for (int r = 0; r < 8; ++r) sh[r] = (SN[t][r] - mean_n) * rstd_n * wv[r] + bv[r];
@@ -930,11 +953,11 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   NB_STAMP(10);
   const float qn = q2 + ((sumsq16(XN0[0], mean0_n) + sumsq16(XN0[1], mean0_n)) + (sumsq16(XN0[2], mean0_n) + sumsq16(XN0[3], mean0_n)));
   const float rr_n = 1.f / sqrtf(row_sum(qn) * (1.f / C) + 1e-5f);
-  if (ok && h == 0) *reinterpret_cast<float4*>(a.stats2 + 4 * row) = make_float4(mean_n, rstd_n, mean0_n, rr_n);
+  if (NB_STORE_OK(ok && h == 0)) *reinterpret_cast<float4*>(a.stats2 + 4 * row) = make_float4(mean_n, rstd_n, mean0_n, rr_n);
   // xhat of the next block, BT layout (block l at N base_l, row (node, m), channels contiguous)
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const tile_t wv = ld_tile(a.eqw2, 32 * t, h), bv = ld_tile(a.eqb2, 32 * t, h);
+    const tile_t wv = ld_par(a.eqw2, 32 * t, h), bv = ld_par(a.eqb2, 32 * t, h);
     tile_t xh;
 #pragma unroll
     for (int r = 0; r < 8; ++r) xh[r] = (XN0[t][r] - mean0_n) * rr_n * wv[r] + bv[r];
@@ -944,7 +967,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   // hidden layer of scalar_mlp -> parked fragments
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    HN[t] += ld_tile(a.b1n, 32 * t, h);
+    HN[t] += ld_par(a.b1n, 32 * t, h);
     NB_SAVE(st_nat(a.pre2 + wblk * (S_TILES * NAT_TILE), t, lane, HN[t]));
     tile_t hv;
 #pragma unroll
@@ -957,7 +980,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
   {
     tile_t XC[5];
     ld_xm<5>(xor_ + M0 + 3 * M1, h, XC);
-    const tile_t wv = ld_tile(a.eqw2, M0 + M1, h);
+    const tile_t wv = ld_par(a.eqw2, M0 + M1, h);
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
 #pragma unroll
@@ -966,12 +989,12 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a)
     }
   }
   for (int j = 0; j < HM / 64; ++j) {
-    const tile_t b0 = ld_tile(a.b2n, 64 * j, h), b1 = ld_tile(a.b2n, 64 * j + 32, h);
+    const tile_t b0 = ld_par(a.b2n, 64 * j, h), b1 = ld_par(a.b2n, 64 * j + 32, h);
     tile_t XA[3];
     tile_t wa = zero16();
     if (j < 2) {
       ld_xm<3>(xor_ + M0 + 3 * 32 * j, h, XA);
-      wa = ld_tile(a.eqw2, M0 + 32 * j, h);
+      wa = ld_par(a.eqw2, M0 + 32 * j, h);
     }
     tile_t a0 = zero16(), a1 = zero16();
     out_pair_p<4>(w, a0, a1, pk);
@@ -1046,7 +1069,7 @@ __device__ __forceinline__ void ln_bwd(tile_t (&g)[4], const float* __restrict__
   float a1 = 0.f, a2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const tile_t wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
+    const tile_t wv = ld_par(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const float dy = g[t][r] * wv[r];
@@ -1058,7 +1081,7 @@ __device__ __forceinline__ void ln_bwd(tile_t (&g)[4], const float* __restrict__
   a2 = row_sum(a2) * (1.f / F);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const tile_t wv = ld_tile(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
+    const tile_t wv = ld_par(lnw, 32 * t, h), sv = ld_tile(srow, 32 * t, h);
 #pragma unroll
     for (int r = 0; r < 8; ++r) g[t][r] = rstd * (g[t][r] * wv[r] - a1 - ((sv[r] - mean) * rstd) * a2) + res[t][r];
   }
@@ -1134,7 +1157,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
     float dotp = 0.f, sgw0 = 0.f, sxc0 = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const tile_t g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_tile(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h);
+      const tile_t g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_par(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const float gw = g[r] * wv[r], xc = xv[r] - mean0;
@@ -1147,7 +1170,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
     for (int t = 0; t < 2; ++t) {
       tile_t X[3];
       ld_xm<3>(xo + M0 + 3 * 32 * t, h, X);
-      const tile_t wv = ld_tile(a.eqw2, M0 + 32 * t, h);
+      const tile_t wv = ld_par(a.eqw2, M0 + 32 * t, h);
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
         const tile_t g = ld_tile(a.g_xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h);
@@ -1158,7 +1181,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
     {
       tile_t X[5];
       ld_xm<5>(xo + M0 + 3 * M1, h, X);
-      const tile_t wv = ld_tile(a.eqw2, M0 + M1, h);
+      const tile_t wv = ld_par(a.eqw2, M0 + M1, h);
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
         const tile_t g = ld_tile(a.g_xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h);
@@ -1170,7 +1193,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
     const float gmean = (r2 * row_sum(sgw0) - coef * row_sum(sxc0)) * (1.f / M0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const tile_t g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_tile(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h),
+      const tile_t g = ld_tile(a.g_xhat2 + row * M0, 32 * t, h), wv = ld_par(a.eqw2, 32 * t, h), xv = ld_tile(xo, 32 * t, h),
                    rv = ld_tile(gxi, 32 * t, h);
       tile_t o;
 #pragma unroll
@@ -1182,7 +1205,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
       tile_t X[3], R[3];
       ld_xm<3>(xo + M0 + 3 * 32 * t, h, X);
       ld_xm<3>(gxi + M0 + 3 * 32 * t, h, R);
-      const tile_t wv = ld_tile(a.eqw2, M0 + 32 * t, h);
+      const tile_t wv = ld_par(a.eqw2, M0 + 32 * t, h);
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
         const tile_t g = ld_tile(a.g_xhat2 + N * M0 + (row * 3 + m) * M1, 32 * t, h);
@@ -1196,7 +1219,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
       tile_t X[5], R[5];
       ld_xm<5>(xo + M0 + 3 * M1, h, X);
       ld_xm<5>(gxi + M0 + 3 * M1, h, R);
-      const tile_t wv = ld_tile(a.eqw2, M0 + M1, h);
+      const tile_t wv = ld_par(a.eqw2, M0 + M1, h);
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
         const tile_t g = ld_tile(a.g_xhat2 + N * (M0 + 3 * M1) + (row * 5 + m) * M2, 0, h);
@@ -1336,7 +1359,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const tile_t wv = ld_tile(a.eqw, 32 * t, h), xv = ld_tile(xrow, 32 * t, h);
+      const tile_t wv = ld_par(a.eqw, 32 * t, h), xv = ld_tile(xrow, 32 * t, h);
       tile_t gw;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -1393,7 +1416,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
     for (int t = 0; t < 2; ++t) {
       tile_t X[3], GW[3];
       ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
-      const tile_t wv = ld_tile(a.eqw, M0 + 32 * t, h);
+      const tile_t wv = ld_par(a.eqw, M0 + 32 * t, h);
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -1441,7 +1464,7 @@ __global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a)
     }
     tile_t X[5], GW[5];
     ld_xm<5>(xrow + M0 + 3 * M1, h, X);
-    const tile_t wv = ld_tile(a.eqw, M0 + M1, h);
+    const tile_t wv = ld_par(a.eqw, M0 + M1, h);
 #pragma unroll
     for (int m = 0; m < 5; ++m)
 #pragma unroll
