@@ -319,6 +319,7 @@ def constant_vector(n: int, value: float, dtype, device) -> torch.Tensor:
             if t.is_cuda:
                 torch.cuda.current_stream().synchronize()   # once per key: the constant is complete before ANY stream may read it
             if len(_SEEDS) > 256:
+                torch.cuda.synchronize()   # (rare: another stream may still read an evicted constant -- steps in flight; round-5 advisor)
                 _SEEDS.clear()
             _SEEDS[key] = t
     return t

@@ -820,6 +820,8 @@ def wq_packed_weights(w_rbf: torch.Tensor, b_rbf: torch.Tensor, num_basis: int, 
     packed = torch.empty(n, dtype=torch.float32, device=w_rbf.device)
     call("xeq_message_wq_pack_weights", ptr(w_rbf), ptr(b_rbf), int(num_basis), int(node_dim), mul3(mul), ptr(packed), stream())
     if len(_WQ_WEIGHT_PACKS) >= 32:
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()   # (rare: another stream -- a step in flight -- may still read the evicted pack; round-5 advisor)
         _WQ_WEIGHT_PACKS.pop(next(iter(_WQ_WEIGHT_PACKS)))
     _WQ_WEIGHT_PACKS[key] = (packed, w_rbf, b_rbf)
     return packed
