@@ -738,12 +738,8 @@ int64_t xeq_rowptr_from_degrees_max(void);   /* a size, not a status */
  * NULL: without the next block), out, stream); out holds xeq_node_block_fwd_tiles(with_tail) * 3072 bytes.
  * b_uv = [update_U.bias | update_V.bias] ([2 F]) or NULL; p_scratch: [n, C] floats (EquivariantDot(U, V), read back by dot_lin). */
 int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]);
-/* launch policy (host only): non-zero when an evaluation of n nodes should take the fused launches -- 1: n >= XEQ_NODE_BLOCK_MIN_NODES
- * (default 6 144), a wave per block of 16 nodes; 2 (round 6): small systems, n <= XEQ_NODE_BLOCK_KSPLIT_MAX (default 2 048), the K-split form
- * (four waves share a block of 16 nodes and split every contraction over its k-steps: the launch's serial chain is ~2.5 x shorter, what an
- * MD-sized system needs; xeq_node_block_fwd / _bwd pick the form by the same rule).  0: the chain of small kernels (in between, and with
- * XEQ_NODE_BLOCK=0).  XEQ_NODE_BLOCK_KSPLIT=0/1 forces the K-split form off / on; an explicit XEQ_NODE_BLOCK_MIN_NODES switches it off.
- * The three forms round differently: results are bit for bit independent of the batch WITHIN a form. */
+/* launch policy (host only): 1 when an evaluation of n nodes should take the fused launches (n >= XEQ_NODE_BLOCK_MIN_NODES, default
+ * 6 144; XEQ_NODE_BLOCK=0: never).  Below that the chain of small kernels is faster (a fused launch is one serial chain per wave). */
 int xeq_node_block_auto(int64_t n);
 /* waves per workgroup of the node-block launches that follow (host only, process-wide): 0 = by node count (one workgroup per CU of 5 .. 8
  * waves between 4 097 and 8 192 wave-blocks of 16 nodes, four otherwise: a lone launch ends with its slowest CU), 4 .. 8 = fixed.  Results

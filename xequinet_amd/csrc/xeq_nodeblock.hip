@@ -34,7 +34,6 @@
 #include <stdlib.h>
 #include <atomic>
 
-#include <type_traits>
 #include <vector>
 
 #include "xeq_common.h"
@@ -207,11 +206,6 @@ struct WStream {
     cur = nxt;
     read(1);
   }
-  static constexpr bool KSPLIT = false;
-  template <int N>
-  __device__ __forceinline__ void allreduce(tile_t (&)[N]) {}   // (K-split streams add the waves' partial sums up here: KStream below)
-  __device__ __forceinline__ void allreduce(tile_t&) {}
-  __device__ __forceinline__ void allreduce(tile_t&, tile_t&) {}
   // the fragments of the next tile of the program
   __device__ __forceinline__ Frag next() {
     const Frag r = cur;
@@ -326,194 +320,6 @@ __device__ __forceinline__ void out_pair_p(WStream& w, tile_t& a0, tile_t& a1, c
     mfma6<1>(a0, w.next(), b);
     mfma6<1>(a1, w.next(), b);
   }
-}
-
-// ------------------------------------------------------------------------------------------------ K-split stream (small systems)
-// The launches above give a wave 16 nodes and the whole chain of ~590 weight tiles: ~55-95 us per launch however few the nodes (MD-sized
-// systems: 21 atoms take as long as 16 000).  For small systems the FOUR waves of a workgroup take the SAME 16 nodes and split every
-// contraction over its k-steps: k-step number i of the launch (counted over the whole program) is multiplied by wave i mod 4, the
-// others step over its weight tiles, and where a contraction's sum is complete the four partial accumulators are added up through LDS in
-// one fixed order (wave 0 + 1 + 2 + 3: every wave ends with the same bits, results do not depend on timing).  Everything between the
-// contractions (norms, gates, residuals, stores) is what the one-wave form does, done alike by all four waves -- their stores are
-// duplicates of equal values.  The weight ring has three stages here: a wave reads a tile's fragments when it multiplies them (no
-// two-tile lookahead to keep in registers across the tiles it steps over), so a stage's slot may only be overwritten once the stage
-// is wholly behind every wave, i.e. two boundaries later.
-constexpr int KS_RING_STAGES = 3, KS_RED_TILES = 4;
-constexpr int KS_RING_U4 = KS_RING_STAGES * STAGE_TILES * TILE_U4;
-constexpr int KS_RED_U4 = 2 * 4 * KS_RED_TILES * 128;   // two buffers x four waves x up to four tiles of 2 KB
-constexpr int KS_LDS_BYTES = (KS_RING_U4 + 4 * PARK_U4 + KS_RED_U4) * 16;
-struct KStream {
-  static constexpr bool KSPLIT = true;
-  const uint4* __restrict__ g;
-  uint4* ring;
-  float4* red;
-  int t, n_tiles, lane, wave, kturn, rbuf;
-  uint4 pf[PF][3];
-  __device__ __forceinline__ void issue(int stage) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      int tile = stage * STAGE_TILES + 4 * i + wave;
-      tile = tile < n_tiles ? tile : n_tiles - 1;
-      const uint4* p = g + (int64_t)tile * TILE_U4 + lane;
-      pf[i][0] = p[0];
-      pf[i][1] = p[64];
-      pf[i][2] = p[128];
-    }
-  }
-  __device__ __forceinline__ void commit(int stage) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      uint4* q = ring + ((stage % KS_RING_STAGES) * STAGE_TILES + 4 * i + wave) * TILE_U4 + lane;
-      q[0] = pf[i][0];
-      q[64] = pf[i][1];
-      q[128] = pf[i][2];
-    }
-  }
-  __device__ __forceinline__ void init(const uint4* g_, uint4* ring_, int n_tiles_, int lane_, int wave_) {
-    g = g_;
-    ring = ring_;
-    red = reinterpret_cast<float4*>(ring_ + KS_RING_U4 + 4 * PARK_U4);
-    n_tiles = n_tiles_;
-    lane = lane_;
-    wave = wave_;
-    t = 0;
-    kturn = 0;
-    rbuf = 0;
-    issue(0);
-    commit(0);
-    issue(1);
-    commit(1);
-    NB_LDS_BARRIER();
-    issue(2);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // one tile further; at the stage boundary every wave arrives -- multiplying or stepping over -- after the same number of tiles
-  __device__ __forceinline__ void advance() {
-    ++t;
-    if ((t & (STAGE_TILES - 1)) == STAGE_TILES - 2) {
-      const int j = t / STAGE_TILES + 1;
-      NB_LDS_BARRIER();   // (with the drain: a wave that stepped over the last tiles has waited for nothing since its commit)
-      commit(j + 1);
-      issue(j + 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  __device__ __forceinline__ Frag take() {   // the fragments of tile t, read now
-    const uint4* q = ring + (((t / STAGE_TILES) % KS_RING_STAGES) * STAGE_TILES + (t & (STAGE_TILES - 1))) * TILE_U4 + lane;
-    Frag f;
-    f.hi = __builtin_bit_cast(bf16x8, q[0]);
-    f.mid = __builtin_bit_cast(bf16x8, q[64]);
-    f.lo = __builtin_bit_cast(bf16x8, q[128]);
-    advance();
-    return f;
-  }
-  __device__ __forceinline__ void skip(int n) {
-    for (int i = 0; i < n; ++i) advance();
-  }
-  __device__ __forceinline__ bool mine() const { return (kturn & 3) == wave; }
-  __device__ __forceinline__ void turn() { ++kturn; }
-  // the four waves' partial sums of N <= 4 accumulator tiles, added in the order wave 0, 1, 2, 3 (every wave: the same bits)
-  template <int N>
-  __device__ __forceinline__ void allreduce(tile_t (&a)[N]) {
-    static_assert(N <= KS_RED_TILES, "allreduce: at most KS_RED_TILES tiles at a time");
-    float4* base = red + rbuf * (4 * KS_RED_TILES * 128);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      float4* slot = base + (wave * KS_RED_TILES + i) * 128 + lane;
-      slot[0] = make_float4(a[i][0], a[i][1], a[i][2], a[i][3]);
-      slot[64] = make_float4(a[i][4], a[i][5], a[i][6], a[i][7]);
-    }
-    NB_LDS_BARRIER();
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      float4 lo[4], hi[4];
-#pragma unroll
-      for (int w_ = 0; w_ < 4; ++w_) {
-        const float4* slot = base + (w_ * KS_RED_TILES + i) * 128 + lane;
-        lo[w_] = slot[0];
-        hi[w_] = slot[64];
-      }
-      a[i][0] = ((lo[0].x + lo[1].x) + lo[2].x) + lo[3].x;
-      a[i][1] = ((lo[0].y + lo[1].y) + lo[2].y) + lo[3].y;
-      a[i][2] = ((lo[0].z + lo[1].z) + lo[2].z) + lo[3].z;
-      a[i][3] = ((lo[0].w + lo[1].w) + lo[2].w) + lo[3].w;
-      a[i][4] = ((hi[0].x + hi[1].x) + hi[2].x) + hi[3].x;
-      a[i][5] = ((hi[0].y + hi[1].y) + hi[2].y) + hi[3].y;
-      a[i][6] = ((hi[0].z + hi[1].z) + hi[2].z) + hi[3].z;
-      a[i][7] = ((hi[0].w + hi[1].w) + hi[2].w) + hi[3].w;
-    }
-    rbuf ^= 1;   // (two buffers: a wave that is ahead writes the other one; by the barrier after that everybody has read this one)
-  }
-  __device__ __forceinline__ void allreduce(tile_t& a) {
-    tile_t v[1] = {a};
-    allreduce<1>(v);
-    a = v[0];
-  }
-  __device__ __forceinline__ void allreduce(tile_t& a, tile_t& b) {
-    tile_t v[2] = {a, b};
-    allreduce<2>(v);
-    a = v[0];
-    b = v[1];
-  }
-};
-// the primitives on a K-split stream: a k-step is multiplied by the wave whose turn it is; accum_tile leaves the adding-up to its caller
-// (a sum over several calls), the whole-contraction forms add up themselves
-template <int NOT>
-__device__ __forceinline__ void accum_tile(KStream& w, tile_t (&acc)[NOT], const tile_t& T) {
-  if (w.mine()) {
-    const Frag f = split_t(T);
-#pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) {
-      const Frag a = w.take();
-      mfma6<0>(acc[ot], a, f);
-    }
-#pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) {
-      const Frag a = w.take();
-      mfma6<1>(acc[ot], a, f);
-    }
-  } else {
-    w.skip(2 * NOT);
-  }
-  w.turn();
-}
-template <int NK>
-__device__ __forceinline__ void out_tile_p(KStream& w, tile_t& acc, const Park& pk) {
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    if (w.mine()) {
-      const Frag b = pk.get(k);
-      const Frag a0 = w.take();
-      mfma6<0>(acc, a0, b);
-      const Frag a1 = w.take();
-      mfma6<1>(acc, a1, b);
-    } else {
-      w.skip(2);
-    }
-    w.turn();
-  }
-  w.allreduce(acc);
-}
-template <int NK>
-__device__ __forceinline__ void out_pair_p(KStream& w, tile_t& a0, tile_t& a1, const Park& pk) {
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    if (w.mine()) {
-      const Frag b = pk.get(k);
-      const Frag f0 = w.take();
-      mfma6<0>(a0, f0, b);
-      const Frag f1 = w.take();
-      mfma6<0>(a1, f1, b);
-      const Frag f2 = w.take();
-      mfma6<1>(a0, f2, b);
-      const Frag f3 = w.take();
-      mfma6<1>(a1, f3, b);
-    } else {
-      w.skip(4);
-    }
-    w.turn();
-  }
-  w.allreduce(a0, a1);
 }
 
 __device__ __forceinline__ tile_t zero16() {
@@ -861,26 +667,25 @@ struct FwdArgs {
   float *stats2, *xhat2, *pre2, *h2;     // xhat2 in BT layout
 };
 
-// KS: the K-split form for small systems (KStream above): the workgroup's four waves share ONE block of 16 nodes
-template <bool TAIL, bool KS = false>
-__global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a) {
+template <bool TAIL>
+__global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_fwd(FwdArgs a) {
   extern __shared__ uint4 ring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, h = lane >> 4;   // node of the wave, channel quarter
-  const int n_waves = KS ? 1 : (int)(blockDim.x >> 6);   // node blocks of the workgroup: 4 .. 8 waves with one each (xeq::nb::waves_for), or one shared by four
-  const int64_t wblk = KS ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * n_waves + wave;   // this wave's block of 16 nodes in the internal layout (= node / 16)
-  const int64_t node = wblk * WAVE_ROWS + n;
+  const int n_waves = (int)(blockDim.x >> 6);   // 4 .. 8, chosen by the host (xeq::nb::waves_for)
+  const int64_t node = ((int64_t)blockIdx.x * n_waves + wave) * WAVE_ROWS + n;
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
   const int64_t N = a.n;
   NB_STAMP(0);
   NB_RSTAMP(17);
-  typename std::conditional<KS, KStream, WStream>::type w;
+  WStream w;
   w.init(a.wp, ring, a.n_tiles, lane, wave & 3);
-  const Park pk{ring + (KS ? KS_RING_U4 : RING_BYTES / 16) + wave * PARK_U4 + lane};
+  const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
   NB_STAMP(1);
   const float* __restrict__ srow = a.s + row * F;
   const float* __restrict__ xrow = a.x + row * D;
+  const int64_t wblk = (int64_t)blockIdx.x * n_waves + wave;   // this wave's block of 16 nodes in the internal layout (= node / 16)
   float* __restrict__ pw = a.p + wblk * (P_TILES * NAT_TILE);
   float* __restrict__ uvw = a.uv + wblk * (UV_TILES * NAT_TILE);
   float* __restrict__ prew = a.pre + wblk * (S_TILES * NAT_TILE);
@@ -1020,7 +825,6 @@ __global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_fwd
     accum_tile<4>(w, HID, v);
   }
   NB_STAMP(6);
-  w.allreduce(HID);   // (K-split: the waves' partial sums over the eleven k-steps)
   // ---- hidden layer of update_mlp: bias, SiLU -> parked fragments
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -1108,7 +912,6 @@ __global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_fwd
       accum_tile<4>(w, IP, cur);
     }
   }
-  w.allreduce(IP);
   // ---- (a_sv, a_ss) per scalar tile and the scalar residual update s_out = s + a_sv dot_lin(p) + a_ss (nn/xpainn.py:221-228)
   tile_t SN[4];
   float* __restrict__ sor = a.s_out + row * F;
@@ -1161,7 +964,6 @@ __global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_fwd
     st_tile(a.xhat2 + row * M0, 32 * t, h, xh, ok);
   }
   NB_STAMP(11);
-  w.allreduce(HN);
   // hidden layer of scalar_mlp -> parked fragments
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -1285,21 +1087,21 @@ __device__ __forceinline__ void ln_bwd(tile_t (&g)[4], const float* __restrict__
   }
 }
 
-template <bool TAIL, bool GX, bool KS = false>
-__global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a) {
+template <bool TAIL, bool GX>
+__global__ void __launch_bounds__(64 * MAX_WAVES, 1) k_node_block_bwd(BwdArgs a) {
   extern __shared__ uint4 ring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, h = lane >> 4;   // node of the wave, channel quarter
-  const int n_waves = KS ? 1 : (int)(blockDim.x >> 6);   // node blocks of the workgroup (as in the forward kernel)
-  const int64_t wblk = KS ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * n_waves + wave;   // this wave's block of 16 nodes in the internal layout (= node / 16)
-  const int64_t node = wblk * WAVE_ROWS + n;
+  const int n_waves = (int)(blockDim.x >> 6);   // 4 .. 8, chosen by the host (xeq::nb::waves_for)
+  const int64_t node = ((int64_t)blockIdx.x * n_waves + wave) * WAVE_ROWS + n;
   const bool ok = node < a.n;
   const int64_t row = ok ? node : a.n - 1;
   const int64_t N = a.n;
-  typename std::conditional<KS, KStream, WStream>::type w;
+  WStream w;
   w.init(a.wp, ring, a.n_tiles, lane, wave & 3);
-  const Park pk{ring + (KS ? KS_RING_U4 : RING_BYTES / 16) + wave * PARK_U4 + lane};
+  const Park pk{ring + RING_BYTES / 16 + wave * PARK_U4 + lane};
   const float e2 = a.eps * a.eps;
+  const int64_t wblk = (int64_t)blockIdx.x * n_waves + wave;   // this wave's block of 16 nodes in the internal layout (= node / 16)
 #ifdef XEQ_NB_EXP_SCRATCH0
   const int64_t cblk = wblk & 255;
 #else
@@ -1330,7 +1132,6 @@ __global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_bwd
       if (kt + 1 < HM / 32) gt = ld_tile(ghr, 32 * (kt + 1), h);
       accum_tile<4>(w, GH, cur);
     }
-    w.allreduce(GH);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const tile_t pv = ld_nat(a.pre2 + sblk * (S_TILES * NAT_TILE), t, lane);
@@ -1492,7 +1293,6 @@ __global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_bwd
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) accum_tile<4>(w, GHID, GS[c]);   // g_a_ss = g_s_out
-  w.allreduce(GHID);
   const float4 st = *reinterpret_cast<const float4*>(a.stats + 4 * row);
   {  // ---- g_hidden silu'(pre) -> fragments; g_shat = W3^T[:F] g_hidden -> LayerNorm reverse -> g_s; g_v = W3^T[F:] g_hidden
 #pragma unroll
@@ -1557,7 +1357,6 @@ __global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_bwd
       accum_tile<4>(w, GXH, gU);
       accum_tile<4>(w, GXH, gV);
     }
-    w.allreduce(GXH);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const tile_t wv = ld_par(a.eqw, 32 * t, h), xv = ld_tile(xrow, 32 * t, h);
@@ -1614,8 +1413,6 @@ __global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_bwd
       }
     }
 #pragma unroll
-    for (int m = 0; m < 3; ++m) w.allreduce(GXH[m]);
-#pragma unroll
     for (int t = 0; t < 2; ++t) {
       tile_t X[3], GW[3];
       ld_xm<3>(xrow + M0 + 3 * 32 * t, h, X);
@@ -1665,8 +1462,6 @@ __global__ void __launch_bounds__(KS ? 256 : 64 * MAX_WAVES, 1) k_node_block_bwd
       accum_tile<1>(w, GXH[m], gU);
       accum_tile<1>(w, GXH[m], gV);
     }
-#pragma unroll
-    for (int m = 0; m < 5; ++m) w.allreduce(GXH[m]);
     tile_t X[5], GW[5];
     ld_xm<5>(xrow + M0 + 3 * M1, h, X);
     const tile_t wv = ld_par(a.eqw, M0 + M1, h);
@@ -1730,42 +1525,14 @@ static hipError_t raise_lds() {
     const void* fns[] = {reinterpret_cast<const void*>(&k_node_block_fwd<true>), reinterpret_cast<const void*>(&k_node_block_fwd<false>),
                          reinterpret_cast<const void*>(&k_node_block_bwd<true, true>), reinterpret_cast<const void*>(&k_node_block_bwd<false, true>),
                          reinterpret_cast<const void*>(&k_node_block_bwd<false, false>)};
-    const void* ks[] = {reinterpret_cast<const void*>(&k_node_block_fwd<true, true>), reinterpret_cast<const void*>(&k_node_block_fwd<false, true>),
-                        reinterpret_cast<const void*>(&k_node_block_bwd<true, true, true>), reinterpret_cast<const void*>(&k_node_block_bwd<false, true, true>),
-                        reinterpret_cast<const void*>(&k_node_block_bwd<false, false, true>)};
     hipError_t e = hipSuccess;
     for (const void* f : fns) {
       const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(MAX_WAVES));
       if (r != hipSuccess) e = r;
     }
-    for (const void* f : ks) {
-      const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS_BYTES);
-      if (r != hipSuccess) e = r;
-    }
     return e;
   }();
   return err;
-}
-
-// Which form a launch over n nodes takes: 0 the chain of small kernels (the callers' choice: xeq_node_block_auto), 1 the one-wave-per-block
-// launches, 2 the K-split launches for small systems (four waves per block of 16 nodes: ~2.5 x shorter chains; KStream).  The K-split form
-// fills the chip up to 256 blocks = 4 096 nodes but its launches do four times the elementwise work, so it ends where the chain of small
-// kernels has spread wide enough to catch up.  XEQ_NODE_BLOCK_KSPLIT = 0 / 1 switches it off / on for every size (tests, development);
-// an explicit XEQ_NODE_BLOCK_MIN_NODES (the tests' way of pinning the one-wave form for every shard of a job) switches it off as well.
-static int64_t ksplit_max_nodes() {
-  if (const char* v = getenv("XEQ_NODE_BLOCK_KSPLIT_MAX")) return atoll(v);
-  return 2048;
-}
-static int launch_form(int64_t n) {
-  const char* off = getenv("XEQ_NODE_BLOCK");
-  if (off && off[0] == '0') return 0;
-  const char* ks = getenv("XEQ_NODE_BLOCK_KSPLIT");
-  if (ks && ks[0] == '1') return 2;
-  const char* mn = getenv("XEQ_NODE_BLOCK_MIN_NODES");
-  const bool ks_off = (ks && ks[0] == '0') || mn != nullptr;
-  if (!ks_off && n <= ksplit_max_nodes()) return 2;
-  const int64_t min_nodes = mn ? atoll(mn) : 6144;
-  return n >= min_nodes ? 1 : 0;
 }
 
 // Waves per workgroup for a launch over n nodes.  A wave is one serial chain (~130 us alone on its SIMD, ~170 us when two share one),
@@ -1811,7 +1578,13 @@ int xeq_node_block_set_waves(int waves) {
  * for 9 000 (~0.1 ms: one workgroup's serial chain): below XEQ_NODE_BLOCK_MIN_NODES (default 6 144) the chain of small kernels, which
  * spreads a few tiles over many workgroups, is the faster path (whole steps, QM9-shape batches: 4 587 atoms 1.22 against 1.18 ms,
  * 9 133 atoms 1.57 against 1.69 ms; profiles/r04_nodeblock.txt).  XEQ_NODE_BLOCK=0 switches the fused launches off. */
-int xeq_node_block_auto(int64_t n) { return launch_form(n); }   /* 0 chain of small kernels, 1 fused launches, 2 fused launches in the K-split form (small systems) */
+int xeq_node_block_auto(int64_t n) {
+  const char* off = getenv("XEQ_NODE_BLOCK");
+  if (off && off[0] == '0') return 0;
+  int64_t min_nodes = 6144;
+  if (const char* v = getenv("XEQ_NODE_BLOCK_MIN_NODES")) min_nodes = atoll(v);
+  return n >= min_nodes;
+}
 
 /* rows of the kernels' internal tensors (uv, p, pre, a, ip, pre_next; gxo, gp, gv, gw): whole wave blocks of 16 nodes plus one workgroup's worth
  * of slack (the last workgroup's idle waves store their padding rows) */
@@ -1876,16 +1649,9 @@ int xeq_node_block_fwd(int64_t n, const float* s, const float* x, const float* l
   fa.p = p_scratch; fa.uv = uv_bt; fa.stats = stats; fa.pre = pre; fa.a = a; fa.ip = ip; fa.s_out = s_out; fa.x_out = x_out;
   fa.lnw2 = ln_w_next; fa.lnb2 = ln_b_next; fa.eqw2 = eq_w_next; fa.eqb2 = eq_b_next; fa.b1n = b1_next; fa.b2n = b2_next;
   fa.stats2 = stats_next; fa.xhat2 = xhat_next; fa.pre2 = pre_next; fa.h2 = h_next;
-  XEQ_CHECK_ARG(raise_lds() == hipSuccess, "xeq_node_block_fwd: cannot raise the dynamic LDS limit");
-  if (launch_form(n) == 2) {   // small systems: four waves per block of 16 nodes
-    const dim3 grid((unsigned)((n + WAVE_ROWS - 1) / WAVE_ROWS));
-    if (tail) hipLaunchKernelGGL((k_node_block_fwd<true, true>), grid, dim3(256), KS_LDS_BYTES, (hipStream_t)stream, fa);
-    else hipLaunchKernelGGL((k_node_block_fwd<false, true>), grid, dim3(256), KS_LDS_BYTES, (hipStream_t)stream, fa);
-    XEQ_CHECK_LAUNCH("xeq_node_block_fwd (K-split)");
-    return XEQ_OK;
-  }
   const int nw = waves_for(n);
   const dim3 grid((unsigned)((n + nw * WAVE_ROWS - 1) / (nw * WAVE_ROWS)));
+  XEQ_CHECK_ARG(raise_lds() == hipSuccess, "xeq_node_block_fwd: cannot raise the dynamic LDS limit");
   if (tail) hipLaunchKernelGGL(k_node_block_fwd<true>, grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, fa);
   else hipLaunchKernelGGL(k_node_block_fwd<false>, grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, fa);
   XEQ_CHECK_LAUNCH("xeq_node_block_fwd");
@@ -1935,17 +1701,9 @@ int xeq_node_block_bwd(int64_t n, const float* g_h, const float* g_xhat_next, co
   b.stats2 = stats_next; b.pre2 = pre_next; b.lnw2 = ln_w_next; b.eqw2 = eq_w_next; b.uv = uv_bt; b.a = a; b.ip = ip; b.pre = pre;
   b.s = s; b.x = x; b.stats = stats; b.lnw = ln_w; b.eqw = eq_w; b.eps = (float)eps; b.wp = (const uint4*)packed;
   b.n_tiles = (int)xeq_node_block_bwd_tiles(tail, gx); b.gxo = gxo; b.gp = gp; b.gv = gv; b.gw = gw; b.g_s = g_s; b.g_x = g_x;
-  XEQ_CHECK_ARG(raise_lds() == hipSuccess, "xeq_node_block_bwd: cannot raise the dynamic LDS limit");
-  if (launch_form(n) == 2) {
-    const dim3 grid((unsigned)((n + WAVE_ROWS - 1) / WAVE_ROWS));
-    if (tail) hipLaunchKernelGGL((k_node_block_bwd<true, true, true>), grid, dim3(256), KS_LDS_BYTES, (hipStream_t)stream, b);
-    else if (gx) hipLaunchKernelGGL((k_node_block_bwd<false, true, true>), grid, dim3(256), KS_LDS_BYTES, (hipStream_t)stream, b);
-    else hipLaunchKernelGGL((k_node_block_bwd<false, false, true>), grid, dim3(256), KS_LDS_BYTES, (hipStream_t)stream, b);
-    XEQ_CHECK_LAUNCH("xeq_node_block_bwd (K-split)");
-    return XEQ_OK;
-  }
   const int nw = waves_for(n);
   const dim3 grid((unsigned)((n + nw * WAVE_ROWS - 1) / (nw * WAVE_ROWS)));
+  XEQ_CHECK_ARG(raise_lds() == hipSuccess, "xeq_node_block_bwd: cannot raise the dynamic LDS limit");
   if (tail) hipLaunchKernelGGL((k_node_block_bwd<true, true>), grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, b);
   else if (gx) hipLaunchKernelGGL((k_node_block_bwd<false, true>), grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, b);
   else hipLaunchKernelGGL((k_node_block_bwd<false, false>), grid, dim3(64 * nw), lds_bytes(nw), (hipStream_t)stream, b);

@@ -489,7 +489,7 @@ class GraphedLanes:
         if n > self.n_atoms or g > self.n_graphs:
             raise ValueError(f"GraphedLanes: batch of {n} atoms / {g} graphs exceeds the capacity {self.n_atoms} / {self.n_graphs}")
         plan = self._plan(ptr_host)
-        sides = {int(ops.lib.load().xeq_node_block_auto(b - a)) for a, b, _, _ in plan}
+        sides = {bool(ops.lib.load().xeq_node_block_auto(b - a)) for a, b, _, _ in plan}
         if len(sides) > 1:
             raise ValueError("GraphedLanes: the lanes fall on both sides of the node-block threshold (their bits would differ from the unsplit step's)")
         pos_c = pos.detach().contiguous()
@@ -647,7 +647,7 @@ class GraphedChunks:
         self.plan = [(int(ph[g0]), int(ph[g1]), int(g0), int(g1)) for g0, g1 in cuts]
         cap = (max(b - a for a, b, _, _ in self.plan) + 64, max(g1 - g0 for _, _, g0, g1 in self.plan),
                max(pair_capacity(ph[g0 : g1 + 1] - ph[g0]) for _, _, g0, g1 in self.plan))
-        sides = {int(ops.lib.load().xeq_node_block_auto(b - a)) for a, b, _, _ in self.plan}
+        sides = {bool(ops.lib.load().xeq_node_block_auto(b - a)) for a, b, _, _ in self.plan}
         if len(sides) > 1:
             raise ValueError("GraphedChunks: the chunks fall on both sides of the node-block threshold (their bits would differ from one evaluation's)")
         self.depth = max(1, min(int(depth), len(self.plan)))
