@@ -572,9 +572,10 @@ def main():
                         "algorithmic_bytes_per_launch": alg, "algorithmic_flops_per_launch": flops, "hbm": hbm_line,
                         "matrix_pipe": {"algorithmic_flops_per_launch": flops, "achieved": tfl, "peak": F32_MATRIX_PEAK_TFLOPS,
                                         "unit": "TFLOP/s", "frac": tfl / F32_MATRIX_PEAK_TFLOPS,
-                                        "dtype": "algorithmic f32 flops against the exact-f32 rate (v_mfma_f32_32x32x2_f32); since round 3 the filter's "
-                                                 "first 16 basis rows run as a three-way bf16 split (six v_mfma_f32_32x32x16_bf16 per chain, 384 instead "
-                                                 "of 704 pipe cycles), so the fraction can exceed what the exact-f32 pipe alone allows"},
+                                        "dtype": "algorithmic f32 flops against the exact-f32 rate (v_mfma_f32_32x32x2_f32); the filter runs as three-way bf16 "
+                                                 "splits (nine v_mfma_f32_32x32x16_bf16 per chain since round 6: 288 pipe cycles per filter tile, round 3-5: 384, "
+                                                 "exact f32: 704), so the fraction can exceed what the exact-f32 pipe alone allows; against the bf16-split-"
+                                                 "equivalent rate (2.5 PFLOP/s / 6) it is 0.377 x this fraction"},
                         "kernels_ms_per_step": {k: v["total_ms"] / cal for k, v in kernel_ms.items()}}
             first = kernel_ms.get(dom + "_first")
             if first is not None:
