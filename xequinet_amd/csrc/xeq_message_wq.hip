@@ -722,9 +722,11 @@ __device__ __forceinline__ void wq_for_isolated(const WqArgs&, int, int, Fn) {}
 #ifndef XEQ_WQ_SB
 #define XEQ_WQ_SB() __builtin_amdgcn_sched_barrier(0)
 #endif
-// fence between the phases of a forward tile (dev switch: -D'XEQ_WQ_FSB()=' lets the compiler interleave them)
+// fence between the phases of a forward tile (dev switch: -D'XEQ_WQ_FSB()=' lets the compiler interleave them).  FENCED (template
+// parameter of the forward body): the first-block kernel runs WITHOUT the fences since round 6 -- its launch 113.6 -> 109.7 us, the general
+// kernel's the same with and without (profiles/r06_small_experiments.txt item 12)
 #ifndef XEQ_WQ_FSB
-#define XEQ_WQ_FSB() XEQ_WQ_SB()
+#define XEQ_WQ_FSB() do { if constexpr (FENCED) XEQ_WQ_SB(); } while (0)
 #endif
 // fences between the quads / passes of a REVERSE tile: none by default since round 3 (this file's reverse half is built with the
 // default, register-pressure-aware machine scheduler: with the owner rows fetched at the tile top it orders the loads of a tile
@@ -811,7 +813,7 @@ __device__ __forceinline__ void wq_stage_fwd(const WqArgs& a, const WqUnit& un, 
 
 //   x_c += xhat[n] (h_state[n] phi_state) + Y (h_edge[n] phi_edge);   s_c += h_msg[n] phi_msg   (l = 0)
 // WIN: the gathered rows of this step are in the LDS window (first node w0); otherwise they are read from global memory
-template <int NM, int KS, bool WIN, bool XZ>
+template <int NM, int KS, bool WIN, bool XZ, bool FENCED>
 __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const WqUnit un, const WqCols& wc,
                                             const float* __restrict__ rec, const float* __restrict__ h,
                                             const float* __restrict__ xhat_, const float* __restrict__ s_in,
@@ -1032,7 +1034,7 @@ __device__ __forceinline__ void wq_fwd_body(const WqArgs& a, int range, const Wq
 
 
 // one role of the forward kernel: the workgroup's steps, each with its window staged first when it fits
-template <int NM, int KS, bool XZ>
+template <int NM, int KS, bool XZ, bool FENCED>
 __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_end, const WqUnit un, const float* __restrict__ rec,
                                             const float* __restrict__ h, const float* __restrict__ xhat,
                                             const float* __restrict__ s_in, const float* __restrict__ x_in, const float* wl,
@@ -1060,8 +1062,8 @@ __device__ __forceinline__ void wq_fwd_role(const WqArgs& a, int s_beg, int s_en
     WQ_STAMP(2);   // barrier behind the staging
     const int range = step * WQ_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: the stream bounds become scalar loads)
     if (range < cl.n_ranges) {
-      if (use_win) wq_fwd_body<NM, KS, true, XZ>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, w0, st_, last_);
-      else wq_fwd_body<NM, KS, false, XZ>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, 0, st_, last_);
+      if (use_win) wq_fwd_body<NM, KS, true, XZ, FENCED>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, w0, st_, last_);
+      else wq_fwd_body<NM, KS, false, XZ, FENCED>(a, range, un, wc, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win, 0, st_, last_);
     }
     WQ_STAMP(3);   // body prologue (isolated nodes, first record) -- what the tile stamps did not take
     __syncthreads();   // the window and the tile tables are rewritten by the next step
@@ -1106,16 +1108,16 @@ k_message_fwd_wq(WqArgs a, const float* __restrict__ rec, const float* __restric
   __syncthreads();
   int* tbl = tbl_all[threadIdx.x >> 6];
 #ifdef XEQ_WQ_ONLY_L   // development: register budget of one role
-  if (un.l == XEQ_WQ_ONLY_L) wq_fwd_role<2 * XEQ_WQ_ONLY_L + 1, KS, XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  if (un.l == XEQ_WQ_ONLY_L) wq_fwd_role<2 * XEQ_WQ_ONLY_L + 1, KS, XZ, !XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
   return;
 #endif
 #ifdef XEQ_WQ_ROLE_TIME_FWD   // development: where and when every workgroup of the production body ran
   unsigned long long rr0_;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rr0_)::"memory");
 #endif
-  if (un.l == 0) wq_fwd_role<1, KS, false>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
-  else if (un.l == 1) wq_fwd_role<3, KS, XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
-  else wq_fwd_role<5, KS, XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  if (un.l == 0) wq_fwd_role<1, KS, false, !XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  else if (un.l == 1) wq_fwd_role<3, KS, XZ, !XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
+  else wq_fwd_role<5, KS, XZ, !XZ>(a, s_beg, s_end, un, rec, h, xhat, s_in, x_in, wl, s_out, x_out, tbl, win);
 #ifdef XEQ_WQ_ROLE_TIME_FWD
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
     unsigned long long rr1_;
@@ -1311,7 +1313,32 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
     for (int g = 0; g < 4; ++g) pend_hm_last[g] = false;
   }
+  // the node gradients of passes S and E are stored at the next tile's top as well (l = 0, 1; the l = 2 role has no registers for it), which
+  // leaves the rows of a tile without a branch: one scheduling region with the matrix chains (OVL below)
+#ifdef XEQ_WQ_NO_DEFER_SE
+  constexpr bool DEFER_SE = false;
+#else
+  constexpr bool DEFER_SE = DEFER && !FIRST && NM <= 3;
+#endif
+  float pend_hs[DEFER_SE ? 4 : 1], pend_he[DEFER_SE ? 4 : 1], pend_gx[DEFER_SE ? 4 : 1][NM];
+  uint32_t pend_own[DEFER_SE ? 4 : 1];
+  bool pend_se_last[DEFER_SE ? 4 : 1];
+  if constexpr (DEFER_SE) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pend_se_last[g] = false;
+  }
   auto flush_parts = [&]() {
+    if constexpr (DEFER_SE) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (pend_se_last[g]) {
+          wq_st(grad_h, pend_own[g] * row_h + wc.b_hs, pend_hs[g]);
+          wq_st(grad_h, pend_own[g] * row_h + wc.b_hs + he_off, pend_he[g]);
+          const uint32_t ox = pend_own[g] * wc.xnode_b + wc.b_x;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) wq_st(grad_xhat, ox + m * wc.xcomp_b, pend_gx[g][m]);
+        }
+    }
     if constexpr (HAS_S && !FIRST) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -1373,11 +1400,25 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
       for (int r = 0; r < 4; ++r) gv[r] = WIN ? wq_lds(win, g0[r] + lgx + 4u * m) : wq_ld(grad_x, g0[r] + wc.b_xe + 4u * m);
     };
+    // The NEXT pass's matrix chains are written in front of THIS pass's rows (round 6).  With the rows free of branches (the node
+    // gradients of a tile are stored at the next tile's top) a pass's rows and the next pass's chains are one scheduling region, and
+    // the compiler places ~7 vector instructions between two matrix instructions instead of issuing eighteen of them back to back: a
+    // wave overlaps its own matrix chains with its own row arithmetic instead of waiting for the SIMD's other wave to do so.
+    // Reverse pair 432 -> 414 us (profiles/r06_small_experiments.txt item 12).  XEQ_WQ_OVERLAP_MAXNM: which roles (default l = 0, 1).
+#ifndef XEQ_WQ_OVERLAP_MAXNM
+#define XEQ_WQ_OVERLAP_MAXNM 3
+#endif
+    constexpr bool OVL = NM <= XEQ_WQ_OVERLAP_MAXNM && (DEFER_SE || (FIRST && HAS_S));
+    f32x16 de_h, qe_h, dm_h, qm_h;
     if constexpr (FIRST && NM > 1) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) pd[v] = 0.f;
     } else {  // ---- pass S
       const f32x16 ds = wq_filter<KS>(R, Ws, lane), qs = wq_filter<KS>(Rd, Ws, lane);
+      if constexpr (OVL) {   // development: the NEXT pass's chains issued in front of this pass's rows (one branch-free region: see OVL)
+        de_h = wq_filter<KS>(R, We, lane);
+        qe_h = wq_filter<KS>(Rd, We, lane);
+      }
       WQ_STAMP(6);   // MFMA issue (all passes)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -1415,7 +1456,13 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
         a_hs = (keep ? a_hs : 0.f) + hsq;
 #pragma unroll
         for (int m = 0; m < NM; ++m) a_x[m] = __builtin_fmaf(o_hs, u[m], keep ? a_x[m] : 0.f);
-        if (last && node_grads) {
+        if constexpr (DEFER_SE) {
+          pend_hs[g] = a_hs;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) pend_gx[g][m] = a_x[m];
+          pend_own[g] = own;
+          pend_se_last[g] = last && node_grads;
+        } else if (last && node_grads) {
           wq_st(grad_h, own * row_h + wc.b_hs, a_hs);
           const uint32_t ox = own * wc.xnode_b + wc.b_x;
 #pragma unroll
@@ -1430,7 +1477,11 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
     const bool keeper = j < 16 && my_q < half_end;                     // one 16-lane row per half stores
     const int64_t my_slot = 4 * (int64_t)my_q + (my_r & 3);
     {  // ---- pass E
-      const f32x16 de = wq_filter<KS>(R, We, lane), qe = wq_filter<KS>(Rd, We, lane);
+      const f32x16 de = OVL ? de_h : wq_filter<KS>(R, We, lane), qe = OVL ? qe_h : wq_filter<KS>(Rd, We, lane);
+      if constexpr (OVL && HAS_S) {
+        dm_h = wq_filter<KS>(R, Wm, lane);
+        qm_h = wq_filter<KS>(Rd, Wm, lane);
+      }
       WQ_STAMP(6);
       float pq[NM > 1 ? NM : 1][4];
 #pragma unroll
@@ -1461,7 +1512,8 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
           pd[v] = __builtin_fmaf(o_he * dge[r], qe[v], pd[v]);
         }
         a_he = (keep ? a_he : 0.f) + heq;
-        if (last && node_grads) wq_st(grad_h, own * row_h + wc.b_hs + he_off, a_he);
+        if constexpr (DEFER_SE) pend_he[g] = a_he;
+        else if (last && node_grads) wq_st(grad_h, own * row_h + wc.b_hs + he_off, a_he);
         if constexpr (NM > 1) XEQ_WQ_RSB();
       }
       if constexpr (NM > 1) {
@@ -1508,7 +1560,7 @@ __device__ __forceinline__ void wq_bwd_body(const WqArgs& a, int range, int unit
 #pragma unroll
         for (int r = 0; r < 4; ++r) gsv[4 * g + r] = WIN ? wq_lds(win, g1[r] + lgs) : wq_ld(grad_s, g1[r] + wc.b_s);
       }
-      const f32x16 dm = wq_filter<KS>(R, Wm, lane), qm = wq_filter<KS>(Rd, Wm, lane);
+      const f32x16 dm = (OVL && HAS_S) ? dm_h : wq_filter<KS>(R, Wm, lane), qm = (OVL && HAS_S) ? qm_h : wq_filter<KS>(Rd, Wm, lane);
       if constexpr (!ROW_EARLY) {
         XEQ_WQ_RSB();
         wq_row<KS, 2, (NM > 1)>(a, st, lane, t + 1, rec, drec, row, (int)gbase);   // last MFMAs issued: next tile's records
