@@ -351,11 +351,18 @@ __device__ __forceinline__ tile_t ld_tile(const float* __restrict__ row, int c0,
 #else
 #define NB_STORE_OK(ok) (ok)
 #endif
+#ifdef XEQ_NB_UNCOND_PINNED   // development: unconditional stores that the scheduler may not move anything across
+#define NB_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define NB_PIN() do { } while (0)
+#endif
 __device__ __forceinline__ void st_tile(float* __restrict__ row, int c0, int h, const tile_t& t, bool ok) {
   if (!NB_STORE_OK(ok)) return;
+  NB_PIN();
 #pragma unroll
   for (int g = 0; g < 2; ++g)
     *reinterpret_cast<float4*>(row + c0 + 16 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+  NB_PIN();
 }
 // a 32-channel tile of a PARAMETER vector (norm weights, biases).  -DXEQ_NB_EXP_NOPARAM (development, timing only, wrong results): no
 // memory access -- what the ~80 small parameter loads of a launch, each requested right in front of its use, cost
@@ -432,6 +439,7 @@ __device__ __forceinline__ void ld_xm(const float* __restrict__ blk, int h, tile
 template <int DL>
 __device__ __forceinline__ void st_xm(float* __restrict__ blk, int h, const tile_t (&X)[DL], bool ok) {
   if (!NB_STORE_OK(ok)) return;
+  NB_PIN();
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     float* p = blk + DL * (16 * g + 4 * h);
@@ -443,6 +451,7 @@ __device__ __forceinline__ void st_xm(float* __restrict__ blk, int h, const tile
 #pragma unroll
     for (int q = 0; q < DL; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(flat[4 * q], flat[4 * q + 1], flat[4 * q + 2], flat[4 * q + 3]);
   }
+  NB_PIN();
 }
 
 __device__ __forceinline__ float sum16(const tile_t& t) { return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])); }
