@@ -308,7 +308,7 @@ int xeq_wgrad(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t n,
 /* A batch of n atoms in g graphs into arrays of n_cap atoms / g_cap graphs in ONE launch (runtime.GraphedStep: neighbour list +
  * model as one captured graph over capacity-sized arrays): atoms n .. n_cap - 1 get atomic number 0, positions
  * (pad0 + spacing (i - n), 0, 0) -- no two within any cutoff -- and sit alone in graph g_cap - 1; graphs g .. g_cap - 2 are empty.
- * ptr [g + 1] / ptr_out [g_cap + 1], batch [n] / batch_out [n_cap] int64. */
+ * ptr [g + 1] / ptr_out [g_cap + 1], batch [n] / batch_out [n_cap] int64; batch may be NULL: an atom's graph is then found in ptr. */
 int xeq_load_padded_batch(int dtype, const void* pos, const int32_t* z, const int64_t* ptr, const int64_t* batch, int64_t n,
                           int64_t g, int64_t n_cap, int64_t g_cap, double pad0, double spacing, void* pos_out, int32_t* z_out,
                           int64_t* ptr_out, int64_t* batch_out, void* stream);

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/xeq.h"
 
@@ -259,6 +260,13 @@ __device__ __forceinline__ void edge_grad(const EdgeGeom<T>& g, T gd, const T* p
 // they come in multiples of the CU count, and the remainder (or everything, for MD-sized systems) is SPLIT: `split` workgroups
 // share a tile, each repeats its cheap first phase and takes every split-th group of output tiles / jobs.
 // Workgroup b < n_full: tile b alone; else tile n_full + (b - n_full) / split, part (b - n_full) % split.
+// Row count up to which the node-side products take their few-row forms (16 x 16 exact-f32 tiles: a quarter of the k-chain per wave,
+// four times the waves; BIT-EQUAL results, see xeq_linear.hip).  XEQ_SMALL_ROWS overrides (0: never; read per call: tests flip it).
+inline int64_t xeq_small_rows() {
+  const char* v = getenv("XEQ_SMALL_ROWS");
+  return v ? atoll(v) : 2048;
+}
+
 struct TileSplit {
   int n_full, split;
   __host__ __device__ unsigned grid(int64_t tiles) const { return (unsigned)(n_full + (tiles - n_full) * split); }

@@ -542,6 +542,125 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))
   }
 }
 
+// ---- few rows (MD-sized systems) ------------------------------------------------------------------------------------------------
+// 16 x 16 exact-f32 tiles (v_mfma_f32_16x16x4_f32): the same fused-multiply-add chain per output element as the 32-row form -- the
+// instruction rounds like a sequential fmaf chain in k order whatever its shape (xeq_linear.hip, scratch/mfma_order) -- so the results
+// are BIT-EQUAL, with a quarter of the chain per wave and four times the waves.  A workgroup of 8 waves owns 16 rows: wave w forms
+// hidden columns [16 w, 16 w + 16) (stage 1: the even / odd accumulators of k_mlp2, one instruction per k-group each, summed at the
+// end), then output tile 8 part + w (stage 2, k_mlp2's single chain); `parts` workgroups share a row tile, each redoing stage 1.
+// Weights from the same packed copies; stage 2's fragments and the first 128 k of stage 1's are requested before anything else.
+constexpr int MLP_S_ROWS = 16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool REVERSE, int NCH>   // NCH: chunks of 16 k-groups (128 k) in stage 1
+__global__ void __launch_bounds__(512) k_mlp2_s(MlpArgs a, int parts) {
+  extern __shared__ __attribute__((aligned(16))) float mlp_s_lds[];
+  const int XLD = a.K1 + 4;
+  float* Xs = mlp_s_lds;                      // [16][K1 + 4]
+  float* Ts = Xs + MLP_S_ROWS * XLD;          // [16][MLP_TLD]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4, kh = kq & 1;
+  const int sel = kq >> 1;
+  const int rt = (int)blockIdx.x / parts, part = (int)blockIdx.x - rt * parts;
+  const int64_t row0 = (int64_t)rt * MLP_S_ROWS;
+  const int rows_here = (int)min((int64_t)MLP_S_ROWS, a.n - row0);
+  const int g1 = a.K1 >> 3;
+  constexpr int G2 = MLP_H / 8, G1 = 16 * NCH;
+  // every weight request first (the chains then wait for memory once): stage 1 whole -- a lane takes the two components of its
+  // float4 it multiplies (x, y: even / odd accumulator of lanes kq < 2; z, w: of lanes kq >= 2) as ONE 8-byte load -- then the
+  // first stage-2 tile
+  const float2* w1 = reinterpret_cast<const float2*>(reinterpret_cast<const float4*>(a.W1p) + (int64_t)(wave >> 1) * (g1 + 1) * 64 +
+                                                     16 * (wave & 1) + i + 32 * kh) + sel;
+  float2 eo[G1];
+#pragma unroll
+  for (int q = 0; q < G1; ++q) eo[q] = w1[(q < g1 ? q : g1 - 1) * 128];
+  const float bias1_a = (a.bias1 && kq == 0) ? reinterpret_cast<const float*>(w1 + (int64_t)g1 * 128)[0] : 0.f;
+  const int nt16 = a.N2 >> 4;
+  int t2 = 8 * part + wave;
+  float wb[G2][2];
+  float bias2_a = 0.f;
+  auto fetch2 = [&](int t) {
+    const int tc = t < nt16 ? t : 0;
+    const float4* w2 = reinterpret_cast<const float4*>(a.W2p) + (int64_t)(tc >> 1) * (G2 + 1) * 64 + 16 * (tc & 1) + i + 32 * kh;
+#pragma unroll
+    for (int q = 0; q < G2; ++q) {
+      const float4 v = w2[q * 64];
+      wb[q][0] = sel ? v.y : v.x;
+      wb[q][1] = sel ? v.w : v.z;
+    }
+    bias2_a = (a.bias2 && kq == 0) ? reinterpret_cast<const float*>(w2 + (int64_t)G2 * 64)[0] : 0.f;
+  };
+  fetch2(t2);
+  const unsigned ic = (unsigned)min(i, rows_here - 1);
+  float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (REVERSE) pv = *reinterpret_cast<const float4*>(a.pre + (row0 + ic) * MLP_H + 16 * wave + 4 * kq);
+  // the rows, whole, into LDS
+  const int k4 = a.K1 >> 2;
+  for (int idx = tid; idx < MLP_S_ROWS * k4; idx += 512) {
+    const int r = idx / k4, c4 = idx - r * k4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows_here) v = *reinterpret_cast<const float4*>(a.X + (row0 + r) * a.ldx + 4 * c4);
+    *reinterpret_cast<float4*>(&Xs[r * XLD + 4 * c4]) = v;
+  }
+  __syncthreads();
+  // ---- stage 1: hidden columns [16 wave, 16 wave + 16)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* xs = &Xs[i * XLD + 4 * kh + 2 * sel];
+#pragma unroll
+  for (int q = 0; q < G1; ++q)
+    if (q < g1) {
+      const float2 xv = *reinterpret_cast<const float2*>(xs + 8 * q);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(eo[q].x, xv.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(eo[q].y, xv.y, acc1, 0, 0, 0);
+    }
+  if (a.bias1) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bias1_a, kq == 0 ? 1.f : 0.f, acc0, 0, 0, 0);
+  {
+    const int col = 16 * wave + 4 * kq;
+    const float4 t = make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+    float4 v;
+    if (!REVERSE) {
+      if (i < rows_here && part == 0) *reinterpret_cast<float4*>(a.pre + (row0 + i) * MLP_H + col) = t;
+      v = make_float4(silu_f(t.x), silu_f(t.y), silu_f(t.z), silu_f(t.w));
+    } else {
+      v = make_float4(t.x * silu_grad_f(pv.x), t.y * silu_grad_f(pv.y), t.z * silu_grad_f(pv.z), t.w * silu_grad_f(pv.w));
+    }
+    *reinterpret_cast<float4*>(&Ts[i * MLP_TLD + col]) = v;
+  }
+  __syncthreads();
+  // ---- stage 2: output tiles 8 part + wave, + 8 parts, ...
+  const float* ts = &Ts[i * MLP_TLD + 4 * kh];
+  for (; t2 < nt16; t2 += 8 * parts) {
+    f32x4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < G2; ++q) {
+      const float4 tv = *reinterpret_cast<const float4*>(ts + 8 * q);
+      y = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[q][0], sel ? tv.y : tv.x, y, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[q][1], sel ? tv.w : tv.z, y, 0, 0, 0);
+    }
+    if (a.bias2) y = __builtin_amdgcn_mfma_f32_16x16x4f32(bias2_a, kq == 0 ? 1.f : 0.f, y, 0, 0, 0);
+    if (i < rows_here) *reinterpret_cast<float4*>(a.Y + (row0 + i) * a.ldy + 16 * t2 + 4 * kq) = make_float4(y[0], y[1], y[2], y[3]);
+    if (t2 + 8 * parts < nt16) fetch2(t2 + 8 * parts);
+  }
+}
+
+constexpr int MLP_S_KMAX = 640;   // five chunks: 160 weight registers in stage 1
+
+template <bool REVERSE>
+static void mlp_launch_small(const MlpArgs& a, hipStream_t stream) {
+  // workgroups per row tile: one output tile per wave while the chip has idle CUs (every workgroup redoes stage 1)
+  const int64_t row_tiles = (a.n + MLP_S_ROWS - 1) / MLP_S_ROWS;
+  const int max_parts = (a.N2 / 16 + 7) / 8;
+  int parts = (int)(256 / row_tiles);
+  parts = parts < 1 ? 1 : (parts > max_parts ? max_parts : parts);
+  const size_t shmem = sizeof(float) * ((size_t)MLP_S_ROWS * (a.K1 + 4) + (size_t)MLP_S_ROWS * MLP_TLD);
+  const dim3 grid((unsigned)row_tiles * (unsigned)parts);
+  const int nch = (a.K1 / 8 + 15) / 16;
+  if (nch <= 1) hipLaunchKernelGGL((k_mlp2_s<REVERSE, 1>), grid, dim3(512), shmem, stream, a, parts);
+  else if (nch <= 3) hipLaunchKernelGGL((k_mlp2_s<REVERSE, 3>), grid, dim3(512), shmem, stream, a, parts);
+  else hipLaunchKernelGGL((k_mlp2_s<REVERSE, 5>), grid, dim3(512), shmem, stream, a, parts);
+}
+
 constexpr int64_t MLP_R64_MIN_ROWS = 64 * 256;   // one full round of 64-row tiles
 // ... and an output wide enough (>= 4 groups of four tiles) that a short last round can be split: measured at 18 k nodes, 64-row
 // against 32-row form: 576 outputs 46.6 / 49.6 us, 480: 56.5 / 56.5, 352: 60.1 / 55.8, 128: 57.5 / 49.3; at 147 k nodes 280 / 332
@@ -608,7 +727,8 @@ int xeq_mlp2_fwd(const float* x, int64_t ldx, int64_t n, int k1, const float* w1
   const bool r64 = mlp_use_r64(n, n2);
   const int64_t tiles = r64 ? (n + 63) / 64 : (n + MLP_ROWS - 1) / MLP_ROWS;
   MlpArgs a{x, ldx, n, k1, n2, w1p, w2p, 1, 1, pre, y, ldy, tile_split(tiles, (n2 / 32 + 3) / 4)};
-  if (r64) hipLaunchKernelGGL(k_mlp2_r64<false>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
+  if (n <= xeq_small_rows() && k1 <= MLP_S_KMAX) mlp_launch_small<false>(a, (hipStream_t)stream);
+  else if (r64) hipLaunchKernelGGL(k_mlp2_r64<false>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_mlp2<false>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_fwd");
   return XEQ_OK;
@@ -622,7 +742,8 @@ int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2
   const bool r64 = mlp_use_r64(n, n2);
   const int64_t tiles = r64 ? (n + 63) / 64 : (n + MLP_ROWS - 1) / MLP_ROWS;
   MlpArgs a{g, ldg, n, k1, n2, w2tp, w1tp, 0, 0, const_cast<float*>(pre), gx, ldgx, tile_split(tiles, (n2 / 32 + 3) / 4)};
-  if (r64) hipLaunchKernelGGL(k_mlp2_r64<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
+  if (n <= xeq_small_rows() && k1 <= MLP_S_KMAX) mlp_launch_small<true>(a, (hipStream_t)stream);
+  else if (r64) hipLaunchKernelGGL(k_mlp2_r64<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_mlp2<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_bwd");
   return XEQ_OK;

@@ -590,7 +590,22 @@ __global__ void k_load_padded_batch(const T* __restrict__ pos, const Z* __restri
     pos_out[3 * i + 1] = real ? pos[3 * i + 1] : T(0);
     pos_out[3 * i + 2] = real ? pos[3 * i + 2] : T(0);
     z_out[i] = real ? (int32_t)z[i] : 0;
-    batch_out[i] = real ? batch[i] - graph0 : G - 1;
+    int64_t b = G - 1;
+    if (real) {
+      if (batch) {
+        b = batch[i] - graph0;
+      } else {   // no graph ids handed over: the graph whose [ptr[k], ptr[k + 1]) holds the atom (empty graphs are skipped: the last k with ptr[k] <= atom)
+        int64_t lo = 0, hi = g;   // invariant: ptr[lo] <= atom < ptr[hi]
+        const int64_t atom = i + atom0;
+        while (hi - lo > 1) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (ptr[mid] <= atom) lo = mid;
+          else hi = mid;
+        }
+        b = lo;
+      }
+    }
+    batch_out[i] = b;
   }
   if (i <= G) ptr_out[i] = i <= g ? ptr[i] - atom0 : (i < G ? n : N);   // graphs g .. G - 2 are empty, graph G - 1 holds the padding atoms
 }

@@ -175,36 +175,19 @@ __device__ __forceinline__ void uv_job(const UvFwdArgs& a, const float* xh, int 
   }
 }
 
-// M0, M1, M2, FF, NORM >= 0: the layout is a compile-time constant (the default model's instantiation: every region test and
-// index division of phase A folds); -1: read from the arguments.
-template <int M0, int M1, int M2, int FF, int NORM>
-__global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float xh[];   // [32][D + 4]: the normalised tile, [node][l][m][channel]
+// phase A of the front half: both norms of a tile of ROWS nodes, 8 lanes per node with the node's row in registers; xhat into LDS as
+// [node][l][m][channel], shat / the statistics to global memory (part 0 only).  One workgroup barrier inside (the staged parameters);
+// the caller places the one behind it.  A node's sums do not depend on ROWS or NT: the 8-lane split of a row is the same.
+template <int M0, int M1, int M2, int FF, int NORM, int ROWS, int NT>
+__device__ __forceinline__ void uv_phase_a(const UvFwdArgs& a, float* xh, const float* lnw, const float* lnb, const float* eqw, const float* eqb,
+                                           int64_t row0, int rows_here, int part_, int tid) {
   const int m0 = M0 >= 0 ? M0 : a.ir.mul[0], m1 = M1 >= 0 ? M1 : a.ir.mul[1], m2 = M2 >= 0 ? M2 : a.ir.mul[2];
   const int F = FF >= 0 ? FF : a.F;
   const bool do_norm = NORM >= 0 ? (NORM != 0) : (a.do_norm != 0);
   const int D = m0 + 3 * m1 + 5 * m2, C = m0 + m1 + m2, XLD = D + 4;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tile_, part_, parts_;
-  a.ts.decode((int)blockIdx.x, tile_, part_, parts_);
-  const int64_t row0 = (int64_t)tile_ * UV_ROWS;
-  const int rows_here = (int)min((int64_t)UV_ROWS, a.n - row0);
-  // norm parameters into LDS first ([ln_w F | ln_b F | eq_w C | eq_b m0], behind the tile): phase A then has ONE round
-  // trip to global memory in its dependency chain (the rows), not three
-  float* prm = xh + UV_ROWS * XLD;
-  float *lnw = prm, *lnb = prm + F, *eqw = prm + 2 * F, *eqb = prm + 2 * F + C;
-  if (do_norm) {
-    for (int f = tid; f < F; f += 256) {
-      lnw[f] = a.lnw[f];
-      lnb[f] = a.lnb[f];
-    }
-    for (int f = tid; f < C; f += 256) eqw[f] = a.eqw[f];
-    for (int f = tid; f < m0; f += 256) eqb[f] = a.eqb[f];
-  }
-
-  {  // ---- phase A: both norms, 8 lanes per node, the node's row in registers
+  {
     const int node = tid >> 3, sub = tid & 7;
+    const bool live = 8 * ROWS >= NT || node < ROWS;   // (a workgroup of more than 8 ROWS threads: the rest only meet the barrier)
     const bool ok = node < rows_here;
     const int64_t gn = row0 + min(node, rows_here - 1);
     const float4* sr = reinterpret_cast<const float4*>(a.s + gn * F);
@@ -225,6 +208,7 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
       xv[k] = make_float4(v ? t.x : 0.f, v ? t.y : 0.f, v ? t.z : 0.f, v ? t.w : 0.f);
     }
     UV_LDS_BARRIER();   // the staged parameters (the row loads above stay in flight across it)
+    if (!live) return;
     float mean = 0.f, rstd = 1.f, mean0 = 0.f, r = 1.f;
     if (do_norm) {
       // nn.LayerNorm over the F scalars (eps 1e-5, biased variance)
@@ -304,7 +288,38 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
       }
     }
     if (ok && sub == 0 && part_ == 0) *reinterpret_cast<float4*>(a.stats + 4 * gn) = make_float4(mean, rstd, mean0, r);
+    }
+}
+
+// M0, M1, M2, FF, NORM >= 0: the layout is a compile-time constant (the default model's instantiation: every region test and
+// index division of phase A folds); -1: read from the arguments.
+template <int M0, int M1, int M2, int FF, int NORM>
+__global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xh[];   // [32][D + 4]: the normalised tile, [node][l][m][channel]
+  const int m0 = M0 >= 0 ? M0 : a.ir.mul[0], m1 = M1 >= 0 ? M1 : a.ir.mul[1], m2 = M2 >= 0 ? M2 : a.ir.mul[2];
+  const int F = FF >= 0 ? FF : a.F;
+  const bool do_norm = NORM >= 0 ? (NORM != 0) : (a.do_norm != 0);
+  const int D = m0 + 3 * m1 + 5 * m2, C = m0 + m1 + m2, XLD = D + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile_, part_, parts_;
+  a.ts.decode((int)blockIdx.x, tile_, part_, parts_);
+  const int64_t row0 = (int64_t)tile_ * UV_ROWS;
+  const int rows_here = (int)min((int64_t)UV_ROWS, a.n - row0);
+  // norm parameters into LDS first ([ln_w F | ln_b F | eq_w C | eq_b m0], behind the tile): phase A then has ONE round
+  // trip to global memory in its dependency chain (the rows), not three
+  float* prm = xh + UV_ROWS * XLD;
+  float *lnw = prm, *lnb = prm + F, *eqw = prm + 2 * F, *eqb = prm + 2 * F + C;
+  if (do_norm) {
+    for (int f = tid; f < F; f += 256) {
+      lnw[f] = a.lnw[f];
+      lnb[f] = a.lnb[f];
+    }
+    for (int f = tid; f < C; f += 256) eqw[f] = a.eqw[f];
+    for (int f = tid; f < m0; f += 256) eqb[f] = a.eqb[f];
   }
+
+  uv_phase_a<M0, M1, M2, FF, NORM, UV_ROWS, 256>(a, xh, lnw, lnb, eqw, eqb, row0, rows_here, part_, tid);
   UV_LDS_BARRIER();
 
   // ---- phase B: the o3.Linear pair on the matrix cores, v and p from the accumulators
@@ -316,6 +331,133 @@ __global__ void __launch_bounds__(256) k_update_uv_fwd(UvFwdArgs a) {
     if (mul == 128) uv_job<16>(a, xh, XLD, l, t, row0, rows_here, lane);
     else if (mul == 64) uv_job<8>(a, xh, XLD, l, t, row0, rows_here, lane);
     else uv_job<4>(a, xh, XLD, l, t, row0, rows_here, lane);
+  }
+}
+
+// ---- few nodes (MD-sized systems): 16-node tiles, 16 x 16 exact-f32 tiles, two workgroups of 8 waves per tile -----------------------
+// v_mfma_f32_16x16x4_f32 fed the k sequence of the 32-row form's instructions rounds to the same bits (a sequential fused-multiply-add
+// chain per output element, whatever the tile shape: xeq_linear.hip, scratch/mfma_order), so this form changes no result: a quarter of
+// the chain per wave, four times the waves.  Phase A as above (threads 0..127 of both workgroups: within 256 registers, which 16 waves
+// in one workgroup are not); phase B: job = (l, 16 output channels), one per wave.
+constexpr int UVS_ROWS = 16, UVS_NT = 512, UVS_PARTS = 2;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct UvJobS {   // one job of the few-node forward form: (l, 16 output channels) and its weight fragments, requested whole
+  int l, t16, mul;
+  float wu[16][2], wv[16][2], bu, bv;
+};
+
+__device__ __forceinline__ void uv_job_s_load(const UvFwdArgs& a, int jj, int m0, int m1, int m2, int lane, UvJobS& j) {
+  const int j0 = m0 >> 4, j1 = m1 >> 4;
+  j.l = jj < j0 ? 0 : (jj < j0 + j1 ? 1 : 2);
+  j.t16 = jj - (j.l == 0 ? 0 : (j.l == 1 ? j0 : j0 + j1));
+  j.mul = j.l == 0 ? m0 : (j.l == 1 ? m1 : m2);
+  const int i = lane & 15, kq = lane >> 4, kh = kq & 1, G = j.mul >> 3;
+  const bool sel = (kq >> 1) != 0;
+  const int lo = 16 * (j.t16 & 1) + i + 32 * kh;   // this lane's slot in a packed 32-column tile
+  const float4* wU = reinterpret_cast<const float4*>(a.wp[j.l]) + (int64_t)(j.t16 >> 1) * (G + 1) * 64 + lo;
+  const float4* wV = reinterpret_cast<const float4*>(a.wp[j.l]) + (int64_t)(j.mul / 32 + (j.t16 >> 1)) * (G + 1) * 64 + lo;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int qc = q < G ? q : G - 1;
+    const float4 u = wU[qc * 64], v = wV[qc * 64];
+    j.wu[q][0] = sel ? u.y : u.x;
+    j.wu[q][1] = sel ? u.w : u.z;
+    j.wv[q][0] = sel ? v.y : v.x;
+    j.wv[q][1] = sel ? v.w : v.z;
+  }
+  j.bu = j.bv = 0.f;
+  if (j.l == 0 && a.has_bias && kq == 0) {
+    j.bu = reinterpret_cast<const float*>(wU + G * 64)[0];
+    j.bv = reinterpret_cast<const float*>(wV + G * 64)[0];
+  }
+}
+
+template <int G>
+__device__ __forceinline__ void uv_job_s_run(const UvFwdArgs& a, const UvJobS& j, const float* xh, int XLD, int64_t row0, int rows_here,
+                                             int lane) {
+  const int i = lane & 15, kq = lane >> 4, kh = kq & 1;
+  const bool sel = (kq >> 1) != 0;
+  const int l = j.l, t16 = j.t16, mul = 8 * G, d = 2 * l + 1;
+  const int m0 = a.ir.mul[0], m1 = a.ir.mul[1];
+  const int base = l == 0 ? 0 : (l == 1 ? m0 : m0 + 3 * m1);
+  const int goff = l == 0 ? 0 : (l == 1 ? m0 : m0 + m1);
+  const bool row_ok = i < rows_here;
+  const bool bias = l == 0 && a.has_bias;
+  const float one_k0 = kq == 0 ? 1.f : 0.f;
+  float* __restrict__ uvb = a.uv + a.n * 2 * base + row0 * d * 2 * mul;
+  f32x4 pacc = {0.f, 0.f, 0.f, 0.f}, vacc = {0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < d; ++m) {
+    f32x4 U = {0.f, 0.f, 0.f, 0.f}, V = {0.f, 0.f, 0.f, 0.f};
+    const float* xs = xh + i * XLD + base + m * mul + 4 * kh;
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const float4 xv = *reinterpret_cast<const float4*>(xs + 8 * q);
+      const float b0 = sel ? xv.y : xv.x, b1 = sel ? xv.w : xv.z;
+      U = __builtin_amdgcn_mfma_f32_16x16x4f32(j.wu[q][0], b0, U, 0, 0, 0);
+      V = __builtin_amdgcn_mfma_f32_16x16x4f32(j.wv[q][0], b0, V, 0, 0, 0);
+      U = __builtin_amdgcn_mfma_f32_16x16x4f32(j.wu[q][1], b1, U, 0, 0, 0);
+      V = __builtin_amdgcn_mfma_f32_16x16x4f32(j.wv[q][1], b1, V, 0, 0, 0);
+    }
+    if (bias) {
+      U = __builtin_amdgcn_mfma_f32_16x16x4f32(j.bu, one_k0, U, 0, 0, 0);
+      V = __builtin_amdgcn_mfma_f32_16x16x4f32(j.bv, one_k0, V, 0, 0, 0);
+    }
+    if (row_ok) {
+      const unsigned o = (unsigned)(i * d + m) * (unsigned)(2 * mul) + (unsigned)(16 * t16 + 4 * kq);
+      *reinterpret_cast<float4*>(uvb + o) = make_float4(U[0], U[1], U[2], U[3]);
+      *reinterpret_cast<float4*>(uvb + o + (unsigned)mul) = make_float4(V[0], V[1], V[2], V[3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pacc[r] = __builtin_fmaf(U[r], V[r], pacc[r]);
+      vacc[r] = __builtin_fmaf(V[r], V[r], vacc[r]);
+    }
+  }
+  if (row_ok) {
+    const float e = a.eps, e2 = a.eps * a.eps;
+    const int64_t row = row0 + i;
+    *reinterpret_cast<float4*>(a.cat + row * a.ld_cat + a.F + goff + 16 * t16 + 4 * kq) =
+        make_float4(sqrtf(vacc[0] + e2) - e, sqrtf(vacc[1] + e2) - e, sqrtf(vacc[2] + e2) - e, sqrtf(vacc[3] + e2) - e);
+    *reinterpret_cast<float4*>(a.p + row * a.ir.C() + goff + 16 * t16 + 4 * kq) = make_float4(pacc[0], pacc[1], pacc[2], pacc[3]);
+  }
+}
+
+template <int M0, int M1, int M2, int FF, int NORM>
+__global__ void __launch_bounds__(UVS_NT) k_update_uv_fwd_s(UvFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xh[];   // [16][D + 4], then the norm parameters
+  const int m0 = M0 >= 0 ? M0 : a.ir.mul[0], m1 = M1 >= 0 ? M1 : a.ir.mul[1], m2 = M2 >= 0 ? M2 : a.ir.mul[2];
+  const int F = FF >= 0 ? FF : a.F;
+  const bool do_norm = NORM >= 0 ? (NORM != 0) : (a.do_norm != 0);
+  const int D = m0 + 3 * m1 + 5 * m2, C = m0 + m1 + m2, XLD = D + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int part = (int)blockIdx.x % UVS_PARTS;
+  const int64_t row0 = (int64_t)(blockIdx.x / UVS_PARTS) * UVS_ROWS;
+  const int rows_here = (int)min((int64_t)UVS_ROWS, a.n - row0);
+  // one job per wave of the tile's two workgroups (16 slots for (m0 + m1 + m2) / 16 jobs; more: further rounds); the first job's
+  // weights are requested before anything else, so the chain waits for memory once
+  const int n_jobs = (m0 + m1 + m2) >> 4;
+  int jj = UVS_PARTS * wave + part;
+  UvJobS job;
+  if (jj < n_jobs) uv_job_s_load(a, jj, m0, m1, m2, lane, job);
+  float* prm = xh + UVS_ROWS * XLD;
+  float *lnw = prm, *lnb = prm + F, *eqw = prm + 2 * F, *eqb = prm + 2 * F + C;
+  if (do_norm) {
+    for (int f = tid; f < F; f += UVS_NT) {
+      lnw[f] = a.lnw[f];
+      lnb[f] = a.lnb[f];
+    }
+    for (int f = tid; f < C; f += UVS_NT) eqw[f] = a.eqw[f];
+    for (int f = tid; f < m0; f += UVS_NT) eqb[f] = a.eqb[f];
+  }
+  uv_phase_a<M0, M1, M2, FF, NORM, UVS_ROWS, UVS_NT>(a, xh, lnw, lnb, eqw, eqb, row0, rows_here, part, tid);
+  UV_LDS_BARRIER();
+  for (; jj < n_jobs; jj += UVS_PARTS * UVS_NT / 64) {
+    if (job.mul == 128) uv_job_s_run<16>(a, job, xh, XLD, row0, rows_here, lane);
+    else if (job.mul == 64) uv_job_s_run<8>(a, job, xh, XLD, row0, rows_here, lane);
+    else uv_job_s_run<4>(a, job, xh, XLD, row0, rows_here, lane);
+    if (jj + UVS_PARTS * UVS_NT / 64 < n_jobs) uv_job_s_load(a, jj + UVS_PARTS * UVS_NT / 64, m0, m1, m2, lane, job);
   }
 }
 
@@ -340,12 +482,12 @@ struct UvBwdArgs {
 };
 
 // phase 1 of block L (D_L = 2L+1 components, channels in quads): [g_U | g_V] rows into bf[node][m][2 mul]
-template <int D_L>
+template <int D_L, int ROWS = UV_ROWS, int NT = 256>
 __device__ __forceinline__ void uvb_form(const UvBwdArgs& a, float* bf, int BLD, int mul, int base, int goff, int F, int Dtot,
                                          int64_t row0, int rows_here, int tid) {
-  const int quads = mul >> 2, items = UV_ROWS * quads;
+  const int quads = mul >> 2, items = ROWS * quads;
   const float e2 = a.eps * a.eps;
-  for (int it = tid; it < items; it += 256) {
+  for (int it = tid; it < items; it += NT) {
     const int node = it / quads, ch = 4 * (it - node * quads);
     const bool ok = node < rows_here;
     const int64_t gn = row0 + min(node, rows_here - 1);
@@ -613,6 +755,95 @@ __global__ void __launch_bounds__(256) k_update_uv_bwd(UvBwdArgs a) {
   }
 }
 
+// ---- few nodes: the split reverse form (dL/dxhat out, the norms' reverse left to xeq_norm_bwd) on 16-node tiles ------------------------
+// Bit-equal to the 32-row form (see k_update_uv_fwd_s).  The [g_U | g_V] rows of ALL three blocks are formed at once (one round trip to
+// global memory, one barrier: 16 rows x 960 floats of LDS for the default layout), then every (l, m, 16 k) product is a job: 30 for the
+// default layout, dealt heaviest first to the 16 waves of the tile's two workgroups, the weight fragments of a job requested whole.
+struct UvbJobS {   // one job of the few-node reverse form: (l, m, 16 k) and its weight fragments (even | odd accumulator), requested whole
+  int l, m, t16, mul;
+  float2 w[32];
+};
+
+__device__ __forceinline__ void uvb_job_s_load(const UvBwdArgs& a, int jj, int m0, int m1, int m2, int lane, UvbJobS& j) {
+  const int j0 = m0 >> 4, j1 = 3 * (m1 >> 4);
+  j.l = jj < j0 ? 0 : (jj < j0 + j1 ? 1 : 2);
+  const int r = jj - (j.l == 0 ? 0 : (j.l == 1 ? j0 : j0 + j1));
+  j.mul = j.l == 0 ? m0 : (j.l == 1 ? m1 : m2);
+  const int T = j.mul >> 4;
+  j.m = r / T;
+  j.t16 = r - j.m * T;
+  const int i = lane & 15, kq = lane >> 4, kh = kq & 1, sel = kq >> 1, G = j.mul >> 2;   // k = 2 mul: G groups of 8
+  const float2* wT = reinterpret_cast<const float2*>(reinterpret_cast<const float4*>(a.wt[j.l]) + (int64_t)(j.t16 >> 1) * (G + 1) * 64 +
+                                                     16 * (j.t16 & 1) + i + 32 * kh) + sel;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) j.w[q] = wT[(q < G ? q : G - 1) * 128];
+}
+
+template <int G>
+__device__ __forceinline__ void uvb_job_s_run(const UvBwdArgs& a, const UvbJobS& j, const float* bf, int BLD, int base, int lane,
+                                              int64_t row0, int rows_here) {
+  const int i = lane & 15, kq = lane >> 4, kh = kq & 1, sel = kq >> 1;
+  const int d = 2 * j.l + 1, mul = 4 * G;   // G groups of 8 over k = 2 mul
+  const float* bs = bf + i * BLD + j.m * 2 * mul + 4 * kh + 2 * sel;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    const float2 xv = *reinterpret_cast<const float2*>(bs + 8 * q);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(j.w[q].x, xv.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(j.w[q].y, xv.y, acc1, 0, 0, 0);
+  }
+  if (i < rows_here)
+    *reinterpret_cast<float4*>(a.g_xhat + a.n * base + ((row0 + i) * d + j.m) * mul + 16 * j.t16 + 4 * kq) =
+        make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+}
+
+template <int M0, int M1, int M2, int FF>
+__global__ void __launch_bounds__(UVS_NT) k_update_uv_bwd_s(UvBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int m0 = M0 >= 0 ? M0 : a.ir.mul[0], m1 = M1 >= 0 ? M1 : a.ir.mul[1], m2 = M2 >= 0 ? M2 : a.ir.mul[2];
+  const int F = FF >= 0 ? FF : a.F;
+  const int D = m0 + 3 * m1 + 5 * m2;
+  const int BLD0 = 2 * m0 + 4, BLD1 = 6 * m1 + 4, BLD2 = 10 * m2 + 4;
+  float* bf0 = lds;
+  float* bf1 = bf0 + UVS_ROWS * BLD0;
+  float* bf2 = bf1 + UVS_ROWS * BLD1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int part = (int)blockIdx.x % UVS_PARTS;
+  const int64_t row0 = (int64_t)(blockIdx.x / UVS_PARTS) * UVS_ROWS;
+  const int rows_here = (int)min((int64_t)UVS_ROWS, a.n - row0);
+  // jobs (l, m, t16), heaviest block first, one per wave of the tile's two workgroups and round; the weights of a wave's first two
+  // jobs are requested before the rows are formed
+  constexpr int STEP = UVS_PARTS * UVS_NT / 64;
+  const int n_jobs = (m0 >> 4) + 3 * (m1 >> 4) + 5 * (m2 >> 4);
+  int jj = UVS_PARTS * wave + part;
+  UvbJobS ja, jb;
+  if (jj < n_jobs) uvb_job_s_load(a, jj, m0, m1, m2, lane, ja);
+  constexpr bool AHEAD2 = M0 >= 0;   // (the layout-generic instantiation has no registers for a second set)
+  if (AHEAD2 && jj + STEP < n_jobs) uvb_job_s_load(a, jj + STEP, m0, m1, m2, lane, jb);
+  if (m0 > 0) uvb_form<1, UVS_ROWS, UVS_NT>(a, bf0, BLD0, m0, 0, 0, F, D, row0, rows_here, tid);
+  if (m1 > 0) uvb_form<3, UVS_ROWS, UVS_NT>(a, bf1, BLD1, m1, m0, m0, F, D, row0, rows_here, tid);
+  if (m2 > 0) uvb_form<5, UVS_ROWS, UVS_NT>(a, bf2, BLD2, m2, m0 + 3 * m1, m0 + m1, F, D, row0, rows_here, tid);
+  UV_LDS_BARRIER();
+  auto run = [&](const UvbJobS& j) {
+    const float* bf = j.l == 0 ? bf0 : (j.l == 1 ? bf1 : bf2);
+    const int BLD = j.l == 0 ? BLD0 : (j.l == 1 ? BLD1 : BLD2);
+    const int base = j.l == 0 ? 0 : (j.l == 1 ? m0 : m0 + 3 * m1);
+    if (j.mul == 128) uvb_job_s_run<32>(a, j, bf, BLD, base, lane, row0, rows_here);
+    else if (j.mul == 64) uvb_job_s_run<16>(a, j, bf, BLD, base, lane, row0, rows_here);
+    else uvb_job_s_run<8>(a, j, bf, BLD, base, lane, row0, rows_here);
+  };
+  for (; jj < n_jobs; jj += 2 * STEP) {
+    run(ja);
+    if (jj + 2 * STEP < n_jobs) uvb_job_s_load(a, jj + 2 * STEP, m0, m1, m2, lane, ja);
+    if (jj + STEP < n_jobs) {
+      if (!AHEAD2) uvb_job_s_load(a, jj + STEP, m0, m1, m2, lane, jb);
+      run(jb);
+      if (AHEAD2 && jj + 3 * STEP < n_jobs) uvb_job_s_load(a, jj + 3 * STEP, m0, m1, m2, lane, jb);
+    }
+  }
+}
+
 static bool uv_shape_ok(int node_dim, const Irreps& ir) {
   for (int l = 0; l < 3; ++l)
     if (!(ir.mul[l] == 0 || ir.mul[l] == 32 || ir.mul[l] == 64 || ir.mul[l] == 128)) return false;
@@ -668,7 +899,13 @@ int xeq_update_uv_fwd(const float* s, const float* x, const float* ln_w, const f
   const int64_t tiles = (n + UV_ROWS - 1) / UV_ROWS;
   a.ts = tile_split(tiles, a.n_jobs);
   const dim3 grid(a.ts.grid(tiles));
-  if (mul[0] == 128 && mul[1] == 64 && mul[2] == 32 && node_dim == 128 && do_norm)   // the default model (nn/model.py: 128x0e + 64x1o + 32x2e)
+  const bool dflt = mul[0] == 128 && mul[1] == 64 && mul[2] == 32 && node_dim == 128 && do_norm;   // the default model (nn/model.py: 128x0e + 64x1o + 32x2e)
+  if (n <= xeq_small_rows()) {   // few nodes: 16-node tiles, 16 waves each (bit-equal results)
+    const size_t lds_s = ((size_t)UVS_ROWS * (ir.D() + 4) + 2 * node_dim + ir.C() + mul[0]) * sizeof(float);
+    const dim3 grid_s((unsigned)((n + UVS_ROWS - 1) / UVS_ROWS) * UVS_PARTS);
+    if (dflt) hipLaunchKernelGGL((k_update_uv_fwd_s<128, 64, 32, 128, 1>), grid_s, dim3(UVS_NT), lds_s, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_update_uv_fwd_s<-1, -1, -1, -1, -1>), grid_s, dim3(UVS_NT), lds_s, (hipStream_t)stream, a);
+  } else if (dflt)
     hipLaunchKernelGGL((k_update_uv_fwd<128, 64, 32, 128, 1>), grid, dim3(256), lds, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((k_update_uv_fwd<-1, -1, -1, -1, -1>), grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -719,7 +956,14 @@ int xeq_update_uv_bwd(const float* uv_bt, const float* g_p, const float* g_cat, 
   });
   XEQ_CHECK_ARG(attr_err == hipSuccess, "xeq_update_uv_bwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr_err));
   const bool dflt = mul[0] == 128 && mul[1] == 64 && mul[2] == 32 && node_dim == 128 && do_norm;
-  if (fuse) {
+  const size_t lds_s = (size_t)UVS_ROWS * (2 * mul[0] + 6 * mul[1] + 10 * mul[2] + 12) * sizeof(float);
+  if (!fuse && n <= xeq_small_rows() && lds_s <= 64 * 1024) {   // few nodes: 16-node tiles, 16 waves each (bit-equal results)
+    const dim3 grid_s((unsigned)((n + UVS_ROWS - 1) / UVS_ROWS) * UVS_PARTS);
+    if (mul[0] == 128 && mul[1] == 64 && mul[2] == 32 && node_dim == 128)
+      hipLaunchKernelGGL((k_update_uv_bwd_s<128, 64, 32, 128>), grid_s, dim3(UVS_NT), lds_s, (hipStream_t)stream, b);
+    else
+      hipLaunchKernelGGL((k_update_uv_bwd_s<-1, -1, -1, -1>), grid_s, dim3(UVS_NT), lds_s, (hipStream_t)stream, b);
+  } else if (fuse) {
     if (dflt) hipLaunchKernelGGL((k_update_uv_bwd<128, 64, 32, 128, 1, true>), grid, dim3(256), lds, (hipStream_t)stream, b);
     else hipLaunchKernelGGL((k_update_uv_bwd<-1, -1, -1, -1, -1, true>), grid, dim3(256), lds, (hipStream_t)stream, b);
   } else {

@@ -332,13 +332,10 @@ class GraphedStep:
         n, g = int(pos.shape[0]), int(ptr.numel() - 1)
         if n > self.n_atoms or g > self.n_graphs - 1:
             raise ValueError(f"GraphedStep: batch of {n} atoms / {g} graphs exceeds the capacity {self.n_atoms} / {self.n_graphs - 1}")
-        if batch is None:
-            counts = ptr[1:] - ptr[:-1]
-            batch = torch.repeat_interleave(torch.arange(g, device=ptr.device), counts, output_size=n)
-        pos_c = pos.detach().to(self.pos.dtype).contiguous()
+        pos_c = pos.detach().to(self.pos.dtype).contiguous()   # (batch None: the load kernel finds an atom's graph in ptr itself -- no launches here)
         z64 = atomic_numbers.dtype == torch.int64     # (a torch.long tensor is read as it is: no conversion launch per step)
         z_c = atomic_numbers.contiguous() if z64 else atomic_numbers.to(torch.int32).contiguous()
-        ptr_c, batch_c = ptr.to(torch.int64).contiguous(), batch.to(torch.int64).contiguous()
+        ptr_c, batch_c = ptr.to(torch.int64).contiguous(), (None if batch is None else batch.to(torch.int64).contiguous())
         call("xeq_load_padded_batch_z64" if z64 else "xeq_load_padded_batch", dtype_code(pos_c), p_(pos_c), p_(z_c), p_(ptr_c), p_(batch_c), n, g, self.n_atoms, self.n_graphs,
              1.0e4, self.PAD_SPACING, p_(self.pos), p_(self.z), p_(self.ptr), p_(self.batch), stream())
 
