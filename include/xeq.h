@@ -676,6 +676,13 @@ int xeq_mlp2_fwd(const float* x, int64_t ldx, int64_t n, int k1, const float* w1
 /* gx[n, n2] = ((g[n, k1] W2) * silu'(pre)) W1 with k1 = the forward's n2 and n2 = the forward's k1. */
 int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2t_packed, const float* pre,
                  const float* w1t_packed, int n2, float* gx, int64_t ldgx, void* stream);
+/* XPainnUpdate's two independent products side by side (reference nn/xpainn.py:219-223: a = update_mlp([shat | v]) and dot_lin(<U, V>);
+ * reverse = 1: their input gradients): xeq_mlp2_fwd (reverse: xeq_mlp2_bwd with stage1_packed = w2t_packed, stage2_packed = w1t_packed)
+ * and xeq_linear_fwd without bias / activation / row gather on the same n rows.  One launch when n takes the few-row forms
+ * (XEQ_SMALL_ROWS, csrc/xeq_common.h), else the two launches in this order.  The same bits as the separate entry points. */
+int xeq_mlp2_and_linear(int reverse, const float* x, int64_t ldx, int64_t n, int k1, const float* stage1_packed, const float* stage2_packed,
+                        int n2, float* pre, float* y, int64_t ldy, const float* lin_x, int64_t lin_ldx, int lin_k,
+                        const float* lin_w_packed, int lin_n_out, float* lin_y, int64_t lin_ldy, void* stream);
 
 /* ---- first half of XPainnUpdate.forward in one launch (f32; mul_l in {0, 32, 64, 128}, node_dim <= 128, D <= 504) -------
  * nn.LayerNorm(s) and EquivariantLayerNorm(x) (nn/xpainn.py:208-209), U = update_U(xhat), V = update_V(xhat) (o3.Linear,

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "libxeq_hip.so")
 SOURCES = ["xeq_graph.hip", "xeq_ops.hip", "xeq_message.hip", "xeq_message_sb.hip", "xeq_message_wq.hip", "xeq_message_wq_bwd.hip", "xeq_node.hip", "xeq_mlp.hip", "xeq_linear.hip", "xeq_update.hip", "xeq_nodeblock.hip", "xeq_tp.hip", "xeq_train.hip", "xeq_train_node.hip"]
-HEADERS = ["xeq_common.h", os.path.join("..", "..", "include", "xeq.h")]
+HEADERS = ["xeq_common.h", "xeq_linear_s.h", os.path.join("..", "..", "include", "xeq.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 # per-source extras.  The matrix-core message kernels: LLVM's max-ILP machine scheduler instead of the default (measured in round 1 on
 # their predecessor: reverse launch 573 -> 544 us, same VGPR budgets).

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "xeq_common.h"
+#include "xeq_linear_s.h"
 
 namespace xeq {
 
@@ -550,19 +551,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))
 // end), then output tile 8 part + w (stage 2, k_mlp2's single chain); `parts` workgroups share a row tile, each redoing stage 1.
 // Weights from the same packed copies; stage 2's fragments and the first 128 k of stage 1's are requested before anything else.
 constexpr int MLP_S_ROWS = 16;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <bool REVERSE, int NCH>   // NCH: chunks of 16 k-groups (128 k) in stage 1
-__global__ void __launch_bounds__(512) k_mlp2_s(MlpArgs a, int parts) {
-  extern __shared__ __attribute__((aligned(16))) float mlp_s_lds[];
+__device__ __forceinline__ void mlp2_s_body(const MlpArgs& a, int parts, float* mlp_s_lds, int block, int tid) {
   const int XLD = a.K1 + 4;
   float* Xs = mlp_s_lds;                      // [16][K1 + 4]
   float* Ts = Xs + MLP_S_ROWS * XLD;          // [16][MLP_TLD]
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kq = lane >> 4, kh = kq & 1;
   const int sel = kq >> 1;
-  const int rt = (int)blockIdx.x / parts, part = (int)blockIdx.x - rt * parts;
+  const int rt = block / parts, part = block - rt * parts;
   const int64_t row0 = (int64_t)rt * MLP_S_ROWS;
   const int rows_here = (int)min((int64_t)MLP_S_ROWS, a.n - row0);
   const int g1 = a.K1 >> 3;
@@ -644,18 +643,45 @@ __global__ void __launch_bounds__(512) k_mlp2_s(MlpArgs a, int parts) {
   }
 }
 
+template <bool REVERSE, int NCH>
+__global__ void __launch_bounds__(512) k_mlp2_s(MlpArgs a, int parts) {
+  extern __shared__ __attribute__((aligned(16))) float mlp_s_lds[];
+  mlp2_s_body<REVERSE, NCH>(a, parts, mlp_s_lds, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+// Two INDEPENDENT products of a node block in one launch (a captured MD-sized step pays ~5 us per launch whatever it does): the first
+// n_mlp workgroups are k_mlp2_s, the rest k_linear_s with eight waves.  XPainnUpdate.forward: a = update_mlp([shat | v]) beside
+// <U, V> -> dot_lin (nn/xpainn.py:219-223); its reverse: dL/d[shat | v] beside dL/dp.  Each half computes what its own launch would.
+template <bool REVERSE, int NCH>
+__global__ void __launch_bounds__(512) k_mlp2_linear_s(MlpArgs a, int parts, int n_mlp, LinArgs b) {
+  extern __shared__ __attribute__((aligned(16))) float mlp_s_lds[];
+  if ((int)blockIdx.x < n_mlp) mlp2_s_body<REVERSE, NCH>(a, parts, mlp_s_lds, (int)blockIdx.x, (int)threadIdx.x);
+  else linear_s_body<8>(b, mlp_s_lds, (int)blockIdx.x - n_mlp, (int)threadIdx.x);
+}
+
 constexpr int MLP_S_KMAX = 640;   // five chunks: 160 weight registers in stage 1
 
 template <bool REVERSE>
-static void mlp_launch_small(const MlpArgs& a, hipStream_t stream) {
+static void mlp_launch_small(const MlpArgs& a, hipStream_t stream, const LinArgs* lin = nullptr) {
   // workgroups per row tile: one output tile per wave while the chip has idle CUs (every workgroup redoes stage 1)
   const int64_t row_tiles = (a.n + MLP_S_ROWS - 1) / MLP_S_ROWS;
   const int max_parts = (a.N2 / 16 + 7) / 8;
   int parts = (int)(256 / row_tiles);
   parts = parts < 1 ? 1 : (parts > max_parts ? max_parts : parts);
-  const size_t shmem = sizeof(float) * ((size_t)MLP_S_ROWS * (a.K1 + 4) + (size_t)MLP_S_ROWS * MLP_TLD);
-  const dim3 grid((unsigned)row_tiles * (unsigned)parts);
+  size_t shmem = sizeof(float) * ((size_t)MLP_S_ROWS * (a.K1 + 4) + (size_t)MLP_S_ROWS * MLP_TLD);
+  const int n_mlp = (int)row_tiles * parts;
   const int nch = (a.K1 / 8 + 15) / 16;
+  if (lin) {
+    const size_t lin_shmem = sizeof(float) * (size_t)LIN_S_ROWS * LIN_XLD;
+    if (lin_shmem > shmem) shmem = lin_shmem;
+    const int n_lin = (int)((lin->n + LIN_S_ROWS - 1) / LIN_S_ROWS) * ((lin->n_out + 127) / 128);
+    const dim3 grid((unsigned)(n_mlp + n_lin));
+    if (nch <= 1) hipLaunchKernelGGL((k_mlp2_linear_s<REVERSE, 1>), grid, dim3(512), shmem, stream, a, parts, n_mlp, *lin);
+    else if (nch <= 3) hipLaunchKernelGGL((k_mlp2_linear_s<REVERSE, 3>), grid, dim3(512), shmem, stream, a, parts, n_mlp, *lin);
+    else hipLaunchKernelGGL((k_mlp2_linear_s<REVERSE, 5>), grid, dim3(512), shmem, stream, a, parts, n_mlp, *lin);
+    return;
+  }
+  const dim3 grid((unsigned)n_mlp);
   if (nch <= 1) hipLaunchKernelGGL((k_mlp2_s<REVERSE, 1>), grid, dim3(512), shmem, stream, a, parts);
   else if (nch <= 3) hipLaunchKernelGGL((k_mlp2_s<REVERSE, 3>), grid, dim3(512), shmem, stream, a, parts);
   else hipLaunchKernelGGL((k_mlp2_s<REVERSE, 5>), grid, dim3(512), shmem, stream, a, parts);
@@ -746,6 +772,30 @@ int xeq_mlp2_bwd(const float* g, int64_t ldg, int64_t n, int k1, const float* w2
   else if (r64) hipLaunchKernelGGL(k_mlp2_r64<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_mlp2<true>, dim3(a.ts.grid(tiles)), dim3(256), 0, (hipStream_t)stream, a);
   XEQ_CHECK_LAUNCH("xeq_mlp2_bwd");
+  return XEQ_OK;
+}
+
+/* XPainnUpdate's two independent products side by side (nn/xpainn.py:219-223 and their reverse): the two-layer MLP of xeq_mlp2_fwd /
+ * _bwd and the single linear layer of xeq_linear_fwd (no bias, no activation, no row gather) -- ONE launch when the rows take the
+ * few-row forms, else the two launches one after the other.  Results are those of the separate entry points bit for bit. */
+int xeq_mlp2_and_linear(int reverse, const float* x, int64_t ldx, int64_t n, int k1, const float* w1p, const float* w2p, int n2, float* pre,
+                        float* y, int64_t ldy, const float* lin_x, int64_t lin_ldx, int lin_k, const float* lin_wp, int lin_n_out,
+                        float* lin_y, int64_t lin_ldy, void* stream) {
+  const bool one = n > 0 && n <= xeq_small_rows() && k1 <= MLP_S_KMAX && xeq_linear_supported(XEQ_F32, lin_k, lin_n_out) &&
+                   lin_ldx % 4 == 0 && lin_ldy % 4 == 0 && lin_ldx >= lin_k && lin_ldy >= lin_n_out && lin_x && lin_wp && lin_y;
+  if (!one) {
+    const int rc = reverse ? xeq_mlp2_bwd(x, ldx, n, k1, w1p, pre, w2p, n2, y, ldy, stream)
+                           : xeq_mlp2_fwd(x, ldx, n, k1, w1p, w2p, n2, pre, y, ldy, stream);
+    if (rc != XEQ_OK) return rc;
+    return xeq_linear_fwd(lin_x, lin_ldx, n, lin_k, nullptr, lin_wp, lin_n_out, 0, 0, nullptr, lin_y, lin_ldy, stream);
+  }
+  if (int rc = mlp_check("xeq_mlp2_and_linear", n, k1, n2, ldx, ldy)) return rc;
+  XEQ_CHECK_ARG(x && w1p && w2p && pre && y, "xeq_mlp2_and_linear: null buffer");
+  MlpArgs a{x, ldx, n, k1, n2, w1p, w2p, reverse ? 0 : 1, reverse ? 0 : 1, pre, y, ldy, tile_split(1, 1)};
+  LinArgs b{lin_x, nullptr, lin_ldx, n, lin_k, lin_n_out, lin_wp, 0, 0, nullptr, lin_y, lin_ldy};
+  if (reverse) mlp_launch_small<true>(a, (hipStream_t)stream, &b);
+  else mlp_launch_small<false>(a, (hipStream_t)stream, &b);
+  XEQ_CHECK_LAUNCH("xeq_mlp2_and_linear");
   return XEQ_OK;
 }
 

@@ -235,6 +235,45 @@ Tensor linear_bwd(const Tensor& g_in, const Tensor& w, const Tensor& b) {   // d
   return gx;
 }
 
+// XPainnUpdate's two independent products side by side (xeq_mlp2_and_linear: one launch for MD-sized systems);
+// nn/fused.py::mlp_and_linear_fwd / _bwd are the Python twins.
+void mlp_and_linear_fwd(const Tensor& x, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2, const Tensor& p, const Tensor& wl,
+                        Tensor& pre, Tensor& y, Tensor& ip) {
+  const MlpPacks* pk = (x.stride(1) == 1 && x.stride(0) % 4 == 0) ? mlp_packs(w1, b1, w2, b2) : nullptr;
+  const LinPack* lp = (p.dim() == 2 && p.stride(1) == 1 && p.stride(0) % 4 == 0) ? lin_pack(wl, Tensor()) : nullptr;
+  if (!pk || !lp) {
+    mlp_fwd(x, w1, b1, w2, b2, pre, y);
+    ip = linear_fwd(p, wl, Tensor());
+    return;
+  }
+  const int64_t n = x.size(0);
+  pre = at::empty({n, w1.size(0)}, x.options());
+  y = at::empty({n, w2.size(0)}, x.options());
+  ip = at::empty({n, wl.size(0)}, x.options());
+  XCALL(xeq_mlp2_and_linear(0, (const float*)x.data_ptr(), x.stride(0), n, (int)w1.size(1), (const float*)pk->w1p.data_ptr(),
+                            (const float*)pk->w2p.data_ptr(), (int)w2.size(0), (float*)pre.data_ptr(), (float*)y.data_ptr(), w2.size(0),
+                            (const float*)p.data_ptr(), p.stride(0), (int)wl.size(1), (const float*)lp->fwd.data_ptr(), (int)wl.size(0),
+                            (float*)ip.data_ptr(), wl.size(0), cur_stream()));
+}
+void mlp_and_linear_bwd(const Tensor& g_y, const Tensor& pre, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2,
+                        const Tensor& g_lin_in, const Tensor& wl, Tensor& g_x, Tensor& g_p) {
+  const MlpPacks* pk = mlp_packs(w1, b1, w2, b2);
+  const LinPack* lp = lin_pack(wl, Tensor());
+  if (!pk || !lp || !lp->bwd.defined()) {
+    g_p = linear_bwd(g_lin_in, wl, Tensor());
+    g_x = mlp_bwd(g_y, pre, w1, b1, w2, b2);
+    return;
+  }
+  const Tensor g = g_y.contiguous(), gl = g_lin_in.contiguous();
+  const int64_t n = g.size(0);
+  g_x = at::empty({n, w1.size(1)}, g.options());
+  g_p = at::empty({n, wl.size(1)}, g.options());
+  XCALL(xeq_mlp2_and_linear(1, (const float*)g.data_ptr(), g.size(1), n, (int)g.size(1), (const float*)pk->w2tp.data_ptr(),
+                            (const float*)pk->w1tp.data_ptr(), (int)w1.size(1), (float*)pre.data_ptr(), (float*)g_x.data_ptr(), w1.size(1),
+                            (const float*)gl.data_ptr(), gl.stride(0), (int)wl.size(0), (const float*)lp->bwd.data_ptr(), (int)wl.size(1),
+                            (float*)g_p.data_ptr(), wl.size(1), cur_stream()));
+}
+
 // [W_U | W_V] / sqrt(mul) blocks (prm layout: one [mul, 2 mul] tensor per l, empty when absent) in fragment order for
 // xeq_update_uv_fwd; nn/fused.py::_packed_uv_frag is the Python twin.  Cached per weight tensor like the MLP packs.
 struct UvFrag {
@@ -789,8 +828,7 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         }
         XCALL(xeq_uv_reduce_fwd(dt, u.uv.data_ptr(), N, mul, hy.inv_eps, cat.data_ptr(), F + C, F, p.data_ptr(), st));
       }
-      mlp_fwd(cat, q[15], q[16], q[17], q[18], u.pre, u.a);
-      u.ip = linear_fwd(p, q[14], Tensor());
+      mlp_and_linear_fwd(cat, q[15], q[16], q[17], q[18], p, q[14], u.pre, u.a, u.ip);
       const bool last = b == hy.blocks - 1;   // the energy head reads the scalars only: the last equivariant output has no consumer
       Tensor s_out = at::empty_like(s), x_out = last ? Tensor() : at::empty_like(x);
       XCALL(xeq_update_out_fwd(dt, s.data_ptr(), x.data_ptr(), u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
@@ -886,8 +924,8 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
         const void* gx_ptr = g_x.defined() ? g_x.data_ptr() : nullptr;
         XCALL(xeq_update_out_bwd(dt, g_s.data_ptr(), gx_ptr, u.uv.data_ptr(), u.a.data_ptr(), u.ip.data_ptr(), N, F, mul,
                                  g_a.data_ptr(), g_ip.data_ptr(), nullptr, st));
-        const Tensor g_p = linear_bwd(g_ip, q[14], Tensor());
-        const Tensor g_cat = mlp_bwd(g_a, u.pre, q[15], q[16], q[17], q[18]);
+        Tensor g_p, g_cat;
+        mlp_and_linear_bwd(g_a, u.pre, q[15], q[16], q[17], q[18], g_ip, q[14], g_cat, g_p);
         Tensor ns, nx;
         const UvFrag* fr = g_cat.is_contiguous() ? uv_frag(&q[10], F, mul) : nullptr;
         if (fr) {   // dL/dU, dL/dV -> dL/dxhat (-> reverse of both norms) in one matrix-core launch

@@ -162,6 +162,7 @@ _PROTOS = {
     "xeq_mlp_pack": [_P, _P, c_int, c_int, c_int, _P, _P],
     "xeq_mlp2_fwd": [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P, c_int64, _P],
     "xeq_mlp2_bwd": [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, c_int64, _P],
+    "xeq_mlp2_and_linear": [c_int, _P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P],
     "xeq_pack_epoch": [],
     "xeq_pack_epoch_bump": [],
     "xeq_rowptr_guard": [_P, c_int64, c_int64, _P, _P, _P],

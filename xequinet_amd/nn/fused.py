@@ -257,6 +257,41 @@ def linear_module_bwd(lin: torch.nn.Linear, g: torch.Tensor) -> torch.Tensor:
     return _linear(g, pack, lin.weight.shape[0], lin.weight.shape[1], False)[0]
 
 
+def mlp_and_linear_fwd(seq, x, lin: torch.nn.Linear, p: torch.Tensor):
+    """(pre, y) of Linear-SiLU-Linear on rows of x and lin(p), two INDEPENDENT products of XPainnUpdate.forward (nn/xpainn.py:219-223),
+    through ``xeq_mlp2_and_linear``: one launch for MD-sized systems, the two launches otherwise -- the same bits either way."""
+    packs = _mlp_packs(seq) if x.is_cuda and x.stride(1) == 1 and x.stride(0) % 4 == 0 else None
+    lpack = _linear_pack(lin, lin.weight, lin.bias, False) if (lin.bias is None and p.is_cuda and p.dim() == 2 and p.stride(1) == 1 and p.stride(0) % 4 == 0) else None
+    if packs is None or lpack is None:
+        pre, y = _mlp_fwd(seq, x)
+        return pre, y, linear_module_fwd(lin, p)
+    n, k1 = x.shape
+    n2, n_out = seq[2].weight.shape[0], lin.weight.shape[0]
+    pre = torch.empty((n, seq[0].weight.shape[0]), dtype=x.dtype, device=x.device)
+    y = torch.empty((n, n2), dtype=x.dtype, device=x.device)
+    ip = torch.empty((n, n_out), dtype=x.dtype, device=x.device)
+    call("xeq_mlp2_and_linear", 0, ptr(x), x.stride(0), n, k1, ptr(packs[0]), ptr(packs[1]), n2, ptr(pre), ptr(y), n2,
+         ptr(p), p.stride(0), lin.weight.shape[1], ptr(lpack), n_out, ptr(ip), n_out, stream())
+    return pre, y, ip
+
+
+def mlp_and_linear_bwd(seq, g_y, pre, lin: torch.nn.Linear, g_lin: torch.Tensor):
+    """dL/dx of the stack and dL/dp of lin (g_lin W), the reverse twins of ``mlp_and_linear_fwd``."""
+    packs = _mlp_packs(seq) if g_y.is_cuda else None
+    g_lin = g_lin.contiguous()
+    lpack = _linear_pack(lin, lin.weight, None, True) if g_lin.is_cuda else None
+    if packs is None or lpack is None:
+        return _mlp_bwd(seq, g_y, pre), linear_module_bwd(lin, g_lin)
+    g_y = g_y.contiguous()
+    n, n2 = g_y.shape
+    k1, k_lin, n_lin = seq[0].weight.shape[1], lin.weight.shape[0], lin.weight.shape[1]
+    g_x = torch.empty((n, k1), dtype=g_y.dtype, device=g_y.device)
+    g_p = torch.empty((n, n_lin), dtype=g_y.dtype, device=g_y.device)
+    call("xeq_mlp2_and_linear", 1, ptr(g_y), n2, n, n2, ptr(packs[2]), ptr(packs[3]), k1, ptr(pre), ptr(g_x), k1,
+         ptr(g_lin), g_lin.stride(0), k_lin, ptr(lpack), n_lin, ptr(g_p), n_lin, stream())
+    return g_x, g_p
+
+
 class EnergyHead(Function):
     """EnergyOut's MLP on node scalars (nn/output.py:104-118): Linear - SiLU - Linear(., 1) -> atomic energies [n], with the
     explicit reverse pass of a force evaluation (input gradient only).  HIP kernels throughout: a row's sums do not depend on
@@ -615,8 +650,7 @@ class UpdateBlock(Function):
                 else:
                     torch.mm(xb, W, out=ub)
             call("xeq_uv_reduce_fwd", dtype_code(s), ptr(uv), n, mul3(mul), float(eps), ptr(cat), F + C, F, ptr(p), stream())
-        pre, a = _mlp_fwd(module.update_mlp, cat)                             # a = [a_vv C | a_sv F | a_ss F]
-        ip = linear_module_fwd(module.dot_lin, p)
+        pre, a, ip = mlp_and_linear_fwd(module.update_mlp, cat, module.dot_lin, p)   # a = [a_vv C | a_sv F | a_ss F]; ip = dot_lin(p)
         # (the last block in front of a scalar-only head: nobody reads its equivariant output, nn/model.py marks the module)
         s_out, x_out = torch.empty_like(s), (None if getattr(module, "equivariant_output_unused", False) else torch.empty_like(x))
         call("xeq_update_out_fwd", dtype_code(s), ptr(s), ptr(x), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(s_out),
@@ -643,10 +677,9 @@ class UpdateBlock(Function):
         # dL/dU of this stage (g_x_out a_vv) is formed inside xeq_uv_reduce_bwd: no write here, no read-modify-write there
         call("xeq_update_out_bwd", dtype_code(s), ptr(g_s_out), ptr(g_x_out), ptr(uv), ptr(a), ptr(ip), n, F, mul3(mul), ptr(g_a),
              ptr(g_ip), None, stream())
-        g_p = linear_module_bwd(module.dot_lin, g_ip)
         if ctx.train:
-            return UpdateBlock._backward_with_params(ctx, g_s_out, g_x_out, g_a, g_ip, g_p)
-        g_cat = _mlp_bwd(module.update_mlp, g_a, pre)                         # [g_shat | g_v]
+            return UpdateBlock._backward_with_params(ctx, g_s_out, g_x_out, g_a, g_ip, linear_module_bwd(module.dot_lin, g_ip))
+        g_cat, g_p = mlp_and_linear_bwd(module.update_mlp, g_a, pre, module.dot_lin, g_ip)   # [g_shat | g_v]; dL/dp
         frag = _packed_uv_frag(module)
         if frag is not None and g_cat.is_contiguous():   # dL/dU, dL/dV -> dL/dxhat -> reverse of both norms in one matrix-core launch
             lw, ew = (module.norm.weight, module.o3norm.affine_weight) if ctx.do_norm else (None, None)
