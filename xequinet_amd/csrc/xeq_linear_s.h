@@ -48,6 +48,25 @@ __device__ __forceinline__ void linear_s_body(const LinArgs& a, float* Xs, int b
   const int G = a.K >> 3;
   const bool tile_ok = 16 * (NW * cg + wave) < a.n_out;
   const int t16 = tile_ok ? NW * cg + wave : 0;   // (a wave without a tile works on tile 0 and stores nothing)
+  // requests in the order of use (a wave's loads return in order): the rows (K <= 256: 1024 / (64 NW) float4 per thread, in registers
+  // until they go to LDS), then all of the tile's weight fragments
+  constexpr int XN = 1024 / (64 * NW);
+  const int k4 = a.K >> 2;
+  float4 xr[XN];
+  int xo[XN];
+#pragma unroll
+  for (int j = 0; j < XN; ++j) {
+    const int idx = tid + 64 * NW * j;
+    const int r = idx / k4, c4 = idx - r * k4;
+    const bool in = idx < LIN_S_ROWS * k4;
+    int64_t src = row0 + min(r, rows_here - 1);
+    if (a.row_index) src = a.row_index[src];
+    const float4 v = *reinterpret_cast<const float4*>(a.X + src * a.ldx + 4 * (in ? c4 : 0));
+    const bool ok = in && r < rows_here;
+    xr[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    xo[j] = in ? r * LIN_XLD + 4 * c4 : -1;
+  }
+  __builtin_amdgcn_sched_barrier(0);
   const float4* wp = reinterpret_cast<const float4*>(a.Wp) + (int64_t)(t16 >> 1) * (G + 1) * 64 + 16 * (t16 & 1) + i + 32 * kh;
   float wa[LIN_KMAX / 8][2];
 #pragma unroll
@@ -57,18 +76,11 @@ __device__ __forceinline__ void linear_s_body(const LinArgs& a, float* Xs, int b
     wa[q][1] = sel ? v.w : v.z;
   }
   const float bias_a = (a.has_bias && kq == 0) ? reinterpret_cast<const float*>(wp + (int64_t)G * 64)[0] : 0.f;
-  const int k4 = a.K >> 2;
-  for (int idx = tid; idx < LIN_S_ROWS * k4; idx += 64 * NW) {
-    const int r = idx / k4, c4 = idx - r * k4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows_here) {
-      int64_t src = row0 + r;
-      if (a.row_index) src = a.row_index[src];
-      v = *reinterpret_cast<const float4*>(a.X + src * a.ldx + 4 * c4);
-    }
-    *reinterpret_cast<float4*>(&Xs[r * LIN_XLD + 4 * c4]) = v;
-  }
-  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < XN; ++j)
+    if (xo[j] >= 0) *reinterpret_cast<float4*>(&Xs[xo[j]]) = xr[j];
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // orders LDS traffic only: the weights stay in flight
   const float* xs = &Xs[i * LIN_XLD + 4 * kh];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -566,9 +566,26 @@ __device__ __forceinline__ void mlp2_s_body(const MlpArgs& a, int parts, float* 
   const int rows_here = (int)min((int64_t)MLP_S_ROWS, a.n - row0);
   const int g1 = a.K1 >> 3;
   constexpr int G2 = MLP_H / 8, G1 = 16 * NCH;
-  // every weight request first (the chains then wait for memory once): stage 1 whole -- a lane takes the two components of its
-  // float4 it multiplies (x, y: even / odd accumulator of lanes kq < 2; z, w: of lanes kq >= 2) as ONE 8-byte load -- then the
-  // first stage-2 tile
+  // Requests in the order of use -- a wave's loads return in order: the rows first (16 rows x K1: at most NCH float4 per thread, held in
+  // registers until they go to LDS), then EVERY weight fragment (the chains then wait for memory once, and start while the tail of
+  // the weights is still on its way): stage 1 whole -- a lane takes the two components of its float4 it multiplies (x, y: even / odd
+  // accumulator of lanes kq < 2; z, w: of lanes kq >= 2) as ONE 8-byte load -- then the first stage-2 tile.
+  const int k4 = a.K1 >> 2;
+  float4 xr[NCH];
+  int xo[NCH];   // LDS offset of the float4, -1: none
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int idx = tid + 512 * j;
+    const int r = idx / k4, c4 = idx - r * k4;
+    const bool in = idx < MLP_S_ROWS * k4;
+    const float4 v = *reinterpret_cast<const float4*>(a.X + (row0 + min(r, rows_here - 1)) * a.ldx + 4 * (in ? c4 : 0));
+    xr[j] = keep4(in && r < rows_here, v);
+    xo[j] = in ? r * XLD + 4 * c4 : -1;
+  }
+  const unsigned ic = (unsigned)min(i, rows_here - 1);
+  float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (REVERSE) pv = *reinterpret_cast<const float4*>(a.pre + (row0 + ic) * MLP_H + 16 * wave + 4 * kq);
+  MLP_SB();
   const float2* w1 = reinterpret_cast<const float2*>(reinterpret_cast<const float4*>(a.W1p) + (int64_t)(wave >> 1) * (g1 + 1) * 64 +
                                                      16 * (wave & 1) + i + 32 * kh) + sel;
   float2 eo[G1];
@@ -590,19 +607,14 @@ __device__ __forceinline__ void mlp2_s_body(const MlpArgs& a, int parts, float* 
     }
     bias2_a = (a.bias2 && kq == 0) ? reinterpret_cast<const float*>(w2 + (int64_t)G2 * 64)[0] : 0.f;
   };
-  fetch2(t2);
-  const unsigned ic = (unsigned)min(i, rows_here - 1);
-  float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (REVERSE) pv = *reinterpret_cast<const float4*>(a.pre + (row0 + ic) * MLP_H + 16 * wave + 4 * kq);
-  // the rows, whole, into LDS
-  const int k4 = a.K1 >> 2;
-  for (int idx = tid; idx < MLP_S_ROWS * k4; idx += 512) {
-    const int r = idx / k4, c4 = idx - r * k4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows_here) v = *reinterpret_cast<const float4*>(a.X + (row0 + r) * a.ldx + 4 * c4);
-    *reinterpret_cast<float4*>(&Xs[r * XLD + 4 * c4]) = v;
-  }
-  __syncthreads();
+  MLP_SB();
+  // the rows into LDS (the weights stay in flight across the barrier: it orders LDS traffic only)
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+    if (xo[j] >= 0) *reinterpret_cast<float4*>(&Xs[xo[j]]) = xr[j];
+  MLP_LDS_BARRIER();
+  fetch2(t2);   // (behind the stage-1 weights in any case; here the rows' registers are free again)
+  MLP_SB();
   // ---- stage 1: hidden columns [16 wave, 16 wave + 16)
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* xs = &Xs[i * XLD + 4 * kh + 2 * sel];
@@ -626,7 +638,7 @@ __device__ __forceinline__ void mlp2_s_body(const MlpArgs& a, int parts, float* 
     }
     *reinterpret_cast<float4*>(&Ts[i * MLP_TLD + col]) = v;
   }
-  __syncthreads();
+  MLP_LDS_BARRIER();
   // ---- stage 2: output tiles 8 part + wave, + 8 parts, ...
   const float* ts = &Ts[i * MLP_TLD + 4 * kh];
   for (; t2 < nt16; t2 += 8 * parts) {

@@ -178,9 +178,14 @@ __device__ __forceinline__ void uv_job(const UvFwdArgs& a, const float* xh, int 
 // phase A of the front half: both norms of a tile of ROWS nodes, 8 lanes per node with the node's row in registers; xhat into LDS as
 // [node][l][m][channel], shat / the statistics to global memory (part 0 only).  One workgroup barrier inside (the staged parameters);
 // the caller places the one behind it.  A node's sums do not depend on ROWS or NT: the 8-lane split of a row is the same.
-template <int M0, int M1, int M2, int FF, int NORM, int ROWS, int NT>
+struct UvNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_loads: called once the node rows are requested, before the barrier (the few-row form requests its job's weights there: a
+// wave's loads return in order, and the rows are what phase A waits for)
+template <int M0, int M1, int M2, int FF, int NORM, int ROWS, int NT, typename Hook = UvNoHook>
 __device__ __forceinline__ void uv_phase_a(const UvFwdArgs& a, float* xh, const float* lnw, const float* lnb, const float* eqw, const float* eqb,
-                                           int64_t row0, int rows_here, int part_, int tid) {
+                                           int64_t row0, int rows_here, int part_, int tid, const Hook& after_loads = Hook()) {
   const int m0 = M0 >= 0 ? M0 : a.ir.mul[0], m1 = M1 >= 0 ? M1 : a.ir.mul[1], m2 = M2 >= 0 ? M2 : a.ir.mul[2];
   const int F = FF >= 0 ? FF : a.F;
   const bool do_norm = NORM >= 0 ? (NORM != 0) : (a.do_norm != 0);
@@ -207,6 +212,7 @@ __device__ __forceinline__ void uv_phase_a(const UvFwdArgs& a, float* xh, const 
       const float4 t = xr[v ? idx : 0];
       xv[k] = make_float4(v ? t.x : 0.f, v ? t.y : 0.f, v ? t.z : 0.f, v ? t.w : 0.f);
     }
+    after_loads();
     UV_LDS_BARRIER();   // the staged parameters (the row loads above stay in flight across it)
     if (!live) return;
     float mean = 0.f, rstd = 1.f, mean0 = 0.f, r = 1.f;
@@ -436,11 +442,10 @@ __global__ void __launch_bounds__(UVS_NT) k_update_uv_fwd_s(UvFwdArgs a) {
   const int64_t row0 = (int64_t)(blockIdx.x / UVS_PARTS) * UVS_ROWS;
   const int rows_here = (int)min((int64_t)UVS_ROWS, a.n - row0);
   // one job per wave of the tile's two workgroups (16 slots for (m0 + m1 + m2) / 16 jobs; more: further rounds); the first job's
-  // weights are requested before anything else, so the chain waits for memory once
+  // weights are requested whole, right behind the node rows of phase A: the chain waits for memory once
   const int n_jobs = (m0 + m1 + m2) >> 4;
   int jj = UVS_PARTS * wave + part;
   UvJobS job;
-  if (jj < n_jobs) uv_job_s_load(a, jj, m0, m1, m2, lane, job);
   float* prm = xh + UVS_ROWS * XLD;
   float *lnw = prm, *lnb = prm + F, *eqw = prm + 2 * F, *eqb = prm + 2 * F + C;
   if (do_norm) {
@@ -451,7 +456,10 @@ __global__ void __launch_bounds__(UVS_NT) k_update_uv_fwd_s(UvFwdArgs a) {
     for (int f = tid; f < C; f += UVS_NT) eqw[f] = a.eqw[f];
     for (int f = tid; f < m0; f += UVS_NT) eqb[f] = a.eqb[f];
   }
-  uv_phase_a<M0, M1, M2, FF, NORM, UVS_ROWS, UVS_NT>(a, xh, lnw, lnb, eqw, eqb, row0, rows_here, part, tid);
+  auto load_first = [&]() {
+    if (jj < n_jobs) uv_job_s_load(a, jj, m0, m1, m2, lane, job);
+  };
+  uv_phase_a<M0, M1, M2, FF, NORM, UVS_ROWS, UVS_NT>(a, xh, lnw, lnb, eqw, eqb, row0, rows_here, part, tid, load_first);
   UV_LDS_BARRIER();
   for (; jj < n_jobs; jj += UVS_PARTS * UVS_NT / 64) {
     if (job.mul == 128) uv_job_s_run<16>(a, job, xh, XLD, row0, rows_here, lane);

@@ -78,25 +78,44 @@ class XPaiNNLMP(XPaiNN):
                     or self._replay.compute_virial != compute_virial):
                 self._replay = GraphedModel(_Core(self), compute_forces=compute_forces, compute_virial=compute_virial,
                                             tune_gemms=self._tune_gemms, reuse_unchanged_topology=True)
-            if keys.BATCH_PTR not in data:
-                n = data[keys.POSITIONS].shape[0]
-                data[keys.BATCH_PTR] = torch.tensor([0, n], dtype=torch.long, device=data[keys.POSITIONS].device)
-            return {k: v.clone() for k, v in self._replay(data).items()}
+            if keys.BATCH_PTR not in data:   # one graph: [0, n], kept per (n, device) -- no host-to-device copy per step
+                n, dev = data[keys.POSITIONS].shape[0], data[keys.POSITIONS].device
+                if getattr(self, "_one_graph_ptr", None) is None or self._one_graph_ptr[0] != (n, dev):
+                    object.__setattr__(self, "_one_graph_ptr", ((n, dev), torch.tensor([0, n], dtype=torch.long, device=dev)))
+                data[keys.BATCH_PTR] = self._one_graph_ptr[1]
+            # the replayed graph's outputs are its static buffers: whatever forward() does not rescale into a new tensor is copied here
+            rescaled = self._rescaled_keys(compute_forces, compute_virial)
+            return {k: (v if k in rescaled else v.clone()) for k, v in self._replay(data).items()}
         return _Core(self)(data, compute_forces, compute_virial)
+
+    def _rescaled_keys(self, compute_forces: bool, compute_virial: bool) -> set:
+        """Results that forward() multiplies by a unit factor other than 1 (the product is a new tensor)."""
+        out = set()
+        if self.energy_unit_factor != 1.0:
+            out.add(keys.TOTAL_ENERGY)
+            if compute_virial:
+                out.add(keys.VIRIAL)
+        if compute_forces and self.forces_unit_factor != 1.0:
+            out.add(keys.FORCES)
+        return out
 
     def forward(self, data: Dict[str, torch.Tensor], compute_forces: bool = True,
                 compute_virial: bool = False) -> Dict[str, torch.Tensor]:
         data = dict(data)
-        data[keys.POSITIONS] = data[keys.POSITIONS] * self.pos_unit_factor
+        # (a unit factor of exactly 1 -- LAMMPS "metal" against eV / Angstrom -- is not multiplied in: x * 1.0 is x bit for bit, and an
+        # MD-sized step pays ~5 us per launch)
+        data[keys.POSITIONS] = (data[keys.POSITIONS] * self.pos_unit_factor if self.pos_unit_factor != 1.0
+                                else data[keys.POSITIONS].detach())   # (an alias, not the caller's tensor: the evaluation marks it requires_grad)
         # like the reference (jit_model.py:62) only the positions are rescaled: a cell, when present, is taken as given
         if self.net_charge is not None:
             data[keys.TOTAL_CHARGE] = torch.tensor([self.net_charge], device=data[keys.POSITIONS].device)
         result = self._evaluate(data, compute_forces, compute_virial)
-        result[keys.TOTAL_ENERGY] = result[keys.TOTAL_ENERGY] * self.energy_unit_factor
-        if compute_forces:
+        if self.energy_unit_factor != 1.0:
+            result[keys.TOTAL_ENERGY] = result[keys.TOTAL_ENERGY] * self.energy_unit_factor
+            if compute_virial:
+                result[keys.VIRIAL] = result[keys.VIRIAL] * self.energy_unit_factor
+        if compute_forces and self.forces_unit_factor != 1.0:
             result[keys.FORCES] = result[keys.FORCES] * self.forces_unit_factor
-        if compute_virial:
-            result[keys.VIRIAL] = result[keys.VIRIAL] * self.energy_unit_factor
         return result
 
 
