@@ -500,6 +500,10 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
  * flags: bit 0 the xhat layout, XEQ_SB_Y0_ZERO (also accepted by xeq_message_fwd_sb's xhat_layout): the l = 0 harmonic counts as 0 -- the
  * record holds a tangent of the harmonics; XEQ_SB_Q_ACCUMULATE: q += instead of q =; XEQ_SB_NO_GY.  f32 / f64. */
 #define XEQ_SB_Y0_ZERO 8
+/* xeq_message_bwd_sb only: xhat_layout | XEQ_SB_ACCUM_VEC ADDS dL/dvec to what grad_vec holds instead of storing it: the message blocks of
+ * one force evaluation share one buffer (the last block of the model stores, the earlier ones add -- the order in which autograd would
+ * sum their separate results, without its two elementwise launches per evaluation). */
+#define XEQ_SB_ACCUM_VEC 16
 #define XEQ_SB_Q_ACCUMULATE 16
 #define XEQ_SB_NO_GY 32   /* gy is not wanted (and not written) */
 int xeq_message_bwd_sbq(int dtype, int64_t n_nodes, int64_t n_edges, const int32_t* n_rowptr, const int32_t* n_perm,

@@ -81,6 +81,7 @@ struct SbArgs {
   int y0_zero;  // the l = 0 harmonic is 0 instead of 1: the record stands for a TANGENT of the harmonics (training pass, second order)
   int q_accum;  // k_message_bwd_sbq: add to the per-edge products instead of storing them
   int want_gy;  // k_message_bwd_sbq: form dL/dY_1, dL/dY_2 per edge (eight wave reductions per edge otherwise saved)
+  int acc_vec;  // k_message_bwd_sb: dL/dvec is ADDED to what grad_vec holds (XEQ_SB_ACCUM_VEC: the blocks of one evaluation share the buffer)
 };
 
 template <typename T, int MAXB>
@@ -398,6 +399,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
         g.inv_d = rd[5];
         T out[3];
         edge_grad<T>(g, gd, q1, q2, out);
+        if (a.acc_vec) {   // (an edge belongs to one segment: no other workgroup touches these three floats)
+          out[0] = grad_vec[3 * e] + out[0];
+          out[1] = grad_vec[3 * e + 1] + out[1];
+          out[2] = grad_vec[3 * e + 2] + out[2];
+        }
         grad_vec[3 * e] = out[0];
         grad_vec[3 * e + 1] = out[1];
         grad_vec[3 * e + 2] = out[2];
@@ -970,6 +976,7 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.perm = n_perm;
   a.other = center;
   a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
+  a.acc_vec = (xhat_layout & XEQ_SB_ACCUM_VEC) ? 1 : 0;
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
   XEQ_SB_DISPATCH(k_message_bwd_sb, 1, 1, a, (const T*)basis, (const T*)dbasis, (const T*)h, (const T*)xhat,
                   (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat,

@@ -989,12 +989,17 @@ std::vector<Tensor> xpainn_eval_impl(const Tensor& pos_in, const Tensor& atomic_
           }
         } else {
           g.sorted_view();
+          // the blocks share ONE dL/dvec buffer: the first to run stores, the others add (XEQ_SB_ACCUM_VEC; ops.message_backward does the same)
+          const bool accum = g_vec_total.defined();
+          if (!accum) g_vec_total = g_vec;
           XCALL(xeq_message_bwd_sb(dt, N, E, (const int32_t*)g.n_rowptr.data_ptr(), (const int32_t*)g.n_perm.data_ptr(),
                                    (const int64_t*)g.ei.select(0, 0).data_ptr(), g.sb_basis.data_ptr(), g.sb_dbasis.data_ptr(),
                                    m.h.data_ptr(), m.xhat.data_ptr(), g_s.data_ptr(), g_x.data_ptr(), q[4].data_ptr(), q[5].data_ptr(),
-                                   hy.B, F, mul, g_h.data_ptr(), g_xhat.data_ptr(), g_vec.data_ptr(), 1, st));
+                                   hy.B, F, mul, g_h.data_ptr(), g_xhat.data_ptr(), g_vec_total.data_ptr(), 1 | (accum ? XEQ_SB_ACCUM_VEC : 0), st));
         }
-        if (m.impl == 0 && defer_edge_grad) {
+        if (m.impl != 0) {
+          // (summed in the kernel)
+        } else if (defer_edge_grad) {
           if (b == 0) g_vec_total = g_vec;
         } else {
           g_vec_total = g_vec_total.defined() ? g_vec_total + g_vec : g_vec;

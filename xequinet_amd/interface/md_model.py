@@ -128,6 +128,11 @@ class _Core:
     def __call__(self, data, compute_forces: bool = True, compute_virial: bool = False):
         m = self.model
         data = compute_edge_data(data=data, compute_forces=compute_forces, compute_virial=compute_virial)
+        # one dL/dvec for all message blocks of this evaluation (ops.EdgeGradDeferral), as BaseModel.forward does (nn/model.py)
+        g = data.get(keys.EDGE_GRAPH)
+        if g is not None:
+            from .. import ops
+            g.edge_grad_deferral = ops.EdgeGradDeferral() if (compute_forces or compute_virial) else None
         for mod in m.mods.values():
             data = mod(data)
         return compute_properties(data=data, compute_forces=compute_forces, compute_virial=compute_virial,

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("XEQ_LIB_PATH") or os.path.join(_HERE, "libxeq_hip.so"
 
 XEQ_F32, XEQ_F64 = 0, 1
 COPY_MANY_MAX = 16       # XEQ_COPY_MANY_MAX of include/xeq.h
+SB_ACCUM_VEC = 16        # XEQ_SB_ACCUM_VEC of include/xeq.h: xeq_message_bwd_sb adds dL/dvec to the buffer it is handed
 XHAT_HIGHER_L_ZERO = 2   # XEQ_XHAT_HIGHER_L_ZERO of include/xeq.h: hint bit on the xhat_layout argument of the wq message kernels
 SB_Y0_ZERO = 8           # XEQ_SB_Y0_ZERO / XEQ_SB_Q_ACCUMULATE: the training-pass forms of the sb message kernels (ops.DiffMessage)
 SB_Q_ACCUMULATE = 16

@@ -155,8 +155,9 @@ def compute_properties(
     graph = data.get(keys.EDGE_GRAPH)
     deferral = getattr(graph, "edge_grad_deferral", None) if graph is not None else None
     if deferral is not None and (compute_forces or compute_virial):
-        if deferral.sets:
-            n_left, deferral.sets = len(deferral.sets), []
+        if deferral.sets or deferral.sb_seen:
+            n_left, deferral.sets = len(deferral.sets) + deferral.sb_seen, []
+            deferral.sb_vec, deferral.sb_seen = None, 0
             raise RuntimeError(f"edge-gradient deferral not drained: {n_left} of {deferral.registered} registered message blocks "
                                "reached the reverse pass; dL/dvec was never emitted")
     if extra_properties is not None:

@@ -881,6 +881,8 @@ class EdgeGradDeferral:
     def __init__(self) -> None:
         self.registered = 0
         self.sets = []
+        self.sb_vec = None      # scalar-broadcast blocks: the one dL/dvec buffer they add into (XEQ_SB_ACCUM_VEC)
+        self.sb_seen = 0
 
     def register(self) -> bool:
         if self.registered >= lib.WQ_MAX_PART_SETS:
@@ -901,6 +903,18 @@ class EdgeGradDeferral:
         return g_vec
 
 
+    def next_sb(self, vec):
+        """A scalar-broadcast block's turn: -> (buffer its kernel writes dL/dvec to, whether it ADDS, whether this block returns it)."""
+        first = self.sb_vec is None
+        if first:
+            self.sb_vec = torch.empty_like(vec)
+        self.sb_seen += 1
+        buf, last = self.sb_vec, self.sb_seen >= self.registered
+        if last:                      # (a second reverse pass over a retained graph starts afresh)
+            self.sb_vec, self.sb_seen = None, 0
+        return buf, not first, last
+
+
 def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_grads: bool = True, deferral: Optional[EdgeGradDeferral] = None):
     """Reverse pass of the fused message: (grad_h, grad_xhat, grad_vec, grad_s, grad_x).  node_grads=False: only grad_vec is
     wanted (the first block of a force evaluation); the wq kernel then stores no node gradients and None is returned for them.
@@ -913,7 +927,7 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
     g_x = torch.zeros((graph.n_nodes, D), dtype=h.dtype, device=h.device) if g_x is None else g_x.contiguous()
     skip = impl == "wq" and not node_grads
     g_h, g_xhat = (None, None) if skip else (torch.empty_like(h), torch.empty_like(xhat))
-    g_vec = None if (impl == "wq" and deferral is not None) else torch.empty_like(vec)  # written at the edge's own position by every kernel family
+    g_vec = None if (impl in ("wq", "sb") and deferral is not None) else torch.empty_like(vec)  # written at the edge's own position by every kernel family
     if impl == "wq":
         N, E = graph.n_nodes, graph.n_edges
         mirror = getattr(graph, "mirror_walk", False)      # symmetric list: the forward plan and its records serve both directions
@@ -932,10 +946,14 @@ def message_backward(saved, graph: EdgeGraph, cfg, impl: str, g_s, g_x, node_gra
             call("xeq_message_wq_edge_grad", ptr(vec), N, E, ptr(plan["qptr"]), ptr(plan["peid"]), ptr(graph.mirror_map if mirror else None),
                  mul3(mul), ptr(parts), ptr(g_vec), stream())
     elif impl == "sb":
+        # with a deferral the blocks of the evaluation share ONE dL/dvec buffer: the first to run (the model's last block) stores, the
+        # others add -- the sum autograd would form from their separate results, in its order, without its elementwise launches
+        buf, accum, emit = deferral.next_sb(vec) if deferral is not None else (g_vec, False, True)
         KERNEL_TIMER.launch("xeq_message_bwd_sb", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),
                             ptr(graph.n_perm), ptr(graph.edge_index[0]), ptr(basis), ptr(dbasis), ptr(h), ptr(xhat), ptr(g_s),
                             ptr(g_x), ptr(w_rbf), ptr(b_rbf), num_basis, node_dim, mul3(mul), ptr(g_h), ptr(g_xhat),
-                            ptr(g_vec), xl, stream())
+                            ptr(buf), xl | (lib.SB_ACCUM_VEC if accum else 0), stream())
+        g_vec = buf if emit else None
     else:
         KERNEL_TIMER.launch("xeq_message_bwd", dtype_code(h), graph.n_nodes, graph.n_edges, ptr(graph.n_rowptr),
                             ptr(graph.n_perm), ptr(graph.edge_index[0]), ptr(vec), ptr(h), ptr(xhat), ptr(g_s), ptr(g_x),
@@ -988,9 +1006,10 @@ def message_param_grad(saved, graph: EdgeGraph, cfg, g_s, g_x):
 
 
 def register_edge_grad(graph: EdgeGraph, impl: str, vec_needs_grad: bool) -> Optional[EdgeGradDeferral]:
-    """The evaluation's EdgeGradDeferral for a block that runs the wq kernels and owes a dL/dvec, registered; else None."""
+    """The evaluation's EdgeGradDeferral for a block that runs the wq or the scalar-broadcast kernels and owes a dL/dvec, registered;
+    else None.  (All blocks of an evaluation run the same family: it follows from the sizes.)"""
     d = getattr(graph, "edge_grad_deferral", None)
-    if d is None or impl != "wq" or not vec_needs_grad or not d.register():
+    if d is None or impl not in ("wq", "sb") or not vec_needs_grad or not d.register():
         return None
     return d
 
