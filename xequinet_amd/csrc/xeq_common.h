@@ -264,7 +264,7 @@ __device__ __forceinline__ void edge_grad(const EdgeGeom<T>& g, T gd, const T* p
 // four times the waves; BIT-EQUAL results, see xeq_linear.hip).  XEQ_SMALL_ROWS overrides (0: never; read per call: tests flip it).
 inline int64_t xeq_small_rows() {
   const char* v = getenv("XEQ_SMALL_ROWS");
-  return v ? atoll(v) : 2048;
+  return v ? atoll(v) : 3584;   // 224 row tiles: measured crossover of a whole replayed step between 3.6 k and 4.6 k atoms (profiles/r06_small_experiments.txt 13)
 }
 
 struct TileSplit {

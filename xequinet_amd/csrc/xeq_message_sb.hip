@@ -301,33 +301,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
       const int32_t slot_v = pb + min(lane, cnt - 1);
       const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
       const int32_t ctr_v = (int32_t)a.other[eid_v];
+      // the centre rows of edge slot j of this group: dL/ds_out, dL/dx_out of the lane's channels
+      auto gather = [&](int j, T (&gxo)[5], T& dgmo) {
+        const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane(ctr_v, j);
+        dgmo = grad_s[ci * (uint32_t)F + cm.ts];
+        const T* gr = grad_x + ci * (uint32_t)D;
+        gxo[0] = gr[gcomp[0]];
+        if (cm.wnm >= 3) {  // wave-uniform
+          gxo[1] = gr[gcomp[1]];
+          gxo[2] = gr[gcomp[2]];
+        } else {
+          gxo[1] = gxo[2] = T(0);
+        }
+        if (cm.wnm >= 5) {
+          gxo[3] = gr[gcomp[3]];
+          gxo[4] = gr[gcomp[4]];
+        } else {
+          gxo[3] = gxo[4] = T(0);
+        }
+      };
+      // U = 1 (every shipped instantiation): the NEXT edge's rows are requested before this edge's arithmetic -- the per-edge work (six
+      // filters, nine wave reductions) then runs under the gather's round trip instead of behind it.  The arithmetic is the one-edge
+      // body itself: same sums, same order.
+      T gxn[5], dgmn = T(0);
+#pragma unroll
+      for (int m = 0; m < 5; ++m) gxn[m] = T(0);
+      if (U == 1) gather(0, gxn, dgmn);
       for (int32_t p = pb; p < pe_; p += U) {
-        uint32_t cidx[U];
         int32_t eid[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = min(p + u, pe_ - 1) - pb;
-          eid[u] = __builtin_amdgcn_readlane(eid_v, j);
-          cidx[u] = (uint32_t)__builtin_amdgcn_readlane(ctr_v, j);
-        }
+        for (int u = 0; u < U; ++u) eid[u] = __builtin_amdgcn_readlane(eid_v, min(p + u, pe_ - 1) - pb);
         T gx[U][5], dgm[U];
+        if (U == 1) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) gx[0][m] = gxn[m];
+          dgm[0] = dgmn;
+          gather(min(p + 1, pe_ - 1) - pb, gxn, dgmn);   // (past the group's last edge: that edge again, never used)
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) gather(min(p + u, pe_ - 1) - pb, gx[u], dgm[u]);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          dgm[u] = grad_s[cidx[u] * (uint32_t)F + cm.ts];
-          const T* gr = grad_x + cidx[u] * (uint32_t)D;
-          gx[u][0] = gr[gcomp[0]];
-          if (cm.wnm >= 3) {  // wave-uniform
-            gx[u][1] = gr[gcomp[1]];
-            gx[u][2] = gr[gcomp[2]];
-          } else {
-            gx[u][1] = gx[u][2] = T(0);
-          }
-          if (cm.wnm >= 5) {
-            gx[u][3] = gr[gcomp[3]];
-            gx[u][4] = gr[gcomp[4]];
-          } else {
-            gx[u][3] = gx[u][4] = T(0);
-          }
 #pragma unroll
           for (int m = 0; m < 5; ++m)
             if (m >= cm.nm) gx[u][m] = T(0);  // components the lane does not own (v_cndmask, no branch)
@@ -978,6 +994,14 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
   a.acc_vec = (xhat_layout & XEQ_SB_ACCUM_VEC) ? 1 : 0;
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
+  if (dtype == XEQ_F32 && num_basis <= 20 && n_nodes <= 512 && n_nodes <= xeq_small_rows()) {
+    // few nodes (an MD-sized system: at most two workgroups per CU): the same kernel allowed 256 registers (no spills; the general
+    // instantiation is held to 128 for four waves per SIMD) -- register allocation only, the arithmetic is the same
+    using T = float;
+    hipLaunchKernelGGL((k_message_bwd_sb<T, 20, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, (const T*)basis, (const T*)dbasis, (const T*)h,
+                       (const T*)xhat, (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat,
+                       (T*)grad_vec);
+  } else
   XEQ_SB_DISPATCH(k_message_bwd_sb, 1, 1, a, (const T*)basis, (const T*)dbasis, (const T*)h, (const T*)xhat,
                   (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat,
                   (T*)grad_vec);
