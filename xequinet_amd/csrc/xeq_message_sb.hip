@@ -157,7 +157,23 @@ __device__ __forceinline__ void lane_y(const T* __restrict__ tail, int l, T (&y)
 // kernels are bound by serial latency chains of one workgroup, so occupancy beats registers: 3 -> 4 waves per SIMD
 // (<= 128 VGPRs, U = 2 forward / 1 reverse) took the forward pass from 0.39 to 0.30 ms and the reverse pass from
 // 0.72 to 0.57 ms; 5 waves (96 VGPRs) spills the weight rows and is 3-5x slower.
-template <typename T, int MAXB, int U, int WPE>
+// STAGE (few nodes: an MD-sized system, where the launch is ONE segment's latency chain): the records of a group of <= 64 edges are
+// copied to LDS with one round of vector loads before the group's arithmetic, instead of one scalar-memory round trip per edge batch in
+// front of its filters; the filters then read their record operands from LDS (broadcast reads).  The same arithmetic, the same bits.
+template <typename T>
+__device__ __forceinline__ void sb_stage_records(const T* __restrict__ src, int EW, int32_t eid_v, int cnt, T* __restrict__ dst, int lane, int wave) {
+  constexpr int LPE = sizeof(T) == 4 ? 16 : 32, EPI = 64 / LPE;   // lanes per edge (16 bytes each), edges per wave instruction
+  const int parts = EW * (int)sizeof(T) / 16;
+  const int part = lane % LPE;
+  for (int j0 = wave * EPI; j0 < cnt; j0 += 4 * EPI) {
+    const int j = j0 + lane / LPE;
+    const int32_t e = __shfl(eid_v, min(j, cnt - 1), 64);
+    if (j < cnt && part < parts)
+      reinterpret_cast<float4*>(dst + j * EW)[part] = reinterpret_cast<const float4*>(src + (uint32_t)e * (uint32_t)EW)[part];
+  }
+}
+
+template <typename T, int MAXB, int U, int WPE, bool STAGE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_message_fwd_sb(SbArgs a, const T* __restrict__ eb, const T* __restrict__ h,
                                                         const T* __restrict__ xhat, const T* __restrict__ s_in,
                                                         const T* __restrict__ x_in, const T* __restrict__ w_rbf,
@@ -176,6 +192,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
   load_w<T, MAXB>(w_rbf, b_rbf, 2 * C + cm.ts, B, cm.has_s, wm, bm);
 
   const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  __shared__ __attribute__((aligned(16))) T srec[STAGE ? 64 * (MAXB + 12) : 4];
   const T y00 = a.y0_zero ? T(0) : T(1);
   XcdWalk walk(a.n_nodes, a.chunk);
   for (int64_t c = walk.next(); c >= 0; c = walk.next()) {
@@ -188,6 +206,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
       const int32_t slot_v = pb + min(lane, cnt - 1);
       const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
       const int32_t nbr_v = (int32_t)a.other[eid_v];
+      if (STAGE) {
+        __syncthreads();   // the previous group's (or segment's) readers are done
+        sb_stage_records<T>(eb, EW, eid_v, cnt, srec, lane, wave);
+        __syncthreads();
+      }
       for (int j0 = 0; j0 < cnt; j0 += U) {
         uint32_t noff[U], eoff[U];  // 32-bit element offsets (host checks N*H and E*EW < 2^31)
 #pragma unroll
@@ -221,7 +244,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (j0 + u < cnt) {  // uniform
-            const T* rec = eb + eoff[u];  // workgroup-uniform address: scalar loads
+            const T* rec = STAGE ? srec + (j0 + u) * EW : eb + eoff[u];  // workgroup-uniform address: scalar loads (STAGE: LDS broadcast reads)
             const T fe = rec[BP];
             const T ps = filt(ws, bs, rec, fe);
             const T pe = filt(we, be, rec, fe);
@@ -262,7 +285,7 @@ __device__ __forceinline__ double wave_total(double v) { return wave_sum<double>
 
 constexpr int SB_RED = 64;  // edges whose reduction slots fit in LDS between two finalisations
 
-template <typename T, int MAXB, int U, int WPE>
+template <typename T, int MAXB, int U, int WPE, bool STAGE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_message_bwd_sb(SbArgs a, const T* __restrict__ eb, const T* __restrict__ ed,
                                                         const T* __restrict__ h, const T* __restrict__ xhat,
                                                         const T* __restrict__ grad_s, const T* __restrict__ grad_x,
@@ -271,6 +294,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
                                                         T* __restrict__ grad_vec) {
   __shared__ T red[SB_RED][4][9];
   __shared__ int32_t red_eid[SB_RED];
+  __shared__ __attribute__((aligned(16))) T srec[STAGE ? 2 * SB_RED * (MAXB + 12) : 4];   // STAGE: value | derivative records of the group
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int B = a.B, C = a.C, F = a.F, D = a.D, H = a.H;
   const int BP = eb_bp(B), EW = BP + 12;
@@ -301,6 +325,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
       const int32_t slot_v = pb + min(lane, cnt - 1);
       const int32_t eid_v = a.perm ? a.perm[slot_v] : slot_v;
       const int32_t ctr_v = (int32_t)a.other[eid_v];
+      if (STAGE) {   // (the group's previous readers passed the barrier that follows every finalisation)
+        sb_stage_records<T>(eb, EW, eid_v, cnt, srec, lane, __builtin_amdgcn_readfirstlane(wave));
+        sb_stage_records<T>(ed, EW, eid_v, cnt, srec + SB_RED * (MAXB + 12), lane, __builtin_amdgcn_readfirstlane(wave));
+        __syncthreads();
+      }
       // the centre rows of edge slot j of this group: dL/ds_out, dL/dx_out of the lane's channels
       auto gather = [&](int j, T (&gxo)[5], T& dgmo) {
         const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane(ctr_v, j);
@@ -351,8 +380,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (p + u < pe_) {  // uniform
-            const T* rec = eb + (uint32_t)eid[u] * (uint32_t)EW;
-            const T* rd = ed + (uint32_t)eid[u] * (uint32_t)EW;
+            const T* rec = STAGE ? srec + (p + u - pb) * EW : eb + (uint32_t)eid[u] * (uint32_t)EW;
+            const T* rd = STAGE ? srec + SB_RED * (MAXB + 12) + (p + u - pb) * EW : ed + (uint32_t)eid[u] * (uint32_t)EW;
             const T fe = rec[BP], dfe = rd[BP];
             const T ps = filt(ws, bs, rec, fe), pe = filt(we, be, rec, fe), pm = filt(wm, bm, rec, fe);
             const T qs = filt(ws, bs, rd, dfe), qe = filt(we, be, rd, dfe), qm = filt(wm, bm, rd, dfe);
@@ -973,6 +1002,12 @@ int xeq_message_fwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.xl = xhat_layout & 1;   // the XEQ_XHAT_HIGHER_L_ZERO hint is for the wq kernels; this family computes the general form
   a.y0_zero = (xhat_layout & XEQ_SB_Y0_ZERO) ? 1 : 0;
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
+  if (dtype == XEQ_F32 && num_basis <= 20 && n_nodes <= 512 && n_nodes <= xeq_small_rows()) {
+    // few nodes (an MD-sized system: at most two workgroups per CU): records staged in LDS per segment, 256 registers allowed
+    using T = float;
+    hipLaunchKernelGGL((k_message_fwd_sb<T, 20, 2, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a, (const T*)basis, (const T*)h, (const T*)xhat,
+                       (const T*)s_in, (const T*)x_in, (const T*)w_rbf, (const T*)b_rbf, (T*)s_out, (T*)x_out);
+  } else
   XEQ_SB_DISPATCH(k_message_fwd_sb, 2, 2, a, (const T*)basis, (const T*)h, (const T*)xhat, (const T*)s_in, (const T*)x_in,
                   (const T*)w_rbf, (const T*)b_rbf, (T*)s_out, (T*)x_out);
   XEQ_CHECK_LAUNCH("xeq_message_fwd_sb");
@@ -995,10 +1030,10 @@ int xeq_message_bwd_sb(int dtype, int64_t n_nodes, int64_t n_edges, const int32_
   a.acc_vec = (xhat_layout & XEQ_SB_ACCUM_VEC) ? 1 : 0;
   dim3 grid((unsigned)(n_nodes < 2048 ? n_nodes : 2048));
   if (dtype == XEQ_F32 && num_basis <= 20 && n_nodes <= 512 && n_nodes <= xeq_small_rows()) {
-    // few nodes (an MD-sized system: at most two workgroups per CU): the same kernel allowed 256 registers (no spills; the general
-    // instantiation is held to 128 for four waves per SIMD) -- register allocation only, the arithmetic is the same
+    // few nodes (an MD-sized system: at most two workgroups per CU): the group's records staged in LDS (one round of vector loads
+    // instead of a scalar-memory round trip per edge) and 256 registers allowed (no spills) -- the arithmetic is the same
     using T = float;
-    hipLaunchKernelGGL((k_message_bwd_sb<T, 20, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, (const T*)basis, (const T*)dbasis, (const T*)h,
+    hipLaunchKernelGGL((k_message_bwd_sb<T, 20, 1, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a, (const T*)basis, (const T*)dbasis, (const T*)h,
                        (const T*)xhat, (const T*)grad_s, (const T*)grad_x, (const T*)w_rbf, (const T*)b_rbf, (T*)grad_h, (T*)grad_xhat,
                        (T*)grad_vec);
   } else
