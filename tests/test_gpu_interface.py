@@ -705,3 +705,41 @@ def test_gromacs_model_whole_step_graph_without_a_box():
         assert torch.equal(outs[0][0], outs[1][0]), step
         assert (outs[0][1] - outs[1][1]).abs().max().item() <= 16 * torch.finfo(dtype).eps * outs[0][1].abs().max().item(), step
     assert fast._step_graph.captures == 1
+
+
+def test_lammps_replay_on_an_unchanged_list_skips_the_plan_rebuild_and_changes_no_bit():
+    """runtime.GraphedModel keeps a second captured graph without the walk-plan rebuild for replays on an unchanged list (a periodic
+    192-atom box: the wq message kernels and their plans).  Same positions through the first graph (capture), the plan-free graph
+    (second and third call) and a model that rebuilds every time: the same bits; moved positions: equal to the eager model."""
+    from xequinet_amd.data import single_radius_graph
+    from xequinet_amd.data import synthetic as syn
+    from xequinet_amd.interface import XPaiNNLMP
+
+    pos, z, _, cell = syn.synth_water_box(4, seed=5)
+    p0 = torch.tensor(pos, dtype=torch.float32, device="cuda")
+    zz = torch.tensor(z, device="cuda")
+    c = torch.tensor(cell[0], dtype=torch.float32, device="cuda")
+    pbc = torch.tensor([True, True, True], device="cuda")
+    ei, co = single_radius_graph(p0, pbc, c, 5.0)
+    kw = dict(unit_style="metal")
+    torch.manual_seed(1)
+    fast = XPaiNNLMP(replay=True, tune_gemms=False, **kw).eval().requires_grad_(False).to("cuda")
+    torch.manual_seed(1)
+    ref = XPaiNNLMP(replay=False, **kw).eval().requires_grad_(False).to("cuda")
+
+    def run(m, p):
+        with torch.enable_grad():
+            out = m({"pos": p.clone(), "atomic_numbers": zz, "edge_index": ei, "cell": c[None], "cell_offsets": co, "pbc": pbc[None]}, True, False)
+        return out["energy"].clone(), out["forces"].clone()
+
+    e1, f1 = run(fast, p0)           # capture + the graph with the plan rebuild
+    e2, f2 = run(fast, p0)           # captures and replays the plan-free graph
+    e3, f3 = run(fast, p0)           # replays it
+    assert fast._replay.captures == 1 and getattr(fast._replay, "captures_same_list", 0) == 1
+    assert torch.equal(e1, e2) and torch.equal(f1, f2) and torch.equal(e1, e3) and torch.equal(f1, f3)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    p1 = p0 + 0.02 * torch.randn(p0.shape, device="cuda", generator=g)
+    e4, f4 = run(fast, p1)
+    e5, f5 = run(ref, p1)
+    assert torch.allclose(e4, e5, rtol=1e-5, atol=1e-5) and (f4 - f5).abs().max().item() <= 2e-4
+    assert not torch.equal(f4, f1)
