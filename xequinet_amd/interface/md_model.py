@@ -85,7 +85,10 @@ class XPaiNNLMP(XPaiNN):
                 data[keys.BATCH_PTR] = self._one_graph_ptr[1]
             # the replayed graph's outputs are its static buffers: whatever forward() does not rescale into a new tensor is copied here
             rescaled = self._rescaled_keys(compute_forces, compute_virial)
-            return {k: (v if k in rescaled else v.clone()) for k, v in self._replay(data).items()}
+            out = self._replay(data)
+            fresh = {k: torch.empty_like(v) for k, v in out.items() if k not in rescaled}
+            ops.copy_many([(fresh[k], out[k]) for k in fresh])      # one launch for all of them
+            return {k: fresh.get(k, v) for k, v in out.items()}
         return _Core(self)(data, compute_forces, compute_virial)
 
     def _rescaled_keys(self, compute_forces: bool, compute_virial: bool) -> set:
@@ -193,11 +196,14 @@ class XPaiNNGMX(XPaiNN):
             # FIRST, so that the wait covers it instead of standing in front of it; a list that outgrew the capacity (rare: the step
             # graph then grows and re-captures) repeats the step
             sg = self._step_graph
-            out = sg(positions.detach(), atomic_numbers, cell, pbc, check=False)
-            energy = _EnergyOfPositions.apply(positions, out[keys.TOTAL_ENERGY].clone(), out[keys.FORCES].clone()) * self.energy_unit_factor
+            def result(out):   # the graph's output buffers copied out with ONE launch
+                e, f = torch.empty_like(out[keys.TOTAL_ENERGY]), torch.empty_like(out[keys.FORCES])
+                ops.copy_many([(e, out[keys.TOTAL_ENERGY]), (f, out[keys.FORCES])])
+                return _EnergyOfPositions.apply(positions, e, f) * self.energy_unit_factor
+
+            energy = result(sg(positions.detach(), atomic_numbers, cell, pbc, check=False))
             if sg.overflowed():
-                out = sg(positions.detach(), atomic_numbers, cell, pbc)
-                energy = _EnergyOfPositions.apply(positions, out[keys.TOTAL_ENERGY].clone(), out[keys.FORCES].clone()) * self.energy_unit_factor
+                energy = result(sg(positions.detach(), atomic_numbers, cell, pbc))
             return energy
         with torch.no_grad():
             edge_index, cell_offsets, rowptr = single_radius_graph(pos=positions, cell=cell, pbc=pbc, cutoff=self.cutoff_radius,
