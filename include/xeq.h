@@ -324,6 +324,9 @@ int xeq_load_padded_shard(int dtype, const void* pos, const void* z, int z_is_in
 
 #define XEQ_COPY_MANY_MAX 16
 int xeq_copy_many(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);
+/* The same number of buffer pairs COMPARED in one launch (runtime.GraphedModel: is the engine's neighbour list the one the captured
+ * graph holds?): flag[0] = gen when any 4-byte word of any pair differs, untouched otherwise; gen: a value the flag has never held. */
+int xeq_compare_many(int n, const void* const* a, const void* const* b, const int64_t* bytes, int32_t gen, int32_t* flag, void* stream);
 
 /* ALL instructions of a general Clebsch-Gordan e3nn.o3.TensorProduct in one launch (round 4; nn/tp.py:20-107 builds the instruction lists;
  * nn/xe3net.py:133-146 'uuu' with shared weights, nn/output.py:411-421 'uuw' with one weight set per sample):

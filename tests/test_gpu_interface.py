@@ -743,3 +743,26 @@ def test_lammps_replay_on_an_unchanged_list_skips_the_plan_rebuild_and_changes_n
     e5, f5 = run(ref, p1)
     assert torch.allclose(e4, e5, rtol=1e-5, atol=1e-5) and (f4 - f5).abs().max().item() <= 2e-4
     assert not torch.equal(f4, f1)
+
+
+def test_any_differs_compares_several_pairs_in_one_launch():
+    """ops.any_differs (xeq_compare_many): what GraphedModel asks about the engine's list -- repeated calls (the flag is never cleared:
+    every call hands a new generation), a difference in any pair, in the last word, shape / dtype mismatches, empty and aliased pairs."""
+    from xequinet_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randint(0, 1000, (2, 4097), device="cuda", generator=g)
+    b = torch.randn(333, 3, device="cuda", generator=g)
+    c = torch.tensor([0, 21], device="cuda")
+    for _ in range(3):
+        assert not ops.any_differs([(a, a.clone()), (b, b.clone()), (c, c.clone())])
+    a2 = a.clone()
+    a2[1, -1] += 1
+    assert ops.any_differs([(a, a2), (b, b.clone())]) and ops.any_differs([(b, b.clone()), (a, a2)])
+    assert not ops.any_differs([(a, a.clone())])                      # and clean again afterwards
+    b2 = b.clone()
+    b2[0, 0] = b2[0, 0] + 1.0
+    assert ops.any_differs([(a, a.clone()), (b, b2)])
+    assert ops.any_differs([(a, a[:, :-1])]) and ops.any_differs([(c, c.to(torch.int32))])
+    assert not ops.any_differs([(a, a), (torch.empty(0, device="cuda"), torch.empty(0, device="cuda"))])
+    assert ops.any_differs([(a.t(), a2.t())]) and not ops.any_differs([(a.t(), a.clone().t())])    # non-contiguous: torch.equal

@@ -348,6 +348,18 @@ __global__ void k_copy_many(CopyMany cm) {
   }
 }
 
+// several pairs of small device buffers compared in one launch: flag[0] = gen when any 4-byte word differs (the caller hands a NEW gen
+// every call, so the flag needs no clearing launch)
+__global__ void k_compare_many(CopyMany cm, int32_t gen, int32_t* __restrict__ flag) {
+  const int b = blockIdx.y;
+  const int64_t words = cm.bytes[b] / 4;
+  const uint32_t* x = reinterpret_cast<const uint32_t*>(cm.src[b]);
+  const uint32_t* y = reinterpret_cast<const uint32_t*>(cm.dst[b]);
+  bool diff = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) diff |= x[i] != y[i];
+  if (__ballot(diff) != 0ull && (threadIdx.x & 63) == 0) flag[0] = gen;   // (every writer writes the same value)
+}
+
 }  // namespace xeq
 
 using namespace xeq;
@@ -571,6 +583,29 @@ int xeq_copy_many(int n, const void* const* src, void* const* dst, const int64_t
   hipLaunchKernelGGL(xeq::k_copy_many, dim3((unsigned)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg)), (unsigned)n), dim3(256), 0,
                      (hipStream_t)stream, cm);
   XEQ_CHECK_LAUNCH("xeq_copy_many");
+  return XEQ_OK;
+}
+
+/* n <= XEQ_COPY_MANY_MAX pairs of device buffers (whole 4-byte words) compared in ONE launch: flag[0] = gen if any pair differs, else
+ * flag[0] is left alone -- hand a gen the flag has never held (a counter): no clearing launch, one read-back. */
+int xeq_compare_many(int n, const void* const* a, const void* const* b, const int64_t* bytes, int32_t gen, int32_t* flag, void* stream) {
+  XEQ_CHECK_ARG(n >= 0 && n <= XEQ_COPY_MANY_MAX && flag, "xeq_compare_many: %d buffers (at most %d) / null flag", n, XEQ_COPY_MANY_MAX);
+  CopyMany cm;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    XEQ_CHECK_ARG(bytes[i] >= 0 && bytes[i] % 4 == 0 && ((uintptr_t)a[i] % 4 == 0) && ((uintptr_t)b[i] % 4 == 0),
+                  "xeq_compare_many: buffer %d is not a whole number of aligned 4-byte words", i);
+    cm.src[i] = (const char*)a[i];
+    cm.dst[i] = (char*)const_cast<void*>(b[i]);
+    cm.bytes[i] = bytes[i];
+    cm.wide[i] = false;
+    most = bytes[i] > most ? bytes[i] : most;
+  }
+  if (n == 0 || most == 0) return XEQ_OK;
+  const int64_t wg = (most / 4 + 1023) / 1024;
+  hipLaunchKernelGGL(xeq::k_compare_many, dim3((unsigned)(wg < 1 ? 1 : (wg > 1024 ? 1024 : wg)), (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     cm, gen, flag);
+  XEQ_CHECK_LAUNCH("xeq_compare_many");
   return XEQ_OK;
 }
 

@@ -87,6 +87,7 @@ _PROTOS = {
     "xeq_load_padded_batch_z64": [c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_double, c_double, _P, _P, _P, _P, _P],
     "xeq_load_padded_shard": [c_int, _P, _P, c_int, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_double, c_double, _P, _P, _P, _P, _P],
     "xeq_copy_many": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), _P],
+    "xeq_compare_many": [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.c_int32, _P, _P],
     "xeq_tensor_product_path": [c_int, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, _P, _P, c_int64, c_double, _P, _P],
     "xeq_tensor_product": [c_int, _P, _P, c_int64, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int32), _P, ctypes.POINTER(ctypes.c_int32),

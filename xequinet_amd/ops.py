@@ -803,6 +803,39 @@ def copy_many(pairs) -> None:
         call("xeq_copy_many", n, srcs, dsts, sizes, stream())
 
 
+_DIFFER_FLAGS = {}
+
+
+def any_differs(pairs) -> bool:
+    """Whether any (a, b) of a few pairs of device tensors differs, with ONE launch and ONE read-back (xeq_compare_many) -- same dtype,
+    shape and device, contiguous, whole 4-byte words; anything else takes torch.equal."""
+    import ctypes
+
+    fast = []
+    for a, b in pairs:
+        if a.shape != b.shape or a.dtype != b.dtype:
+            return True
+        if (a.is_cuda and b.is_cuda and a.device == b.device and a.is_contiguous() and b.is_contiguous()
+                and (a.numel() * a.element_size()) % 4 == 0 and len(fast) < lib.COPY_MANY_MAX):
+            if a.numel() > 0 and a.data_ptr() != b.data_ptr():
+                fast.append((a, b))
+        elif not torch.equal(a, b):
+            return True
+    if not fast:
+        return False
+    dev = fast[0][0].device
+    st = _DIFFER_FLAGS.get(dev)
+    if st is None:
+        st = _DIFFER_FLAGS[dev] = [torch.zeros(1, dtype=torch.int32, device=dev), 0]
+    st[1] = st[1] % 2_000_000_000 + 1          # never the value the flag holds (it holds an older one, or 0)
+    n = len(fast)
+    pa = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in fast])
+    pb = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t in fast])
+    sizes = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t, _ in fast])
+    call("xeq_compare_many", n, pa, pb, sizes, st[1], ptr(st[0]), stream())
+    return int(st[0].item()) == st[1]
+
+
 _WQ_WEIGHT_PACKS = {}
 
 

@@ -208,15 +208,14 @@ class GraphedModel:
         for k in (keys.POSITIONS, keys.ATOMIC_NUMBERS, keys.BATCH_PTR, keys.CELL_OFFSETS, keys.CELL) + (() if c.derived_batch else (keys.BATCH,)):
             if (k in data) != (k in c.inputs) or (k in data and (data[k].shape != c.inputs[k].shape or data[k].dtype != c.inputs[k].dtype)):
                 return False
-        if c.derived_batch and keys.BATCH_PTR in data and not torch.equal(data[keys.BATCH_PTR], c.inputs[keys.BATCH_PTR]):
-            return False
-        if not torch.equal(ei, ref):
-            return False
-        # a periodic list's mirror map pairs edges by their image offsets as well: the same pairs under other offsets are another map
-        if (c.edge_graph.mirror_map is not None and keys.CELL_OFFSETS in data
-                and not torch.equal(data[keys.CELL_OFFSETS], c.inputs[keys.CELL_OFFSETS])):
-            return False
-        return True
+        # one launch and one read-back for all of them (ops.any_differs): the list itself; ptr when the graph index was derived from it;
+        # a periodic list's image offsets (its mirror map pairs edges by them as well: the same pairs under other offsets are another map)
+        pairs = [(ei, ref)]
+        if c.derived_batch and keys.BATCH_PTR in data:
+            pairs.append((data[keys.BATCH_PTR], c.inputs[keys.BATCH_PTR]))
+        if c.edge_graph.mirror_map is not None and keys.CELL_OFFSETS in data:
+            pairs.append((data[keys.CELL_OFFSETS], c.inputs[keys.CELL_OFFSETS]))
+        return not ops.any_differs(pairs)
 
 
 # ----------------------------------------------------------------------------------------------- whole step as one graph
