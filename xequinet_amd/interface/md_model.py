@@ -179,12 +179,14 @@ class XPaiNNGMX(XPaiNN):
     def forward(self, positions: torch.Tensor, atomic_numbers: torch.Tensor, box: Optional[torch.Tensor] = None,
                 pbc: Optional[torch.Tensor] = None) -> torch.Tensor:
         positions = positions * self.pos_unit_factor
-        if box is None:
-            cell = torch.eye(3, dtype=positions.dtype, device=positions.device)
-        else:
-            cell = box * self.pos_unit_factor
+        if box is None or pbc is None:   # the stand-ins of an open system, kept per (dtype, device): no fill launches per step
+            key = (positions.dtype, positions.device)
+            if getattr(self, "_open_system", None) is None or self._open_system[0] != key:
+                object.__setattr__(self, "_open_system", (key, torch.eye(3, dtype=positions.dtype, device=positions.device),
+                                                          torch.zeros(3, dtype=torch.bool, device=positions.device)))
+        cell = self._open_system[1] if box is None else box * self.pos_unit_factor
         if pbc is None:
-            pbc = torch.zeros(3, dtype=torch.bool, device=positions.device)
+            pbc = self._open_system[2]
         if self._use_replay and self._whole_step and self.net_charge is None:
             from ..runtime import GraphedStepPBC
             if self._step_graph is None or self._step_graph.n_atoms != positions.shape[0]:

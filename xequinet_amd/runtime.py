@@ -830,8 +830,15 @@ class GraphedStepPBC:
 
         from .data.radius_graph import host_cell_tables_np
 
+        # the usual step: the box the tables were built for (NVT, or NPT between barostat moves) and the very periodicity tensor of the
+        # last call -- asked on the device with one launch and one read-back (ops.any_differs) instead of two read-backs of the values
+        if (self._cell_host is not None and isinstance(pbc, torch.Tensor) and cell.is_cuda and cell.dtype == self.dtype
+                and getattr(self, "_pbc_seen", None) is not None and self._pbc_seen[0] is pbc and self._pbc_seen[1] == pbc._version
+                and not ops.any_differs([(cell.detach().reshape(self.cell.shape), self.cell)])):
+            return
         c = np.ascontiguousarray(cell.detach().to(self.dtype).reshape(1, 3, 3).cpu().numpy())     # the step's one small round trip
         pbc_ = [bool(v) for v in (pbc.detach().cpu().tolist() if isinstance(pbc, torch.Tensor) else pbc)]
+        self._pbc_seen = (pbc, pbc._version) if isinstance(pbc, torch.Tensor) else None
         if self._cell_host is not None and pbc_ == self._pbc and np.array_equal(c, self._cell_host):
             return
         reps, n_cells, flat_h = host_cell_tables_np(c, pbc_, self.cutoff, False, dtype_code_of=self.cell)
