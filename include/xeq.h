@@ -755,6 +755,10 @@ int xeq_node_block_supported(int dtype, int node_dim, const int32_t mul[3]);
 /* launch policy (host only): 1 when an evaluation of n nodes should take the fused launches (n >= XEQ_NODE_BLOCK_MIN_NODES, default
  * 6 144; XEQ_NODE_BLOCK=0: never).  Below that the chain of small kernels is faster (a fused launch is one serial chain per wave). */
 int xeq_node_block_auto(int64_t n);
+/* launch policy (host only): the row count up to which xeq_linear_fwd, xeq_mlp2_fwd / _bwd, xeq_mlp2_and_linear and xeq_update_uv_fwd /
+ * _bwd (split form) take their few-row forms -- 16 x 16 exact-f32 tiles whose results equal the 32-row kernels' bit for bit (MD-sized
+ * systems: a quarter of the k-chain per wave, four times the waves).  3 584; XEQ_SMALL_ROWS overrides (0: never), read per call. */
+int64_t xeq_small_rows_limit(void);
 /* waves per workgroup of the node-block launches that follow (host only, process-wide): 0 = by node count (one workgroup per CU of 5 .. 8
  * waves between 4 097 and 8 192 wave-blocks of 16 nodes, four otherwise: a lone launch ends with its slowest CU), 4 .. 8 = fixed.  Results
  * do not depend on it.  -> the former setting; -1: out of range, nothing changed. */

@@ -393,6 +393,18 @@ def test_launch_policy_is_stated_once_in_the_c_abi():
     assert eps(18609, 311994) == 80 and eps(5000, 119000) == 79 and eps(1000, 100000) == 80 and eps(192, 10390) == 54
     assert eps(21, 360) == 17 and eps(10, 20) == 16
     assert int(L.xeq_message_wq_win_ints(100)) >= 2 * (25 + 9)   # both stream classes' window tables
+    # the few-row forms of the node-side products (bit-equal to the 32-row kernels): one limit, stated in the C ABI, overridable per call
+    old = os.environ.pop("XEQ_SMALL_ROWS", None)
+    try:
+        assert int(L.xeq_small_rows_limit()) == 3584
+        os.environ["XEQ_SMALL_ROWS"] = "0"
+        assert int(L.xeq_small_rows_limit()) == 0
+        os.environ["XEQ_SMALL_ROWS"] = "100000"
+        assert int(L.xeq_small_rows_limit()) == 100000
+    finally:
+        os.environ.pop("XEQ_SMALL_ROWS", None)
+        if old is not None:
+            os.environ["XEQ_SMALL_ROWS"] = old
     import inspect
 
     from xequinet_amd import ops

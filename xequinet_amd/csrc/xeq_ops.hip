@@ -397,6 +397,10 @@ int xeq_message_auto_family(int dtype, int64_t n_nodes, int64_t n_edges, int num
   return XEQ_FAMILY_GENERIC;
 }
 
+/* rows up to which the node-side products take their few-row forms (16 x 16 exact-f32 tiles, bit-equal to the 32-row forms;
+ * csrc/xeq_linear_s.h): 3 584 unless XEQ_SMALL_ROWS says otherwise (0: never).  Host only. */
+int64_t xeq_small_rows_limit(void) { return xeq_small_rows(); }
+
 int xeq_message_wq_edges_per_stream(int64_t n_nodes, int64_t n_edges) {
   // a step (eight half-wave streams) should gather from few enough nodes for its window to fit LDS: 64 edges per stream is ~30 owner
   // nodes; small systems get shorter streams so that the launch still spreads over the chip, never below the mean segment length.

@@ -172,6 +172,7 @@ _PROTOS = {
     "xeq_node_block_fwd_tiles": [c_int],
     "xeq_node_block_rows": [c_int64],
     "xeq_node_block_auto": [c_int64],
+    "xeq_small_rows_limit": [],
     "xeq_node_block_set_waves": [c_int],
     "xeq_node_block_pack_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "xeq_node_block_fwd": [c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -184,7 +185,7 @@ _PROTOS = {
 }
 # entry points that return a size, not a status
 _RET_I64 = {"xeq_launch_count", "xeq_launch_names", "xeq_message_wq_packed_weight_floats", "xeq_rowptr_from_degrees_max", "xeq_csr_by_key_workspace", "xeq_message_wq_pcap", "xeq_message_wq_plan_workspace", "xeq_message_wq_win_ints",
-            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch", "xeq_tensor_product_wgrad_chunks"}
+            "xeq_message_wq_parts_floats", "xeq_mlp_packed_floats", "xeq_exclusive_scan_i32_workspace", "xeq_node_block_fwd_tiles", "xeq_node_block_bwd_tiles", "xeq_node_block_rows", "xeq_pack_epoch", "xeq_tensor_product_wgrad_chunks", "xeq_small_rows_limit"}
 EXPORTS = ["xeq_version", "xeq_last_error", *_PROTOS]
 
 _lib: Optional[ctypes.CDLL] = None
