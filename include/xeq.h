@@ -278,6 +278,10 @@ int xeq_first_block_front(const void* z, int z_is_int64, int64_t n, int64_t n_ro
  * act 0 none / 1 SiLU; pre (optional) receives the pre-activation.  A row's sums run in one fixed order whatever n is.
  * xeq_head_dot: out[n] = <hidden[n, :], w2> + b2 (the head's last layer, nn/output.py:104-106); xeq_head_bwd_hidden: its
  * reverse with the SiLU in front, g_hidden[n, j] = g_atomic[n] w2[j] silu'(pre[n, j]) (g_atomic NULL: ones). */
+/* Test entry for the property the few-row forms rest on (csrc/xeq_linear_s.h): one 32 x 32 block of a [32, 224] x b [224, 32] through
+ * v_mfma_f32_32x32x2_f32, through v_mfma_f32_16x16x4_f32 and as a sequential fmaf chain per element; diff[0] / diff[1] (int32, zeroed by the
+ * caller) += the outputs whose bits differ between the two instruction shapes / between the matrix instruction and the chain. */
+int xeq_mfma_order_probe(const float* a, const float* b, int32_t* diff, void* stream);
 int xeq_linear_supported(int dtype, int k_in, int n_out);
 int xeq_linear_fwd(const void* x, int64_t ldx, int64_t n, int k_in, const int32_t* row_index, const void* w_packed, int n_out,
                    int has_bias, int act, void* pre, void* y, int64_t ldy, void* stream);

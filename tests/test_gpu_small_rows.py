@@ -40,6 +40,23 @@ def _both(fn):
     return a, b
 
 
+def test_exact_f32_matrix_instructions_round_like_a_sequential_fmaf_chain():
+    """The hardware property every few-row form rests on (xeq_mfma_order_probe): v_mfma_f32_32x32x2_f32 and v_mfma_f32_16x16x4_f32 fed the
+    same k sequence give the same bits, and both equal a sequential fmaf chain per output element -- over operands of mixed magnitudes."""
+    from xequinet_amd.lib import call, ptr, stream
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    diff = torch.zeros(2, dtype=torch.int32, device=_dev())
+    for trial in range(40):
+        scale = (1.0, 100.0, 1e-3, 1e4)[trial % 4]
+        a = (torch.rand(32, 224, device=_dev(), generator=g) - 0.5) * scale
+        b = torch.rand(224, 32, device=_dev(), generator=g) - 0.5
+        if trial % 5 == 0:
+            a = a * torch.exp(8.0 * (torch.rand(32, 224, device=_dev(), generator=g) - 0.5))     # eight decades inside one row
+        call("xeq_mfma_order_probe", ptr(a.contiguous()), ptr(b.contiguous()), ptr(diff), stream())
+    assert diff.tolist() == [0, 0], f"outputs differing: between the instruction shapes {int(diff[0])}, from the fmaf chain {int(diff[1])}"
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 21, 33, 192, 1000])
 @pytest.mark.parametrize("k_in,n_out,bias", [(224, 128, False), (128, 224, False), (56, 128, True), (128, 64, True), (256, 256, True)])
 def test_linear_few_row_form_changes_no_bit(n, k_in, n_out, bias):

@@ -359,11 +359,57 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
     }
 }
 
+// ---- the hardware property the few-row forms rest on, as a test entry (xeq_mfma_order_probe) -------------------------------------------
+// D = A B over K = 224 for one 32 x 32 output block: once with v_mfma_f32_32x32x2_f32 (the 32-row kernels' instruction), once with
+// v_mfma_f32_16x16x4_f32 on its four 16 x 16 quarters (the few-row kernels'), once as a sequential fmaf chain per output element on the
+// vector pipe; counts the outputs whose BITS differ.
+constexpr int PROBE_K = 224;
+__global__ void __launch_bounds__(256) k_mfma_order_probe(const float* __restrict__ A, const float* __restrict__ B, int32_t* __restrict__ diff) {
+  __shared__ float d32[1024], d16[1024];
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    const int i = l & 31, kh = l >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < PROBE_K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i * PROBE_K + k + kh], B[(k + kh) * 32 + i], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d32[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + i] = acc[r];
+  }
+  {
+    const int i = l & 15, kq = l >> 4, bi = wave >> 1, bj = wave & 1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < PROBE_K; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(16 * bi + i) * PROBE_K + k + kq], B[(k + kq) * 32 + 16 * bj + i], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d16[(16 * bi + 4 * kq + r) * 32 + 16 * bj + i] = acc[r];
+  }
+  __syncthreads();
+  int n_shape = 0, n_chain = 0;
+  for (int x = tid; x < 1024; x += 256) {
+    const int i = x >> 5, j = x & 31;
+    float s = 0.f;
+    for (int k = 0; k < PROBE_K; ++k) s = __builtin_fmaf(A[i * PROBE_K + k], B[k * 32 + j], s);
+    n_shape += __float_as_uint(d32[x]) != __float_as_uint(d16[x]);
+    n_chain += __float_as_uint(d32[x]) != __float_as_uint(s);
+  }
+  if (n_shape) atomicAdd(&diff[0], n_shape);
+  if (n_chain) atomicAdd(&diff[1], n_chain);
+}
+
 }  // namespace xeq
 
 using namespace xeq;
 
 extern "C" {
+
+/* test entry: a [32, 224] and b [224, 32] f32 on the device; diff[0] += outputs of a b whose bits differ between v_mfma_f32_32x32x2_f32 and
+ * v_mfma_f32_16x16x4_f32, diff[1] += outputs that differ between the former and a sequential fmaf chain (diff: two int32, zeroed by the caller) */
+int xeq_mfma_order_probe(const float* a, const float* b, int32_t* diff, void* stream) {
+  XEQ_CHECK_ARG(a && b && diff, "xeq_mfma_order_probe: null buffer");
+  hipLaunchKernelGGL(k_mfma_order_probe, dim3(1), dim3(256), 0, (hipStream_t)stream, a, b, diff);
+  XEQ_CHECK_LAUNCH("xeq_mfma_order_probe");
+  return XEQ_OK;
+}
 
 int xeq_linear_supported(int dtype, int k_in, int n_out) {
   return dtype == XEQ_F32 && k_in >= 8 && k_in % 8 == 0 && k_in <= LIN_KMAX && n_out >= 32 && n_out % 32 == 0 && n_out <= 256 ? 1 : 0;

@@ -72,6 +72,7 @@ _PROTOS = {
     "xeq_eqln_bwd": [c_int, _P, _P, _P, c_int64, _I3, c_double, _P, _P],
     "xeq_segment_sum": [c_int, _P, _P, c_int64, c_int64, _P, _P],
     "xeq_linear_supported": [c_int, c_int, c_int],
+    "xeq_mfma_order_probe": [_P, _P, _P, _P],
     "xeq_linear_fwd": [_P, c_int64, c_int64, c_int, _P, _P, c_int, c_int, c_int, _P, _P, c_int64, _P],
     "xeq_head_dot": [_P, c_int64, c_int, _P, _P, _P, _P],
     "xeq_head_bwd_hidden": [_P, c_int64, c_int, _P, _P, _P, _P],
